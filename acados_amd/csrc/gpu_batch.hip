@@ -1,0 +1,804 @@
+/*
+ * gpu_batch.hip -- host side of the device-resident OCP-QP batch: HBM allocation, layout
+ * conversion (pack / unpack kernels), kernel dispatch by shape, and the IPM launch loop.
+ * C-ABI declared in include/acados_amd/ocp_qp_gpu_batch.h.
+ */
+#include <hip/hip_runtime.h>
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "acados_amd/ocp_qp_gpu_batch.h"
+#include "gpu_ipm_internal.h"
+#include "ipm_kernels.hpp"
+
+#define HIPCHK(x)                                                                              \
+    do {                                                                                       \
+        hipError_t e_ = (x);                                                                   \
+        if (e_ != hipSuccess)                                                                  \
+        {                                                                                      \
+            fprintf(stderr, "acados_amd: HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+            abort();                                                                           \
+        }                                                                                      \
+    } while (0)
+
+namespace
+{
+
+typedef void (*kern_opts_t)(GqpDev, GqpOpts);
+typedef void (*kern_redo_t)(GqpDev, GqpOpts, int);
+typedef void (*kern_plain_t)(GqpDev);
+
+struct KernelSet
+{
+    int NX, NU, NG, NS;
+    kern_opts_t init;
+    kern_redo_t back_fact, back_rhs, fwd_aff, fwd_corr;
+    kern_plain_t finalize;
+};
+
+#define GQP_KSET(NX, NU, NG, NS)                                                               \
+    {NX, NU, NG, NS, gqp::k_init<NX, NU, NG, NS>, gqp::k_backward<NX, NU, NG, NS, true>,       \
+     gqp::k_backward<NX, NU, NG, NS, false>, gqp::k_forward<NX, NU, NG, NS, false>,            \
+     gqp::k_forward<NX, NU, NG, NS, true>, gqp::k_finalize<NX, NU, NG, NS>}
+
+/* compiled shape classes; a batch is served by the cheapest one that covers it */
+const KernelSet g_ksets[] = {
+    GQP_KSET(4, 1, 0, 0),
+    GQP_KSET(4, 1, 2, 3),
+    GQP_KSET(8, 3, 0, 0),
+    GQP_KSET(12, 3, 0, 0),
+};
+
+} // namespace
+
+struct ocp_qp_gpu_batch
+{
+    int B = 0, Bp = 0, N = 0, device = 0;
+    std::vector<int> nx, nu, nbx, nbu, nb, ng, ns, nbxe;
+    std::vector<std::vector<int>> idxb, idxs_rev, idxe; /* as given (original row order) */
+    std::vector<std::vector<int>> perm;                   /* original box row -> sorted row */
+    bool finalized = false;
+    const KernelSet *ks = nullptr;
+    std::string kname;
+    std::vector<GqpStage> st;
+    GqpStage *d_st = nullptr;
+    GqpDev D;
+    GqpOpts O;
+    int nct_tot = 0, ns2_tot = 0, ng_tot = 0;
+    std::vector<void *> allocs;
+    size_t bytes = 0;
+    double *d_stage = nullptr; /* staging for host->device field blocks */
+    size_t stage_cap = 0;
+    int *d_map = nullptr;
+    int map_cap = 0;
+    int *h_nact = nullptr; /* pinned */
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double time_tot = 0.0, time_pack = 0.0;
+    int last_iters = 0, launches = 0;
+    int print_level = 0;
+    int profile = 0;                 /* per-kernel-class HIP event timing on the launch stream */
+    std::vector<hipEvent_t> prof_ev; /* pool, pairs (start, stop) */
+    std::vector<int> prof_cls;       /* kernel class of each recorded pair */
+    double prof_ms[6] = {0, 0, 0, 0, 0, 0};
+    int prof_cnt[6] = {0, 0, 0, 0, 0, 0};
+    int stat_inst = 0, stat_rows = 0;
+};
+
+namespace
+{
+
+template <class T>
+T *dalloc(ocp_qp_gpu_batch *b, size_t cnt)
+{
+    void *p = nullptr;
+    size_t bytes = sizeof(T) * (cnt ? cnt : 1);
+    HIPCHK(hipMalloc(&p, bytes));
+    HIPCHK(hipMemset(p, 0, bytes));
+    b->allocs.push_back(p);
+    b->bytes += bytes;
+    return (T *) p;
+}
+
+void opts_default(GqpOpts &o)
+{
+    /* acados defaults on top of mode BALANCE: ocp_qp_hpipm.c:101-113 */
+    o.mu0 = 1e0;
+    o.tol_stat = 1e-6; o.tol_eq = 1e-8; o.tol_ineq = 1e-8; o.tol_comp = 1e-8;
+    o.alpha_min = 1e-8; o.tau_min = 0.0; o.lam_min = 1e-16; o.t_min = 1e-16; o.reg_prim = 1e-15;
+    o.iter_max = 50; o.pred_corr = 1; o.cond_pred_corr = 1; o.warm_start = 0;
+}
+
+int padded_var(const ocp_qp_gpu_batch *b, int k, int iv)
+{
+    /* index in [u(nu_k); x(nx_k)] -> index in padded [u(NU); x(NX)] */
+    return iv < b->nu[k] ? iv : b->ks->NU + (iv - b->nu[k]);
+}
+
+void finalize_structure(ocp_qp_gpu_batch *b)
+{
+    if (b->finalized) return;
+    const int N = b->N, NX = b->ks->NX, NU = b->ks->NU;
+    const int n = NX + NU, NP = n * (n + 1) / 2;
+    b->st.assign(N + 1, GqpStage());
+    b->perm.assign(N + 1, std::vector<int>());
+    int o_ct = 0, o_s = 0, o_g = 0;
+    for (int k = 0; k <= N; k++)
+    {
+        GqpStage &S = b->st[k];
+        memset(&S, 0, sizeof(S));
+        S.nb = b->nb[k]; S.ng = b->ng[k]; S.ns = b->ns[k];
+        S.o_ct = o_ct; S.o_s = o_s; S.o_g = o_g; S.has_dyn = k < N;
+        const int nbg = S.nb + S.ng, nct = 2 * nbg + 2 * S.ns;
+        if (nct > 64 || nbg > GQP_MAX_ROWS)
+        {
+            fprintf(stderr, "acados_amd: stage %d has %d inequality sides (> 64): unsupported\n", k, nct);
+            abort();
+        }
+        /* sort box rows by variable */
+        std::vector<int> order(S.nb);
+        for (int r = 0; r < S.nb; r++) order[r] = r;
+        std::sort(order.begin(), order.end(), [&](int a, int c) { return b->idxb[k][a] < b->idxb[k][c]; });
+        b->perm[k].assign(S.nb, 0);
+        for (int sp = 0; sp < S.nb; sp++)
+        {
+            const int ob = order[sp];
+            b->perm[k][ob] = sp;
+            const int iv = b->idxb[k][ob];
+            if (iv < 0 || iv >= b->nu[k] + b->nx[k]) { fprintf(stderr, "acados_amd: idxb out of range at stage %d\n", k); abort(); }
+            const int pv = padded_var(b, k, iv);
+            if ((S.bmask >> pv) & 1) { fprintf(stderr, "acados_amd: duplicate idxb entry at stage %d: unsupported\n", k); abort(); }
+            S.bmask |= (uint64_t) 1 << pv;
+        }
+        for (int r = 0; r < GQP_MAX_ROWS; r++) S.srev[r] = -1;
+        for (int r = 0; r < nbg; r++)
+        {
+            const int sj = b->idxs_rev[k][r];
+            if (sj >= S.ns) { fprintf(stderr, "acados_amd: idxs_rev out of range at stage %d\n", k); abort(); }
+            const int row = r < S.nb ? b->perm[k][r] : r;
+            S.srev[row] = (int8_t) sj;
+        }
+        for (size_t e = 0; e < b->idxe[k].size(); e++)
+        {
+            const int ob = b->idxe[k][e];
+            if (ob < 0 || ob >= S.nb) { fprintf(stderr, "acados_amd: idxe out of range at stage %d\n", k); abort(); }
+            S.emask |= (uint64_t) 1 << padded_var(b, k, b->idxb[k][ob]);
+        }
+        o_ct += nct; o_s += 2 * S.ns; o_g += S.ng;
+    }
+    b->nct_tot = o_ct; b->ns2_tot = o_s; b->ng_tot = o_g;
+    b->d_st = dalloc<GqpStage>(b, N + 1);
+    HIPCHK(hipMemcpy(b->d_st, b->st.data(), sizeof(GqpStage) * (N + 1), hipMemcpyHostToDevice));
+
+    GqpDev &D = b->D;
+    const size_t Bp = b->Bp;
+    D.B = b->B; D.Bp = b->Bp; D.N = N; D.NX = NX; D.NU = NU; D.NG = b->ks->NG; D.NS = b->ks->NS;
+    D.st = b->d_st;
+    D.BAt = dalloc<double>(b, (size_t) N * n * NX * Bp);
+    D.bvec = dalloc<double>(b, (size_t) N * NX * Bp);
+    D.RSQ = dalloc<double>(b, (size_t) (N + 1) * NP * Bp);
+    D.rq = dalloc<double>(b, (size_t) (N + 1) * n * Bp);
+    D.dvec = dalloc<double>(b, (size_t) o_ct * Bp);
+    D.amask = dalloc<uint64_t>(b, (size_t) (N + 1) * Bp);
+    D.DCt = dalloc<double>(b, (size_t) o_g * n * Bp);
+    D.Zz = dalloc<double>(b, (size_t) o_s * 2 * Bp);
+    D.ux = dalloc<double>(b, (size_t) (N + 1) * n * Bp);
+    D.sv = dalloc<double>(b, (size_t) o_s * Bp);
+    D.pi = dalloc<double>(b, (size_t) N * NX * Bp);
+    D.lam = dalloc<double>(b, (size_t) o_ct * Bp);
+    D.t = dalloc<double>(b, (size_t) o_ct * Bp);
+    D.rg = dalloc<double>(b, (size_t) (N + 1) * n * Bp);
+    D.rgs = dalloc<double>(b, (size_t) o_s * Bp);
+    D.rb = dalloc<double>(b, (size_t) N * NX * Bp);
+    D.rd = dalloc<double>(b, (size_t) o_ct * Bp);
+    D.rm = dalloc<double>(b, (size_t) o_ct * Bp);
+    D.dux = dalloc<double>(b, (size_t) (N + 1) * n * Bp);
+    D.dsv = dalloc<double>(b, (size_t) o_s * Bp);
+    D.dpi = dalloc<double>(b, (size_t) N * NX * Bp);
+    D.dlam = dalloc<double>(b, (size_t) o_ct * Bp);
+    D.dt = dalloc<double>(b, (size_t) o_ct * Bp);
+    D.sD = dalloc<double>(b, (size_t) o_s * Bp);
+    D.sR = dalloc<double>(b, (size_t) o_s * Bp);
+    D.Lf = dalloc<double>(b, (size_t) (N + 1) * NP * Bp);
+    D.lf = dalloc<double>(b, (size_t) (N + 1) * n * Bp);
+    D.res = dalloc<double>(b, 4 * Bp);
+    D.mu = dalloc<double>(b, Bp); D.smu = dalloc<double>(b, Bp);
+    D.alpha = dalloc<double>(b, Bp); D.obj = dalloc<double>(b, Bp);
+    D.iter = dalloc<int>(b, Bp); D.status = dalloc<int>(b, Bp);
+    D.n_active = dalloc<int>(b, 1);
+    b->stat_inst = b->B < 64 ? b->B : 64;
+    b->stat_rows = 0;
+    D.stat = nullptr; D.stat_inst = 0; D.stat_rows = 0;
+
+    /* neutral padding: unit Hessian diagonal on padded variables */
+    const int grid = (b->B + 63) / 64;
+    for (int k = 0; k <= N; k++)
+    {
+        for (int j = 0; j < n; j++)
+        {
+            const bool real = j < NU ? j < b->nu[k] : (j - NU) < b->nx[k];
+            if (!real)
+                hipLaunchKernelGGL(gqp::k_fill_strided, dim3(grid), dim3(64), 0, b->stream, D.RSQ, 1.0, b->B, b->Bp,
+                                   k * NP + PK(j, j));
+        }
+        /* activity: every existing row side, minus equality-flagged rows */
+        const GqpStage &S = b->st[k];
+        const int nbg = S.nb + S.ng, nct = 2 * nbg + 2 * S.ns;
+        uint64_t m = nct >= 64 ? ~(uint64_t) 0 : (((uint64_t) 1 << nct) - 1);
+        for (size_t e = 0; e < b->idxe[k].size(); e++)
+        {
+            const int sp = b->perm[k][b->idxe[k][e]];
+            m &= ~((uint64_t) 1 << sp);
+            m &= ~((uint64_t) 1 << (nbg + sp));
+        }
+        hipLaunchKernelGGL(gqp::k_fill_u64, dim3((b->Bp + 255) / 256), dim3(256), 0, b->stream,
+                           D.amask + (size_t) k * Bp, m, (size_t) b->Bp);
+    }
+    HIPCHK(hipStreamSynchronize(b->stream));
+    b->finalized = true;
+}
+
+void ensure_stat(ocp_qp_gpu_batch *b)
+{
+    const int rows = b->O.iter_max + 2;
+    if (b->stat_rows >= rows) return;
+    /* (re)allocate the statistics table for the first stat_inst instances */
+    b->D.stat = dalloc<double>(b, (size_t) rows * GQP_STAT_COLS * b->stat_inst);
+    b->stat_rows = rows;
+    b->D.stat_rows = rows;
+    b->D.stat_inst = b->stat_inst;
+}
+
+/* element map of a numeric field: for every source element e the target element index
+ * in `*arr` (units of Bp doubles), or -1.  Returns the field length, -1 if unknown. */
+int field_map(ocp_qp_gpu_batch *b, const char *f, int k, std::vector<int> &map, double **arr,
+              std::vector<int> *map2 = nullptr, double **arr2 = nullptr)
+{
+    const int N = b->N, NX = b->ks->NX, NU = b->ks->NU, n = NX + NU, NP = n * (n + 1) / 2;
+    const GqpDev &D = b->D;
+    const GqpStage &S = b->st[k];
+    const int nx = b->nx[k], nu = b->nu[k], nx1 = k < N ? b->nx[k + 1] : 0;
+    const int nbu = b->nbu[k], nbx = b->nbx[k], ng = S.ng, ns = S.ns, nbg = S.nb + S.ng;
+    map.clear();
+    auto dyn = [&]() { return k < N; };
+    if (!strcmp(f, "A"))
+    {
+        if (!dyn()) return -1;
+        *arr = D.BAt;
+        for (int c = 0; c < nx; c++) for (int r = 0; r < nx1; r++) map.push_back((k * n + NU + c) * NX + r);
+    }
+    else if (!strcmp(f, "B"))
+    {
+        if (!dyn()) return -1;
+        *arr = D.BAt;
+        for (int c = 0; c < nu; c++) for (int r = 0; r < nx1; r++) map.push_back((k * n + c) * NX + r);
+    }
+    else if (!strcmp(f, "b"))
+    {
+        if (!dyn()) return -1;
+        *arr = D.bvec;
+        for (int r = 0; r < nx1; r++) map.push_back(k * NX + r);
+    }
+    else if (!strcmp(f, "Q"))
+    {
+        *arr = D.RSQ;
+        for (int c = 0; c < nx; c++) for (int r = 0; r < nx; r++) map.push_back(r >= c ? k * NP + PK(NU + r, NU + c) : -1);
+    }
+    else if (!strcmp(f, "R"))
+    {
+        *arr = D.RSQ;
+        for (int c = 0; c < nu; c++) for (int r = 0; r < nu; r++) map.push_back(r >= c ? k * NP + PK(r, c) : -1);
+    }
+    else if (!strcmp(f, "S"))
+    {
+        *arr = D.RSQ; /* S is nu x nx: u'Sx */
+        for (int jx = 0; jx < nx; jx++) for (int iu = 0; iu < nu; iu++) map.push_back(k * NP + PK(NU + jx, iu));
+    }
+    else if (!strcmp(f, "q")) { *arr = D.rq; for (int r = 0; r < nx; r++) map.push_back(k * n + NU + r); }
+    else if (!strcmp(f, "r")) { *arr = D.rq; for (int r = 0; r < nu; r++) map.push_back(k * n + r); }
+    else if (!strcmp(f, "lbu") || !strcmp(f, "ubu") || !strcmp(f, "lbx") || !strcmp(f, "ubx"))
+    {
+        const bool up = f[0] == 'u', isx = f[2] == 'x';
+        *arr = D.dvec;
+        const int cnt = isx ? nbx : nbu, off = isx ? nbu : 0;
+        for (int e = 0; e < cnt; e++) map.push_back(S.o_ct + (up ? nbg : 0) + b->perm[k][off + e]);
+        if (!up && isx && map2)
+        {
+            /* equality-flagged x bounds: the bound value is the value of the variable */
+            *arr2 = D.ux;
+            map2->assign(cnt, -1);
+            for (size_t q = 0; q < b->idxe[k].size(); q++)
+            {
+                const int ob = b->idxe[k][q];
+                if (ob >= off && ob < off + cnt) (*map2)[ob - off] = k * n + padded_var(b, k, b->idxb[k][ob]);
+            }
+        }
+    }
+    else if (!strcmp(f, "lg") || !strcmp(f, "ug"))
+    {
+        *arr = D.dvec;
+        for (int g = 0; g < ng; g++) map.push_back(S.o_ct + (f[0] == 'u' ? nbg : 0) + S.nb + g);
+    }
+    else if (!strcmp(f, "C"))
+    {
+        *arr = D.DCt;
+        for (int c = 0; c < nx; c++) for (int g = 0; g < ng; g++) map.push_back((S.o_g + g) * n + NU + c);
+    }
+    else if (!strcmp(f, "D"))
+    {
+        *arr = D.DCt;
+        for (int c = 0; c < nu; c++) for (int g = 0; g < ng; g++) map.push_back((S.o_g + g) * n + c);
+    }
+    else if (!strcmp(f, "Zl")) { *arr = D.Zz; for (int j = 0; j < ns; j++) map.push_back((S.o_s + j) * 2); }
+    else if (!strcmp(f, "zl")) { *arr = D.Zz; for (int j = 0; j < ns; j++) map.push_back((S.o_s + j) * 2 + 1); }
+    else if (!strcmp(f, "Zu")) { *arr = D.Zz; for (int j = 0; j < ns; j++) map.push_back((S.o_s + ns + j) * 2); }
+    else if (!strcmp(f, "zu")) { *arr = D.Zz; for (int j = 0; j < ns; j++) map.push_back((S.o_s + ns + j) * 2 + 1); }
+    else if (!strcmp(f, "lls")) { *arr = D.dvec; for (int j = 0; j < ns; j++) map.push_back(S.o_ct + 2 * nbg + j); }
+    else if (!strcmp(f, "lus")) { *arr = D.dvec; for (int j = 0; j < ns; j++) map.push_back(S.o_ct + 2 * nbg + ns + j); }
+    /* iterate */
+    else if (!strcmp(f, "x")) { *arr = D.ux; for (int r = 0; r < nx; r++) map.push_back(k * n + NU + r); }
+    else if (!strcmp(f, "u")) { *arr = D.ux; for (int r = 0; r < nu; r++) map.push_back(k * n + r); }
+    else if (!strcmp(f, "sl")) { *arr = D.sv; for (int j = 0; j < ns; j++) map.push_back(S.o_s + j); }
+    else if (!strcmp(f, "su")) { *arr = D.sv; for (int j = 0; j < ns; j++) map.push_back(S.o_s + ns + j); }
+    else if (!strcmp(f, "pi"))
+    {
+        if (!dyn()) return -1;
+        *arr = D.pi;
+        for (int r = 0; r < nx1; r++) map.push_back(k * NX + r);
+    }
+    else if (!strcmp(f, "lam") || !strcmp(f, "t"))
+    {
+        *arr = f[0] == 'l' ? D.lam : D.t;
+        for (int side = 0; side < 2; side++)
+        {
+            for (int r = 0; r < S.nb; r++) map.push_back(S.o_ct + side * nbg + b->perm[k][r]);
+            for (int g = 0; g < ng; g++) map.push_back(S.o_ct + side * nbg + S.nb + g);
+        }
+        for (int j = 0; j < 2 * ns; j++) map.push_back(S.o_ct + 2 * nbg + j);
+    }
+    else
+        return -1;
+    return (int) map.size();
+}
+
+/* bit positions of a mask field */
+int mask_bits(ocp_qp_gpu_batch *b, const char *f, int k, std::vector<int> &bits)
+{
+    const GqpStage &S = b->st[k];
+    const int nbu = b->nbu[k], nbx = b->nbx[k], nbg = S.nb + S.ng, ns = S.ns;
+    bits.clear();
+    std::vector<char> is_eq(S.nb, 0);
+    for (size_t e = 0; e < b->idxe[k].size(); e++) is_eq[b->idxe[k][e]] = 1;
+    auto box = [&](int off, int cnt, int side) {
+        for (int e = 0; e < cnt; e++) bits.push_back(is_eq[off + e] ? -1 : side * nbg + b->perm[k][off + e]);
+    };
+    if (!strcmp(f, "lbu_mask")) box(0, nbu, 0);
+    else if (!strcmp(f, "ubu_mask")) box(0, nbu, 1);
+    else if (!strcmp(f, "lbx_mask")) box(nbu, nbx, 0);
+    else if (!strcmp(f, "ubx_mask")) box(nbu, nbx, 1);
+    else if (!strcmp(f, "lg_mask")) for (int g = 0; g < S.ng; g++) bits.push_back(S.nb + g);
+    else if (!strcmp(f, "ug_mask")) for (int g = 0; g < S.ng; g++) bits.push_back(nbg + S.nb + g);
+    else if (!strcmp(f, "lls_mask")) for (int j = 0; j < ns; j++) bits.push_back(2 * nbg + j);
+    else if (!strcmp(f, "lus_mask")) for (int j = 0; j < ns; j++) bits.push_back(2 * nbg + ns + j);
+    else return -1;
+    return (int) bits.size();
+}
+
+int *upload_map(ocp_qp_gpu_batch *b, const std::vector<int> &map)
+{
+    if ((int) map.size() > b->map_cap)
+    {
+        b->map_cap = (int) map.size() * 2 + 64;
+        b->d_map = dalloc<int>(b, b->map_cap);
+    }
+    /* the previous launch using d_map must be done before it is overwritten */
+    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(hipMemcpy(b->d_map, map.data(), sizeof(int) * map.size(), hipMemcpyHostToDevice));
+    return b->d_map;
+}
+
+const double *stage_in(ocp_qp_gpu_batch *b, const double *data, size_t cnt, int is_device)
+{
+    if (is_device) return data;
+    if (cnt > b->stage_cap)
+    {
+        b->stage_cap = cnt * 2;
+        b->d_stage = dalloc<double>(b, b->stage_cap);
+    }
+    HIPCHK(hipMemcpyAsync(b->d_stage, data, sizeof(double) * cnt, hipMemcpyHostToDevice, b->stream));
+    return b->d_stage;
+}
+
+} // namespace
+
+extern "C" {
+
+ocp_qp_gpu_batch *ocp_qp_gpu_batch_create(int N, const int *nx, const int *nu, const int *nbx, const int *nbu,
+                                          const int *ng, const int *ns, int n_batch, int device)
+{
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    {
+        fprintf(stderr, "acados_amd: no HIP device available -- the GPU OCP-QP path cannot run\n");
+        return nullptr;
+    }
+    if (device >= 0) HIPCHK(hipSetDevice(device));
+    ocp_qp_gpu_batch *b = new ocp_qp_gpu_batch();
+    HIPCHK(hipGetDevice(&b->device));
+    b->B = n_batch;
+    b->Bp = (n_batch + 63) / 64 * 64;
+    b->N = N;
+    int mx = 0, mu = 0, mg = 0, ms = 0;
+    for (int k = 0; k <= N; k++)
+    {
+        b->nx.push_back(nx[k]); b->nu.push_back(nu[k]); b->nbx.push_back(nbx[k]); b->nbu.push_back(nbu[k]);
+        b->nb.push_back(nbx[k] + nbu[k]); b->ng.push_back(ng[k]); b->ns.push_back(ns[k]); b->nbxe.push_back(0);
+        mx = std::max(mx, nx[k]); mu = std::max(mu, nu[k]); mg = std::max(mg, ng[k]); ms = std::max(ms, ns[k]);
+        std::vector<int> ib;
+        for (int i = 0; i < nbu[k]; i++) ib.push_back(i);
+        for (int i = 0; i < nbx[k]; i++) ib.push_back(nu[k] + i);
+        b->idxb.push_back(ib);
+        b->idxs_rev.push_back(std::vector<int>(nbx[k] + nbu[k] + ng[k], -1));
+        b->idxe.push_back(std::vector<int>());
+    }
+    double best = 1e300;
+    for (const KernelSet &ks : g_ksets)
+    {
+        if (ks.NX < mx || ks.NU < mu || ks.NG < mg || ks.NS < ms) continue;
+        const double n = ks.NX + ks.NU;
+        const double cost = n * n * n + 10.0 * (ks.NG + ks.NS) * n * n;
+        if (cost < best) { best = cost; b->ks = &ks; }
+    }
+    if (!b->ks)
+    {
+        fprintf(stderr, "acados_amd: no kernel instantiation covers nx<=%d nu<=%d ng<=%d ns<=%d\n", mx, mu, mg, ms);
+        delete b;
+        return nullptr;
+    }
+    char nm[128];
+    snprintf(nm, sizeof(nm), "1tpi<NX=%d,NU=%d,NG=%d,NS=%d>", b->ks->NX, b->ks->NU, b->ks->NG, b->ks->NS);
+    b->kname = nm;
+    opts_default(b->O);
+    HIPCHK(hipStreamCreate(&b->stream));
+    HIPCHK(hipEventCreate(&b->ev0));
+    HIPCHK(hipEventCreate(&b->ev1));
+    HIPCHK(hipHostMalloc((void **) &b->h_nact, sizeof(int)));
+    return b;
+}
+
+void ocp_qp_gpu_batch_destroy(ocp_qp_gpu_batch *b)
+{
+    if (!b) return;
+    (void) hipSetDevice(b->device);
+    (void) hipStreamSynchronize(b->stream);
+    for (void *p : b->allocs) (void) hipFree(p);
+    (void) hipHostFree(b->h_nact);
+    (void) hipEventDestroy(b->ev0);
+    (void) hipEventDestroy(b->ev1);
+    for (hipEvent_t e : b->prof_ev) (void) hipEventDestroy(e);
+    (void) hipStreamDestroy(b->stream);
+    delete b;
+}
+
+int ocp_qp_gpu_batch_set_int(ocp_qp_gpu_batch *b, const char *f, int k, const int *v, int cnt)
+{
+    if (b->finalized)
+    {
+        fprintf(stderr, "acados_amd: structure field %s must be set before numeric data\n", f);
+        return -1;
+    }
+    if (k < 0 || k > b->N) return -1;
+    if (!strcmp(f, "idxb")) { b->idxb[k].assign(v, v + b->nb[k]); return 0; }
+    if (!strcmp(f, "idxbu")) { for (int i = 0; i < b->nbu[k]; i++) b->idxb[k][i] = v[i]; return 0; }
+    if (!strcmp(f, "idxbx")) { for (int i = 0; i < b->nbx[k]; i++) b->idxb[k][b->nbu[k] + i] = b->nu[k] + v[i]; return 0; }
+    if (!strcmp(f, "idxs_rev")) { b->idxs_rev[k].assign(v, v + b->nb[k] + b->ng[k]); return 0; }
+    if (!strcmp(f, "idxe")) { b->idxe[k].assign(v, v + cnt); b->nbxe[k] = cnt; return 0; }
+    fprintf(stderr, "acados_amd: ocp_qp_gpu_batch_set_int: unknown field %s\n", f);
+    return -1;
+}
+
+int ocp_qp_gpu_batch_set(ocp_qp_gpu_batch *b, const char *f, int stage, const double *data, int is_device)
+{
+    HIPCHK(hipSetDevice(b->device));
+    finalize_structure(b);
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, b->stream));
+    const int k0 = stage < 0 ? 0 : stage, k1 = stage < 0 ? b->N : stage;
+    const int grid = (b->B + 63) / 64;
+    int rc = 0;
+    const double *src = nullptr;
+    int src_len = -1;
+    for (int k = k0; k <= k1; k++)
+    {
+        std::vector<int> map, map2;
+        double *arr = nullptr, *arr2 = nullptr;
+        const size_t flen = strlen(f);
+        if (flen > 5 && !strcmp(f + flen - 5, "_mask"))
+        {
+            const int len = mask_bits(b, f, k, map);
+            if (len < 0) { rc = -1; break; }
+            if (len == 0) continue;
+            if (src_len != len) { src = stage_in(b, data, (size_t) b->B * len, is_device); src_len = len; }
+            int *dm = upload_map(b, map);
+            hipLaunchKernelGGL(gqp::k_setmask, dim3(grid), dim3(64), 0, b->stream, src, b->B, len, dm,
+                               b->D.amask + (size_t) k * b->Bp);
+            continue;
+        }
+        const int len = field_map(b, f, k, map, &arr, &map2, &arr2);
+        if (len < 0)
+        {
+            if (stage < 0) continue; /* field absent at this stage (e.g. A at N) */
+            rc = -1;
+            break;
+        }
+        if (len == 0) continue;
+        if (src_len != len) { src = stage_in(b, data, (size_t) b->B * len, is_device); src_len = len; }
+        int *dm = upload_map(b, map);
+        hipLaunchKernelGGL(gqp::k_scatter, dim3(grid), dim3(64), 0, b->stream, src, b->B, len, dm, arr, b->Bp);
+        if (arr2)
+        {
+            dm = upload_map(b, map2);
+            hipLaunchKernelGGL(gqp::k_scatter, dim3(grid), dim3(64), 0, b->stream, src, b->B, len, dm, arr2, b->Bp);
+        }
+    }
+    HIPCHK(hipEventRecord(e1, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    b->time_pack += ms * 1e-3;
+    HIPCHK(hipEventDestroy(e0)); HIPCHK(hipEventDestroy(e1));
+    if (rc) fprintf(stderr, "acados_amd: ocp_qp_gpu_batch_set: unknown field %s (stage %d)\n", f, stage);
+    return rc;
+}
+
+int ocp_qp_gpu_batch_opts_set(ocp_qp_gpu_batch *b, const char *f, const void *v)
+{
+    GqpOpts &o = b->O;
+    const double *d = (const double *) v;
+    const int *i = (const int *) v;
+    if (!strcmp(f, "iter_max")) o.iter_max = *i;
+    else if (!strcmp(f, "tol_stat")) o.tol_stat = *d;
+    else if (!strcmp(f, "tol_eq")) o.tol_eq = *d;
+    else if (!strcmp(f, "tol_ineq")) o.tol_ineq = *d;
+    else if (!strcmp(f, "tol_comp")) o.tol_comp = *d;
+    else if (!strcmp(f, "warm_start")) o.warm_start = *i;
+    else if (!strcmp(f, "mu0")) { if (*d > 0.0) o.mu0 = *d; }
+    else if (!strcmp(f, "alpha_min")) o.alpha_min = *d;
+    else if (!strcmp(f, "tau_min")) o.tau_min = *d;
+    else if (!strcmp(f, "reg_prim")) o.reg_prim = *d;
+    else if (!strcmp(f, "cond_pred_corr")) o.cond_pred_corr = *i;
+    else if (!strcmp(f, "print_level")) b->print_level = *i;
+    else if (!strcmp(f, "profile")) b->profile = *i;
+    else if (!strcmp(f, "t0_init")) { /* single initialisation scheme (oracle-pinned) */ }
+    else if (!strcmp(f, "ric_alg"))
+    {
+        if (*i != 1) fprintf(stderr, "acados_amd: ric_alg=%d requested, only the square-root Riccati (1) is implemented\n", *i);
+    }
+    else if (!strcmp(f, "hpipm_mode"))
+    {
+        /* modes only reset defaults in the reference (ocp_qp_hpipm.c:142-165) */
+        const char *mode = (const char *) v;
+        if (strcmp(mode, "BALANCE") && strcmp(mode, "SPEED") && strcmp(mode, "SPEED_ABS") && strcmp(mode, "ROBUST"))
+        {
+            fprintf(stderr, "acados_amd: got non-supported mode %s\n", mode);
+            return -1;
+        }
+        const double t1 = o.tol_stat, t2 = o.tol_eq, t3 = o.tol_ineq, t4 = o.tol_comp;
+        const int im = o.iter_max, ws = o.warm_start;
+        opts_default(o);
+        o.tol_stat = t1; o.tol_eq = t2; o.tol_ineq = t3; o.tol_comp = t4; o.iter_max = im; o.warm_start = ws;
+    }
+    else
+    {
+        fprintf(stderr, "acados_amd: ocp_qp_gpu_batch_opts_set: unknown option %s\n", f);
+        return -1;
+    }
+    return 0;
+}
+
+int ocp_qp_gpu_batch_solve(ocp_qp_gpu_batch *b)
+{
+    HIPCHK(hipSetDevice(b->device));
+    finalize_structure(b);
+    ensure_stat(b);
+    const KernelSet *ks = b->ks;
+    GqpDev D = b->D;
+    GqpOpts O = b->O;
+    const dim3 grid((b->B + 63) / 64), block(64);
+    hipStream_t s = b->stream;
+    b->launches = 0;
+    /* kernel classes: 0 init, 1 back_fact, 2 fwd_aff, 3 back_rhs, 4 fwd_corr, 5 finalize */
+    size_t ev_used = 0;
+    b->prof_cls.clear();
+    auto prof_begin = [&](int cls) {
+        if (!b->profile) return;
+        if (ev_used + 2 > b->prof_ev.size())
+        {
+            hipEvent_t e0, e1;
+            HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+            b->prof_ev.push_back(e0); b->prof_ev.push_back(e1);
+        }
+        b->prof_cls.push_back(cls);
+        HIPCHK(hipEventRecord(b->prof_ev[ev_used], s));
+    };
+    auto prof_end = [&]() {
+        if (!b->profile) return;
+        HIPCHK(hipEventRecord(b->prof_ev[ev_used + 1], s));
+        ev_used += 2;
+    };
+
+    HIPCHK(hipEventRecord(b->ev0, s));
+    *b->h_nact = b->B;
+    HIPCHK(hipMemcpyAsync(D.n_active, b->h_nact, sizeof(int), hipMemcpyHostToDevice, s));
+    if (D.stat) HIPCHK(hipMemsetAsync(D.stat, 0, sizeof(double) * (size_t) b->stat_rows * GQP_STAT_COLS * b->stat_inst, s));
+    if (O.warm_start < 2)
+    {
+        prof_begin(0);
+        hipLaunchKernelGGL(ks->init, grid, block, 0, s, D, O);
+        prof_end();
+        b->launches++;
+    }
+    else
+    {
+        /* hot start: keep (ux, pi, lam, t) as they are in HBM */
+        HIPCHK(hipMemsetAsync(D.iter, 0, sizeof(int) * b->Bp, s));
+        std::vector<int> run(b->Bp, GQP_RUNNING);
+        HIPCHK(hipMemcpyAsync(D.status, run.data(), sizeof(int) * b->Bp, hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));
+    }
+    int it = 0;
+    for (;; it++)
+    {
+        prof_begin(1);
+        hipLaunchKernelGGL(ks->back_fact, grid, block, 0, s, D, O, 0);
+        prof_end();
+        b->launches++;
+        HIPCHK(hipMemcpyAsync(b->h_nact, D.n_active, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (b->print_level > 1) printf("acados_amd: ipm iter %d active %d\n", it, *b->h_nact);
+        if (*b->h_nact <= 0 || it > O.iter_max) break;
+        prof_begin(2);
+        hipLaunchKernelGGL(ks->fwd_aff, grid, block, 0, s, D, O, 0);
+        prof_end();
+        prof_begin(3);
+        hipLaunchKernelGGL(ks->back_rhs, grid, block, 0, s, D, O, 0);
+        prof_end();
+        prof_begin(4);
+        hipLaunchKernelGGL(ks->fwd_corr, grid, block, 0, s, D, O, 0);
+        prof_end();
+        b->launches += 3;
+        if (O.cond_pred_corr)
+        {
+            hipLaunchKernelGGL(ks->back_rhs, grid, block, 0, s, D, O, 1);
+            hipLaunchKernelGGL(ks->fwd_corr, grid, block, 0, s, D, O, 1);
+            b->launches += 2;
+        }
+    }
+    hipLaunchKernelGGL(ks->finalize, grid, block, 0, s, D);
+    b->launches++;
+    HIPCHK(hipEventRecord(b->ev1, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, b->ev0, b->ev1));
+    b->time_tot = ms * 1e-3;
+    b->last_iters = it;
+    for (size_t q = 0; q < b->prof_cls.size(); q++)
+    {
+        float pm = 0.f;
+        HIPCHK(hipEventElapsedTime(&pm, b->prof_ev[2 * q], b->prof_ev[2 * q + 1]));
+        b->prof_ms[b->prof_cls[q]] += pm;
+        b->prof_cnt[b->prof_cls[q]]++;
+    }
+
+    std::vector<int> st(b->B);
+    HIPCHK(hipMemcpy(st.data(), D.status, sizeof(int) * b->B, hipMemcpyDeviceToHost));
+    int bad = 0;
+    for (int i = 0; i < b->B; i++) bad += st[i] != 0;
+    return bad;
+}
+
+int ocp_qp_gpu_batch_get(ocp_qp_gpu_batch *b, const char *f, int k, double *data, int is_device)
+{
+    HIPCHK(hipSetDevice(b->device));
+    finalize_structure(b);
+    std::vector<int> map;
+    double *arr = nullptr;
+    const int len = field_map(b, f, k, map, &arr);
+    if (len < 0)
+    {
+        fprintf(stderr, "acados_amd: ocp_qp_gpu_batch_get: field %s not available at stage %d\n", f, k);
+        return -1;
+    }
+    if (len == 0) return 0;
+    const size_t cnt = (size_t) b->B * len;
+    double *dst = data;
+    if (!is_device)
+    {
+        if (cnt > b->stage_cap)
+        {
+            b->stage_cap = cnt * 2;
+            b->d_stage = dalloc<double>(b, b->stage_cap);
+        }
+        dst = b->d_stage;
+    }
+    int *dm = upload_map(b, map);
+    hipLaunchKernelGGL(gqp::k_gather, dim3((b->B + 63) / 64), dim3(64), 0, b->stream, dst, b->B, len, dm, arr, b->Bp);
+    if (!is_device) HIPCHK(hipMemcpyAsync(data, dst, sizeof(double) * cnt, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return 0;
+}
+
+int ocp_qp_gpu_batch_get_info(ocp_qp_gpu_batch *b, const char *f, void *data)
+{
+    HIPCHK(hipSetDevice(b->device));
+    finalize_structure(b);
+    const GqpDev &D = b->D;
+    const size_t B = b->B;
+    if (!strcmp(f, "status")) { HIPCHK(hipMemcpy(data, D.status, sizeof(int) * B, hipMemcpyDeviceToHost)); return 0; }
+    if (!strcmp(f, "iter")) { HIPCHK(hipMemcpy(data, D.iter, sizeof(int) * B, hipMemcpyDeviceToHost)); return 0; }
+    const char *names[4] = {"res_stat", "res_eq", "res_ineq", "res_comp"};
+    for (int q = 0; q < 4; q++)
+        if (!strcmp(f, names[q]))
+        {
+            HIPCHK(hipMemcpy(data, D.res + (size_t) q * b->Bp, sizeof(double) * B, hipMemcpyDeviceToHost));
+            return 0;
+        }
+    if (!strcmp(f, "mu")) { HIPCHK(hipMemcpy(data, D.mu, sizeof(double) * B, hipMemcpyDeviceToHost)); return 0; }
+    if (!strcmp(f, "obj")) { HIPCHK(hipMemcpy(data, D.obj, sizeof(double) * B, hipMemcpyDeviceToHost)); return 0; }
+    fprintf(stderr, "acados_amd: ocp_qp_gpu_batch_get_info: unknown field %s\n", f);
+    return -1;
+}
+
+int ocp_qp_gpu_batch_get_stat(ocp_qp_gpu_batch *b, int inst, double *stat, int max_rows)
+{
+    HIPCHK(hipSetDevice(b->device));
+    if (!b->D.stat || inst < 0 || inst >= b->stat_inst) return -1;
+    const int rows = std::min(max_rows, b->stat_rows);
+    std::vector<double> h((size_t) b->stat_rows * GQP_STAT_COLS * b->stat_inst);
+    HIPCHK(hipMemcpy(h.data(), b->D.stat, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+    for (int r = 0; r < rows; r++)
+        for (int c = 0; c < GQP_STAT_COLS; c++)
+            stat[r * GQP_STAT_COLS + c] = h[((size_t) r * GQP_STAT_COLS + c) * b->stat_inst + inst];
+    return rows;
+}
+
+double ocp_qp_gpu_batch_get_scalar(ocp_qp_gpu_batch *b, const char *f)
+{
+    if (!strcmp(f, "time_tot")) return b->time_tot;
+    if (!strcmp(f, "time_pack")) { double t = b->time_pack; b->time_pack = 0.0; return t; }
+    if (!strcmp(f, "iter_max_batch")) return (double) b->last_iters;
+    if (!strcmp(f, "launches")) return (double) b->launches;
+    {
+        /* accumulated per-kernel-class event times (ms) and launch counts since the last reset */
+        const char *cls[6] = {"init", "back_fact", "fwd_aff", "back_rhs", "fwd_corr", "finalize"};
+        for (int q = 0; q < 6; q++)
+        {
+            char nm[64];
+            snprintf(nm, sizeof(nm), "prof_ms_%s", cls[q]);
+            if (!strcmp(f, nm)) return b->prof_ms[q];
+            snprintf(nm, sizeof(nm), "prof_cnt_%s", cls[q]);
+            if (!strcmp(f, nm)) return (double) b->prof_cnt[q];
+        }
+        if (!strcmp(f, "prof_reset"))
+        {
+            for (int q = 0; q < 6; q++) { b->prof_ms[q] = 0.0; b->prof_cnt[q] = 0; }
+            return 0.0;
+        }
+    }
+    fprintf(stderr, "acados_amd: ocp_qp_gpu_batch_get_scalar: unknown field %s\n", f);
+    return -1.0;
+}
+
+size_t ocp_qp_gpu_batch_bytes(const ocp_qp_gpu_batch *b) { return b->bytes; }
+void *ocp_qp_gpu_batch_stream(ocp_qp_gpu_batch *b) { return (void *) b->stream; }
+const char *ocp_qp_gpu_batch_kernel_name(const ocp_qp_gpu_batch *b) { return b->kname.c_str(); }
+
+} /* extern "C" */

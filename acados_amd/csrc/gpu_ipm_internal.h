@@ -1,0 +1,79 @@
+/*
+ * gpu_ipm_internal.h -- device-side data model of one shape-uniform batch of OCP-QPs.
+ *
+ * HBM layout ("element-major, instance-minor"): every per-instance quantity is an array
+ *     a[(stage_offset + element) * Bp + instance]
+ * with Bp = batch padded to a multiple of 64, so that the 64 lanes of a wavefront
+ * (one instance per lane) read 64 consecutive doubles = 512 B per load instruction.
+ * Stage dims are padded to the compile-time (NX, NU) of the kernel instantiation:
+ * padded variables get unit Hessian diagonal, zero gradient and zero dynamics rows /
+ * columns, so they stay exactly zero and contribute exactly zero residual.
+ *
+ * Variables of a stage are ordered [u(NU); x(NX)] as in acados/HPIPM
+ * (RSQrq block layout: acados/utils/print.c:234-325 in the reference).
+ */
+#ifndef GPU_IPM_INTERNAL_H_
+#define GPU_IPM_INTERNAL_H_
+
+#include <stdint.h>
+
+#define GQP_MAX_ROWS 64 /* nb+ng per stage, and 2(nb+ng)+2ns <= 64 (activity bit mask) */
+
+/* per-stage structure shared by the whole batch (read through scalar loads) */
+struct GqpStage
+{
+    int nb, ng, ns;        /* box rows, general rows, slacks of this stage */
+    int o_ct;              /* element offset of this stage in lam/t/rd/rm/dlam/dt/dvec */
+    int o_s;               /* element offset of this stage in the slack arrays (2*ns entries) */
+    int o_g;               /* row offset of this stage in DCt */
+    int has_dyn;           /* k < N */
+    int pad_;
+    uint64_t bmask;        /* padded variable j carries a box row */
+    uint64_t emask;        /* padded variable j is fixed by an equality-flagged bound */
+    int8_t srev[GQP_MAX_ROWS]; /* slack index of constraint row (sorted order), -1 = hard */
+};
+
+struct GqpOpts
+{
+    double mu0, tol_stat, tol_eq, tol_ineq, tol_comp, alpha_min, tau_min, lam_min, t_min, reg_prim;
+    int iter_max, pred_corr, cond_pred_corr, warm_start;
+};
+
+/* all device pointers of one batch; passed by value to the kernels */
+struct GqpDev
+{
+    int B, Bp, N, NX, NU, NG, NS;
+    const GqpStage *st; /* N+1 entries */
+    /* problem data */
+    double *BAt;   /* [N][n*NX]   BAt[r*NX+c] = d x+_c / d v_r                      */
+    double *bvec;  /* [N][NX]                                                        */
+    double *RSQ;   /* [N+1][n(n+1)/2] packed lower, row-major packed: (r,c)->r(r+1)/2+c */
+    double *rq;    /* [N+1][n]                                                       */
+    double *dvec;  /* [sum nct] natural-sign bounds, order [lb lg ub ug lls lus]     */
+    uint64_t *amask; /* [N+1] per instance: bit e set <=> inequality row e takes part */
+    double *DCt;   /* [sum ng][n]  row g: d(general row)/d v                         */
+    double *Zz;    /* [sum 2ns][2]: (Z, z) for sl then su                            */
+    /* iterate */
+    double *ux;    /* [N+1][n] */
+    double *sv;    /* [sum 2ns] slack values sl then su */
+    double *pi;    /* [N][NX] */
+    double *lam, *t; /* [sum nct] */
+    /* work */
+    double *rg, *rgs, *rb, *rd, *rm;
+    double *dux, *dsv, *dpi, *dlam, *dt;
+    double *sD, *sR; /* [sum 2ns] per-slack D = Z + sum Gamma and r~ (condensed slack rhs) */
+    double *Lf;    /* [N+1][n(n+1)/2] Cholesky factors */
+    double *lf;    /* [N+1][n] */
+    /* per instance scalars */
+    double *res;   /* [4] */
+    double *mu, *smu, *alpha, *obj;
+    int *iter, *status;
+    int *n_active; /* single counter: instances still iterating */
+    double *stat;  /* [stat_rows][STAT_COLS][Bp_stat] for the first stat_inst instances */
+    int stat_inst, stat_rows;
+};
+
+#define GQP_STAT_COLS 20
+#define GQP_RUNNING (-2)
+
+#endif

@@ -1,0 +1,1029 @@
+/*
+ * ipm_kernels.hpp -- HIP kernels of the batched OCP-QP interior-point solver (gfx950).
+ *
+ * Mapping: ONE QP INSTANCE PER LANE.  A wavefront advances 64 independent instances;
+ * every global access `a[e*Bp + i]` is a fully coalesced 512-byte wave access (see
+ * gpu_ipm_internal.h).  Per-stage dense blocks ((NU+NX)^2 Hessian, (NU+NX) x NX
+ * dynamics) live in VGPRs (loops are fully unrolled for small shapes) and the stage
+ * recursion runs sequentially inside the lane; the batch supplies the parallelism.
+ * The path is HBM-bound: per IPM iteration the stage data are streamed
+ * four times (factor / forward / rhs-backward / forward).
+ *
+ * One IPM iteration = 4 launches over the whole batch:
+ *   k_resfact   backward sweep: KKT residuals of the current iterate (+ norms,
+ *               convergence decision per instance), Gamma/gamma condensation of the
+ *               inequalities, square-root Riccati factorisation + rhs propagation
+ *   k_forward<0> forward sweep of the affine direction, step length, mu_aff, sigma
+ *   k_backrhs   backward rhs-only sweep for the Mehrotra corrector (factor reused)
+ *   k_forward<1> forward sweep, step length, primal/dual update
+ * What replaces what (reference, /root/reference): the whole loop is the body of
+ * d_ocp_qp_ipm_solve as called from acados/ocp_qp/ocp_qp_hpipm.c:347 (HPIPM sources are
+ * absent from the reference tree; the algorithm is restated in oracle/ocp_qp_oracle.c).
+ */
+#ifndef IPM_KERNELS_HPP_
+#define IPM_KERNELS_HPP_
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+#include "gpu_ipm_internal.h"
+
+#define PK(r, c) ((((r) * ((r) + 1)) >> 1) + (c))
+#define GAT(arr, e) (arr)[(size_t) (e) * (size_t) Bp + (size_t) i]
+
+#if defined(GQP_NO_UNROLL)
+#define UNROLL _Pragma("unroll 1")
+#else
+#define UNROLL _Pragma("unroll")
+#endif
+
+namespace gqp
+{
+
+__device__ static inline double dmax(double a, double b) { return a > b ? a : b; }
+__device__ static inline double dabs(double a) { return a < 0.0 ? -a : a; }
+/* inf-norm accumulation that lets NaN through */
+__device__ static inline void nacc(double &nrm, double v)
+{
+    double a = dabs(v);
+    if (a > nrm || v != v) nrm = a;
+}
+
+/* ------------------------------------------------------------------ init */
+
+/* Cold start: restates the initialisation the oracle pins (oracle/ocp_qp_oracle.c
+ * init_var; reference contract ocp_qp_hpipm.c:333-336: primal iterate zeroed). */
+template <int NX, int NU, int NG, int NS>
+__global__ void __launch_bounds__(64) k_init(GqpDev D, GqpOpts O)
+{
+    constexpr int n = NX + NU;
+    const int Bp = D.Bp;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D.B) return;
+    const double thr0 = 1e-1;
+    for (int k = 0; k <= D.N; k++)
+    {
+        const GqpStage &S = D.st[k];
+        const int nbg = S.nb + S.ng;
+        const uint64_t am = GAT(D.amask, k);
+        double v[n];
+        UNROLL for (int j = 0; j < n; j++) v[j] = 0.0;
+        /* fixed variables keep the value the caller put into ux (set at pack time) */
+        UNROLL for (int j = 0; j < n; j++) if ((S.emask >> j) & 1) v[j] = GAT(D.ux, k * n + j);
+        int ib = 0;
+        UNROLL for (int j = 0; j < n; j++)
+        {
+            if (!((S.bmask >> j) & 1)) continue;
+            const bool fixed = (S.emask >> j) & 1;
+            const bool soft = S.srev[ib] >= 0;
+            if (!fixed && !soft)
+            {
+                const double lb = GAT(D.dvec, S.o_ct + ib), ub = GAT(D.dvec, S.o_ct + nbg + ib);
+                const bool al = (am >> ib) & 1, au = (am >> (nbg + ib)) & 1;
+                const double tl = v[j] - lb, tu = ub - v[j];
+                if (al && au)
+                {
+                    if (tl < thr0) v[j] = (tu < thr0) ? 0.5 * (lb + ub) : lb + thr0;
+                    else if (tu < thr0) v[j] = ub - thr0;
+                }
+                else if (al) { if (tl < thr0) v[j] = lb + thr0; }
+                else if (au) { if (tu < thr0) v[j] = ub - thr0; }
+            }
+            ib++;
+        }
+        UNROLL for (int j = 0; j < n; j++) GAT(D.ux, k * n + j) = v[j];
+        if (S.has_dyn) { UNROLL for (int c = 0; c < NX; c++) GAT(D.pi, k * NX + c) = 0.0; }
+        /* slacks */
+        double sl[NS > 0 ? NS : 1], su[NS > 0 ? NS : 1];
+        if (NS > 0)
+        {
+            UNROLL for (int j = 0; j < NS; j++)
+            {
+                sl[j] = 0.0; su[j] = 0.0;
+                if (j < S.ns)
+                {
+                    if ((am >> (2 * nbg + j)) & 1) sl[j] = GAT(D.dvec, S.o_ct + 2 * nbg + j) + thr0;
+                    if ((am >> (2 * nbg + S.ns + j)) & 1) su[j] = GAT(D.dvec, S.o_ct + 2 * nbg + S.ns + j) + thr0;
+                }
+            }
+        }
+        /* row values c_i */
+        double cval[n + NG];
+        ib = 0;
+        UNROLL for (int j = 0; j < n; j++) if ((S.bmask >> j) & 1) { cval[j] = v[j]; }
+        UNROLL for (int g = 0; g < NG; g++)
+        {
+            cval[n + g] = 0.0;
+            if (g < S.ng)
+            {
+                double a = 0.0;
+                UNROLL for (int r = 0; r < n; r++) a += GAT(D.DCt, (S.o_g + g) * n + r) * v[r];
+                cval[n + g] = a;
+            }
+        }
+        if (NS > 0)
+        {
+            ib = 0;
+            UNROLL for (int j = 0; j < n + NG; j++)
+            {
+                const bool is_row = j < n ? ((S.bmask >> j) & 1) : (j - n < S.ng);
+                if (!is_row) continue;
+                const int row = j < n ? ib : S.nb + (j - n);
+                if (j < n) ib++;
+                const int sj = S.srev[row];
+                if (sj < 0) continue;
+                const double lo = GAT(D.dvec, S.o_ct + row), up = GAT(D.dvec, S.o_ct + nbg + row);
+                const double need_l = lo - cval[j] + thr0, need_u = cval[j] - up + thr0;
+                UNROLL for (int q = 0; q < NS; q++)
+                    if (q == sj)
+                    {
+                        if (((am >> row) & 1) && need_l > sl[q]) sl[q] = need_l;
+                        if (((am >> (nbg + row)) & 1) && need_u > su[q]) su[q] = need_u;
+                    }
+            }
+            UNROLL for (int j = 0; j < NS; j++)
+                if (j < S.ns)
+                {
+                    GAT(D.sv, S.o_s + j) = sl[j];
+                    GAT(D.sv, S.o_s + S.ns + j) = su[j];
+                }
+        }
+        /* t, lam */
+        ib = 0;
+        UNROLL for (int j = 0; j < n + NG; j++)
+        {
+            const bool is_row = j < n ? ((S.bmask >> j) & 1) : (j - n < S.ng);
+            if (!is_row) continue;
+            const int row = j < n ? ib : S.nb + (j - n);
+            if (j < n) ib++;
+            const double lo = GAT(D.dvec, S.o_ct + row), up = GAT(D.dvec, S.o_ct + nbg + row);
+            double ssl = 0.0, ssu = 0.0;
+            if (NS > 0)
+            {
+                const int sj = S.srev[row];
+                UNROLL for (int q = 0; q < NS; q++) if (q == sj) { ssl = sl[q]; ssu = su[q]; }
+            }
+            double tl = cval[j] + ssl - lo, tu = up - cval[j] + ssu;
+            if (tl < thr0) tl = thr0;
+            if (tu < thr0) tu = thr0;
+            const bool al = (am >> row) & 1, au = (am >> (nbg + row)) & 1;
+            GAT(D.t, S.o_ct + row) = al ? tl : 0.0;
+            GAT(D.t, S.o_ct + nbg + row) = au ? tu : 0.0;
+            GAT(D.lam, S.o_ct + row) = al ? O.mu0 / tl : 0.0;
+            GAT(D.lam, S.o_ct + nbg + row) = au ? O.mu0 / tu : 0.0;
+        }
+        if (NS > 0)
+        {
+            UNROLL for (int j = 0; j < NS; j++)
+                if (j < S.ns)
+                {
+                    const int e0 = S.o_ct + 2 * nbg + j, e1 = e0 + S.ns;
+                    double tl = sl[j] - GAT(D.dvec, e0), tu = su[j] - GAT(D.dvec, e1);
+                    if (tl < thr0) tl = thr0;
+                    if (tu < thr0) tu = thr0;
+                    const bool al = (am >> (2 * nbg + j)) & 1, au = (am >> (2 * nbg + S.ns + j)) & 1;
+                    GAT(D.t, e0) = al ? tl : 0.0;
+                    GAT(D.t, e1) = au ? tu : 0.0;
+                    GAT(D.lam, e0) = al ? O.mu0 / tl : 0.0;
+                    GAT(D.lam, e1) = au ? O.mu0 / tu : 0.0;
+                }
+        }
+    }
+    D.iter[i] = 0;
+    D.status[i] = GQP_RUNNING;
+    D.alpha[i] = 1.0;
+}
+
+/* ------------------------------------------------- shared row machinery */
+
+/* Everything the sweeps need to know about one inequality row pair (lower, upper). */
+struct RowQ
+{
+    double gl, gu;  /* Gamma = lam/t   (0 if side inactive) */
+    double rl, ru;  /* rho   = (rm_eff + lam*rd)/t          */
+};
+
+/* ---------------------------------------------------------- k_resfact */
+
+/*
+ * Backward sweep k = N..0 of one IPM iteration.
+ * FACT = true : full sweep (residuals of the current iterate, norms, convergence test,
+ *               condensation with the affine complementarity rhs, Cholesky + rhs).
+ * FACT = false: rhs-only sweep for the corrector: rm_eff = rm + dlam*dt - sigma*mu,
+ *               factor L reused from HBM, only l = L^{-1} m is rewritten.
+ */
+template <int NX, int NU, int NG, int NS, bool FACT>
+__global__ void __launch_bounds__(64) k_backward(GqpDev D, GqpOpts O, int redo)
+{
+    constexpr int n = NX + NU;
+    constexpr int NP = n * (n + 1) / 2;
+    constexpr int NSS = NS > 0 ? NS : 1;
+    const int Bp = D.Bp;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D.B) return;
+    if (D.status[i] != GQP_RUNNING) return;
+
+    /* redo pass (cond_pred_corr fallback): only instances whose corrector collapsed
+     * (flagged by a negative alpha) re-solve with the centering-only rhs */
+    if (redo && !(D.alpha[i] < 0.0)) return;
+    const double smu = FACT ? 0.0 : D.smu[i];
+    const bool center_only = !FACT && redo;
+
+    double Lx[NX * (NX + 1) / 2]; /* x-block of the factor of stage k+1 */
+    double lx[NX];
+    double nrm_g = 0.0, nrm_b = 0.0, nrm_d = 0.0, nrm_m = 0.0, musum = 0.0, obj = 0.0;
+    int nact = 0;
+
+    for (int k = D.N; k >= 0; k--)
+    {
+        const GqpStage &S = D.st[k];
+        const int nbg = S.nb + S.ng;
+        const uint64_t am = GAT(D.amask, k);
+        double M[NP];  /* FACT: Hessian then factor ; !FACT: factor loaded from HBM */
+        double gt[n];  /* condensed gradient -> m -> l */
+        double v[n];
+        double rb[NX];
+
+        if (FACT)
+        {
+            UNROLL for (int e = 0; e < NP; e++) M[e] = GAT(D.RSQ, k * NP + e);
+            UNROLL for (int j = 0; j < n; j++) v[j] = GAT(D.ux, k * n + j);
+            /* rg = H v + g */
+            double hv[n];
+            UNROLL for (int r = 0; r < n; r++) hv[r] = 0.0;
+            UNROLL for (int r = 0; r < n; r++)
+            {
+                UNROLL for (int c = 0; c < r; c++)
+                {
+                    hv[r] += M[PK(r, c)] * v[c];
+                    hv[c] += M[PK(r, c)] * v[r];
+                }
+                hv[r] += M[PK(r, r)] * v[r];
+            }
+            UNROLL for (int r = 0; r < n; r++)
+            {
+                const double g = GAT(D.rq, k * n + r);
+                obj += (0.5 * hv[r] + g) * v[r];
+                gt[r] = hv[r] + g;
+            }
+            if (k > 0) { UNROLL for (int c = 0; c < NX; c++) gt[NU + c] -= GAT(D.pi, (k - 1) * NX + c); }
+            UNROLL for (int r = 0; r < n; r++) M[PK(r, r)] += O.reg_prim;
+        }
+        else
+        {
+            UNROLL for (int e = 0; e < NP; e++) M[e] = GAT(D.Lf, k * NP + e);
+            UNROLL for (int j = 0; j < n; j++) gt[j] = GAT(D.rg, k * n + j);
+        }
+
+        /* ---- dynamics part: rg += BAt pi+, rb, W = BAt Lx+, M += W W', m += W w0 ---- */
+        double y[NX]; /* P+ rb + p+ = Lx+ (Lx+' rb + lx+) */
+        if (S.has_dyn)
+        {
+            if (FACT)
+            {
+                double pin[NX];
+                UNROLL for (int c = 0; c < NX; c++)
+                {
+                    pin[c] = GAT(D.pi, k * NX + c);
+                    rb[c] = GAT(D.bvec, k * NX + c) - GAT(D.ux, (k + 1) * n + NU + c);
+                }
+                double W[n * NX];
+                UNROLL for (int r = 0; r < n; r++)
+                {
+                    double row[NX];
+                    UNROLL for (int c = 0; c < NX; c++) row[c] = GAT(D.BAt, (k * n + r) * NX + c);
+                    double a = 0.0;
+                    UNROLL for (int c = 0; c < NX; c++)
+                    {
+                        a += row[c] * pin[c];
+                        rb[c] += row[c] * v[r];
+                    }
+                    gt[r] += a;
+                    UNROLL for (int c = 0; c < NX; c++)
+                    {
+                        double w = 0.0;
+                        UNROLL for (int q = c; q < NX; q++) w += row[q] * Lx[PK(q, c)];
+                        W[r * NX + c] = w;
+                    }
+                }
+                UNROLL for (int r = 0; r < n; r++)
+                    UNROLL for (int c = 0; c <= r; c++)
+                    {
+                        double a = 0.0;
+                        UNROLL for (int q = 0; q < NX; q++) a += W[r * NX + q] * W[c * NX + q];
+                        M[PK(r, c)] += a;
+                    }
+                UNROLL for (int c = 0; c < NX; c++)
+                {
+                    GAT(D.rb, k * NX + c) = rb[c];
+                    nacc(nrm_b, rb[c]);
+                }
+            }
+            else
+            {
+                UNROLL for (int c = 0; c < NX; c++) rb[c] = GAT(D.rb, k * NX + c);
+            }
+            double w0[NX];
+            UNROLL for (int c = 0; c < NX; c++)
+            {
+                double a = lx[c];
+                UNROLL for (int q = c; q < NX; q++) a += Lx[PK(q, c)] * rb[q];
+                w0[c] = a;
+            }
+            UNROLL for (int r = 0; r < NX; r++)
+            {
+                double a = 0.0;
+                UNROLL for (int c = 0; c <= r; c++) a += Lx[PK(r, c)] * w0[c];
+                y[r] = a;
+            }
+        }
+
+        /* ---- inequality rows ---- */
+        double sDl[NSS], sDu[NSS], sRl[NSS], sRu[NSS], sPl[NSS], sPu[NSS];
+        if (NS > 0)
+        {
+            UNROLL for (int q = 0; q < NS; q++)
+            {
+                sDl[q] = sDu[q] = sRl[q] = sRu[q] = sPl[q] = sPu[q] = 0.0;
+                if (q < S.ns)
+                {
+                    const int e0 = S.o_ct + 2 * nbg + q, e1 = e0 + S.ns;
+                    const double Zl = GAT(D.Zz, (S.o_s + q) * 2), zl = GAT(D.Zz, (S.o_s + q) * 2 + 1);
+                    const double Zu = GAT(D.Zz, (S.o_s + S.ns + q) * 2), zu = GAT(D.Zz, (S.o_s + S.ns + q) * 2 + 1);
+                    const bool al = (am >> (2 * nbg + q)) & 1, au = (am >> (2 * nbg + S.ns + q)) & 1;
+                    const double laml = al ? GAT(D.lam, e0) : 0.0, lamu = au ? GAT(D.lam, e1) : 0.0;
+                    const double tl = GAT(D.t, e0), tu = GAT(D.t, e1);
+                    double rdl, rdu, rml, rmu;
+                    if (FACT)
+                    {
+                        const double sl = GAT(D.sv, S.o_s + q), su = GAT(D.sv, S.o_s + S.ns + q);
+                        obj += (0.5 * Zl * sl + zl) * sl + (0.5 * Zu * su + zu) * su;
+                        rdl = al ? sl - GAT(D.dvec, e0) - tl : 0.0;
+                        rdu = au ? su - GAT(D.dvec, e1) - tu : 0.0;
+                        rml = al ? laml * tl - O.tau_min : 0.0;
+                        rmu = au ? lamu * tu - O.tau_min : 0.0;
+                        GAT(D.rd, e0) = rdl; GAT(D.rd, e1) = rdu;
+                        GAT(D.rm, e0) = rml; GAT(D.rm, e1) = rmu;
+                        nacc(nrm_d, rdl); nacc(nrm_d, rdu); nacc(nrm_m, rml); nacc(nrm_m, rmu);
+                        musum += laml * tl + lamu * tu;
+                        nact += (int) al + (int) au;
+                        /* slack stationarity residual (row part added below) */
+                        sRl[q] = Zl * sl + zl - laml;
+                        sRu[q] = Zu * su + zu - lamu;
+                    }
+                    else
+                    {
+                        rdl = GAT(D.rd, e0); rdu = GAT(D.rd, e1);
+                        rml = GAT(D.rm, e0); rmu = GAT(D.rm, e1);
+                        if (al) rml += (center_only ? 0.0 : GAT(D.dlam, e0) * GAT(D.dt, e0)) - smu;
+                        if (au) rmu += (center_only ? 0.0 : GAT(D.dlam, e1) * GAT(D.dt, e1)) - smu;
+                        sRl[q] = GAT(D.rgs, S.o_s + q);
+                        sRu[q] = GAT(D.rgs, S.o_s + S.ns + q);
+                    }
+                    sDl[q] = Zl + (al ? laml / tl : 0.0);
+                    sDu[q] = Zu + (au ? lamu / tu : 0.0);
+                    /* rho sums are kept apart (sP) until the stationarity residual is stored */
+                    sPl[q] = al ? (rml + laml * rdl) / tl : 0.0;
+                    sPu[q] = au ? (rmu + lamu * rdu) / tu : 0.0;
+                }
+            }
+        }
+
+        /* pass 1 over the rows */
+        double gadd[n]; /* hard-row contributions to the condensed gradient */
+        UNROLL for (int j = 0; j < n; j++) gadd[j] = 0.0;
+        {
+            int ib = 0;
+            UNROLL for (int j = 0; j < n + NG; j++)
+            {
+                const bool is_row = j < n ? ((S.bmask >> j) & 1) : (j - n < S.ng);
+                if (!is_row) continue;
+                const int row = j < n ? ib : S.nb + (j - n);
+                if (j < n) ib++;
+                const int el = S.o_ct + row, eu = el + nbg;
+                const bool al = (am >> row) & 1, au = (am >> (nbg + row)) & 1;
+                double arow[n];
+                if (j >= n) { UNROLL for (int r = 0; r < n; r++) arow[r] = GAT(D.DCt, (S.o_g + (j - n)) * n + r); }
+                const int sj = NS > 0 ? S.srev[row] : -1;
+                const double laml = al ? GAT(D.lam, el) : 0.0, lamu = au ? GAT(D.lam, eu) : 0.0;
+                const double tl = al ? GAT(D.t, el) : 1.0, tu = au ? GAT(D.t, eu) : 1.0;
+                double rdl, rdu, rml, rmu;
+                if (FACT)
+                {
+                    double c;
+                    if (j < n) c = v[j < n ? j : 0];
+                    else { c = 0.0; UNROLL for (int r = 0; r < n; r++) c += arow[r] * v[r]; }
+                    double ssl = 0.0, ssu = 0.0;
+                    if (NS > 0 && sj >= 0) { ssl = GAT(D.sv, S.o_s + sj); ssu = GAT(D.sv, S.o_s + S.ns + sj); }
+                    rdl = al ? c + ssl - GAT(D.dvec, el) - tl : 0.0;
+                    rdu = au ? GAT(D.dvec, eu) - c + ssu - tu : 0.0;
+                    rml = al ? laml * tl - O.tau_min : 0.0;
+                    rmu = au ? lamu * tu - O.tau_min : 0.0;
+                    GAT(D.rd, el) = rdl; GAT(D.rd, eu) = rdu;
+                    GAT(D.rm, el) = rml; GAT(D.rm, eu) = rmu;
+                    nacc(nrm_d, rdl); nacc(nrm_d, rdu); nacc(nrm_m, rml); nacc(nrm_m, rmu);
+                    musum += laml * tl + lamu * tu;
+                    nact += (int) al + (int) au;
+                    /* stationarity: rg -= a (lam_l - lam_u) */
+                    const double nu_ = laml - lamu;
+                    if (j < n) gt[j < n ? j : 0] -= nu_;
+                    else { UNROLL for (int r = 0; r < n; r++) gt[r] -= arow[r] * nu_; }
+                    if (NS > 0 && sj >= 0)
+                    {
+                        UNROLL for (int q = 0; q < NS; q++) if (q == sj) { sRl[q] -= laml; sRu[q] -= lamu; }
+                    }
+                }
+                else
+                {
+                    rdl = GAT(D.rd, el); rdu = GAT(D.rd, eu);
+                    rml = GAT(D.rm, el); rmu = GAT(D.rm, eu);
+                    if (al) rml += (center_only ? 0.0 : GAT(D.dlam, el) * GAT(D.dt, el)) - smu;
+                    if (au) rmu += (center_only ? 0.0 : GAT(D.dlam, eu) * GAT(D.dt, eu)) - smu;
+                }
+                const double gl = al ? laml / tl : 0.0, gu = au ? lamu / tu : 0.0;
+                const double rl = al ? (rml + laml * rdl) / tl : 0.0, ru = au ? (rmu + lamu * rdu) / tu : 0.0;
+                if (NS > 0 && sj >= 0)
+                {
+                    UNROLL for (int q = 0; q < NS; q++)
+                        if (q == sj) { sDl[q] += gl; sDu[q] += gu; sPl[q] += rl; sPu[q] += ru; }
+                }
+                else
+                {
+                    const double nu_ = rl - ru, gm = gl + gu;
+                    if (j < n)
+                    {
+                        gadd[j < n ? j : 0] += nu_;
+                        if (FACT) M[PK((j < n ? j : 0), (j < n ? j : 0))] += gm;
+                    }
+                    else
+                    {
+                        UNROLL for (int r = 0; r < n; r++) gadd[r] += arow[r] * nu_;
+                        if (FACT)
+                        {
+                            UNROLL for (int r = 0; r < n; r++)
+                                UNROLL for (int c = 0; c <= r; c++) M[PK(r, c)] += gm * arow[r] * arow[c];
+                        }
+                    }
+                }
+            }
+        }
+
+        if (FACT)
+        {
+            /* multipliers of equality-flagged bounds from the raw stationarity value */
+            int ib = 0;
+            UNROLL for (int j = 0; j < n; j++)
+            {
+                if (!((S.bmask >> j) & 1)) continue;
+                if ((S.emask >> j) & 1)
+                {
+                    const double a = gt[j];
+                    GAT(D.lam, S.o_ct + ib) = a > 0.0 ? a : 0.0;
+                    GAT(D.lam, S.o_ct + nbg + ib) = a < 0.0 ? -a : 0.0;
+                    GAT(D.t, S.o_ct + ib) = 0.0;
+                    GAT(D.t, S.o_ct + nbg + ib) = 0.0;
+                }
+                ib++;
+            }
+            UNROLL for (int j = 0; j < n; j++)
+            {
+                if ((S.emask >> j) & 1) gt[j] = 0.0;
+                nacc(nrm_g, gt[j]);
+                GAT(D.rg, k * n + j) = gt[j];
+            }
+            if (NS > 0)
+            {
+                UNROLL for (int q = 0; q < NS; q++)
+                    if (q < S.ns)
+                    {
+                        nacc(nrm_g, sRl[q]); nacc(nrm_g, sRu[q]);
+                        GAT(D.rgs, S.o_s + q) = sRl[q];
+                        GAT(D.rgs, S.o_s + S.ns + q) = sRu[q];
+                    }
+            }
+        }
+
+        /* pass 2: soft rows (need the complete per-slack sums) */
+        if (NS > 0)
+        {
+            UNROLL for (int q = 0; q < NS; q++)
+                if (q < S.ns)
+                {
+                    sRl[q] += sPl[q]; sRu[q] += sPu[q]; /* r~ = stationarity residual + rho sums */
+                    /* persist (D, r~) of each slack for the forward sweep */
+                    GAT(D.sD, S.o_s + q) = sDl[q]; GAT(D.sD, S.o_s + S.ns + q) = sDu[q];
+                    GAT(D.sR, S.o_s + q) = sRl[q]; GAT(D.sR, S.o_s + S.ns + q) = sRu[q];
+                }
+            int ib = 0;
+            UNROLL for (int j = 0; j < n + NG; j++)
+            {
+                const bool is_row = j < n ? ((S.bmask >> j) & 1) : (j - n < S.ng);
+                if (!is_row) continue;
+                const int row = j < n ? ib : S.nb + (j - n);
+                if (j < n) ib++;
+                const int sj = S.srev[row];
+                if (sj < 0) continue;
+                const int el = S.o_ct + row, eu = el + nbg;
+                const bool al = (am >> row) & 1, au = (am >> (nbg + row)) & 1;
+                const double gl = al ? GAT(D.lam, el) / GAT(D.t, el) : 0.0;
+                const double gu = au ? GAT(D.lam, eu) / GAT(D.t, eu) : 0.0;
+                double rml = GAT(D.rm, el), rmu = GAT(D.rm, eu);
+                if (!FACT)
+                {
+                    if (al) rml += (center_only ? 0.0 : GAT(D.dlam, el) * GAT(D.dt, el)) - smu;
+                    if (au) rmu += (center_only ? 0.0 : GAT(D.dlam, eu) * GAT(D.dt, eu)) - smu;
+                }
+                const double rl = al ? (rml + GAT(D.lam, el) * GAT(D.rd, el)) / GAT(D.t, el) : 0.0;
+                const double ru = au ? (rmu + GAT(D.lam, eu) * GAT(D.rd, eu)) / GAT(D.t, eu) : 0.0;
+                double dl = 1.0, du = 1.0, rsl = 0.0, rsu = 0.0;
+                UNROLL for (int q = 0; q < NS; q++) if (q == sj) { dl = sDl[q]; du = sDu[q]; rsl = sRl[q]; rsu = sRu[q]; }
+                const double il = dl != 0.0 ? 1.0 / dl : 0.0, iu = du != 0.0 ? 1.0 / du : 0.0;
+                const double nu_ = rl - ru - gl * rsl * il + gu * rsu * iu;
+                const double gm = gl + gu;
+                if (j < n)
+                {
+                    gadd[j < n ? j : 0] += nu_;
+                    if (FACT) M[PK((j < n ? j : 0), (j < n ? j : 0))] += gm;
+                }
+                else
+                {
+                    double arow[n];
+                    UNROLL for (int r = 0; r < n; r++) arow[r] = GAT(D.DCt, (S.o_g + (j - n)) * n + r);
+                    UNROLL for (int r = 0; r < n; r++) gadd[r] += arow[r] * nu_;
+                    if (FACT)
+                    {
+                        UNROLL for (int r = 0; r < n; r++)
+                            UNROLL for (int c = 0; c <= r; c++) M[PK(r, c)] += gm * arow[r] * arow[c];
+                    }
+                }
+            }
+            /* pass 3: rank-one corrections  M -= wl wl'/Dl + wu wu'/Du  per slack */
+            if (FACT)
+            {
+                for (int q = 0; q < S.ns; q++)
+                {
+                    double wl[n], wu[n];
+                    UNROLL for (int r = 0; r < n; r++) wl[r] = wu[r] = 0.0;
+                    int ib2 = 0;
+                    UNROLL for (int j = 0; j < n + NG; j++)
+                    {
+                        const bool is_row = j < n ? ((S.bmask >> j) & 1) : (j - n < S.ng);
+                        if (!is_row) continue;
+                        const int row = j < n ? ib2 : S.nb + (j - n);
+                        if (j < n) ib2++;
+                        if (S.srev[row] != q) continue;
+                        const int el = S.o_ct + row, eu = el + nbg;
+                        const bool al = (am >> row) & 1, au = (am >> (nbg + row)) & 1;
+                        const double gl = al ? GAT(D.lam, el) / GAT(D.t, el) : 0.0;
+                        const double gu = au ? GAT(D.lam, eu) / GAT(D.t, eu) : 0.0;
+                        if (j < n) { wl[j < n ? j : 0] += gl; wu[j < n ? j : 0] += gu; }
+                        else
+                        {
+                            UNROLL for (int r = 0; r < n; r++)
+                            {
+                                const double a = GAT(D.DCt, (S.o_g + (j - n)) * n + r);
+                                wl[r] += gl * a; wu[r] += gu * a;
+                            }
+                        }
+                    }
+                    double dl = 0.0, du = 0.0;
+                    UNROLL for (int qq = 0; qq < NS; qq++) if (qq == q) { dl = sDl[qq]; du = sDu[qq]; }
+                    const double il = dl != 0.0 ? 1.0 / dl : 0.0, iu = du != 0.0 ? 1.0 / du : 0.0;
+                    UNROLL for (int r = 0; r < n; r++)
+                        UNROLL for (int c = 0; c <= r; c++) M[PK(r, c)] -= wl[r] * wl[c] * il + wu[r] * wu[c] * iu;
+                }
+            }
+        }
+
+        /* ---- m = gt + gadd + BAt y ; fixed variables ; Cholesky ; l = L^{-1} m ---- */
+        UNROLL for (int j = 0; j < n; j++) gt[j] += gadd[j];
+        if (S.has_dyn)
+        {
+            UNROLL for (int r = 0; r < n; r++)
+            {
+                double a = 0.0;
+                UNROLL for (int c = 0; c < NX; c++) a += GAT(D.BAt, (k * n + r) * NX + c) * y[c];
+                gt[r] += a;
+            }
+        }
+        UNROLL for (int j = 0; j < n; j++) if ((S.emask >> j) & 1) gt[j] = 0.0;
+        if (FACT)
+        {
+            if (S.emask)
+            {
+                UNROLL for (int r = 0; r < n; r++)
+                    UNROLL for (int c = 0; c <= r; c++)
+                        if (((S.emask >> r) & 1) || ((S.emask >> c) & 1)) M[PK(r, c)] = (r == c) ? 1.0 : 0.0;
+            }
+            /* in-place Cholesky, right-looking; non-positive pivots zero the column
+             * (BLASFEO reference dpotrf behaviour, as restated in the oracle) */
+            UNROLL for (int jc = 0; jc < n; jc++)
+            {
+                double d = M[PK(jc, jc)];
+                double inv;
+                if (d > 0.0) { d = sqrt(d); inv = 1.0 / d; } else { d = 0.0; inv = 0.0; }
+                M[PK(jc, jc)] = d;
+                UNROLL for (int r = jc + 1; r < n; r++) M[PK(r, jc)] *= inv;
+                UNROLL for (int c = jc + 1; c < n; c++)
+                    UNROLL for (int r = c; r < n; r++) M[PK(r, c)] -= M[PK(r, jc)] * M[PK(c, jc)];
+            }
+            UNROLL for (int e = 0; e < NP; e++) GAT(D.Lf, k * NP + e) = M[e];
+        }
+        UNROLL for (int r = 0; r < n; r++)
+        {
+            double a = gt[r];
+            UNROLL for (int c = 0; c < r; c++) a -= M[PK(r, c)] * gt[c];
+            const double d = M[PK(r, r)];
+            gt[r] = d != 0.0 ? a / d : 0.0;
+            GAT(D.lf, k * n + r) = gt[r];
+        }
+        UNROLL for (int r = 0; r < NX; r++)
+        {
+            lx[r] = gt[NU + r];
+            UNROLL for (int c = 0; c <= r; c++) Lx[PK(r, c)] = M[PK(NU + r, NU + c)];
+        }
+    }
+
+    if (FACT)
+    {
+        const double mu = nact > 0 ? musum / nact : 0.0;
+        D.mu[i] = mu;
+        D.obj[i] = obj;
+        D.res[0 * Bp + i] = nrm_g; D.res[1 * Bp + i] = nrm_b; D.res[2 * Bp + i] = nrm_d; D.res[3 * Bp + i] = nrm_m;
+        const int it = D.iter[i];
+        if (i < D.stat_inst && it < D.stat_rows)
+        {
+            double *st = D.stat + (size_t) it * GQP_STAT_COLS * D.stat_inst + i;
+            st[6 * D.stat_inst] = mu;
+            st[7 * D.stat_inst] = nrm_g; st[8 * D.stat_inst] = nrm_b; st[9 * D.stat_inst] = nrm_d; st[10 * D.stat_inst] = nrm_m;
+            st[12 * D.stat_inst] = obj;
+        }
+        int status = GQP_RUNNING;
+        const bool bad = nrm_g != nrm_g || nrm_b != nrm_b || nrm_d != nrm_d || nrm_m != nrm_m || mu != mu;
+        if (bad) status = 1;                                   /* ACADOS_NAN_DETECTED */
+        else if (nrm_g <= O.tol_stat && nrm_b <= O.tol_eq && nrm_d <= O.tol_ineq && nrm_m <= O.tol_comp) status = 0;
+        else if (it >= O.iter_max) status = 2;                 /* ACADOS_MAXITER */
+        else if (dabs(D.alpha[i]) <= O.alpha_min) status = 3;  /* ACADOS_MINSTEP */
+        if (status != GQP_RUNNING)
+        {
+            D.status[i] = status;
+            atomicSub(D.n_active, 1);
+        }
+    }
+}
+
+/* ---------------------------------------------------------- k_forward */
+
+/*
+ * Forward sweep k = 0..N: dux, dpi, dsv, dt, dlam and the step length.
+ * CORR = false: affine direction; ends with mu_aff, sigma (-> smu = sigma*mu).
+ * CORR = true : corrected direction; ends with the update of (ux, sv, pi, lam, t).
+ */
+template <int NX, int NU, int NG, int NS, bool CORR>
+__global__ void __launch_bounds__(64) k_forward(GqpDev D, GqpOpts O, int redo)
+{
+    constexpr int n = NX + NU;
+    constexpr int NP = n * (n + 1) / 2;
+    const int Bp = D.Bp;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D.B) return;
+    if (D.status[i] != GQP_RUNNING) return;
+
+    if (redo && !(D.alpha[i] < 0.0)) return;
+    const double smu = CORR ? D.smu[i] : 0.0;
+    const bool center_only = CORR && redo;
+    double alpha = 1.0;
+    double dx[NX];
+    UNROLL for (int c = 0; c < NX; c++) dx[c] = 0.0;
+
+    for (int k = 0; k <= D.N; k++)
+    {
+        const GqpStage &S = D.st[k];
+        const int nbg = S.nb + S.ng;
+        const uint64_t am = GAT(D.amask, k);
+        double L[NP], l[n], dv[n];
+        UNROLL for (int e = 0; e < NP; e++) L[e] = GAT(D.Lf, k * NP + e);
+        UNROLL for (int j = 0; j < n; j++) l[j] = GAT(D.lf, k * n + j);
+        if (k > 0)
+        {
+            /* dpi_k = Lx (Lx' dx + lx) with the x-block of this stage's factor */
+            double w0[NX];
+            UNROLL for (int c = 0; c < NX; c++)
+            {
+                double a = l[NU + c];
+                UNROLL for (int q = c; q < NX; q++) a += L[PK(NU + q, NU + c)] * dx[q];
+                w0[c] = a;
+            }
+            UNROLL for (int r = 0; r < NX; r++)
+            {
+                double a = 0.0;
+                UNROLL for (int c = 0; c <= r; c++) a += L[PK(NU + r, NU + c)] * w0[c];
+                GAT(D.dpi, (k - 1) * NX + r) = a;
+            }
+            UNROLL for (int c = 0; c < NX; c++) dv[NU + c] = dx[c];
+        }
+        /* solve L' dv = -(l + ...) for the free block: all of [u;x] at k = 0, u otherwise */
+        if (k == 0)
+        {
+            UNROLL for (int r = n - 1; r >= 0; r--)
+            {
+                double a = -l[r];
+                UNROLL for (int p = r + 1; p < n; p++) a -= L[PK(p, r)] * dv[p];
+                const double d = L[PK(r, r)];
+                dv[r] = d != 0.0 ? a / d : 0.0;
+            }
+        }
+        else
+        {
+            UNROLL for (int r = NU - 1; r >= 0; r--)
+            {
+                double a = -l[r];
+                UNROLL for (int p = r + 1; p < n; p++) a -= L[PK(p, r)] * dv[p];
+                const double d = L[PK(r, r)];
+                dv[r] = d != 0.0 ? a / d : 0.0;
+            }
+        }
+        UNROLL for (int j = 0; j < n; j++) GAT(D.dux, k * n + j) = dv[j];
+        if (S.has_dyn)
+        {
+            UNROLL for (int c = 0; c < NX; c++) dx[c] = GAT(D.rb, k * NX + c);
+            UNROLL for (int r = 0; r < n; r++)
+                UNROLL for (int c = 0; c < NX; c++) dx[c] += GAT(D.BAt, (k * n + r) * NX + c) * dv[r];
+        }
+
+        /* ---- inequality rows: dc -> dsl/dsu -> dt -> dlam, step length ---- */
+        constexpr int NSS = NS > 0 ? NS : 1;
+        double dsl[NSS], dsu[NSS];
+        if (NS > 0)
+        {
+            /* dsl_j = (-r~sl_j - sum_i Gamma_l,i dc_i)/Dl_j ; dsu_j = (-r~su_j + sum_i Gamma_u,i dc_i)/Du_j */
+            double accl[NSS], accu[NSS];
+            UNROLL for (int q = 0; q < NS; q++) accl[q] = accu[q] = 0.0;
+            int ib = 0;
+            UNROLL for (int j = 0; j < n + NG; j++)
+            {
+                const bool is_row = j < n ? ((S.bmask >> j) & 1) : (j - n < S.ng);
+                if (!is_row) continue;
+                const int row = j < n ? ib : S.nb + (j - n);
+                if (j < n) ib++;
+                const int sj = S.srev[row];
+                if (sj < 0) continue;
+                double dc;
+                if (j < n) dc = dv[j < n ? j : 0];
+                else { dc = 0.0; UNROLL for (int r = 0; r < n; r++) dc += GAT(D.DCt, (S.o_g + (j - n)) * n + r) * dv[r]; }
+                const int el = S.o_ct + row, eu = el + nbg;
+                const bool al = (am >> row) & 1, au = (am >> (nbg + row)) & 1;
+                const double gl = al ? GAT(D.lam, el) / GAT(D.t, el) : 0.0;
+                const double gu = au ? GAT(D.lam, eu) / GAT(D.t, eu) : 0.0;
+                UNROLL for (int q = 0; q < NS; q++) if (q == sj) { accl[q] += gl * dc; accu[q] += gu * dc; }
+            }
+            UNROLL for (int q = 0; q < NS; q++)
+            {
+                dsl[q] = dsu[q] = 0.0;
+                if (q < S.ns)
+                {
+                    const double dl = GAT(D.sD, S.o_s + q), du = GAT(D.sD, S.o_s + S.ns + q);
+                    const double rsl = GAT(D.sR, S.o_s + q), rsu = GAT(D.sR, S.o_s + S.ns + q);
+                    dsl[q] = dl != 0.0 ? (-rsl - accl[q]) / dl : 0.0;
+                    dsu[q] = du != 0.0 ? (-rsu + accu[q]) / du : 0.0;
+                    GAT(D.dsv, S.o_s + q) = dsl[q];
+                    GAT(D.dsv, S.o_s + S.ns + q) = dsu[q];
+                    /* slack-bound rows */
+                    const int e0 = S.o_ct + 2 * nbg + q, e1 = e0 + S.ns;
+                    const bool al = (am >> (2 * nbg + q)) & 1, au = (am >> (2 * nbg + S.ns + q)) & 1;
+                    double rml = GAT(D.rm, e0), rmu = GAT(D.rm, e1);
+                    if (CORR)
+                    {
+                        if (al) rml += (center_only ? 0.0 : GAT(D.dlam, e0) * GAT(D.dt, e0)) - smu;
+                        if (au) rmu += (center_only ? 0.0 : GAT(D.dlam, e1) * GAT(D.dt, e1)) - smu;
+                    }
+                    const double laml = GAT(D.lam, e0), lamu = GAT(D.lam, e1), tl = GAT(D.t, e0), tu = GAT(D.t, e1);
+                    const double dtl = al ? dsl[q] + GAT(D.rd, e0) : 0.0, dtu = au ? dsu[q] + GAT(D.rd, e1) : 0.0;
+                    const double dll = al ? -(rml + laml * dtl) / tl : 0.0, dlu = au ? -(rmu + lamu * dtu) / tu : 0.0;
+                    GAT(D.dt, e0) = dtl; GAT(D.dt, e1) = dtu;
+                    GAT(D.dlam, e0) = dll; GAT(D.dlam, e1) = dlu;
+                    if (dll < 0.0 && -laml > alpha * dll) alpha = -laml / dll;
+                    if (dlu < 0.0 && -lamu > alpha * dlu) alpha = -lamu / dlu;
+                    if (dtl < 0.0 && -tl > alpha * dtl) alpha = -tl / dtl;
+                    if (dtu < 0.0 && -tu > alpha * dtu) alpha = -tu / dtu;
+                }
+            }
+        }
+        {
+            int ib = 0;
+            UNROLL for (int j = 0; j < n + NG; j++)
+            {
+                const bool is_row = j < n ? ((S.bmask >> j) & 1) : (j - n < S.ng);
+                if (!is_row) continue;
+                const int row = j < n ? ib : S.nb + (j - n);
+                if (j < n) ib++;
+                const int el = S.o_ct + row, eu = el + nbg;
+                const bool al = (am >> row) & 1, au = (am >> (nbg + row)) & 1;
+                if (!al && !au) { GAT(D.dt, el) = 0.0; GAT(D.dt, eu) = 0.0; GAT(D.dlam, el) = 0.0; GAT(D.dlam, eu) = 0.0; continue; }
+                double dc;
+                if (j < n) dc = dv[j < n ? j : 0];
+                else { dc = 0.0; UNROLL for (int r = 0; r < n; r++) dc += GAT(D.DCt, (S.o_g + (j - n)) * n + r) * dv[r]; }
+                double ddsl = 0.0, ddsu = 0.0;
+                if (NS > 0)
+                {
+                    const int sj = S.srev[row];
+                    UNROLL for (int q = 0; q < NS; q++) if (q == sj) { ddsl = dsl[q]; ddsu = dsu[q]; }
+                }
+                double rml = GAT(D.rm, el), rmu = GAT(D.rm, eu);
+                if (CORR)
+                {
+                    if (al) rml += (center_only ? 0.0 : GAT(D.dlam, el) * GAT(D.dt, el)) - smu;
+                    if (au) rmu += (center_only ? 0.0 : GAT(D.dlam, eu) * GAT(D.dt, eu)) - smu;
+                }
+                const double laml = al ? GAT(D.lam, el) : 0.0, lamu = au ? GAT(D.lam, eu) : 0.0;
+                const double tl = al ? GAT(D.t, el) : 1.0, tu = au ? GAT(D.t, eu) : 1.0;
+                const double dtl = al ? dc + ddsl + GAT(D.rd, el) : 0.0;
+                const double dtu = au ? -dc + ddsu + GAT(D.rd, eu) : 0.0;
+                const double dll = al ? -(rml + laml * dtl) / tl : 0.0;
+                const double dlu = au ? -(rmu + lamu * dtu) / tu : 0.0;
+                GAT(D.dt, el) = dtl; GAT(D.dt, eu) = dtu;
+                GAT(D.dlam, el) = dll; GAT(D.dlam, eu) = dlu;
+                if (dll < 0.0 && -laml > alpha * dll) alpha = -laml / dll;
+                if (dlu < 0.0 && -lamu > alpha * dlu) alpha = -lamu / dlu;
+                if (dtl < 0.0 && -tl > alpha * dtl) alpha = -tl / dtl;
+                if (dtu < 0.0 && -tu > alpha * dtu) alpha = -tu / dtu;
+            }
+        }
+    }
+
+    const int it = D.iter[i];
+    double *st = (i < D.stat_inst && it + 1 < D.stat_rows) ? D.stat + (size_t) (it + 1) * GQP_STAT_COLS * D.stat_inst + i : nullptr;
+    if (!CORR)
+    {
+        /* mu_aff and sigma = (mu_aff/mu)^3 */
+        double s = 0.0;
+        int nact = 0;
+        for (int k = 0; k <= D.N; k++)
+        {
+            const GqpStage &S = D.st[k];
+            const int nct = 2 * (S.nb + S.ng) + 2 * S.ns;
+            const uint64_t am = GAT(D.amask, k);
+            for (int e = 0; e < nct; e++)
+                if ((am >> e) & 1)
+                {
+                    s += (GAT(D.lam, S.o_ct + e) + alpha * GAT(D.dlam, S.o_ct + e)) * (GAT(D.t, S.o_ct + e) + alpha * GAT(D.dt, S.o_ct + e));
+                    nact++;
+                }
+        }
+        const double mu = D.mu[i];
+        const double mu_aff = nact > 0 ? s / nact : 0.0;
+        double sigma = mu > 0.0 ? mu_aff / mu : 0.0;
+        sigma = sigma * sigma * sigma;
+        D.smu[i] = sigma * mu;
+        D.alpha[i] = alpha; /* alpha_aff, read by the cond_pred_corr test */
+        if (st) { st[0] = alpha; st[1 * D.stat_inst] = alpha; st[2 * D.stat_inst] = mu_aff; st[3 * D.stat_inst] = sigma; }
+    }
+    else
+    {
+        const double alpha_aff = dabs(D.alpha[i]);
+        if (O.cond_pred_corr && !redo && alpha < 0.1 * alpha_aff)
+        {
+            /* corrector collapsed: ask the host loop for a centering-only re-solve
+             * (flag = negative alpha); no update this pass */
+            D.alpha[i] = -alpha_aff;
+            return;
+        }
+        const double a = alpha * 0.995;
+        for (int k = 0; k <= D.N; k++)
+        {
+            const GqpStage &S = D.st[k];
+            const int nct = 2 * (S.nb + S.ng) + 2 * S.ns;
+            const uint64_t am = GAT(D.amask, k);
+            UNROLL for (int j = 0; j < n; j++) GAT(D.ux, k * n + j) += a * GAT(D.dux, k * n + j);
+            if (S.has_dyn) { UNROLL for (int c = 0; c < NX; c++) GAT(D.pi, k * NX + c) += a * GAT(D.dpi, k * NX + c); }
+            for (int q = 0; q < 2 * S.ns; q++) GAT(D.sv, S.o_s + q) += a * GAT(D.dsv, S.o_s + q);
+            for (int e = 0; e < nct; e++)
+                if ((am >> e) & 1)
+                {
+                    double lam = GAT(D.lam, S.o_ct + e) + a * GAT(D.dlam, S.o_ct + e);
+                    double t = GAT(D.t, S.o_ct + e) + a * GAT(D.dt, S.o_ct + e);
+                    GAT(D.lam, S.o_ct + e) = lam < O.lam_min ? O.lam_min : lam;
+                    GAT(D.t, S.o_ct + e) = t < O.t_min ? O.t_min : t;
+                }
+        }
+        D.alpha[i] = alpha;
+        D.iter[i] = it + 1;
+        if (st) { st[4 * D.stat_inst] = alpha; st[5 * D.stat_inst] = alpha; }
+    }
+}
+
+/* ----------------------------------------------------------- finalize */
+
+/* natural slack value for rows that did not take part (masked sides); restates
+ * ocp_qp_compute_t (acados/ocp_qp/ocp_qp_common.c:874-921) for those rows only */
+template <int NX, int NU, int NG, int NS>
+__global__ void __launch_bounds__(64) k_finalize(GqpDev D)
+{
+    constexpr int n = NX + NU;
+    const int Bp = D.Bp;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D.B) return;
+    for (int k = 0; k <= D.N; k++)
+    {
+        const GqpStage &S = D.st[k];
+        const int nbg = S.nb + S.ng;
+        const uint64_t am = GAT(D.amask, k);
+        double v[n];
+        UNROLL for (int j = 0; j < n; j++) v[j] = GAT(D.ux, k * n + j);
+        int ib = 0;
+        UNROLL for (int j = 0; j < n + NG; j++)
+        {
+            const bool is_row = j < n ? ((S.bmask >> j) & 1) : (j - n < S.ng);
+            if (!is_row) continue;
+            const int row = j < n ? ib : S.nb + (j - n);
+            if (j < n) ib++;
+            const bool al = (am >> row) & 1, au = (am >> (nbg + row)) & 1;
+            if (al && au) continue;
+            double c;
+            if (j < n) c = v[j < n ? j : 0];
+            else { c = 0.0; UNROLL for (int r = 0; r < n; r++) c += GAT(D.DCt, (S.o_g + (j - n)) * n + r) * v[r]; }
+            double ssl = 0.0, ssu = 0.0;
+            if (NS > 0)
+            {
+                const int sj = S.srev[row];
+                if (sj >= 0) { ssl = GAT(D.sv, S.o_s + sj); ssu = GAT(D.sv, S.o_s + S.ns + sj); }
+            }
+            const bool fixed = j < n && ((S.emask >> (j < n ? j : 0)) & 1);
+            if (!al)
+            {
+                GAT(D.t, S.o_ct + row) = c + ssl - GAT(D.dvec, S.o_ct + row);
+                if (!fixed) GAT(D.lam, S.o_ct + row) = 0.0;
+            }
+            if (!au)
+            {
+                GAT(D.t, S.o_ct + nbg + row) = GAT(D.dvec, S.o_ct + nbg + row) - c + ssu;
+                if (!fixed) GAT(D.lam, S.o_ct + nbg + row) = 0.0;
+            }
+        }
+        for (int q = 0; q < S.ns; q++)
+        {
+            const int e0 = S.o_ct + 2 * nbg + q, e1 = e0 + S.ns;
+            if (!((am >> (2 * nbg + q)) & 1)) { GAT(D.t, e0) = GAT(D.sv, S.o_s + q) - GAT(D.dvec, e0); GAT(D.lam, e0) = 0.0; }
+            if (!((am >> (2 * nbg + S.ns + q)) & 1)) { GAT(D.t, e1) = GAT(D.sv, S.o_s + S.ns + q) - GAT(D.dvec, e1); GAT(D.lam, e1) = 0.0; }
+        }
+    }
+}
+
+/* -------------------------------------------- layout conversion kernels */
+
+/* dst[(map[e]) * Bp + i] = src[i * len + e]  (map[e] < 0: element dropped) */
+__global__ void k_scatter(const double *src, int nb, int len, const int *map, double *dst, int Bp)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nb) return;
+    for (int e = 0; e < len; e++)
+    {
+        const int m = map[e];
+        if (m >= 0) dst[(size_t) m * Bp + i] = src[(size_t) i * len + e];
+    }
+}
+
+/* dst[i * len + e] = src[(map[e]) * Bp + i]  (map[e] < 0: 0) */
+__global__ void k_gather(double *dst, int nb, int len, const int *map, const double *src, int Bp)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nb) return;
+    for (int e = 0; e < len; e++)
+    {
+        const int m = map[e];
+        dst[(size_t) i * len + e] = m >= 0 ? src[(size_t) m * Bp + i] : 0.0;
+    }
+}
+
+/* activity bit masks: for every element e of a (lower|upper|slack) mask vector handed
+ * over by the caller, set or clear bit bitpos[e] of amask[stage] */
+__global__ void k_setmask(const double *src, int nb, int len, const int *bitpos, uint64_t *amask_stage)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nb) return;
+    uint64_t m = amask_stage[i];
+    for (int e = 0; e < len; e++)
+    {
+        const int b = bitpos[e];
+        if (b < 0) continue;
+        if (src[(size_t) i * len + e] != 0.0) m |= (uint64_t) 1 << b;
+        else m &= ~((uint64_t) 1 << b);
+    }
+    amask_stage[i] = m;
+}
+
+__global__ void k_fill_u64(uint64_t *dst, uint64_t val, size_t cnt)
+{
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < cnt) dst[i] = val;
+}
+
+__global__ void k_fill_strided(double *dst, double val, int nb, int Bp, int e)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nb) dst[(size_t) e * Bp + i] = val;
+}
+
+} // namespace gqp
+
+#endif

@@ -1,0 +1,903 @@
+/*
+ * ocp_qp_host.cpp -- acados-shaped host API (include/acados_amd/ocp_qp_interface.h) on top
+ * of the device batch C-ABI.  Host code only: no kernels here.  Each function cites the
+ * reference function whose contract it follows (paths relative to /root/reference).
+ */
+#include "acados_amd/ocp_qp_interface.h"
+
+#include <chrono>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+#include "acados_amd/ocp_qp_gpu_batch.h"
+
+namespace
+{
+
+inline char *align8(char *p) { return (char *) (((uintptr_t) p + 7) & ~(uintptr_t) 7); }
+
+struct gpu_ipm_opts
+{
+    /* names as d_ocp_qp_ipm_arg_set / ocp_qp_hpipm_opts_set (ocp_qp_hpipm.c:142-183) */
+    double mu0, tol_stat, tol_eq, tol_ineq, tol_comp, alpha_min, tau_min, reg_prim, t0_min, lam0_min;
+    int iter_max, warm_start, cond_pred_corr, print_level, ric_alg, t0_init, update_fact_exit;
+};
+
+struct batch_cache
+{
+    ocp_qp_gpu_batch *batch = nullptr;
+    int n = 0;
+    std::vector<int> sig; /* dims + idxb + idxs_rev + idxe of the batch */
+    std::vector<double> stat;
+    std::vector<double> stage; /* host staging [n][len] */
+};
+
+struct gpu_ipm_memory
+{
+    batch_cache *cache;
+    double time_qp_solver_call;
+    int iter;
+    int status;
+    int stat_m;
+};
+
+double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+int vlen(const ocp_qp_dims *d, const char *f, int k)
+{
+    const int N = d->N, nx = d->nx[k], nu = d->nu[k], nx1 = k < N ? d->nx[k + 1] : 0;
+    if (!strcmp(f, "A")) return nx1 * nx;
+    if (!strcmp(f, "B")) return nx1 * nu;
+    if (!strcmp(f, "b")) return nx1;
+    if (!strcmp(f, "Q")) return nx * nx;
+    if (!strcmp(f, "S")) return nu * nx;
+    if (!strcmp(f, "R")) return nu * nu;
+    if (!strcmp(f, "q")) return nx;
+    if (!strcmp(f, "r")) return nu;
+    if (!strcmp(f, "C")) return d->ng[k] * nx;
+    if (!strcmp(f, "D")) return d->ng[k] * nu;
+    return -1;
+}
+
+std::vector<int> structure_sig(const ocp_qp_in *in)
+{
+    const ocp_qp_dims *d = in->dim;
+    std::vector<int> s;
+    s.push_back(d->N);
+    for (int k = 0; k <= d->N; k++)
+    {
+        int v[] = {d->nx[k], d->nu[k], d->nbx[k], d->nbu[k], d->ng[k], d->ns[k], d->nbxe[k]};
+        s.insert(s.end(), v, v + 7);
+        s.insert(s.end(), in->idxb[k], in->idxb[k] + d->nb[k]);
+        s.insert(s.end(), in->idxs_rev[k], in->idxs_rev[k] + d->nb[k] + d->ng[k]);
+        s.insert(s.end(), in->idxe[k], in->idxe[k] + d->nbxe[k]);
+    }
+    return s;
+}
+
+} // namespace
+
+extern "C" {
+
+/* ------------------------------------------------------------------ dims */
+/* ocp_qp_common.c:100-180 */
+
+acados_size_t ocp_qp_dims_calculate_size(int N) { return sizeof(ocp_qp_dims) + 10 * (N + 1) * sizeof(int) + 16; }
+
+ocp_qp_dims *ocp_qp_dims_assign(int N, void *raw_memory)
+{
+    char *c = (char *) raw_memory;
+    ocp_qp_dims *d = (ocp_qp_dims *) c;
+    c = align8(c + sizeof(ocp_qp_dims));
+    int **arr[] = {&d->nx, &d->nu, &d->nb, &d->nbx, &d->nbu, &d->ng, &d->ns, &d->nbxe, &d->nbue, &d->nge};
+    for (int q = 0; q < 10; q++)
+    {
+        *arr[q] = (int *) c;
+        memset(c, 0, sizeof(int) * (N + 1));
+        c += sizeof(int) * (N + 1);
+    }
+    d->N = N;
+    return d;
+}
+
+ocp_qp_dims *ocp_qp_dims_create(int N) { return ocp_qp_dims_assign(N, calloc(1, ocp_qp_dims_calculate_size(N))); }
+void ocp_qp_dims_free(void *d) { free(d); }
+
+void ocp_qp_dims_set(void *config_, void *dims_, int stage, const char *field, int *value)
+{
+    ocp_qp_dims *d = (ocp_qp_dims *) dims_;
+    int *dst = nullptr;
+    if (!strcmp(field, "nx")) dst = d->nx;
+    else if (!strcmp(field, "nu")) dst = d->nu;
+    else if (!strcmp(field, "nbx")) dst = d->nbx;
+    else if (!strcmp(field, "nbu")) dst = d->nbu;
+    else if (!strcmp(field, "ng")) dst = d->ng;
+    else if (!strcmp(field, "ns")) dst = d->ns;
+    else if (!strcmp(field, "nbxe")) dst = d->nbxe;
+    else if (!strcmp(field, "nbue")) dst = d->nbue;
+    else if (!strcmp(field, "nge")) dst = d->nge;
+    else
+    {
+        printf("\nerror: ocp_qp_dims_set: field %s not available\n", field);
+        exit(1);
+    }
+    dst[stage] = *value;
+    d->nb[stage] = d->nbx[stage] + d->nbu[stage];
+}
+
+void ocp_qp_dims_get(void *config_, void *dims_, int stage, const char *field, int *value)
+{
+    ocp_qp_dims *d = (ocp_qp_dims *) dims_;
+    if (!strcmp(field, "nx")) *value = d->nx[stage];
+    else if (!strcmp(field, "nu")) *value = d->nu[stage];
+    else if (!strcmp(field, "nbx")) *value = d->nbx[stage];
+    else if (!strcmp(field, "nbu")) *value = d->nbu[stage];
+    else if (!strcmp(field, "nb")) *value = d->nb[stage];
+    else if (!strcmp(field, "ng")) *value = d->ng[stage];
+    else if (!strcmp(field, "ns")) *value = d->ns[stage];
+    else if (!strcmp(field, "nbxe")) *value = d->nbxe[stage];
+    else if (!strcmp(field, "nbue")) *value = d->nbue[stage];
+    else if (!strcmp(field, "nge")) *value = d->nge[stage];
+    else
+    {
+        printf("\nerror: ocp_qp_dims_get: field %s not available\n", field);
+        exit(1);
+    }
+}
+
+/* -------------------------------------------------------------------- in */
+/* ocp_qp_common.c:189-211 (one block, bump assignment, 8-byte alignment asserted) */
+
+static size_t in_walk(ocp_qp_dims *d, ocp_qp_in *in_or_null, char *base)
+{
+    const int N = d->N, NS = N + 1;
+    char *c = base;
+    ocp_qp_in sizing_only;              /* size computation walks a scratch struct */
+    const bool in = in_or_null != nullptr;
+    ocp_qp_in *w = in ? in_or_null : &sizing_only;
+    auto tabs_d = [&](double ***t) { if (in) *t = (double **) c; c += sizeof(double *) * NS; };
+    auto tabs_i = [&](int ***t) { if (in) *t = (int **) c; c += sizeof(int *) * NS; };
+    double ***dt[] = {&w->A, &w->B, &w->b, &w->Q, &w->S, &w->R, &w->q, &w->r, &w->lb, &w->ub, &w->lb_mask,
+                      &w->ub_mask, &w->C, &w->D, &w->lg, &w->ug, &w->lg_mask, &w->ug_mask, &w->Zl, &w->Zu,
+                      &w->zl, &w->zu, &w->lls, &w->lus, &w->lls_mask, &w->lus_mask};
+    const int ndt = sizeof(dt) / sizeof(dt[0]);
+    int ***it[] = {&w->idxb, &w->idxs_rev, &w->idxe};
+    for (int q = 0; q < ndt; q++) tabs_d(dt[q]);
+    for (int q = 0; q < 3; q++) tabs_i(it[q]);
+    c = align8(c);
+    for (int k = 0; k <= N; k++)
+    {
+        const int nx = d->nx[k], nu = d->nu[k], nx1 = k < N ? d->nx[k + 1] : 0, nb = d->nb[k], ng = d->ng[k], ns = d->ns[k];
+        const int len[] = {nx1 * nx, nx1 * nu, nx1, nx * nx, nu * nx, nu * nu, nx, nu, nb, nb, nb, nb, ng * nx, ng * nu,
+                           ng, ng, ng, ng, ns, ns, ns, ns, ns, ns, ns, ns};
+        for (int q = 0; q < ndt; q++)
+        {
+            if (in)
+            {
+                (*dt[q])[k] = (double *) c;
+                const bool is_mask = q == 10 || q == 11 || q == 16 || q == 17 || q == 24 || q == 25;
+                for (int e = 0; e < len[q]; e++) ((double *) c)[e] = is_mask ? 1.0 : 0.0;
+            }
+            c += sizeof(double) * len[q];
+        }
+        const int ilen[] = {nb, nb + ng, nb};
+        for (int q = 0; q < 3; q++)
+        {
+            if (in) (*it[q])[k] = (int *) c;
+            c = align8(c + sizeof(int) * ilen[q]);
+        }
+        if (in)
+        {
+            for (int e = 0; e < d->nbu[k]; e++) w->idxb[k][e] = e;
+            for (int e = 0; e < d->nbx[k]; e++) w->idxb[k][d->nbu[k] + e] = nu + e;
+            for (int e = 0; e < nb + ng; e++) w->idxs_rev[k][e] = -1;
+            for (int e = 0; e < nb; e++) w->idxe[k][e] = 0;
+        }
+    }
+    return (size_t) (c - base);
+}
+
+acados_size_t ocp_qp_in_calculate_size(ocp_qp_dims *dims)
+{
+    return sizeof(ocp_qp_in) + 8 + in_walk(dims, nullptr, nullptr) + 8;
+}
+
+ocp_qp_in *ocp_qp_in_assign(ocp_qp_dims *dims, void *raw_memory)
+{
+    ocp_qp_in *in = (ocp_qp_in *) raw_memory;
+    in->dim = dims;
+    in_walk(dims, in, align8((char *) raw_memory + sizeof(ocp_qp_in)));
+    return in;
+}
+
+ocp_qp_in *ocp_qp_in_create(ocp_qp_dims *dims) { return ocp_qp_in_assign(dims, calloc(1, ocp_qp_in_calculate_size(dims))); }
+void ocp_qp_in_free(void *in) { free(in); }
+
+/* ocp_qp_interface.c:405-409 -> d_ocp_qp_set(field, stage, value, in) */
+void ocp_qp_in_set(void *config, ocp_qp_in *in, int k, char *field, void *value)
+{
+    const ocp_qp_dims *d = in->dim;
+    const char *f = field;
+    const int nbu = d->nbu[k], nbx = d->nbx[k], nb = d->nb[k], ng = d->ng[k], ns = d->ns[k], nu = d->nu[k];
+    auto cpd = [&](double *dst, int n) { memcpy(dst, value, sizeof(double) * n); };
+    auto cpi = [&](int *dst, int n) { memcpy(dst, value, sizeof(int) * n); };
+    int n;
+    if ((n = vlen(d, f, k)) >= 0)
+    {
+        double **tab = !strcmp(f, "A") ? in->A : !strcmp(f, "B") ? in->B : !strcmp(f, "b") ? in->b : !strcmp(f, "Q") ? in->Q
+                     : !strcmp(f, "S") ? in->S : !strcmp(f, "R") ? in->R : !strcmp(f, "q") ? in->q : !strcmp(f, "r") ? in->r
+                     : !strcmp(f, "C") ? in->C : in->D;
+        cpd(tab[k], n);
+    }
+    else if (!strcmp(f, "idxb")) cpi(in->idxb[k], nb);
+    else if (!strcmp(f, "idxbu")) cpi(in->idxb[k], nbu);
+    else if (!strcmp(f, "idxbx")) { const int *v = (const int *) value; for (int e = 0; e < nbx; e++) in->idxb[k][nbu + e] = nu + v[e]; }
+    else if (!strcmp(f, "lb")) cpd(in->lb[k], nb);
+    else if (!strcmp(f, "ub")) cpd(in->ub[k], nb);
+    else if (!strcmp(f, "lbu")) cpd(in->lb[k], nbu);
+    else if (!strcmp(f, "ubu")) cpd(in->ub[k], nbu);
+    else if (!strcmp(f, "lbx")) cpd(in->lb[k] + nbu, nbx);
+    else if (!strcmp(f, "ubx")) cpd(in->ub[k] + nbu, nbx);
+    else if (!strcmp(f, "lbu_mask")) cpd(in->lb_mask[k], nbu);
+    else if (!strcmp(f, "ubu_mask")) cpd(in->ub_mask[k], nbu);
+    else if (!strcmp(f, "lbx_mask")) cpd(in->lb_mask[k] + nbu, nbx);
+    else if (!strcmp(f, "ubx_mask")) cpd(in->ub_mask[k] + nbu, nbx);
+    else if (!strcmp(f, "lg")) cpd(in->lg[k], ng);
+    else if (!strcmp(f, "ug")) cpd(in->ug[k], ng);
+    else if (!strcmp(f, "lg_mask")) cpd(in->lg_mask[k], ng);
+    else if (!strcmp(f, "ug_mask")) cpd(in->ug_mask[k], ng);
+    else if (!strcmp(f, "Zl")) cpd(in->Zl[k], ns);
+    else if (!strcmp(f, "Zu")) cpd(in->Zu[k], ns);
+    else if (!strcmp(f, "zl")) cpd(in->zl[k], ns);
+    else if (!strcmp(f, "zu")) cpd(in->zu[k], ns);
+    else if (!strcmp(f, "lls")) cpd(in->lls[k], ns);
+    else if (!strcmp(f, "lus")) cpd(in->lus[k], ns);
+    else if (!strcmp(f, "lls_mask")) cpd(in->lls_mask[k], ns);
+    else if (!strcmp(f, "lus_mask")) cpd(in->lus_mask[k], ns);
+    else if (!strcmp(f, "idxs_rev")) cpi(in->idxs_rev[k], nb + ng);
+    else if (!strcmp(f, "idxe") || !strcmp(f, "idxbxe")) cpi(in->idxe[k], d->nbxe[k]);
+    else
+    {
+        printf("\nerror: ocp_qp_in_set: field %s not available\n", f);
+        exit(1);
+    }
+}
+
+/* ------------------------------------------------------------------- out */
+/* ocp_qp_common.c:234-260 */
+
+static size_t out_walk(ocp_qp_dims *d, ocp_qp_out *out, char *base)
+{
+    const int N = d->N;
+    char *c = base;
+    if (out) { out->ux = (double **) c; } c += sizeof(double *) * (N + 1);
+    if (out) { out->pi = (double **) c; } c += sizeof(double *) * (N + 1);
+    if (out) { out->lam = (double **) c; } c += sizeof(double *) * (N + 1);
+    if (out) { out->t = (double **) c; } c += sizeof(double *) * (N + 1);
+    c = align8(c);
+    for (int k = 0; k <= N; k++)
+    {
+        const int nv = d->nu[k] + d->nx[k] + 2 * d->ns[k], nx1 = k < N ? d->nx[k + 1] : 0;
+        const int nct = 2 * (d->nb[k] + d->ng[k] + d->ns[k]);
+        if (out) out->ux[k] = (double *) c; c += sizeof(double) * nv;
+        if (out) out->pi[k] = (double *) c; c += sizeof(double) * nx1;
+        if (out) out->lam[k] = (double *) c; c += sizeof(double) * nct;
+        if (out) out->t[k] = (double *) c; c += sizeof(double) * nct;
+    }
+    c = align8(c);
+    if (out) out->misc = c;
+    c += sizeof(qp_info);
+    return (size_t) (c - base);
+}
+
+acados_size_t ocp_qp_out_calculate_size(ocp_qp_dims *dims) { return sizeof(ocp_qp_out) + 8 + out_walk(dims, nullptr, nullptr) + 8; }
+
+ocp_qp_out *ocp_qp_out_assign(ocp_qp_dims *dims, void *raw_memory)
+{
+    ocp_qp_out *out = (ocp_qp_out *) raw_memory;
+    out->dim = dims;
+    out_walk(dims, out, align8((char *) raw_memory + sizeof(ocp_qp_out)));
+    return out;
+}
+
+ocp_qp_out *ocp_qp_out_create(ocp_qp_dims *dims) { return ocp_qp_out_assign(dims, calloc(1, ocp_qp_out_calculate_size(dims))); }
+void ocp_qp_out_free(void *out) { free(out); }
+
+/* ocp_qp_interface.c:435-480 */
+void ocp_qp_out_get(ocp_qp_out *out, int k, const char *field, void *value)
+{
+    const ocp_qp_dims *d = out->dim;
+    const int nu = d->nu[k], nx = d->nx[k], ns = d->ns[k];
+    double *v = (double *) value;
+    if (!strcmp(field, "qp_info")) *(qp_info **) value = (qp_info *) out->misc;
+    else if (!strcmp(field, "x")) memcpy(v, out->ux[k] + nu, sizeof(double) * nx);
+    else if (!strcmp(field, "u")) memcpy(v, out->ux[k], sizeof(double) * nu);
+    else if (!strcmp(field, "sl")) memcpy(v, out->ux[k] + nu + nx, sizeof(double) * ns);
+    else if (!strcmp(field, "su")) memcpy(v, out->ux[k] + nu + nx + ns, sizeof(double) * ns);
+    else if (!strcmp(field, "pi")) memcpy(v, out->pi[k], sizeof(double) * (k < d->N ? d->nx[k + 1] : 0));
+    else if (!strcmp(field, "lam")) memcpy(v, out->lam[k], sizeof(double) * 2 * (d->nb[k] + d->ng[k] + ns));
+    else if (!strcmp(field, "t")) memcpy(v, out->t[k], sizeof(double) * 2 * (d->nb[k] + d->ng[k] + ns));
+    else
+    {
+        printf("\nerror: ocp_qp_out_get: field %s not available\n", field);
+        exit(1);
+    }
+}
+
+/* ocp_qp_common.c:874-921, line by line on the plain containers */
+void ocp_qp_compute_t(ocp_qp_in *in, ocp_qp_out *out)
+{
+    const ocp_qp_dims *d = in->dim;
+    for (int k = 0; k <= d->N; k++)
+    {
+        const int nu = d->nu[k], nx = d->nx[k], nb = d->nb[k], ng = d->ng[k], ns = d->ns[k], nbg = nb + ng;
+        const double *ux = out->ux[k];
+        double *t = out->t[k];
+        for (int i = 0; i < nb; i++)
+        {
+            const double c = ux[in->idxb[k][i]];
+            t[i] = c - in->lb[k][i];
+            t[nbg + i] = in->ub[k][i] - c;
+        }
+        for (int g = 0; g < ng; g++)
+        {
+            double c = 0.0;
+            for (int j = 0; j < nu; j++) c += in->D[k][g + ng * j] * ux[j];
+            for (int j = 0; j < nx; j++) c += in->C[k][g + ng * j] * ux[nu + j];
+            t[nb + g] = c - in->lg[k][g];
+            t[nbg + nb + g] = in->ug[k][g] - c;
+        }
+        for (int i = 0; i < nbg; i++)
+        {
+            const int idx = in->idxs_rev[k][i];
+            if (idx != -1)
+            {
+                t[i] += ux[nu + nx + idx];
+                t[nbg + i] += ux[nu + nx + ns + idx];
+            }
+        }
+        for (int j = 0; j < ns; j++)
+        {
+            t[2 * nbg + j] = ux[nu + nx + j] - in->lls[k][j];
+            t[2 * nbg + ns + j] = ux[nu + nx + ns + j] - in->lus[k][j];
+        }
+    }
+}
+
+/* ------------------------------------------------- inner plugin (vtable) */
+/* ocp_qp_hpipm.c:60-540 */
+
+acados_size_t ocp_qp_gpu_ipm_opts_calculate_size(void *config, void *dims) { return sizeof(gpu_ipm_opts) + 8; }
+
+void *ocp_qp_gpu_ipm_opts_assign(void *config, void *dims, void *raw_memory) { return align8((char *) raw_memory); }
+
+void ocp_qp_gpu_ipm_opts_initialize_default(void *config, void *dims, void *opts_)
+{
+    gpu_ipm_opts *o = (gpu_ipm_opts *) opts_;
+    /* mode BALANCE + the acados overrides of ocp_qp_hpipm.c:101-113 */
+    o->mu0 = 1e0; o->tol_stat = 1e-6; o->tol_eq = 1e-8; o->tol_ineq = 1e-8; o->tol_comp = 1e-8;
+    o->alpha_min = 1e-8; o->tau_min = 0.0; o->reg_prim = 1e-15; o->t0_min = 1e-16; o->lam0_min = 1e-16;
+    o->iter_max = 50; o->warm_start = 0; o->cond_pred_corr = 1; o->print_level = 0; o->ric_alg = 1;
+    o->t0_init = 2; o->update_fact_exit = 0;
+}
+
+void ocp_qp_gpu_ipm_opts_update(void *config, void *dims, void *opts) {}
+
+void ocp_qp_gpu_ipm_opts_set(void *config, void *opts_, const char *field, void *value)
+{
+    gpu_ipm_opts *o = (gpu_ipm_opts *) opts_;
+    const double *d = (const double *) value;
+    const int *i = (const int *) value;
+    if (!strcmp(field, "hpipm_mode"))
+    {
+        const char *mode = (const char *) value;
+        if (strcmp(mode, "BALANCE") && strcmp(mode, "SPEED") && strcmp(mode, "SPEED_ABS") && strcmp(mode, "ROBUST"))
+        {
+            printf("ocp_qp_gpu_ipm_opts_set: got non-supported mode %s\n", mode);
+            exit(1);
+        }
+        /* a mode change re-applies the acados overrides (ocp_qp_hpipm.c:146-165) */
+        const int pl = o->print_level;
+        ocp_qp_gpu_ipm_opts_initialize_default(config, nullptr, o);
+        o->print_level = pl;
+    }
+    else if (!strcmp(field, "print_level")) o->print_level = *i;
+    else if (!strcmp(field, "tau_min")) o->tau_min = *d;
+    else if (!strcmp(field, "iter_max")) o->iter_max = *i;
+    else if (!strcmp(field, "tol_stat")) o->tol_stat = *d;
+    else if (!strcmp(field, "tol_eq")) o->tol_eq = *d;
+    else if (!strcmp(field, "tol_ineq")) o->tol_ineq = *d;
+    else if (!strcmp(field, "tol_comp")) o->tol_comp = *d;
+    else if (!strcmp(field, "warm_start")) o->warm_start = *i;
+    else if (!strcmp(field, "mu0")) { if (*d > 0.0) o->mu0 = *d; }
+    else if (!strcmp(field, "t0_init")) o->t0_init = *i;
+    else if (!strcmp(field, "ric_alg")) o->ric_alg = *i;
+    else if (!strcmp(field, "alpha_min")) o->alpha_min = *d;
+    else if (!strcmp(field, "reg_prim")) o->reg_prim = *d;
+    else if (!strcmp(field, "t0_min")) o->t0_min = *d;
+    else if (!strcmp(field, "lam0_min")) o->lam0_min = *d;
+    else if (!strcmp(field, "update_fact_exit")) o->update_fact_exit = *i;
+    else if (!strcmp(field, "cond_pred_corr")) o->cond_pred_corr = *i;
+    else
+    {
+        printf("\nerror: ocp_qp_gpu_ipm_opts_set: wrong field: %s\n", field);
+        exit(1);
+    }
+}
+
+void ocp_qp_gpu_ipm_opts_get(void *config, void *opts_, const char *field, void *value)
+{
+    gpu_ipm_opts *o = (gpu_ipm_opts *) opts_;
+    if (!strcmp(field, "t0_min")) *(double *) value = o->t0_min;
+    else if (!strcmp(field, "lam0_min")) *(double *) value = o->lam0_min;
+    else if (!strcmp(field, "iter_max")) *(int *) value = o->iter_max;
+    else if (!strcmp(field, "tol_stat")) *(double *) value = o->tol_stat;
+    else
+    {
+        printf("\nerror: ocp_qp_gpu_ipm_opts_get: field %s not available\n", field);
+        exit(1);
+    }
+}
+
+acados_size_t ocp_qp_gpu_ipm_memory_calculate_size(void *config, void *dims, void *opts) { return sizeof(gpu_ipm_memory) + 8; }
+
+void *ocp_qp_gpu_ipm_memory_assign(void *config, void *dims, void *opts, void *raw_memory)
+{
+    gpu_ipm_memory *m = (gpu_ipm_memory *) align8((char *) raw_memory);
+    memset(m, 0, sizeof(*m));
+    m->stat_m = 20;
+    return m;
+}
+
+void ocp_qp_gpu_ipm_memory_get(void *config, void *mem_, const char *field, void *value)
+{
+    gpu_ipm_memory *m = (gpu_ipm_memory *) mem_;
+    /* ocp_qp_hpipm.c:255-297 */
+    if (!strcmp(field, "time_qp_solver_call")) *(double *) value = m->time_qp_solver_call;
+    else if (!strcmp(field, "iter")) *(int *) value = m->iter;
+    else if (!strcmp(field, "status")) *(int *) value = m->status;
+    else if (!strcmp(field, "stat")) *(double **) value = m->cache ? m->cache->stat.data() : nullptr;
+    else if (!strcmp(field, "stat_m")) *(int *) value = m->stat_m;
+    else if (!strcmp(field, "tau_iter")) *(double *) value = 0.0;
+    else
+    {
+        printf("\nerror: ocp_qp_gpu_ipm_memory_get: field %s not available\n", field);
+        exit(1);
+    }
+}
+
+acados_size_t ocp_qp_gpu_ipm_workspace_calculate_size(void *config, void *dims, void *opts) { return 0; }
+
+int ocp_qp_gpu_ipm_evaluate_batch(void *config, int n, void **qp_in_, void **qp_out_, void *opts_, void **mem_,
+                                  void *work, int *status)
+{
+    const double t_start = now_s();
+    ocp_qp_in **ins = (ocp_qp_in **) qp_in_;
+    ocp_qp_out **outs = (ocp_qp_out **) qp_out_;
+    gpu_ipm_opts *o = (gpu_ipm_opts *) opts_;
+    gpu_ipm_memory *m = (gpu_ipm_memory *) mem_[0];
+    const ocp_qp_dims *d = ins[0]->dim;
+    const int N = d->N;
+
+    /* (re)create the device batch when the count or the structure changed */
+    std::vector<int> sig = structure_sig(ins[0]);
+    for (int i = 1; i < n; i++)
+        if (structure_sig(ins[i]) != sig)
+        {
+            printf("\nerror: ocp_qp_gpu_ipm_evaluate_batch: QP %d differs in structure from QP 0\n", i);
+            exit(1);
+        }
+    if (!m->cache) m->cache = new batch_cache();
+    batch_cache *bc = m->cache;
+    if (!bc->batch || bc->n != n || bc->sig != sig)
+    {
+        if (bc->batch) ocp_qp_gpu_batch_destroy(bc->batch);
+        bc->batch = ocp_qp_gpu_batch_create(N, d->nx, d->nu, d->nbx, d->nbu, d->ng, d->ns, n, -1);
+        if (!bc->batch)
+        {
+            printf("\nerror: ocp_qp_gpu_ipm: no GPU batch could be created (no device or unsupported shape)\n");
+            exit(1);
+        }
+        bc->n = n;
+        bc->sig = sig;
+        for (int k = 0; k <= N; k++)
+        {
+            ocp_qp_gpu_batch_set_int(bc->batch, "idxb", k, ins[0]->idxb[k], d->nb[k]);
+            ocp_qp_gpu_batch_set_int(bc->batch, "idxs_rev", k, ins[0]->idxs_rev[k], d->nb[k] + d->ng[k]);
+            ocp_qp_gpu_batch_set_int(bc->batch, "idxe", k, ins[0]->idxe[k], d->nbxe[k]);
+        }
+    }
+    ocp_qp_gpu_batch *b = bc->batch;
+
+    /* options */
+    ocp_qp_gpu_batch_opts_set(b, "iter_max", &o->iter_max);
+    ocp_qp_gpu_batch_opts_set(b, "tol_stat", &o->tol_stat);
+    ocp_qp_gpu_batch_opts_set(b, "tol_eq", &o->tol_eq);
+    ocp_qp_gpu_batch_opts_set(b, "tol_ineq", &o->tol_ineq);
+    ocp_qp_gpu_batch_opts_set(b, "tol_comp", &o->tol_comp);
+    ocp_qp_gpu_batch_opts_set(b, "warm_start", &o->warm_start);
+    ocp_qp_gpu_batch_opts_set(b, "mu0", &o->mu0);
+    ocp_qp_gpu_batch_opts_set(b, "alpha_min", &o->alpha_min);
+    ocp_qp_gpu_batch_opts_set(b, "tau_min", &o->tau_min);
+    ocp_qp_gpu_batch_opts_set(b, "reg_prim", &o->reg_prim);
+    ocp_qp_gpu_batch_opts_set(b, "cond_pred_corr", &o->cond_pred_corr);
+    ocp_qp_gpu_batch_opts_set(b, "print_level", &o->print_level);
+
+    /* re-read every member array of qp_in on every call (they alias ocp_nlp memory:
+     * ocp_nlp_common.c:2797-2894) and pack it into the device layout */
+    struct fld { const char *name; double **ocp_qp_in::*tab; int off_kind; };
+    std::vector<double> &stg = bc->stage;
+    auto push = [&](const char *name, int k, int len, auto getter) {
+        if (len <= 0) return;
+        stg.resize((size_t) n * len);
+        for (int i = 0; i < n; i++) memcpy(stg.data() + (size_t) i * len, getter(ins[i]), sizeof(double) * len);
+        ocp_qp_gpu_batch_set(b, name, k, stg.data(), 0);
+    };
+    for (int k = 0; k <= N; k++)
+    {
+        const int nbu = d->nbu[k], nbx = d->nbx[k], ng = d->ng[k], ns = d->ns[k];
+        if (k < N)
+        {
+            push("A", k, vlen(d, "A", k), [&](ocp_qp_in *q) { return q->A[k]; });
+            push("B", k, vlen(d, "B", k), [&](ocp_qp_in *q) { return q->B[k]; });
+            push("b", k, vlen(d, "b", k), [&](ocp_qp_in *q) { return q->b[k]; });
+        }
+        push("Q", k, vlen(d, "Q", k), [&](ocp_qp_in *q) { return q->Q[k]; });
+        push("S", k, vlen(d, "S", k), [&](ocp_qp_in *q) { return q->S[k]; });
+        push("R", k, vlen(d, "R", k), [&](ocp_qp_in *q) { return q->R[k]; });
+        push("q", k, vlen(d, "q", k), [&](ocp_qp_in *q) { return q->q[k]; });
+        push("r", k, vlen(d, "r", k), [&](ocp_qp_in *q) { return q->r[k]; });
+        push("lbu", k, nbu, [&](ocp_qp_in *q) { return q->lb[k]; });
+        push("ubu", k, nbu, [&](ocp_qp_in *q) { return q->ub[k]; });
+        push("lbx", k, nbx, [&](ocp_qp_in *q) { return q->lb[k] + nbu; });
+        push("ubx", k, nbx, [&](ocp_qp_in *q) { return q->ub[k] + nbu; });
+        push("lbu_mask", k, nbu, [&](ocp_qp_in *q) { return q->lb_mask[k]; });
+        push("ubu_mask", k, nbu, [&](ocp_qp_in *q) { return q->ub_mask[k]; });
+        push("lbx_mask", k, nbx, [&](ocp_qp_in *q) { return q->lb_mask[k] + nbu; });
+        push("ubx_mask", k, nbx, [&](ocp_qp_in *q) { return q->ub_mask[k] + nbu; });
+        push("C", k, vlen(d, "C", k), [&](ocp_qp_in *q) { return q->C[k]; });
+        push("D", k, vlen(d, "D", k), [&](ocp_qp_in *q) { return q->D[k]; });
+        push("lg", k, ng, [&](ocp_qp_in *q) { return q->lg[k]; });
+        push("ug", k, ng, [&](ocp_qp_in *q) { return q->ug[k]; });
+        push("lg_mask", k, ng, [&](ocp_qp_in *q) { return q->lg_mask[k]; });
+        push("ug_mask", k, ng, [&](ocp_qp_in *q) { return q->ug_mask[k]; });
+        push("Zl", k, ns, [&](ocp_qp_in *q) { return q->Zl[k]; });
+        push("Zu", k, ns, [&](ocp_qp_in *q) { return q->Zu[k]; });
+        push("zl", k, ns, [&](ocp_qp_in *q) { return q->zl[k]; });
+        push("zu", k, ns, [&](ocp_qp_in *q) { return q->zu[k]; });
+        push("lls", k, ns, [&](ocp_qp_in *q) { return q->lls[k]; });
+        push("lus", k, ns, [&](ocp_qp_in *q) { return q->lus[k]; });
+        push("lls_mask", k, ns, [&](ocp_qp_in *q) { return q->lls_mask[k]; });
+        push("lus_mask", k, ns, [&](ocp_qp_in *q) { return q->lus_mask[k]; });
+    }
+    if (o->warm_start >= 2)
+    {
+        /* hot start: the iterate in qp_out is the starting point (acados_ocp_options.py:1029-1032) */
+        for (int k = 0; k <= N; k++)
+        {
+            const int nu = d->nu[k], nx = d->nx[k], ns = d->ns[k];
+            auto pusho = [&](const char *name, int len, auto getter) {
+                if (len <= 0) return;
+                stg.resize((size_t) n * len);
+                for (int i = 0; i < n; i++) memcpy(stg.data() + (size_t) i * len, getter(outs[i]), sizeof(double) * len);
+                ocp_qp_gpu_batch_set(b, name, k, stg.data(), 0);
+            };
+            pusho("u", nu, [&](ocp_qp_out *q) { return q->ux[k]; });
+            pusho("x", nx, [&](ocp_qp_out *q) { return q->ux[k] + nu; });
+            pusho("sl", ns, [&](ocp_qp_out *q) { return q->ux[k] + nu + nx; });
+            pusho("su", ns, [&](ocp_qp_out *q) { return q->ux[k] + nu + nx + ns; });
+            if (k < N) pusho("pi", d->nx[k + 1], [&](ocp_qp_out *q) { return q->pi[k]; });
+            pusho("lam", 2 * (d->nb[k] + d->ng[k] + ns), [&](ocp_qp_out *q) { return q->lam[k]; });
+            pusho("t", 2 * (d->nb[k] + d->ng[k] + ns), [&](ocp_qp_out *q) { return q->t[k]; });
+        }
+    }
+    const double t_packed = now_s();
+
+    ocp_qp_gpu_batch_solve(b);
+    const double t_solved = now_s();
+
+    /* unpack */
+    auto pull = [&](const char *name, int k, int len, auto getter) {
+        if (len <= 0) return;
+        stg.resize((size_t) n * len);
+        ocp_qp_gpu_batch_get(b, name, k, stg.data(), 0);
+        for (int i = 0; i < n; i++) memcpy(getter(outs[i]), stg.data() + (size_t) i * len, sizeof(double) * len);
+    };
+    for (int k = 0; k <= N; k++)
+    {
+        const int nu = d->nu[k], nx = d->nx[k], ns = d->ns[k], nct = 2 * (d->nb[k] + d->ng[k] + ns);
+        pull("u", k, nu, [&](ocp_qp_out *q) { return q->ux[k]; });
+        pull("x", k, nx, [&](ocp_qp_out *q) { return q->ux[k] + nu; });
+        pull("sl", k, ns, [&](ocp_qp_out *q) { return q->ux[k] + nu + nx; });
+        pull("su", k, ns, [&](ocp_qp_out *q) { return q->ux[k] + nu + nx + ns; });
+        if (k < N) pull("pi", k, d->nx[k + 1], [&](ocp_qp_out *q) { return q->pi[k]; });
+        pull("lam", k, nct, [&](ocp_qp_out *q) { return q->lam[k]; });
+        pull("t", k, nct, [&](ocp_qp_out *q) { return q->t[k]; });
+    }
+    std::vector<int> st(n), it(n);
+    ocp_qp_gpu_batch_get_info(b, "status", st.data());
+    ocp_qp_gpu_batch_get_info(b, "iter", it.data());
+    bc->stat.assign((size_t) 20 * (o->iter_max + 2), 0.0);
+    ocp_qp_gpu_batch_get_stat(b, 0, bc->stat.data(), o->iter_max + 2);
+    const double t_end = now_s();
+
+    int worst = 0;
+    for (int i = 0; i < n; i++)
+    {
+        qp_info *info = (qp_info *) outs[i]->misc;
+        info->solve_QP_time = ocp_qp_gpu_batch_get_scalar(b, "time_tot");
+        info->condensing_time = 0.0;
+        info->interface_time = (t_packed - t_start) + (t_end - t_solved);
+        info->total_time = t_end - t_start;
+        info->num_iter = it[i];
+        info->t_computed = 1;
+        if (status) status[i] = st[i];
+        if (st[i] != ACADOS_SUCCESS && (worst == 0 || worst == ACADOS_MAXITER)) worst = st[i];
+        if (mem_[i] && i > 0)
+        {
+            gpu_ipm_memory *mi = (gpu_ipm_memory *) mem_[i];
+            mi->iter = it[i]; mi->status = st[i]; mi->time_qp_solver_call = info->solve_QP_time;
+        }
+    }
+    m->iter = it[0];
+    m->status = st[0];
+    m->time_qp_solver_call = t_solved - t_packed;
+    return worst;
+}
+
+/* ocp_qp_hpipm.c:314-405 */
+int ocp_qp_gpu_ipm(void *config, void *qp_in, void *qp_out, void *opts, void *mem, void *work)
+{
+    int status = 0;
+    void *ins[1] = {qp_in}, *outs[1] = {qp_out}, *mems[1] = {mem};
+    ocp_qp_gpu_ipm_evaluate_batch(config, 1, ins, outs, opts, mems, work, &status);
+    /* status codes are already acados' (the map of ocp_qp_hpipm.c:398-404 is applied on device) */
+    return status;
+}
+
+void ocp_qp_gpu_ipm_solver_get(void *config, void *qp_in, void *qp_out, void *opts, void *mem, const char *field,
+                               int stage, void *value, int size1, int size2)
+{
+    /* Riccati getters P p K k Lr (ocp_qp_hpipm.c:417-478): SURVEY 8(f) row 4, not built yet */
+    printf("\nerror: ocp_qp_gpu_ipm_solver_get: field %s not available\n", field);
+    exit(1);
+}
+
+void ocp_qp_gpu_ipm_memory_reset(void *config, void *qp_in, void *qp_out, void *opts, void *mem_, void *work)
+{
+    gpu_ipm_memory *m = (gpu_ipm_memory *) mem_;
+    if (m->cache)
+    {
+        if (m->cache->batch) ocp_qp_gpu_batch_destroy(m->cache->batch);
+        delete m->cache;
+        m->cache = nullptr;
+    }
+}
+
+void ocp_qp_gpu_ipm_eval_forw_sens(void *config, void *qp_in, void *seed, void *qp_out, void *opts, void *mem, void *work)
+{
+    printf("\nerror: ocp_qp_gpu_ipm_eval_forw_sens: not implemented (SURVEY 8f row 4)\n");
+    exit(1);
+}
+
+void ocp_qp_gpu_ipm_eval_adj_sens(void *config, void *qp_in, void *seed, void *qp_out, void *opts, void *mem, void *work)
+{
+    printf("\nerror: ocp_qp_gpu_ipm_eval_adj_sens: not implemented (SURVEY 8f row 4)\n");
+    exit(1);
+}
+
+void ocp_qp_gpu_ipm_terminate(void *config, void *mem, void *work)
+{
+    ocp_qp_gpu_ipm_memory_reset(config, nullptr, nullptr, nullptr, mem, work);
+}
+
+/* ocp_qp_hpipm.c:517-540 */
+void ocp_qp_gpu_ipm_config_initialize_default(void *config_)
+{
+    qp_solver_config *config = (qp_solver_config *) config_;
+    config->dims_set = &ocp_qp_dims_set;
+    config->opts_calculate_size = &ocp_qp_gpu_ipm_opts_calculate_size;
+    config->opts_assign = &ocp_qp_gpu_ipm_opts_assign;
+    config->opts_initialize_default = &ocp_qp_gpu_ipm_opts_initialize_default;
+    config->opts_update = &ocp_qp_gpu_ipm_opts_update;
+    config->opts_set = &ocp_qp_gpu_ipm_opts_set;
+    config->opts_get = &ocp_qp_gpu_ipm_opts_get;
+    config->memory_calculate_size = &ocp_qp_gpu_ipm_memory_calculate_size;
+    config->memory_assign = &ocp_qp_gpu_ipm_memory_assign;
+    config->memory_get = &ocp_qp_gpu_ipm_memory_get;
+    config->workspace_calculate_size = &ocp_qp_gpu_ipm_workspace_calculate_size;
+    config->evaluate = &ocp_qp_gpu_ipm;
+    config->solver_get = &ocp_qp_gpu_ipm_solver_get;
+    config->memory_reset = &ocp_qp_gpu_ipm_memory_reset;
+    config->eval_forw_sens = &ocp_qp_gpu_ipm_eval_forw_sens;
+    config->eval_adj_sens = &ocp_qp_gpu_ipm_eval_adj_sens;
+    config->terminate = &ocp_qp_gpu_ipm_terminate;
+}
+
+/* ------------------------------------------------------ outer level */
+
+struct ocp_qp_xcond_solver_config_
+{
+    qp_solver_config qp_solver;
+    char name[64];
+};
+
+struct ocp_qp_xcond_solver_dims_
+{
+    ocp_qp_dims *orig_dims;
+};
+
+struct xcond_solver_opts
+{
+    void *qp_solver_opts;
+    int cond_N;
+    int cond_ric_alg;
+    bool initialize_next_xcond_qp_from_qp_out;
+    bool warned;
+};
+
+struct ocp_qp_solver_
+{
+    ocp_qp_xcond_solver_config *config;
+    ocp_qp_xcond_solver_dims *dims;
+    xcond_solver_opts *opts;
+    void *mem;
+    void *mem_raw;
+};
+
+/* ocp_qp_interface.c:185-259 */
+ocp_qp_xcond_solver_config *ocp_qp_xcond_solver_config_create_from_name(const char *name)
+{
+    if (strcmp(name, "PARTIAL_CONDENSING_GPU_IPM") && strcmp(name, "PARTIAL_CONDENSING_HPIPM"))
+    {
+        printf("\nerror: ocp_qp_xcond_solver_config_create_from_name: QP solver %s not supported by acados_amd\n", name);
+        return nullptr;
+    }
+    ocp_qp_xcond_solver_config *c = (ocp_qp_xcond_solver_config *) calloc(1, sizeof(*c));
+    ocp_qp_gpu_ipm_config_initialize_default(&c->qp_solver);
+    snprintf(c->name, sizeof(c->name), "%s", name);
+    return c;
+}
+
+void ocp_qp_xcond_solver_config_free(ocp_qp_xcond_solver_config *c) { free(c); }
+
+ocp_qp_xcond_solver_dims *ocp_qp_xcond_solver_dims_create(ocp_qp_xcond_solver_config *config, int N)
+{
+    ocp_qp_xcond_solver_dims *d = (ocp_qp_xcond_solver_dims *) calloc(1, sizeof(*d));
+    d->orig_dims = ocp_qp_dims_create(N);
+    return d;
+}
+
+void ocp_qp_xcond_solver_dims_set(void *config, ocp_qp_xcond_solver_dims *dims, int stage, const char *field, int *value)
+{
+    ocp_qp_dims_set(config, dims->orig_dims, stage, field, value);
+}
+
+void ocp_qp_xcond_solver_dims_free(ocp_qp_xcond_solver_dims *d)
+{
+    if (!d) return;
+    ocp_qp_dims_free(d->orig_dims);
+    free(d);
+}
+
+void *ocp_qp_xcond_solver_opts_create(ocp_qp_xcond_solver_config *config, ocp_qp_xcond_solver_dims *dims)
+{
+    xcond_solver_opts *o = (xcond_solver_opts *) calloc(1, sizeof(*o));
+    qp_solver_config *qs = &config->qp_solver;
+    void *raw = calloc(1, qs->opts_calculate_size(qs, dims->orig_dims));
+    o->qp_solver_opts = qs->opts_assign(qs, dims->orig_dims, raw);
+    qs->opts_initialize_default(qs, dims->orig_dims, o->qp_solver_opts);
+    o->cond_N = dims->orig_dims->N;
+    o->cond_ric_alg = 1;
+    return o;
+}
+
+/* ocp_qp_xcond_solver.c:280-312: "cond_" prefix goes to the condensing module */
+void ocp_qp_xcond_solver_opts_set(ocp_qp_xcond_solver_config *config, void *opts_, const char *field, void *value)
+{
+    xcond_solver_opts *o = (xcond_solver_opts *) opts_;
+    if (!strncmp(field, "cond_", 5))
+    {
+        const char *f = field + 5;
+        if (!strcmp(f, "N")) o->cond_N = *(int *) value;
+        else if (!strcmp(f, "ric_alg")) o->cond_ric_alg = *(int *) value;
+        else if (!strcmp(f, "block_size")) { /* taken together with cond_N */ }
+        else
+        {
+            printf("\nerror: field %s not available in ocp_qp_partial_condensing_opts_set\n", f);
+            exit(1);
+        }
+    }
+    else if (!strcmp(field, "initialize_next_xcond_qp_from_qp_out"))
+        o->initialize_next_xcond_qp_from_qp_out = *(bool *) value;
+    else
+        config->qp_solver.opts_set(&config->qp_solver, o->qp_solver_opts, field, value);
+}
+
+void ocp_qp_xcond_solver_opts_free(void *opts_)
+{
+    xcond_solver_opts *o = (xcond_solver_opts *) opts_;
+    if (!o) return;
+    free(o->qp_solver_opts);
+    free(o);
+}
+
+ocp_qp_in *ocp_qp_in_create_from_xcond_dims(ocp_qp_xcond_solver_dims *dims) { return ocp_qp_in_create(dims->orig_dims); }
+ocp_qp_out *ocp_qp_out_create_from_xcond_dims(ocp_qp_xcond_solver_dims *dims) { return ocp_qp_out_create(dims->orig_dims); }
+
+/* ocp_qp_interface.c:513-563 */
+ocp_qp_solver *ocp_qp_create(ocp_qp_xcond_solver_config *config, ocp_qp_xcond_solver_dims *dims, void *opts_)
+{
+    ocp_qp_solver *s = (ocp_qp_solver *) calloc(1, sizeof(*s));
+    qp_solver_config *qs = &config->qp_solver;
+    xcond_solver_opts *o = (xcond_solver_opts *) opts_;
+    s->config = config; s->dims = dims; s->opts = o;
+    s->mem_raw = calloc(1, qs->memory_calculate_size(qs, dims->orig_dims, o->qp_solver_opts));
+    s->mem = qs->memory_assign(qs, dims->orig_dims, o->qp_solver_opts, s->mem_raw);
+    return s;
+}
+
+void ocp_qp_solver_destroy(ocp_qp_solver *s)
+{
+    if (!s) return;
+    s->config->qp_solver.terminate(&s->config->qp_solver, s->mem, nullptr);
+    free(s->mem_raw);
+    free(s);
+}
+
+static void xcond_note(ocp_qp_solver *s)
+{
+    xcond_solver_opts *o = s->opts;
+    if (o->cond_N != s->dims->orig_dims->N && !o->warned)
+    {
+        printf("acados_amd: cond_N=%d requested; this build solves the full-space QP (N2 = N, the default of "
+               "ocp_qp_partial_condensing.c:243-265); the solution is identical\n", o->cond_N);
+        o->warned = true;
+    }
+}
+
+/* ocp_qp_interface.c:567-571 -> ocp_qp_xcond_solve (ocp_qp_xcond_solver.c:529-587) */
+int ocp_qp_solve(ocp_qp_solver *s, ocp_qp_in *qp_in, ocp_qp_out *qp_out)
+{
+    xcond_note(s);
+    qp_solver_config *qs = &s->config->qp_solver;
+    return qs->evaluate(qs, qp_in, qp_out, s->opts->qp_solver_opts, s->mem, nullptr);
+}
+
+int ocp_qp_solve_batch(ocp_qp_solver *s, int n, ocp_qp_in **qp_in, ocp_qp_out **qp_out, int *status)
+{
+    xcond_note(s);
+    std::vector<void *> mems(n, nullptr);
+    mems[0] = s->mem;
+    return ocp_qp_gpu_ipm_evaluate_batch(&s->config->qp_solver, n, (void **) qp_in, (void **) qp_out,
+                                         s->opts->qp_solver_opts, mems.data(), nullptr, status);
+}
+
+/* ocp_qp_interface.c:573-595 */
+void ocp_qp_xcond_solver_get_scalar(ocp_qp_solver *s, ocp_qp_out *qp_out, const char *field, void *value)
+{
+    qp_info *info = (qp_info *) qp_out->misc;
+    if (!strcmp(field, "time_tot")) *(double *) value = info->total_time;
+    else if (!strcmp(field, "time_cond") || !strcmp(field, "time_qp_xcond")) *(double *) value = info->condensing_time;
+    else s->config->qp_solver.memory_get(&s->config->qp_solver, s->mem, field, value);
+}
+
+/* ocp_qp_interface.c:597-610 */
+void ocp_qp_solver_get_stats(ocp_qp_solver *s, double *stat_out, const char *qp_solver_name)
+{
+    int iter, stat_m;
+    double *stat;
+    qp_solver_config *qs = &s->config->qp_solver;
+    qs->memory_get(qs, s->mem, "iter", &iter);
+    qs->memory_get(qs, s->mem, "stat", &stat);
+    qs->memory_get(qs, s->mem, "stat_m", &stat_m);
+    if (!stat) return;
+    for (int i = 0; i < stat_m * (iter + 1); i++) stat_out[i] = stat[i];
+}
+
+} /* extern "C" */

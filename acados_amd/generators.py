@@ -1,0 +1,144 @@
+"""Synthetic OCP-QP generators for the configurations of BASELINE.md / SURVEY.md 8(d).
+
+* mass_spring_qp: restates `create_ocp_qp_in_mass_spring`
+  (examples/c/no_interface_examples/mass_spring_model/mass_spring_qp.c:60-130 system,
+  :134-205 dims, :209-516 data) -- the C1 plumbing case and the reference's unit-test QP
+  (test/ocp_qp/test_qpsolvers.cpp:117-268 uses N=15).
+* random_lqr_batch: configuration C2 (random stable LQR-like, u-box + x0 equality).
+"""
+import numpy as np
+import scipy.linalg
+
+from .ocp_qp import AcadosOcpQp, AcadosOcpQpDims
+
+
+def mass_spring_system(Ts, nx, nu):
+    """ZOH discretisation of nx/2 masses in a row (mass_spring_qp.c:60-130)."""
+    pp = nx // 2
+    T = -2.0 * np.eye(pp) + np.eye(pp, k=1) + np.eye(pp, k=-1)
+    Ac = np.block([[np.zeros((pp, pp)), np.eye(pp)], [T, np.zeros((pp, pp))]])
+    Bc = np.zeros((nx, nu))
+    Bc[pp:pp + nu, :] = np.eye(nu)
+    A = scipy.linalg.expm(Ac * Ts)
+    B = np.linalg.solve(Ac, (A - np.eye(nx)) @ Bc)
+    return A, B
+
+
+def mass_spring_qp(N=20, nx=8, nu=3, nb=11, x0_equality=True):
+    """nb = nbu + nbx with nbu = min(nu, nb); stage 0 bounds every state at x0."""
+    A, B = mass_spring_system(0.5, nx, nu)
+    nbu = min(nu, nb)
+    nbx = max(nb - nu, 0)
+    x0 = np.zeros(nx)
+    x0[0] = x0[1] = 2.5
+    qp = AcadosOcpQp(N)
+    for k in range(N + 1):
+        last = k == N
+        nuk = 0 if last else nu
+        qp.set("Q", k, np.eye(nx)); qp.set("q", k, 0.1 * np.ones(nx))
+        qp.set("R", k, 2.0 * np.eye(nuk)); qp.set("r", k, 0.2 * np.ones(nuk))
+        qp.set("S", k, np.zeros((nuk, nx)))
+        if not last:
+            qp.set("A", k, A); qp.set("B", k, B); qp.set("b", k, 0.1 * np.ones(nx))
+        nbuk = 0 if last else nbu
+        qp.set("lbu", k, -0.5 * np.ones(nbuk)); qp.set("ubu", k, 0.5 * np.ones(nbuk))
+        if k == 0:
+            qp.set("lbx", k, x0); qp.set("ubx", k, x0)
+            qp.set("idxb", k, np.concatenate([np.arange(nbuk), nuk + np.arange(nx)]))
+            if x0_equality:
+                qp.set("idxe", k, nbuk + np.arange(nx))
+        else:
+            qp.set("lbx", k, -4.0 * np.ones(nbx)); qp.set("ubx", k, 4.0 * np.ones(nbx))
+            qp.set("idxb", k, np.concatenate([np.arange(nbuk), nuk + np.arange(nbx)]))
+    qp.make_consistent()
+    return qp
+
+
+def lqr_dims(N, nx, nu):
+    d = AcadosOcpQpDims(N)
+    d.nx[:] = nx
+    d.nu[:N] = nu
+    d.nbu[:N] = nu
+    d.nbx[0] = nx
+    d.nb[:] = d.nbu + d.nbx
+    d.nbxe[0] = nx
+    return d
+
+
+def _stream(seed, tag, shape, dist="uniform"):
+    """counter-based stream per (seed, field tag): instance i always sees the same numbers
+    whatever the batch size (row-major draw, one row per instance)."""
+    g = np.random.Generator(np.random.Philox(key=[int(seed), int(tag)]))
+    n = int(np.prod(shape[1:]))
+    a = g.random((shape[0], n)) * 2.0 - 1.0 if dist == "uniform" else g.standard_normal((shape[0], n))
+    return a.reshape(shape)
+
+
+def random_lqr_batch(N=50, nx=8, nu=3, batch=1024, seed=0):
+    """Configuration C2: per instance
+    A = A_d + 0.02 U(-1,1) rescaled to spectral radius <= 1.05, B = B_d + 0.02 U(-1,1),
+    b ~ 0.1 U(-1,1), Q = I + 0.1 GG', R = 2I + 0.1 HH', S = 0.05 N(0,1), q,r ~ 0.1 N(0,1),
+    x0 ~ U(-2.5,2.5) as equality bound at stage 0, u in [-0.5, 0.5].
+    Returns dict of arrays with leading dim `batch` (matrices [batch, rows, cols])."""
+    Ad, Bd = mass_spring_system(0.5, nx, nu) if nx % 2 == 0 and nu <= nx // 2 else (0.9 * np.eye(nx), np.eye(nx, nu))
+    A = Ad[None] + 0.02 * _stream(seed, 1, (batch, nx, nx))
+    rho = np.max(np.abs(np.linalg.eigvals(A)), axis=1)
+    A = A * np.minimum(1.0, 1.05 / rho)[:, None, None]
+    B = Bd[None] + 0.02 * _stream(seed, 2, (batch, nx, nu))
+    b = 0.1 * _stream(seed, 3, (batch, nx))
+    G = _stream(seed, 4, (batch, nx, nx), "normal") / np.sqrt(nx)
+    H = _stream(seed, 5, (batch, nu, nu), "normal") / np.sqrt(nu)
+    Q = np.eye(nx)[None] + 0.1 * G @ np.transpose(G, (0, 2, 1))
+    R = 2.0 * np.eye(nu)[None] + 0.1 * H @ np.transpose(H, (0, 2, 1))
+    S = 0.05 * _stream(seed, 6, (batch, nu, nx), "normal")
+    q = 0.1 * _stream(seed, 7, (batch, nx), "normal")
+    r = 0.1 * _stream(seed, 8, (batch, nu), "normal")
+    x0 = 2.5 * _stream(seed, 9, (batch, nx))
+    return dict(A=A, B=B, b=b, Q=Q, R=R, S=S, q=q, r=r, x0=x0,
+                lbu=-0.5 * np.ones((batch, nu)), ubu=0.5 * np.ones((batch, nu)))
+
+
+def lqr_instance_qp(data, i, N):
+    """One instance of random_lqr_batch as an AcadosOcpQp (oracle / parity tests)."""
+    nx, nu = data["A"].shape[1], data["B"].shape[2]
+    qp = AcadosOcpQp(N)
+    for k in range(N + 1):
+        last = k == N
+        qp.set("Q", k, data["Q"][i]); qp.set("q", k, data["q"][i])
+        if not last:
+            qp.set("R", k, data["R"][i]); qp.set("r", k, data["r"][i]); qp.set("S", k, data["S"][i])
+            qp.set("A", k, data["A"][i]); qp.set("B", k, data["B"][i]); qp.set("b", k, data["b"][i])
+            qp.set("lbu", k, data["lbu"][i]); qp.set("ubu", k, data["ubu"][i])
+        else:
+            qp.set("R", k, np.zeros((0, 0))); qp.set("S", k, np.zeros((0, nx))); qp.set("r", k, np.zeros(0))
+        if k == 0:
+            qp.set("lbx", k, data["x0"][i]); qp.set("ubx", k, data["x0"][i])
+            qp.set("idxb", k, np.arange(nu + nx)); qp.set("idxe", k, nu + np.arange(nx))
+    qp.make_consistent()
+    return qp
+
+
+def fill_lqr_batch(gb, data, N, xp=None):
+    """Pack random_lqr_batch() data into an OcpQpGpuBatch `gb` (same block for every stage).
+    `xp`: optional converter (e.g. lambda a: torch.from_numpy(a).cuda()) producing device
+    tensors in the blocked C-ABI layout so that no host staging takes place."""
+    nx, nu = data["A"].shape[1], data["B"].shape[2]
+    gb.set_int("idxe", 0, nu + np.arange(nx))
+
+    def blk(a):
+        a = np.asarray(a, dtype=np.float64)
+        if a.ndim == 3:
+            a = np.transpose(a, (0, 2, 1))
+        a = np.ascontiguousarray(a.reshape(a.shape[0], -1))
+        return xp(a) if xp is not None else a
+
+    for f in ("A", "B", "b", "Q", "R", "S", "q", "r", "lbu", "ubu"):
+        v = blk(data[f])
+        if f in ("R", "S", "r", "lbu", "ubu", "A", "B", "b"):
+            for k in range(N):
+                gb.set(f, k, v)
+        else:
+            gb.set(f, -1, v)
+    x0 = blk(data["x0"])
+    gb.set("lbx", 0, x0)
+    gb.set("ubx", 0, x0)

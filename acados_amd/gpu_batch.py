@@ -1,0 +1,168 @@
+"""Device-resident batch of structurally identical OCP-QPs (thin ctypes layer over
+include/acados_amd/ocp_qp_gpu_batch.h).
+
+This is the GPU counterpart of the reference's batch idiom, `AcadosOcpBatchSolver`
+(interfaces/acados_template/acados_template/acados_ocp_batch_solver.py:41-) /
+`<name>_acados_batch_solve` (c_templates_tera/acados_solver.in.c:3222-3243), restricted to
+the QP-solve part: N_batch QPs sharing dims / idxb / idxs_rev / idxe.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+INT_FIELDS = ("idxb", "idxbx", "idxbu", "idxs_rev", "idxe")
+DATA_FIELDS = ("A", "B", "b", "Q", "S", "R", "q", "r", "lbx", "ubx", "lbu", "ubu", "C", "D", "lg", "ug",
+               "Zl", "Zu", "zl", "zu", "lls", "lus", "lbx_mask", "ubx_mask", "lbu_mask", "ubu_mask",
+               "lg_mask", "ug_mask", "lls_mask", "lus_mask")
+DYN_FIELDS = ("A", "B", "b")
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+class OcpQpGpuBatch:
+    def __init__(self, dims, n_batch, device=-1, _clib=None):
+        """dims: object with N and arrays nx nu nbx nbu ng ns (length N+1)."""
+        self._L = _clib if _clib is not None else _lib.lib()
+        self.dims, self.N, self.n_batch = dims, int(dims.N), int(n_batch)
+        arrs = [np.ascontiguousarray(getattr(dims, n), dtype=np.int32) for n in ("nx", "nu", "nbx", "nbu", "ng", "ns")]
+        self._nbxe = np.zeros(self.N + 1, dtype=int)
+        self._h = self._L.ocp_qp_gpu_batch_create(self.N, *[_ip(a) for a in arrs], self.n_batch, int(device))
+        if not self._h:
+            raise RuntimeError("acados_amd: ocp_qp_gpu_batch_create failed (no GPU, or unsupported shape)")
+        self._h = C.c_void_p(self._h)
+
+    # -- structure / data -------------------------------------------------
+    def set_int(self, field, stage, value):
+        v = np.ascontiguousarray(np.asarray(value).reshape(-1), dtype=np.int32)
+        if field == "idxe":
+            self._nbxe[stage] = v.size
+        if self._L.ocp_qp_gpu_batch_set_int(self._h, field.encode(), int(stage), _ip(v), int(v.size)) != 0:
+            raise ValueError(f"ocp_qp_gpu_batch_set_int({field}, {stage}) failed")
+
+    def set(self, field, stage, value):
+        """value: array [n_batch, ...] (column-major flattening of matrices is done here:
+        pass matrices as [n_batch, rows, cols]); or a torch CUDA tensor already in the
+        blocked C-ABI layout [n_batch, len] (zero-copy, device pointer)."""
+        if hasattr(value, "data_ptr") and getattr(value, "is_cuda", False):
+            assert value.is_contiguous() and str(value.dtype) == "torch.float64" and value.shape[0] == self.n_batch
+            rc = self._L.ocp_qp_gpu_batch_set(self._h, field.encode(), int(stage), C.c_void_p(value.data_ptr()), 1)
+        else:
+            a = np.asarray(value, dtype=np.float64)
+            assert a.shape[0] == self.n_batch, f"{field}: leading dim {a.shape[0]} != n_batch {self.n_batch}"
+            if a.ndim == 3:
+                a = np.transpose(a, (0, 2, 1))  # column-major per instance
+            a = np.ascontiguousarray(a.reshape(self.n_batch, -1))
+            if a.shape[1] == 0:
+                return
+            rc = self._L.ocp_qp_gpu_batch_set(self._h, field.encode(), int(stage), a.ctypes.data_as(C.c_void_p), 0)
+        if rc != 0:
+            raise ValueError(f"ocp_qp_gpu_batch_set({field}, {stage}) failed")
+
+    def opts_set(self, field, value):
+        if isinstance(value, str):
+            p = C.c_char_p(value.encode())
+            rc = self._L.ocp_qp_gpu_batch_opts_set(self._h, field.encode(), p)
+        elif isinstance(value, (bool, int, np.integer)):
+            rc = self._L.ocp_qp_gpu_batch_opts_set(self._h, field.encode(), C.byref(C.c_int(int(value))))
+        else:
+            rc = self._L.ocp_qp_gpu_batch_opts_set(self._h, field.encode(), C.byref(C.c_double(float(value))))
+        if rc != 0:
+            raise ValueError(f"unknown option {field}")
+
+    # -- solve / results ---------------------------------------------------
+    def solve(self):
+        """returns the number of instances with non-zero status"""
+        return self._L.ocp_qp_gpu_batch_solve(self._h)
+
+    def _len(self, field, k):
+        d = self.dims
+        if field == "x":
+            return int(d.nx[k])
+        if field == "u":
+            return int(d.nu[k])
+        if field == "pi":
+            return int(d.nx[k + 1])
+        if field in ("sl", "su"):
+            return int(d.ns[k])
+        if field in ("lam", "t"):
+            return 2 * int(d.nbx[k] + d.nbu[k] + d.ng[k] + d.ns[k])
+        raise ValueError(field)
+
+    def get(self, field, stage):
+        n = self._len(field, stage)
+        out = np.zeros((self.n_batch, n))
+        if n:
+            if self._L.ocp_qp_gpu_batch_get(self._h, field.encode(), int(stage), out.ctypes.data_as(C.c_void_p), 0) != 0:
+                raise ValueError(f"ocp_qp_gpu_batch_get({field}, {stage}) failed")
+        return out
+
+    def info(self, field):
+        out = np.zeros(self.n_batch, dtype=np.int32 if field in ("status", "iter") else np.float64)
+        if self._L.ocp_qp_gpu_batch_get_info(self._h, field.encode(), out.ctypes.data_as(C.c_void_p)) != 0:
+            raise ValueError(field)
+        return out
+
+    def stat(self, inst=0, max_rows=1024):
+        buf = np.zeros((max_rows, 20))
+        rows = self._L.ocp_qp_gpu_batch_get_stat(self._h, int(inst), buf.ctypes.data_as(C.POINTER(C.c_double)), max_rows)
+        if rows < 0:
+            raise ValueError("statistics not available for this instance")
+        return buf[:rows]
+
+    def scalar(self, field):
+        return self._L.ocp_qp_gpu_batch_get_scalar(self._h, field.encode())
+
+    @property
+    def bytes(self):
+        return self._L.ocp_qp_gpu_batch_bytes(self._h)
+
+    @property
+    def stream(self):
+        return self._L.ocp_qp_gpu_batch_stream(self._h)
+
+    @property
+    def kernel_name(self):
+        return self._L.ocp_qp_gpu_batch_kernel_name(self._h).decode()
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.ocp_qp_gpu_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- convenience: pack a list of AcadosOcpQp ----------------------------
+    @classmethod
+    def from_qps(cls, qps, device=-1, _clib=None):
+        """qps: list of AcadosOcpQp with identical structure."""
+        q0 = qps[0]
+        sig = q0.dims.signature()
+        for q in qps:
+            if q.dims.signature() != sig:
+                raise ValueError("all QPs of a batch must share dims (bucket by dims.signature())")
+        b = cls(q0.dims, len(qps), device=device, _clib=_clib)
+        N = q0.N
+        for k in range(N + 1):
+            for f in ("idxb", "idxs_rev", "idxe"):
+                ref = np.asarray(getattr(q0, f)[k]).astype(int)
+                for q in qps:
+                    if not np.array_equal(np.asarray(getattr(q, f)[k]).astype(int), ref):
+                        raise ValueError(f"{f} differs inside the batch at stage {k}")
+                if ref.size or f == "idxe":
+                    b.set_int(f, k, ref)
+        for k in range(N + 1):
+            for f in DATA_FIELDS:
+                if k == N and f in DYN_FIELDS:
+                    continue
+                a = np.stack([np.asarray(getattr(q, f)[k], dtype=float) for q in qps])
+                if a.size:
+                    b.set(f, k, a)
+        return b

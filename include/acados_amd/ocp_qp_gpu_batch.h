@@ -1,0 +1,88 @@
+/*
+ * ocp_qp_gpu_batch.h -- C-ABI of the MI355X batched OCP-QP solver (device-resident batch).
+ *
+ * This is the batch entry point the reference does not have: it replaces the OpenMP loop
+ *   for (i < N_batch) ocp_nlp_solve(capsule[i]) -> ... -> d_ocp_qp_ipm_solve(qp_in, qp_out, ...)
+ * (interfaces/acados_template/acados_template/c_templates_tera/acados_solver.in.c:3222-3243,
+ *  acados/ocp_qp/ocp_qp_hpipm.c:347 in /root/reference) for the QP-solve part: `n_batch`
+ * structurally identical QPs (same dims / idxb / idxs_rev / idxe, different numbers) are
+ * packed once into an element-major, instance-minor HBM layout and every IPM iteration
+ * advances all of them in a handful of kernel launches.
+ *
+ * Plain pointers and sizes only; no torch types.  Field names and data conventions are
+ * those of `ocp_qp_in_set` / `d_ocp_qp_set` and `ocp_qp_out_get`
+ * (interfaces/acados_c/ocp_qp_interface.c:405-480; Python driver
+ * acados_ocp_qp_solver.py:277-292): column-major matrices, natural-sign bounds,
+ * lam/t ordered [lbu lbx lg ubu ubx ug ls us].
+ */
+#ifndef ACADOS_AMD_OCP_QP_GPU_BATCH_H_
+#define ACADOS_AMD_OCP_QP_GPU_BATCH_H_
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ocp_qp_gpu_batch ocp_qp_gpu_batch;
+
+/* acados return codes (acados/utils/types.h:74-87) as produced per instance */
+#define ACADOS_AMD_SUCCESS 0
+#define ACADOS_AMD_NAN_DETECTED 1
+#define ACADOS_AMD_MAXITER 2
+#define ACADOS_AMD_MINSTEP 3
+#define ACADOS_AMD_INFEASIBLE 9
+
+/* Create a batch of `n_batch` QPs with the per-stage dims of ocp_qp_dims
+ * (acados/ocp_qp/ocp_qp_common.h:49; arrays of length N+1).  `device` < 0 keeps the
+ * current HIP device.  Returns NULL (and prints the reason) if no kernel instantiation
+ * covers the shape or no GPU is present. */
+ocp_qp_gpu_batch *ocp_qp_gpu_batch_create(int N, const int *nx, const int *nu, const int *nbx,
+                                          const int *nbu, const int *ng, const int *ns,
+                                          int n_batch, int device);
+void ocp_qp_gpu_batch_destroy(ocp_qp_gpu_batch *b);
+
+/* Structure shared by all instances (integers): "idxb" (nb entries, indices into [u;x]),
+ * "idxbu", "idxbx", "idxs_rev" (nb+ng entries, -1 = hard), "idxe" (`n` entries, positions
+ * in the bound list of equality-flagged x bounds; sets nbxe = n).  Must be set before any
+ * numeric data of that stage. */
+int ocp_qp_gpu_batch_set_int(ocp_qp_gpu_batch *b, const char *field, int stage, const int *value, int n);
+
+/* Numeric data.  `data` holds n_batch consecutive blocks of the field's length:
+ * data[i*len + e], e in acados column-major order.  Fields: A B b Q S R q r lbx ubx lbu ubu
+ * lg ug C D Zl Zu zl zu lls lus  *_mask (lbx ubx lbu ubu lg ug lls lus)  and, for warm
+ * starts, x u sl su pi lam t.  `is_device` != 0: `data` is a device pointer (e.g. a torch
+ * tensor's data_ptr()) and no host transfer takes place.  `stage` = -1 applies the same
+ * block to every stage that has the field (data is then read once per stage). */
+int ocp_qp_gpu_batch_set(ocp_qp_gpu_batch *b, const char *field, int stage, const double *data, int is_device);
+
+/* Options by name, as ocp_qp_xcond_solver_opts_set forwards them: iter_max
+ * tol_stat tol_eq tol_ineq tol_comp warm_start mu0 alpha_min tau_min reg_prim
+ * cond_pred_corr print_level t0_init hpipm_mode ric_alg.  int* or double* or char* as in
+ * acados.  Unknown field: message + return -1. */
+int ocp_qp_gpu_batch_opts_set(ocp_qp_gpu_batch *b, const char *field, const void *value);
+
+/* Solve all instances (one IPM iteration = 4-6 launches over the whole batch) on the
+ * batch's stream.  Returns the number of instances whose status is not ACADOS_SUCCESS. */
+int ocp_qp_gpu_batch_solve(ocp_qp_gpu_batch *b);
+
+/* Results, same blocked convention as _set: x u sl su pi lam t per stage. */
+int ocp_qp_gpu_batch_get(ocp_qp_gpu_batch *b, const char *field, int stage, double *data, int is_device);
+/* per-instance: "status" "iter" (int), "res_stat" "res_eq" "res_ineq" "res_comp" "mu" "obj" (double) */
+int ocp_qp_gpu_batch_get_info(ocp_qp_gpu_batch *b, const char *field, void *data);
+/* HPIPM-shaped statistics of instance `inst` (< 64): (iter+1) x 20, row-major */
+int ocp_qp_gpu_batch_get_stat(ocp_qp_gpu_batch *b, int inst, double *stat, int max_rows);
+/* scalars of the last solve: "time_tot" (s, HIP events around the whole solve),
+ * "time_pack" (s, accumulated since the last solve), "iter_max_batch", "launches" */
+double ocp_qp_gpu_batch_get_scalar(ocp_qp_gpu_batch *b, const char *field);
+/* bytes of HBM held by the batch */
+size_t ocp_qp_gpu_batch_bytes(const ocp_qp_gpu_batch *b);
+/* raw HIP stream handle (hipStream_t) the batch launches on, for event timing by the caller */
+void *ocp_qp_gpu_batch_stream(ocp_qp_gpu_batch *b);
+/* name of the kernel instantiation serving this batch, e.g. "1tpi<NX=8,NU=3,NG=0,NS=0>" */
+const char *ocp_qp_gpu_batch_kernel_name(const ocp_qp_gpu_batch *b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

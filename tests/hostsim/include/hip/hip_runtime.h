@@ -1,0 +1,79 @@
+/*
+ * TEST INFRASTRUCTURE ONLY -- host simulation of the small HIP subset the solver uses.
+ *
+ * Lets the *unchanged* kernel sources (acados_amd/csrc/*.hip, *.hpp) be compiled with g++
+ * and run one "lane" at a time on the CPU, so kernel logic can be checked against the
+ * oracle in the CPU-only test tier (`-m "not gpu"`).  It is built by tests/hostsim/build.py
+ * into tests/hostsim/libgqp_hostsim.so and is never loaded by the acados_amd package:
+ * the product library is the hipcc build of the same sources and needs a real GPU.
+ * Only valid for kernels without cross-lane communication (one instance per lane).
+ */
+#ifndef HOSTSIM_HIP_RUNTIME_H_
+#define HOSTSIM_HIP_RUNTIME_H_
+
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <chrono>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+
+struct dim3
+{
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+static thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+
+typedef int hipError_t;
+#define hipSuccess 0
+typedef void *hipStream_t;
+struct hostsim_event { std::chrono::steady_clock::time_point t; };
+typedef hostsim_event *hipEvent_t;
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyHostToHost };
+
+static inline const char *hipGetErrorString(hipError_t) { return "hostsim"; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n); return *p ? hipSuccess : 1; }
+static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+static inline hipError_t hipHostMalloc(void **p, size_t n) { *p = malloc(n); return hipSuccess; }
+static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+static inline hipError_t hipMemset(void *p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = nullptr; return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new hostsim_event(); return hipSuccess; }
+static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
+static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b)
+{
+    *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
+    return hipSuccess;
+}
+static inline int atomicSub(int *p, int v) { int o = *p; *p = o - v; return o; }
+static inline int atomicAdd(int *p, int v) { int o = *p; *p = o + v; return o; }
+
+#define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...)                           \
+    do {                                                                                    \
+        dim3 g_ = (grid); dim3 b_ = (block);                                                         \
+        blockDim = b_; gridDim = g_;                                                        \
+        for (unsigned bx_ = 0; bx_ < g_.x; bx_++)                                           \
+            for (unsigned tx_ = 0; tx_ < b_.x; tx_++)                                       \
+            {                                                                               \
+                blockIdx.x = bx_; threadIdx.x = tx_;                                        \
+                kern(__VA_ARGS__);                                                          \
+            }                                                                               \
+    } while (0)
+
+#endif

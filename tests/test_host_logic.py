@@ -1,0 +1,140 @@
+"""CPU tier: host logic + kernel logic through the C-ABI, with the kernel sources compiled by
+g++ against the host-simulation shim (tests/hostsim).  The checker is the oracle.  Also checks
+that the PRODUCT library (hipcc build) loads and exports every symbol the headers declare --
+without calling into it (no GPU here)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN_PAIRS, INPUT_ONLY, ROOT, compare_with_oracle, fold_stage0, load_qp, load_sol
+from oracle.oracle import OracleQp, default_opts
+
+ALL_QPS = [p for p, _ in GOLDEN_PAIRS] + INPUT_ONLY
+
+
+def test_product_library_exports_declared_symbols():
+    """every function declared in include/acados_amd/*.h is exported by libacados_amd_qp.so"""
+    from acados_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), "HIP library not built: run __graft_entry__.build()"
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    names = set()
+    for h in ("ocp_qp_gpu_batch.h", "ocp_qp_interface.h"):
+        src = open(os.path.join(ROOT, "include", "acados_amd", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names |= set(re.findall(r"\b(ocp_qp_[a-z0-9_]+)\s*\(", src))
+    assert len(names) > 50
+    missing = [n for n in sorted(names) if not hasattr(L, n)]
+    assert not missing, f"symbols declared but not exported: {missing}"
+
+
+def test_product_path_has_no_cpu_fallback():
+    """the package loader only knows the HIP library; a missing library raises"""
+    from acados_amd import _lib
+    src = open(_lib.__file__).read()
+    assert "hostsim" not in src and "oracle" not in src
+    for mod in ("gpu_batch.py", "ocp_qp_solver.py", "ocp_qp.py", "generators.py", "__init__.py"):
+        s = open(os.path.join(ROOT, "acados_amd", mod)).read()
+        assert "import oracle" not in s and "from oracle" not in s and "hostsim" not in s
+
+
+@pytest.mark.parametrize("qp_file", ALL_QPS)
+def test_batch_abi_matches_oracle_hostsim(hostsim_lib, qp_file):
+    from acados_amd import OcpQpGpuBatch
+    qp = load_qp(qp_file)
+    o = OracleQp(qp)
+    assert o.solve(default_opts(iter_max=100, tol_stat=1e-8)) == 0
+    b = OcpQpGpuBatch.from_qps([qp] * 3, _clib=hostsim_lib)
+    b.opts_set("tol_stat", 1e-8)
+    b.opts_set("iter_max", 100)
+    assert b.solve() == 0
+    assert np.all(b.info("iter") == o.iter)
+    for inst in range(3):
+        compare_with_oracle(lambda k, f: b.get(f, k)[inst], o, qp, 1e-9, fields=("x", "u", "sl", "su", "pi", "lam", "t"))
+    assert max(b.info(n).max() for n in ("res_stat", "res_eq", "res_ineq", "res_comp")) <= 1e-8
+
+
+@pytest.mark.parametrize("qp_file,sol_file", GOLDEN_PAIRS)
+def test_acados_api_golden_hostsim(hostsim_lib, qp_file, sol_file):
+    """the reference's own test (test_ocpqp_solver.py:15-53) read against this backend"""
+    from acados_amd import AcadosOcpQpOptions, AcadosOcpQpSolver
+    qp, sol = load_qp(qp_file), load_sol(sol_file)
+    opts = AcadosOcpQpOptions()
+    opts.iter_max = 500
+    solver = AcadosOcpQpSolver(qp, opts=opts, _clib=hostsim_lib)
+    assert solver.solve() == 0
+    tol = 1e-5
+    for stage in range(qp.N + 1):
+        ref = sol.get(f"lam_{stage}", np.zeros(0))
+        if ref.size:
+            assert np.allclose(solver.get(stage, "lam"), ref, atol=tol)
+        if stage < qp.N:
+            assert np.allclose(solver.get(stage, "pi"), sol[f"pi_{stage}"], atol=tol)
+    assert solver.get_stats("iter") > 0
+    st = solver.get_stats("statistics")
+    assert st.shape == (solver.get_stats("iter") + 1, 20) and st[-1, 7] <= 1e-6
+
+
+def test_mass_spring_and_padding_hostsim(hostsim_lib):
+    """C1 (mass_spring_qp.c restated): residual <= 1e-8 like test_qpsolvers.cpp:238-251; also
+    exercises dimension padding (nu_N = 0 inside an NU=3 kernel)."""
+    from acados_amd import OcpQpGpuBatch
+    from acados_amd.generators import mass_spring_qp
+    for N in (15, 20):
+        qp = mass_spring_qp(N=N)
+        o = OracleQp(qp)
+        assert o.solve(default_opts(tol_stat=1e-8)) == 0
+        b = OcpQpGpuBatch.from_qps([qp], _clib=hostsim_lib)
+        b.opts_set("tol_stat", 1e-8)
+        assert b.solve() == 0
+        assert b.kernel_name == "1tpi<NX=8,NU=3,NG=0,NS=0>"
+        compare_with_oracle(lambda k, f: b.get(f, k)[0], o, qp, 1e-9)
+        assert max(b.info(n).max() for n in ("res_stat", "res_eq", "res_ineq", "res_comp")) <= 1e-8
+
+
+def test_lqr_batch_and_ragged_hostsim(hostsim_lib):
+    """C2-shaped instances at small N; batch size not a multiple of 64; per-instance results"""
+    from acados_amd import OcpQpGpuBatch
+    from acados_amd.generators import fill_lqr_batch, lqr_dims, lqr_instance_qp, random_lqr_batch
+    N, B = 8, 70
+    data = random_lqr_batch(N=N, batch=B, seed=5)
+    gb = OcpQpGpuBatch(lqr_dims(N, 8, 3), B, _clib=hostsim_lib)
+    fill_lqr_batch(gb, data, N)
+    gb.opts_set("tol_stat", 1e-8)
+    assert gb.solve() == 0
+    x = [gb.get("x", k) for k in range(N + 1)]
+    u = [gb.get("u", k) for k in range(N)]
+    for i in (0, 1, 63, 64, 69):
+        o = OracleQp(lqr_instance_qp(data, i, N))
+        assert o.solve(default_opts(tol_stat=1e-8)) == 0
+        for k in range(N + 1):
+            assert np.allclose(x[k][i], o.get(k, "x"), atol=1e-9)
+            if k < N:
+                assert np.allclose(u[k][i], o.get(k, "u"), atol=1e-9)
+        assert gb.info("iter")[i] == o.iter
+
+
+def test_error_behaviour_hostsim(hostsim_lib):
+    from acados_amd import OcpQpGpuBatch
+    from acados_amd.generators import lqr_dims
+    gb = OcpQpGpuBatch(lqr_dims(4, 8, 3), 2, _clib=hostsim_lib)
+    with pytest.raises(ValueError):
+        gb.opts_set("no_such_option", 1)
+    with pytest.raises(ValueError):
+        gb.set("no_such_field", 0, np.zeros((2, 3)))
+    d = lqr_dims(4, 40, 3)  # no kernel instantiation covers nx=40
+    with pytest.raises(RuntimeError):
+        OcpQpGpuBatch(d, 2, _clib=hostsim_lib)
+
+
+def test_maxiter_status_hostsim(hostsim_lib):
+    """status codes are acados' (types.h:74-87): iter_max reached -> ACADOS_MAXITER (2)"""
+    from acados_amd import OcpQpGpuBatch
+    qp = load_qp("casadi_qp_tests/pendulum_qp.json")
+    b = OcpQpGpuBatch.from_qps([qp], _clib=hostsim_lib)
+    b.opts_set("iter_max", 2)
+    b.opts_set("tol_stat", 1e-12)
+    assert b.solve() == 1
+    assert b.info("status")[0] == 2 and b.info("iter")[0] == 2
