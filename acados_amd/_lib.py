@@ -43,5 +43,11 @@ def lib():
             raise RuntimeError(
                 f"acados_amd: HIP library {LIB_PATH} not built; run __graft_entry__.build() "
                 "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        try:
+            # PyTorch ships its own copy of the HIP runtime; loading it first makes this library
+            # and torch (device memory, streams, torch.distributed) share ONE runtime instance.
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _LIB = bind(C.CDLL(LIB_PATH))
     return _LIB
