@@ -128,10 +128,8 @@ def main():
     elapsed = time.perf_counter() - t0
     gb.opts_set("profile", 0)
 
-    if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    from acados_amd.sharding import gather_instances, reduce_max
+    elapsed = reduce_max(elapsed, dist, dev)      # MAX over ranks
 
     iters = gb.info("iter")
     status = gb.info("status")
@@ -140,18 +138,15 @@ def main():
     # ---- gather of solutions + statistics over RCCL/xGMI, outside the timed region ----
     gather_ms = None
     if dist is not None:
-        u0 = torch.from_numpy(gb.get("u", 0)).to(dev)
-        stats = torch.tensor([float(iters.mean()), float(iters.max()), float((status != 0).sum()), res_max],
-                             dtype=torch.float64, device=dev)
+        u0 = gb.get("u", 0)
+        stats = np.array([[float(iters.mean()), float(iters.max()), float((status != 0).sum()), res_max]])
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        u_all = [torch.empty_like(u0) for _ in range(world)]
-        s_all = [torch.empty_like(stats) for _ in range(world)]
-        dist.all_gather(u_all, u0)
-        dist.all_gather(s_all, stats)
+        u_all = gather_instances(u0, world * B, dist, dev)          # RCCL all_gather over xGMI
+        s_all = gather_instances(stats, world, dist, dev)
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - t0) * 1e3
-        s_all = torch.stack(s_all).cpu().numpy()
+        assert u_all.shape == (world * B, nu)
         mean_iter, max_iter = float(s_all[:, 0].mean()), int(s_all[:, 1].max())
         failures, res_max = int(s_all[:, 2].sum()), float(s_all[:, 3].max())
     else:

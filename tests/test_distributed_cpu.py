@@ -1,0 +1,60 @@
+"""CPU tier: the N>1 path (instance sharding + gather + max-reduction) with gloo, world_size 2.
+Each rank solves its shard through the C-ABI (kernel sources under the host-simulation shim) and
+the gathered result must equal the single-process solve of the whole batch, instance by instance."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+from conftest import ROOT
+
+WORKER = r"""
+import ctypes, os, sys
+import numpy as np
+import torch.distributed as dist
+sys.path.insert(0, os.environ["REPO_ROOT"]); sys.path.insert(0, os.path.join(os.environ["REPO_ROOT"], "tests"))
+from acados_amd import OcpQpGpuBatch, _lib
+from acados_amd.generators import fill_lqr_batch, lqr_dims, random_lqr_batch
+from acados_amd.sharding import shard_range, gather_instances, reduce_max
+from hostsim.build import build
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+L = _lib.bind(ctypes.CDLL(build()))
+N, TOTAL = 6, 37
+data = random_lqr_batch(N=N, batch=TOTAL, seed=4)
+lo, hi = shard_range(TOTAL, rank, world)
+local = {k: np.ascontiguousarray(v[lo:hi]) for k, v in data.items()}
+gb = OcpQpGpuBatch(lqr_dims(N, 8, 3), hi - lo, _clib=L)
+fill_lqr_batch(gb, local, N)
+assert gb.solve() == 0
+u0 = gather_instances(gb.get("u", 0), TOTAL, dist)
+it = gather_instances(gb.info("iter").astype(np.float64)[:, None], TOTAL, dist)
+tmax = reduce_max(float(rank + 1), dist)
+if rank == 0:
+    np.save(os.environ["OUT_FILE"], np.concatenate([u0, it], axis=1))
+    assert tmax == float(world)
+dist.destroy_process_group()
+"""
+
+
+def test_sharded_solve_equals_single_process(tmp_path, hostsim_lib):
+    from acados_amd import OcpQpGpuBatch
+    from acados_amd.generators import fill_lqr_batch, lqr_dims, random_lqr_batch
+    from acados_amd.sharding import shard_range
+    assert [shard_range(37, r, 2) for r in range(2)] == [(0, 19), (19, 37)]
+    assert [shard_range(8, r, 3) for r in range(3)] == [(0, 3), (3, 6), (6, 8)]
+    out = tmp_path / "gathered.npy"
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    env = dict(os.environ, REPO_ROOT=ROOT, OUT_FILE=str(out), MASTER_ADDR="127.0.0.1")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                           "--master-addr", "127.0.0.1", "--master-port", "29533", str(script)], env=env, timeout=300)
+    got = np.load(out)
+    N, TOTAL = 6, 37
+    data = random_lqr_batch(N=N, batch=TOTAL, seed=4)
+    gb = OcpQpGpuBatch(lqr_dims(N, 8, 3), TOTAL, _clib=hostsim_lib)
+    fill_lqr_batch(gb, data, N)
+    assert gb.solve() == 0
+    assert np.array_equal(got[:, :3], gb.get("u", 0))
+    assert np.array_equal(got[:, 3], gb.info("iter").astype(np.float64))
