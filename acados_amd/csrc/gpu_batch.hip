@@ -16,6 +16,7 @@
 #include "acados_amd/ocp_qp_gpu_batch.h"
 #include "gpu_ipm_internal.h"
 #include "ipm_kernels.hpp"
+#include "ipm_kernels_box.hpp"
 
 #define HIPCHK(x)                                                                              \
     do {                                                                                       \
@@ -40,12 +41,20 @@ struct KernelSet
     kern_opts_t init;
     kern_redo_t back_fact, back_rhs, fwd_aff, fwd_corr;
     kern_plain_t finalize;
+    /* fast path for box-only QPs (ipm_kernels_box.hpp); index = XBOX (any box row on a state) */
+    kern_redo_t box_fact[2], box_rhs[2], box_fwd_aff[2], box_fwd_corr[2];
+    kern_plain_t box_finalize;
 };
 
 #define GQP_KSET(NX, NU, NG, NS)                                                               \
     {NX, NU, NG, NS, gqp::k_init<NX, NU, NG, NS>, gqp::k_backward<NX, NU, NG, NS, true>,       \
      gqp::k_backward<NX, NU, NG, NS, false>, gqp::k_forward<NX, NU, NG, NS, false>,            \
-     gqp::k_forward<NX, NU, NG, NS, true>, gqp::k_finalize<NX, NU, NG, NS>}
+     gqp::k_forward<NX, NU, NG, NS, true>, gqp::k_finalize<NX, NU, NG, NS>,                    \
+     {gqp::kb_factor<NX, NU, false>, gqp::kb_factor<NX, NU, true>},                            \
+     {gqp::kb_backrhs<NX, NU, false>, gqp::kb_backrhs<NX, NU, true>},                          \
+     {gqp::kb_forward<NX, NU, false, false>, gqp::kb_forward<NX, NU, true, false>},            \
+     {gqp::kb_forward<NX, NU, false, true>, gqp::kb_forward<NX, NU, true, true>},              \
+     gqp::kb_finalize<NX, NU>}
 
 /* compiled shape classes; a batch is served by the cheapest one that covers it */
 const KernelSet g_ksets[] = {
@@ -64,6 +73,8 @@ struct ocp_qp_gpu_batch
     std::vector<std::vector<int>> idxb, idxs_rev, idxe; /* as given (original row order) */
     std::vector<std::vector<int>> perm;                   /* original box row -> sorted row */
     bool finalized = false;
+    bool use_box = false; /* box-only fast path */
+    int xbox = 0;
     const KernelSet *ks = nullptr;
     std::string kname;
     std::vector<GqpStage> st;
@@ -173,6 +184,16 @@ void finalize_structure(ocp_qp_gpu_batch *b)
         o_ct += nct; o_s += 2 * S.ns; o_g += S.ng;
     }
     b->nct_tot = o_ct; b->ns2_tot = o_s; b->ng_tot = o_g;
+    b->use_box = o_g == 0 && o_s == 0 && !getenv("ACADOS_AMD_GENERAL_KERNELS");
+    b->xbox = 0;
+    for (int k = 0; k <= N; k++)
+        if (((b->st[k].bmask & ~b->st[k].emask) >> NU) != 0) b->xbox = 1;
+    if (b->use_box)
+    {
+        char nm[160];
+        snprintf(nm, sizeof(nm), "1tpi-box<NX=%d,NU=%d,XBOX=%d>", NX, NU, b->xbox);
+        b->kname = nm;
+    }
     b->d_st = dalloc<GqpStage>(b, N + 1);
     HIPCHK(hipMemcpy(b->d_st, b->st.data(), sizeof(GqpStage) * (N + 1), hipMemcpyHostToDevice));
 
@@ -180,29 +201,31 @@ void finalize_structure(ocp_qp_gpu_batch *b)
     const size_t Bp = b->Bp;
     D.B = b->B; D.Bp = b->Bp; D.N = N; D.NX = NX; D.NU = NU; D.NG = b->ks->NG; D.NS = b->ks->NS;
     D.st = b->d_st;
-    D.BAt = dalloc<double>(b, (size_t) N * n * NX * Bp);
-    D.bvec = dalloc<double>(b, (size_t) N * NX * Bp);
+    const size_t RP = 16; /* spare row elements (clamped dummy row index) */
+    D.BAt = dalloc<double>(b, (size_t) (N + 1) * n * NX * Bp);
+    D.bvec = dalloc<double>(b, (size_t) (N + 1) * NX * Bp);
     D.RSQ = dalloc<double>(b, (size_t) (N + 1) * NP * Bp);
     D.rq = dalloc<double>(b, (size_t) (N + 1) * n * Bp);
-    D.dvec = dalloc<double>(b, (size_t) o_ct * Bp);
+    D.dvec = dalloc<double>(b, (size_t) (o_ct + RP) * Bp);
     D.amask = dalloc<uint64_t>(b, (size_t) (N + 1) * Bp);
     D.DCt = dalloc<double>(b, (size_t) o_g * n * Bp);
     D.Zz = dalloc<double>(b, (size_t) o_s * 2 * Bp);
-    D.ux = dalloc<double>(b, (size_t) (N + 1) * n * Bp);
+    D.ux = dalloc<double>(b, (size_t) (N + 2) * n * Bp);
     D.sv = dalloc<double>(b, (size_t) o_s * Bp);
-    D.pi = dalloc<double>(b, (size_t) N * NX * Bp);
-    D.lam = dalloc<double>(b, (size_t) o_ct * Bp);
-    D.t = dalloc<double>(b, (size_t) o_ct * Bp);
+    D.pi = dalloc<double>(b, (size_t) (N + 2) * NX * Bp);
+    D.lam = dalloc<double>(b, (size_t) (o_ct + RP) * Bp);
+    D.t = dalloc<double>(b, (size_t) (o_ct + RP) * Bp);
     D.rg = dalloc<double>(b, (size_t) (N + 1) * n * Bp);
     D.rgs = dalloc<double>(b, (size_t) o_s * Bp);
-    D.rb = dalloc<double>(b, (size_t) N * NX * Bp);
-    D.rd = dalloc<double>(b, (size_t) o_ct * Bp);
-    D.rm = dalloc<double>(b, (size_t) o_ct * Bp);
-    D.dux = dalloc<double>(b, (size_t) (N + 1) * n * Bp);
+    D.rb = dalloc<double>(b, (size_t) (N + 1) * NX * Bp);
+    D.rd = dalloc<double>(b, (size_t) (o_ct + RP) * Bp);
+    D.rm = dalloc<double>(b, (size_t) (o_ct + RP) * Bp);
+    D.dux = dalloc<double>(b, (size_t) (N + 2) * n * Bp);
     D.dsv = dalloc<double>(b, (size_t) o_s * Bp);
-    D.dpi = dalloc<double>(b, (size_t) N * NX * Bp);
-    D.dlam = dalloc<double>(b, (size_t) o_ct * Bp);
-    D.dt = dalloc<double>(b, (size_t) o_ct * Bp);
+    D.dpi = dalloc<double>(b, (size_t) (N + 2) * NX * Bp);
+    D.dlam = dalloc<double>(b, (size_t) (o_ct + RP) * Bp);
+    D.dt = dalloc<double>(b, (size_t) (o_ct + RP) * Bp);
+    D.pcorr = dalloc<double>(b, (size_t) (o_ct + RP) * Bp);
     D.sD = dalloc<double>(b, (size_t) o_s * Bp);
     D.sR = dalloc<double>(b, (size_t) o_s * Bp);
     D.Lf = dalloc<double>(b, (size_t) (N + 1) * NP * Bp);
@@ -349,8 +372,8 @@ int field_map(ocp_qp_gpu_batch *b, const char *f, int k, std::vector<int> &map, 
     else if (!strcmp(f, "pi"))
     {
         if (!dyn()) return -1;
-        *arr = D.pi;
-        for (int r = 0; r < nx1; r++) map.push_back(k * NX + r);
+        *arr = D.pi; /* acados pi[k] = multiplier of the dynamics producing x_{k+1}: slot k+1 */
+        for (int r = 0; r < nx1; r++) map.push_back((k + 1) * NX + r);
     }
     else if (!strcmp(f, "lam") || !strcmp(f, "t"))
     {
@@ -609,6 +632,12 @@ int ocp_qp_gpu_batch_solve(ocp_qp_gpu_batch *b)
     finalize_structure(b);
     ensure_stat(b);
     const KernelSet *ks = b->ks;
+    const int xb = b->xbox;
+    const kern_redo_t k_fact = b->use_box ? ks->box_fact[xb] : ks->back_fact;
+    const kern_redo_t k_rhs = b->use_box ? ks->box_rhs[xb] : ks->back_rhs;
+    const kern_redo_t k_faff = b->use_box ? ks->box_fwd_aff[xb] : ks->fwd_aff;
+    const kern_redo_t k_fcorr = b->use_box ? ks->box_fwd_corr[xb] : ks->fwd_corr;
+    const kern_plain_t k_final = b->use_box ? ks->box_finalize : ks->finalize;
     GqpDev D = b->D;
     GqpOpts O = b->O;
     const dim3 grid((b->B + 63) / 64), block(64);
@@ -657,7 +686,7 @@ int ocp_qp_gpu_batch_solve(ocp_qp_gpu_batch *b)
     for (;; it++)
     {
         prof_begin(1);
-        hipLaunchKernelGGL(ks->back_fact, grid, block, 0, s, D, O, 0);
+        hipLaunchKernelGGL(k_fact, grid, block, 0, s, D, O, 0);
         prof_end();
         b->launches++;
         HIPCHK(hipMemcpyAsync(b->h_nact, D.n_active, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -665,23 +694,23 @@ int ocp_qp_gpu_batch_solve(ocp_qp_gpu_batch *b)
         if (b->print_level > 1) printf("acados_amd: ipm iter %d active %d\n", it, *b->h_nact);
         if (*b->h_nact <= 0 || it > O.iter_max) break;
         prof_begin(2);
-        hipLaunchKernelGGL(ks->fwd_aff, grid, block, 0, s, D, O, 0);
+        hipLaunchKernelGGL(k_faff, grid, block, 0, s, D, O, 0);
         prof_end();
         prof_begin(3);
-        hipLaunchKernelGGL(ks->back_rhs, grid, block, 0, s, D, O, 0);
+        hipLaunchKernelGGL(k_rhs, grid, block, 0, s, D, O, 0);
         prof_end();
         prof_begin(4);
-        hipLaunchKernelGGL(ks->fwd_corr, grid, block, 0, s, D, O, 0);
+        hipLaunchKernelGGL(k_fcorr, grid, block, 0, s, D, O, 0);
         prof_end();
         b->launches += 3;
         if (O.cond_pred_corr)
         {
-            hipLaunchKernelGGL(ks->back_rhs, grid, block, 0, s, D, O, 1);
-            hipLaunchKernelGGL(ks->fwd_corr, grid, block, 0, s, D, O, 1);
+            hipLaunchKernelGGL(k_rhs, grid, block, 0, s, D, O, 1);
+            hipLaunchKernelGGL(k_fcorr, grid, block, 0, s, D, O, 1);
             b->launches += 2;
         }
     }
-    hipLaunchKernelGGL(ks->finalize, grid, block, 0, s, D);
+    hipLaunchKernelGGL(k_final, grid, block, 0, s, D);
     b->launches++;
     HIPCHK(hipEventRecord(b->ev1, s));
     HIPCHK(hipStreamSynchronize(s));

@@ -45,8 +45,14 @@ struct GqpDev
     int B, Bp, N, NX, NU, NG, NS;
     const GqpStage *st; /* N+1 entries */
     /* problem data */
-    double *BAt;   /* [N][n*NX]   BAt[r*NX+c] = d x+_c / d v_r                      */
-    double *bvec;  /* [N][NX]                                                        */
+    /* Slot conventions that make the stage body uniform (no k<N / k>0 branches in the fast
+     * kernels): dynamics arrays have N+1 stage slots, slot N is all zero ("x_{N+1} = 0*x+0*u+0");
+     * pi/dpi have N+2 slots, slot s holds the multiplier of the dynamics that PRODUCE x_s
+     * (acados pi[k] lives in slot k+1), slots 0 and N+1 are zero; ux/dux have N+2 slots, slot
+     * N+1 zero; row arrays carry 16 spare elements so that a clamped dummy row index is
+     * always readable. */
+    double *BAt;   /* [N+1][n*NX]  BAt[r*NX+c] = d x+_c / d v_r                     */
+    double *bvec;  /* [N+1][NX]                                                      */
     double *RSQ;   /* [N+1][n(n+1)/2] packed lower, row-major packed: (r,c)->r(r+1)/2+c */
     double *rq;    /* [N+1][n]                                                       */
     double *dvec;  /* [sum nct] natural-sign bounds, order [lb lg ub ug lls lus]     */
@@ -54,13 +60,14 @@ struct GqpDev
     double *DCt;   /* [sum ng][n]  row g: d(general row)/d v                         */
     double *Zz;    /* [sum 2ns][2]: (Z, z) for sl then su                            */
     /* iterate */
-    double *ux;    /* [N+1][n] */
+    double *ux;    /* [N+2][n] */
     double *sv;    /* [sum 2ns] slack values sl then su */
-    double *pi;    /* [N][NX] */
+    double *pi;    /* [N+2][NX], see slot conventions */
     double *lam, *t; /* [sum nct] */
     /* work */
     double *rg, *rgs, *rb, *rd, *rm;
     double *dux, *dsv, *dpi, *dlam, *dt;
+    double *pcorr; /* [sum nct] dlam_aff*dt_aff of the affine step (fast path stores only the product) */
     double *sD, *sR; /* [sum 2ns] per-slack D = Z + sum Gamma and r~ (condensed slack rhs) */
     double *Lf;    /* [N+1][n(n+1)/2] Cholesky factors */
     double *lf;    /* [N+1][n] */

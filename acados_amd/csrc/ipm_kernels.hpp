@@ -29,7 +29,9 @@
 #include "gpu_ipm_internal.h"
 
 #define PK(r, c) ((((r) * ((r) + 1)) >> 1) + (c))
-#define GAT(arr, e) (arr)[(size_t) (e) * (size_t) Bp + (size_t) i]
+/* uniform (scalar) base pointer + 32-bit per-lane offset: selects the saddr form of global_load /
+ * global_store, so no per-element 64-bit address lives in VGPRs */
+/* GAT defined below, after gat_ref */
 
 #if defined(GQP_NO_UNROLL)
 #define UNROLL _Pragma("unroll 1")
@@ -39,6 +41,15 @@
 
 namespace gqp
 {
+
+template <class T>
+__device__ static inline T &gat_ref(T *base, unsigned int byte_off)
+{
+    /* base is wave-uniform (kernel argument + stage/element offset), byte_off is the only
+     * per-lane part and is a 32-bit BYTE offset: exactly the saddr + voffset operand pair */
+    return *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_off);
+}
+#define GAT(arr, e) gat_ref((arr) + (size_t) (e) * (size_t) Bp, (unsigned int) i * (unsigned int) sizeof(*(arr)))
 
 __device__ static inline double dmax(double a, double b) { return a > b ? a : b; }
 __device__ static inline double dabs(double a) { return a < 0.0 ? -a : a; }
@@ -92,7 +103,7 @@ __global__ void __launch_bounds__(64) k_init(GqpDev D, GqpOpts O)
             ib++;
         }
         UNROLL for (int j = 0; j < n; j++) GAT(D.ux, k * n + j) = v[j];
-        if (S.has_dyn) { UNROLL for (int c = 0; c < NX; c++) GAT(D.pi, k * NX + c) = 0.0; }
+        if (S.has_dyn) { UNROLL for (int c = 0; c < NX; c++) GAT(D.pi, (k + 1) * NX + c) = 0.0; }
         /* slacks */
         double sl[NS > 0 ? NS : 1], su[NS > 0 ? NS : 1];
         if (NS > 0)
@@ -266,7 +277,7 @@ __global__ void __launch_bounds__(64) k_backward(GqpDev D, GqpOpts O, int redo)
                 obj += (0.5 * hv[r] + g) * v[r];
                 gt[r] = hv[r] + g;
             }
-            if (k > 0) { UNROLL for (int c = 0; c < NX; c++) gt[NU + c] -= GAT(D.pi, (k - 1) * NX + c); }
+            if (k > 0) { UNROLL for (int c = 0; c < NX; c++) gt[NU + c] -= GAT(D.pi, k * NX + c); }
             UNROLL for (int r = 0; r < n; r++) M[PK(r, r)] += O.reg_prim;
         }
         else
@@ -284,7 +295,7 @@ __global__ void __launch_bounds__(64) k_backward(GqpDev D, GqpOpts O, int redo)
                 double pin[NX];
                 UNROLL for (int c = 0; c < NX; c++)
                 {
-                    pin[c] = GAT(D.pi, k * NX + c);
+                    pin[c] = GAT(D.pi, (k + 1) * NX + c);
                     rb[c] = GAT(D.bvec, k * NX + c) - GAT(D.ux, (k + 1) * n + NU + c);
                 }
                 double W[n * NX];
@@ -718,7 +729,7 @@ __global__ void __launch_bounds__(64) k_forward(GqpDev D, GqpOpts O, int redo)
             {
                 double a = 0.0;
                 UNROLL for (int c = 0; c <= r; c++) a += L[PK(NU + r, NU + c)] * w0[c];
-                GAT(D.dpi, (k - 1) * NX + r) = a;
+                GAT(D.dpi, k * NX + r) = a;
             }
             UNROLL for (int c = 0; c < NX; c++) dv[NU + c] = dx[c];
         }
@@ -895,7 +906,7 @@ __global__ void __launch_bounds__(64) k_forward(GqpDev D, GqpOpts O, int redo)
             const int nct = 2 * (S.nb + S.ng) + 2 * S.ns;
             const uint64_t am = GAT(D.amask, k);
             UNROLL for (int j = 0; j < n; j++) GAT(D.ux, k * n + j) += a * GAT(D.dux, k * n + j);
-            if (S.has_dyn) { UNROLL for (int c = 0; c < NX; c++) GAT(D.pi, k * NX + c) += a * GAT(D.dpi, k * NX + c); }
+            if (S.has_dyn) { UNROLL for (int c = 0; c < NX; c++) GAT(D.pi, (k + 1) * NX + c) += a * GAT(D.dpi, (k + 1) * NX + c); }
             for (int q = 0; q < 2 * S.ns; q++) GAT(D.sv, S.o_s + q) += a * GAT(D.dsv, S.o_s + q);
             for (int e = 0; e < nct; e++)
                 if ((am >> e) & 1)

@@ -20,6 +20,7 @@
 #define __device__
 #define __host__
 #define __forceinline__ inline
+#define __shared__ static /* one simulated lane at a time: a lane only reads what it wrote */
 #define __launch_bounds__(...)
 
 struct dim3

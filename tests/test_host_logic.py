@@ -89,9 +89,26 @@ def test_mass_spring_and_padding_hostsim(hostsim_lib):
         b = OcpQpGpuBatch.from_qps([qp], _clib=hostsim_lib)
         b.opts_set("tol_stat", 1e-8)
         assert b.solve() == 0
-        assert b.kernel_name == "1tpi<NX=8,NU=3,NG=0,NS=0>"
+        assert b.kernel_name == "1tpi-box<NX=8,NU=3,XBOX=1>"
         compare_with_oracle(lambda k, f: b.get(f, k)[0], o, qp, 1e-9)
         assert max(b.info(n).max() for n in ("res_stat", "res_eq", "res_ineq", "res_comp")) <= 1e-8
+
+
+def test_general_kernels_on_box_qps_hostsim(hostsim_lib, monkeypatch):
+    """box-only QPs are normally served by the fast-path kernels; the general kernels must give
+    the same answer (ACADOS_AMD_GENERAL_KERNELS=1 is a debugging switch of the library)"""
+    from acados_amd import OcpQpGpuBatch
+    from acados_amd.generators import mass_spring_qp
+    qp = mass_spring_qp(N=10)
+    fast = OcpQpGpuBatch.from_qps([qp], _clib=hostsim_lib)
+    assert fast.solve() == 0 and fast.kernel_name.startswith("1tpi-box")
+    monkeypatch.setenv("ACADOS_AMD_GENERAL_KERNELS", "1")
+    gen = OcpQpGpuBatch.from_qps([qp], _clib=hostsim_lib)
+    assert gen.solve() == 0 and gen.kernel_name == "1tpi<NX=8,NU=3,NG=0,NS=0>"
+    for k in range(qp.N + 1):
+        for f in ("x", "u", "lam", "t") + (("pi",) if k < qp.N else ()):
+            assert np.allclose(fast.get(f, k), gen.get(f, k), rtol=1e-10, atol=1e-12), (f, k)
+    assert fast.info("iter")[0] == gen.info("iter")[0]
 
 
 def test_lqr_batch_and_ragged_hostsim(hostsim_lib):
