@@ -17,6 +17,7 @@
 #include "gpu_ipm_internal.h"
 #include "ipm_kernels.hpp"
 #include "ipm_kernels_box.hpp"
+#include "kernel_sets.h"
 
 #define HIPCHK(x)                                                                              \
     do {                                                                                       \
@@ -30,31 +31,6 @@
 
 namespace
 {
-
-typedef void (*kern_opts_t)(GqpDev, GqpOpts);
-typedef void (*kern_redo_t)(GqpDev, GqpOpts, int);
-typedef void (*kern_plain_t)(GqpDev);
-
-struct KernelSet
-{
-    int NX, NU, NG, NS;
-    kern_opts_t init;
-    kern_redo_t back_fact, back_rhs, fwd_aff, fwd_corr;
-    kern_plain_t finalize;
-    /* fast path for box-only QPs (ipm_kernels_box.hpp); index = XBOX (any box row on a state) */
-    kern_redo_t box_fact[2], box_rhs[2], box_fwd_aff[2], box_fwd_corr[2];
-    kern_plain_t box_finalize;
-};
-
-#define GQP_KSET(NX, NU, NG, NS)                                                               \
-    {NX, NU, NG, NS, gqp::k_init<NX, NU, NG, NS>, gqp::k_backward<NX, NU, NG, NS, true>,       \
-     gqp::k_backward<NX, NU, NG, NS, false>, gqp::k_forward<NX, NU, NG, NS, false>,            \
-     gqp::k_forward<NX, NU, NG, NS, true>, gqp::k_finalize<NX, NU, NG, NS>,                    \
-     {gqp::kb_factor<NX, NU, false>, gqp::kb_factor<NX, NU, true>},                            \
-     {gqp::kb_backrhs<NX, NU, false>, gqp::kb_backrhs<NX, NU, true>},                          \
-     {gqp::kb_forward<NX, NU, false, false>, gqp::kb_forward<NX, NU, true, false>},            \
-     {gqp::kb_forward<NX, NU, false, true>, gqp::kb_forward<NX, NU, true, true>},              \
-     gqp::kb_finalize<NX, NU>}
 
 /* compiled shape classes; a batch is served by the cheapest one that covers it */
 const KernelSet g_ksets[] = {
@@ -471,13 +447,14 @@ ocp_qp_gpu_batch *ocp_qp_gpu_batch_create(int N, const int *nx, const int *nu, c
         b->idxe.push_back(std::vector<int>());
     }
     double best = 1e300;
-    for (const KernelSet &ks : g_ksets)
-    {
-        if (ks.NX < mx || ks.NU < mu || ks.NG < mg || ks.NS < ms) continue;
+    auto consider = [&](const KernelSet &ks) {
+        if (ks.NX < mx || ks.NU < mu || ks.NG < mg || ks.NS < ms) return;
         const double n = ks.NX + ks.NU;
         const double cost = n * n * n + 10.0 * (ks.NG + ks.NS) * n * n;
         if (cost < best) { best = cost; b->ks = &ks; }
-    }
+    };
+    for (const KernelSet &ks : g_ksets) consider(ks);
+    for (int q = 0; q < g_n_ksets_large; q++) consider(g_ksets_large[q]);
     if (!b->ks)
     {
         fprintf(stderr, "acados_amd: no kernel instantiation covers nx<=%d nu<=%d ng<=%d ns<=%d\n", mx, mu, mg, ms);

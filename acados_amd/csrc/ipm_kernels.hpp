@@ -983,7 +983,7 @@ __global__ void __launch_bounds__(64) k_finalize(GqpDev D)
 /* -------------------------------------------- layout conversion kernels */
 
 /* dst[(map[e]) * Bp + i] = src[i * len + e]  (map[e] < 0: element dropped) */
-__global__ void k_scatter(const double *src, int nb, int len, const int *map, double *dst, int Bp)
+static __global__ void k_scatter(const double *src, int nb, int len, const int *map, double *dst, int Bp)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nb) return;
@@ -995,7 +995,7 @@ __global__ void k_scatter(const double *src, int nb, int len, const int *map, do
 }
 
 /* dst[i * len + e] = src[(map[e]) * Bp + i]  (map[e] < 0: 0) */
-__global__ void k_gather(double *dst, int nb, int len, const int *map, const double *src, int Bp)
+static __global__ void k_gather(double *dst, int nb, int len, const int *map, const double *src, int Bp)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nb) return;
@@ -1008,7 +1008,7 @@ __global__ void k_gather(double *dst, int nb, int len, const int *map, const dou
 
 /* activity bit masks: for every element e of a (lower|upper|slack) mask vector handed
  * over by the caller, set or clear bit bitpos[e] of amask[stage] */
-__global__ void k_setmask(const double *src, int nb, int len, const int *bitpos, uint64_t *amask_stage)
+static __global__ void k_setmask(const double *src, int nb, int len, const int *bitpos, uint64_t *amask_stage)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nb) return;
@@ -1023,13 +1023,13 @@ __global__ void k_setmask(const double *src, int nb, int len, const int *bitpos,
     amask_stage[i] = m;
 }
 
-__global__ void k_fill_u64(uint64_t *dst, uint64_t val, size_t cnt)
+static __global__ void k_fill_u64(uint64_t *dst, uint64_t val, size_t cnt)
 {
     const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i < cnt) dst[i] = val;
 }
 
-__global__ void k_fill_strided(double *dst, double val, int nb, int Bp, int e)
+static __global__ void k_fill_strided(double *dst, double val, int nb, int Bp, int e)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < nb) dst[(size_t) e * Bp + i] = val;

@@ -188,7 +188,9 @@ __global__ void __launch_bounds__(64) kb_factor(GqpDev D, GqpOpts O, int redo)
      * coexist with the Hessian, and keeping both in VGPRs pushed the kernel into scratch.
      * The read index goes through an opaque move so that hipcc does not forward the stored
      * values straight back into registers. */
-    __shared__ double Wl[NX * NX * 64];
+    constexpr bool W_IN_LDS = NX * NX * 64 * 8 <= 40 * 1024; /* 4 single-wave blocks per CU must fit */
+    __shared__ double Wl[W_IN_LDS ? NX * NX * 64 : 1];
+    double Wx[W_IN_LDS ? 1 : NX * NX]; /* larger shapes: per-lane block (scratch, see kernel_sets.h) */
     const int lane_w = threadIdx.x;
     int lane_r = threadIdx.x;
     GQP_OPAQUE(lane_r);
@@ -236,7 +238,8 @@ __global__ void __launch_bounds__(64) kb_factor(GqpDev D, GqpOpts O, int redo)
                 double w = 0.0;
                 UNROLL for (int q = c; q < NX; q++) w += row[q] * Lx[PK(q, c)];
                 if (r < NU) Wu[(r < NU ? r : 0) * NX + c] = w;
-                else Wl[(((r < NU ? NU : r) - NU) * NX + c) * 64 + lane_w] = w;
+                else if (W_IN_LDS) Wl[W_IN_LDS ? (((r < NU ? NU : r) - NU) * NX + c) * 64 + lane_w : 0] = w;
+                else Wx[W_IN_LDS ? 0 : ((r < NU ? NU : r) - NU) * NX + c] = w;
             }
         }
         /* w0 = Lx+' rb + lx+ (needs the final rb) */
@@ -322,7 +325,9 @@ __global__ void __launch_bounds__(64) kb_factor(GqpDev D, GqpOpts O, int redo)
         {
             double wr[NX];
             UNROLL for (int q = 0; q < NX; q++)
-                wr[q] = r < NU ? Wu[(r < NU ? r : 0) * NX + q] : Wl[(((r < NU ? NU : r) - NU) * NX + q) * 64 + lane_r];
+                wr[q] = r < NU ? Wu[(r < NU ? r : 0) * NX + q]
+                      : W_IN_LDS ? Wl[W_IN_LDS ? (((r < NU ? NU : r) - NU) * NX + q) * 64 + lane_r : 0]
+                                 : Wx[W_IN_LDS ? 0 : ((r < NU ? NU : r) - NU) * NX + q];
             double a = 0.0;
             UNROLL for (int c = 0; c < NX; c++) a += wr[c] * w0[c];
             gt[r] += a;
@@ -331,7 +336,9 @@ __global__ void __launch_bounds__(64) kb_factor(GqpDev D, GqpOpts O, int redo)
                 double s = 0.0;
                 UNROLL for (int q = 0; q < NX; q++)
                 {
-                    const double wc = c < NU ? Wu[(c < NU ? c : 0) * NX + q] : Wl[(((c < NU ? NU : c) - NU) * NX + q) * 64 + lane_r];
+                    const double wc = c < NU ? Wu[(c < NU ? c : 0) * NX + q]
+                                    : W_IN_LDS ? Wl[W_IN_LDS ? (((c < NU ? NU : c) - NU) * NX + q) * 64 + lane_r : 0]
+                                               : Wx[W_IN_LDS ? 0 : ((c < NU ? NU : c) - NU) * NX + q];
                     s += wr[q] * wc;
                 }
                 M[PK(r, c)] += s;

@@ -1,0 +1,41 @@
+/*
+ * kernel_sets.h -- table of compiled kernel instantiations ("shape classes").
+ * Small shapes are fully unrolled (register-resident stage blocks, gpu_batch.hip); large shapes
+ * are compiled in their own translation unit with rolled loops (gpu_shapes_large.hip): their stage
+ * blocks do not fit the register file of a one-instance-per-lane mapping and live in scratch --
+ * correct and covered by the parity tests, but not the design point for those shapes.
+ */
+#ifndef KERNEL_SETS_H_
+#define KERNEL_SETS_H_
+
+#include "gpu_ipm_internal.h"
+
+typedef void (*kern_opts_t)(GqpDev, GqpOpts);
+typedef void (*kern_redo_t)(GqpDev, GqpOpts, int);
+typedef void (*kern_plain_t)(GqpDev);
+
+struct KernelSet
+{
+    int NX, NU, NG, NS;
+    kern_opts_t init;
+    kern_redo_t back_fact, back_rhs, fwd_aff, fwd_corr;
+    kern_plain_t finalize;
+    /* fast path for box-only QPs (ipm_kernels_box.hpp); index = XBOX (any box row on a state) */
+    kern_redo_t box_fact[2], box_rhs[2], box_fwd_aff[2], box_fwd_corr[2];
+    kern_plain_t box_finalize;
+};
+
+#define GQP_KSET(NX, NU, NG, NS)                                                               \
+    {NX, NU, NG, NS, gqp::k_init<NX, NU, NG, NS>, gqp::k_backward<NX, NU, NG, NS, true>,       \
+     gqp::k_backward<NX, NU, NG, NS, false>, gqp::k_forward<NX, NU, NG, NS, false>,            \
+     gqp::k_forward<NX, NU, NG, NS, true>, gqp::k_finalize<NX, NU, NG, NS>,                    \
+     {gqp::kb_factor<NX, NU, false>, gqp::kb_factor<NX, NU, true>},                            \
+     {gqp::kb_backrhs<NX, NU, false>, gqp::kb_backrhs<NX, NU, true>},                          \
+     {gqp::kb_forward<NX, NU, false, false>, gqp::kb_forward<NX, NU, true, false>},            \
+     {gqp::kb_forward<NX, NU, false, true>, gqp::kb_forward<NX, NU, true, true>},              \
+     gqp::kb_finalize<NX, NU>}
+
+extern const KernelSet g_ksets_large[];
+extern const int g_n_ksets_large;
+
+#endif

@@ -142,3 +142,79 @@ def fill_lqr_batch(gb, data, N, xp=None):
     x0 = blk(data["x0"])
     gb.set("lbx", 0, x0)
     gb.set("ubx", 0, x0)
+
+
+def chain_soft_qp(i=0, N=40, nx=24, nu=3, seed=1):
+    """Configuration C4, instance i: chain-like linearisation data with
+    hard input bounds, 4 soft state bounds, 4 soft general rows, ns = 8 slacks
+    (idxs_rev: soft x-bounds -> slacks 0..3, general rows -> slacks 4..7), Z = 1e2, z = 1e1,
+    x0 as equality bound at stage 0.  Stage 0 carries no soft rows (all 24 states are
+    equality rows there; this backend addresses at most 64 inequality sides per stage)."""
+    g = np.random.Generator(np.random.Philox(key=[int(seed), 1000 + int(i)]))
+    T = -2.0 * np.eye(nx) + np.eye(nx, k=1) + np.eye(nx, k=-1)
+    A = np.eye(nx) + 0.1 * T + 0.01 * g.standard_normal((nx, nx))
+    B = np.zeros((nx, nu))
+    B[nx - nu:, :] = 0.1 * np.eye(nu)
+    B += 0.01 * g.standard_normal((nx, nu))
+    Q = np.diag(g.uniform(0.1, 10.0, nx))
+    R = np.diag(g.uniform(0.01, 1.0, nu))
+    x0 = g.uniform(-1.0, 1.0, nx)
+    ng, nsx = 4, 4
+    ixs = nu + 6 * np.arange(nsx) + 1            # wall constraint on the "y positions"
+    qp = AcadosOcpQp(N)
+    for k in range(N + 1):
+        last = k == N
+        nuk = 0 if last else nu
+        qp.set("Q", k, Q); qp.set("q", k, Q @ (0.1 * g.standard_normal(nx)))
+        qp.set("R", k, R[:nuk, :nuk]); qp.set("r", k, (R @ (0.1 * g.standard_normal(nu)))[:nuk])
+        qp.set("S", k, np.zeros((nuk, nx)))
+        if not last:
+            qp.set("A", k, A); qp.set("B", k, B); qp.set("b", k, 0.01 * g.standard_normal(nx))
+        qp.set("lbu", k, -1.0 * np.ones(nuk)); qp.set("ubu", k, 1.0 * np.ones(nuk))
+        if k == 0:
+            qp.set("lbx", k, x0); qp.set("ubx", k, x0)
+            qp.set("idxb", k, np.arange(nu + nx)); qp.set("idxe", k, nu + np.arange(nx))
+            continue
+        C = g.standard_normal((ng, nx)) / np.sqrt(nx)
+        D = g.standard_normal((ng, nuk)) / np.sqrt(nu)
+        qp.set("C", k, C); qp.set("D", k, D)
+        qp.set("lg", k, -0.5 * np.ones(ng)); qp.set("ug", k, 0.5 * np.ones(ng))
+        qp.set("lbx", k, -0.3 * np.ones(nsx)); qp.set("ubx", k, 0.3 * np.ones(nsx))
+        qp.set("idxb", k, np.concatenate([np.arange(nuk), (ixs - nu) + nuk]))
+        qp.set("idxs_rev", k, np.concatenate([-np.ones(nuk, dtype=int), np.arange(nsx), nsx + np.arange(ng)]))
+        ns = nsx + ng
+        qp.set("Zl", k, 1e2 * np.ones(ns)); qp.set("Zu", k, 1e2 * np.ones(ns))
+        qp.set("zl", k, 1e1 * np.ones(ns)); qp.set("zu", k, 1e1 * np.ones(ns))
+        qp.set("lls", k, np.zeros(ns)); qp.set("lus", k, np.zeros(ns))
+    qp.make_consistent()
+    return qp
+
+
+C5_CLASSES = [(nx, int(np.ceil(nx / 4)), N) for nx in (4, 12, 24) for N in (20, 50, 100)]
+
+
+def multiphase_qp(i=0, N=20, nx_a=12, nx_b=4, nu=3, seed=2):
+    """C5 "multi-phase" class: the state dimension switches nx_a -> nx_b at k = N/2 through a
+    non-square A (nx_b x nx_a); exercises per-stage dims inside one padded kernel shape."""
+    g = np.random.Generator(np.random.Philox(key=[int(seed), 2000 + int(i)]))
+    ks = N // 2
+    qp = AcadosOcpQp(N)
+    x0 = g.uniform(-1.0, 1.0, nx_a)
+    for k in range(N + 1):
+        nx = nx_a if k <= ks else nx_b
+        nx1 = nx_a if k + 1 <= ks else nx_b
+        last = k == N
+        nuk = 0 if last else nu
+        G = g.standard_normal((nx, nx)) / np.sqrt(nx)
+        qp.set("Q", k, np.eye(nx) + 0.1 * G @ G.T); qp.set("q", k, 0.1 * g.standard_normal(nx))
+        qp.set("R", k, 2.0 * np.eye(nuk)); qp.set("r", k, 0.1 * g.standard_normal(nuk))
+        qp.set("S", k, 0.05 * g.standard_normal((nuk, nx)))
+        if not last:
+            A = 0.9 * np.eye(nx1, nx) + 0.02 * g.uniform(-1, 1, (nx1, nx))
+            qp.set("A", k, A); qp.set("B", k, 0.3 * g.uniform(-1, 1, (nx1, nuk))); qp.set("b", k, 0.1 * g.uniform(-1, 1, nx1))
+        qp.set("lbu", k, -0.5 * np.ones(nuk)); qp.set("ubu", k, 0.5 * np.ones(nuk))
+        if k == 0:
+            qp.set("lbx", k, x0); qp.set("ubx", k, x0)
+            qp.set("idxb", k, np.arange(nuk + nx)); qp.set("idxe", k, nuk + np.arange(nx))
+    qp.make_consistent()
+    return qp

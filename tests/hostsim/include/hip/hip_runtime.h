@@ -28,7 +28,7 @@ struct dim3
     unsigned x, y, z;
     dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
-static thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+inline thread_local dim3 threadIdx, blockIdx, blockDim, gridDim; /* one copy across translation units */
 
 typedef int hipError_t;
 #define hipSuccess 0

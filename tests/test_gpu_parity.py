@@ -143,6 +143,45 @@ def test_full_size_properties_gpu(gpu_lib):
     assert np.array_equal(gs.get("u", 0), u0_big)   # batch size must not change any instance's bits
 
 
+def _check_batch_vs_oracle_gpu(qps, n_check, tol=1e-8):
+    from acados_amd import OcpQpGpuBatch
+    b = OcpQpGpuBatch.from_qps(qps)
+    for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+        b.opts_set(f, 1e-8)
+    assert b.solve() == 0
+    for i in np.linspace(0, len(qps) - 1, n_check).astype(int):
+        o = OracleQp(qps[i])
+        assert o.solve(default_opts(tol_stat=1e-8)) == 0
+        compare_with_oracle(lambda k, f: b.get(f, k)[i], o, qps[i], tol)
+    assert max(b.info(n).max() for n in ("res_stat", "res_eq", "res_ineq", "res_comp")) <= 1e-8
+    return b
+
+
+def test_c4_chain_soft_constraints_gpu(gpu_lib):
+    """C4 shape: N=40 nx=24 nu=3, hard input bounds, soft state bounds, soft general rows, ns=8"""
+    from acados_amd.generators import chain_soft_qp
+    b = _check_batch_vs_oracle_gpu([chain_soft_qp(i, N=40) for i in range(96)], 4)
+    assert b.kernel_name == "1tpi<NX=24,NU=3,NG=4,NS=8>"
+
+
+def test_c5_mixed_shape_classes_gpu(gpu_lib):
+    """C5: the 9 shape classes (nx in {4,12,24}, N in {20,50,100}) bucketed by dims.signature(),
+    plus the multi-phase class; every bucket is one device batch"""
+    from acados_amd.generators import C5_CLASSES, lqr_instance_qp, multiphase_qp, random_lqr_batch
+    buckets = {}
+    for (nx, nu, N) in C5_CLASSES:
+        data = random_lqr_batch(N=N, nx=nx, nu=nu, batch=70, seed=nx + N)
+        for i in range(70):
+            qp = lqr_instance_qp(data, i, N)
+            buckets.setdefault(qp.dims.signature(), []).append(qp)
+    for i in range(70):
+        qp = multiphase_qp(i, N=20)
+        buckets.setdefault(qp.dims.signature(), []).append(qp)
+    assert len(buckets) == 10
+    for sig, qps in buckets.items():
+        _check_batch_vs_oracle_gpu(qps, 2)
+
+
 def test_device_pointer_input_gpu(gpu_lib):
     """torch CUDA tensors handed over as raw device pointers give the same result as host arrays"""
     import torch

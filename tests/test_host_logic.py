@@ -155,3 +155,35 @@ def test_maxiter_status_hostsim(hostsim_lib):
     b.opts_set("tol_stat", 1e-12)
     assert b.solve() == 1
     assert b.info("status")[0] == 2 and b.info("iter")[0] == 2
+
+
+def _check_batch_vs_oracle(qps, lib, tol=1e-8):
+    from acados_amd import OcpQpGpuBatch
+    b = OcpQpGpuBatch.from_qps(qps, _clib=lib)
+    for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+        b.opts_set(f, 1e-8)
+    assert b.solve() == 0
+    for i, qp in enumerate(qps):
+        o = OracleQp(qp)
+        assert o.solve(default_opts(tol_stat=1e-8)) == 0
+        compare_with_oracle(lambda k, f: b.get(f, k)[i], o, qp, tol)
+        assert abs(int(b.info("iter")[i]) - o.iter) <= 1
+    return b
+
+
+def test_c4_shape_general_constraints_and_slacks_hostsim(hostsim_lib):
+    """C4 (nx=24, nu=3, soft state bounds + soft general rows, ns=8) at a short horizon"""
+    from acados_amd.generators import chain_soft_qp
+    b = _check_batch_vs_oracle([chain_soft_qp(i, N=6) for i in range(2)], hostsim_lib)
+    assert b.kernel_name == "1tpi<NX=24,NU=3,NG=4,NS=8>"
+
+
+def test_c5_shape_classes_and_multiphase_hostsim(hostsim_lib):
+    """C5: shape classes nx in {4,12,24} (nu = ceil(nx/4)) and the multi-phase class whose state
+    dimension switches 12 -> 4 mid-horizon (per-stage dims inside one padded kernel shape)"""
+    from acados_amd.generators import lqr_instance_qp, multiphase_qp, random_lqr_batch
+    for nx, nu in ((4, 1), (12, 3), (24, 6)):
+        data = random_lqr_batch(N=5, nx=nx, nu=nu, batch=2, seed=7)
+        _check_batch_vs_oracle([lqr_instance_qp(data, i, 5) for i in range(2)], hostsim_lib)
+    b = _check_batch_vs_oracle([multiphase_qp(i, N=8) for i in range(3)], hostsim_lib)
+    assert b.kernel_name.startswith("1tpi-box<NX=12,NU=3")
