@@ -22,6 +22,8 @@ def bind(L):
     L.ocp_qp_gpu_batch_set.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_int]
     L.ocp_qp_gpu_batch_opts_set.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
     L.ocp_qp_gpu_batch_solve.argtypes = [C.c_void_p]
+    L.ocp_qp_gpu_batch_condense_lhs.argtypes = [C.c_void_p]
+    L.ocp_qp_gpu_batch_condense_rhs_and_solve.argtypes = [C.c_void_p]
     L.ocp_qp_gpu_batch_get.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_int]
     L.ocp_qp_gpu_batch_get_info.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
     L.ocp_qp_gpu_batch_get_stat.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_int]

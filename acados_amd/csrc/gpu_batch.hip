@@ -36,6 +36,7 @@ namespace
 const KernelSet g_ksets[] = {
     GQP_KSET(4, 1, 0, 0),
     GQP_KSET(4, 1, 2, 3),
+    GQP_KSET(4, 4, 0, 0), /* child shape of (4,1) condensed in blocks of <= 4 */
     GQP_KSET(8, 3, 0, 0),
     GQP_KSET(12, 3, 0, 0),
 };
@@ -76,6 +77,16 @@ struct ocp_qp_gpu_batch
     double prof_ms[6] = {0, 0, 0, 0, 0, 0};
     int prof_cnt[6] = {0, 0, 0, 0, 0, 0};
     int stat_inst = 0, stat_rows = 0;
+    /* partial condensing (pcond_kernels.hpp) */
+    int cond_N = 0;                 /* requested N2; 0 or N = full space */
+    int force_NX = 0, force_NU = 0; /* child batches are pinned to the kernel shape the condense kernel writes */
+    int pcond_state = 0;            /* 0 unchecked, 1 active, -1 not applicable (message printed once) */
+    ocp_qp_gpu_batch *child = nullptr;
+    const PcondSet *pc = nullptr;
+    std::vector<int> blk_start;
+    gqp::PcondMap pmap;
+    double time_xcond = 0.0;
+    bool lhs_ready = false;         /* condense_lhs done: the next solve only condenses the vector part */
 };
 
 namespace
@@ -418,8 +429,17 @@ const double *stage_in(ocp_qp_gpu_batch *b, const double *data, size_t cnt, int 
 
 extern "C" {
 
+static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu, const int *nbx, const int *nbu,
+                                            const int *ng, const int *ns, int n_batch, int device, int force_NX, int force_NU);
+
 ocp_qp_gpu_batch *ocp_qp_gpu_batch_create(int N, const int *nx, const int *nu, const int *nbx, const int *nbu,
                                           const int *ng, const int *ns, int n_batch, int device)
+{
+    return batch_create_shape(N, nx, nu, nbx, nbu, ng, ns, n_batch, device, 0, 0);
+}
+
+static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu, const int *nbx, const int *nbu,
+                                            const int *ng, const int *ns, int n_batch, int device, int force_NX, int force_NU)
 {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -430,6 +450,7 @@ ocp_qp_gpu_batch *ocp_qp_gpu_batch_create(int N, const int *nx, const int *nu, c
     if (device >= 0) HIPCHK(hipSetDevice(device));
     ocp_qp_gpu_batch *b = new ocp_qp_gpu_batch();
     HIPCHK(hipGetDevice(&b->device));
+    b->force_NX = force_NX; b->force_NU = force_NU;
     b->B = n_batch;
     b->Bp = (n_batch + 63) / 64 * 64;
     b->N = N;
@@ -449,6 +470,7 @@ ocp_qp_gpu_batch *ocp_qp_gpu_batch_create(int N, const int *nx, const int *nu, c
     double best = 1e300;
     auto consider = [&](const KernelSet &ks) {
         if (ks.NX < mx || ks.NU < mu || ks.NG < mg || ks.NS < ms) return;
+        if (b->force_NX && (ks.NX != b->force_NX || ks.NU != b->force_NU || ks.NG || ks.NS)) return;
         const double n = ks.NX + ks.NU;
         const double cost = n * n * n + 10.0 * (ks.NG + ks.NS) * n * n;
         if (cost < best) { best = cost; b->ks = &ks; }
@@ -483,6 +505,7 @@ void ocp_qp_gpu_batch_destroy(ocp_qp_gpu_batch *b)
     (void) hipEventDestroy(b->ev1);
     for (hipEvent_t e : b->prof_ev) (void) hipEventDestroy(e);
     (void) hipStreamDestroy(b->stream);
+    if (b->child) ocp_qp_gpu_batch_destroy(b->child);
     delete b;
 }
 
@@ -576,6 +599,15 @@ int ocp_qp_gpu_batch_opts_set(ocp_qp_gpu_batch *b, const char *f, const void *v)
     else if (!strcmp(f, "cond_pred_corr")) o.cond_pred_corr = *i;
     else if (!strcmp(f, "print_level")) b->print_level = *i;
     else if (!strcmp(f, "profile")) b->profile = *i;
+    else if (!strcmp(f, "cond_N"))
+    {
+        if (*i != b->cond_N)
+        {
+            b->cond_N = *i;
+            b->pcond_state = 0;
+            if (b->child) { ocp_qp_gpu_batch_destroy(b->child); b->child = nullptr; }
+        }
+    }
     else if (!strcmp(f, "t0_init")) { /* single initialisation scheme (oracle-pinned) */ }
     else if (!strcmp(f, "ric_alg"))
     {
@@ -603,10 +635,145 @@ int ocp_qp_gpu_batch_opts_set(ocp_qp_gpu_batch *b, const char *f, const void *v)
     return 0;
 }
 
+
+/* ---- partial condensing (ocp_qp_partial_condensing.c:523-556, :664-689) ---- */
+static void pcond_setup(ocp_qp_gpu_batch *b)
+{
+    const int N = b->N, N2 = b->cond_N;
+    b->pcond_state = -1;
+    auto decline = [&](const char *why) {
+        fprintf(stderr, "acados_amd: cond_N=%d requested but %s; solving the full-space QP (N2 = N, the default of "
+                        "ocp_qp_partial_condensing.c:243-265) -- the solution is identical\n", N2, why);
+    };
+    if (N2 <= 0 || N2 >= N) return;
+    /* block sizes as d_part_cond_qp_compute_block_size: N/N2 each, remainder to the first blocks */
+    b->blk_start.assign(N2 + 1, 0);
+    int bsmax = 0;
+    for (int j = 0; j < N2; j++)
+    {
+        const int bs = N / N2 + (j < N % N2 ? 1 : 0);
+        b->blk_start[j + 1] = b->blk_start[j] + bs;
+        bsmax = std::max(bsmax, bs);
+    }
+    std::vector<char> is_start(N + 1, 0);
+    for (int j = 0; j <= N2; j++) is_start[b->blk_start[j]] = 1;
+    for (int k = 0; k <= N; k++)
+    {
+        if (b->ng[k] || b->ns[k]) { decline("the QP has general constraints or slacks (not condensed by this build)"); return; }
+        if (b->nbx[k] && !is_start[k]) { decline("state bounds inside a block would become general constraints (not condensed by this build)"); return; }
+    }
+    b->pc = nullptr;
+    for (int q = 0; q < g_n_pcond_sets; q++)
+        if (g_pcond_sets[q].NX == b->ks->NX && g_pcond_sets[q].NU == b->ks->NU && g_pcond_sets[q].BSMAX >= bsmax &&
+            (!b->pc || g_pcond_sets[q].BSMAX < b->pc->BSMAX))
+            b->pc = &g_pcond_sets[q];
+    if (!b->pc) { decline("no condensing kernel is compiled for this shape / block size"); return; }
+    const int NU = b->ks->NU, BS = b->pc->BSMAX;
+
+    /* child dims + structure */
+    std::vector<int> cnx(N2 + 1), cnu(N2 + 1), cnbx(N2 + 1), cnbu(N2 + 1), zero(N2 + 1, 0);
+    std::vector<std::vector<int>> cidxb(N2 + 1), row_kp(N2 + 1), row_op(N2 + 1);
+    std::vector<int> cidxe;
+    for (int j = 0; j <= N2; j++)
+    {
+        const int k0 = b->blk_start[j], k1 = j < N2 ? b->blk_start[j + 1] : N + 1;
+        cnx[j] = b->nx[k0];
+        cnu[j] = j < N2 ? (k1 - k0) * NU : 0;
+        for (int k = k0; k < (j < N2 ? k1 : k0); k++)
+            for (int r = 0; r < b->nbu[k]; r++)
+            {
+                cidxb[j].push_back((k - k0) * NU + b->idxb[k][r]);
+                row_kp[j].push_back(k); row_op[j].push_back(r);
+            }
+        cnbu[j] = (int) cidxb[j].size();
+        for (int r = 0; r < b->nbx[k0]; r++)
+        {
+            cidxb[j].push_back(cnu[j] + (b->idxb[k0][b->nbu[k0] + r] - b->nu[k0]));
+            row_kp[j].push_back(k0); row_op[j].push_back(b->nbu[k0] + r);
+        }
+        cnbx[j] = b->nbx[k0];
+        if (j == 0)
+            for (size_t e = 0; e < b->idxe[0].size(); e++) cidxe.push_back(cnbu[0] + (b->idxe[0][e] - b->nbu[0]));
+        if (j > 0 && !b->idxe[k0].empty()) { decline("equality-flagged bounds after stage 0"); return; }
+        if (j == N2 && b->nbu[N]) { decline("input bounds at the terminal stage"); return; }
+    }
+    ocp_qp_gpu_batch *c = batch_create_shape(N2, cnx.data(), cnu.data(), cnbx.data(), cnbu.data(), zero.data(), zero.data(),
+                                             b->B, b->device, b->ks->NX, BS * NU);
+    if (!c) { decline("the condensed shape has no kernel instantiation"); return; }
+    for (int j = 0; j <= N2; j++)
+        if (!cidxb[j].empty()) ocp_qp_gpu_batch_set_int(c, "idxb", j, cidxb[j].data(), (int) cidxb[j].size());
+    ocp_qp_gpu_batch_set_int(c, "idxe", 0, cidxe.data(), (int) cidxe.size());
+    finalize_structure(c);
+    /* row maps in the sorted (device) row order of both batches */
+    std::vector<int> h_off(N2 + 2, 0), h_kp, h_rp;
+    for (int j = 0; j <= N2; j++)
+    {
+        const int nb = (int) cidxb[j].size();
+        std::vector<int> kp(nb), rp(nb);
+        for (int oc = 0; oc < nb; oc++)
+        {
+            const int rc = c->perm[j][oc];
+            kp[rc] = row_kp[j][oc];
+            rp[rc] = b->perm[row_kp[j][oc]][row_op[j][oc]];
+        }
+        h_kp.insert(h_kp.end(), kp.begin(), kp.end());
+        h_rp.insert(h_rp.end(), rp.begin(), rp.end());
+        h_off[j + 1] = h_off[j] + nb;
+    }
+    int *d_start = dalloc<int>(b, N2 + 1), *d_kp = dalloc<int>(b, h_kp.size()), *d_rp = dalloc<int>(b, h_rp.size());
+    int *d_off = dalloc<int>(b, N2 + 2);
+    HIPCHK(hipMemcpy(d_start, b->blk_start.data(), sizeof(int) * (N2 + 1), hipMemcpyHostToDevice));
+    if (!h_kp.empty())
+    {
+        HIPCHK(hipMemcpy(d_kp, h_kp.data(), sizeof(int) * h_kp.size(), hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d_rp, h_rp.data(), sizeof(int) * h_rp.size(), hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipMemcpy(d_off, h_off.data(), sizeof(int) * (N2 + 2), hipMemcpyHostToDevice));
+    b->pmap.blk_start = d_start; b->pmap.row_kp = d_kp; b->pmap.row_rp = d_rp; b->pmap.row_off = d_off; b->pmap.N2 = N2;
+    b->child = c;
+    b->pcond_state = 1;
+}
+
+static int pcond_solve(ocp_qp_gpu_batch *b, int mode = 3)
+{
+    ocp_qp_gpu_batch *c = b->child;
+    b->pmap.mode = mode;
+    const dim3 grid((b->B + 63) / 64), block(64);
+    hipEvent_t e0, e1, e2, e3;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventCreate(&e2)); HIPCHK(hipEventCreate(&e3));
+    c->O = b->O;
+    c->print_level = b->print_level;
+    HIPCHK(hipEventRecord(e0, b->stream));
+    hipLaunchKernelGGL(b->pc->cond, grid, block, 0, b->stream, b->D, c->D, b->pmap);
+    HIPCHK(hipEventRecord(e1, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    const int bad = ocp_qp_gpu_batch_solve(c);
+    HIPCHK(hipEventRecord(e2, b->stream));
+    hipLaunchKernelGGL(b->pc->expand, grid, block, 0, b->stream, b->D, c->D, b->pmap);
+    HIPCHK(hipEventRecord(e3, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(hipGetLastError());
+    float m0 = 0.f, m1 = 0.f;
+    HIPCHK(hipEventElapsedTime(&m0, e0, e1));
+    HIPCHK(hipEventElapsedTime(&m1, e2, e3));
+    b->time_xcond = (m0 + m1) * 1e-3;
+    b->time_tot = c->time_tot + b->time_xcond;
+    b->last_iters = c->last_iters;
+    b->launches = c->launches + 2;
+    HIPCHK(hipEventDestroy(e0)); HIPCHK(hipEventDestroy(e1)); HIPCHK(hipEventDestroy(e2)); HIPCHK(hipEventDestroy(e3));
+    return bad;
+}
+
 int ocp_qp_gpu_batch_solve(ocp_qp_gpu_batch *b)
 {
     HIPCHK(hipSetDevice(b->device));
     finalize_structure(b);
+    if (b->cond_N > 0 && b->cond_N < b->N)
+    {
+        if (b->pcond_state == 0) pcond_setup(b);
+        if (b->pcond_state == 1) return pcond_solve(b, b->lhs_ready ? 2 : 3);
+    }
+    b->time_xcond = 0.0;
     ensure_stat(b);
     const KernelSet *ks = b->ks;
     const int xb = b->xbox;
@@ -766,6 +933,7 @@ int ocp_qp_gpu_batch_get_info(ocp_qp_gpu_batch *b, const char *f, void *data)
 int ocp_qp_gpu_batch_get_stat(ocp_qp_gpu_batch *b, int inst, double *stat, int max_rows)
 {
     HIPCHK(hipSetDevice(b->device));
+    if (b->pcond_state == 1 && b->child) return ocp_qp_gpu_batch_get_stat(b->child, inst, stat, max_rows);
     if (!b->D.stat || inst < 0 || inst >= b->stat_inst) return -1;
     const int rows = std::min(max_rows, b->stat_rows);
     std::vector<double> h((size_t) b->stat_rows * GQP_STAT_COLS * b->stat_inst);
@@ -782,6 +950,8 @@ double ocp_qp_gpu_batch_get_scalar(ocp_qp_gpu_batch *b, const char *f)
     if (!strcmp(f, "time_pack")) { double t = b->time_pack; b->time_pack = 0.0; return t; }
     if (!strcmp(f, "iter_max_batch")) return (double) b->last_iters;
     if (!strcmp(f, "launches")) return (double) b->launches;
+    if (!strcmp(f, "time_xcond")) return b->time_xcond;
+    if (!strcmp(f, "cond_N_active")) return b->pcond_state == 1 ? (double) b->cond_N : (double) b->N;
     {
         /* accumulated per-kernel-class event times (ms) and launch counts since the last reset */
         const char *cls[6] = {"init", "back_fact", "fwd_aff", "back_rhs", "fwd_corr", "finalize"};
@@ -801,6 +971,28 @@ double ocp_qp_gpu_batch_get_scalar(ocp_qp_gpu_batch *b, const char *f)
     }
     fprintf(stderr, "acados_amd: ocp_qp_gpu_batch_get_scalar: unknown field %s\n", f);
     return -1.0;
+}
+
+int ocp_qp_gpu_batch_condense_lhs(ocp_qp_gpu_batch *b)
+{
+    HIPCHK(hipSetDevice(b->device));
+    finalize_structure(b);
+    b->lhs_ready = false;
+    if (!(b->cond_N > 0 && b->cond_N < b->N)) return 0;
+    if (b->pcond_state == 0) pcond_setup(b);
+    if (b->pcond_state != 1) return 0;
+    b->pmap.mode = 1;
+    hipLaunchKernelGGL(b->pc->cond, dim3((b->B + 63) / 64), dim3(64), 0, b->stream, b->D, b->child->D, b->pmap);
+    HIPCHK(hipStreamSynchronize(b->stream));
+    b->lhs_ready = true;
+    return 0;
+}
+
+int ocp_qp_gpu_batch_condense_rhs_and_solve(ocp_qp_gpu_batch *b)
+{
+    const int bad = ocp_qp_gpu_batch_solve(b); /* uses mode 2 when the lhs is in place */
+    b->lhs_ready = false;
+    return bad;
 }
 
 size_t ocp_qp_gpu_batch_bytes(const ocp_qp_gpu_batch *b) { return b->bytes; }

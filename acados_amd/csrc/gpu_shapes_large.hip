@@ -15,5 +15,11 @@
 const KernelSet g_ksets_large[] = {
     GQP_KSET(24, 3, 4, 8),
     GQP_KSET(24, 6, 0, 0),
+    GQP_KSET(8, 15, 0, 0), /* C3: N=50 nx=8 nu=3 condensed to N2=10 blocks of 5 */
 };
+const PcondSet g_pcond_sets[] = {
+    GQP_PCOND(8, 3, 5),
+    GQP_PCOND(4, 1, 4),
+};
+const int g_n_pcond_sets = (int) (sizeof(g_pcond_sets) / sizeof(g_pcond_sets[0]));
 const int g_n_ksets_large = (int) (sizeof(g_ksets_large) / sizeof(g_ksets_large[0]));

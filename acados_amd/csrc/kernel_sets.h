@@ -9,6 +9,7 @@
 #define KERNEL_SETS_H_
 
 #include "gpu_ipm_internal.h"
+#include "pcond_kernels.hpp"
 
 typedef void (*kern_opts_t)(GqpDev, GqpOpts);
 typedef void (*kern_redo_t)(GqpDev, GqpOpts, int);
@@ -34,6 +35,18 @@ struct KernelSet
      {gqp::kb_forward<NX, NU, false, false>, gqp::kb_forward<NX, NU, true, false>},            \
      {gqp::kb_forward<NX, NU, false, true>, gqp::kb_forward<NX, NU, true, true>},              \
      gqp::kb_finalize<NX, NU>}
+
+/* partial condensing: parent shape (NX, NU), blocks of at most BSMAX stages -> child shape
+ * (NX, BSMAX*NU); kernels in pcond_kernels.hpp */
+typedef void (*kern_pcond_t)(GqpDev, GqpDev, gqp::PcondMap);
+struct PcondSet
+{
+    int NX, NU, BSMAX;
+    kern_pcond_t cond, expand;
+};
+#define GQP_PCOND(NX, NU, BS) {NX, NU, BS, gqp::k_pcond<NX, NU, BS>, gqp::k_pexpand<NX, NU, BS>}
+extern const PcondSet g_pcond_sets[];
+extern const int g_n_pcond_sets;
 
 extern const KernelSet g_ksets_large[];
 extern const int g_n_ksets_large;

@@ -473,6 +473,8 @@ void ocp_qp_gpu_ipm_memory_get(void *config, void *mem_, const char *field, void
 
 acados_size_t ocp_qp_gpu_ipm_workspace_calculate_size(void *config, void *dims, void *opts) { return 0; }
 
+static int g_cond_N_request = 0; /* set by the xcond level right before evaluate (single-threaded handoff) */
+
 int ocp_qp_gpu_ipm_evaluate_batch(void *config, int n, void **qp_in_, void **qp_out_, void *opts_, void **mem_,
                                   void *work, int *status)
 {
@@ -527,6 +529,10 @@ int ocp_qp_gpu_ipm_evaluate_batch(void *config, int n, void **qp_in_, void **qp_
     ocp_qp_gpu_batch_opts_set(b, "reg_prim", &o->reg_prim);
     ocp_qp_gpu_batch_opts_set(b, "cond_pred_corr", &o->cond_pred_corr);
     ocp_qp_gpu_batch_opts_set(b, "print_level", &o->print_level);
+    {
+        int cn = g_cond_N_request > 0 ? g_cond_N_request : N;
+        ocp_qp_gpu_batch_opts_set(b, "cond_N", &cn);
+    }
 
     /* re-read every member array of qp_in on every call (they alias ocp_nlp memory:
      * ocp_nlp_common.c:2797-2894) and pack it into the device layout */
@@ -630,8 +636,8 @@ int ocp_qp_gpu_ipm_evaluate_batch(void *config, int n, void **qp_in_, void **qp_
     for (int i = 0; i < n; i++)
     {
         qp_info *info = (qp_info *) outs[i]->misc;
-        info->solve_QP_time = ocp_qp_gpu_batch_get_scalar(b, "time_tot");
-        info->condensing_time = 0.0;
+        info->condensing_time = ocp_qp_gpu_batch_get_scalar(b, "time_xcond");
+        info->solve_QP_time = ocp_qp_gpu_batch_get_scalar(b, "time_tot") - info->condensing_time;
         info->interface_time = (t_packed - t_start) + (t_end - t_solved);
         info->total_time = t_end - t_start;
         info->num_iter = it[i];
@@ -852,13 +858,9 @@ void ocp_qp_solver_destroy(ocp_qp_solver *s)
 
 static void xcond_note(ocp_qp_solver *s)
 {
-    xcond_solver_opts *o = s->opts;
-    if (o->cond_N != s->dims->orig_dims->N && !o->warned)
-    {
-        printf("acados_amd: cond_N=%d requested; this build solves the full-space QP (N2 = N, the default of "
-               "ocp_qp_partial_condensing.c:243-265); the solution is identical\n", o->cond_N);
-        o->warned = true;
-    }
+    /* the condensing request travels with the call (ocp_qp_xcond_solve: condense -> solve -> expand,
+     * ocp_qp_xcond_solver.c:529-587); the device batch decides whether the QP class is condensable */
+    g_cond_N_request = s->opts->cond_N;
 }
 
 /* ocp_qp_interface.c:567-571 -> ocp_qp_xcond_solve (ocp_qp_xcond_solver.c:529-587) */

@@ -1,0 +1,257 @@
+/*
+ * pcond_kernels.hpp -- partial condensing N -> N2 and expansion on the device.
+ *
+ * Stands in for `ocp_qp_partial_condensing` / `ocp_qp_partial_expansion`
+ * (acados/ocp_qp/ocp_qp_partial_condensing.c:523-556, :664-689 in /root/reference, i.e. HPIPM's
+ * d_part_cond_qp_cond / d_part_cond_qp_expand_sol, whose sources are absent there).  Block j of the
+ * condensed QP covers stages k0..k1-1 of the original one; its variables are
+ *     xbar = x_{k0},   ubar = [u_{k0}; u_{k0+1}; ...; u_{k1-1}]        (slot i*NU + a)
+ * and the eliminated states are x_{k0+i} = X_i [ubar; xbar] + c_i.  With Z_i = [E_i; X_i]
+ * (E_i selects u_{k0+i}) the block data are
+ *     Hbar = sum_i Z_i' H_i Z_i,   gbar = sum_i Z_i'(H_i [0; c_i] + g_i),
+ *     [Bbar Abar] = X_bs,  bbar = c_bs.
+ * Input bounds stay box rows of ubar, bounds on x_{k0} stay box rows of xbar (this is where the
+ * equality-flagged x0 rows live).  The host only enables this path when no other inequality
+ * exists (state bounds inside a block would become general constraints of the condensed QP);
+ * otherwise the full-space QP is solved, which is the reference's default N2 = N.
+ *
+ * Mapping: one instance per lane like the IPM kernels; the block matrices (X: NX x nc,
+ * Hbar: nc(nc+1)/2, nc = BS*NU + NX) are per-lane arrays addressed in rolled loops.  This is a
+ * once-per-solve pre/post-processing step; the FP64-MFMA formulation of the Z'HZ contraction
+ * named by the north star only pays for nx >= 16 and is left to a later round.
+ */
+#ifndef PCOND_KERNELS_HPP_
+#define PCOND_KERNELS_HPP_
+
+#include "ipm_kernels.hpp"
+
+namespace gqp
+{
+
+struct PcondMap
+{
+    const int *blk_start; /* N2+1 entries: first original stage of each block; blk_start[N2] = N */
+    const int *row_kp;    /* per child row (all child stages concatenated): parent stage */
+    const int *row_rp;    /* ... parent sorted row index */
+    const int *row_off;   /* N2+2 entries: first child row of each child stage */
+    int N2;
+    int mode;             /* 3: everything; 1: matrix part only (Hbar, Abar, Bbar -- condense_lhs);
+                             2: vector part only (gbar, bbar, bounds -- condense_rhs), the split RTI
+                             uses (ocp_qp_partial_condensing.c:575-598, :602-630) */
+};
+
+/* parent (NX, NU) -> child (NX, NUC = BSMAX*NU) */
+template <int NX, int NU, int BSMAX>
+__global__ void __launch_bounds__(64) k_pcond(GqpDev P, GqpDev Cd, PcondMap Mp)
+{
+    constexpr int n = NX + NU, NP = n * (n + 1) / 2;
+    constexpr int NUC = BSMAX * NU, nc = NUC + NX, NPC = nc * (nc + 1) / 2;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.B) return;
+    const int Bp = P.Bp; /* parent and child share B, Bp */
+
+    double X[NX * nc], Xn[NX * nc], T[NX * nc], c[NX], cn[NX], Hb[NPC], gb[nc], H[NP], y[n];
+
+    for (int jb = 0; jb <= Mp.N2; jb++)
+    {
+        const int k0 = Mp.blk_start[jb < Mp.N2 ? jb : Mp.N2];
+        const int k1 = jb < Mp.N2 ? Mp.blk_start[jb + 1] : P.N + 1; /* terminal: stage N alone */
+        const int bs = jb < Mp.N2 ? k1 - k0 : 1;
+        for (int e = 0; e < NX * nc; e++) X[e] = 0.0;
+        for (int r = 0; r < NX; r++) { X[r * nc + NUC + r] = 1.0; c[r] = 0.0; }
+        for (int e = 0; e < NPC; e++) Hb[e] = 0.0;
+        for (int e = 0; e < nc; e++) gb[e] = 0.0;
+
+        for (int ii = 0; ii < bs; ii++)
+        {
+            const int k = k0 + ii;
+            for (int e = 0; e < NP; e++) H[e] = GAT(P.RSQ, k * NP + e);
+            /* y = H [0; c] + g */
+            for (int r = 0; r < n; r++)
+            {
+                double a = GAT(P.rq, k * n + r);
+                for (int q = 0; q < NX; q++)
+                {
+                    const int cc = NU + q;
+                    a += (r >= cc ? H[PK(r, cc)] : H[PK(cc, r)]) * c[q];
+                }
+                y[r] = a;
+            }
+            /* gbar += Z' y */
+            for (int a = 0; a < NU; a++) gb[ii * NU + a] += y[a];
+            for (int col = 0; col < nc; col++)
+            {
+                double s = 0.0;
+                for (int r = 0; r < NX; r++) s += X[r * nc + col] * y[NU + r];
+                gb[col] += s;
+            }
+            /* Hbar += Z' H Z  with Z = [E_ii; X]:  R on the (ii,ii) input block, S X on the
+             * input rows, X' Q X everywhere */
+            if (Mp.mode & 1)
+            {
+            for (int a = 0; a < NU; a++)
+                for (int b = 0; b <= a; b++) Hb[PK(ii * NU + a, ii * NU + b)] += H[PK(a, b)];
+            for (int a = 0; a < NU; a++)
+            {
+                const int ra = ii * NU + a;
+                for (int col = 0; col < nc; col++)
+                {
+                    double s = 0.0; /* (S X)[a][col], S[a][r] = H[NU+r][a] */
+                    for (int r = 0; r < NX; r++) s += H[PK(NU + r, a)] * X[r * nc + col];
+                    if (col == ra) Hb[PK(ra, ra)] += 2.0 * s;
+                    else if (col < ra) Hb[PK(ra, col)] += s;
+                    else Hb[PK(col, ra)] += s;
+                }
+            }
+            for (int r = 0; r < NX; r++)
+                for (int col = 0; col < nc; col++)
+                {
+                    double s = 0.0; /* T = Q X */
+                    for (int q = 0; q < NX; q++)
+                        s += (r >= q ? H[PK(NU + r, NU + q)] : H[PK(NU + q, NU + r)]) * X[q * nc + col];
+                    T[r * nc + col] = s;
+                }
+            for (int ra = 0; ra < nc; ra++)
+                for (int cb = 0; cb <= ra; cb++)
+                {
+                    double s = 0.0;
+                    for (int r = 0; r < NX; r++) s += X[r * nc + ra] * T[r * nc + cb];
+                    Hb[PK(ra, cb)] += s;
+                }
+            }
+            /* propagate x_{k+1} = A x_k + B u_k + b  (slot N of BAt/bvec is zero) */
+            if (jb < Mp.N2)
+            {
+                for (int r = 0; r < NX; r++)
+                {
+                    double a = GAT(P.bvec, k * NX + r);
+                    for (int q = 0; q < NX; q++) a += GAT(P.BAt, (k * n + NU + q) * NX + r) * c[q];
+                    cn[r] = a;
+                    for (int col = 0; col < nc; col++)
+                    {
+                        double s = 0.0;
+                        for (int q = 0; q < NX; q++) s += GAT(P.BAt, (k * n + NU + q) * NX + r) * X[q * nc + col];
+                        Xn[r * nc + col] = s;
+                    }
+                    for (int a2 = 0; a2 < NU; a2++) Xn[r * nc + ii * NU + a2] += GAT(P.BAt, (k * n + a2) * NX + r);
+                }
+                for (int e = 0; e < NX * nc; e++) X[e] = Xn[e];
+                for (int r = 0; r < NX; r++) c[r] = cn[r];
+            }
+        }
+        /* unused input slots of a short block (and all of them at the terminal stage): unit diagonal */
+        const int used = jb < Mp.N2 ? bs * NU : 0;
+        for (int s2 = used; s2 < NUC; s2++) Hb[PK(s2, s2)] = 1.0;
+
+        /* ---- write child stage jb ---- */
+        if (Mp.mode & 1)
+        {
+            for (int e = 0; e < NPC; e++) GAT(Cd.RSQ, jb * NPC + e) = Hb[e];
+            if (jb < Mp.N2)
+                for (int col = 0; col < nc; col++)
+                    for (int r = 0; r < NX; r++) GAT(Cd.BAt, (jb * nc + col) * NX + r) = X[r * nc + col];
+        }
+        if (!(Mp.mode & 2)) continue;
+        for (int e = 0; e < nc; e++) GAT(Cd.rq, jb * nc + e) = gb[e];
+        if (jb < Mp.N2)
+            for (int r = 0; r < NX; r++) GAT(Cd.bvec, jb * NX + r) = c[r];
+        /* box rows, activity bits, value of fixed variables */
+        const GqpStage &Sc = Cd.st[jb];
+        const int r0 = Mp.row_off[jb], nbc = Sc.nb;
+        uint64_t amc = 0;
+        for (int rc = 0; rc < nbc; rc++)
+        {
+            const int kp = Mp.row_kp[r0 + rc], rp = Mp.row_rp[r0 + rc];
+            const GqpStage &Sp = P.st[kp];
+            const uint64_t amp = GAT(P.amask, kp);
+            GAT(Cd.dvec, Sc.o_ct + rc) = GAT(P.dvec, Sp.o_ct + rp);
+            GAT(Cd.dvec, Sc.o_ct + nbc + rc) = GAT(P.dvec, Sp.o_ct + Sp.nb + rp);
+            if ((amp >> rp) & 1) amc |= (uint64_t) 1 << rc;
+            if ((amp >> (Sp.nb + rp)) & 1) amc |= (uint64_t) 1 << (nbc + rc);
+        }
+        GAT(Cd.amask, jb) = amc;
+        for (int r = 0; r < NX; r++)
+            if ((Sc.emask >> (NUC + r)) & 1) GAT(Cd.ux, jb * nc + NUC + r) = GAT(P.ux, k0 * n + NU + r);
+    }
+}
+
+/* expansion: original (ux, pi, lam, t) from the condensed solution */
+template <int NX, int NU, int BSMAX>
+__global__ void __launch_bounds__(64) k_pexpand(GqpDev P, GqpDev Cd, PcondMap Mp)
+{
+    constexpr int n = NX + NU, NP = n * (n + 1) / 2;
+    constexpr int NUC = BSMAX * NU, nc = NUC + NX;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.B) return;
+    const int Bp = P.Bp;
+    double x[NX], xn[NX], u[NU], pk[NX], pn[NX];
+
+    for (int jb = 0; jb <= Mp.N2; jb++)
+    {
+        const int k0 = Mp.blk_start[jb < Mp.N2 ? jb : Mp.N2];
+        const int bs = jb < Mp.N2 ? Mp.blk_start[jb + 1] - k0 : 1;
+        /* forward simulation of the eliminated states */
+        for (int r = 0; r < NX; r++) x[r] = GAT(Cd.ux, jb * nc + NUC + r);
+        for (int ii = 0; ii < bs; ii++)
+        {
+            const int k = k0 + ii;
+            for (int a = 0; a < NU; a++) u[a] = jb < Mp.N2 ? GAT(Cd.ux, jb * nc + ii * NU + a) : 0.0;
+            for (int a = 0; a < NU; a++) GAT(P.ux, k * n + a) = u[a];
+            for (int r = 0; r < NX; r++) GAT(P.ux, k * n + NU + r) = x[r];
+            if (jb < Mp.N2 && ii + 1 < bs)
+            {
+                for (int r = 0; r < NX; r++)
+                {
+                    double a = GAT(P.bvec, k * NX + r);
+                    for (int q = 0; q < NX; q++) a += GAT(P.BAt, (k * n + NU + q) * NX + r) * x[q];
+                    for (int q = 0; q < NU; q++) a += GAT(P.BAt, (k * n + q) * NX + r) * u[q];
+                    xn[r] = a;
+                }
+                for (int r = 0; r < NX; r++) x[r] = xn[r];
+            }
+        }
+        /* multipliers of the eliminated dynamics: pi_k = Q x_k + S' u_k + q_k + A_k' pi_{k+1}
+         * (no inequality touches an eliminated state), backwards from the block boundary */
+        if (jb < Mp.N2)
+        {
+            const int k1 = k0 + bs;
+            for (int r = 0; r < NX; r++) { pn[r] = GAT(Cd.pi, (jb + 1) * NX + r); GAT(P.pi, k1 * NX + r) = pn[r]; }
+            for (int k = k1 - 1; k > k0; k--)
+            {
+                for (int r = 0; r < NX; r++)
+                {
+                    double a = GAT(P.rq, k * n + NU + r);
+                    for (int q = 0; q < n; q++)
+                    {
+                        const int rr = NU + r;
+                        a += (rr >= q ? GAT(P.RSQ, k * NP + PK(rr, q)) : GAT(P.RSQ, k * NP + PK(q, rr))) * GAT(P.ux, k * n + q);
+                    }
+                    for (int q = 0; q < NX; q++) a += GAT(P.BAt, (k * n + NU + r) * NX + q) * pn[q];
+                    pk[r] = a;
+                }
+                for (int r = 0; r < NX; r++) { pn[r] = pk[r]; GAT(P.pi, k * NX + r) = pk[r]; }
+            }
+        }
+        /* inequality rows */
+        const GqpStage &Sc = Cd.st[jb];
+        const int r0 = Mp.row_off[jb], nbc = Sc.nb;
+        for (int rc = 0; rc < nbc; rc++)
+        {
+            const int kp = Mp.row_kp[r0 + rc], rp = Mp.row_rp[r0 + rc];
+            const GqpStage &Sp = P.st[kp];
+            GAT(P.lam, Sp.o_ct + rp) = GAT(Cd.lam, Sc.o_ct + rc);
+            GAT(P.lam, Sp.o_ct + Sp.nb + rp) = GAT(Cd.lam, Sc.o_ct + nbc + rc);
+            GAT(P.t, Sp.o_ct + rp) = GAT(Cd.t, Sc.o_ct + rc);
+            GAT(P.t, Sp.o_ct + Sp.nb + rp) = GAT(Cd.t, Sc.o_ct + nbc + rc);
+        }
+    }
+    P.iter[i] = Cd.iter[i];
+    P.status[i] = Cd.status[i];
+    P.mu[i] = Cd.mu[i];
+    P.obj[i] = Cd.obj[i];
+    for (int q = 0; q < 4; q++) P.res[q * Bp + i] = Cd.res[q * Bp + i];
+}
+
+} // namespace gqp
+
+#endif

@@ -78,6 +78,14 @@ class OcpQpGpuBatch:
         """returns the number of instances with non-zero status"""
         return self._L.ocp_qp_gpu_batch_solve(self._h)
 
+    def condense_lhs(self):
+        """RTI preparation phase: matrix part of the partial condensing (no-op for cond_N == N)"""
+        return self._L.ocp_qp_gpu_batch_condense_lhs(self._h)
+
+    def condense_rhs_and_solve(self):
+        """RTI feedback phase: vector part of the condensing + solve + expansion"""
+        return self._L.ocp_qp_gpu_batch_condense_rhs_and_solve(self._h)
+
     def _len(self, field, k):
         d = self.dims
         if field == "x":

@@ -58,13 +58,20 @@ int ocp_qp_gpu_batch_set(ocp_qp_gpu_batch *b, const char *field, int stage, cons
 
 /* Options by name, as ocp_qp_xcond_solver_opts_set forwards them: iter_max
  * tol_stat tol_eq tol_ineq tol_comp warm_start mu0 alpha_min tau_min reg_prim
- * cond_pred_corr print_level t0_init hpipm_mode ric_alg.  int* or double* or char* as in
+ * cond_pred_corr print_level t0_init hpipm_mode ric_alg cond_N (partial condensing to N2 blocks) profile.  int* or double* or char* as in
  * acados.  Unknown field: message + return -1. */
 int ocp_qp_gpu_batch_opts_set(ocp_qp_gpu_batch *b, const char *field, const void *value);
 
 /* Solve all instances (one IPM iteration = 4-6 launches over the whole batch) on the
  * batch's stream.  Returns the number of instances whose status is not ACADOS_SUCCESS. */
 int ocp_qp_gpu_batch_solve(ocp_qp_gpu_batch *b);
+
+/* RTI split (ocp_qp_xcond_solver.c:591-669): condense the matrix part while waiting for the new
+ * initial state, then condense the vector part and solve.  With cond_N == N (or a QP class this
+ * build does not condense) condense_lhs is a no-op and the second call is a plain solve.
+ * The matrix-dependent condensed blocks stay resident in HBM between the two calls. */
+int ocp_qp_gpu_batch_condense_lhs(ocp_qp_gpu_batch *b);
+int ocp_qp_gpu_batch_condense_rhs_and_solve(ocp_qp_gpu_batch *b);
 
 /* Results, same blocked convention as _set: x u sl su pi lam t per stage. */
 int ocp_qp_gpu_batch_get(ocp_qp_gpu_batch *b, const char *field, int stage, double *data, int is_device);

@@ -187,3 +187,39 @@ def test_c5_shape_classes_and_multiphase_hostsim(hostsim_lib):
         _check_batch_vs_oracle([lqr_instance_qp(data, i, 5) for i in range(2)], hostsim_lib)
     b = _check_batch_vs_oracle([multiphase_qp(i, N=8) for i in range(3)], hostsim_lib)
     assert b.kernel_name.startswith("1tpi-box<NX=12,NU=3")
+
+
+def test_partial_condensing_hostsim(hostsim_lib):
+    """a5-a7: condensing N -> N2 blocks, IPM on the condensed QP, expansion; the expanded solution
+    must equal the full-space oracle solution (x, u, pi, lam, t).  Covers C3 (N=50 -> 10 blocks of 5),
+    uneven block sizes, the reference's golden pendulum QP, the RTI lhs/rhs split and the decline
+    path (state bounds inside a block -> full-space solve, same answer)."""
+    from acados_amd import OcpQpGpuBatch
+    from acados_amd.generators import lqr_instance_qp, mass_spring_qp, random_lqr_batch
+
+    def run(qps, cond_N, expect_active, split=False):
+        b = OcpQpGpuBatch.from_qps(qps, _clib=hostsim_lib)
+        for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+            b.opts_set(f, 1e-8)
+        b.opts_set("cond_N", cond_N)
+        if split:
+            assert b.condense_lhs() == 0
+            assert b.condense_rhs_and_solve() == 0
+        else:
+            assert b.solve() == 0
+        assert int(b.scalar("cond_N_active")) == expect_active
+        for i, qp in enumerate(qps):
+            o = OracleQp(qp)
+            assert o.solve(default_opts(tol_stat=1e-8)) == 0
+            compare_with_oracle(lambda k, f: b.get(f, k)[i], o, qp, 1e-8, fields=("x", "u", "pi", "lam", "t"))
+        return b
+
+    data = random_lqr_batch(N=50, batch=2, seed=0)
+    qps = [lqr_instance_qp(data, i, 50) for i in range(2)]
+    b = run(qps, 10, 10)
+    assert b.kernel_name.startswith("1tpi-box<NX=8,NU=3")
+    run(qps, 10, 10, split=True)
+    data = random_lqr_batch(N=10, batch=3, seed=3)
+    run([lqr_instance_qp(data, i, 10) for i in range(3)], 3, 3)        # blocks of 4, 3, 3
+    run([load_qp("qp_test/last_qp_nonuniform_pendulum.json")], 3, 3)   # N=7 -> 3, 2, 2 ; x0 equality rows
+    run([mass_spring_qp(N=15)], 5, 15)                                  # declined: state bounds in blocks
