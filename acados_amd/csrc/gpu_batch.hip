@@ -87,6 +87,14 @@ struct ocp_qp_gpu_batch
     gqp::PcondMap pmap;
     double time_xcond = 0.0;
     bool lhs_ready = false;         /* condense_lhs done: the next solve only condenses the vector part */
+    /* compaction of the still-iterating instances into a dense sub-batch (see run_ipm) */
+    ocp_qp_gpu_batch *compact = nullptr; /* next level, capacity <= B/2, created on first use */
+    const KernelSet *force_ks = nullptr; /* sub-batches run the very same kernel set */
+    int compact_min = 1 << 30;           /* levels smaller than this are not compacted; off by default: it only
+                                            pays once every sweep kernel is bandwidth-bound */
+    int *d_list = nullptr;               /* instance index of every slot of `compact` */
+    int list_cap = 0;
+    int n_compactions = 0;
 };
 
 namespace
@@ -102,6 +110,16 @@ T *dalloc(ocp_qp_gpu_batch *b, size_t cnt)
     b->allocs.push_back(p);
     b->bytes += bytes;
     return (T *) p;
+}
+
+/* wave-tiled per-instance array with E elements per instance (gpu_ipm_internal.h, GArrT) */
+template <class T>
+GArrT<T> garr(ocp_qp_gpu_batch *b, size_t E)
+{
+    GArrT<T> a;
+    a.E = (int) (E ? E : 1);
+    a.p = dalloc<T>(b, (size_t) a.E * (size_t) b->Bp);
+    return a;
 }
 
 void opts_default(GqpOpts &o)
@@ -189,34 +207,34 @@ void finalize_structure(ocp_qp_gpu_batch *b)
     D.B = b->B; D.Bp = b->Bp; D.N = N; D.NX = NX; D.NU = NU; D.NG = b->ks->NG; D.NS = b->ks->NS;
     D.st = b->d_st;
     const size_t RP = 16; /* spare row elements (clamped dummy row index) */
-    D.BAt = dalloc<double>(b, (size_t) (N + 1) * n * NX * Bp);
-    D.bvec = dalloc<double>(b, (size_t) (N + 1) * NX * Bp);
-    D.RSQ = dalloc<double>(b, (size_t) (N + 1) * NP * Bp);
-    D.rq = dalloc<double>(b, (size_t) (N + 1) * n * Bp);
-    D.dvec = dalloc<double>(b, (size_t) (o_ct + RP) * Bp);
-    D.amask = dalloc<uint64_t>(b, (size_t) (N + 1) * Bp);
-    D.DCt = dalloc<double>(b, (size_t) o_g * n * Bp);
-    D.Zz = dalloc<double>(b, (size_t) o_s * 2 * Bp);
-    D.ux = dalloc<double>(b, (size_t) (N + 2) * n * Bp);
-    D.sv = dalloc<double>(b, (size_t) o_s * Bp);
-    D.pi = dalloc<double>(b, (size_t) (N + 2) * NX * Bp);
-    D.lam = dalloc<double>(b, (size_t) (o_ct + RP) * Bp);
-    D.t = dalloc<double>(b, (size_t) (o_ct + RP) * Bp);
-    D.rg = dalloc<double>(b, (size_t) (N + 1) * n * Bp);
-    D.rgs = dalloc<double>(b, (size_t) o_s * Bp);
-    D.rb = dalloc<double>(b, (size_t) (N + 1) * NX * Bp);
-    D.rd = dalloc<double>(b, (size_t) (o_ct + RP) * Bp);
-    D.rm = dalloc<double>(b, (size_t) (o_ct + RP) * Bp);
-    D.dux = dalloc<double>(b, (size_t) (N + 2) * n * Bp);
-    D.dsv = dalloc<double>(b, (size_t) o_s * Bp);
-    D.dpi = dalloc<double>(b, (size_t) (N + 2) * NX * Bp);
-    D.dlam = dalloc<double>(b, (size_t) (o_ct + RP) * Bp);
-    D.dt = dalloc<double>(b, (size_t) (o_ct + RP) * Bp);
-    D.pcorr = dalloc<double>(b, (size_t) (o_ct + RP) * Bp);
-    D.sD = dalloc<double>(b, (size_t) o_s * Bp);
-    D.sR = dalloc<double>(b, (size_t) o_s * Bp);
-    D.Lf = dalloc<double>(b, (size_t) (N + 1) * NP * Bp);
-    D.lf = dalloc<double>(b, (size_t) (N + 1) * n * Bp);
+    D.BAt = garr<double>(b, (size_t) ((N + 1) * n * NX));
+    D.bvec = garr<double>(b, (size_t) ((N + 1) * NX));
+    D.RSQ = garr<double>(b, (size_t) ((N + 1) * NP));
+    D.rq = garr<double>(b, (size_t) ((N + 1) * n));
+    D.dvec = garr<double>(b, (size_t) ((o_ct + RP)));
+    D.amask = garr<uint64_t>(b, (size_t) ((N + 1)));
+    D.DCt = garr<double>(b, (size_t) (o_g * n));
+    D.Zz = garr<double>(b, (size_t) (o_s * 2));
+    D.ux = garr<double>(b, (size_t) ((N + 2) * n));
+    D.sv = garr<double>(b, (size_t) (o_s));
+    D.pi = garr<double>(b, (size_t) ((N + 2) * NX));
+    D.lam = garr<double>(b, (size_t) ((o_ct + RP)));
+    D.t = garr<double>(b, (size_t) ((o_ct + RP)));
+    D.rg = garr<double>(b, (size_t) ((N + 1) * n));
+    D.rgs = garr<double>(b, (size_t) (o_s));
+    D.rb = garr<double>(b, (size_t) ((N + 1) * NX));
+    D.rd = garr<double>(b, (size_t) ((o_ct + RP)));
+    D.rm = garr<double>(b, (size_t) ((o_ct + RP)));
+    D.dux = garr<double>(b, (size_t) ((N + 2) * n));
+    D.dsv = garr<double>(b, (size_t) (o_s));
+    D.dpi = garr<double>(b, (size_t) ((N + 2) * NX));
+    D.dlam = garr<double>(b, (size_t) ((o_ct + RP)));
+    D.dt = garr<double>(b, (size_t) ((o_ct + RP)));
+    D.pcorr = garr<double>(b, (size_t) ((o_ct + RP)));
+    D.sD = garr<double>(b, (size_t) (o_s));
+    D.sR = garr<double>(b, (size_t) (o_s));
+    D.Lf = garr<double>(b, (size_t) ((N + 1) * NP));
+    D.lf = garr<double>(b, (size_t) ((N + 1) * n));
     D.res = dalloc<double>(b, 4 * Bp);
     D.mu = dalloc<double>(b, Bp); D.smu = dalloc<double>(b, Bp);
     D.alpha = dalloc<double>(b, Bp); D.obj = dalloc<double>(b, Bp);
@@ -234,7 +252,7 @@ void finalize_structure(ocp_qp_gpu_batch *b)
         {
             const bool real = j < NU ? j < b->nu[k] : (j - NU) < b->nx[k];
             if (!real)
-                hipLaunchKernelGGL(gqp::k_fill_strided, dim3(grid), dim3(64), 0, b->stream, D.RSQ, 1.0, b->B, b->Bp,
+                hipLaunchKernelGGL(gqp::k_fill_strided, dim3(grid), dim3(64), 0, b->stream, D.RSQ, 1.0, b->B,
                                    k * NP + PK(j, j));
         }
         /* activity: every existing row side, minus equality-flagged rows */
@@ -247,8 +265,7 @@ void finalize_structure(ocp_qp_gpu_batch *b)
             m &= ~((uint64_t) 1 << sp);
             m &= ~((uint64_t) 1 << (nbg + sp));
         }
-        hipLaunchKernelGGL(gqp::k_fill_u64, dim3((b->Bp + 255) / 256), dim3(256), 0, b->stream,
-                           D.amask + (size_t) k * Bp, m, (size_t) b->Bp);
+        hipLaunchKernelGGL(gqp::k_fill_u64, dim3(grid), dim3(64), 0, b->stream, D.amask, m, b->Bp, k);
     }
     HIPCHK(hipStreamSynchronize(b->stream));
     b->finalized = true;
@@ -267,8 +284,8 @@ void ensure_stat(ocp_qp_gpu_batch *b)
 
 /* element map of a numeric field: for every source element e the target element index
  * in `*arr` (units of Bp doubles), or -1.  Returns the field length, -1 if unknown. */
-int field_map(ocp_qp_gpu_batch *b, const char *f, int k, std::vector<int> &map, double **arr,
-              std::vector<int> *map2 = nullptr, double **arr2 = nullptr)
+int field_map(ocp_qp_gpu_batch *b, const char *f, int k, std::vector<int> &map, GArr *arr,
+              std::vector<int> *map2 = nullptr, GArr *arr2 = nullptr)
 {
     const int N = b->N, NX = b->ks->NX, NU = b->ks->NU, n = NX + NU, NP = n * (n + 1) / 2;
     const GqpDev &D = b->D;
@@ -431,6 +448,7 @@ extern "C" {
 
 static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu, const int *nbx, const int *nbu,
                                             const int *ng, const int *ns, int n_batch, int device, int force_NX, int force_NU);
+static const KernelSet *g_force_ks = nullptr; /* set only while a compaction sub-batch is being created */
 
 ocp_qp_gpu_batch *ocp_qp_gpu_batch_create(int N, const int *nx, const int *nu, const int *nbx, const int *nbu,
                                           const int *ng, const int *ns, int n_batch, int device)
@@ -477,6 +495,7 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
     };
     for (const KernelSet &ks : g_ksets) consider(ks);
     for (int q = 0; q < g_n_ksets_large; q++) consider(g_ksets_large[q]);
+    if (g_force_ks) b->ks = g_force_ks;
     if (!b->ks)
     {
         fprintf(stderr, "acados_amd: no kernel instantiation covers nx<=%d nu<=%d ng<=%d ns<=%d\n", mx, mu, mg, ms);
@@ -506,6 +525,7 @@ void ocp_qp_gpu_batch_destroy(ocp_qp_gpu_batch *b)
     for (hipEvent_t e : b->prof_ev) (void) hipEventDestroy(e);
     (void) hipStreamDestroy(b->stream);
     if (b->child) ocp_qp_gpu_batch_destroy(b->child);
+    if (b->compact) ocp_qp_gpu_batch_destroy(b->compact);
     delete b;
 }
 
@@ -541,7 +561,7 @@ int ocp_qp_gpu_batch_set(ocp_qp_gpu_batch *b, const char *f, int stage, const do
     for (int k = k0; k <= k1; k++)
     {
         std::vector<int> map, map2;
-        double *arr = nullptr, *arr2 = nullptr;
+        GArr arr = {nullptr, 0}, arr2 = {nullptr, 0};
         const size_t flen = strlen(f);
         if (flen > 5 && !strcmp(f + flen - 5, "_mask"))
         {
@@ -550,8 +570,7 @@ int ocp_qp_gpu_batch_set(ocp_qp_gpu_batch *b, const char *f, int stage, const do
             if (len == 0) continue;
             if (src_len != len) { src = stage_in(b, data, (size_t) b->B * len, is_device); src_len = len; }
             int *dm = upload_map(b, map);
-            hipLaunchKernelGGL(gqp::k_setmask, dim3(grid), dim3(64), 0, b->stream, src, b->B, len, dm,
-                               b->D.amask + (size_t) k * b->Bp);
+            hipLaunchKernelGGL(gqp::k_setmask, dim3(grid), dim3(64), 0, b->stream, src, b->B, len, dm, b->D.amask, k);
             continue;
         }
         const int len = field_map(b, f, k, map, &arr, &map2, &arr2);
@@ -564,11 +583,11 @@ int ocp_qp_gpu_batch_set(ocp_qp_gpu_batch *b, const char *f, int stage, const do
         if (len == 0) continue;
         if (src_len != len) { src = stage_in(b, data, (size_t) b->B * len, is_device); src_len = len; }
         int *dm = upload_map(b, map);
-        hipLaunchKernelGGL(gqp::k_scatter, dim3(grid), dim3(64), 0, b->stream, src, b->B, len, dm, arr, b->Bp);
-        if (arr2)
+        hipLaunchKernelGGL(gqp::k_scatter, dim3(grid), dim3(64), 0, b->stream, src, b->B, len, dm, arr);
+        if (arr2.p)
         {
             dm = upload_map(b, map2);
-            hipLaunchKernelGGL(gqp::k_scatter, dim3(grid), dim3(64), 0, b->stream, src, b->B, len, dm, arr2, b->Bp);
+            hipLaunchKernelGGL(gqp::k_scatter, dim3(grid), dim3(64), 0, b->stream, src, b->B, len, dm, arr2);
         }
     }
     HIPCHK(hipEventRecord(e1, b->stream));
@@ -599,6 +618,7 @@ int ocp_qp_gpu_batch_opts_set(ocp_qp_gpu_batch *b, const char *f, const void *v)
     else if (!strcmp(f, "cond_pred_corr")) o.cond_pred_corr = *i;
     else if (!strcmp(f, "print_level")) b->print_level = *i;
     else if (!strcmp(f, "profile")) b->profile = *i;
+    else if (!strcmp(f, "compact_min")) b->compact_min = *i;
     else if (!strcmp(f, "cond_N"))
     {
         if (*i != b->cond_N)
@@ -764,6 +784,167 @@ static int pcond_solve(ocp_qp_gpu_batch *b, int mode = 3)
     return bad;
 }
 
+/* ---- the IPM launch loop of one level (root batch or compaction sub-batch) ---- */
+struct IpmKernels
+{
+    kern_redo_t fact, rhs, faff, fcorr;
+    kern_plain_t final_;
+};
+
+static IpmKernels pick_kernels(const ocp_qp_gpu_batch *b)
+{
+    const KernelSet *ks = b->ks;
+    const int xb = b->xbox;
+    IpmKernels k;
+    k.fact = b->use_box ? ks->box_fact[xb] : ks->back_fact;
+    k.rhs = b->use_box ? ks->box_rhs[xb] : ks->back_rhs;
+    k.faff = b->use_box ? ks->box_fwd_aff[xb] : ks->fwd_aff;
+    k.fcorr = b->use_box ? ks->box_fwd_corr[xb] : ks->fwd_corr;
+    k.final_ = b->use_box ? ks->box_finalize : ks->finalize;
+    return k;
+}
+
+/* per-kernel-class HIP event timing, accumulated on the ROOT batch */
+struct Prof
+{
+    ocp_qp_gpu_batch *root;
+    size_t used = 0;
+    void begin(int cls, hipStream_t s)
+    {
+        if (!root->profile) return;
+        if (used + 2 > root->prof_ev.size())
+        {
+            hipEvent_t e0, e1;
+            HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+            root->prof_ev.push_back(e0); root->prof_ev.push_back(e1);
+        }
+        root->prof_cls.push_back(cls);
+        HIPCHK(hipEventRecord(root->prof_ev[used], s));
+    }
+    void end(hipStream_t s)
+    {
+        if (!root->profile) return;
+        HIPCHK(hipEventRecord(root->prof_ev[used + 1], s));
+        used += 2;
+    }
+};
+
+static void compact_into(ocp_qp_gpu_batch *b, int nact, hipStream_t s);
+static void compact_back(ocp_qp_gpu_batch *b, hipStream_t s);
+
+/*
+ * One level of the IPM loop.  After the factor kernel of every iteration the host reads the
+ * number of still-iterating instances.  Converged instances are scattered over the waves, so a
+ * wave keeps paying full HBM traffic as long as ONE of its 64 lanes is active; when at most half
+ * of the level is still iterating, the survivors (QP data + iterate, ~98 KB each for C2) are
+ * copied into a dense sub-batch, the loop continues there (recursively), and the results are
+ * scattered back.  Per-instance arithmetic is unchanged, so results are bit-identical.
+ */
+static void run_ipm(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch *root, Prof &prof, hipStream_t s, int it)
+{
+    const IpmKernels K = pick_kernels(b);
+    GqpDev D = b->D;
+    GqpOpts O = root->O;
+    const dim3 grid((b->B + 63) / 64), block(64);
+    for (;; it++)
+    {
+        prof.begin(1, s);
+        hipLaunchKernelGGL(K.fact, grid, block, 0, s, D, O, 0);
+        prof.end(s);
+        root->launches++;
+        HIPCHK(hipMemcpyAsync(b->h_nact, D.n_active, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        const int nact = *b->h_nact;
+        if (root->print_level > 1) printf("acados_amd: ipm iter %d level size %d active %d\n", it, b->B, nact);
+        if (nact <= 0 || it > O.iter_max) break;
+        if (b->B >= root->compact_min && 2 * nact <= b->B)
+        {
+            compact_into(b, nact, s);
+            root->n_compactions++;
+            run_ipm(b->compact, root, prof, s, it);
+            compact_back(b, s);
+            break;
+        }
+        prof.begin(2, s);
+        hipLaunchKernelGGL(K.faff, grid, block, 0, s, D, O, 0);
+        prof.end(s);
+        prof.begin(3, s);
+        hipLaunchKernelGGL(K.rhs, grid, block, 0, s, D, O, 0);
+        prof.end(s);
+        prof.begin(4, s);
+        hipLaunchKernelGGL(K.fcorr, grid, block, 0, s, D, O, 0);
+        prof.end(s);
+        root->launches += 3;
+        if (O.cond_pred_corr)
+        {
+            hipLaunchKernelGGL(K.rhs, grid, block, 0, s, D, O, 1);
+            hipLaunchKernelGGL(K.fcorr, grid, block, 0, s, D, O, 1);
+            root->launches += 2;
+        }
+    }
+}
+
+/* arrays that define a QP instance and its iterate (everything else is recomputed) */
+#define GQP_FOR_STATE_ARRAYS(X) X(BAt) X(bvec) X(RSQ) X(rq) X(dvec) X(DCt) X(Zz) X(ux) X(sv) X(pi) X(lam) X(t)
+#define GQP_FOR_RESULT_ARRAYS(X) X(ux) X(sv) X(pi) X(lam) X(t)
+
+static void compact_into(ocp_qp_gpu_batch *b, int nact, hipStream_t s)
+{
+    /* sorted list of the still-iterating instances (sorted => the gather reads stay coalesced) */
+    std::vector<int> st(b->B), list;
+    HIPCHK(hipMemcpy(st.data(), b->D.status, sizeof(int) * b->B, hipMemcpyDeviceToHost));
+    list.reserve(nact);
+    for (int i = 0; i < b->B; i++) if (st[i] == GQP_RUNNING) list.push_back(i);
+    const int cnt = (int) list.size();
+    if (!b->compact)
+    {
+        const int cap = (b->B + 1) / 2;
+        g_force_ks = b->ks;
+        ocp_qp_gpu_batch *c = batch_create_shape(b->N, b->nx.data(), b->nu.data(), b->nbx.data(), b->nbu.data(),
+                                                 b->ng.data(), b->ns.data(), cap, b->device, 0, 0);
+        g_force_ks = nullptr;
+        if (!c) { fprintf(stderr, "acados_amd: cannot create the compaction sub-batch\n"); abort(); }
+        c->idxb = b->idxb; c->idxs_rev = b->idxs_rev; c->idxe = b->idxe; c->nbxe = b->nbxe;
+        c->compact_min = b->compact_min;
+        finalize_structure(c);
+        b->compact = c;
+        b->d_list = dalloc<int>(b, cap);
+        b->list_cap = cap;
+    }
+    ocp_qp_gpu_batch *c = b->compact;
+    HIPCHK(hipMemcpyAsync(b->d_list, list.data(), sizeof(int) * cnt, hipMemcpyHostToDevice, s));
+    c->B = cnt; /* the level works on `cnt` slots of its capacity */
+    c->D.B = cnt;
+    const dim3 block(64);
+#define GQP_COPY_IN(A)                                                                                     \
+    if (b->D.A.E > 0 && b->D.A.p && c->D.A.p)                                                              \
+        hipLaunchKernelGGL(gqp::k_compact_copy<double>, dim3((cnt + 63) / 64, (b->D.A.E + 63) / 64), block, 0, s, \
+                           b->D.A, c->D.A, b->d_list, cnt, 0);
+    GQP_FOR_STATE_ARRAYS(GQP_COPY_IN)
+#undef GQP_COPY_IN
+    hipLaunchKernelGGL(gqp::k_compact_copy<uint64_t>, dim3((cnt + 63) / 64, (b->D.amask.E + 63) / 64), block, 0, s,
+                       b->D.amask, c->D.amask, b->d_list, cnt, 0);
+    hipLaunchKernelGGL(gqp::k_compact_scalars, dim3((cnt + 63) / 64), block, 0, s, b->D, c->D, b->d_list, cnt, 0);
+    *c->h_nact = cnt;
+    HIPCHK(hipMemcpyAsync(c->D.n_active, c->h_nact, sizeof(int), hipMemcpyHostToDevice, s));
+    c->D.stat = nullptr; c->D.stat_inst = 0; c->D.stat_rows = 0;
+    HIPCHK(hipStreamSynchronize(s)); /* `list` (host) must outlive the copy */
+}
+
+static void compact_back(ocp_qp_gpu_batch *b, hipStream_t s)
+{
+    ocp_qp_gpu_batch *c = b->compact;
+    const int cnt = c->B;
+    const dim3 block(64);
+#define GQP_COPY_OUT(A)                                                                                    \
+    if (b->D.A.E > 0 && b->D.A.p && c->D.A.p)                                                              \
+        hipLaunchKernelGGL(gqp::k_compact_copy<double>, dim3((cnt + 63) / 64, (b->D.A.E + 63) / 64), block, 0, s, \
+                           b->D.A, c->D.A, b->d_list, cnt, 1);
+    GQP_FOR_RESULT_ARRAYS(GQP_COPY_OUT)
+#undef GQP_COPY_OUT
+    hipLaunchKernelGGL(gqp::k_compact_scalars, dim3((cnt + 63) / 64), block, 0, s, b->D, c->D, b->d_list, cnt, 1);
+}
+
 int ocp_qp_gpu_batch_solve(ocp_qp_gpu_batch *b)
 {
     HIPCHK(hipSetDevice(b->device));
@@ -776,36 +957,16 @@ int ocp_qp_gpu_batch_solve(ocp_qp_gpu_batch *b)
     b->time_xcond = 0.0;
     ensure_stat(b);
     const KernelSet *ks = b->ks;
-    const int xb = b->xbox;
-    const kern_redo_t k_fact = b->use_box ? ks->box_fact[xb] : ks->back_fact;
-    const kern_redo_t k_rhs = b->use_box ? ks->box_rhs[xb] : ks->back_rhs;
-    const kern_redo_t k_faff = b->use_box ? ks->box_fwd_aff[xb] : ks->fwd_aff;
-    const kern_redo_t k_fcorr = b->use_box ? ks->box_fwd_corr[xb] : ks->fwd_corr;
-    const kern_plain_t k_final = b->use_box ? ks->box_finalize : ks->finalize;
     GqpDev D = b->D;
     GqpOpts O = b->O;
     const dim3 grid((b->B + 63) / 64), block(64);
     hipStream_t s = b->stream;
     b->launches = 0;
+    b->n_compactions = 0;
     /* kernel classes: 0 init, 1 back_fact, 2 fwd_aff, 3 back_rhs, 4 fwd_corr, 5 finalize */
-    size_t ev_used = 0;
     b->prof_cls.clear();
-    auto prof_begin = [&](int cls) {
-        if (!b->profile) return;
-        if (ev_used + 2 > b->prof_ev.size())
-        {
-            hipEvent_t e0, e1;
-            HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
-            b->prof_ev.push_back(e0); b->prof_ev.push_back(e1);
-        }
-        b->prof_cls.push_back(cls);
-        HIPCHK(hipEventRecord(b->prof_ev[ev_used], s));
-    };
-    auto prof_end = [&]() {
-        if (!b->profile) return;
-        HIPCHK(hipEventRecord(b->prof_ev[ev_used + 1], s));
-        ev_used += 2;
-    };
+    Prof prof;
+    prof.root = b;
 
     HIPCHK(hipEventRecord(b->ev0, s));
     *b->h_nact = b->B;
@@ -813,9 +974,9 @@ int ocp_qp_gpu_batch_solve(ocp_qp_gpu_batch *b)
     if (D.stat) HIPCHK(hipMemsetAsync(D.stat, 0, sizeof(double) * (size_t) b->stat_rows * GQP_STAT_COLS * b->stat_inst, s));
     if (O.warm_start < 2)
     {
-        prof_begin(0);
+        prof.begin(0, s);
         hipLaunchKernelGGL(ks->init, grid, block, 0, s, D, O);
-        prof_end();
+        prof.end(s);
         b->launches++;
     }
     else
@@ -826,35 +987,8 @@ int ocp_qp_gpu_batch_solve(ocp_qp_gpu_batch *b)
         HIPCHK(hipMemcpyAsync(D.status, run.data(), sizeof(int) * b->Bp, hipMemcpyHostToDevice, s));
         HIPCHK(hipStreamSynchronize(s));
     }
-    int it = 0;
-    for (;; it++)
-    {
-        prof_begin(1);
-        hipLaunchKernelGGL(k_fact, grid, block, 0, s, D, O, 0);
-        prof_end();
-        b->launches++;
-        HIPCHK(hipMemcpyAsync(b->h_nact, D.n_active, sizeof(int), hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-        if (b->print_level > 1) printf("acados_amd: ipm iter %d active %d\n", it, *b->h_nact);
-        if (*b->h_nact <= 0 || it > O.iter_max) break;
-        prof_begin(2);
-        hipLaunchKernelGGL(k_faff, grid, block, 0, s, D, O, 0);
-        prof_end();
-        prof_begin(3);
-        hipLaunchKernelGGL(k_rhs, grid, block, 0, s, D, O, 0);
-        prof_end();
-        prof_begin(4);
-        hipLaunchKernelGGL(k_fcorr, grid, block, 0, s, D, O, 0);
-        prof_end();
-        b->launches += 3;
-        if (O.cond_pred_corr)
-        {
-            hipLaunchKernelGGL(k_rhs, grid, block, 0, s, D, O, 1);
-            hipLaunchKernelGGL(k_fcorr, grid, block, 0, s, D, O, 1);
-            b->launches += 2;
-        }
-    }
-    hipLaunchKernelGGL(k_final, grid, block, 0, s, D);
+    run_ipm(b, b, prof, s, 0);
+    hipLaunchKernelGGL(pick_kernels(b).final_, grid, block, 0, s, D);
     b->launches++;
     HIPCHK(hipEventRecord(b->ev1, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -862,7 +996,13 @@ int ocp_qp_gpu_batch_solve(ocp_qp_gpu_batch *b)
     float ms = 0.f;
     HIPCHK(hipEventElapsedTime(&ms, b->ev0, b->ev1));
     b->time_tot = ms * 1e-3;
-    b->last_iters = it;
+    {
+        std::vector<int> itv(b->B);
+        HIPCHK(hipMemcpy(itv.data(), D.iter, sizeof(int) * b->B, hipMemcpyDeviceToHost));
+        int mx = 0;
+        for (int v : itv) mx = std::max(mx, v);
+        b->last_iters = mx;
+    }
     for (size_t q = 0; q < b->prof_cls.size(); q++)
     {
         float pm = 0.f;
@@ -883,7 +1023,7 @@ int ocp_qp_gpu_batch_get(ocp_qp_gpu_batch *b, const char *f, int k, double *data
     HIPCHK(hipSetDevice(b->device));
     finalize_structure(b);
     std::vector<int> map;
-    double *arr = nullptr;
+    GArr arr = {nullptr, 0};
     const int len = field_map(b, f, k, map, &arr);
     if (len < 0)
     {
@@ -903,7 +1043,7 @@ int ocp_qp_gpu_batch_get(ocp_qp_gpu_batch *b, const char *f, int k, double *data
         dst = b->d_stage;
     }
     int *dm = upload_map(b, map);
-    hipLaunchKernelGGL(gqp::k_gather, dim3((b->B + 63) / 64), dim3(64), 0, b->stream, dst, b->B, len, dm, arr, b->Bp);
+    hipLaunchKernelGGL(gqp::k_gather, dim3((b->B + 63) / 64), dim3(64), 0, b->stream, dst, b->B, len, dm, arr);
     if (!is_device) HIPCHK(hipMemcpyAsync(data, dst, sizeof(double) * cnt, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     return 0;
@@ -951,6 +1091,7 @@ double ocp_qp_gpu_batch_get_scalar(ocp_qp_gpu_batch *b, const char *f)
     if (!strcmp(f, "iter_max_batch")) return (double) b->last_iters;
     if (!strcmp(f, "launches")) return (double) b->launches;
     if (!strcmp(f, "time_xcond")) return b->time_xcond;
+    if (!strcmp(f, "compactions")) return (double) b->n_compactions;
     if (!strcmp(f, "cond_N_active")) return b->pcond_state == 1 ? (double) b->cond_N : (double) b->N;
     {
         /* accumulated per-kernel-class event times (ms) and launch counts since the last reset */

@@ -1,10 +1,11 @@
 /*
  * gpu_ipm_internal.h -- device-side data model of one shape-uniform batch of OCP-QPs.
  *
- * HBM layout ("element-major, instance-minor"): every per-instance quantity is an array
- *     a[(stage_offset + element) * Bp + instance]
- * with Bp = batch padded to a multiple of 64, so that the 64 lanes of a wavefront
- * (one instance per lane) read 64 consecutive doubles = 512 B per load instruction.
+ * HBM layout: every per-instance quantity is a wave-tiled array (GArrT below),
+ *     a.p[((instance / 64) * a.E + stage_offset + element) * 64 + instance % 64]
+ * with the batch padded to a multiple of 64 (Bp): the 64 lanes of a wavefront (one instance
+ * per lane) read 64 consecutive doubles = 512 B per load instruction, and everything one
+ * wavefront touches in one array is one contiguous region.
  * Stage dims are padded to the compile-time (NX, NU) of the kernel instantiation:
  * padded variables get unit Hessian diagonal, zero gradient and zero dynamics rows /
  * columns, so they stay exactly zero and contribute exactly zero residual.
@@ -39,6 +40,21 @@ struct GqpOpts
     int iter_max, pred_corr, cond_pred_corr, warm_start;
 };
 
+/* One per-instance HBM array: `E` elements per instance, stored WAVE-TILED,
+ *     p[((i / 64) * E + e) * 64 + (i % 64)]          (instance i, element e)
+ * so that the 64 lanes of a wavefront still read 512 contiguous bytes per load instruction
+ * AND consecutive elements / stages of one wavefront are adjacent in memory: a wave streams
+ * its own contiguous region of every array (DRAM-row and TLB friendly), instead of touching
+ * a new 512-KB-distant address per element as in a plain [element][instance] layout. */
+template <class T>
+struct GArrT
+{
+    T *p;
+    int E;
+};
+typedef GArrT<double> GArr;
+typedef GArrT<uint64_t> GArrU64;
+
 /* all device pointers of one batch; passed by value to the kernels */
 struct GqpDev
 {
@@ -51,26 +67,26 @@ struct GqpDev
      * (acados pi[k] lives in slot k+1), slots 0 and N+1 are zero; ux/dux have N+2 slots, slot
      * N+1 zero; row arrays carry 16 spare elements so that a clamped dummy row index is
      * always readable. */
-    double *BAt;   /* [N+1][n*NX]  BAt[r*NX+c] = d x+_c / d v_r                     */
-    double *bvec;  /* [N+1][NX]                                                      */
-    double *RSQ;   /* [N+1][n(n+1)/2] packed lower, row-major packed: (r,c)->r(r+1)/2+c */
-    double *rq;    /* [N+1][n]                                                       */
-    double *dvec;  /* [sum nct] natural-sign bounds, order [lb lg ub ug lls lus]     */
-    uint64_t *amask; /* [N+1] per instance: bit e set <=> inequality row e takes part */
-    double *DCt;   /* [sum ng][n]  row g: d(general row)/d v                         */
-    double *Zz;    /* [sum 2ns][2]: (Z, z) for sl then su                            */
+    GArr BAt;      /* [N+1][n*NX]  BAt[r*NX+c] = d x+_c / d v_r                     */
+    GArr bvec;     /* [N+1][NX]                                                      */
+    GArr RSQ;      /* [N+1][n(n+1)/2] packed lower, row-major packed: (r,c)->r(r+1)/2+c */
+    GArr rq;       /* [N+1][n]                                                       */
+    GArr dvec;     /* [sum nct] natural-sign bounds, order [lb lg ub ug lls lus]     */
+    GArrU64 amask; /* [N+1] per instance: bit e set <=> inequality row e takes part */
+    GArr DCt;      /* [sum ng][n]  row g: d(general row)/d v                         */
+    GArr Zz;       /* [sum 2ns][2]: (Z, z) for sl then su                            */
     /* iterate */
-    double *ux;    /* [N+2][n] */
-    double *sv;    /* [sum 2ns] slack values sl then su */
-    double *pi;    /* [N+2][NX], see slot conventions */
-    double *lam, *t; /* [sum nct] */
+    GArr ux;       /* [N+2][n] */
+    GArr sv;       /* [sum 2ns] slack values sl then su */
+    GArr pi;       /* [N+2][NX], see slot conventions */
+    GArr lam, t;   /* [sum nct] */
     /* work */
-    double *rg, *rgs, *rb, *rd, *rm;
-    double *dux, *dsv, *dpi, *dlam, *dt;
-    double *pcorr; /* [sum nct] dlam_aff*dt_aff of the affine step (fast path stores only the product) */
-    double *sD, *sR; /* [sum 2ns] per-slack D = Z + sum Gamma and r~ (condensed slack rhs) */
-    double *Lf;    /* [N+1][n(n+1)/2] Cholesky factors */
-    double *lf;    /* [N+1][n] */
+    GArr rg, rgs, rb, rd, rm;
+    GArr dux, dsv, dpi, dlam, dt;
+    GArr pcorr;    /* [sum nct] dlam_aff*dt_aff of the affine step (fast path stores only the product) */
+    GArr sD, sR;   /* [sum 2ns] per-slack D = Z + sum Gamma and r~ (condensed slack rhs) */
+    GArr Lf;       /* [N+1][n(n+1)/2] Cholesky factors */
+    GArr lf;       /* [N+1][n] */
     /* per instance scalars */
     double *res;   /* [4] */
     double *mu, *smu, *alpha, *obj;

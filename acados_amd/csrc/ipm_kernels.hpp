@@ -42,14 +42,8 @@
 namespace gqp
 {
 
-template <class T>
-__device__ static inline T &gat_ref(T *base, unsigned int byte_off)
-{
-    /* base is wave-uniform (kernel argument + stage/element offset), byte_off is the only
-     * per-lane part and is a 32-bit BYTE offset: exactly the saddr + voffset operand pair */
-    return *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + byte_off);
-}
-#define GAT(arr, e) gat_ref((arr) + (size_t) (e) * (size_t) Bp, (unsigned int) i * (unsigned int) sizeof(*(arr)))
+/* element e of this lane's instance in a wave-tiled array (gpu_ipm_internal.h, GArrT) */
+#define GAT(arr, e) (arr).p[((size_t) (i >> 6) * (size_t) (arr).E + (size_t) (e)) * 64 + (size_t) (i & 63)]
 
 __device__ static inline double dmax(double a, double b) { return a > b ? a : b; }
 __device__ static inline double dabs(double a) { return a < 0.0 ? -a : a; }
@@ -982,37 +976,37 @@ __global__ void __launch_bounds__(64) k_finalize(GqpDev D)
 
 /* -------------------------------------------- layout conversion kernels */
 
-/* dst[(map[e]) * Bp + i] = src[i * len + e]  (map[e] < 0: element dropped) */
-static __global__ void k_scatter(const double *src, int nb, int len, const int *map, double *dst, int Bp)
+/* element map[e] of instance i <- src[i * len + e]  (map[e] < 0: element dropped) */
+static __global__ void k_scatter(const double *src, int nb, int len, const int *map, GArr dst)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nb) return;
     for (int e = 0; e < len; e++)
     {
         const int m = map[e];
-        if (m >= 0) dst[(size_t) m * Bp + i] = src[(size_t) i * len + e];
+        if (m >= 0) GAT(dst, m) = src[(size_t) i * len + e];
     }
 }
 
-/* dst[i * len + e] = src[(map[e]) * Bp + i]  (map[e] < 0: 0) */
-static __global__ void k_gather(double *dst, int nb, int len, const int *map, const double *src, int Bp)
+/* dst[i * len + e] = element map[e] of instance i  (map[e] < 0: 0) */
+static __global__ void k_gather(double *dst, int nb, int len, const int *map, GArr src)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nb) return;
     for (int e = 0; e < len; e++)
     {
         const int m = map[e];
-        dst[(size_t) i * len + e] = m >= 0 ? src[(size_t) m * Bp + i] : 0.0;
+        dst[(size_t) i * len + e] = m >= 0 ? GAT(src, m) : 0.0;
     }
 }
 
 /* activity bit masks: for every element e of a (lower|upper|slack) mask vector handed
  * over by the caller, set or clear bit bitpos[e] of amask[stage] */
-static __global__ void k_setmask(const double *src, int nb, int len, const int *bitpos, uint64_t *amask_stage)
+static __global__ void k_setmask(const double *src, int nb, int len, const int *bitpos, GArrU64 amask, int stage)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nb) return;
-    uint64_t m = amask_stage[i];
+    uint64_t m = GAT(amask, stage);
     for (int e = 0; e < len; e++)
     {
         const int b = bitpos[e];
@@ -1020,19 +1014,59 @@ static __global__ void k_setmask(const double *src, int nb, int len, const int *
         if (src[(size_t) i * len + e] != 0.0) m |= (uint64_t) 1 << b;
         else m &= ~((uint64_t) 1 << b);
     }
-    amask_stage[i] = m;
+    GAT(amask, stage) = m;
 }
 
-static __global__ void k_fill_u64(uint64_t *dst, uint64_t val, size_t cnt)
+/* gather (dir 0): slot s of the dense level `c` <- instance list[s] of level `b`; scatter (dir 1):
+ * the reverse.  blockIdx.y selects a chunk of 64 elements, so the copy is parallel over elements;
+ * `list` is sorted, so the strided side still touches few 512-byte lines per wave. */
+template <class T>
+static __global__ void k_compact_copy(GArrT<T> big, GArrT<T> small, const int *list, int cnt, int dir)
 {
-    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < cnt) dst[i] = val;
+    const int sidx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sidx >= cnt) return;
+    const int src = list[sidx];
+    const int e0 = blockIdx.y * 64, e1 = e0 + 64 < big.E ? e0 + 64 : big.E;
+    T *pb = big.p + ((size_t) (src >> 6) * (size_t) big.E) * 64 + (src & 63);
+    T *ps = small.p + ((size_t) (sidx >> 6) * (size_t) small.E) * 64 + (sidx & 63);
+    if (dir == 0) for (int e = e0; e < e1; e++) ps[(size_t) e * 64] = pb[(size_t) e * 64];
+    else for (int e = e0; e < e1; e++) pb[(size_t) e * 64] = ps[(size_t) e * 64];
 }
 
-static __global__ void k_fill_strided(double *dst, double val, int nb, int Bp, int e)
+static __global__ void k_compact_scalars(GqpDev big, GqpDev small, const int *list, int cnt, int dir)
+{
+    const int sidx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sidx >= cnt) return;
+    const int i = list[sidx];
+    if (dir == 0)
+    {
+        small.iter[sidx] = big.iter[i];
+        small.status[sidx] = big.status[i];
+        small.alpha[sidx] = big.alpha[i];
+        small.mu[sidx] = big.mu[i];
+        small.smu[sidx] = big.smu[i];
+    }
+    else
+    {
+        big.iter[i] = small.iter[sidx];
+        big.status[i] = small.status[sidx];
+        big.alpha[i] = small.alpha[sidx];
+        big.mu[i] = small.mu[sidx];
+        big.obj[i] = small.obj[sidx];
+        for (int q = 0; q < 4; q++) big.res[(size_t) q * big.Bp + i] = small.res[(size_t) q * small.Bp + sidx];
+    }
+}
+
+static __global__ void k_fill_u64(GArrU64 dst, uint64_t val, int nb, int e)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nb) dst[(size_t) e * Bp + i] = val;
+    if (i < nb) GAT(dst, e) = val;
+}
+
+static __global__ void k_fill_strided(GArr dst, double val, int nb, int e)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < nb) GAT(dst, e) = val;
 }
 
 } // namespace gqp

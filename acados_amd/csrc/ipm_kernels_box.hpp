@@ -110,7 +110,7 @@ __device__ static inline StageU stage_u(const GqpStage *st, int k)
  * i.e. ONE 32-bit VGPR (lane byte offset) serves every access and the element offset is scalar.
  * With plain pointers hipcc keeps a 64-bit VGPR address per access (360 v_lshl_add_u64 and as
  * many VGPR pairs per stage in the factor kernel), which is what pushed it into scratch.
- * Element offsets stay below 4 GiB because the SRD is rebased per stage.
+ * The SRD points at this wave's tile of the array; element offsets are e * 512 B.
  * --------------------------------------------------------------------------------------- */
 struct Acc
 {
@@ -122,6 +122,11 @@ struct Acc
     {
         return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, (unsigned int) e * bp8, 0));
     }
+    /* load whose lane offset carries the (always zero) ordering token, see kb_factor */
+    __device__ inline double ldo(int e, int ord) const
+    {
+        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, voff + (unsigned int) ord, (unsigned int) e * bp8, 0));
+    }
     __device__ inline void st(int e, double v) const
     {
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(raw_t, v), rs, voff, (unsigned int) e * bp8, 0);
@@ -130,24 +135,28 @@ struct Acc
     double *p;
     size_t bp;
     double ld(int e) const { return p[(size_t) e * bp]; }
+    double ldo(int e, int) const { return p[(size_t) e * bp]; }
     void st(int e, double v) const { p[(size_t) e * bp] = v; }
 #endif
 };
 
-__device__ static inline Acc acc_at(double *base, size_t e0, int Bp, int i)
+__device__ static inline Acc acc_at(GArr arr, size_t e0, int i)
 {
     Acc a;
+    /* this wave's tile of the array: blocks are single waves of 64 lanes, so the tile index is
+     * blockIdx.x -- wave-uniform and provably so (a value derived from threadIdx would not be) */
+    double *base = arr.p + ((size_t) blockIdx.x * (size_t) arr.E + e0) * 64;
 #if defined(__HIP_DEVICE_COMPILE__)
-    a.rs = __builtin_amdgcn_make_buffer_rsrc((void *) (base + e0 * (size_t) Bp), 0, 0xFFFFFFFFu, 0x00020000);
-    a.bp8 = (unsigned int) Bp * 8u;
-    a.voff = (unsigned int) i * 8u;
+    a.rs = __builtin_amdgcn_make_buffer_rsrc((void *) base, 0, 0xFFFFFFFFu, 0x00020000);
+    a.bp8 = 512u; /* 64 lanes x 8 bytes per element */
+    a.voff = (unsigned int) (i & 63) * 8u;
 #else
-    a.p = base + e0 * (size_t) Bp + i;
-    a.bp = (size_t) Bp;
+    a.p = base + (i & 63);
+    a.bp = 64;
 #endif
     return a;
 }
-#define ACC(arr, e0) acc_at((arr), (size_t) (e0), Bp, i)
+#define ACC(arr, e0) acc_at((arr), (size_t) (e0), i)
 
 /* Scheduling fence: hipcc's machine scheduler hoists every load of a straight-line stage body
  * to its top (it only watches the 512-register ceiling), and the allocator then spills the
@@ -165,7 +174,15 @@ __device__ static inline Acc acc_at(double *base, size_t e0, int Bp, int i)
 #define GQP_OPAQUE(x) do { } while (0)
 #endif
 
-#define GQP_ROW_CHUNK 4 /* rows of [B A]' fetched per memory round trip in kb_factor */
+/* x (an int living in a VGPR, always 0 or a lane index) becomes data-dependent on val */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define GQP_AFTER(x, val) asm volatile("" : "+v"(x) : "v"(val))
+#else
+#define GQP_AFTER(x, val) do { } while (0)
+#endif
+
+#define GQP_ROW_CHUNK 4  /* rows of [B A]' fetched per load phase in kb_factor */
+#define GQP_HROW_CHUNK 3 /* Hessian rows fetched per load phase in kb_factor */
 
 /* row bookkeeping of variable j: exists?, compact row index (clamped to 0 when absent) */
 #define GQP_ROW(j, has, ib)                                                                    \
@@ -207,6 +224,15 @@ __global__ void __launch_bounds__(64) kb_factor(GqpDev D, GqpOpts O, int redo)
         const uint64_t am = GAT(D.amask, k);
         const int nbg = S.nb;
 
+        /* The stage body is a chain of load phases.  `ord` is an always-zero lane offset that is
+         * "laundered" (GQP_AFTER) through a value computed at the end of the previous phase and
+         * added to the addresses of the next phase's loads: the compiler therefore cannot hoist
+         * those loads above that computation.  This bounds the number of loaded blocks that are
+         * live at once -- without it hipcc hoists all ~230 loads of the stage to the top, runs
+         * out of registers and then serialises the loads one by one (profiles/r01_*).  Unlike an
+         * instruction fence it leaves the scheduler free inside a phase. */
+        int ord = 0;
+
         /* ---------------- phase 0 loads: what the dynamics rows need ---------------- */
         double rb[NX], pin[NX], v[n], gt[n];
         UNROLL for (int c = 0; c < NX; c++)
@@ -216,23 +242,22 @@ __global__ void __launch_bounds__(64) kb_factor(GqpDev D, GqpOpts O, int redo)
         }
         UNROLL for (int j = 0; j < n; j++) v[j] = ACC(D.ux, 0).ld(k * n + j);
 
-        /* ---------------- dynamics, one row of [B A]' at a time ----------------
-         * rb += row*v_r, gt_r = g_r + row.pi+, W_r = row * Lx+ */
+        /* ---------------- dynamics, GQP_ROW_CHUNK rows of [B A]' per load phase ----------------
+         * rb += row*v_r, gt_r = row.pi+, W_r = row * Lx+ (state rows of W go to LDS) */
         double Wu[NU * NX];
-        const int kr = k;
-        GQP_PHASE();
+        const Acc aBAt = ACC(D.BAt, k * n * NX);
         UNROLL for (int r = 0; r < n; r++)
         {
-            if (r > 0 && r % GQP_ROW_CHUNK == 0) GQP_PHASE();
+            if (r > 0 && r % GQP_ROW_CHUNK == 0) GQP_AFTER(ord, rb[0]);
             double row[NX];
-            UNROLL for (int c = 0; c < NX; c++) row[c] = ACC(D.BAt, 0).ld((kr * n + r) * NX + c);
+            UNROLL for (int c = 0; c < NX; c++) row[c] = aBAt.ldo(r * NX + c, ord);
             double a = 0.0;
             UNROLL for (int c = 0; c < NX; c++)
             {
                 a += row[c] * pin[c];
                 rb[c] += row[c] * v[r];
             }
-            gt[r] = a; /* BAt pi+ ; gradient and H v are added in the last phase */
+            gt[r] = a; /* BAt pi+ ; gradient and H v are added below */
             UNROLL for (int c = 0; c < NX; c++)
             {
                 double w = 0.0;
@@ -251,64 +276,85 @@ __global__ void __launch_bounds__(64) kb_factor(GqpDev D, GqpOpts O, int redo)
             w0[c] = a;
         }
 
-        /* last load phase: the Hessian */
-        GQP_PHASE();
-        double M[NP];
-        UNROLL for (int e = 0; e < NP; e++) M[e] = ACC(D.RSQ, 0).ld(kr * NP + e);
+        /* ---------------- box rows (need v only) ---------------- */
+        GQP_AFTER(ord, w0[0]);
         double g[n], pik[NX];
-        UNROLL for (int j = 0; j < n; j++) g[j] = ACC(D.rq, 0).ld(k * n + j);
-        UNROLL for (int c = 0; c < NX; c++) pik[c] = ACC(D.pi, 0).ld(k * NX + c);
-        double lbv[NB], ubv[NB], laml[NB], lamu[NB], tl[NB], tu[NB];
+        UNROLL for (int j = 0; j < n; j++) g[j] = ACC(D.rq, 0).ldo(k * n + j, ord);
+        UNROLL for (int c = 0; c < NX; c++) pik[c] = ACC(D.pi, 0).ldo(k * NX + c, ord);
+        double rdl[NB], rdu[NB], gadd[NB], gam[NB];
         UNROLL for (int j = 0; j < NB; j++)
         {
             GQP_ROW(j, has, ib);
             const int el = S.o_ct + ib, eu = el + nbg;
-            lbv[j] = ACC(D.dvec, 0).ld(el); ubv[j] = ACC(D.dvec, 0).ld(eu);
-            laml[j] = ACC(D.lam, 0).ld(el); lamu[j] = ACC(D.lam, 0).ld(eu);
-            tl[j] = ACC(D.t, 0).ld(el); tu[j] = ACC(D.t, 0).ld(eu);
-        }
-
-        /* ---------------- stationarity: H v ---------------- */
-        {
-            double hv[n];
-            UNROLL for (int r = 0; r < n; r++) hv[r] = 0.0;
-            UNROLL for (int r = 0; r < n; r++)
-            {
-                UNROLL for (int c = 0; c < r; c++)
-                {
-                    hv[r] += M[PK(r, c)] * v[c];
-                    hv[c] += M[PK(r, c)] * v[r];
-                }
-                hv[r] += M[PK(r, r)] * v[r];
-            }
-            UNROLL for (int r = 0; r < n; r++)
-            {
-                obj += (0.5 * hv[r] + g[r]) * v[r];
-                gt[r] += hv[r] + g[r];
-            }
-        }
-        UNROLL for (int c = 0; c < NX; c++) gt[NU + c] -= pik[c];
-        UNROLL for (int r = 0; r < n; r++) M[PK(r, r)] += O.reg_prim;
-
-        /* ---------------- box rows ---------------- */
-        double rdl[NB], rdu[NB], gadd[NB];
-        UNROLL for (int j = 0; j < NB; j++)
-        {
-            GQP_ROW(j, has, ib);
+            const double lbv = ACC(D.dvec, 0).ldo(el, ord), ubv = ACC(D.dvec, 0).ldo(eu, ord);
+            const double laml = ACC(D.lam, 0).ldo(el, ord), lamu = ACC(D.lam, 0).ldo(eu, ord);
+            const double tl = ACC(D.t, 0).ldo(el, ord), tu = ACC(D.t, 0).ldo(eu, ord);
             const bool al = has && ((am >> ib) & 1), au = has && ((am >> (nbg + ib)) & 1);
-            const double ll = al ? laml[j] : 0.0, lu = au ? lamu[j] : 0.0;
-            const double ttl = al ? tl[j] : 1.0, ttu = au ? tu[j] : 1.0;
-            rdl[j] = al ? v[j] - lbv[j] - ttl : 0.0;
-            rdu[j] = au ? ubv[j] - v[j] - ttu : 0.0;
+            const double ll = al ? laml : 0.0, lu = au ? lamu : 0.0;
+            const double ttl = al ? tl : 1.0, ttu = au ? tu : 1.0;
+            rdl[j] = al ? v[j] - lbv - ttl : 0.0;
+            rdu[j] = au ? ubv - v[j] - ttu : 0.0;
             const double rml = al ? ll * ttl - O.tau_min : 0.0, rmu = au ? lu * ttu - O.tau_min : 0.0;
             nacc(nrm_d, rdl[j]); nacc(nrm_d, rdu[j]); nacc(nrm_m, rml); nacc(nrm_m, rmu);
             musum += ll * ttl + lu * ttu;
             nact += (int) al + (int) au;
             gt[j] -= ll - lu;
             const double itl = frcp(ttl), itu = frcp(ttu);
-            M[PK(j, j)] += ll * itl + lu * itu;
+            gam[j] = ll * itl + lu * itu;
             gadd[j] = (rml + ll * rdl[j]) * itl - (rmu + lu * rdu[j]) * itu;
         }
+
+        /* ---------------- Hessian rows in load phases: H v, M = H~ + W W', W w0 ---------------- */
+        double M[NP], hv[n], mm[n];
+        UNROLL for (int r = 0; r < n; r++) hv[r] = 0.0;
+        const Acc aRSQ = ACC(D.RSQ, k * NP);
+        UNROLL for (int r = 0; r < n; r++)
+        {
+            if (r % GQP_HROW_CHUNK == 0)
+            {
+                /* next chunk of Hessian rows; ordered after the previous chunk's last update */
+                if (r > 0) GQP_AFTER(ord, M[PK(r - 1, r - 1)]);
+                UNROLL for (int r2 = r; r2 < n && r2 < r + GQP_HROW_CHUNK; r2++)
+                    UNROLL for (int c = 0; c <= r2; c++) M[PK(r2, c)] = aRSQ.ldo(PK(r2, c), ord);
+            }
+            UNROLL for (int c = 0; c < r; c++)
+            {
+                hv[r] += M[PK(r, c)] * v[c];
+                hv[c] += M[PK(r, c)] * v[r];
+            }
+            hv[r] += M[PK(r, r)] * v[r];
+            M[PK(r, r)] += O.reg_prim + (r < NB ? gam[r < NB ? r : 0] : 0.0);
+            /* row r of W, then the rows c <= r two at a time (bounded LDS reads in flight) */
+            int lr = lane_r;
+            GQP_AFTER(lr, hv[r]);
+            double wr[NX];
+            UNROLL for (int q = 0; q < NX; q++)
+                wr[q] = r < NU ? Wu[(r < NU ? r : 0) * NX + q]
+                      : W_IN_LDS ? Wl[W_IN_LDS ? (((r < NU ? NU : r) - NU) * NX + q) * 64 + lr : 0]
+                                 : Wx[W_IN_LDS ? 0 : ((r < NU ? NU : r) - NU) * NX + q];
+            double a = 0.0;
+            UNROLL for (int c = 0; c < NX; c++) a += wr[c] * w0[c];
+            mm[r] = a + (r < NB ? gadd[r < NB ? r : 0] : 0.0);
+            UNROLL for (int c = 0; c <= r; c++)
+            {
+                if (c >= NU && ((c - NU) & 1) == 0 && c > NU) GQP_AFTER(lr, M[PK(r, c - 1)]);
+                double sacc = 0.0;
+                UNROLL for (int q = 0; q < NX; q++)
+                {
+                    const double wc = c < NU ? Wu[(c < NU ? c : 0) * NX + q]
+                                    : W_IN_LDS ? Wl[W_IN_LDS ? (((c < NU ? NU : c) - NU) * NX + q) * 64 + lr : 0]
+                                               : Wx[W_IN_LDS ? 0 : ((c < NU ? NU : c) - NU) * NX + q];
+                    sacc += wr[q] * wc;
+                }
+                M[PK(r, c)] += sacc;
+            }
+        }
+        UNROLL for (int r = 0; r < n; r++)
+        {
+            obj += (0.5 * hv[r] + g[r]) * v[r];
+            gt[r] += hv[r] + g[r];
+        }
+        UNROLL for (int c = 0; c < NX; c++) gt[NU + c] -= pik[c];
         /* residual norms; fixed variables carry no residual */
         UNROLL for (int j = 0; j < n; j++)
         {
@@ -318,32 +364,8 @@ __global__ void __launch_bounds__(64) kb_factor(GqpDev D, GqpOpts O, int redo)
         UNROLL for (int c = 0; c < NX; c++) nacc(nrm_b, rb[c]);
         UNROLL for (int j = 0; j < n; j++) ACC(D.rg, 0).st(k * n + j, gt[j]);
         UNROLL for (int c = 0; c < NX; c++) ACC(D.rb, 0).st(k * NX + c, rb[c]);
-
-        /* ---------------- M += W W', m = gt + gadd + W w0 ---------------- */
-        UNROLL for (int j = 0; j < NB; j++) gt[j] += gadd[j];
-        UNROLL for (int r = 0; r < n; r++)
-        {
-            double wr[NX];
-            UNROLL for (int q = 0; q < NX; q++)
-                wr[q] = r < NU ? Wu[(r < NU ? r : 0) * NX + q]
-                      : W_IN_LDS ? Wl[W_IN_LDS ? (((r < NU ? NU : r) - NU) * NX + q) * 64 + lane_r : 0]
-                                 : Wx[W_IN_LDS ? 0 : ((r < NU ? NU : r) - NU) * NX + q];
-            double a = 0.0;
-            UNROLL for (int c = 0; c < NX; c++) a += wr[c] * w0[c];
-            gt[r] += a;
-            UNROLL for (int c = 0; c <= r; c++)
-            {
-                double s = 0.0;
-                UNROLL for (int q = 0; q < NX; q++)
-                {
-                    const double wc = c < NU ? Wu[(c < NU ? c : 0) * NX + q]
-                                    : W_IN_LDS ? Wl[W_IN_LDS ? (((c < NU ? NU : c) - NU) * NX + q) * 64 + lane_r : 0]
-                                               : Wx[W_IN_LDS ? 0 : ((c < NU ? NU : c) - NU) * NX + q];
-                    s += wr[q] * wc;
-                }
-                M[PK(r, c)] += s;
-            }
-        }
+        /* m = stationarity residual + condensed inequality terms + W w0 */
+        UNROLL for (int j = 0; j < n; j++) gt[j] += mm[j];
         /* fixed variables: unit row/column, zero rhs (select, no branch) */
         UNROLL for (int r = 0; r < n; r++)
         {

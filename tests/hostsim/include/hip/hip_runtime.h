@@ -69,12 +69,13 @@ static inline int atomicAdd(int *p, int v) { int o = *p; *p = o + v; return o; }
     do {                                                                                    \
         dim3 g_ = (grid); dim3 b_ = (block);                                                         \
         blockDim = b_; gridDim = g_;                                                        \
-        for (unsigned bx_ = 0; bx_ < g_.x; bx_++)                                           \
-            for (unsigned tx_ = 0; tx_ < b_.x; tx_++)                                       \
-            {                                                                               \
-                blockIdx.x = bx_; threadIdx.x = tx_;                                        \
-                kern(__VA_ARGS__);                                                          \
-            }                                                                               \
+        for (unsigned by_ = 0; by_ < g_.y; by_++)                                           \
+            for (unsigned bx_ = 0; bx_ < g_.x; bx_++)                                       \
+                for (unsigned tx_ = 0; tx_ < b_.x; tx_++)                                   \
+                {                                                                           \
+                    blockIdx.x = bx_; blockIdx.y = by_; threadIdx.x = tx_;                  \
+                    kern(__VA_ARGS__);                                                      \
+                }                                                                           \
     } while (0)
 
 #endif

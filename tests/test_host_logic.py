@@ -223,3 +223,28 @@ def test_partial_condensing_hostsim(hostsim_lib):
     run([lqr_instance_qp(data, i, 10) for i in range(3)], 3, 3)        # blocks of 4, 3, 3
     run([load_qp("qp_test/last_qp_nonuniform_pendulum.json")], 3, 3)   # N=7 -> 3, 2, 2 ; x0 equality rows
     run([mass_spring_qp(N=15)], 5, 15)                                  # declined: state bounds in blocks
+
+
+def test_compaction_is_bit_identical_hostsim(hostsim_lib):
+    """late IPM iterations continue on a dense sub-batch of the still-active instances (recursive
+    compaction); per-instance arithmetic is unchanged, so every output bit must equal the run
+    without compaction"""
+    from acados_amd import OcpQpGpuBatch
+    from acados_amd.generators import fill_lqr_batch, lqr_dims, random_lqr_batch
+    N, B = 12, 150
+    data = random_lqr_batch(N=N, batch=B, seed=9)
+    runs = []
+    for cmin in (1 << 30, 4):
+        gb = OcpQpGpuBatch(lqr_dims(N, 8, 3), B, _clib=hostsim_lib)
+        fill_lqr_batch(gb, data, N)
+        gb.opts_set("tol_stat", 1e-8)
+        gb.opts_set("compact_min", cmin)
+        assert gb.solve() == 0
+        runs.append(gb)
+    assert int(runs[0].scalar("compactions")) == 0 and int(runs[1].scalar("compactions")) >= 2
+    assert len(set(runs[0].info("iter").tolist())) >= 3     # instances really finish at different iterations
+    for f in ("status", "iter", "res_stat", "res_comp", "mu"):
+        assert np.array_equal(runs[0].info(f), runs[1].info(f)), f
+    for k in range(N + 1):
+        for f in ("x", "u", "lam", "t") + (("pi",) if k < N else ()):
+            assert np.array_equal(runs[0].get(f, k), runs[1].get(f, k)), (f, k)
