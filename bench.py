@@ -70,6 +70,7 @@ def main():
     ap.add_argument("--nu", type=int, default=3)
     ap.add_argument("--cpu-sample", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--compact-min", type=int, default=None, help="override the library default of the compaction threshold")
     ap.add_argument("--check", type=int, default=8, help="instances per rank checked against the oracle (outside timing)")
     args = ap.parse_args()
 
@@ -109,6 +110,8 @@ def main():
         gb.opts_set(f, 1e-8)
     gb.opts_set("iter_max", 50)
     gb.opts_set("warm_start", 0)
+    if args.compact_min is not None:
+        gb.opts_set("compact_min", args.compact_min)
 
     def barrier():
         if dist is not None:
@@ -185,6 +188,19 @@ def main():
     avg_s = dom_ms * 1e-3 / max(dom_cnt, 1)
     achieved = per_launch_bytes / avg_s / 1e9
     solves_per_s = world * B * args.steps / elapsed
+    # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 cannot run inside
+    # this process); corrected as MI355X_MICROARCH.md prescribes, see profiles/r01_v2_pmc_traffic.json
+    kern_sym = {"back_fact": "kb_factor", "fwd_aff": "kb_forward", "back_rhs": "kb_backrhs", "fwd_corr": "kb_forward"}[dom] \
+        if dom in ("back_fact", "fwd_aff", "back_rhs", "fwd_corr") else dom
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_v2_pmc_traffic.json")))
+        want = {"back_fact": f"kb_factor<{nx}, {nu}, false>", "back_rhs": f"kb_backrhs<{nx}, {nu}, false>",
+                "fwd_aff": f"kb_forward<{nx}, {nu}, false, false>", "fwd_corr": f"kb_forward<{nx}, {nu}, false, true>"}.get(dom)
+        if want in pmc and B == 65536 and N == 50:
+            traffic = pmc[want]["hbm_bytes_per_launch_avg"]
+    except Exception:
+        traffic = None
     out = {
         "metric": "OCP-QP solves/sec (batch) at N=50 nx=8 nu=3",
         "value": solves_per_s,
@@ -205,9 +221,9 @@ def main():
         "ipm": {"mean_iter": mean_iter, "max_iter": max_iter, "failures": failures, "max_kkt_residual": res_max,
                 "max_rel_primal_err_vs_oracle": err, "oracle_checked_instances": args.check,
                 "launches_per_step": int(gb.scalar("launches"))},
-        "roofline": {"bound": "hbm", "kernel": f"k_backward<FACT> ({dom})" if dom == "back_fact" else dom,
+        "roofline": {"bound": "hbm", "kernel": f"{kern_sym} ({dom}) of {gb.kernel_name}",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": None,
+                     "traffic": traffic,
                      "bytes_per_launch": per_launch_bytes, "avg_launch_ms": avg_s * 1e3, "launches_timed": dom_cnt,
                      "kernel_ms_share": {c: prof[c][0] for c in classes},
                      "whole_solve_GBps": solves_per_s / world * (b_in + b_out) / 1e9,
