@@ -65,35 +65,45 @@ def lqr_dims(N, nx, nu):
     return d
 
 
-def _stream(seed, tag, shape, dist="uniform"):
-    """counter-based stream per (seed, field tag): instance i always sees the same numbers
-    whatever the batch size (row-major draw, one row per instance)."""
-    g = np.random.Generator(np.random.Philox(key=[int(seed), int(tag)]))
+_CHUNK = 4096
+
+
+def _stream(seed, tag, shape, dist="uniform", first=0):
+    """counter-based streams, one per (seed, field tag, chunk of 4096 instances): instance i always
+    sees the same numbers whatever the batch size or the rank that generates it, and a rank only
+    generates the chunks that overlap its own instance range [first, first + shape[0])."""
     n = int(np.prod(shape[1:]))
-    a = g.random((shape[0], n)) * 2.0 - 1.0 if dist == "uniform" else g.standard_normal((shape[0], n))
-    return a.reshape(shape)
+    out = np.empty((shape[0], n))
+    lo, hi = first, first + shape[0]
+    for c in range(lo // _CHUNK, (hi + _CHUNK - 1) // _CHUNK):
+        g = np.random.Generator(np.random.Philox(key=[int(seed), (int(tag) << 32) + c]))
+        a = g.random((_CHUNK, n)) * 2.0 - 1.0 if dist == "uniform" else g.standard_normal((_CHUNK, n))
+        s0, s1 = max(lo, c * _CHUNK), min(hi, (c + 1) * _CHUNK)
+        out[s0 - lo:s1 - lo] = a[s0 - c * _CHUNK:s1 - c * _CHUNK]
+    return out.reshape(shape)
 
 
-def random_lqr_batch(N=50, nx=8, nu=3, batch=1024, seed=0):
+def random_lqr_batch(N=50, nx=8, nu=3, batch=1024, seed=0, first=0):
     """Configuration C2: per instance
     A = A_d + 0.02 U(-1,1) rescaled to spectral radius <= 1.05, B = B_d + 0.02 U(-1,1),
     b ~ 0.1 U(-1,1), Q = I + 0.1 GG', R = 2I + 0.1 HH', S = 0.05 N(0,1), q,r ~ 0.1 N(0,1),
     x0 ~ U(-2.5,2.5) as equality bound at stage 0, u in [-0.5, 0.5].
+    Generates the global instances [first, first + batch).
     Returns dict of arrays with leading dim `batch` (matrices [batch, rows, cols])."""
     Ad, Bd = mass_spring_system(0.5, nx, nu) if nx % 2 == 0 and nu <= nx // 2 else (0.9 * np.eye(nx), np.eye(nx, nu))
-    A = Ad[None] + 0.02 * _stream(seed, 1, (batch, nx, nx))
+    A = Ad[None] + 0.02 * _stream(seed, 1, (batch, nx, nx), first=first)
     rho = np.max(np.abs(np.linalg.eigvals(A)), axis=1)
     A = A * np.minimum(1.0, 1.05 / rho)[:, None, None]
-    B = Bd[None] + 0.02 * _stream(seed, 2, (batch, nx, nu))
-    b = 0.1 * _stream(seed, 3, (batch, nx))
-    G = _stream(seed, 4, (batch, nx, nx), "normal") / np.sqrt(nx)
-    H = _stream(seed, 5, (batch, nu, nu), "normal") / np.sqrt(nu)
+    B = Bd[None] + 0.02 * _stream(seed, 2, (batch, nx, nu), first=first)
+    b = 0.1 * _stream(seed, 3, (batch, nx), first=first)
+    G = _stream(seed, 4, (batch, nx, nx), "normal", first=first) / np.sqrt(nx)
+    H = _stream(seed, 5, (batch, nu, nu), "normal", first=first) / np.sqrt(nu)
     Q = np.eye(nx)[None] + 0.1 * G @ np.transpose(G, (0, 2, 1))
     R = 2.0 * np.eye(nu)[None] + 0.1 * H @ np.transpose(H, (0, 2, 1))
-    S = 0.05 * _stream(seed, 6, (batch, nu, nx), "normal")
-    q = 0.1 * _stream(seed, 7, (batch, nx), "normal")
-    r = 0.1 * _stream(seed, 8, (batch, nu), "normal")
-    x0 = 2.5 * _stream(seed, 9, (batch, nx))
+    S = 0.05 * _stream(seed, 6, (batch, nu, nx), "normal", first=first)
+    q = 0.1 * _stream(seed, 7, (batch, nx), "normal", first=first)
+    r = 0.1 * _stream(seed, 8, (batch, nu), "normal", first=first)
+    x0 = 2.5 * _stream(seed, 9, (batch, nx), first=first)
     return dict(A=A, B=B, b=b, Q=Q, R=R, S=S, q=q, r=r, x0=x0,
                 lbu=-0.5 * np.ones((batch, nu)), ubu=0.5 * np.ones((batch, nu)))
 

@@ -91,10 +91,7 @@ def main():
 
     N, nx, nu, B = args.horizon, args.nx, args.nu, args.batch
     # instance ids are global: rank r owns [r*B, (r+1)*B) of one counter-based stream
-    data_all = random_lqr_batch(N=N, nx=nx, nu=nu, batch=B * (rank + 1), seed=0) if rank > 0 else \
-        random_lqr_batch(N=N, nx=nx, nu=nu, batch=B, seed=0)
-    data = {k: np.ascontiguousarray(v[rank * B:(rank + 1) * B]) for k, v in data_all.items()}
-    del data_all
+    data = random_lqr_batch(N=N, nx=nx, nu=nu, batch=B, seed=0, first=rank * B)
 
     gb = OcpQpGpuBatch(lqr_dims(N, nx, nu), B, device=local_rank)
 

@@ -50,6 +50,7 @@ typedef struct
     double *W;               /* n x nx1 col-major: [B A]' * Lx+ */
     double *gt;              /* n: condensed gradient */
     double *c, *dc;          /* nbg */
+    double *rmc;             /* nct: corrected complementarity rhs */
     double *tmp;             /* max(n, nx1) scratch */
 } stg;
 
@@ -128,7 +129,7 @@ oqp *oqp_create(int N, const int *nx, const int *nu, const int *nbx, const int *
         s->Dl = dz(nss); s->Du = dz(nss); s->rsl = dz(nss); s->rsu = dz(nss);
         s->wl = dz(nss * n); s->wu = dz(nss * n);
         s->L = dz(n * n); s->l = dz(n); s->W = dz(n * nx1); s->gt = dz(n);
-        s->c = dz(nbg); s->dc = dz(nbg);
+        s->c = dz(nbg); s->dc = dz(nbg); s->rmc = dz(nct);
         s->tmp = dz((n > nx1 ? n : nx1) + 1);
     }
     return qp;
@@ -146,7 +147,7 @@ void oqp_free(oqp *qp)
                      s->idxs_rev, s->idxe, s->ux, s->pi, s->lam, s->t, s->act, s->fixed,
                      s->fixval, s->rg, s->rb, s->rd, s->rm, s->dux, s->dpi, s->dlam, s->dt,
                      s->Gam, s->rho, s->Dl, s->Du, s->rsl, s->rsu, s->wl, s->wu, s->L, s->l,
-                     s->W, s->gt, s->c, s->dc, s->tmp};
+                     s->W, s->gt, s->c, s->dc, s->tmp, s->rmc};
         for (unsigned i = 0; i < sizeof(p) / sizeof(p[0]); i++) free(p[i]);
     }
     free(qp->s);
@@ -827,9 +828,13 @@ int oqp_solve(oqp *qp, const oqp_opts *o)
 {
     int N = qp->N;
     double mu, nrm[4];
-    const double **rm_ptr = (const double **) malloc(sizeof(double *) * (N + 1));
-    double **rmc = (double **) malloc(sizeof(double *) * (N + 1));
-    for (int k = 0; k <= N; k++) rmc[k] = dz(qp->s[k].nct);
+    /* no allocation inside the solve (acados rule, ocp_qp_interface.c:550-563) -- and none that
+     * could serialise the OpenMP batch loop on the allocator */
+    const double *rm_ptr_buf[1024];
+    double *rmc_buf[1024];
+    const double **rm_ptr = N + 1 <= 1024 ? rm_ptr_buf : (const double **) malloc(sizeof(double *) * (N + 1));
+    double **rmc = N + 1 <= 1024 ? rmc_buf : (double **) malloc(sizeof(double *) * (N + 1));
+    for (int k = 0; k <= N; k++) rmc[k] = qp->s[k].rmc;
 
     setup_active(qp);
     if (o->warm_start < 2) init_var(qp, o);
@@ -933,9 +938,7 @@ int oqp_solve(oqp *qp, const oqp_opts *o)
     finalize_sol(qp);
     qp->iter = it;
     qp->status = status;
-    for (int k = 0; k <= N; k++) free(rmc[k]);
-    free(rmc);
-    free((void *) rm_ptr);
+    if (N + 1 > 1024) { free(rmc); free((void *) rm_ptr); }
     return status;
 }
 
@@ -944,7 +947,7 @@ int oqp_solve_batch(oqp **qps, int n, const oqp_opts *opts, int *status, int nth
     int bad = 0;
     (void) nthreads;
 #ifdef _OPENMP
-#pragma omp parallel for num_threads(nthreads) reduction(+ : bad) schedule(dynamic, 8)
+#pragma omp parallel for num_threads(nthreads) reduction(+ : bad) schedule(static)
 #endif
     for (int i = 0; i < n; i++)
     {
