@@ -95,6 +95,16 @@ struct ocp_qp_gpu_batch
     int *d_list = nullptr;               /* instance index of every slot of `compact` */
     int list_cap = 0;
     int n_compactions = 0;
+    /* bulk pack / unpack (one H2D + one launch per direction) */
+    struct BulkMap
+    {
+        bool built = false;
+        int len = 0, nm = 0;
+        std::vector<std::string> fields; /* per segment */
+        std::vector<int> seg_stage, seg_off, seg_len;
+        int *d_arr = nullptr, *d_elem = nullptr, *d_moff = nullptr, *d_mstage = nullptr, *d_mbit = nullptr;
+        gqp::GArrTable T;
+    } bulk_in, bulk_out;
 };
 
 namespace
@@ -378,6 +388,21 @@ int field_map(ocp_qp_gpu_batch *b, const char *f, int k, std::vector<int> &map, 
         if (!dyn()) return -1;
         *arr = D.pi; /* acados pi[k] = multiplier of the dynamics producing x_{k+1}: slot k+1 */
         for (int r = 0; r < nx1; r++) map.push_back((k + 1) * NX + r);
+    }
+    else if (!strcmp(f, "ric_L"))
+    {
+        /* Cholesky factor of the stage matrix of the last factorisation, variables [u;x] of this
+         * stage (padding removed), nv x nv column-major, lower triangle (upper = 0) */
+        *arr = D.Lf;
+        const int nv = nu + nx;
+        for (int c = 0; c < nv; c++)
+            for (int r = 0; r < nv; r++)
+                map.push_back(r >= c ? k * NP + PK(padded_var(b, k, r), padded_var(b, k, c)) : -1);
+    }
+    else if (!strcmp(f, "ric_l"))
+    {
+        *arr = D.lf;
+        for (int r = 0; r < nu + nx; r++) map.push_back(k * n + padded_var(b, k, r));
     }
     else if (!strcmp(f, "lam") || !strcmp(f, "t"))
     {
@@ -1134,6 +1159,142 @@ int ocp_qp_gpu_batch_condense_rhs_and_solve(ocp_qp_gpu_batch *b)
     const int bad = ocp_qp_gpu_batch_solve(b); /* uses mode 2 when the lhs is in place */
     b->lhs_ready = false;
     return bad;
+}
+
+
+/* ---- bulk pack / unpack ---- */
+static const char *const k_bulk_in_fields[] = {"A", "B", "b", "Q", "S", "R", "q", "r", "lbu", "ubu", "lbx", "ubx", "lg", "ug",
+                                               "C", "D", "Zl", "Zu", "zl", "zu", "lls", "lus", "lbu_mask", "ubu_mask",
+                                               "lbx_mask", "ubx_mask", "lg_mask", "ug_mask", "lls_mask", "lus_mask"};
+static const char *const k_bulk_out_fields[] = {"u", "x", "sl", "su", "pi", "lam", "t"};
+
+static void bulk_build(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch::BulkMap &M, const char *const *fields, int nf)
+{
+    if (M.built) return;
+    finalize_structure(b);
+    const GqpDev &D = b->D;
+    const GArr table[16] = {D.BAt, D.bvec, D.RSQ, D.rq, D.dvec, D.DCt, D.Zz, D.ux, D.sv, D.pi, D.lam, D.t,
+                            {nullptr, 0}, {nullptr, 0}, {nullptr, 0}, {nullptr, 0}};
+    for (int q = 0; q < 16; q++) M.T.a[q] = table[q];
+    auto table_index = [&](const GArr &a) {
+        for (int q = 0; q < 12; q++) if (table[q].p == a.p) return q;
+        return -1;
+    };
+    std::vector<int> h_arr, h_elem, h_moff, h_mstage, h_mbit;
+    for (int k = 0; k <= b->N; k++)
+        for (int fi = 0; fi < nf; fi++)
+        {
+            const char *f = fields[fi];
+            std::vector<int> map, map2;
+            GArr arr = {nullptr, 0}, arr2 = {nullptr, 0};
+            const size_t flen = strlen(f);
+            int len;
+            const bool is_mask = flen > 5 && !strcmp(f + flen - 5, "_mask");
+            if (is_mask) len = mask_bits(b, f, k, map);
+            else len = field_map(b, f, k, map, &arr, &map2, &arr2);
+            if (len <= 0) continue;
+            M.fields.push_back(f); M.seg_stage.push_back(k); M.seg_off.push_back((int) h_arr.size()); M.seg_len.push_back(len);
+            for (int e = 0; e < len; e++)
+            {
+                if (is_mask)
+                {
+                    h_moff.push_back((int) h_arr.size()); h_mstage.push_back(k); h_mbit.push_back(map[e]);
+                    h_arr.push_back(-1); h_elem.push_back(0);
+                }
+                else
+                {
+                    h_arr.push_back(map[e] >= 0 ? table_index(arr) : -1); h_elem.push_back(map[e] >= 0 ? map[e] : 0);
+                }
+            }
+            if (arr2.p)
+            {
+                /* equality-flagged x bounds also define the value of the variable: a second, hidden
+                 * segment that re-reads the same blob entries is not possible, so those entries are
+                 * written through a duplicate segment placed right after (the caller's blob carries
+                 * lbx twice: once as bound, once as value -- see ocp_qp_gpu_batch_bulk_offset) */
+                M.fields.push_back(std::string(f) + "#value"); M.seg_stage.push_back(k);
+                M.seg_off.push_back((int) h_arr.size()); M.seg_len.push_back(len);
+                for (int e = 0; e < len; e++)
+                {
+                    h_arr.push_back(map2[e] >= 0 ? table_index(arr2) : -1); h_elem.push_back(map2[e] >= 0 ? map2[e] : 0);
+                }
+            }
+        }
+    M.len = (int) h_arr.size();
+    M.nm = (int) h_moff.size();
+    M.d_arr = dalloc<int>(b, M.len); M.d_elem = dalloc<int>(b, M.len);
+    HIPCHK(hipMemcpy(M.d_arr, h_arr.data(), sizeof(int) * M.len, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(M.d_elem, h_elem.data(), sizeof(int) * M.len, hipMemcpyHostToDevice));
+    M.d_moff = dalloc<int>(b, M.nm); M.d_mstage = dalloc<int>(b, M.nm); M.d_mbit = dalloc<int>(b, M.nm);
+    if (M.nm)
+    {
+        HIPCHK(hipMemcpy(M.d_moff, h_moff.data(), sizeof(int) * M.nm, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(M.d_mstage, h_mstage.data(), sizeof(int) * M.nm, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(M.d_mbit, h_mbit.data(), sizeof(int) * M.nm, hipMemcpyHostToDevice));
+    }
+    M.built = true;
+}
+
+int ocp_qp_gpu_batch_bulk_len(ocp_qp_gpu_batch *b, int output)
+{
+    HIPCHK(hipSetDevice(b->device));
+    auto &M = output ? b->bulk_out : b->bulk_in;
+    bulk_build(b, M, output ? k_bulk_out_fields : k_bulk_in_fields, output ? 7 : 30);
+    return M.len;
+}
+
+int ocp_qp_gpu_batch_bulk_offset(ocp_qp_gpu_batch *b, int output, const char *field, int stage, int *len)
+{
+    ocp_qp_gpu_batch_bulk_len(b, output);
+    auto &M = output ? b->bulk_out : b->bulk_in;
+    for (size_t q = 0; q < M.fields.size(); q++)
+        if (M.seg_stage[q] == stage && M.fields[q] == field)
+        {
+            if (len) *len = M.seg_len[q];
+            return M.seg_off[q];
+        }
+    if (len) *len = 0;
+    return -1;
+}
+
+int ocp_qp_gpu_batch_set_bulk(ocp_qp_gpu_batch *b, const double *blob, int is_device)
+{
+    const int len = ocp_qp_gpu_batch_bulk_len(b, 0);
+    auto &M = b->bulk_in;
+    hipEvent_t e0, e1;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipEventRecord(e0, b->stream));
+    const double *src = stage_in(b, blob, (size_t) b->B * len, is_device);
+    const dim3 grid((b->B + 63) / 64, (len + 255) / 256), block(64);
+    hipLaunchKernelGGL(gqp::k_bulk_scatter, grid, block, 0, b->stream, src, b->B, len, M.d_arr, M.d_elem, M.T);
+    if (M.nm)
+        hipLaunchKernelGGL(gqp::k_bulk_masks, dim3((b->B + 63) / 64), block, 0, b->stream, src, b->B, len, M.d_moff,
+                           M.d_mstage, M.d_mbit, M.nm, b->D.amask);
+    HIPCHK(hipEventRecord(e1, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+    b->time_pack += ms * 1e-3;
+    HIPCHK(hipEventDestroy(e0)); HIPCHK(hipEventDestroy(e1));
+    return 0;
+}
+
+int ocp_qp_gpu_batch_get_bulk(ocp_qp_gpu_batch *b, double *blob, int is_device)
+{
+    const int len = ocp_qp_gpu_batch_bulk_len(b, 1);
+    auto &M = b->bulk_out;
+    const size_t cnt = (size_t) b->B * len;
+    double *dst = blob;
+    if (!is_device)
+    {
+        if (cnt > b->stage_cap) { b->stage_cap = cnt * 2; b->d_stage = dalloc<double>(b, b->stage_cap); }
+        dst = b->d_stage;
+    }
+    const dim3 grid((b->B + 63) / 64, (len + 255) / 256), block(64);
+    hipLaunchKernelGGL(gqp::k_bulk_gather, grid, block, 0, b->stream, dst, b->B, len, M.d_arr, M.d_elem, M.T);
+    if (!is_device) HIPCHK(hipMemcpyAsync(blob, dst, sizeof(double) * cnt, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return 0;
 }
 
 size_t ocp_qp_gpu_batch_bytes(const ocp_qp_gpu_batch *b) { return b->bytes; }

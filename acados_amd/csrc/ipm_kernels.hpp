@@ -1017,6 +1017,54 @@ static __global__ void k_setmask(const double *src, int nb, int len, const int *
     GAT(amask, stage) = m;
 }
 
+/* ---- bulk pack / unpack: one launch moves a whole QP (or solution) per instance ----
+ * blob[i * len + e] <-> element map_elem[e] of array map_arr[e] (map_arr < 0: entry skipped) */
+struct GArrTable
+{
+    GArr a[16];
+};
+
+static __global__ void k_bulk_scatter(const double *blob, int nb, int len, const int *map_arr, const int *map_elem,
+                                      GArrTable T)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nb) return;
+    const int e0 = blockIdx.y * 256, e1 = e0 + 256 < len ? e0 + 256 : len;
+    for (int e = e0; e < e1; e++)
+    {
+        const int a = map_arr[e];
+        if (a >= 0) GAT(T.a[a], map_elem[e]) = blob[(size_t) i * len + e];
+    }
+}
+
+static __global__ void k_bulk_gather(double *blob, int nb, int len, const int *map_arr, const int *map_elem, GArrTable T)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nb) return;
+    const int e0 = blockIdx.y * 256, e1 = e0 + 256 < len ? e0 + 256 : len;
+    for (int e = e0; e < e1; e++)
+    {
+        const int a = map_arr[e];
+        blob[(size_t) i * len + e] = a >= 0 ? GAT(T.a[a], map_elem[e]) : 0.0;
+    }
+}
+
+/* mask entries of the blob: (offset in blob, stage, bit) triples */
+static __global__ void k_bulk_masks(const double *blob, int nb, int len, const int *m_off, const int *m_stage,
+                                    const int *m_bit, int nm, GArrU64 amask)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nb) return;
+    for (int q = 0; q < nm; q++)
+    {
+        if (m_bit[q] < 0) continue;
+        uint64_t m = GAT(amask, m_stage[q]);
+        if (blob[(size_t) i * len + m_off[q]] != 0.0) m |= (uint64_t) 1 << m_bit[q];
+        else m &= ~((uint64_t) 1 << m_bit[q]);
+        GAT(amask, m_stage[q]) = m;
+    }
+}
+
 /* gather (dir 0): slot s of the dense level `c` <- instance list[s] of level `b`; scatter (dir 1):
  * the reverse.  blockIdx.y selects a chunk of 64 elements, so the copy is parallel over elements;
  * `list` is sorted, so the strided side still touches few 512-byte lines per wave. */

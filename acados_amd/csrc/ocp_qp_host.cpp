@@ -32,6 +32,7 @@ struct batch_cache
     std::vector<int> sig; /* dims + idxb + idxs_rev + idxe of the batch */
     std::vector<double> stat;
     std::vector<double> stage; /* host staging [n][len] */
+    std::vector<double> blob_in, blob_out; /* bulk pack / unpack staging: [n][bulk_len] */
 };
 
 struct gpu_ipm_memory
@@ -535,51 +536,63 @@ int ocp_qp_gpu_ipm_evaluate_batch(void *config, int n, void **qp_in_, void **qp_
     }
 
     /* re-read every member array of qp_in on every call (they alias ocp_nlp memory:
-     * ocp_nlp_common.c:2797-2894) and pack it into the device layout */
-    struct fld { const char *name; double **ocp_qp_in::*tab; int off_kind; };
+     * ocp_nlp_common.c:2797-2894) and pack them: one host blob per instance, ONE host->device copy and ONE
+     * launch for the whole batch (ocp_qp_gpu_batch_set_bulk) */
     std::vector<double> &stg = bc->stage;
-    auto push = [&](const char *name, int k, int len, auto getter) {
-        if (len <= 0) return;
-        stg.resize((size_t) n * len);
-        for (int i = 0; i < n; i++) memcpy(stg.data() + (size_t) i * len, getter(ins[i]), sizeof(double) * len);
-        ocp_qp_gpu_batch_set(b, name, k, stg.data(), 0);
-    };
-    for (int k = 0; k <= N; k++)
     {
-        const int nbu = d->nbu[k], nbx = d->nbx[k], ng = d->ng[k], ns = d->ns[k];
-        if (k < N)
+        const int L = ocp_qp_gpu_batch_bulk_len(b, 0);
+        bc->blob_in.assign((size_t) n * L, 0.0);
+        double *blob = bc->blob_in.data();
+        auto push = [&](const char *name, int k, int len, auto getter) {
+            if (len <= 0) return;
+            int seg_len = 0;
+            const int off = ocp_qp_gpu_batch_bulk_offset(b, 0, name, k, &seg_len);
+            if (off < 0 || seg_len != len)
+            {
+                printf("\nerror: ocp_qp_gpu_ipm: field %s at stage %d has no place in the device layout\n", name, k);
+                exit(1);
+            }
+            for (int i = 0; i < n; i++) memcpy(blob + (size_t) i * L + off, getter(ins[i]), sizeof(double) * len);
+        };
+        for (int k = 0; k <= N; k++)
         {
-            push("A", k, vlen(d, "A", k), [&](ocp_qp_in *q) { return q->A[k]; });
-            push("B", k, vlen(d, "B", k), [&](ocp_qp_in *q) { return q->B[k]; });
-            push("b", k, vlen(d, "b", k), [&](ocp_qp_in *q) { return q->b[k]; });
+            const int nbu = d->nbu[k], nbx = d->nbx[k], ng = d->ng[k], ns = d->ns[k];
+            if (k < N)
+            {
+                push("A", k, vlen(d, "A", k), [&](ocp_qp_in *q) { return q->A[k]; });
+                push("B", k, vlen(d, "B", k), [&](ocp_qp_in *q) { return q->B[k]; });
+                push("b", k, vlen(d, "b", k), [&](ocp_qp_in *q) { return q->b[k]; });
+            }
+            push("Q", k, vlen(d, "Q", k), [&](ocp_qp_in *q) { return q->Q[k]; });
+            push("S", k, vlen(d, "S", k), [&](ocp_qp_in *q) { return q->S[k]; });
+            push("R", k, vlen(d, "R", k), [&](ocp_qp_in *q) { return q->R[k]; });
+            push("q", k, vlen(d, "q", k), [&](ocp_qp_in *q) { return q->q[k]; });
+            push("r", k, vlen(d, "r", k), [&](ocp_qp_in *q) { return q->r[k]; });
+            push("lbu", k, nbu, [&](ocp_qp_in *q) { return q->lb[k]; });
+            push("ubu", k, nbu, [&](ocp_qp_in *q) { return q->ub[k]; });
+            push("lbx", k, nbx, [&](ocp_qp_in *q) { return q->lb[k] + nbu; });
+            if (d->nbxe[k] > 0) push("lbx#value", k, nbx, [&](ocp_qp_in *q) { return q->lb[k] + nbu; });
+            push("ubx", k, nbx, [&](ocp_qp_in *q) { return q->ub[k] + nbu; });
+            push("lbu_mask", k, nbu, [&](ocp_qp_in *q) { return q->lb_mask[k]; });
+            push("ubu_mask", k, nbu, [&](ocp_qp_in *q) { return q->ub_mask[k]; });
+            push("lbx_mask", k, nbx, [&](ocp_qp_in *q) { return q->lb_mask[k] + nbu; });
+            push("ubx_mask", k, nbx, [&](ocp_qp_in *q) { return q->ub_mask[k] + nbu; });
+            push("C", k, vlen(d, "C", k), [&](ocp_qp_in *q) { return q->C[k]; });
+            push("D", k, vlen(d, "D", k), [&](ocp_qp_in *q) { return q->D[k]; });
+            push("lg", k, ng, [&](ocp_qp_in *q) { return q->lg[k]; });
+            push("ug", k, ng, [&](ocp_qp_in *q) { return q->ug[k]; });
+            push("lg_mask", k, ng, [&](ocp_qp_in *q) { return q->lg_mask[k]; });
+            push("ug_mask", k, ng, [&](ocp_qp_in *q) { return q->ug_mask[k]; });
+            push("Zl", k, ns, [&](ocp_qp_in *q) { return q->Zl[k]; });
+            push("Zu", k, ns, [&](ocp_qp_in *q) { return q->Zu[k]; });
+            push("zl", k, ns, [&](ocp_qp_in *q) { return q->zl[k]; });
+            push("zu", k, ns, [&](ocp_qp_in *q) { return q->zu[k]; });
+            push("lls", k, ns, [&](ocp_qp_in *q) { return q->lls[k]; });
+            push("lus", k, ns, [&](ocp_qp_in *q) { return q->lus[k]; });
+            push("lls_mask", k, ns, [&](ocp_qp_in *q) { return q->lls_mask[k]; });
+            push("lus_mask", k, ns, [&](ocp_qp_in *q) { return q->lus_mask[k]; });
         }
-        push("Q", k, vlen(d, "Q", k), [&](ocp_qp_in *q) { return q->Q[k]; });
-        push("S", k, vlen(d, "S", k), [&](ocp_qp_in *q) { return q->S[k]; });
-        push("R", k, vlen(d, "R", k), [&](ocp_qp_in *q) { return q->R[k]; });
-        push("q", k, vlen(d, "q", k), [&](ocp_qp_in *q) { return q->q[k]; });
-        push("r", k, vlen(d, "r", k), [&](ocp_qp_in *q) { return q->r[k]; });
-        push("lbu", k, nbu, [&](ocp_qp_in *q) { return q->lb[k]; });
-        push("ubu", k, nbu, [&](ocp_qp_in *q) { return q->ub[k]; });
-        push("lbx", k, nbx, [&](ocp_qp_in *q) { return q->lb[k] + nbu; });
-        push("ubx", k, nbx, [&](ocp_qp_in *q) { return q->ub[k] + nbu; });
-        push("lbu_mask", k, nbu, [&](ocp_qp_in *q) { return q->lb_mask[k]; });
-        push("ubu_mask", k, nbu, [&](ocp_qp_in *q) { return q->ub_mask[k]; });
-        push("lbx_mask", k, nbx, [&](ocp_qp_in *q) { return q->lb_mask[k] + nbu; });
-        push("ubx_mask", k, nbx, [&](ocp_qp_in *q) { return q->ub_mask[k] + nbu; });
-        push("C", k, vlen(d, "C", k), [&](ocp_qp_in *q) { return q->C[k]; });
-        push("D", k, vlen(d, "D", k), [&](ocp_qp_in *q) { return q->D[k]; });
-        push("lg", k, ng, [&](ocp_qp_in *q) { return q->lg[k]; });
-        push("ug", k, ng, [&](ocp_qp_in *q) { return q->ug[k]; });
-        push("lg_mask", k, ng, [&](ocp_qp_in *q) { return q->lg_mask[k]; });
-        push("ug_mask", k, ng, [&](ocp_qp_in *q) { return q->ug_mask[k]; });
-        push("Zl", k, ns, [&](ocp_qp_in *q) { return q->Zl[k]; });
-        push("Zu", k, ns, [&](ocp_qp_in *q) { return q->Zu[k]; });
-        push("zl", k, ns, [&](ocp_qp_in *q) { return q->zl[k]; });
-        push("zu", k, ns, [&](ocp_qp_in *q) { return q->zu[k]; });
-        push("lls", k, ns, [&](ocp_qp_in *q) { return q->lls[k]; });
-        push("lus", k, ns, [&](ocp_qp_in *q) { return q->lus[k]; });
-        push("lls_mask", k, ns, [&](ocp_qp_in *q) { return q->lls_mask[k]; });
-        push("lus_mask", k, ns, [&](ocp_qp_in *q) { return q->lus_mask[k]; });
+        ocp_qp_gpu_batch_set_bulk(b, blob, 0);
     }
     if (o->warm_start >= 2)
     {
@@ -607,23 +620,30 @@ int ocp_qp_gpu_ipm_evaluate_batch(void *config, int n, void **qp_in_, void **qp_
     ocp_qp_gpu_batch_solve(b);
     const double t_solved = now_s();
 
-    /* unpack */
-    auto pull = [&](const char *name, int k, int len, auto getter) {
-        if (len <= 0) return;
-        stg.resize((size_t) n * len);
-        ocp_qp_gpu_batch_get(b, name, k, stg.data(), 0);
-        for (int i = 0; i < n; i++) memcpy(getter(outs[i]), stg.data() + (size_t) i * len, sizeof(double) * len);
-    };
-    for (int k = 0; k <= N; k++)
+    /* unpack: one gather launch + one device->host copy for the whole batch */
     {
-        const int nu = d->nu[k], nx = d->nx[k], ns = d->ns[k], nct = 2 * (d->nb[k] + d->ng[k] + ns);
-        pull("u", k, nu, [&](ocp_qp_out *q) { return q->ux[k]; });
-        pull("x", k, nx, [&](ocp_qp_out *q) { return q->ux[k] + nu; });
-        pull("sl", k, ns, [&](ocp_qp_out *q) { return q->ux[k] + nu + nx; });
-        pull("su", k, ns, [&](ocp_qp_out *q) { return q->ux[k] + nu + nx + ns; });
-        if (k < N) pull("pi", k, d->nx[k + 1], [&](ocp_qp_out *q) { return q->pi[k]; });
-        pull("lam", k, nct, [&](ocp_qp_out *q) { return q->lam[k]; });
-        pull("t", k, nct, [&](ocp_qp_out *q) { return q->t[k]; });
+        const int L = ocp_qp_gpu_batch_bulk_len(b, 1);
+        bc->blob_out.resize((size_t) n * L);
+        ocp_qp_gpu_batch_get_bulk(b, bc->blob_out.data(), 0);
+        const double *blob = bc->blob_out.data();
+        auto pull = [&](const char *name, int k, int len, auto getter) {
+            if (len <= 0) return;
+            int seg_len = 0;
+            const int off = ocp_qp_gpu_batch_bulk_offset(b, 1, name, k, &seg_len);
+            if (off < 0) return;
+            for (int i = 0; i < n; i++) memcpy(getter(outs[i]), blob + (size_t) i * L + off, sizeof(double) * len);
+        };
+        for (int k = 0; k <= N; k++)
+        {
+            const int nu = d->nu[k], nx = d->nx[k], ns = d->ns[k], nct = 2 * (d->nb[k] + d->ng[k] + ns);
+            pull("u", k, nu, [&](ocp_qp_out *q) { return q->ux[k]; });
+            pull("x", k, nx, [&](ocp_qp_out *q) { return q->ux[k] + nu; });
+            pull("sl", k, ns, [&](ocp_qp_out *q) { return q->ux[k] + nu + nx; });
+            pull("su", k, ns, [&](ocp_qp_out *q) { return q->ux[k] + nu + nx + ns; });
+            if (k < N) pull("pi", k, d->nx[k + 1], [&](ocp_qp_out *q) { return q->pi[k]; });
+            pull("lam", k, nct, [&](ocp_qp_out *q) { return q->lam[k]; });
+            pull("t", k, nct, [&](ocp_qp_out *q) { return q->t[k]; });
+        }
     }
     std::vector<int> st(n), it(n);
     ocp_qp_gpu_batch_get_info(b, "status", st.data());
@@ -666,12 +686,72 @@ int ocp_qp_gpu_ipm(void *config, void *qp_in, void *qp_out, void *opts, void *me
     return status;
 }
 
-void ocp_qp_gpu_ipm_solver_get(void *config, void *qp_in, void *qp_out, void *opts, void *mem, const char *field,
+void ocp_qp_gpu_ipm_solver_get(void *config, void *qp_in_, void *qp_out, void *opts, void *mem_, const char *field,
                                int stage, void *value, int size1, int size2)
 {
-    /* Riccati getters P p K k Lr (ocp_qp_hpipm.c:417-478): SURVEY 8(f) row 4, not built yet */
-    printf("\nerror: ocp_qp_gpu_ipm_solver_get: field %s not available\n", field);
-    exit(1);
+    /* ocp_qp_hpipm.c:417-478: P (nx x nx), p (nx), K (nu x nx), k (nu), Lr (nu x nu), column-major, of the
+     * last factorisation; u = K x + k as ocp_nlp_ddp.c:373-377 uses them */
+    ocp_qp_in *in = (ocp_qp_in *) qp_in_;
+    gpu_ipm_memory *m = (gpu_ipm_memory *) mem_;
+    const int nx = in->dim->nx[stage], nu = in->dim->nu[stage], nv = nu + nx;
+    double *out = (double *) value;
+    if (!m->cache || !m->cache->batch)
+    {
+        printf("\nocp_qp_gpu_ipm_solver_get: no factorisation available (solve first)\n");
+        exit(1);
+    }
+    const int nb = m->cache->n;
+    std::vector<double> Lb((size_t) nb * nv * nv), lb((size_t) nb * nv);
+    ocp_qp_gpu_batch_get(m->cache->batch, "ric_L", stage, Lb.data(), 0);
+    ocp_qp_gpu_batch_get(m->cache->batch, "ric_l", stage, lb.data(), 0);
+    const double *L = Lb.data(), *l = lb.data(); /* instance 0: the QP this memory belongs to */
+    auto bad_size = [&](int e1, int e2) {
+        if (size1 != e1 || size2 != e2)
+            printf("\nocp_qp_gpu_ipm_solver_get: size of field %s not as expected, got size %d %d.\n", field, size1, size2);
+    };
+    if (!strcmp(field, "P"))
+    {
+        bad_size(nx, nx);
+        for (int c = 0; c < nx; c++)
+            for (int r = 0; r < nx; r++)
+            {
+                double a = 0.0;
+                for (int q = 0; q <= (r < c ? r : c); q++) a += L[(nu + r) + nv * (nu + q)] * L[(nu + c) + nv * (nu + q)];
+                out[r + nx * c] = a;
+            }
+    }
+    else if (!strcmp(field, "p"))
+    {
+        bad_size(nx, 1);
+        for (int r = 0; r < nx; r++)
+        {
+            double a = 0.0;
+            for (int q = 0; q <= r; q++) a += L[(nu + r) + nv * (nu + q)] * l[nu + q];
+            out[r] = a;
+        }
+    }
+    else if (!strcmp(field, "K") || !strcmp(field, "k"))
+    {
+        const bool isK = field[0] == 'K';
+        bad_size(nu, isK ? nx : 1);
+        const int ncol = isK ? nx : 1;
+        /* solve Lr' X = -rhs, rhs = Ls' (K) or lr (k) */
+        for (int c = 0; c < ncol; c++)
+            for (int r = nu - 1; r >= 0; r--)
+            {
+                double a = isK ? -L[(nu + c) + nv * r] : -l[r];
+                for (int q = r + 1; q < nu; q++) a -= L[q + nv * r] * out[q + nu * c];
+                out[r + nu * c] = a / L[r + nv * r];
+            }
+    }
+    else if (!strcmp(field, "Lr"))
+    {
+        bad_size(nu, nu);
+        for (int c = 0; c < nu; c++)
+            for (int r = 0; r < nu; r++) out[r + nu * c] = r >= c ? L[r + nv * c] : 0.0;
+    }
+    else
+        printf("\nocp_qp_gpu_ipm_solver_get: field %s not supported", field);
 }
 
 void ocp_qp_gpu_ipm_memory_reset(void *config, void *qp_in, void *qp_out, void *opts, void *mem_, void *work)
@@ -887,6 +967,14 @@ void ocp_qp_xcond_solver_get_scalar(ocp_qp_solver *s, ocp_qp_out *qp_out, const 
     if (!strcmp(field, "time_tot")) *(double *) value = info->total_time;
     else if (!strcmp(field, "time_cond") || !strcmp(field, "time_qp_xcond")) *(double *) value = info->condensing_time;
     else s->config->qp_solver.memory_get(&s->config->qp_solver, s->mem, field, value);
+}
+
+/* outer-level access to the solver_get slot (what ocp_nlp_ddp.c:373-377 does through the xcond vtable) */
+void ocp_qp_solver_get_ric(ocp_qp_solver *s, ocp_qp_in *qp_in, ocp_qp_out *qp_out, const char *field, int stage,
+                           void *value, int size1, int size2)
+{
+    qp_solver_config *qs = &s->config->qp_solver;
+    qs->solver_get(qs, qp_in, qp_out, s->opts->qp_solver_opts, s->mem, field, stage, value, size1, size2);
 }
 
 /* ocp_qp_interface.c:597-610 */

@@ -98,6 +98,10 @@ class OcpQpGpuBatch:
             return int(d.ns[k])
         if field in ("lam", "t"):
             return 2 * int(d.nbx[k] + d.nbu[k] + d.ng[k] + d.ns[k])
+        if field == "ric_L":
+            return int(d.nx[k] + d.nu[k]) ** 2
+        if field == "ric_l":
+            return int(d.nx[k] + d.nu[k])
         raise ValueError(field)
 
     def get(self, field, stage):
@@ -107,6 +111,25 @@ class OcpQpGpuBatch:
             if self._L.ocp_qp_gpu_batch_get(self._h, field.encode(), int(stage), out.ctypes.data_as(C.c_void_p), 0) != 0:
                 raise ValueError(f"ocp_qp_gpu_batch_get({field}, {stage}) failed")
         return out
+
+    def riccati(self, stage):
+        """P, p, K, k, Lr of the last factorisation per instance, conventions of the reference's getters
+        (ocp_qp_hpipm.c:417-478; ocp_nlp_ddp.c:373-377 uses u = K x + k): arrays with leading dim n_batch"""
+        d = self.dims
+        nu, nx = int(d.nu[stage]), int(d.nx[stage])
+        nv = nu + nx
+        L = self.get("ric_L", stage).reshape(self.n_batch, nv, nv).transpose(0, 2, 1)  # column-major blocks
+        l = self.get("ric_l", stage)
+        Lr, Ls, Lx = L[:, :nu, :nu], L[:, nu:, :nu], L[:, nu:, nu:]
+        P = Lx @ Lx.transpose(0, 2, 1)
+        p = np.einsum("bij,bj->bi", Lx, l[:, nu:])
+        if nu:
+            LrT = Lr.transpose(0, 2, 1)
+            K = -np.linalg.solve(LrT, Ls.transpose(0, 2, 1))
+            k = -np.linalg.solve(LrT, l[:, :nu, None])[:, :, 0]
+        else:
+            K, k = np.zeros((self.n_batch, 0, nx)), np.zeros((self.n_batch, 0))
+        return {"P": P, "p": p, "K": K, "k": k, "Lr": Lr}
 
     def info(self, field):
         out = np.zeros(self.n_batch, dtype=np.int32 if field in ("status", "iter") else np.float64)

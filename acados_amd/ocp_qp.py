@@ -178,6 +178,12 @@ class AcadosOcpQp:
                 json_data = json.load(f)
         return cls.from_dict(json_data)
 
+    def to_json(self, json_file_path: str):
+        """write the zero-padded-key JSON format of `dump_last_qp_to_json`
+        (interfaces/acados_c/ocp_nlp_interface.c:2213-2372) that from_json reads back"""
+        with open(json_file_path, "w") as f:
+            json.dump(self.to_dict(), f)
+
     def to_dict(self) -> dict:
         width = len(str(self.N + 1))
         out = {}

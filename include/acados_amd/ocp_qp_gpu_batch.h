@@ -56,6 +56,20 @@ int ocp_qp_gpu_batch_set_int(ocp_qp_gpu_batch *b, const char *field, int stage, 
  * block to every stage that has the field (data is then read once per stage). */
 int ocp_qp_gpu_batch_set(ocp_qp_gpu_batch *b, const char *field, int stage, const double *data, int is_device);
 
+/* Bulk pack / unpack: ONE host->device copy and ONE launch move every numeric field of every stage
+ * (the acados adapter's evaluate path: all member arrays of n ocp_qp_in in one go).  The per-instance
+ * blob is the concatenation, stage by stage, of the fields
+ *   input  (output = 0): A B b Q S R q r lbu ubu lbx ubx lg ug C D Zl Zu zl zu lls lus and the 8 *_mask
+ *   output (output = 1): u x sl su pi lam t
+ * (fields of length 0 at a stage are skipped).  _bulk_len gives the doubles per instance,
+ * _bulk_offset the position (and length) of one field; for an equality-flagged lbx the blob has a second
+ * segment "lbx#value" right after "lbx" (same numbers: the bound is also the value of the variable).
+ * blob[i * len + off + e], e in acados column-major order. */
+int ocp_qp_gpu_batch_bulk_len(ocp_qp_gpu_batch *b, int output);
+int ocp_qp_gpu_batch_bulk_offset(ocp_qp_gpu_batch *b, int output, const char *field, int stage, int *len);
+int ocp_qp_gpu_batch_set_bulk(ocp_qp_gpu_batch *b, const double *blob, int is_device);
+int ocp_qp_gpu_batch_get_bulk(ocp_qp_gpu_batch *b, double *blob, int is_device);
+
 /* Options by name, as ocp_qp_xcond_solver_opts_set forwards them: iter_max
  * tol_stat tol_eq tol_ineq tol_comp warm_start mu0 alpha_min tau_min reg_prim
  * cond_pred_corr print_level t0_init hpipm_mode ric_alg cond_N (partial condensing to N2 blocks) profile.  int* or double* or char* as in
@@ -73,7 +87,10 @@ int ocp_qp_gpu_batch_solve(ocp_qp_gpu_batch *b);
 int ocp_qp_gpu_batch_condense_lhs(ocp_qp_gpu_batch *b);
 int ocp_qp_gpu_batch_condense_rhs_and_solve(ocp_qp_gpu_batch *b);
 
-/* Results, same blocked convention as _set: x u sl su pi lam t per stage. */
+/* Results, same blocked convention as _set: x u sl su pi lam t per stage; and the Riccati factor of
+ * the last factorisation: ric_L ((nu+nx)^2, column-major lower Cholesky factor [Lr 0; Ls Lx] of the
+ * stage matrix) and ric_l (nu+nx), from which P = Lx Lx', p = Lx lx, K = -Lr^-T Ls', k = -Lr^-T lr
+ * (the getters of ocp_qp_hpipm.c:417-478) follow. */
 int ocp_qp_gpu_batch_get(ocp_qp_gpu_batch *b, const char *field, int stage, double *data, int is_device);
 /* per-instance: "status" "iter" (int), "res_stat" "res_eq" "res_ineq" "res_comp" "mu" "obj" (double) */
 int ocp_qp_gpu_batch_get_info(ocp_qp_gpu_batch *b, const char *field, void *data);

@@ -179,6 +179,10 @@ int ocp_qp_solve(ocp_qp_solver *solver, ocp_qp_in *qp_in, ocp_qp_out *qp_out);
 int ocp_qp_solve_batch(ocp_qp_solver *solver, int n, ocp_qp_in **qp_in, ocp_qp_out **qp_out, int *status);
 void ocp_qp_xcond_solver_get_scalar(ocp_qp_solver *solver, ocp_qp_out *qp_out, const char *field, void *value);
 void ocp_qp_solver_get_stats(ocp_qp_solver *solver, double *stat, const char *qp_solver_name);
+/* Riccati quantities of the last factorisation through the solver_get slot: field in P p K k Lr
+ * (ocp_qp_hpipm.c:417-478); column-major; u = K x + k */
+void ocp_qp_solver_get_ric(ocp_qp_solver *solver, ocp_qp_in *qp_in, ocp_qp_out *qp_out, const char *field, int stage,
+                           void *value, int size1, int size2);
 
 #ifdef __cplusplus
 }

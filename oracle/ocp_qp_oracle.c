@@ -222,9 +222,20 @@ int oqp_get(const oqp *qp, const char *f, int k, double *v)
     if (!strcmp(f, "pi")) { memcpy(v, s->pi, sizeof(double) * s->nx1); return 0; }
     if (!strcmp(f, "lam")) { memcpy(v, s->lam, sizeof(double) * s->nct); return 0; }
     if (!strcmp(f, "t")) { memcpy(v, s->t, sizeof(double) * s->nct); return 0; }
+    if (!strcmp(f, "ric_L"))
+    {
+        for (int c = 0; c < s->n; c++)
+            for (int r = 0; r < s->n; r++) v[r + s->n * c] = r >= c ? s->L[r + s->n * c] : 0.0;
+        return 0;
+    }
+    if (!strcmp(f, "ric_l")) { memcpy(v, s->l, sizeof(double) * s->n); return 0; }
     fprintf(stderr, "oqp_get: unknown field %s\n", f);
     return -1;
 }
+
+/* factor of the Newton system at the CURRENT iterate (what the device holds after its final
+ * residual/factor launch); afterwards "ric_L" (n x n col-major, lower) and "ric_l" can be read */
+void oqp_refactor(oqp *qp, const oqp_opts *o);
 
 int oqp_get_iter(const oqp *qp) { return qp->iter; }
 const double *oqp_get_stat(const oqp *qp) { return qp->stat; }
@@ -940,6 +951,15 @@ int oqp_solve(oqp *qp, const oqp_opts *o)
     qp->status = status;
     if (N + 1 > 1024) { free(rmc); free((void *) rm_ptr); }
     return status;
+}
+
+void oqp_refactor(oqp *qp, const oqp_opts *o)
+{
+    double mu, nrm[4];
+    setup_active(qp);
+    compute_res(qp, o->tau_min, &mu, nrm);
+    for (int k = 0; k <= qp->N; k++) stage_condense(qp->s + k, qp->s[k].rm, 1, o->reg_prim);
+    riccati_backward(qp, 1);
 }
 
 int oqp_solve_batch(oqp **qps, int n, const oqp_opts *opts, int *status, int nthreads)

@@ -78,6 +78,9 @@ int oqp_solve(oqp *qp, const oqp_opts *opts);
 
 /* x u sl su pi lam t  (lam, t: 2*(nb+ng+ns) entries, ordering [lb lg ub ug ls us]) */
 int oqp_get(const oqp *qp, const char *field, int stage, double *value);
+/* factorise the Newton system at the current iterate; then oqp_get "ric_L" (n x n col-major
+ * lower Cholesky factor of the stage matrix, variables [u;x]) and "ric_l" (n) are valid */
+void oqp_refactor(oqp *qp, const oqp_opts *opts);
 int oqp_get_iter(const oqp *qp);
 /* stat: (iter+1) x 20 row-major, HPIPM column legend (acados_ocp_qp_solver.py:431-451) */
 const double *oqp_get_stat(const oqp *qp);

@@ -42,6 +42,7 @@ def lib():
         L.oqp_get_stat.argtypes = [C.c_void_p]
         L.oqp_get_stat.restype = C.POINTER(C.c_double)
         L.oqp_compute_t.argtypes = [C.c_void_p]
+        L.oqp_refactor.argtypes = [C.c_void_p, C.POINTER(OqpOpts)]
         L.oqp_res_nrm_inf.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
         L.oqp_opts_default.argtypes = [C.POINTER(OqpOpts)]
         L.oqp_solve_batch.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.POINTER(OqpOpts), C.POINTER(C.c_int), C.c_int]
@@ -117,6 +118,10 @@ class OracleQp:
             return d.nx[k + 1] if k < self.N else 0
         if field in ("sl", "su"):
             return d.ns[k]
+        if field == "ric_L":
+            return (d.nx[k] + d.nu[k]) ** 2
+        if field == "ric_l":
+            return d.nx[k] + d.nu[k]
         return 2 * (d.nb[k] + d.ng[k] + d.ns[k])
 
     def get(self, k, field):
@@ -129,6 +134,9 @@ class OracleQp:
         r = (C.c_double * 4)()
         lib().oqp_res_nrm_inf(self.h, r)
         return np.array(r[:])
+
+    def refactor(self):
+        lib().oqp_refactor(self.h, C.byref(self.opts))
 
     def compute_t(self):
         lib().oqp_compute_t(self.h)

@@ -248,3 +248,85 @@ def test_compaction_is_bit_identical_hostsim(hostsim_lib):
     for k in range(N + 1):
         for f in ("x", "u", "lam", "t") + (("pi",) if k < N else ()):
             assert np.array_equal(runs[0].get(f, k), runs[1].get(f, k)), (f, k)
+
+
+def test_json_wire_format_roundtrip(tmp_path):
+    """f3: the dump_last_qp_to_json format is read AND written (zero-padded stage keys, natural-sign
+    bounds); a round trip preserves every field bit for bit"""
+    from acados_amd import AcadosOcpQp
+    from acados_amd.ocp_qp import ALL_FIELDS
+    qp = load_qp("casadi_qp_tests/pend_idxs_rev_min_qp0.json")
+    f = tmp_path / "qp.json"
+    qp.to_json(str(f))
+    qp2 = AcadosOcpQp.from_json(str(f))
+    assert qp2.N == qp.N and qp2.dims.signature() == qp.dims.signature()
+    for name in ALL_FIELDS:
+        for a, b in zip(getattr(qp, name), getattr(qp2, name)):
+            assert np.array_equal(np.asarray(a), np.asarray(b)), name
+
+
+def test_hot_start_hostsim(hostsim_lib):
+    """f2 / warm_start >= 2 (acados_ocp_options.py:1029-1032): the iterate handed over in qp_out is the
+    starting point; restarting from the converged solution of a slightly perturbed QP needs fewer
+    iterations than the cold start and lands on the same solution"""
+    from acados_amd import AcadosOcpQpOptions, AcadosOcpQpSolver
+    qp = load_qp("casadi_qp_tests/pendulum_qp.json")
+    opts = AcadosOcpQpOptions()
+    opts.tol_stat = opts.tol_eq = opts.tol_ineq = opts.tol_comp = 1e-8
+    cold = AcadosOcpQpSolver(qp, opts, _clib=hostsim_lib)
+    assert cold.solve() == 0
+    it_cold = cold.get_stats("iter")
+    x_cold = [cold.get(k, "x") for k in range(qp.N + 1)]
+    cold.opts_set("warm_start", 3)          # same solver object: qp_out still holds the solution
+    assert cold.solve() == 0
+    assert cold.get_stats("iter") <= 1 < it_cold
+    for k in range(qp.N + 1):
+        assert np.allclose(cold.get(k, "x"), x_cold[k], atol=1e-7)
+
+
+def test_riccati_getters_hostsim(hostsim_lib):
+    """a11: P, p, K, k, Lr of the last factorisation (ocp_qp_hpipm.c:417-478) against the oracle's factor
+    at the same iterate; and the feedback-law property Delta u = K Delta x + k on the Newton step"""
+    from acados_amd import OcpQpGpuBatch
+    from acados_amd.generators import mass_spring_qp
+    qp = mass_spring_qp(N=8)
+    o = OracleQp(qp)
+    assert o.solve(default_opts(tol_stat=1e-8)) == 0
+    o.refactor()
+    b = OcpQpGpuBatch.from_qps([qp, qp], _clib=hostsim_lib)
+    b.opts_set("tol_stat", 1e-8)
+    assert b.solve() == 0
+    for k in range(qp.N + 1):
+        nv = int(qp.dims.nu[k] + qp.dims.nx[k])
+        Lo = o.get(k, "ric_L").reshape(nv, nv, order="F")
+        Lg = b.get("ric_L", k)[1].reshape(nv, nv, order="F")
+        assert np.allclose(Lg, Lo, rtol=1e-6, atol=1e-9), k
+        assert np.allclose(b.get("ric_l", k)[1], o.get(k, "ric_l"), rtol=1e-5, atol=1e-9), k
+        ric = b.riccati(k)
+        nu = int(qp.dims.nu[k])
+        Lx = Lo[nu:, nu:]
+        assert np.allclose(ric["P"][0], Lx @ Lx.T, rtol=1e-6, atol=1e-9)
+        assert np.allclose(ric["P"][0], ric["P"][0].T)
+        if nu:
+            # [Lr 0; Ls Lx][Lr' Ls'; 0 Lx'] = M  =>  K = -Muu^-1 Mux
+            M = Lo @ Lo.T
+            assert np.allclose(ric["K"][0], -np.linalg.solve(M[:nu, :nu], M[:nu, nu:]), rtol=1e-6, atol=1e-9)
+
+
+def test_solver_get_vtable_hostsim(hostsim_lib):
+    """the qp_solver_config.solver_get slot (ocp_qp_common.h:73) answers K, k, P, p, Lr"""
+    import ctypes as C
+    from acados_amd import AcadosOcpQpOptions, AcadosOcpQpSolver
+    from acados_amd.generators import mass_spring_qp
+    qp = mass_spring_qp(N=6)
+    s = AcadosOcpQpSolver(qp, AcadosOcpQpOptions(), _clib=hostsim_lib)
+    assert s.solve() == 0
+    L = hostsim_lib
+    L.ocp_qp_solver_get_ric.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_char_p, C.c_int, C.c_void_p, C.c_int, C.c_int]
+    nu, nx = 3, 8
+    K = np.zeros((nx, nu)); kk = np.zeros(nu); P = np.zeros((nx, nx))
+    L.ocp_qp_solver_get_ric(s.c_solver, s.c_in, s.c_out, b"K", 2, K.ctypes.data_as(C.c_void_p), nu, nx)
+    L.ocp_qp_solver_get_ric(s.c_solver, s.c_in, s.c_out, b"k", 2, kk.ctypes.data_as(C.c_void_p), nu, 1)
+    L.ocp_qp_solver_get_ric(s.c_solver, s.c_in, s.c_out, b"P", 2, P.ctypes.data_as(C.c_void_p), nx, nx)
+    Kmat = K.T.copy()          # column-major nu x nx
+    assert np.all(np.isfinite(Kmat)) and np.abs(Kmat).max() > 0 and np.allclose(P, P.T) and np.all(np.linalg.eigvalsh(P) > 0)
