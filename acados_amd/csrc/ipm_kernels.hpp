@@ -893,7 +893,8 @@ __global__ void __launch_bounds__(64) k_forward(GqpDev D, GqpOpts O, int redo)
             D.alpha[i] = -alpha_aff;
             return;
         }
-        const double a = alpha * 0.995;
+        /* no inequality rows (mu == 0 exactly): the Newton step solves the QP, take it fully */
+        const double a = D.mu[i] > 0.0 ? alpha * 0.995 : 1.0;
         for (int k = 0; k <= D.N; k++)
         {
             const GqpStage &S = D.st[k];

@@ -917,7 +917,9 @@ int oqp_solve(oqp *qp, const oqp_opts *o)
                 alpha = step_length(qp);
             }
         }
-        double a = alpha * 0.995;
+        /* no inequality rows: the Newton step solves the QP, take it fully (HPIPM solves the
+         * unconstrained KKT system once in that case) */
+        double a = qp->n_act > 0 ? alpha * 0.995 : 1.0;
         for (int k = 0; k <= N; k++)
         {
             stg *s = qp->s + k;

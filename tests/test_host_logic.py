@@ -330,3 +330,55 @@ def test_solver_get_vtable_hostsim(hostsim_lib):
     L.ocp_qp_solver_get_ric(s.c_solver, s.c_in, s.c_out, b"P", 2, P.ctypes.data_as(C.c_void_p), nx, nx)
     Kmat = K.T.copy()          # column-major nu x nx
     assert np.all(np.isfinite(Kmat)) and np.abs(Kmat).max() > 0 and np.allclose(P, P.T) and np.all(np.linalg.eigvalsh(P) > 0)
+
+
+def test_edge_cases_hostsim(hostsim_lib):
+    """edge cases: no inequality at all (pure LQR: one Newton step), N = 1, single instance, exact wave
+    multiple, infeasible bounds (non-zero acados status, no hang), NaN in the data (ACADOS_NAN_DETECTED)"""
+    from acados_amd import AcadosOcpQp, OcpQpGpuBatch
+    from acados_amd.generators import lqr_instance_qp, random_lqr_batch
+
+    # pure LQR with free initial state: no inequality rows anywhere
+    data = random_lqr_batch(N=6, batch=2, seed=1)
+    qp = AcadosOcpQp(6)
+    for k in range(7):
+        qp.set("Q", k, data["Q"][0]); qp.set("q", k, data["q"][0])
+        if k < 6:
+            qp.set("R", k, data["R"][0]); qp.set("r", k, data["r"][0]); qp.set("S", k, data["S"][0])
+            qp.set("A", k, data["A"][0]); qp.set("B", k, data["B"][0]); qp.set("b", k, data["b"][0])
+    qp.make_consistent()
+    o = OracleQp(qp)
+    assert o.solve(default_opts(tol_stat=1e-8)) == 0
+    b = OcpQpGpuBatch.from_qps([qp], _clib=hostsim_lib)
+    b.opts_set("tol_stat", 1e-8)
+    assert b.solve() == 0 and b.info("iter")[0] == 1 == o.iter
+    compare_with_oracle(lambda k, f: b.get(f, k)[0], o, qp, 1e-10, fields=("x", "u", "pi"))
+
+    # N = 1 and exactly one wave of instances
+    data = random_lqr_batch(N=1, batch=64, seed=2)
+    qps = [lqr_instance_qp(data, i, 1) for i in range(64)]
+    b = OcpQpGpuBatch.from_qps(qps, _clib=hostsim_lib)
+    b.opts_set("tol_stat", 1e-8)
+    assert b.solve() == 0
+    o = OracleQp(qps[63])
+    assert o.solve(default_opts(tol_stat=1e-8)) == 0
+    compare_with_oracle(lambda k, f: b.get(f, k)[63], o, qps[63], 1e-9)
+
+    # infeasible: lower input bound above the upper one -> status MAXITER (2) or MINSTEP (3), never 0
+    data = random_lqr_batch(N=4, batch=3, seed=3)
+    data["lbu"][1] = 1.0
+    data["ubu"][1] = -1.0
+    qps = [lqr_instance_qp(data, i, 4) for i in range(3)]
+    b = OcpQpGpuBatch.from_qps(qps, _clib=hostsim_lib)
+    b.opts_set("iter_max", 30)
+    assert b.solve() == 1
+    st = b.info("status")
+    assert st[0] == 0 and st[2] == 0 and st[1] in (2, 3)
+
+    # NaN in the data of one instance -> ACADOS_NAN_DETECTED (1) for that instance only
+    data = random_lqr_batch(N=4, batch=3, seed=4)
+    data["q"][2, 0] = np.nan
+    qps = [lqr_instance_qp(data, i, 4) for i in range(3)]
+    b = OcpQpGpuBatch.from_qps(qps, _clib=hostsim_lib)
+    assert b.solve() == 1
+    assert list(b.info("status")) == [0, 0, 1]
