@@ -466,30 +466,28 @@ __global__ void __launch_bounds__(64) kb_backrhs(GqpDev D, GqpOpts O, int redo)
         const uint64_t am = GAT(D.amask, k);
         const int nbg = S.nb;
 
-        double L[NP], bat[n * NX], rb[NX], gt[n];
-        UNROLL for (int e = 0; e < NP; e++) L[e] = ACC(D.Lf, 0).ld(k * NP + e);
-        UNROLL for (int e = 0; e < n * NX; e++) bat[e] = ACC(D.BAt, 0).ld(k * n * NX + e);
+        /* With box rows on the states (XBOX) the stage needs 8 x (NU+NX) row values on top of L and
+         * [B A]': the loads are then issued in ordered phases (see kb_factor) -- rows, dynamics rows,
+         * factor -- so that no phase holds more than one big block.  Without state rows everything
+         * fits and is fetched in one go (ord stays a compile-time 0). */
+        int ord = 0;
+        double rb[NX], gt[n];
         UNROLL for (int c = 0; c < NX; c++) rb[c] = ACC(D.rb, 0).ld(k * NX + c);
         UNROLL for (int j = 0; j < n; j++) gt[j] = ACC(D.rg, 0).ld(k * n + j);
-        double laml[NB], lamu[NB], tl[NB], tu[NB], rdl[NB], rdu[NB], pl[NB], pu[NB];
         UNROLL for (int j = 0; j < NB; j++)
         {
             GQP_ROW(j, has, ib);
             const int el = S.o_ct + ib, eu = el + nbg;
-            laml[j] = ACC(D.lam, 0).ld(el); lamu[j] = ACC(D.lam, 0).ld(eu);
-            tl[j] = ACC(D.t, 0).ld(el); tu[j] = ACC(D.t, 0).ld(eu);
-            rdl[j] = ACC(D.rd, 0).ld(el); rdu[j] = ACC(D.rd, 0).ld(eu);
-            pl[j] = ACC(D.pcorr, 0).ld(el); pu[j] = ACC(D.pcorr, 0).ld(eu);
-        }
-        UNROLL for (int j = 0; j < NB; j++)
-        {
-            GQP_ROW(j, has, ib);
+            const double laml = ACC(D.lam, 0).ld(el), lamu = ACC(D.lam, 0).ld(eu);
+            const double tl = ACC(D.t, 0).ld(el), tu = ACC(D.t, 0).ld(eu);
+            const double rdl = ACC(D.rd, 0).ld(el), rdu = ACC(D.rd, 0).ld(eu);
+            const double pl = ACC(D.pcorr, 0).ld(el), pu = ACC(D.pcorr, 0).ld(eu);
             const bool al = has && ((am >> ib) & 1), au = has && ((am >> (nbg + ib)) & 1);
-            const double ll = al ? laml[j] : 0.0, lu = au ? lamu[j] : 0.0;
-            const double ttl = al ? tl[j] : 1.0, ttu = au ? tu[j] : 1.0;
-            const double rml = al ? ll * ttl - O.tau_min + pscale * pl[j] - smu : 0.0;
-            const double rmu = au ? lu * ttu - O.tau_min + pscale * pu[j] - smu : 0.0;
-            const double dl = al ? rdl[j] : 0.0, du = au ? rdu[j] : 0.0;
+            const double ll = al ? laml : 0.0, lu = au ? lamu : 0.0;
+            const double ttl = al ? tl : 1.0, ttu = au ? tu : 1.0;
+            const double rml = al ? ll * ttl - O.tau_min + pscale * pl - smu : 0.0;
+            const double rmu = au ? lu * ttu - O.tau_min + pscale * pu - smu : 0.0;
+            const double dl = al ? rdl : 0.0, du = au ? rdu : 0.0;
             gt[j] += (rml + ll * dl) * frcp(ttl) - (rmu + lu * du) * frcp(ttu);
         }
         /* y = Lx+ (Lx+' rb + lx+) ; m = gt + BAt y */
@@ -506,13 +504,18 @@ __global__ void __launch_bounds__(64) kb_backrhs(GqpDev D, GqpOpts O, int redo)
             UNROLL for (int c = 0; c <= r; c++) a += Lx[PK(r, c)] * w0[c];
             y[r] = a;
         }
+        if (XBOX) GQP_AFTER(ord, gt[NB - 1]);
+        const Acc aBAt = ACC(D.BAt, k * n * NX);
         UNROLL for (int r = 0; r < n; r++)
         {
             double a = 0.0;
-            UNROLL for (int c = 0; c < NX; c++) a += bat[r * NX + c] * y[c];
+            UNROLL for (int c = 0; c < NX; c++) a += aBAt.ldo(r * NX + c, ord) * y[c];
             gt[r] += a;
         }
         UNROLL for (int r = 0; r < n; r++) if ((S.emask >> r) & 1) gt[r] = 0.0;
+        if (XBOX) GQP_AFTER(ord, gt[n - 1]);
+        double L[NP];
+        UNROLL for (int e = 0; e < NP; e++) L[e] = ACC(D.Lf, 0).ldo(k * NP + e, ord);
         UNROLL for (int r = 0; r < n; r++)
         {
             double a = gt[r];
