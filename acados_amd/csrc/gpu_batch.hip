@@ -51,6 +51,7 @@ struct ocp_qp_gpu_batch
     std::vector<std::vector<int>> perm;                   /* original box row -> sorted row */
     bool finalized = false;
     bool use_box = false; /* box-only fast path */
+    int aos = 0;          /* instance-major arrays: wave-per-instance kernel family */
     int xbox = 0;
     const KernelSet *ks = nullptr;
     std::string kname;
@@ -127,6 +128,7 @@ template <class T>
 GArrT<T> garr(ocp_qp_gpu_batch *b, size_t E)
 {
     GArrT<T> a;
+    a.aos = b->aos;
     a.E = (int) (E ? E : 1);
     a.p = dalloc<T>(b, (size_t) a.E * (size_t) b->Bp);
     return a;
@@ -586,7 +588,7 @@ int ocp_qp_gpu_batch_set(ocp_qp_gpu_batch *b, const char *f, int stage, const do
     for (int k = k0; k <= k1; k++)
     {
         std::vector<int> map, map2;
-        GArr arr = {nullptr, 0}, arr2 = {nullptr, 0};
+        GArr arr = {nullptr, 0, 0}, arr2 = {nullptr, 0, 0};
         const size_t flen = strlen(f);
         if (flen > 5 && !strcmp(f + flen - 5, "_mask"))
         {
@@ -1048,7 +1050,7 @@ int ocp_qp_gpu_batch_get(ocp_qp_gpu_batch *b, const char *f, int k, double *data
     HIPCHK(hipSetDevice(b->device));
     finalize_structure(b);
     std::vector<int> map;
-    GArr arr = {nullptr, 0};
+    GArr arr = {nullptr, 0, 0};
     const int len = field_map(b, f, k, map, &arr);
     if (len < 0)
     {
@@ -1174,7 +1176,7 @@ static void bulk_build(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch::BulkMap &M, const 
     finalize_structure(b);
     const GqpDev &D = b->D;
     const GArr table[16] = {D.BAt, D.bvec, D.RSQ, D.rq, D.dvec, D.DCt, D.Zz, D.ux, D.sv, D.pi, D.lam, D.t,
-                            {nullptr, 0}, {nullptr, 0}, {nullptr, 0}, {nullptr, 0}};
+                            {nullptr, 0, 0}, {nullptr, 0, 0}, {nullptr, 0, 0}, {nullptr, 0, 0}};
     for (int q = 0; q < 16; q++) M.T.a[q] = table[q];
     auto table_index = [&](const GArr &a) {
         for (int q = 0; q < 12; q++) if (table[q].p == a.p) return q;
@@ -1186,7 +1188,7 @@ static void bulk_build(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch::BulkMap &M, const 
         {
             const char *f = fields[fi];
             std::vector<int> map, map2;
-            GArr arr = {nullptr, 0}, arr2 = {nullptr, 0};
+            GArr arr = {nullptr, 0, 0}, arr2 = {nullptr, 0, 0};
             const size_t flen = strlen(f);
             int len;
             const bool is_mask = flen > 5 && !strcmp(f + flen - 5, "_mask");

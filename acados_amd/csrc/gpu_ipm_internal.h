@@ -51,6 +51,8 @@ struct GArrT
 {
     T *p;
     int E;
+    int aos; /* 0: wave-tiled (one instance per lane kernels); 1: instance-major p[i * E + e] -- the
+                wave-per-instance kernels (ipm_kernels_wpi.hpp) stream one instance's block per wave */
 };
 typedef GArrT<double> GArr;
 typedef GArrT<uint64_t> GArrU64;

@@ -44,6 +44,10 @@ namespace gqp
 
 /* element e of this lane's instance in a wave-tiled array (gpu_ipm_internal.h, GArrT) */
 #define GAT(arr, e) (arr).p[((size_t) (i >> 6) * (size_t) (arr).E + (size_t) (e)) * 64 + (size_t) (i & 63)]
+/* layout-agnostic form for the kernels that are not on the hot path (pack/unpack, init, finalize,
+ * condensing, compaction): wave-tiled or instance-major, decided by the array */
+#define GATL(arr, e) (arr).p[(arr).aos ? (size_t) i * (size_t) (arr).E + (size_t) (e) \
+                                       : ((size_t) (i >> 6) * (size_t) (arr).E + (size_t) (e)) * 64 + (size_t) (i & 63)]
 
 __device__ static inline double dmax(double a, double b) { return a > b ? a : b; }
 __device__ static inline double dabs(double a) { return a < 0.0 ? -a : a; }
@@ -70,11 +74,11 @@ __global__ void __launch_bounds__(64) k_init(GqpDev D, GqpOpts O)
     {
         const GqpStage &S = D.st[k];
         const int nbg = S.nb + S.ng;
-        const uint64_t am = GAT(D.amask, k);
+        const uint64_t am = GATL(D.amask, k);
         double v[n];
         UNROLL for (int j = 0; j < n; j++) v[j] = 0.0;
         /* fixed variables keep the value the caller put into ux (set at pack time) */
-        UNROLL for (int j = 0; j < n; j++) if ((S.emask >> j) & 1) v[j] = GAT(D.ux, k * n + j);
+        UNROLL for (int j = 0; j < n; j++) if ((S.emask >> j) & 1) v[j] = GATL(D.ux, k * n + j);
         int ib = 0;
         UNROLL for (int j = 0; j < n; j++)
         {
@@ -83,7 +87,7 @@ __global__ void __launch_bounds__(64) k_init(GqpDev D, GqpOpts O)
             const bool soft = S.srev[ib] >= 0;
             if (!fixed && !soft)
             {
-                const double lb = GAT(D.dvec, S.o_ct + ib), ub = GAT(D.dvec, S.o_ct + nbg + ib);
+                const double lb = GATL(D.dvec, S.o_ct + ib), ub = GATL(D.dvec, S.o_ct + nbg + ib);
                 const bool al = (am >> ib) & 1, au = (am >> (nbg + ib)) & 1;
                 const double tl = v[j] - lb, tu = ub - v[j];
                 if (al && au)
@@ -96,8 +100,8 @@ __global__ void __launch_bounds__(64) k_init(GqpDev D, GqpOpts O)
             }
             ib++;
         }
-        UNROLL for (int j = 0; j < n; j++) GAT(D.ux, k * n + j) = v[j];
-        if (S.has_dyn) { UNROLL for (int c = 0; c < NX; c++) GAT(D.pi, (k + 1) * NX + c) = 0.0; }
+        UNROLL for (int j = 0; j < n; j++) GATL(D.ux, k * n + j) = v[j];
+        if (S.has_dyn) { UNROLL for (int c = 0; c < NX; c++) GATL(D.pi, (k + 1) * NX + c) = 0.0; }
         /* slacks */
         double sl[NS > 0 ? NS : 1], su[NS > 0 ? NS : 1];
         if (NS > 0)
@@ -107,8 +111,8 @@ __global__ void __launch_bounds__(64) k_init(GqpDev D, GqpOpts O)
                 sl[j] = 0.0; su[j] = 0.0;
                 if (j < S.ns)
                 {
-                    if ((am >> (2 * nbg + j)) & 1) sl[j] = GAT(D.dvec, S.o_ct + 2 * nbg + j) + thr0;
-                    if ((am >> (2 * nbg + S.ns + j)) & 1) su[j] = GAT(D.dvec, S.o_ct + 2 * nbg + S.ns + j) + thr0;
+                    if ((am >> (2 * nbg + j)) & 1) sl[j] = GATL(D.dvec, S.o_ct + 2 * nbg + j) + thr0;
+                    if ((am >> (2 * nbg + S.ns + j)) & 1) su[j] = GATL(D.dvec, S.o_ct + 2 * nbg + S.ns + j) + thr0;
                 }
             }
         }
@@ -122,7 +126,7 @@ __global__ void __launch_bounds__(64) k_init(GqpDev D, GqpOpts O)
             if (g < S.ng)
             {
                 double a = 0.0;
-                UNROLL for (int r = 0; r < n; r++) a += GAT(D.DCt, (S.o_g + g) * n + r) * v[r];
+                UNROLL for (int r = 0; r < n; r++) a += GATL(D.DCt, (S.o_g + g) * n + r) * v[r];
                 cval[n + g] = a;
             }
         }
@@ -137,7 +141,7 @@ __global__ void __launch_bounds__(64) k_init(GqpDev D, GqpOpts O)
                 if (j < n) ib++;
                 const int sj = S.srev[row];
                 if (sj < 0) continue;
-                const double lo = GAT(D.dvec, S.o_ct + row), up = GAT(D.dvec, S.o_ct + nbg + row);
+                const double lo = GATL(D.dvec, S.o_ct + row), up = GATL(D.dvec, S.o_ct + nbg + row);
                 const double need_l = lo - cval[j] + thr0, need_u = cval[j] - up + thr0;
                 UNROLL for (int q = 0; q < NS; q++)
                     if (q == sj)
@@ -149,8 +153,8 @@ __global__ void __launch_bounds__(64) k_init(GqpDev D, GqpOpts O)
             UNROLL for (int j = 0; j < NS; j++)
                 if (j < S.ns)
                 {
-                    GAT(D.sv, S.o_s + j) = sl[j];
-                    GAT(D.sv, S.o_s + S.ns + j) = su[j];
+                    GATL(D.sv, S.o_s + j) = sl[j];
+                    GATL(D.sv, S.o_s + S.ns + j) = su[j];
                 }
         }
         /* t, lam */
@@ -161,7 +165,7 @@ __global__ void __launch_bounds__(64) k_init(GqpDev D, GqpOpts O)
             if (!is_row) continue;
             const int row = j < n ? ib : S.nb + (j - n);
             if (j < n) ib++;
-            const double lo = GAT(D.dvec, S.o_ct + row), up = GAT(D.dvec, S.o_ct + nbg + row);
+            const double lo = GATL(D.dvec, S.o_ct + row), up = GATL(D.dvec, S.o_ct + nbg + row);
             double ssl = 0.0, ssu = 0.0;
             if (NS > 0)
             {
@@ -172,10 +176,10 @@ __global__ void __launch_bounds__(64) k_init(GqpDev D, GqpOpts O)
             if (tl < thr0) tl = thr0;
             if (tu < thr0) tu = thr0;
             const bool al = (am >> row) & 1, au = (am >> (nbg + row)) & 1;
-            GAT(D.t, S.o_ct + row) = al ? tl : 0.0;
-            GAT(D.t, S.o_ct + nbg + row) = au ? tu : 0.0;
-            GAT(D.lam, S.o_ct + row) = al ? O.mu0 / tl : 0.0;
-            GAT(D.lam, S.o_ct + nbg + row) = au ? O.mu0 / tu : 0.0;
+            GATL(D.t, S.o_ct + row) = al ? tl : 0.0;
+            GATL(D.t, S.o_ct + nbg + row) = au ? tu : 0.0;
+            GATL(D.lam, S.o_ct + row) = al ? O.mu0 / tl : 0.0;
+            GATL(D.lam, S.o_ct + nbg + row) = au ? O.mu0 / tu : 0.0;
         }
         if (NS > 0)
         {
@@ -183,14 +187,14 @@ __global__ void __launch_bounds__(64) k_init(GqpDev D, GqpOpts O)
                 if (j < S.ns)
                 {
                     const int e0 = S.o_ct + 2 * nbg + j, e1 = e0 + S.ns;
-                    double tl = sl[j] - GAT(D.dvec, e0), tu = su[j] - GAT(D.dvec, e1);
+                    double tl = sl[j] - GATL(D.dvec, e0), tu = su[j] - GATL(D.dvec, e1);
                     if (tl < thr0) tl = thr0;
                     if (tu < thr0) tu = thr0;
                     const bool al = (am >> (2 * nbg + j)) & 1, au = (am >> (2 * nbg + S.ns + j)) & 1;
-                    GAT(D.t, e0) = al ? tl : 0.0;
-                    GAT(D.t, e1) = au ? tu : 0.0;
-                    GAT(D.lam, e0) = al ? O.mu0 / tl : 0.0;
-                    GAT(D.lam, e1) = au ? O.mu0 / tu : 0.0;
+                    GATL(D.t, e0) = al ? tl : 0.0;
+                    GATL(D.t, e1) = au ? tu : 0.0;
+                    GATL(D.lam, e0) = al ? O.mu0 / tl : 0.0;
+                    GATL(D.lam, e1) = au ? O.mu0 / tu : 0.0;
                 }
         }
     }
@@ -933,9 +937,9 @@ __global__ void __launch_bounds__(64) k_finalize(GqpDev D)
     {
         const GqpStage &S = D.st[k];
         const int nbg = S.nb + S.ng;
-        const uint64_t am = GAT(D.amask, k);
+        const uint64_t am = GATL(D.amask, k);
         double v[n];
-        UNROLL for (int j = 0; j < n; j++) v[j] = GAT(D.ux, k * n + j);
+        UNROLL for (int j = 0; j < n; j++) v[j] = GATL(D.ux, k * n + j);
         int ib = 0;
         UNROLL for (int j = 0; j < n + NG; j++)
         {
@@ -947,30 +951,30 @@ __global__ void __launch_bounds__(64) k_finalize(GqpDev D)
             if (al && au) continue;
             double c;
             if (j < n) c = v[j < n ? j : 0];
-            else { c = 0.0; UNROLL for (int r = 0; r < n; r++) c += GAT(D.DCt, (S.o_g + (j - n)) * n + r) * v[r]; }
+            else { c = 0.0; UNROLL for (int r = 0; r < n; r++) c += GATL(D.DCt, (S.o_g + (j - n)) * n + r) * v[r]; }
             double ssl = 0.0, ssu = 0.0;
             if (NS > 0)
             {
                 const int sj = S.srev[row];
-                if (sj >= 0) { ssl = GAT(D.sv, S.o_s + sj); ssu = GAT(D.sv, S.o_s + S.ns + sj); }
+                if (sj >= 0) { ssl = GATL(D.sv, S.o_s + sj); ssu = GATL(D.sv, S.o_s + S.ns + sj); }
             }
             const bool fixed = j < n && ((S.emask >> (j < n ? j : 0)) & 1);
             if (!al)
             {
-                GAT(D.t, S.o_ct + row) = c + ssl - GAT(D.dvec, S.o_ct + row);
-                if (!fixed) GAT(D.lam, S.o_ct + row) = 0.0;
+                GATL(D.t, S.o_ct + row) = c + ssl - GATL(D.dvec, S.o_ct + row);
+                if (!fixed) GATL(D.lam, S.o_ct + row) = 0.0;
             }
             if (!au)
             {
-                GAT(D.t, S.o_ct + nbg + row) = GAT(D.dvec, S.o_ct + nbg + row) - c + ssu;
-                if (!fixed) GAT(D.lam, S.o_ct + nbg + row) = 0.0;
+                GATL(D.t, S.o_ct + nbg + row) = GATL(D.dvec, S.o_ct + nbg + row) - c + ssu;
+                if (!fixed) GATL(D.lam, S.o_ct + nbg + row) = 0.0;
             }
         }
         for (int q = 0; q < S.ns; q++)
         {
             const int e0 = S.o_ct + 2 * nbg + q, e1 = e0 + S.ns;
-            if (!((am >> (2 * nbg + q)) & 1)) { GAT(D.t, e0) = GAT(D.sv, S.o_s + q) - GAT(D.dvec, e0); GAT(D.lam, e0) = 0.0; }
-            if (!((am >> (2 * nbg + S.ns + q)) & 1)) { GAT(D.t, e1) = GAT(D.sv, S.o_s + S.ns + q) - GAT(D.dvec, e1); GAT(D.lam, e1) = 0.0; }
+            if (!((am >> (2 * nbg + q)) & 1)) { GATL(D.t, e0) = GATL(D.sv, S.o_s + q) - GATL(D.dvec, e0); GATL(D.lam, e0) = 0.0; }
+            if (!((am >> (2 * nbg + S.ns + q)) & 1)) { GATL(D.t, e1) = GATL(D.sv, S.o_s + S.ns + q) - GATL(D.dvec, e1); GATL(D.lam, e1) = 0.0; }
         }
     }
 }
@@ -985,7 +989,7 @@ static __global__ void k_scatter(const double *src, int nb, int len, const int *
     for (int e = 0; e < len; e++)
     {
         const int m = map[e];
-        if (m >= 0) GAT(dst, m) = src[(size_t) i * len + e];
+        if (m >= 0) GATL(dst, m) = src[(size_t) i * len + e];
     }
 }
 
@@ -997,7 +1001,7 @@ static __global__ void k_gather(double *dst, int nb, int len, const int *map, GA
     for (int e = 0; e < len; e++)
     {
         const int m = map[e];
-        dst[(size_t) i * len + e] = m >= 0 ? GAT(src, m) : 0.0;
+        dst[(size_t) i * len + e] = m >= 0 ? GATL(src, m) : 0.0;
     }
 }
 
@@ -1007,7 +1011,7 @@ static __global__ void k_setmask(const double *src, int nb, int len, const int *
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nb) return;
-    uint64_t m = GAT(amask, stage);
+    uint64_t m = GATL(amask, stage);
     for (int e = 0; e < len; e++)
     {
         const int b = bitpos[e];
@@ -1015,7 +1019,7 @@ static __global__ void k_setmask(const double *src, int nb, int len, const int *
         if (src[(size_t) i * len + e] != 0.0) m |= (uint64_t) 1 << b;
         else m &= ~((uint64_t) 1 << b);
     }
-    GAT(amask, stage) = m;
+    GATL(amask, stage) = m;
 }
 
 /* ---- bulk pack / unpack: one launch moves a whole QP (or solution) per instance ----
@@ -1034,7 +1038,7 @@ static __global__ void k_bulk_scatter(const double *blob, int nb, int len, const
     for (int e = e0; e < e1; e++)
     {
         const int a = map_arr[e];
-        if (a >= 0) GAT(T.a[a], map_elem[e]) = blob[(size_t) i * len + e];
+        if (a >= 0) GATL(T.a[a], map_elem[e]) = blob[(size_t) i * len + e];
     }
 }
 
@@ -1046,7 +1050,7 @@ static __global__ void k_bulk_gather(double *blob, int nb, int len, const int *m
     for (int e = e0; e < e1; e++)
     {
         const int a = map_arr[e];
-        blob[(size_t) i * len + e] = a >= 0 ? GAT(T.a[a], map_elem[e]) : 0.0;
+        blob[(size_t) i * len + e] = a >= 0 ? GATL(T.a[a], map_elem[e]) : 0.0;
     }
 }
 
@@ -1059,10 +1063,10 @@ static __global__ void k_bulk_masks(const double *blob, int nb, int len, const i
     for (int q = 0; q < nm; q++)
     {
         if (m_bit[q] < 0) continue;
-        uint64_t m = GAT(amask, m_stage[q]);
+        uint64_t m = GATL(amask, m_stage[q]);
         if (blob[(size_t) i * len + m_off[q]] != 0.0) m |= (uint64_t) 1 << m_bit[q];
         else m &= ~((uint64_t) 1 << m_bit[q]);
-        GAT(amask, m_stage[q]) = m;
+        GATL(amask, m_stage[q]) = m;
     }
 }
 
@@ -1076,10 +1080,11 @@ static __global__ void k_compact_copy(GArrT<T> big, GArrT<T> small, const int *l
     if (sidx >= cnt) return;
     const int src = list[sidx];
     const int e0 = blockIdx.y * 64, e1 = e0 + 64 < big.E ? e0 + 64 : big.E;
-    T *pb = big.p + ((size_t) (src >> 6) * (size_t) big.E) * 64 + (src & 63);
-    T *ps = small.p + ((size_t) (sidx >> 6) * (size_t) small.E) * 64 + (sidx & 63);
-    if (dir == 0) for (int e = e0; e < e1; e++) ps[(size_t) e * 64] = pb[(size_t) e * 64];
-    else for (int e = e0; e < e1; e++) pb[(size_t) e * 64] = ps[(size_t) e * 64];
+    const size_t sb = big.aos ? 1 : 64, ss = small.aos ? 1 : 64;
+    T *pb = big.aos ? big.p + (size_t) src * big.E : big.p + ((size_t) (src >> 6) * (size_t) big.E) * 64 + (src & 63);
+    T *ps = small.aos ? small.p + (size_t) sidx * small.E : small.p + ((size_t) (sidx >> 6) * (size_t) small.E) * 64 + (sidx & 63);
+    if (dir == 0) for (int e = e0; e < e1; e++) ps[(size_t) e * ss] = pb[(size_t) e * sb];
+    else for (int e = e0; e < e1; e++) pb[(size_t) e * sb] = ps[(size_t) e * ss];
 }
 
 static __global__ void k_compact_scalars(GqpDev big, GqpDev small, const int *list, int cnt, int dir)
@@ -1109,13 +1114,13 @@ static __global__ void k_compact_scalars(GqpDev big, GqpDev small, const int *li
 static __global__ void k_fill_u64(GArrU64 dst, uint64_t val, int nb, int e)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nb) GAT(dst, e) = val;
+    if (i < nb) GATL(dst, e) = val;
 }
 
 static __global__ void k_fill_strided(GArr dst, double val, int nb, int e)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < nb) GAT(dst, e) = val;
+    if (i < nb) GATL(dst, e) = val;
 }
 
 } // namespace gqp

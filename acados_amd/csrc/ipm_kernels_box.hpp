@@ -157,6 +157,7 @@ __device__ static inline Acc acc_at(GArr arr, size_t e0, int i)
     return a;
 }
 #define ACC(arr, e0) acc_at((arr), (size_t) (e0), i)
+#define GATL_LD(arr, e) GATL(arr, e)
 
 /* Scheduling fence: hipcc's machine scheduler hoists every load of a straight-line stage body
  * to its top (it only watches the 512-register ceiling), and the allocator then spills the
@@ -737,9 +738,9 @@ __global__ void __launch_bounds__(64) kb_finalize(GqpDev D)
         const StageU S = stage_u(D.st, k);
         if (S.nb == 0) continue;
         const int nbg = S.nb;
-        const uint64_t am = GAT(D.amask, k);
+        const uint64_t am = GATL(D.amask, k);
         double v[n];
-        UNROLL for (int j = 0; j < n; j++) v[j] = ACC(D.ux, 0).ld(k * n + j);
+        UNROLL for (int j = 0; j < n; j++) v[j] = GATL_LD(D.ux, k * n + j);
         int ib = 0;
         UNROLL for (int j = 0; j < n; j++)
         {
@@ -747,19 +748,19 @@ __global__ void __launch_bounds__(64) kb_finalize(GqpDev D)
             const int el = S.o_ct + ib, eu = el + nbg;
             if ((S.emask >> j) & 1)
             {
-                double a = ACC(D.rq, 0).ld(k * n + j);
-                UNROLL for (int c = 0; c < n; c++) a += ACC(D.RSQ, 0).ld(k * NP + (c <= j ? PK(j, c) : PK(c, j))) * v[c];
-                UNROLL for (int c = 0; c < NX; c++) a += ACC(D.BAt, 0).ld((k * n + j) * NX + c) * ACC(D.pi, 0).ld((k + 1) * NX + c);
-                if (j >= NU) a -= ACC(D.pi, 0).ld(k * NX + (j >= NU ? j - NU : 0));
-                ACC(D.lam, 0).st(el, a > 0.0 ? a : 0.0);
-                ACC(D.lam, 0).st(eu, a < 0.0 ? -a : 0.0);
-                ACC(D.t, 0).st(el, 0.0);
-                ACC(D.t, 0).st(eu, 0.0);
+                double a = GATL_LD(D.rq, k * n + j);
+                UNROLL for (int c = 0; c < n; c++) a += GATL_LD(D.RSQ, k * NP + (c <= j ? PK(j, c) : PK(c, j))) * v[c];
+                UNROLL for (int c = 0; c < NX; c++) a += GATL_LD(D.BAt, (k * n + j) * NX + c) * GATL_LD(D.pi, (k + 1) * NX + c);
+                if (j >= NU) a -= GATL_LD(D.pi, k * NX + (j >= NU ? j - NU : 0));
+                GATL(D.lam, el) = a > 0.0 ? a : 0.0;
+                GATL(D.lam, eu) = a < 0.0 ? -a : 0.0;
+                GATL(D.t, el) = 0.0;
+                GATL(D.t, eu) = 0.0;
             }
             else
             {
-                if (!((am >> ib) & 1)) { ACC(D.t, 0).st(el, v[j] - ACC(D.dvec, 0).ld(el)); ACC(D.lam, 0).st(el, 0.0); }
-                if (!((am >> (nbg + ib)) & 1)) { ACC(D.t, 0).st(eu, ACC(D.dvec, 0).ld(eu) - v[j]); ACC(D.lam, 0).st(eu, 0.0); }
+                if (!((am >> ib) & 1)) { GATL(D.t, el) = v[j] - GATL(D.dvec, el); GATL(D.lam, el) = 0.0; }
+                if (!((am >> (nbg + ib)) & 1)) { GATL(D.t, eu) = GATL(D.dvec, eu) - v[j]; GATL(D.lam, eu) = 0.0; }
             }
             ib++;
         }

@@ -65,11 +65,11 @@ __global__ void __launch_bounds__(64) k_pcond(GqpDev P, GqpDev Cd, PcondMap Mp)
         for (int ii = 0; ii < bs; ii++)
         {
             const int k = k0 + ii;
-            for (int e = 0; e < NP; e++) H[e] = GAT(P.RSQ, k * NP + e);
+            for (int e = 0; e < NP; e++) H[e] = GATL(P.RSQ, k * NP + e);
             /* y = H [0; c] + g */
             for (int r = 0; r < n; r++)
             {
-                double a = GAT(P.rq, k * n + r);
+                double a = GATL(P.rq, k * n + r);
                 for (int q = 0; q < NX; q++)
                 {
                     const int cc = NU + q;
@@ -124,16 +124,16 @@ __global__ void __launch_bounds__(64) k_pcond(GqpDev P, GqpDev Cd, PcondMap Mp)
             {
                 for (int r = 0; r < NX; r++)
                 {
-                    double a = GAT(P.bvec, k * NX + r);
-                    for (int q = 0; q < NX; q++) a += GAT(P.BAt, (k * n + NU + q) * NX + r) * c[q];
+                    double a = GATL(P.bvec, k * NX + r);
+                    for (int q = 0; q < NX; q++) a += GATL(P.BAt, (k * n + NU + q) * NX + r) * c[q];
                     cn[r] = a;
                     for (int col = 0; col < nc; col++)
                     {
                         double s = 0.0;
-                        for (int q = 0; q < NX; q++) s += GAT(P.BAt, (k * n + NU + q) * NX + r) * X[q * nc + col];
+                        for (int q = 0; q < NX; q++) s += GATL(P.BAt, (k * n + NU + q) * NX + r) * X[q * nc + col];
                         Xn[r * nc + col] = s;
                     }
-                    for (int a2 = 0; a2 < NU; a2++) Xn[r * nc + ii * NU + a2] += GAT(P.BAt, (k * n + a2) * NX + r);
+                    for (int a2 = 0; a2 < NU; a2++) Xn[r * nc + ii * NU + a2] += GATL(P.BAt, (k * n + a2) * NX + r);
                 }
                 for (int e = 0; e < NX * nc; e++) X[e] = Xn[e];
                 for (int r = 0; r < NX; r++) c[r] = cn[r];
@@ -146,15 +146,15 @@ __global__ void __launch_bounds__(64) k_pcond(GqpDev P, GqpDev Cd, PcondMap Mp)
         /* ---- write child stage jb ---- */
         if (Mp.mode & 1)
         {
-            for (int e = 0; e < NPC; e++) GAT(Cd.RSQ, jb * NPC + e) = Hb[e];
+            for (int e = 0; e < NPC; e++) GATL(Cd.RSQ, jb * NPC + e) = Hb[e];
             if (jb < Mp.N2)
                 for (int col = 0; col < nc; col++)
-                    for (int r = 0; r < NX; r++) GAT(Cd.BAt, (jb * nc + col) * NX + r) = X[r * nc + col];
+                    for (int r = 0; r < NX; r++) GATL(Cd.BAt, (jb * nc + col) * NX + r) = X[r * nc + col];
         }
         if (!(Mp.mode & 2)) continue;
-        for (int e = 0; e < nc; e++) GAT(Cd.rq, jb * nc + e) = gb[e];
+        for (int e = 0; e < nc; e++) GATL(Cd.rq, jb * nc + e) = gb[e];
         if (jb < Mp.N2)
-            for (int r = 0; r < NX; r++) GAT(Cd.bvec, jb * NX + r) = c[r];
+            for (int r = 0; r < NX; r++) GATL(Cd.bvec, jb * NX + r) = c[r];
         /* box rows, activity bits, value of fixed variables */
         const GqpStage &Sc = Cd.st[jb];
         const int r0 = Mp.row_off[jb], nbc = Sc.nb;
@@ -163,15 +163,15 @@ __global__ void __launch_bounds__(64) k_pcond(GqpDev P, GqpDev Cd, PcondMap Mp)
         {
             const int kp = Mp.row_kp[r0 + rc], rp = Mp.row_rp[r0 + rc];
             const GqpStage &Sp = P.st[kp];
-            const uint64_t amp = GAT(P.amask, kp);
-            GAT(Cd.dvec, Sc.o_ct + rc) = GAT(P.dvec, Sp.o_ct + rp);
-            GAT(Cd.dvec, Sc.o_ct + nbc + rc) = GAT(P.dvec, Sp.o_ct + Sp.nb + rp);
+            const uint64_t amp = GATL(P.amask, kp);
+            GATL(Cd.dvec, Sc.o_ct + rc) = GATL(P.dvec, Sp.o_ct + rp);
+            GATL(Cd.dvec, Sc.o_ct + nbc + rc) = GATL(P.dvec, Sp.o_ct + Sp.nb + rp);
             if ((amp >> rp) & 1) amc |= (uint64_t) 1 << rc;
             if ((amp >> (Sp.nb + rp)) & 1) amc |= (uint64_t) 1 << (nbc + rc);
         }
-        GAT(Cd.amask, jb) = amc;
+        GATL(Cd.amask, jb) = amc;
         for (int r = 0; r < NX; r++)
-            if ((Sc.emask >> (NUC + r)) & 1) GAT(Cd.ux, jb * nc + NUC + r) = GAT(P.ux, k0 * n + NU + r);
+            if ((Sc.emask >> (NUC + r)) & 1) GATL(Cd.ux, jb * nc + NUC + r) = GATL(P.ux, k0 * n + NU + r);
     }
 }
 
@@ -191,20 +191,20 @@ __global__ void __launch_bounds__(64) k_pexpand(GqpDev P, GqpDev Cd, PcondMap Mp
         const int k0 = Mp.blk_start[jb < Mp.N2 ? jb : Mp.N2];
         const int bs = jb < Mp.N2 ? Mp.blk_start[jb + 1] - k0 : 1;
         /* forward simulation of the eliminated states */
-        for (int r = 0; r < NX; r++) x[r] = GAT(Cd.ux, jb * nc + NUC + r);
+        for (int r = 0; r < NX; r++) x[r] = GATL(Cd.ux, jb * nc + NUC + r);
         for (int ii = 0; ii < bs; ii++)
         {
             const int k = k0 + ii;
-            for (int a = 0; a < NU; a++) u[a] = jb < Mp.N2 ? GAT(Cd.ux, jb * nc + ii * NU + a) : 0.0;
-            for (int a = 0; a < NU; a++) GAT(P.ux, k * n + a) = u[a];
-            for (int r = 0; r < NX; r++) GAT(P.ux, k * n + NU + r) = x[r];
+            for (int a = 0; a < NU; a++) u[a] = jb < Mp.N2 ? GATL(Cd.ux, jb * nc + ii * NU + a) : 0.0;
+            for (int a = 0; a < NU; a++) GATL(P.ux, k * n + a) = u[a];
+            for (int r = 0; r < NX; r++) GATL(P.ux, k * n + NU + r) = x[r];
             if (jb < Mp.N2 && ii + 1 < bs)
             {
                 for (int r = 0; r < NX; r++)
                 {
-                    double a = GAT(P.bvec, k * NX + r);
-                    for (int q = 0; q < NX; q++) a += GAT(P.BAt, (k * n + NU + q) * NX + r) * x[q];
-                    for (int q = 0; q < NU; q++) a += GAT(P.BAt, (k * n + q) * NX + r) * u[q];
+                    double a = GATL(P.bvec, k * NX + r);
+                    for (int q = 0; q < NX; q++) a += GATL(P.BAt, (k * n + NU + q) * NX + r) * x[q];
+                    for (int q = 0; q < NU; q++) a += GATL(P.BAt, (k * n + q) * NX + r) * u[q];
                     xn[r] = a;
                 }
                 for (int r = 0; r < NX; r++) x[r] = xn[r];
@@ -215,21 +215,21 @@ __global__ void __launch_bounds__(64) k_pexpand(GqpDev P, GqpDev Cd, PcondMap Mp
         if (jb < Mp.N2)
         {
             const int k1 = k0 + bs;
-            for (int r = 0; r < NX; r++) { pn[r] = GAT(Cd.pi, (jb + 1) * NX + r); GAT(P.pi, k1 * NX + r) = pn[r]; }
+            for (int r = 0; r < NX; r++) { pn[r] = GATL(Cd.pi, (jb + 1) * NX + r); GATL(P.pi, k1 * NX + r) = pn[r]; }
             for (int k = k1 - 1; k > k0; k--)
             {
                 for (int r = 0; r < NX; r++)
                 {
-                    double a = GAT(P.rq, k * n + NU + r);
+                    double a = GATL(P.rq, k * n + NU + r);
                     for (int q = 0; q < n; q++)
                     {
                         const int rr = NU + r;
-                        a += (rr >= q ? GAT(P.RSQ, k * NP + PK(rr, q)) : GAT(P.RSQ, k * NP + PK(q, rr))) * GAT(P.ux, k * n + q);
+                        a += (rr >= q ? GATL(P.RSQ, k * NP + PK(rr, q)) : GATL(P.RSQ, k * NP + PK(q, rr))) * GATL(P.ux, k * n + q);
                     }
-                    for (int q = 0; q < NX; q++) a += GAT(P.BAt, (k * n + NU + r) * NX + q) * pn[q];
+                    for (int q = 0; q < NX; q++) a += GATL(P.BAt, (k * n + NU + r) * NX + q) * pn[q];
                     pk[r] = a;
                 }
-                for (int r = 0; r < NX; r++) { pn[r] = pk[r]; GAT(P.pi, k * NX + r) = pk[r]; }
+                for (int r = 0; r < NX; r++) { pn[r] = pk[r]; GATL(P.pi, k * NX + r) = pk[r]; }
             }
         }
         /* inequality rows */
@@ -239,10 +239,10 @@ __global__ void __launch_bounds__(64) k_pexpand(GqpDev P, GqpDev Cd, PcondMap Mp
         {
             const int kp = Mp.row_kp[r0 + rc], rp = Mp.row_rp[r0 + rc];
             const GqpStage &Sp = P.st[kp];
-            GAT(P.lam, Sp.o_ct + rp) = GAT(Cd.lam, Sc.o_ct + rc);
-            GAT(P.lam, Sp.o_ct + Sp.nb + rp) = GAT(Cd.lam, Sc.o_ct + nbc + rc);
-            GAT(P.t, Sp.o_ct + rp) = GAT(Cd.t, Sc.o_ct + rc);
-            GAT(P.t, Sp.o_ct + Sp.nb + rp) = GAT(Cd.t, Sc.o_ct + nbc + rc);
+            GATL(P.lam, Sp.o_ct + rp) = GATL(Cd.lam, Sc.o_ct + rc);
+            GATL(P.lam, Sp.o_ct + Sp.nb + rp) = GATL(Cd.lam, Sc.o_ct + nbc + rc);
+            GATL(P.t, Sp.o_ct + rp) = GATL(Cd.t, Sc.o_ct + rc);
+            GATL(P.t, Sp.o_ct + Sp.nb + rp) = GATL(Cd.t, Sc.o_ct + nbc + rc);
         }
     }
     P.iter[i] = Cd.iter[i];

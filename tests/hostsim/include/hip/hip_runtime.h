@@ -15,6 +15,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <chrono>
+#include <thread>
+#include <vector>
+#include <pthread.h>
 
 #define __global__
 #define __device__
@@ -64,6 +67,37 @@ static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t
 }
 static inline int atomicSub(int *p, int v) { int o = *p; *p = o - v; return o; }
 static inline int atomicAdd(int *p, int v) { int o = *p; *p = o + v; return o; }
+
+/* ---- cooperative kernels (one block = lanes that really run concurrently) ----
+ * Kernels that use __syncthreads() and block-shared memory are launched through
+ * GQP_LAUNCH_COOP: every lane of a block becomes a host thread, __syncthreads() is a pthread
+ * barrier, `__shared__` statics and the dynamic shared buffer are shared by those threads.
+ * Blocks run one after the other. */
+struct hostsim_coop
+{
+    static pthread_barrier_t &bar() { static pthread_barrier_t b; return b; }
+    static std::vector<double> &dyn() { static std::vector<double> v; return v; }
+};
+static inline void __syncthreads() { pthread_barrier_wait(&hostsim_coop::bar()); }
+#define GQP_DYN_SHARED(name) double *name = hostsim_coop::dyn().data()
+
+#define GQP_LAUNCH_COOP(kern, grid, block, shmem, stream, ...)                              \
+    do {                                                                                    \
+        dim3 g_ = (grid); dim3 b_ = (block);                                                \
+        hostsim_coop::dyn().assign(((size_t) (shmem) + 7) / 8 + 8, 0.0);                    \
+        for (unsigned bx_ = 0; bx_ < g_.x; bx_++)                                           \
+        {                                                                                   \
+            pthread_barrier_init(&hostsim_coop::bar(), nullptr, b_.x);                      \
+            std::vector<std::thread> th_;                                                   \
+            for (unsigned tx_ = 0; tx_ < b_.x; tx_++)                                       \
+                th_.emplace_back([=]() {                                                    \
+                    blockDim = b_; gridDim = g_; blockIdx.x = bx_; threadIdx.x = tx_;       \
+                    kern(__VA_ARGS__);                                                      \
+                });                                                                         \
+            for (auto &t_ : th_) t_.join();                                                 \
+            pthread_barrier_destroy(&hostsim_coop::bar());                                  \
+        }                                                                                   \
+    } while (0)
 
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...)                           \
     do {                                                                                    \
