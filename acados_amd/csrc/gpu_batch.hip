@@ -17,6 +17,7 @@
 #include "gpu_ipm_internal.h"
 #include "ipm_kernels.hpp"
 #include "ipm_kernels_box.hpp"
+#include "ipm_kernels_wpi.hpp"
 #include "kernel_sets.h"
 
 #define HIPCHK(x)                                                                              \
@@ -31,6 +32,8 @@
 
 namespace
 {
+
+#define GQP_WPI_MIN_N 13 /* nu+nx from which the wave-per-instance kernels serve box-constrained QPs */
 
 /* compiled shape classes; a batch is served by the cheapest one that covers it */
 const KernelSet g_ksets[] = {
@@ -52,6 +55,9 @@ struct ocp_qp_gpu_batch
     bool finalized = false;
     bool use_box = false; /* box-only fast path */
     int aos = 0;          /* instance-major arrays: wave-per-instance kernel family */
+    int wpi = 0;          /* wave-per-instance kernels (ipm_kernels_wpi.hpp): one workgroup per instance */
+    size_t shmem = 0;     /* their dynamic LDS bytes */
+    KernelSet own_ks;     /* runtime-shaped kernel set of a wpi batch (ks points here) */
     int xbox = 0;
     const KernelSet *ks = nullptr;
     std::string kname;
@@ -210,6 +216,20 @@ void finalize_structure(ocp_qp_gpu_batch *b)
         char nm[160];
         snprintf(nm, sizeof(nm), "1tpi-box<NX=%d,NU=%d,XBOX=%d>", NX, NU, b->xbox);
         b->kname = nm;
+    }
+    if (b->wpi)
+    {
+        char nm[160];
+        snprintf(nm, sizeof(nm), "wpi-box(nx=%d,nu=%d,lds=%zuB)", NX, NU, b->shmem);
+        b->kname = nm;
+        b->use_box = true;
+        if (b->shmem > 64 * 1024)
+        {
+            /* more than the default dynamic LDS limit: raise it for the four sweep kernels */
+            const void *fns[] = {(const void *) gqp::kw_backward<true>, (const void *) gqp::kw_backward<false>,
+                                 (const void *) gqp::kw_forward<false>, (const void *) gqp::kw_forward<true>};
+            for (const void *f : fns) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int) b->shmem));
+        }
     }
     b->d_st = dalloc<GqpStage>(b, N + 1);
     HIPCHK(hipMemcpy(b->d_st, b->st.data(), sizeof(GqpStage) * (N + 1), hipMemcpyHostToDevice));
@@ -523,6 +543,28 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
     for (const KernelSet &ks : g_ksets) consider(ks);
     for (int q = 0; q < g_n_ksets_large; q++) consider(g_ksets_large[q]);
     if (g_force_ks) b->ks = g_force_ks;
+    /* wave-per-instance family (ipm_kernels_wpi.hpp): box-constrained QPs whose stage block is too large for
+     * the one-instance-per-lane register mapping.  Dimensions are runtime values there: no padding to a
+     * compiled shape.  ACADOS_AMD_WPI=0/1 overrides the size rule (tests). */
+    if (!g_force_ks && mg == 0 && ms == 0)
+    {
+        const int wx = force_NX ? force_NX : mx, wu = force_NU ? force_NU : mu;
+        const char *env = getenv("ACADOS_AMD_WPI");
+        const bool want = env ? atoi(env) != 0 : (wx + wu >= GQP_WPI_MIN_N || !b->ks);
+        if (want && wx + wu <= 64 && wx >= 1)
+        {
+            b->own_ks = KernelSet{wx, wu, 0, 0, gqp::kw_init, gqp::kw_backward<true>, gqp::kw_backward<false>,
+                                  gqp::kw_forward<false>, gqp::kw_forward<true>, gqp::kw_finalize,
+                                  {gqp::kw_backward<true>, gqp::kw_backward<true>},
+                                  {gqp::kw_backward<false>, gqp::kw_backward<false>},
+                                  {gqp::kw_forward<false>, gqp::kw_forward<false>},
+                                  {gqp::kw_forward<true>, gqp::kw_forward<true>}, gqp::kw_finalize};
+            b->ks = &b->own_ks;
+            b->wpi = 1;
+            b->aos = 1;
+            b->shmem = gqp::wpi_lds_doubles(wx, wu) * sizeof(double);
+        }
+    }
     if (!b->ks)
     {
         fprintf(stderr, "acados_amd: no kernel instantiation covers nx<=%d nu<=%d ng<=%d ns<=%d\n", mx, mu, mg, ms);
@@ -530,7 +572,8 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
         return nullptr;
     }
     char nm[128];
-    snprintf(nm, sizeof(nm), "1tpi<NX=%d,NU=%d,NG=%d,NS=%d>", b->ks->NX, b->ks->NU, b->ks->NG, b->ks->NS);
+    if (b->wpi) snprintf(nm, sizeof(nm), "wpi-box(nx=%d,nu=%d,lds=%zuB)", b->ks->NX, b->ks->NU, b->shmem);
+    else snprintf(nm, sizeof(nm), "1tpi<NX=%d,NU=%d,NG=%d,NS=%d>", b->ks->NX, b->ks->NU, b->ks->NG, b->ks->NS);
     b->kname = nm;
     opts_default(b->O);
     HIPCHK(hipStreamCreate(&b->stream));
@@ -818,6 +861,14 @@ struct IpmKernels
     kern_plain_t final_;
 };
 
+/* launch geometry of the IPM kernels of one level: 64 instances per single-wave block (one instance per
+ * lane) or one single-wave block per instance with the stage matrices in dynamic LDS (wpi) */
+#define GQP_IPM_LAUNCH(b, kern, s, ...)                                                                       \
+    do {                                                                                                      \
+        if ((b)->wpi) GQP_LAUNCH_COOP(kern, dim3((b)->B), dim3(64), (b)->shmem, s, __VA_ARGS__);              \
+        else hipLaunchKernelGGL(kern, dim3(((b)->B + 63) / 64), dim3(64), 0, s, __VA_ARGS__);                 \
+    } while (0)
+
 static IpmKernels pick_kernels(const ocp_qp_gpu_batch *b)
 {
     const KernelSet *ks = b->ks;
@@ -872,11 +923,10 @@ static void run_ipm(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch *root, Prof &prof, hip
     const IpmKernels K = pick_kernels(b);
     GqpDev D = b->D;
     GqpOpts O = root->O;
-    const dim3 grid((b->B + 63) / 64), block(64);
     for (;; it++)
     {
         prof.begin(1, s);
-        hipLaunchKernelGGL(K.fact, grid, block, 0, s, D, O, 0);
+        GQP_IPM_LAUNCH(b, K.fact, s, D, O, 0);
         prof.end(s);
         root->launches++;
         HIPCHK(hipMemcpyAsync(b->h_nact, D.n_active, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -893,19 +943,19 @@ static void run_ipm(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch *root, Prof &prof, hip
             break;
         }
         prof.begin(2, s);
-        hipLaunchKernelGGL(K.faff, grid, block, 0, s, D, O, 0);
+        GQP_IPM_LAUNCH(b, K.faff, s, D, O, 0);
         prof.end(s);
         prof.begin(3, s);
-        hipLaunchKernelGGL(K.rhs, grid, block, 0, s, D, O, 0);
+        GQP_IPM_LAUNCH(b, K.rhs, s, D, O, 0);
         prof.end(s);
         prof.begin(4, s);
-        hipLaunchKernelGGL(K.fcorr, grid, block, 0, s, D, O, 0);
+        GQP_IPM_LAUNCH(b, K.fcorr, s, D, O, 0);
         prof.end(s);
         root->launches += 3;
         if (O.cond_pred_corr)
         {
-            hipLaunchKernelGGL(K.rhs, grid, block, 0, s, D, O, 1);
-            hipLaunchKernelGGL(K.fcorr, grid, block, 0, s, D, O, 1);
+            GQP_IPM_LAUNCH(b, K.rhs, s, D, O, 1);
+            GQP_IPM_LAUNCH(b, K.fcorr, s, D, O, 1);
             root->launches += 2;
         }
     }
@@ -933,6 +983,7 @@ static void compact_into(ocp_qp_gpu_batch *b, int nact, hipStream_t s)
         if (!c) { fprintf(stderr, "acados_amd: cannot create the compaction sub-batch\n"); abort(); }
         c->idxb = b->idxb; c->idxs_rev = b->idxs_rev; c->idxe = b->idxe; c->nbxe = b->nbxe;
         c->compact_min = b->compact_min;
+        c->aos = b->aos; c->wpi = b->wpi; c->shmem = b->shmem;
         finalize_structure(c);
         b->compact = c;
         b->d_list = dalloc<int>(b, cap);
@@ -1002,7 +1053,7 @@ int ocp_qp_gpu_batch_solve(ocp_qp_gpu_batch *b)
     if (O.warm_start < 2)
     {
         prof.begin(0, s);
-        hipLaunchKernelGGL(ks->init, grid, block, 0, s, D, O);
+        GQP_IPM_LAUNCH(b, ks->init, s, D, O);
         prof.end(s);
         b->launches++;
     }
@@ -1015,7 +1066,7 @@ int ocp_qp_gpu_batch_solve(ocp_qp_gpu_batch *b)
         HIPCHK(hipStreamSynchronize(s));
     }
     run_ipm(b, b, prof, s, 0);
-    hipLaunchKernelGGL(pick_kernels(b).final_, grid, block, 0, s, D);
+    GQP_IPM_LAUNCH(b, pick_kernels(b).final_, s, D);
     b->launches++;
     HIPCHK(hipEventRecord(b->ev1, s));
     HIPCHK(hipStreamSynchronize(s));

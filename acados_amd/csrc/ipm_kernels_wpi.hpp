@@ -1,0 +1,683 @@
+/*
+ * ipm_kernels_wpi.hpp -- WAVE-PER-INSTANCE kernels of the batched OCP-QP interior-point solver.
+ *
+ * For stage blocks that do not fit the register file of the one-instance-per-lane mapping
+ * (nu+nx > ~14: configuration C4, the nx = 12/24 classes of C5, the condensed QP of C3).  One
+ * 64-lane wavefront (= one workgroup) owns one QP instance; the stage matrices live in LDS and the
+ * 64 lanes split every dense operation:
+ *   - lane r owns variable r of the stage ([u;x], nu+nx <= 64) for all vector work;
+ *   - matrix entries are dealt round-robin over the lanes (packed lower-triangular index);
+ *   - the Cholesky factorisation runs column by column in LDS with the rhs carried as an extra row
+ *     (so l = L^{-1} m falls out of the same loop), two workgroup barriers per column.
+ * Arrays are instance-major (GArrT::aos = 1): everything a wave reads in a stage is one contiguous
+ * block, loaded with fully coalesced wave accesses.  Dimensions are RUNTIME values (dynamic LDS), so
+ * one compiled kernel serves every shape -- there is no per-shape instantiation list.
+ *
+ * Same algorithm, same arrays and slot conventions as ipm_kernels_box.hpp (box constraints; general
+ * constraints and slacks are handled by the general one-instance-per-lane kernels for now).
+ * Only __syncthreads(), LDS and plain global accesses are used, so the CPU test tier can run these
+ * kernels under tests/hostsim (lanes = host threads).
+ */
+#ifndef IPM_KERNELS_WPI_HPP_
+#define IPM_KERNELS_WPI_HPP_
+
+#include "ipm_kernels.hpp"
+#include "ipm_kernels_box.hpp"
+
+#ifndef GQP_DYN_SHARED /* the host-simulation shim of the CPU test tier brings its own */
+#define GQP_DYN_SHARED(name) extern __shared__ double name[]
+#endif
+#ifndef GQP_LAUNCH_COOP
+#define GQP_LAUNCH_COOP hipLaunchKernelGGL
+#endif
+
+namespace gqp
+{
+
+/* element e of instance `inst` in an instance-major array */
+#define WAT(arr, e) (arr).p[(size_t) inst * (size_t) (arr).E + (size_t) (e)]
+
+/* LDS carve-up shared by the three sweep kernels (doubles) */
+struct WpiLds
+{
+    double *M;   /* (n+1) x n : stage matrix / factor, row n = rhs row */
+    double *B;   /* n x NX    : [B A]' */
+    double *W;   /* n x NX    : [B A]' Lx+ */
+    double *Lx;  /* NX x NX   : x-block of the factor of stage k+1 (lower) */
+    double *lx, *v, *g, *rb, *pin, *pik, *w0, *y, *gam, *red; /* vectors */
+    unsigned char *prow, *pcol; /* packed index -> (row, col) */
+};
+
+__host__ __device__ static inline size_t wpi_lds_doubles(int NX, int NU)
+{
+    const int n = NX + NU, NP = n * (n + 1) / 2;
+    return (size_t) (n + 1) * n + 2 * (size_t) n * NX + (size_t) NX * NX + 10 * 64 + 64 + (2 * (size_t) NP + 15) / 8 + 8;
+}
+
+__device__ static inline WpiLds wpi_carve(double *sm, int NX, int NU)
+{
+    const int n = NX + NU;
+    WpiLds L;
+    double *p = sm;
+    L.M = p; p += (n + 1) * n;
+    L.B = p; p += n * NX;
+    L.W = p; p += n * NX;
+    L.Lx = p; p += NX * NX;
+    L.lx = p; p += 64; L.v = p; p += 64; L.g = p; p += 64; L.rb = p; p += 64; L.pin = p; p += 64;
+    L.pik = p; p += 64; L.w0 = p; p += 64; L.y = p; p += 64; L.gam = p; p += 64; L.red = p; p += 64;
+    p += 64;
+    L.prow = (unsigned char *) p;
+    L.pcol = L.prow + n * (n + 1) / 2;
+    return L;
+}
+
+/* packed lower-triangular index tables (lane r fills its row) */
+__device__ static inline void wpi_tables(const WpiLds &L, int n, int lane)
+{
+    for (int r = lane; r < n; r += 64)
+        for (int c = 0; c <= r; c++)
+        {
+            L.prow[PK(r, c)] = (unsigned char) r;
+            L.pcol[PK(r, c)] = (unsigned char) c;
+        }
+    __syncthreads();
+}
+
+/* block-wide reductions through LDS (NaN-propagating max, sum, min) */
+__device__ static inline double wpi_max(double v, double *red, int lane)
+{
+    red[lane] = v;
+    __syncthreads();
+    for (int s = 32; s > 0; s >>= 1)
+    {
+        if (lane < s)
+        {
+            const double a = red[lane + s], b = red[lane];
+            red[lane] = (a > b || a != a) ? a : b;
+        }
+        __syncthreads();
+    }
+    const double r = red[0];
+    __syncthreads();
+    return r;
+}
+__device__ static inline double wpi_sum(double v, double *red, int lane)
+{
+    red[lane] = v;
+    __syncthreads();
+    for (int s = 32; s > 0; s >>= 1)
+    {
+        if (lane < s) red[lane] += red[lane + s];
+        __syncthreads();
+    }
+    const double r = red[0];
+    __syncthreads();
+    return r;
+}
+__device__ static inline double wpi_min(double v, double *red, int lane)
+{
+    red[lane] = v;
+    __syncthreads();
+    for (int s = 32; s > 0; s >>= 1)
+    {
+        if (lane < s && red[lane + s] < red[lane]) red[lane] = red[lane + s];
+        __syncthreads();
+    }
+    const double r = red[0];
+    __syncthreads();
+    return r;
+}
+
+/* column-by-column Cholesky of the n x n lower triangle of M with the rhs as row n:
+ * afterwards M = L (lower), row n = l = L^{-1} m.  Non-positive pivots zero the column. */
+__device__ static inline void wpi_chol_rhs(const WpiLds &L, int n, int lane)
+{
+    double *M = L.M;
+    for (int j = 0; j < n; j++)
+    {
+        const double d = M[j * n + j];
+        const bool pos = d > 0.0;
+        const double inv = pos ? frsqrt(d) : 0.0;
+        for (int r = j + 1 + lane; r <= n; r += 64) M[r * n + j] *= inv;
+        __syncthreads();
+        /* the pivot itself is rewritten only now: nobody reads it during the trailing update */
+        if (lane == 63) M[j * n + j] = pos ? d * inv : 0.0;
+        /* trailing update of rows j+1..n (row n = rhs), columns j+1..min(r, n-1) */
+        const int m = n - j - 1;               /* size of the trailing triangle */
+        const int T = m * (m + 1) / 2 + m;     /* + the rhs row (m entries) */
+        for (int idx = lane; idx < T; idx += 64)
+        {
+            int r, c;
+            if (idx < m * (m + 1) / 2) { r = j + 1 + L.prow[idx]; c = j + 1 + L.pcol[idx]; }
+            else { r = n; c = j + 1 + (idx - m * (m + 1) / 2); }
+            M[r * n + c] -= M[r * n + j] * M[c * n + j];
+        }
+        __syncthreads();
+    }
+}
+
+/* forward substitution of the rhs row only (factor already in M): row n <- L^{-1} row n */
+__device__ static inline void wpi_fsub(const WpiLds &L, int n, int lane)
+{
+    double *M = L.M;
+    for (int j = 0; j < n; j++)
+    {
+        const double d = M[j * n + j];
+        if (lane == 0) M[n * n + j] = d != 0.0 ? M[n * n + j] * frcp(d) : 0.0;
+        __syncthreads();
+        const double lj = M[n * n + j];
+        for (int c = j + 1 + lane; c < n; c += 64) M[n * n + c] -= M[c * n + j] * lj;
+        __syncthreads();
+    }
+}
+
+/* ------------------------------------------------------------------ factor / rhs-only backward */
+
+/* FACT = 1: residuals, norms, status decision, condensation, factorisation.
+ * FACT = 0: corrector rhs (redo = 1: centering only), factor reused. */
+template <bool FACT>
+__global__ void __launch_bounds__(64) kw_backward(GqpDev D, GqpOpts O, int redo)
+{
+    GQP_DYN_SHARED(smem);
+    const int NX = D.NX, NU = D.NU, n = NX + NU, NP = n * (n + 1) / 2;
+    const int inst = blockIdx.x, lane = threadIdx.x;
+    if (inst >= D.B) return;
+    if (D.status[inst] != GQP_RUNNING) return;
+    if (!FACT && redo && !(D.alpha[inst] < 0.0)) return;
+    const WpiLds L = wpi_carve(smem, NX, NU);
+    wpi_tables(L, n, lane);
+    const double smu = FACT ? 0.0 : D.smu[inst];
+    const double pscale = (FACT || redo) ? 0.0 : 1.0;
+
+    for (int e = lane; e < NX * NX; e += 64) L.Lx[e] = 0.0;
+    if (lane < NX) L.lx[lane] = 0.0;
+    double nrm_g = 0.0, nrm_b = 0.0, nrm_d = 0.0, nrm_m = 0.0, musum = 0.0, obj = 0.0;
+    int nact = 0;
+    __syncthreads();
+
+    for (int k = D.N; k >= 0; k--)
+    {
+        const GqpStage &S = D.st[k];
+        const uint64_t imask = S.bmask & ~S.emask;
+        const uint64_t am = WAT(D.amask, k);
+        const int nbg = S.nb;
+        const bool mine = lane < n;
+        const bool fixed = mine && ((S.emask >> lane) & 1);
+
+        /* ---- loads into LDS (coalesced: the stage block of this instance is contiguous) ---- */
+        for (int e = lane; e < n * NX; e += 64) L.B[e] = WAT(D.BAt, k * n * NX + e);
+        if (FACT) { for (int p = lane; p < NP; p += 64) L.M[L.prow[p] * n + L.pcol[p]] = WAT(D.RSQ, k * NP + p); }
+        else { for (int p = lane; p < NP; p += 64) L.M[L.prow[p] * n + L.pcol[p]] = WAT(D.Lf, k * NP + p); }
+        double gt = 0.0; /* lane r: entry r of the gradient-like vector being built */
+        if (FACT)
+        {
+            if (mine) { L.v[lane] = WAT(D.ux, k * n + lane); L.g[lane] = WAT(D.rq, k * n + lane); }
+            if (lane < NX)
+            {
+                L.rb[lane] = WAT(D.bvec, k * NX + lane) - WAT(D.ux, (k + 1) * n + NU + lane);
+                L.pin[lane] = WAT(D.pi, (k + 1) * NX + lane);
+                L.pik[lane] = WAT(D.pi, k * NX + lane);
+            }
+        }
+        else
+        {
+            if (mine) gt = WAT(D.rg, k * n + lane);
+            if (lane < NX) L.rb[lane] = WAT(D.rb, k * NX + lane);
+        }
+        /* box row of variable `lane` */
+        const bool has = mine && ((imask >> lane) & 1);
+        const int ib = has ? popc64(S.bmask & (((uint64_t) 1 << lane) - 1)) : 0;
+        const bool al = has && ((am >> ib) & 1), au = has && ((am >> (nbg + ib)) & 1);
+        const int el = S.o_ct + ib, eu = el + nbg;
+        const double ll = al ? WAT(D.lam, el) : 0.0, lu = au ? WAT(D.lam, eu) : 0.0;
+        const double ttl = al ? WAT(D.t, el) : 1.0, ttu = au ? WAT(D.t, eu) : 1.0;
+        __syncthreads();
+
+        double gam = 0.0, gadd = 0.0;
+        if (FACT)
+        {
+            /* rb, BAt pi+, W */
+            if (lane < NX)
+            {
+                double a = L.rb[lane];
+                for (int r = 0; r < n; r++) a += L.B[r * NX + lane] * L.v[r];
+                L.rb[lane] = a; /* own slot only */
+            }
+            if (mine)
+            {
+                double a = 0.0;
+                for (int c = 0; c < NX; c++) a += L.B[lane * NX + c] * L.pin[c];
+                gt = a;
+            }
+            for (int e = lane; e < n * NX; e += 64)
+            {
+                const int r = e / NX, c = e - r * NX;
+                double w = 0.0;
+                for (int q = c; q < NX; q++) w += L.B[r * NX + q] * L.Lx[q * NX + c];
+                L.W[e] = w;
+            }
+            /* H v */
+            double hv = 0.0;
+            if (mine)
+            {
+                for (int c = 0; c <= lane; c++) hv += L.M[lane * n + c] * L.v[c];
+                for (int c = lane + 1; c < n; c++) hv += L.M[c * n + lane] * L.v[c];
+                obj += (0.5 * hv + L.g[lane]) * L.v[lane];
+                gt += hv + L.g[lane];
+                if (lane >= NU) gt -= L.pik[lane - NU];
+            }
+            /* box row */
+            double rdl = 0.0, rdu = 0.0;
+            if (has)
+            {
+                const double vj = L.v[lane];
+                rdl = al ? vj - WAT(D.dvec, el) - ttl : 0.0;
+                rdu = au ? WAT(D.dvec, eu) - vj - ttu : 0.0;
+                const double rml = al ? ll * ttl - O.tau_min : 0.0, rmu = au ? lu * ttu - O.tau_min : 0.0;
+                nacc(nrm_d, rdl); nacc(nrm_d, rdu); nacc(nrm_m, rml); nacc(nrm_m, rmu);
+                musum += ll * ttl + lu * ttu;
+                nact += (int) al + (int) au;
+                gt -= ll - lu;
+                const double itl = frcp(ttl), itu = frcp(ttu);
+                gam = ll * itl + lu * itu;
+                gadd = (rml + ll * rdl) * itl - (rmu + lu * rdu) * itu;
+                WAT(D.rd, el) = rdl;
+                WAT(D.rd, eu) = rdu;
+            }
+            if (fixed) gt = 0.0;
+            if (mine) { nacc(nrm_g, gt); WAT(D.rg, k * n + lane) = gt; }
+            __syncthreads(); /* rb complete, W complete */
+            if (lane < NX) { nacc(nrm_b, L.rb[lane]); WAT(D.rb, k * NX + lane) = L.rb[lane]; }
+        }
+        else
+        {
+            if (has)
+            {
+                const double rdl = al ? WAT(D.rd, el) : 0.0, rdu = au ? WAT(D.rd, eu) : 0.0;
+                const double rml = al ? ll * ttl - O.tau_min + pscale * WAT(D.pcorr, el) - smu : 0.0;
+                const double rmu = au ? lu * ttu - O.tau_min + pscale * WAT(D.pcorr, eu) - smu : 0.0;
+                gadd = (rml + ll * rdl) * frcp(ttl) - (rmu + lu * rdu) * frcp(ttu);
+            }
+        }
+        /* w0 = Lx+' rb + lx+ ; y = Lx+ w0 */
+        if (lane < NX)
+        {
+            double a = L.lx[lane];
+            for (int q = lane; q < NX; q++) a += L.Lx[q * NX + lane] * L.rb[q];
+            L.w0[lane] = a;
+        }
+        if (FACT && mine) L.gam[lane] = gam;
+        __syncthreads();
+        double m;
+        if (FACT)
+        {
+            /* M += W W' (+ reg and Gamma on the diagonal); m = gt + gadd + W w0 */
+            for (int p = lane; p < NP; p += 64)
+            {
+                const int r = L.prow[p], c = L.pcol[p];
+                double a = 0.0;
+                for (int q = 0; q < NX; q++) a += L.W[r * NX + q] * L.W[c * NX + q];
+                if (r == c) a += O.reg_prim + L.gam[r];
+                L.M[r * n + c] += a;
+            }
+            double a = 0.0;
+            if (mine) for (int c = 0; c < NX; c++) a += L.W[lane * NX + c] * L.w0[c];
+            m = gt + gadd + a;
+        }
+        else
+        {
+            if (lane < NX)
+            {
+                double a = 0.0;
+                for (int c = 0; c <= lane; c++) a += L.Lx[lane * NX + c] * L.w0[c];
+                L.y[lane] = a;
+            }
+            __syncthreads();
+            double a = 0.0;
+            if (mine) for (int c = 0; c < NX; c++) a += L.B[lane * NX + c] * L.y[c];
+            m = gt + gadd + a;
+        }
+        if (fixed) m = 0.0;
+        __syncthreads();
+        if (mine) L.M[n * n + lane] = m; /* rhs row */
+        if (FACT && S.emask)
+        {
+            for (int p = lane; p < NP; p += 64)
+            {
+                const int r = L.prow[p], c = L.pcol[p];
+                if (((S.emask >> r) & 1) || ((S.emask >> c) & 1)) L.M[r * n + c] = r == c ? 1.0 : 0.0;
+            }
+        }
+        __syncthreads();
+        if (FACT)
+        {
+            wpi_chol_rhs(L, n, lane);
+            for (int p = lane; p < NP; p += 64) WAT(D.Lf, k * NP + p) = L.M[L.prow[p] * n + L.pcol[p]];
+        }
+        else
+            wpi_fsub(L, n, lane);
+        if (mine) WAT(D.lf, k * n + lane) = L.M[n * n + lane];
+        /* x-block of the factor and of l for the next (earlier) stage */
+        for (int e = lane; e < NX * NX; e += 64)
+        {
+            const int r = e / NX, c = e - r * NX;
+            L.Lx[e] = c <= r ? L.M[(NU + r) * n + NU + c] : 0.0;
+        }
+        if (lane < NX) L.lx[lane] = L.M[n * n + NU + lane];
+        __syncthreads();
+    }
+
+    if (FACT)
+    {
+        nrm_g = wpi_max(nrm_g, L.red, lane);
+        nrm_b = wpi_max(nrm_b, L.red, lane);
+        nrm_d = wpi_max(nrm_d, L.red, lane);
+        nrm_m = wpi_max(nrm_m, L.red, lane);
+        musum = wpi_sum(musum, L.red, lane);
+        obj = wpi_sum(obj, L.red, lane);
+        const double nact_d = wpi_sum((double) nact, L.red, lane);
+        if (lane == 0)
+        {
+            const int Bp = D.Bp;
+            const double mu = nact_d > 0.0 ? musum / nact_d : 0.0;
+            D.mu[inst] = mu;
+            D.obj[inst] = obj;
+            D.res[0 * Bp + inst] = nrm_g; D.res[1 * Bp + inst] = nrm_b; D.res[2 * Bp + inst] = nrm_d; D.res[3 * Bp + inst] = nrm_m;
+            const int it = D.iter[inst];
+            if (inst < D.stat_inst && it < D.stat_rows)
+            {
+                double *st = D.stat + (size_t) it * GQP_STAT_COLS * D.stat_inst + inst;
+                st[6 * D.stat_inst] = mu;
+                st[7 * D.stat_inst] = nrm_g; st[8 * D.stat_inst] = nrm_b; st[9 * D.stat_inst] = nrm_d; st[10 * D.stat_inst] = nrm_m;
+                st[12 * D.stat_inst] = obj;
+            }
+            int status = GQP_RUNNING;
+            const bool bad = nrm_g != nrm_g || nrm_b != nrm_b || nrm_d != nrm_d || nrm_m != nrm_m || mu != mu;
+            if (bad) status = 1;
+            else if (nrm_g <= O.tol_stat && nrm_b <= O.tol_eq && nrm_d <= O.tol_ineq && nrm_m <= O.tol_comp) status = 0;
+            else if (it >= O.iter_max) status = 2;
+            else if (dabs(D.alpha[inst]) <= O.alpha_min) status = 3;
+            if (status != GQP_RUNNING)
+            {
+                D.status[inst] = status;
+                atomicSub(D.n_active, 1);
+            }
+        }
+    }
+}
+
+/* ----------------------------------------------------------------------------------- forward */
+
+template <bool CORR>
+__global__ void __launch_bounds__(64) kw_forward(GqpDev D, GqpOpts O, int redo)
+{
+    GQP_DYN_SHARED(smem);
+    const int NX = D.NX, NU = D.NU, n = NX + NU, NP = n * (n + 1) / 2;
+    const int inst = blockIdx.x, lane = threadIdx.x;
+    if (inst >= D.B) return;
+    if (D.status[inst] != GQP_RUNNING) return;
+    if (redo && !(D.alpha[inst] < 0.0)) return;
+    const WpiLds L = wpi_carve(smem, NX, NU);
+    wpi_tables(L, n, lane);
+    const double smu = CORR ? D.smu[inst] : 0.0;
+    const double pscale = (CORR && !redo) ? 1.0 : 0.0;
+    double alpha = 1.0, S0 = 0.0, S1 = 0.0, S2 = 0.0;
+    int nact = 0;
+    double *dvv = L.v;  /* dv of the stage, entry per variable */
+    double *dx = L.y;   /* dx of the stage being entered */
+    if (lane < NX) dx[lane] = 0.0;
+    __syncthreads();
+
+    for (int k = 0; k <= D.N; k++)
+    {
+        const GqpStage &S = D.st[k];
+        const uint64_t imask = S.bmask & ~S.emask;
+        const uint64_t am = WAT(D.amask, k);
+        const int nbg = S.nb;
+        const bool mine = lane < n;
+
+        for (int p = lane; p < NP; p += 64) L.M[L.prow[p] * n + L.pcol[p]] = WAT(D.Lf, k * NP + p);
+        for (int e = lane; e < n * NX; e += 64) L.B[e] = WAT(D.BAt, k * n * NX + e);
+        if (mine) L.g[lane] = WAT(D.lf, k * n + lane); /* l */
+        if (lane < NX) L.rb[lane] = WAT(D.rb, k * NX + lane);
+        const bool has = mine && ((imask >> lane) & 1);
+        const int ib = has ? popc64(S.bmask & (((uint64_t) 1 << lane) - 1)) : 0;
+        const bool al = has && ((am >> ib) & 1), au = has && ((am >> (nbg + ib)) & 1);
+        const int el = S.o_ct + ib, eu = el + nbg;
+        const double ll = al ? WAT(D.lam, el) : 0.0, lu = au ? WAT(D.lam, eu) : 0.0;
+        const double ttl = al ? WAT(D.t, el) : 1.0, ttu = au ? WAT(D.t, eu) : 1.0;
+        const double rdl = al ? WAT(D.rd, el) : 0.0, rdu = au ? WAT(D.rd, eu) : 0.0;
+        const double pl = (CORR && al) ? WAT(D.pcorr, el) : 0.0, pu = (CORR && au) ? WAT(D.pcorr, eu) : 0.0;
+        __syncthreads();
+
+        /* dpi_k = Lx (Lx' dx + lx) */
+        if (CORR && k > 0)
+        {
+            if (lane < NX)
+            {
+                double a = L.g[NU + lane];
+                for (int q = lane; q < NX; q++) a += L.M[(NU + q) * n + NU + lane] * dx[q];
+                L.w0[lane] = a;
+            }
+            __syncthreads();
+            if (lane < NX)
+            {
+                double a = 0.0;
+                for (int c = 0; c <= lane; c++) a += L.M[(NU + lane) * n + NU + c] * L.w0[c];
+                WAT(D.dpi, k * NX + lane) = a;
+            }
+        }
+        /* solve L' dv = -l for the free block: everything at k = 0, the inputs otherwise.
+         * acc[r] = -l[r] - sum_{p >= top} L[p][r] dv[p] first, then a short sequential sweep. */
+        const int top = k == 0 ? n : NU;
+        if (mine && lane >= top) dvv[lane] = dx[lane - NU];
+        __syncthreads();
+        double acc = 0.0;
+        if (lane < top)
+        {
+            acc = -L.g[lane];
+            for (int p = top; p < n; p++) acc -= L.M[p * n + lane] * dvv[p];
+        }
+        for (int r = top - 1; r >= 0; r--)
+        {
+            if (lane == r)
+            {
+                const double d = L.M[r * n + r];
+                dvv[r] = d != 0.0 ? acc * frcp(d) : 0.0;
+            }
+            __syncthreads();
+            if (lane < r) acc -= L.M[r * n + lane] * dvv[r];
+        }
+        __syncthreads();
+        const double dvj = mine ? dvv[lane] : 0.0;
+        if (CORR && mine) WAT(D.dux, k * n + lane) = dvj;
+        /* dx of the next stage */
+        double dxn = 0.0;
+        if (lane < NX)
+        {
+            dxn = L.rb[lane];
+            for (int r = 0; r < n; r++) dxn += L.B[r * NX + lane] * dvv[r];
+        }
+        /* box row: dt, dlam, ratio test */
+        if (has)
+        {
+            const double rml = al ? ll * ttl - O.tau_min + pscale * pl - smu : 0.0;
+            const double rmu = au ? lu * ttu - O.tau_min + pscale * pu - smu : 0.0;
+            const double dtl = al ? dvj + rdl : 0.0, dtu = au ? -dvj + rdu : 0.0;
+            const double dll = al ? -(rml + ll * dtl) * frcp(ttl) : 0.0;
+            const double dlu = au ? -(rmu + lu * dtu) * frcp(ttu) : 0.0;
+            const double c1 = -ll * frcp(dll), c2 = -lu * frcp(dlu), c3 = -ttl * frcp(dtl), c4 = -ttu * frcp(dtu);
+            alpha = (dll < 0.0 && c1 < alpha) ? c1 : alpha;
+            alpha = (dlu < 0.0 && c2 < alpha) ? c2 : alpha;
+            alpha = (dtl < 0.0 && c3 < alpha) ? c3 : alpha;
+            alpha = (dtu < 0.0 && c4 < alpha) ? c4 : alpha;
+            if (!CORR)
+            {
+                S0 += ll * ttl + lu * ttu;
+                S1 += ll * dtl + ttl * dll + lu * dtu + ttu * dlu;
+                S2 += dll * dtl + dlu * dtu;
+                nact += (int) al + (int) au;
+                WAT(D.pcorr, el) = dll * dtl;
+                WAT(D.pcorr, eu) = dlu * dtu;
+            }
+            else
+            {
+                WAT(D.dlam, el) = dll; WAT(D.dlam, eu) = dlu;
+                WAT(D.dt, el) = dtl; WAT(D.dt, eu) = dtu;
+            }
+        }
+        __syncthreads();
+        if (lane < NX) dx[lane] = dxn;
+        __syncthreads();
+    }
+
+    alpha = wpi_min(alpha, L.red, lane);
+    const int it = D.iter[inst];
+    double *st = (inst < D.stat_inst && it + 1 < D.stat_rows) ? D.stat + (size_t) (it + 1) * GQP_STAT_COLS * D.stat_inst + inst : nullptr;
+    if (!CORR)
+    {
+        S0 = wpi_sum(S0, L.red, lane); S1 = wpi_sum(S1, L.red, lane); S2 = wpi_sum(S2, L.red, lane);
+        const double nact_d = wpi_sum((double) nact, L.red, lane);
+        if (lane == 0)
+        {
+            const double mu = D.mu[inst];
+            const double mu_aff = nact_d > 0.0 ? (S0 + alpha * S1 + alpha * alpha * S2) / nact_d : 0.0;
+            double sigma = mu > 0.0 ? mu_aff / mu : 0.0;
+            sigma = sigma * sigma * sigma;
+            D.smu[inst] = sigma * mu;
+            D.alpha[inst] = alpha;
+            if (st) { st[0] = alpha; st[1 * D.stat_inst] = alpha; st[2 * D.stat_inst] = mu_aff; st[3 * D.stat_inst] = sigma; }
+        }
+        return;
+    }
+    const double alpha_aff = dabs(D.alpha[inst]);
+    if (O.cond_pred_corr && !redo && alpha < 0.1 * alpha_aff)
+    {
+        __syncthreads(); /* everybody has read alpha[inst] */
+        if (lane == 0) D.alpha[inst] = -alpha_aff;
+        return;
+    }
+    const double a = D.mu[inst] > 0.0 ? alpha * 0.995 : 1.0;
+    /* update: the arrays of one instance are contiguous */
+    for (int e = lane; e < (D.N + 1) * n; e += 64) WAT(D.ux, e) += a * WAT(D.dux, e);
+    for (int e = NX + lane; e < (D.N + 1) * NX; e += 64) WAT(D.pi, e) += a * WAT(D.dpi, e);
+    for (int k = 0; k <= D.N; k++)
+    {
+        const GqpStage &S = D.st[k];
+        const uint64_t imask = S.bmask & ~S.emask;
+        const uint64_t am = WAT(D.amask, k);
+        const int nbg = S.nb;
+        if (lane < n && ((imask >> lane) & 1))
+        {
+            const int ib = popc64(S.bmask & (((uint64_t) 1 << lane) - 1));
+            for (int side = 0; side < 2; side++)
+            {
+                const int e = S.o_ct + side * nbg + ib;
+                if (!((am >> (side * nbg + ib)) & 1)) continue;
+                const double lam = WAT(D.lam, e) + a * WAT(D.dlam, e);
+                const double t = WAT(D.t, e) + a * WAT(D.dt, e);
+                WAT(D.lam, e) = lam < O.lam_min ? O.lam_min : lam;
+                WAT(D.t, e) = t < O.t_min ? O.t_min : t;
+            }
+        }
+    }
+    __syncthreads();
+    if (lane == 0)
+    {
+        D.alpha[inst] = alpha;
+        D.iter[inst] = it + 1;
+        if (st) { st[4 * D.stat_inst] = alpha; st[5 * D.stat_inst] = alpha; }
+    }
+}
+
+/* ------------------------------------------------------------------------ init / finalize */
+
+/* cold start, same rules as k_init (ipm_kernels.hpp) for box rows; lane = variable */
+__global__ void __launch_bounds__(64) kw_init(GqpDev D, GqpOpts O)
+{
+    const int NX = D.NX, NU = D.NU, n = NX + NU;
+    const int inst = blockIdx.x, lane = threadIdx.x;
+    if (inst >= D.B) return;
+    const double thr0 = 1e-1;
+    for (int k = 0; k <= D.N; k++)
+    {
+        const GqpStage &S = D.st[k];
+        const int nbg = S.nb;
+        const uint64_t am = WAT(D.amask, k);
+        if (lane < n)
+        {
+            const bool fixed = (S.emask >> lane) & 1;
+            double v = fixed ? WAT(D.ux, k * n + lane) : 0.0;
+            if ((S.bmask >> lane) & 1)
+            {
+                const int ib = popc64(S.bmask & (((uint64_t) 1 << lane) - 1));
+                const double lb = WAT(D.dvec, S.o_ct + ib), ub = WAT(D.dvec, S.o_ct + nbg + ib);
+                const bool al = (am >> ib) & 1, au = (am >> (nbg + ib)) & 1;
+                if (!fixed)
+                {
+                    const double tl = v - lb, tu = ub - v;
+                    if (al && au)
+                    {
+                        if (tl < thr0) v = (tu < thr0) ? 0.5 * (lb + ub) : lb + thr0;
+                        else if (tu < thr0) v = ub - thr0;
+                    }
+                    else if (al) { if (tl < thr0) v = lb + thr0; }
+                    else if (au) { if (tu < thr0) v = ub - thr0; }
+                }
+                double tl = v - lb, tu = ub - v;
+                if (tl < thr0) tl = thr0;
+                if (tu < thr0) tu = thr0;
+                WAT(D.t, S.o_ct + ib) = al ? tl : 0.0;
+                WAT(D.t, S.o_ct + nbg + ib) = au ? tu : 0.0;
+                WAT(D.lam, S.o_ct + ib) = al ? O.mu0 / tl : 0.0;
+                WAT(D.lam, S.o_ct + nbg + ib) = au ? O.mu0 / tu : 0.0;
+            }
+            WAT(D.ux, k * n + lane) = v;
+        }
+        if (S.has_dyn && lane < NX) WAT(D.pi, (k + 1) * NX + lane) = 0.0;
+    }
+    if (lane == 0)
+    {
+        D.iter[inst] = 0;
+        D.status[inst] = GQP_RUNNING;
+        D.alpha[inst] = 1.0;
+    }
+}
+
+/* multipliers of the fixed variables and natural slacks of the masked sides, as kb_finalize */
+__global__ void __launch_bounds__(64) kw_finalize(GqpDev D)
+{
+    const int NX = D.NX, NU = D.NU, n = NX + NU, NP = n * (n + 1) / 2;
+    const int inst = blockIdx.x, lane = threadIdx.x;
+    if (inst >= D.B) return;
+    for (int k = 0; k <= D.N; k++)
+    {
+        const GqpStage &S = D.st[k];
+        if (S.nb == 0 || lane >= n || !((S.bmask >> lane) & 1)) continue;
+        const int nbg = S.nb, j = lane;
+        const uint64_t am = WAT(D.amask, k);
+        const int ib = popc64(S.bmask & (((uint64_t) 1 << j) - 1));
+        const int el = S.o_ct + ib, eu = el + nbg;
+        const double vj = WAT(D.ux, k * n + j);
+        if ((S.emask >> j) & 1)
+        {
+            double a = WAT(D.rq, k * n + j);
+            for (int c = 0; c < n; c++) a += WAT(D.RSQ, k * NP + (c <= j ? PK(j, c) : PK(c, j))) * WAT(D.ux, k * n + c);
+            for (int c = 0; c < NX; c++) a += WAT(D.BAt, (k * n + j) * NX + c) * WAT(D.pi, (k + 1) * NX + c);
+            if (j >= NU) a -= WAT(D.pi, k * NX + j - NU);
+            WAT(D.lam, el) = a > 0.0 ? a : 0.0;
+            WAT(D.lam, eu) = a < 0.0 ? -a : 0.0;
+            WAT(D.t, el) = 0.0;
+            WAT(D.t, eu) = 0.0;
+        }
+        else
+        {
+            if (!((am >> ib) & 1)) { WAT(D.t, el) = vj - WAT(D.dvec, el); WAT(D.lam, el) = 0.0; }
+            if (!((am >> (nbg + ib)) & 1)) { WAT(D.t, eu) = WAT(D.dvec, eu) - vj; WAT(D.lam, eu) = 0.0; }
+        }
+    }
+}
+
+} // namespace gqp
+
+#endif

@@ -65,6 +65,8 @@ static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t
     *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
     return hipSuccess;
 }
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize };
+static inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
 static inline int atomicSub(int *p, int v) { int o = *p; *p = o - v; return o; }
 static inline int atomicAdd(int *p, int v) { int o = *p; *p = o + v; return o; }
 

@@ -178,15 +178,53 @@ def test_c4_shape_general_constraints_and_slacks_hostsim(hostsim_lib):
     assert b.kernel_name == "1tpi<NX=24,NU=3,NG=4,NS=8>"
 
 
-def test_c5_shape_classes_and_multiphase_hostsim(hostsim_lib):
+@pytest.mark.parametrize("wpi", ["0", "1"])
+def test_c5_shape_classes_and_multiphase_hostsim(hostsim_lib, monkeypatch, wpi):
     """C5: shape classes nx in {4,12,24} (nu = ceil(nx/4)) and the multi-phase class whose state
-    dimension switches 12 -> 4 mid-horizon (per-stage dims inside one padded kernel shape)"""
+    dimension switches 12 -> 4 mid-horizon (per-stage dims inside one padded kernel shape).
+    Both kernel families: one instance per lane (ACADOS_AMD_WPI=0) and one wave per instance
+    (ACADOS_AMD_WPI=1; the default from nu+nx = 13 on)."""
     from acados_amd.generators import lqr_instance_qp, multiphase_qp, random_lqr_batch
+    monkeypatch.setenv("ACADOS_AMD_WPI", wpi)
+    fam = "wpi-box(" if wpi == "1" else "1tpi-box<"
     for nx, nu in ((4, 1), (12, 3), (24, 6)):
         data = random_lqr_batch(N=5, nx=nx, nu=nu, batch=2, seed=7)
-        _check_batch_vs_oracle([lqr_instance_qp(data, i, 5) for i in range(2)], hostsim_lib)
+        b = _check_batch_vs_oracle([lqr_instance_qp(data, i, 5) for i in range(2)], hostsim_lib)
+        assert b.kernel_name.startswith(fam)
     b = _check_batch_vs_oracle([multiphase_qp(i, N=8) for i in range(3)], hostsim_lib)
-    assert b.kernel_name.startswith("1tpi-box<NX=12,NU=3")
+    assert b.kernel_name.startswith("wpi-box(nx=12,nu=3" if wpi == "1" else "1tpi-box<NX=12,NU=3")
+
+
+def test_wave_per_instance_default_rule_hostsim(hostsim_lib):
+    """without the override: small stage blocks stay on the one-instance-per-lane kernels, nu+nx >= 13
+    goes to the wave-per-instance family; a batch that is not a multiple of anything, per-instance
+    iteration counts, Riccati getters and hot start on that family"""
+    from acados_amd import OcpQpGpuBatch
+    from acados_amd.generators import fill_lqr_batch, lqr_dims, lqr_instance_qp, random_lqr_batch
+    N, B = 6, 5
+    data = random_lqr_batch(N=N, nx=12, nu=3, batch=B, seed=11)
+    gb = OcpQpGpuBatch(lqr_dims(N, 12, 3), B, _clib=hostsim_lib)
+    assert gb.kernel_name.startswith("wpi-box(nx=12,nu=3")
+    fill_lqr_batch(gb, data, N)
+    gb.opts_set("tol_stat", 1e-8)
+    assert gb.solve() == 0
+    iters = gb.info("iter").copy()
+    for i in range(B):
+        qp = lqr_instance_qp(data, i, N)
+        o = OracleQp(qp)
+        assert o.solve(default_opts(tol_stat=1e-8)) == 0
+        compare_with_oracle(lambda k, f: gb.get(f, k)[i], o, qp, 1e-8)
+        assert abs(int(iters[i]) - o.iter) <= 1
+        if i == 0:
+            o.refactor()
+            for k in (0, N):
+                assert np.allclose(gb.get("ric_L", k)[i], o.get(k, "ric_L"), rtol=1e-6, atol=1e-8)
+    small = OcpQpGpuBatch(lqr_dims(N, 8, 3), 2, _clib=hostsim_lib)
+    assert small.kernel_name.startswith("1tpi")
+    # hot start from the solution: converged at the first residual evaluation
+    gb.opts_set("warm_start", 2)
+    assert gb.solve() == 0
+    assert int(gb.info("iter").max()) <= 1
 
 
 def test_partial_condensing_hostsim(hostsim_lib):

@@ -12,6 +12,9 @@ def rate(gb, tag, n):
     t0 = time.perf_counter(); bad = gb.solve(); dt = time.perf_counter() - t0
     it = gb.info("iter")
     print(f"{tag:44s} kernel {gb.kernel_name:34s} batch {n:6d}  {dt*1e3:9.1f} ms/solve  {n/dt:11.0f} solves/s  iters {it.mean():.1f}/{it.max()}  failures {bad}")
+    gb.scalar("prof_reset"); gb.opts_set("profile", 1); gb.solve(); gb.opts_set("profile", 0)
+    cls = ("back_fact", "fwd_aff", "back_rhs", "fwd_corr")
+    print("    avg ms per launch: " + "  ".join(f"{c} {gb.scalar('prof_ms_' + c) / max(gb.scalar('prof_cnt_' + c), 1):.3f}" for c in cls))
 
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
