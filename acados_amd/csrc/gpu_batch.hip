@@ -56,7 +56,8 @@ struct ocp_qp_gpu_batch
     bool use_box = false; /* box-only fast path */
     int aos = 0;          /* instance-major arrays: wave-per-instance kernel family */
     int wpi = 0;          /* wave-per-instance kernels (ipm_kernels_wpi.hpp): one workgroup per instance */
-    size_t shmem = 0;     /* their dynamic LDS bytes */
+    size_t shmem = 0;     /* their dynamic LDS bytes (rhs / forward sweeps) */
+    size_t shmem_fact = 0; /* dynamic LDS bytes of the factor sweep */
     KernelSet own_ks;     /* runtime-shaped kernel set of a wpi batch (ks points here) */
     int xbox = 0;
     const KernelSet *ks = nullptr;
@@ -223,12 +224,13 @@ void finalize_structure(ocp_qp_gpu_batch *b)
         snprintf(nm, sizeof(nm), "wpi-box(nx=%d,nu=%d,lds=%zuB)", NX, NU, b->shmem);
         b->kname = nm;
         b->use_box = true;
-        if (b->shmem > 64 * 1024)
+        if (std::max(b->shmem, b->shmem_fact) > 64 * 1024)
         {
             /* more than the default dynamic LDS limit: raise it for the four sweep kernels */
-            const void *fns[] = {(const void *) gqp::kw_backward<true>, (const void *) gqp::kw_backward<false>,
-                                 (const void *) gqp::kw_forward<false>, (const void *) gqp::kw_forward<true>};
-            for (const void *f : fns) HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int) b->shmem));
+            const void *fns[] = {(const void *) b->own_ks.back_fact, (const void *) b->own_ks.back_rhs,
+                                 (const void *) b->own_ks.fwd_aff, (const void *) b->own_ks.fwd_corr};
+            for (const void *f : fns)
+                HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int) std::max(b->shmem, b->shmem_fact)));
         }
     }
     b->d_st = dalloc<GqpStage>(b, N + 1);
@@ -553,16 +555,24 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
         const bool want = env ? atoi(env) != 0 : (wx + wu >= GQP_WPI_MIN_N || !b->ks);
         if (want && wx + wu <= 64 && wx >= 1)
         {
-            b->own_ks = KernelSet{wx, wu, 0, 0, gqp::kw_init, gqp::kw_backward<true>, gqp::kw_backward<false>,
-                                  gqp::kw_forward<false>, gqp::kw_forward<true>, gqp::kw_finalize,
-                                  {gqp::kw_backward<true>, gqp::kw_backward<true>},
-                                  {gqp::kw_backward<false>, gqp::kw_backward<false>},
-                                  {gqp::kw_forward<false>, gqp::kw_forward<false>},
-                                  {gqp::kw_forward<true>, gqp::kw_forward<true>}, gqp::kw_finalize};
+            /* factor sweep: register-tile kernel for the tile count of this shape; rhs-only and forward sweeps on
+             * the packed factor.  ACADOS_AMD_WPI_V1=1 selects the plain LDS-resident reference kernels of the
+             * family instead (kw_backward / kw_forward), kept for cross-checking. */
+            static const kern_redo_t fact_t8[8] = {gqp::kw_factor<1>, gqp::kw_factor<2>, gqp::kw_factor<3>, gqp::kw_factor<4>,
+                                                   gqp::kw_factor<5>, gqp::kw_factor<6>, gqp::kw_factor<7>, gqp::kw_factor<8>};
+            const char *v1 = getenv("ACADOS_AMD_WPI_V1");
+            const bool ref = v1 && atoi(v1) != 0;
+            const kern_redo_t fact = ref ? gqp::kw_backward<true> : fact_t8[(wx + wu + 7) / 8 - 1];
+            const kern_redo_t rhs = ref ? gqp::kw_backward<false> : gqp::kw_backrhs;
+            const kern_redo_t faff = ref ? gqp::kw_forward<false> : gqp::kw_fwd<false>;
+            const kern_redo_t fcor = ref ? gqp::kw_forward<true> : gqp::kw_fwd<true>;
+            b->own_ks = KernelSet{wx, wu, 0, 0, gqp::kw_init, fact, rhs, faff, fcor, gqp::kw_finalize,
+                                  {fact, fact}, {rhs, rhs}, {faff, faff}, {fcor, fcor}, gqp::kw_finalize};
             b->ks = &b->own_ks;
             b->wpi = 1;
             b->aos = 1;
-            b->shmem = gqp::wpi_lds_doubles(wx, wu) * sizeof(double);
+            b->shmem = (ref ? gqp::wpi_lds_doubles(wx, wu) : gqp::wpi3_lds_doubles(wx, wu)) * sizeof(double);
+            b->shmem_fact = (ref ? gqp::wpi_lds_doubles(wx, wu) : gqp::wpi2_lds_doubles(wx, wu)) * sizeof(double);
         }
     }
     if (!b->ks)
@@ -863,11 +873,12 @@ struct IpmKernels
 
 /* launch geometry of the IPM kernels of one level: 64 instances per single-wave block (one instance per
  * lane) or one single-wave block per instance with the stage matrices in dynamic LDS (wpi) */
-#define GQP_IPM_LAUNCH(b, kern, s, ...)                                                                       \
+#define GQP_IPM_LAUNCH_SHM(b, kern, shm, s, ...)                                                              \
     do {                                                                                                      \
-        if ((b)->wpi) GQP_LAUNCH_COOP(kern, dim3((b)->B), dim3(64), (b)->shmem, s, __VA_ARGS__);              \
+        if ((b)->wpi) GQP_LAUNCH_COOP(kern, dim3((b)->B), dim3(64), shm, s, __VA_ARGS__);                     \
         else hipLaunchKernelGGL(kern, dim3(((b)->B + 63) / 64), dim3(64), 0, s, __VA_ARGS__);                 \
     } while (0)
+#define GQP_IPM_LAUNCH(b, kern, s, ...) GQP_IPM_LAUNCH_SHM(b, kern, (b)->shmem, s, __VA_ARGS__)
 
 static IpmKernels pick_kernels(const ocp_qp_gpu_batch *b)
 {
@@ -926,7 +937,7 @@ static void run_ipm(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch *root, Prof &prof, hip
     for (;; it++)
     {
         prof.begin(1, s);
-        GQP_IPM_LAUNCH(b, K.fact, s, D, O, 0);
+        GQP_IPM_LAUNCH_SHM(b, K.fact, b->shmem_fact, s, D, O, 0);
         prof.end(s);
         root->launches++;
         HIPCHK(hipMemcpyAsync(b->h_nact, D.n_active, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -983,7 +994,7 @@ static void compact_into(ocp_qp_gpu_batch *b, int nact, hipStream_t s)
         if (!c) { fprintf(stderr, "acados_amd: cannot create the compaction sub-batch\n"); abort(); }
         c->idxb = b->idxb; c->idxs_rev = b->idxs_rev; c->idxe = b->idxe; c->nbxe = b->nbxe;
         c->compact_min = b->compact_min;
-        c->aos = b->aos; c->wpi = b->wpi; c->shmem = b->shmem;
+        c->aos = b->aos; c->wpi = b->wpi; c->shmem = b->shmem; c->shmem_fact = b->shmem_fact;
         finalize_structure(c);
         b->compact = c;
         b->d_list = dalloc<int>(b, cap);
@@ -1355,3 +1366,16 @@ void *ocp_qp_gpu_batch_stream(ocp_qp_gpu_batch *b) { return (void *) b->stream; 
 const char *ocp_qp_gpu_batch_kernel_name(const ocp_qp_gpu_batch *b) { return b->kname.c_str(); }
 
 } /* extern "C" */
+
+#if defined(GQP_WPI_TIMING)
+/* development aid (make timing): per-phase cycle counters of the wave-per-instance factor kernel */
+extern "C" void gqp_wpi_cycles_read(unsigned long long *out, int reset)
+{
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(gqp::gqp_wpi_cycles), sizeof(unsigned long long) * 8));
+    if (reset)
+    {
+        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(gqp::gqp_wpi_cycles), z, sizeof(z)));
+    }
+}
+#endif

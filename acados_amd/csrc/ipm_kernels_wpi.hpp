@@ -31,6 +31,9 @@
 #define GQP_LAUNCH_COOP hipLaunchKernelGGL
 #endif
 
+/* dot-product loops over LDS operands: several reads in flight per lane */
+#define GQP_DOT_UNROLL _Pragma("unroll 4")
+
 namespace gqp
 {
 
@@ -240,12 +243,14 @@ __global__ void __launch_bounds__(64) kw_backward(GqpDev D, GqpOpts O, int redo)
             if (lane < NX)
             {
                 double a = L.rb[lane];
+                GQP_DOT_UNROLL
                 for (int r = 0; r < n; r++) a += L.B[r * NX + lane] * L.v[r];
                 L.rb[lane] = a; /* own slot only */
             }
             if (mine)
             {
                 double a = 0.0;
+                GQP_DOT_UNROLL
                 for (int c = 0; c < NX; c++) a += L.B[lane * NX + c] * L.pin[c];
                 gt = a;
             }
@@ -253,6 +258,7 @@ __global__ void __launch_bounds__(64) kw_backward(GqpDev D, GqpOpts O, int redo)
             {
                 const int r = e / NX, c = e - r * NX;
                 double w = 0.0;
+                GQP_DOT_UNROLL
                 for (int q = c; q < NX; q++) w += L.B[r * NX + q] * L.Lx[q * NX + c];
                 L.W[e] = w;
             }
@@ -260,7 +266,9 @@ __global__ void __launch_bounds__(64) kw_backward(GqpDev D, GqpOpts O, int redo)
             double hv = 0.0;
             if (mine)
             {
+                GQP_DOT_UNROLL
                 for (int c = 0; c <= lane; c++) hv += L.M[lane * n + c] * L.v[c];
+                GQP_DOT_UNROLL
                 for (int c = lane + 1; c < n; c++) hv += L.M[c * n + lane] * L.v[c];
                 obj += (0.5 * hv + L.g[lane]) * L.v[lane];
                 gt += hv + L.g[lane];
@@ -303,6 +311,7 @@ __global__ void __launch_bounds__(64) kw_backward(GqpDev D, GqpOpts O, int redo)
         if (lane < NX)
         {
             double a = L.lx[lane];
+            GQP_DOT_UNROLL
             for (int q = lane; q < NX; q++) a += L.Lx[q * NX + lane] * L.rb[q];
             L.w0[lane] = a;
         }
@@ -316,12 +325,17 @@ __global__ void __launch_bounds__(64) kw_backward(GqpDev D, GqpOpts O, int redo)
             {
                 const int r = L.prow[p], c = L.pcol[p];
                 double a = 0.0;
+                GQP_DOT_UNROLL
                 for (int q = 0; q < NX; q++) a += L.W[r * NX + q] * L.W[c * NX + q];
                 if (r == c) a += O.reg_prim + L.gam[r];
                 L.M[r * n + c] += a;
             }
             double a = 0.0;
-            if (mine) for (int c = 0; c < NX; c++) a += L.W[lane * NX + c] * L.w0[c];
+            if (mine)
+            {
+                GQP_DOT_UNROLL
+                for (int c = 0; c < NX; c++) a += L.W[lane * NX + c] * L.w0[c];
+            }
             m = gt + gadd + a;
         }
         else
@@ -329,12 +343,17 @@ __global__ void __launch_bounds__(64) kw_backward(GqpDev D, GqpOpts O, int redo)
             if (lane < NX)
             {
                 double a = 0.0;
+                GQP_DOT_UNROLL
                 for (int c = 0; c <= lane; c++) a += L.Lx[lane * NX + c] * L.w0[c];
                 L.y[lane] = a;
             }
             __syncthreads();
             double a = 0.0;
-            if (mine) for (int c = 0; c < NX; c++) a += L.B[lane * NX + c] * L.y[c];
+            if (mine)
+            {
+                GQP_DOT_UNROLL
+                for (int c = 0; c < NX; c++) a += L.B[lane * NX + c] * L.y[c];
+            }
             m = gt + gadd + a;
         }
         if (fixed) m = 0.0;
@@ -456,6 +475,7 @@ __global__ void __launch_bounds__(64) kw_forward(GqpDev D, GqpOpts O, int redo)
             if (lane < NX)
             {
                 double a = L.g[NU + lane];
+                GQP_DOT_UNROLL
                 for (int q = lane; q < NX; q++) a += L.M[(NU + q) * n + NU + lane] * dx[q];
                 L.w0[lane] = a;
             }
@@ -463,6 +483,7 @@ __global__ void __launch_bounds__(64) kw_forward(GqpDev D, GqpOpts O, int redo)
             if (lane < NX)
             {
                 double a = 0.0;
+                GQP_DOT_UNROLL
                 for (int c = 0; c <= lane; c++) a += L.M[(NU + lane) * n + NU + c] * L.w0[c];
                 WAT(D.dpi, k * NX + lane) = a;
             }
@@ -476,6 +497,7 @@ __global__ void __launch_bounds__(64) kw_forward(GqpDev D, GqpOpts O, int redo)
         if (lane < top)
         {
             acc = -L.g[lane];
+            GQP_DOT_UNROLL
             for (int p = top; p < n; p++) acc -= L.M[p * n + lane] * dvv[p];
         }
         for (int r = top - 1; r >= 0; r--)
@@ -496,6 +518,7 @@ __global__ void __launch_bounds__(64) kw_forward(GqpDev D, GqpOpts O, int redo)
         if (lane < NX)
         {
             dxn = L.rb[lane];
+            GQP_DOT_UNROLL
             for (int r = 0; r < n; r++) dxn += L.B[r * NX + lane] * dvv[r];
         }
         /* box row: dt, dlam, ratio test */
@@ -559,6 +582,731 @@ __global__ void __launch_bounds__(64) kw_forward(GqpDev D, GqpOpts O, int redo)
     }
     const double a = D.mu[inst] > 0.0 ? alpha * 0.995 : 1.0;
     /* update: the arrays of one instance are contiguous */
+    for (int e = lane; e < (D.N + 1) * n; e += 64) WAT(D.ux, e) += a * WAT(D.dux, e);
+    for (int e = NX + lane; e < (D.N + 1) * NX; e += 64) WAT(D.pi, e) += a * WAT(D.dpi, e);
+    for (int k = 0; k <= D.N; k++)
+    {
+        const GqpStage &S = D.st[k];
+        const uint64_t imask = S.bmask & ~S.emask;
+        const uint64_t am = WAT(D.amask, k);
+        const int nbg = S.nb;
+        if (lane < n && ((imask >> lane) & 1))
+        {
+            const int ib = popc64(S.bmask & (((uint64_t) 1 << lane) - 1));
+            for (int side = 0; side < 2; side++)
+            {
+                const int e = S.o_ct + side * nbg + ib;
+                if (!((am >> (side * nbg + ib)) & 1)) continue;
+                const double lam = WAT(D.lam, e) + a * WAT(D.dlam, e);
+                const double t = WAT(D.t, e) + a * WAT(D.dt, e);
+                WAT(D.lam, e) = lam < O.lam_min ? O.lam_min : lam;
+                WAT(D.t, e) = t < O.t_min ? O.t_min : t;
+            }
+        }
+    }
+    __syncthreads();
+    if (lane == 0)
+    {
+        D.alpha[inst] = alpha;
+        D.iter[inst] = it + 1;
+        if (st) { st[4 * D.stat_inst] = alpha; st[5 * D.stat_inst] = alpha; }
+    }
+}
+
+/* ------------------------------------------------------------------ factor, register tiles */
+
+/*
+ * kw_factor<T8>: the factorisation sweep with the stage matrix held in REGISTER TILES.
+ * The 64 lanes form an 8 x 8 grid (lr = lane / 8, lc = lane % 8); lane (lr, lc) owns the entries
+ * (lr + 8a, lc + 8b), b <= a < T8 = ceil(n / 8), of the lower triangle (2-D cyclic distribution, so the
+ * trailing matrix of every Cholesky column is spread over all lanes).  Per stage:
+ *   - H (packed), [B A]' and the vectors are fetched with coalesced loads into LDS;
+ *   - W = [B A]' Lx+ and M = H~ + W W' are computed as outer-product tiles: 2 T8 LDS reads feed
+ *     T8 (T8+1)/2 FMAs per k-step (LDS rows have an odd stride: conflict-free);
+ *   - Cholesky column j: the 8 owner lanes publish the column (one LDS round trip), every lane rescales
+ *     its 2 T8 operands itself and updates its tiles; the rhs (one entry per lane, lane = variable) rides
+ *     along, so l = L^{-1} m needs no extra pass.  One workgroup barrier per column (free for a
+ *     single-wave workgroup; it is what the host simulation of the CPU test tier synchronises on).
+ * Same arithmetic as kw_backward<true> (which stays as the plain reference of this family).
+ */
+#if defined(GQP_WPI_TIMING)
+/* development aid (not in the default build): cycles per phase of instance 0, lane 0 */
+static __device__ unsigned long long gqp_wpi_cycles[8];
+#endif
+#if defined(GQP_WPI_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+#define GQP_TICK(slot)                                                             \
+    do {                                                                           \
+        const unsigned long long now_ = clock64();                                 \
+        if (inst == 0 && lane == 0) gqp_wpi_cycles[slot] += now_ - tick_;          \
+        tick_ = now_;                                                              \
+    } while (0)
+#define GQP_TICK_INIT() unsigned long long tick_ = clock64()
+#else
+#define GQP_TICK(slot) do { } while (0)
+#define GQP_TICK_INIT() do { } while (0)
+#endif
+
+struct WpiLds2
+{
+    double *__restrict__ Hp;   /* NP: packed H, later packed L */
+    double *__restrict__ Bw;   /* 8 T8 x SX: [B A]' then W (rows >= n stay zero) */
+    double *__restrict__ Lx;   /* NX x SX: x-block of the factor of stage k+1, zeros above the diagonal */
+    double *__restrict__ lx, *__restrict__ v, *__restrict__ rb, *__restrict__ pin, *__restrict__ w0, *__restrict__ gam;
+    double *__restrict__ cb;   /* 2 x 72: published Cholesky column (double-buffered) + rhs entry */
+    double *__restrict__ red;
+    int SX;
+};
+
+__host__ __device__ static inline int wpi2_sx(int NX) { return (8 * ((NX + 7) / 8)) | 1; }
+__host__ __device__ static inline size_t wpi2_lds_doubles(int NX, int NU)
+{
+    const int n = NX + NU, NP = n * (n + 1) / 2, T8 = (n + 7) / 8, SX = wpi2_sx(NX);
+    return (size_t) NP + 8 + (size_t) 8 * T8 * SX + (size_t) NX * SX + 6 * 64 + 2 * 72 + 64 + 8;
+}
+
+__device__ static inline WpiLds2 wpi2_carve(double *sm, int NX, int NU)
+{
+    const int n = NX + NU, NP = n * (n + 1) / 2, T8 = (n + 7) / 8;
+    WpiLds2 L;
+    L.SX = wpi2_sx(NX);
+    double *p = sm;
+    L.Hp = p; p += NP + 8;
+    L.Bw = p; p += 8 * T8 * L.SX;
+    L.Lx = p; p += NX * L.SX;
+    L.lx = p; p += 64; L.v = p; p += 64; L.rb = p; p += 64; L.pin = p; p += 64; L.w0 = p; p += 64; L.gam = p; p += 64;
+    L.cb = p; p += 2 * 72;
+    L.red = p; p += 64;
+    return L;
+}
+
+template <int T8>
+__global__ void __launch_bounds__(64) kw_factor(GqpDev D, GqpOpts O, int redo)
+{
+    GQP_DYN_SHARED(smem);
+    const int NX = D.NX, NU = D.NU, n = NX + NU, NP = n * (n + 1) / 2;
+    const int inst = blockIdx.x, lane = threadIdx.x;
+    if (inst >= D.B) return;
+    if (D.status[inst] != GQP_RUNNING) return;
+    const WpiLds2 L = wpi2_carve(smem, NX, NU);
+    const int SX = L.SX, TX = (NX + 7) / 8;
+    const int lr = lane >> 3, lc = lane & 7;
+    const bool mine = lane < n;
+
+    /* zero what is only ever partly overwritten */
+    for (int e = lane; e < 8 * T8 * SX; e += 64) L.Bw[e] = 0.0;
+    for (int e = lane; e < NX * SX; e += 64) L.Lx[e] = 0.0;
+    for (int e = lane; e < 2 * 72; e += 64) L.cb[e] = 0.0;
+    L.lx[lane] = 0.0;
+    double nrm_g = 0.0, nrm_b = 0.0, nrm_d = 0.0, nrm_m = 0.0, musum = 0.0, obj = 0.0;
+    int nact = 0;
+    __syncthreads();
+
+    GQP_TICK_INIT();
+    for (int k = D.N; k >= 0; k--)
+    {
+        const GqpStage &S = D.st[k];
+        const uint64_t imask = S.bmask & ~S.emask;
+        const uint64_t am = WAT(D.amask, k);
+        const int nbg = S.nb;
+        const bool fixed = mine && ((S.emask >> lane) & 1);
+
+        /* ---- coalesced loads into LDS ---- */
+        for (int p = lane; p < NP; p += 64) L.Hp[p] = WAT(D.RSQ, k * NP + p);
+        {
+            int r = lane / NX, c = lane - r * NX;
+            const int dr = 64 / NX, dc = 64 - dr * NX;
+            for (int e = lane; e < n * NX; e += 64)
+            {
+                L.Bw[r * SX + c] = WAT(D.BAt, k * n * NX + e);
+                r += dr; c += dc;
+                if (c >= NX) { c -= NX; r++; }
+            }
+        }
+        double vj = 0.0, gj = 0.0, pik = 0.0;
+        if (mine) { vj = WAT(D.ux, k * n + lane); gj = WAT(D.rq, k * n + lane); L.v[lane] = vj; }
+        if (lane < NX)
+        {
+            L.rb[lane] = WAT(D.bvec, k * NX + lane) - WAT(D.ux, (k + 1) * n + NU + lane);
+            L.pin[lane] = WAT(D.pi, (k + 1) * NX + lane);
+        }
+        if (mine && lane >= NU) pik = WAT(D.pi, k * NX + lane - NU);
+        const bool has = mine && ((imask >> lane) & 1);
+        const int ib = has ? popc64(S.bmask & (((uint64_t) 1 << lane) - 1)) : 0;
+        const bool al = has && ((am >> ib) & 1), au = has && ((am >> (nbg + ib)) & 1);
+        const int el = S.o_ct + ib, eu = el + nbg;
+        const double ll = al ? WAT(D.lam, el) : 0.0, lu = au ? WAT(D.lam, eu) : 0.0;
+        const double ttl = al ? WAT(D.t, el) : 1.0, ttu = au ? WAT(D.t, eu) : 1.0;
+        const double lbv = al ? WAT(D.dvec, el) : 0.0, ubv = au ? WAT(D.dvec, eu) : 0.0;
+        __syncthreads();
+        GQP_TICK(0);
+
+        GQP_TICK(5);
+        /* ---- W tiles: W = [B A]' Lx+ (Lx+ has explicit zeros above its diagonal) ---- */
+        double Wt[T8][T8];
+#pragma unroll
+        for (int a = 0; a < T8; a++)
+#pragma unroll
+            for (int b = 0; b < T8; b++) Wt[a][b] = 0.0;
+#pragma unroll 2
+        for (int q = 0; q < NX; q++)
+        {
+            double bb[T8], xx[T8];
+#pragma unroll
+            for (int a = 0; a < T8; a++) bb[a] = L.Bw[(lr + 8 * a) * SX + q];
+#pragma unroll
+            for (int b = 0; b < T8; b++) xx[b] = b < TX ? L.Lx[q * SX + lc + 8 * b] : 0.0;
+#pragma unroll
+            for (int a = 0; a < T8; a++)
+#pragma unroll
+                for (int b = 0; b < T8; b++)
+                    if (b < TX) Wt[a][b] += bb[a] * xx[b];
+        }
+        GQP_TICK(6);
+        /* ---- vector part, lane = variable: rb, [B A] pi+, H v, box row ---- */
+        double gt = 0.0, gadd = 0.0, gam = 0.0;
+        if (lane < NX)
+        {
+            double a = L.rb[lane];
+            GQP_DOT_UNROLL
+            for (int r = 0; r < n; r++) a += L.Bw[r * SX + lane] * L.v[r];
+            nacc(nrm_b, a);
+            WAT(D.rb, k * NX + lane) = a;
+            L.rb[lane] = a; /* own slot: nobody else reads rb before the next barrier */
+        }
+        if (mine)
+        {
+            double a = 0.0;
+            GQP_DOT_UNROLL
+            for (int c = 0; c < NX; c++) a += L.Bw[lane * SX + c] * L.pin[c];
+            double hv = 0.0;
+            GQP_DOT_UNROLL
+            for (int c = 0; c <= lane; c++) hv += L.Hp[PK(lane, c)] * L.v[c];
+            GQP_DOT_UNROLL
+            for (int c = lane + 1; c < n; c++) hv += L.Hp[PK(c, lane)] * L.v[c];
+            obj += (0.5 * hv + gj) * vj;
+            gt = a + hv + gj - pik;
+        }
+        if (has)
+        {
+            const double rdl = al ? vj - lbv - ttl : 0.0, rdu = au ? ubv - vj - ttu : 0.0;
+            const double rml = al ? ll * ttl - O.tau_min : 0.0, rmu = au ? lu * ttu - O.tau_min : 0.0;
+            nacc(nrm_d, rdl); nacc(nrm_d, rdu); nacc(nrm_m, rml); nacc(nrm_m, rmu);
+            musum += ll * ttl + lu * ttu;
+            nact += (int) al + (int) au;
+            gt -= ll - lu;
+            const double itl = frcp(ttl), itu = frcp(ttu);
+            gam = ll * itl + lu * itu;
+            gadd = (rml + ll * rdl) * itl - (rmu + lu * rdu) * itu;
+            WAT(D.rd, el) = rdl;
+            WAT(D.rd, eu) = rdu;
+        }
+        if (fixed) gt = 0.0;
+        if (mine) { nacc(nrm_g, gt); WAT(D.rg, k * n + lane) = gt; }
+        L.gam[lane] = gam;
+        __syncthreads(); /* everybody is done with [B A]': the buffer becomes W */
+        GQP_TICK(1);
+#pragma unroll
+        for (int a = 0; a < T8; a++)
+#pragma unroll
+            for (int b = 0; b < T8; b++)
+            {
+                const int r = lr + 8 * a, c = lc + 8 * b;
+                if (b < TX && r < n && c < NX) L.Bw[r * SX + c] = Wt[a][b];
+            }
+        /* ---- tiles of H (only now: the W tiles are dead, the two never share registers) ---- */
+        double Mt[T8][T8];
+#pragma unroll
+        for (int a = 0; a < T8; a++)
+#pragma unroll
+            for (int b = 0; b <= a; b++)
+            {
+                const int r = lr + 8 * a, c = lc + 8 * b;
+                Mt[a][b] = (r < n && c <= r) ? L.Hp[PK(r, c)] : (r == c ? 1.0 : 0.0);
+            }
+        __syncthreads();
+        /* w0 = Lx+' rb + lx+ */
+        if (lane < NX)
+        {
+            double a = L.lx[lane];
+            GQP_DOT_UNROLL
+            for (int q = lane; q < NX; q++) a += L.Lx[q * SX + lane] * L.rb[q];
+            L.w0[lane] = a;
+        }
+        /* ---- M = H + reg + Gamma + W W' in tiles ---- */
+#pragma unroll 2
+        for (int q = 0; q < NX; q++)
+        {
+            double wr[T8], wc[T8];
+#pragma unroll
+            for (int a = 0; a < T8; a++) wr[a] = L.Bw[(lr + 8 * a) * SX + q];
+#pragma unroll
+            for (int b = 0; b < T8; b++) wc[b] = L.Bw[(lc + 8 * b) * SX + q];
+#pragma unroll
+            for (int a = 0; a < T8; a++)
+#pragma unroll
+                for (int b = 0; b <= a; b++) Mt[a][b] += wr[a] * wc[b];
+        }
+#pragma unroll
+        for (int a = 0; a < T8; a++)
+        {
+            const int r = lr + 8 * a;
+            if (lr == lc && r < n) Mt[a][a] += O.reg_prim + L.gam[r];
+        }
+        if (S.emask)
+        {
+#pragma unroll
+            for (int a = 0; a < T8; a++)
+#pragma unroll
+                for (int b = 0; b <= a; b++)
+                {
+                    const int r = lr + 8 * a, c = lc + 8 * b;
+                    if (((S.emask >> r) & 1) || ((S.emask >> c) & 1)) Mt[a][b] = r == c ? 1.0 : 0.0;
+                }
+        }
+        __syncthreads(); /* w0 published */
+        GQP_TICK(2);
+        double m = 0.0;
+        if (mine)
+        {
+            double a = 0.0;
+            GQP_DOT_UNROLL
+            for (int c = 0; c < NX; c++) a += L.Bw[lane * SX + c] * L.w0[c];
+            m = fixed ? 0.0 : gt + gadd + a;
+        }
+
+        /* ---- Cholesky, column by column; rhs entry m of variable `lane` rides along ---- */
+        int pb = 0;
+#pragma unroll
+        for (int jb = 0; jb < T8; jb++)
+        {
+            for (int jj = 0; jj < 8; jj++)
+            {
+                const int j = 8 * jb + jj;
+                if (j >= n) break;
+                double *cb = L.cb + pb * 72;
+                pb ^= 1;
+                if (lc == jj)
+                {
+#pragma unroll
+                    for (int a = jb; a < T8; a++) cb[lr + 8 * a] = Mt[a][jb];
+                }
+                if (lane == j) cb[64] = m;
+                __syncthreads();
+                /* everything this lane needs from the published column in ONE round trip */
+                const double d = cb[j], mj = cb[64], cmine = cb[lane];
+                double rL[T8], cL[T8];
+#pragma unroll
+                for (int a = jb; a < T8; a++) rL[a] = cb[lr + 8 * a];
+#pragma unroll
+                for (int b = jb; b < T8; b++) cL[b] = cb[lc + 8 * b];
+                const bool pos = d > 0.0;
+                const double inv0 = frsqrt(pos ? d : 1.0);
+                const double inv = pos ? inv0 : 0.0;
+                const double lj = mj * inv;
+#pragma unroll
+                for (int a = jb; a < T8; a++) rL[a] *= inv;
+#pragma unroll
+                for (int b = jb; b < T8; b++) cL[b] *= inv;
+                const double lmine = cmine * inv; /* L[lane][j] for the rhs update */
+                /* the column itself */
+                if (lc == jj)
+                {
+#pragma unroll
+                    for (int a = jb; a < T8; a++)
+                    {
+                        const int r = lr + 8 * a;
+                        Mt[a][jb] = r > j ? rL[a] : (r == j ? (pos ? d * inv : 0.0) : Mt[a][jb]);
+                    }
+                }
+                /* trailing update: operands of finished rows / columns are zeroed instead of predicating */
+#pragma unroll
+                for (int a = jb; a < T8; a++) rL[a] = (lr + 8 * a > j) ? rL[a] : 0.0;
+#pragma unroll
+                for (int b = jb; b < T8; b++) cL[b] = (lc + 8 * b > j) ? cL[b] : 0.0;
+#pragma unroll
+                for (int a = jb; a < T8; a++)
+#pragma unroll
+                    for (int b = jb; b <= a; b++) Mt[a][b] -= rL[a] * cL[b];
+                if (lane == j) m = lj;
+                else if (lane > j) m -= lmine * lj;
+            }
+        }
+        __syncthreads(); /* Hp (packed H) is dead: it receives the packed factor */
+        GQP_TICK(3);
+#pragma unroll
+        for (int a = 0; a < T8; a++)
+#pragma unroll
+            for (int b = 0; b < T8; b++)
+            {
+                const int r = lr + 8 * a, c = lc + 8 * b;
+                if (b <= a && r < n && c <= r) L.Hp[PK(r, c)] = Mt[a][b];
+                /* x-block for the next (earlier) stage, explicit zeros above the diagonal */
+                if (r >= NU && r < n && c >= NU && c < n) L.Lx[(r - NU) * SX + c - NU] = (b <= a && c <= r) ? Mt[a][b] : 0.0;
+            }
+        if (mine)
+        {
+            WAT(D.lf, k * n + lane) = m;
+            if (lane >= NU) L.lx[lane - NU] = m;
+        }
+        __syncthreads();
+        for (int p = lane; p < NP; p += 64) WAT(D.Lf, k * NP + p) = L.Hp[p];
+        __syncthreads(); /* Hp is refilled by the next stage */
+        GQP_TICK(4);
+    }
+
+    nrm_g = wpi_max(nrm_g, L.red, lane);
+    nrm_b = wpi_max(nrm_b, L.red, lane);
+    nrm_d = wpi_max(nrm_d, L.red, lane);
+    nrm_m = wpi_max(nrm_m, L.red, lane);
+    musum = wpi_sum(musum, L.red, lane);
+    obj = wpi_sum(obj, L.red, lane);
+    const double nact_d = wpi_sum((double) nact, L.red, lane);
+    if (lane == 0)
+    {
+        const int Bp = D.Bp;
+        const double mu = nact_d > 0.0 ? musum / nact_d : 0.0;
+        D.mu[inst] = mu;
+        D.obj[inst] = obj;
+        D.res[0 * Bp + inst] = nrm_g; D.res[1 * Bp + inst] = nrm_b; D.res[2 * Bp + inst] = nrm_d; D.res[3 * Bp + inst] = nrm_m;
+        const int it = D.iter[inst];
+        if (inst < D.stat_inst && it < D.stat_rows)
+        {
+            double *st = D.stat + (size_t) it * GQP_STAT_COLS * D.stat_inst + inst;
+            st[6 * D.stat_inst] = mu;
+            st[7 * D.stat_inst] = nrm_g; st[8 * D.stat_inst] = nrm_b; st[9 * D.stat_inst] = nrm_d; st[10 * D.stat_inst] = nrm_m;
+            st[12 * D.stat_inst] = obj;
+        }
+        int status = GQP_RUNNING;
+        const bool bad = nrm_g != nrm_g || nrm_b != nrm_b || nrm_d != nrm_d || nrm_m != nrm_m || mu != mu;
+        if (bad) status = 1;
+        else if (nrm_g <= O.tol_stat && nrm_b <= O.tol_eq && nrm_d <= O.tol_ineq && nrm_m <= O.tol_comp) status = 0;
+        else if (it >= O.iter_max) status = 2;
+        else if (dabs(D.alpha[inst]) <= O.alpha_min) status = 3;
+        if (status != GQP_RUNNING)
+        {
+            D.status[inst] = status;
+            atomicSub(D.n_active, 1);
+        }
+    }
+}
+
+/* ------------------------------------------------- rhs-only backward and forward, packed factor */
+
+/*
+ * The corrector's rhs-only backward sweep does NOT need l = L^{-1} m in full.  With L = [Lr 0; Ls Lx],
+ * m = [m_u; m_x]:  l_u = Lr^{-1} m_u  and  p = Lx l_x = m_x - Ls l_u,  and everything downstream uses l_x only
+ * through p (P rb + p = Lx (Lx' rb) + p in the next stage, dpi = Lx (Lx' dx) + p and dv_u = -Lr^{-T}(l_u + Ls' dx)
+ * in the forward sweep).  So the sequential part of a stage is NU substitution steps instead of NU + NX;
+ * the rest is matrix-vector work that the lanes share.  lf then holds [l_u; p] ("p-form"); only stage 0 of
+ * the forward sweep, where the states are free, recovers l_x = Lx^{-1} p.  The factor sweep keeps writing the
+ * plain l (its Cholesky carries the rhs along for free, and the Riccati getters read it).
+ * The factor stays PACKED in LDS (coalesced copy from HBM, index arithmetic instead of a re-layout).
+ */
+struct WpiLds3
+{
+    double *__restrict__ Lp;  /* 2 x NPa: packed factor of this stage / of the stage handled before */
+    double *__restrict__ B;   /* n x SXb: [B A]' */
+    double *__restrict__ rb, *__restrict__ w0, *__restrict__ y, *__restrict__ pn, *__restrict__ dv, *__restrict__ dx, *__restrict__ bc, *__restrict__ red;
+    int NPa, SXb;
+};
+
+__host__ __device__ static inline size_t wpi3_lds_doubles(int NX, int NU)
+{
+    const int n = NX + NU, NPa = n * (n + 1) / 2 + 8, SXb = NX | 1;
+    return 2 * (size_t) NPa + (size_t) n * SXb + 8 * 64 + 8;
+}
+
+__device__ static inline WpiLds3 wpi3_carve(double *sm, int NX, int NU)
+{
+    const int n = NX + NU;
+    WpiLds3 L;
+    L.NPa = n * (n + 1) / 2 + 8;
+    L.SXb = NX | 1;
+    double *p = sm;
+    L.Lp = p; p += 2 * L.NPa;
+    L.B = p; p += n * L.SXb;
+    L.rb = p; p += 64; L.w0 = p; p += 64; L.y = p; p += 64; L.pn = p; p += 64;
+    L.dv = p; p += 64; L.dx = p; p += 64; L.bc = p; p += 64; L.red = p; p += 64;
+    return L;
+}
+
+/* coalesced [B A]' -> LDS rows of odd stride */
+__device__ static inline void wpi_load_B(double *__restrict__ dst, int SXb, const GArr &BAt, int inst, int k, int n, int NX, int lane)
+{
+    int r = lane / NX, c = lane - r * NX;
+    const int dr = 64 / NX, dc = 64 - dr * NX;
+    for (int e = lane; e < n * NX; e += 64)
+    {
+        dst[r * SXb + c] = WAT(BAt, k * n * NX + e);
+        r += dr; c += dc;
+        if (c >= NX) { c -= NX; r++; }
+    }
+}
+
+__global__ void __launch_bounds__(64) kw_backrhs(GqpDev D, GqpOpts O, int redo)
+{
+    GQP_DYN_SHARED(smem);
+    const int NX = D.NX, NU = D.NU, n = NX + NU, NP = n * (n + 1) / 2;
+    const int inst = blockIdx.x, lane = threadIdx.x;
+    if (inst >= D.B) return;
+    if (D.status[inst] != GQP_RUNNING) return;
+    if (redo && !(D.alpha[inst] < 0.0)) return;
+    const WpiLds3 L = wpi3_carve(smem, NX, NU);
+    const int SXb = L.SXb;
+    const double smu = D.smu[inst];
+    const double pscale = redo ? 0.0 : 1.0;
+    const bool mine = lane < n;
+    for (int e = lane; e < 2 * L.NPa; e += 64) L.Lp[e] = 0.0;
+    L.pn[lane] = 0.0;
+    int cur = 0;
+    __syncthreads();
+
+    for (int k = D.N; k >= 0; k--)
+    {
+        const GqpStage &S = D.st[k];
+        const uint64_t imask = S.bmask & ~S.emask;
+        const uint64_t am = WAT(D.amask, k);
+        const int nbg = S.nb;
+        double *__restrict__ Lc = L.Lp + cur * L.NPa;
+        const double *__restrict__ Ln = L.Lp + (cur ^ 1) * L.NPa;
+        const bool fixed = mine && ((S.emask >> lane) & 1);
+
+        for (int p = lane; p < NP; p += 64) Lc[p] = WAT(D.Lf, k * NP + p);
+        wpi_load_B(L.B, SXb, D.BAt, inst, k, n, NX, lane);
+        if (lane < NX) L.rb[lane] = WAT(D.rb, k * NX + lane);
+        double m = mine ? WAT(D.rg, k * n + lane) : 0.0;
+        const bool has = mine && ((imask >> lane) & 1);
+        if (has)
+        {
+            const int ib = popc64(S.bmask & (((uint64_t) 1 << lane) - 1));
+            const bool al = (am >> ib) & 1, au = (am >> (nbg + ib)) & 1;
+            const int el = S.o_ct + ib, eu = el + nbg;
+            const double ll = al ? WAT(D.lam, el) : 0.0, lu = au ? WAT(D.lam, eu) : 0.0;
+            const double ttl = al ? WAT(D.t, el) : 1.0, ttu = au ? WAT(D.t, eu) : 1.0;
+            const double rdl = al ? WAT(D.rd, el) : 0.0, rdu = au ? WAT(D.rd, eu) : 0.0;
+            const double rml = al ? ll * ttl - O.tau_min + pscale * WAT(D.pcorr, el) - smu : 0.0;
+            const double rmu = au ? lu * ttu - O.tau_min + pscale * WAT(D.pcorr, eu) - smu : 0.0;
+            m += (rml + ll * rdl) * frcp(ttl) - (rmu + lu * rdu) * frcp(ttu);
+        }
+        __syncthreads();
+        /* y = Lx+ (Lx+' rb) + p+ with the x-block of the factor handled one stage ago */
+        if (lane < NX)
+        {
+            double a = 0.0;
+            GQP_DOT_UNROLL
+            for (int q = lane; q < NX; q++) a += Ln[PK(NU + q, NU + lane)] * L.rb[q];
+            L.w0[lane] = a;
+        }
+        __syncthreads();
+        if (lane < NX)
+        {
+            double a = L.pn[lane];
+            GQP_DOT_UNROLL
+            for (int c = 0; c <= lane; c++) a += Ln[PK(NU + lane, NU + c)] * L.w0[c];
+            L.y[lane] = a;
+        }
+        __syncthreads();
+        if (mine)
+        {
+            double a = 0.0;
+            GQP_DOT_UNROLL
+            for (int c = 0; c < NX; c++) a += L.B[lane * SXb + c] * L.y[c];
+            m = fixed ? 0.0 : m + a;
+        }
+        /* l_u = Lr^{-1} m_u ; the lanes below keep m_r -= L[r][j] l_j, which leaves p in the state lanes */
+        for (int j = 0; j < NU; j++)
+        {
+            const double lrj = (mine && lane > j) ? Lc[PK(lane, j)] : 0.0;
+            if (lane == j)
+            {
+                const double d = Lc[PK(j, j)];
+                m = d != 0.0 ? m * frcp(d) : 0.0;
+                L.bc[j & 1] = m;
+            }
+            __syncthreads();
+            m -= lrj * L.bc[j & 1];
+        }
+        if (mine)
+        {
+            WAT(D.lf, k * n + lane) = m;
+            if (lane >= NU) L.pn[lane - NU] = m;
+        }
+        cur ^= 1;
+        __syncthreads();
+    }
+}
+
+/* forward sweep; PFORM (= CORR): lf holds [l_u; p], otherwise the plain l of the factor sweep */
+template <bool CORR>
+__global__ void __launch_bounds__(64) kw_fwd(GqpDev D, GqpOpts O, int redo)
+{
+    GQP_DYN_SHARED(smem);
+    constexpr bool PFORM = CORR;
+    const int NX = D.NX, NU = D.NU, n = NX + NU, NP = n * (n + 1) / 2;
+    const int inst = blockIdx.x, lane = threadIdx.x;
+    if (inst >= D.B) return;
+    if (D.status[inst] != GQP_RUNNING) return;
+    if (redo && !(D.alpha[inst] < 0.0)) return;
+    const WpiLds3 L = wpi3_carve(smem, NX, NU);
+    const int SXb = L.SXb;
+    double *__restrict__ Lc = L.Lp;
+    const double smu = CORR ? D.smu[inst] : 0.0;
+    const double pscale = (CORR && !redo) ? 1.0 : 0.0;
+    const bool mine = lane < n;
+    double alpha = 1.0, S0 = 0.0, S1 = 0.0, S2 = 0.0;
+    int nact = 0;
+    L.dx[lane] = 0.0;
+    __syncthreads();
+
+    for (int k = 0; k <= D.N; k++)
+    {
+        const GqpStage &S = D.st[k];
+        const uint64_t imask = S.bmask & ~S.emask;
+        const uint64_t am = WAT(D.amask, k);
+        const int nbg = S.nb;
+
+        for (int p = lane; p < NP; p += 64) Lc[p] = WAT(D.Lf, k * NP + p);
+        wpi_load_B(L.B, SXb, D.BAt, inst, k, n, NX, lane);
+        double lv = mine ? WAT(D.lf, k * n + lane) : 0.0; /* l_u / l_x or p */
+        const double rbv = lane < NX ? WAT(D.rb, k * NX + lane) : 0.0;
+        const bool has = mine && ((imask >> lane) & 1);
+        const int ib = has ? popc64(S.bmask & (((uint64_t) 1 << lane) - 1)) : 0;
+        const bool al = has && ((am >> ib) & 1), au = has && ((am >> (nbg + ib)) & 1);
+        const int el = S.o_ct + ib, eu = el + nbg;
+        const double ll = al ? WAT(D.lam, el) : 0.0, lu = au ? WAT(D.lam, eu) : 0.0;
+        const double ttl = al ? WAT(D.t, el) : 1.0, ttu = au ? WAT(D.t, eu) : 1.0;
+        const double rdl = al ? WAT(D.rd, el) : 0.0, rdu = au ? WAT(D.rd, eu) : 0.0;
+        const double pl = (CORR && al) ? WAT(D.pcorr, el) : 0.0, pu = (CORR && au) ? WAT(D.pcorr, eu) : 0.0;
+        __syncthreads();
+
+        if (PFORM && k == 0)
+        {
+            /* the states of stage 0 are free: recover l_x = Lx^{-1} p */
+            for (int j = NU; j < n; j++)
+            {
+                const double lrj = (mine && lane > j) ? Lc[PK(lane, j)] : 0.0;
+                if (lane == j)
+                {
+                    const double d = Lc[PK(j, j)];
+                    lv = d != 0.0 ? lv * frcp(d) : 0.0;
+                    L.bc[j & 1] = lv;
+                }
+                __syncthreads();
+                lv -= lrj * L.bc[j & 1];
+            }
+        }
+        /* dpi_k = Lx (Lx' dx + l_x)  resp.  Lx (Lx' dx) + p */
+        if (CORR && k > 0)
+        {
+            if (lane < NX)
+            {
+                double a = 0.0;
+                GQP_DOT_UNROLL
+                for (int q = lane; q < NX; q++) a += Lc[PK(NU + q, NU + lane)] * L.dx[q];
+                L.w0[lane] = a;
+            }
+            __syncthreads();
+            if (lane < NX)
+            {
+                double a = 0.0;
+                GQP_DOT_UNROLL
+                for (int c = 0; c <= lane; c++) a += Lc[PK(NU + lane, NU + c)] * L.w0[c];
+                L.y[lane] = a; /* + p of this lane's state, added by its owner below */
+            }
+            __syncthreads();
+            if (mine && lane >= NU) WAT(D.dpi, k * NX + lane - NU) = L.y[lane - NU] + lv;
+        }
+        /* L' dv = -l for the free block: everything at k = 0, the inputs otherwise */
+        const int top = k == 0 ? n : NU;
+        if (mine && lane >= top) L.dv[lane] = L.dx[lane - NU];
+        __syncthreads();
+        double acc = 0.0;
+        if (lane < top)
+        {
+            acc = -lv;
+            GQP_DOT_UNROLL
+            for (int p = top; p < n; p++) acc -= Lc[PK(p, lane)] * L.dv[p];
+        }
+        for (int r = top - 1; r >= 0; r--)
+        {
+            const double lrl = lane < r ? Lc[PK(r, lane)] : 0.0;
+            if (lane == r)
+            {
+                const double d = Lc[PK(r, r)];
+                L.dv[r] = d != 0.0 ? acc * frcp(d) : 0.0;
+            }
+            __syncthreads();
+            acc -= lrl * L.dv[r];
+        }
+        __syncthreads();
+        const double dvj = mine ? L.dv[lane] : 0.0;
+        if (CORR && mine) WAT(D.dux, k * n + lane) = dvj;
+        double dxn = 0.0;
+        if (lane < NX)
+        {
+            dxn = rbv;
+            GQP_DOT_UNROLL
+            for (int r = 0; r < n; r++) dxn += L.B[r * SXb + lane] * L.dv[r];
+        }
+        if (has)
+        {
+            const double rml = al ? ll * ttl - O.tau_min + pscale * pl - smu : 0.0;
+            const double rmu = au ? lu * ttu - O.tau_min + pscale * pu - smu : 0.0;
+            const double dtl = al ? dvj + rdl : 0.0, dtu = au ? -dvj + rdu : 0.0;
+            const double dll = al ? -(rml + ll * dtl) * frcp(ttl) : 0.0;
+            const double dlu = au ? -(rmu + lu * dtu) * frcp(ttu) : 0.0;
+            const double c1 = -ll * frcp(dll), c2 = -lu * frcp(dlu), c3 = -ttl * frcp(dtl), c4 = -ttu * frcp(dtu);
+            alpha = (dll < 0.0 && c1 < alpha) ? c1 : alpha;
+            alpha = (dlu < 0.0 && c2 < alpha) ? c2 : alpha;
+            alpha = (dtl < 0.0 && c3 < alpha) ? c3 : alpha;
+            alpha = (dtu < 0.0 && c4 < alpha) ? c4 : alpha;
+            if (!CORR)
+            {
+                S0 += ll * ttl + lu * ttu;
+                S1 += ll * dtl + ttl * dll + lu * dtu + ttu * dlu;
+                S2 += dll * dtl + dlu * dtu;
+                nact += (int) al + (int) au;
+                WAT(D.pcorr, el) = dll * dtl;
+                WAT(D.pcorr, eu) = dlu * dtu;
+            }
+            else
+            {
+                WAT(D.dlam, el) = dll; WAT(D.dlam, eu) = dlu;
+                WAT(D.dt, el) = dtl; WAT(D.dt, eu) = dtu;
+            }
+        }
+        __syncthreads();
+        if (lane < NX) L.dx[lane] = dxn;
+        __syncthreads();
+    }
+
+    alpha = wpi_min(alpha, L.red, lane);
+    const int it = D.iter[inst];
+    double *st = (inst < D.stat_inst && it + 1 < D.stat_rows) ? D.stat + (size_t) (it + 1) * GQP_STAT_COLS * D.stat_inst + inst : nullptr;
+    if (!CORR)
+    {
+        S0 = wpi_sum(S0, L.red, lane); S1 = wpi_sum(S1, L.red, lane); S2 = wpi_sum(S2, L.red, lane);
+        const double nact_d = wpi_sum((double) nact, L.red, lane);
+        if (lane == 0)
+        {
+            const double mu = D.mu[inst];
+            const double mu_aff = nact_d > 0.0 ? (S0 + alpha * S1 + alpha * alpha * S2) / nact_d : 0.0;
+            double sigma = mu > 0.0 ? mu_aff / mu : 0.0;
+            sigma = sigma * sigma * sigma;
+            D.smu[inst] = sigma * mu;
+            D.alpha[inst] = alpha;
+            if (st) { st[0] = alpha; st[1 * D.stat_inst] = alpha; st[2 * D.stat_inst] = mu_aff; st[3 * D.stat_inst] = sigma; }
+        }
+        return;
+    }
+    const double alpha_aff = dabs(D.alpha[inst]);
+    if (O.cond_pred_corr && !redo && alpha < 0.1 * alpha_aff)
+    {
+        __syncthreads(); /* everybody has read alpha[inst] */
+        if (lane == 0) D.alpha[inst] = -alpha_aff;
+        return;
+    }
+    const double a = D.mu[inst] > 0.0 ? alpha * 0.995 : 1.0;
     for (int e = lane; e < (D.N + 1) * n; e += 64) WAT(D.ux, e) += a * WAT(D.dux, e);
     for (int e = NX + lane; e < (D.N + 1) * NX; e += 64) WAT(D.pi, e) += a * WAT(D.dpi, e);
     for (int k = 0; k <= D.N; k++)
@@ -662,7 +1410,9 @@ __global__ void __launch_bounds__(64) kw_finalize(GqpDev D)
         if ((S.emask >> j) & 1)
         {
             double a = WAT(D.rq, k * n + j);
+            GQP_DOT_UNROLL
             for (int c = 0; c < n; c++) a += WAT(D.RSQ, k * NP + (c <= j ? PK(j, c) : PK(c, j))) * WAT(D.ux, k * n + c);
+            GQP_DOT_UNROLL
             for (int c = 0; c < NX; c++) a += WAT(D.BAt, (k * n + j) * NX + c) * WAT(D.pi, (k + 1) * NX + c);
             if (j >= NU) a -= WAT(D.pi, k * NX + j - NU);
             WAT(D.lam, el) = a > 0.0 ? a : 0.0;
