@@ -212,7 +212,7 @@ void finalize_structure(ocp_qp_gpu_batch *b)
     b->xbox = 0;
     for (int k = 0; k <= N; k++)
         if (((b->st[k].bmask & ~b->st[k].emask) >> NU) != 0) b->xbox = 1;
-    if (b->use_box)
+    if (b->use_box && !b->wpi)
     {
         char nm[160];
         snprintf(nm, sizeof(nm), "1tpi-box<NX=%d,NU=%d,XBOX=%d>", NX, NU, b->xbox);
@@ -220,9 +220,6 @@ void finalize_structure(ocp_qp_gpu_batch *b)
     }
     if (b->wpi)
     {
-        char nm[160];
-        snprintf(nm, sizeof(nm), "wpi-box(nx=%d,nu=%d,lds=%zuB)", NX, NU, b->shmem);
-        b->kname = nm;
         b->use_box = true;
         if (std::max(b->shmem, b->shmem_fact) > 64 * 1024)
         {
@@ -548,31 +545,41 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
     /* wave-per-instance family (ipm_kernels_wpi.hpp): box-constrained QPs whose stage block is too large for
      * the one-instance-per-lane register mapping.  Dimensions are runtime values there: no padding to a
      * compiled shape.  ACADOS_AMD_WPI=0/1 overrides the size rule (tests). */
-    if (!g_force_ks && mg == 0 && ms == 0)
+    if (!g_force_ks)
     {
         const int wx = force_NX ? force_NX : mx, wu = force_NU ? force_NU : mu;
+        const bool gen = mg > 0 || ms > 0;
         const char *env = getenv("ACADOS_AMD_WPI");
+        const char *v1 = getenv("ACADOS_AMD_WPI_V1");
+        const bool ref = v1 && atoi(v1) != 0 && !gen;
         const bool want = env ? atoi(env) != 0 : (wx + wu >= GQP_WPI_MIN_N || !b->ks);
-        if (want && wx + wu <= 64 && wx >= 1)
+        if (want && wx + wu <= 64 && wx >= 1 && mg <= 32 && ms <= 32)
         {
             /* factor sweep: register-tile kernel for the tile count of this shape; rhs-only and forward sweeps on
-             * the packed factor.  ACADOS_AMD_WPI_V1=1 selects the plain LDS-resident reference kernels of the
-             * family instead (kw_backward / kw_forward), kept for cross-checking. */
-            static const kern_redo_t fact_t8[8] = {gqp::kw_factor<1>, gqp::kw_factor<2>, gqp::kw_factor<3>, gqp::kw_factor<4>,
-                                                   gqp::kw_factor<5>, gqp::kw_factor<6>, gqp::kw_factor<7>, gqp::kw_factor<8>};
-            const char *v1 = getenv("ACADOS_AMD_WPI_V1");
-            const bool ref = v1 && atoi(v1) != 0;
-            const kern_redo_t fact = ref ? gqp::kw_backward<true> : fact_t8[(wx + wu + 7) / 8 - 1];
-            const kern_redo_t rhs = ref ? gqp::kw_backward<false> : gqp::kw_backrhs;
-            const kern_redo_t faff = ref ? gqp::kw_forward<false> : gqp::kw_fwd<false>;
-            const kern_redo_t fcor = ref ? gqp::kw_forward<true> : gqp::kw_fwd<true>;
-            b->own_ks = KernelSet{wx, wu, 0, 0, gqp::kw_init, fact, rhs, faff, fcor, gqp::kw_finalize,
-                                  {fact, fact}, {rhs, rhs}, {faff, faff}, {fcor, fcor}, gqp::kw_finalize};
+             * the packed factor; GEN variants carry general constraints and slacks.  ACADOS_AMD_WPI_V1=1 selects
+             * the plain LDS-resident reference kernels of the family (box-constrained QPs only), kept for
+             * cross-checking. */
+            static const kern_redo_t fact_box[8] = {gqp::kw_factor<1, false>, gqp::kw_factor<2, false>, gqp::kw_factor<3, false>,
+                                                    gqp::kw_factor<4, false>, gqp::kw_factor<5, false>, gqp::kw_factor<6, false>,
+                                                    gqp::kw_factor<7, false>, gqp::kw_factor<8, false>};
+            static const kern_redo_t fact_gen[8] = {gqp::kw_factor<1, true>, gqp::kw_factor<2, true>, gqp::kw_factor<3, true>,
+                                                    gqp::kw_factor<4, true>, gqp::kw_factor<5, true>, gqp::kw_factor<6, true>,
+                                                    gqp::kw_factor<7, true>, gqp::kw_factor<8, true>};
+            const int t8 = (wx + wu + 7) / 8 - 1;
+            const kern_redo_t fact = ref ? gqp::kw_backward<true> : gen ? fact_gen[t8] : fact_box[t8];
+            const kern_redo_t rhs = ref ? gqp::kw_backward<false> : gen ? gqp::kw_backrhs<true> : gqp::kw_backrhs<false>;
+            const kern_redo_t faff = ref ? gqp::kw_forward<false> : gen ? gqp::kw_fwd<false, true> : gqp::kw_fwd<false, false>;
+            const kern_redo_t fcor = ref ? gqp::kw_forward<true> : gen ? gqp::kw_fwd<true, true> : gqp::kw_fwd<true, false>;
+            const kern_opts_t init = gen ? gqp::kw_init<true> : gqp::kw_init<false>;
+            const kern_plain_t fin = gen ? gqp::kw_finalize<true> : gqp::kw_finalize<false>;
+            b->own_ks = KernelSet{wx, wu, mg, ms, init, fact, rhs, faff, fcor, fin,
+                                  {fact, fact}, {rhs, rhs}, {faff, faff}, {fcor, fcor}, fin};
             b->ks = &b->own_ks;
             b->wpi = 1;
             b->aos = 1;
-            b->shmem = (ref ? gqp::wpi_lds_doubles(wx, wu) : gqp::wpi3_lds_doubles(wx, wu)) * sizeof(double);
-            b->shmem_fact = (ref ? gqp::wpi_lds_doubles(wx, wu) : gqp::wpi2_lds_doubles(wx, wu)) * sizeof(double);
+            const size_t con = gqp::wpi_con_doubles(wx + wu, mg, ms);
+            b->shmem = (ref ? gqp::wpi_lds_doubles(wx, wu) : gqp::wpi3_lds_doubles(wx, wu) + con) * sizeof(double);
+            b->shmem_fact = (ref ? gqp::wpi_lds_doubles(wx, wu) : gqp::wpi2_lds_doubles(wx, wu) + con) * sizeof(double);
         }
     }
     if (!b->ks)
@@ -582,7 +589,9 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
         return nullptr;
     }
     char nm[128];
-    if (b->wpi) snprintf(nm, sizeof(nm), "wpi-box(nx=%d,nu=%d,lds=%zuB)", b->ks->NX, b->ks->NU, b->shmem);
+    if (b->wpi && (b->ks->NG || b->ks->NS))
+        snprintf(nm, sizeof(nm), "wpi-gen(nx=%d,nu=%d,ng=%d,ns=%d,lds=%zuB)", b->ks->NX, b->ks->NU, b->ks->NG, b->ks->NS, b->shmem_fact);
+    else if (b->wpi) snprintf(nm, sizeof(nm), "wpi-box(nx=%d,nu=%d,lds=%zuB)", b->ks->NX, b->ks->NU, b->shmem);
     else snprintf(nm, sizeof(nm), "1tpi<NX=%d,NU=%d,NG=%d,NS=%d>", b->ks->NX, b->ks->NU, b->ks->NG, b->ks->NS);
     b->kname = nm;
     opts_default(b->O);

@@ -629,6 +629,102 @@ __global__ void __launch_bounds__(64) kw_forward(GqpDev D, GqpOpts O, int redo)
  *     single-wave workgroup; it is what the host simulation of the CPU test tier synchronises on).
  * Same arithmetic as kw_backward<true> (which stays as the plain reference of this family).
  */
+/* ---------------------------------------------------- general constraints and slacks (GEN kernels)
+ * Inequality rows of a stage: box rows (sorted by variable, row = rank of the variable in bmask) and general
+ * rows (row = nb + g), each with a lower and an upper side; slack q couples to the rows with srev[row] == q.
+ * Lane roles per stage: lane j < n owns variable j and its box row, lane g < ng owns general row g, lane
+ * q < ns owns slack q (its two bound rows, its Z/z, its sums over the coupled rows).  What the roles exchange
+ * goes through the small LDS block below.  Algebra as in ipm_kernels.hpp (k_backward / k_forward):
+ *   hard row: M += (Gl+Gu) a a', grad += a (rho_l - rho_u)
+ *   slack q:  D = Z + lam_s/t_s + sum Gamma_row, r~ = stationarity residual of the slack + rho_s + sum rho_row
+ *   soft row i -> q, CANCELLATION-FREE form of the Schur complement of the slack block (an active soft row
+ *   has Gamma_i >> Z, and Gamma_i - Gamma_i^2/D would lose every digit of the Z + Gamma_s it leaves behind):
+ *             E_i = D - Gamma_i and X_i = r~ - rho_i are summed WITHOUT row i;
+ *             M += (Gl El/Dl + Gu Eu/Du) a a',  grad += a ((rho_l El - Gl Xl)/Dl - (rho_u Eu - Gu Xu)/Du),
+ *             dt_l = (El dc - r~l - sum_{k != i} Gl_k dc_k)/Dl + rd_l  in the forward sweep;
+ *   rows sharing one slack add the cross terms  M -= (Gl_i Gl_k/Dl + Gu_i Gu_k/Du) a_i a_k'.
+ * (oracle/ocp_qp_oracle.c stage_condense / expand_step use the same form.) */
+struct WpiCon
+{
+    double *__restrict__ G;   /* NG x SG: general rows [D C] */
+    double *__restrict__ rGl, *__restrict__ rGu, *__restrict__ rRl, *__restrict__ rRu, *__restrict__ rLl, *__restrict__ rLu; /* per row */
+    double *__restrict__ sIl, *__restrict__ sIu, *__restrict__ sRl, *__restrict__ sRu, *__restrict__ dsl, *__restrict__ dsu;   /* per slack */
+    double *__restrict__ sEl, *__restrict__ sEu, *__restrict__ sXl, *__restrict__ sXu; /* per slack: Z + Gamma_s, stationarity + rho_s */
+    double *__restrict__ nuG, *__restrict__ gmG; /* per general row */
+    int SG;
+};
+
+__host__ __device__ static inline size_t wpi_con_doubles(int n, int NG, int NS)
+{
+    if (NG == 0 && NS == 0) return 0;
+    const int SG = n | 1;
+    return (size_t) NG * SG + 18 * 32 + 8;
+}
+
+__device__ static inline WpiCon wpi_con_carve(double *p, int n, int NG, int NS)
+{
+    WpiCon C;
+    C.SG = n | 1;
+    C.G = p; p += NG * C.SG;
+    C.rGl = p; p += 32; C.rGu = p; p += 32; C.rRl = p; p += 32; C.rRu = p; p += 32; C.rLl = p; p += 32; C.rLu = p; p += 32;
+    C.sIl = p; p += 32; C.sIu = p; p += 32; C.sRl = p; p += 32; C.sRu = p; p += 32; C.dsl = p; p += 32; C.dsu = p; p += 32;
+    C.sEl = p; p += 32; C.sEu = p; p += 32; C.sXl = p; p += 32; C.sXu = p; p += 32;
+    C.nuG = p; p += 32; C.gmG = p;
+    return C;
+}
+
+/* coalesced copy of the ng x n general rows of a stage into LDS rows of odd stride */
+__device__ static inline void wpi_load_G(const WpiCon &C, const GArr &DCt, int inst, int o_g, int ng, int n, int lane)
+{
+    int r = lane / n, c = lane - r * n;
+    const int dr = 64 / n, dc = 64 - dr * n;
+    for (int e = lane; e < ng * n; e += 64)
+    {
+        C.G[r * C.SG + c] = WAT(DCt, o_g * n + e);
+        r += dr; c += dc;
+        if (c >= n) { c -= n; r++; }
+    }
+}
+
+/* sums over the rows coupled to slack q, WITHOUT row `row` */
+__device__ static inline void wpi_excl(const GqpStage &S, int nbg, int row, int q, const double *al_, const double *au_, double &sl, double &su)
+{
+    sl = 0.0; su = 0.0;
+    for (int k = 0; k < nbg; k++)
+        if (k != row && S.srev[k] == q) { sl += al_[k]; su += au_[k]; }
+}
+
+/* entry idx of the constraint row `row` (box row: unit vector of its variable; general row: row of G) */
+__device__ static inline double wpi_arow(const WpiCon &C, const GqpStage &S, int row, int idx)
+{
+    if (row >= S.nb) return C.G[(row - S.nb) * C.SG + idx];
+    return popc64(S.bmask & (((uint64_t) 1 << idx) - 1)) == row && ((S.bmask >> idx) & 1) ? 1.0 : 0.0;
+}
+
+/* one side pair of an inequality row as its owner lane sees it */
+struct WpiRow
+{
+    bool al, au;
+    int el, eu, sj;
+    double ll, lu, tl, tu; /* lam (0 if inactive), t (1 if inactive) */
+};
+
+__device__ static inline WpiRow wpi_row(const GqpDev &D, const GqpStage &S, uint64_t am, int inst, int row, bool exists)
+{
+    const int nbg = S.nb + S.ng;
+    WpiRow R;
+    R.al = exists && ((am >> row) & 1);
+    R.au = exists && ((am >> (nbg + row)) & 1);
+    R.el = S.o_ct + (exists ? row : 0);
+    R.eu = R.el + nbg;
+    R.sj = exists ? (int) S.srev[row] : -1;
+    R.ll = R.al ? WAT(D.lam, R.el) : 0.0;
+    R.lu = R.au ? WAT(D.lam, R.eu) : 0.0;
+    R.tl = R.al ? WAT(D.t, R.el) : 1.0;
+    R.tu = R.au ? WAT(D.t, R.eu) : 1.0;
+    return R;
+}
+
 #if defined(GQP_WPI_TIMING)
 /* development aid (not in the default build): cycles per phase of instance 0, lane 0 */
 static __device__ unsigned long long gqp_wpi_cycles[8];
@@ -679,7 +775,7 @@ __device__ static inline WpiLds2 wpi2_carve(double *sm, int NX, int NU)
     return L;
 }
 
-template <int T8>
+template <int T8, bool GEN>
 __global__ void __launch_bounds__(64) kw_factor(GqpDev D, GqpOpts O, int redo)
 {
     GQP_DYN_SHARED(smem);
@@ -688,6 +784,7 @@ __global__ void __launch_bounds__(64) kw_factor(GqpDev D, GqpOpts O, int redo)
     if (inst >= D.B) return;
     if (D.status[inst] != GQP_RUNNING) return;
     const WpiLds2 L = wpi2_carve(smem, NX, NU);
+    const WpiCon C = wpi_con_carve(smem + wpi2_lds_doubles(NX, NU), n, GEN ? D.NG : 0, GEN ? D.NS : 0);
     const int SX = L.SX, TX = (NX + 7) / 8;
     const int lr = lane >> 3, lc = lane & 7;
     const bool mine = lane < n;
@@ -707,7 +804,7 @@ __global__ void __launch_bounds__(64) kw_factor(GqpDev D, GqpOpts O, int redo)
         const GqpStage &S = D.st[k];
         const uint64_t imask = S.bmask & ~S.emask;
         const uint64_t am = WAT(D.amask, k);
-        const int nbg = S.nb;
+        const int nbg = S.nb + (GEN ? S.ng : 0);
         const bool fixed = mine && ((S.emask >> lane) & 1);
 
         /* ---- coalesced loads into LDS ---- */
@@ -737,6 +834,37 @@ __global__ void __launch_bounds__(64) kw_factor(GqpDev D, GqpOpts O, int redo)
         const double ll = al ? WAT(D.lam, el) : 0.0, lu = au ? WAT(D.lam, eu) : 0.0;
         const double ttl = al ? WAT(D.t, el) : 1.0, ttu = au ? WAT(D.t, eu) : 1.0;
         const double lbv = al ? WAT(D.dvec, el) : 0.0, ubv = au ? WAT(D.dvec, eu) : 0.0;
+        /* GEN: soft box row, general row g = lane, slack q = lane */
+        const int bsj = (GEN && has) ? (int) S.srev[ib] : -1;
+        double bssl = 0.0, bssu = 0.0;
+        const bool isg = GEN && lane < S.ng, iss = GEN && lane < S.ns;
+        WpiRow Rg;
+        double gdl = 0.0, gdu = 0.0, gssl = 0.0, gssu = 0.0;
+        bool sal = false, sau = false;
+        int se0 = 0, se1 = 0;
+        double sll = 0.0, slu = 0.0, stl = 1.0, stu = 1.0, sZl = 0.0, szl = 0.0, sZu = 0.0, szu = 0.0, ssl = 0.0, ssu = 0.0, sdl = 0.0, sdu = 0.0;
+        if (GEN)
+        {
+            wpi_load_G(C, D.DCt, inst, S.o_g, S.ng, n, lane);
+            if (bsj >= 0) { bssl = WAT(D.sv, S.o_s + bsj); bssu = WAT(D.sv, S.o_s + S.ns + bsj); }
+            Rg = wpi_row(D, S, am, inst, S.nb + lane, isg);
+            if (isg)
+            {
+                gdl = Rg.al ? WAT(D.dvec, Rg.el) : 0.0; gdu = Rg.au ? WAT(D.dvec, Rg.eu) : 0.0;
+                if (Rg.sj >= 0) { gssl = WAT(D.sv, S.o_s + Rg.sj); gssu = WAT(D.sv, S.o_s + S.ns + Rg.sj); }
+            }
+            if (iss)
+            {
+                se0 = S.o_ct + 2 * nbg + lane; se1 = se0 + S.ns;
+                sal = (am >> (2 * nbg + lane)) & 1; sau = (am >> (2 * nbg + S.ns + lane)) & 1;
+                sll = sal ? WAT(D.lam, se0) : 0.0; slu = sau ? WAT(D.lam, se1) : 0.0;
+                stl = sal ? WAT(D.t, se0) : 1.0; stu = sau ? WAT(D.t, se1) : 1.0;
+                sdl = sal ? WAT(D.dvec, se0) : 0.0; sdu = sau ? WAT(D.dvec, se1) : 0.0;
+                sZl = WAT(D.Zz, (S.o_s + lane) * 2); szl = WAT(D.Zz, (S.o_s + lane) * 2 + 1);
+                sZu = WAT(D.Zz, (S.o_s + S.ns + lane) * 2); szu = WAT(D.Zz, (S.o_s + S.ns + lane) * 2 + 1);
+                ssl = WAT(D.sv, S.o_s + lane); ssu = WAT(D.sv, S.o_s + S.ns + lane);
+            }
+        }
         __syncthreads();
         GQP_TICK(0);
 
@@ -786,19 +914,114 @@ __global__ void __launch_bounds__(64) kw_factor(GqpDev D, GqpOpts O, int redo)
             obj += (0.5 * hv + gj) * vj;
             gt = a + hv + gj - pik;
         }
+        double bGl = 0.0, bGu = 0.0, bRl = 0.0, bRu = 0.0; /* Gamma, rho of this lane's box row */
         if (has)
         {
-            const double rdl = al ? vj - lbv - ttl : 0.0, rdu = au ? ubv - vj - ttu : 0.0;
+            const double rdl = al ? vj + bssl - lbv - ttl : 0.0, rdu = au ? ubv - vj + bssu - ttu : 0.0;
             const double rml = al ? ll * ttl - O.tau_min : 0.0, rmu = au ? lu * ttu - O.tau_min : 0.0;
             nacc(nrm_d, rdl); nacc(nrm_d, rdu); nacc(nrm_m, rml); nacc(nrm_m, rmu);
             musum += ll * ttl + lu * ttu;
             nact += (int) al + (int) au;
             gt -= ll - lu;
             const double itl = frcp(ttl), itu = frcp(ttu);
-            gam = ll * itl + lu * itu;
-            gadd = (rml + ll * rdl) * itl - (rmu + lu * rdu) * itu;
+            bGl = ll * itl; bGu = lu * itu;
+            bRl = (rml + ll * rdl) * itl; bRu = (rmu + lu * rdu) * itu;
+            gam = bGl + bGu;
+            gadd = bRl - bRu; /* hard row; a soft row is completed below */
             WAT(D.rd, el) = rdl;
             WAT(D.rd, eu) = rdu;
+            if (GEN && bsj >= 0) { C.rGl[ib] = bGl; C.rGu[ib] = bGu; C.rRl[ib] = bRl; C.rRu[ib] = bRu; C.rLl[ib] = ll; C.rLu[ib] = lu; }
+        }
+        double gGl = 0.0, gGu = 0.0, gRl = 0.0, gRu = 0.0; /* general row of this lane */
+        double sGl = 0.0, sGu = 0.0, sPl = 0.0, sPu = 0.0; /* slack-bound rows of this lane's slack */
+        if (GEN)
+        {
+            if (isg)
+            {
+                double c = 0.0;
+                GQP_DOT_UNROLL
+                for (int r = 0; r < n; r++) c += C.G[lane * C.SG + r] * L.v[r];
+                const double rdl = Rg.al ? c + gssl - gdl - Rg.tl : 0.0, rdu = Rg.au ? gdu - c + gssu - Rg.tu : 0.0;
+                const double rml = Rg.al ? Rg.ll * Rg.tl - O.tau_min : 0.0, rmu = Rg.au ? Rg.lu * Rg.tu - O.tau_min : 0.0;
+                nacc(nrm_d, rdl); nacc(nrm_d, rdu); nacc(nrm_m, rml); nacc(nrm_m, rmu);
+                musum += Rg.ll * Rg.tl + Rg.lu * Rg.tu;
+                nact += (int) Rg.al + (int) Rg.au;
+                const double itl = frcp(Rg.tl), itu = frcp(Rg.tu);
+                gGl = Rg.ll * itl; gGu = Rg.lu * itu;
+                gRl = (rml + Rg.ll * rdl) * itl; gRu = (rmu + Rg.lu * rdu) * itu;
+                WAT(D.rd, Rg.el) = rdl;
+                WAT(D.rd, Rg.eu) = rdu;
+                const int row = S.nb + lane;
+                C.rGl[row] = gGl; C.rGu[row] = gGu; C.rRl[row] = gRl; C.rRu[row] = gRu; C.rLl[row] = Rg.ll; C.rLu[row] = Rg.lu;
+            }
+            if (iss)
+            {
+                obj += (0.5 * sZl * ssl + szl) * ssl + (0.5 * sZu * ssu + szu) * ssu;
+                const double rdl = sal ? ssl - sdl - stl : 0.0, rdu = sau ? ssu - sdu - stu : 0.0;
+                const double rml = sal ? sll * stl - O.tau_min : 0.0, rmu = sau ? slu * stu - O.tau_min : 0.0;
+                nacc(nrm_d, rdl); nacc(nrm_d, rdu); nacc(nrm_m, rml); nacc(nrm_m, rmu);
+                musum += sll * stl + slu * stu;
+                nact += (int) sal + (int) sau;
+                const double itl = frcp(stl), itu = frcp(stu);
+                sGl = sll * itl; sGu = slu * itu;
+                sPl = (rml + sll * rdl) * itl; sPu = (rmu + slu * rdu) * itu;
+                WAT(D.rd, se0) = rdl;
+                WAT(D.rd, se1) = rdu;
+            }
+            __syncthreads(); /* rows published */
+            if (iss)
+            {
+                /* sums over the rows coupled to this slack */
+                double Dl = sZl + sGl, Du = sZu + sGu, Pl = sPl, Pu = sPu, Rl = sZl * ssl + szl - sll, Ru = sZu * ssu + szu - slu;
+                for (int row = 0; row < nbg; row++)
+                    if (S.srev[row] == lane)
+                    {
+                        Dl += C.rGl[row]; Du += C.rGu[row];
+                        Pl += C.rRl[row]; Pu += C.rRu[row];
+                        Rl -= C.rLl[row]; Ru -= C.rLu[row];
+                    }
+                nacc(nrm_g, Rl); nacc(nrm_g, Ru);
+                WAT(D.rgs, S.o_s + lane) = Rl; WAT(D.rgs, S.o_s + S.ns + lane) = Ru;
+                C.sEl[lane] = sZl + sGl; C.sEu[lane] = sZu + sGu; /* what D leaves behind without the rows */
+                C.sXl[lane] = Rl + sPl; C.sXu[lane] = Ru + sPu;   /* what r~ is without the rows */
+                Rl += Pl; Ru += Pu; /* r~ */
+                WAT(D.sD, S.o_s + lane) = Dl; WAT(D.sD, S.o_s + S.ns + lane) = Du;
+                WAT(D.sR, S.o_s + lane) = Rl; WAT(D.sR, S.o_s + S.ns + lane) = Ru;
+                C.sIl[lane] = Dl != 0.0 ? frcp(Dl) : 0.0; C.sIu[lane] = Du != 0.0 ? frcp(Du) : 0.0;
+            }
+            if (mine)
+            {
+                /* stationarity: general rows */
+                double a = 0.0;
+                for (int g = 0; g < S.ng; g++) a += C.G[g * C.SG + lane] * (C.rLl[S.nb + g] - C.rLu[S.nb + g]);
+                gt -= a;
+            }
+            __syncthreads(); /* slack sums published */
+            if (has && bsj >= 0)
+            {
+                double El, Eu, Xl, Xu;
+                wpi_excl(S, nbg, ib, bsj, C.rGl, C.rGu, El, Eu);
+                wpi_excl(S, nbg, ib, bsj, C.rRl, C.rRu, Xl, Xu);
+                El += C.sEl[bsj]; Eu += C.sEu[bsj]; Xl += C.sXl[bsj]; Xu += C.sXu[bsj];
+                gam = bGl * El * C.sIl[bsj] + bGu * Eu * C.sIu[bsj];
+                gadd = (bRl * El - bGl * Xl) * C.sIl[bsj] - (bRu * Eu - bGu * Xu) * C.sIu[bsj];
+            }
+            if (isg)
+            {
+                double nu = gRl - gRu, gm = gGl + gGu;
+                if (Rg.sj >= 0)
+                {
+                    const int q = Rg.sj;
+                    double El, Eu, Xl, Xu;
+                    wpi_excl(S, nbg, S.nb + lane, q, C.rGl, C.rGu, El, Eu);
+                    wpi_excl(S, nbg, S.nb + lane, q, C.rRl, C.rRu, Xl, Xu);
+                    El += C.sEl[q]; Eu += C.sEu[q]; Xl += C.sXl[q]; Xu += C.sXu[q];
+                    gm = gGl * El * C.sIl[q] + gGu * Eu * C.sIu[q];
+                    nu = (gRl * El - gGl * Xl) * C.sIl[q] - (gRu * Eu - gGu * Xu) * C.sIu[q];
+                }
+                C.nuG[lane] = nu;
+                C.gmG[lane] = gm;
+            }
         }
         if (fixed) gt = 0.0;
         if (mine) { nacc(nrm_g, gt); WAT(D.rg, k * n + lane) = gt; }
@@ -845,6 +1068,44 @@ __global__ void __launch_bounds__(64) kw_factor(GqpDev D, GqpOpts O, int redo)
             for (int a = 0; a < T8; a++)
 #pragma unroll
                 for (int b = 0; b <= a; b++) Mt[a][b] += wr[a] * wc[b];
+        }
+        if (GEN)
+        {
+            if (mine)
+                for (int g = 0; g < S.ng; g++) gadd += C.G[g * C.SG + lane] * C.nuG[g];
+            /* M += sum_g Gamma_eff a a' in tiles */
+            for (int g = 0; g < S.ng; g++)
+            {
+                const double gm = C.gmG[g];
+                double gr[T8], gc[T8];
+#pragma unroll
+                for (int a = 0; a < T8; a++) gr[a] = (lr + 8 * a < n) ? C.G[g * C.SG + lr + 8 * a] * gm : 0.0;
+#pragma unroll
+                for (int b = 0; b < T8; b++) gc[b] = (lc + 8 * b < n) ? C.G[g * C.SG + lc + 8 * b] : 0.0;
+#pragma unroll
+                for (int a = 0; a < T8; a++)
+#pragma unroll
+                    for (int b = 0; b <= a; b++) Mt[a][b] += gr[a] * gc[b];
+            }
+            /* rows sharing a slack: cross terms (rare; plain loops) */
+            for (int i = 0; i < nbg; i++)
+            {
+                const int q = S.srev[i];
+                if (q < 0) continue;
+                for (int kk = 0; kk < nbg; kk++)
+                {
+                    if (kk == i || S.srev[kk] != q) continue;
+                    const double cf = C.rGl[i] * C.rGl[kk] * C.sIl[q] + C.rGu[i] * C.rGu[kk] * C.sIu[q];
+#pragma unroll
+                    for (int a = 0; a < T8; a++)
+#pragma unroll
+                        for (int b = 0; b <= a; b++)
+                        {
+                            const int r = lr + 8 * a, c = lc + 8 * b;
+                            if (r < n && c < n) Mt[a][b] -= cf * wpi_arow(C, S, i, r) * wpi_arow(C, S, kk, c);
+                        }
+                }
+            }
         }
 #pragma unroll
         for (int a = 0; a < T8; a++)
@@ -1043,6 +1304,7 @@ __device__ static inline void wpi_load_B(double *__restrict__ dst, int SXb, cons
     }
 }
 
+template <bool GEN>
 __global__ void __launch_bounds__(64) kw_backrhs(GqpDev D, GqpOpts O, int redo)
 {
     GQP_DYN_SHARED(smem);
@@ -1052,6 +1314,7 @@ __global__ void __launch_bounds__(64) kw_backrhs(GqpDev D, GqpOpts O, int redo)
     if (D.status[inst] != GQP_RUNNING) return;
     if (redo && !(D.alpha[inst] < 0.0)) return;
     const WpiLds3 L = wpi3_carve(smem, NX, NU);
+    const WpiCon C = wpi_con_carve(smem + wpi3_lds_doubles(NX, NU), n, GEN ? D.NG : 0, GEN ? D.NS : 0);
     const int SXb = L.SXb;
     const double smu = D.smu[inst];
     const double pscale = redo ? 0.0 : 1.0;
@@ -1066,7 +1329,7 @@ __global__ void __launch_bounds__(64) kw_backrhs(GqpDev D, GqpOpts O, int redo)
         const GqpStage &S = D.st[k];
         const uint64_t imask = S.bmask & ~S.emask;
         const uint64_t am = WAT(D.amask, k);
-        const int nbg = S.nb;
+        const int nbg = S.nb + (GEN ? S.ng : 0);
         double *__restrict__ Lc = L.Lp + cur * L.NPa;
         const double *__restrict__ Ln = L.Lp + (cur ^ 1) * L.NPa;
         const bool fixed = mine && ((S.emask >> lane) & 1);
@@ -1076,17 +1339,90 @@ __global__ void __launch_bounds__(64) kw_backrhs(GqpDev D, GqpOpts O, int redo)
         if (lane < NX) L.rb[lane] = WAT(D.rb, k * NX + lane);
         double m = mine ? WAT(D.rg, k * n + lane) : 0.0;
         const bool has = mine && ((imask >> lane) & 1);
+        const int ib = has ? popc64(S.bmask & (((uint64_t) 1 << lane) - 1)) : 0;
+        const int bsj = (GEN && has) ? (int) S.srev[ib] : -1;
+        double bGl = 0.0, bGu = 0.0, bRl = 0.0, bRu = 0.0;
         if (has)
         {
-            const int ib = popc64(S.bmask & (((uint64_t) 1 << lane) - 1));
-            const bool al = (am >> ib) & 1, au = (am >> (nbg + ib)) & 1;
-            const int el = S.o_ct + ib, eu = el + nbg;
-            const double ll = al ? WAT(D.lam, el) : 0.0, lu = au ? WAT(D.lam, eu) : 0.0;
-            const double ttl = al ? WAT(D.t, el) : 1.0, ttu = au ? WAT(D.t, eu) : 1.0;
-            const double rdl = al ? WAT(D.rd, el) : 0.0, rdu = au ? WAT(D.rd, eu) : 0.0;
-            const double rml = al ? ll * ttl - O.tau_min + pscale * WAT(D.pcorr, el) - smu : 0.0;
-            const double rmu = au ? lu * ttu - O.tau_min + pscale * WAT(D.pcorr, eu) - smu : 0.0;
-            m += (rml + ll * rdl) * frcp(ttl) - (rmu + lu * rdu) * frcp(ttu);
+            const WpiRow R = wpi_row(D, S, am, inst, ib, true);
+            const double rdl = R.al ? WAT(D.rd, R.el) : 0.0, rdu = R.au ? WAT(D.rd, R.eu) : 0.0;
+            const double rml = R.al ? R.ll * R.tl - O.tau_min + pscale * WAT(D.pcorr, R.el) - smu : 0.0;
+            const double rmu = R.au ? R.lu * R.tu - O.tau_min + pscale * WAT(D.pcorr, R.eu) - smu : 0.0;
+            const double itl = frcp(R.tl), itu = frcp(R.tu);
+            bGl = R.ll * itl; bGu = R.lu * itu;
+            bRl = (rml + R.ll * rdl) * itl; bRu = (rmu + R.lu * rdu) * itu;
+            if (bsj < 0) m += bRl - bRu;
+            else { C.rRl[ib] = bRl; C.rRu[ib] = bRu; C.rGl[ib] = bGl; C.rGu[ib] = bGu; }
+        }
+        if (GEN)
+        {
+            wpi_load_G(C, D.DCt, inst, S.o_g, S.ng, n, lane);
+            const bool isg = lane < S.ng, iss = lane < S.ns;
+            double gGl = 0.0, gGu = 0.0, gRl = 0.0, gRu = 0.0;
+            int gsj = -1;
+            if (isg)
+            {
+                const WpiRow R = wpi_row(D, S, am, inst, S.nb + lane, true);
+                const double rdl = R.al ? WAT(D.rd, R.el) : 0.0, rdu = R.au ? WAT(D.rd, R.eu) : 0.0;
+                const double rml = R.al ? R.ll * R.tl - O.tau_min + pscale * WAT(D.pcorr, R.el) - smu : 0.0;
+                const double rmu = R.au ? R.lu * R.tu - O.tau_min + pscale * WAT(D.pcorr, R.eu) - smu : 0.0;
+                const double itl = frcp(R.tl), itu = frcp(R.tu);
+                gGl = R.ll * itl; gGu = R.lu * itu;
+                gRl = (rml + R.ll * rdl) * itl; gRu = (rmu + R.lu * rdu) * itu;
+                gsj = R.sj;
+                C.rRl[S.nb + lane] = gRl; C.rRu[S.nb + lane] = gRu; C.rGl[S.nb + lane] = gGl; C.rGu[S.nb + lane] = gGu;
+            }
+            double sPl = 0.0, sPu = 0.0, sGl = 0.0, sGu = 0.0;
+            if (iss)
+            {
+                const int e0 = S.o_ct + 2 * nbg + lane, e1 = e0 + S.ns;
+                const bool al = (am >> (2 * nbg + lane)) & 1, au = (am >> (2 * nbg + S.ns + lane)) & 1;
+                const double ll = al ? WAT(D.lam, e0) : 0.0, lu = au ? WAT(D.lam, e1) : 0.0;
+                const double tl = al ? WAT(D.t, e0) : 1.0, tu = au ? WAT(D.t, e1) : 1.0;
+                const double rdl = al ? WAT(D.rd, e0) : 0.0, rdu = au ? WAT(D.rd, e1) : 0.0;
+                const double rml = al ? ll * tl - O.tau_min + pscale * WAT(D.pcorr, e0) - smu : 0.0;
+                const double rmu = au ? lu * tu - O.tau_min + pscale * WAT(D.pcorr, e1) - smu : 0.0;
+                sPl = (rml + ll * rdl) * frcp(tl); sPu = (rmu + lu * rdu) * frcp(tu);
+                sGl = ll * frcp(tl); sGu = lu * frcp(tu);
+            }
+            __syncthreads(); /* rho of the soft rows published */
+            if (iss)
+            {
+                double Rl = WAT(D.rgs, S.o_s + lane) + sPl, Ru = WAT(D.rgs, S.o_s + S.ns + lane) + sPu;
+                C.sXl[lane] = Rl; C.sXu[lane] = Ru; /* r~ without the rows */
+                C.sEl[lane] = WAT(D.Zz, (S.o_s + lane) * 2) + sGl; C.sEu[lane] = WAT(D.Zz, (S.o_s + S.ns + lane) * 2) + sGu;
+                for (int row = 0; row < nbg; row++)
+                    if (S.srev[row] == lane) { Rl += C.rRl[row]; Ru += C.rRu[row]; }
+                WAT(D.sR, S.o_s + lane) = Rl; WAT(D.sR, S.o_s + S.ns + lane) = Ru;
+                const double Dl = WAT(D.sD, S.o_s + lane), Du = WAT(D.sD, S.o_s + S.ns + lane);
+                C.sIl[lane] = Dl != 0.0 ? frcp(Dl) : 0.0;
+                C.sIu[lane] = Du != 0.0 ? frcp(Du) : 0.0;
+            }
+            __syncthreads();
+            if (has && bsj >= 0)
+            {
+                double El, Eu, Xl, Xu;
+                wpi_excl(S, nbg, ib, bsj, C.rGl, C.rGu, El, Eu);
+                wpi_excl(S, nbg, ib, bsj, C.rRl, C.rRu, Xl, Xu);
+                El += C.sEl[bsj]; Eu += C.sEu[bsj]; Xl += C.sXl[bsj]; Xu += C.sXu[bsj];
+                m += (bRl * El - bGl * Xl) * C.sIl[bsj] - (bRu * Eu - bGu * Xu) * C.sIu[bsj];
+            }
+            if (isg)
+            {
+                double nu = gRl - gRu;
+                if (gsj >= 0)
+                {
+                    double El, Eu, Xl, Xu;
+                    wpi_excl(S, nbg, S.nb + lane, gsj, C.rGl, C.rGu, El, Eu);
+                    wpi_excl(S, nbg, S.nb + lane, gsj, C.rRl, C.rRu, Xl, Xu);
+                    El += C.sEl[gsj]; Eu += C.sEu[gsj]; Xl += C.sXl[gsj]; Xu += C.sXu[gsj];
+                    nu = (gRl * El - gGl * Xl) * C.sIl[gsj] - (gRu * Eu - gGu * Xu) * C.sIu[gsj];
+                }
+                C.nuG[lane] = nu;
+            }
+            __syncthreads();
+            if (mine)
+                for (int g = 0; g < S.ng; g++) m += C.G[g * C.SG + lane] * C.nuG[g];
         }
         __syncthreads();
         /* y = Lx+ (Lx+' rb) + p+ with the x-block of the factor handled one stage ago */
@@ -1137,7 +1473,7 @@ __global__ void __launch_bounds__(64) kw_backrhs(GqpDev D, GqpOpts O, int redo)
 }
 
 /* forward sweep; PFORM (= CORR): lf holds [l_u; p], otherwise the plain l of the factor sweep */
-template <bool CORR>
+template <bool CORR, bool GEN>
 __global__ void __launch_bounds__(64) kw_fwd(GqpDev D, GqpOpts O, int redo)
 {
     GQP_DYN_SHARED(smem);
@@ -1148,6 +1484,7 @@ __global__ void __launch_bounds__(64) kw_fwd(GqpDev D, GqpOpts O, int redo)
     if (D.status[inst] != GQP_RUNNING) return;
     if (redo && !(D.alpha[inst] < 0.0)) return;
     const WpiLds3 L = wpi3_carve(smem, NX, NU);
+    const WpiCon C = wpi_con_carve(smem + wpi3_lds_doubles(NX, NU), n, GEN ? D.NG : 0, GEN ? D.NS : 0);
     const int SXb = L.SXb;
     double *__restrict__ Lc = L.Lp;
     const double smu = CORR ? D.smu[inst] : 0.0;
@@ -1163,9 +1500,10 @@ __global__ void __launch_bounds__(64) kw_fwd(GqpDev D, GqpOpts O, int redo)
         const GqpStage &S = D.st[k];
         const uint64_t imask = S.bmask & ~S.emask;
         const uint64_t am = WAT(D.amask, k);
-        const int nbg = S.nb;
+        const int nbg = S.nb + (GEN ? S.ng : 0);
 
         for (int p = lane; p < NP; p += 64) Lc[p] = WAT(D.Lf, k * NP + p);
+        if (GEN) wpi_load_G(C, D.DCt, inst, S.o_g, S.ng, n, lane);
         wpi_load_B(L.B, SXb, D.BAt, inst, k, n, NX, lane);
         double lv = mine ? WAT(D.lf, k * n + lane) : 0.0; /* l_u / l_x or p */
         const double rbv = lane < NX ? WAT(D.rb, k * NX + lane) : 0.0;
@@ -1248,11 +1586,135 @@ __global__ void __launch_bounds__(64) kw_fwd(GqpDev D, GqpOpts O, int redo)
             GQP_DOT_UNROLL
             for (int r = 0; r < n; r++) dxn += L.B[r * SXb + lane] * L.dv[r];
         }
+        /* ---- inequality rows: dc -> slack steps -> dt, dlam, ratio test ---- */
+        double bdsl = 0.0, bdsu = 0.0; /* soft box row of this lane: dc + ds resp. -dc + ds, cancellation-free */
+        bool bsoft = false;
+        if (GEN)
+        {
+            const bool isg = lane < S.ng, iss = lane < S.ns;
+            const int bsj = has ? (int) S.srev[ib] : -1;
+            WpiRow Rg = wpi_row(D, S, am, inst, S.nb + lane, isg);
+            double gdc = 0.0;
+            if (isg)
+            {
+                GQP_DOT_UNROLL
+                for (int r = 0; r < n; r++) gdc += C.G[lane * C.SG + r] * L.dv[r];
+                if (Rg.sj >= 0)
+                {
+                    const double gl_ = Rg.ll * frcp(Rg.tl), gu_ = Rg.lu * frcp(Rg.tu);
+                    C.rGl[S.nb + lane] = gl_; C.rGu[S.nb + lane] = gu_;
+                    C.rRl[S.nb + lane] = gl_ * gdc; C.rRu[S.nb + lane] = gu_ * gdc;
+                }
+            }
+            if (bsj >= 0)
+            {
+                const double gl_ = ll * frcp(ttl), gu_ = lu * frcp(ttu);
+                C.rGl[ib] = gl_; C.rGu[ib] = gu_;
+                C.rRl[ib] = gl_ * dvj; C.rRu[ib] = gu_ * dvj;
+            }
+            __syncthreads(); /* Gamma dc of the soft rows published */
+            if (iss)
+            {
+                double accl = 0.0, accu = 0.0;
+                for (int row = 0; row < nbg; row++)
+                    if (S.srev[row] == lane) { accl += C.rRl[row]; accu += C.rRu[row]; }
+                const double Dl = WAT(D.sD, S.o_s + lane), Du = WAT(D.sD, S.o_s + S.ns + lane);
+                const double il = Dl != 0.0 ? frcp(Dl) : 0.0, iu = Du != 0.0 ? frcp(Du) : 0.0;
+                const double rsl = WAT(D.sR, S.o_s + lane), rsu = WAT(D.sR, S.o_s + S.ns + lane);
+                const double dsl = (-rsl - accl) * il, dsu = (-rsu + accu) * iu;
+                C.sIl[lane] = il; C.sIu[lane] = iu; C.sRl[lane] = rsl; C.sRu[lane] = rsu;
+                if (CORR) { WAT(D.dsv, S.o_s + lane) = dsl; WAT(D.dsv, S.o_s + S.ns + lane) = dsu; }
+                /* the two bound rows of the slack */
+                const int e0 = S.o_ct + 2 * nbg + lane, e1 = e0 + S.ns;
+                const bool sal = (am >> (2 * nbg + lane)) & 1, sau = (am >> (2 * nbg + S.ns + lane)) & 1;
+                const double sll = sal ? WAT(D.lam, e0) : 0.0, slu = sau ? WAT(D.lam, e1) : 0.0;
+                const double stl = sal ? WAT(D.t, e0) : 1.0, stu = sau ? WAT(D.t, e1) : 1.0;
+                C.sEl[lane] = WAT(D.Zz, (S.o_s + lane) * 2) + sll * frcp(stl);
+                C.sEu[lane] = WAT(D.Zz, (S.o_s + S.ns + lane) * 2) + slu * frcp(stu);
+                const double spl = (CORR && sal) ? WAT(D.pcorr, e0) : 0.0, spu = (CORR && sau) ? WAT(D.pcorr, e1) : 0.0;
+                const double rml = sal ? sll * stl - O.tau_min + pscale * spl - smu : 0.0;
+                const double rmu = sau ? slu * stu - O.tau_min + pscale * spu - smu : 0.0;
+                const double dtl = sal ? dsl + WAT(D.rd, e0) : 0.0, dtu = sau ? dsu + WAT(D.rd, e1) : 0.0;
+                const double dll = sal ? -(rml + sll * dtl) * frcp(stl) : 0.0;
+                const double dlu = sau ? -(rmu + slu * dtu) * frcp(stu) : 0.0;
+                const double c1 = -sll * frcp(dll), c2 = -slu * frcp(dlu), c3 = -stl * frcp(dtl), c4 = -stu * frcp(dtu);
+                alpha = (dll < 0.0 && c1 < alpha) ? c1 : alpha;
+                alpha = (dlu < 0.0 && c2 < alpha) ? c2 : alpha;
+                alpha = (dtl < 0.0 && c3 < alpha) ? c3 : alpha;
+                alpha = (dtu < 0.0 && c4 < alpha) ? c4 : alpha;
+                if (!CORR)
+                {
+                    S0 += sll * stl + slu * stu;
+                    S1 += sll * dtl + stl * dll + slu * dtu + stu * dlu;
+                    S2 += dll * dtl + dlu * dtu;
+                    nact += (int) sal + (int) sau;
+                    WAT(D.pcorr, e0) = dll * dtl;
+                    WAT(D.pcorr, e1) = dlu * dtu;
+                }
+                else
+                {
+                    WAT(D.dlam, e0) = dll; WAT(D.dlam, e1) = dlu;
+                    WAT(D.dt, e0) = dtl; WAT(D.dt, e1) = dtu;
+                }
+            }
+            __syncthreads(); /* slack steps published */
+            if (bsj >= 0)
+            {
+                /* dc + ds = (E dc - r~ - sum_{k != i} Gamma_k dc_k)/D */
+                double El, Eu, al_, au_;
+                wpi_excl(S, nbg, ib, bsj, C.rGl, C.rGu, El, Eu);
+                wpi_excl(S, nbg, ib, bsj, C.rRl, C.rRu, al_, au_);
+                El += C.sEl[bsj]; Eu += C.sEu[bsj];
+                bsoft = true;
+                bdsl = (El * dvj - C.sRl[bsj] - al_) * C.sIl[bsj];
+                bdsu = (-Eu * dvj - C.sRu[bsj] + au_) * C.sIu[bsj];
+            }
+            if (isg)
+            {
+                double gsl_ = gdc, gsu_ = -gdc; /* dc + ds resp. -dc + ds */
+                if (Rg.sj >= 0)
+                {
+                    const int q = Rg.sj;
+                    double El, Eu, al_, au_;
+                    wpi_excl(S, nbg, S.nb + lane, q, C.rGl, C.rGu, El, Eu);
+                    wpi_excl(S, nbg, S.nb + lane, q, C.rRl, C.rRu, al_, au_);
+                    El += C.sEl[q]; Eu += C.sEu[q];
+                    gsl_ = (El * gdc - C.sRl[q] - al_) * C.sIl[q];
+                    gsu_ = (-Eu * gdc - C.sRu[q] + au_) * C.sIu[q];
+                }
+                const double grdl = Rg.al ? WAT(D.rd, Rg.el) : 0.0, grdu = Rg.au ? WAT(D.rd, Rg.eu) : 0.0;
+                const double gpl = (CORR && Rg.al) ? WAT(D.pcorr, Rg.el) : 0.0, gpu = (CORR && Rg.au) ? WAT(D.pcorr, Rg.eu) : 0.0;
+                const double rml = Rg.al ? Rg.ll * Rg.tl - O.tau_min + pscale * gpl - smu : 0.0;
+                const double rmu = Rg.au ? Rg.lu * Rg.tu - O.tau_min + pscale * gpu - smu : 0.0;
+                const double dtl = Rg.al ? gsl_ + grdl : 0.0, dtu = Rg.au ? gsu_ + grdu : 0.0;
+                const double dll = Rg.al ? -(rml + Rg.ll * dtl) * frcp(Rg.tl) : 0.0;
+                const double dlu = Rg.au ? -(rmu + Rg.lu * dtu) * frcp(Rg.tu) : 0.0;
+                const double c1 = -Rg.ll * frcp(dll), c2 = -Rg.lu * frcp(dlu), c3 = -Rg.tl * frcp(dtl), c4 = -Rg.tu * frcp(dtu);
+                alpha = (dll < 0.0 && c1 < alpha) ? c1 : alpha;
+                alpha = (dlu < 0.0 && c2 < alpha) ? c2 : alpha;
+                alpha = (dtl < 0.0 && c3 < alpha) ? c3 : alpha;
+                alpha = (dtu < 0.0 && c4 < alpha) ? c4 : alpha;
+                if (!CORR)
+                {
+                    S0 += Rg.ll * Rg.tl + Rg.lu * Rg.tu;
+                    S1 += Rg.ll * dtl + Rg.tl * dll + Rg.lu * dtu + Rg.tu * dlu;
+                    S2 += dll * dtl + dlu * dtu;
+                    nact += (int) Rg.al + (int) Rg.au;
+                    WAT(D.pcorr, Rg.el) = dll * dtl;
+                    WAT(D.pcorr, Rg.eu) = dlu * dtu;
+                }
+                else
+                {
+                    WAT(D.dlam, Rg.el) = dll; WAT(D.dlam, Rg.eu) = dlu;
+                    WAT(D.dt, Rg.el) = dtl; WAT(D.dt, Rg.eu) = dtu;
+                }
+            }
+        }
         if (has)
         {
             const double rml = al ? ll * ttl - O.tau_min + pscale * pl - smu : 0.0;
             const double rmu = au ? lu * ttu - O.tau_min + pscale * pu - smu : 0.0;
-            const double dtl = al ? dvj + rdl : 0.0, dtu = au ? -dvj + rdu : 0.0;
+            const double dtl = al ? (bsoft ? bdsl : dvj) + rdl : 0.0, dtu = au ? (bsoft ? bdsu : -dvj) + rdu : 0.0;
             const double dll = al ? -(rml + ll * dtl) * frcp(ttl) : 0.0;
             const double dlu = au ? -(rmu + lu * dtu) * frcp(ttu) : 0.0;
             const double c1 = -ll * frcp(dll), c2 = -lu * frcp(dlu), c3 = -ttl * frcp(dtl), c4 = -ttu * frcp(dtu);
@@ -1309,24 +1771,24 @@ __global__ void __launch_bounds__(64) kw_fwd(GqpDev D, GqpOpts O, int redo)
     const double a = D.mu[inst] > 0.0 ? alpha * 0.995 : 1.0;
     for (int e = lane; e < (D.N + 1) * n; e += 64) WAT(D.ux, e) += a * WAT(D.dux, e);
     for (int e = NX + lane; e < (D.N + 1) * NX; e += 64) WAT(D.pi, e) += a * WAT(D.dpi, e);
+    if (GEN)
+    {
+        const GqpStage &SN = D.st[D.N];
+        for (int e = lane; e < SN.o_s + 2 * SN.ns; e += 64) WAT(D.sv, e) += a * WAT(D.dsv, e);
+    }
     for (int k = 0; k <= D.N; k++)
     {
+        /* one lane per inequality side of the stage (at most 64) */
         const GqpStage &S = D.st[k];
-        const uint64_t imask = S.bmask & ~S.emask;
         const uint64_t am = WAT(D.amask, k);
-        const int nbg = S.nb;
-        if (lane < n && ((imask >> lane) & 1))
+        const int nct = 2 * (S.nb + S.ng) + 2 * S.ns;
+        if (lane < nct && ((am >> lane) & 1))
         {
-            const int ib = popc64(S.bmask & (((uint64_t) 1 << lane) - 1));
-            for (int side = 0; side < 2; side++)
-            {
-                const int e = S.o_ct + side * nbg + ib;
-                if (!((am >> (side * nbg + ib)) & 1)) continue;
-                const double lam = WAT(D.lam, e) + a * WAT(D.dlam, e);
-                const double t = WAT(D.t, e) + a * WAT(D.dt, e);
-                WAT(D.lam, e) = lam < O.lam_min ? O.lam_min : lam;
-                WAT(D.t, e) = t < O.t_min ? O.t_min : t;
-            }
+            const int e = S.o_ct + lane;
+            const double lam = WAT(D.lam, e) + a * WAT(D.dlam, e);
+            const double t = WAT(D.t, e) + a * WAT(D.dt, e);
+            WAT(D.lam, e) = lam < O.lam_min ? O.lam_min : lam;
+            WAT(D.t, e) = t < O.t_min ? O.t_min : t;
         }
     }
     __syncthreads();
@@ -1340,28 +1802,35 @@ __global__ void __launch_bounds__(64) kw_fwd(GqpDev D, GqpOpts O, int redo)
 
 /* ------------------------------------------------------------------------ init / finalize */
 
-/* cold start, same rules as k_init (ipm_kernels.hpp) for box rows; lane = variable */
+/* cold start, same rules as k_init (ipm_kernels.hpp); lane = variable / general row / slack */
+template <bool GEN>
 __global__ void __launch_bounds__(64) kw_init(GqpDev D, GqpOpts O)
 {
+    GQP_DYN_SHARED(smem);
     const int NX = D.NX, NU = D.NU, n = NX + NU;
     const int inst = blockIdx.x, lane = threadIdx.x;
     if (inst >= D.B) return;
     const double thr0 = 1e-1;
+    double *vv = smem, *cv = smem + 64, *ssl = smem + 128, *ssu = smem + 160; /* v, row values, slack values */
     for (int k = 0; k <= D.N; k++)
     {
         const GqpStage &S = D.st[k];
-        const int nbg = S.nb;
+        const int nbg = S.nb + (GEN ? S.ng : 0);
         const uint64_t am = WAT(D.amask, k);
-        if (lane < n)
+        const bool mine = lane < n, hasb = mine && ((S.bmask >> lane) & 1);
+        const bool fixed = mine && ((S.emask >> lane) & 1);
+        const int ib = hasb ? popc64(S.bmask & (((uint64_t) 1 << lane) - 1)) : 0;
+        const int bsj = (GEN && hasb) ? (int) S.srev[ib] : -1;
+        double v = 0.0, lb = 0.0, ub = 0.0;
+        bool al = false, au = false;
+        if (mine)
         {
-            const bool fixed = (S.emask >> lane) & 1;
-            double v = fixed ? WAT(D.ux, k * n + lane) : 0.0;
-            if ((S.bmask >> lane) & 1)
+            v = fixed ? WAT(D.ux, k * n + lane) : 0.0;
+            if (hasb)
             {
-                const int ib = popc64(S.bmask & (((uint64_t) 1 << lane) - 1));
-                const double lb = WAT(D.dvec, S.o_ct + ib), ub = WAT(D.dvec, S.o_ct + nbg + ib);
-                const bool al = (am >> ib) & 1, au = (am >> (nbg + ib)) & 1;
-                if (!fixed)
+                lb = WAT(D.dvec, S.o_ct + ib); ub = WAT(D.dvec, S.o_ct + nbg + ib);
+                al = (am >> ib) & 1; au = (am >> (nbg + ib)) & 1;
+                if (!fixed && bsj < 0)
                 {
                     const double tl = v - lb, tu = ub - v;
                     if (al && au)
@@ -1372,17 +1841,72 @@ __global__ void __launch_bounds__(64) kw_init(GqpDev D, GqpOpts O)
                     else if (al) { if (tl < thr0) v = lb + thr0; }
                     else if (au) { if (tu < thr0) v = ub - thr0; }
                 }
-                double tl = v - lb, tu = ub - v;
-                if (tl < thr0) tl = thr0;
-                if (tu < thr0) tu = thr0;
-                WAT(D.t, S.o_ct + ib) = al ? tl : 0.0;
-                WAT(D.t, S.o_ct + nbg + ib) = au ? tu : 0.0;
-                WAT(D.lam, S.o_ct + ib) = al ? O.mu0 / tl : 0.0;
-                WAT(D.lam, S.o_ct + nbg + ib) = au ? O.mu0 / tu : 0.0;
             }
             WAT(D.ux, k * n + lane) = v;
         }
         if (S.has_dyn && lane < NX) WAT(D.pi, (k + 1) * NX + lane) = 0.0;
+        double sl = 0.0, su = 0.0; /* slack values seen by this lane's box row */
+        if (GEN)
+        {
+            vv[lane] = v;
+            __syncthreads();
+            /* row values: box rows by their owner, general rows by lane g */
+            const bool isg = lane < S.ng, iss = lane < S.ns;
+            double gc = 0.0;
+            if (isg)
+            {
+                for (int r = 0; r < n; r++) gc += WAT(D.DCt, (S.o_g + lane) * n + r) * vv[r];
+                cv[S.nb + lane] = gc;
+            }
+            if (hasb) cv[ib] = v;
+            __syncthreads();
+            if (iss)
+            {
+                double a = 0.0, c = 0.0;
+                if ((am >> (2 * nbg + lane)) & 1) a = WAT(D.dvec, S.o_ct + 2 * nbg + lane) + thr0;
+                if ((am >> (2 * nbg + S.ns + lane)) & 1) c = WAT(D.dvec, S.o_ct + 2 * nbg + S.ns + lane) + thr0;
+                for (int row = 0; row < nbg; row++)
+                    if (S.srev[row] == lane)
+                    {
+                        const double need_l = WAT(D.dvec, S.o_ct + row) - cv[row] + thr0, need_u = cv[row] - WAT(D.dvec, S.o_ct + nbg + row) + thr0;
+                        if (((am >> row) & 1) && need_l > a) a = need_l;
+                        if (((am >> (nbg + row)) & 1) && need_u > c) c = need_u;
+                    }
+                WAT(D.sv, S.o_s + lane) = a; WAT(D.sv, S.o_s + S.ns + lane) = c;
+                ssl[lane] = a; ssu[lane] = c;
+                const int e0 = S.o_ct + 2 * nbg + lane, e1 = e0 + S.ns;
+                double tl = a - WAT(D.dvec, e0), tu = c - WAT(D.dvec, e1);
+                if (tl < thr0) tl = thr0;
+                if (tu < thr0) tu = thr0;
+                const bool sal = (am >> (2 * nbg + lane)) & 1, sau = (am >> (2 * nbg + S.ns + lane)) & 1;
+                WAT(D.t, e0) = sal ? tl : 0.0; WAT(D.t, e1) = sau ? tu : 0.0;
+                WAT(D.lam, e0) = sal ? O.mu0 / tl : 0.0; WAT(D.lam, e1) = sau ? O.mu0 / tu : 0.0;
+            }
+            __syncthreads();
+            if (bsj >= 0) { sl = ssl[bsj]; su = ssu[bsj]; }
+            if (isg)
+            {
+                const int row = S.nb + lane, sj = S.srev[row];
+                const double gsl = sj >= 0 ? ssl[sj] : 0.0, gsu = sj >= 0 ? ssu[sj] : 0.0;
+                double tl = gc + gsl - WAT(D.dvec, S.o_ct + row), tu = WAT(D.dvec, S.o_ct + nbg + row) - gc + gsu;
+                if (tl < thr0) tl = thr0;
+                if (tu < thr0) tu = thr0;
+                const bool gal = (am >> row) & 1, gau = (am >> (nbg + row)) & 1;
+                WAT(D.t, S.o_ct + row) = gal ? tl : 0.0; WAT(D.t, S.o_ct + nbg + row) = gau ? tu : 0.0;
+                WAT(D.lam, S.o_ct + row) = gal ? O.mu0 / tl : 0.0; WAT(D.lam, S.o_ct + nbg + row) = gau ? O.mu0 / tu : 0.0;
+            }
+            __syncthreads(); /* the exchange buffers are reused by the next stage */
+        }
+        if (hasb)
+        {
+            double tl = v + sl - lb, tu = ub - v + su;
+            if (tl < thr0) tl = thr0;
+            if (tu < thr0) tu = thr0;
+            WAT(D.t, S.o_ct + ib) = al ? tl : 0.0;
+            WAT(D.t, S.o_ct + nbg + ib) = au ? tu : 0.0;
+            WAT(D.lam, S.o_ct + ib) = al ? O.mu0 / tl : 0.0;
+            WAT(D.lam, S.o_ct + nbg + ib) = au ? O.mu0 / tu : 0.0;
+        }
     }
     if (lane == 0)
     {
@@ -1392,7 +1916,10 @@ __global__ void __launch_bounds__(64) kw_init(GqpDev D, GqpOpts O)
     }
 }
 
-/* multipliers of the fixed variables and natural slacks of the masked sides, as kb_finalize */
+/* multipliers of the fixed variables from stationarity; natural slacks and zero multipliers of the masked
+ * sides (ocp_qp_compute_t, acados/ocp_qp/ocp_qp_common.c:874-921, restated for those rows), as kb_finalize /
+ * k_finalize */
+template <bool GEN>
 __global__ void __launch_bounds__(64) kw_finalize(GqpDev D)
 {
     const int NX = D.NX, NU = D.NU, n = NX + NU, NP = n * (n + 1) / 2;
@@ -1401,29 +1928,54 @@ __global__ void __launch_bounds__(64) kw_finalize(GqpDev D)
     for (int k = 0; k <= D.N; k++)
     {
         const GqpStage &S = D.st[k];
-        if (S.nb == 0 || lane >= n || !((S.bmask >> lane) & 1)) continue;
-        const int nbg = S.nb, j = lane;
+        const int nbg = S.nb + (GEN ? S.ng : 0);
         const uint64_t am = WAT(D.amask, k);
-        const int ib = popc64(S.bmask & (((uint64_t) 1 << j) - 1));
-        const int el = S.o_ct + ib, eu = el + nbg;
-        const double vj = WAT(D.ux, k * n + j);
-        if ((S.emask >> j) & 1)
+        if (lane < n && ((S.bmask >> lane) & 1))
         {
-            double a = WAT(D.rq, k * n + j);
-            GQP_DOT_UNROLL
-            for (int c = 0; c < n; c++) a += WAT(D.RSQ, k * NP + (c <= j ? PK(j, c) : PK(c, j))) * WAT(D.ux, k * n + c);
-            GQP_DOT_UNROLL
-            for (int c = 0; c < NX; c++) a += WAT(D.BAt, (k * n + j) * NX + c) * WAT(D.pi, (k + 1) * NX + c);
-            if (j >= NU) a -= WAT(D.pi, k * NX + j - NU);
-            WAT(D.lam, el) = a > 0.0 ? a : 0.0;
-            WAT(D.lam, eu) = a < 0.0 ? -a : 0.0;
-            WAT(D.t, el) = 0.0;
-            WAT(D.t, eu) = 0.0;
+            const int j = lane;
+            const int ib = popc64(S.bmask & (((uint64_t) 1 << j) - 1));
+            const int el = S.o_ct + ib, eu = el + nbg;
+            const double vj = WAT(D.ux, k * n + j);
+            if ((S.emask >> j) & 1)
+            {
+                double a = WAT(D.rq, k * n + j);
+                for (int c = 0; c < n; c++) a += WAT(D.RSQ, k * NP + (c <= j ? PK(j, c) : PK(c, j))) * WAT(D.ux, k * n + c);
+                for (int c = 0; c < NX; c++) a += WAT(D.BAt, (k * n + j) * NX + c) * WAT(D.pi, (k + 1) * NX + c);
+                if (j >= NU) a -= WAT(D.pi, k * NX + j - NU);
+                if (GEN)
+                    for (int g = 0; g < S.ng; g++)
+                        a -= WAT(D.DCt, (S.o_g + g) * n + j) * (WAT(D.lam, S.o_ct + S.nb + g) - WAT(D.lam, S.o_ct + nbg + S.nb + g));
+                WAT(D.lam, el) = a > 0.0 ? a : 0.0;
+                WAT(D.lam, eu) = a < 0.0 ? -a : 0.0;
+                WAT(D.t, el) = 0.0;
+                WAT(D.t, eu) = 0.0;
+            }
+            else
+            {
+                const int sj = GEN ? (int) S.srev[ib] : -1;
+                const double sl = sj >= 0 ? WAT(D.sv, S.o_s + sj) : 0.0, su = sj >= 0 ? WAT(D.sv, S.o_s + S.ns + sj) : 0.0;
+                if (!((am >> ib) & 1)) { WAT(D.t, el) = vj + sl - WAT(D.dvec, el); WAT(D.lam, el) = 0.0; }
+                if (!((am >> (nbg + ib)) & 1)) { WAT(D.t, eu) = WAT(D.dvec, eu) - vj + su; WAT(D.lam, eu) = 0.0; }
+            }
         }
-        else
+        if (GEN && lane < S.ng)
         {
-            if (!((am >> ib) & 1)) { WAT(D.t, el) = vj - WAT(D.dvec, el); WAT(D.lam, el) = 0.0; }
-            if (!((am >> (nbg + ib)) & 1)) { WAT(D.t, eu) = WAT(D.dvec, eu) - vj; WAT(D.lam, eu) = 0.0; }
+            const int row = S.nb + lane, el = S.o_ct + row, eu = el + nbg, sj = S.srev[row];
+            const bool al = (am >> row) & 1, au = (am >> (nbg + row)) & 1;
+            if (!al || !au)
+            {
+                double c = 0.0;
+                for (int r = 0; r < n; r++) c += WAT(D.DCt, (S.o_g + lane) * n + r) * WAT(D.ux, k * n + r);
+                const double sl = sj >= 0 ? WAT(D.sv, S.o_s + sj) : 0.0, su = sj >= 0 ? WAT(D.sv, S.o_s + S.ns + sj) : 0.0;
+                if (!al) { WAT(D.t, el) = c + sl - WAT(D.dvec, el); WAT(D.lam, el) = 0.0; }
+                if (!au) { WAT(D.t, eu) = WAT(D.dvec, eu) - c + su; WAT(D.lam, eu) = 0.0; }
+            }
+        }
+        if (GEN && lane < S.ns)
+        {
+            const int e0 = S.o_ct + 2 * nbg + lane, e1 = e0 + S.ns;
+            if (!((am >> (2 * nbg + lane)) & 1)) { WAT(D.t, e0) = WAT(D.sv, S.o_s + lane) - WAT(D.dvec, e0); WAT(D.lam, e0) = 0.0; }
+            if (!((am >> (2 * nbg + S.ns + lane)) & 1)) { WAT(D.t, e1) = WAT(D.sv, S.o_s + S.ns + lane) - WAT(D.dvec, e1); WAT(D.lam, e1) = 0.0; }
         }
     }
 }

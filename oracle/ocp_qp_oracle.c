@@ -44,7 +44,8 @@ typedef struct
     double *dux, *dpi, *dlam, *dt;
     double *Gam, *rho;       /* nct */
     double *Dl, *Du, *rsl, *rsu; /* ns */
-    double *wl, *wu;         /* ns x n (row j = slack j) */
+    double *gme, *El, *Eu, *Xl, *Xu; /* nbg: effective Gamma, exclusive sums of the slack elimination */
+    double *tmp2;
     double *L;               /* n x n col-major lower Cholesky factor */
     double *l;               /* n: L^{-1} m */
     double *W;               /* n x nx1 col-major: [B A]' * Lx+ */
@@ -127,7 +128,8 @@ oqp *oqp_create(int N, const int *nx, const int *nu, const int *nbx, const int *
         s->dux = dz(n + 2 * nss); s->dpi = dz(nx1); s->dlam = dz(nct); s->dt = dz(nct);
         s->Gam = dz(nct); s->rho = dz(nct);
         s->Dl = dz(nss); s->Du = dz(nss); s->rsl = dz(nss); s->rsu = dz(nss);
-        s->wl = dz(nss * n); s->wu = dz(nss * n);
+        s->gme = dz(nbg); s->El = dz(nbg); s->Eu = dz(nbg); s->Xl = dz(nbg); s->Xu = dz(nbg);
+        s->tmp2 = dz(n + 1);
         s->L = dz(n * n); s->l = dz(n); s->W = dz(n * nx1); s->gt = dz(n);
         s->c = dz(nbg); s->dc = dz(nbg); s->rmc = dz(nct);
         s->tmp = dz((n > nx1 ? n : nx1) + 1);
@@ -146,7 +148,7 @@ void oqp_free(oqp *qp)
                      s->Zl, s->Zu, s->zl, s->zu, s->lls, s->lus, s->lls_mask, s->lus_mask,
                      s->idxs_rev, s->idxe, s->ux, s->pi, s->lam, s->t, s->act, s->fixed,
                      s->fixval, s->rg, s->rb, s->rd, s->rm, s->dux, s->dpi, s->dlam, s->dt,
-                     s->Gam, s->rho, s->Dl, s->Du, s->rsl, s->rsu, s->wl, s->wu, s->L, s->l,
+                     s->Gam, s->rho, s->Dl, s->Du, s->rsl, s->rsu, s->gme, s->El, s->Eu, s->Xl, s->Xu, s->tmp2, s->L, s->l,
                      s->W, s->gt, s->c, s->dc, s->tmp, s->rmc};
         for (unsigned i = 0; i < sizeof(p) / sizeof(p[0]); i++) free(p[i]);
     }
@@ -449,18 +451,18 @@ static void stage_condense(stg *s, const double *rm_eff, int do_mat, double reg)
         s->Gam[i] = s->lam[i] / s->t[i];
         s->rho[i] = (rm_eff[i] + s->lam[i] * s->rd[i]) / s->t[i];
     }
-    /* slack elimination */
+    /* slack elimination.  D = Z + Gamma_s + sum Gamma_row, r~ = slack stationarity + rho_s + sum rho_row.
+     * The Schur complement of the slack block is accumulated in its CANCELLATION-FREE form: for a row i
+     * coupled to slack j,  Gamma_i - Gamma_i^2/D = Gamma_i E_i/D  with  E_i = D - Gamma_i  summed without
+     * Gamma_i (an active soft row has Gamma_i >> Z, and Gamma_i - Gamma_i^2/D would lose every digit of the
+     * Z + Gamma_s it should leave behind); likewise rho_i - Gamma_i r~/D = (rho_i E_i - Gamma_i (r~ - rho_i))/D.
+     * Rows sharing one slack add the cross terms -Gamma_i Gamma_k/D a_i a_k'. */
     for (int j = 0; j < ns; j++)
     {
         s->Dl[j] = s->Zl[j] + s->Gam[2 * nbg + j];
         s->Du[j] = s->Zu[j] + s->Gam[2 * nbg + ns + j];
         s->rsl[j] = s->rg[n + j] + s->rho[2 * nbg + j];
         s->rsu[j] = s->rg[n + ns + j] + s->rho[2 * nbg + ns + j];
-    }
-    if (ns > 0 && do_mat)
-    {
-        memset(s->wl, 0, sizeof(double) * ns * n);
-        memset(s->wu, 0, sizeof(double) * ns * n);
     }
     for (int i = 0; i < nbg; i++)
     {
@@ -470,26 +472,33 @@ static void stage_condense(stg *s, const double *rm_eff, int do_mat, double reg)
         s->Du[j] += s->Gam[nbg + i];
         s->rsl[j] += s->rho[i];
         s->rsu[j] += s->rho[nbg + i];
-        if (do_mat)
-        {
-            stage_jrow(s, i, s->tmp);
-            for (int c = 0; c < n; c++)
-            {
-                s->wl[j * n + c] += s->Gam[i] * s->tmp[c];
-                s->wu[j * n + c] += s->Gam[nbg + i] * s->tmp[c];
-            }
-        }
     }
-    /* gradient: gt = rg + J'(rho_l - rho_u) - sum_j (wl_j rsl_j/Dl_j - wu_j rsu_j/Du_j) */
-    memcpy(s->gt, s->rg, sizeof(double) * n);
-    for (int i = 0; i < nbg; i++) s->dc[i] = s->rho[i] - s->rho[nbg + i];
-    stage_jt_add(s, s->dc, 1.0, s->gt);
-    for (int j = 0; j < ns; j++)
+    /* per soft row: exclusive sums E (-> El, Eu) and r~ - rho (-> Xl, Xu); effective Gamma and nu */
+    for (int i = 0; i < nbg; i++)
     {
-        double al = s->Dl[j] != 0.0 ? s->rsl[j] / s->Dl[j] : 0.0;
-        double au = s->Du[j] != 0.0 ? s->rsu[j] / s->Du[j] : 0.0;
-        for (int c = 0; c < n; c++) s->gt[c] += -s->wl[j * n + c] * al + s->wu[j * n + c] * au;
+        int j = s->idxs_rev[i];
+        if (j < 0)
+        {
+            s->gme[i] = s->Gam[i] + s->Gam[nbg + i];
+            s->dc[i] = s->rho[i] - s->rho[nbg + i];
+            continue;
+        }
+        double El = s->Zl[j] + s->Gam[2 * nbg + j], Eu = s->Zu[j] + s->Gam[2 * nbg + ns + j];
+        double Xl = s->rg[n + j] + s->rho[2 * nbg + j], Xu = s->rg[n + ns + j] + s->rho[2 * nbg + ns + j];
+        for (int k = 0; k < nbg; k++)
+            if (k != i && s->idxs_rev[k] == j)
+            {
+                El += s->Gam[k]; Eu += s->Gam[nbg + k];
+                Xl += s->rho[k]; Xu += s->rho[nbg + k];
+            }
+        s->El[i] = El; s->Eu[i] = Eu; s->Xl[i] = Xl; s->Xu[i] = Xu;
+        double il = s->Dl[j] != 0.0 ? 1.0 / s->Dl[j] : 0.0, iu = s->Du[j] != 0.0 ? 1.0 / s->Du[j] : 0.0;
+        s->gme[i] = s->Gam[i] * El * il + s->Gam[nbg + i] * Eu * iu;
+        s->dc[i] = (s->rho[i] * El - s->Gam[i] * Xl) * il - (s->rho[nbg + i] * Eu - s->Gam[nbg + i] * Xu) * iu;
     }
+    /* gradient: gt = rg + J' nu_eff */
+    memcpy(s->gt, s->rg, sizeof(double) * n);
+    stage_jt_add(s, s->dc, 1.0, s->gt);
     if (!do_mat) return;
     /* Hessian (full symmetric storage, col-major n x n) */
     for (int j = 0; j < nu; j++)
@@ -503,22 +512,31 @@ static void stage_condense(stg *s, const double *rm_eff, int do_mat, double reg)
         for (int i = 0; i < nx; i++) M[nu + i + n * (nu + j)] = s->Q[i + nx * j];
     }
     for (int i = 0; i < n; i++) M[i + n * i] += reg;
-    for (int i = 0; i < s->nb; i++) M[s->idxb[i] * (n + 1)] += s->Gam[i] + s->Gam[nbg + i];
+    for (int i = 0; i < s->nb; i++) M[s->idxb[i] * (n + 1)] += s->gme[i];
     for (int g = 0; g < s->ng; g++)
     {
-        double gm = s->Gam[s->nb + g] + s->Gam[nbg + s->nb + g];
+        double gm = s->gme[s->nb + g];
         if (gm == 0.0) continue;
         stage_jrow(s, s->nb + g, s->tmp);
         for (int c = 0; c < n; c++)
             for (int r = 0; r < n; r++) M[r + n * c] += gm * s->tmp[r] * s->tmp[c];
     }
-    for (int j = 0; j < ns; j++)
+    /* rows sharing a slack: cross terms */
+    for (int i = 0; i < nbg; i++)
     {
-        double il = s->Dl[j] != 0.0 ? 1.0 / s->Dl[j] : 0.0;
-        double iu = s->Du[j] != 0.0 ? 1.0 / s->Du[j] : 0.0;
-        const double *wl = s->wl + j * n, *wu = s->wu + j * n;
-        for (int c = 0; c < n; c++)
-            for (int r = 0; r < n; r++) M[r + n * c] -= wl[r] * wl[c] * il + wu[r] * wu[c] * iu;
+        int j = s->idxs_rev[i];
+        if (j < 0) continue;
+        double il = s->Dl[j] != 0.0 ? 1.0 / s->Dl[j] : 0.0, iu = s->Du[j] != 0.0 ? 1.0 / s->Du[j] : 0.0;
+        for (int k = 0; k < nbg; k++)
+        {
+            if (k == i || s->idxs_rev[k] != j) continue;
+            double cf = s->Gam[i] * s->Gam[k] * il + s->Gam[nbg + i] * s->Gam[nbg + k] * iu;
+            if (cf == 0.0) continue;
+            stage_jrow(s, i, s->tmp);
+            stage_jrow(s, k, s->tmp2);
+            for (int c = 0; c < n; c++)
+                for (int r = 0; r < n; r++) M[r + n * c] -= cf * s->tmp[r] * s->tmp2[c];
+        }
     }
 }
 
@@ -676,20 +694,27 @@ static void expand_step(oqp *qp, const double *const *rm_eff)
         for (int j = 0; j < ns; j++)
         {
             double al = 0.0, au = 0.0;
-            for (int c = 0; c < n; c++)
-            {
-                al += s->wl[j * n + c] * s->dux[c];
-                au += s->wu[j * n + c] * s->dux[c];
-            }
+            for (int i = 0; i < nbg; i++)
+                if (s->idxs_rev[i] == j) { al += s->Gam[i] * s->dc[i]; au += s->Gam[nbg + i] * s->dc[i]; }
             s->dux[n + j] = s->Dl[j] != 0.0 ? (-s->rsl[j] - al) / s->Dl[j] : 0.0;
             s->dux[n + ns + j] = s->Du[j] != 0.0 ? (-s->rsu[j] + au) / s->Du[j] : 0.0;
         }
         for (int i = 0; i < nbg; i++)
         {
             int j = s->idxs_rev[i];
-            double dsl = j >= 0 ? s->dux[n + j] : 0.0, dsu = j >= 0 ? s->dux[n + ns + j] : 0.0;
-            s->dt[i] = s->dc[i] + dsl + s->rd[i];
-            s->dt[nbg + i] = -s->dc[i] + dsu + s->rd[nbg + i];
+            if (j < 0)
+            {
+                s->dt[i] = s->dc[i] + s->rd[i];
+                s->dt[nbg + i] = -s->dc[i] + s->rd[nbg + i];
+                continue;
+            }
+            /* dc + ds in the cancellation-free form (E dc - r~ - sum_{k != i} Gamma_k dc_k)/D */
+            double al = 0.0, au = 0.0;
+            for (int k = 0; k < nbg; k++)
+                if (k != i && s->idxs_rev[k] == j) { al += s->Gam[k] * s->dc[k]; au += s->Gam[nbg + k] * s->dc[k]; }
+            double il = s->Dl[j] != 0.0 ? 1.0 / s->Dl[j] : 0.0, iu = s->Du[j] != 0.0 ? 1.0 / s->Du[j] : 0.0;
+            s->dt[i] = (s->El[i] * s->dc[i] - s->rsl[j] - al) * il + s->rd[i];
+            s->dt[nbg + i] = (-s->Eu[i] * s->dc[i] - s->rsu[j] + au) * iu + s->rd[nbg + i];
         }
         for (int j = 0; j < ns; j++)
         {

@@ -165,6 +165,15 @@ def test_c4_chain_soft_constraints_gpu(gpu_lib):
     # acados' own default tolerances for this backend slot: res_g_max 1e-6, the rest 1e-8
     # (ocp_qp_hpipm.c:104-107); the solutions still agree with the oracle to 1e-6 relative
     b = _check_batch_vs_oracle_gpu([chain_soft_qp(i, N=40) for i in range(96)], 4, tol=1e-6, tol_stat=1e-6)
+    assert b.kernel_name.startswith("wpi-gen(nx=24,nu=3,ng=4,ns=8")
+
+
+def test_c4_one_instance_per_lane_kernels_gpu(gpu_lib, monkeypatch):
+    """the general one-instance-per-lane kernels (what shapes below nu+nx = 13 with general rows / slacks
+    run on) on the C4 shape, forced with ACADOS_AMD_WPI=0"""
+    from acados_amd.generators import chain_soft_qp
+    monkeypatch.setenv("ACADOS_AMD_WPI", "0")
+    b = _check_batch_vs_oracle_gpu([chain_soft_qp(i, N=10) for i in range(8)], 2, tol=1e-6, tol_stat=1e-6)
     assert b.kernel_name == "1tpi<NX=24,NU=3,NG=4,NS=8>"
 
 

@@ -141,9 +141,10 @@ def test_error_behaviour_hostsim(hostsim_lib):
         gb.opts_set("no_such_option", 1)
     with pytest.raises(ValueError):
         gb.set("no_such_field", 0, np.zeros((2, 3)))
-    d = lqr_dims(4, 40, 3)  # no kernel instantiation covers nx=40
+    # nx=40 has no one-instance-per-lane instantiation: served by the wave-per-instance family (nu+nx <= 64)
+    assert OcpQpGpuBatch(lqr_dims(4, 40, 3), 2, _clib=hostsim_lib).kernel_name.startswith("wpi-box(nx=40,nu=3")
     with pytest.raises(RuntimeError):
-        OcpQpGpuBatch(d, 2, _clib=hostsim_lib)
+        OcpQpGpuBatch(lqr_dims(4, 70, 3), 2, _clib=hostsim_lib)  # nothing covers nu+nx > 64
 
 
 def test_maxiter_status_hostsim(hostsim_lib):
@@ -171,11 +172,30 @@ def _check_batch_vs_oracle(qps, lib, tol=1e-8):
     return b
 
 
-def test_c4_shape_general_constraints_and_slacks_hostsim(hostsim_lib):
-    """C4 (nx=24, nu=3, soft state bounds + soft general rows, ns=8) at a short horizon"""
+@pytest.mark.parametrize("wpi", ["0", "1"])
+def test_c4_shape_general_constraints_and_slacks_hostsim(hostsim_lib, monkeypatch, wpi):
+    """C4 (nx=24, nu=3, soft state bounds + soft general rows, ns=8) at a short horizon, on both kernel
+    families (one instance per lane / one wave per instance, the default for this shape)"""
     from acados_amd.generators import chain_soft_qp
+    monkeypatch.setenv("ACADOS_AMD_WPI", wpi)
     b = _check_batch_vs_oracle([chain_soft_qp(i, N=6) for i in range(2)], hostsim_lib)
-    assert b.kernel_name == "1tpi<NX=24,NU=3,NG=4,NS=8>"
+    assert b.kernel_name.startswith("wpi-gen(nx=24,nu=3,ng=4,ns=8" if wpi == "1" else "1tpi<NX=24,NU=3,NG=4,NS=8>")
+
+
+def test_wave_per_instance_general_rows_shared_slacks_hostsim(hostsim_lib, monkeypatch):
+    """the reference's casadi QP fixtures (general constraints, slacks, one slack shared by several rows,
+    masks) forced onto the wave-per-instance kernels: same solution as the oracle"""
+    from acados_amd import OcpQpGpuBatch
+    monkeypatch.setenv("ACADOS_AMD_WPI", "1")
+    for rel in INPUT_ONLY:
+        qp = load_qp(rel)
+        o = OracleQp(qp)
+        assert o.solve(default_opts(tol_stat=1e-8)) == 0
+        b = OcpQpGpuBatch.from_qps([qp, qp], _clib=hostsim_lib)
+        b.opts_set("tol_stat", 1e-8)
+        assert b.solve() == 0 and b.kernel_name.startswith("wpi-")
+        compare_with_oracle(lambda k, f: b.get(f, k)[1], o, qp, 1e-7)
+        assert int(b.info("iter")[1]) == o.iter
 
 
 @pytest.mark.parametrize("wpi", ["0", "1"])

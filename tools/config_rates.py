@@ -30,7 +30,7 @@ fill_lqr_batch(gb, data, 50)
 for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"): gb.opts_set(f, 1e-8)
 gb.opts_set("cond_N", 10)
 rate(gb, "C3 = C2 data, partial condensing N2=10", B)
-nb = min(B, 512)
+nb = min(B, 4096)
 qps = [chain_soft_qp(i, N=40) for i in range(nb)]
 gb = OcpQpGpuBatch.from_qps(qps)
 rate(gb, "C4 chain nx=24 nu=3 ng=4 ns=8 N=40", nb)
