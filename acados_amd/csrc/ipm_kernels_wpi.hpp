@@ -651,6 +651,8 @@ struct WpiCon
     double *__restrict__ sIl, *__restrict__ sIu, *__restrict__ sRl, *__restrict__ sRu, *__restrict__ dsl, *__restrict__ dsu;   /* per slack */
     double *__restrict__ sEl, *__restrict__ sEu, *__restrict__ sXl, *__restrict__ sXu; /* per slack: Z + Gamma_s, stationarity + rho_s */
     double *__restrict__ nuG, *__restrict__ gmG; /* per general row */
+    int *__restrict__ rsj;  /* slack index of every row of the stage (copy of GqpStage::srev) */
+    int *__restrict__ scnt; /* rows coupled to each slack */
     int SG;
 };
 
@@ -658,7 +660,7 @@ __host__ __device__ static inline size_t wpi_con_doubles(int n, int NG, int NS)
 {
     if (NG == 0 && NS == 0) return 0;
     const int SG = n | 1;
-    return (size_t) NG * SG + 18 * 32 + 8;
+    return (size_t) NG * SG + 18 * 32 + 32 + 16 + 8;
 }
 
 __device__ static inline WpiCon wpi_con_carve(double *p, int n, int NG, int NS)
@@ -669,13 +671,16 @@ __device__ static inline WpiCon wpi_con_carve(double *p, int n, int NG, int NS)
     C.rGl = p; p += 32; C.rGu = p; p += 32; C.rRl = p; p += 32; C.rRu = p; p += 32; C.rLl = p; p += 32; C.rLu = p; p += 32;
     C.sIl = p; p += 32; C.sIu = p; p += 32; C.sRl = p; p += 32; C.sRu = p; p += 32; C.dsl = p; p += 32; C.dsu = p; p += 32;
     C.sEl = p; p += 32; C.sEu = p; p += 32; C.sXl = p; p += 32; C.sXu = p; p += 32;
-    C.nuG = p; p += 32; C.gmG = p;
+    C.nuG = p; p += 32; C.gmG = p; p += 32;
+    C.rsj = (int *) p; p += 32;
+    C.scnt = (int *) p;
     return C;
 }
 
 /* coalesced copy of the ng x n general rows of a stage into LDS rows of odd stride */
-__device__ static inline void wpi_load_G(const WpiCon &C, const GArr &DCt, int inst, int o_g, int ng, int n, int lane)
+__device__ static inline void wpi_load_G(const WpiCon &C, const GqpStage &S, const GArr &DCt, int inst, int o_g, int ng, int n, int lane)
 {
+    C.rsj[lane] = S.srev[lane];
     int r = lane / n, c = lane - r * n;
     const int dr = 64 / n, dc = 64 - dr * n;
     for (int e = lane; e < ng * n; e += 64)
@@ -687,11 +692,12 @@ __device__ static inline void wpi_load_G(const WpiCon &C, const GArr &DCt, int i
 }
 
 /* sums over the rows coupled to slack q, WITHOUT row `row` */
-__device__ static inline void wpi_excl(const GqpStage &S, int nbg, int row, int q, const double *al_, const double *au_, double &sl, double &su)
+__device__ static inline void wpi_excl(const WpiCon &C, int nbg, int row, int q, const double *al_, const double *au_, double &sl, double &su)
 {
     sl = 0.0; su = 0.0;
+    if (C.scnt[q] < 2) return; /* the usual case: one row per slack */
     for (int k = 0; k < nbg; k++)
-        if (k != row && S.srev[k] == q) { sl += al_[k]; su += au_[k]; }
+        if (k != row && C.rsj[k] == q) { sl += al_[k]; su += au_[k]; }
 }
 
 /* entry idx of the constraint row `row` (box row: unit vector of its variable; general row: row of G) */
@@ -845,7 +851,7 @@ __global__ void __launch_bounds__(64) kw_factor(GqpDev D, GqpOpts O, int redo)
         double sll = 0.0, slu = 0.0, stl = 1.0, stu = 1.0, sZl = 0.0, szl = 0.0, sZu = 0.0, szu = 0.0, ssl = 0.0, ssu = 0.0, sdl = 0.0, sdu = 0.0;
         if (GEN)
         {
-            wpi_load_G(C, D.DCt, inst, S.o_g, S.ng, n, lane);
+            wpi_load_G(C, S, D.DCt, inst, S.o_g, S.ng, n, lane);
             if (bsj >= 0) { bssl = WAT(D.sv, S.o_s + bsj); bssu = WAT(D.sv, S.o_s + S.ns + bsj); }
             Rg = wpi_row(D, S, am, inst, S.nb + lane, isg);
             if (isg)
@@ -868,27 +874,6 @@ __global__ void __launch_bounds__(64) kw_factor(GqpDev D, GqpOpts O, int redo)
         __syncthreads();
         GQP_TICK(0);
 
-        GQP_TICK(5);
-        /* ---- W tiles: W = [B A]' Lx+ (Lx+ has explicit zeros above its diagonal) ---- */
-        double Wt[T8][T8];
-#pragma unroll
-        for (int a = 0; a < T8; a++)
-#pragma unroll
-            for (int b = 0; b < T8; b++) Wt[a][b] = 0.0;
-#pragma unroll 2
-        for (int q = 0; q < NX; q++)
-        {
-            double bb[T8], xx[T8];
-#pragma unroll
-            for (int a = 0; a < T8; a++) bb[a] = L.Bw[(lr + 8 * a) * SX + q];
-#pragma unroll
-            for (int b = 0; b < T8; b++) xx[b] = b < TX ? L.Lx[q * SX + lc + 8 * b] : 0.0;
-#pragma unroll
-            for (int a = 0; a < T8; a++)
-#pragma unroll
-                for (int b = 0; b < T8; b++)
-                    if (b < TX) Wt[a][b] += bb[a] * xx[b];
-        }
         GQP_TICK(6);
         /* ---- vector part, lane = variable: rb, [B A] pi+, H v, box row ---- */
         double gt = 0.0, gadd = 0.0, gam = 0.0;
@@ -973,13 +958,16 @@ __global__ void __launch_bounds__(64) kw_factor(GqpDev D, GqpOpts O, int redo)
             {
                 /* sums over the rows coupled to this slack */
                 double Dl = sZl + sGl, Du = sZu + sGu, Pl = sPl, Pu = sPu, Rl = sZl * ssl + szl - sll, Ru = sZu * ssu + szu - slu;
+                int cnt = 0;
                 for (int row = 0; row < nbg; row++)
-                    if (S.srev[row] == lane)
+                    if (C.rsj[row] == lane)
                     {
                         Dl += C.rGl[row]; Du += C.rGu[row];
                         Pl += C.rRl[row]; Pu += C.rRu[row];
                         Rl -= C.rLl[row]; Ru -= C.rLu[row];
+                        cnt++;
                     }
+                C.scnt[lane] = cnt;
                 nacc(nrm_g, Rl); nacc(nrm_g, Ru);
                 WAT(D.rgs, S.o_s + lane) = Rl; WAT(D.rgs, S.o_s + S.ns + lane) = Ru;
                 C.sEl[lane] = sZl + sGl; C.sEu[lane] = sZu + sGu; /* what D leaves behind without the rows */
@@ -1000,8 +988,8 @@ __global__ void __launch_bounds__(64) kw_factor(GqpDev D, GqpOpts O, int redo)
             if (has && bsj >= 0)
             {
                 double El, Eu, Xl, Xu;
-                wpi_excl(S, nbg, ib, bsj, C.rGl, C.rGu, El, Eu);
-                wpi_excl(S, nbg, ib, bsj, C.rRl, C.rRu, Xl, Xu);
+                wpi_excl(C, nbg, ib, bsj, C.rGl, C.rGu, El, Eu);
+                wpi_excl(C, nbg, ib, bsj, C.rRl, C.rRu, Xl, Xu);
                 El += C.sEl[bsj]; Eu += C.sEu[bsj]; Xl += C.sXl[bsj]; Xu += C.sXu[bsj];
                 gam = bGl * El * C.sIl[bsj] + bGu * Eu * C.sIu[bsj];
                 gadd = (bRl * El - bGl * Xl) * C.sIl[bsj] - (bRu * Eu - bGu * Xu) * C.sIu[bsj];
@@ -1013,8 +1001,8 @@ __global__ void __launch_bounds__(64) kw_factor(GqpDev D, GqpOpts O, int redo)
                 {
                     const int q = Rg.sj;
                     double El, Eu, Xl, Xu;
-                    wpi_excl(S, nbg, S.nb + lane, q, C.rGl, C.rGu, El, Eu);
-                    wpi_excl(S, nbg, S.nb + lane, q, C.rRl, C.rRu, Xl, Xu);
+                    wpi_excl(C, nbg, S.nb + lane, q, C.rGl, C.rGu, El, Eu);
+                    wpi_excl(C, nbg, S.nb + lane, q, C.rRl, C.rRu, Xl, Xu);
                     El += C.sEl[q]; Eu += C.sEu[q]; Xl += C.sXl[q]; Xu += C.sXu[q];
                     gm = gGl * El * C.sIl[q] + gGu * Eu * C.sIu[q];
                     nu = (gRl * El - gGl * Xl) * C.sIl[q] - (gRu * Eu - gGu * Xu) * C.sIu[q];
@@ -1026,6 +1014,27 @@ __global__ void __launch_bounds__(64) kw_factor(GqpDev D, GqpOpts O, int redo)
         if (fixed) gt = 0.0;
         if (mine) { nacc(nrm_g, gt); WAT(D.rg, k * n + lane) = gt; }
         L.gam[lane] = gam;
+        GQP_TICK(5);
+        /* ---- W tiles: W = [B A]' Lx+ (Lx+ has explicit zeros above its diagonal) ---- */
+        double Wt[T8][T8];
+#pragma unroll
+        for (int a = 0; a < T8; a++)
+#pragma unroll
+            for (int b = 0; b < T8; b++) Wt[a][b] = 0.0;
+#pragma unroll 2
+        for (int q = 0; q < NX; q++)
+        {
+            double bb[T8], xx[T8];
+#pragma unroll
+            for (int a = 0; a < T8; a++) bb[a] = L.Bw[(lr + 8 * a) * SX + q];
+#pragma unroll
+            for (int b = 0; b < T8; b++) xx[b] = b < TX ? L.Lx[q * SX + lc + 8 * b] : 0.0;
+#pragma unroll
+            for (int a = 0; a < T8; a++)
+#pragma unroll
+                for (int b = 0; b < T8; b++)
+                    if (b < TX) Wt[a][b] += bb[a] * xx[b];
+        }
         __syncthreads(); /* everybody is done with [B A]': the buffer becomes W */
         GQP_TICK(1);
 #pragma unroll
@@ -1090,11 +1099,11 @@ __global__ void __launch_bounds__(64) kw_factor(GqpDev D, GqpOpts O, int redo)
             /* rows sharing a slack: cross terms (rare; plain loops) */
             for (int i = 0; i < nbg; i++)
             {
-                const int q = S.srev[i];
-                if (q < 0) continue;
+                const int q = C.rsj[i];
+                if (q < 0 || C.scnt[q] < 2) continue;
                 for (int kk = 0; kk < nbg; kk++)
                 {
-                    if (kk == i || S.srev[kk] != q) continue;
+                    if (kk == i || C.rsj[kk] != q) continue;
                     const double cf = C.rGl[i] * C.rGl[kk] * C.sIl[q] + C.rGu[i] * C.rGu[kk] * C.sIu[q];
 #pragma unroll
                     for (int a = 0; a < T8; a++)
@@ -1356,7 +1365,7 @@ __global__ void __launch_bounds__(64) kw_backrhs(GqpDev D, GqpOpts O, int redo)
         }
         if (GEN)
         {
-            wpi_load_G(C, D.DCt, inst, S.o_g, S.ng, n, lane);
+            wpi_load_G(C, S, D.DCt, inst, S.o_g, S.ng, n, lane);
             const bool isg = lane < S.ng, iss = lane < S.ns;
             double gGl = 0.0, gGu = 0.0, gRl = 0.0, gRu = 0.0;
             int gsj = -1;
@@ -1391,8 +1400,10 @@ __global__ void __launch_bounds__(64) kw_backrhs(GqpDev D, GqpOpts O, int redo)
                 double Rl = WAT(D.rgs, S.o_s + lane) + sPl, Ru = WAT(D.rgs, S.o_s + S.ns + lane) + sPu;
                 C.sXl[lane] = Rl; C.sXu[lane] = Ru; /* r~ without the rows */
                 C.sEl[lane] = WAT(D.Zz, (S.o_s + lane) * 2) + sGl; C.sEu[lane] = WAT(D.Zz, (S.o_s + S.ns + lane) * 2) + sGu;
+                int cnt = 0;
                 for (int row = 0; row < nbg; row++)
-                    if (S.srev[row] == lane) { Rl += C.rRl[row]; Ru += C.rRu[row]; }
+                    if (C.rsj[row] == lane) { Rl += C.rRl[row]; Ru += C.rRu[row]; cnt++; }
+                C.scnt[lane] = cnt;
                 WAT(D.sR, S.o_s + lane) = Rl; WAT(D.sR, S.o_s + S.ns + lane) = Ru;
                 const double Dl = WAT(D.sD, S.o_s + lane), Du = WAT(D.sD, S.o_s + S.ns + lane);
                 C.sIl[lane] = Dl != 0.0 ? frcp(Dl) : 0.0;
@@ -1402,8 +1413,8 @@ __global__ void __launch_bounds__(64) kw_backrhs(GqpDev D, GqpOpts O, int redo)
             if (has && bsj >= 0)
             {
                 double El, Eu, Xl, Xu;
-                wpi_excl(S, nbg, ib, bsj, C.rGl, C.rGu, El, Eu);
-                wpi_excl(S, nbg, ib, bsj, C.rRl, C.rRu, Xl, Xu);
+                wpi_excl(C, nbg, ib, bsj, C.rGl, C.rGu, El, Eu);
+                wpi_excl(C, nbg, ib, bsj, C.rRl, C.rRu, Xl, Xu);
                 El += C.sEl[bsj]; Eu += C.sEu[bsj]; Xl += C.sXl[bsj]; Xu += C.sXu[bsj];
                 m += (bRl * El - bGl * Xl) * C.sIl[bsj] - (bRu * Eu - bGu * Xu) * C.sIu[bsj];
             }
@@ -1413,8 +1424,8 @@ __global__ void __launch_bounds__(64) kw_backrhs(GqpDev D, GqpOpts O, int redo)
                 if (gsj >= 0)
                 {
                     double El, Eu, Xl, Xu;
-                    wpi_excl(S, nbg, S.nb + lane, gsj, C.rGl, C.rGu, El, Eu);
-                    wpi_excl(S, nbg, S.nb + lane, gsj, C.rRl, C.rRu, Xl, Xu);
+                    wpi_excl(C, nbg, S.nb + lane, gsj, C.rGl, C.rGu, El, Eu);
+                    wpi_excl(C, nbg, S.nb + lane, gsj, C.rRl, C.rRu, Xl, Xu);
                     El += C.sEl[gsj]; Eu += C.sEu[gsj]; Xl += C.sXl[gsj]; Xu += C.sXu[gsj];
                     nu = (gRl * El - gGl * Xl) * C.sIl[gsj] - (gRu * Eu - gGu * Xu) * C.sIu[gsj];
                 }
@@ -1503,7 +1514,7 @@ __global__ void __launch_bounds__(64) kw_fwd(GqpDev D, GqpOpts O, int redo)
         const int nbg = S.nb + (GEN ? S.ng : 0);
 
         for (int p = lane; p < NP; p += 64) Lc[p] = WAT(D.Lf, k * NP + p);
-        if (GEN) wpi_load_G(C, D.DCt, inst, S.o_g, S.ng, n, lane);
+        if (GEN) wpi_load_G(C, S, D.DCt, inst, S.o_g, S.ng, n, lane);
         wpi_load_B(L.B, SXb, D.BAt, inst, k, n, NX, lane);
         double lv = mine ? WAT(D.lf, k * n + lane) : 0.0; /* l_u / l_x or p */
         const double rbv = lane < NX ? WAT(D.rb, k * NX + lane) : 0.0;
@@ -1616,8 +1627,10 @@ __global__ void __launch_bounds__(64) kw_fwd(GqpDev D, GqpOpts O, int redo)
             if (iss)
             {
                 double accl = 0.0, accu = 0.0;
+                int cnt = 0;
                 for (int row = 0; row < nbg; row++)
-                    if (S.srev[row] == lane) { accl += C.rRl[row]; accu += C.rRu[row]; }
+                    if (C.rsj[row] == lane) { accl += C.rRl[row]; accu += C.rRu[row]; cnt++; }
+                C.scnt[lane] = cnt;
                 const double Dl = WAT(D.sD, S.o_s + lane), Du = WAT(D.sD, S.o_s + S.ns + lane);
                 const double il = Dl != 0.0 ? frcp(Dl) : 0.0, iu = Du != 0.0 ? frcp(Du) : 0.0;
                 const double rsl = WAT(D.sR, S.o_s + lane), rsu = WAT(D.sR, S.o_s + S.ns + lane);
@@ -1662,8 +1675,8 @@ __global__ void __launch_bounds__(64) kw_fwd(GqpDev D, GqpOpts O, int redo)
             {
                 /* dc + ds = (E dc - r~ - sum_{k != i} Gamma_k dc_k)/D */
                 double El, Eu, al_, au_;
-                wpi_excl(S, nbg, ib, bsj, C.rGl, C.rGu, El, Eu);
-                wpi_excl(S, nbg, ib, bsj, C.rRl, C.rRu, al_, au_);
+                wpi_excl(C, nbg, ib, bsj, C.rGl, C.rGu, El, Eu);
+                wpi_excl(C, nbg, ib, bsj, C.rRl, C.rRu, al_, au_);
                 El += C.sEl[bsj]; Eu += C.sEu[bsj];
                 bsoft = true;
                 bdsl = (El * dvj - C.sRl[bsj] - al_) * C.sIl[bsj];
@@ -1676,8 +1689,8 @@ __global__ void __launch_bounds__(64) kw_fwd(GqpDev D, GqpOpts O, int redo)
                 {
                     const int q = Rg.sj;
                     double El, Eu, al_, au_;
-                    wpi_excl(S, nbg, S.nb + lane, q, C.rGl, C.rGu, El, Eu);
-                    wpi_excl(S, nbg, S.nb + lane, q, C.rRl, C.rRu, al_, au_);
+                    wpi_excl(C, nbg, S.nb + lane, q, C.rGl, C.rGu, El, Eu);
+                    wpi_excl(C, nbg, S.nb + lane, q, C.rRl, C.rRu, al_, au_);
                     El += C.sEl[q]; Eu += C.sEu[q];
                     gsl_ = (El * gdc - C.sRl[q] - al_) * C.sIl[q];
                     gsu_ = (-Eu * gdc - C.sRu[q] + au_) * C.sIu[q];
