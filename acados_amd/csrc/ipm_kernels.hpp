@@ -51,6 +51,14 @@ namespace gqp
 
 __device__ static inline double dmax(double a, double b) { return a > b ? a : b; }
 __device__ static inline double dabs(double a) { return a < 0.0 ? -a : a; }
+__device__ static inline int popc64_g(uint64_t x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __popcll(x);
+#else
+    return __builtin_popcountll(x);
+#endif
+}
 /* inf-norm accumulation that lets NaN through */
 __device__ static inline void nacc(double &nrm, double v)
 {
@@ -349,11 +357,16 @@ __global__ void __launch_bounds__(64) k_backward(GqpDev D, GqpOpts O, int redo)
 
         /* ---- inequality rows ---- */
         double sDl[NSS], sDu[NSS], sRl[NSS], sRu[NSS], sPl[NSS], sPu[NSS];
+        /* cancellation-free elimination of the slack block (see pass 2): what D and r~ are WITHOUT the rows */
+        double sE0l[NSS], sE0u[NSS], sP0l[NSS], sP0u[NSS];
+        int scnt[NSS];
         if (NS > 0)
         {
             UNROLL for (int q = 0; q < NS; q++)
             {
                 sDl[q] = sDu[q] = sRl[q] = sRu[q] = sPl[q] = sPu[q] = 0.0;
+                sE0l[q] = sE0u[q] = sP0l[q] = sP0u[q] = 0.0;
+                scnt[q] = 0;
                 if (q < S.ns)
                 {
                     const int e0 = S.o_ct + 2 * nbg + q, e1 = e0 + S.ns;
@@ -394,6 +407,8 @@ __global__ void __launch_bounds__(64) k_backward(GqpDev D, GqpOpts O, int redo)
                     /* rho sums are kept apart (sP) until the stationarity residual is stored */
                     sPl[q] = al ? (rml + laml * rdl) / tl : 0.0;
                     sPu[q] = au ? (rmu + lamu * rdu) / tu : 0.0;
+                    sE0l[q] = sDl[q]; sE0u[q] = sDu[q];
+                    sP0l[q] = sPl[q]; sP0u[q] = sPu[q];
                 }
             }
         }
@@ -454,7 +469,7 @@ __global__ void __launch_bounds__(64) k_backward(GqpDev D, GqpOpts O, int redo)
                 if (NS > 0 && sj >= 0)
                 {
                     UNROLL for (int q = 0; q < NS; q++)
-                        if (q == sj) { sDl[q] += gl; sDu[q] += gu; sPl[q] += rl; sPu[q] += ru; }
+                        if (q == sj) { sDl[q] += gl; sDu[q] += gu; sPl[q] += rl; sPu[q] += ru; scnt[q]++; }
                 }
                 else
                 {
@@ -512,17 +527,42 @@ __global__ void __launch_bounds__(64) k_backward(GqpDev D, GqpOpts O, int redo)
             }
         }
 
-        /* pass 2: soft rows (need the complete per-slack sums) */
+        /* pass 2: soft rows (need the complete per-slack sums).  Schur complement of the slack block in its
+         * CANCELLATION-FREE form: for row i coupled to slack q,  Gamma_i - Gamma_i^2/D = Gamma_i E_i/D  with
+         * E_i = D - Gamma_i summed WITHOUT row i (an active soft row has Gamma_i >> Z: the difference would
+         * lose every digit of the Z + Gamma_s it leaves behind), and
+         * rho_i - Gamma_i r~/D = (rho_i E_i - Gamma_i X_i)/D with X_i = r~ - rho_i summed without row i.
+         * Rows that share a slack add the cross terms -Gamma_i Gamma_k/D a_i a_k' (pass 3). */
         if (NS > 0)
         {
+            double sX0l[NSS], sX0u[NSS];
             UNROLL for (int q = 0; q < NS; q++)
+            {
+                sX0l[q] = sX0u[q] = 0.0;
                 if (q < S.ns)
                 {
+                    sX0l[q] = sRl[q] + sP0l[q]; sX0u[q] = sRu[q] + sP0u[q]; /* r~ without the rows */
                     sRl[q] += sPl[q]; sRu[q] += sPu[q]; /* r~ = stationarity residual + rho sums */
                     /* persist (D, r~) of each slack for the forward sweep */
                     GAT(D.sD, S.o_s + q) = sDl[q]; GAT(D.sD, S.o_s + S.ns + q) = sDu[q];
                     GAT(D.sR, S.o_s + q) = sRl[q]; GAT(D.sR, S.o_s + S.ns + q) = sRu[q];
                 }
+            }
+            /* Gamma and rho of a row, recomputed from HBM (rows are revisited; registers do not hold them) */
+            auto row_gr = [&](int row, double &gl, double &gu, double &rl, double &ru) {
+                const int el = S.o_ct + row, eu = el + nbg;
+                const bool al = (am >> row) & 1, au = (am >> (nbg + row)) & 1;
+                gl = al ? GAT(D.lam, el) / GAT(D.t, el) : 0.0;
+                gu = au ? GAT(D.lam, eu) / GAT(D.t, eu) : 0.0;
+                double rml = GAT(D.rm, el), rmu = GAT(D.rm, eu);
+                if (!FACT)
+                {
+                    if (al) rml += (center_only ? 0.0 : GAT(D.dlam, el) * GAT(D.dt, el)) - smu;
+                    if (au) rmu += (center_only ? 0.0 : GAT(D.dlam, eu) * GAT(D.dt, eu)) - smu;
+                }
+                rl = al ? (rml + GAT(D.lam, el) * GAT(D.rd, el)) / GAT(D.t, el) : 0.0;
+                ru = au ? (rmu + GAT(D.lam, eu) * GAT(D.rd, eu)) / GAT(D.t, eu) : 0.0;
+            };
             int ib = 0;
             UNROLL for (int j = 0; j < n + NG; j++)
             {
@@ -532,23 +572,28 @@ __global__ void __launch_bounds__(64) k_backward(GqpDev D, GqpOpts O, int redo)
                 if (j < n) ib++;
                 const int sj = S.srev[row];
                 if (sj < 0) continue;
-                const int el = S.o_ct + row, eu = el + nbg;
-                const bool al = (am >> row) & 1, au = (am >> (nbg + row)) & 1;
-                const double gl = al ? GAT(D.lam, el) / GAT(D.t, el) : 0.0;
-                const double gu = au ? GAT(D.lam, eu) / GAT(D.t, eu) : 0.0;
-                double rml = GAT(D.rm, el), rmu = GAT(D.rm, eu);
-                if (!FACT)
+                double gl, gu, rl, ru;
+                row_gr(row, gl, gu, rl, ru);
+                double El = 0.0, Eu = 0.0, Xl = 0.0, Xu = 0.0, il = 0.0, iu = 0.0;
+                int cnt = 0;
+                UNROLL for (int q = 0; q < NS; q++)
+                    if (q == sj)
+                    {
+                        El = sE0l[q]; Eu = sE0u[q]; Xl = sX0l[q]; Xu = sX0u[q]; cnt = scnt[q];
+                        il = sDl[q] != 0.0 ? 1.0 / sDl[q] : 0.0; iu = sDu[q] != 0.0 ? 1.0 / sDu[q] : 0.0;
+                    }
+                if (cnt > 1)
                 {
-                    if (al) rml += (center_only ? 0.0 : GAT(D.dlam, el) * GAT(D.dt, el)) - smu;
-                    if (au) rmu += (center_only ? 0.0 : GAT(D.dlam, eu) * GAT(D.dt, eu)) - smu;
+                    for (int k2 = 0; k2 < nbg; k2++)
+                        if (k2 != row && S.srev[k2] == sj)
+                        {
+                            double g2l, g2u, r2l, r2u;
+                            row_gr(k2, g2l, g2u, r2l, r2u);
+                            El += g2l; Eu += g2u; Xl += r2l; Xu += r2u;
+                        }
                 }
-                const double rl = al ? (rml + GAT(D.lam, el) * GAT(D.rd, el)) / GAT(D.t, el) : 0.0;
-                const double ru = au ? (rmu + GAT(D.lam, eu) * GAT(D.rd, eu)) / GAT(D.t, eu) : 0.0;
-                double dl = 1.0, du = 1.0, rsl = 0.0, rsu = 0.0;
-                UNROLL for (int q = 0; q < NS; q++) if (q == sj) { dl = sDl[q]; du = sDu[q]; rsl = sRl[q]; rsu = sRu[q]; }
-                const double il = dl != 0.0 ? 1.0 / dl : 0.0, iu = du != 0.0 ? 1.0 / du : 0.0;
-                const double nu_ = rl - ru - gl * rsl * il + gu * rsu * iu;
-                const double gm = gl + gu;
+                const double nu_ = (rl * El - gl * Xl) * il - (ru * Eu - gu * Xu) * iu;
+                const double gm = gl * El * il + gu * Eu * iu;
                 if (j < n)
                 {
                     gadd[j < n ? j : 0] += nu_;
@@ -566,40 +611,44 @@ __global__ void __launch_bounds__(64) k_backward(GqpDev D, GqpOpts O, int redo)
                     }
                 }
             }
-            /* pass 3: rank-one corrections  M -= wl wl'/Dl + wu wu'/Du  per slack */
+            /* pass 3: rows sharing one slack, cross terms (rare: plain loops, row vectors rebuilt on the fly) */
             if (FACT)
             {
-                for (int q = 0; q < S.ns; q++)
+                for (int r1 = 0; r1 < nbg; r1++)
                 {
-                    double wl[n], wu[n];
-                    UNROLL for (int r = 0; r < n; r++) wl[r] = wu[r] = 0.0;
-                    int ib2 = 0;
-                    UNROLL for (int j = 0; j < n + NG; j++)
-                    {
-                        const bool is_row = j < n ? ((S.bmask >> j) & 1) : (j - n < S.ng);
-                        if (!is_row) continue;
-                        const int row = j < n ? ib2 : S.nb + (j - n);
-                        if (j < n) ib2++;
-                        if (S.srev[row] != q) continue;
-                        const int el = S.o_ct + row, eu = el + nbg;
-                        const bool al = (am >> row) & 1, au = (am >> (nbg + row)) & 1;
-                        const double gl = al ? GAT(D.lam, el) / GAT(D.t, el) : 0.0;
-                        const double gu = au ? GAT(D.lam, eu) / GAT(D.t, eu) : 0.0;
-                        if (j < n) { wl[j < n ? j : 0] += gl; wu[j < n ? j : 0] += gu; }
-                        else
+                    const int q = S.srev[r1];
+                    if (q < 0) continue;
+                    int cnt = 0;
+                    double il = 0.0, iu = 0.0;
+                    UNROLL for (int qq = 0; qq < NS; qq++)
+                        if (qq == q)
                         {
-                            UNROLL for (int r = 0; r < n; r++)
+                            cnt = scnt[qq];
+                            il = sDl[qq] != 0.0 ? 1.0 / sDl[qq] : 0.0; iu = sDu[qq] != 0.0 ? 1.0 / sDu[qq] : 0.0;
+                        }
+                    if (cnt < 2) continue;
+                    double g1l, g1u, r1l, r1u;
+                    row_gr(r1, g1l, g1u, r1l, r1u);
+                    for (int r2 = 0; r2 < nbg; r2++)
+                    {
+                        if (r2 == r1 || S.srev[r2] != q) continue;
+                        double g2l, g2u, r2l, r2u;
+                        row_gr(r2, g2l, g2u, r2l, r2u);
+                        const double cf = g1l * g2l * il + g1u * g2u * iu;
+                        /* a_i: unit vector of the variable of a box row, row of DCt for a general row */
+                        UNROLL for (int r = 0; r < n; r++)
+                        {
+                            const double a1 = r1 >= S.nb ? GAT(D.DCt, (S.o_g + r1 - S.nb) * n + r)
+                                                         : ((((S.bmask >> r) & 1) && popc64_g(S.bmask & (((uint64_t) 1 << r) - 1)) == r1) ? 1.0 : 0.0);
+                            if (a1 == 0.0) continue;
+                            UNROLL for (int c = 0; c <= r; c++)
                             {
-                                const double a = GAT(D.DCt, (S.o_g + (j - n)) * n + r);
-                                wl[r] += gl * a; wu[r] += gu * a;
+                                const double a2 = r2 >= S.nb ? GAT(D.DCt, (S.o_g + r2 - S.nb) * n + c)
+                                                             : ((((S.bmask >> c) & 1) && popc64_g(S.bmask & (((uint64_t) 1 << c) - 1)) == r2) ? 1.0 : 0.0);
+                                M[PK(r, c)] -= cf * a1 * a2;
                             }
                         }
                     }
-                    double dl = 0.0, du = 0.0;
-                    UNROLL for (int qq = 0; qq < NS; qq++) if (qq == q) { dl = sDl[qq]; du = sDu[qq]; }
-                    const double il = dl != 0.0 ? 1.0 / dl : 0.0, iu = du != 0.0 ? 1.0 / du : 0.0;
-                    UNROLL for (int r = 0; r < n; r++)
-                        UNROLL for (int c = 0; c <= r; c++) M[PK(r, c)] -= wl[r] * wl[c] * il + wu[r] * wu[c] * iu;
                 }
             }
         }
@@ -763,11 +812,14 @@ __global__ void __launch_bounds__(64) k_forward(GqpDev D, GqpOpts O, int redo)
         /* ---- inequality rows: dc -> dsl/dsu -> dt -> dlam, step length ---- */
         constexpr int NSS = NS > 0 ? NS : 1;
         double dsl[NSS], dsu[NSS];
+        /* per slack, for the cancellation-free dt of the soft rows (k_backward pass 2):
+         * E0 = Z + Gamma_s, r~, 1/D, Gamma-weighted dc sums, rows coupled */
+        double fE0l[NSS], fE0u[NSS], fRl[NSS], fRu[NSS], fIl[NSS], fIu[NSS], accl[NSS], accu[NSS];
+        int fcnt[NSS];
         if (NS > 0)
         {
             /* dsl_j = (-r~sl_j - sum_i Gamma_l,i dc_i)/Dl_j ; dsu_j = (-r~su_j + sum_i Gamma_u,i dc_i)/Du_j */
-            double accl[NSS], accu[NSS];
-            UNROLL for (int q = 0; q < NS; q++) accl[q] = accu[q] = 0.0;
+            UNROLL for (int q = 0; q < NS; q++) { accl[q] = accu[q] = 0.0; fcnt[q] = 0; }
             int ib = 0;
             UNROLL for (int j = 0; j < n + NG; j++)
             {
@@ -784,11 +836,12 @@ __global__ void __launch_bounds__(64) k_forward(GqpDev D, GqpOpts O, int redo)
                 const bool al = (am >> row) & 1, au = (am >> (nbg + row)) & 1;
                 const double gl = al ? GAT(D.lam, el) / GAT(D.t, el) : 0.0;
                 const double gu = au ? GAT(D.lam, eu) / GAT(D.t, eu) : 0.0;
-                UNROLL for (int q = 0; q < NS; q++) if (q == sj) { accl[q] += gl * dc; accu[q] += gu * dc; }
+                UNROLL for (int q = 0; q < NS; q++) if (q == sj) { accl[q] += gl * dc; accu[q] += gu * dc; fcnt[q]++; }
             }
             UNROLL for (int q = 0; q < NS; q++)
             {
                 dsl[q] = dsu[q] = 0.0;
+                fE0l[q] = fE0u[q] = fRl[q] = fRu[q] = fIl[q] = fIu[q] = 0.0;
                 if (q < S.ns)
                 {
                     const double dl = GAT(D.sD, S.o_s + q), du = GAT(D.sD, S.o_s + S.ns + q);
@@ -807,6 +860,10 @@ __global__ void __launch_bounds__(64) k_forward(GqpDev D, GqpOpts O, int redo)
                         if (au) rmu += (center_only ? 0.0 : GAT(D.dlam, e1) * GAT(D.dt, e1)) - smu;
                     }
                     const double laml = GAT(D.lam, e0), lamu = GAT(D.lam, e1), tl = GAT(D.t, e0), tu = GAT(D.t, e1);
+                    fE0l[q] = GAT(D.Zz, (S.o_s + q) * 2) + (al ? laml / tl : 0.0);
+                    fE0u[q] = GAT(D.Zz, (S.o_s + S.ns + q) * 2) + (au ? lamu / tu : 0.0);
+                    fRl[q] = rsl; fRu[q] = rsu;
+                    fIl[q] = dl != 0.0 ? 1.0 / dl : 0.0; fIu[q] = du != 0.0 ? 1.0 / du : 0.0;
                     const double dtl = al ? dsl[q] + GAT(D.rd, e0) : 0.0, dtu = au ? dsu[q] + GAT(D.rd, e1) : 0.0;
                     const double dll = al ? -(rml + laml * dtl) / tl : 0.0, dlu = au ? -(rmu + lamu * dtu) / tu : 0.0;
                     GAT(D.dt, e0) = dtl; GAT(D.dt, e1) = dtu;
@@ -832,11 +889,40 @@ __global__ void __launch_bounds__(64) k_forward(GqpDev D, GqpOpts O, int redo)
                 double dc;
                 if (j < n) dc = dv[j < n ? j : 0];
                 else { dc = 0.0; UNROLL for (int r = 0; r < n; r++) dc += GAT(D.DCt, (S.o_g + (j - n)) * n + r) * dv[r]; }
-                double ddsl = 0.0, ddsu = 0.0;
+                const double laml = al ? GAT(D.lam, el) : 0.0, lamu = au ? GAT(D.lam, eu) : 0.0;
+                const double tl = al ? GAT(D.t, el) : 1.0, tu = au ? GAT(D.t, eu) : 1.0;
+                /* dc + ds resp. -dc + ds; soft rows: (E dc - r~ - sum_{k != i} Gamma_k dc_k)/D, no cancellation */
+                double dcl = dc, dcu = -dc;
                 if (NS > 0)
                 {
                     const int sj = S.srev[row];
-                    UNROLL for (int q = 0; q < NS; q++) if (q == sj) { ddsl = dsl[q]; ddsu = dsu[q]; }
+                    if (sj >= 0)
+                    {
+                        double El = 0.0, Eu = 0.0, xl = 0.0, xu = 0.0, rsl = 0.0, rsu = 0.0, il = 0.0, iu = 0.0;
+                        int cnt = 0;
+                        UNROLL for (int q = 0; q < NS; q++)
+                            if (q == sj) { El = fE0l[q]; Eu = fE0u[q]; rsl = fRl[q]; rsu = fRu[q]; il = fIl[q]; iu = fIu[q]; cnt = fcnt[q]; }
+                        if (cnt > 1)
+                        {
+                            for (int k2 = 0; k2 < nbg; k2++)
+                                if (k2 != row && S.srev[k2] == sj)
+                                {
+                                    const bool a2l = (am >> k2) & 1, a2u = (am >> (nbg + k2)) & 1;
+                                    const double g2l = a2l ? GAT(D.lam, S.o_ct + k2) / GAT(D.t, S.o_ct + k2) : 0.0;
+                                    const double g2u = a2u ? GAT(D.lam, S.o_ct + nbg + k2) / GAT(D.t, S.o_ct + nbg + k2) : 0.0;
+                                    double dc2 = 0.0;
+                                    if (k2 >= S.nb) { UNROLL for (int r = 0; r < n; r++) dc2 += GAT(D.DCt, (S.o_g + k2 - S.nb) * n + r) * dv[r]; }
+                                    else
+                                    {
+                                        UNROLL for (int r = 0; r < n; r++)
+                                            if (((S.bmask >> r) & 1) && popc64_g(S.bmask & (((uint64_t) 1 << r) - 1)) == k2) dc2 = dv[r];
+                                    }
+                                    El += g2l; Eu += g2u; xl += g2l * dc2; xu += g2u * dc2;
+                                }
+                        }
+                        dcl = (El * dc - rsl - xl) * il;
+                        dcu = (-Eu * dc - rsu + xu) * iu;
+                    }
                 }
                 double rml = GAT(D.rm, el), rmu = GAT(D.rm, eu);
                 if (CORR)
@@ -844,10 +930,8 @@ __global__ void __launch_bounds__(64) k_forward(GqpDev D, GqpOpts O, int redo)
                     if (al) rml += (center_only ? 0.0 : GAT(D.dlam, el) * GAT(D.dt, el)) - smu;
                     if (au) rmu += (center_only ? 0.0 : GAT(D.dlam, eu) * GAT(D.dt, eu)) - smu;
                 }
-                const double laml = al ? GAT(D.lam, el) : 0.0, lamu = au ? GAT(D.lam, eu) : 0.0;
-                const double tl = al ? GAT(D.t, el) : 1.0, tu = au ? GAT(D.t, eu) : 1.0;
-                const double dtl = al ? dc + ddsl + GAT(D.rd, el) : 0.0;
-                const double dtu = au ? -dc + ddsu + GAT(D.rd, eu) : 0.0;
+                const double dtl = al ? dcl + GAT(D.rd, el) : 0.0;
+                const double dtu = au ? dcu + GAT(D.rd, eu) : 0.0;
                 const double dll = al ? -(rml + laml * dtl) / tl : 0.0;
                 const double dlu = au ? -(rmu + lamu * dtu) / tu : 0.0;
                 GAT(D.dt, el) = dtl; GAT(D.dt, eu) = dtu;

@@ -162,10 +162,16 @@ def _check_batch_vs_oracle_gpu(qps, n_check, tol=1e-8, tol_stat=1e-8):
 def test_c4_chain_soft_constraints_gpu(gpu_lib):
     """C4 shape: N=40 nx=24 nu=3, hard input bounds, soft state bounds, soft general rows, ns=8"""
     from acados_amd.generators import chain_soft_qp
-    # acados' own default tolerances for this backend slot: res_g_max 1e-6, the rest 1e-8
-    # (ocp_qp_hpipm.c:104-107); the solutions still agree with the oracle to 1e-6 relative
-    b = _check_batch_vs_oracle_gpu([chain_soft_qp(i, N=40) for i in range(96)], 4, tol=1e-6, tol_stat=1e-6)
+    # all four tolerances at 1e-8 (what ocp_nlp sets, ocp_nlp_common.c:1281-1293).  Instance 53 is the one
+    # that used to stall at res_stat ~1e-5 with mu at 1e-16 until the slack block was eliminated in its
+    # cancellation-free form (DESIGN.md): it is part of the batch on purpose.
+    qps = [chain_soft_qp(i, N=40) for i in range(96)]
+    b = _check_batch_vs_oracle_gpu(qps, 4, tol=1e-7, tol_stat=1e-8)
     assert b.kernel_name.startswith("wpi-gen(nx=24,nu=3,ng=4,ns=8")
+    o = OracleQp(qps[53])
+    assert o.solve(default_opts(tol_stat=1e-8)) == 0
+    compare_with_oracle(lambda k, f: b.get(f, k)[53], o, qps[53], 1e-7)
+    assert abs(int(b.info("iter")[53]) - o.iter) <= 1 and o.iter < 20
 
 
 def test_c4_one_instance_per_lane_kernels_gpu(gpu_lib, monkeypatch):
@@ -173,7 +179,7 @@ def test_c4_one_instance_per_lane_kernels_gpu(gpu_lib, monkeypatch):
     run on) on the C4 shape, forced with ACADOS_AMD_WPI=0"""
     from acados_amd.generators import chain_soft_qp
     monkeypatch.setenv("ACADOS_AMD_WPI", "0")
-    b = _check_batch_vs_oracle_gpu([chain_soft_qp(i, N=10) for i in range(8)], 2, tol=1e-6, tol_stat=1e-6)
+    b = _check_batch_vs_oracle_gpu([chain_soft_qp(i, N=10) for i in range(8)], 2, tol=1e-7, tol_stat=1e-8)
     assert b.kernel_name == "1tpi<NX=24,NU=3,NG=4,NS=8>"
 
 
