@@ -33,7 +33,8 @@
 namespace
 {
 
-#define GQP_WPI_MIN_N 13 /* nu+nx from which the wave-per-instance kernels serve box-constrained QPs */
+#define GQP_WPI_MIN_N 13       /* nu+nx from which the wave-per-instance kernels serve every batch */
+#define GQP_WPI_BATCH_MAX 8192 /* batch size up to which they also serve the smaller stage blocks */
 
 /* compiled shape classes; a batch is served by the cheapest one that covers it */
 const KernelSet g_ksets[] = {
@@ -552,7 +553,12 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
         const char *env = getenv("ACADOS_AMD_WPI");
         const char *v1 = getenv("ACADOS_AMD_WPI_V1");
         const bool ref = v1 && atoi(v1) != 0 && !gen;
-        const bool want = env ? atoi(env) != 0 : (wx + wu >= GQP_WPI_MIN_N || !b->ks);
+        /* size rule: large stage blocks always; small ones while the batch is too small to fill the chip with 64
+         * instances per wave (measured crossover on the C2 shape between 4,096 and 16,384 instances,
+         * tools/family_crossover.py).  ACADOS_AMD_WPI_BATCH_MAX overrides the batch threshold. */
+        const char *bm = getenv("ACADOS_AMD_WPI_BATCH_MAX");
+        const int batch_max = bm ? atoi(bm) : GQP_WPI_BATCH_MAX;
+        const bool want = env ? atoi(env) != 0 : (wx + wu >= GQP_WPI_MIN_N || !b->ks || n_batch <= batch_max);
         if (want && wx + wu <= 64 && wx >= 1 && mg <= 32 && ms <= 32)
         {
             /* factor sweep: register-tile kernel for the tile count of this shape; rhs-only and forward sweeps on

@@ -14,6 +14,12 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+# The library picks the kernel family by stage-block size AND batch size (small batches go to the
+# wave-per-instance kernels).  The tests run small batches but mean to cover both families, so the batch rule is
+# switched off here; tests that want it (or a specific family) set ACADOS_AMD_WPI_BATCH_MAX / ACADOS_AMD_WPI.
+os.environ.setdefault("ACADOS_AMD_WPI_BATCH_MAX", "0")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

@@ -215,7 +215,7 @@ def test_c5_shape_classes_and_multiphase_hostsim(hostsim_lib, monkeypatch, wpi):
     assert b.kernel_name.startswith("wpi-box(nx=12,nu=3" if wpi == "1" else "1tpi-box<NX=12,NU=3")
 
 
-def test_wave_per_instance_default_rule_hostsim(hostsim_lib):
+def test_wave_per_instance_default_rule_hostsim(hostsim_lib, monkeypatch):
     """without the override: small stage blocks stay on the one-instance-per-lane kernels, nu+nx >= 13
     goes to the wave-per-instance family; a batch that is not a multiple of anything, per-instance
     iteration counts, Riccati getters and hot start on that family"""
@@ -240,7 +240,12 @@ def test_wave_per_instance_default_rule_hostsim(hostsim_lib):
             for k in (0, N):
                 assert np.allclose(gb.get("ric_L", k)[i], o.get(k, "ric_L"), rtol=1e-6, atol=1e-8)
     small = OcpQpGpuBatch(lqr_dims(N, 8, 3), 2, _clib=hostsim_lib)
-    assert small.kernel_name.startswith("1tpi")
+    assert small.kernel_name.startswith("1tpi")   # the test session switches the batch-size rule off (conftest)
+    # batch-size rule: small stage blocks also go to the wave-per-instance kernels while the batch is small
+    monkeypatch.setenv("ACADOS_AMD_WPI_BATCH_MAX", "100")
+    assert OcpQpGpuBatch(lqr_dims(N, 8, 3), 100, _clib=hostsim_lib).kernel_name.startswith("wpi-box(nx=8,nu=3")
+    assert OcpQpGpuBatch(lqr_dims(N, 8, 3), 101, _clib=hostsim_lib).kernel_name.startswith("1tpi")
+    monkeypatch.setenv("ACADOS_AMD_WPI_BATCH_MAX", "0")
     # hot start from the solution: converged at the first residual evaluation
     gb.opts_set("warm_start", 2)
     assert gb.solve() == 0
