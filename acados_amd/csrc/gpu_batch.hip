@@ -101,7 +101,10 @@ struct ocp_qp_gpu_batch
     const KernelSet *force_ks = nullptr; /* sub-batches run the very same kernel set */
     int compact_min = 1 << 30;           /* levels smaller than this are not compacted; off by default: it only
                                             pays once every sweep kernel is bandwidth-bound */
-    int *d_list = nullptr;               /* instance index of every slot of `compact` */
+    ocp_qp_gpu_batch *tail = nullptr;    /* wave-per-instance sub-batch for the last survivors of a one-instance-per-lane level */
+    int tail_max = 6144;                 /* switch to it when at most this many instances (and a quarter of the level) remain; 0 = off */
+    int n_tail_switches = 0;
+    int *d_list = nullptr;               /* instance index of every slot of `compact` / `tail` */
     int list_cap = 0;
     int n_compactions = 0;
     /* bulk pack / unpack (one H2D + one launch per direction) */
@@ -496,6 +499,7 @@ extern "C" {
 static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu, const int *nbx, const int *nbu,
                                             const int *ng, const int *ns, int n_batch, int device, int force_NX, int force_NU);
 static const KernelSet *g_force_ks = nullptr; /* set only while a compaction sub-batch is being created */
+static bool g_force_wpi = false;              /* set only while a tail sub-batch is being created */
 
 ocp_qp_gpu_batch *ocp_qp_gpu_batch_create(int N, const int *nx, const int *nu, const int *nbx, const int *nbu,
                                           const int *ng, const int *ns, int n_batch, int device)
@@ -546,7 +550,7 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
     /* wave-per-instance family (ipm_kernels_wpi.hpp): box-constrained QPs whose stage block is too large for
      * the one-instance-per-lane register mapping.  Dimensions are runtime values there: no padding to a
      * compiled shape.  ACADOS_AMD_WPI=0/1 overrides the size rule (tests). */
-    if (!g_force_ks)
+    if (!g_force_ks || g_force_wpi)
     {
         const int wx = force_NX ? force_NX : mx, wu = force_NU ? force_NU : mu;
         const bool gen = mg > 0 || ms > 0;
@@ -558,7 +562,7 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
          * tools/family_crossover.py).  ACADOS_AMD_WPI_BATCH_MAX overrides the batch threshold. */
         const char *bm = getenv("ACADOS_AMD_WPI_BATCH_MAX");
         const int batch_max = bm ? atoi(bm) : GQP_WPI_BATCH_MAX;
-        const bool want = env ? atoi(env) != 0 : (wx + wu >= GQP_WPI_MIN_N || !b->ks || n_batch <= batch_max);
+        const bool want = g_force_wpi || (env ? atoi(env) != 0 : (wx + wu >= GQP_WPI_MIN_N || !b->ks || n_batch <= batch_max));
         if (want && wx + wu <= 64 && wx >= 1 && mg <= 32 && ms <= 32)
         {
             /* factor sweep: register-tile kernel for the tile count of this shape; rhs-only and forward sweeps on
@@ -621,6 +625,7 @@ void ocp_qp_gpu_batch_destroy(ocp_qp_gpu_batch *b)
     (void) hipStreamDestroy(b->stream);
     if (b->child) ocp_qp_gpu_batch_destroy(b->child);
     if (b->compact) ocp_qp_gpu_batch_destroy(b->compact);
+    if (b->tail) ocp_qp_gpu_batch_destroy(b->tail);
     delete b;
 }
 
@@ -714,6 +719,7 @@ int ocp_qp_gpu_batch_opts_set(ocp_qp_gpu_batch *b, const char *f, const void *v)
     else if (!strcmp(f, "print_level")) b->print_level = *i;
     else if (!strcmp(f, "profile")) b->profile = *i;
     else if (!strcmp(f, "compact_min")) b->compact_min = *i;
+    else if (!strcmp(f, "tail_max")) b->tail_max = *i;
     else if (!strcmp(f, "cond_N"))
     {
         if (*i != b->cond_N)
@@ -933,8 +939,8 @@ struct Prof
     }
 };
 
-static void compact_into(ocp_qp_gpu_batch *b, int nact, hipStream_t s);
-static void compact_back(ocp_qp_gpu_batch *b, hipStream_t s);
+static void compact_into(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch *root, int nact, hipStream_t s, bool tail);
+static void compact_back(ocp_qp_gpu_batch *b, hipStream_t s, ocp_qp_gpu_batch *c, int it0);
 
 /*
  * One level of the IPM loop.  After the factor kernel of every iteration the host reads the
@@ -951,32 +957,47 @@ static void run_ipm(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch *root, Prof &prof, hip
     GqpOpts O = root->O;
     for (;; it++)
     {
-        prof.begin(1, s);
+        if (b == root) prof.begin(1, s); /* per-class timing covers the root level only (full-batch launches) */
         GQP_IPM_LAUNCH_SHM(b, K.fact, b->shmem_fact, s, D, O, 0);
-        prof.end(s);
+        if (b == root) prof.end(s);
         root->launches++;
         HIPCHK(hipMemcpyAsync(b->h_nact, D.n_active, sizeof(int), hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
         const int nact = *b->h_nact;
         if (root->print_level > 1) printf("acados_amd: ipm iter %d level size %d active %d\n", it, b->B, nact);
         if (nact <= 0 || it > O.iter_max) break;
-        if (b->B >= root->compact_min && 2 * nact <= b->B)
+        if (!b->wpi && root->tail_max > 0 && nact <= root->tail_max && 4 * nact <= b->B)
         {
-            compact_into(b, nact, s);
-            root->n_compactions++;
-            run_ipm(b->compact, root, prof, s, it);
-            compact_back(b, s);
+            /* the last survivors of a one-instance-per-lane level: a wave that still has ONE active lane pays
+             * the full per-wave latency of every sweep, so the tail continues one wave per instance */
+            compact_into(b, root, nact, s, true);
+            root->n_tail_switches++;
+            run_ipm(b->tail, root, prof, s, it);
+            /* the family's own finalize first: the general one-instance-per-lane kernels refresh the multipliers
+             * of the fixed variables in every factor sweep and their finalize relies on that, the wave-per-instance
+             * kernels compute them once at the end */
+            GQP_IPM_LAUNCH(b->tail, pick_kernels(b->tail).final_, s, b->tail->D);
+            root->launches++;
+            compact_back(b, s, b->tail, it);
             break;
         }
-        prof.begin(2, s);
+        if (b->B >= root->compact_min && 2 * nact <= b->B)
+        {
+            compact_into(b, root, nact, s, false);
+            root->n_compactions++;
+            run_ipm(b->compact, root, prof, s, it);
+            compact_back(b, s, b->compact, it);
+            break;
+        }
+        if (b == root) prof.begin(2, s);
         GQP_IPM_LAUNCH(b, K.faff, s, D, O, 0);
-        prof.end(s);
-        prof.begin(3, s);
+        if (b == root) prof.end(s);
+        if (b == root) prof.begin(3, s);
         GQP_IPM_LAUNCH(b, K.rhs, s, D, O, 0);
-        prof.end(s);
-        prof.begin(4, s);
+        if (b == root) prof.end(s);
+        if (b == root) prof.begin(4, s);
         GQP_IPM_LAUNCH(b, K.fcorr, s, D, O, 0);
-        prof.end(s);
+        if (b == root) prof.end(s);
         root->launches += 3;
         if (O.cond_pred_corr)
         {
@@ -991,7 +1012,7 @@ static void run_ipm(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch *root, Prof &prof, hip
 #define GQP_FOR_STATE_ARRAYS(X) X(BAt) X(bvec) X(RSQ) X(rq) X(dvec) X(DCt) X(Zz) X(ux) X(sv) X(pi) X(lam) X(t)
 #define GQP_FOR_RESULT_ARRAYS(X) X(ux) X(sv) X(pi) X(lam) X(t)
 
-static void compact_into(ocp_qp_gpu_batch *b, int nact, hipStream_t s)
+static void compact_into(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch *root, int nact, hipStream_t s, bool tail)
 {
     /* sorted list of the still-iterating instances (sorted => the gather reads stay coalesced) */
     std::vector<int> st(b->B), list;
@@ -999,23 +1020,31 @@ static void compact_into(ocp_qp_gpu_batch *b, int nact, hipStream_t s)
     list.reserve(nact);
     for (int i = 0; i < b->B; i++) if (st[i] == GQP_RUNNING) list.push_back(i);
     const int cnt = (int) list.size();
-    if (!b->compact)
+    if (!b->d_list)
     {
-        const int cap = (b->B + 1) / 2;
+        b->list_cap = (b->B + 1) / 2;
+        b->d_list = dalloc<int>(b, b->list_cap);
+    }
+    ocp_qp_gpu_batch *&slot = tail ? b->tail : b->compact;
+    if (!slot)
+    {
+        /* same kernel set (compaction) or the wave-per-instance family at the very same padded dims (tail) */
+        const int cap = tail ? std::min(b->tail_max, b->list_cap) : (b->B + 1) / 2;
         g_force_ks = b->ks;
+        g_force_wpi = tail;
         ocp_qp_gpu_batch *c = batch_create_shape(b->N, b->nx.data(), b->nu.data(), b->nbx.data(), b->nbu.data(),
-                                                 b->ng.data(), b->ns.data(), cap, b->device, 0, 0);
+                                                 b->ng.data(), b->ns.data(), cap, b->device, tail ? b->ks->NX : 0, tail ? b->ks->NU : 0);
         g_force_ks = nullptr;
+        g_force_wpi = false;
         if (!c) { fprintf(stderr, "acados_amd: cannot create the compaction sub-batch\n"); abort(); }
         c->idxb = b->idxb; c->idxs_rev = b->idxs_rev; c->idxe = b->idxe; c->nbxe = b->nbxe;
         c->compact_min = b->compact_min;
-        c->aos = b->aos; c->wpi = b->wpi; c->shmem = b->shmem; c->shmem_fact = b->shmem_fact;
+        c->tail_max = b->tail_max;
+        if (!tail) { c->aos = b->aos; c->wpi = b->wpi; c->shmem = b->shmem; c->shmem_fact = b->shmem_fact; }
         finalize_structure(c);
-        b->compact = c;
-        b->d_list = dalloc<int>(b, cap);
-        b->list_cap = cap;
+        slot = c;
     }
-    ocp_qp_gpu_batch *c = b->compact;
+    ocp_qp_gpu_batch *c = slot;
     HIPCHK(hipMemcpyAsync(b->d_list, list.data(), sizeof(int) * cnt, hipMemcpyHostToDevice, s));
     c->B = cnt; /* the level works on `cnt` slots of its capacity */
     c->D.B = cnt;
@@ -1031,14 +1060,18 @@ static void compact_into(ocp_qp_gpu_batch *b, int nact, hipStream_t s)
     hipLaunchKernelGGL(gqp::k_compact_scalars, dim3((cnt + 63) / 64), block, 0, s, b->D, c->D, b->d_list, cnt, 0);
     *c->h_nact = cnt;
     HIPCHK(hipMemcpyAsync(c->D.n_active, c->h_nact, sizeof(int), hipMemcpyHostToDevice, s));
-    c->D.stat = nullptr; c->D.stat_inst = 0; c->D.stat_rows = 0;
+    /* the level keeps its own statistics rows for its first slots; merged into the parent's table afterwards */
+    c->O = root->O;
+    ensure_stat(c);
+    HIPCHK(hipMemsetAsync(c->D.stat, 0, sizeof(double) * (size_t) c->stat_rows * GQP_STAT_COLS * c->stat_inst, s));
     HIPCHK(hipStreamSynchronize(s)); /* `list` (host) must outlive the copy */
 }
 
-static void compact_back(ocp_qp_gpu_batch *b, hipStream_t s)
+static void compact_back(ocp_qp_gpu_batch *b, hipStream_t s, ocp_qp_gpu_batch *c, int it0)
 {
-    ocp_qp_gpu_batch *c = b->compact;
     const int cnt = c->B;
+    if (b->D.stat && c->D.stat)
+        hipLaunchKernelGGL(gqp::k_stat_merge, dim3(1), dim3(64), 0, s, b->D, c->D, b->d_list, cnt < 64 ? cnt : 64, it0);
     const dim3 block(64);
 #define GQP_COPY_OUT(A)                                                                                    \
     if (b->D.A.E > 0 && b->D.A.p && c->D.A.p)                                                              \
@@ -1067,6 +1100,7 @@ int ocp_qp_gpu_batch_solve(ocp_qp_gpu_batch *b)
     hipStream_t s = b->stream;
     b->launches = 0;
     b->n_compactions = 0;
+    b->n_tail_switches = 0;
     /* kernel classes: 0 init, 1 back_fact, 2 fwd_aff, 3 back_rhs, 4 fwd_corr, 5 finalize */
     b->prof_cls.clear();
     Prof prof;
@@ -1196,6 +1230,7 @@ double ocp_qp_gpu_batch_get_scalar(ocp_qp_gpu_batch *b, const char *f)
     if (!strcmp(f, "launches")) return (double) b->launches;
     if (!strcmp(f, "time_xcond")) return b->time_xcond;
     if (!strcmp(f, "compactions")) return (double) b->n_compactions;
+    if (!strcmp(f, "tail_switches")) return (double) b->n_tail_switches;
     if (!strcmp(f, "cond_N_active")) return b->pcond_state == 1 ? (double) b->cond_N : (double) b->N;
     {
         /* accumulated per-kernel-class event times (ms) and launch counts since the last reset */

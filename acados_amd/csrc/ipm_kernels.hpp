@@ -1195,6 +1195,23 @@ static __global__ void k_compact_scalars(GqpDev big, GqpDev small, const int *li
     }
 }
 
+/* statistics rows >= row0 of the sub-level slots whose instance has a row in the parent's table
+ * (the list is sorted: they are the first slots) */
+static __global__ void k_stat_merge(GqpDev big, GqpDev small, const int *list, int nslots, int row0)
+{
+    const int sidx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sidx >= nslots || sidx >= small.stat_inst) return;
+    const int i = list[sidx];
+    if (i >= big.stat_inst) return;
+    const int rows = big.stat_rows < small.stat_rows ? big.stat_rows : small.stat_rows;
+    for (int r = row0; r < rows; r++)
+        for (int c = 0; c < GQP_STAT_COLS; c++)
+        {
+            const double v = small.stat[((size_t) r * GQP_STAT_COLS + c) * small.stat_inst + sidx];
+            if (v != 0.0) big.stat[((size_t) r * GQP_STAT_COLS + c) * big.stat_inst + i] = v;
+        }
+}
+
 static __global__ void k_fill_u64(GArrU64 dst, uint64_t val, int nb, int e)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -181,7 +181,14 @@ def main():
     dom = max(prof, key=lambda c: prof[c][0])
     dom_ms, dom_cnt = prof[dom]
     b_in, b_out = algorithmic_bytes(N, nx, nu)
-    per_launch_bytes = B * (b_in + b_out)
+    # units one launch processes: launch j of the factor kernel sees the instances that have not converged before
+    # iteration j (iter >= j), the other sweeps those with iter > j; only the launches of the full batch are timed
+    # (the last survivors continue on a small wave-per-instance sub-batch)
+    launches_per_solve = max(dom_cnt // max(args.steps, 1), 1)
+    hist = np.bincount(iters, minlength=launches_per_solve + 1)
+    still = B - np.cumsum(hist)                      # still[j] = instances with iter > j
+    units = [(B if j == 0 else int(still[j - 1])) if dom == "back_fact" else int(still[j]) for j in range(launches_per_solve)]
+    per_launch_bytes = float(np.mean(units)) * (b_in + b_out)
     avg_s = dom_ms * 1e-3 / max(dom_cnt, 1)
     achieved = per_launch_bytes / avg_s / 1e9
     solves_per_s = world * B * args.steps / elapsed
@@ -221,7 +228,8 @@ def main():
         "roofline": {"bound": "hbm", "kernel": f"{kern_sym} ({dom}) of {gb.kernel_name}",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic,
-                     "bytes_per_launch": per_launch_bytes, "avg_launch_ms": avg_s * 1e3, "launches_timed": dom_cnt,
+                     "bytes_per_launch": per_launch_bytes, "units_per_launch": units, "avg_launch_ms": avg_s * 1e3,
+                     "launches_timed": dom_cnt,
                      "kernel_ms_share": {c: prof[c][0] for c in classes},
                      "whole_solve_GBps": solves_per_s / world * (b_in + b_out) / 1e9,
                      "whole_solve_frac": solves_per_s / world * (b_in + b_out) / 1e9 / HBM_PEAK_GBS},

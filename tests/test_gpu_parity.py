@@ -132,15 +132,22 @@ def test_full_size_properties_gpu(gpu_lib):
         pred = np.einsum("bij,bj->bi", data["A"], xk) + np.einsum("bij,bj->bi", data["B"], uk) + data["b"]
         assert np.max(np.abs(pred - xn)) <= 1e-7
         xk = xn
+    u0_default = gb.get("u", 0)[:64].copy()
+    assert int(gb.scalar("tail_switches")) == 1      # the last survivors finished one wave per instance
+    # with every level on the same kernels (tail_max = 0) the batch size must not change any instance's bits
+    gb.opts_set("tail_max", 0)
+    assert gb.solve() == 0
     u0_big = gb.get("u", 0)[:64].copy()
+    assert np.allclose(u0_default, u0_big, rtol=0.0, atol=1e-10)
     del gb
     small = {k: v[:64] for k, v in data.items()}
     gs = OcpQpGpuBatch(lqr_dims(N, 8, 3), 64)
     fill_lqr_batch(gs, small, N)
     for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
         gs.opts_set(f, 1e-8)
+    gs.opts_set("tail_max", 0)
     assert gs.solve() == 0
-    assert np.array_equal(gs.get("u", 0), u0_big)   # batch size must not change any instance's bits
+    assert np.array_equal(gs.get("u", 0), u0_big)
 
 
 def _check_batch_vs_oracle_gpu(qps, n_check, tol=1e-8, tol_stat=1e-8):

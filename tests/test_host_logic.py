@@ -121,6 +121,15 @@ def test_lqr_batch_and_ragged_hostsim(hostsim_lib):
     fill_lqr_batch(gb, data, N)
     gb.opts_set("tol_stat", 1e-8)
     assert gb.solve() == 0
+    # the last survivors (<= a quarter of the level) finish on the wave-per-instance kernels
+    assert gb.kernel_name.startswith("1tpi") and int(gb.scalar("tail_switches")) == 1
+    # ... and their statistics rows are merged back: the table of the slowest of the first 64 instances is
+    # complete (mu and the residual norms of every iteration, converged values in the last row)
+    it = gb.info("iter")
+    slow = int(np.argmax(it[:64]))
+    st = gb.stat(slow)
+    assert st.shape[0] >= it[slow] + 1 and np.all(st[: it[slow] + 1, 6] > 0.0)
+    assert st[it[slow], 7] <= 1e-8 and st[it[slow], 10] <= 1e-8
     x = [gb.get("x", k) for k in range(N + 1)]
     u = [gb.get("u", k) for k in range(N)]
     for i in (0, 1, 63, 64, 69):
@@ -180,6 +189,25 @@ def test_c4_shape_general_constraints_and_slacks_hostsim(hostsim_lib, monkeypatc
     monkeypatch.setenv("ACADOS_AMD_WPI", wpi)
     b = _check_batch_vs_oracle([chain_soft_qp(i, N=6) for i in range(2)], hostsim_lib)
     assert b.kernel_name.startswith("wpi-gen(nx=24,nu=3,ng=4,ns=8" if wpi == "1" else "1tpi<NX=24,NU=3,NG=4,NS=8>")
+
+
+def test_tail_switch_with_general_rows_hostsim(hostsim_lib, monkeypatch):
+    """a one-instance-per-lane level hands its last survivors to the wave-per-instance kernels; with
+    equality-flagged x0 and general rows the multipliers of the fixed variables must come out of the family
+    that finished the instance (regression: they were left at the value of the hand-over iteration)"""
+    from acados_amd import OcpQpGpuBatch
+    from acados_amd.generators import chain_soft_qp
+    monkeypatch.setenv("ACADOS_AMD_WPI", "0")
+    qps = [chain_soft_qp(i, N=5) for i in range(8)]
+    b = OcpQpGpuBatch.from_qps(qps, _clib=hostsim_lib)
+    for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+        b.opts_set(f, 1e-8)
+    assert b.solve() == 0
+    assert b.kernel_name.startswith("1tpi<") and int(b.scalar("tail_switches")) == 1
+    for i, qp in enumerate(qps):
+        o = OracleQp(qp)
+        assert o.solve(default_opts(tol_stat=1e-8)) == 0
+        compare_with_oracle(lambda k, f: b.get(f, k)[i], o, qp, 1e-7)
 
 
 def test_wave_per_instance_general_rows_shared_slacks_hostsim(hostsim_lib, monkeypatch):
@@ -302,6 +330,7 @@ def test_compaction_is_bit_identical_hostsim(hostsim_lib):
         fill_lqr_batch(gb, data, N)
         gb.opts_set("tol_stat", 1e-8)
         gb.opts_set("compact_min", cmin)
+        gb.opts_set("tail_max", 0)   # keep every level on the same kernels: this test is about bit identity
         assert gb.solve() == 0
         runs.append(gb)
     assert int(runs[0].scalar("compactions")) == 0 and int(runs[1].scalar("compactions")) >= 2
