@@ -5,10 +5,14 @@
  */
 #include "acados_amd/ocp_qp_interface.h"
 
+#include <hip/hip_runtime.h> /* pinned staging buffers only */
+
+#include <algorithm>
 #include <chrono>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <thread>
 #include <vector>
 
 #include "acados_amd/ocp_qp_gpu_batch.h"
@@ -25,6 +29,11 @@ struct gpu_ipm_opts
     int iter_max, warm_start, cond_pred_corr, print_level, ric_alg, t0_init, update_fact_exit;
 };
 
+/* one member array of ocp_qp_in / ocp_qp_out and its place in the per-instance bulk blob */
+enum { F_A, F_B, F_b, F_Q, F_S, F_R, F_q, F_r, F_lb, F_ub, F_lbm, F_ubm, F_C, F_D, F_lg, F_ug, F_lgm, F_ugm,
+       F_Zl, F_Zu, F_zl, F_zu, F_lls, F_lus, F_llsm, F_lusm, O_ux, O_pi, O_lam, O_t };
+struct blob_seg { int off, len, fid, k, shift; };
+
 struct batch_cache
 {
     ocp_qp_gpu_batch *batch = nullptr;
@@ -32,8 +41,73 @@ struct batch_cache
     std::vector<int> sig; /* dims + idxb + idxs_rev + idxe of the batch */
     std::vector<double> stat;
     std::vector<double> stage; /* host staging [n][len] */
-    std::vector<double> blob_in, blob_out; /* bulk pack / unpack staging: [n][bulk_len] */
+    /* bulk pack / unpack: segment tables (built once per batch) and PINNED staging [n][bulk_len] */
+    std::vector<blob_seg> seg_in, seg_out;
+    int L_in = 0, L_out = 0;
+    double *blob_in = nullptr, *blob_out = nullptr;
+    size_t cap_in = 0, cap_out = 0;
+    ~batch_cache()
+    {
+        if (blob_in) (void) hipHostFree(blob_in);
+        if (blob_out) (void) hipHostFree(blob_out);
+    }
 };
+
+inline const double *in_field(const ocp_qp_in *q, int fid, int k)
+{
+    switch (fid)
+    {
+        case F_A: return q->A[k]; case F_B: return q->B[k]; case F_b: return q->b[k];
+        case F_Q: return q->Q[k]; case F_S: return q->S[k]; case F_R: return q->R[k];
+        case F_q: return q->q[k]; case F_r: return q->r[k];
+        case F_lb: return q->lb[k]; case F_ub: return q->ub[k]; case F_lbm: return q->lb_mask[k]; case F_ubm: return q->ub_mask[k];
+        case F_C: return q->C[k]; case F_D: return q->D[k];
+        case F_lg: return q->lg[k]; case F_ug: return q->ug[k]; case F_lgm: return q->lg_mask[k]; case F_ugm: return q->ug_mask[k];
+        case F_Zl: return q->Zl[k]; case F_Zu: return q->Zu[k]; case F_zl: return q->zl[k]; case F_zu: return q->zu[k];
+        case F_lls: return q->lls[k]; case F_lus: return q->lus[k]; case F_llsm: return q->lls_mask[k]; case F_lusm: return q->lus_mask[k];
+    }
+    return nullptr;
+}
+
+inline double *out_field(ocp_qp_out *q, int fid, int k)
+{
+    switch (fid)
+    {
+        case O_ux: return q->ux[k]; case O_pi: return q->pi[k]; case O_lam: return q->lam[k]; case O_t: return q->t[k];
+    }
+    return nullptr;
+}
+
+/* instances [lo, hi) in parallel on host threads (member arrays of n QPs are copied one by one: the copies of
+ * different instances are independent) */
+template <class F>
+void par_instances(int n, F f)
+{
+    int T = (int) std::min<unsigned>(std::max(1u, std::thread::hardware_concurrency()), 16u);
+    T = std::min(T, (n + 127) / 128);
+    if (T <= 1) { f(0, n); return; }
+    std::vector<std::thread> th;
+    const int chunk = (n + T - 1) / T;
+    for (int t = 0; t < T; t++)
+    {
+        const int lo = t * chunk, hi = std::min(n, lo + chunk);
+        if (lo < hi) th.emplace_back(f, lo, hi);
+    }
+    for (auto &t : th) t.join();
+}
+
+void pinned_reserve(double *&p, size_t &cap, size_t cnt)
+{
+    if (cnt <= cap) return;
+    if (p) (void) hipHostFree(p);
+    if (hipHostMalloc((void **) &p, cnt * sizeof(double)) != hipSuccess)
+    {
+        printf("\nerror: ocp_qp_gpu_ipm: cannot allocate %zu bytes of pinned host memory\n", cnt * sizeof(double));
+        exit(1);
+    }
+    memset(p, 0, cnt * sizeof(double));
+    cap = cnt;
+}
 
 struct gpu_ipm_memory
 {
@@ -508,6 +582,8 @@ int ocp_qp_gpu_ipm_evaluate_batch(void *config, int n, void **qp_in_, void **qp_
         }
         bc->n = n;
         bc->sig = sig;
+        bc->seg_in.clear();
+        bc->seg_out.clear();
         for (int k = 0; k <= N; k++)
         {
             ocp_qp_gpu_batch_set_int(bc->batch, "idxb", k, ins[0]->idxb[k], d->nb[k]);
@@ -539,59 +615,84 @@ int ocp_qp_gpu_ipm_evaluate_batch(void *config, int n, void **qp_in_, void **qp_
      * ocp_nlp_common.c:2797-2894) and pack them: one host blob per instance, ONE host->device copy and ONE
      * launch for the whole batch (ocp_qp_gpu_batch_set_bulk) */
     std::vector<double> &stg = bc->stage;
+    if (bc->seg_in.empty())
     {
-        const int L = ocp_qp_gpu_batch_bulk_len(b, 0);
-        bc->blob_in.assign((size_t) n * L, 0.0);
-        double *blob = bc->blob_in.data();
-        auto push = [&](const char *name, int k, int len, auto getter) {
+        /* segment tables of the bulk blobs, once per device batch */
+        bc->L_in = ocp_qp_gpu_batch_bulk_len(b, 0);
+        bc->L_out = ocp_qp_gpu_batch_bulk_len(b, 1);
+        auto add = [&](std::vector<blob_seg> &tab, int output, const char *name, int k, int len, int fid, int shift) {
             if (len <= 0) return;
             int seg_len = 0;
-            const int off = ocp_qp_gpu_batch_bulk_offset(b, 0, name, k, &seg_len);
+            const int off = ocp_qp_gpu_batch_bulk_offset(b, output, name, k, &seg_len);
             if (off < 0 || seg_len != len)
             {
+                if (output) return;
                 printf("\nerror: ocp_qp_gpu_ipm: field %s at stage %d has no place in the device layout\n", name, k);
                 exit(1);
             }
-            for (int i = 0; i < n; i++) memcpy(blob + (size_t) i * L + off, getter(ins[i]), sizeof(double) * len);
+            tab.push_back(blob_seg{off, len, fid, k, shift});
         };
         for (int k = 0; k <= N; k++)
         {
-            const int nbu = d->nbu[k], nbx = d->nbx[k], ng = d->ng[k], ns = d->ns[k];
+            const int nu = d->nu[k], nx = d->nx[k], nbu = d->nbu[k], nbx = d->nbx[k], ng = d->ng[k], ns = d->ns[k];
+            std::vector<blob_seg> &ti = bc->seg_in, &to = bc->seg_out;
             if (k < N)
             {
-                push("A", k, vlen(d, "A", k), [&](ocp_qp_in *q) { return q->A[k]; });
-                push("B", k, vlen(d, "B", k), [&](ocp_qp_in *q) { return q->B[k]; });
-                push("b", k, vlen(d, "b", k), [&](ocp_qp_in *q) { return q->b[k]; });
+                add(ti, 0, "A", k, vlen(d, "A", k), F_A, 0);
+                add(ti, 0, "B", k, vlen(d, "B", k), F_B, 0);
+                add(ti, 0, "b", k, vlen(d, "b", k), F_b, 0);
             }
-            push("Q", k, vlen(d, "Q", k), [&](ocp_qp_in *q) { return q->Q[k]; });
-            push("S", k, vlen(d, "S", k), [&](ocp_qp_in *q) { return q->S[k]; });
-            push("R", k, vlen(d, "R", k), [&](ocp_qp_in *q) { return q->R[k]; });
-            push("q", k, vlen(d, "q", k), [&](ocp_qp_in *q) { return q->q[k]; });
-            push("r", k, vlen(d, "r", k), [&](ocp_qp_in *q) { return q->r[k]; });
-            push("lbu", k, nbu, [&](ocp_qp_in *q) { return q->lb[k]; });
-            push("ubu", k, nbu, [&](ocp_qp_in *q) { return q->ub[k]; });
-            push("lbx", k, nbx, [&](ocp_qp_in *q) { return q->lb[k] + nbu; });
-            if (d->nbxe[k] > 0) push("lbx#value", k, nbx, [&](ocp_qp_in *q) { return q->lb[k] + nbu; });
-            push("ubx", k, nbx, [&](ocp_qp_in *q) { return q->ub[k] + nbu; });
-            push("lbu_mask", k, nbu, [&](ocp_qp_in *q) { return q->lb_mask[k]; });
-            push("ubu_mask", k, nbu, [&](ocp_qp_in *q) { return q->ub_mask[k]; });
-            push("lbx_mask", k, nbx, [&](ocp_qp_in *q) { return q->lb_mask[k] + nbu; });
-            push("ubx_mask", k, nbx, [&](ocp_qp_in *q) { return q->ub_mask[k] + nbu; });
-            push("C", k, vlen(d, "C", k), [&](ocp_qp_in *q) { return q->C[k]; });
-            push("D", k, vlen(d, "D", k), [&](ocp_qp_in *q) { return q->D[k]; });
-            push("lg", k, ng, [&](ocp_qp_in *q) { return q->lg[k]; });
-            push("ug", k, ng, [&](ocp_qp_in *q) { return q->ug[k]; });
-            push("lg_mask", k, ng, [&](ocp_qp_in *q) { return q->lg_mask[k]; });
-            push("ug_mask", k, ng, [&](ocp_qp_in *q) { return q->ug_mask[k]; });
-            push("Zl", k, ns, [&](ocp_qp_in *q) { return q->Zl[k]; });
-            push("Zu", k, ns, [&](ocp_qp_in *q) { return q->Zu[k]; });
-            push("zl", k, ns, [&](ocp_qp_in *q) { return q->zl[k]; });
-            push("zu", k, ns, [&](ocp_qp_in *q) { return q->zu[k]; });
-            push("lls", k, ns, [&](ocp_qp_in *q) { return q->lls[k]; });
-            push("lus", k, ns, [&](ocp_qp_in *q) { return q->lus[k]; });
-            push("lls_mask", k, ns, [&](ocp_qp_in *q) { return q->lls_mask[k]; });
-            push("lus_mask", k, ns, [&](ocp_qp_in *q) { return q->lus_mask[k]; });
+            add(ti, 0, "Q", k, vlen(d, "Q", k), F_Q, 0);
+            add(ti, 0, "S", k, vlen(d, "S", k), F_S, 0);
+            add(ti, 0, "R", k, vlen(d, "R", k), F_R, 0);
+            add(ti, 0, "q", k, vlen(d, "q", k), F_q, 0);
+            add(ti, 0, "r", k, vlen(d, "r", k), F_r, 0);
+            add(ti, 0, "lbu", k, nbu, F_lb, 0);
+            add(ti, 0, "ubu", k, nbu, F_ub, 0);
+            add(ti, 0, "lbx", k, nbx, F_lb, nbu);
+            if (d->nbxe[k] > 0) add(ti, 0, "lbx#value", k, nbx, F_lb, nbu);
+            add(ti, 0, "ubx", k, nbx, F_ub, nbu);
+            add(ti, 0, "lbu_mask", k, nbu, F_lbm, 0);
+            add(ti, 0, "ubu_mask", k, nbu, F_ubm, 0);
+            add(ti, 0, "lbx_mask", k, nbx, F_lbm, nbu);
+            add(ti, 0, "ubx_mask", k, nbx, F_ubm, nbu);
+            add(ti, 0, "C", k, vlen(d, "C", k), F_C, 0);
+            add(ti, 0, "D", k, vlen(d, "D", k), F_D, 0);
+            add(ti, 0, "lg", k, ng, F_lg, 0);
+            add(ti, 0, "ug", k, ng, F_ug, 0);
+            add(ti, 0, "lg_mask", k, ng, F_lgm, 0);
+            add(ti, 0, "ug_mask", k, ng, F_ugm, 0);
+            add(ti, 0, "Zl", k, ns, F_Zl, 0);
+            add(ti, 0, "Zu", k, ns, F_Zu, 0);
+            add(ti, 0, "zl", k, ns, F_zl, 0);
+            add(ti, 0, "zu", k, ns, F_zu, 0);
+            add(ti, 0, "lls", k, ns, F_lls, 0);
+            add(ti, 0, "lus", k, ns, F_lus, 0);
+            add(ti, 0, "lls_mask", k, ns, F_llsm, 0);
+            add(ti, 0, "lus_mask", k, ns, F_lusm, 0);
+            const int nct = 2 * (d->nb[k] + ng + ns);
+            add(to, 1, "u", k, nu, O_ux, 0);
+            add(to, 1, "x", k, nx, O_ux, nu);
+            add(to, 1, "sl", k, ns, O_ux, nu + nx);
+            add(to, 1, "su", k, ns, O_ux, nu + nx + ns);
+            if (k < N) add(to, 1, "pi", k, d->nx[k + 1], O_pi, 0);
+            add(to, 1, "lam", k, nct, O_lam, 0);
+            add(to, 1, "t", k, nct, O_t, 0);
         }
+    }
+    {
+        /* every member array of every qp_in is re-read on every call (they alias ocp_nlp memory:
+         * ocp_nlp_common.c:2797-2894): host threads gather them into ONE pinned blob, then one host->device copy
+         * and one scatter launch move the whole batch (ocp_qp_gpu_batch_set_bulk) */
+        const size_t L = (size_t) bc->L_in;
+        pinned_reserve(bc->blob_in, bc->cap_in, (size_t) n * L);
+        double *blob = bc->blob_in;
+        const std::vector<blob_seg> &tab = bc->seg_in;
+        par_instances(n, [&](int lo, int hi) {
+            for (int i = lo; i < hi; i++)
+                for (const blob_seg &g : tab)
+                    memcpy(blob + (size_t) i * L + g.off, in_field(ins[i], g.fid, g.k) + g.shift, sizeof(double) * g.len);
+        });
         ocp_qp_gpu_batch_set_bulk(b, blob, 0);
     }
     if (o->warm_start >= 2)
@@ -620,30 +721,18 @@ int ocp_qp_gpu_ipm_evaluate_batch(void *config, int n, void **qp_in_, void **qp_
     ocp_qp_gpu_batch_solve(b);
     const double t_solved = now_s();
 
-    /* unpack: one gather launch + one device->host copy for the whole batch */
+    /* unpack: one gather launch + one device->host copy for the whole batch, then host threads scatter */
     {
-        const int L = ocp_qp_gpu_batch_bulk_len(b, 1);
-        bc->blob_out.resize((size_t) n * L);
-        ocp_qp_gpu_batch_get_bulk(b, bc->blob_out.data(), 0);
-        const double *blob = bc->blob_out.data();
-        auto pull = [&](const char *name, int k, int len, auto getter) {
-            if (len <= 0) return;
-            int seg_len = 0;
-            const int off = ocp_qp_gpu_batch_bulk_offset(b, 1, name, k, &seg_len);
-            if (off < 0) return;
-            for (int i = 0; i < n; i++) memcpy(getter(outs[i]), blob + (size_t) i * L + off, sizeof(double) * len);
-        };
-        for (int k = 0; k <= N; k++)
-        {
-            const int nu = d->nu[k], nx = d->nx[k], ns = d->ns[k], nct = 2 * (d->nb[k] + d->ng[k] + ns);
-            pull("u", k, nu, [&](ocp_qp_out *q) { return q->ux[k]; });
-            pull("x", k, nx, [&](ocp_qp_out *q) { return q->ux[k] + nu; });
-            pull("sl", k, ns, [&](ocp_qp_out *q) { return q->ux[k] + nu + nx; });
-            pull("su", k, ns, [&](ocp_qp_out *q) { return q->ux[k] + nu + nx + ns; });
-            if (k < N) pull("pi", k, d->nx[k + 1], [&](ocp_qp_out *q) { return q->pi[k]; });
-            pull("lam", k, nct, [&](ocp_qp_out *q) { return q->lam[k]; });
-            pull("t", k, nct, [&](ocp_qp_out *q) { return q->t[k]; });
-        }
+        const size_t L = (size_t) bc->L_out;
+        pinned_reserve(bc->blob_out, bc->cap_out, (size_t) n * L);
+        ocp_qp_gpu_batch_get_bulk(b, bc->blob_out, 0);
+        const double *blob = bc->blob_out;
+        const std::vector<blob_seg> &tab = bc->seg_out;
+        par_instances(n, [&](int lo, int hi) {
+            for (int i = lo; i < hi; i++)
+                for (const blob_seg &g : tab)
+                    memcpy(out_field(outs[i], g.fid, g.k) + g.shift, blob + (size_t) i * L + g.off, sizeof(double) * g.len);
+        });
     }
     std::vector<int> st(n), it(n);
     ocp_qp_gpu_batch_get_info(b, "status", st.data());
