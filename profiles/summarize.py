@@ -13,7 +13,8 @@ def kernel(db):
         print(f"{name[:80]:80s} {calls:6d} {tot:12.1f} {avg:10.1f} {pct:6.2f}")
     print("\nper-dispatch durations of the IPM kernels (us), in launch order, first 60:")
     rows = cur.execute("select name,duration,vgpr_count,accum_vgpr_count,sgpr_count,scratch_size from kernels "
-                       "where name like '%gqp::k_backward%' or name like '%gqp::k_forward%' order by start limit 60").fetchall()
+                       "where name like '%gqp::k_backward%' or name like '%gqp::k_forward%' or name like '%gqp::kb_%' "
+                       "or name like '%gqp::kw_%' order by start limit 60").fetchall()
     for name, dur, v, a, s, sc in rows:
         short = name.split("gqp::")[1].split("(")[0]
         print(f"  {short:40s} {dur / 1e3:10.1f}  vgpr {v} agpr {a} sgpr {s} scratch {sc}")
