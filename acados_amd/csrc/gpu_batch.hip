@@ -154,6 +154,16 @@ void opts_default(GqpOpts &o)
     o.iter_max = 50; o.pred_corr = 1; o.cond_pred_corr = 1; o.warm_start = 0;
 }
 
+/* options as the kernels see them: the complementarity target never drops below 1e-3 tol_comp (barrier floor,
+ * see oracle/ocp_qp_oracle.c tau_eff: below that only the rounding error of the Newton step grows) */
+GqpOpts effective_opts(const GqpOpts &o)
+{
+    GqpOpts e = o;
+    const double f = 1e-3 * o.tol_comp;
+    if (e.tau_min < f) e.tau_min = f;
+    return e;
+}
+
 int padded_var(const ocp_qp_gpu_batch *b, int k, int iv)
 {
     /* index in [u(nu_k); x(nx_k)] -> index in padded [u(NU); x(NX)] */
@@ -954,7 +964,7 @@ static void run_ipm(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch *root, Prof &prof, hip
 {
     const IpmKernels K = pick_kernels(b);
     GqpDev D = b->D;
-    GqpOpts O = root->O;
+    GqpOpts O = effective_opts(root->O);
     for (;; it++)
     {
         if (b == root) prof.begin(1, s); /* per-class timing covers the root level only (full-batch launches) */
@@ -1095,7 +1105,7 @@ int ocp_qp_gpu_batch_solve(ocp_qp_gpu_batch *b)
     ensure_stat(b);
     const KernelSet *ks = b->ks;
     GqpDev D = b->D;
-    GqpOpts O = b->O;
+    GqpOpts O = effective_opts(b->O);
     const dim3 grid((b->B + 63) / 64), block(64);
     hipStream_t s = b->stream;
     b->launches = 0;

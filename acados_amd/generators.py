@@ -200,6 +200,111 @@ def chain_soft_qp(i=0, N=40, nx=24, nu=3, seed=1):
     return qp
 
 
+def chain_soft_dims(N=40, nx=24, nu=3, ng=4, nsx=4):
+    """dims of the C4 class (see chain_soft_qp)"""
+    d = AcadosOcpQpDims(N)
+    d.nx[:] = nx
+    d.nu[:N] = nu
+    d.nbu[:N] = nu
+    d.nbx[0] = nx
+    d.nbx[1:] = nsx
+    d.ng[1:] = ng
+    d.ns[1:] = nsx + ng
+    d.nb[:] = d.nbu + d.nbx
+    d.nbxe[0] = nx
+    return d
+
+
+def chain_soft_batch(N=40, nx=24, nu=3, batch=1024, seed=1, first=0):
+    """Configuration C4 for whole batches: the same problem class as chain_soft_qp (same structure, same
+    distributions) from the chunked counter-based streams of this module, as arrays with leading dim
+    `batch`; per-stage fields carry a stage axis.  Global instances [first, first + batch)."""
+    ng, nsx = 4, 4
+    T = -2.0 * np.eye(nx) + np.eye(nx, k=1) + np.eye(nx, k=-1)
+    A = (np.eye(nx) + 0.1 * T)[None] + 0.01 * _stream(seed, 101, (batch, nx, nx), "normal", first)
+    B0 = np.zeros((nx, nu))
+    B0[nx - nu:, :] = 0.1 * np.eye(nu)
+    B = B0[None] + 0.01 * _stream(seed, 102, (batch, nx, nu), "normal", first)
+    Qd = 5.05 + 4.95 * _stream(seed, 103, (batch, nx), first=first)      # U(0.1, 10)
+    Rd = 0.505 + 0.495 * _stream(seed, 104, (batch, nu), first=first)    # U(0.01, 1)
+    x0 = _stream(seed, 105, (batch, nx), first=first)
+    q = Qd[:, None, :] * (0.1 * _stream(seed, 106, (batch, N + 1, nx), "normal", first))
+    r = Rd[:, None, :] * (0.1 * _stream(seed, 107, (batch, N, nu), "normal", first))
+    b = 0.01 * _stream(seed, 108, (batch, N, nx), "normal", first)
+    C = _stream(seed, 109, (batch, N, ng, nx), "normal", first) / np.sqrt(nx)      # stages 1..N
+    D = _stream(seed, 110, (batch, N, ng, nu), "normal", first) / np.sqrt(nu)      # stages 1..N-1 use it
+    return dict(A=A, B=B, Qd=Qd, Rd=Rd, x0=x0, q=q, r=r, b=b, C=C, D=D, ng=ng, nsx=nsx)
+
+
+def chain_soft_instance_qp(data, i, N):
+    """One instance of chain_soft_batch as an AcadosOcpQp (oracle / parity tests)."""
+    nx, nu = data["A"].shape[1], data["B"].shape[2]
+    ng, nsx = data["ng"], data["nsx"]
+    ixs = nu + 6 * np.arange(nsx) + 1
+    qp = AcadosOcpQp(N)
+    for k in range(N + 1):
+        last = k == N
+        nuk = 0 if last else nu
+        qp.set("Q", k, np.diag(data["Qd"][i])); qp.set("q", k, data["q"][i, k])
+        qp.set("R", k, np.diag(data["Rd"][i])[:nuk, :nuk]); qp.set("r", k, data["r"][i, k] if not last else np.zeros(0))
+        qp.set("S", k, np.zeros((nuk, nx)))
+        if not last:
+            qp.set("A", k, data["A"][i]); qp.set("B", k, data["B"][i]); qp.set("b", k, data["b"][i, k])
+        qp.set("lbu", k, -1.0 * np.ones(nuk)); qp.set("ubu", k, 1.0 * np.ones(nuk))
+        if k == 0:
+            qp.set("lbx", k, data["x0"][i]); qp.set("ubx", k, data["x0"][i])
+            qp.set("idxb", k, np.arange(nu + nx)); qp.set("idxe", k, nu + np.arange(nx))
+            continue
+        qp.set("C", k, data["C"][i, k - 1]); qp.set("D", k, data["D"][i, k - 1][:, :nuk])
+        qp.set("lg", k, -0.5 * np.ones(ng)); qp.set("ug", k, 0.5 * np.ones(ng))
+        qp.set("lbx", k, -0.3 * np.ones(nsx)); qp.set("ubx", k, 0.3 * np.ones(nsx))
+        qp.set("idxb", k, np.concatenate([np.arange(nuk), (ixs - nu) + nuk]))
+        qp.set("idxs_rev", k, np.concatenate([-np.ones(nuk, dtype=int), np.arange(nsx), nsx + np.arange(ng)]))
+        ns = nsx + ng
+        qp.set("Zl", k, 1e2 * np.ones(ns)); qp.set("Zu", k, 1e2 * np.ones(ns))
+        qp.set("zl", k, 1e1 * np.ones(ns)); qp.set("zu", k, 1e1 * np.ones(ns))
+        qp.set("lls", k, np.zeros(ns)); qp.set("lus", k, np.zeros(ns))
+    qp.make_consistent()
+    return qp
+
+
+def fill_chain_soft_batch(gb, data, N):
+    """Pack chain_soft_batch() data into an OcpQpGpuBatch created from chain_soft_dims(N)."""
+    Bn, nx, nu = data["A"].shape[0], data["A"].shape[1], data["B"].shape[2]
+    ng, nsx = data["ng"], data["nsx"]
+    ns = nsx + ng
+    ixs = 6 * np.arange(nsx) + 1
+    ones = lambda m, v=1.0: np.full((Bn, m), v)
+    colmaj = lambda a: np.ascontiguousarray(np.transpose(a, (0, 2, 1)).reshape(a.shape[0], -1))
+    eye_nx = np.eye(nx)[None]
+    Q = colmaj(data["Qd"][:, :, None] * eye_nx)
+    R = colmaj(data["Rd"][:, :, None] * np.eye(nu)[None])
+    A, Bm = colmaj(data["A"]), colmaj(data["B"])
+    gb.set_int("idxe", 0, nu + np.arange(nx))
+    for k in range(1, N + 1):
+        nuk = nu if k < N else 0
+        gb.set_int("idxb", k, np.concatenate([np.arange(nuk), ixs + nuk]))
+        gb.set_int("idxs_rev", k, np.concatenate([-np.ones(nuk, dtype=int), np.arange(nsx), nsx + np.arange(ng)]))
+    for k in range(N + 1):
+        last = k == N
+        gb.set("Q", k, Q); gb.set("q", k, np.ascontiguousarray(data["q"][:, k]))
+        if not last:
+            gb.set("R", k, R); gb.set("r", k, np.ascontiguousarray(data["r"][:, k]))
+            gb.set("A", k, A); gb.set("B", k, Bm); gb.set("b", k, np.ascontiguousarray(data["b"][:, k]))
+            gb.set("lbu", k, ones(nu, -1.0)); gb.set("ubu", k, ones(nu, 1.0))
+        if k == 0:
+            gb.set("lbx", 0, data["x0"]); gb.set("ubx", 0, data["x0"])
+            continue
+        gb.set("C", k, colmaj(data["C"][:, k - 1]))
+        if not last:
+            gb.set("D", k, colmaj(data["D"][:, k - 1]))
+        gb.set("lg", k, ones(ng, -0.5)); gb.set("ug", k, ones(ng, 0.5))
+        gb.set("lbx", k, ones(nsx, -0.3)); gb.set("ubx", k, ones(nsx, 0.3))
+        gb.set("Zl", k, ones(ns, 1e2)); gb.set("Zu", k, ones(ns, 1e2))
+        gb.set("zl", k, ones(ns, 1e1)); gb.set("zu", k, ones(ns, 1e1))
+        gb.set("lls", k, ones(ns, 0.0)); gb.set("lus", k, ones(ns, 0.0))
+
+
 C5_CLASSES = [(nx, int(np.ceil(nx / 4)), N) for nx in (4, 12, 24) for N in (20, 50, 100)]
 
 

@@ -190,6 +190,79 @@ def test_c4_one_instance_per_lane_kernels_gpu(gpu_lib, monkeypatch):
     assert b.kernel_name == "1tpi<NX=24,NU=3,NG=4,NS=8>"
 
 
+def test_c4_full_size_properties_gpu(gpu_lib):
+    """C4 at the BASELINE size (16,384 instances, N=40, nx=24, nu=3, 4 soft state bounds, 4 soft general rows,
+    ns=8): size-independent properties over the whole batch -- status 0, the four KKT residual norms <= 1e-8,
+    dynamics round trip, hard input bounds, slacks >= 0 and soft rows satisfied up to their slack, x_0 as given --
+    plus four instances against the oracle."""
+    from acados_amd import OcpQpGpuBatch
+    from acados_amd.generators import chain_soft_batch, chain_soft_dims, chain_soft_instance_qp, fill_chain_soft_batch
+    N, B = 40, 16384
+    data = chain_soft_batch(N=N, batch=B, seed=1)
+    gb = OcpQpGpuBatch(chain_soft_dims(N), B)
+    fill_chain_soft_batch(gb, data, N)
+    for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+        gb.opts_set(f, 1e-8)
+    assert gb.solve() == 0 and gb.kernel_name.startswith("wpi-gen(nx=24,nu=3,ng=4,ns=8")
+    assert np.all(gb.info("status") == 0)
+    for n in ("res_stat", "res_eq", "res_ineq", "res_comp"):
+        assert gb.info(n).max() <= 1e-8
+    assert gb.info("iter").max() <= 50
+    xk = gb.get("x", 0)
+    assert np.array_equal(xk, data["x0"])
+    ixs = 6 * np.arange(4) + 1
+    for k in range(N + 1):
+        if k < N:
+            uk = gb.get("u", k)
+            assert np.abs(uk).max() <= 1.0 + 1e-9
+            xn = gb.get("x", k + 1)
+            pred = np.einsum("bij,bj->bi", data["A"], xk) + np.einsum("bij,bj->bi", data["B"], uk) + data["b"][:, k]
+            assert np.max(np.abs(pred - xn)) <= 1e-7
+        if k > 0:
+            sl, su = gb.get("sl", k), gb.get("su", k)
+            assert sl.min() >= -1e-9 and su.min() >= -1e-9
+            xs = xk[:, ixs]
+            assert np.all(xs >= -0.3 - sl[:, :4] - 1e-7) and np.all(xs <= 0.3 + su[:, :4] + 1e-7)
+            g = np.einsum("bij,bj->bi", data["C"][:, k - 1], xk)
+            if k < N:
+                g = g + np.einsum("bij,bj->bi", data["D"][:, k - 1], gb.get("u", k))
+            assert np.all(g >= -0.5 - sl[:, 4:] - 1e-7) and np.all(g <= 0.5 + su[:, 4:] + 1e-7)
+        if k < N:
+            xk = xn
+    for i in (0, 5461, 10922, 16383):
+        qp = chain_soft_instance_qp(data, i, N)
+        o = OracleQp(qp)
+        assert o.solve(default_opts(tol_stat=1e-8)) == 0
+        compare_with_oracle(lambda k, f: gb.get(f, k)[i], o, qp, 1e-7)
+
+
+def test_c5_per_gpu_share_properties_gpu(gpu_lib):
+    """C5 at the per-GPU share of the BASELINE size (524,288 instances on 8 GPUs = 65,536 per GPU, split over
+    the 9 shape classes): every class as one device batch, size-independent properties over all instances"""
+    from acados_amd import OcpQpGpuBatch
+    from acados_amd.generators import C5_CLASSES, fill_lqr_batch, lqr_dims, random_lqr_batch
+    per_class = 65536 // len(C5_CLASSES)
+    for (nx, nu, N) in C5_CLASSES:
+        data = random_lqr_batch(N=N, nx=nx, nu=nu, batch=per_class, seed=100 + nx + N)
+        gb = OcpQpGpuBatch(lqr_dims(N, nx, nu), per_class)
+        fill_lqr_batch(gb, data, N)
+        for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+            gb.opts_set(f, 1e-8)
+        assert gb.solve() == 0, (nx, nu, N, gb.kernel_name)
+        for n in ("res_stat", "res_eq", "res_ineq", "res_comp"):
+            assert gb.info(n).max() <= 1e-8
+        xk = gb.get("x", 0)
+        assert np.array_equal(xk, data["x0"])
+        for k in range(N):
+            uk = gb.get("u", k)
+            assert uk.min() >= -0.5 - 1e-9 and uk.max() <= 0.5 + 1e-9
+            xn = gb.get("x", k + 1)
+            pred = np.einsum("bij,bj->bi", data["A"], xk) + np.einsum("bij,bj->bi", data["B"], uk) + data["b"]
+            assert np.max(np.abs(pred - xn)) <= 1e-6 * max(1.0, np.abs(xn).max())
+            xk = xn
+        del gb
+
+
 def test_c5_mixed_shape_classes_gpu(gpu_lib):
     """C5: the 9 shape classes (nx in {4,12,24}, N in {20,50,100}) bucketed by dims.signature(),
     plus the multi-phase class; every bucket is one device batch"""
