@@ -873,6 +873,20 @@ __global__ void __launch_bounds__(64) kw_factor(GqpDev D, GqpOpts O, int redo)
         }
         __syncthreads();
         GQP_TICK(0);
+        /* touch the next stage's matrix blocks (one 8-byte load per 64-byte line): by the time the stage loop
+         * comes round, they wait in L2 instead of HBM.  The values are only looked at after the Cholesky.
+         * Only from T8 = 3 on: the smaller kernels sit at 128 VGPRs (4 waves per SIMD) and the handful of
+         * registers this costs would take one wave away (measured: nx=12 nu=3 lost 20 %). */
+        double pf0 = 0.0, pf1 = 0.0, pf2 = 0.0, pf3 = 0.0;
+        if (T8 >= 3 && k > 0)
+        {
+            const int e8 = lane * 8, nb_ = n * NX;
+            if (e8 < NP) pf0 = WAT(D.RSQ, (k - 1) * NP + e8);
+            if (e8 < nb_) pf1 = WAT(D.BAt, (k - 1) * nb_ + e8);
+            if (e8 + 512 < nb_) pf2 = WAT(D.BAt, (k - 1) * nb_ + e8 + 512);
+            if (e8 + 1024 < nb_) pf3 = WAT(D.BAt, (k - 1) * nb_ + e8 + 1024);
+            if (e8 + 512 < NP) pf0 += WAT(D.RSQ, (k - 1) * NP + e8 + 512);
+        }
 
         GQP_TICK(6);
         /* ---- vector part, lane = variable: rb, [B A] pi+, H v, box row ---- */
@@ -1201,6 +1215,7 @@ __global__ void __launch_bounds__(64) kw_factor(GqpDev D, GqpOpts O, int redo)
                 else if (lane > j) m -= lmine * lj;
             }
         }
+        if (T8 >= 3 && pf0 + pf1 + pf2 + pf3 == 1.2345678e-300) L.red[lane] = pf0; /* keeps the touch loads alive; never true in practice, harmless if it were */
         __syncthreads(); /* Hp (packed H) is dead: it receives the packed factor */
         GQP_TICK(3);
 #pragma unroll
@@ -1298,6 +1313,20 @@ __device__ static inline WpiLds3 wpi3_carve(double *sm, int NX, int NU)
     L.rb = p; p += 64; L.w0 = p; p += 64; L.y = p; p += 64; L.pn = p; p += 64;
     L.dv = p; p += 64; L.dx = p; p += 64; L.bc = p; p += 64; L.red = p; p += 64;
     return L;
+}
+
+/* touch the matrix blocks of stage `ks` (one 8-byte load per 64-byte line) so that they wait in L2 when the stage
+ * loop comes round; the returned sum is only looked at much later (keeps the loads alive, costs no wait) */
+__device__ static inline double wpi_touch(const GArr &M1, int NP, const GArr &BAt, int nb_, int inst, int ks, int lane)
+{
+    const int e8 = lane * 8;
+    double a = 0.0, b = 0.0, c = 0.0, d = 0.0;
+    if (e8 < NP) a = WAT(M1, ks * NP + e8);
+    if (e8 + 512 < NP) b = WAT(M1, ks * NP + e8 + 512);
+    if (e8 < nb_) c = WAT(BAt, ks * nb_ + e8);
+    if (e8 + 512 < nb_) d = WAT(BAt, ks * nb_ + e8 + 512);
+    if (e8 + 1024 < nb_) c += WAT(BAt, ks * nb_ + e8 + 1024);
+    return (a + b) + (c + d);
 }
 
 /* coalesced [B A]' -> LDS rows of odd stride */
@@ -1436,6 +1465,7 @@ __global__ void __launch_bounds__(64) kw_backrhs(GqpDev D, GqpOpts O, int redo)
                 for (int g = 0; g < S.ng; g++) m += C.G[g * C.SG + lane] * C.nuG[g];
         }
         __syncthreads();
+        const double pf = k > 0 ? wpi_touch(D.Lf, NP, D.BAt, n * NX, inst, k - 1, lane) : 0.0;
         /* y = Lx+ (Lx+' rb) + p+ with the x-block of the factor handled one stage ago */
         if (lane < NX)
         {
@@ -1478,6 +1508,7 @@ __global__ void __launch_bounds__(64) kw_backrhs(GqpDev D, GqpOpts O, int redo)
             WAT(D.lf, k * n + lane) = m;
             if (lane >= NU) L.pn[lane - NU] = m;
         }
+        if (pf == 1.2345678e-300) L.bc[2] = pf; /* never true in practice: keeps the touch loads alive */
         cur ^= 1;
         __syncthreads();
     }
@@ -1527,6 +1558,7 @@ __global__ void __launch_bounds__(64) kw_fwd(GqpDev D, GqpOpts O, int redo)
         const double rdl = al ? WAT(D.rd, el) : 0.0, rdu = au ? WAT(D.rd, eu) : 0.0;
         const double pl = (CORR && al) ? WAT(D.pcorr, el) : 0.0, pu = (CORR && au) ? WAT(D.pcorr, eu) : 0.0;
         __syncthreads();
+        const double pf = k < D.N ? wpi_touch(D.Lf, NP, D.BAt, n * NX, inst, k + 1, lane) : 0.0;
 
         if (PFORM && k == 0)
         {
@@ -1752,6 +1784,7 @@ __global__ void __launch_bounds__(64) kw_fwd(GqpDev D, GqpOpts O, int redo)
         }
         __syncthreads();
         if (lane < NX) L.dx[lane] = dxn;
+        if (pf == 1.2345678e-300) L.bc[2] = pf; /* never true in practice: keeps the touch loads alive */
         __syncthreads();
     }
 
