@@ -30,6 +30,16 @@ def test_product_library_exports_declared_symbols():
     assert not missing, f"symbols declared but not exported: {missing}"
 
 
+def test_c_abi_headers_are_plain_c():
+    """include/*.h is what a C maintainer binds: both headers must compile as C11 on their own"""
+    import subprocess
+    for h in ("ocp_qp_gpu_batch.h", "ocp_qp_interface.h"):
+        src = f'#include "acados_amd/{h}"\nint main(void) {{ return 0; }}\n'
+        r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), "-x", "c", "-"],
+                           input=src.encode(), capture_output=True)
+        assert r.returncode == 0, r.stderr.decode()
+
+
 def test_product_path_has_no_cpu_fallback():
     """the package loader only knows the HIP library; a missing library raises"""
     from acados_amd import _lib
