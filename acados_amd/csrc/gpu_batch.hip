@@ -91,7 +91,9 @@ struct ocp_qp_gpu_batch
     int force_NX = 0, force_NU = 0; /* child batches are pinned to the kernel shape the condense kernel writes */
     int pcond_state = 0;            /* 0 unchecked, 1 active, -1 not applicable (message printed once) */
     ocp_qp_gpu_batch *child = nullptr;
-    const PcondSet *pc = nullptr;
+    const PcondSet *pc = nullptr;   /* compiled one-instance-per-lane condensing kernels, or ... */
+    int pc_rt = 0;                  /* ... the run-time-shaped wave-per-instance ones (kw_pcond / kw_pexpand) */
+    size_t pc_shmem = 0;
     std::vector<int> blk_start;
     gqp::PcondMap pmap;
     double time_xcond = 0.0;
@@ -794,12 +796,21 @@ static void pcond_setup(ocp_qp_gpu_batch *b)
         if (b->nbx[k] && !is_start[k]) { decline("state bounds inside a block would become general constraints (not condensed by this build)"); return; }
     }
     b->pc = nullptr;
+    b->pc_rt = 0;
     for (int q = 0; q < g_n_pcond_sets; q++)
         if (g_pcond_sets[q].NX == b->ks->NX && g_pcond_sets[q].NU == b->ks->NU && g_pcond_sets[q].BSMAX >= bsmax &&
             (!b->pc || g_pcond_sets[q].BSMAX < b->pc->BSMAX))
             b->pc = &g_pcond_sets[q];
-    if (!b->pc) { decline("no condensing kernel is compiled for this shape / block size"); return; }
-    const int NU = b->ks->NU, BS = b->pc->BSMAX;
+    /* the wave-per-instance condensing kernels take every shape with nx + bs*nu <= 64 at run time; the compiled
+     * one-instance-per-lane ones remain as the cross-check (ACADOS_AMD_PCOND_1TPI=1) */
+    {
+        const char *e1 = getenv("ACADOS_AMD_PCOND_1TPI");
+        const bool want_1tpi = e1 && atoi(e1) != 0;
+        if (!(want_1tpi && b->pc) && b->ks->NX + bsmax * b->ks->NU <= 64) b->pc_rt = 1;
+    }
+    if (!b->pc && !b->pc_rt) { decline("no condensing kernel covers this shape / block size"); return; }
+    const int NU = b->ks->NU, BS = b->pc_rt ? bsmax : b->pc->BSMAX;
+    b->pc_shmem = gqp::pcondw_lds_doubles(b->ks->NX, NU, BS * NU) * sizeof(double);
 
     /* child dims + structure */
     std::vector<int> cnx(N2 + 1), cnu(N2 + 1), cnbx(N2 + 1), cnbu(N2 + 1), zero(N2 + 1, 0);
@@ -865,6 +876,21 @@ static void pcond_setup(ocp_qp_gpu_batch *b)
     b->pcond_state = 1;
 }
 
+static void pcond_launch(ocp_qp_gpu_batch *b, bool expand)
+{
+    ocp_qp_gpu_batch *c = b->child;
+    if (b->pc_rt)
+    {
+        if (expand) GQP_LAUNCH_COOP(gqp::kw_pexpand, dim3(b->B), dim3(64), b->pc_shmem, b->stream, b->D, c->D, b->pmap);
+        else GQP_LAUNCH_COOP(gqp::kw_pcond, dim3(b->B), dim3(64), b->pc_shmem, b->stream, b->D, c->D, b->pmap);
+    }
+    else
+    {
+        const kern_pcond_t kern = expand ? b->pc->expand : b->pc->cond;
+        hipLaunchKernelGGL(kern, dim3((b->B + 63) / 64), dim3(64), 0, b->stream, b->D, c->D, b->pmap);
+    }
+}
+
 static int pcond_solve(ocp_qp_gpu_batch *b, int mode = 3)
 {
     ocp_qp_gpu_batch *c = b->child;
@@ -875,12 +901,12 @@ static int pcond_solve(ocp_qp_gpu_batch *b, int mode = 3)
     c->O = b->O;
     c->print_level = b->print_level;
     HIPCHK(hipEventRecord(e0, b->stream));
-    hipLaunchKernelGGL(b->pc->cond, grid, block, 0, b->stream, b->D, c->D, b->pmap);
+    pcond_launch(b, false);
     HIPCHK(hipEventRecord(e1, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     const int bad = ocp_qp_gpu_batch_solve(c);
     HIPCHK(hipEventRecord(e2, b->stream));
-    hipLaunchKernelGGL(b->pc->expand, grid, block, 0, b->stream, b->D, c->D, b->pmap);
+    pcond_launch(b, true);
     HIPCHK(hipEventRecord(e3, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     HIPCHK(hipGetLastError());
@@ -1272,7 +1298,7 @@ int ocp_qp_gpu_batch_condense_lhs(ocp_qp_gpu_batch *b)
     if (b->pcond_state == 0) pcond_setup(b);
     if (b->pcond_state != 1) return 0;
     b->pmap.mode = 1;
-    hipLaunchKernelGGL(b->pc->cond, dim3((b->B + 63) / 64), dim3(64), 0, b->stream, b->D, b->child->D, b->pmap);
+    pcond_launch(b, false);
     HIPCHK(hipStreamSynchronize(b->stream));
     b->lhs_ready = true;
     return 0;

@@ -252,6 +252,268 @@ __global__ void __launch_bounds__(64) k_pexpand(GqpDev P, GqpDev Cd, PcondMap Mp
     for (int q = 0; q < 4; q++) P.res[q * Bp + i] = Cd.res[q * Bp + i];
 }
 
+/* ---------------------------------------------------------------------------------------------------
+ * Wave-per-instance versions (run-time dims, any NX + BS*NU <= 64): one 64-lane workgroup condenses /
+ * expands one instance, the block matrices live in LDS and the lanes split the output entries.  Parent and
+ * child arrays are addressed through a layout-agnostic accessor (either may be wave-tiled or instance-major).
+ * Same arithmetic as k_pcond / k_pexpand above, which stay as the one-instance-per-lane reference
+ * (ACADOS_AMD_PCOND_1TPI=1).
+ * --------------------------------------------------------------------------------------------------- */
+#ifndef GQP_DYN_SHARED
+#define GQP_DYN_SHARED(name) extern __shared__ double name[]
+#endif
+#define PLAT(arr, e) (arr).p[(arr).aos ? (size_t) inst * (size_t) (arr).E + (size_t) (e) \
+                                       : ((size_t) (inst >> 6) * (size_t) (arr).E + (size_t) (e)) * 64 + (size_t) (inst & 63)]
+
+__host__ __device__ static inline size_t pcondw_lds_doubles(int NX, int NU, int NUC)
+{
+    const int n = NX + NU, NP = n * (n + 1) / 2, nc = NUC + NX, ncp = nc | 1, NPC = nc * (nc + 1) / 2;
+    return (size_t) NP + (size_t) n * NX + 3 * (size_t) NX * ncp + NPC + 2 * (size_t) nc + 6 * 64 + 8;
+}
+
+static __global__ void __launch_bounds__(64) kw_pcond(GqpDev P, GqpDev Cd, PcondMap Mp)
+{
+    GQP_DYN_SHARED(smem);
+    const int NX = P.NX, NU = P.NU, n = NX + NU, NP = n * (n + 1) / 2;
+    const int NUC = Cd.NU, nc = NUC + NX, ncp = nc | 1, NPC = nc * (nc + 1) / 2;
+    const int inst = blockIdx.x, lane = threadIdx.x;
+    if (inst >= P.B) return;
+    double *H = smem, *Bl = H + NP, *X = Bl + n * NX, *Xn = X + NX * ncp, *T = Xn + NX * ncp, *Hb = T + NX * ncp;
+    double *gb = Hb + NPC, *y = gb + nc + nc, *g = y + 64, *c = g + 64, *cn = c + 64, *bl = cn + 64;
+    auto Hs = [&](int r, int q) { return r >= q ? H[PK(r, q)] : H[PK(q, r)]; };
+
+    for (int jb = 0; jb <= Mp.N2; jb++)
+    {
+        const int k0 = Mp.blk_start[jb < Mp.N2 ? jb : Mp.N2];
+        const int k1 = jb < Mp.N2 ? Mp.blk_start[jb + 1] : P.N + 1; /* terminal: stage N alone */
+        const int bs = jb < Mp.N2 ? k1 - k0 : 1;
+        for (int e = lane; e < NX * ncp; e += 64) X[e] = 0.0;
+        for (int e = lane; e < NPC; e += 64) Hb[e] = 0.0;
+        for (int e = lane; e < nc; e += 64) gb[e] = 0.0;
+        c[lane] = 0.0;
+        __syncthreads();
+        if (lane < NX) X[lane * ncp + NUC + lane] = 1.0;
+        __syncthreads();
+
+        for (int ii = 0; ii < bs; ii++)
+        {
+            const int k = k0 + ii, u0 = ii * NU;
+            for (int e = lane; e < NP; e += 64) H[e] = PLAT(P.RSQ, k * NP + e);
+            for (int e = lane; e < n * NX; e += 64) Bl[e] = PLAT(P.BAt, k * n * NX + e);
+            if (lane < n) g[lane] = PLAT(P.rq, k * n + lane);
+            if (lane < NX) bl[lane] = PLAT(P.bvec, k * NX + lane);
+            __syncthreads();
+            /* y = H [0; c] + g */
+            if (lane < n)
+            {
+                double a = g[lane];
+                for (int q = 0; q < NX; q++) a += Hs(lane, NU + q) * c[q];
+                y[lane] = a;
+            }
+            /* T = Q X */
+            if (Mp.mode & 1)
+                for (int e = lane; e < NX * nc; e += 64)
+                {
+                    const int r = e / nc, col = e - r * nc;
+                    double s = 0.0;
+                    for (int q = 0; q < NX; q++) s += Hs(NU + r, NU + q) * X[q * ncp + col];
+                    T[r * ncp + col] = s;
+                }
+            __syncthreads();
+            /* gbar += Z' y */
+            for (int col = lane; col < nc; col += 64)
+            {
+                double s = (col >= u0 && col < u0 + NU) ? y[col - u0] : 0.0;
+                for (int r = 0; r < NX; r++) s += X[r * ncp + col] * y[NU + r];
+                gb[col] += s;
+            }
+            /* Hbar += Z' H Z: every packed entry (p, q), q <= p, by ONE lane:
+             *   X' Q X  +  [p in U] (S X)[a_p][q]  +  [q in U] (S X)[a_q][p]  +  [p, q in U] R[a_p][a_q] */
+            if (Mp.mode & 1)
+            {
+                int pr = 0, pc2 = 0; /* (row, col) of packed entry `lane`, advanced by 64 entries per step */
+                {
+                    int e = lane;
+                    while (e > pr) { e -= pr + 1; pr++; }
+                    pc2 = e;
+                }
+                for (int e = lane; e < NPC; e += 64)
+                {
+                    double s = 0.0;
+                    for (int r = 0; r < NX; r++) s += X[r * ncp + pr] * T[r * ncp + pc2];
+                    const bool pu = pr >= u0 && pr < u0 + NU, qu = pc2 >= u0 && pc2 < u0 + NU;
+                    if (pu) for (int r = 0; r < NX; r++) s += H[PK(NU + r, pr - u0)] * X[r * ncp + pc2];
+                    if (qu) for (int r = 0; r < NX; r++) s += H[PK(NU + r, pc2 - u0)] * X[r * ncp + pr];
+                    if (pu && qu) s += H[PK(pr - u0, pc2 - u0)];
+                    Hb[e] += s;
+                    /* advance (pr, pc2) by 64 packed entries */
+                    int adv = 64;
+                    while (adv > 0)
+                    {
+                        const int room = pr - pc2; /* entries left in this row after pc2 */
+                        if (adv <= room) { pc2 += adv; adv = 0; }
+                        else { adv -= room + 1; pr++; pc2 = 0; }
+                    }
+                }
+            }
+            /* propagate x_{k+1} = A x_k + B u_k + b */
+            if (jb < Mp.N2)
+            {
+                if (lane < NX)
+                {
+                    double a = bl[lane];
+                    for (int q = 0; q < NX; q++) a += Bl[(NU + q) * NX + lane] * c[q];
+                    cn[lane] = a;
+                }
+                for (int e = lane; e < NX * nc; e += 64)
+                {
+                    const int r = e / nc, col = e - r * nc;
+                    double s = (col >= u0 && col < u0 + NU) ? Bl[(col - u0) * NX + r] : 0.0;
+                    for (int q = 0; q < NX; q++) s += Bl[(NU + q) * NX + r] * X[q * ncp + col];
+                    Xn[r * ncp + col] = s;
+                }
+            }
+            __syncthreads();
+            if (jb < Mp.N2)
+            {
+                for (int e = lane; e < NX * ncp; e += 64) X[e] = Xn[e];
+                if (lane < NX) c[lane] = cn[lane];
+            }
+            __syncthreads();
+        }
+        /* unused input slots of a short block (and all of them at the terminal stage): unit diagonal */
+        const int used = jb < Mp.N2 ? bs * NU : 0;
+        for (int s2 = used + lane; s2 < NUC; s2 += 64) Hb[PK(s2, s2)] = 1.0;
+        __syncthreads();
+
+        /* ---- write child stage jb ---- */
+        if (Mp.mode & 1)
+        {
+            for (int e = lane; e < NPC; e += 64) PLAT(Cd.RSQ, jb * NPC + e) = Hb[e];
+            if (jb < Mp.N2)
+                for (int e = lane; e < nc * NX; e += 64)
+                {
+                    const int col = e / NX, r = e - col * NX;
+                    PLAT(Cd.BAt, jb * nc * NX + e) = X[r * ncp + col];
+                }
+        }
+        if (Mp.mode & 2)
+        {
+            for (int e = lane; e < nc; e += 64) PLAT(Cd.rq, jb * nc + e) = gb[e];
+            if (jb < Mp.N2 && lane < NX) PLAT(Cd.bvec, jb * NX + lane) = c[lane];
+            /* box rows, activity bits, value of fixed variables */
+            const GqpStage &Sc = Cd.st[jb];
+            const int r0 = Mp.row_off[jb], nbc = Sc.nb;
+            for (int rc = lane; rc < nbc; rc += 64)
+            {
+                const int kp = Mp.row_kp[r0 + rc], rp = Mp.row_rp[r0 + rc];
+                const GqpStage &Sp = P.st[kp];
+                PLAT(Cd.dvec, Sc.o_ct + rc) = PLAT(P.dvec, Sp.o_ct + rp);
+                PLAT(Cd.dvec, Sc.o_ct + nbc + rc) = PLAT(P.dvec, Sp.o_ct + Sp.nb + rp);
+            }
+            if (lane == 0)
+            {
+                uint64_t amc = 0;
+                for (int rc = 0; rc < nbc; rc++)
+                {
+                    const int kp = Mp.row_kp[r0 + rc], rp = Mp.row_rp[r0 + rc];
+                    const GqpStage &Sp = P.st[kp];
+                    const uint64_t amp = PLAT(P.amask, kp);
+                    if ((amp >> rp) & 1) amc |= (uint64_t) 1 << rc;
+                    if ((amp >> (Sp.nb + rp)) & 1) amc |= (uint64_t) 1 << (nbc + rc);
+                }
+                PLAT(Cd.amask, jb) = amc;
+            }
+            if (lane < NX && ((Sc.emask >> (NUC + lane)) & 1)) PLAT(Cd.ux, jb * nc + NUC + lane) = PLAT(P.ux, k0 * n + NU + lane);
+        }
+        __syncthreads();
+    }
+}
+
+/* expansion: original (ux, pi, lam, t) from the condensed solution */
+static __global__ void __launch_bounds__(64) kw_pexpand(GqpDev P, GqpDev Cd, PcondMap Mp)
+{
+    GQP_DYN_SHARED(smem);
+    const int NX = P.NX, NU = P.NU, n = NX + NU, NP = n * (n + 1) / 2;
+    const int NUC = Cd.NU, nc = NUC + NX;
+    const int inst = blockIdx.x, lane = threadIdx.x;
+    if (inst >= P.B) return;
+    double *x = smem, *u = x + 64, *pn = u + 64, *ux = pn + 64; /* ux: [u; x] of the stage being visited */
+
+    for (int jb = 0; jb <= Mp.N2; jb++)
+    {
+        const int k0 = Mp.blk_start[jb < Mp.N2 ? jb : Mp.N2];
+        const int bs = jb < Mp.N2 ? Mp.blk_start[jb + 1] - k0 : 1;
+        /* forward simulation of the eliminated states */
+        if (lane < NX) x[lane] = PLAT(Cd.ux, jb * nc + NUC + lane);
+        __syncthreads();
+        for (int ii = 0; ii < bs; ii++)
+        {
+            const int k = k0 + ii;
+            if (lane < NU) u[lane] = jb < Mp.N2 ? PLAT(Cd.ux, jb * nc + ii * NU + lane) : 0.0;
+            __syncthreads();
+            if (lane < NU) PLAT(P.ux, k * n + lane) = u[lane];
+            if (lane < NX) PLAT(P.ux, k * n + NU + lane) = x[lane];
+            double xn = 0.0;
+            const bool step = jb < Mp.N2 && ii + 1 < bs;
+            if (step && lane < NX)
+            {
+                xn = PLAT(P.bvec, k * NX + lane);
+                for (int q = 0; q < NX; q++) xn += PLAT(P.BAt, (k * n + NU + q) * NX + lane) * x[q];
+                for (int q = 0; q < NU; q++) xn += PLAT(P.BAt, (k * n + q) * NX + lane) * u[q];
+            }
+            __syncthreads();
+            if (step && lane < NX) x[lane] = xn;
+            __syncthreads();
+        }
+        /* multipliers of the eliminated dynamics: pi_k = Q x_k + S' u_k + q_k + A_k' pi_{k+1}, backwards */
+        if (jb < Mp.N2)
+        {
+            const int k1 = k0 + bs;
+            if (lane < NX) { pn[lane] = PLAT(Cd.pi, (jb + 1) * NX + lane); PLAT(P.pi, k1 * NX + lane) = pn[lane]; }
+            __syncthreads();
+            for (int k = k1 - 1; k > k0; k--)
+            {
+                if (lane < n) ux[lane] = PLAT(P.ux, k * n + lane);
+                __syncthreads();
+                double pk = 0.0;
+                if (lane < NX)
+                {
+                    const int rr = NU + lane;
+                    pk = PLAT(P.rq, k * n + rr);
+                    for (int q = 0; q < n; q++) pk += PLAT(P.RSQ, k * NP + (rr >= q ? PK(rr, q) : PK(q, rr))) * ux[q];
+                    for (int q = 0; q < NX; q++) pk += PLAT(P.BAt, (k * n + rr) * NX + q) * pn[q];
+                }
+                __syncthreads();
+                if (lane < NX) { pn[lane] = pk; PLAT(P.pi, k * NX + lane) = pk; }
+                __syncthreads();
+            }
+        }
+        /* inequality rows */
+        const GqpStage &Sc = Cd.st[jb];
+        const int r0 = Mp.row_off[jb], nbc = Sc.nb;
+        for (int rc = lane; rc < nbc; rc += 64)
+        {
+            const int kp = Mp.row_kp[r0 + rc], rp = Mp.row_rp[r0 + rc];
+            const GqpStage &Sp = P.st[kp];
+            PLAT(P.lam, Sp.o_ct + rp) = PLAT(Cd.lam, Sc.o_ct + rc);
+            PLAT(P.lam, Sp.o_ct + Sp.nb + rp) = PLAT(Cd.lam, Sc.o_ct + nbc + rc);
+            PLAT(P.t, Sp.o_ct + rp) = PLAT(Cd.t, Sc.o_ct + rc);
+            PLAT(P.t, Sp.o_ct + Sp.nb + rp) = PLAT(Cd.t, Sc.o_ct + nbc + rc);
+        }
+        __syncthreads();
+    }
+    if (lane == 0)
+    {
+        P.iter[inst] = Cd.iter[inst];
+        P.status[inst] = Cd.status[inst];
+        P.mu[inst] = Cd.mu[inst];
+        P.obj[inst] = Cd.obj[inst];
+        for (int q = 0; q < 4; q++) P.res[(size_t) q * P.Bp + inst] = Cd.res[(size_t) q * P.Bp + inst];
+    }
+}
+
 } // namespace gqp
+
 
 #endif

@@ -290,7 +290,7 @@ def test_wave_per_instance_default_rule_hostsim(hostsim_lib, monkeypatch):
     assert int(gb.info("iter").max()) <= 1
 
 
-def test_partial_condensing_hostsim(hostsim_lib):
+def test_partial_condensing_hostsim(hostsim_lib, monkeypatch):
     """a5-a7: condensing N -> N2 blocks, IPM on the condensed QP, expansion; the expanded solution
     must equal the full-space oracle solution (x, u, pi, lam, t).  Covers C3 (N=50 -> 10 blocks of 5),
     uneven block sizes, the reference's golden pendulum QP, the RTI lhs/rhs split and the decline
@@ -320,6 +320,9 @@ def test_partial_condensing_hostsim(hostsim_lib):
     b = run(qps, 10, 10)
     assert b.kernel_name.startswith("1tpi-box<NX=8,NU=3")
     run(qps, 10, 10, split=True)
+    monkeypatch.setenv("ACADOS_AMD_PCOND_1TPI", "1")   # the compiled one-instance-per-lane condensing kernels
+    run(qps, 10, 10)
+    monkeypatch.delenv("ACADOS_AMD_PCOND_1TPI")
     data = random_lqr_batch(N=10, batch=3, seed=3)
     run([lqr_instance_qp(data, i, 10) for i in range(3)], 3, 3)        # blocks of 4, 3, 3
     run([load_qp("qp_test/last_qp_nonuniform_pendulum.json")], 3, 3)   # N=7 -> 3, 2, 2 ; x0 equality rows
