@@ -150,6 +150,42 @@ def test_full_size_properties_gpu(gpu_lib):
     assert np.array_equal(gs.get("u", 0), u0_big)
 
 
+def test_c3_full_size_properties_gpu(gpu_lib):
+    """C3 at the BASELINE size (C2 data, 65,536 instances, partial condensing to N2 = 10): the expanded solution
+    satisfies the full-space problem -- status 0, KKT residual norms of the condensed solve <= 1e-8, dynamics round
+    trip over all 50 stages, input bounds, x_0 as given -- and equals the full-space solve of the same batch"""
+    from acados_amd import OcpQpGpuBatch
+    from acados_amd.generators import fill_lqr_batch, lqr_dims, random_lqr_batch
+    N, B = 50, 65536
+    data = random_lqr_batch(N=N, batch=B, seed=0)
+    sols = []
+    for cond_N in (10, 0):
+        gb = OcpQpGpuBatch(lqr_dims(N, 8, 3), B)
+        fill_lqr_batch(gb, data, N)
+        for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+            gb.opts_set(f, 1e-8)
+        if cond_N:
+            gb.opts_set("cond_N", cond_N)
+        assert gb.solve() == 0
+        assert int(gb.scalar("cond_N_active")) == (cond_N if cond_N else N)
+        for n in ("res_stat", "res_eq", "res_ineq", "res_comp"):
+            assert gb.info(n).max() <= 1e-8
+        xk = gb.get("x", 0)
+        assert np.array_equal(xk, data["x0"])
+        us = []
+        for k in range(N):
+            uk = gb.get("u", k)
+            us.append(uk)
+            assert uk.min() >= -0.5 - 1e-9 and uk.max() <= 0.5 + 1e-9
+            xn = gb.get("x", k + 1)
+            pred = np.einsum("bij,bj->bi", data["A"], xk) + np.einsum("bij,bj->bi", data["B"], uk) + data["b"]
+            assert np.max(np.abs(pred - xn)) <= 1e-7
+            xk = xn
+        sols.append(np.stack(us))
+        del gb
+    assert np.max(np.abs(sols[0] - sols[1])) <= 1e-6
+
+
 def _check_batch_vs_oracle_gpu(qps, n_check, tol=1e-8, tol_stat=1e-8):
     from acados_amd import OcpQpGpuBatch
     b = OcpQpGpuBatch.from_qps(qps)
