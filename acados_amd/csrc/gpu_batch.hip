@@ -56,6 +56,7 @@ struct ocp_qp_gpu_batch
     bool finalized = false;
     bool use_box = false; /* box-only fast path */
     int aos = 0;          /* instance-major arrays: wave-per-instance kernel family */
+    int AW = 1;           /* activity words per stage (64 inequality sides each); 2 only for wave-per-instance batches */
     int wpi = 0;          /* wave-per-instance kernels (ipm_kernels_wpi.hpp): one workgroup per instance */
     size_t shmem = 0;     /* their dynamic LDS bytes (rhs / forward sweeps) */
     size_t shmem_fact = 0; /* dynamic LDS bytes of the factor sweep */
@@ -187,10 +188,10 @@ void finalize_structure(ocp_qp_gpu_batch *b)
         S.nb = b->nb[k]; S.ng = b->ng[k]; S.ns = b->ns[k];
         S.o_ct = o_ct; S.o_s = o_s; S.o_g = o_g; S.has_dyn = k < N;
         const int nbg = S.nb + S.ng, nct = 2 * nbg + 2 * S.ns;
-        if (nct > 64 || nbg > GQP_MAX_ROWS)
+        if (nct > 64 * b->AW || nbg > GQP_MAX_ROWS)
         {
-            fprintf(stderr, "acados_amd: stage %d has %d inequality sides (> 64): unsupported\n", k, nct);
-            abort();
+            fprintf(stderr, "acados_amd: stage %d has %d inequality sides (> %d): unsupported\n", k, nct, 64 * b->AW);
+            abort(); /* not reachable through ocp_qp_gpu_batch_create, which refuses such dims */
         }
         /* sort box rows by variable */
         std::vector<int> order(S.nb);
@@ -259,7 +260,8 @@ void finalize_structure(ocp_qp_gpu_batch *b)
     D.RSQ = garr<double>(b, (size_t) ((N + 1) * NP));
     D.rq = garr<double>(b, (size_t) ((N + 1) * n));
     D.dvec = garr<double>(b, (size_t) ((o_ct + RP)));
-    D.amask = garr<uint64_t>(b, (size_t) ((N + 1)));
+    D.AW = b->AW;
+    D.amask = garr<uint64_t>(b, (size_t) ((N + 1) * b->AW));
     D.DCt = garr<double>(b, (size_t) (o_g * n));
     D.Zz = garr<double>(b, (size_t) (o_s * 2));
     D.ux = garr<double>(b, (size_t) ((N + 2) * n));
@@ -305,14 +307,16 @@ void finalize_structure(ocp_qp_gpu_batch *b)
         /* activity: every existing row side, minus equality-flagged rows */
         const GqpStage &S = b->st[k];
         const int nbg = S.nb + S.ng, nct = 2 * nbg + 2 * S.ns;
-        uint64_t m = nct >= 64 ? ~(uint64_t) 0 : (((uint64_t) 1 << nct) - 1);
+        uint64_t m[2] = {0, 0};
+        for (int e = 0; e < nct; e++) m[e >> 6] |= (uint64_t) 1 << (e & 63);
         for (size_t e = 0; e < b->idxe[k].size(); e++)
         {
             const int sp = b->perm[k][b->idxe[k][e]];
-            m &= ~((uint64_t) 1 << sp);
-            m &= ~((uint64_t) 1 << (nbg + sp));
+            m[sp >> 6] &= ~((uint64_t) 1 << (sp & 63));
+            m[(nbg + sp) >> 6] &= ~((uint64_t) 1 << ((nbg + sp) & 63));
         }
-        hipLaunchKernelGGL(gqp::k_fill_u64, dim3(grid), dim3(64), 0, b->stream, D.amask, m, b->Bp, k);
+        for (int w = 0; w < b->AW; w++)
+            hipLaunchKernelGGL(gqp::k_fill_u64, dim3(grid), dim3(64), 0, b->stream, D.amask, m[w], b->Bp, k * b->AW + w);
     }
     HIPCHK(hipStreamSynchronize(b->stream));
     b->finalized = true;
@@ -562,6 +566,18 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
     /* wave-per-instance family (ipm_kernels_wpi.hpp): box-constrained QPs whose stage block is too large for
      * the one-instance-per-lane register mapping.  Dimensions are runtime values there: no padding to a
      * compiled shape.  ACADOS_AMD_WPI=0/1 overrides the size rule (tests). */
+    /* inequality sides per stage: 64 per activity word; the one-instance-per-lane kernels read one word, the
+     * wave-per-instance ones up to two */
+    int nct_max = 0;
+    for (int k = 0; k <= N; k++) nct_max = std::max(nct_max, 2 * (nbx[k] + nbu[k] + ng[k]) + 2 * ns[k]);
+    if (nct_max > 128)
+    {
+        fprintf(stderr, "acados_amd: a stage has %d inequality sides (2(nb+ng)+2ns > 128): unsupported\n", nct_max);
+        delete b;
+        return nullptr;
+    }
+    const bool need_wpi = nct_max > 64;
+    if (need_wpi) b->ks = nullptr; /* no one-instance-per-lane kernel may serve it */
     if (!g_force_ks || g_force_wpi)
     {
         const int wx = force_NX ? force_NX : mx, wu = force_NU ? force_NU : mu;
@@ -574,7 +590,7 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
          * tools/family_crossover.py).  ACADOS_AMD_WPI_BATCH_MAX overrides the batch threshold. */
         const char *bm = getenv("ACADOS_AMD_WPI_BATCH_MAX");
         const int batch_max = bm ? atoi(bm) : GQP_WPI_BATCH_MAX;
-        const bool want = g_force_wpi || (env ? atoi(env) != 0 : (wx + wu >= GQP_WPI_MIN_N || !b->ks || n_batch <= batch_max));
+        const bool want = g_force_wpi || need_wpi || (env ? atoi(env) != 0 : (wx + wu >= GQP_WPI_MIN_N || !b->ks || n_batch <= batch_max));
         if (want && wx + wu <= 64 && wx >= 1 && mg <= 32 && ms <= 32)
         {
             /* factor sweep: register-tile kernel for the tile count of this shape; rhs-only and forward sweeps on
@@ -599,6 +615,7 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
             b->ks = &b->own_ks;
             b->wpi = 1;
             b->aos = 1;
+            b->AW = need_wpi ? 2 : 1;
             const size_t con = gqp::wpi_con_doubles(wx + wu, mg, ms);
             b->shmem = (ref ? gqp::wpi_lds_doubles(wx, wu) : gqp::wpi3_lds_doubles(wx, wu) + con) * sizeof(double);
             b->shmem_fact = (ref ? gqp::wpi_lds_doubles(wx, wu) : gqp::wpi2_lds_doubles(wx, wu) + con) * sizeof(double);
@@ -682,7 +699,7 @@ int ocp_qp_gpu_batch_set(ocp_qp_gpu_batch *b, const char *f, int stage, const do
             if (len == 0) continue;
             if (src_len != len) { src = stage_in(b, data, (size_t) b->B * len, is_device); src_len = len; }
             int *dm = upload_map(b, map);
-            hipLaunchKernelGGL(gqp::k_setmask, dim3(grid), dim3(64), 0, b->stream, src, b->B, len, dm, b->D.amask, k);
+            hipLaunchKernelGGL(gqp::k_setmask, dim3(grid), dim3(64), 0, b->stream, src, b->B, len, dm, b->D.amask, k, b->AW);
             continue;
         }
         const int len = field_map(b, f, k, map, &arr, &map2, &arr2);
@@ -879,7 +896,7 @@ static void pcond_setup(ocp_qp_gpu_batch *b)
 static void pcond_launch(ocp_qp_gpu_batch *b, bool expand)
 {
     ocp_qp_gpu_batch *c = b->child;
-    if (b->pc_rt)
+    if (b->pc_rt || b->AW > 1 || c->AW > 1)
     {
         if (expand) GQP_LAUNCH_COOP(gqp::kw_pexpand, dim3(b->B), dim3(64), b->pc_shmem, b->stream, b->D, c->D, b->pmap);
         else GQP_LAUNCH_COOP(gqp::kw_pcond, dim3(b->B), dim3(64), b->pc_shmem, b->stream, b->D, c->D, b->pmap);
@@ -1419,7 +1436,7 @@ int ocp_qp_gpu_batch_set_bulk(ocp_qp_gpu_batch *b, const double *blob, int is_de
     hipLaunchKernelGGL(gqp::k_bulk_scatter, grid, block, 0, b->stream, src, b->B, len, M.d_arr, M.d_elem, M.T);
     if (M.nm)
         hipLaunchKernelGGL(gqp::k_bulk_masks, dim3((b->B + 63) / 64), block, 0, b->stream, src, b->B, len, M.d_moff,
-                           M.d_mstage, M.d_mbit, M.nm, b->D.amask);
+                           M.d_mstage, M.d_mbit, M.nm, b->D.amask, b->AW);
     HIPCHK(hipEventRecord(e1, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     float ms = 0.f;

@@ -18,7 +18,8 @@
 
 #include <stdint.h>
 
-#define GQP_MAX_ROWS 64 /* nb+ng per stage, and 2(nb+ng)+2ns <= 64 (activity bit mask) */
+#define GQP_MAX_ROWS 64 /* nb+ng per stage; inequality sides 2(nb+ng)+2ns <= 64 * AW (activity words per stage:
+                           1 for the one-instance-per-lane kernels, up to 2 for the wave-per-instance ones) */
 
 /* per-stage structure shared by the whole batch (read through scalar loads) */
 struct GqpStage
@@ -61,6 +62,7 @@ typedef GArrT<uint64_t> GArrU64;
 struct GqpDev
 {
     int B, Bp, N, NX, NU, NG, NS;
+    int AW;             /* activity words per stage in amask (1 or 2) */
     const GqpStage *st; /* N+1 entries */
     /* problem data */
     /* Slot conventions that make the stage body uniform (no k<N / k>0 branches in the fast
@@ -74,7 +76,7 @@ struct GqpDev
     GArr RSQ;      /* [N+1][n(n+1)/2] packed lower, row-major packed: (r,c)->r(r+1)/2+c */
     GArr rq;       /* [N+1][n]                                                       */
     GArr dvec;     /* [sum nct] natural-sign bounds, order [lb lg ub ug lls lus]     */
-    GArrU64 amask; /* [N+1] per instance: bit e set <=> inequality row e takes part */
+    GArrU64 amask; /* [(N+1) * AW] per instance: bit e of stage k (word k*AW + e/64) set <=> inequality side e takes part */
     GArr DCt;      /* [sum ng][n]  row g: d(general row)/d v                         */
     GArr Zz;       /* [sum 2ns][2]: (Z, z) for sl then su                            */
     /* iterate */

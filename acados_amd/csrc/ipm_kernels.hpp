@@ -1091,19 +1091,22 @@ static __global__ void k_gather(double *dst, int nb, int len, const int *map, GA
 
 /* activity bit masks: for every element e of a (lower|upper|slack) mask vector handed
  * over by the caller, set or clear bit bitpos[e] of amask[stage] */
-static __global__ void k_setmask(const double *src, int nb, int len, const int *bitpos, GArrU64 amask, int stage)
+static __global__ void k_setmask(const double *src, int nb, int len, const int *bitpos, GArrU64 amask, int stage, int AW)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nb) return;
-    uint64_t m = GATL(amask, stage);
-    for (int e = 0; e < len; e++)
+    for (int w = 0; w < AW; w++)
     {
-        const int b = bitpos[e];
-        if (b < 0) continue;
-        if (src[(size_t) i * len + e] != 0.0) m |= (uint64_t) 1 << b;
-        else m &= ~((uint64_t) 1 << b);
+        uint64_t m = GATL(amask, stage * AW + w);
+        for (int e = 0; e < len; e++)
+        {
+            const int b = bitpos[e] - 64 * w;
+            if (bitpos[e] < 0 || b < 0 || b >= 64) continue;
+            if (src[(size_t) i * len + e] != 0.0) m |= (uint64_t) 1 << b;
+            else m &= ~((uint64_t) 1 << b);
+        }
+        GATL(amask, stage * AW + w) = m;
     }
-    GATL(amask, stage) = m;
 }
 
 /* ---- bulk pack / unpack: one launch moves a whole QP (or solution) per instance ----
@@ -1140,17 +1143,18 @@ static __global__ void k_bulk_gather(double *blob, int nb, int len, const int *m
 
 /* mask entries of the blob: (offset in blob, stage, bit) triples */
 static __global__ void k_bulk_masks(const double *blob, int nb, int len, const int *m_off, const int *m_stage,
-                                    const int *m_bit, int nm, GArrU64 amask)
+                                    const int *m_bit, int nm, GArrU64 amask, int AW)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nb) return;
     for (int q = 0; q < nm; q++)
     {
         if (m_bit[q] < 0) continue;
-        uint64_t m = GATL(amask, m_stage[q]);
-        if (blob[(size_t) i * len + m_off[q]] != 0.0) m |= (uint64_t) 1 << m_bit[q];
-        else m &= ~((uint64_t) 1 << m_bit[q]);
-        GATL(amask, m_stage[q]) = m;
+        const int w = m_stage[q] * AW + (m_bit[q] >> 6), bit = m_bit[q] & 63;
+        uint64_t m = GATL(amask, w);
+        if (blob[(size_t) i * len + m_off[q]] != 0.0) m |= (uint64_t) 1 << bit;
+        else m &= ~((uint64_t) 1 << bit);
+        GATL(amask, w) = m;
     }
 }
 

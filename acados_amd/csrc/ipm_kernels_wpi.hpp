@@ -40,6 +40,20 @@ namespace gqp
 /* element e of instance `inst` in an instance-major array */
 #define WAT(arr, e) (arr).p[(size_t) inst * (size_t) (arr).E + (size_t) (e)]
 
+/* activity bits of one stage: up to 128 inequality sides (GqpDev::AW words) */
+struct Am128
+{
+    uint64_t lo, hi;
+};
+__device__ static inline Am128 wpi_am(const GqpDev &D, int inst, int k)
+{
+    Am128 a;
+    a.lo = WAT(D.amask, k * D.AW);
+    a.hi = D.AW > 1 ? WAT(D.amask, k * D.AW + 1) : 0;
+    return a;
+}
+__device__ static inline bool abit(const Am128 &a, int i) { return i < 64 ? (a.lo >> i) & 1 : (a.hi >> (i - 64)) & 1; }
+
 /* LDS carve-up shared by the three sweep kernels (doubles) */
 struct WpiLds
 {
@@ -202,7 +216,7 @@ __global__ void __launch_bounds__(64) kw_backward(GqpDev D, GqpOpts O, int redo)
     {
         const GqpStage &S = D.st[k];
         const uint64_t imask = S.bmask & ~S.emask;
-        const uint64_t am = WAT(D.amask, k);
+        const Am128 am = wpi_am(D, inst, k);
         const int nbg = S.nb;
         const bool mine = lane < n;
         const bool fixed = mine && ((S.emask >> lane) & 1);
@@ -230,7 +244,7 @@ __global__ void __launch_bounds__(64) kw_backward(GqpDev D, GqpOpts O, int redo)
         /* box row of variable `lane` */
         const bool has = mine && ((imask >> lane) & 1);
         const int ib = has ? popc64(S.bmask & (((uint64_t) 1 << lane) - 1)) : 0;
-        const bool al = has && ((am >> ib) & 1), au = has && ((am >> (nbg + ib)) & 1);
+        const bool al = has && abit(am, ib), au = has && abit(am, nbg + ib);
         const int el = S.o_ct + ib, eu = el + nbg;
         const double ll = al ? WAT(D.lam, el) : 0.0, lu = au ? WAT(D.lam, eu) : 0.0;
         const double ttl = al ? WAT(D.t, el) : 1.0, ttu = au ? WAT(D.t, eu) : 1.0;
@@ -451,7 +465,7 @@ __global__ void __launch_bounds__(64) kw_forward(GqpDev D, GqpOpts O, int redo)
     {
         const GqpStage &S = D.st[k];
         const uint64_t imask = S.bmask & ~S.emask;
-        const uint64_t am = WAT(D.amask, k);
+        const Am128 am = wpi_am(D, inst, k);
         const int nbg = S.nb;
         const bool mine = lane < n;
 
@@ -461,7 +475,7 @@ __global__ void __launch_bounds__(64) kw_forward(GqpDev D, GqpOpts O, int redo)
         if (lane < NX) L.rb[lane] = WAT(D.rb, k * NX + lane);
         const bool has = mine && ((imask >> lane) & 1);
         const int ib = has ? popc64(S.bmask & (((uint64_t) 1 << lane) - 1)) : 0;
-        const bool al = has && ((am >> ib) & 1), au = has && ((am >> (nbg + ib)) & 1);
+        const bool al = has && abit(am, ib), au = has && abit(am, nbg + ib);
         const int el = S.o_ct + ib, eu = el + nbg;
         const double ll = al ? WAT(D.lam, el) : 0.0, lu = au ? WAT(D.lam, eu) : 0.0;
         const double ttl = al ? WAT(D.t, el) : 1.0, ttu = au ? WAT(D.t, eu) : 1.0;
@@ -588,7 +602,7 @@ __global__ void __launch_bounds__(64) kw_forward(GqpDev D, GqpOpts O, int redo)
     {
         const GqpStage &S = D.st[k];
         const uint64_t imask = S.bmask & ~S.emask;
-        const uint64_t am = WAT(D.amask, k);
+        const Am128 am = wpi_am(D, inst, k);
         const int nbg = S.nb;
         if (lane < n && ((imask >> lane) & 1))
         {
@@ -596,7 +610,7 @@ __global__ void __launch_bounds__(64) kw_forward(GqpDev D, GqpOpts O, int redo)
             for (int side = 0; side < 2; side++)
             {
                 const int e = S.o_ct + side * nbg + ib;
-                if (!((am >> (side * nbg + ib)) & 1)) continue;
+                if (!abit(am, side * nbg + ib)) continue;
                 const double lam = WAT(D.lam, e) + a * WAT(D.dlam, e);
                 const double t = WAT(D.t, e) + a * WAT(D.dt, e);
                 WAT(D.lam, e) = lam < O.lam_min ? O.lam_min : lam;
@@ -660,7 +674,7 @@ __host__ __device__ static inline size_t wpi_con_doubles(int n, int NG, int NS)
 {
     if (NG == 0 && NS == 0) return 0;
     const int SG = n | 1;
-    return (size_t) NG * SG + 18 * 32 + 32 + 16 + 8;
+    return (size_t) NG * SG + 6 * 64 + 12 * 32 + 32 + 16 + 8;
 }
 
 __device__ static inline WpiCon wpi_con_carve(double *p, int n, int NG, int NS)
@@ -668,7 +682,7 @@ __device__ static inline WpiCon wpi_con_carve(double *p, int n, int NG, int NS)
     WpiCon C;
     C.SG = n | 1;
     C.G = p; p += NG * C.SG;
-    C.rGl = p; p += 32; C.rGu = p; p += 32; C.rRl = p; p += 32; C.rRu = p; p += 32; C.rLl = p; p += 32; C.rLu = p; p += 32;
+    C.rGl = p; p += 64; C.rGu = p; p += 64; C.rRl = p; p += 64; C.rRu = p; p += 64; C.rLl = p; p += 64; C.rLu = p; p += 64;
     C.sIl = p; p += 32; C.sIu = p; p += 32; C.sRl = p; p += 32; C.sRu = p; p += 32; C.dsl = p; p += 32; C.dsu = p; p += 32;
     C.sEl = p; p += 32; C.sEu = p; p += 32; C.sXl = p; p += 32; C.sXu = p; p += 32;
     C.nuG = p; p += 32; C.gmG = p; p += 32;
@@ -715,12 +729,12 @@ struct WpiRow
     double ll, lu, tl, tu; /* lam (0 if inactive), t (1 if inactive) */
 };
 
-__device__ static inline WpiRow wpi_row(const GqpDev &D, const GqpStage &S, uint64_t am, int inst, int row, bool exists)
+__device__ static inline WpiRow wpi_row(const GqpDev &D, const GqpStage &S, const Am128 &am, int inst, int row, bool exists)
 {
     const int nbg = S.nb + S.ng;
     WpiRow R;
-    R.al = exists && ((am >> row) & 1);
-    R.au = exists && ((am >> (nbg + row)) & 1);
+    R.al = exists && abit(am, row);
+    R.au = exists && abit(am, nbg + row);
     R.el = S.o_ct + (exists ? row : 0);
     R.eu = R.el + nbg;
     R.sj = exists ? (int) S.srev[row] : -1;
@@ -809,7 +823,7 @@ __global__ void __launch_bounds__(64) kw_factor(GqpDev D, GqpOpts O, int redo)
     {
         const GqpStage &S = D.st[k];
         const uint64_t imask = S.bmask & ~S.emask;
-        const uint64_t am = WAT(D.amask, k);
+        const Am128 am = wpi_am(D, inst, k);
         const int nbg = S.nb + (GEN ? S.ng : 0);
         const bool fixed = mine && ((S.emask >> lane) & 1);
 
@@ -835,7 +849,7 @@ __global__ void __launch_bounds__(64) kw_factor(GqpDev D, GqpOpts O, int redo)
         if (mine && lane >= NU) pik = WAT(D.pi, k * NX + lane - NU);
         const bool has = mine && ((imask >> lane) & 1);
         const int ib = has ? popc64(S.bmask & (((uint64_t) 1 << lane) - 1)) : 0;
-        const bool al = has && ((am >> ib) & 1), au = has && ((am >> (nbg + ib)) & 1);
+        const bool al = has && abit(am, ib), au = has && abit(am, nbg + ib);
         const int el = S.o_ct + ib, eu = el + nbg;
         const double ll = al ? WAT(D.lam, el) : 0.0, lu = au ? WAT(D.lam, eu) : 0.0;
         const double ttl = al ? WAT(D.t, el) : 1.0, ttu = au ? WAT(D.t, eu) : 1.0;
@@ -862,7 +876,7 @@ __global__ void __launch_bounds__(64) kw_factor(GqpDev D, GqpOpts O, int redo)
             if (iss)
             {
                 se0 = S.o_ct + 2 * nbg + lane; se1 = se0 + S.ns;
-                sal = (am >> (2 * nbg + lane)) & 1; sau = (am >> (2 * nbg + S.ns + lane)) & 1;
+                sal = abit(am, 2 * nbg + lane); sau = abit(am, 2 * nbg + S.ns + lane);
                 sll = sal ? WAT(D.lam, se0) : 0.0; slu = sau ? WAT(D.lam, se1) : 0.0;
                 stl = sal ? WAT(D.t, se0) : 1.0; stu = sau ? WAT(D.t, se1) : 1.0;
                 sdl = sal ? WAT(D.dvec, se0) : 0.0; sdu = sau ? WAT(D.dvec, se1) : 0.0;
@@ -1366,7 +1380,7 @@ __global__ void __launch_bounds__(64) kw_backrhs(GqpDev D, GqpOpts O, int redo)
     {
         const GqpStage &S = D.st[k];
         const uint64_t imask = S.bmask & ~S.emask;
-        const uint64_t am = WAT(D.amask, k);
+        const Am128 am = wpi_am(D, inst, k);
         const int nbg = S.nb + (GEN ? S.ng : 0);
         double *__restrict__ Lc = L.Lp + cur * L.NPa;
         const double *__restrict__ Ln = L.Lp + (cur ^ 1) * L.NPa;
@@ -1414,7 +1428,7 @@ __global__ void __launch_bounds__(64) kw_backrhs(GqpDev D, GqpOpts O, int redo)
             if (iss)
             {
                 const int e0 = S.o_ct + 2 * nbg + lane, e1 = e0 + S.ns;
-                const bool al = (am >> (2 * nbg + lane)) & 1, au = (am >> (2 * nbg + S.ns + lane)) & 1;
+                const bool al = abit(am, 2 * nbg + lane), au = abit(am, 2 * nbg + S.ns + lane);
                 const double ll = al ? WAT(D.lam, e0) : 0.0, lu = au ? WAT(D.lam, e1) : 0.0;
                 const double tl = al ? WAT(D.t, e0) : 1.0, tu = au ? WAT(D.t, e1) : 1.0;
                 const double rdl = al ? WAT(D.rd, e0) : 0.0, rdu = au ? WAT(D.rd, e1) : 0.0;
@@ -1541,7 +1555,7 @@ __global__ void __launch_bounds__(64) kw_fwd(GqpDev D, GqpOpts O, int redo)
     {
         const GqpStage &S = D.st[k];
         const uint64_t imask = S.bmask & ~S.emask;
-        const uint64_t am = WAT(D.amask, k);
+        const Am128 am = wpi_am(D, inst, k);
         const int nbg = S.nb + (GEN ? S.ng : 0);
 
         for (int p = lane; p < NP; p += 64) Lc[p] = WAT(D.Lf, k * NP + p);
@@ -1551,7 +1565,7 @@ __global__ void __launch_bounds__(64) kw_fwd(GqpDev D, GqpOpts O, int redo)
         const double rbv = lane < NX ? WAT(D.rb, k * NX + lane) : 0.0;
         const bool has = mine && ((imask >> lane) & 1);
         const int ib = has ? popc64(S.bmask & (((uint64_t) 1 << lane) - 1)) : 0;
-        const bool al = has && ((am >> ib) & 1), au = has && ((am >> (nbg + ib)) & 1);
+        const bool al = has && abit(am, ib), au = has && abit(am, nbg + ib);
         const int el = S.o_ct + ib, eu = el + nbg;
         const double ll = al ? WAT(D.lam, el) : 0.0, lu = au ? WAT(D.lam, eu) : 0.0;
         const double ttl = al ? WAT(D.t, el) : 1.0, ttu = au ? WAT(D.t, eu) : 1.0;
@@ -1671,7 +1685,7 @@ __global__ void __launch_bounds__(64) kw_fwd(GqpDev D, GqpOpts O, int redo)
                 if (CORR) { WAT(D.dsv, S.o_s + lane) = dsl; WAT(D.dsv, S.o_s + S.ns + lane) = dsu; }
                 /* the two bound rows of the slack */
                 const int e0 = S.o_ct + 2 * nbg + lane, e1 = e0 + S.ns;
-                const bool sal = (am >> (2 * nbg + lane)) & 1, sau = (am >> (2 * nbg + S.ns + lane)) & 1;
+                const bool sal = abit(am, 2 * nbg + lane), sau = abit(am, 2 * nbg + S.ns + lane);
                 const double sll = sal ? WAT(D.lam, e0) : 0.0, slu = sau ? WAT(D.lam, e1) : 0.0;
                 const double stl = sal ? WAT(D.t, e0) : 1.0, stu = sau ? WAT(D.t, e1) : 1.0;
                 C.sEl[lane] = WAT(D.Zz, (S.o_s + lane) * 2) + sll * frcp(stl);
@@ -1824,18 +1838,19 @@ __global__ void __launch_bounds__(64) kw_fwd(GqpDev D, GqpOpts O, int redo)
     }
     for (int k = 0; k <= D.N; k++)
     {
-        /* one lane per inequality side of the stage (at most 64) */
+        /* one lane per inequality side of the stage (at most 128 sides: two passes) */
         const GqpStage &S = D.st[k];
-        const uint64_t am = WAT(D.amask, k);
+        const Am128 am = wpi_am(D, inst, k);
         const int nct = 2 * (S.nb + S.ng) + 2 * S.ns;
-        if (lane < nct && ((am >> lane) & 1))
-        {
-            const int e = S.o_ct + lane;
-            const double lam = WAT(D.lam, e) + a * WAT(D.dlam, e);
-            const double t = WAT(D.t, e) + a * WAT(D.dt, e);
-            WAT(D.lam, e) = lam < O.lam_min ? O.lam_min : lam;
-            WAT(D.t, e) = t < O.t_min ? O.t_min : t;
-        }
+        for (int side = lane; side < nct; side += 64)
+            if (abit(am, side))
+            {
+                const int e = S.o_ct + side;
+                const double lam = WAT(D.lam, e) + a * WAT(D.dlam, e);
+                const double t = WAT(D.t, e) + a * WAT(D.dt, e);
+                WAT(D.lam, e) = lam < O.lam_min ? O.lam_min : lam;
+                WAT(D.t, e) = t < O.t_min ? O.t_min : t;
+            }
     }
     __syncthreads();
     if (lane == 0)
@@ -1862,7 +1877,7 @@ __global__ void __launch_bounds__(64) kw_init(GqpDev D, GqpOpts O)
     {
         const GqpStage &S = D.st[k];
         const int nbg = S.nb + (GEN ? S.ng : 0);
-        const uint64_t am = WAT(D.amask, k);
+        const Am128 am = wpi_am(D, inst, k);
         const bool mine = lane < n, hasb = mine && ((S.bmask >> lane) & 1);
         const bool fixed = mine && ((S.emask >> lane) & 1);
         const int ib = hasb ? popc64(S.bmask & (((uint64_t) 1 << lane) - 1)) : 0;
@@ -1875,7 +1890,7 @@ __global__ void __launch_bounds__(64) kw_init(GqpDev D, GqpOpts O)
             if (hasb)
             {
                 lb = WAT(D.dvec, S.o_ct + ib); ub = WAT(D.dvec, S.o_ct + nbg + ib);
-                al = (am >> ib) & 1; au = (am >> (nbg + ib)) & 1;
+                al = abit(am, ib); au = abit(am, nbg + ib);
                 if (!fixed && bsj < 0)
                 {
                     const double tl = v - lb, tu = ub - v;
@@ -1909,14 +1924,14 @@ __global__ void __launch_bounds__(64) kw_init(GqpDev D, GqpOpts O)
             if (iss)
             {
                 double a = 0.0, c = 0.0;
-                if ((am >> (2 * nbg + lane)) & 1) a = WAT(D.dvec, S.o_ct + 2 * nbg + lane) + thr0;
-                if ((am >> (2 * nbg + S.ns + lane)) & 1) c = WAT(D.dvec, S.o_ct + 2 * nbg + S.ns + lane) + thr0;
+                if (abit(am, 2 * nbg + lane)) a = WAT(D.dvec, S.o_ct + 2 * nbg + lane) + thr0;
+                if (abit(am, 2 * nbg + S.ns + lane)) c = WAT(D.dvec, S.o_ct + 2 * nbg + S.ns + lane) + thr0;
                 for (int row = 0; row < nbg; row++)
                     if (S.srev[row] == lane)
                     {
                         const double need_l = WAT(D.dvec, S.o_ct + row) - cv[row] + thr0, need_u = cv[row] - WAT(D.dvec, S.o_ct + nbg + row) + thr0;
-                        if (((am >> row) & 1) && need_l > a) a = need_l;
-                        if (((am >> (nbg + row)) & 1) && need_u > c) c = need_u;
+                        if (abit(am, row) && need_l > a) a = need_l;
+                        if (abit(am, nbg + row) && need_u > c) c = need_u;
                     }
                 WAT(D.sv, S.o_s + lane) = a; WAT(D.sv, S.o_s + S.ns + lane) = c;
                 ssl[lane] = a; ssu[lane] = c;
@@ -1924,7 +1939,7 @@ __global__ void __launch_bounds__(64) kw_init(GqpDev D, GqpOpts O)
                 double tl = a - WAT(D.dvec, e0), tu = c - WAT(D.dvec, e1);
                 if (tl < thr0) tl = thr0;
                 if (tu < thr0) tu = thr0;
-                const bool sal = (am >> (2 * nbg + lane)) & 1, sau = (am >> (2 * nbg + S.ns + lane)) & 1;
+                const bool sal = abit(am, 2 * nbg + lane), sau = abit(am, 2 * nbg + S.ns + lane);
                 WAT(D.t, e0) = sal ? tl : 0.0; WAT(D.t, e1) = sau ? tu : 0.0;
                 WAT(D.lam, e0) = sal ? O.mu0 / tl : 0.0; WAT(D.lam, e1) = sau ? O.mu0 / tu : 0.0;
             }
@@ -1937,7 +1952,7 @@ __global__ void __launch_bounds__(64) kw_init(GqpDev D, GqpOpts O)
                 double tl = gc + gsl - WAT(D.dvec, S.o_ct + row), tu = WAT(D.dvec, S.o_ct + nbg + row) - gc + gsu;
                 if (tl < thr0) tl = thr0;
                 if (tu < thr0) tu = thr0;
-                const bool gal = (am >> row) & 1, gau = (am >> (nbg + row)) & 1;
+                const bool gal = abit(am, row), gau = abit(am, nbg + row);
                 WAT(D.t, S.o_ct + row) = gal ? tl : 0.0; WAT(D.t, S.o_ct + nbg + row) = gau ? tu : 0.0;
                 WAT(D.lam, S.o_ct + row) = gal ? O.mu0 / tl : 0.0; WAT(D.lam, S.o_ct + nbg + row) = gau ? O.mu0 / tu : 0.0;
             }
@@ -1975,7 +1990,7 @@ __global__ void __launch_bounds__(64) kw_finalize(GqpDev D)
     {
         const GqpStage &S = D.st[k];
         const int nbg = S.nb + (GEN ? S.ng : 0);
-        const uint64_t am = WAT(D.amask, k);
+        const Am128 am = wpi_am(D, inst, k);
         if (lane < n && ((S.bmask >> lane) & 1))
         {
             const int j = lane;
@@ -2000,14 +2015,14 @@ __global__ void __launch_bounds__(64) kw_finalize(GqpDev D)
             {
                 const int sj = GEN ? (int) S.srev[ib] : -1;
                 const double sl = sj >= 0 ? WAT(D.sv, S.o_s + sj) : 0.0, su = sj >= 0 ? WAT(D.sv, S.o_s + S.ns + sj) : 0.0;
-                if (!((am >> ib) & 1)) { WAT(D.t, el) = vj + sl - WAT(D.dvec, el); WAT(D.lam, el) = 0.0; }
-                if (!((am >> (nbg + ib)) & 1)) { WAT(D.t, eu) = WAT(D.dvec, eu) - vj + su; WAT(D.lam, eu) = 0.0; }
+                if (!abit(am, ib)) { WAT(D.t, el) = vj + sl - WAT(D.dvec, el); WAT(D.lam, el) = 0.0; }
+                if (!abit(am, nbg + ib)) { WAT(D.t, eu) = WAT(D.dvec, eu) - vj + su; WAT(D.lam, eu) = 0.0; }
             }
         }
         if (GEN && lane < S.ng)
         {
             const int row = S.nb + lane, el = S.o_ct + row, eu = el + nbg, sj = S.srev[row];
-            const bool al = (am >> row) & 1, au = (am >> (nbg + row)) & 1;
+            const bool al = abit(am, row), au = abit(am, nbg + row);
             if (!al || !au)
             {
                 double c = 0.0;
@@ -2020,8 +2035,8 @@ __global__ void __launch_bounds__(64) kw_finalize(GqpDev D)
         if (GEN && lane < S.ns)
         {
             const int e0 = S.o_ct + 2 * nbg + lane, e1 = e0 + S.ns;
-            if (!((am >> (2 * nbg + lane)) & 1)) { WAT(D.t, e0) = WAT(D.sv, S.o_s + lane) - WAT(D.dvec, e0); WAT(D.lam, e0) = 0.0; }
-            if (!((am >> (2 * nbg + S.ns + lane)) & 1)) { WAT(D.t, e1) = WAT(D.sv, S.o_s + S.ns + lane) - WAT(D.dvec, e1); WAT(D.lam, e1) = 0.0; }
+            if (!abit(am, 2 * nbg + lane)) { WAT(D.t, e0) = WAT(D.sv, S.o_s + lane) - WAT(D.dvec, e0); WAT(D.lam, e0) = 0.0; }
+            if (!abit(am, 2 * nbg + S.ns + lane)) { WAT(D.t, e1) = WAT(D.sv, S.o_s + S.ns + lane) - WAT(D.dvec, e1); WAT(D.lam, e1) = 0.0; }
         }
     }
 }

@@ -413,16 +413,17 @@ static __global__ void __launch_bounds__(64) kw_pcond(GqpDev P, GqpDev Cd, Pcond
             }
             if (lane == 0)
             {
-                uint64_t amc = 0;
+                uint64_t amc[2] = {0, 0};
                 for (int rc = 0; rc < nbc; rc++)
                 {
                     const int kp = Mp.row_kp[r0 + rc], rp = Mp.row_rp[r0 + rc];
                     const GqpStage &Sp = P.st[kp];
-                    const uint64_t amp = PLAT(P.amask, kp);
-                    if ((amp >> rp) & 1) amc |= (uint64_t) 1 << rc;
-                    if ((amp >> (Sp.nb + rp)) & 1) amc |= (uint64_t) 1 << (nbc + rc);
+                    const int bl_ = rp, bu_ = Sp.nb + rp; /* the parent stage has box rows only */
+                    const uint64_t wl = PLAT(P.amask, kp * P.AW + (bl_ >> 6)), wu = PLAT(P.amask, kp * P.AW + (bu_ >> 6));
+                    if ((wl >> (bl_ & 63)) & 1) amc[rc >> 6] |= (uint64_t) 1 << (rc & 63);
+                    if ((wu >> (bu_ & 63)) & 1) amc[(nbc + rc) >> 6] |= (uint64_t) 1 << ((nbc + rc) & 63);
                 }
-                PLAT(Cd.amask, jb) = amc;
+                for (int w = 0; w < Cd.AW; w++) PLAT(Cd.amask, jb * Cd.AW + w) = amc[w];
             }
             if (lane < NX && ((Sc.emask >> (NUC + lane)) & 1)) PLAT(Cd.ux, jb * nc + NUC + lane) = PLAT(P.ux, k0 * n + NU + lane);
         }

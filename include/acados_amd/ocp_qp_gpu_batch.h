@@ -35,8 +35,8 @@ typedef struct ocp_qp_gpu_batch ocp_qp_gpu_batch;
 
 /* Create a batch of `n_batch` QPs with the per-stage dims of ocp_qp_dims
  * (acados/ocp_qp/ocp_qp_common.h:49; arrays of length N+1).  `device` < 0 keeps the
- * current HIP device.  Returns NULL (and prints the reason) if no kernel instantiation
- * covers the shape or no GPU is present. */
+ * current HIP device.  Returns NULL (and prints the reason) if no kernel covers the shape (limits: nu + nx <= 64 per
+ * stage, ng <= 32, ns <= 32, at most 128 inequality sides 2(nb+ng)+2ns per stage) or no GPU is present. */
 ocp_qp_gpu_batch *ocp_qp_gpu_batch_create(int N, const int *nx, const int *nu, const int *nbx,
                                           const int *nbu, const int *ng, const int *ns,
                                           int n_batch, int device);

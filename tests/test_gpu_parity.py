@@ -150,6 +150,16 @@ def test_full_size_properties_gpu(gpu_lib):
     assert np.array_equal(gs.get("u", 0), u0_big)
 
 
+def test_large_stage_blocks_gpu(gpu_lib):
+    """stage blocks up to nu + nx = 64 (no compiled shape list: run-time dims of the wave-per-instance family;
+    the largest tile count T8 = 8 and more than 64 KB of dynamic LDS) against the oracle"""
+    from acados_amd.generators import lqr_instance_qp, random_lqr_batch
+    for nx, nu, N in ((40, 3, 6), (48, 16, 4), (32, 8, 8)):   # 86, 128 and 80 inequality sides at stage 0
+        data = random_lqr_batch(N=N, nx=nx, nu=nu, batch=6, seed=3 + nx)
+        b = _check_batch_vs_oracle_gpu([lqr_instance_qp(data, i, N) for i in range(6)], 3)
+        assert b.kernel_name.startswith(f"wpi-box(nx={nx},nu={nu}")
+
+
 def test_c3_full_size_properties_gpu(gpu_lib):
     """C3 at the BASELINE size (C2 data, 65,536 instances, partial condensing to N2 = 10): the expanded solution
     satisfies the full-space problem -- status 0, KKT residual norms of the condensed solve <= 1e-8, dynamics round

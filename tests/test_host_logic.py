@@ -201,6 +201,33 @@ def test_c4_shape_general_constraints_and_slacks_hostsim(hostsim_lib, monkeypatc
     assert b.kernel_name.startswith("wpi-gen(nx=24,nu=3,ng=4,ns=8" if wpi == "1" else "1tpi<NX=24,NU=3,NG=4,NS=8>")
 
 
+def test_more_than_64_inequality_sides_hostsim(hostsim_lib):
+    """stages with 65..128 inequality sides (two activity words per stage, wave-per-instance kernels only):
+    nx + nu = 40 with x0 as equality bounds (80 sides at stage 0), and partial condensing with blocks of 10
+    stages (child stage: 30 input rows + 8 state rows = 76 sides); more than 128 sides are refused (NULL handle,
+    message) instead of aborting"""
+    from acados_amd import OcpQpGpuBatch
+    from acados_amd.generators import lqr_dims, lqr_instance_qp, random_lqr_batch
+    data = random_lqr_batch(N=3, nx=32, nu=8, batch=2, seed=4)
+    b = _check_batch_vs_oracle([lqr_instance_qp(data, i, 3) for i in range(2)], hostsim_lib)
+    assert b.kernel_name.startswith("wpi-box(nx=32,nu=8")
+    data = random_lqr_batch(N=20, batch=2, seed=6)
+    qps = [lqr_instance_qp(data, i, 20) for i in range(2)]
+    b = OcpQpGpuBatch.from_qps(qps, _clib=hostsim_lib)
+    for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+        b.opts_set(f, 1e-8)
+    b.opts_set("cond_N", 2)
+    assert b.solve() == 0 and int(b.scalar("cond_N_active")) == 2
+    for i, qp in enumerate(qps):
+        o = OracleQp(qp)
+        assert o.solve(default_opts(tol_stat=1e-8)) == 0
+        compare_with_oracle(lambda k, f: b.get(f, k)[i], o, qp, 1e-8, fields=("x", "u", "pi", "lam", "t"))
+    d = lqr_dims(3, 40, 20)
+    d.ng[0] = 8                                                     # 2 * (40 + 20 + 8) = 136 sides at stage 0
+    with pytest.raises(RuntimeError):
+        OcpQpGpuBatch(d, 2, _clib=hostsim_lib)
+
+
 def test_tail_switch_with_general_rows_hostsim(hostsim_lib, monkeypatch):
     """a one-instance-per-lane level hands its last survivors to the wave-per-instance kernels; with
     equality-flagged x0 and general rows the multipliers of the fixed variables must come out of the family
