@@ -1424,7 +1424,7 @@ __global__ void __launch_bounds__(64) kw_backrhs(GqpDev D, GqpOpts O, int redo)
                 gsj = R.sj;
                 C.rRl[S.nb + lane] = gRl; C.rRu[S.nb + lane] = gRu; C.rGl[S.nb + lane] = gGl; C.rGu[S.nb + lane] = gGu;
             }
-            double sPl = 0.0, sPu = 0.0, sGl = 0.0, sGu = 0.0;
+            double sPl = 0.0, sPu = 0.0, sGl = 0.0, sGu = 0.0, sRgl = 0.0, sRgu = 0.0, sZl_ = 0.0, sZu_ = 0.0, sDl_ = 0.0, sDu_ = 0.0;
             if (iss)
             {
                 const int e0 = S.o_ct + 2 * nbg + lane, e1 = e0 + S.ns;
@@ -1436,19 +1436,23 @@ __global__ void __launch_bounds__(64) kw_backrhs(GqpDev D, GqpOpts O, int redo)
                 const double rmu = au ? lu * tu - O.tau_min + pscale * WAT(D.pcorr, e1) - smu : 0.0;
                 sPl = (rml + ll * rdl) * frcp(tl); sPu = (rmu + lu * rdu) * frcp(tu);
                 sGl = ll * frcp(tl); sGu = lu * frcp(tu);
+                /* everything else this lane needs from HBM, issued before the barrier */
+                sRgl = WAT(D.rgs, S.o_s + lane); sRgu = WAT(D.rgs, S.o_s + S.ns + lane);
+                sZl_ = WAT(D.Zz, (S.o_s + lane) * 2); sZu_ = WAT(D.Zz, (S.o_s + S.ns + lane) * 2);
+                sDl_ = WAT(D.sD, S.o_s + lane); sDu_ = WAT(D.sD, S.o_s + S.ns + lane);
             }
             __syncthreads(); /* rho of the soft rows published */
             if (iss)
             {
-                double Rl = WAT(D.rgs, S.o_s + lane) + sPl, Ru = WAT(D.rgs, S.o_s + S.ns + lane) + sPu;
+                double Rl = sRgl + sPl, Ru = sRgu + sPu;
                 C.sXl[lane] = Rl; C.sXu[lane] = Ru; /* r~ without the rows */
-                C.sEl[lane] = WAT(D.Zz, (S.o_s + lane) * 2) + sGl; C.sEu[lane] = WAT(D.Zz, (S.o_s + S.ns + lane) * 2) + sGu;
+                C.sEl[lane] = sZl_ + sGl; C.sEu[lane] = sZu_ + sGu;
                 int cnt = 0;
                 for (int row = 0; row < nbg; row++)
                     if (C.rsj[row] == lane) { Rl += C.rRl[row]; Ru += C.rRu[row]; cnt++; }
                 C.scnt[lane] = cnt;
                 WAT(D.sR, S.o_s + lane) = Rl; WAT(D.sR, S.o_s + S.ns + lane) = Ru;
-                const double Dl = WAT(D.sD, S.o_s + lane), Du = WAT(D.sD, S.o_s + S.ns + lane);
+                const double Dl = sDl_, Du = sDu_;
                 C.sIl[lane] = Dl != 0.0 ? frcp(Dl) : 0.0;
                 C.sIu[lane] = Du != 0.0 ? frcp(Du) : 0.0;
             }
@@ -1571,6 +1575,32 @@ __global__ void __launch_bounds__(64) kw_fwd(GqpDev D, GqpOpts O, int redo)
         const double ttl = al ? WAT(D.t, el) : 1.0, ttu = au ? WAT(D.t, eu) : 1.0;
         const double rdl = al ? WAT(D.rd, el) : 0.0, rdu = au ? WAT(D.rd, eu) : 0.0;
         const double pl = (CORR && al) ? WAT(D.pcorr, el) : 0.0, pu = (CORR && au) ? WAT(D.pcorr, eu) : 0.0;
+        /* GEN: what the slack lane and the general-row lane need from HBM, issued with the other loads */
+        double fDl = 0.0, fDu = 0.0, fRl = 0.0, fRu = 0.0, fZl = 0.0, fZu = 0.0, fsll = 0.0, fslu = 0.0, fstl = 1.0, fstu = 1.0,
+               fspl = 0.0, fspu = 0.0, fsrdl = 0.0, fsrdu = 0.0, fgrdl = 0.0, fgrdu = 0.0, fgpl = 0.0, fgpu = 0.0;
+        bool fsal = false, fsau = false;
+        WpiRow Rg;
+        if (GEN)
+        {
+            Rg = wpi_row(D, S, am, inst, S.nb + lane, lane < S.ng);
+            if (lane < S.ng)
+            {
+                fgrdl = Rg.al ? WAT(D.rd, Rg.el) : 0.0; fgrdu = Rg.au ? WAT(D.rd, Rg.eu) : 0.0;
+                fgpl = (CORR && Rg.al) ? WAT(D.pcorr, Rg.el) : 0.0; fgpu = (CORR && Rg.au) ? WAT(D.pcorr, Rg.eu) : 0.0;
+            }
+            if (lane < S.ns)
+            {
+                const int e0 = S.o_ct + 2 * nbg + lane, e1 = e0 + S.ns;
+                fsal = abit(am, 2 * nbg + lane); fsau = abit(am, 2 * nbg + S.ns + lane);
+                fDl = WAT(D.sD, S.o_s + lane); fDu = WAT(D.sD, S.o_s + S.ns + lane);
+                fRl = WAT(D.sR, S.o_s + lane); fRu = WAT(D.sR, S.o_s + S.ns + lane);
+                fZl = WAT(D.Zz, (S.o_s + lane) * 2); fZu = WAT(D.Zz, (S.o_s + S.ns + lane) * 2);
+                fsll = fsal ? WAT(D.lam, e0) : 0.0; fslu = fsau ? WAT(D.lam, e1) : 0.0;
+                fstl = fsal ? WAT(D.t, e0) : 1.0; fstu = fsau ? WAT(D.t, e1) : 1.0;
+                fspl = (CORR && fsal) ? WAT(D.pcorr, e0) : 0.0; fspu = (CORR && fsau) ? WAT(D.pcorr, e1) : 0.0;
+                fsrdl = fsal ? WAT(D.rd, e0) : 0.0; fsrdu = fsau ? WAT(D.rd, e1) : 0.0;
+            }
+        }
         __syncthreads();
         const double pf = k < D.N ? wpi_touch(D.Lf, NP, D.BAt, n * NX, inst, k + 1, lane) : 0.0;
 
@@ -1650,7 +1680,6 @@ __global__ void __launch_bounds__(64) kw_fwd(GqpDev D, GqpOpts O, int redo)
         {
             const bool isg = lane < S.ng, iss = lane < S.ns;
             const int bsj = has ? (int) S.srev[ib] : -1;
-            WpiRow Rg = wpi_row(D, S, am, inst, S.nb + lane, isg);
             double gdc = 0.0;
             if (isg)
             {
@@ -1677,23 +1706,22 @@ __global__ void __launch_bounds__(64) kw_fwd(GqpDev D, GqpOpts O, int redo)
                 for (int row = 0; row < nbg; row++)
                     if (C.rsj[row] == lane) { accl += C.rRl[row]; accu += C.rRu[row]; cnt++; }
                 C.scnt[lane] = cnt;
-                const double Dl = WAT(D.sD, S.o_s + lane), Du = WAT(D.sD, S.o_s + S.ns + lane);
+                const double Dl = fDl, Du = fDu;
                 const double il = Dl != 0.0 ? frcp(Dl) : 0.0, iu = Du != 0.0 ? frcp(Du) : 0.0;
-                const double rsl = WAT(D.sR, S.o_s + lane), rsu = WAT(D.sR, S.o_s + S.ns + lane);
+                const double rsl = fRl, rsu = fRu;
                 const double dsl = (-rsl - accl) * il, dsu = (-rsu + accu) * iu;
                 C.sIl[lane] = il; C.sIu[lane] = iu; C.sRl[lane] = rsl; C.sRu[lane] = rsu;
                 if (CORR) { WAT(D.dsv, S.o_s + lane) = dsl; WAT(D.dsv, S.o_s + S.ns + lane) = dsu; }
                 /* the two bound rows of the slack */
                 const int e0 = S.o_ct + 2 * nbg + lane, e1 = e0 + S.ns;
-                const bool sal = abit(am, 2 * nbg + lane), sau = abit(am, 2 * nbg + S.ns + lane);
-                const double sll = sal ? WAT(D.lam, e0) : 0.0, slu = sau ? WAT(D.lam, e1) : 0.0;
-                const double stl = sal ? WAT(D.t, e0) : 1.0, stu = sau ? WAT(D.t, e1) : 1.0;
-                C.sEl[lane] = WAT(D.Zz, (S.o_s + lane) * 2) + sll * frcp(stl);
-                C.sEu[lane] = WAT(D.Zz, (S.o_s + S.ns + lane) * 2) + slu * frcp(stu);
-                const double spl = (CORR && sal) ? WAT(D.pcorr, e0) : 0.0, spu = (CORR && sau) ? WAT(D.pcorr, e1) : 0.0;
+                const bool sal = fsal, sau = fsau;
+                const double sll = fsll, slu = fslu, stl = fstl, stu = fstu;
+                C.sEl[lane] = fZl + sll * frcp(stl);
+                C.sEu[lane] = fZu + slu * frcp(stu);
+                const double spl = fspl, spu = fspu;
                 const double rml = sal ? sll * stl - O.tau_min + pscale * spl - smu : 0.0;
                 const double rmu = sau ? slu * stu - O.tau_min + pscale * spu - smu : 0.0;
-                const double dtl = sal ? dsl + WAT(D.rd, e0) : 0.0, dtu = sau ? dsu + WAT(D.rd, e1) : 0.0;
+                const double dtl = sal ? dsl + fsrdl : 0.0, dtu = sau ? dsu + fsrdu : 0.0;
                 const double dll = sal ? -(rml + sll * dtl) * frcp(stl) : 0.0;
                 const double dlu = sau ? -(rmu + slu * dtu) * frcp(stu) : 0.0;
                 const double c1 = -sll * frcp(dll), c2 = -slu * frcp(dlu), c3 = -stl * frcp(dtl), c4 = -stu * frcp(dtu);
@@ -1741,8 +1769,7 @@ __global__ void __launch_bounds__(64) kw_fwd(GqpDev D, GqpOpts O, int redo)
                     gsl_ = (El * gdc - C.sRl[q] - al_) * C.sIl[q];
                     gsu_ = (-Eu * gdc - C.sRu[q] + au_) * C.sIu[q];
                 }
-                const double grdl = Rg.al ? WAT(D.rd, Rg.el) : 0.0, grdu = Rg.au ? WAT(D.rd, Rg.eu) : 0.0;
-                const double gpl = (CORR && Rg.al) ? WAT(D.pcorr, Rg.el) : 0.0, gpu = (CORR && Rg.au) ? WAT(D.pcorr, Rg.eu) : 0.0;
+                const double grdl = fgrdl, grdu = fgrdu, gpl = fgpl, gpu = fgpu;
                 const double rml = Rg.al ? Rg.ll * Rg.tl - O.tau_min + pscale * gpl - smu : 0.0;
                 const double rmu = Rg.au ? Rg.lu * Rg.tu - O.tau_min + pscale * gpu - smu : 0.0;
                 const double dtl = Rg.al ? gsl_ + grdl : 0.0, dtu = Rg.au ? gsu_ + grdu : 0.0;
