@@ -561,7 +561,13 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
         if (cost < best) { best = cost; b->ks = &ks; }
     };
     for (const KernelSet &ks : g_ksets) consider(ks);
-    for (int q = 0; q < g_n_ksets_large; q++) consider(g_ksets_large[q]);
+    {
+        /* the rolled-loop / scratch-resident instantiations only serve as a cross-check of the wave-per-instance
+         * family (ACADOS_AMD_WPI=0); by default a shape no register-resident instantiation covers goes there */
+        const char *e0 = getenv("ACADOS_AMD_WPI");
+        if (e0 && atoi(e0) == 0)
+            for (int q = 0; q < g_n_ksets_large; q++) consider(g_ksets_large[q]);
+    }
     if (g_force_ks) b->ks = g_force_ks;
     /* wave-per-instance family (ipm_kernels_wpi.hpp): box-constrained QPs whose stage block is too large for
      * the one-instance-per-lane register mapping.  Dimensions are runtime values there: no padding to a
