@@ -18,6 +18,7 @@
 #include "ipm_kernels.hpp"
 #include "ipm_kernels_box.hpp"
 #include "ipm_kernels_wpi.hpp"
+#include "ipm_kernels_w16.hpp"
 #include "kernel_sets.h"
 
 #define HIPCHK(x)                                                                              \
@@ -45,6 +46,18 @@ const KernelSet g_ksets[] = {
     GQP_KSET(12, 3, 0, 0),
 };
 
+/* sixteen-lanes-per-instance sweeps (ipm_kernels_w16.hpp): compiled (NX, NU) with nu + nx <= 16 */
+struct W16Set
+{
+    int NX, NU;
+    kern_redo_t fact, rhs, faff, fcor;
+    size_t shmem;
+};
+#define GQP_W16(NX, NU)                                                                                       \
+    {NX, NU, gqp::kx_factor<NX, NU>, gqp::kx_backrhs<NX, NU>, gqp::kx_fwd<NX, NU, false>, gqp::kx_fwd<NX, NU, true>, \
+     4 * gqp::W16Lds<NX, NU>::SZ * sizeof(double)}
+const W16Set g_w16_sets[] = {GQP_W16(4, 1), GQP_W16(8, 3), GQP_W16(12, 3), GQP_W16(4, 4)};
+
 } // namespace
 
 struct ocp_qp_gpu_batch
@@ -58,8 +71,10 @@ struct ocp_qp_gpu_batch
     int aos = 0;          /* instance-major arrays: wave-per-instance kernel family */
     int AW = 1;           /* activity words per stage (64 inequality sides each); 2 only for wave-per-instance batches */
     int wpi = 0;          /* wave-per-instance kernels (ipm_kernels_wpi.hpp): one workgroup per instance */
+    int w16 = 0;          /* ... whose four sweeps are the 16-lanes-per-instance kernels (ipm_kernels_w16.hpp): 4 instances per workgroup */
     size_t shmem = 0;     /* their dynamic LDS bytes (rhs / forward sweeps) */
     size_t shmem_fact = 0; /* dynamic LDS bytes of the factor sweep */
+    size_t w16_shmem = 0;  /* dynamic LDS bytes of a 16-lanes-per-instance workgroup (4 instances) */
     KernelSet own_ks;     /* runtime-shaped kernel set of a wpi batch (ks points here) */
     int xbox = 0;
     const KernelSet *ks = nullptr;
@@ -622,6 +637,23 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
             b->wpi = 1;
             b->aos = 1;
             b->AW = need_wpi ? 2 : 1;
+            /* small box-constrained stage blocks: four instances per wave, register rows + DPP row broadcasts */
+            {
+                const char *e16 = getenv("ACADOS_AMD_W16");
+                if (!gen && !ref && !need_wpi && !(e16 && atoi(e16) == 0))
+                    for (const W16Set &ws : g_w16_sets)
+                        if (ws.NX == wx && ws.NU == wu)
+                        {
+                            b->own_ks.back_fact = ws.fact; b->own_ks.back_rhs = ws.rhs; b->own_ks.fwd_aff = ws.faff; b->own_ks.fwd_corr = ws.fcor;
+                            for (int q = 0; q < 2; q++)
+                            {
+                                b->own_ks.box_fact[q] = ws.fact; b->own_ks.box_rhs[q] = ws.rhs;
+                                b->own_ks.box_fwd_aff[q] = ws.faff; b->own_ks.box_fwd_corr[q] = ws.fcor;
+                            }
+                            b->w16 = 1;
+                            b->w16_shmem = ws.shmem;
+                        }
+            }
             const size_t con = gqp::wpi_con_doubles(wx + wu, mg, ms);
             b->shmem = (ref ? gqp::wpi_lds_doubles(wx, wu) : gqp::wpi3_lds_doubles(wx, wu) + con) * sizeof(double);
             b->shmem_fact = (ref ? gqp::wpi_lds_doubles(wx, wu) : gqp::wpi2_lds_doubles(wx, wu) + con) * sizeof(double);
@@ -636,6 +668,7 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
     char nm[128];
     if (b->wpi && (b->ks->NG || b->ks->NS))
         snprintf(nm, sizeof(nm), "wpi-gen(nx=%d,nu=%d,ng=%d,ns=%d,lds=%zuB)", b->ks->NX, b->ks->NU, b->ks->NG, b->ks->NS, b->shmem_fact);
+    else if (b->w16) snprintf(nm, sizeof(nm), "w16-box<NX=%d,NU=%d>", b->ks->NX, b->ks->NU);
     else if (b->wpi) snprintf(nm, sizeof(nm), "wpi-box(nx=%d,nu=%d,lds=%zuB)", b->ks->NX, b->ks->NU, b->shmem);
     else snprintf(nm, sizeof(nm), "1tpi<NX=%d,NU=%d,NG=%d,NS=%d>", b->ks->NX, b->ks->NU, b->ks->NG, b->ks->NS);
     b->kname = nm;
@@ -959,6 +992,12 @@ struct IpmKernels
         else hipLaunchKernelGGL(kern, dim3(((b)->B + 63) / 64), dim3(64), 0, s, __VA_ARGS__);                 \
     } while (0)
 #define GQP_IPM_LAUNCH(b, kern, s, ...) GQP_IPM_LAUNCH_SHM(b, kern, (b)->shmem, s, __VA_ARGS__)
+/* the four sweeps: 16-lanes-per-instance batches pack 4 instances into one 64-lane workgroup */
+#define GQP_SWEEP_LAUNCH(b, kern, shm, s, ...)                                                                \
+    do {                                                                                                      \
+        if ((b)->w16) GQP_LAUNCH_COOP(kern, dim3(((b)->B + 3) / 4), dim3(64), (b)->w16_shmem, s, __VA_ARGS__);  \
+        else GQP_IPM_LAUNCH_SHM(b, kern, shm, s, __VA_ARGS__);                                                \
+    } while (0)
 
 static IpmKernels pick_kernels(const ocp_qp_gpu_batch *b)
 {
@@ -1017,7 +1056,7 @@ static void run_ipm(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch *root, Prof &prof, hip
     for (;; it++)
     {
         if (b == root) prof.begin(1, s); /* per-class timing covers the root level only (full-batch launches) */
-        GQP_IPM_LAUNCH_SHM(b, K.fact, b->shmem_fact, s, D, O, 0);
+        GQP_SWEEP_LAUNCH(b, K.fact, b->shmem_fact, s, D, O, 0);
         if (b == root) prof.end(s);
         root->launches++;
         HIPCHK(hipMemcpyAsync(b->h_nact, D.n_active, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1049,19 +1088,19 @@ static void run_ipm(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch *root, Prof &prof, hip
             break;
         }
         if (b == root) prof.begin(2, s);
-        GQP_IPM_LAUNCH(b, K.faff, s, D, O, 0);
+        GQP_SWEEP_LAUNCH(b, K.faff, b->shmem, s, D, O, 0);
         if (b == root) prof.end(s);
         if (b == root) prof.begin(3, s);
-        GQP_IPM_LAUNCH(b, K.rhs, s, D, O, 0);
+        GQP_SWEEP_LAUNCH(b, K.rhs, b->shmem, s, D, O, 0);
         if (b == root) prof.end(s);
         if (b == root) prof.begin(4, s);
-        GQP_IPM_LAUNCH(b, K.fcorr, s, D, O, 0);
+        GQP_SWEEP_LAUNCH(b, K.fcorr, b->shmem, s, D, O, 0);
         if (b == root) prof.end(s);
         root->launches += 3;
         if (O.cond_pred_corr)
         {
-            GQP_IPM_LAUNCH(b, K.rhs, s, D, O, 1);
-            GQP_IPM_LAUNCH(b, K.fcorr, s, D, O, 1);
+            GQP_SWEEP_LAUNCH(b, K.rhs, b->shmem, s, D, O, 1);
+            GQP_SWEEP_LAUNCH(b, K.fcorr, b->shmem, s, D, O, 1);
             root->launches += 2;
         }
     }
@@ -1099,7 +1138,7 @@ static void compact_into(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch *root, int nact, 
         c->idxb = b->idxb; c->idxs_rev = b->idxs_rev; c->idxe = b->idxe; c->nbxe = b->nbxe;
         c->compact_min = b->compact_min;
         c->tail_max = b->tail_max;
-        if (!tail) { c->aos = b->aos; c->wpi = b->wpi; c->shmem = b->shmem; c->shmem_fact = b->shmem_fact; }
+        if (!tail) { c->aos = b->aos; c->wpi = b->wpi; c->shmem = b->shmem; c->shmem_fact = b->shmem_fact; c->w16 = b->w16; c->w16_shmem = b->w16_shmem; }
         finalize_structure(c);
         slot = c;
     }

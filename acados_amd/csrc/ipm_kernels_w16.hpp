@@ -1,0 +1,552 @@
+/*
+ * ipm_kernels_w16.hpp -- SIXTEEN LANES PER INSTANCE: small stage blocks (nu + nx <= 16, box constraints).
+ *
+ * The wave-per-instance kernels (ipm_kernels_wpi.hpp) spend a whole wavefront on an 11 x 11 stage block and are
+ * bound by LDS round trips.  Here one wavefront carries FOUR instances (one per 16-lane DPP row); lane l of a row
+ * owns variable l AND row l of every stage matrix, in REGISTERS:
+ *   - the O(n^3) parts (W = [B A]' Lx+, M = H~ + W W', Cholesky with the rhs riding along) run on register rows
+ *     with `v_mov_b32_dpp row_newbcast:j` as the broadcast of lane j's value to its row -- no LDS, no barrier;
+ *   - the few products that need a COLUMN of a factor (Lx+' rb, the back substitution) exchange through a small
+ *     per-instance LDS tile (write rows, read columns);
+ *   - arrays are instance-major as for the wave-per-instance family, whose init / finalize kernels are reused.
+ * Same algorithm and HBM contract (arrays, slot conventions, p-form of the corrector sweep) as ipm_kernels_wpi.hpp.
+ * Shapes are compile-time (NX, NU): the broadcast lane is an immediate of the DPP instruction.
+ *
+ * Rows are independent: a row whose instance has converged leaves the kernel, the other rows of the wave go on
+ * (DPP row operations never cross rows).  Inside a live row all 16 lanes execute every broadcast.
+ * The CPU test tier runs these kernels under tests/hostsim: lanes are host threads, the row broadcast goes through
+ * a shared buffer and a per-row barrier (GQP_ROWSYNC).
+ */
+#ifndef IPM_KERNELS_W16_HPP_
+#define IPM_KERNELS_W16_HPP_
+
+#include "ipm_kernels_wpi.hpp"
+
+namespace gqp
+{
+
+#if defined(__HIP_DEVICE_COMPILE__)
+/* all lanes of a row see each other's LDS writes in program order (one wavefront); only the compiler must be kept
+ * from reordering across the exchange */
+#define GQP_ROWSYNC()                                                   \
+    do {                                                                \
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");          \
+        __builtin_amdgcn_wave_barrier();                                \
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");          \
+    } while (0)
+template <int J>
+__device__ static inline double w16_bc(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + J, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + J, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+/* value of lane j (0..15) of this lane's row; j must be a compile-time constant after unrolling */
+__device__ static inline double w16_bcast(double v, int j, double *)
+{
+    switch (j)
+    {
+        case 0: return w16_bc<0>(v); case 1: return w16_bc<1>(v); case 2: return w16_bc<2>(v); case 3: return w16_bc<3>(v);
+        case 4: return w16_bc<4>(v); case 5: return w16_bc<5>(v); case 6: return w16_bc<6>(v); case 7: return w16_bc<7>(v);
+        case 8: return w16_bc<8>(v); case 9: return w16_bc<9>(v); case 10: return w16_bc<10>(v); case 11: return w16_bc<11>(v);
+        case 12: return w16_bc<12>(v); case 13: return w16_bc<13>(v); case 14: return w16_bc<14>(v); default: return w16_bc<15>(v);
+    }
+}
+#else
+/* host simulation (tests/hostsim defines GQP_ROWSYNC as a per-row thread barrier) and the host pass of hipcc
+ * (kernels are only parsed there): the broadcast goes through the exchange buffer */
+#ifndef GQP_ROWSYNC
+#define GQP_ROWSYNC() do { } while (0)
+#endif
+__device__ static inline double w16_bcast(double v, int j, double *xbuf)
+{
+    const int l = threadIdx.x & 15;
+    xbuf[l] = v;
+    GQP_ROWSYNC();
+    const double r = xbuf[j];
+    GQP_ROWSYNC();
+    return r;
+}
+#endif
+
+/* per-instance LDS tile (doubles): exchange buffer, x-block tiles of two factors, one full factor tile, vectors */
+template <int NX, int NU>
+struct W16Lds
+{
+    static constexpr int n = NX + NU, LDX = NX + 1, LDF = n + 1;
+    static constexpr int XB = 0, TA = 16, TB = TA + NX * LDX, TF = TB + NX * LDX, VEC = TF + n * LDF, SZ = VEC + 16;
+};
+
+#define W16_UNROLL _Pragma("unroll")
+
+/* reductions over the 16 lanes of a row (result in every lane) */
+__device__ static inline double w16_rmax(double v, double *xb)
+{
+    double r = v;
+    W16_UNROLL for (int j = 0; j < 16; j++)
+    {
+        const double o = w16_bcast(v, j, xb);
+        r = (o > r || o != o) ? o : r;
+    }
+    return r;
+}
+__device__ static inline double w16_rsum(double v, double *xb)
+{
+    double r = 0.0;
+    W16_UNROLL for (int j = 0; j < 16; j++) r += w16_bcast(v, j, xb);
+    return r;
+}
+__device__ static inline double w16_rmin(double v, double *xb)
+{
+    double r = v;
+    W16_UNROLL for (int j = 0; j < 16; j++)
+    {
+        const double o = w16_bcast(v, j, xb);
+        r = o < r ? o : r;
+    }
+    return r;
+}
+
+/* ------------------------------------------------------------------------------------------------ factor */
+
+template <int NX, int NU>
+__global__ void __launch_bounds__(64) kx_factor(GqpDev D, GqpOpts O, int redo)
+{
+    GQP_DYN_SHARED(smem);
+    typedef W16Lds<NX, NU> LY;
+    constexpr int n = NX + NU, NP = n * (n + 1) / 2, LDX = LY::LDX;
+    const int l = threadIdx.x & 15, inst = blockIdx.x * 4 + (threadIdx.x >> 4);
+    if (inst >= D.B) return;
+    if (D.status[inst] != GQP_RUNNING) return;
+    double *T = smem + (threadIdx.x >> 4) * LY::SZ, *xb = T + LY::XB;
+    double *TA = T + LY::TA; /* x-block of the factor of stage k+1, [q][c] */
+    const bool mine = l < n, isx = l >= NU && l < n;
+    const int cx = isx ? l - NU : 0; /* state index of a state lane */
+
+    double Lp[NX];   /* row (NU + cx) of the x-block of the factor of stage k+1 (state lanes) */
+    double LpT[NX];  /* column cx of the same block */
+    W16_UNROLL for (int c = 0; c < NX; c++) { Lp[c] = 0.0; LpT[c] = 0.0; }
+    double lxn = 0.0; /* lx+ of this lane's state */
+    double nrm_g = 0.0, nrm_b = 0.0, nrm_d = 0.0, nrm_m = 0.0, musum = 0.0, obj = 0.0, nact = 0.0;
+
+    for (int k = D.N; k >= 0; k--)
+    {
+        const GqpStage &S = D.st[k];
+        const uint64_t imask = S.bmask & ~S.emask;
+        const uint64_t am = WAT(D.amask, k * D.AW);
+        const int nbg = S.nb;
+        const bool fixed = mine && ((S.emask >> l) & 1);
+
+        /* ---- loads: symmetric row l of H, row l of [B A]', column cx of [B A]' (state lanes) ---- */
+        double M[n], Br[NX], Bc[n];
+        W16_UNROLL for (int c = 0; c < n; c++) M[c] = mine ? WAT(D.RSQ, k * NP + (c <= l ? PK(l, c) : PK(c, l))) : (c == l ? 1.0 : 0.0);
+        W16_UNROLL for (int c = 0; c < NX; c++) Br[c] = mine ? WAT(D.BAt, (k * n + l) * NX + c) : 0.0;
+        W16_UNROLL for (int r = 0; r < n; r++) Bc[r] = isx ? WAT(D.BAt, (k * n + r) * NX + cx) : 0.0;
+        const double v = mine ? WAT(D.ux, k * n + l) : 0.0, g = mine ? WAT(D.rq, k * n + l) : 0.0;
+        double rb = isx ? WAT(D.bvec, k * NX + cx) - WAT(D.ux, (k + 1) * n + NU + cx) : 0.0;
+        const double pin = isx ? WAT(D.pi, (k + 1) * NX + cx) : 0.0, pik = isx ? WAT(D.pi, k * NX + cx) : 0.0;
+        const bool has = mine && ((imask >> l) & 1);
+        const int ib = has ? popc64(S.bmask & (((uint64_t) 1 << l) - 1)) : 0;
+        const bool al = has && ((am >> ib) & 1), au = has && ((am >> (nbg + ib)) & 1);
+        const int el = S.o_ct + ib, eu = el + nbg;
+        const double ll = al ? WAT(D.lam, el) : 0.0, lu = au ? WAT(D.lam, eu) : 0.0;
+        const double ttl = al ? WAT(D.t, el) : 1.0, ttu = au ? WAT(D.t, eu) : 1.0;
+        const double lbv = al ? WAT(D.dvec, el) : 0.0, ubv = au ? WAT(D.dvec, eu) : 0.0;
+
+        /* ---- rb += [B A] v, H v (one broadcast of v per variable serves both) ---- */
+        double hv = 0.0;
+        W16_UNROLL for (int r = 0; r < n; r++)
+        {
+            const double vr = w16_bcast(v, r, xb);
+            rb += Bc[r] * vr;
+            hv += M[r] * vr;
+        }
+        /* [B A]' pi+ */
+        double bp = 0.0;
+        W16_UNROLL for (int c = 0; c < NX; c++) bp += Br[c] * w16_bcast(pin, NU + c, xb);
+        double gt = 0.0, gadd = 0.0, gam = 0.0;
+        if (mine)
+        {
+            obj += (0.5 * hv + g) * v;
+            gt = bp + hv + g - pik;
+        }
+        if (isx) { nacc(nrm_b, rb); WAT(D.rb, k * NX + cx) = rb; }
+        if (has)
+        {
+            const double rdl = al ? v - lbv - ttl : 0.0, rdu = au ? ubv - v - ttu : 0.0;
+            const double rml = al ? ll * ttl - O.tau_min : 0.0, rmu = au ? lu * ttu - O.tau_min : 0.0;
+            nacc(nrm_d, rdl); nacc(nrm_d, rdu); nacc(nrm_m, rml); nacc(nrm_m, rmu);
+            musum += ll * ttl + lu * ttu;
+            nact += (double) ((int) al + (int) au);
+            gt -= ll - lu;
+            const double itl = frcp(ttl), itu = frcp(ttu);
+            gam = ll * itl + lu * itu;
+            gadd = (rml + ll * rdl) * itl - (rmu + lu * rdu) * itu;
+            WAT(D.rd, el) = rdl;
+            WAT(D.rd, eu) = rdu;
+        }
+        if (fixed) gt = 0.0;
+        if (mine) { nacc(nrm_g, gt); WAT(D.rg, k * n + l) = gt; }
+
+        /* ---- W row: W[c] = sum_{q >= c} Br[q] Lx+[q][c], Lx+[q][c] = entry c of the row held by lane NU + q ---- */
+        double W[NX];
+        W16_UNROLL for (int c = 0; c < NX; c++) W[c] = 0.0;
+        W16_UNROLL for (int q = 0; q < NX; q++)
+            W16_UNROLL for (int c = 0; c <= q; c++) W[c] += Br[q] * w16_bcast(Lp[c], NU + q, xb);
+        /* w0[c] (state lanes) = lx+[c] + sum_{q >= c} Lx+[q][c] rb[q]: column c of Lx+ is LpT */
+        double w0 = lxn;
+        W16_UNROLL for (int q = 0; q < NX; q++)
+        {
+            const double rbq = w16_bcast(rb, NU + q, xb);
+            w0 += (q >= cx ? LpT[q] : 0.0) * rbq;
+        }
+        if (!isx) w0 = 0.0;
+        /* m = gt + gadd + W w0 */
+        double m = gt + gadd;
+        W16_UNROLL for (int c = 0; c < NX; c++) m += W[c] * w16_bcast(w0, NU + c, xb);
+        if (fixed || !mine) m = 0.0;
+        /* ---- M += W W' + reg + Gamma: M[c] += sum_q W_l[q] W_c[q] ---- */
+        W16_UNROLL for (int q = 0; q < NX; q++)
+            W16_UNROLL for (int c = 0; c < n; c++) M[c] += W[q] * w16_bcast(W[q], c, xb);
+        W16_UNROLL for (int c = 0; c < n; c++)
+        {
+            if (c == l) M[c] += O.reg_prim + gam;
+            const bool fc = (S.emask >> c) & 1;
+            if (fixed || fc) M[c] = (c == l) ? 1.0 : 0.0;
+        }
+        if (!mine) { W16_UNROLL for (int c = 0; c < n; c++) M[c] = (c == l) ? 1.0 : 0.0; }
+
+        /* ---- Cholesky on register rows; the rhs entry m rides along (l = L^{-1} m) ---- */
+        W16_UNROLL for (int j = 0; j < n; j++)
+        {
+            const double d = w16_bcast(M[j], j, xb);
+            const bool pos = d > 0.0;
+            const double inv0 = frsqrt(pos ? d : 1.0);
+            const double inv = pos ? inv0 : 0.0;
+            const double lj = w16_bcast(m, j, xb) * inv;
+            const double Llj = l > j ? M[j] * inv : (l == j ? (pos ? d * inv : 0.0) : M[j]); /* L[l][j]; rows above keep their entry */
+            M[j] = Llj;
+            const double lo = l > j ? Llj : 0.0; /* finished rows take no part in the trailing update */
+            W16_UNROLL for (int c = j + 1; c < n; c++) M[c] -= lo * w16_bcast(lo, c, xb);
+            m = l == j ? lj : m - lo * lj;
+        }
+
+        /* ---- outputs ---- */
+        if (mine)
+        {
+            W16_UNROLL for (int c = 0; c < n; c++)
+                if (c <= l) WAT(D.Lf, k * NP + PK(l, c)) = M[c];
+            WAT(D.lf, k * n + l) = m;
+        }
+        /* x-block for the next (earlier) stage: rows stay in registers, columns go through the LDS tile */
+        GQP_ROWSYNC();
+        if (isx)
+        {
+            W16_UNROLL for (int c = 0; c < NX; c++)
+            {
+                Lp[c] = c <= cx ? M[NU + c] : 0.0;
+                TA[cx * LDX + c] = Lp[c];
+            }
+        }
+        GQP_ROWSYNC();
+        if (isx)
+        {
+            W16_UNROLL for (int q = 0; q < NX; q++) LpT[q] = TA[q * LDX + cx];
+        }
+        lxn = isx ? m : 0.0;
+    }
+
+    nrm_g = w16_rmax(nrm_g, xb); nrm_b = w16_rmax(nrm_b, xb); nrm_d = w16_rmax(nrm_d, xb); nrm_m = w16_rmax(nrm_m, xb);
+    musum = w16_rsum(musum, xb); obj = w16_rsum(obj, xb);
+    const double nact_d = w16_rsum(nact, xb);
+    if (l == 0)
+    {
+        const int Bp = D.Bp;
+        const double mu = nact_d > 0.0 ? musum / nact_d : 0.0;
+        D.mu[inst] = mu;
+        D.obj[inst] = obj;
+        D.res[0 * Bp + inst] = nrm_g; D.res[1 * Bp + inst] = nrm_b; D.res[2 * Bp + inst] = nrm_d; D.res[3 * Bp + inst] = nrm_m;
+        const int it = D.iter[inst];
+        if (inst < D.stat_inst && it < D.stat_rows)
+        {
+            double *st = D.stat + (size_t) it * GQP_STAT_COLS * D.stat_inst + inst;
+            st[6 * D.stat_inst] = mu;
+            st[7 * D.stat_inst] = nrm_g; st[8 * D.stat_inst] = nrm_b; st[9 * D.stat_inst] = nrm_d; st[10 * D.stat_inst] = nrm_m;
+            st[12 * D.stat_inst] = obj;
+        }
+        int status = GQP_RUNNING;
+        const bool bad = nrm_g != nrm_g || nrm_b != nrm_b || nrm_d != nrm_d || nrm_m != nrm_m || mu != mu;
+        if (bad) status = 1;
+        else if (nrm_g <= O.tol_stat && nrm_b <= O.tol_eq && nrm_d <= O.tol_ineq && nrm_m <= O.tol_comp) status = 0;
+        else if (it >= O.iter_max) status = 2;
+        else if (dabs(D.alpha[inst]) <= O.alpha_min) status = 3;
+        if (status != GQP_RUNNING)
+        {
+            D.status[inst] = status;
+            atomicSub(D.n_active, 1);
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------- rhs-only backward (p-form) */
+
+template <int NX, int NU>
+__global__ void __launch_bounds__(64) kx_backrhs(GqpDev D, GqpOpts O, int redo)
+{
+    GQP_DYN_SHARED(smem);
+    typedef W16Lds<NX, NU> LY;
+    constexpr int n = NX + NU, NP = n * (n + 1) / 2, LDX = LY::LDX;
+    const int l = threadIdx.x & 15, inst = blockIdx.x * 4 + (threadIdx.x >> 4);
+    if (inst >= D.B) return;
+    if (D.status[inst] != GQP_RUNNING) return;
+    if (redo && !(D.alpha[inst] < 0.0)) return;
+    double *T = smem + (threadIdx.x >> 4) * LY::SZ, *xb = T + LY::XB, *TA = T + LY::TA;
+    const bool mine = l < n, isx = l >= NU && l < n;
+    const int cx = isx ? l - NU : 0;
+    const double smu = D.smu[inst];
+    const double pscale = redo ? 0.0 : 1.0;
+    double Lp[NX], LpT[NX];
+    W16_UNROLL for (int c = 0; c < NX; c++) { Lp[c] = 0.0; LpT[c] = 0.0; }
+    double pn = 0.0; /* p of the stage handled before (state lanes) */
+
+    for (int k = D.N; k >= 0; k--)
+    {
+        const GqpStage &S = D.st[k];
+        const uint64_t imask = S.bmask & ~S.emask;
+        const uint64_t am = WAT(D.amask, k * D.AW);
+        const int nbg = S.nb;
+        const bool fixed = mine && ((S.emask >> l) & 1);
+        /* row l of the factor: the first NU columns (Lr, Ls) and, for state lanes, the x-block */
+        double Lu[NU > 0 ? NU : 1], Lx[NX], Br[NX];
+        W16_UNROLL for (int c = 0; c < NU; c++) Lu[c] = (mine && c <= l) ? WAT(D.Lf, k * NP + PK(l, c)) : 0.0;
+        W16_UNROLL for (int c = 0; c < NX; c++) Lx[c] = (isx && c <= cx) ? WAT(D.Lf, k * NP + PK(l, NU + c)) : 0.0;
+        W16_UNROLL for (int c = 0; c < NX; c++) Br[c] = mine ? WAT(D.BAt, (k * n + l) * NX + c) : 0.0;
+        const double rb = isx ? WAT(D.rb, k * NX + cx) : 0.0;
+        double m = mine ? WAT(D.rg, k * n + l) : 0.0;
+        const bool has = mine && ((imask >> l) & 1);
+        if (has)
+        {
+            const int ib = popc64(S.bmask & (((uint64_t) 1 << l) - 1));
+            const bool al = (am >> ib) & 1, au = (am >> (nbg + ib)) & 1;
+            const int el = S.o_ct + ib, eu = el + nbg;
+            const double ll = al ? WAT(D.lam, el) : 0.0, lu = au ? WAT(D.lam, eu) : 0.0;
+            const double ttl = al ? WAT(D.t, el) : 1.0, ttu = au ? WAT(D.t, eu) : 1.0;
+            const double rdl = al ? WAT(D.rd, el) : 0.0, rdu = au ? WAT(D.rd, eu) : 0.0;
+            const double rml = al ? ll * ttl - O.tau_min + pscale * WAT(D.pcorr, el) - smu : 0.0;
+            const double rmu = au ? lu * ttu - O.tau_min + pscale * WAT(D.pcorr, eu) - smu : 0.0;
+            m += (rml + ll * rdl) * frcp(ttl) - (rmu + lu * rdu) * frcp(ttu);
+        }
+        /* y = Lx+ (Lx+' rb) + p+ */
+        double w0 = 0.0;
+        W16_UNROLL for (int q = 0; q < NX; q++) w0 += (q >= cx ? LpT[q] : 0.0) * w16_bcast(rb, NU + q, xb);
+        if (!isx) w0 = 0.0;
+        double y = pn;
+        W16_UNROLL for (int c = 0; c < NX; c++) y += Lp[c] * w16_bcast(w0, NU + c, xb); /* Lp[c] = 0 above the diagonal */
+        if (!isx) y = 0.0;
+        double a = 0.0;
+        W16_UNROLL for (int c = 0; c < NX; c++) a += Br[c] * w16_bcast(y, NU + c, xb);
+        m = (fixed || !mine) ? 0.0 : m + a;
+        /* l_u = Lr^{-1} m_u; the rows below keep m_r -= L[r][j] l_j, which leaves p in the state lanes */
+        W16_UNROLL for (int j = 0; j < NU; j++)
+        {
+            const double d = w16_bcast(Lu[j], j, xb);
+            const double lj = d != 0.0 ? w16_bcast(m, j, xb) * frcp(d) : 0.0;
+            m = l == j ? lj : (l > j ? m - Lu[j] * lj : m);
+        }
+        if (mine) WAT(D.lf, k * n + l) = m;
+        /* this stage's x-block becomes "the stage handled before" */
+        GQP_ROWSYNC();
+        if (isx)
+        {
+            W16_UNROLL for (int c = 0; c < NX; c++) { Lp[c] = Lx[c]; TA[cx * LDX + c] = Lx[c]; }
+        }
+        GQP_ROWSYNC();
+        if (isx)
+        {
+            W16_UNROLL for (int q = 0; q < NX; q++) LpT[q] = TA[q * LDX + cx];
+        }
+        pn = isx ? m : 0.0;
+    }
+}
+
+/* --------------------------------------------------------------------------------------------------- forward */
+
+/* PFORM (= CORR): lf holds [l_u; p] (written by kx_backrhs), otherwise the plain l of the factor sweep */
+template <int NX, int NU, bool CORR>
+__global__ void __launch_bounds__(64) kx_fwd(GqpDev D, GqpOpts O, int redo)
+{
+    GQP_DYN_SHARED(smem);
+    typedef W16Lds<NX, NU> LY;
+    constexpr bool PFORM = CORR;
+    constexpr int n = NX + NU, NP = n * (n + 1) / 2, LDF = LY::LDF;
+    const int l = threadIdx.x & 15, inst = blockIdx.x * 4 + (threadIdx.x >> 4);
+    if (inst >= D.B) return;
+    if (D.status[inst] != GQP_RUNNING) return;
+    if (redo && !(D.alpha[inst] < 0.0)) return;
+    double *T = smem + (threadIdx.x >> 4) * LY::SZ, *xb = T + LY::XB, *TF = T + LY::TF;
+    const bool mine = l < n, isx = l >= NU && l < n;
+    const int cx = isx ? l - NU : 0;
+    const double smu = CORR ? D.smu[inst] : 0.0;
+    const double pscale = (CORR && !redo) ? 1.0 : 0.0;
+    double alpha = 1.0, S0 = 0.0, S1 = 0.0, S2 = 0.0, nact = 0.0;
+    double dx = 0.0; /* dx of this lane's state for the stage being entered */
+
+    for (int k = 0; k <= D.N; k++)
+    {
+        const GqpStage &S = D.st[k];
+        const uint64_t imask = S.bmask & ~S.emask;
+        const uint64_t am = WAT(D.amask, k * D.AW);
+        const int nbg = S.nb;
+        /* row l of the factor (registers) and, through the LDS tile, column l */
+        double Lr[n], Lc[n], Bc[n];
+        W16_UNROLL for (int c = 0; c < n; c++) Lr[c] = (mine && c <= l) ? WAT(D.Lf, k * NP + PK(l, c)) : 0.0;
+        W16_UNROLL for (int r = 0; r < n; r++) Bc[r] = isx ? WAT(D.BAt, (k * n + r) * NX + cx) : 0.0;
+        double lv = mine ? WAT(D.lf, k * n + l) : 0.0;
+        const double rbv = isx ? WAT(D.rb, k * NX + cx) : 0.0;
+        const bool has = mine && ((imask >> l) & 1);
+        const int ib = has ? popc64(S.bmask & (((uint64_t) 1 << l) - 1)) : 0;
+        const bool al = has && ((am >> ib) & 1), au = has && ((am >> (nbg + ib)) & 1);
+        const int el = S.o_ct + ib, eu = el + nbg;
+        const double ll = al ? WAT(D.lam, el) : 0.0, lu = au ? WAT(D.lam, eu) : 0.0;
+        const double ttl = al ? WAT(D.t, el) : 1.0, ttu = au ? WAT(D.t, eu) : 1.0;
+        const double rdl = al ? WAT(D.rd, el) : 0.0, rdu = au ? WAT(D.rd, eu) : 0.0;
+        const double pl = (CORR && al) ? WAT(D.pcorr, el) : 0.0, pu = (CORR && au) ? WAT(D.pcorr, eu) : 0.0;
+        GQP_ROWSYNC();
+        if (mine)
+        {
+            W16_UNROLL for (int c = 0; c < n; c++) TF[l * LDF + c] = Lr[c];
+        }
+        GQP_ROWSYNC();
+        W16_UNROLL for (int r = 0; r < n; r++) Lc[r] = (mine && r >= l) ? TF[r * LDF + l] : 0.0; /* L[r][l] */
+
+        if (PFORM && k == 0)
+        {
+            /* the states of stage 0 are free: recover l_x = Lx^{-1} p */
+            W16_UNROLL for (int j = NU; j < n; j++)
+            {
+                const double d = w16_bcast(Lr[j], j, xb);
+                const double lj = d != 0.0 ? w16_bcast(lv, j, xb) * frcp(d) : 0.0;
+                lv = l == j ? lj : (l > j ? lv - Lr[j] * lj : lv);
+            }
+        }
+        /* dpi_k = Lx (Lx' dx) + p  (CORR only; k > 0) */
+        if (CORR && k > 0)
+        {
+            double w0 = 0.0; /* (Lx' dx)[cx] = sum_{q >= cx} L[NU+q][NU+cx] dx[q]: column l of L */
+            W16_UNROLL for (int q = 0; q < NX; q++) w0 += Lc[NU + q] * w16_bcast(dx, NU + q, xb);
+            if (!isx) w0 = 0.0;
+            double a = lv;
+            W16_UNROLL for (int c = 0; c < NX; c++) a += Lr[NU + c] * w16_bcast(w0, NU + c, xb);
+            if (isx) WAT(D.dpi, k * NX + cx) = a;
+        }
+        /* L' dv = -l for the free block: everything at k = 0, the inputs otherwise; dv of the states = dx for k > 0 */
+        double dv = (k > 0 && isx) ? dx : 0.0;
+        double acc = -lv;
+        if (k > 0)
+        {
+            W16_UNROLL for (int p = NU; p < n; p++) acc -= Lc[p] * w16_bcast(dv, p, xb);
+        }
+        W16_UNROLL for (int r = n - 1; r >= 0; r--)
+        {
+            if (k > 0 && r >= NU) continue; /* uniform: states are given */
+            const double d = w16_bcast(Lr[r], r, xb);
+            const double dvr = d != 0.0 ? w16_bcast(acc, r, xb) * frcp(d) : 0.0;
+            if (l == r) dv = dvr;
+            else if (l < r) acc -= Lc[r] * dvr;
+        }
+        if (!mine) dv = 0.0;
+        if (CORR && mine) WAT(D.dux, k * n + l) = dv;
+        /* dx of the next stage */
+        double dxn = rbv;
+        W16_UNROLL for (int r = 0; r < n; r++) dxn += Bc[r] * w16_bcast(dv, r, xb);
+        if (has)
+        {
+            const double rml = al ? ll * ttl - O.tau_min + pscale * pl - smu : 0.0;
+            const double rmu = au ? lu * ttu - O.tau_min + pscale * pu - smu : 0.0;
+            const double dtl = al ? dv + rdl : 0.0, dtu = au ? -dv + rdu : 0.0;
+            const double dll = al ? -(rml + ll * dtl) * frcp(ttl) : 0.0;
+            const double dlu = au ? -(rmu + lu * dtu) * frcp(ttu) : 0.0;
+            const double c1 = -ll * frcp(dll), c2 = -lu * frcp(dlu), c3 = -ttl * frcp(dtl), c4 = -ttu * frcp(dtu);
+            alpha = (dll < 0.0 && c1 < alpha) ? c1 : alpha;
+            alpha = (dlu < 0.0 && c2 < alpha) ? c2 : alpha;
+            alpha = (dtl < 0.0 && c3 < alpha) ? c3 : alpha;
+            alpha = (dtu < 0.0 && c4 < alpha) ? c4 : alpha;
+            if (!CORR)
+            {
+                S0 += ll * ttl + lu * ttu;
+                S1 += ll * dtl + ttl * dll + lu * dtu + ttu * dlu;
+                S2 += dll * dtl + dlu * dtu;
+                nact += (double) ((int) al + (int) au);
+                WAT(D.pcorr, el) = dll * dtl;
+                WAT(D.pcorr, eu) = dlu * dtu;
+            }
+            else
+            {
+                WAT(D.dlam, el) = dll; WAT(D.dlam, eu) = dlu;
+                WAT(D.dt, el) = dtl; WAT(D.dt, eu) = dtu;
+            }
+        }
+        dx = isx ? dxn : 0.0;
+    }
+
+    alpha = w16_rmin(alpha, xb);
+    const int it = D.iter[inst];
+    double *st = (inst < D.stat_inst && it + 1 < D.stat_rows) ? D.stat + (size_t) (it + 1) * GQP_STAT_COLS * D.stat_inst + inst : nullptr;
+    if (!CORR)
+    {
+        S0 = w16_rsum(S0, xb); S1 = w16_rsum(S1, xb); S2 = w16_rsum(S2, xb);
+        const double nact_d = w16_rsum(nact, xb);
+        if (l == 0)
+        {
+            const double mu = D.mu[inst];
+            const double mu_aff = nact_d > 0.0 ? (S0 + alpha * S1 + alpha * alpha * S2) / nact_d : 0.0;
+            double sigma = mu > 0.0 ? mu_aff / mu : 0.0;
+            sigma = sigma * sigma * sigma;
+            D.smu[inst] = sigma * mu;
+            D.alpha[inst] = alpha;
+            if (st) { st[0] = alpha; st[1 * D.stat_inst] = alpha; st[2 * D.stat_inst] = mu_aff; st[3 * D.stat_inst] = sigma; }
+        }
+        return;
+    }
+    const double alpha_aff = dabs(D.alpha[inst]);
+    GQP_ROWSYNC(); /* everybody has read alpha[inst] */
+    if (O.cond_pred_corr && !redo && alpha < 0.1 * alpha_aff)
+    {
+        if (l == 0) D.alpha[inst] = -alpha_aff;
+        return;
+    }
+    const double a = D.mu[inst] > 0.0 ? alpha * 0.995 : 1.0;
+    /* update: one lane per variable / state / box row of the stage (dux, dpi, dlam, dt were written by these very lanes) */
+    for (int k = 0; k <= D.N; k++)
+    {
+        const GqpStage &S = D.st[k];
+        const uint64_t imask = S.bmask & ~S.emask;
+        const uint64_t am = WAT(D.amask, k * D.AW);
+        const int nbg = S.nb;
+        if (mine) WAT(D.ux, k * n + l) += a * WAT(D.dux, k * n + l);
+        if (isx && k > 0) WAT(D.pi, k * NX + cx) += a * WAT(D.dpi, k * NX + cx);
+        if (mine && ((imask >> l) & 1))
+        {
+            const int ib = popc64(S.bmask & (((uint64_t) 1 << l) - 1));
+            for (int side = 0; side < 2; side++)
+            {
+                const int e = S.o_ct + side * nbg + ib;
+                if (!((am >> (side * nbg + ib)) & 1)) continue;
+                const double lam = WAT(D.lam, e) + a * WAT(D.dlam, e);
+                const double t = WAT(D.t, e) + a * WAT(D.dt, e);
+                WAT(D.lam, e) = lam < O.lam_min ? O.lam_min : lam;
+                WAT(D.t, e) = t < O.t_min ? O.t_min : t;
+            }
+        }
+    }
+    if (l == 0)
+    {
+        D.alpha[inst] = alpha;
+        D.iter[inst] = it + 1;
+        if (st) { st[4 * D.stat_inst] = alpha; st[5 * D.stat_inst] = alpha; }
+    }
+}
+
+} // namespace gqp
+
+#endif

@@ -78,9 +78,12 @@ static inline int atomicAdd(int *p, int v) { int o = *p; *p = o + v; return o; }
 struct hostsim_coop
 {
     static pthread_barrier_t &bar() { static pthread_barrier_t b; return b; }
+    static pthread_barrier_t &rowbar(int row) { static pthread_barrier_t b[4]; return b[row & 3]; } /* 16-lane rows */
     static std::vector<double> &dyn() { static std::vector<double> v; return v; }
 };
 static inline void __syncthreads() { pthread_barrier_wait(&hostsim_coop::bar()); }
+/* lanes of one 16-lane row (kernels with several independent instances per block) */
+#define GQP_ROWSYNC() pthread_barrier_wait(&hostsim_coop::rowbar(threadIdx.x >> 4))
 #define GQP_DYN_SHARED(name) double *name = hostsim_coop::dyn().data()
 
 #define GQP_LAUNCH_COOP(kern, grid, block, shmem, stream, ...)                              \
@@ -90,6 +93,7 @@ static inline void __syncthreads() { pthread_barrier_wait(&hostsim_coop::bar());
         for (unsigned bx_ = 0; bx_ < g_.x; bx_++)                                           \
         {                                                                                   \
             pthread_barrier_init(&hostsim_coop::bar(), nullptr, b_.x);                      \
+            for (int r_ = 0; r_ < 4; r_++) pthread_barrier_init(&hostsim_coop::rowbar(r_), nullptr, 16); \
             std::vector<std::thread> th_;                                                   \
             for (unsigned tx_ = 0; tx_ < b_.x; tx_++)                                       \
                 th_.emplace_back([=]() {                                                    \
@@ -98,6 +102,7 @@ static inline void __syncthreads() { pthread_barrier_wait(&hostsim_coop::bar());
                 });                                                                         \
             for (auto &t_ : th_) t_.join();                                                 \
             pthread_barrier_destroy(&hostsim_coop::bar());                                  \
+            for (int r_ = 0; r_ < 4; r_++) pthread_barrier_destroy(&hostsim_coop::rowbar(r_)); \
         }                                                                                   \
     } while (0)
 
