@@ -37,9 +37,9 @@ namespace gqp
 template <int J>
 __device__ static inline double w16_bc(double v)
 {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + J, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + J, 0xF, 0xF, false);
-    return __hiloint2double(hi, lo);
+    /* one v_mov_b64_dpp (gfx90a+: 64-bit DPP exists for row_newbcast); every lane of the row is written
+     * (bound_ctrl, full masks), so there is no `old` value to initialise */
+    return __builtin_amdgcn_update_dpp(v, v, 0x150 + J, 0xF, 0xF, true);
 }
 /* value of lane j (0..15) of this lane's row; j must be a compile-time constant after unrolling */
 __device__ static inline double w16_bcast(double v, int j, double *)

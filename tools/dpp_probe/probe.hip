@@ -4,9 +4,7 @@
 template <int J>
 __device__ inline double row_bcast(double v)
 {
-    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x150 + J, 0xF, 0xF, false);
-    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x150 + J, 0xF, 0xF, false);
-    return __hiloint2double(hi, lo);
+    return __builtin_amdgcn_update_dpp(v, v, 0x150 + J, 0xF, 0xF, true); /* v_mov_b64_dpp row_newbcast:J bound_ctrl:1 */
 }
 __global__ void k(double *p)
 {
