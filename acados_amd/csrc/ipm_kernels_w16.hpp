@@ -137,18 +137,21 @@ __global__ void __launch_bounds__(64) kx_factor(GqpDev D, GqpOpts O, int redo)
         const int nbg = S.nb;
         const bool fixed = mine && ((S.emask >> l) & 1);
 
-        /* ---- loads: symmetric row l of H, row l of [B A]', column cx of [B A]' (state lanes) ---- */
+        /* ---- loads: symmetric row l of H, row l of [B A]', column cx of [B A]' (state lanes).  Idle lanes read
+         * through clamped indices and zero the values afterwards: no exec-masked branch per load ---- */
+        const int lc_ = mine ? l : 0, xc_ = isx ? cx : 0;
+        const double zm = mine ? 1.0 : 0.0, zx = isx ? 1.0 : 0.0;
         double M[n], Br[NX], Bc[n];
-        W16_UNROLL for (int c = 0; c < n; c++) M[c] = mine ? WAT(D.RSQ, k * NP + (c <= l ? PK(l, c) : PK(c, l))) : (c == l ? 1.0 : 0.0);
-        W16_UNROLL for (int c = 0; c < NX; c++) Br[c] = mine ? WAT(D.BAt, (k * n + l) * NX + c) : 0.0;
-        W16_UNROLL for (int r = 0; r < n; r++) Bc[r] = isx ? WAT(D.BAt, (k * n + r) * NX + cx) : 0.0;
-        const double v = mine ? WAT(D.ux, k * n + l) : 0.0, g = mine ? WAT(D.rq, k * n + l) : 0.0;
-        double rb = isx ? WAT(D.bvec, k * NX + cx) - WAT(D.ux, (k + 1) * n + NU + cx) : 0.0;
-        const double pin = isx ? WAT(D.pi, (k + 1) * NX + cx) : 0.0, pik = isx ? WAT(D.pi, k * NX + cx) : 0.0;
+        W16_UNROLL for (int c = 0; c < n; c++) M[c] = zm * WAT(D.RSQ, k * NP + (c <= lc_ ? PK(lc_, c) : PK(c, lc_)));
+        W16_UNROLL for (int c = 0; c < NX; c++) Br[c] = zm * WAT(D.BAt, (k * n + lc_) * NX + c);
+        W16_UNROLL for (int r = 0; r < n; r++) Bc[r] = zx * WAT(D.BAt, (k * n + r) * NX + xc_);
+        const double v = zm * WAT(D.ux, k * n + lc_), g = zm * WAT(D.rq, k * n + lc_);
+        double rb = zx * (WAT(D.bvec, k * NX + xc_) - WAT(D.ux, (k + 1) * n + NU + xc_));
+        const double pin = zx * WAT(D.pi, (k + 1) * NX + xc_), pik = zx * WAT(D.pi, k * NX + xc_);
         const bool has = mine && ((imask >> l) & 1);
         const int ib = has ? popc64(S.bmask & (((uint64_t) 1 << l) - 1)) : 0;
         const bool al = has && ((am >> ib) & 1), au = has && ((am >> (nbg + ib)) & 1);
-        const int el = S.o_ct + ib, eu = el + nbg;
+        const int el = S.o_ct + ib, eu = el + nbg; /* row 0 of the stage when the lane has no row: always readable */
         const double ll = al ? WAT(D.lam, el) : 0.0, lu = au ? WAT(D.lam, eu) : 0.0;
         const double ttl = al ? WAT(D.t, el) : 1.0, ttu = au ? WAT(D.t, eu) : 1.0;
         const double lbv = al ? WAT(D.dvec, el) : 0.0, ubv = au ? WAT(D.dvec, eu) : 0.0;
@@ -208,13 +211,15 @@ __global__ void __launch_bounds__(64) kx_factor(GqpDev D, GqpOpts O, int redo)
         /* ---- M += W W' + reg + Gamma: M[c] += sum_q W_l[q] W_c[q] ---- */
         W16_UNROLL for (int q = 0; q < NX; q++)
             W16_UNROLL for (int c = 0; c < n; c++) M[c] += W[q] * w16_bcast(W[q], c, xb);
-        W16_UNROLL for (int c = 0; c < n; c++)
+        W16_UNROLL for (int c = 0; c < n; c++) M[c] += (c == l) ? O.reg_prim + gam : 0.0;
+        if (S.emask) /* uniform: only a stage with fixed variables pays for the masking */
         {
-            if (c == l) M[c] += O.reg_prim + gam;
-            const bool fc = (S.emask >> c) & 1;
-            if (fixed || fc) M[c] = (c == l) ? 1.0 : 0.0;
+            W16_UNROLL for (int c = 0; c < n; c++)
+            {
+                const bool fc = (S.emask >> c) & 1;
+                if (fixed || fc) M[c] = (c == l) ? 1.0 : 0.0;
+            }
         }
-        if (!mine) { W16_UNROLL for (int c = 0; c < n; c++) M[c] = (c == l) ? 1.0 : 0.0; }
 
         /* ---- Cholesky on register rows; the rhs entry m rides along (l = L^{-1} m) ---- */
         W16_UNROLL for (int j = 0; j < n; j++)
@@ -224,7 +229,9 @@ __global__ void __launch_bounds__(64) kx_factor(GqpDev D, GqpOpts O, int redo)
             const double inv0 = frsqrt(pos ? d : 1.0);
             const double inv = pos ? inv0 : 0.0;
             const double lj = w16_bcast(m, j, xb) * inv;
-            const double Llj = l > j ? M[j] * inv : (l == j ? (pos ? d * inv : 0.0) : M[j]); /* L[l][j]; rows above keep their entry */
+            /* L[l][j] = M[l][j] inv for l >= j (the pivot lane holds d: d inv = sqrt(d), 0 for a non-positive pivot);
+             * rows above keep their entry */
+            const double Llj = l >= j ? M[j] * inv : M[j];
             M[j] = Llj;
             const double lo = l > j ? Llj : 0.0; /* finished rows take no part in the trailing update */
             W16_UNROLL for (int c = j + 1; c < n; c++) M[c] -= lo * w16_bcast(lo, c, xb);
@@ -317,12 +324,15 @@ __global__ void __launch_bounds__(64) kx_backrhs(GqpDev D, GqpOpts O, int redo)
         const int nbg = S.nb;
         const bool fixed = mine && ((S.emask >> l) & 1);
         /* row l of the factor: the first NU columns (Lr, Ls) and, for state lanes, the x-block */
+        /* branch-free loads: clamped indices, idle lanes zero the value */
+        const int lc_ = mine ? l : 0, xl_ = isx ? l : NU, xc_ = isx ? cx : 0;
+        const double zm = mine ? 1.0 : 0.0, zx = isx ? 1.0 : 0.0;
         double Lu[NU > 0 ? NU : 1], Lx[NX], Br[NX];
-        W16_UNROLL for (int c = 0; c < NU; c++) Lu[c] = (mine && c <= l) ? WAT(D.Lf, k * NP + PK(l, c)) : 0.0;
-        W16_UNROLL for (int c = 0; c < NX; c++) Lx[c] = (isx && c <= cx) ? WAT(D.Lf, k * NP + PK(l, NU + c)) : 0.0;
-        W16_UNROLL for (int c = 0; c < NX; c++) Br[c] = mine ? WAT(D.BAt, (k * n + l) * NX + c) : 0.0;
-        const double rb = isx ? WAT(D.rb, k * NX + cx) : 0.0;
-        double m = mine ? WAT(D.rg, k * n + l) : 0.0;
+        W16_UNROLL for (int c = 0; c < NU; c++) Lu[c] = (c <= lc_ ? zm : 0.0) * WAT(D.Lf, k * NP + PK(lc_, (c <= lc_ ? c : 0)));
+        W16_UNROLL for (int c = 0; c < NX; c++) Lx[c] = (c <= xc_ ? zx : 0.0) * WAT(D.Lf, k * NP + PK(xl_, NU + (c <= xc_ ? c : 0)));
+        W16_UNROLL for (int c = 0; c < NX; c++) Br[c] = zm * WAT(D.BAt, (k * n + lc_) * NX + c);
+        const double rb = zx * WAT(D.rb, k * NX + xc_);
+        double m = zm * WAT(D.rg, k * n + lc_);
         const bool has = mine && ((imask >> l) & 1);
         if (has)
         {
@@ -398,11 +408,13 @@ __global__ void __launch_bounds__(64) kx_fwd(GqpDev D, GqpOpts O, int redo)
         const uint64_t am = WAT(D.amask, k * D.AW);
         const int nbg = S.nb;
         /* row l of the factor (registers) and, through the LDS tile, column l */
+        const int lc_ = mine ? l : 0, xc_ = isx ? cx : 0;
+        const double zm = mine ? 1.0 : 0.0, zx = isx ? 1.0 : 0.0;
         double Lr[n], Lc[n], Bc[n];
-        W16_UNROLL for (int c = 0; c < n; c++) Lr[c] = (mine && c <= l) ? WAT(D.Lf, k * NP + PK(l, c)) : 0.0;
-        W16_UNROLL for (int r = 0; r < n; r++) Bc[r] = isx ? WAT(D.BAt, (k * n + r) * NX + cx) : 0.0;
-        double lv = mine ? WAT(D.lf, k * n + l) : 0.0;
-        const double rbv = isx ? WAT(D.rb, k * NX + cx) : 0.0;
+        W16_UNROLL for (int c = 0; c < n; c++) Lr[c] = (c <= lc_ ? zm : 0.0) * WAT(D.Lf, k * NP + PK(lc_, (c <= lc_ ? c : 0)));
+        W16_UNROLL for (int r = 0; r < n; r++) Bc[r] = zx * WAT(D.BAt, (k * n + r) * NX + xc_);
+        double lv = zm * WAT(D.lf, k * n + lc_);
+        const double rbv = zx * WAT(D.rb, k * NX + xc_);
         const bool has = mine && ((imask >> l) & 1);
         const int ib = has ? popc64(S.bmask & (((uint64_t) 1 << l) - 1)) : 0;
         const bool al = has && ((am >> ib) & 1), au = has && ((am >> (nbg + ib)) & 1);
@@ -516,27 +528,43 @@ __global__ void __launch_bounds__(64) kx_fwd(GqpDev D, GqpOpts O, int redo)
         return;
     }
     const double a = D.mu[inst] > 0.0 ? alpha * 0.995 : 1.0;
-    /* update: one lane per variable / state / box row of the stage (dux, dpi, dlam, dt were written by these very lanes) */
+    /* update: one lane per variable / state / box row of the stage (dux, dpi, dlam, dt were written by these very
+     * lanes); separate loops with independent iterations, several stages in flight */
+    const int lc_ = mine ? l : 0, xc_ = isx ? cx : 0;
+    _Pragma("unroll 4")
     for (int k = 0; k <= D.N; k++)
     {
-        const GqpStage &S = D.st[k];
-        const uint64_t imask = S.bmask & ~S.emask;
-        const uint64_t am = WAT(D.amask, k * D.AW);
-        const int nbg = S.nb;
-        if (mine) WAT(D.ux, k * n + l) += a * WAT(D.dux, k * n + l);
-        if (isx && k > 0) WAT(D.pi, k * NX + cx) += a * WAT(D.dpi, k * NX + cx);
-        if (mine && ((imask >> l) & 1))
+        const double u0 = WAT(D.ux, k * n + lc_), du = WAT(D.dux, k * n + lc_);
+        if (mine) WAT(D.ux, k * n + l) = u0 + a * du;
+    }
+    _Pragma("unroll 4")
+    for (int k = 1; k <= D.N; k++)
+    {
+        const double p0 = WAT(D.pi, k * NX + xc_), dp = WAT(D.dpi, k * NX + xc_);
+        if (isx) WAT(D.pi, k * NX + cx) = p0 + a * dp;
+    }
+    {
+        /* distinct arrays: tell the compiler, so that the loads of several stages can be in flight */
+        const GqpStage *__restrict__ st_ = D.st;
+        const uint64_t *__restrict__ am_ = D.amask.p + (size_t) inst * D.amask.E;
+        double *__restrict__ lam_ = D.lam.p + (size_t) inst * D.lam.E;
+        double *__restrict__ t_ = D.t.p + (size_t) inst * D.t.E;
+        const double *__restrict__ dlam_ = D.dlam.p + (size_t) inst * D.dlam.E;
+        const double *__restrict__ dt_ = D.dt.p + (size_t) inst * D.dt.E;
+        _Pragma("unroll 4")
+        for (int k = 0; k <= D.N; k++)
         {
-            const int ib = popc64(S.bmask & (((uint64_t) 1 << l) - 1));
-            for (int side = 0; side < 2; side++)
-            {
-                const int e = S.o_ct + side * nbg + ib;
-                if (!((am >> (side * nbg + ib)) & 1)) continue;
-                const double lam = WAT(D.lam, e) + a * WAT(D.dlam, e);
-                const double t = WAT(D.t, e) + a * WAT(D.dt, e);
-                WAT(D.lam, e) = lam < O.lam_min ? O.lam_min : lam;
-                WAT(D.t, e) = t < O.t_min ? O.t_min : t;
-            }
+            const uint64_t bm = st_[k].bmask, imask = bm & ~st_[k].emask;
+            const uint64_t am = am_[k * D.AW];
+            const int nbg = st_[k].nb;
+            const bool has = mine && ((imask >> l) & 1);
+            const int ib = has ? popc64(bm & (((uint64_t) 1 << l) - 1)) : 0;
+            const int el = st_[k].o_ct + ib, eu = el + nbg;
+            const bool al = has && ((am >> ib) & 1), au = has && ((am >> (nbg + ib)) & 1);
+            const double laml = lam_[el] + a * dlam_[el], lamu = lam_[eu] + a * dlam_[eu];
+            const double tl = t_[el] + a * dt_[el], tu = t_[eu] + a * dt_[eu];
+            if (al) { lam_[el] = laml < O.lam_min ? O.lam_min : laml; t_[el] = tl < O.t_min ? O.t_min : tl; }
+            if (au) { lam_[eu] = lamu < O.lam_min ? O.lam_min : lamu; t_[eu] = tu < O.t_min ? O.t_min : tu; }
         }
     }
     if (l == 0)
