@@ -36,6 +36,7 @@ namespace
 
 #define GQP_WPI_MIN_N 13       /* nu+nx from which the wave-per-instance kernels serve every batch */
 #define GQP_WPI_BATCH_MAX 8192 /* batch size up to which they also serve the smaller stage blocks */
+#define GQP_W16_BATCH_MAX 20480 /* ... where a 16-lanes-per-instance instantiation exists (crossover of the C2 shape: ~20k) */
 
 /* compiled shape classes; a batch is served by the cheapest one that covers it */
 const KernelSet g_ksets[] = {
@@ -120,7 +121,7 @@ struct ocp_qp_gpu_batch
     int compact_min = 1 << 30;           /* levels smaller than this are not compacted; off by default: it only
                                             pays once every sweep kernel is bandwidth-bound */
     ocp_qp_gpu_batch *tail = nullptr;    /* wave-per-instance sub-batch for the last survivors of a one-instance-per-lane level */
-    int tail_max = 6144;                 /* switch to it when at most this many instances (and a quarter of the level) remain; 0 = off */
+    int tail_max = 12288;                /* switch to it when at most this many instances (and a quarter of the level) remain; 0 = off */
     int n_tail_switches = 0;
     int *d_list = nullptr;               /* instance index of every slot of `compact` / `tail` */
     int list_cap = 0;
@@ -610,7 +611,13 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
          * instances per wave (measured crossover on the C2 shape between 4,096 and 16,384 instances,
          * tools/family_crossover.py).  ACADOS_AMD_WPI_BATCH_MAX overrides the batch threshold. */
         const char *bm = getenv("ACADOS_AMD_WPI_BATCH_MAX");
-        const int batch_max = bm ? atoi(bm) : GQP_WPI_BATCH_MAX;
+        bool has_w16 = false;
+        {
+            const char *e16 = getenv("ACADOS_AMD_W16");
+            if (!gen && !need_wpi && !(e16 && atoi(e16) == 0))
+                for (const W16Set &ws : g_w16_sets) has_w16 = has_w16 || (ws.NX == wx && ws.NU == wu);
+        }
+        const int batch_max = bm ? atoi(bm) : (has_w16 ? GQP_W16_BATCH_MAX : GQP_WPI_BATCH_MAX);
         const bool want = g_force_wpi || need_wpi || (env ? atoi(env) != 0 : (wx + wu >= GQP_WPI_MIN_N || !b->ks || n_batch <= batch_max));
         if (want && wx + wu <= 64 && wx >= 1 && mg <= 32 && ms <= 32)
         {

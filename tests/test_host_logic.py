@@ -258,26 +258,29 @@ def test_wave_per_instance_general_rows_shared_slacks_hostsim(hostsim_lib, monke
         assert o.solve(default_opts(tol_stat=1e-8)) == 0
         b = OcpQpGpuBatch.from_qps([qp, qp], _clib=hostsim_lib)
         b.opts_set("tol_stat", 1e-8)
-        assert b.solve() == 0 and b.kernel_name.startswith("wpi-")
+        assert b.solve() == 0 and b.kernel_name.startswith(("wpi-", "w16-"))
         compare_with_oracle(lambda k, f: b.get(f, k)[1], o, qp, 1e-7)
         assert int(b.info("iter")[1]) == o.iter
 
 
-@pytest.mark.parametrize("wpi", ["0", "1"])
-def test_c5_shape_classes_and_multiphase_hostsim(hostsim_lib, monkeypatch, wpi):
+@pytest.mark.parametrize("fam", ["1tpi", "wpi", "w16"])
+def test_c5_shape_classes_and_multiphase_hostsim(hostsim_lib, monkeypatch, fam):
     """C5: shape classes nx in {4,12,24} (nu = ceil(nx/4)) and the multi-phase class whose state
     dimension switches 12 -> 4 mid-horizon (per-stage dims inside one padded kernel shape).
-    Both kernel families: one instance per lane (ACADOS_AMD_WPI=0) and one wave per instance
-    (ACADOS_AMD_WPI=1; the default from nu+nx = 13 on)."""
+    All three kernel families: one instance per lane (ACADOS_AMD_WPI=0), one wave per instance
+    (ACADOS_AMD_WPI=1 ACADOS_AMD_W16=0) and sixteen lanes per instance (ACADOS_AMD_WPI=1; exists for
+    nu+nx <= 16, nx=24 nu=6 stays one wave per instance)."""
     from acados_amd.generators import lqr_instance_qp, multiphase_qp, random_lqr_batch
-    monkeypatch.setenv("ACADOS_AMD_WPI", wpi)
-    fam = "wpi-box(" if wpi == "1" else "1tpi-box<"
+    monkeypatch.setenv("ACADOS_AMD_WPI", "0" if fam == "1tpi" else "1")
+    monkeypatch.setenv("ACADOS_AMD_W16", "1" if fam == "w16" else "0")
     for nx, nu in ((4, 1), (12, 3), (24, 6)):
-        data = random_lqr_batch(N=5, nx=nx, nu=nu, batch=2, seed=7)
-        b = _check_batch_vs_oracle([lqr_instance_qp(data, i, 5) for i in range(2)], hostsim_lib)
-        assert b.kernel_name.startswith(fam)
+        data = random_lqr_batch(N=5, nx=nx, nu=nu, batch=2 if fam != "w16" else 5, seed=7)
+        nb = 2 if fam != "w16" else 5   # 5 instances: a full 4-instance workgroup and a ragged one
+        b = _check_batch_vs_oracle([lqr_instance_qp(data, i, 5) for i in range(nb)], hostsim_lib)
+        want = {"1tpi": "1tpi-box<", "wpi": "wpi-box(", "w16": "w16-box<" if nx + nu <= 16 else "wpi-box("}[fam]
+        assert b.kernel_name.startswith(want)
     b = _check_batch_vs_oracle([multiphase_qp(i, N=8) for i in range(3)], hostsim_lib)
-    assert b.kernel_name.startswith("wpi-box(nx=12,nu=3" if wpi == "1" else "1tpi-box<NX=12,NU=3")
+    assert b.kernel_name.startswith({"1tpi": "1tpi-box<NX=12,NU=3", "wpi": "wpi-box(nx=12,nu=3", "w16": "w16-box<NX=12,NU=3>"}[fam])
 
 
 def test_wave_per_instance_default_rule_hostsim(hostsim_lib, monkeypatch):
@@ -288,6 +291,7 @@ def test_wave_per_instance_default_rule_hostsim(hostsim_lib, monkeypatch):
     from acados_amd.generators import fill_lqr_batch, lqr_dims, lqr_instance_qp, random_lqr_batch
     N, B = 6, 5
     data = random_lqr_batch(N=N, nx=12, nu=3, batch=B, seed=11)
+    monkeypatch.setenv("ACADOS_AMD_W16", "0")   # this test is about the run-time-shaped family
     gb = OcpQpGpuBatch(lqr_dims(N, 12, 3), B, _clib=hostsim_lib)
     assert gb.kernel_name.startswith("wpi-box(nx=12,nu=3")
     fill_lqr_batch(gb, data, N)
@@ -309,6 +313,8 @@ def test_wave_per_instance_default_rule_hostsim(hostsim_lib, monkeypatch):
     # batch-size rule: small stage blocks also go to the wave-per-instance kernels while the batch is small
     monkeypatch.setenv("ACADOS_AMD_WPI_BATCH_MAX", "100")
     assert OcpQpGpuBatch(lqr_dims(N, 8, 3), 100, _clib=hostsim_lib).kernel_name.startswith("wpi-box(nx=8,nu=3")
+    monkeypatch.setenv("ACADOS_AMD_W16", "1")   # ... and, where one is compiled, to the 16-lanes-per-instance kernels
+    assert OcpQpGpuBatch(lqr_dims(N, 8, 3), 100, _clib=hostsim_lib).kernel_name == "w16-box<NX=8,NU=3>"
     assert OcpQpGpuBatch(lqr_dims(N, 8, 3), 101, _clib=hostsim_lib).kernel_name.startswith("1tpi")
     monkeypatch.setenv("ACADOS_AMD_WPI_BATCH_MAX", "0")
     # hot start from the solution: converged at the first residual evaluation

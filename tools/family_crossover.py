@@ -7,7 +7,7 @@ from acados_amd import OcpQpGpuBatch
 from acados_amd.generators import fill_lqr_batch, lqr_dims, random_lqr_batch
 
 N, nx, nu = 50, 8, 3
-for B in (1, 16, 64, 256, 1024, 4096, 16384):
+for B in ([int(a) for a in sys.argv[1:]] or [1, 16, 64, 256, 1024, 4096, 16384]):
     data = random_lqr_batch(N=N, nx=nx, nu=nu, batch=B, seed=0)
     row = []
     for fam in ("0", "1"):
