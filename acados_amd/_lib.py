@@ -35,6 +35,8 @@ def bind(L):
     L.ocp_qp_gpu_batch_stream.restype = C.c_void_p
     L.ocp_qp_gpu_batch_kernel_name.argtypes = [C.c_void_p]
     L.ocp_qp_gpu_batch_kernel_name.restype = C.c_char_p
+    L.ocp_qp_gpu_batch_sens_set.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p]
+    L.ocp_qp_gpu_batch_sens_solve.argtypes = [C.c_void_p]
     return L
 
 

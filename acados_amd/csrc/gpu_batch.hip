@@ -123,6 +123,11 @@ struct ocp_qp_gpu_batch
     ocp_qp_gpu_batch *tail = nullptr;    /* wave-per-instance sub-batch for the last survivors of a one-instance-per-lane level */
     int tail_max = 12288;                /* switch to it when at most this many instances (and a quarter of the level) remain; 0 = off */
     int n_tail_switches = 0;
+    /* solution sensitivities / factor at the solution */
+    bool factor_stale = false;           /* the last solve finished instances on a sub-level: Lf of the root is not theirs */
+    bool sens_open = false;              /* seeds are being collected (rg, rb, rd hold seeds, not residuals) */
+    GArr sfix = {nullptr, 0, 0};         /* derivative of the equality-flagged variables (e.g. x0), [N+2][n] */
+    int *d_saved_status = nullptr;
     int *d_list = nullptr;               /* instance index of every slot of `compact` / `tail` */
     int list_cap = 0;
     int n_compactions = 0;
@@ -1231,6 +1236,8 @@ int ocp_qp_gpu_batch_solve(ocp_qp_gpu_batch *b)
         HIPCHK(hipStreamSynchronize(s));
     }
     run_ipm(b, b, prof, s, 0);
+    b->factor_stale = b->n_tail_switches + b->n_compactions > 0;
+    b->sens_open = false;
     GQP_IPM_LAUNCH(b, pick_kernels(b).final_, s, D);
     b->launches++;
     HIPCHK(hipEventRecord(b->ev1, s));
@@ -1261,13 +1268,134 @@ int ocp_qp_gpu_batch_solve(ocp_qp_gpu_batch *b)
     return bad;
 }
 
+/* One factor sweep at the final iterate with every instance awake: Lf / lf of the whole batch belong to the
+ * solution afterwards (after a tail switch the root's factors of the handed-over instances are older).  Statuses
+ * are restored. */
+static void refactor_at_solution(ocp_qp_gpu_batch *b)
+{
+    hipStream_t s = b->stream;
+    const dim3 g64((b->B + 63) / 64), blk(64);
+    if (!b->d_saved_status) b->d_saved_status = dalloc<int>(b, b->Bp);
+    GqpOpts O = effective_opts(b->O);
+    hipLaunchKernelGGL(gqp::k_sens_prep, g64, blk, 0, s, b->D, O.tau_min, b->d_saved_status);
+    GQP_SWEEP_LAUNCH(b, pick_kernels(b).fact, b->shmem_fact, s, b->D, O, 0);
+    hipLaunchKernelGGL(gqp::k_status_restore, g64, blk, 0, s, b->D, b->d_saved_status);
+    HIPCHK(hipStreamSynchronize(s));
+    b->factor_stale = false;
+}
+
+static int sens_begin(ocp_qp_gpu_batch *b)
+{
+    if (b->sens_open) return 0;
+    if (!b->wpi)
+    {
+        fprintf(stderr, "acados_amd: solution sensitivities run on the wave-per-instance / sixteen-lanes kernel families; this "
+                        "batch uses %s (create it with at most 20,480 instances or ACADOS_AMD_WPI=1)\n", b->kname.c_str());
+        return -1;
+    }
+    refactor_at_solution(b);
+    const GqpDev &D = b->D;
+    const int n = D.NX + D.NU;
+    if (!b->sfix.p) b->sfix = garr<double>(b, (size_t) (b->N + 2) * n);
+    const GArr z[] = {D.rg, D.rgs, D.rb, D.rd, b->sfix};
+    for (const GArr &a : z) HIPCHK(hipMemsetAsync(a.p, 0, sizeof(double) * (size_t) a.E * b->Bp, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    b->sens_open = true;
+    return 0;
+}
+
+int ocp_qp_gpu_batch_sens_set(ocp_qp_gpu_batch *b, const char *f, int k, const double *data)
+{
+    HIPCHK(hipSetDevice(b->device));
+    finalize_structure(b);
+    if (strncmp(f, "seed_", 5) || k < 0 || k > b->N)
+    {
+        fprintf(stderr, "acados_amd: ocp_qp_gpu_batch_sens_set: unknown seed %s (stage %d)\n", f, k);
+        return -1;
+    }
+    if (sens_begin(b)) return -1;
+    const char *base = f + 5;
+    std::vector<int> map, map2;
+    GArr arr = {nullptr, 0, 0}, arr2 = {nullptr, 0, 0};
+    const int len = field_map(b, base, k, map, &arr, &map2, &arr2);
+    double sign = 1.0;
+    GArr dst = {nullptr, 0, 0};
+    if (len >= 0)
+    {
+        if (arr.p == b->D.rq.p) dst = b->D.rg;
+        else if (arr.p == b->D.bvec.p) dst = b->D.rb;
+        else if (arr.p == b->D.dvec.p) { dst = b->D.rd; sign = (base[0] == 'l' && base[1] != 'u') || !strcmp(base, "lls") ? -1.0 : 1.0; }
+    }
+    if (len < 0 || !dst.p)
+    {
+        fprintf(stderr, "acados_amd: ocp_qp_gpu_batch_sens_set: %s is not a seed of this stage (seeds: seed_q seed_r seed_b "
+                        "seed_lbu seed_ubu seed_lbx seed_ubx seed_lg seed_ug)\n", f);
+        return -1;
+    }
+    if (len == 0) return 0;
+    if (!strcmp(base, "lus")) sign = -1.0; /* su >= lus is a LOWER bound of the slack, like lls */
+    std::vector<double> h((size_t) b->B * len);
+    for (size_t e = 0; e < h.size(); e++) h[e] = sign * data[e];
+    const double *src = stage_in(b, h.data(), h.size(), 0);
+    int *dm = upload_map(b, map);
+    hipLaunchKernelGGL(gqp::k_scatter, dim3((b->B + 63) / 64), dim3(64), 0, b->stream, src, b->B, len, dm, dst);
+    HIPCHK(hipStreamSynchronize(b->stream));
+    if (arr2.p)
+    {
+        /* equality-flagged bounds: the seed of the bound is the derivative of the variable itself */
+        bool any = false;
+        for (int &m : map2) { if (m >= 0) any = true; }
+        if (any)
+        {
+            src = stage_in(b, data, (size_t) b->B * len, 0);
+            dm = upload_map(b, map2);
+            hipLaunchKernelGGL(gqp::k_scatter, dim3((b->B + 63) / 64), dim3(64), 0, b->stream, src, b->B, len, dm, b->sfix);
+            HIPCHK(hipStreamSynchronize(b->stream));
+        }
+    }
+    return 0;
+}
+
+int ocp_qp_gpu_batch_sens_solve(ocp_qp_gpu_batch *b)
+{
+    HIPCHK(hipSetDevice(b->device));
+    finalize_structure(b);
+    if (sens_begin(b)) return -1; /* no seed set: all-zero seeds, zero sensitivities */
+    hipStream_t s = b->stream;
+    const dim3 g64((b->B + 63) / 64), blk(64);
+    GqpOpts O = effective_opts(b->O);
+    const IpmKernels K = pick_kernels(b);
+    hipLaunchKernelGGL(gqp::k_sens_fixed, g64, blk, 0, s, b->D, b->sfix, 0);
+    hipLaunchKernelGGL(gqp::k_sens_prep, g64, blk, 0, s, b->D, O.tau_min, b->d_saved_status);
+    GQP_SWEEP_LAUNCH(b, K.rhs, b->shmem, s, b->D, O, 2);
+    GQP_SWEEP_LAUNCH(b, K.fcorr, b->shmem, s, b->D, O, 2);
+    hipLaunchKernelGGL(gqp::k_sens_fixed, g64, blk, 0, s, b->D, b->sfix, 1);
+    hipLaunchKernelGGL(gqp::k_status_restore, g64, blk, 0, s, b->D, b->d_saved_status);
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    b->sens_open = false;
+    return 0;
+}
+
 int ocp_qp_gpu_batch_get(ocp_qp_gpu_batch *b, const char *f, int k, double *data, int is_device)
 {
     HIPCHK(hipSetDevice(b->device));
     finalize_structure(b);
     std::vector<int> map;
     GArr arr = {nullptr, 0, 0};
-    const int len = field_map(b, f, k, map, &arr);
+    if (b->factor_stale && !strncmp(f, "ric_", 4)) refactor_at_solution(b);
+    /* sensitivities: the direction arrays of the last ocp_qp_gpu_batch_sens_solve */
+    const bool is_sens = !strncmp(f, "sens_", 5);
+    int len = field_map(b, is_sens ? f + 5 : f, k, map, &arr);
+    if (is_sens && len >= 0)
+    {
+        if (arr.p == b->D.ux.p) arr = b->D.dux;
+        else if (arr.p == b->D.sv.p) arr = b->D.dsv;
+        else if (arr.p == b->D.pi.p) arr = b->D.dpi;
+        else if (arr.p == b->D.lam.p) arr = b->D.dlam;
+        else if (arr.p == b->D.t.p) arr = b->D.dt;
+        else len = -1;
+    }
     if (len < 0)
     {
         fprintf(stderr, "acados_amd: ocp_qp_gpu_batch_get: field %s not available at stage %d\n", f, k);

@@ -1199,6 +1199,60 @@ static __global__ void k_compact_scalars(GqpDev big, GqpDev small, const int *li
     }
 }
 
+/* ---- solution sensitivities (forward / adjoint with the factorisation at the solution) ----
+ * The seed of a parameter p is the derivative of the problem data: d g/dp (-> rg), d b/dp (-> rb), d bounds/dp in
+ * natural sign (-> rd: lower sides -d lb, upper sides +d ub).  A corrector-style pass with these "residuals" and
+ * zero complementarity rhs returns -K^{-1} (d residual/dp) = d solution/dp in (dux, dsv, dpi, dlam, dt).
+ * k_sens_prep makes the complementarity rhs vanish (pcorr = tau - lam t, smu = 0) and wakes every instance up;
+ * k_sens_fixed moves the derivative of equality-flagged variables (their value IS the parameter, e.g. x0) into the
+ * seeds of the rows they touch -- dynamics, stationarity of the free variables, general rows -- and afterwards
+ * (out = 1) writes it into dux. */
+static __global__ void k_sens_prep(GqpDev D, double tau, int *saved_status)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D.B) return;
+    for (int e = 0; e < D.lam.E; e++) GATL(D.pcorr, e) = tau - GATL(D.lam, e) * GATL(D.t, e);
+    D.smu[i] = 0.0;
+    saved_status[i] = D.status[i];
+    D.status[i] = GQP_RUNNING;
+}
+
+static __global__ void k_status_restore(GqpDev D, const int *saved_status)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < D.B) D.status[i] = saved_status[i];
+}
+
+static __global__ void k_sens_fixed(GqpDev D, GArr sfix, int out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D.B) return;
+    const int NX = D.NX, NU = D.NU, n = NX + NU, NP = n * (n + 1) / 2;
+    for (int k = 0; k <= D.N; k++)
+    {
+        const GqpStage &S = D.st[k];
+        if (!S.emask) continue;
+        for (int j = 0; j < n; j++)
+        {
+            if (!((S.emask >> j) & 1)) continue;
+            const double dl = GATL(sfix, k * n + j);
+            if (out) { GATL(D.dux, k * n + j) = dl; continue; }
+            if (dl == 0.0) continue;
+            if (S.has_dyn)
+                for (int c = 0; c < NX; c++) GATL(D.rb, k * NX + c) += GATL(D.BAt, (k * n + j) * NX + c) * dl;
+            for (int r = 0; r < n; r++)
+                if (!((S.emask >> r) & 1)) GATL(D.rg, k * n + r) += GATL(D.RSQ, k * NP + (r >= j ? PK(r, j) : PK(j, r))) * dl;
+            const int nbg = S.nb + S.ng;
+            for (int g = 0; g < S.ng; g++)
+            {
+                const double a = GATL(D.DCt, (S.o_g + g) * n + j) * dl;
+                GATL(D.rd, S.o_ct + S.nb + g) += a;
+                GATL(D.rd, S.o_ct + nbg + S.nb + g) -= a;
+            }
+        }
+    }
+}
+
 /* statistics rows >= row0 of the sub-level slots whose instance has a row in the parent's table
  * (the list is sorted: they are the first slots) */
 static __global__ void k_stat_merge(GqpDev big, GqpDev small, const int *list, int nslots, int row0)

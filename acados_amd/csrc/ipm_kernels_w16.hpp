@@ -306,12 +306,12 @@ __global__ void __launch_bounds__(64) kx_backrhs(GqpDev D, GqpOpts O, int redo)
     const int l = threadIdx.x & 15, inst = blockIdx.x * 4 + (threadIdx.x >> 4);
     if (inst >= D.B) return;
     if (D.status[inst] != GQP_RUNNING) return;
-    if (redo && !(D.alpha[inst] < 0.0)) return;
+    if (redo == 1 && !(D.alpha[inst] < 0.0)) return; /* redo = 2: sensitivity pass (direction only, every instance) */
     double *T = smem + (threadIdx.x >> 4) * LY::SZ, *xb = T + LY::XB, *TA = T + LY::TA;
     const bool mine = l < n, isx = l >= NU && l < n;
     const int cx = isx ? l - NU : 0;
     const double smu = D.smu[inst];
-    const double pscale = redo ? 0.0 : 1.0;
+    const double pscale = redo == 1 ? 0.0 : 1.0;
     double Lp[NX], LpT[NX];
     W16_UNROLL for (int c = 0; c < NX; c++) { Lp[c] = 0.0; LpT[c] = 0.0; }
     double pn = 0.0; /* p of the stage handled before (state lanes) */
@@ -392,12 +392,12 @@ __global__ void __launch_bounds__(64) kx_fwd(GqpDev D, GqpOpts O, int redo)
     const int l = threadIdx.x & 15, inst = blockIdx.x * 4 + (threadIdx.x >> 4);
     if (inst >= D.B) return;
     if (D.status[inst] != GQP_RUNNING) return;
-    if (redo && !(D.alpha[inst] < 0.0)) return;
+    if (redo == 1 && !(D.alpha[inst] < 0.0)) return; /* redo = 2: sensitivity pass (direction only, every instance) */
     double *T = smem + (threadIdx.x >> 4) * LY::SZ, *xb = T + LY::XB, *TF = T + LY::TF;
     const bool mine = l < n, isx = l >= NU && l < n;
     const int cx = isx ? l - NU : 0;
     const double smu = CORR ? D.smu[inst] : 0.0;
-    const double pscale = (CORR && !redo) ? 1.0 : 0.0;
+    const double pscale = (CORR && redo != 1) ? 1.0 : 0.0;
     double alpha = 1.0, S0 = 0.0, S1 = 0.0, S2 = 0.0, nact = 0.0;
     double dx = 0.0; /* dx of this lane's state for the stage being entered */
 
@@ -501,6 +501,7 @@ __global__ void __launch_bounds__(64) kx_fwd(GqpDev D, GqpOpts O, int redo)
         dx = isx ? dxn : 0.0;
     }
 
+    if (redo == 2) return; /* sensitivity pass: dux, dpi, dlam, dt are the result */
     alpha = w16_rmin(alpha, xb);
     const int it = D.iter[inst];
     double *st = (inst < D.stat_inst && it + 1 < D.stat_rows) ? D.stat + (size_t) (it + 1) * GQP_STAT_COLS * D.stat_inst + inst : nullptr;

@@ -1364,12 +1364,12 @@ __global__ void __launch_bounds__(64) kw_backrhs(GqpDev D, GqpOpts O, int redo)
     const int inst = blockIdx.x, lane = threadIdx.x;
     if (inst >= D.B) return;
     if (D.status[inst] != GQP_RUNNING) return;
-    if (redo && !(D.alpha[inst] < 0.0)) return;
+    if (redo == 1 && !(D.alpha[inst] < 0.0)) return; /* redo = 2: sensitivity pass (direction only, every instance) */
     const WpiLds3 L = wpi3_carve(smem, NX, NU);
     const WpiCon C = wpi_con_carve(smem + wpi3_lds_doubles(NX, NU), n, GEN ? D.NG : 0, GEN ? D.NS : 0);
     const int SXb = L.SXb;
     const double smu = D.smu[inst];
-    const double pscale = redo ? 0.0 : 1.0;
+    const double pscale = redo == 1 ? 0.0 : 1.0;
     const bool mine = lane < n;
     for (int e = lane; e < 2 * L.NPa; e += 64) L.Lp[e] = 0.0;
     L.pn[lane] = 0.0;
@@ -1542,13 +1542,13 @@ __global__ void __launch_bounds__(64) kw_fwd(GqpDev D, GqpOpts O, int redo)
     const int inst = blockIdx.x, lane = threadIdx.x;
     if (inst >= D.B) return;
     if (D.status[inst] != GQP_RUNNING) return;
-    if (redo && !(D.alpha[inst] < 0.0)) return;
+    if (redo == 1 && !(D.alpha[inst] < 0.0)) return; /* redo = 2: sensitivity pass (direction only, every instance) */
     const WpiLds3 L = wpi3_carve(smem, NX, NU);
     const WpiCon C = wpi_con_carve(smem + wpi3_lds_doubles(NX, NU), n, GEN ? D.NG : 0, GEN ? D.NS : 0);
     const int SXb = L.SXb;
     double *__restrict__ Lc = L.Lp;
     const double smu = CORR ? D.smu[inst] : 0.0;
-    const double pscale = (CORR && !redo) ? 1.0 : 0.0;
+    const double pscale = (CORR && redo != 1) ? 1.0 : 0.0;
     const bool mine = lane < n;
     double alpha = 1.0, S0 = 0.0, S1 = 0.0, S2 = 0.0;
     int nact = 0;
@@ -1829,6 +1829,7 @@ __global__ void __launch_bounds__(64) kw_fwd(GqpDev D, GqpOpts O, int redo)
         __syncthreads();
     }
 
+    if (redo == 2) return; /* sensitivity pass: dux, dsv, dpi, dlam, dt are the result */
     alpha = wpi_min(alpha, L.red, lane);
     const int it = D.iter[inst];
     double *st = (inst < D.stat_inst && it + 1 < D.stat_rows) ? D.stat + (size_t) (it + 1) * GQP_STAT_COLS * D.stat_inst + inst : nullptr;

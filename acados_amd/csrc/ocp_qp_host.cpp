@@ -405,6 +405,36 @@ void ocp_qp_out_get(ocp_qp_out *out, int k, const char *field, void *value)
 }
 
 /* ocp_qp_common.c:874-921, line by line on the plain containers */
+/* d_ocp_qp_seed (acados/ocp_qp/ocp_qp_common.h: ocp_qp_seed): seed_g [r; q; zl; zu], seed_b, seed_d
+ * [lb lg ub ug ls us] (natural sign), seed_m; one calloc'ed block */
+ocp_qp_seed *ocp_qp_seed_create(ocp_qp_dims *dims)
+{
+    const int N = dims->N;
+    size_t cnt = 0;
+    for (int k = 0; k <= N; k++)
+        cnt += dims->nu[k] + dims->nx[k] + 2 * dims->ns[k] + (k < N ? dims->nx[k + 1] : 0) + 4 * (size_t) (dims->nb[k] + dims->ng[k] + dims->ns[k]);
+    char *raw = (char *) calloc(1, sizeof(ocp_qp_seed) + 4 * (N + 1) * sizeof(double *) + cnt * sizeof(double) + 64);
+    ocp_qp_seed *sd = (ocp_qp_seed *) raw;
+    raw = align8(raw + sizeof(ocp_qp_seed));
+    sd->dim = dims;
+    sd->seed_g = (double **) raw; raw += (N + 1) * sizeof(double *);
+    sd->seed_b = (double **) raw; raw += (N + 1) * sizeof(double *);
+    sd->seed_d = (double **) raw; raw += (N + 1) * sizeof(double *);
+    sd->seed_m = (double **) raw; raw += (N + 1) * sizeof(double *);
+    double *p = (double *) align8(raw);
+    for (int k = 0; k <= N; k++)
+    {
+        const int nct = 2 * (dims->nb[k] + dims->ng[k] + dims->ns[k]);
+        sd->seed_g[k] = p; p += dims->nu[k] + dims->nx[k] + 2 * dims->ns[k];
+        sd->seed_b[k] = p; p += k < N ? dims->nx[k + 1] : 0;
+        sd->seed_d[k] = p; p += nct;
+        sd->seed_m[k] = p; p += nct;
+    }
+    return sd;
+}
+
+void ocp_qp_seed_free(void *seed) { free(seed); }
+
 void ocp_qp_compute_t(ocp_qp_in *in, ocp_qp_out *out)
 {
     const ocp_qp_dims *d = in->dim;
@@ -854,16 +884,73 @@ void ocp_qp_gpu_ipm_memory_reset(void *config, void *qp_in, void *qp_out, void *
     }
 }
 
-void ocp_qp_gpu_ipm_eval_forw_sens(void *config, void *qp_in, void *seed, void *qp_out, void *opts, void *mem, void *work)
+/* ocp_qp_hpipm.c:481-506.  The seed is the derivative of the problem data of ONE qp (the one `mem` belongs to,
+ * i.e. instance 0 of the device batch of the last evaluate), the result d(solution)/d(parameter) lands in the
+ * ocp_qp_out container: ux = [du; dx; dsl; dsu], pi, lam, t (ocp_nlp_common.c:4095-4104 copies exactly these). */
+static void gpu_ipm_eval_sens(const char *who, void *qp_in_, void *seed_, void *qp_out_, void *mem_)
 {
-    printf("\nerror: ocp_qp_gpu_ipm_eval_forw_sens: not implemented (SURVEY 8f row 4)\n");
-    exit(1);
+    ocp_qp_in *in = (ocp_qp_in *) qp_in_;
+    ocp_qp_seed *seed = (ocp_qp_seed *) seed_;
+    ocp_qp_out *out = (ocp_qp_out *) qp_out_;
+    gpu_ipm_memory *m = (gpu_ipm_memory *) mem_;
+    if (!m->cache || !m->cache->batch)
+    {
+        printf("\n%s: no factorisation available (solve first)\n", who);
+        exit(1);
+    }
+    ocp_qp_gpu_batch *b = m->cache->batch;
+    const ocp_qp_dims *d = in->dim;
+    const int nb_ = m->cache->n;
+    std::vector<double> buf;
+    auto push = [&](const char *name, int k, int len, const double *src) {
+        if (len <= 0) return;
+        buf.assign((size_t) nb_ * len, 0.0); /* the seed belongs to instance 0; the other instances get zero seeds */
+        memcpy(buf.data(), src, sizeof(double) * len);
+        if (ocp_qp_gpu_batch_sens_set(b, name, k, buf.data()) != 0) exit(1);
+    };
+    for (int k = 0; k <= d->N; k++)
+    {
+        const int nu = d->nu[k], nx = d->nx[k], nbu = d->nbu[k], nbx = d->nbx[k], nb = d->nb[k], ng = d->ng[k];
+        push("seed_r", k, nu, seed->seed_g[k]);
+        push("seed_q", k, nx, seed->seed_g[k] + nu);
+        if (k < d->N) push("seed_b", k, d->nx[k + 1], seed->seed_b[k]);
+        push("seed_lbu", k, nbu, seed->seed_d[k]);
+        push("seed_lbx", k, nbx, seed->seed_d[k] + nbu);
+        push("seed_lg", k, ng, seed->seed_d[k] + nb);
+        push("seed_ubu", k, nbu, seed->seed_d[k] + nb + ng);
+        push("seed_ubx", k, nbx, seed->seed_d[k] + nb + ng + nbu);
+        push("seed_ug", k, ng, seed->seed_d[k] + 2 * nb + ng);
+    }
+    if (ocp_qp_gpu_batch_sens_solve(b) != 0) exit(1);
+    auto pull = [&](const char *name, int k, int len, double *dst) {
+        if (len <= 0) return;
+        buf.assign((size_t) nb_ * len, 0.0);
+        ocp_qp_gpu_batch_get(b, name, k, buf.data(), 0);
+        memcpy(dst, buf.data(), sizeof(double) * len);
+    };
+    for (int k = 0; k <= d->N; k++)
+    {
+        const int nu = d->nu[k], nx = d->nx[k], ns = d->ns[k], nct = 2 * (d->nb[k] + d->ng[k] + ns);
+        pull("sens_u", k, nu, out->ux[k]);
+        pull("sens_x", k, nx, out->ux[k] + nu);
+        pull("sens_sl", k, ns, out->ux[k] + nu + nx);
+        pull("sens_su", k, ns, out->ux[k] + nu + nx + ns);
+        if (k < d->N) pull("sens_pi", k, d->nx[k + 1], out->pi[k]);
+        pull("sens_lam", k, nct, out->lam[k]);
+        pull("sens_t", k, nct, out->t[k]);
+    }
 }
 
+void ocp_qp_gpu_ipm_eval_forw_sens(void *config, void *qp_in, void *seed, void *qp_out, void *opts, void *mem, void *work)
+{
+    gpu_ipm_eval_sens("ocp_qp_gpu_ipm_eval_forw_sens", qp_in, seed, qp_out, mem);
+}
+
+/* the KKT matrix of the condensed Newton system is symmetric: the adjoint solve of a seed is the forward solve of the
+ * same seed (acados seeds only seed_g here and reads ux, pi: ocp_nlp_common.c:4128-4160) */
 void ocp_qp_gpu_ipm_eval_adj_sens(void *config, void *qp_in, void *seed, void *qp_out, void *opts, void *mem, void *work)
 {
-    printf("\nerror: ocp_qp_gpu_ipm_eval_adj_sens: not implemented (SURVEY 8f row 4)\n");
-    exit(1);
+    gpu_ipm_eval_sens("ocp_qp_gpu_ipm_eval_adj_sens", qp_in, seed, qp_out, mem);
 }
 
 void ocp_qp_gpu_ipm_terminate(void *config, void *mem, void *work)
@@ -1059,6 +1146,18 @@ void ocp_qp_xcond_solver_get_scalar(ocp_qp_solver *s, ocp_qp_out *qp_out, const 
 }
 
 /* outer-level access to the solver_get slot (what ocp_nlp_ddp.c:373-377 does through the xcond vtable) */
+void ocp_qp_solver_eval_forw_sens(ocp_qp_solver *s, ocp_qp_in *qp_in, ocp_qp_seed *seed, ocp_qp_out *sens_out)
+{
+    qp_solver_config *qs = &s->config->qp_solver;
+    qs->eval_forw_sens(qs, qp_in, seed, sens_out, s->opts->qp_solver_opts, s->mem, nullptr);
+}
+
+void ocp_qp_solver_eval_adj_sens(ocp_qp_solver *s, ocp_qp_in *qp_in, ocp_qp_seed *seed, ocp_qp_out *sens_out)
+{
+    qp_solver_config *qs = &s->config->qp_solver;
+    qs->eval_adj_sens(qs, qp_in, seed, sens_out, s->opts->qp_solver_opts, s->mem, nullptr);
+}
+
 void ocp_qp_solver_get_ric(ocp_qp_solver *s, ocp_qp_in *qp_in, ocp_qp_out *qp_out, const char *field, int stage,
                            void *value, int size1, int size2)
 {

@@ -88,6 +88,8 @@ class OcpQpGpuBatch:
 
     def _len(self, field, k):
         d = self.dims
+        if field.startswith("sens_"):
+            field = field[5:]
         if field == "x":
             return int(d.nx[k])
         if field == "u":
@@ -130,6 +132,21 @@ class OcpQpGpuBatch:
         else:
             K, k = np.zeros((self.n_batch, 0, nx)), np.zeros((self.n_batch, 0))
         return {"P": P, "p": p, "K": K, "k": k, "Lr": Lr}
+
+    # -- solution sensitivities ------------------------------------------------
+    def sens_set(self, field, stage, value):
+        """seed = derivative of the problem data w.r.t. a parameter: seed_q seed_r seed_b seed_lbu seed_ubu seed_lbx
+        seed_ubx seed_lg seed_ug (natural-sign bounds); value [n_batch, len].  The first seed after a solve opens a
+        new seed set (all other seeds zero)."""
+        v = np.ascontiguousarray(np.asarray(value, dtype=np.float64).reshape(self.n_batch, -1))
+        if self._L.ocp_qp_gpu_batch_sens_set(self._h, field.encode(), int(stage), v.ctypes.data_as(C.c_void_p)) != 0:
+            raise ValueError(f"ocp_qp_gpu_batch_sens_set({field}, {stage}) failed")
+
+    def sens_solve(self):
+        """d solution / d parameter for the seeds set since the last solve; read with get("sens_x" / "sens_u" /
+        "sens_pi" / "sens_lam" / "sens_t" / "sens_sl" / "sens_su", stage)"""
+        if self._L.ocp_qp_gpu_batch_sens_solve(self._h) != 0:
+            raise RuntimeError("ocp_qp_gpu_batch_sens_solve failed")
 
     def info(self, field):
         out = np.zeros(self.n_batch, dtype=np.int32 if field in ("status", "iter") else np.float64)

@@ -45,6 +45,10 @@ def _bind(L):
         "ocp_qp_solve_batch": (ci, [vp, ci, C.POINTER(vp), C.POINTER(vp), C.POINTER(ci)]),
         "ocp_qp_xcond_solver_get_scalar": (None, [vp, vp, cp, vp]),
         "ocp_qp_solver_get_stats": (None, [vp, C.POINTER(C.c_double), cp]),
+        "ocp_qp_seed_create": (vp, [vp]),
+        "ocp_qp_seed_free": (None, [vp]),
+        "ocp_qp_solver_eval_forw_sens": (None, [vp, vp, vp, vp]),
+        "ocp_qp_solver_eval_adj_sens": (None, [vp, vp, vp, vp]),
     }
     for name, (res, args) in sigs.items():
         fn = getattr(L, name)
@@ -174,6 +178,42 @@ class AcadosOcpQpSolver:
             unique = lam_0[hard:] - lam_0[:hard]
             out[:hard] = np.maximum(0.0, -unique)
             out[hard:2 * hard] = np.maximum(0.0, unique)
+        return out
+
+    def eval_solution_sens(self, seeds: dict, adjoint: bool = False) -> dict:
+        """d(solution)/d(parameter) of the QP solved last (the eval_forw_sens / eval_adj_sens slots of the plugin,
+        ocp_qp_hpipm.c:481-506).  `seeds`: {(field, stage): vector} with the derivative of the problem data w.r.t. the
+        parameter, field in r q b lbu ubu lbx ubx lg ug (natural-sign bounds; for the equality-flagged x0 rows set lbx
+        AND ubx, as ocp_nlp_common.c:4057-4064 does).  Returns {"x": [...per stage...], "u": ..., "pi": ..., "lam": ..., "t": ...}."""
+        L = self._L
+
+        class _Dims(C.Structure):
+            _fields_ = [("N", C.c_int)] + [(n_, C.POINTER(C.c_int)) for n_ in ("nx", "nu", "nb", "nbx", "nbu", "ng", "ns", "nbxe", "nbue", "nge")]
+
+        class _Seed(C.Structure):
+            _fields_ = [("dim", C.POINTER(_Dims))] + [(n_, C.POINTER(C.POINTER(C.c_double))) for n_ in ("seed_g", "seed_b", "seed_d", "seed_m")]
+
+        class _In(C.Structure):
+            _fields_ = [("dim", C.POINTER(_Dims))]
+
+        dim_ptr = C.cast(self.c_in, C.POINTER(_In)).contents.dim
+        c_seed = C.c_void_p(L.ocp_qp_seed_create(dim_ptr))
+        sd = C.cast(c_seed, C.POINTER(_Seed)).contents
+        d = self.qp.dims
+        for (field, k), val in seeds.items():
+            v = np.asarray(val, dtype=np.float64).reshape(-1)
+            nu, nbu, nbx, nb, ng = int(d.nu[k]), int(d.nbu[k]), int(d.nbx[k]), int(d.nbu[k] + d.nbx[k]), int(d.ng[k])
+            arr, off = {"r": ("seed_g", 0), "q": ("seed_g", nu), "b": ("seed_b", 0), "lbu": ("seed_d", 0), "lbx": ("seed_d", nbu),
+                        "lg": ("seed_d", nb), "ubu": ("seed_d", nb + ng), "ubx": ("seed_d", nb + ng + nbu), "ug": ("seed_d", 2 * nb + ng)}[field]
+            p = getattr(sd, arr)[k]
+            for e in range(v.size):
+                p[off + e] = v[e]
+        c_sens = C.c_void_p(L.ocp_qp_out_create_from_xcond_dims(self.c_dims))
+        (L.ocp_qp_solver_eval_adj_sens if adjoint else L.ocp_qp_solver_eval_forw_sens)(self.c_solver, self.c_in, c_seed, c_sens)
+        out = {f: [self.get(k, f, unique_duals=False, _c_out=c_sens) for k in range(self.N + (0 if f == "pi" else 1))]
+               for f in ("x", "u", "pi", "lam", "t")}
+        L.ocp_qp_out_free(c_sens)
+        L.ocp_qp_seed_free(c_seed)
         return out
 
     def get_stats(self, field_: str):

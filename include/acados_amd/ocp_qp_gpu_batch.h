@@ -92,6 +92,19 @@ int ocp_qp_gpu_batch_condense_rhs_and_solve(ocp_qp_gpu_batch *b);
  * stage matrix) and ric_l (nu+nx), from which P = Lx Lx', p = Lx lx, K = -Lr^-T Ls', k = -Lr^-T lr
  * (the getters of ocp_qp_hpipm.c:417-478) follow. */
 int ocp_qp_gpu_batch_get(ocp_qp_gpu_batch *b, const char *field, int stage, double *data, int is_device);
+/* Solution sensitivities with the factorisation at the solution: what d_ocp_qp_ipm_sens_frw / _sens_adj do behind
+ * ocp_qp_hpipm_eval_forw_sens / _adj_sens (acados/ocp_qp/ocp_qp_hpipm.c:481-506; callers
+ * acados/ocp_nlp/ocp_nlp_common.c:4091, 4141).  A seed is the derivative of the problem data w.r.t. a parameter p:
+ * "seed_q" "seed_r" (gradient), "seed_b" (dynamics offset), "seed_lbu" "seed_ubu" "seed_lbx" "seed_ubx" "seed_lg"
+ * "seed_ug" (bounds, natural sign; for an equality-flagged bound -- x0 -- the seed is the derivative of the variable
+ * itself, ocp_nlp_common.c:4057-4064).  `data`: host pointer, n_batch blocks of the field's length.  The first seed
+ * after a solve opens a new all-zero seed set; _sens_solve runs one rhs-only backward and one forward sweep and leaves
+ * d(solution)/dp in the fields "sens_u" "sens_x" "sens_sl" "sens_su" "sens_pi" "sens_lam" "sens_t" of
+ * ocp_qp_gpu_batch_get.  The KKT matrix is symmetric, so the adjoint solve of a seed in (q, r) is the same call.
+ * Available on the wave-per-instance / sixteen-lanes kernel families (returns -1 with a message otherwise). */
+int ocp_qp_gpu_batch_sens_set(ocp_qp_gpu_batch *b, const char *field, int stage, const double *data);
+int ocp_qp_gpu_batch_sens_solve(ocp_qp_gpu_batch *b);
+
 /* per-instance: "status" "iter" (int), "res_stat" "res_eq" "res_ineq" "res_comp" "mu" "obj" (double) */
 int ocp_qp_gpu_batch_get_info(ocp_qp_gpu_batch *b, const char *field, void *data);
 /* HPIPM-shaped statistics of instance `inst` (< 64): (iter+1) x 20, row-major */

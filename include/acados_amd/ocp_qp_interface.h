@@ -83,6 +83,16 @@ typedef struct
     void *misc;   /* qp_info */
 } ocp_qp_out;
 
+/* seed of a solution-sensitivity solve (struct d_ocp_qp_seed behind acados' ocp_qp_seed, ocp_qp_common.h):
+ * derivative of the problem data w.r.t. a parameter.  seed_g[k] = d[r; q; zl; zu], seed_b[k] = d b,
+ * seed_d[k] = d[lb lg ub ug ls us] in natural sign (ocp_nlp_common.c:4057-4064 seeds +1 on both sides of an x0 row),
+ * seed_m[k] (complementarity; not used by acados, ignored) */
+typedef struct
+{
+    ocp_qp_dims *dim;
+    double **seed_g, **seed_b, **seed_d, **seed_m;
+} ocp_qp_seed;
+
 typedef struct
 {
     void (*dims_set)(void *config_, void *dims_, int stage, const char *field, int *value);
@@ -124,6 +134,9 @@ ocp_qp_out *ocp_qp_out_assign(ocp_qp_dims *dims, void *raw_memory);
 ocp_qp_out *ocp_qp_out_create(ocp_qp_dims *dims);
 void ocp_qp_out_get(ocp_qp_out *out, int stage, const char *field, void *value);
 void ocp_qp_out_free(void *out);
+
+ocp_qp_seed *ocp_qp_seed_create(ocp_qp_dims *dims); /* zero-initialised */
+void ocp_qp_seed_free(void *seed);
 
 /* t = slack of every inequality at the current ux (ocp_qp_common.c:874-921) */
 void ocp_qp_compute_t(ocp_qp_in *qp_in, ocp_qp_out *qp_out);
@@ -179,6 +192,10 @@ int ocp_qp_solve(ocp_qp_solver *solver, ocp_qp_in *qp_in, ocp_qp_out *qp_out);
 int ocp_qp_solve_batch(ocp_qp_solver *solver, int n, ocp_qp_in **qp_in, ocp_qp_out **qp_out, int *status);
 void ocp_qp_xcond_solver_get_scalar(ocp_qp_solver *solver, ocp_qp_out *qp_out, const char *field, void *value);
 void ocp_qp_solver_get_stats(ocp_qp_solver *solver, double *stat, const char *qp_solver_name);
+/* solution sensitivities through the eval_forw_sens / eval_adj_sens slots (ocp_nlp reaches them through the
+ * vtable, ocp_nlp_common.c:4091, 4141): d(solution)/d(parameter) of the QP solved last, into sens_out (ux, pi, lam, t) */
+void ocp_qp_solver_eval_forw_sens(ocp_qp_solver *solver, ocp_qp_in *qp_in, ocp_qp_seed *seed, ocp_qp_out *sens_out);
+void ocp_qp_solver_eval_adj_sens(ocp_qp_solver *solver, ocp_qp_in *qp_in, ocp_qp_seed *seed, ocp_qp_out *sens_out);
 /* Riccati quantities of the last factorisation through the solver_get slot: field in P p K k Lr
  * (ocp_qp_hpipm.c:417-478); column-major; u = K x + k */
 void ocp_qp_solver_get_ric(ocp_qp_solver *solver, ocp_qp_in *qp_in, ocp_qp_out *qp_out, const char *field, int stage,

@@ -378,3 +378,47 @@ def _to_dev(torch, a):
 def test_smoke_entry_gpu(gpu_lib):
     import __graft_entry__ as g
     g.smoke()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("w16", ["1", "0"])
+def test_solution_sensitivities_gpu(gpu_lib, monkeypatch, w16):
+    """a12 on the device: d(x, u)/dp from one rhs-only backward + one forward sweep with the factorisation at the
+    solution, against central finite differences of the solver's own solutions (64 instances, N = 20), on the
+    sixteen-lanes and the wave-per-instance kernels"""
+    from acados_amd import OcpQpGpuBatch
+    from acados_amd.generators import fill_lqr_batch, lqr_dims, random_lqr_batch
+    monkeypatch.setenv("ACADOS_AMD_WPI", "1")
+    monkeypatch.setenv("ACADOS_AMD_W16", w16)
+    N, B, nx, nu = 20, 64, 8, 3
+    data = random_lqr_batch(N=N, batch=B, seed=8)
+
+    def build(d):
+        gb = OcpQpGpuBatch(lqr_dims(N, nx, nu), B)
+        fill_lqr_batch(gb, d, N)
+        for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+            gb.opts_set(f, 1e-9)
+        assert gb.solve() == 0
+        return gb
+
+    def xu(g, pre=""):
+        return np.concatenate([g.get(pre + "x", k) for k in range(N + 1)] + [g.get(pre + "u", k) for k in range(N)], axis=1)
+
+    ref = build(data)
+    assert ref.kernel_name.startswith("w16-box" if w16 == "1" else "wpi-box")
+    e = np.zeros((B, nx)); e[:, 2] = 1.0
+    h = 1e-4   # finite-difference noise: solution accuracy / h ~ 1e-5; an instance whose active set changes within
+               # +-h has no derivative to compare with -- hence the per-instance statistics below
+    for key, seeds in (("q", [("seed_q", k, e) for k in range(N + 1)]), ("x0", [("seed_lbx", 0, e), ("seed_ubx", 0, e)])):
+        sols = []
+        for sg in (+h, -h):
+            d = {k: v.copy() for k, v in data.items()}
+            d[key][:, 2] += sg
+            sols.append(xu(build(d)))
+        fd = (sols[0] - sols[1]) / (2 * h)
+        for (f, k, v) in seeds:
+            ref.sens_set(f, k, v)
+        ref.sens_solve()
+        se = xu(ref, "sens_")
+        err = np.max(np.abs(fd - se), axis=1) / np.maximum(1.0, np.max(np.abs(se), axis=1))
+        assert np.mean(err <= 5e-5) >= 0.9 and np.median(err) <= 1e-5, (key, np.sort(err)[-5:])

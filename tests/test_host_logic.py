@@ -520,3 +520,144 @@ def test_edge_cases_hostsim(hostsim_lib):
     b = OcpQpGpuBatch.from_qps(qps, _clib=hostsim_lib)
     assert b.solve() == 1
     assert list(b.info("status")) == [0, 0, 1]
+
+
+@pytest.mark.parametrize("fam", ["w16", "wpi"])
+def test_solution_sensitivities_hostsim(hostsim_lib, monkeypatch, fam):
+    """a12: forward sensitivities with the factorisation at the solution (what eval_forw_sens / eval_adj_sens stand
+    for, ocp_qp_hpipm.c:481-506): d(x, u)/dp from one rhs-only backward + one forward sweep equals the central finite
+    difference of the solver's own solution, for p in the gradient, in the dynamics offset, in x0 (equality-flagged
+    bound: the parameter IS the variable) and in an input bound"""
+    from acados_amd import OcpQpGpuBatch
+    from acados_amd.generators import fill_lqr_batch, lqr_dims, random_lqr_batch
+    monkeypatch.setenv("ACADOS_AMD_WPI", "1")
+    monkeypatch.setenv("ACADOS_AMD_W16", "1" if fam == "w16" else "0")
+    N, B, nx, nu = 4, 2, 8, 3
+    data = random_lqr_batch(N=N, batch=B, seed=4)
+
+    def build(d):
+        gb = OcpQpGpuBatch(lqr_dims(N, nx, nu), B, _clib=hostsim_lib)
+        fill_lqr_batch(gb, d, N)
+        for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+            gb.opts_set(f, 1e-10)
+        assert gb.solve() == 0
+        return gb
+
+    def xu(g, pre=""):
+        return np.concatenate([g.get(pre + "x", k) for k in range(N + 1)] + [g.get(pre + "u", k) for k in range(N)], axis=1)
+
+    e3 = np.zeros((B, nx)); e3[:, 3] = 1.0
+    eu = np.zeros((B, nu)); eu[:, 1] = 1.0
+    cases = {
+        "q": (("q", 3), [("seed_q", k, e3) for k in range(N + 1)]),
+        "b": (("b", 3), [("seed_b", k, e3) for k in range(N)]),
+        "x0": (("x0", 3), [("seed_lbx", 0, e3), ("seed_ubx", 0, e3)]),
+        "ubu": (("ubu", 1), [("seed_ubu", k, eu) for k in range(N)]),
+    }
+    ref = build(data)
+    assert ref.kernel_name.startswith("w16-box" if fam == "w16" else "wpi-box")
+    for name, ((key, idx), seeds) in cases.items():
+        sols = []
+        for sg in (+1e-6, -1e-6):
+            d = {k: v.copy() for k, v in data.items()}
+            d[key][:, idx] += sg
+            sols.append(xu(build(d)))
+        fd = (sols[0] - sols[1]) / 2e-6
+        for (f, k, v) in seeds:
+            ref.sens_set(f, k, v)
+        ref.sens_solve()
+        se = xu(ref, "sens_")
+        assert np.max(np.abs(fd - se)) <= 1e-6 * max(1.0, np.max(np.abs(se))), name
+        if name == "ubu":
+            assert np.max(np.abs(se)) > 1e-3   # some upper input bound is active somewhere: the solution moves with it
+    # a batch on the one-instance-per-lane kernels says so instead of answering
+    monkeypatch.setenv("ACADOS_AMD_WPI", "0")
+    with pytest.raises(ValueError):
+        build(data).sens_set("seed_q", 0, e3)
+
+
+def test_solution_sensitivities_acados_api_hostsim(hostsim_lib, monkeypatch):
+    """the eval_forw_sens / eval_adj_sens slots of the plugin on the reference's golden pendulum QP: sensitivity
+    w.r.t. x0 (seed on both sides of the equality-flagged row, as ocp_nlp_common.c:4057-4064 sets it) against finite
+    differences; the adjoint slot returns the same for a gradient seed (symmetric KKT matrix)"""
+    import copy
+    from acados_amd import AcadosOcpQpOptions, AcadosOcpQpSolver
+    monkeypatch.setenv("ACADOS_AMD_WPI", "1")
+    qp = load_qp("qp_test/last_qp_nonuniform_pendulum.json")
+    opts = AcadosOcpQpOptions()
+    for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+        setattr(opts, f, 1e-10)
+
+    def solve(q):
+        s = AcadosOcpQpSolver(q, opts, _clib=hostsim_lib)
+        assert s.solve() == 0
+        return s
+
+    def xu(s):
+        return np.concatenate([s.get(k, "x") for k in range(qp.N + 1)] + [s.get(k, "u") for k in range(qp.N)])
+
+    s0 = solve(qp)
+    i, h = 2, 1e-6
+    sols = []
+    for sg in (+h, -h):
+        q_ = copy.deepcopy(qp)
+        lb = np.array(q_.lbx[0], dtype=float)
+        lb[i] += sg
+        q_.set("lbx", 0, lb); q_.set("ubx", 0, lb)
+        sols.append(xu(solve(q_)))
+    fd = (sols[0] - sols[1]) / (2 * h)
+    e = np.zeros(len(qp.lbx[0])); e[i] = 1.0
+    se = s0.eval_solution_sens({("lbx", 0): e, ("ubx", 0): e})
+    sv = np.concatenate(se["x"] + se["u"])
+    assert np.max(np.abs(fd - sv)) <= 1e-6 * np.max(np.abs(sv))
+    assert abs(se["x"][0][i] - 1.0) <= 1e-12                      # d x0_i / d x0_i
+    eq = np.zeros(int(qp.dims.nx[3])); eq[1] = 1.0
+    f_ = s0.eval_solution_sens({("q", 3): eq})
+    a_ = s0.eval_solution_sens({("q", 3): eq}, adjoint=True)
+    assert all(np.array_equal(f_["x"][k], a_["x"][k]) for k in range(qp.N + 1))
+
+
+def test_solution_sensitivities_soft_constraints_hostsim(hostsim_lib, monkeypatch):
+    """sensitivities on the general-constraint / slack kernels (C4 class, short horizon): gradient seed and x0 seed
+    against finite differences, at the tolerances acados uses (1e-8).  (Pushing the tolerances to 1e-11 drives
+    Gamma = lam/t of the active soft rows to 1e17 and the rounding of dlam = -Gamma dt up to the percent level --
+    the same amplification the barrier floor exists for; at 1e-8 the agreement is 1e-6 relative.)"""
+    from acados_amd import OcpQpGpuBatch
+    from acados_amd.generators import chain_soft_batch, chain_soft_dims, fill_chain_soft_batch
+    monkeypatch.setenv("ACADOS_AMD_WPI", "1")
+    N, B = 3, 2
+    data = chain_soft_batch(N=N, batch=B, seed=1)
+
+    def build(d):
+        gb = OcpQpGpuBatch(chain_soft_dims(N), B, _clib=hostsim_lib)
+        fill_chain_soft_batch(gb, d, N)
+        for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+            gb.opts_set(f, 1e-8)
+        assert gb.solve() == 0
+        return gb
+
+    def xus(g, pre=""):
+        return np.concatenate([g.get(pre + "x", k) for k in range(N + 1)] + [g.get(pre + "u", k) for k in range(N)]
+                              + [g.get(pre + "sl", k) for k in range(1, N + 1)] + [g.get(pre + "su", k) for k in range(1, N + 1)], axis=1)
+
+    ref = build(data)
+    assert ref.kernel_name.startswith("wpi-gen(")
+    e = np.zeros((B, 24)); e[:, 7] = 1.0
+    h = 1e-3
+    for name in ("q", "x0"):
+        sols = []
+        for sg in (+h, -h):
+            d = {k: (v.copy() if hasattr(v, "copy") else v) for k, v in data.items()}
+            if name == "q":
+                d["q"][:, 2, 7] += sg
+            else:
+                d["x0"][:, 7] += sg
+            sols.append(xus(build(d)))
+        fd = (sols[0] - sols[1]) / (2 * h)
+        if name == "q":
+            ref.sens_set("seed_q", 2, e)
+        else:
+            ref.sens_set("seed_lbx", 0, e); ref.sens_set("seed_ubx", 0, e)
+        ref.sens_solve()
+        se = xus(ref, "sens_")
+        assert np.max(np.abs(fd - se)) <= 2e-5 * np.max(np.abs(se)), name
