@@ -128,6 +128,9 @@ struct ocp_qp_gpu_batch
     bool sens_open = false;              /* seeds are being collected (rg, rb, rd hold seeds, not residuals) */
     GArr sfix = {nullptr, 0, 0};         /* derivative of the equality-flagged variables (e.g. x0), [N+2][n] */
     int *d_saved_status = nullptr;
+    ocp_qp_gpu_batch *sens_child = nullptr; /* wave-per-instance sub-batch the sensitivities of a one-instance-per-lane batch run in */
+    int *d_slist = nullptr;
+    int sens_cap = 0;
     int *d_list = nullptr;               /* instance index of every slot of `compact` / `tail` */
     int list_cap = 0;
     int n_compactions = 0;
@@ -706,6 +709,7 @@ void ocp_qp_gpu_batch_destroy(ocp_qp_gpu_batch *b)
     if (b->child) ocp_qp_gpu_batch_destroy(b->child);
     if (b->compact) ocp_qp_gpu_batch_destroy(b->compact);
     if (b->tail) ocp_qp_gpu_batch_destroy(b->tail);
+    if (b->sens_child) ocp_qp_gpu_batch_destroy(b->sens_child);
     delete b;
 }
 
@@ -1287,13 +1291,13 @@ static void refactor_at_solution(ocp_qp_gpu_batch *b)
 static int sens_begin(ocp_qp_gpu_batch *b)
 {
     if (b->sens_open) return 0;
-    if (!b->wpi)
+    if (b->cond_N > 0 && b->cond_N < b->N)
     {
-        fprintf(stderr, "acados_amd: solution sensitivities run on the wave-per-instance / sixteen-lanes kernel families; this "
-                        "batch uses %s (create it with at most 20,480 instances or ACADOS_AMD_WPI=1)\n", b->kname.c_str());
+        fprintf(stderr, "acados_amd: solution sensitivities are not available with partial condensing on the device batch\n");
         return -1;
     }
-    refactor_at_solution(b);
+    /* a one-instance-per-lane batch hands slices of itself to a wave-per-instance sub-batch in sens_solve */
+    if (b->wpi) refactor_at_solution(b);
     const GqpDev &D = b->D;
     const int n = D.NX + D.NU;
     if (!b->sfix.p) b->sfix = garr<double>(b, (size_t) (b->N + 2) * n);
@@ -1356,12 +1360,9 @@ int ocp_qp_gpu_batch_sens_set(ocp_qp_gpu_batch *b, const char *f, int k, const d
     return 0;
 }
 
-int ocp_qp_gpu_batch_sens_solve(ocp_qp_gpu_batch *b)
+/* the seed pass on a wave-per-instance / sixteen-lanes batch whose factor belongs to the solution */
+static void sens_pass(ocp_qp_gpu_batch *b, hipStream_t s)
 {
-    HIPCHK(hipSetDevice(b->device));
-    finalize_structure(b);
-    if (sens_begin(b)) return -1; /* no seed set: all-zero seeds, zero sensitivities */
-    hipStream_t s = b->stream;
     const dim3 g64((b->B + 63) / 64), blk(64);
     GqpOpts O = effective_opts(b->O);
     const IpmKernels K = pick_kernels(b);
@@ -1371,7 +1372,88 @@ int ocp_qp_gpu_batch_sens_solve(ocp_qp_gpu_batch *b)
     GQP_SWEEP_LAUNCH(b, K.fcorr, b->shmem, s, b->D, O, 2);
     hipLaunchKernelGGL(gqp::k_sens_fixed, g64, blk, 0, s, b->D, b->sfix, 1);
     hipLaunchKernelGGL(gqp::k_status_restore, g64, blk, 0, s, b->D, b->d_saved_status);
-    HIPCHK(hipStreamSynchronize(s));
+}
+
+/*
+ * One-instance-per-lane batches: the direction-only sweeps exist in the wave-per-instance families only, so the
+ * batch is walked in slices of at most GQP_SENS_SLICE instances; a slice (QP data, solution, seeds) is copied into a
+ * sub-batch of the wave-per-instance family at the same padded dims (the tail switch's conversion), factorised there
+ * at the solution, swept, and the directions are copied back.  ~3 extra passes over the data per call.
+ */
+#define GQP_SENS_SLICE 16384
+static void sens_solve_sliced(ocp_qp_gpu_batch *b)
+{
+    hipStream_t s = b->stream;
+    const char *env = getenv("ACADOS_AMD_SENS_SLICE");
+    const int cap = b->sens_child ? b->sens_cap : std::min(b->B, env && atoi(env) > 0 ? atoi(env) : GQP_SENS_SLICE);
+    if (!b->sens_child)
+    {
+        g_force_ks = b->ks;
+        g_force_wpi = true;
+        ocp_qp_gpu_batch *c = batch_create_shape(b->N, b->nx.data(), b->nu.data(), b->nbx.data(), b->nbu.data(), b->ng.data(),
+                                                 b->ns.data(), cap, b->device, b->ks->NX, b->ks->NU);
+        g_force_ks = nullptr;
+        g_force_wpi = false;
+        if (!c) { fprintf(stderr, "acados_amd: cannot create the sensitivity sub-batch\n"); abort(); }
+        c->idxb = b->idxb; c->idxs_rev = b->idxs_rev; c->idxe = b->idxe; c->nbxe = b->nbxe;
+        c->tail_max = 0;
+        finalize_structure(c);
+        const int n = c->D.NX + c->D.NU;
+        c->sfix = garr<double>(c, (size_t) (c->N + 2) * n);
+        b->sens_child = c;
+        b->sens_cap = cap;
+        b->d_slist = dalloc<int>(b, cap);
+    }
+    ocp_qp_gpu_batch *c = b->sens_child;
+    c->O = b->O;
+    std::vector<int> list(cap);
+    const dim3 block(64);
+    for (int i0 = 0; i0 < b->B; i0 += cap)
+    {
+        const int cnt = std::min(cap, b->B - i0);
+        for (int j = 0; j < cnt; j++) list[j] = i0 + j;
+        HIPCHK(hipMemcpyAsync(b->d_slist, list.data(), sizeof(int) * cnt, hipMemcpyHostToDevice, s));
+        c->B = cnt;
+        c->D.B = cnt;
+#define GQP_SLICE_COPY(SRC, DST, DIR)                                                                         \
+    if ((SRC).E > 0 && (SRC).p && (DST).p)                                                                    \
+        hipLaunchKernelGGL(gqp::k_compact_copy<double>, dim3((cnt + 63) / 64, ((SRC).E + 63) / 64), block, 0, s, SRC, DST, \
+                           b->d_slist, cnt, DIR);
+#define GQP_COPY_IN(A) GQP_SLICE_COPY(b->D.A, c->D.A, 0)
+        GQP_FOR_STATE_ARRAYS(GQP_COPY_IN)
+        hipLaunchKernelGGL(gqp::k_compact_copy<uint64_t>, dim3((cnt + 63) / 64, (b->D.amask.E + 63) / 64), block, 0, s,
+                           b->D.amask, c->D.amask, b->d_slist, cnt, 0);
+        hipLaunchKernelGGL(gqp::k_compact_scalars, dim3((cnt + 63) / 64), block, 0, s, b->D, c->D, b->d_slist, cnt, 0);
+        HIPCHK(hipStreamSynchronize(s)); /* the sub-batch works on its own stream */
+        refactor_at_solution(c);         /* writes the residual arrays: the seeds go in afterwards */
+        GQP_COPY_IN(rg) GQP_COPY_IN(rgs) GQP_COPY_IN(rb) GQP_COPY_IN(rd)
+#undef GQP_COPY_IN
+        GQP_SLICE_COPY(b->sfix, c->sfix, 0)
+        HIPCHK(hipStreamSynchronize(s));
+        sens_pass(c, c->stream);
+        HIPCHK(hipStreamSynchronize(c->stream));
+#define GQP_COPY_OUT(A) GQP_SLICE_COPY(b->D.A, c->D.A, 1)
+        GQP_COPY_OUT(dux) GQP_COPY_OUT(dsv) GQP_COPY_OUT(dpi) GQP_COPY_OUT(dlam) GQP_COPY_OUT(dt)
+#undef GQP_COPY_OUT
+#undef GQP_SLICE_COPY
+        HIPCHK(hipStreamSynchronize(s));
+    }
+}
+
+int ocp_qp_gpu_batch_sens_solve(ocp_qp_gpu_batch *b)
+{
+    HIPCHK(hipSetDevice(b->device));
+    finalize_structure(b);
+    if (sens_begin(b)) return -1; /* no seed set: all-zero seeds, zero sensitivities */
+    if (!b->wpi)
+    {
+        sens_solve_sliced(b);
+        HIPCHK(hipGetLastError());
+        b->sens_open = false;
+        return 0;
+    }
+    sens_pass(b, b->stream);
+    HIPCHK(hipStreamSynchronize(b->stream));
     HIPCHK(hipGetLastError());
     b->sens_open = false;
     return 0;

@@ -101,7 +101,9 @@ int ocp_qp_gpu_batch_get(ocp_qp_gpu_batch *b, const char *field, int stage, doub
  * after a solve opens a new all-zero seed set; _sens_solve runs one rhs-only backward and one forward sweep and leaves
  * d(solution)/dp in the fields "sens_u" "sens_x" "sens_sl" "sens_su" "sens_pi" "sens_lam" "sens_t" of
  * ocp_qp_gpu_batch_get.  The KKT matrix is symmetric, so the adjoint solve of a seed in (q, r) is the same call.
- * Available on the wave-per-instance / sixteen-lanes kernel families (returns -1 with a message otherwise). */
+ * The sweeps exist in the wave-per-instance / sixteen-lanes kernel families; a one-instance-per-lane batch is walked
+ * in slices of 16,384 instances through a sub-batch of those families (ACADOS_AMD_SENS_SLICE changes the slice).
+ * Not available with partial condensing on the device batch (returns -1 with a message). */
 int ocp_qp_gpu_batch_sens_set(ocp_qp_gpu_batch *b, const char *field, int stage, const double *data);
 int ocp_qp_gpu_batch_sens_solve(ocp_qp_gpu_batch *b);
 

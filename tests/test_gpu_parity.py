@@ -422,3 +422,38 @@ def test_solution_sensitivities_gpu(gpu_lib, monkeypatch, w16):
         se = xu(ref, "sens_")
         err = np.max(np.abs(fd - se), axis=1) / np.maximum(1.0, np.max(np.abs(se), axis=1))
         assert np.mean(err <= 5e-5) >= 0.9 and np.median(err) <= 1e-5, (key, np.sort(err)[-5:])
+
+
+@pytest.mark.gpu
+def test_solution_sensitivities_large_batch_gpu(gpu_lib, monkeypatch):
+    """a12 on a batch of the headline kernel family (one instance per lane, 40,000 instances = three slices through the
+    wave-per-instance sub-batch): the x0-sensitivities equal those of a small batch of the same leading instances
+    computed on the sixteen-lanes kernels directly, and the slices beyond the first answer too"""
+    from acados_amd import OcpQpGpuBatch
+    from acados_amd.generators import fill_lqr_batch, lqr_dims, random_lqr_batch
+    N, B, nx, nu, Bs = 10, 40000, 8, 3, 256
+    data = random_lqr_batch(N=N, batch=B, seed=12)
+    e = np.zeros((B, nx)); e[:, 1] = 1.0
+
+    def run(d, nb):
+        monkeypatch.setenv("ACADOS_AMD_WPI", "0" if nb == B else "1")
+        gb = OcpQpGpuBatch(lqr_dims(N, nx, nu), nb)
+        fill_lqr_batch(gb, d, N)
+        gb.opts_set("tol_stat", 1e-9); gb.opts_set("tol_comp", 1e-9)
+        assert gb.solve() == 0
+        gb.sens_set("seed_lbx", 0, e[:nb]); gb.sens_set("seed_ubx", 0, e[:nb])
+        gb.sens_solve()
+        return gb, np.concatenate([gb.get("sens_x", k) for k in range(N + 1)] + [gb.get("sens_u", k) for k in range(N)], axis=1)
+
+    big, sb = run(data, B)
+    assert big.kernel_name.startswith("1tpi")
+    head = {k: v[:Bs] for k, v in data.items()}
+    tailp = {k: v[B - Bs:] for k, v in data.items()}
+    small, ss = run(head, Bs)
+    assert small.kernel_name.startswith("w16")
+    _, st = run(tailp, Bs)
+    # same kernels on the same solutions up to the solvers' own accuracy (two different iteration paths)
+    for got, want in ((sb[:Bs], ss), (sb[B - Bs:], st)):
+        err = np.max(np.abs(got - want), axis=1) / np.maximum(1.0, np.max(np.abs(want), axis=1))
+        assert np.mean(err <= 1e-5) >= 0.95 and np.median(err) <= 1e-6, np.sort(err)[-5:]
+    assert np.all(sb[:, 1] == 1.0) and np.max(np.abs(sb[:, nx:])) > 1e-2

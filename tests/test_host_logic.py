@@ -522,17 +522,19 @@ def test_edge_cases_hostsim(hostsim_lib):
     assert list(b.info("status")) == [0, 0, 1]
 
 
-@pytest.mark.parametrize("fam", ["w16", "wpi"])
+@pytest.mark.parametrize("fam", ["w16", "wpi", "1tpi"])
 def test_solution_sensitivities_hostsim(hostsim_lib, monkeypatch, fam):
     """a12: forward sensitivities with the factorisation at the solution (what eval_forw_sens / eval_adj_sens stand
     for, ocp_qp_hpipm.c:481-506): d(x, u)/dp from one rhs-only backward + one forward sweep equals the central finite
     difference of the solver's own solution, for p in the gradient, in the dynamics offset, in x0 (equality-flagged
-    bound: the parameter IS the variable) and in an input bound"""
+    bound: the parameter IS the variable) and in an input bound.  A batch on the one-instance-per-lane kernels answers
+    through slices handed to a wave-per-instance sub-batch (here: 3 instances in slices of 2)"""
     from acados_amd import OcpQpGpuBatch
     from acados_amd.generators import fill_lqr_batch, lqr_dims, random_lqr_batch
-    monkeypatch.setenv("ACADOS_AMD_WPI", "1")
+    monkeypatch.setenv("ACADOS_AMD_WPI", "0" if fam == "1tpi" else "1")
     monkeypatch.setenv("ACADOS_AMD_W16", "1" if fam == "w16" else "0")
-    N, B, nx, nu = 4, 2, 8, 3
+    monkeypatch.setenv("ACADOS_AMD_SENS_SLICE", "2")
+    N, B, nx, nu = 4, (3 if fam == "1tpi" else 2), 8, 3
     data = random_lqr_batch(N=N, batch=B, seed=4)
 
     def build(d):
@@ -555,7 +557,7 @@ def test_solution_sensitivities_hostsim(hostsim_lib, monkeypatch, fam):
         "ubu": (("ubu", 1), [("seed_ubu", k, eu) for k in range(N)]),
     }
     ref = build(data)
-    assert ref.kernel_name.startswith("w16-box" if fam == "w16" else "wpi-box")
+    assert ref.kernel_name.startswith({"w16": "w16-box", "wpi": "wpi-box", "1tpi": "1tpi-box"}[fam])
     for name, ((key, idx), seeds) in cases.items():
         sols = []
         for sg in (+1e-6, -1e-6):
@@ -570,10 +572,6 @@ def test_solution_sensitivities_hostsim(hostsim_lib, monkeypatch, fam):
         assert np.max(np.abs(fd - se)) <= 1e-6 * max(1.0, np.max(np.abs(se))), name
         if name == "ubu":
             assert np.max(np.abs(se)) > 1e-3   # some upper input bound is active somewhere: the solution moves with it
-    # a batch on the one-instance-per-lane kernels says so instead of answering
-    monkeypatch.setenv("ACADOS_AMD_WPI", "0")
-    with pytest.raises(ValueError):
-        build(data).sens_set("seed_q", 0, e3)
 
 
 def test_solution_sensitivities_acados_api_hostsim(hostsim_lib, monkeypatch):
