@@ -862,11 +862,12 @@ static void pcond_setup(ocp_qp_gpu_batch *b)
     }
     std::vector<char> is_start(N + 1, 0);
     for (int j = 0; j <= N2; j++) is_start[b->blk_start[j]] = 1;
+    /* box-only class: input bounds anywhere, state bounds at block starts only -- every child row is a box row;
+     * anything else (state bounds inside a block, general rows, slacks) makes general rows in the condensed stages,
+     * which only the wave-per-instance condensing kernels write */
+    bool box_class = true;
     for (int k = 0; k <= N; k++)
-    {
-        if (b->ng[k] || b->ns[k]) { decline("the QP has general constraints or slacks (not condensed by this build)"); return; }
-        if (b->nbx[k] && !is_start[k]) { decline("state bounds inside a block would become general constraints (not condensed by this build)"); return; }
-    }
+        if (b->ng[k] || b->ns[k] || (b->nbx[k] && !is_start[k])) box_class = false;
     b->pc = nullptr;
     b->pc_rt = 0;
     for (int q = 0; q < g_n_pcond_sets; q++)
@@ -877,20 +878,24 @@ static void pcond_setup(ocp_qp_gpu_batch *b)
      * one-instance-per-lane ones remain as the cross-check (ACADOS_AMD_PCOND_1TPI=1) */
     {
         const char *e1 = getenv("ACADOS_AMD_PCOND_1TPI");
-        const bool want_1tpi = e1 && atoi(e1) != 0;
+        const bool want_1tpi = e1 && atoi(e1) != 0 && box_class;
         if (!(want_1tpi && b->pc) && b->ks->NX + bsmax * b->ks->NU <= 64) b->pc_rt = 1;
     }
+    if (!box_class && !b->pc_rt) { decline("the condensed stage (nx + block size * nu > 64) is beyond the condensing kernels"); return; }
     if (!b->pc && !b->pc_rt) { decline("no condensing kernel covers this shape / block size"); return; }
     const int NU = b->ks->NU, BS = b->pc_rt ? bsmax : b->pc->BSMAX;
     b->pc_shmem = gqp::pcondw_lds_doubles(b->ks->NX, NU, BS * NU) * sizeof(double);
 
-    /* child dims + structure */
-    std::vector<int> cnx(N2 + 1), cnu(N2 + 1), cnbx(N2 + 1), cnbu(N2 + 1), zero(N2 + 1, 0);
-    std::vector<std::vector<int>> cidxb(N2 + 1), row_kp(N2 + 1), row_op(N2 + 1);
-    std::vector<int> cidxe;
+    /* child dims + structure.  Child rows in their original order: [input boxes of the block's stages][state boxes of
+     * the block's first stage][general rows: per stage of the block, its state boxes (inner stages) then its general
+     * rows]; child slacks: the block's stages one after the other */
+    std::vector<int> cnx(N2 + 1), cnu(N2 + 1), cnbx(N2 + 1), cnbu(N2 + 1), cng(N2 + 1, 0), cns(N2 + 1, 0);
+    std::vector<std::vector<int>> cidxb(N2 + 1), row_kp(N2 + 1), row_op(N2 + 1), crev(N2 + 1);
+    std::vector<int> cidxe, h_gk(N + 2, 0), h_grp, h_gvar, h_soff(N2 + 2, 0), h_skp, h_ssp, slack_base(N + 1, 0);
     for (int j = 0; j <= N2; j++)
     {
         const int k0 = b->blk_start[j], k1 = j < N2 ? b->blk_start[j + 1] : N + 1;
+        const int kend = j < N2 ? k1 : k0 + 1; /* stages of this block */
         cnx[j] = b->nx[k0];
         cnu[j] = j < N2 ? (k1 - k0) * NU : 0;
         for (int k = k0; k < (j < N2 ? k1 : k0); k++)
@@ -910,39 +915,76 @@ static void pcond_setup(ocp_qp_gpu_batch *b)
             for (size_t e = 0; e < b->idxe[0].size(); e++) cidxe.push_back(cnbu[0] + (b->idxe[0][e] - b->nbu[0]));
         if (j > 0 && !b->idxe[k0].empty()) { decline("equality-flagged bounds after stage 0"); return; }
         if (j == N2 && b->nbu[N]) { decline("input bounds at the terminal stage"); return; }
+        for (int k = k0; k < kend; k++)
+        {
+            if (k > k0 && !b->idxe[k].empty()) { decline("equality-flagged bounds after stage 0"); return; }
+            h_gk[k] = (int) h_grp.size();
+            if (k > k0)
+                for (int r = b->nbu[k]; r < b->nb[k]; r++)
+                {
+                    h_grp.push_back(b->perm[k][r]); h_gvar.push_back(b->idxb[k][r] - b->nu[k]);
+                    row_kp[j].push_back(k); row_op[j].push_back(r);
+                }
+            for (int g = 0; g < b->ng[k]; g++)
+            {
+                h_grp.push_back(b->nb[k] + g); h_gvar.push_back(0);
+                row_kp[j].push_back(k); row_op[j].push_back(b->nb[k] + g);
+            }
+            slack_base[k] = cns[j];
+            for (int q = 0; q < b->ns[k]; q++) { h_skp.push_back(k); h_ssp.push_back(q); }
+            cns[j] += b->ns[k];
+        }
+        cng[j] = (int) row_kp[j].size() - (int) cidxb[j].size();
+        h_soff[j + 1] = h_soff[j] + cns[j];
+        const int nrow = (int) row_kp[j].size();
+        if (nrow > GQP_MAX_ROWS || 2 * nrow + 2 * cns[j] > 128)
+        {
+            decline("a condensed stage would carry more than 64 inequality rows / 128 sides");
+            return;
+        }
+        crev[j].assign(nrow, -1);
+        for (int oc = 0; oc < nrow; oc++)
+        {
+            const int k = row_kp[j][oc], sj = b->idxs_rev[k].empty() ? -1 : b->idxs_rev[k][row_op[j][oc]];
+            if (sj >= 0) crev[j][oc] = slack_base[k] + sj;
+        }
     }
-    ocp_qp_gpu_batch *c = batch_create_shape(N2, cnx.data(), cnu.data(), cnbx.data(), cnbu.data(), zero.data(), zero.data(),
+    h_gk[N + 1] = (int) h_grp.size();
+    ocp_qp_gpu_batch *c = batch_create_shape(N2, cnx.data(), cnu.data(), cnbx.data(), cnbu.data(), cng.data(), cns.data(),
                                              b->B, b->device, b->ks->NX, BS * NU);
     if (!c) { decline("the condensed shape has no kernel instantiation"); return; }
     for (int j = 0; j <= N2; j++)
+    {
         if (!cidxb[j].empty()) ocp_qp_gpu_batch_set_int(c, "idxb", j, cidxb[j].data(), (int) cidxb[j].size());
+        if (cns[j]) ocp_qp_gpu_batch_set_int(c, "idxs_rev", j, crev[j].data(), (int) crev[j].size());
+    }
     ocp_qp_gpu_batch_set_int(c, "idxe", 0, cidxe.data(), (int) cidxe.size());
     finalize_structure(c);
-    /* row maps in the sorted (device) row order of both batches */
+    /* row maps in the sorted (device) row order of both batches: box rows sorted by variable, general rows as listed */
     std::vector<int> h_off(N2 + 2, 0), h_kp, h_rp;
     for (int j = 0; j <= N2; j++)
     {
-        const int nb = (int) cidxb[j].size();
-        std::vector<int> kp(nb), rp(nb);
-        for (int oc = 0; oc < nb; oc++)
+        const int nb = (int) cidxb[j].size(), nrow = (int) row_kp[j].size();
+        std::vector<int> kp(nrow), rp(nrow);
+        for (int oc = 0; oc < nrow; oc++)
         {
-            const int rc = c->perm[j][oc];
-            kp[rc] = row_kp[j][oc];
-            rp[rc] = b->perm[row_kp[j][oc]][row_op[j][oc]];
+            const int rc = oc < nb ? c->perm[j][oc] : oc;
+            const int k = row_kp[j][oc], op = row_op[j][oc];
+            kp[rc] = k;
+            rp[rc] = op < b->nb[k] ? b->perm[k][op] : op;
         }
         h_kp.insert(h_kp.end(), kp.begin(), kp.end());
         h_rp.insert(h_rp.end(), rp.begin(), rp.end());
-        h_off[j + 1] = h_off[j] + nb;
+        h_off[j + 1] = h_off[j] + nrow;
     }
-    int *d_start = dalloc<int>(b, N2 + 1), *d_kp = dalloc<int>(b, h_kp.size()), *d_rp = dalloc<int>(b, h_rp.size());
-    int *d_off = dalloc<int>(b, N2 + 2);
-    HIPCHK(hipMemcpy(d_start, b->blk_start.data(), sizeof(int) * (N2 + 1), hipMemcpyHostToDevice));
-    if (!h_kp.empty())
-    {
-        HIPCHK(hipMemcpy(d_kp, h_kp.data(), sizeof(int) * h_kp.size(), hipMemcpyHostToDevice));
-        HIPCHK(hipMemcpy(d_rp, h_rp.data(), sizeof(int) * h_rp.size(), hipMemcpyHostToDevice));
-    }
-    HIPCHK(hipMemcpy(d_off, h_off.data(), sizeof(int) * (N2 + 2), hipMemcpyHostToDevice));
+    auto up = [&](const std::vector<int> &v) {
+        int *d = dalloc<int>(b, std::max<size_t>(1, v.size()));
+        if (!v.empty()) HIPCHK(hipMemcpy(d, v.data(), sizeof(int) * v.size(), hipMemcpyHostToDevice));
+        return d;
+    };
+    int *d_start = up(b->blk_start), *d_kp = up(h_kp), *d_rp = up(h_rp), *d_off = up(h_off);
+    b->pmap.gk_off = up(h_gk); b->pmap.g_rp = up(h_grp); b->pmap.g_var = up(h_gvar);
+    b->pmap.slk_off = up(h_soff); b->pmap.slk_kp = up(h_skp); b->pmap.slk_sp = up(h_ssp);
     b->pmap.blk_start = d_start; b->pmap.row_kp = d_kp; b->pmap.row_rp = d_rp; b->pmap.row_off = d_off; b->pmap.N2 = N2;
     b->child = c;
     b->pcond_state = 1;

@@ -11,9 +11,14 @@
  *     Hbar = sum_i Z_i' H_i Z_i,   gbar = sum_i Z_i'(H_i [0; c_i] + g_i),
  *     [Bbar Abar] = X_bs,  bbar = c_bs.
  * Input bounds stay box rows of ubar, bounds on x_{k0} stay box rows of xbar (this is where the
- * equality-flagged x0 rows live).  The host only enables this path when no other inequality
- * exists (state bounds inside a block would become general constraints of the condensed QP);
- * otherwise the full-space QP is solved, which is the reference's default N2 = N.
+ * equality-flagged x0 rows live).  Every other inequality row a' v_{k0+i} -- a state bound of a stage inside the
+ * block, a general row of any stage -- becomes a GENERAL row of the condensed stage with coefficients
+ * a_u' E_i + a_x' X_i and bounds shifted by a_x' c_i; slacks (idxs_rev, also shared ones) travel with their rows,
+ * one-sided rows keep their activity bits (wave-per-instance kernels kw_pcond / kw_pexpand; the compiled
+ * one-instance-per-lane pair k_pcond / k_pexpand covers the box-only class and is the cross-check there).  The
+ * expansion recovers pi of the eliminated dynamics from stationarity including the inequality terms.  Limits: a
+ * condensed stage carries at most 64 rows / 128 inequality sides and nx + bs*nu <= 64; beyond that the full-space QP
+ * is solved (the reference's default N2 = N) with a one-line notice.
  *
  * Mapping: one instance per lane like the IPM kernels; the block matrices (X: NX x nc,
  * Hbar: nc(nc+1)/2, nc = BS*NU + NX) are per-lane arrays addressed in rolled loops.  This is a
@@ -34,6 +39,15 @@ struct PcondMap
     const int *row_kp;    /* per child row (all child stages concatenated): parent stage */
     const int *row_rp;    /* ... parent sorted row index */
     const int *row_off;   /* N2+2 entries: first child row of each child stage */
+    /* wave-per-instance kernels only: rows that become GENERAL rows of the condensed stage (state bounds of a stage
+     * inside a block, every general row), listed by parent stage; their position in the list minus gk_off[k0] is the
+     * general-row index in the child stage.  row_kp / row_rp cover box AND general child rows (sorted child order). */
+    const int *gk_off;    /* N+2 entries: first list entry of parent stage k */
+    const int *g_rp;      /* parent sorted row index (< nb: box row, else general row nb + g) */
+    const int *g_var;     /* box rows: state index of the bounded variable */
+    const int *slk_off;   /* N2+2 entries: first child slack of each child stage (all child slacks concatenated) */
+    const int *slk_kp;    /* per child slack: parent stage */
+    const int *slk_sp;    /* ... parent slack index */
     int N2;
     int mode;             /* 3: everything; 1: matrix part only (Hbar, Abar, Bbar -- condense_lhs);
                              2: vector part only (gbar, bbar, bounds -- condense_rhs), the split RTI
@@ -303,6 +317,38 @@ static __global__ void __launch_bounds__(64) kw_pcond(GqpDev P, GqpDev Cd, Pcond
             if (lane < n) g[lane] = PLAT(P.rq, k * n + lane);
             if (lane < NX) bl[lane] = PLAT(P.bvec, k * NX + lane);
             __syncthreads();
+            /* rows of stage k that are general rows of the condensed stage: a_row' v_k = a_row' (Z_ii vbar + [0; c]),
+             * i.e. coefficients a_u E_ii + a_x X, bounds shifted by a_x' c */
+            {
+                const int g0 = Mp.gk_off[k], ngk = Mp.gk_off[k + 1] - g0, gbase = g0 - Mp.gk_off[k0];
+                const GqpStage &Sp = P.st[k];
+                const GqpStage &Sc = Cd.st[jb];
+                if (Mp.mode & 1)
+                    for (int e = lane; e < ngk * nc; e += 64)
+                    {
+                        const int gi = e / nc, col = e - gi * nc, rp = Mp.g_rp[g0 + gi];
+                        double s;
+                        if (rp < Sp.nb) s = X[Mp.g_var[g0 + gi] * ncp + col];
+                        else
+                        {
+                            const int rowp = (Sp.o_g + rp - Sp.nb) * n;
+                            s = (col >= u0 && col < u0 + NU) ? PLAT(P.DCt, rowp + col - u0) : 0.0;
+                            for (int q = 0; q < NX; q++) s += PLAT(P.DCt, rowp + NU + q) * X[q * ncp + col];
+                        }
+                        PLAT(Cd.DCt, (Sc.o_g + gbase + gi) * nc + col) = s;
+                    }
+                if (Mp.mode & 2)
+                    for (int gi = lane; gi < ngk; gi += 64)
+                    {
+                        const int rp = Mp.g_rp[g0 + gi], rc = Sc.nb + gbase + gi;
+                        double sh = 0.0;
+                        if (rp < Sp.nb) sh = c[Mp.g_var[g0 + gi]];
+                        else
+                            for (int q = 0; q < NX; q++) sh += PLAT(P.DCt, (Sp.o_g + rp - Sp.nb) * n + NU + q) * c[q];
+                        PLAT(Cd.dvec, Sc.o_ct + rc) = PLAT(P.dvec, Sp.o_ct + rp) - sh;
+                        PLAT(Cd.dvec, Sc.o_ct + Sc.nb + Sc.ng + rc) = PLAT(P.dvec, Sp.o_ct + Sp.nb + Sp.ng + rp) - sh;
+                    }
+            }
             /* y = H [0; c] + g */
             if (lane < n)
             {
@@ -403,25 +449,45 @@ static __global__ void __launch_bounds__(64) kw_pcond(GqpDev P, GqpDev Cd, Pcond
             if (jb < Mp.N2 && lane < NX) PLAT(Cd.bvec, jb * NX + lane) = c[lane];
             /* box rows, activity bits, value of fixed variables */
             const GqpStage &Sc = Cd.st[jb];
-            const int r0 = Mp.row_off[jb], nbc = Sc.nb;
-            for (int rc = lane; rc < nbc; rc += 64)
+            const int r0 = Mp.row_off[jb], nbc = Sc.nb, nbgc = Sc.nb + Sc.ng, q0 = Mp.slk_off[jb];
+            for (int rc = lane; rc < nbc; rc += 64) /* box rows keep their bounds (general rows: written above) */
             {
                 const int kp = Mp.row_kp[r0 + rc], rp = Mp.row_rp[r0 + rc];
                 const GqpStage &Sp = P.st[kp];
                 PLAT(Cd.dvec, Sc.o_ct + rc) = PLAT(P.dvec, Sp.o_ct + rp);
-                PLAT(Cd.dvec, Sc.o_ct + nbc + rc) = PLAT(P.dvec, Sp.o_ct + Sp.nb + rp);
+                PLAT(Cd.dvec, Sc.o_ct + nbgc + rc) = PLAT(P.dvec, Sp.o_ct + Sp.nb + Sp.ng + rp);
+            }
+            for (int sc = lane; sc < Sc.ns; sc += 64) /* slacks travel unchanged: cost, bounds */
+            {
+                const int kp = Mp.slk_kp[q0 + sc], sp = Mp.slk_sp[q0 + sc];
+                const GqpStage &Sp = P.st[kp];
+                const int cp = Sp.o_ct + 2 * (Sp.nb + Sp.ng), cc = Sc.o_ct + 2 * nbgc;
+                PLAT(Cd.dvec, cc + sc) = PLAT(P.dvec, cp + sp);
+                PLAT(Cd.dvec, cc + Sc.ns + sc) = PLAT(P.dvec, cp + Sp.ns + sp);
+                for (int w = 0; w < 2; w++)
+                {
+                    PLAT(Cd.Zz, (Sc.o_s + sc) * 2 + w) = PLAT(P.Zz, (Sp.o_s + sp) * 2 + w);
+                    PLAT(Cd.Zz, (Sc.o_s + Sc.ns + sc) * 2 + w) = PLAT(P.Zz, (Sp.o_s + Sp.ns + sp) * 2 + w);
+                }
             }
             if (lane == 0)
             {
                 uint64_t amc[2] = {0, 0};
-                for (int rc = 0; rc < nbc; rc++)
+                auto take = [&](int kp, int side_p, int side_c) {
+                    if ((PLAT(P.amask, kp * P.AW + (side_p >> 6)) >> (side_p & 63)) & 1) amc[side_c >> 6] |= (uint64_t) 1 << (side_c & 63);
+                };
+                for (int rc = 0; rc < nbgc; rc++)
                 {
                     const int kp = Mp.row_kp[r0 + rc], rp = Mp.row_rp[r0 + rc];
-                    const GqpStage &Sp = P.st[kp];
-                    const int bl_ = rp, bu_ = Sp.nb + rp; /* the parent stage has box rows only */
-                    const uint64_t wl = PLAT(P.amask, kp * P.AW + (bl_ >> 6)), wu = PLAT(P.amask, kp * P.AW + (bu_ >> 6));
-                    if ((wl >> (bl_ & 63)) & 1) amc[rc >> 6] |= (uint64_t) 1 << (rc & 63);
-                    if ((wu >> (bu_ & 63)) & 1) amc[(nbc + rc) >> 6] |= (uint64_t) 1 << ((nbc + rc) & 63);
+                    take(kp, rp, rc);
+                    take(kp, P.st[kp].nb + P.st[kp].ng + rp, nbgc + rc);
+                }
+                for (int sc = 0; sc < Sc.ns; sc++)
+                {
+                    const int kp = Mp.slk_kp[q0 + sc], sp = Mp.slk_sp[q0 + sc];
+                    const int bp = 2 * (P.st[kp].nb + P.st[kp].ng);
+                    take(kp, bp + sp, 2 * nbgc + sc);
+                    take(kp, bp + P.st[kp].ns + sp, 2 * nbgc + Sc.ns + sc);
                 }
                 for (int w = 0; w < Cd.AW; w++) PLAT(Cd.amask, jb * Cd.AW + w) = amc[w];
             }
@@ -467,7 +533,34 @@ static __global__ void __launch_bounds__(64) kw_pexpand(GqpDev P, GqpDev Cd, Pco
             if (step && lane < NX) x[lane] = xn;
             __syncthreads();
         }
-        /* multipliers of the eliminated dynamics: pi_k = Q x_k + S' u_k + q_k + A_k' pi_{k+1}, backwards */
+        /* inequality rows and slacks: same constraints, same multipliers */
+        const GqpStage &Sc = Cd.st[jb];
+        const int r0 = Mp.row_off[jb], nbgc = Sc.nb + Sc.ng, q0 = Mp.slk_off[jb];
+        for (int rc = lane; rc < nbgc; rc += 64)
+        {
+            const int kp = Mp.row_kp[r0 + rc], rp = Mp.row_rp[r0 + rc];
+            const GqpStage &Sp = P.st[kp];
+            const int up = Sp.o_ct + Sp.nb + Sp.ng + rp, uc = Sc.o_ct + nbgc + rc;
+            PLAT(P.lam, Sp.o_ct + rp) = PLAT(Cd.lam, Sc.o_ct + rc);
+            PLAT(P.lam, up) = PLAT(Cd.lam, uc);
+            PLAT(P.t, Sp.o_ct + rp) = PLAT(Cd.t, Sc.o_ct + rc);
+            PLAT(P.t, up) = PLAT(Cd.t, uc);
+        }
+        for (int sc = lane; sc < Sc.ns; sc += 64)
+        {
+            const int kp = Mp.slk_kp[q0 + sc], sp = Mp.slk_sp[q0 + sc];
+            const GqpStage &Sp = P.st[kp];
+            const int cp = Sp.o_ct + 2 * (Sp.nb + Sp.ng), cc = Sc.o_ct + 2 * nbgc;
+            PLAT(P.sv, Sp.o_s + sp) = PLAT(Cd.sv, Sc.o_s + sc);
+            PLAT(P.sv, Sp.o_s + Sp.ns + sp) = PLAT(Cd.sv, Sc.o_s + Sc.ns + sc);
+            PLAT(P.lam, cp + sp) = PLAT(Cd.lam, cc + sc);
+            PLAT(P.lam, cp + Sp.ns + sp) = PLAT(Cd.lam, cc + Sc.ns + sc);
+            PLAT(P.t, cp + sp) = PLAT(Cd.t, cc + sc);
+            PLAT(P.t, cp + Sp.ns + sp) = PLAT(Cd.t, cc + Sc.ns + sc);
+        }
+        __syncthreads(); /* the multipliers of the inner stages are read back below */
+        /* multipliers of the eliminated dynamics, backwards:
+         * pi_k = Q x_k + S' u_k + q_k + A_k' pi_{k+1} - J_x'(lam_lower - lam_upper) over the active rows of stage k */
         if (jb < Mp.N2)
         {
             const int k1 = k0 + bs;
@@ -484,23 +577,21 @@ static __global__ void __launch_bounds__(64) kw_pexpand(GqpDev P, GqpDev Cd, Pco
                     pk = PLAT(P.rq, k * n + rr);
                     for (int q = 0; q < n; q++) pk += PLAT(P.RSQ, k * NP + (rr >= q ? PK(rr, q) : PK(q, rr))) * ux[q];
                     for (int q = 0; q < NX; q++) pk += PLAT(P.BAt, (k * n + rr) * NX + q) * pn[q];
+                    const GqpStage &Sp = P.st[k];
+                    const int nbgp = Sp.nb + Sp.ng;
+                    auto dlam = [&](int rp) { /* lam_lower - lam_upper of sorted row rp, active sides only */
+                        const int su_ = nbgp + rp;
+                        const bool al = (PLAT(P.amask, k * P.AW + (rp >> 6)) >> (rp & 63)) & 1;
+                        const bool au = (PLAT(P.amask, k * P.AW + (su_ >> 6)) >> (su_ & 63)) & 1;
+                        return (al ? PLAT(P.lam, Sp.o_ct + rp) : 0.0) - (au ? PLAT(P.lam, Sp.o_ct + su_) : 0.0);
+                    };
+                    if ((Sp.bmask >> rr) & 1) pk -= dlam(popc64_g(Sp.bmask & (((uint64_t) 1 << rr) - 1)));
+                    for (int gq = 0; gq < Sp.ng; gq++) pk -= PLAT(P.DCt, (Sp.o_g + gq) * n + rr) * dlam(Sp.nb + gq);
                 }
                 __syncthreads();
                 if (lane < NX) { pn[lane] = pk; PLAT(P.pi, k * NX + lane) = pk; }
                 __syncthreads();
             }
-        }
-        /* inequality rows */
-        const GqpStage &Sc = Cd.st[jb];
-        const int r0 = Mp.row_off[jb], nbc = Sc.nb;
-        for (int rc = lane; rc < nbc; rc += 64)
-        {
-            const int kp = Mp.row_kp[r0 + rc], rp = Mp.row_rp[r0 + rc];
-            const GqpStage &Sp = P.st[kp];
-            PLAT(P.lam, Sp.o_ct + rp) = PLAT(Cd.lam, Sc.o_ct + rc);
-            PLAT(P.lam, Sp.o_ct + Sp.nb + rp) = PLAT(Cd.lam, Sc.o_ct + nbc + rc);
-            PLAT(P.t, Sp.o_ct + rp) = PLAT(Cd.t, Sc.o_ct + rc);
-            PLAT(P.t, Sp.o_ct + Sp.nb + rp) = PLAT(Cd.t, Sc.o_ct + nbc + rc);
         }
         __syncthreads();
     }

@@ -68,7 +68,9 @@ def test_mass_spring_gpu(gpu_lib, N):
         opts.cond_N = cond_N
         s = AcadosOcpQpBatchSolver([qp, qp], opts)
         assert s.solve() == 0
-        compare_with_oracle(lambda k, f: s.get_batch(1, k, f, unique_duals=False), o, qp, 1e-8)
+        # condensed runs follow another iterate path to the same solution: multipliers of nearly active rows
+        # (lam ~ 1e-6) then agree to a few 1e-8 only
+        compare_with_oracle(lambda k, f: s.get_batch(1, k, f, unique_duals=False), o, qp, 1e-8 if cond_N == N else 2e-7)
         it0 = s.get_iter(0)
         assert s.solve() == 0 and s.get_iter(0) == it0   # cold start every time (mass_spring_example.c:352)
 
@@ -457,3 +459,53 @@ def test_solution_sensitivities_large_batch_gpu(gpu_lib, monkeypatch):
         err = np.max(np.abs(got - want), axis=1) / np.maximum(1.0, np.max(np.abs(want), axis=1))
         assert np.mean(err <= 1e-5) >= 0.95 and np.median(err) <= 1e-6, np.sort(err)[-5:]
     assert np.all(sb[:, 1] == 1.0) and np.max(np.abs(sb[:, nx:])) > 1e-2
+
+
+@pytest.mark.gpu
+def test_partial_condensing_general_rows_gpu(gpu_lib):
+    """a5-a7 beyond the box class on the device: the C4 class (soft state bounds + soft general rows, nx = 24)
+    condensed N = 40 -> 20 blocks of 2 (state bounds / general rows of the inner stages become general rows of the
+    condensed stages, slacks travel along), 2,048 instances: the expanded solution equals the full-space solution
+    of the same batch, and the KKT residuals of the ORIGINAL QP evaluated at the expanded solution by a hot-started
+    full-space call are at tolerance.  Plus the reference's mass-spring unit-test QP with state bounds at every
+    stage, N2 = 5 and 3, against the oracle."""
+    from acados_amd import OcpQpGpuBatch
+    from acados_amd.generators import chain_soft_batch, chain_soft_dims, fill_chain_soft_batch, mass_spring_qp
+    N, B = 40, 2048
+    data = chain_soft_batch(N=N, batch=B, seed=3)
+    sol = {}
+    for cond_N in (N, 20):
+        gb = OcpQpGpuBatch(chain_soft_dims(N), B)
+        fill_chain_soft_batch(gb, data, N)
+        for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+            gb.opts_set(f, 1e-8)
+        gb.opts_set("cond_N", cond_N)
+        assert gb.solve() == 0
+        assert int(gb.scalar("cond_N_active")) == cond_N
+        sol[cond_N] = {f: np.concatenate([gb.get(f, k) for k in range(N + (f != "pi" and f != "u"))], axis=1)
+                       for f in ("x", "u", "pi", "lam", "sl", "su")}
+        if cond_N < N:
+            # the expanded point in the ORIGINAL QP: a hot-started full-space call finds its KKT residuals at
+            # tolerance straight away (one more iteration allowed: the condensed residual norms are not the same norms)
+            gb.opts_set("cond_N", N)
+            gb.opts_set("warm_start", 2)
+            assert gb.solve() == 0
+            assert int(gb.info("iter").max()) <= 1
+    # two iterate paths to the same solution; nearly degenerate instances (lam and t both small) move by more
+    for f in ("x", "u", "sl", "su", "pi", "lam"):
+        a, c = sol[N][f], sol[20][f]
+        err = np.max(np.abs(a - c) / np.maximum(1.0, np.abs(a)), axis=1)
+        # (complementarity 1e-8 leaves lam ~ t ~ 1e-4 on a weakly active row: such instances differ by ~1e-4)
+        w = 1.0 if f in ("x", "u") else 10.0
+        assert np.median(err) <= 2e-6 * w and np.mean(err <= 2e-5 * w) >= 0.9 and err.max() <= 2e-2, \
+            (f, np.median(err), np.sort(err)[-5:])
+    for cn in (5, 3):
+        qp = mass_spring_qp(N=15)
+        b = OcpQpGpuBatch.from_qps([qp] * 70)
+        for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+            b.opts_set(f, 1e-8)
+        b.opts_set("cond_N", cn)
+        assert b.solve() == 0 and int(b.scalar("cond_N_active")) == cn
+        o = OracleQp(qp)
+        assert o.solve(default_opts(tol_stat=1e-8)) == 0
+        compare_with_oracle(lambda k, f: b.get(f, k)[69], o, qp, 2e-7, fields=("x", "u", "pi", "lam", "t"))

@@ -326,8 +326,7 @@ def test_wave_per_instance_default_rule_hostsim(hostsim_lib, monkeypatch):
 def test_partial_condensing_hostsim(hostsim_lib, monkeypatch):
     """a5-a7: condensing N -> N2 blocks, IPM on the condensed QP, expansion; the expanded solution
     must equal the full-space oracle solution (x, u, pi, lam, t).  Covers C3 (N=50 -> 10 blocks of 5),
-    uneven block sizes, the reference's golden pendulum QP, the RTI lhs/rhs split and the decline
-    path (state bounds inside a block -> full-space solve, same answer)."""
+    uneven block sizes, the reference's golden pendulum QP and the RTI lhs/rhs split."""
     from acados_amd import OcpQpGpuBatch
     from acados_amd.generators import lqr_instance_qp, mass_spring_qp, random_lqr_batch
 
@@ -359,7 +358,40 @@ def test_partial_condensing_hostsim(hostsim_lib, monkeypatch):
     data = random_lqr_batch(N=10, batch=3, seed=3)
     run([lqr_instance_qp(data, i, 10) for i in range(3)], 3, 3)        # blocks of 4, 3, 3
     run([load_qp("qp_test/last_qp_nonuniform_pendulum.json")], 3, 3)   # N=7 -> 3, 2, 2 ; x0 equality rows
-    run([mass_spring_qp(N=15)], 5, 15)                                  # declined: state bounds in blocks
+
+
+def test_partial_condensing_general_rows_hostsim(hostsim_lib):
+    """a5-a7 beyond the box class: state bounds inside a block become general rows of the condensed stage
+    (coefficients = rows of the block's state-transfer matrix, bounds shifted by the free response), general rows are
+    carried through the same substitution, slacks (also shared ones, idxs_rev) travel with their rows, one-sided
+    bounds keep their activity bits; the expansion recovers pi of the eliminated dynamics including the inequality
+    terms.  Mass-spring with N2 in {5, 3} is the reference's own unit-test setting (test_qpsolvers.cpp:117-268)."""
+    from acados_amd import OcpQpGpuBatch
+    from acados_amd.generators import chain_soft_qp, mass_spring_qp
+
+    # two different iterate paths (condensed / full space) stopped at residuals <= 1e-8: multipliers of nearly
+    # active rows (lam ~ 1e-6) agree to a few 1e-8, hence 2e-7 here
+    def run(qp, cond_N, split=False, tol=2e-7):
+        b = OcpQpGpuBatch.from_qps([qp, qp], _clib=hostsim_lib)
+        for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+            b.opts_set(f, 1e-8)
+        b.opts_set("cond_N", cond_N)
+        if split:
+            assert b.condense_lhs() == 0
+            assert b.condense_rhs_and_solve() == 0
+        else:
+            assert b.solve() == 0
+        assert int(b.scalar("cond_N_active")) == cond_N
+        o = OracleQp(qp)
+        assert o.solve(default_opts(tol_stat=1e-8)) == 0
+        compare_with_oracle(lambda k, f: b.get(f, k)[1], o, qp, tol, fields=("x", "u", "sl", "su", "pi", "lam", "t"))
+
+    run(mass_spring_qp(N=15), 5)
+    run(mass_spring_qp(N=15), 3, split=True)
+    run(load_qp("qp_test/last_qp_one_sided_test.json"), 5)              # one-sided state bounds inside the blocks
+    run(load_qp("casadi_qp_tests/pendulum_slack.json"), 2)              # general rows + slacks, N = 5 -> 3, 2
+    run(load_qp("casadi_qp_tests/pend_idxs_rev_min_qp0.json"), 3)       # slack shared by two rows
+    run(chain_soft_qp(N=6, seed=2, i=0), 3)                             # C4 class: nx = 24, soft state bounds + general rows
 
 
 def test_compaction_is_bit_identical_hostsim(hostsim_lib):
