@@ -6,7 +6,8 @@
  * oracle in the CPU-only test tier (`-m "not gpu"`).  It is built by tests/hostsim/build.py
  * into tests/hostsim/libgqp_hostsim.so and is never loaded by the acados_amd package:
  * the product library is the hipcc build of the same sources and needs a real GPU.
- * Only valid for kernels without cross-lane communication (one instance per lane).
+ * One-instance-per-lane kernels run lane after lane; kernels with cross-lane communication through shared memory
+ * and barriers run as coroutines (GQP_LAUNCH_COOP below).
  */
 #ifndef HOSTSIM_HIP_RUNTIME_H_
 #define HOSTSIM_HIP_RUNTIME_H_
@@ -17,7 +18,8 @@
 #include <chrono>
 #include <thread>
 #include <vector>
-#include <pthread.h>
+#include <functional>
+#include <ucontext.h>
 
 #define __global__
 #define __device__
@@ -70,39 +72,68 @@ static inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int
 static inline int atomicSub(int *p, int v) { int o = *p; *p = o - v; return o; }
 static inline int atomicAdd(int *p, int v) { int o = *p; *p = o + v; return o; }
 
-/* ---- cooperative kernels (one block = lanes that really run concurrently) ----
- * Kernels that use __syncthreads() and block-shared memory are launched through
- * GQP_LAUNCH_COOP: every lane of a block becomes a host thread, __syncthreads() is a pthread
- * barrier, `__shared__` statics and the dynamic shared buffer are shared by those threads.
- * Blocks run one after the other. */
+/* ---- cooperative kernels (lanes of a block that exchange data through shared memory) ----
+ * Kernels that use __syncthreads() and block-shared memory are launched through GQP_LAUNCH_COOP: every lane of a
+ * block becomes a coroutine (ucontext) on the calling thread; a barrier hands control back to a round-robin
+ * scheduler, which resumes a lane only after every other unfinished lane has run up to ITS next barrier (or to its
+ * end).  All lanes of a synchronisation group execute the same barrier sequence, so they advance in lockstep; groups
+ * that do not share data (the 16-lane rows of the sixteen-lanes kernels) may run different numbers of barriers.
+ * `__shared__` statics and the dynamic shared buffer are shared by the lanes.  Blocks run one after the other.
+ * (Coroutines instead of one host thread per lane: a futex barrier among 64 threads on a few cores costs ~100 us, a
+ * context switch well under 1 us -- the CPU test tier runs the wave-per-instance kernels thousands of times.) */
 struct hostsim_coop
 {
-    static pthread_barrier_t &bar() { static pthread_barrier_t b; return b; }
-    static pthread_barrier_t &rowbar(int row) { static pthread_barrier_t b[4]; return b[row & 3]; } /* 16-lane rows */
+    enum { MAXL = 64, STACK = 1 << 20 };
+    struct state
+    {
+        ucontext_t sched, ctx[MAXL];
+        char *stacks = nullptr;
+        bool done[MAXL];
+        int cur = 0;
+        std::function<void()> body;
+    };
+    static state &st() { static thread_local state s; return s; }
     static std::vector<double> &dyn() { static std::vector<double> v; return v; }
+    static void yield() { state &s = st(); swapcontext(&s.ctx[s.cur], &s.sched); }
+    static void tramp() { state &s = st(); s.body(); s.done[s.cur] = true; }
+    static void run_block(unsigned nl)
+    {
+        state &s = st();
+        if (!s.stacks) s.stacks = (char *) malloc((size_t) MAXL * STACK);
+        for (unsigned l = 0; l < nl; l++)
+        {
+            getcontext(&s.ctx[l]);
+            s.ctx[l].uc_stack.ss_sp = s.stacks + (size_t) l * STACK;
+            s.ctx[l].uc_stack.ss_size = STACK;
+            s.ctx[l].uc_link = &s.sched;
+            makecontext(&s.ctx[l], (void (*)()) tramp, 0);
+            s.done[l] = false;
+        }
+        for (unsigned left = nl; left > 0;)
+            for (unsigned l = 0; l < nl; l++)
+            {
+                if (s.done[l]) continue;
+                s.cur = (int) l;
+                threadIdx.x = l;
+                swapcontext(&s.sched, &s.ctx[l]);
+                if (s.done[l]) left--;
+            }
+    }
 };
-static inline void __syncthreads() { pthread_barrier_wait(&hostsim_coop::bar()); }
+static inline void __syncthreads() { hostsim_coop::yield(); }
 /* lanes of one 16-lane row (kernels with several independent instances per block) */
-#define GQP_ROWSYNC() pthread_barrier_wait(&hostsim_coop::rowbar(threadIdx.x >> 4))
+#define GQP_ROWSYNC() hostsim_coop::yield()
 #define GQP_DYN_SHARED(name) double *name = hostsim_coop::dyn().data()
 
 #define GQP_LAUNCH_COOP(kern, grid, block, shmem, stream, ...)                              \
     do {                                                                                    \
         dim3 g_ = (grid); dim3 b_ = (block);                                                \
         hostsim_coop::dyn().assign(((size_t) (shmem) + 7) / 8 + 8, 0.0);                    \
+        hostsim_coop::st().body = [&]() { kern(__VA_ARGS__); };                             \
         for (unsigned bx_ = 0; bx_ < g_.x; bx_++)                                           \
         {                                                                                   \
-            pthread_barrier_init(&hostsim_coop::bar(), nullptr, b_.x);                      \
-            for (int r_ = 0; r_ < 4; r_++) pthread_barrier_init(&hostsim_coop::rowbar(r_), nullptr, 16); \
-            std::vector<std::thread> th_;                                                   \
-            for (unsigned tx_ = 0; tx_ < b_.x; tx_++)                                       \
-                th_.emplace_back([=]() {                                                    \
-                    blockDim = b_; gridDim = g_; blockIdx.x = bx_; threadIdx.x = tx_;       \
-                    kern(__VA_ARGS__);                                                      \
-                });                                                                         \
-            for (auto &t_ : th_) t_.join();                                                 \
-            pthread_barrier_destroy(&hostsim_coop::bar());                                  \
-            for (int r_ = 0; r_ < 4; r_++) pthread_barrier_destroy(&hostsim_coop::rowbar(r_)); \
+            blockDim = b_; gridDim = g_; blockIdx.x = bx_;                                  \
+            hostsim_coop::run_block(b_.x);                                                  \
         }                                                                                   \
     } while (0)
 
