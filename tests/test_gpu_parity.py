@@ -509,3 +509,33 @@ def test_partial_condensing_general_rows_gpu(gpu_lib):
         o = OracleQp(qp)
         assert o.solve(default_opts(tol_stat=1e-8)) == 0
         compare_with_oracle(lambda k, f: b.get(f, k)[69], o, qp, 2e-7, fields=("x", "u", "pi", "lam", "t"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("wpi", ["0", "1"])
+def test_random_structures_gpu(gpu_lib, monkeypatch, wpi):
+    """40 QPs with random STRUCTURE (tests/random_qp.py: per-stage dims, box subsets, one-sided rows, general rows,
+    slacks shared between rows, equality-flagged x0, N = 1..6), 70 copies per batch, on the one-instance-per-lane
+    and the wave-per-instance kernels against the oracle; with N >= 2 also partially condensed (N2 = ceil(N/2)):
+    the expanded point satisfies the ORIGINAL KKT conditions (hot-started full-space call: 0 iterations)"""
+    from acados_amd import OcpQpGpuBatch
+    from random_qp import random_structure_qp
+    monkeypatch.setenv("ACADOS_AMD_WPI", wpi)
+    for seed in range(40):
+        qp = random_structure_qp(seed)
+        o = OracleQp(qp)
+        assert o.solve(default_opts(tol_stat=1e-8, iter_max=60)) == 0, seed
+        b = OcpQpGpuBatch.from_qps([qp] * 70)
+        for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+            b.opts_set(f, 1e-8)
+        b.opts_set("iter_max", 60)
+        assert b.solve() == 0, (seed, b.kernel_name)
+        assert abs(int(b.info("iter")[69]) - o.iter) <= 1, (seed, b.kernel_name)
+        compare_with_oracle(lambda k, f: b.get(f, k)[69], o, qp, 1e-7, fields=("x", "u", "sl", "su", "pi", "lam", "t"))
+        if qp.N >= 2:
+            b.opts_set("cond_N", (qp.N + 1) // 2)
+            assert b.solve() == 0, seed
+            compare_with_oracle(lambda k, f: b.get(f, k)[69], o, qp, 1e-4, fields=("x", "u", "sl", "su", "pi", "lam", "t"))
+            b.opts_set("cond_N", qp.N)
+            b.opts_set("warm_start", 2)
+            assert b.solve() == 0 and int(b.info("iter").max()) == 0, seed

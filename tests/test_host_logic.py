@@ -502,11 +502,15 @@ def test_solver_get_vtable_hostsim(hostsim_lib):
     assert np.all(np.isfinite(Kmat)) and np.abs(Kmat).max() > 0 and np.allclose(P, P.T) and np.all(np.linalg.eigvalsh(P) > 0)
 
 
-def test_edge_cases_hostsim(hostsim_lib):
+@pytest.mark.parametrize("fam", ["1tpi", "wpi", "w16"])
+def test_edge_cases_hostsim(hostsim_lib, monkeypatch, fam):
     """edge cases: no inequality at all (pure LQR: one Newton step), N = 1, single instance, exact wave
-    multiple, infeasible bounds (non-zero acados status, no hang), NaN in the data (ACADOS_NAN_DETECTED)"""
+    multiple, infeasible bounds (non-zero acados status, no hang), NaN in the data (ACADOS_NAN_DETECTED) -- on each
+    of the three kernel families"""
     from acados_amd import AcadosOcpQp, OcpQpGpuBatch
     from acados_amd.generators import lqr_instance_qp, random_lqr_batch
+    monkeypatch.setenv("ACADOS_AMD_WPI", "0" if fam == "1tpi" else "1")
+    monkeypatch.setenv("ACADOS_AMD_W16", "1" if fam == "w16" else "0")
 
     # pure LQR with free initial state: no inequality rows anywhere
     data = random_lqr_batch(N=6, batch=2, seed=1)
@@ -691,3 +695,59 @@ def test_solution_sensitivities_soft_constraints_hostsim(hostsim_lib, monkeypatc
         ref.sens_solve()
         se = xus(ref, "sens_")
         assert np.max(np.abs(fd - se)) <= 2e-5 * np.max(np.abs(se)), name
+
+
+@pytest.mark.parametrize("wpi", ["0", "1"])
+def test_random_structures_hostsim(hostsim_lib, monkeypatch, wpi):
+    """30 QPs with random STRUCTURE (tests/random_qp.py: per-stage dims, box subsets, one-sided rows, general rows,
+    slacks shared between rows, equality-flagged x0, N = 1..6) on the one-instance-per-lane kernels (where a compiled
+    shape covers the dims) and on the wave-per-instance family, three copies per batch, against the oracle"""
+    from acados_amd import OcpQpGpuBatch
+    from random_qp import random_structure_qp
+    monkeypatch.setenv("ACADOS_AMD_WPI", wpi)
+    fams = set()
+    for seed in range(30):
+        qp = random_structure_qp(seed)
+        o = OracleQp(qp)
+        assert o.solve(default_opts(tol_stat=1e-8, iter_max=60)) == 0, seed
+        b = OcpQpGpuBatch.from_qps([qp] * 3, _clib=hostsim_lib)
+        for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+            b.opts_set(f, 1e-8)
+        b.opts_set("iter_max", 60)
+        assert b.solve() == 0, (seed, b.kernel_name)
+        fams.add(b.kernel_name.split("(")[0].split("<")[0])
+        assert abs(int(b.info("iter")[2]) - o.iter) <= 1, (seed, b.kernel_name)
+        try:
+            compare_with_oracle(lambda k, f: b.get(f, k)[2], o, qp, 1e-7, fields=("x", "u", "sl", "su", "pi", "lam", "t"))
+        except AssertionError as e:
+            raise AssertionError(f"seed {seed} kernel {b.kernel_name}: {e}")
+    assert all(f.startswith(("wpi", "w16") if wpi == "1" else "1tpi") for f in fams), fams
+
+
+def test_random_structures_partial_condensing_hostsim(hostsim_lib):
+    """partial condensing on QPs with random structure (tests/random_qp.py; N2 = ceil(N/2), uneven blocks, per-stage
+    dims, one-sided rows, general rows, shared slacks): the expanded point must satisfy the KKT conditions of the
+    ORIGINAL QP at tolerance -- a hot-started full-space call converges at its first residual evaluation -- and lie
+    close to the oracle's solution (the two iterate paths stop at different points of the 1e-8 complementarity ball)"""
+    from acados_amd import OcpQpGpuBatch
+    from random_qp import random_structure_qp
+    condensed = 0
+    for seed in range(40):
+        qp = random_structure_qp(seed)
+        if qp.N < 2:
+            continue
+        o = OracleQp(qp)
+        assert o.solve(default_opts(tol_stat=1e-8, iter_max=60)) == 0
+        b = OcpQpGpuBatch.from_qps([qp] * 2, _clib=hostsim_lib)
+        for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+            b.opts_set(f, 1e-8)
+        b.opts_set("iter_max", 60)
+        b.opts_set("cond_N", (qp.N + 1) // 2)
+        assert b.solve() == 0, seed
+        condensed += int(b.scalar("cond_N_active")) == (qp.N + 1) // 2
+        compare_with_oracle(lambda k, f: b.get(f, k)[1], o, qp, 1e-4, fields=("x", "u", "sl", "su", "pi", "lam", "t"))
+        b.opts_set("cond_N", qp.N)
+        b.opts_set("warm_start", 2)
+        assert b.solve() == 0 and int(b.info("iter").max()) == 0, seed
+        assert max(b.info(n).max() for n in ("res_stat", "res_eq", "res_ineq", "res_comp")) <= 1e-8
+    assert condensed >= 30
