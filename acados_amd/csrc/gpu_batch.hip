@@ -131,6 +131,7 @@ struct ocp_qp_gpu_batch
     ocp_qp_gpu_batch *sens_child = nullptr; /* wave-per-instance sub-batch the sensitivities of a one-instance-per-lane batch run in */
     int *d_slist = nullptr;
     int sens_cap = 0;
+    int tail_cap = 0;
     int *d_list = nullptr;               /* instance index of every slot of `compact` / `tail` */
     int list_cap = 0;
     int n_compactions = 0;
@@ -1182,10 +1183,17 @@ static void compact_into(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch *root, int nact, 
         b->d_list = dalloc<int>(b, b->list_cap);
     }
     ocp_qp_gpu_batch *&slot = tail ? b->tail : b->compact;
+    if (slot && tail && cnt > b->tail_cap)
+    {
+        /* tail_max was raised after the sub-batch had been sized */
+        ocp_qp_gpu_batch_destroy(slot);
+        slot = nullptr;
+    }
     if (!slot)
     {
         /* same kernel set (compaction) or the wave-per-instance family at the very same padded dims (tail) */
-        const int cap = tail ? std::min(b->tail_max, b->list_cap) : (b->B + 1) / 2;
+        const int cap = tail ? std::max(cnt, std::min(b->tail_max, b->list_cap)) : (b->B + 1) / 2;
+        if (tail) b->tail_cap = cap;
         g_force_ks = b->ks;
         g_force_wpi = tail;
         ocp_qp_gpu_batch *c = batch_create_shape(b->N, b->nx.data(), b->nu.data(), b->nbx.data(), b->nbu.data(),

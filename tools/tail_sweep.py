@@ -1,0 +1,20 @@
+"""C2 (65,536 instances): solve time against the hand-over threshold of the tail switch (`tail_max`)."""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from acados_amd import OcpQpGpuBatch
+from acados_amd.generators import fill_lqr_batch, lqr_dims, random_lqr_batch
+
+N, B = 50, 65536
+data = random_lqr_batch(N=N, batch=B, seed=0)
+gb = OcpQpGpuBatch(lqr_dims(N, 8, 3), B)
+fill_lqr_batch(gb, data, N)
+for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+    gb.opts_set(f, 1e-8)
+for tm in [int(a) for a in sys.argv[1:]] or [0, 8192, 12288, 16384, 20480, 24576, 28672, 32768]:
+    gb.opts_set("tail_max", tm)
+    gb.solve()
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter(); bad = gb.solve(); ts.append(time.perf_counter() - t0)
+    print(f"tail_max {tm:6d}: {min(ts)*1e3:7.2f} ms  {B/min(ts):10.0f} solves/s  tail switches {int(gb.scalar('tail_switches'))}  failures {bad}", flush=True)
