@@ -8,6 +8,7 @@ from .ocp_qp import AcadosOcpQp, AcadosOcpQpDims
 from .ocp_qp_options import AcadosOcpQpOptions
 from .ocp_qp_solver import AcadosOcpQpSolver, AcadosOcpQpBatchSolver
 from .gpu_batch import OcpQpGpuBatch
+from .ocp_qp_condensing import AcadosOcpQpCondensing
 
 __all__ = ["AcadosOcpQp", "AcadosOcpQpDims", "AcadosOcpQpOptions", "AcadosOcpQpSolver",
-           "AcadosOcpQpBatchSolver", "OcpQpGpuBatch"]
+           "AcadosOcpQpBatchSolver", "OcpQpGpuBatch", "AcadosOcpQpCondensing"]

@@ -37,6 +37,11 @@ def bind(L):
     L.ocp_qp_gpu_batch_kernel_name.restype = C.c_char_p
     L.ocp_qp_gpu_batch_sens_set.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p]
     L.ocp_qp_gpu_batch_sens_solve.argtypes = [C.c_void_p]
+    L.ocp_qp_gpu_batch_condense.argtypes = [C.c_void_p]
+    L.ocp_qp_gpu_batch_condense.restype = C.c_void_p
+    L.ocp_qp_gpu_batch_expand.argtypes = [C.c_void_p]
+    L.ocp_qp_gpu_batch_get_dims.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]
+    L.ocp_qp_gpu_batch_get_int.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_int)]
     return L
 
 

@@ -106,6 +106,7 @@ struct ocp_qp_gpu_batch
     /* partial condensing (pcond_kernels.hpp) */
     int cond_N = 0;                 /* requested N2; 0 or N = full space */
     int force_NX = 0, force_NU = 0; /* child batches are pinned to the kernel shape the condense kernel writes */
+    std::vector<int> user_blocks;   /* cond_block_size (N2 entries) or empty: N/N2 each, remainder to the first blocks */
     int pcond_state = 0;            /* 0 unchecked, 1 active, -1 not applicable (message printed once) */
     ocp_qp_gpu_batch *child = nullptr;
     const PcondSet *pc = nullptr;   /* compiled one-instance-per-lane condensing kernels, or ... */
@@ -810,9 +811,29 @@ int ocp_qp_gpu_batch_opts_set(ocp_qp_gpu_batch *b, const char *f, const void *v)
         if (*i != b->cond_N)
         {
             b->cond_N = *i;
+            b->user_blocks.clear();
             b->pcond_state = 0;
             if (b->child) { ocp_qp_gpu_batch_destroy(b->child); b->child = nullptr; }
         }
+    }
+    else if (!strcmp(f, "cond_block_size"))
+    {
+        /* user block sizes, N2 + 1 entries as ocp_qp_partial_condensing.c:305-313; set cond_N first.  They must sum to
+         * N (:346-356); the last entry -- inputs condensed into the terminal stage -- must be 0 in this build. */
+        const int N2 = b->cond_N;
+        if (N2 <= 0 || N2 >= b->N) { fprintf(stderr, "acados_amd: cond_block_size needs cond_N in 1..N-1 first\n"); return -1; }
+        int sum = 0;
+        for (int j = 0; j <= N2; j++) sum += i[j];
+        bool ok = sum == b->N && i[N2] == 0;
+        for (int j = 0; j < N2; j++) ok = ok && i[j] >= 1;
+        if (!ok)
+        {
+            fprintf(stderr, "acados_amd: partial condensing: block sizes must be >= 1, sum to N = %d (got %d) and end with 0\n", b->N, sum);
+            return -1;
+        }
+        b->user_blocks.assign(i, i + N2);
+        b->pcond_state = 0;
+        if (b->child) { ocp_qp_gpu_batch_destroy(b->child); b->child = nullptr; }
     }
     else if (!strcmp(f, "t0_init")) { /* single initialisation scheme (oracle-pinned) */ }
     else if (!strcmp(f, "ric_alg"))
@@ -857,7 +878,7 @@ static void pcond_setup(ocp_qp_gpu_batch *b)
     int bsmax = 0;
     for (int j = 0; j < N2; j++)
     {
-        const int bs = N / N2 + (j < N % N2 ? 1 : 0);
+        const int bs = (int) b->user_blocks.size() == N2 ? b->user_blocks[j] : N / N2 + (j < N % N2 ? 1 : 0);
         b->blk_start[j + 1] = b->blk_start[j] + bs;
         bsmax = std::max(bsmax, bs);
     }
@@ -1518,7 +1539,35 @@ int ocp_qp_gpu_batch_get(ocp_qp_gpu_batch *b, const char *f, int k, double *data
     if (b->factor_stale && !strncmp(f, "ric_", 4)) refactor_at_solution(b);
     /* sensitivities: the direction arrays of the last ocp_qp_gpu_batch_sens_solve */
     const bool is_sens = !strncmp(f, "sens_", 5);
+    {
+        const size_t flen = strlen(f);
+        if (flen > 5 && !strcmp(f + flen - 5, "_mask"))
+        {
+            /* activity of the sides as 1.0 / 0.0 (equality-flagged rows: 1.0) */
+            const int mlen = mask_bits(b, f, k, map);
+            if (mlen < 0) { fprintf(stderr, "acados_amd: ocp_qp_gpu_batch_get: field %s not available at stage %d\n", f, k); return -1; }
+            if (mlen == 0) return 0;
+            const size_t mcnt = (size_t) b->B * mlen;
+            double *mdst = data;
+            if (!is_device)
+            {
+                if (mcnt > b->stage_cap) { b->stage_cap = mcnt * 2; b->d_stage = dalloc<double>(b, b->stage_cap); }
+                mdst = b->d_stage;
+            }
+            int *dmm = upload_map(b, map);
+            hipLaunchKernelGGL(gqp::k_getmask, dim3((b->B + 63) / 64), dim3(64), 0, b->stream, mdst, b->B, mlen, dmm, b->D.amask, k, b->AW);
+            if (!is_device) HIPCHK(hipMemcpyAsync(data, mdst, sizeof(double) * mcnt, hipMemcpyDeviceToHost, b->stream));
+            HIPCHK(hipStreamSynchronize(b->stream));
+            return 0;
+        }
+    }
     int len = field_map(b, is_sens ? f + 5 : f, k, map, &arr);
+    if (len > 0 && (!strcmp(f, "Q") || !strcmp(f, "R")))
+    {
+        /* the packed lower triangle holds the matrix: mirror it for the reader */
+        const int dim = f[0] == 'Q' ? b->nx[k] : b->nu[k];
+        for (int c = 0; c < dim; c++) for (int r = 0; r < c; r++) map[c * dim + r] = map[r * dim + c];
+    }
     if (is_sens && len >= 0)
     {
         if (arr.p == b->D.ux.p) arr = b->D.dux;
@@ -1631,6 +1680,57 @@ int ocp_qp_gpu_batch_condense_lhs(ocp_qp_gpu_batch *b)
     HIPCHK(hipStreamSynchronize(b->stream));
     b->lhs_ready = true;
     return 0;
+}
+
+/* condensing-only boundary (interfaces/acados_c/condensing_interface.h:73-75): the condensed QP as an object of its
+ * own, and the expansion of a solution of it */
+ocp_qp_gpu_batch *ocp_qp_gpu_batch_condense(ocp_qp_gpu_batch *b)
+{
+    HIPCHK(hipSetDevice(b->device));
+    finalize_structure(b);
+    if (!(b->cond_N > 0 && b->cond_N < b->N)) return nullptr;
+    if (b->pcond_state == 0) pcond_setup(b);
+    if (b->pcond_state != 1) return nullptr;
+    b->pmap.mode = 3;
+    pcond_launch(b, false);
+    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(hipGetLastError());
+    b->lhs_ready = false;
+    return b->child;
+}
+
+int ocp_qp_gpu_batch_expand(ocp_qp_gpu_batch *b)
+{
+    HIPCHK(hipSetDevice(b->device));
+    if (b->pcond_state != 1 || !b->child) return -1;
+    HIPCHK(hipStreamSynchronize(b->child->stream));
+    pcond_launch(b, true);
+    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int ocp_qp_gpu_batch_get_dims(ocp_qp_gpu_batch *b, const char *f, int *out)
+{
+    const std::vector<int> *v = nullptr;
+    if (!strcmp(f, "N")) { out[0] = b->N; return 0; }
+    if (!strcmp(f, "n_batch")) { out[0] = b->B; return 0; }
+    if (!strcmp(f, "nx")) v = &b->nx; else if (!strcmp(f, "nu")) v = &b->nu; else if (!strcmp(f, "nbx")) v = &b->nbx;
+    else if (!strcmp(f, "nbu")) v = &b->nbu; else if (!strcmp(f, "nb")) v = &b->nb; else if (!strcmp(f, "ng")) v = &b->ng;
+    else if (!strcmp(f, "ns")) v = &b->ns; else if (!strcmp(f, "nbxe")) v = &b->nbxe;
+    if (!v) { fprintf(stderr, "acados_amd: ocp_qp_gpu_batch_get_dims: unknown field %s\n", f); return -1; }
+    for (int k = 0; k <= b->N; k++) out[k] = (*v)[k];
+    return 0;
+}
+
+int ocp_qp_gpu_batch_get_int(ocp_qp_gpu_batch *b, const char *f, int k, int *out)
+{
+    if (k < 0 || k > b->N) return -1;
+    const std::vector<int> *v = nullptr;
+    if (!strcmp(f, "idxb")) v = &b->idxb[k]; else if (!strcmp(f, "idxs_rev")) v = &b->idxs_rev[k]; else if (!strcmp(f, "idxe")) v = &b->idxe[k];
+    if (!v) { fprintf(stderr, "acados_amd: ocp_qp_gpu_batch_get_int: unknown field %s\n", f); return -1; }
+    for (size_t e = 0; e < v->size(); e++) out[e] = (*v)[e];
+    return (int) v->size();
 }
 
 int ocp_qp_gpu_batch_condense_rhs_and_solve(ocp_qp_gpu_batch *b)

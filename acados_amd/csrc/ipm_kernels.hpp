@@ -1089,6 +1089,18 @@ static __global__ void k_gather(double *dst, int nb, int len, const int *map, GA
     }
 }
 
+/* dst[i * len + e] = 1.0 / 0.0: bit bitpos[e] of amask[stage] (bitpos < 0: a row that always takes part) */
+static __global__ void k_getmask(double *dst, int nb, int len, const int *bitpos, GArrU64 amask, int stage, int AW)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nb) return;
+    for (int e = 0; e < len; e++)
+    {
+        const int b = bitpos[e];
+        dst[(size_t) i * len + e] = (b < 0 || ((GATL(amask, stage * AW + (b >> 6)) >> (b & 63)) & 1)) ? 1.0 : 0.0;
+    }
+}
+
 /* activity bit masks: for every element e of a (lower|upper|slack) mask vector handed
  * over by the caller, set or clear bit bitpos[e] of amask[stage] */
 static __global__ void k_setmask(const double *src, int nb, int len, const int *bitpos, GArrU64 amask, int stage, int AW)

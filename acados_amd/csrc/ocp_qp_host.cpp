@@ -38,6 +38,7 @@ struct batch_cache
 {
     ocp_qp_gpu_batch *batch = nullptr;
     int n = 0;
+    bool blocks_sent = false; /* user block sizes handed to this device batch */
     std::vector<int> sig; /* dims + idxb + idxs_rev + idxe of the batch */
     std::vector<double> stat;
     std::vector<double> stage; /* host staging [n][len] */
@@ -579,6 +580,7 @@ void ocp_qp_gpu_ipm_memory_get(void *config, void *mem_, const char *field, void
 acados_size_t ocp_qp_gpu_ipm_workspace_calculate_size(void *config, void *dims, void *opts) { return 0; }
 
 static int g_cond_N_request = 0; /* set by the xcond level right before evaluate (single-threaded handoff) */
+static const int *g_cond_blocks_request = nullptr;
 
 int ocp_qp_gpu_ipm_evaluate_batch(void *config, int n, void **qp_in_, void **qp_out_, void *opts_, void **mem_,
                                   void *work, int *status)
@@ -611,6 +613,7 @@ int ocp_qp_gpu_ipm_evaluate_batch(void *config, int n, void **qp_in_, void **qp_
             exit(1);
         }
         bc->n = n;
+        bc->blocks_sent = false;
         bc->sig = sig;
         bc->seg_in.clear();
         bc->seg_out.clear();
@@ -639,6 +642,11 @@ int ocp_qp_gpu_ipm_evaluate_batch(void *config, int n, void **qp_in_, void **qp_
     {
         int cn = g_cond_N_request > 0 ? g_cond_N_request : N;
         ocp_qp_gpu_batch_opts_set(b, "cond_N", &cn);
+        if (g_cond_blocks_request && cn > 0 && cn < N && !bc->blocks_sent)
+        {
+            if (ocp_qp_gpu_batch_opts_set(b, "cond_block_size", g_cond_blocks_request) != 0) exit(1); /* :352-356 */
+            bc->blocks_sent = true;
+        }
     }
 
     /* re-read every member array of qp_in on every call (they alias ocp_nlp memory:
@@ -1001,6 +1009,7 @@ struct xcond_solver_opts
     int cond_ric_alg;
     bool initialize_next_xcond_qp_from_qp_out;
     bool warned;
+    int *cond_block_size; /* cond_N + 1 entries or NULL (ocp_qp_partial_condensing.c:305-313) */
 };
 
 struct ocp_qp_solver_
@@ -1068,7 +1077,13 @@ void ocp_qp_xcond_solver_opts_set(ocp_qp_xcond_solver_config *config, void *opts
         const char *f = field + 5;
         if (!strcmp(f, "N")) o->cond_N = *(int *) value;
         else if (!strcmp(f, "ric_alg")) o->cond_ric_alg = *(int *) value;
-        else if (!strcmp(f, "block_size")) { /* taken together with cond_N */ }
+        else if (!strcmp(f, "block_size"))
+        {
+            /* N2 + 1 entries; N2 ("cond_N") has to be set before, as in the reference (:305-313) */
+            free(o->cond_block_size);
+            o->cond_block_size = (int *) malloc(sizeof(int) * (o->cond_N + 1));
+            for (int i = 0; i <= o->cond_N; i++) o->cond_block_size[i] = ((int *) value)[i];
+        }
         else
         {
             printf("\nerror: field %s not available in ocp_qp_partial_condensing_opts_set\n", f);
@@ -1086,6 +1101,7 @@ void ocp_qp_xcond_solver_opts_free(void *opts_)
     xcond_solver_opts *o = (xcond_solver_opts *) opts_;
     if (!o) return;
     free(o->qp_solver_opts);
+    free(o->cond_block_size);
     free(o);
 }
 
@@ -1117,6 +1133,7 @@ static void xcond_note(ocp_qp_solver *s)
     /* the condensing request travels with the call (ocp_qp_xcond_solve: condense -> solve -> expand,
      * ocp_qp_xcond_solver.c:529-587); the device batch decides whether the QP class is condensable */
     g_cond_N_request = s->opts->cond_N;
+    g_cond_blocks_request = s->opts->cond_block_size;
 }
 
 /* ocp_qp_interface.c:567-571 -> ocp_qp_xcond_solve (ocp_qp_xcond_solver.c:529-587) */
@@ -1176,6 +1193,174 @@ void ocp_qp_solver_get_stats(ocp_qp_solver *s, double *stat_out, const char *qp_
     qs->memory_get(qs, s->mem, "stat_m", &stat_m);
     if (!stat) return;
     for (int i = 0; i < stat_m * (iter + 1); i++) stat_out[i] = stat[i];
+}
+
+/* ---- condensing-only boundary (interfaces/acados_c/condensing_interface.c; the `condensing` / `expansion` slots of
+ *      ocp_qp_xcond_config, ocp_qp_common.h:84-107, filled by ocp_qp_partial_condensing.c:523-556, :664-689) ----
+ * A module owns a one-instance device batch; the condensed QP is handed out in a plain ocp_qp_in of the condensed
+ * dims ("xcond_dims"), the solution of it comes back in a plain ocp_qp_out. */
+struct ocp_qp_condensing_module_
+{
+    ocp_qp_dims *dims = nullptr, *xdims = nullptr;
+    int cond_N = 0;
+    std::vector<int> blocks;
+    ocp_qp_gpu_batch *batch = nullptr, *child = nullptr;
+    std::vector<int> sig;
+};
+
+struct cfield { const char *name; int fid; int dyn; };
+static const cfield k_cfields[] = {
+    {"A", F_A, 1}, {"B", F_B, 1}, {"b", F_b, 1}, {"Q", F_Q, 0}, {"S", F_S, 0}, {"R", F_R, 0}, {"q", F_q, 0}, {"r", F_r, 0},
+    {"C", F_C, 0}, {"D", F_D, 0}, {"lg", F_lg, 0}, {"ug", F_ug, 0}, {"lg_mask", F_lgm, 0}, {"ug_mask", F_ugm, 0},
+    {"Zl", F_Zl, 0}, {"Zu", F_Zu, 0}, {"zl", F_zl, 0}, {"zu", F_zu, 0}, {"lls", F_lls, 0}, {"lus", F_lus, 0},
+    {"lls_mask", F_llsm, 0}, {"lus_mask", F_lusm, 0}};
+
+static int clen(const ocp_qp_dims *d, const char *f, int k)
+{
+    const int n = vlen(d, f, k);
+    if (n >= 0) return n;
+    return (f[0] == 'l' || f[0] == 'u') && f[1] == 'g' ? d->ng[k] : d->ns[k]; /* lg ug (+ masks) | Zl Zu zl zu lls lus (+ masks) */
+}
+
+static ocp_qp_gpu_batch *condensing_batch(ocp_qp_condensing_module *m, const ocp_qp_dims *d, int *const *idxb,
+                                          int *const *idxs_rev, int *const *idxe)
+{
+    ocp_qp_gpu_batch *b = ocp_qp_gpu_batch_create(d->N, d->nx, d->nu, d->nbx, d->nbu, d->ng, d->ns, 1, -1);
+    if (!b) return nullptr;
+    for (int k = 0; k <= d->N; k++)
+    {
+        std::vector<int> ib(d->nb[k]), rev(d->nb[k] + d->ng[k], -1), ie(d->nbxe[k]);
+        for (int r = 0; r < d->nb[k]; r++) ib[r] = idxb ? idxb[k][r] : (r < d->nbu[k] ? r : d->nu[k] + r - d->nbu[k]);
+        if (idxs_rev) for (size_t r = 0; r < rev.size(); r++) rev[r] = idxs_rev[k][r];
+        for (int r = 0; r < d->nbxe[k]; r++) ie[r] = idxe ? idxe[k][r] : d->nbu[k] + r;
+        ocp_qp_gpu_batch_set_int(b, "idxb", k, ib.data(), (int) ib.size());
+        ocp_qp_gpu_batch_set_int(b, "idxs_rev", k, rev.data(), (int) rev.size());
+        ocp_qp_gpu_batch_set_int(b, "idxe", k, ie.data(), (int) ie.size());
+    }
+    ocp_qp_gpu_batch_opts_set(b, "cond_N", &m->cond_N);
+    if (!m->blocks.empty() && ocp_qp_gpu_batch_opts_set(b, "cond_block_size", m->blocks.data()) != 0)
+    {
+        printf("\nerror: partial condensing: sum of block_size should match N = %d\n", d->N);
+        exit(1); /* ocp_qp_partial_condensing.c:352-356 */
+    }
+    return b;
+}
+
+ocp_qp_condensing_module *ocp_qp_condensing_create(ocp_qp_dims *dims, int cond_N, const int *block_size)
+{
+    ocp_qp_condensing_module *m = new ocp_qp_condensing_module_();
+    m->dims = dims;
+    m->cond_N = cond_N;
+    if (block_size) m->blocks.assign(block_size, block_size + cond_N + 1);
+    /* the condensed dims depend on the per-stage counts only: a batch with the default index sets tells them */
+    ocp_qp_gpu_batch *probe = condensing_batch(m, dims, nullptr, nullptr, nullptr);
+    ocp_qp_gpu_batch *c = probe ? ocp_qp_gpu_batch_condense(probe) : nullptr;
+    if (!c)
+    {
+        printf("\nerror: ocp_qp_condensing_create: this QP class is not condensed to N2 = %d (no device, cond_N outside 1..N-1, "
+               "or beyond the limits of the condensing kernels)\n", cond_N);
+        if (probe) ocp_qp_gpu_batch_destroy(probe);
+        delete m;
+        return nullptr;
+    }
+    m->xdims = ocp_qp_dims_create(cond_N);
+    const char *names[] = {"nx", "nu", "nb", "nbx", "nbu", "ng", "ns", "nbxe"};
+    int *dst[] = {m->xdims->nx, m->xdims->nu, m->xdims->nb, m->xdims->nbx, m->xdims->nbu, m->xdims->ng, m->xdims->ns, m->xdims->nbxe};
+    for (int q = 0; q < 8; q++) ocp_qp_gpu_batch_get_dims(c, names[q], dst[q]);
+    ocp_qp_gpu_batch_destroy(probe);
+    return m;
+}
+
+void ocp_qp_condensing_free(ocp_qp_condensing_module *m)
+{
+    if (!m) return;
+    if (m->batch) ocp_qp_gpu_batch_destroy(m->batch);
+    ocp_qp_dims_free(m->xdims);
+    delete m;
+}
+
+ocp_qp_dims *ocp_qp_condensing_get_xcond_dims(ocp_qp_condensing_module *m) { return m->xdims; }
+
+/* bounds and their masks: the containers keep [bu; bx] in one array, the device batch takes them per kind */
+static void condensing_bounds(ocp_qp_gpu_batch *b, ocp_qp_in *q, int k, bool to_device)
+{
+    const ocp_qp_dims *d = q->dim;
+    const int nbu = d->nbu[k];
+    struct { const char *name; double *p; int n; } f[] = {
+        {"lbu", q->lb[k], nbu}, {"ubu", q->ub[k], nbu}, {"lbu_mask", q->lb_mask[k], nbu}, {"ubu_mask", q->ub_mask[k], nbu},
+        {"lbx", q->lb[k] + nbu, d->nbx[k]}, {"ubx", q->ub[k] + nbu, d->nbx[k]},
+        {"lbx_mask", q->lb_mask[k] + nbu, d->nbx[k]}, {"ubx_mask", q->ub_mask[k] + nbu, d->nbx[k]}};
+    for (auto &e : f)
+    {
+        if (e.n <= 0) continue;
+        if (to_device) ocp_qp_gpu_batch_set(b, e.name, k, e.p, 0);
+        else ocp_qp_gpu_batch_get(b, e.name, k, e.p, 0);
+    }
+}
+
+int ocp_qp_condense(ocp_qp_condensing_module *m, void *qp_in_, void *xcond_qp_in_)
+{
+    ocp_qp_in *in = (ocp_qp_in *) qp_in_, *xc = (ocp_qp_in *) xcond_qp_in_;
+    const ocp_qp_dims *d = in->dim;
+    std::vector<int> sig = structure_sig(in);
+    if (!m->batch || sig != m->sig)
+    {
+        if (m->batch) ocp_qp_gpu_batch_destroy(m->batch);
+        m->batch = condensing_batch(m, d, in->idxb, in->idxs_rev, in->idxe);
+        m->sig = sig;
+        if (!m->batch) return ACADOS_QP_FAILURE;
+    }
+    ocp_qp_gpu_batch *b = m->batch;
+    for (int k = 0; k <= d->N; k++)
+    {
+        for (const cfield &f : k_cfields)
+            if (!(f.dyn && k == d->N) && clen(d, f.name, k) > 0) ocp_qp_gpu_batch_set(b, f.name, k, in_field(in, f.fid, k), 0);
+        condensing_bounds(b, in, k, true);
+    }
+    ocp_qp_gpu_batch *c = ocp_qp_gpu_batch_condense(b);
+    m->child = c;
+    if (!c) return ACADOS_QP_FAILURE;
+    const ocp_qp_dims *xd = xc->dim;
+    for (int k = 0; k <= xd->N; k++)
+    {
+        for (const cfield &f : k_cfields)
+            if (!(f.dyn && k == xd->N) && clen(xd, f.name, k) > 0)
+                ocp_qp_gpu_batch_get(c, f.name, k, const_cast<double *>(in_field(xc, f.fid, k)), 0);
+        condensing_bounds(c, xc, k, false);
+        ocp_qp_gpu_batch_get_int(c, "idxb", k, xc->idxb[k]);
+        ocp_qp_gpu_batch_get_int(c, "idxs_rev", k, xc->idxs_rev[k]);
+        ocp_qp_gpu_batch_get_int(c, "idxe", k, xc->idxe[k]);
+    }
+    return ACADOS_SUCCESS;
+}
+
+/* ux = [u; x; sl; su], pi, lam, t of one container <-> the fields of a one-instance batch */
+static void condensing_solution(ocp_qp_gpu_batch *b, const ocp_qp_dims *d, ocp_qp_out *o, bool to_device)
+{
+    for (int k = 0; k <= d->N; k++)
+    {
+        const int nu = d->nu[k], nx = d->nx[k], ns = d->ns[k], nct = d->nb[k] + d->ng[k] + ns;
+        struct { const char *name; double *p; int n; } f[] = {
+            {"u", o->ux[k], nu}, {"x", o->ux[k] + nu, nx}, {"sl", o->ux[k] + nu + nx, ns}, {"su", o->ux[k] + nu + nx + ns, ns},
+            {"pi", k < d->N ? o->pi[k] : nullptr, k < d->N ? d->nx[k + 1] : 0}, {"lam", o->lam[k], nct}, {"t", o->t[k], nct}};
+        for (auto &e : f)
+        {
+            if (e.n <= 0) continue;
+            if (to_device) ocp_qp_gpu_batch_set(b, e.name, k, e.p, 0);
+            else ocp_qp_gpu_batch_get(b, e.name, k, e.p, 0);
+        }
+    }
+}
+
+int ocp_qp_expand(ocp_qp_condensing_module *m, void *xcond_qp_out_, void *qp_out_)
+{
+    ocp_qp_out *xo = (ocp_qp_out *) xcond_qp_out_, *out = (ocp_qp_out *) qp_out_;
+    if (!m->batch || !m->child) return ACADOS_QP_FAILURE;
+    condensing_solution(m->child, m->xdims, xo, true);
+    if (ocp_qp_gpu_batch_expand(m->batch) != 0) return ACADOS_QP_FAILURE;
+    condensing_solution(m->batch, m->dims, out, false);
+    if (out->misc) ((qp_info *) out->misc)->t_computed = 1;
+    return ACADOS_SUCCESS;
 }
 
 } /* extern "C" */

@@ -86,10 +86,83 @@ class OcpQpGpuBatch:
         """RTI feedback phase: vector part of the condensing + solve + expansion"""
         return self._L.ocp_qp_gpu_batch_condense_rhs_and_solve(self._h)
 
+    # -- condensing-only boundary (interfaces/acados_c/condensing_interface.h:73-75) ---------------------------
+    def condense(self):
+        """partial condensing (opts cond_N / cond_block_size) without the solve: returns the condensed QP as a batch
+        object owned by this one (None when the QP is not condensed)"""
+        h = self._L.ocp_qp_gpu_batch_condense(self._h)
+        if not h:
+            return None
+        c = object.__new__(OcpQpGpuBatch)
+        c._L, c._h, c._owner = self._L, C.c_void_p(h), self   # non-owning view; keeps the parent alive
+        one = np.zeros(1, dtype=np.int32)
+        self._L.ocp_qp_gpu_batch_get_dims(c._h, b"N", _ip(one))
+        c.N, c.n_batch = int(one[0]), self.n_batch
+        from .ocp_qp import AcadosOcpQpDims
+        c.dims = AcadosOcpQpDims(c.N)
+        for f in ("nx", "nu", "nbx", "nbu", "nb", "ng", "ns", "nbxe"):
+            v = np.zeros(c.N + 1, dtype=np.int32)
+            self._L.ocp_qp_gpu_batch_get_dims(c._h, f.encode(), _ip(v))
+            getattr(c.dims, f)[:] = v
+        c._nbxe = np.array(c.dims.nbxe, dtype=int)
+        return c
+
+    def expand(self):
+        """the condensed batch's current solution mapped back to the stages of this batch"""
+        if self._L.ocp_qp_gpu_batch_expand(self._h) != 0:
+            raise RuntimeError("ocp_qp_gpu_batch_expand: nothing condensed")
+
+    def get_int(self, field, stage):
+        d = self.dims
+        out = np.zeros(int(d.nbx[stage] + d.nbu[stage] + d.ng[stage]) + 1, dtype=np.int32)
+        n = self._L.ocp_qp_gpu_batch_get_int(self._h, field.encode(), int(stage), _ip(out))
+        if n < 0:
+            raise ValueError(field)
+        return out[:n].astype(int)
+
+    def to_qp(self, i):
+        """instance i of the batch as an AcadosOcpQp (data read back from the device)"""
+        from .ocp_qp import AcadosOcpQp
+        qp = AcadosOcpQp(self.N)
+        d = self.dims
+        for k in range(self.N + 1):
+            nx, nu = int(d.nx[k]), int(d.nu[k])
+            nb, ng, ns = int(d.nbx[k] + d.nbu[k]), int(d.ng[k]), int(d.ns[k])
+            if nb:
+                qp.set("idxb", k, self.get_int("idxb", k))
+            if ns:
+                qp.set("idxs_rev", k, self.get_int("idxs_rev", k))
+            if int(self._nbxe[k]):
+                qp.set("idxe", k, self.get_int("idxe", k))
+            for f in DATA_FIELDS:
+                if k == self.N and f in DYN_FIELDS:
+                    continue
+                v = self.get(f, k)[i]
+                if f in ("A", "B", "Q", "R", "S", "C", "D"):
+                    rows = {"A": int(d.nx[min(k + 1, self.N)]), "B": int(d.nx[min(k + 1, self.N)]), "Q": nx, "R": nu, "S": nu,
+                            "C": ng, "D": ng}[f]
+                    v = v.reshape(-1, rows).T if rows else v.reshape(0, 0)
+                    if v.size == 0:
+                        continue
+                elif v.size == 0:
+                    continue
+                qp.set(f, k, v)
+        qp.make_consistent()
+        return qp
+
     def _len(self, field, k):
         d = self.dims
         if field.startswith("sens_"):
             field = field[5:]
+        nx, nu, ng, ns = int(d.nx[k]), int(d.nu[k]), int(d.ng[k]), int(d.ns[k])
+        nx1 = int(d.nx[k + 1]) if k < self.N else 0
+        data_len = {"A": nx1 * nx, "B": nx1 * nu, "b": nx1, "Q": nx * nx, "R": nu * nu, "S": nu * nx, "q": nx, "r": nu,
+                    "lbx": int(d.nbx[k]), "ubx": int(d.nbx[k]), "lbu": int(d.nbu[k]), "ubu": int(d.nbu[k]),
+                    "lbx_mask": int(d.nbx[k]), "ubx_mask": int(d.nbx[k]), "lbu_mask": int(d.nbu[k]), "ubu_mask": int(d.nbu[k]),
+                    "C": ng * nx, "D": ng * nu, "lg": ng, "ug": ng, "lg_mask": ng, "ug_mask": ng,
+                    "Zl": ns, "Zu": ns, "zl": ns, "zu": ns, "lls": ns, "lus": ns, "lls_mask": ns, "lus_mask": ns}
+        if field in data_len:
+            return data_len[field]
         if field == "x":
             return int(d.nx[k])
         if field == "u":
@@ -178,7 +251,8 @@ class OcpQpGpuBatch:
 
     def close(self):
         if getattr(self, "_h", None):
-            self._L.ocp_qp_gpu_batch_destroy(self._h)
+            if getattr(self, "_owner", None) is None:   # a condensed view belongs to its parent
+                self._L.ocp_qp_gpu_batch_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -1,0 +1,164 @@
+"""Condensing-only boundary: Python mirror of the reference's `condensing_module`
+(interfaces/acados_c/condensing_interface.h:61-75 -- ocp_qp_condensing_create, ocp_qp_condense, ocp_qp_expand) over the
+C-ABI of include/acados_amd/ocp_qp_interface.h.  Partial condensing N -> N2 runs on the device
+(acados_amd/csrc/pcond_kernels.hpp); this class moves one QP in and the condensed QP / the expanded solution out.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .ocp_qp import AcadosOcpQp
+
+_DP = C.POINTER(C.c_double)
+_IP = C.POINTER(C.c_int)
+
+
+class _Dims(C.Structure):
+    _fields_ = [("N", C.c_int)] + [(n, _IP) for n in ("nx", "nu", "nb", "nbx", "nbu", "ng", "ns", "nbxe", "nbue", "nge")]
+
+
+class _In(C.Structure):
+    _fields_ = ([("dim", C.POINTER(_Dims))] + [(n, C.POINTER(_DP)) for n in ("A", "B", "b", "Q", "S", "R", "q", "r")]
+                + [("idxb", C.POINTER(_IP))]
+                + [(n, C.POINTER(_DP)) for n in ("lb", "ub", "lb_mask", "ub_mask", "C", "D", "lg", "ug", "lg_mask", "ug_mask",
+                                                   "Zl", "Zu", "zl", "zu", "lls", "lus", "lls_mask", "lus_mask")]
+                + [("idxs_rev", C.POINTER(_IP)), ("idxe", C.POINTER(_IP))])
+
+
+class _Out(C.Structure):
+    _fields_ = [("dim", C.POINTER(_Dims))] + [(n, C.POINTER(_DP)) for n in ("ux", "pi", "lam", "t")] + [("misc", C.c_void_p)]
+
+
+def _bind(L):
+    vp, ci, cp = C.c_void_p, C.c_int, C.c_char_p
+    sigs = {
+        "ocp_qp_dims_create": (vp, [ci]), "ocp_qp_dims_free": (None, [vp]),
+        "ocp_qp_dims_set": (None, [vp, vp, ci, cp, _IP]),
+        "ocp_qp_in_create": (vp, [vp]), "ocp_qp_in_free": (None, [vp]), "ocp_qp_in_set": (None, [vp, vp, ci, cp, vp]),
+        "ocp_qp_out_create": (vp, [vp]), "ocp_qp_out_free": (None, [vp]), "ocp_qp_out_get": (None, [vp, ci, cp, vp]),
+        "ocp_qp_condensing_create": (vp, [vp, ci, _IP]), "ocp_qp_condensing_free": (None, [vp]),
+        "ocp_qp_condensing_get_xcond_dims": (vp, [vp]),
+        "ocp_qp_condense": (ci, [vp, vp, vp]), "ocp_qp_expand": (ci, [vp, vp, vp]),
+    }
+    for name, (res, args) in sigs.items():
+        fn = getattr(L, name)
+        fn.restype, fn.argtypes = res, args
+    return L
+
+
+_DATA = ("A", "B", "b", "Q", "S", "R", "q", "r", "lbx", "ubx", "lbu", "ubu", "C", "D", "lg", "ug", "Zl", "Zu", "zl", "zu",
+         "lls", "lus", "lbx_mask", "ubx_mask", "lbu_mask", "ubu_mask", "lg_mask", "ug_mask", "lls_mask", "lus_mask")
+
+
+class AcadosOcpQpCondensing:
+    def __init__(self, qp: AcadosOcpQp, cond_N: int, block_size=None, _clib=None):
+        self._L = _bind(_clib if _clib is not None else _lib.lib())
+        self.qp, self.N, self.cond_N = qp, qp.N, int(cond_N)
+        L, d = self._L, qp.dims
+        self.c_dims = L.ocp_qp_dims_create(qp.N)
+        for k in range(qp.N + 1):
+            for name in ("nx", "nu", "nbx", "nbu", "ng", "ns", "nbxe"):
+                v = C.c_int(int(getattr(d, name)[k]))
+                L.ocp_qp_dims_set(None, self.c_dims, k, name.encode(), C.byref(v))
+        bs = None
+        if block_size is not None:
+            self._bs = np.ascontiguousarray(block_size, dtype=np.intc)
+            assert self._bs.size == self.cond_N + 1
+            bs = self._bs.ctypes.data_as(_IP)
+        self.c_module = L.ocp_qp_condensing_create(self.c_dims, self.cond_N, bs)
+        if not self.c_module:
+            raise RuntimeError("ocp_qp_condensing_create failed")
+        self.c_xdims = L.ocp_qp_condensing_get_xcond_dims(self.c_module)
+        self.c_in, self.c_out = L.ocp_qp_in_create(self.c_dims), L.ocp_qp_out_create(self.c_dims)
+        self.c_xin, self.c_xout = L.ocp_qp_in_create(self.c_xdims), L.ocp_qp_out_create(self.c_xdims)
+        self.set_qp(qp)
+
+    def set_qp(self, qp):
+        for k in range(qp.N + 1):
+            for name in ("idxb", "idxs_rev", "idxe") + _DATA:
+                if k == qp.N and name in qp.dynamics_fields:
+                    continue
+                v = getattr(qp, name)[k]
+                a = np.ascontiguousarray(np.ravel(np.asarray(v).astype(np.int32 if name.startswith("idx") else float), order="F"))
+                if a.size:
+                    self._L.ocp_qp_in_set(None, self.c_in, k, name.encode(), a.ctypes.data_as(C.c_void_p))
+
+    def xcond_dims(self):
+        xd = C.cast(self.c_xdims, C.POINTER(_Dims)).contents
+        return {n: np.array([getattr(xd, n)[k] for k in range(xd.N + 1)]) for n in ("nx", "nu", "nb", "nbx", "nbu", "ng", "ns", "nbxe")}
+
+    def condense(self) -> AcadosOcpQp:
+        """ocp_qp_condense: the condensed QP as an AcadosOcpQp"""
+        if self._L.ocp_qp_condense(self.c_module, self.c_in, self.c_xin) != 0:
+            raise RuntimeError("ocp_qp_condense failed")
+        x = C.cast(self.c_xin, C.POINTER(_In)).contents
+        d = self.xcond_dims()
+        N2 = self.cond_N
+        qc = AcadosOcpQp(N2)
+        arr = lambda p, n: np.array([p[i] for i in range(n)], dtype=float)
+        for k in range(N2 + 1):
+            nx, nu, nb, nbu, ng, ns = (int(d[n][k]) for n in ("nx", "nu", "nb", "nbu", "ng", "ns"))
+            nx1 = int(d["nx"][k + 1]) if k < N2 else 0
+            mat = lambda p, r, c: arr(p, r * c).reshape(c, r).T
+            if k < N2:
+                qc.set("A", k, mat(x.A[k], nx1, nx)); qc.set("B", k, mat(x.B[k], nx1, nu)); qc.set("b", k, arr(x.b[k], nx1))
+            qc.set("Q", k, mat(x.Q[k], nx, nx)); qc.set("R", k, mat(x.R[k], nu, nu)); qc.set("S", k, mat(x.S[k], nu, nx))
+            qc.set("q", k, arr(x.q[k], nx)); qc.set("r", k, arr(x.r[k], nu))
+            if nb:
+                qc.set("idxb", k, np.array([x.idxb[k][i] for i in range(nb)], dtype=int))
+            for name, src, lo, n in (("lbu", x.lb, 0, nbu), ("ubu", x.ub, 0, nbu), ("lbx", x.lb, nbu, nb - nbu), ("ubx", x.ub, nbu, nb - nbu),
+                                     ("lbu_mask", x.lb_mask, 0, nbu), ("ubu_mask", x.ub_mask, 0, nbu),
+                                     ("lbx_mask", x.lb_mask, nbu, nb - nbu), ("ubx_mask", x.ub_mask, nbu, nb - nbu)):
+                qc.set(name, k, np.array([src[k][lo + i] for i in range(n)], dtype=float))
+            if ng:
+                qc.set("C", k, mat(x.C[k], ng, nx)); qc.set("D", k, mat(x.D[k], ng, nu))
+                for name in ("lg", "ug", "lg_mask", "ug_mask"):
+                    qc.set(name, k, arr(getattr(x, name)[k], ng))
+            if ns:
+                qc.set("idxs_rev", k, np.array([x.idxs_rev[k][i] for i in range(nb + ng)], dtype=int))
+                for name in ("Zl", "Zu", "zl", "zu", "lls", "lus", "lls_mask", "lus_mask"):
+                    qc.set(name, k, arr(getattr(x, name)[k], ns))
+            if int(d["nbxe"][k]):
+                qc.set("idxe", k, np.array([x.idxe[k][i] for i in range(int(d["nbxe"][k]))], dtype=int))
+        qc.make_consistent()
+        return qc
+
+    def expand(self, get_condensed):
+        """ocp_qp_expand: get_condensed(stage, field) returns x, u, sl, su, pi, lam, t of the condensed QP's solution;
+        returns a function (stage, field) -> array for the original QP"""
+        xo = C.cast(self.c_xout, C.POINTER(_Out)).contents
+        d = self.xcond_dims()
+        for k in range(self.cond_N + 1):
+            nu, nx, ns = int(d["nu"][k]), int(d["nx"][k]), int(d["ns"][k])
+            ux = np.concatenate([np.asarray(get_condensed(k, f), dtype=float).reshape(-1) for f in ("u", "x", "sl", "su")])
+            assert ux.size == nu + nx + 2 * ns
+            for i, v in enumerate(ux):
+                xo.ux[k][i] = v
+            for f, dst in (("lam", xo.lam), ("t", xo.t)) + ((("pi", xo.pi),) if k < self.cond_N else ()):
+                for i, v in enumerate(np.asarray(get_condensed(k, f), dtype=float).reshape(-1)):
+                    dst[k][i] = v
+        if self._L.ocp_qp_expand(self.c_module, self.c_xout, self.c_out) != 0:
+            raise RuntimeError("ocp_qp_expand failed")
+        q = self.qp.dims
+
+        def get(k, f):
+            n = {"x": q.nx[k], "u": q.nu[k], "sl": q.ns[k], "su": q.ns[k], "pi": q.nx[k + 1] if k < self.N else 0,
+                 "lam": 2 * (q.nbx[k] + q.nbu[k] + q.ng[k] + q.ns[k]), "t": 2 * (q.nbx[k] + q.nbu[k] + q.ng[k] + q.ns[k])}[f]
+            out = np.zeros(int(n))
+            if out.size:
+                self._L.ocp_qp_out_get(self.c_out, int(k), f.encode(), out.ctypes.data_as(C.c_void_p))
+            return out
+        return get
+
+    def __del__(self):
+        try:
+            L = self._L
+            L.ocp_qp_condensing_free(self.c_module)
+            for p in (self.c_in, self.c_xin):
+                L.ocp_qp_in_free(p)
+            for p in (self.c_out, self.c_xout):
+                L.ocp_qp_out_free(p)
+            L.ocp_qp_dims_free(self.c_dims)
+        except Exception:
+            pass

@@ -72,7 +72,7 @@ int ocp_qp_gpu_batch_get_bulk(ocp_qp_gpu_batch *b, double *blob, int is_device);
 
 /* Options by name, as ocp_qp_xcond_solver_opts_set forwards them: iter_max
  * tol_stat tol_eq tol_ineq tol_comp warm_start mu0 alpha_min tau_min reg_prim
- * cond_pred_corr print_level t0_init hpipm_mode ric_alg cond_N (partial condensing to N2 blocks) profile.  int* or double* or char* as in
+ * cond_pred_corr print_level t0_init hpipm_mode ric_alg cond_N (partial condensing to N2 blocks) cond_block_size (int[N2+1], after cond_N; ocp_qp_partial_condensing.c:305-313) profile.  int* or double* or char* as in
  * acados.  Unknown field: message + return -1. */
 int ocp_qp_gpu_batch_opts_set(ocp_qp_gpu_batch *b, const char *field, const void *value);
 
@@ -86,6 +86,21 @@ int ocp_qp_gpu_batch_solve(ocp_qp_gpu_batch *b);
  * The matrix-dependent condensed blocks stay resident in HBM between the two calls. */
 int ocp_qp_gpu_batch_condense_lhs(ocp_qp_gpu_batch *b);
 int ocp_qp_gpu_batch_condense_rhs_and_solve(ocp_qp_gpu_batch *b);
+/* Condensing-only boundary: ocp_qp_condense / ocp_qp_expand of interfaces/acados_c/condensing_interface.h:73-75
+ * (the `condensing(qp_in, xcond_qp_in, ...)` / `expansion(...)` slots of ocp_qp_xcond_config,
+ * acados/ocp_qp/ocp_qp_common.h:84-107).  _condense runs partial condensing (opts cond_N, cond_block_size) and
+ * returns the condensed QP as a batch object OWNED BY `b` (do not destroy it; NULL when the QP is not condensed --
+ * cond_N == N or beyond the limits of INTEGRATION.md): its data are readable with ocp_qp_gpu_batch_get / _get_dims /
+ * _get_int (what memory_get "xcond_qp_in" / dims_get "xcond_dims" answer in the reference,
+ * ocp_qp_partial_condensing.c:138-155, :467-504), it can be solved with ocp_qp_gpu_batch_solve or receive a
+ * solution computed elsewhere (set "x" "u" "pi" "lam" "t" "sl" "su").  _expand maps the condensed batch's current
+ * solution back to the stages of `b` (x, u, sl, su, pi, lam, t). */
+ocp_qp_gpu_batch *ocp_qp_gpu_batch_condense(ocp_qp_gpu_batch *b);
+int ocp_qp_gpu_batch_expand(ocp_qp_gpu_batch *b);
+/* "N" "n_batch" (one int) or "nx" "nu" "nbx" "nbu" "nb" "ng" "ns" "nbxe" (N+1 ints) */
+int ocp_qp_gpu_batch_get_dims(ocp_qp_gpu_batch *b, const char *field, int *out);
+/* "idxb" (nb) "idxs_rev" (nb+ng) "idxe": returns the number of entries written */
+int ocp_qp_gpu_batch_get_int(ocp_qp_gpu_batch *b, const char *field, int stage, int *out);
 
 /* Results, same blocked convention as _set: x u sl su pi lam t per stage; and the Riccati factor of
  * the last factorisation: ric_L ((nu+nx)^2, column-major lower Cholesky factor [Lr 0; Ls Lx] of the

@@ -196,6 +196,21 @@ void ocp_qp_solver_get_stats(ocp_qp_solver *solver, double *stat, const char *qp
  * vtable, ocp_nlp_common.c:4091, 4141): d(solution)/d(parameter) of the QP solved last, into sens_out (ux, pi, lam, t) */
 void ocp_qp_solver_eval_forw_sens(ocp_qp_solver *solver, ocp_qp_in *qp_in, ocp_qp_seed *seed, ocp_qp_out *sens_out);
 void ocp_qp_solver_eval_adj_sens(ocp_qp_solver *solver, ocp_qp_in *qp_in, ocp_qp_seed *seed, ocp_qp_out *sens_out);
+/* ---- condensing-only boundary: interfaces/acados_c/condensing_interface.h:61-75 (ocp_qp_condensing_create,
+ *      ocp_qp_condense, ocp_qp_expand) over the `condensing` / `expansion` slots of ocp_qp_xcond_config
+ *      (acados/ocp_qp/ocp_qp_common.h:84-107; partial condensing: ocp_qp_partial_condensing.c:523-556, :664-689).
+ * cond_N = N2; block_size: N2 + 1 entries summing to N with a trailing 0, or NULL for the default split
+ * (d_part_cond_qp_compute_block_size: N / N2 each, remainder to the first blocks).  _get_xcond_dims is what
+ * dims_get("xcond_dims") answers in the reference: create the condensed ocp_qp_in / ocp_qp_out from it.
+ * ocp_qp_condense writes the condensed QP (data, index sets, masks) into xcond_qp_in; ocp_qp_expand takes a solution
+ * of the condensed QP (ux, pi, lam, t) and writes the solution of the original one.  Both return ACADOS_SUCCESS (0) or
+ * ACADOS_QP_FAILURE. */
+typedef struct ocp_qp_condensing_module_ ocp_qp_condensing_module;
+ocp_qp_condensing_module *ocp_qp_condensing_create(ocp_qp_dims *dims, int cond_N, const int *block_size);
+void ocp_qp_condensing_free(ocp_qp_condensing_module *module);
+ocp_qp_dims *ocp_qp_condensing_get_xcond_dims(ocp_qp_condensing_module *module);
+int ocp_qp_condense(ocp_qp_condensing_module *module, void *qp_in, void *xcond_qp_in);
+int ocp_qp_expand(ocp_qp_condensing_module *module, void *xcond_qp_out, void *qp_out);
 /* Riccati quantities of the last factorisation through the solver_get slot: field in P p K k Lr
  * (ocp_qp_hpipm.c:417-478); column-major; u = K x + k */
 void ocp_qp_solver_get_ric(ocp_qp_solver *solver, ocp_qp_in *qp_in, ocp_qp_out *qp_out, const char *field, int stage,

@@ -751,3 +751,107 @@ def test_random_structures_partial_condensing_hostsim(hostsim_lib):
         assert b.solve() == 0 and int(b.info("iter").max()) == 0, seed
         assert max(b.info(n).max() for n in ("res_stat", "res_eq", "res_ineq", "res_comp")) <= 1e-8
     assert condensed >= 30
+
+
+def test_condensing_only_boundary_hostsim(hostsim_lib):
+    """the condensing-only boundary (ocp_qp_condense / ocp_qp_expand, condensing_interface.h:73-75): the condensed QP
+    is read back from the device as a QP of its own, solved by the CPU ORACLE (an independent solver: this pins the
+    condensed data -- Hbar, gbar, [Bbar Abar], bbar, the general rows made of inner state bounds, shifted bounds,
+    slacks, masks -- not just the round trip), its solution is written into the condensed batch and expanded; the
+    result must be the full-space oracle solution.  Random structures + user block sizes (cond_block_size)."""
+    from acados_amd import OcpQpGpuBatch
+    from acados_amd.generators import lqr_instance_qp, mass_spring_qp, random_lqr_batch
+    from random_qp import random_structure_qp
+
+    def roundtrip(qp, cond_N, blocks=None, tol=1e-4):
+        o = OracleQp(qp)
+        assert o.solve(default_opts(tol_stat=1e-8, iter_max=60)) == 0
+        b = OcpQpGpuBatch.from_qps([qp] * 2, _clib=hostsim_lib)
+        b.opts_set("cond_N", cond_N)
+        if blocks is not None:
+            arr = (ctypes.c_int * len(blocks))(*blocks)
+            assert b._L.ocp_qp_gpu_batch_opts_set(b._h, b"cond_block_size", arr) == 0
+        c = b.condense()
+        assert c is not None and c.N == cond_N
+        qc = c.to_qp(1)
+        if blocks is not None:
+            assert list(qc.dims.nu[:cond_N]) == [bs * int(qp.dims.nu[0]) for bs in blocks[:cond_N]]
+        oc = OracleQp(qc)
+        assert oc.solve(default_opts(tol_stat=1e-8, iter_max=60)) == 0
+        for k in range(c.N + 1):
+            for f in ("x", "u", "sl", "su", "lam", "t") + (("pi",) if k < c.N else ()):
+                v = oc.get(k, f)
+                if v.size:
+                    c.set(f, k, np.tile(v, (2, 1)))
+        b.expand()
+        compare_with_oracle(lambda k, f: b.get(f, k)[1], o, qp, tol, fields=("x", "u", "sl", "su", "pi", "lam", "t"))
+        # ... and the expanded point satisfies the original KKT conditions at tolerance
+        for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+            b.opts_set(f, 1e-8)
+        b.opts_set("cond_N", qp.N)
+        b.opts_set("warm_start", 2)
+        assert b.solve() == 0 and int(b.info("iter").max()) == 0
+
+    import ctypes
+    data = random_lqr_batch(N=10, batch=1, seed=5)
+    roundtrip(lqr_instance_qp(data, 0, 10), 3, blocks=[2, 5, 3, 0])
+    roundtrip(mass_spring_qp(N=15), 5)
+    n = 0
+    for seed in range(24):
+        qp = random_structure_qp(seed)
+        if qp.N >= 2:
+            roundtrip(qp, (qp.N + 1) // 2)
+            n += 1
+    assert n >= 18
+    # block sizes that do not sum to N are refused (the reference exits, ocp_qp_partial_condensing.c:346-356)
+    b = OcpQpGpuBatch.from_qps([mass_spring_qp(N=15)], _clib=hostsim_lib)
+    b.opts_set("cond_N", 3)
+    assert b._L.ocp_qp_gpu_batch_opts_set(b._h, b"cond_block_size", (ctypes.c_int * 4)(5, 5, 4, 0)) != 0
+
+
+def test_condensing_module_acados_api_hostsim(hostsim_lib):
+    """the condensing module on the acados-shaped containers (ocp_qp_condensing_create / ocp_qp_condense /
+    ocp_qp_expand, condensing_interface.h:61-75): xcond dims, the condensed QP in a plain ocp_qp_in solved by the CPU
+    oracle, its solution expanded through a plain ocp_qp_out == the full-space oracle solution; user block sizes"""
+    from acados_amd import AcadosOcpQpCondensing
+    from acados_amd.generators import mass_spring_qp
+    from random_qp import random_structure_qp
+    cases = [(mass_spring_qp(N=15), 5, None), (mass_spring_qp(N=15), 4, [3, 4, 4, 4, 0]),
+             (load_qp("casadi_qp_tests/pend_idxs_rev_min_qp0.json"), 3, None), (load_qp("qp_test/last_qp_one_sided_test.json"), 4, None)]
+    cases += [(random_structure_qp(s), None, None) for s in (0, 4, 7, 13, 22)]
+    for qp, cn, blocks in cases:
+        cn = (qp.N + 1) // 2 if cn is None else cn
+        o = OracleQp(qp)
+        assert o.solve(default_opts(tol_stat=1e-8, iter_max=60)) == 0
+        mod = AcadosOcpQpCondensing(qp, cn, block_size=blocks, _clib=hostsim_lib)
+        xd = mod.xcond_dims()
+        if blocks is not None:
+            assert list(xd["nu"][:cn]) == [bs * int(qp.dims.nu[0]) for bs in blocks[:cn]]
+        qc = mod.condense()
+        assert qc.N == cn and list(qc.dims.nx) == list(xd["nx"])
+        oc = OracleQp(qc)
+        assert oc.solve(default_opts(tol_stat=1e-8, iter_max=60)) == 0
+        get = mod.expand(lambda k, f: oc.get(k, f))
+        compare_with_oracle(get, o, qp, 1e-4, fields=("x", "u", "sl", "su", "pi", "lam", "t"))
+        # objective values agree: the condensed QP is the same problem (up to the constant the elimination drops,
+        # which both solutions share) -- compare the primal solutions' cost in the ORIGINAL QP instead
+        x = np.concatenate([get(k, "x") for k in range(qp.N + 1)]); xr = np.concatenate([o.get(k, "x") for k in range(qp.N + 1)])
+        assert np.max(np.abs(x - xr)) <= 1e-4 * max(1.0, np.max(np.abs(xr)))
+
+
+def test_cond_block_size_option_acados_api_hostsim(hostsim_lib, capfd):
+    """`cond_block_size` through the xcond-solver options (ocp_qp_partial_condensing.c:305-313; the Python driver
+    sends it like acados_ocp_qp_solver.py does): user blocks reach the device condensing, same solution"""
+    from acados_amd import AcadosOcpQpOptions, AcadosOcpQpSolver
+    from acados_amd.generators import mass_spring_qp
+    qp = mass_spring_qp(N=15)
+    o = OracleQp(qp)
+    assert o.solve(default_opts(tol_stat=1e-8)) == 0
+    opts = AcadosOcpQpOptions()
+    opts.tol_stat = opts.tol_eq = opts.tol_ineq = opts.tol_comp = 1e-8
+    opts.cond_N = 4
+    opts.cond_block_size = [3, 4, 4, 4, 0]
+    s = AcadosOcpQpSolver(qp, opts, _clib=hostsim_lib)
+    assert s.solve() == 0
+    compare_with_oracle(lambda k, f: s.get(k, f, unique_duals=False), o, qp, 2e-7, fields=("x", "u", "pi", "lam", "t"))
+    assert "solving the full-space QP" not in capfd.readouterr().err
