@@ -539,3 +539,49 @@ def test_random_structures_gpu(gpu_lib, monkeypatch, wpi):
             b.opts_set("cond_N", qp.N)
             b.opts_set("warm_start", 2)
             assert b.solve() == 0 and int(b.info("iter").max()) == 0, seed
+
+
+@pytest.mark.gpu
+def test_condensing_only_boundary_gpu(gpu_lib):
+    """ocp_qp_condense / ocp_qp_expand on the device (condensing_interface.h:73-75): the condensed QP read back from
+    the GPU is solved by the CPU oracle, that solution is expanded on the GPU and must be the full-space oracle
+    solution -- the condensed DATA are pinned, not only the round trip.  Mass-spring with user block sizes, the golden
+    shared-slack fixture, random structures; through the batch API (70 copies) and the acados-shaped module."""
+    from acados_amd import AcadosOcpQpCondensing, OcpQpGpuBatch
+    from acados_amd.generators import mass_spring_qp
+    from random_qp import random_structure_qp
+    import ctypes
+    cases = [(mass_spring_qp(N=15), 4, [3, 4, 4, 4, 0]), (load_qp("casadi_qp_tests/pend_idxs_rev_min_qp0.json"), 3, None)]
+    cases += [(random_structure_qp(s), None, None) for s in (0, 4, 7, 13, 22, 26)]
+    for qp, cn, blocks in cases:
+        cn = (qp.N + 1) // 2 if cn is None else cn
+        o = OracleQp(qp)
+        assert o.solve(default_opts(tol_stat=1e-8, iter_max=60)) == 0
+        b = OcpQpGpuBatch.from_qps([qp] * 70)
+        b.opts_set("cond_N", cn)
+        if blocks is not None:
+            assert b._L.ocp_qp_gpu_batch_opts_set(b._h, b"cond_block_size", (ctypes.c_int * len(blocks))(*blocks)) == 0
+        c = b.condense()
+        assert c is not None and c.N == cn
+        qc = c.to_qp(69)
+        oc = OracleQp(qc)
+        assert oc.solve(default_opts(tol_stat=1e-8, iter_max=60)) == 0
+        for k in range(cn + 1):
+            for f in ("x", "u", "sl", "su", "lam", "t") + (("pi",) if k < cn else ()):
+                v = oc.get(k, f)
+                if v.size:
+                    c.set(f, k, np.tile(v, (70, 1)))
+        b.expand()
+        compare_with_oracle(lambda k, f: b.get(f, k)[69], o, qp, 1e-4, fields=("x", "u", "sl", "su", "pi", "lam", "t"))
+        for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+            b.opts_set(f, 1e-8)
+        b.opts_set("cond_N", qp.N)
+        b.opts_set("warm_start", 2)
+        assert b.solve() == 0 and int(b.info("iter").max()) == 0   # KKT of the ORIGINAL QP at the expanded point
+        mod = AcadosOcpQpCondensing(qp, cn, block_size=blocks)
+        qc2 = mod.condense()
+        for k in range(cn + 1):
+            for f in ("Q", "R", "S", "q", "r", "lbx", "ubx", "lg", "ug", "C", "D"):
+                assert np.allclose(np.asarray(getattr(qc2, f)[k]), np.asarray(getattr(qc, f)[k]), rtol=0, atol=1e-12), (f, k)
+        get = mod.expand(lambda k, f: oc.get(k, f))
+        compare_with_oracle(get, o, qp, 1e-4, fields=("x", "u", "sl", "su", "pi", "lam", "t"))
