@@ -536,6 +536,17 @@ const double *stage_in(ocp_qp_gpu_batch *b, const double *data, size_t cnt, int 
 
 } // namespace
 
+/* one array of a level <-> the same array of its sub-level (dir 0: gather the listed instances, 1: scatter back);
+ * levels of different layouts exchange through the LDS-transposing kernel */
+template <class T>
+static void copy_level(const GArrT<T> &big, const GArrT<T> &small, const int *d_list, int cnt, int dir, hipStream_t s)
+{
+    if (!(big.E > 0 && big.p && small.p) || cnt <= 0) return;
+    const dim3 grid((cnt + 63) / 64, (big.E + 63) / 64), block(64);
+    if (big.aos != small.aos) GQP_LAUNCH_COOP(gqp::k_compact_tile<T>, grid, block, 0, s, big, small, d_list, cnt, dir);
+    else hipLaunchKernelGGL(gqp::k_compact_copy<T>, grid, block, 0, s, big, small, d_list, cnt, dir);
+}
+
 extern "C" {
 
 static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu, const int *nbx, const int *nbu,
@@ -1234,14 +1245,10 @@ static void compact_into(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch *root, int nact, 
     c->B = cnt; /* the level works on `cnt` slots of its capacity */
     c->D.B = cnt;
     const dim3 block(64);
-#define GQP_COPY_IN(A)                                                                                     \
-    if (b->D.A.E > 0 && b->D.A.p && c->D.A.p)                                                              \
-        hipLaunchKernelGGL(gqp::k_compact_copy<double>, dim3((cnt + 63) / 64, (b->D.A.E + 63) / 64), block, 0, s, \
-                           b->D.A, c->D.A, b->d_list, cnt, 0);
+#define GQP_COPY_IN(A) copy_level(b->D.A, c->D.A, b->d_list, cnt, 0, s);
     GQP_FOR_STATE_ARRAYS(GQP_COPY_IN)
 #undef GQP_COPY_IN
-    hipLaunchKernelGGL(gqp::k_compact_copy<uint64_t>, dim3((cnt + 63) / 64, (b->D.amask.E + 63) / 64), block, 0, s,
-                       b->D.amask, c->D.amask, b->d_list, cnt, 0);
+    copy_level(b->D.amask, c->D.amask, b->d_list, cnt, 0, s);
     hipLaunchKernelGGL(gqp::k_compact_scalars, dim3((cnt + 63) / 64), block, 0, s, b->D, c->D, b->d_list, cnt, 0);
     *c->h_nact = cnt;
     HIPCHK(hipMemcpyAsync(c->D.n_active, c->h_nact, sizeof(int), hipMemcpyHostToDevice, s));
@@ -1256,12 +1263,10 @@ static void compact_back(ocp_qp_gpu_batch *b, hipStream_t s, ocp_qp_gpu_batch *c
 {
     const int cnt = c->B;
     if (b->D.stat && c->D.stat)
-        hipLaunchKernelGGL(gqp::k_stat_merge, dim3(1), dim3(64), 0, s, b->D, c->D, b->d_list, cnt < 64 ? cnt : 64, it0);
+        hipLaunchKernelGGL(gqp::k_stat_merge, dim3(1, std::max(1, std::min(b->stat_rows, c->stat_rows) - it0)), dim3(64), 0, s, b->D,
+                           c->D, b->d_list, cnt < 64 ? cnt : 64, it0);
     const dim3 block(64);
-#define GQP_COPY_OUT(A)                                                                                    \
-    if (b->D.A.E > 0 && b->D.A.p && c->D.A.p)                                                              \
-        hipLaunchKernelGGL(gqp::k_compact_copy<double>, dim3((cnt + 63) / 64, (b->D.A.E + 63) / 64), block, 0, s, \
-                           b->D.A, c->D.A, b->d_list, cnt, 1);
+#define GQP_COPY_OUT(A) copy_level(b->D.A, c->D.A, b->d_list, cnt, 1, s);
     GQP_FOR_RESULT_ARRAYS(GQP_COPY_OUT)
 #undef GQP_COPY_OUT
     hipLaunchKernelGGL(gqp::k_compact_scalars, dim3((cnt + 63) / 64), block, 0, s, b->D, c->D, b->d_list, cnt, 1);
@@ -1486,14 +1491,10 @@ static void sens_solve_sliced(ocp_qp_gpu_batch *b)
         HIPCHK(hipMemcpyAsync(b->d_slist, list.data(), sizeof(int) * cnt, hipMemcpyHostToDevice, s));
         c->B = cnt;
         c->D.B = cnt;
-#define GQP_SLICE_COPY(SRC, DST, DIR)                                                                         \
-    if ((SRC).E > 0 && (SRC).p && (DST).p)                                                                    \
-        hipLaunchKernelGGL(gqp::k_compact_copy<double>, dim3((cnt + 63) / 64, ((SRC).E + 63) / 64), block, 0, s, SRC, DST, \
-                           b->d_slist, cnt, DIR);
+#define GQP_SLICE_COPY(SRC, DST, DIR) copy_level(SRC, DST, b->d_slist, cnt, DIR, s);
 #define GQP_COPY_IN(A) GQP_SLICE_COPY(b->D.A, c->D.A, 0)
         GQP_FOR_STATE_ARRAYS(GQP_COPY_IN)
-        hipLaunchKernelGGL(gqp::k_compact_copy<uint64_t>, dim3((cnt + 63) / 64, (b->D.amask.E + 63) / 64), block, 0, s,
-                           b->D.amask, c->D.amask, b->d_slist, cnt, 0);
+        copy_level(b->D.amask, c->D.amask, b->d_slist, cnt, 0, s);
         hipLaunchKernelGGL(gqp::k_compact_scalars, dim3((cnt + 63) / 64), block, 0, s, b->D, c->D, b->d_slist, cnt, 0);
         HIPCHK(hipStreamSynchronize(s)); /* the sub-batch works on its own stream */
         refactor_at_solution(c);         /* writes the residual arrays: the seeds go in afterwards */

@@ -1187,6 +1187,46 @@ static __global__ void k_compact_copy(GArrT<T> big, GArrT<T> small, const int *l
     else for (int e = e0; e < e1; e++) pb[(size_t) e * sb] = ps[(size_t) e * ss];
 }
 
+/* the same copy between a wave-tiled and an instance-major level (tail switch, sensitivity slices): a 64 x 64
+ * (slots x elements) tile goes through LDS so that BOTH sides see coalesced accesses -- lanes walk instances on the
+ * wave-tiled side and elements on the instance-major side.  One wave per block; grid (slots/64, elements/64). */
+template <class T>
+static __global__ void __launch_bounds__(64) k_compact_tile(GArrT<T> big, GArrT<T> small, const int *list, int cnt, int dir)
+{
+    __shared__ T tile[64 * 65];
+    const int lane = threadIdx.x, s0 = blockIdx.x * 64, e0 = blockIdx.y * 64;
+    const int ns = cnt - s0 < 64 ? cnt - s0 : 64, ne = big.E - e0 < 64 ? big.E - e0 : 64;
+    const GArrT<T> &X = dir == 0 ? big : small, &Y = dir == 0 ? small : big;
+    const bool x_big = dir == 0;
+    /* source -> tile[e][s] */
+    if (X.aos)
+        for (int s = 0; s < ns; s++)
+        {
+            const int inst = x_big ? list[s0 + s] : s0 + s;
+            if (lane < ne) tile[lane * 65 + s] = X.p[(size_t) inst * X.E + e0 + lane];
+        }
+    else if (lane < ns)
+    {
+        const int inst = x_big ? list[s0 + lane] : s0 + lane;
+        const T *px = X.p + ((size_t) (inst >> 6) * (size_t) X.E + e0) * 64 + (inst & 63);
+        for (int e = 0; e < ne; e++) tile[e * 65 + lane] = px[(size_t) e * 64];
+    }
+    __syncthreads();
+    /* tile -> destination */
+    if (Y.aos)
+        for (int s = 0; s < ns; s++)
+        {
+            const int inst = x_big ? s0 + s : list[s0 + s];
+            if (lane < ne) Y.p[(size_t) inst * Y.E + e0 + lane] = tile[lane * 65 + s];
+        }
+    else if (lane < ns)
+    {
+        const int inst = x_big ? s0 + lane : list[s0 + lane];
+        T *py = Y.p + ((size_t) (inst >> 6) * (size_t) Y.E + e0) * 64 + (inst & 63);
+        for (int e = 0; e < ne; e++) py[(size_t) e * 64] = tile[e * 65 + lane];
+    }
+}
+
 static __global__ void k_compact_scalars(GqpDev big, GqpDev small, const int *list, int cnt, int dir)
 {
     const int sidx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1274,12 +1314,13 @@ static __global__ void k_stat_merge(GqpDev big, GqpDev small, const int *list, i
     const int i = list[sidx];
     if (i >= big.stat_inst) return;
     const int rows = big.stat_rows < small.stat_rows ? big.stat_rows : small.stat_rows;
-    for (int r = row0; r < rows; r++)
-        for (int c = 0; c < GQP_STAT_COLS; c++)
-        {
-            const double v = small.stat[((size_t) r * GQP_STAT_COLS + c) * small.stat_inst + sidx];
-            if (v != 0.0) big.stat[((size_t) r * GQP_STAT_COLS + c) * big.stat_inst + i] = v;
-        }
+    const int r = row0 + blockIdx.y; /* one table row per block row */
+    if (r >= rows) return;
+    for (int c = 0; c < GQP_STAT_COLS; c++)
+    {
+        const double v = small.stat[((size_t) r * GQP_STAT_COLS + c) * small.stat_inst + sidx];
+        if (v != 0.0) big.stat[((size_t) r * GQP_STAT_COLS + c) * big.stat_inst + i] = v;
+    }
 }
 
 static __global__ void k_fill_u64(GArrU64 dst, uint64_t val, int nb, int e)

@@ -53,6 +53,7 @@ def cpu_baseline(data, N, sample, threads):
         best = min(best, time.perf_counter() - t0)
     assert np.all(st == 0)
     iters = float(np.mean([q.iter for q in qps]))
+    cpu_baseline.solved = qps     # the same solutions double as the >= 1,024-instance parity sample
     return {"value": sample / best, "unit": "OCP-QP solves/s", "cores": threads, "kind": "port",
             "sample": f"{sample} instances of the same workload (seed 0, first instances), min of 3 repeats, "
                       f"OpenMP over instances as acados_solver.in.c:3232 does; restated CPU oracle, not HPIPM",
@@ -240,6 +241,18 @@ def main():
     if world == 1 and not args.no_cpu_baseline:
         threads = os.cpu_count() or 1
         out["cpu_baseline"] = cpu_baseline(data, N, min(args.cpu_sample, B), threads)
+        if args.check > 0:
+            # max relative primal error of the GPU solution against the oracle over the whole CPU sample
+            err_s = 0.0
+            for i, o in enumerate(cpu_baseline.solved):
+                for k in range(N + 1):
+                    r = o.get(k, "x")
+                    err_s = max(err_s, float(np.max(np.abs(xs[k][i] - r) / np.maximum(1.0, np.abs(r)))))
+                    if k < N:
+                        r = o.get(k, "u")
+                        err_s = max(err_s, float(np.max(np.abs(us[k][i] - r) / np.maximum(1.0, np.abs(r)))))
+            out["ipm"]["max_rel_primal_err_vs_oracle"] = max(err, err_s)
+            out["ipm"]["oracle_checked_instances"] = args.check + len(cpu_baseline.solved)
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -130,11 +130,12 @@ static inline void __syncthreads() { hostsim_coop::yield(); }
         dim3 g_ = (grid); dim3 b_ = (block);                                                \
         hostsim_coop::dyn().assign(((size_t) (shmem) + 7) / 8 + 8, 0.0);                    \
         hostsim_coop::st().body = [&]() { kern(__VA_ARGS__); };                             \
-        for (unsigned bx_ = 0; bx_ < g_.x; bx_++)                                           \
-        {                                                                                   \
-            blockDim = b_; gridDim = g_; blockIdx.x = bx_;                                  \
-            hostsim_coop::run_block(b_.x);                                                  \
-        }                                                                                   \
+        for (unsigned by_ = 0; by_ < g_.y; by_++)                                           \
+            for (unsigned bx_ = 0; bx_ < g_.x; bx_++)                                       \
+            {                                                                               \
+                blockDim = b_; gridDim = g_; blockIdx.x = bx_; blockIdx.y = by_;            \
+                hostsim_coop::run_block(b_.x);                                              \
+            }                                                                               \
     } while (0)
 
 #define hipLaunchKernelGGL(kern, grid, block, shmem, stream, ...)                           \
