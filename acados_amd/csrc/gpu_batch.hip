@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <string>
+#include <climits>
 #include <vector>
 
 #include "acados_amd/ocp_qp_gpu_batch.h"
@@ -57,7 +58,7 @@ struct W16Set
 #define GQP_W16(NX, NU)                                                                                       \
     {NX, NU, gqp::kx_factor<NX, NU>, gqp::kx_backrhs<NX, NU>, gqp::kx_fwd<NX, NU, false>, gqp::kx_fwd<NX, NU, true>, \
      4 * gqp::W16Lds<NX, NU>::SZ * sizeof(double)}
-const W16Set g_w16_sets[] = {GQP_W16(4, 1), GQP_W16(8, 3), GQP_W16(12, 3), GQP_W16(4, 4)};
+const W16Set g_w16_sets[] = {GQP_W16(4, 1), GQP_W16(8, 3), GQP_W16(12, 3), GQP_W16(4, 4), GQP_W16(12, 4)};
 
 } // namespace
 
@@ -623,7 +624,7 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
     if (need_wpi) b->ks = nullptr; /* no one-instance-per-lane kernel may serve it */
     if (!g_force_ks || g_force_wpi)
     {
-        const int wx = force_NX ? force_NX : mx, wu = force_NU ? force_NU : mu;
+        int wx = force_NX ? force_NX : mx, wu = force_NU ? force_NU : mu;
         const bool gen = mg > 0 || ms > 0;
         const char *env = getenv("ACADOS_AMD_WPI");
         const char *v1 = getenv("ACADOS_AMD_WPI_V1");
@@ -632,16 +633,28 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
          * instances per wave (measured crossover on the C2 shape between 4,096 and 16,384 instances,
          * tools/family_crossover.py).  ACADOS_AMD_WPI_BATCH_MAX overrides the batch threshold. */
         const char *bm = getenv("ACADOS_AMD_WPI_BATCH_MAX");
-        bool has_w16 = false;
+        /* sixteen lanes per instance: the smallest compiled shape that covers the dims (per-stage dims live inside
+         * the padded shape); a sub-level created for a hand-over must match its parent's padded dims exactly */
+        const W16Set *w16 = nullptr;
         {
             const char *e16 = getenv("ACADOS_AMD_W16");
-            if (!gen && !need_wpi && !(e16 && atoi(e16) == 0))
-                for (const W16Set &ws : g_w16_sets) has_w16 = has_w16 || (ws.NX == wx && ws.NU == wu);
+            if (!gen && !need_wpi && !ref && !(e16 && atoi(e16) == 0))
+                for (const W16Set &ws : g_w16_sets)
+                {
+                    const bool fits = force_NX ? (ws.NX == wx && ws.NU == wu) : (ws.NX >= wx && ws.NU >= wu);
+                    if (fits && (!w16 || ws.NX + ws.NU < w16->NX + w16->NU)) w16 = &ws;
+                }
         }
-        const int batch_max = bm ? atoi(bm) : (has_w16 ? GQP_W16_BATCH_MAX : GQP_WPI_BATCH_MAX);
+        const bool has_w16 = w16 != nullptr;
+        /* state bounds after stage 0 (the mass-spring class): the one-instance-per-lane kernels of that class run out
+         * of registers, the sixteen-lanes kernels win at every batch size measured (tools/xbox_rate.py) */
+        bool xbox_dims = false;
+        for (int k = 1; k <= N; k++) xbox_dims = xbox_dims || nbx[k] > 0;
+        const int batch_max = bm ? atoi(bm) : (has_w16 ? (xbox_dims ? INT_MAX : GQP_W16_BATCH_MAX) : GQP_WPI_BATCH_MAX);
         const bool want = g_force_wpi || need_wpi || (env ? atoi(env) != 0 : (wx + wu >= GQP_WPI_MIN_N || !b->ks || n_batch <= batch_max));
         if (want && wx + wu <= 64 && wx >= 1 && mg <= 32 && ms <= 32)
         {
+            if (w16) { wx = w16->NX; wu = w16->NU; }
             /* factor sweep: register-tile kernel for the tile count of this shape; rhs-only and forward sweeps on
              * the packed factor; GEN variants carry general constraints and slacks.  ACADOS_AMD_WPI_V1=1 selects
              * the plain LDS-resident reference kernels of the family (box-constrained QPs only), kept for
@@ -666,21 +679,17 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
             b->aos = 1;
             b->AW = need_wpi ? 2 : 1;
             /* small box-constrained stage blocks: four instances per wave, register rows + DPP row broadcasts */
+            if (w16)
             {
-                const char *e16 = getenv("ACADOS_AMD_W16");
-                if (!gen && !ref && !need_wpi && !(e16 && atoi(e16) == 0))
-                    for (const W16Set &ws : g_w16_sets)
-                        if (ws.NX == wx && ws.NU == wu)
-                        {
-                            b->own_ks.back_fact = ws.fact; b->own_ks.back_rhs = ws.rhs; b->own_ks.fwd_aff = ws.faff; b->own_ks.fwd_corr = ws.fcor;
-                            for (int q = 0; q < 2; q++)
-                            {
-                                b->own_ks.box_fact[q] = ws.fact; b->own_ks.box_rhs[q] = ws.rhs;
-                                b->own_ks.box_fwd_aff[q] = ws.faff; b->own_ks.box_fwd_corr[q] = ws.fcor;
-                            }
-                            b->w16 = 1;
-                            b->w16_shmem = ws.shmem;
-                        }
+                const W16Set &ws = *w16;
+                b->own_ks.back_fact = ws.fact; b->own_ks.back_rhs = ws.rhs; b->own_ks.fwd_aff = ws.faff; b->own_ks.fwd_corr = ws.fcor;
+                for (int q = 0; q < 2; q++)
+                {
+                    b->own_ks.box_fact[q] = ws.fact; b->own_ks.box_rhs[q] = ws.rhs;
+                    b->own_ks.box_fwd_aff[q] = ws.faff; b->own_ks.box_fwd_corr[q] = ws.fcor;
+                }
+                b->w16 = 1;
+                b->w16_shmem = ws.shmem;
             }
             const size_t con = gqp::wpi_con_doubles(wx + wu, mg, ms);
             b->shmem = (ref ? gqp::wpi_lds_doubles(wx, wu) : gqp::wpi3_lds_doubles(wx, wu) + con) * sizeof(double);

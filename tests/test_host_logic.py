@@ -855,3 +855,16 @@ def test_cond_block_size_option_acados_api_hostsim(hostsim_lib, capfd):
     assert s.solve() == 0
     compare_with_oracle(lambda k, f: s.get(k, f, unique_duals=False), o, qp, 2e-7, fields=("x", "u", "pi", "lam", "t"))
     assert "solving the full-space QP" not in capfd.readouterr().err
+
+
+def test_sixteen_lanes_covering_shapes_hostsim(hostsim_lib, monkeypatch):
+    """box-constrained shapes without a compiled sixteen-lanes instantiation of their own run in the smallest one
+    that covers them (dims padded inside the compiled shape): (6,2) and (7,3) in <8,3>, (3,1) in <4,1>, (10,4) in
+    <12,4>, (3,3) in <4,4>; ragged batch of 6 = one full workgroup of four instances + two"""
+    from acados_amd.generators import lqr_instance_qp, random_lqr_batch
+    monkeypatch.setenv("ACADOS_AMD_WPI", "1")
+    for (nx, nu), want in (((6, 2), "w16-box<NX=8,NU=3>"), ((7, 3), "w16-box<NX=8,NU=3>"), ((3, 1), "w16-box<NX=4,NU=1>"),
+                           ((10, 4), "w16-box<NX=12,NU=4>"), ((3, 3), "w16-box<NX=4,NU=4>")):
+        data = random_lqr_batch(N=5, nx=nx, nu=nu, batch=6, seed=20 + nx)
+        b = _check_batch_vs_oracle([lqr_instance_qp(data, i, 5) for i in range(6)], hostsim_lib)
+        assert b.kernel_name == want, b.kernel_name
