@@ -1376,11 +1376,8 @@ static void refactor_at_solution(ocp_qp_gpu_batch *b)
 static int sens_begin(ocp_qp_gpu_batch *b)
 {
     if (b->sens_open) return 0;
-    if (b->cond_N > 0 && b->cond_N < b->N)
-    {
-        fprintf(stderr, "acados_amd: solution sensitivities are not available with partial condensing on the device batch\n");
-        return -1;
-    }
+    /* after a partially condensed solve the expanded solution sits in this (full-space) batch: the factorisation at
+     * the solution and the seed sweeps run here, the condensed sub-batch is not involved */
     /* a one-instance-per-lane batch hands slices of itself to a wave-per-instance sub-batch in sens_solve */
     if (b->wpi) refactor_at_solution(b);
     const GqpDev &D = b->D;

@@ -118,7 +118,7 @@ int ocp_qp_gpu_batch_get(ocp_qp_gpu_batch *b, const char *field, int stage, doub
  * ocp_qp_gpu_batch_get.  The KKT matrix is symmetric, so the adjoint solve of a seed in (q, r) is the same call.
  * The sweeps exist in the wave-per-instance / sixteen-lanes kernel families; a one-instance-per-lane batch is walked
  * in slices of 16,384 instances through a sub-batch of those families (ACADOS_AMD_SENS_SLICE changes the slice).
- * Not available with partial condensing on the device batch (returns -1 with a message). */
+ * After a partially condensed solve the sensitivities are computed in the full space at the expanded solution. */
 int ocp_qp_gpu_batch_sens_set(ocp_qp_gpu_batch *b, const char *field, int stage, const double *data);
 int ocp_qp_gpu_batch_sens_solve(ocp_qp_gpu_batch *b);
 

@@ -868,3 +868,38 @@ def test_sixteen_lanes_covering_shapes_hostsim(hostsim_lib, monkeypatch):
         data = random_lqr_batch(N=5, nx=nx, nu=nu, batch=6, seed=20 + nx)
         b = _check_batch_vs_oracle([lqr_instance_qp(data, i, 5) for i in range(6)], hostsim_lib)
         assert b.kernel_name == want, b.kernel_name
+
+
+def test_solution_sensitivities_after_partial_condensing_hostsim(hostsim_lib, monkeypatch):
+    """sensitivities of a partially condensed solve: computed in the full space at the expanded solution, equal to
+    the finite differences of (partially condensed) solves"""
+    from acados_amd import OcpQpGpuBatch
+    from acados_amd.generators import fill_lqr_batch, lqr_dims, random_lqr_batch
+    monkeypatch.setenv("ACADOS_AMD_WPI", "1")
+    N, B, nx, nu = 6, 2, 8, 3
+    data = random_lqr_batch(N=N, batch=B, seed=4)
+
+    def build(d):
+        gb = OcpQpGpuBatch(lqr_dims(N, nx, nu), B, _clib=hostsim_lib)
+        fill_lqr_batch(gb, d, N)
+        for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+            gb.opts_set(f, 1e-10)
+        gb.opts_set("cond_N", 3)
+        assert gb.solve() == 0 and int(gb.scalar("cond_N_active")) == 3
+        return gb
+
+    def xu(g, pre=""):
+        return np.concatenate([g.get(pre + "x", k) for k in range(N + 1)] + [g.get(pre + "u", k) for k in range(N)], axis=1)
+
+    e3 = np.zeros((B, nx)); e3[:, 3] = 1.0
+    ref = build(data)
+    sols = []
+    for sg in (+1e-6, -1e-6):
+        d = {k: v.copy() for k, v in data.items()}
+        d["x0"][:, 3] += sg
+        sols.append(xu(build(d)))
+    fd = (sols[0] - sols[1]) / 2e-6
+    ref.sens_set("seed_lbx", 0, e3); ref.sens_set("seed_ubx", 0, e3)
+    ref.sens_solve()
+    se = xu(ref, "sens_")
+    assert np.max(np.abs(fd - se)) <= 1e-5 * max(1.0, np.max(np.abs(se)))
