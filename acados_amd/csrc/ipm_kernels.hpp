@@ -74,7 +74,6 @@ template <int NX, int NU, int NG, int NS>
 __global__ void __launch_bounds__(64) k_init(GqpDev D, GqpOpts O)
 {
     constexpr int n = NX + NU;
-    const int Bp = D.Bp;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= D.B) return;
     const double thr0 = 1e-1;
@@ -742,7 +741,6 @@ __global__ void __launch_bounds__(64) k_forward(GqpDev D, GqpOpts O, int redo)
 {
     constexpr int n = NX + NU;
     constexpr int NP = n * (n + 1) / 2;
-    const int Bp = D.Bp;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= D.B) return;
     if (D.status[i] != GQP_RUNNING) return;
@@ -1014,7 +1012,6 @@ template <int NX, int NU, int NG, int NS>
 __global__ void __launch_bounds__(64) k_finalize(GqpDev D)
 {
     constexpr int n = NX + NU;
-    const int Bp = D.Bp;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= D.B) return;
     for (int k = 0; k <= D.N; k++)

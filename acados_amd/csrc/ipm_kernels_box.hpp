@@ -448,7 +448,6 @@ template <int NX, int NU, bool XBOX>
 __global__ void __launch_bounds__(64) kb_backrhs(GqpDev D, GqpOpts O, int redo)
 {
     constexpr int n = NX + NU, NP = n * (n + 1) / 2, NPX = NX * (NX + 1) / 2, NB = XBOX ? n : NU;
-    const int Bp = D.Bp;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= D.B) return;
     if (D.status[i] != GQP_RUNNING) return;
@@ -539,7 +538,6 @@ template <int NX, int NU, bool XBOX, bool CORR>
 __global__ void __launch_bounds__(64) kb_forward(GqpDev D, GqpOpts O, int redo)
 {
     constexpr int n = NX + NU, NP = n * (n + 1) / 2, NB = XBOX ? n : NU;
-    const int Bp = D.Bp;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= D.B) return;
     if (D.status[i] != GQP_RUNNING) return;
@@ -730,7 +728,6 @@ template <int NX, int NU>
 __global__ void __launch_bounds__(64) kb_finalize(GqpDev D)
 {
     constexpr int n = NX + NU, NP = n * (n + 1) / 2;
-    const int Bp = D.Bp;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= D.B) return;
     for (int k = 0; k <= D.N; k++)

@@ -360,10 +360,10 @@ static size_t out_walk(ocp_qp_dims *d, ocp_qp_out *out, char *base)
     {
         const int nv = d->nu[k] + d->nx[k] + 2 * d->ns[k], nx1 = k < N ? d->nx[k + 1] : 0;
         const int nct = 2 * (d->nb[k] + d->ng[k] + d->ns[k]);
-        if (out) out->ux[k] = (double *) c; c += sizeof(double) * nv;
-        if (out) out->pi[k] = (double *) c; c += sizeof(double) * nx1;
-        if (out) out->lam[k] = (double *) c; c += sizeof(double) * nct;
-        if (out) out->t[k] = (double *) c; c += sizeof(double) * nct;
+        if (out) { out->ux[k] = (double *) c; out->pi[k] = (double *) (c + sizeof(double) * nv); }
+        c += sizeof(double) * (nv + nx1);
+        if (out) { out->lam[k] = (double *) c; out->t[k] = (double *) (c + sizeof(double) * nct); }
+        c += sizeof(double) * 2 * nct;
     }
     c = align8(c);
     if (out) out->misc = c;

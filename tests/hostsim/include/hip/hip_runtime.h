@@ -1,7 +1,7 @@
 /*
  * TEST INFRASTRUCTURE ONLY -- host simulation of the small HIP subset the solver uses.
  *
- * Lets the *unchanged* kernel sources (acados_amd/csrc/*.hip, *.hpp) be compiled with g++
+ * Lets the *unchanged* kernel sources (the .hip / .hpp files of acados_amd/csrc) be compiled with g++
  * and run one "lane" at a time on the CPU, so kernel logic can be checked against the
  * oracle in the CPU-only test tier (`-m "not gpu"`).  It is built by tests/hostsim/build.py
  * into tests/hostsim/libgqp_hostsim.so and is never loaded by the acados_amd package:
