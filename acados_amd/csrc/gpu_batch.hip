@@ -53,11 +53,13 @@ struct W16Set
 {
     int NX, NU;
     kern_redo_t fact, rhs, faff, fcor;
+    kern_redo_t sfact, srhs, sfaff, sfcor; /* SOFT variants: soft box rows, one slack per row */
     size_t shmem;
 };
 #define GQP_W16(NX, NU)                                                                                       \
     {NX, NU, gqp::kx_factor<NX, NU>, gqp::kx_backrhs<NX, NU>, gqp::kx_fwd<NX, NU, false>, gqp::kx_fwd<NX, NU, true>, \
-     4 * gqp::W16Lds<NX, NU>::SZ * sizeof(double)}
+     gqp::kx_factor<NX, NU, true>, gqp::kx_backrhs<NX, NU, true>, gqp::kx_fwd<NX, NU, false, true>,            \
+     gqp::kx_fwd<NX, NU, true, true>, 4 * gqp::W16Lds<NX, NU>::SZ * sizeof(double)}
 const W16Set g_w16_sets[] = {GQP_W16(4, 1), GQP_W16(8, 3), GQP_W16(12, 3), GQP_W16(4, 4), GQP_W16(12, 4)};
 
 } // namespace
@@ -76,6 +78,8 @@ struct ocp_qp_gpu_batch
     int w16 = 0;          /* ... whose four sweeps are the 16-lanes-per-instance kernels (ipm_kernels_w16.hpp): 4 instances per workgroup */
     size_t shmem = 0;     /* their dynamic LDS bytes (rhs / forward sweeps) */
     size_t shmem_fact = 0; /* dynamic LDS bytes of the factor sweep */
+    bool w16_soft = false; /* ... with soft box rows (one slack per row) */
+    KernelSet wpi_ks;      /* the wave-per-instance set of the same padded dims (fallback of w16_soft) */
     size_t w16_shmem = 0;  /* dynamic LDS bytes of a 16-lanes-per-instance workgroup (4 instances) */
     KernelSet own_ks;     /* runtime-shaped kernel set of a wpi batch (ks points here) */
     int xbox = 0;
@@ -252,6 +256,31 @@ void finalize_structure(ocp_qp_gpu_batch *b)
         o_ct += nct; o_s += 2 * S.ns; o_g += S.ng;
     }
     b->nct_tot = o_ct; b->ns2_tot = o_s; b->ng_tot = o_g;
+    if (b->w16 && b->w16_soft)
+    {
+        /* the SOFT sixteen-lanes kernels eliminate a slack inside the lane that owns its row: every slack must belong
+         * to exactly one box row that is not an equality-flagged one; anything else runs on the general
+         * wave-per-instance kernels of the same padded dims */
+        bool ok = true;
+        for (int k = 0; k <= N && ok; k++)
+        {
+            const GqpStage &S = b->st[k];
+            std::vector<int> refs(S.ns, 0);
+            for (int r = 0; r < S.nb; r++)
+                if (S.srev[r] >= 0) refs[S.srev[r]]++;
+            for (int q = 0; q < S.ns; q++) ok = ok && refs[q] == 1;
+            for (size_t e = 0; e < b->idxe[k].size(); e++) ok = ok && b->idxs_rev[k][b->idxe[k][e]] < 0;
+        }
+        if (!ok)
+        {
+            b->own_ks = b->wpi_ks;
+            b->w16 = 0;
+            b->w16_soft = false;
+            char nm[160];
+            snprintf(nm, sizeof(nm), "wpi-gen(nx=%d,nu=%d,ng=%d,ns=%d,lds=%zuB)", b->ks->NX, b->ks->NU, b->ks->NG, b->ks->NS, b->shmem_fact);
+            b->kname = nm;
+        }
+    }
     b->use_box = o_g == 0 && o_s == 0 && !getenv("ACADOS_AMD_GENERAL_KERNELS");
     b->xbox = 0;
     for (int k = 0; k <= N; k++)
@@ -635,10 +664,11 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
         const char *bm = getenv("ACADOS_AMD_WPI_BATCH_MAX");
         /* sixteen lanes per instance: the smallest compiled shape that covers the dims (per-stage dims live inside
          * the padded shape); a sub-level created for a hand-over must match its parent's padded dims exactly */
+        const bool soft_dims = mg == 0 && ms > 0; /* slacks on box rows only: the SOFT variants, if the structure allows */
         const W16Set *w16 = nullptr;
         {
             const char *e16 = getenv("ACADOS_AMD_W16");
-            if (!gen && !need_wpi && !ref && !(e16 && atoi(e16) == 0))
+            if ((!gen || soft_dims) && !need_wpi && !ref && !(e16 && atoi(e16) == 0))
                 for (const W16Set &ws : g_w16_sets)
                 {
                     const bool fits = force_NX ? (ws.NX == wx && ws.NU == wu) : (ws.NX >= wx && ws.NU >= wu);
@@ -682,13 +712,17 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
             if (w16)
             {
                 const W16Set &ws = *w16;
-                b->own_ks.back_fact = ws.fact; b->own_ks.back_rhs = ws.rhs; b->own_ks.fwd_aff = ws.faff; b->own_ks.fwd_corr = ws.fcor;
+                b->wpi_ks = b->own_ks; /* what the batch falls back to if the slack structure is not one-slack-per-box-row */
+                const kern_redo_t kf = soft_dims ? ws.sfact : ws.fact, kr = soft_dims ? ws.srhs : ws.rhs;
+                const kern_redo_t ka = soft_dims ? ws.sfaff : ws.faff, kc = soft_dims ? ws.sfcor : ws.fcor;
+                b->own_ks.back_fact = kf; b->own_ks.back_rhs = kr; b->own_ks.fwd_aff = ka; b->own_ks.fwd_corr = kc;
                 for (int q = 0; q < 2; q++)
                 {
-                    b->own_ks.box_fact[q] = ws.fact; b->own_ks.box_rhs[q] = ws.rhs;
-                    b->own_ks.box_fwd_aff[q] = ws.faff; b->own_ks.box_fwd_corr[q] = ws.fcor;
+                    b->own_ks.box_fact[q] = kf; b->own_ks.box_rhs[q] = kr;
+                    b->own_ks.box_fwd_aff[q] = ka; b->own_ks.box_fwd_corr[q] = kc;
                 }
                 b->w16 = 1;
+                b->w16_soft = soft_dims;
                 b->w16_shmem = ws.shmem;
             }
             const size_t con = gqp::wpi_con_doubles(wx + wu, mg, ms);
@@ -703,9 +737,9 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
         return nullptr;
     }
     char nm[128];
-    if (b->wpi && (b->ks->NG || b->ks->NS))
+    if (b->w16) snprintf(nm, sizeof(nm), b->w16_soft ? "w16-soft<NX=%d,NU=%d>" : "w16-box<NX=%d,NU=%d>", b->ks->NX, b->ks->NU);
+    else if (b->wpi && (b->ks->NG || b->ks->NS))
         snprintf(nm, sizeof(nm), "wpi-gen(nx=%d,nu=%d,ng=%d,ns=%d,lds=%zuB)", b->ks->NX, b->ks->NU, b->ks->NG, b->ks->NS, b->shmem_fact);
-    else if (b->w16) snprintf(nm, sizeof(nm), "w16-box<NX=%d,NU=%d>", b->ks->NX, b->ks->NU);
     else if (b->wpi) snprintf(nm, sizeof(nm), "wpi-box(nx=%d,nu=%d,lds=%zuB)", b->ks->NX, b->ks->NU, b->shmem);
     else snprintf(nm, sizeof(nm), "1tpi<NX=%d,NU=%d,NG=%d,NS=%d>", b->ks->NX, b->ks->NU, b->ks->NG, b->ks->NS);
     b->kname = nm;
@@ -1245,7 +1279,7 @@ static void compact_into(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch *root, int nact, 
         c->idxb = b->idxb; c->idxs_rev = b->idxs_rev; c->idxe = b->idxe; c->nbxe = b->nbxe;
         c->compact_min = b->compact_min;
         c->tail_max = b->tail_max;
-        if (!tail) { c->aos = b->aos; c->wpi = b->wpi; c->shmem = b->shmem; c->shmem_fact = b->shmem_fact; c->w16 = b->w16; c->w16_shmem = b->w16_shmem; }
+        if (!tail) { c->aos = b->aos; c->wpi = b->wpi; c->shmem = b->shmem; c->shmem_fact = b->shmem_fact; c->w16 = b->w16; c->w16_soft = b->w16_soft; c->w16_shmem = b->w16_shmem; }
         finalize_structure(c);
         slot = c;
     }

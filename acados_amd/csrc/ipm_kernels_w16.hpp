@@ -109,7 +109,11 @@ __device__ static inline double w16_rmin(double v, double *xb)
 
 /* ------------------------------------------------------------------------------------------------ factor */
 
-template <int NX, int NU>
+/* SOFT: box rows may be soft, every slack belongs to exactly ONE box row (no general rows, no shared slacks -- the
+ * host checks it, gpu_batch.hip): the slack block of a row is eliminated by the lane that owns the row, with the
+ * cancellation-free formulas of ipm_kernels_wpi.hpp specialised to one row per slack (E = Z + Gamma_s, X = slack
+ * stationarity + rho_s); nothing crosses lanes. */
+template <int NX, int NU, bool SOFT = false>
 __global__ void __launch_bounds__(64) kx_factor(GqpDev D, GqpOpts O, int redo)
 {
     GQP_DYN_SHARED(smem);
@@ -155,6 +159,20 @@ __global__ void __launch_bounds__(64) kx_factor(GqpDev D, GqpOpts O, int redo)
         const double ll = al ? WAT(D.lam, el) : 0.0, lu = au ? WAT(D.lam, eu) : 0.0;
         const double ttl = al ? WAT(D.t, el) : 1.0, ttu = au ? WAT(D.t, eu) : 1.0;
         const double lbv = al ? WAT(D.dvec, el) : 0.0, ubv = au ? WAT(D.dvec, eu) : 0.0;
+        /* SOFT: the slack of this lane's row (values, cost, its two bound rows) */
+        const int sj = (SOFT && has) ? (int) S.srev[ib] : -1;
+        const int sq = sj >= 0 ? sj : 0, se0 = S.o_ct + 2 * nbg + sq, se1 = se0 + S.ns;
+        const bool sal = sj >= 0 && ((am >> (2 * nbg + sq)) & 1), sau = sj >= 0 && ((am >> (2 * nbg + S.ns + sq)) & 1);
+        double ssl = 0.0, ssu = 0.0, sll = 0.0, slu = 0.0, stl = 1.0, stu = 1.0, sdl = 0.0, sdu = 0.0, sZl = 0.0, szl = 0.0, sZu = 0.0, szu = 0.0;
+        if (SOFT && sj >= 0)
+        {
+            ssl = WAT(D.sv, S.o_s + sq); ssu = WAT(D.sv, S.o_s + S.ns + sq);
+            sll = sal ? WAT(D.lam, se0) : 0.0; slu = sau ? WAT(D.lam, se1) : 0.0;
+            stl = sal ? WAT(D.t, se0) : 1.0; stu = sau ? WAT(D.t, se1) : 1.0;
+            sdl = sal ? WAT(D.dvec, se0) : 0.0; sdu = sau ? WAT(D.dvec, se1) : 0.0;
+            sZl = WAT(D.Zz, (S.o_s + sq) * 2); szl = WAT(D.Zz, (S.o_s + sq) * 2 + 1);
+            sZu = WAT(D.Zz, (S.o_s + S.ns + sq) * 2); szu = WAT(D.Zz, (S.o_s + S.ns + sq) * 2 + 1);
+        }
 
         /* ---- rb += [B A] v, H v (one broadcast of v per variable serves both) ---- */
         double hv = 0.0;
@@ -176,17 +194,42 @@ __global__ void __launch_bounds__(64) kx_factor(GqpDev D, GqpOpts O, int redo)
         if (isx) { nacc(nrm_b, rb); WAT(D.rb, k * NX + cx) = rb; }
         if (has)
         {
-            const double rdl = al ? v - lbv - ttl : 0.0, rdu = au ? ubv - v - ttu : 0.0;
+            const double rdl = al ? v + ssl - lbv - ttl : 0.0, rdu = au ? ubv - v + ssu - ttu : 0.0;
             const double rml = al ? ll * ttl - O.tau_min : 0.0, rmu = au ? lu * ttu - O.tau_min : 0.0;
             nacc(nrm_d, rdl); nacc(nrm_d, rdu); nacc(nrm_m, rml); nacc(nrm_m, rmu);
             musum += ll * ttl + lu * ttu;
             nact += (double) ((int) al + (int) au);
             gt -= ll - lu;
             const double itl = frcp(ttl), itu = frcp(ttu);
-            gam = ll * itl + lu * itu;
-            gadd = (rml + ll * rdl) * itl - (rmu + lu * rdu) * itu;
+            const double bGl = ll * itl, bGu = lu * itu, bRl = (rml + ll * rdl) * itl, bRu = (rmu + lu * rdu) * itu;
+            gam = bGl + bGu;
+            gadd = bRl - bRu;
             WAT(D.rd, el) = rdl;
             WAT(D.rd, eu) = rdu;
+            if (SOFT && sj >= 0)
+            {
+                obj += (0.5 * sZl * ssl + szl) * ssl + (0.5 * sZu * ssu + szu) * ssu;
+                const double srdl = sal ? ssl - sdl - stl : 0.0, srdu = sau ? ssu - sdu - stu : 0.0;
+                const double srml = sal ? sll * stl - O.tau_min : 0.0, srmu = sau ? slu * stu - O.tau_min : 0.0;
+                nacc(nrm_d, srdl); nacc(nrm_d, srdu); nacc(nrm_m, srml); nacc(nrm_m, srmu);
+                musum += sll * stl + slu * stu;
+                nact += (double) ((int) sal + (int) sau);
+                const double sitl = frcp(stl), situ = frcp(stu);
+                const double sGl = sll * sitl, sGu = slu * situ;
+                const double sPl = (srml + sll * srdl) * sitl, sPu = (srmu + slu * srdu) * situ;
+                WAT(D.rd, se0) = srdl;
+                WAT(D.rd, se1) = srdu;
+                const double Rl = sZl * ssl + szl - sll - ll, Ru = sZu * ssu + szu - slu - lu; /* slack stationarity */
+                nacc(nrm_g, Rl); nacc(nrm_g, Ru);
+                WAT(D.rgs, S.o_s + sq) = Rl; WAT(D.rgs, S.o_s + S.ns + sq) = Ru;
+                const double El = sZl + sGl, Eu = sZu + sGu, Xl = Rl + sPl, Xu = Ru + sPu; /* D, r~ without the row */
+                const double Dl = El + bGl, Du = Eu + bGu;
+                WAT(D.sD, S.o_s + sq) = Dl; WAT(D.sD, S.o_s + S.ns + sq) = Du;
+                WAT(D.sR, S.o_s + sq) = Xl + bRl; WAT(D.sR, S.o_s + S.ns + sq) = Xu + bRu;
+                const double Il = Dl != 0.0 ? frcp(Dl) : 0.0, Iu = Du != 0.0 ? frcp(Du) : 0.0;
+                gam = bGl * El * Il + bGu * Eu * Iu;
+                gadd = (bRl * El - bGl * Xl) * Il - (bRu * Eu - bGu * Xu) * Iu;
+            }
         }
         if (fixed) gt = 0.0;
         if (mine) { nacc(nrm_g, gt); WAT(D.rg, k * n + l) = gt; }
@@ -297,7 +340,7 @@ __global__ void __launch_bounds__(64) kx_factor(GqpDev D, GqpOpts O, int redo)
 
 /* ------------------------------------------------------------------------------- rhs-only backward (p-form) */
 
-template <int NX, int NU>
+template <int NX, int NU, bool SOFT = false>
 __global__ void __launch_bounds__(64) kx_backrhs(GqpDev D, GqpOpts O, int redo)
 {
     GQP_DYN_SHARED(smem);
@@ -344,7 +387,29 @@ __global__ void __launch_bounds__(64) kx_backrhs(GqpDev D, GqpOpts O, int redo)
             const double rdl = al ? WAT(D.rd, el) : 0.0, rdu = au ? WAT(D.rd, eu) : 0.0;
             const double rml = al ? ll * ttl - O.tau_min + pscale * WAT(D.pcorr, el) - smu : 0.0;
             const double rmu = au ? lu * ttu - O.tau_min + pscale * WAT(D.pcorr, eu) - smu : 0.0;
-            m += (rml + ll * rdl) * frcp(ttl) - (rmu + lu * rdu) * frcp(ttu);
+            const double itl = frcp(ttl), itu = frcp(ttu);
+            const double bRl = (rml + ll * rdl) * itl, bRu = (rmu + lu * rdu) * itu;
+            const int sj = SOFT ? (int) S.srev[ib] : -1;
+            if (!SOFT || sj < 0) m += bRl - bRu;
+            else
+            {
+                const double bGl = ll * itl, bGu = lu * itu;
+                const int e0 = S.o_ct + 2 * nbg + sj, e1 = e0 + S.ns;
+                const bool sal = (am >> (2 * nbg + sj)) & 1, sau = (am >> (2 * nbg + S.ns + sj)) & 1;
+                const double sll = sal ? WAT(D.lam, e0) : 0.0, slu = sau ? WAT(D.lam, e1) : 0.0;
+                const double stl = sal ? WAT(D.t, e0) : 1.0, stu = sau ? WAT(D.t, e1) : 1.0;
+                const double srdl = sal ? WAT(D.rd, e0) : 0.0, srdu = sau ? WAT(D.rd, e1) : 0.0;
+                const double srml = sal ? sll * stl - O.tau_min + pscale * WAT(D.pcorr, e0) - smu : 0.0;
+                const double srmu = sau ? slu * stu - O.tau_min + pscale * WAT(D.pcorr, e1) - smu : 0.0;
+                const double sitl = frcp(stl), situ = frcp(stu);
+                const double Xl = WAT(D.rgs, S.o_s + sj) + (srml + sll * srdl) * sitl;            /* r~ without the row */
+                const double Xu = WAT(D.rgs, S.o_s + S.ns + sj) + (srmu + slu * srdu) * situ;
+                const double El = WAT(D.Zz, (S.o_s + sj) * 2) + sll * sitl, Eu = WAT(D.Zz, (S.o_s + S.ns + sj) * 2) + slu * situ;
+                WAT(D.sR, S.o_s + sj) = Xl + bRl; WAT(D.sR, S.o_s + S.ns + sj) = Xu + bRu;
+                const double Dl = WAT(D.sD, S.o_s + sj), Du = WAT(D.sD, S.o_s + S.ns + sj);
+                const double Il = Dl != 0.0 ? frcp(Dl) : 0.0, Iu = Du != 0.0 ? frcp(Du) : 0.0;
+                m += (bRl * El - bGl * Xl) * Il - (bRu * Eu - bGu * Xu) * Iu;
+            }
         }
         /* y = Lx+ (Lx+' rb) + p+ */
         double w0 = 0.0;
@@ -382,7 +447,7 @@ __global__ void __launch_bounds__(64) kx_backrhs(GqpDev D, GqpOpts O, int redo)
 /* --------------------------------------------------------------------------------------------------- forward */
 
 /* PFORM (= CORR): lf holds [l_u; p] (written by kx_backrhs), otherwise the plain l of the factor sweep */
-template <int NX, int NU, bool CORR>
+template <int NX, int NU, bool CORR, bool SOFT = false>
 __global__ void __launch_bounds__(64) kx_fwd(GqpDev D, GqpOpts O, int redo)
 {
     GQP_DYN_SHARED(smem);
@@ -475,7 +540,51 @@ __global__ void __launch_bounds__(64) kx_fwd(GqpDev D, GqpOpts O, int redo)
         {
             const double rml = al ? ll * ttl - O.tau_min + pscale * pl - smu : 0.0;
             const double rmu = au ? lu * ttu - O.tau_min + pscale * pu - smu : 0.0;
-            const double dtl = al ? dv + rdl : 0.0, dtu = au ? -dv + rdu : 0.0;
+            double dcl = dv, dcu = -dv; /* dc + ds resp. -dc + ds: the row's own slack step included (SOFT) */
+            const int sj = SOFT ? (int) S.srev[ib] : -1;
+            if (SOFT && sj >= 0)
+            {
+                const int e0 = S.o_ct + 2 * nbg + sj, e1 = e0 + S.ns;
+                const bool sal = (am >> (2 * nbg + sj)) & 1, sau = (am >> (2 * nbg + S.ns + sj)) & 1;
+                const double sll = sal ? WAT(D.lam, e0) : 0.0, slu = sau ? WAT(D.lam, e1) : 0.0;
+                const double stl = sal ? WAT(D.t, e0) : 1.0, stu = sau ? WAT(D.t, e1) : 1.0;
+                const double Dl = WAT(D.sD, S.o_s + sj), Du = WAT(D.sD, S.o_s + S.ns + sj);
+                const double rsl = WAT(D.sR, S.o_s + sj), rsu = WAT(D.sR, S.o_s + S.ns + sj);
+                const double il = Dl != 0.0 ? frcp(Dl) : 0.0, iu = Du != 0.0 ? frcp(Du) : 0.0;
+                const double gl_ = ll * frcp(ttl), gu_ = lu * frcp(ttu);
+                const double dsl = (-rsl - gl_ * dv) * il, dsu = (-rsu + gu_ * dv) * iu;
+                if (CORR) { WAT(D.dsv, S.o_s + sj) = dsl; WAT(D.dsv, S.o_s + S.ns + sj) = dsu; }
+                const double sitl = frcp(stl), situ = frcp(stu);
+                const double El = WAT(D.Zz, (S.o_s + sj) * 2) + sll * sitl, Eu = WAT(D.Zz, (S.o_s + S.ns + sj) * 2) + slu * situ;
+                dcl = (El * dv - rsl) * il;
+                dcu = (-Eu * dv - rsu) * iu;
+                /* the two bound rows of the slack */
+                const double spl = (CORR && sal) ? WAT(D.pcorr, e0) : 0.0, spu = (CORR && sau) ? WAT(D.pcorr, e1) : 0.0;
+                const double srml = sal ? sll * stl - O.tau_min + pscale * spl - smu : 0.0;
+                const double srmu = sau ? slu * stu - O.tau_min + pscale * spu - smu : 0.0;
+                const double sdtl = sal ? dsl + WAT(D.rd, e0) : 0.0, sdtu = sau ? dsu + WAT(D.rd, e1) : 0.0;
+                const double sdll = sal ? -(srml + sll * sdtl) * sitl : 0.0, sdlu = sau ? -(srmu + slu * sdtu) * situ : 0.0;
+                const double q1 = -sll * frcp(sdll), q2 = -slu * frcp(sdlu), q3 = -stl * frcp(sdtl), q4 = -stu * frcp(sdtu);
+                alpha = (sdll < 0.0 && q1 < alpha) ? q1 : alpha;
+                alpha = (sdlu < 0.0 && q2 < alpha) ? q2 : alpha;
+                alpha = (sdtl < 0.0 && q3 < alpha) ? q3 : alpha;
+                alpha = (sdtu < 0.0 && q4 < alpha) ? q4 : alpha;
+                if (!CORR)
+                {
+                    S0 += sll * stl + slu * stu;
+                    S1 += sll * sdtl + stl * sdll + slu * sdtu + stu * sdlu;
+                    S2 += sdll * sdtl + sdlu * sdtu;
+                    nact += (double) ((int) sal + (int) sau);
+                    WAT(D.pcorr, e0) = sdll * sdtl;
+                    WAT(D.pcorr, e1) = sdlu * sdtu;
+                }
+                else
+                {
+                    WAT(D.dlam, e0) = sdll; WAT(D.dlam, e1) = sdlu;
+                    WAT(D.dt, e0) = sdtl; WAT(D.dt, e1) = sdtu;
+                }
+            }
+            const double dtl = al ? dcl + rdl : 0.0, dtu = au ? dcu + rdu : 0.0;
             const double dll = al ? -(rml + ll * dtl) * frcp(ttl) : 0.0;
             const double dlu = au ? -(rmu + lu * dtu) * frcp(ttu) : 0.0;
             const double c1 = -ll * frcp(dll), c2 = -lu * frcp(dlu), c3 = -ttl * frcp(dtl), c4 = -ttu * frcp(dtu);
@@ -566,6 +675,26 @@ __global__ void __launch_bounds__(64) kx_fwd(GqpDev D, GqpOpts O, int redo)
             const double tl = t_[el] + a * dt_[el], tu = t_[eu] + a * dt_[eu];
             if (al) { lam_[el] = laml < O.lam_min ? O.lam_min : laml; t_[el] = tl < O.t_min ? O.t_min : tl; }
             if (au) { lam_[eu] = lamu < O.lam_min ? O.lam_min : lamu; t_[eu] = tu < O.t_min ? O.t_min : tu; }
+            if (SOFT && has)
+            {
+                const int sj = (int) st_[k].srev[ib];
+                if (sj >= 0)
+                {
+                    const int ns = st_[k].ns, o_s = st_[k].o_s;
+                    WAT(D.sv, o_s + sj) += a * WAT(D.dsv, o_s + sj);
+                    WAT(D.sv, o_s + ns + sj) += a * WAT(D.dsv, o_s + ns + sj);
+                    for (int w = 0; w < 2; w++)
+                    {
+                        const int side = 2 * nbg + w * ns + sj, e = st_[k].o_ct + side;
+                        if ((am >> side) & 1)
+                        {
+                            const double lm = lam_[e] + a * dlam_[e], tt = t_[e] + a * dt_[e];
+                            lam_[e] = lm < O.lam_min ? O.lam_min : lm;
+                            t_[e] = tt < O.t_min ? O.t_min : tt;
+                        }
+                    }
+                }
+            }
         }
     }
     if (l == 0)

@@ -585,3 +585,71 @@ def test_condensing_only_boundary_gpu(gpu_lib):
                 assert np.allclose(np.asarray(getattr(qc2, f)[k]), np.asarray(getattr(qc, f)[k]), rtol=0, atol=1e-12), (f, k)
         get = mod.expand(lambda k, f: oc.get(k, f))
         compare_with_oracle(get, o, qp, 1e-4, fields=("x", "u", "sl", "su", "pi", "lam", "t"))
+
+
+@pytest.mark.gpu
+def test_sixteen_lanes_soft_box_rows_gpu(gpu_lib, monkeypatch):
+    """SOFT variants of the sixteen-lanes kernels on the device: 40 random structures without general rows (soft and
+    hard box rows mixed, one-sided rows, per-stage dims; a slack shared by several rows falls back to the general
+    wave-per-instance kernels), 70 copies each, against the oracle; then the C2 shape with soft bounds on every state,
+    4,096 instances: residual norms, slack signs, soft rows satisfied up to their slack, 4 instances vs the oracle"""
+    from acados_amd import OcpQpGpuBatch
+    from acados_amd.generators import fill_lqr_batch, lqr_dims, lqr_instance_qp, random_lqr_batch
+    from random_qp import random_structure_qp
+    monkeypatch.setenv("ACADOS_AMD_WPI", "1")
+    fams = {}
+    for seed in range(40):
+        qp = random_structure_qp(seed, allow_general=False)
+        o = OracleQp(qp)
+        assert o.solve(default_opts(tol_stat=1e-8, iter_max=60)) == 0, seed
+        b = OcpQpGpuBatch.from_qps([qp] * 70)
+        for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+            b.opts_set(f, 1e-8)
+        b.opts_set("iter_max", 60)
+        assert b.solve() == 0, (seed, b.kernel_name)
+        fam = b.kernel_name.split("<")[0].split("(")[0]
+        fams[fam] = fams.get(fam, 0) + 1
+        assert abs(int(b.info("iter")[69]) - o.iter) <= 1, (seed, b.kernel_name)
+        compare_with_oracle(lambda k, f: b.get(f, k)[69], o, qp, 1e-7, fields=("x", "u", "sl", "su", "pi", "lam", "t"))
+    assert fams.get("w16-soft", 0) >= 8 and fams.get("wpi-gen", 0) >= 1, fams
+    monkeypatch.delenv("ACADOS_AMD_WPI")
+    N, nx, nu, B = 50, 8, 3, 4096
+    data = random_lqr_batch(N=N, nx=nx, nu=nu, batch=B, seed=0)
+    d = lqr_dims(N, nx, nu)
+    d.nbx[1:] = nx
+    d.nb[:] = d.nbu + d.nbx
+    d.ns[1:] = nx
+    gb = OcpQpGpuBatch(d, B)
+    for k in range(1, N + 1):
+        gb.set_int("idxs_rev", k, np.concatenate([-np.ones(int(d.nbu[k]), dtype=int), np.arange(nx)]))
+    fill_lqr_batch(gb, data, N)
+    for k in range(1, N + 1):
+        gb.set("lbx", k, np.full((B, nx), -1.0)); gb.set("ubx", k, np.full((B, nx), 1.0))
+        for f, v in (("Zl", 1e2), ("Zu", 1e2), ("zl", 1e1), ("zu", 1e1), ("lls", 0.0), ("lus", 0.0)):
+            gb.set(f, k, np.full((B, nx), v))
+    for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+        gb.opts_set(f, 1e-8)
+    assert gb.solve() == 0 and gb.kernel_name == "w16-soft<NX=8,NU=3>"
+    for n_ in ("res_stat", "res_eq", "res_ineq", "res_comp"):
+        assert gb.info(n_).max() <= 1e-8
+    viol = 0.0
+    for k in range(1, N + 1):
+        x, sl, su = gb.get("x", k), gb.get("sl", k), gb.get("su", k)
+        assert sl.min() >= -1e-9 and su.min() >= -1e-9
+        assert np.all(x >= -1.0 - sl - 1e-7) and np.all(x <= 1.0 + su + 1e-7)
+        viol = max(viol, float(sl.max()), float(su.max()))
+    assert viol > 1e-2   # the soft bounds are really used
+    for i in (0, 1365, 2730, 4095):
+        qp = lqr_instance_qp(data, i, N)
+        for k in range(1, N + 1):
+            nuk = nu if k < N else 0
+            qp.set("idxb", k, np.arange(nuk + nx))
+            qp.set("lbx", k, -np.ones(nx)); qp.set("ubx", k, np.ones(nx))
+            qp.set("lbx_mask", k, np.ones(nx)); qp.set("ubx_mask", k, np.ones(nx))
+            qp.set("idxs_rev", k, np.concatenate([-np.ones(nuk, dtype=int), np.arange(nx)]))
+            for f, v in (("Zl", 1e2), ("Zu", 1e2), ("zl", 1e1), ("zu", 1e1), ("lls", 0.0), ("lus", 0.0)):
+                qp.set(f, k, v * np.ones(nx))
+        qp.make_consistent()
+        o = OracleQp(qp)
+        assert o.solve(default_opts(tol_stat=1e-8)) == 0
+        compare_with_oracle(lambda k, f: gb.get(f, k)[i], o, qp, 1e-7, fields=("x", "u", "sl", "su", "pi", "lam", "t"))

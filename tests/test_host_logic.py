@@ -903,3 +903,54 @@ def test_solution_sensitivities_after_partial_condensing_hostsim(hostsim_lib, mo
     ref.sens_solve()
     se = xu(ref, "sens_")
     assert np.max(np.abs(fd - se)) <= 1e-5 * max(1.0, np.max(np.abs(se)))
+
+
+def test_sixteen_lanes_soft_box_rows_hostsim(hostsim_lib, monkeypatch):
+    """SOFT variants of the sixteen-lanes kernels: soft box rows with one slack per row (slack block eliminated inside
+    the lane that owns the row), mixed with hard rows, one-sided rows, per-stage dims; structures with a slack shared
+    by several rows fall back to the general wave-per-instance kernels.  40 random structures without general rows
+    (tests/random_qp.py) + the C2 shape with soft bounds on every state, against the oracle."""
+    from acados_amd import AcadosOcpQp, OcpQpGpuBatch
+    from acados_amd.generators import lqr_instance_qp, random_lqr_batch
+    from random_qp import random_structure_qp
+    monkeypatch.setenv("ACADOS_AMD_WPI", "1")
+    names = {}
+    for seed in range(40):
+        qp = random_structure_qp(seed, allow_general=False)
+        o = OracleQp(qp)
+        assert o.solve(default_opts(tol_stat=1e-8, iter_max=60)) == 0, seed
+        b = OcpQpGpuBatch.from_qps([qp] * 5, _clib=hostsim_lib)
+        for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+            b.opts_set(f, 1e-8)
+        b.opts_set("iter_max", 60)
+        assert b.solve() == 0, (seed, b.kernel_name)
+        fam = b.kernel_name.split("<")[0].split("(")[0]
+        names[fam] = names.get(fam, 0) + 1
+        shared = any(np.sum(np.asarray(qp.idxs_rev[k]) == j) > 1 for k in range(qp.N + 1) for j in range(int(qp.dims.ns[k])))
+        if int(np.sum(qp.dims.ns)) > 0:
+            assert fam == ("wpi-gen" if shared else "w16-soft"), (seed, b.kernel_name, shared)
+        assert abs(int(b.info("iter")[4]) - o.iter) <= 1, (seed, b.kernel_name)
+        try:
+            compare_with_oracle(lambda k, f: b.get(f, k)[4], o, qp, 1e-7, fields=("x", "u", "sl", "su", "pi", "lam", "t"))
+        except AssertionError as e:
+            raise AssertionError(f"seed {seed} kernel {b.kernel_name}: {e}")
+    assert names.get("w16-soft", 0) >= 8 and names.get("wpi-gen", 0) >= 1 and names.get("w16-box", 0) >= 5, names
+    # C2 shape, every state bound soft from stage 1 on
+    N, nx, nu = 6, 8, 3
+    data = random_lqr_batch(N=N, nx=nx, nu=nu, batch=2, seed=3)
+    qps = []
+    for i in range(2):
+        qp = lqr_instance_qp(data, i, N)
+        for k in range(1, N + 1):
+            nuk = nu if k < N else 0
+            qp.set("idxb", k, np.arange(nuk + nx))
+            qp.set("lbx", k, -0.5 * np.ones(nx)); qp.set("ubx", k, 0.5 * np.ones(nx))
+            qp.set("lbx_mask", k, np.ones(nx)); qp.set("ubx_mask", k, np.ones(nx))
+            qp.set("idxs_rev", k, np.concatenate([-np.ones(nuk, dtype=int), np.arange(nx)]))
+            for f, v in (("Zl", 1e2), ("Zu", 1e2), ("zl", 1e1), ("zu", 1e1), ("lls", 0.0), ("lus", 0.0)):
+                qp.set(f, k, v * np.ones(nx))
+        qp.make_consistent()
+        qps.append(qp)
+    b = _check_batch_vs_oracle(qps, hostsim_lib)
+    assert b.kernel_name == "w16-soft<NX=8,NU=3>"
+    assert max(float(np.max(b.get("sl", k))) for k in range(1, N + 1)) > 1e-3   # some soft bound is really violated
