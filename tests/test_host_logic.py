@@ -954,3 +954,51 @@ def test_sixteen_lanes_soft_box_rows_hostsim(hostsim_lib, monkeypatch):
     b = _check_batch_vs_oracle(qps, hostsim_lib)
     assert b.kernel_name == "w16-soft<NX=8,NU=3>"
     assert max(float(np.max(b.get("sl", k))) for k in range(1, N + 1)) > 1e-3   # some soft bound is really violated
+
+
+def test_solution_sensitivities_soft_box_rows_hostsim(hostsim_lib, monkeypatch):
+    """sensitivities on the SOFT sixteen-lanes kernels (C2 shape, soft bounds on every state): x0 seed against finite
+    differences, slack sensitivities included"""
+    from acados_amd import OcpQpGpuBatch
+    from acados_amd.generators import fill_lqr_batch, lqr_dims, random_lqr_batch
+    monkeypatch.setenv("ACADOS_AMD_WPI", "1")
+    N, B, nx, nu = 4, 2, 8, 3
+    data = random_lqr_batch(N=N, batch=B, seed=3)
+
+    def build(dd):
+        d = lqr_dims(N, nx, nu)
+        d.nbx[1:] = nx
+        d.nb[:] = d.nbu + d.nbx
+        d.ns[1:] = nx
+        gb = OcpQpGpuBatch(d, B, _clib=hostsim_lib)
+        for k in range(1, N + 1):
+            gb.set_int("idxs_rev", k, np.concatenate([-np.ones(int(d.nbu[k]), dtype=int), np.arange(nx)]))
+        fill_lqr_batch(gb, dd, N)
+        for k in range(1, N + 1):
+            gb.set("lbx", k, np.full((B, nx), -0.5)); gb.set("ubx", k, np.full((B, nx), 0.5))
+            for f, v in (("Zl", 1e2), ("Zu", 1e2), ("zl", 1e1), ("zu", 1e1), ("lls", 0.0), ("lus", 0.0)):
+                gb.set(f, k, np.full((B, nx), v))
+        for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+            gb.opts_set(f, 1e-8)
+        assert gb.solve() == 0
+        return gb
+
+    def xus(g, pre=""):
+        return np.concatenate([g.get(pre + "x", k) for k in range(N + 1)] + [g.get(pre + "u", k) for k in range(N)]
+                              + [g.get(pre + "sl", k) for k in range(1, N + 1)] + [g.get(pre + "su", k) for k in range(1, N + 1)], axis=1)
+
+    ref = build(data)
+    assert ref.kernel_name == "w16-soft<NX=8,NU=3>"
+    e = np.zeros((B, nx)); e[:, 2] = 1.0
+    h = 1e-3
+    sols = []
+    for sg in (+h, -h):
+        d = {k: v.copy() for k, v in data.items()}
+        d["x0"][:, 2] += sg
+        sols.append(xus(build(d)))
+    fd = (sols[0] - sols[1]) / (2 * h)
+    ref.sens_set("seed_lbx", 0, e); ref.sens_set("seed_ubx", 0, e)
+    ref.sens_solve()
+    se = xus(ref, "sens_")
+    assert np.max(np.abs(se[:, -2 * N * nx:])) > 1e-3          # some slack moves with x0
+    assert np.max(np.abs(fd - se)) <= 5e-5 * np.max(np.abs(se))
