@@ -107,6 +107,15 @@ __device__ static inline double w16_rmin(double v, double *xb)
     return r;
 }
 
+/* slack index of sorted box row ib (< 16 here) without a lane-indexed memory access: the first 16 entries of the
+ * stage's row -> slack map are two uniform 64-bit words, the lane picks its byte */
+__device__ static inline int w16_srev(const GqpStage &S, int ib)
+{
+    const uint64_t *sp = reinterpret_cast<const uint64_t *>(S.srev);
+    const uint64_t w = ib < 8 ? sp[0] : sp[1];
+    return (int) (int8_t) (w >> ((ib & 7) * 8));
+}
+
 /* ------------------------------------------------------------------------------------------------ factor */
 
 /* SOFT: box rows may be soft, every slack belongs to exactly ONE box row (no general rows, no shared slacks -- the
@@ -160,19 +169,11 @@ __global__ void __launch_bounds__(64) kx_factor(GqpDev D, GqpOpts O, int redo)
         const double ttl = al ? WAT(D.t, el) : 1.0, ttu = au ? WAT(D.t, eu) : 1.0;
         const double lbv = al ? WAT(D.dvec, el) : 0.0, ubv = au ? WAT(D.dvec, eu) : 0.0;
         /* SOFT: the slack of this lane's row (values, cost, its two bound rows) */
-        const int sj = (SOFT && has) ? (int) S.srev[ib] : -1;
+        const int sj = (SOFT && has) ? w16_srev(S, ib) : -1;
         const int sq = sj >= 0 ? sj : 0, se0 = S.o_ct + 2 * nbg + sq, se1 = se0 + S.ns;
         const bool sal = sj >= 0 && ((am >> (2 * nbg + sq)) & 1), sau = sj >= 0 && ((am >> (2 * nbg + S.ns + sq)) & 1);
-        double ssl = 0.0, ssu = 0.0, sll = 0.0, slu = 0.0, stl = 1.0, stu = 1.0, sdl = 0.0, sdu = 0.0, sZl = 0.0, szl = 0.0, sZu = 0.0, szu = 0.0;
-        if (SOFT && sj >= 0)
-        {
-            ssl = WAT(D.sv, S.o_s + sq); ssu = WAT(D.sv, S.o_s + S.ns + sq);
-            sll = sal ? WAT(D.lam, se0) : 0.0; slu = sau ? WAT(D.lam, se1) : 0.0;
-            stl = sal ? WAT(D.t, se0) : 1.0; stu = sau ? WAT(D.t, se1) : 1.0;
-            sdl = sal ? WAT(D.dvec, se0) : 0.0; sdu = sau ? WAT(D.dvec, se1) : 0.0;
-            sZl = WAT(D.Zz, (S.o_s + sq) * 2); szl = WAT(D.Zz, (S.o_s + sq) * 2 + 1);
-            sZu = WAT(D.Zz, (S.o_s + S.ns + sq) * 2); szu = WAT(D.Zz, (S.o_s + S.ns + sq) * 2 + 1);
-        }
+        double ssl = 0.0, ssu = 0.0;
+        if (SOFT && sj >= 0) { ssl = WAT(D.sv, S.o_s + sq); ssu = WAT(D.sv, S.o_s + S.ns + sq); }
 
         /* ---- rb += [B A] v, H v (one broadcast of v per variable serves both) ---- */
         double hv = 0.0;
@@ -208,6 +209,13 @@ __global__ void __launch_bounds__(64) kx_factor(GqpDev D, GqpOpts O, int redo)
             WAT(D.rd, eu) = rdu;
             if (SOFT && sj >= 0)
             {
+                /* loaded here, not with the stage's other loads: the kernel sits at the 256-VGPR line (two waves per
+                 * SIMD) and these twelve values would stay live across the broadcast loops above */
+                const double sll = sal ? WAT(D.lam, se0) : 0.0, slu = sau ? WAT(D.lam, se1) : 0.0;
+                const double stl = sal ? WAT(D.t, se0) : 1.0, stu = sau ? WAT(D.t, se1) : 1.0;
+                const double sdl = sal ? WAT(D.dvec, se0) : 0.0, sdu = sau ? WAT(D.dvec, se1) : 0.0;
+                const double sZl = WAT(D.Zz, (S.o_s + sq) * 2), szl = WAT(D.Zz, (S.o_s + sq) * 2 + 1);
+                const double sZu = WAT(D.Zz, (S.o_s + S.ns + sq) * 2), szu = WAT(D.Zz, (S.o_s + S.ns + sq) * 2 + 1);
                 obj += (0.5 * sZl * ssl + szl) * ssl + (0.5 * sZu * ssu + szu) * ssu;
                 const double srdl = sal ? ssl - sdl - stl : 0.0, srdu = sau ? ssu - sdu - stu : 0.0;
                 const double srml = sal ? sll * stl - O.tau_min : 0.0, srmu = sau ? slu * stu - O.tau_min : 0.0;
@@ -377,6 +385,23 @@ __global__ void __launch_bounds__(64) kx_backrhs(GqpDev D, GqpOpts O, int redo)
         const double rb = zx * WAT(D.rb, k * NX + xc_);
         double m = zm * WAT(D.rg, k * n + lc_);
         const bool has = mine && ((imask >> l) & 1);
+        /* SOFT: the loads of the row's slack, issued with the stage's other loads */
+        const int ibs = (SOFT && has) ? popc64(S.bmask & (((uint64_t) 1 << l) - 1)) : 0;
+        const int sj = (SOFT && has) ? w16_srev(S, ibs) : -1;
+        const int sq = sj >= 0 ? sj : 0, e0 = S.o_ct + 2 * nbg + sq, e1 = e0 + S.ns;
+        const bool sal = sj >= 0 && ((am >> (2 * nbg + sq)) & 1), sau = sj >= 0 && ((am >> (2 * nbg + S.ns + sq)) & 1);
+        double sll = 0.0, slu = 0.0, stl = 1.0, stu = 1.0, srdl = 0.0, srdu = 0.0, spl = 0.0, spu = 0.0, sgl = 0.0, sgu = 0.0,
+               sZl = 0.0, sZu = 0.0, sDl = 0.0, sDu = 0.0;
+        if (SOFT && sj >= 0)
+        {
+            sll = sal ? WAT(D.lam, e0) : 0.0; slu = sau ? WAT(D.lam, e1) : 0.0;
+            stl = sal ? WAT(D.t, e0) : 1.0; stu = sau ? WAT(D.t, e1) : 1.0;
+            srdl = sal ? WAT(D.rd, e0) : 0.0; srdu = sau ? WAT(D.rd, e1) : 0.0;
+            spl = sal ? WAT(D.pcorr, e0) : 0.0; spu = sau ? WAT(D.pcorr, e1) : 0.0;
+            sgl = WAT(D.rgs, S.o_s + sq); sgu = WAT(D.rgs, S.o_s + S.ns + sq);
+            sZl = WAT(D.Zz, (S.o_s + sq) * 2); sZu = WAT(D.Zz, (S.o_s + S.ns + sq) * 2);
+            sDl = WAT(D.sD, S.o_s + sq); sDu = WAT(D.sD, S.o_s + S.ns + sq);
+        }
         if (has)
         {
             const int ib = popc64(S.bmask & (((uint64_t) 1 << l) - 1));
@@ -389,25 +414,17 @@ __global__ void __launch_bounds__(64) kx_backrhs(GqpDev D, GqpOpts O, int redo)
             const double rmu = au ? lu * ttu - O.tau_min + pscale * WAT(D.pcorr, eu) - smu : 0.0;
             const double itl = frcp(ttl), itu = frcp(ttu);
             const double bRl = (rml + ll * rdl) * itl, bRu = (rmu + lu * rdu) * itu;
-            const int sj = SOFT ? (int) S.srev[ib] : -1;
             if (!SOFT || sj < 0) m += bRl - bRu;
             else
             {
                 const double bGl = ll * itl, bGu = lu * itu;
-                const int e0 = S.o_ct + 2 * nbg + sj, e1 = e0 + S.ns;
-                const bool sal = (am >> (2 * nbg + sj)) & 1, sau = (am >> (2 * nbg + S.ns + sj)) & 1;
-                const double sll = sal ? WAT(D.lam, e0) : 0.0, slu = sau ? WAT(D.lam, e1) : 0.0;
-                const double stl = sal ? WAT(D.t, e0) : 1.0, stu = sau ? WAT(D.t, e1) : 1.0;
-                const double srdl = sal ? WAT(D.rd, e0) : 0.0, srdu = sau ? WAT(D.rd, e1) : 0.0;
-                const double srml = sal ? sll * stl - O.tau_min + pscale * WAT(D.pcorr, e0) - smu : 0.0;
-                const double srmu = sau ? slu * stu - O.tau_min + pscale * WAT(D.pcorr, e1) - smu : 0.0;
+                const double srml = sal ? sll * stl - O.tau_min + pscale * spl - smu : 0.0;
+                const double srmu = sau ? slu * stu - O.tau_min + pscale * spu - smu : 0.0;
                 const double sitl = frcp(stl), situ = frcp(stu);
-                const double Xl = WAT(D.rgs, S.o_s + sj) + (srml + sll * srdl) * sitl;            /* r~ without the row */
-                const double Xu = WAT(D.rgs, S.o_s + S.ns + sj) + (srmu + slu * srdu) * situ;
-                const double El = WAT(D.Zz, (S.o_s + sj) * 2) + sll * sitl, Eu = WAT(D.Zz, (S.o_s + S.ns + sj) * 2) + slu * situ;
+                const double Xl = sgl + (srml + sll * srdl) * sitl, Xu = sgu + (srmu + slu * srdu) * situ; /* r~ without the row */
+                const double El = sZl + sll * sitl, Eu = sZu + slu * situ;
                 WAT(D.sR, S.o_s + sj) = Xl + bRl; WAT(D.sR, S.o_s + S.ns + sj) = Xu + bRu;
-                const double Dl = WAT(D.sD, S.o_s + sj), Du = WAT(D.sD, S.o_s + S.ns + sj);
-                const double Il = Dl != 0.0 ? frcp(Dl) : 0.0, Iu = Du != 0.0 ? frcp(Du) : 0.0;
+                const double Il = sDl != 0.0 ? frcp(sDl) : 0.0, Iu = sDu != 0.0 ? frcp(sDu) : 0.0;
                 m += (bRl * El - bGl * Xl) * Il - (bRu * Eu - bGu * Xu) * Iu;
             }
         }
@@ -488,6 +505,23 @@ __global__ void __launch_bounds__(64) kx_fwd(GqpDev D, GqpOpts O, int redo)
         const double ttl = al ? WAT(D.t, el) : 1.0, ttu = au ? WAT(D.t, eu) : 1.0;
         const double rdl = al ? WAT(D.rd, el) : 0.0, rdu = au ? WAT(D.rd, eu) : 0.0;
         const double pl = (CORR && al) ? WAT(D.pcorr, el) : 0.0, pu = (CORR && au) ? WAT(D.pcorr, eu) : 0.0;
+        /* SOFT: everything the slack of this lane's row needs, issued with the other loads of the stage (the
+         * substitution below hides their latency) */
+        const int sj = (SOFT && has) ? w16_srev(S, ib) : -1;
+        const int sq = sj >= 0 ? sj : 0, e0 = S.o_ct + 2 * nbg + sq, e1 = e0 + S.ns;
+        const bool sal = sj >= 0 && ((am >> (2 * nbg + sq)) & 1), sau = sj >= 0 && ((am >> (2 * nbg + S.ns + sq)) & 1);
+        double sll = 0.0, slu = 0.0, stl = 1.0, stu = 1.0, sDl = 0.0, sDu = 0.0, rsl = 0.0, rsu = 0.0, sZl = 0.0, sZu = 0.0,
+               spl = 0.0, spu = 0.0, srdl = 0.0, srdu = 0.0;
+        if (SOFT && sj >= 0)
+        {
+            sll = sal ? WAT(D.lam, e0) : 0.0; slu = sau ? WAT(D.lam, e1) : 0.0;
+            stl = sal ? WAT(D.t, e0) : 1.0; stu = sau ? WAT(D.t, e1) : 1.0;
+            sDl = WAT(D.sD, S.o_s + sq); sDu = WAT(D.sD, S.o_s + S.ns + sq);
+            rsl = WAT(D.sR, S.o_s + sq); rsu = WAT(D.sR, S.o_s + S.ns + sq);
+            sZl = WAT(D.Zz, (S.o_s + sq) * 2); sZu = WAT(D.Zz, (S.o_s + S.ns + sq) * 2);
+            spl = (CORR && sal) ? WAT(D.pcorr, e0) : 0.0; spu = (CORR && sau) ? WAT(D.pcorr, e1) : 0.0;
+            srdl = sal ? WAT(D.rd, e0) : 0.0; srdu = sau ? WAT(D.rd, e1) : 0.0;
+        }
         GQP_ROWSYNC();
         if (mine)
         {
@@ -541,28 +575,20 @@ __global__ void __launch_bounds__(64) kx_fwd(GqpDev D, GqpOpts O, int redo)
             const double rml = al ? ll * ttl - O.tau_min + pscale * pl - smu : 0.0;
             const double rmu = au ? lu * ttu - O.tau_min + pscale * pu - smu : 0.0;
             double dcl = dv, dcu = -dv; /* dc + ds resp. -dc + ds: the row's own slack step included (SOFT) */
-            const int sj = SOFT ? (int) S.srev[ib] : -1;
             if (SOFT && sj >= 0)
             {
-                const int e0 = S.o_ct + 2 * nbg + sj, e1 = e0 + S.ns;
-                const bool sal = (am >> (2 * nbg + sj)) & 1, sau = (am >> (2 * nbg + S.ns + sj)) & 1;
-                const double sll = sal ? WAT(D.lam, e0) : 0.0, slu = sau ? WAT(D.lam, e1) : 0.0;
-                const double stl = sal ? WAT(D.t, e0) : 1.0, stu = sau ? WAT(D.t, e1) : 1.0;
-                const double Dl = WAT(D.sD, S.o_s + sj), Du = WAT(D.sD, S.o_s + S.ns + sj);
-                const double rsl = WAT(D.sR, S.o_s + sj), rsu = WAT(D.sR, S.o_s + S.ns + sj);
-                const double il = Dl != 0.0 ? frcp(Dl) : 0.0, iu = Du != 0.0 ? frcp(Du) : 0.0;
+                const double il = sDl != 0.0 ? frcp(sDl) : 0.0, iu = sDu != 0.0 ? frcp(sDu) : 0.0;
                 const double gl_ = ll * frcp(ttl), gu_ = lu * frcp(ttu);
                 const double dsl = (-rsl - gl_ * dv) * il, dsu = (-rsu + gu_ * dv) * iu;
                 if (CORR) { WAT(D.dsv, S.o_s + sj) = dsl; WAT(D.dsv, S.o_s + S.ns + sj) = dsu; }
                 const double sitl = frcp(stl), situ = frcp(stu);
-                const double El = WAT(D.Zz, (S.o_s + sj) * 2) + sll * sitl, Eu = WAT(D.Zz, (S.o_s + S.ns + sj) * 2) + slu * situ;
+                const double El = sZl + sll * sitl, Eu = sZu + slu * situ;
                 dcl = (El * dv - rsl) * il;
                 dcu = (-Eu * dv - rsu) * iu;
                 /* the two bound rows of the slack */
-                const double spl = (CORR && sal) ? WAT(D.pcorr, e0) : 0.0, spu = (CORR && sau) ? WAT(D.pcorr, e1) : 0.0;
                 const double srml = sal ? sll * stl - O.tau_min + pscale * spl - smu : 0.0;
                 const double srmu = sau ? slu * stu - O.tau_min + pscale * spu - smu : 0.0;
-                const double sdtl = sal ? dsl + WAT(D.rd, e0) : 0.0, sdtu = sau ? dsu + WAT(D.rd, e1) : 0.0;
+                const double sdtl = sal ? dsl + srdl : 0.0, sdtu = sau ? dsu + srdu : 0.0;
                 const double sdll = sal ? -(srml + sll * sdtl) * sitl : 0.0, sdlu = sau ? -(srmu + slu * sdtu) * situ : 0.0;
                 const double q1 = -sll * frcp(sdll), q2 = -slu * frcp(sdlu), q3 = -stl * frcp(sdtl), q4 = -stu * frcp(sdtu);
                 alpha = (sdll < 0.0 && q1 < alpha) ? q1 : alpha;
@@ -677,7 +703,7 @@ __global__ void __launch_bounds__(64) kx_fwd(GqpDev D, GqpOpts O, int redo)
             if (au) { lam_[eu] = lamu < O.lam_min ? O.lam_min : lamu; t_[eu] = tu < O.t_min ? O.t_min : tu; }
             if (SOFT && has)
             {
-                const int sj = (int) st_[k].srev[ib];
+                const int sj = w16_srev(st_[k], ib);
                 if (sj >= 0)
                 {
                     const int ns = st_[k].ns, o_s = st_[k].o_s;

@@ -31,5 +31,8 @@ for soft in (0, 1):
     bad = gb.solve()
     t0 = time.perf_counter(); bad = gb.solve(); dt = time.perf_counter() - t0
     it = gb.info("iter")
+    gb.scalar("prof_reset"); gb.opts_set("profile", 1); gb.solve(); gb.opts_set("profile", 0)
+    cls = ("back_fact", "fwd_aff", "back_rhs", "fwd_corr")
+    print("    avg ms per launch: " + "  ".join(f"{c} {gb.scalar('prof_ms_' + c) / max(gb.scalar('prof_cnt_' + c), 1):.3f}" for c in cls))
     print(f"{'soft' if soft else 'hard'} state bounds: kernel {gb.kernel_name:40s} batch {B}  {dt*1e3:8.1f} ms  {B/dt:10.0f} solves/s  "
           f"iters {it.mean():.1f}/{it.max()}  failures {bad}", flush=True)
