@@ -681,7 +681,8 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
         bool xbox_dims = false;
         for (int k = 1; k <= N; k++) xbox_dims = xbox_dims || nbx[k] > 0;
         const int batch_max = bm ? atoi(bm) : (has_w16 ? (xbox_dims ? INT_MAX : GQP_W16_BATCH_MAX) : GQP_WPI_BATCH_MAX);
-        const bool want = g_force_wpi || need_wpi || (env ? atoi(env) != 0 : (wx + wu >= GQP_WPI_MIN_N || !b->ks || n_batch <= batch_max));
+        /* (a shape no compiled one-instance-per-lane set covers runs here whatever the override says) */
+        const bool want = g_force_wpi || need_wpi || !b->ks || (env ? atoi(env) != 0 : (wx + wu >= GQP_WPI_MIN_N || n_batch <= batch_max));
         if (want && wx + wu <= 64 && wx >= 1 && mg <= 32 && ms <= 32)
         {
             if (w16) { wx = w16->NX; wu = w16->NU; }

@@ -1002,3 +1002,31 @@ def test_solution_sensitivities_soft_box_rows_hostsim(hostsim_lib, monkeypatch):
     se = xus(ref, "sens_")
     assert np.max(np.abs(se[:, -2 * N * nx:])) > 1e-3          # some slack moves with x0
     assert np.max(np.abs(fd - se)) <= 5e-5 * np.max(np.abs(se))
+
+
+@pytest.mark.parametrize("wpi", ["0", "1"])
+def test_random_structures_larger_dims_hostsim(hostsim_lib, monkeypatch, wpi):
+    """random structures with nx up to 12 and nu up to 4 (every second one without general rows): whatever family the
+    dispatch picks -- one-instance-per-lane general / box kernels, wave-per-instance GEN, sixteen-lanes box / soft,
+    padded into <12,3> / <12,4> -- against the oracle; a shape no compiled one-instance-per-lane set covers runs on the
+    wave-per-instance family even when the test override asks for the other one"""
+    from acados_amd import OcpQpGpuBatch
+    from random_qp import random_structure_qp
+    monkeypatch.setenv("ACADOS_AMD_WPI", wpi)
+    fams = set()
+    for seed in range(100, 130):
+        qp = random_structure_qp(seed, nx_max=12, nu_max=4, allow_general=(seed % 2 == 0))
+        o = OracleQp(qp)
+        assert o.solve(default_opts(tol_stat=1e-8, iter_max=80)) == 0, seed
+        b = OcpQpGpuBatch.from_qps([qp] * 3, _clib=hostsim_lib)
+        for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+            b.opts_set(f, 1e-8)
+        b.opts_set("iter_max", 80)
+        assert b.solve() == 0, (seed, b.kernel_name)
+        fams.add(b.kernel_name.split("<")[0].split("(")[0])
+        assert abs(int(b.info("iter")[2]) - o.iter) <= 1, (seed, b.kernel_name)
+        try:
+            compare_with_oracle(lambda k, f: b.get(f, k)[2], o, qp, 1e-7, fields=("x", "u", "sl", "su", "pi", "lam", "t"))
+        except AssertionError as e:
+            raise AssertionError(f"seed {seed} kernel {b.kernel_name}: {e}")
+    assert len(fams) >= 3, fams
