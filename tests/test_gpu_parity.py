@@ -653,3 +653,26 @@ def test_sixteen_lanes_soft_box_rows_gpu(gpu_lib, monkeypatch):
         o = OracleQp(qp)
         assert o.solve(default_opts(tol_stat=1e-8)) == 0
         compare_with_oracle(lambda k, f: gb.get(f, k)[i], o, qp, 1e-7, fields=("x", "u", "sl", "su", "pi", "lam", "t"))
+
+
+@pytest.mark.gpu
+def test_random_structures_large_dims_gpu(gpu_lib):
+    """random structures with nx up to 40 and nu up to 8 (tile counts T8 = 1..6 of the wave-per-instance GEN kernels,
+    stages with more than 64 inequality sides) and nx up to 12 / nu up to 4 (the padded sixteen-lanes shapes, hard and
+    soft), default dispatch, 70 copies each, against the oracle"""
+    from acados_amd import OcpQpGpuBatch
+    from random_qp import random_structure_qp
+    fams = set()
+    for seed, (nxm, num) in [(s, (40, 8)) for s in range(200, 220)] + [(s, (12, 4)) for s in range(100, 130)]:
+        qp = random_structure_qp(seed, nx_max=nxm, nu_max=num, allow_general=(seed % 2 == 0))
+        o = OracleQp(qp)
+        assert o.solve(default_opts(tol_stat=1e-8, iter_max=80)) == 0, seed
+        b = OcpQpGpuBatch.from_qps([qp] * 70)
+        for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+            b.opts_set(f, 1e-8)
+        b.opts_set("iter_max", 80)
+        assert b.solve() == 0, (seed, b.kernel_name)
+        fams.add(b.kernel_name.split("<")[0].split("(")[0])
+        assert abs(int(b.info("iter")[69]) - o.iter) <= 1, (seed, b.kernel_name)
+        compare_with_oracle(lambda k, f: b.get(f, k)[69], o, qp, 3e-7, fields=("x", "u", "sl", "su", "pi", "lam", "t"))
+    assert len(fams) >= 3, fams
