@@ -581,8 +581,9 @@ extern "C" {
 
 static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu, const int *nbx, const int *nbu,
                                             const int *ng, const int *ns, int n_batch, int device, int force_NX, int force_NU);
-static const KernelSet *g_force_ks = nullptr; /* set only while a compaction sub-batch is being created */
-static bool g_force_wpi = false;              /* set only while a tail sub-batch is being created */
+/* per thread: the reference's batch idiom solves distinct capsules from OpenMP threads (acados_solver.in.c:3232-3236) */
+static thread_local const KernelSet *g_force_ks = nullptr; /* set only while a compaction sub-batch is being created */
+static thread_local bool g_force_wpi = false;              /* set only while a tail sub-batch is being created */
 
 ocp_qp_gpu_batch *ocp_qp_gpu_batch_create(int N, const int *nx, const int *nu, const int *nbx, const int *nbu,
                                           const int *ng, const int *ns, int n_batch, int device)

@@ -579,8 +579,8 @@ void ocp_qp_gpu_ipm_memory_get(void *config, void *mem_, const char *field, void
 
 acados_size_t ocp_qp_gpu_ipm_workspace_calculate_size(void *config, void *dims, void *opts) { return 0; }
 
-static int g_cond_N_request = 0; /* set by the xcond level right before evaluate (single-threaded handoff) */
-static const int *g_cond_blocks_request = nullptr;
+static thread_local int g_cond_N_request = 0; /* set by the xcond level right before evaluate (same thread) */
+static thread_local const int *g_cond_blocks_request = nullptr;
 
 int ocp_qp_gpu_ipm_evaluate_batch(void *config, int n, void **qp_in_, void **qp_out_, void *opts_, void **mem_,
                                   void *work, int *status)

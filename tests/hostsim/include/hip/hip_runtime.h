@@ -25,7 +25,7 @@
 #define __device__
 #define __host__
 #define __forceinline__ inline
-#define __shared__ static /* one simulated lane at a time: a lane only reads what it wrote */
+#define __shared__ static thread_local /* shared by the simulated lanes of the calling host thread */
 #define __launch_bounds__(...)
 
 struct dim3
@@ -93,7 +93,7 @@ struct hostsim_coop
         std::function<void()> body;
     };
     static state &st() { static thread_local state s; return s; }
-    static std::vector<double> &dyn() { static std::vector<double> v; return v; }
+    static std::vector<double> &dyn() { static thread_local std::vector<double> v; return v; }
     static void yield() { state &s = st(); swapcontext(&s.ctx[s.cur], &s.sched); }
     static void tramp() { state &s = st(); s.body(); s.done[s.cur] = true; }
     static void run_block(unsigned nl)

@@ -676,3 +676,41 @@ def test_random_structures_large_dims_gpu(gpu_lib):
         assert abs(int(b.info("iter")[69]) - o.iter) <= 1, (seed, b.kernel_name)
         compare_with_oracle(lambda k, f: b.get(f, k)[69], o, qp, 3e-7, fields=("x", "u", "sl", "su", "pi", "lam", "t"))
     assert len(fams) >= 3, fams
+
+
+@pytest.mark.gpu
+def test_concurrent_solvers_from_host_threads_gpu(gpu_lib):
+    """the reference's batch idiom calls ocp_qp_solve from OpenMP threads on distinct solver objects
+    (acados_solver.in.c:3232-3236): four host threads, each with its own solver, own stream and own QP (one partially
+    condensed, one with soft constraints), eight solves each, reproduce the sequential results bit for bit"""
+    import threading
+    from acados_amd import AcadosOcpQpOptions, AcadosOcpQpSolver
+    from acados_amd.generators import mass_spring_qp
+    qps = [mass_spring_qp(N=15), load_qp("casadi_qp_tests/pendulum_slack.json"), mass_spring_qp(N=12),
+           load_qp("qp_test/last_qp_one_sided_test.json")]
+    condN = [5, None, None, None]
+
+    def run(i, out):
+        opts = AcadosOcpQpOptions()
+        opts.tol_stat = opts.tol_eq = opts.tol_ineq = opts.tol_comp = 1e-8
+        if condN[i]:
+            opts.cond_N = condN[i]
+        s = AcadosOcpQpSolver(qps[i], opts)
+        res = []
+        for _ in range(8):
+            assert s.solve() == 0
+            res.append(np.concatenate([s.get(k, "x") for k in range(qps[i].N + 1)] + [s.get(k, "lam", unique_duals=False) for k in range(qps[i].N + 1)]))
+        out[i] = res
+
+    seq, par = {}, {}
+    for i in range(4):
+        run(i, seq)
+    th = [threading.Thread(target=run, args=(i, par)) for i in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for i in range(4):
+        assert len(par.get(i, [])) == 8
+        for a, c in zip(seq[i], par[i]):
+            assert np.array_equal(a, c), i

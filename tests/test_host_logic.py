@@ -1030,3 +1030,41 @@ def test_random_structures_larger_dims_hostsim(hostsim_lib, monkeypatch, wpi):
         except AssertionError as e:
             raise AssertionError(f"seed {seed} kernel {b.kernel_name}: {e}")
     assert len(fams) >= 3, fams
+
+
+def test_concurrent_solvers_from_host_threads_hostsim(hostsim_lib):
+    """the reference's batch idiom calls ocp_qp_solve from OpenMP threads on distinct solver objects
+    (acados_solver.in.c:3232-3236): four host threads, each with its own solver and its own QP (one of them partially
+    condensed, one with soft constraints), must reproduce the sequential results bit for bit"""
+    import threading
+    from acados_amd import AcadosOcpQpOptions, AcadosOcpQpSolver
+    from acados_amd.generators import mass_spring_qp
+    qps = [mass_spring_qp(N=15), load_qp("casadi_qp_tests/pendulum_slack.json"), mass_spring_qp(N=12),
+           load_qp("qp_test/last_qp_one_sided_test.json")]
+    condN = [5, None, None, None]
+
+    def run(i, out):
+        opts = AcadosOcpQpOptions()
+        opts.tol_stat = opts.tol_eq = opts.tol_ineq = opts.tol_comp = 1e-8
+        if condN[i]:
+            opts.cond_N = condN[i]
+        s = AcadosOcpQpSolver(qps[i], opts, _clib=hostsim_lib)
+        res = []
+        for _ in range(3):
+            assert s.solve() == 0
+            res.append(np.concatenate([s.get(k, "x") for k in range(qps[i].N + 1)] + [s.get(k, "lam", unique_duals=False) for k in range(qps[i].N + 1)]))
+        out[i] = res
+
+    seq = {}
+    for i in range(4):
+        run(i, seq)
+    par = {}
+    th = [threading.Thread(target=run, args=(i, par)) for i in range(4)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    for i in range(4):
+        assert len(par[i]) == 3
+        for a, c in zip(seq[i], par[i]):
+            assert np.array_equal(a, c), i
