@@ -1068,3 +1068,26 @@ def test_concurrent_solvers_from_host_threads_hostsim(hostsim_lib):
         assert len(par[i]) == 3
         for a, c in zip(seq[i], par[i]):
             assert np.array_equal(a, c), i
+
+
+@pytest.mark.parametrize("fam", ["0", "1"])
+def test_degenerate_sizes_hostsim(hostsim_lib, monkeypatch, fam):
+    """N = 0 (a single stage, no dynamics, no inputs) and an EMPTY batch (zero instances: solve is a no-op returning 0)"""
+    from acados_amd import AcadosOcpQp, OcpQpGpuBatch
+    from acados_amd.generators import lqr_dims
+    monkeypatch.setenv("ACADOS_AMD_WPI", fam)
+    g = np.random.default_rng(5)
+    qp = AcadosOcpQp(0)
+    M = g.standard_normal((3, 3))
+    qp.set("Q", 0, M @ M.T + np.eye(3)); qp.set("q", 0, g.standard_normal(3))
+    qp.set("R", 0, np.zeros((0, 0))); qp.set("S", 0, np.zeros((0, 3))); qp.set("r", 0, np.zeros(0))
+    qp.set("idxb", 0, np.arange(3)); qp.set("lbx", 0, -0.1 * np.ones(3)); qp.set("ubx", 0, 0.1 * np.ones(3))
+    qp.make_consistent()
+    o = OracleQp(qp)
+    assert o.solve(default_opts(tol_stat=1e-8)) == 0
+    b = OcpQpGpuBatch.from_qps([qp] * 2, _clib=hostsim_lib)
+    b.opts_set("tol_stat", 1e-8)
+    assert b.solve() == 0 and abs(int(b.info("iter")[1]) - o.iter) <= 1
+    compare_with_oracle(lambda k, f: b.get(f, k)[1], o, qp, 1e-8, fields=("x", "lam", "t"))
+    e = OcpQpGpuBatch(lqr_dims(5, 8, 3), 0, _clib=hostsim_lib)
+    assert e.solve() == 0 and e.get("x", 0).shape == (0, 8)
