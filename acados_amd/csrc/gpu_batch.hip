@@ -1073,8 +1073,8 @@ static void pcond_launch(ocp_qp_gpu_batch *b, bool expand)
     ocp_qp_gpu_batch *c = b->child;
     if (b->pc_rt || b->AW > 1 || c->AW > 1)
     {
-        if (expand) GQP_LAUNCH_COOP(gqp::kw_pexpand, dim3(b->B), dim3(64), b->pc_shmem, b->stream, b->D, c->D, b->pmap);
-        else GQP_LAUNCH_COOP(gqp::kw_pcond, dim3(b->B), dim3(64), b->pc_shmem, b->stream, b->D, c->D, b->pmap);
+        if (expand) GQP_LAUNCH_COOP(gqp::kw_pexpand, dim3(b->Bp), dim3(64), b->pc_shmem, b->stream, b->D, c->D, b->pmap);
+        else GQP_LAUNCH_COOP(gqp::kw_pcond, dim3(b->Bp), dim3(64), b->pc_shmem, b->stream, b->D, c->D, b->pmap);
     }
     else
     {

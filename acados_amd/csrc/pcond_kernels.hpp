@@ -279,6 +279,13 @@ __global__ void __launch_bounds__(64) k_pexpand(GqpDev P, GqpDev Cd, PcondMap Mp
 #define PLAT(arr, e) (arr).p[(arr).aos ? (size_t) inst * (size_t) (arr).E + (size_t) (e) \
                                        : ((size_t) (inst >> 6) * (size_t) (arr).E + (size_t) (e)) * 64 + (size_t) (inst & 63)]
 
+/* workgroup -> instance.  With a wave-tiled parent, element e of the instances 8j..8j+7 shares one 64-byte line;
+ * workgroup b runs on XCD b % 8 (each XCD has its own L2), so the eight workgroups b = 8q..8q+7 -- dispatched together
+ * -- would pull the same lines into eight L2s.  The map below gives every XCD its own eight-instance group of each
+ * 64-instance tile (XCD x: instances 8x..8x+7 of the tile), consecutive workgroups of an XCD walk through it: each
+ * line is fetched by one L2 only.  A bijection on every tile; the grid covers whole tiles. */
+__device__ static inline int pcond_inst(int b) { return ((b >> 6) << 6) + ((b & 7) << 3) + ((b >> 3) & 7); }
+
 __host__ __device__ static inline size_t pcondw_lds_doubles(int NX, int NU, int NUC)
 {
     const int n = NX + NU, NP = n * (n + 1) / 2, nc = NUC + NX, ncp = nc | 1, NPC = nc * (nc + 1) / 2;
@@ -290,7 +297,7 @@ static __global__ void __launch_bounds__(64) kw_pcond(GqpDev P, GqpDev Cd, Pcond
     GQP_DYN_SHARED(smem);
     const int NX = P.NX, NU = P.NU, n = NX + NU, NP = n * (n + 1) / 2;
     const int NUC = Cd.NU, nc = NUC + NX, ncp = nc | 1, NPC = nc * (nc + 1) / 2;
-    const int inst = blockIdx.x, lane = threadIdx.x;
+    const int inst = pcond_inst(blockIdx.x), lane = threadIdx.x;
     if (inst >= P.B) return;
     double *H = smem, *Bl = H + NP, *X = Bl + n * NX, *Xn = X + NX * ncp, *T = Xn + NX * ncp, *Hb = T + NX * ncp;
     double *gb = Hb + NPC, *y = gb + nc + nc, *g = y + 64, *c = g + 64, *cn = c + 64, *bl = cn + 64;
@@ -360,9 +367,11 @@ static __global__ void __launch_bounds__(64) kw_pcond(GqpDev P, GqpDev Cd, Pcond
             if (Mp.mode & 1)
                 for (int e = lane; e < NX * nc; e += 64)
                 {
+                    /* x_k does not depend on the inputs of stage k and later: those columns of X (and of T) are zero */
                     const int r = e / nc, col = e - r * nc;
                     double s = 0.0;
-                    for (int q = 0; q < NX; q++) s += Hs(NU + r, NU + q) * X[q * ncp + col];
+                    if (!(col >= u0 && col < NUC))
+                        for (int q = 0; q < NX; q++) s += Hs(NU + r, NU + q) * X[q * ncp + col];
                     T[r * ncp + col] = s;
                 }
             __syncthreads();
@@ -386,10 +395,11 @@ static __global__ void __launch_bounds__(64) kw_pcond(GqpDev P, GqpDev Cd, Pcond
                 for (int e = lane; e < NPC; e += 64)
                 {
                     double s = 0.0;
-                    for (int r = 0; r < NX; r++) s += X[r * ncp + pr] * T[r * ncp + pc2];
+                    const bool zp = pr >= u0 && pr < NUC, zq = pc2 >= u0 && pc2 < NUC; /* zero columns of X */
+                    if (!zp && !zq) for (int r = 0; r < NX; r++) s += X[r * ncp + pr] * T[r * ncp + pc2];
                     const bool pu = pr >= u0 && pr < u0 + NU, qu = pc2 >= u0 && pc2 < u0 + NU;
-                    if (pu) for (int r = 0; r < NX; r++) s += H[PK(NU + r, pr - u0)] * X[r * ncp + pc2];
-                    if (qu) for (int r = 0; r < NX; r++) s += H[PK(NU + r, pc2 - u0)] * X[r * ncp + pr];
+                    if (pu && !zq) for (int r = 0; r < NX; r++) s += H[PK(NU + r, pr - u0)] * X[r * ncp + pc2];
+                    if (qu && !zp) for (int r = 0; r < NX; r++) s += H[PK(NU + r, pc2 - u0)] * X[r * ncp + pr];
                     if (pu && qu) s += H[PK(pr - u0, pc2 - u0)];
                     Hb[e] += s;
                     /* advance (pr, pc2) by 64 packed entries */
@@ -415,7 +425,8 @@ static __global__ void __launch_bounds__(64) kw_pcond(GqpDev P, GqpDev Cd, Pcond
                 {
                     const int r = e / nc, col = e - r * nc;
                     double s = (col >= u0 && col < u0 + NU) ? Bl[(col - u0) * NX + r] : 0.0;
-                    for (int q = 0; q < NX; q++) s += Bl[(NU + q) * NX + r] * X[q * ncp + col];
+                    if (!(col >= u0 && col < NUC))
+                        for (int q = 0; q < NX; q++) s += Bl[(NU + q) * NX + r] * X[q * ncp + col];
                     Xn[r * ncp + col] = s;
                 }
             }
@@ -503,7 +514,7 @@ static __global__ void __launch_bounds__(64) kw_pexpand(GqpDev P, GqpDev Cd, Pco
     GQP_DYN_SHARED(smem);
     const int NX = P.NX, NU = P.NU, n = NX + NU, NP = n * (n + 1) / 2;
     const int NUC = Cd.NU, nc = NUC + NX;
-    const int inst = blockIdx.x, lane = threadIdx.x;
+    const int inst = pcond_inst(blockIdx.x), lane = threadIdx.x;
     if (inst >= P.B) return;
     double *x = smem, *u = x + 64, *pn = u + 64, *ux = pn + 64; /* ux: [u; x] of the stage being visited */
 
