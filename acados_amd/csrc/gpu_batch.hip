@@ -76,7 +76,8 @@ struct ocp_qp_gpu_batch
     int AW = 1;           /* activity words per stage (64 inequality sides each); 2 only for wave-per-instance batches */
     int wpi = 0;          /* wave-per-instance kernels (ipm_kernels_wpi.hpp): one workgroup per instance */
     int w16 = 0;          /* ... whose four sweeps are the 16-lanes-per-instance kernels (ipm_kernels_w16.hpp): 4 instances per workgroup */
-    size_t shmem = 0;     /* their dynamic LDS bytes (rhs / forward sweeps) */
+    size_t shmem = 0;     /* their dynamic LDS bytes (rhs sweep, init, finalize) */
+    size_t shmem_fwd = 0; /* ... of the forward sweeps (one factor buffer instead of two) */
     size_t shmem_fact = 0; /* dynamic LDS bytes of the factor sweep */
     bool w16_soft = false; /* ... with soft box rows (one slack per row) */
     KernelSet wpi_ks;      /* the wave-per-instance set of the same padded dims (fallback of w16_soft) */
@@ -729,6 +730,7 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
             }
             const size_t con = gqp::wpi_con_doubles(wx + wu, mg, ms);
             b->shmem = (ref ? gqp::wpi_lds_doubles(wx, wu) : gqp::wpi3_lds_doubles(wx, wu) + con) * sizeof(double);
+            b->shmem_fwd = (ref ? gqp::wpi_lds_doubles(wx, wu) : gqp::wpi3_lds_doubles(wx, wu, 1) + con) * sizeof(double);
             b->shmem_fact = (ref ? gqp::wpi_lds_doubles(wx, wu) : gqp::wpi2_lds_doubles(wx, wu) + con) * sizeof(double);
         }
     }
@@ -1224,19 +1226,19 @@ static void run_ipm(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch *root, Prof &prof, hip
             break;
         }
         if (b == root) prof.begin(2, s);
-        GQP_SWEEP_LAUNCH(b, K.faff, b->shmem, s, D, O, 0);
+        GQP_SWEEP_LAUNCH(b, K.faff, b->shmem_fwd, s, D, O, 0);
         if (b == root) prof.end(s);
         if (b == root) prof.begin(3, s);
         GQP_SWEEP_LAUNCH(b, K.rhs, b->shmem, s, D, O, 0);
         if (b == root) prof.end(s);
         if (b == root) prof.begin(4, s);
-        GQP_SWEEP_LAUNCH(b, K.fcorr, b->shmem, s, D, O, 0);
+        GQP_SWEEP_LAUNCH(b, K.fcorr, b->shmem_fwd, s, D, O, 0);
         if (b == root) prof.end(s);
         root->launches += 3;
         if (O.cond_pred_corr)
         {
             GQP_SWEEP_LAUNCH(b, K.rhs, b->shmem, s, D, O, 1);
-            GQP_SWEEP_LAUNCH(b, K.fcorr, b->shmem, s, D, O, 1);
+            GQP_SWEEP_LAUNCH(b, K.fcorr, b->shmem_fwd, s, D, O, 1);
             root->launches += 2;
         }
     }
@@ -1281,7 +1283,7 @@ static void compact_into(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch *root, int nact, 
         c->idxb = b->idxb; c->idxs_rev = b->idxs_rev; c->idxe = b->idxe; c->nbxe = b->nbxe;
         c->compact_min = b->compact_min;
         c->tail_max = b->tail_max;
-        if (!tail) { c->aos = b->aos; c->wpi = b->wpi; c->shmem = b->shmem; c->shmem_fact = b->shmem_fact; c->w16 = b->w16; c->w16_soft = b->w16_soft; c->w16_shmem = b->w16_shmem; }
+        if (!tail) { c->aos = b->aos; c->wpi = b->wpi; c->shmem = b->shmem; c->shmem_fwd = b->shmem_fwd; c->shmem_fact = b->shmem_fact; c->w16 = b->w16; c->w16_soft = b->w16_soft; c->w16_shmem = b->w16_shmem; }
         finalize_structure(c);
         slot = c;
     }
@@ -1487,7 +1489,7 @@ static void sens_pass(ocp_qp_gpu_batch *b, hipStream_t s)
     hipLaunchKernelGGL(gqp::k_sens_fixed, g64, blk, 0, s, b->D, b->sfix, 0);
     hipLaunchKernelGGL(gqp::k_sens_prep, g64, blk, 0, s, b->D, O.tau_min, b->d_saved_status);
     GQP_SWEEP_LAUNCH(b, K.rhs, b->shmem, s, b->D, O, 2);
-    GQP_SWEEP_LAUNCH(b, K.fcorr, b->shmem, s, b->D, O, 2);
+    GQP_SWEEP_LAUNCH(b, K.fcorr, b->shmem_fwd, s, b->D, O, 2);
     hipLaunchKernelGGL(gqp::k_sens_fixed, g64, blk, 0, s, b->D, b->sfix, 1);
     hipLaunchKernelGGL(gqp::k_status_restore, g64, blk, 0, s, b->D, b->d_saved_status);
 }

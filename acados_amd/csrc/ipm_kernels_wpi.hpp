@@ -31,6 +31,13 @@
 #define GQP_LAUNCH_COOP hipLaunchKernelGGL
 #endif
 
+/* lower bound on the waves per SIMD the register allocation must allow (template-dependent expressions are fine) */
+#if defined(__HIPCC__)
+#define GQP_WAVES_PER_EU(minw) __attribute__((amdgpu_waves_per_eu(minw, 8)))
+#else
+#define GQP_WAVES_PER_EU(minw)
+#endif
+
 /* dot-product loops over LDS operands: several reads in flight per lane */
 #define GQP_DOT_UNROLL _Pragma("unroll 4")
 
@@ -670,23 +677,27 @@ struct WpiCon
     int SG;
 };
 
+/* sized by what the batch can hold: at most n box rows + NG general rows per stage, NS slacks (the LDS of a wave
+ * decides how many waves a CU keeps: the arrays used to be sized for 64 rows / 32 slacks whatever the problem) */
+__host__ __device__ static inline int wpi_con_rows(int n, int NG) { return (n + NG + 1) & ~1; }
 __host__ __device__ static inline size_t wpi_con_doubles(int n, int NG, int NS)
 {
     if (NG == 0 && NS == 0) return 0;
-    const int SG = n | 1;
-    return (size_t) NG * SG + 6 * 64 + 12 * 32 + 32 + 16 + 8;
+    const int SG = n | 1, NR = wpi_con_rows(n, NG), NSe = (NS + 1) & ~1, NGe = (NG + 1) & ~1;
+    return (size_t) NG * SG + 6 * NR + 10 * NSe + 2 * NGe + NR / 2 + NSe / 2 + 8;
 }
 
 __device__ static inline WpiCon wpi_con_carve(double *p, int n, int NG, int NS)
 {
     WpiCon C;
+    const int NR = wpi_con_rows(n, NG), NSe = (NS + 1) & ~1, NGe = (NG + 1) & ~1;
     C.SG = n | 1;
     C.G = p; p += NG * C.SG;
-    C.rGl = p; p += 64; C.rGu = p; p += 64; C.rRl = p; p += 64; C.rRu = p; p += 64; C.rLl = p; p += 64; C.rLu = p; p += 64;
-    C.sIl = p; p += 32; C.sIu = p; p += 32; C.sRl = p; p += 32; C.sRu = p; p += 32; C.dsl = p; p += 32; C.dsu = p; p += 32;
-    C.sEl = p; p += 32; C.sEu = p; p += 32; C.sXl = p; p += 32; C.sXu = p; p += 32;
-    C.nuG = p; p += 32; C.gmG = p; p += 32;
-    C.rsj = (int *) p; p += 32;
+    C.rGl = p; p += NR; C.rGu = p; p += NR; C.rRl = p; p += NR; C.rRu = p; p += NR; C.rLl = p; p += NR; C.rLu = p; p += NR;
+    C.sIl = p; p += NSe; C.sIu = p; p += NSe; C.sRl = p; p += NSe; C.sRu = p; p += NSe; C.dsl = p; p += NSe; C.dsu = p; p += NSe;
+    C.sEl = p; p += NSe; C.sEu = p; p += NSe; C.sXl = p; p += NSe; C.sXu = p; p += NSe;
+    C.nuG = p; p += NGe; C.gmG = p; p += NGe;
+    C.rsj = (int *) p; p += NR / 2;
     C.scnt = (int *) p;
     return C;
 }
@@ -694,7 +705,7 @@ __device__ static inline WpiCon wpi_con_carve(double *p, int n, int NG, int NS)
 /* coalesced copy of the ng x n general rows of a stage into LDS rows of odd stride */
 __device__ static inline void wpi_load_G(const WpiCon &C, const GqpStage &S, const GArr &DCt, int inst, int o_g, int ng, int n, int lane)
 {
-    C.rsj[lane] = S.srev[lane];
+    if (lane < S.nb + ng) C.rsj[lane] = S.srev[lane];
     int r = lane / n, c = lane - r * n;
     const int dr = 64 / n, dc = 64 - dr * n;
     for (int e = lane; e < ng * n; e += 64)
@@ -796,7 +807,8 @@ __device__ static inline WpiLds2 wpi2_carve(double *sm, int NX, int NU)
 }
 
 template <int T8, bool GEN>
-__global__ void __launch_bounds__(64) kw_factor(GqpDev D, GqpOpts O, int redo)
+/* T8 <= 4: keep two waves per SIMD (<= 256 VGPRs; the GEN variant sits right at the line) */
+__global__ void __launch_bounds__(64) GQP_WAVES_PER_EU(T8 <= 4 ? 2 : 1) kw_factor(GqpDev D, GqpOpts O, int redo)
 {
     GQP_DYN_SHARED(smem);
     const int NX = D.NX, NU = D.NU, n = NX + NU, NP = n * (n + 1) / 2;
@@ -1309,20 +1321,22 @@ struct WpiLds3
     int NPa, SXb;
 };
 
-__host__ __device__ static inline size_t wpi3_lds_doubles(int NX, int NU)
+/* nbuf: packed-factor buffers -- two for the backward sweep (this stage's and the previous one's), one for the
+ * forward sweep (less LDS per wave there = more waves per CU) */
+__host__ __device__ static inline size_t wpi3_lds_doubles(int NX, int NU, int nbuf = 2)
 {
     const int n = NX + NU, NPa = n * (n + 1) / 2 + 8, SXb = NX | 1;
-    return 2 * (size_t) NPa + (size_t) n * SXb + 8 * 64 + 8;
+    return (size_t) nbuf * NPa + (size_t) n * SXb + 8 * 64 + 8;
 }
 
-__device__ static inline WpiLds3 wpi3_carve(double *sm, int NX, int NU)
+__device__ static inline WpiLds3 wpi3_carve(double *sm, int NX, int NU, int nbuf = 2)
 {
     const int n = NX + NU;
     WpiLds3 L;
     L.NPa = n * (n + 1) / 2 + 8;
     L.SXb = NX | 1;
     double *p = sm;
-    L.Lp = p; p += 2 * L.NPa;
+    L.Lp = p; p += nbuf * L.NPa;
     L.B = p; p += n * L.SXb;
     L.rb = p; p += 64; L.w0 = p; p += 64; L.y = p; p += 64; L.pn = p; p += 64;
     L.dv = p; p += 64; L.dx = p; p += 64; L.bc = p; p += 64; L.red = p; p += 64;
@@ -1543,8 +1557,8 @@ __global__ void __launch_bounds__(64) kw_fwd(GqpDev D, GqpOpts O, int redo)
     if (inst >= D.B) return;
     if (D.status[inst] != GQP_RUNNING) return;
     if (redo == 1 && !(D.alpha[inst] < 0.0)) return; /* redo = 2: sensitivity pass (direction only, every instance) */
-    const WpiLds3 L = wpi3_carve(smem, NX, NU);
-    const WpiCon C = wpi_con_carve(smem + wpi3_lds_doubles(NX, NU), n, GEN ? D.NG : 0, GEN ? D.NS : 0);
+    const WpiLds3 L = wpi3_carve(smem, NX, NU, 1);
+    const WpiCon C = wpi_con_carve(smem + wpi3_lds_doubles(NX, NU, 1), n, GEN ? D.NG : 0, GEN ? D.NS : 0);
     const int SXb = L.SXb;
     double *__restrict__ Lc = L.Lp;
     const double smu = CORR ? D.smu[inst] : 0.0;
