@@ -1325,8 +1325,8 @@ struct WpiLds3
  * forward sweep (less LDS per wave there = more waves per CU) */
 __host__ __device__ static inline size_t wpi3_lds_doubles(int NX, int NU, int nbuf = 2)
 {
-    const int n = NX + NU, NPa = n * (n + 1) / 2 + 8, SXb = NX | 1;
-    return (size_t) nbuf * NPa + (size_t) n * SXb + 8 * 64 + 8;
+    const int n = NX + NU, NPa = n * (n + 1) / 2 + 8, SXb = NX | 1, nv = (n + 1) & ~1;
+    return (size_t) nbuf * NPa + (size_t) n * SXb + 6 * (size_t) nv + 8 + 64 + 8;
 }
 
 __device__ static inline WpiLds3 wpi3_carve(double *sm, int NX, int NU, int nbuf = 2)
@@ -1338,8 +1338,9 @@ __device__ static inline WpiLds3 wpi3_carve(double *sm, int NX, int NU, int nbuf
     double *p = sm;
     L.Lp = p; p += nbuf * L.NPa;
     L.B = p; p += n * L.SXb;
-    L.rb = p; p += 64; L.w0 = p; p += 64; L.y = p; p += 64; L.pn = p; p += 64;
-    L.dv = p; p += 64; L.dx = p; p += 64; L.bc = p; p += 64; L.red = p; p += 64;
+    const int nv = (n + 1) & ~1; /* vectors over the variables: n entries, not a full wave's 64 */
+    L.rb = p; p += nv; L.w0 = p; p += nv; L.y = p; p += nv; L.pn = p; p += nv;
+    L.dv = p; p += nv; L.dx = p; p += nv; L.bc = p; p += 8; L.red = p; p += 64;
     return L;
 }
 
@@ -1386,7 +1387,7 @@ __global__ void __launch_bounds__(64) kw_backrhs(GqpDev D, GqpOpts O, int redo)
     const double pscale = redo == 1 ? 0.0 : 1.0;
     const bool mine = lane < n;
     for (int e = lane; e < 2 * L.NPa; e += 64) L.Lp[e] = 0.0;
-    L.pn[lane] = 0.0;
+    if (lane < n) L.pn[lane] = 0.0;
     int cur = 0;
     __syncthreads();
 
@@ -1566,7 +1567,7 @@ __global__ void __launch_bounds__(64) kw_fwd(GqpDev D, GqpOpts O, int redo)
     const bool mine = lane < n;
     double alpha = 1.0, S0 = 0.0, S1 = 0.0, S2 = 0.0;
     int nact = 0;
-    L.dx[lane] = 0.0;
+    if (lane < n) L.dx[lane] = 0.0;
     __syncthreads();
 
     for (int k = 0; k <= D.N; k++)
