@@ -81,8 +81,8 @@ int ocp_qp_gpu_batch_opts_set(ocp_qp_gpu_batch *b, const char *field, const void
 int ocp_qp_gpu_batch_solve(ocp_qp_gpu_batch *b);
 
 /* RTI split (ocp_qp_xcond_solver.c:591-669): condense the matrix part while waiting for the new
- * initial state, then condense the vector part and solve.  With cond_N == N (or a QP class this
- * build does not condense) condense_lhs is a no-op and the second call is a plain solve.
+ * initial state, then condense the vector part and solve.  With cond_N == N (or a QP whose condensed stages
+ * would exceed the limits of INTEGRATION.md) condense_lhs is a no-op and the second call is a plain solve.
  * The matrix-dependent condensed blocks stay resident in HBM between the two calls. */
 int ocp_qp_gpu_batch_condense_lhs(ocp_qp_gpu_batch *b);
 int ocp_qp_gpu_batch_condense_rhs_and_solve(ocp_qp_gpu_batch *b);
