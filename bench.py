@@ -194,12 +194,12 @@ def main():
     achieved = per_launch_bytes / avg_s / 1e9
     solves_per_s = world * B * args.steps / elapsed
     # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 cannot run inside
-    # this process); corrected as MI355X_MICROARCH.md prescribes, see profiles/r01_v3_pmc_traffic.json
+    # this process); corrected as MI355X_MICROARCH.md prescribes, see profiles/r01_v6_pmc_traffic.json
     kern_sym = {"back_fact": "kb_factor", "fwd_aff": "kb_forward", "back_rhs": "kb_backrhs", "fwd_corr": "kb_forward"}[dom] \
         if dom in ("back_fact", "fwd_aff", "back_rhs", "fwd_corr") else dom
     traffic = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_v3_pmc_traffic.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_v6_pmc_traffic.json")))
         want = {"back_fact": f"kb_factor<{nx}, {nu}, false>", "back_rhs": f"kb_backrhs<{nx}, {nu}, false>",
                 "fwd_aff": f"kb_forward<{nx}, {nu}, false, false>", "fwd_corr": f"kb_forward<{nx}, {nu}, false, true>"}.get(dom)
         if want in pmc and B == 65536 and N == 50:
