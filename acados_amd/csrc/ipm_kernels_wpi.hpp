@@ -1061,7 +1061,7 @@ __global__ void __launch_bounds__(64) GQP_WAVES_PER_EU(T8 <= 4 ? 2 : 1) kw_facto
         for (int a = 0; a < T8; a++)
 #pragma unroll
             for (int b = 0; b < T8; b++) Wt[a][b] = 0.0;
-#pragma unroll 2
+#pragma unroll (T8 == 4 && !GEN ? 4 : 2)
         for (int q = 0; q < NX; q++)
         {
             double bb[T8], xx[T8];
@@ -1105,7 +1105,7 @@ __global__ void __launch_bounds__(64) GQP_WAVES_PER_EU(T8 <= 4 ? 2 : 1) kw_facto
             L.w0[lane] = a;
         }
         /* ---- M = H + reg + Gamma + W W' in tiles ---- */
-#pragma unroll 2
+#pragma unroll (T8 == 4 && !GEN ? 4 : 2)
         for (int q = 0; q < NX; q++)
         {
             double wr[T8], wc[T8];
