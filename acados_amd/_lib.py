@@ -42,6 +42,14 @@ def bind(L):
     L.ocp_qp_gpu_batch_expand.argtypes = [C.c_void_p]
     L.ocp_qp_gpu_batch_get_dims.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int)]
     L.ocp_qp_gpu_batch_get_int.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.POINTER(C.c_int)]
+    L.ocp_qp_gpu_batch_condense_rhs.argtypes = [C.c_void_p]
+    L.ocp_qp_gpu_batch_condense_rhs.restype = C.c_void_p
+    L.ocp_qp_gpu_batch_condensed.argtypes = [C.c_void_p]
+    L.ocp_qp_gpu_batch_condensed.restype = C.c_void_p
+    L.ocp_qp_gpu_batch_set_bulk_out.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.ocp_qp_gpu_batch_condense_sol.argtypes = [C.c_void_p]
+    L.ocp_qp_gpu_batch_res_compute.argtypes = [C.c_void_p]
+    L.ocp_qp_gpu_batch_res_nrm_inf.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     return L
 
 

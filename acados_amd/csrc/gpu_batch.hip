@@ -20,6 +20,7 @@
 #include "ipm_kernels_box.hpp"
 #include "ipm_kernels_wpi.hpp"
 #include "ipm_kernels_w16.hpp"
+#include "res_kernels.hpp"
 #include "kernel_sets.h"
 
 #define HIPCHK(x)                                                                              \
@@ -103,6 +104,7 @@ struct ocp_qp_gpu_batch
     double time_tot = 0.0, time_pack = 0.0;
     int last_iters = 0, launches = 0;
     int print_level = 0;
+    double t0_min = 1e-16, lam0_min = 1e-16; /* lower clips of t / lam at a hot start (HPIPM args of the same name) */
     int profile = 0;                 /* per-kernel-class HIP event timing on the launch stream */
     std::vector<hipEvent_t> prof_ev; /* pool, pairs (start, stop) */
     std::vector<int> prof_cls;       /* kernel class of each recorded pair */
@@ -142,6 +144,8 @@ struct ocp_qp_gpu_batch
     int *d_list = nullptr;               /* instance index of every slot of `compact` / `tail` */
     int list_cap = 0;
     int n_compactions = 0;
+    /* KKT residuals of the current (data, iterate) on demand (res_kernels.hpp) */
+    gqp::ResOut R = {{nullptr, 0, 0}, {nullptr, 0, 0}, {nullptr, 0, 0}, {nullptr, 0, 0}, {nullptr, 0, 0}, nullptr, 0};
     /* bulk pack / unpack (one H2D + one launch per direction) */
     struct BulkMap
     {
@@ -893,6 +897,10 @@ int ocp_qp_gpu_batch_opts_set(ocp_qp_gpu_batch *b, const char *f, const void *v)
         b->pcond_state = 0;
         if (b->child) { ocp_qp_gpu_batch_destroy(b->child); b->child = nullptr; }
     }
+    else if (!strcmp(f, "t0_min")) b->t0_min = *d;
+    else if (!strcmp(f, "lam0_min")) b->lam0_min = *d;
+    else if (!strcmp(f, "update_fact_exit")) { /* the factor sweep factorises before it decides: the factor at the exit
+                                                  point is always there (and re-done lazily after a hand-over) */ }
     else if (!strcmp(f, "t0_init")) { /* single initialisation scheme (oracle-pinned) */ }
     else if (!strcmp(f, "ric_alg"))
     {
@@ -1096,8 +1104,13 @@ static int pcond_solve(ocp_qp_gpu_batch *b, int mode = 3)
     c->print_level = b->print_level;
     HIPCHK(hipEventRecord(e0, b->stream));
     pcond_launch(b, false);
+    if (b->O.warm_start >= 2)
+        /* hot start: the root's iterate restated in the condensed variables (condense_qp_out,
+         * ocp_qp_xcond_solver.c:554-565) is the child's starting point */
+        hipLaunchKernelGGL(gqp::k_pcond_sol, grid, block, 0, b->stream, b->D, c->D, b->pmap);
     HIPCHK(hipEventRecord(e1, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
+    c->t0_min = b->t0_min; c->lam0_min = b->lam0_min;
     const int bad = ocp_qp_gpu_batch_solve(c);
     HIPCHK(hipEventRecord(e2, b->stream));
     pcond_launch(b, true);
@@ -1256,22 +1269,24 @@ static void compact_into(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch *root, int nact, 
     list.reserve(nact);
     for (int i = 0; i < b->B; i++) if (st[i] == GQP_RUNNING) list.push_back(i);
     const int cnt = (int) list.size();
-    if (!b->d_list)
+    /* capacities follow the level's CAPACITY (Bp), not its current count: a level is re-used by later solves with
+     * more survivors (its B changes between solves) */
+    if (!b->d_list || cnt > b->list_cap)
     {
-        b->list_cap = (b->B + 1) / 2;
+        b->list_cap = std::max(cnt, (b->Bp + 1) / 2);
         b->d_list = dalloc<int>(b, b->list_cap);
     }
     ocp_qp_gpu_batch *&slot = tail ? b->tail : b->compact;
-    if (slot && tail && cnt > b->tail_cap)
+    if (slot && cnt > (tail ? b->tail_cap : slot->Bp))
     {
-        /* tail_max was raised after the sub-batch had been sized */
+        /* more survivors than the sub-batch was sized for (tail_max raised, or a later solve of a re-used level) */
         ocp_qp_gpu_batch_destroy(slot);
         slot = nullptr;
     }
     if (!slot)
     {
         /* same kernel set (compaction) or the wave-per-instance family at the very same padded dims (tail) */
-        const int cap = tail ? std::max(cnt, std::min(b->tail_max, b->list_cap)) : (b->B + 1) / 2;
+        const int cap = tail ? std::max(cnt, std::min(b->tail_max, b->list_cap)) : std::max(cnt, (b->Bp + 1) / 2);
         if (tail) b->tail_cap = cap;
         g_force_ks = b->ks;
         g_force_wpi = tail;
@@ -1356,11 +1371,10 @@ int ocp_qp_gpu_batch_solve(ocp_qp_gpu_batch *b)
     }
     else
     {
-        /* hot start: keep (ux, pi, lam, t) as they are in HBM */
-        HIPCHK(hipMemsetAsync(D.iter, 0, sizeof(int) * b->Bp, s));
-        std::vector<int> run(b->Bp, GQP_RUNNING);
-        HIPCHK(hipMemcpyAsync(D.status, run.data(), sizeof(int) * b->Bp, hipMemcpyHostToDevice, s));
-        HIPCHK(hipStreamSynchronize(s));
+        /* hot start: keep (ux, pi, lam, t) as they are in HBM; loop state reset as a cold start leaves it */
+        const double clip = O.warm_start == 2 ? 0.1 : 0.0;
+        hipLaunchKernelGGL(gqp::k_hot_start, grid, block, 0, s, D, std::max(clip, b->t0_min), std::max(clip, b->lam0_min));
+        b->launches++;
     }
     run_ipm(b, b, prof, s, 0);
     b->factor_stale = b->n_tail_switches + b->n_compactions > 0;
@@ -1606,7 +1620,28 @@ int ocp_qp_gpu_batch_get(ocp_qp_gpu_batch *b, const char *f, int k, double *data
             return 0;
         }
     }
-    int len = field_map(b, is_sens ? f + 5 : f, k, map, &arr);
+    int len;
+    if (!strncmp(f, "res_", 4))
+    {
+        /* residual vectors of the last ocp_qp_gpu_batch_res_compute: res_g ([u; x]), res_gs ([sl; su]), res_b, res_d,
+         * res_m -- same element maps as the quantity each residual belongs to */
+        if (!b->R.nrm) { fprintf(stderr, "acados_amd: ocp_qp_gpu_batch_get: %s before ocp_qp_gpu_batch_res_compute\n", f); return -1; }
+        const char *like = !strcmp(f, "res_g") ? "ric_l" : !strcmp(f, "res_b") ? "pi" : !strcmp(f, "res_d") || !strcmp(f, "res_m") ? "lam" : nullptr;
+        if (!strcmp(f, "res_gs"))
+        {
+            len = 2 * b->st[k].ns;
+            for (int j = 0; j < len; j++) map.push_back(b->st[k].o_s + j);
+            arr = b->R.gs;
+        }
+        else if (like)
+        {
+            len = field_map(b, like, k, map, &arr);
+            if (!strcmp(f, "res_b")) for (int &m : map) m -= b->ks->NX; /* pi lives in slot k+1, res_b in slot k */
+            arr = !strcmp(f, "res_g") ? b->R.g : !strcmp(f, "res_b") ? b->R.b : !strcmp(f, "res_d") ? b->R.d : b->R.m;
+        }
+        else len = -1;
+    }
+    else len = field_map(b, is_sens ? f + 5 : f, k, map, &arr);
     if (len > 0 && (!strcmp(f, "Q") || !strcmp(f, "R")))
     {
         /* the packed lower triangle holds the matrix: mirror it for the reader */
@@ -1643,6 +1678,42 @@ int ocp_qp_gpu_batch_get(ocp_qp_gpu_batch *b, const char *f, int k, double *data
     hipLaunchKernelGGL(gqp::k_gather, dim3((b->B + 63) / 64), dim3(64), 0, b->stream, dst, b->B, len, dm, arr);
     if (!is_device) HIPCHK(hipMemcpyAsync(data, dst, sizeof(double) * cnt, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
+    return 0;
+}
+
+/* KKT residuals of the QP data and the iterate (ux, pi, lam, t) that are in HBM right now -- whoever put them there
+ * (the solver, a warm-start set, an expansion): ocp_qp_res_compute + ocp_qp_res_compute_nrm_inf of
+ * acados/ocp_qp/ocp_qp_common.c:559-667 for the whole batch in one launch.  Independent of the IPM sweeps. */
+int ocp_qp_gpu_batch_res_compute(ocp_qp_gpu_batch *b)
+{
+    HIPCHK(hipSetDevice(b->device));
+    finalize_structure(b);
+    const GqpDev &D = b->D;
+    if (!b->R.nrm)
+    {
+        const int n = D.NX + D.NU;
+        b->R.g = garr<double>(b, (size_t) (b->N + 1) * n);
+        b->R.gs = garr<double>(b, (size_t) b->ns2_tot);
+        b->R.b = garr<double>(b, (size_t) (b->N + 1) * D.NX);
+        b->R.d = garr<double>(b, (size_t) b->nct_tot + 16);
+        b->R.m = garr<double>(b, (size_t) b->nct_tot + 16);
+        b->R.nrm = dalloc<double>(b, 4 * (size_t) b->Bp);
+        b->R.Bp = b->Bp;
+    }
+    hipLaunchKernelGGL(gqp::k_res_compute, dim3((b->B + 63) / 64), dim3(64), 0, b->stream, b->D, b->R);
+    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+/* res[i * 4 + q]: inf-norms of res_g, res_b, res_d, res_m of instance i (ocp_qp_res_compute_nrm_inf) */
+int ocp_qp_gpu_batch_res_nrm_inf(ocp_qp_gpu_batch *b, double *res)
+{
+    if (!b->R.nrm && ocp_qp_gpu_batch_res_compute(b) != 0) return -1;
+    std::vector<double> h(4 * (size_t) b->Bp);
+    HIPCHK(hipMemcpy(h.data(), b->R.nrm, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+    for (int i = 0; i < b->B; i++)
+        for (int q = 0; q < 4; q++) res[(size_t) i * 4 + q] = h[(size_t) q * b->Bp + i];
     return 0;
 }
 
@@ -1743,6 +1814,35 @@ ocp_qp_gpu_batch *ocp_qp_gpu_batch_condense(ocp_qp_gpu_batch *b)
     b->lhs_ready = false;
     return b->child;
 }
+
+/* vector part alone (gbar, bbar, bounds) on top of a resident matrix part: the `condense_rhs` slot of
+ * ocp_qp_xcond_config (ocp_qp_partial_condensing.c:602-630); returns the condensed batch like _condense */
+ocp_qp_gpu_batch *ocp_qp_gpu_batch_condense_rhs(ocp_qp_gpu_batch *b)
+{
+    HIPCHK(hipSetDevice(b->device));
+    finalize_structure(b);
+    if (b->pcond_state != 1 || !b->child) return ocp_qp_gpu_batch_condense(b); /* no lhs yet: everything */
+    b->pmap.mode = 2;
+    pcond_launch(b, false);
+    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(hipGetLastError());
+    return b->child;
+}
+
+/* the current iterate of `b` restated in the condensed variables, written into the condensed batch: the
+ * `condense_qp_out` slot (ocp_qp_partial_condensing.c:559-571) */
+int ocp_qp_gpu_batch_condense_sol(ocp_qp_gpu_batch *b)
+{
+    HIPCHK(hipSetDevice(b->device));
+    if (b->pcond_state != 1 || !b->child) return -1;
+    hipLaunchKernelGGL(gqp::k_pcond_sol, dim3((b->B + 63) / 64), dim3(64), 0, b->stream, b->D, b->child->D, b->pmap);
+    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+/* the condensed batch currently owned by `b` (after _condense / _condense_lhs), or NULL */
+ocp_qp_gpu_batch *ocp_qp_gpu_batch_condensed(ocp_qp_gpu_batch *b) { return b->pcond_state == 1 ? b->child : nullptr; }
 
 int ocp_qp_gpu_batch_expand(ocp_qp_gpu_batch *b)
 {
@@ -1900,6 +2000,19 @@ int ocp_qp_gpu_batch_set_bulk(ocp_qp_gpu_batch *b, const double *blob, int is_de
     HIPCHK(hipEventElapsedTime(&ms, e0, e1));
     b->time_pack += ms * 1e-3;
     HIPCHK(hipEventDestroy(e0)); HIPCHK(hipEventDestroy(e1));
+    return 0;
+}
+
+/* an iterate in the OUTPUT blob layout (u x sl su pi lam t) written into the batch: the starting point of a hot
+ * start, one host->device copy and one launch (inverse of _get_bulk) */
+int ocp_qp_gpu_batch_set_bulk_out(ocp_qp_gpu_batch *b, const double *blob, int is_device)
+{
+    const int len = ocp_qp_gpu_batch_bulk_len(b, 1);
+    auto &M = b->bulk_out;
+    const double *src = stage_in(b, blob, (size_t) b->B * len, is_device);
+    const dim3 grid((b->B + 63) / 64, (len + 255) / 256), block(64);
+    hipLaunchKernelGGL(gqp::k_bulk_scatter, grid, block, 0, b->stream, src, b->B, len, M.d_arr, M.d_elem, M.T);
+    HIPCHK(hipStreamSynchronize(b->stream));
     return 0;
 }
 

@@ -1266,6 +1266,34 @@ static __global__ void k_sens_prep(GqpDev D, double tau, int *saved_status)
     D.status[i] = GQP_RUNNING;
 }
 
+/* Hot start (warm_start >= 2, acados_ocp_options.py:1029-1032): the iterate (ux, pi, lam, t) in HBM is the starting
+ * point.  Per-instance loop state is reset exactly as the cold-start kernels leave it (iter 0, running, alpha 1 --
+ * a stale alpha of 0 would read as MINSTEP in the first factor sweep), and t / lam of the rows that take part are
+ * clipped from below (warm_start 2: 0.1; 3: the t0_min / lam0_min the factorize-only path of
+ * ocp_nlp_common.c:3946-3971 sets to keep the factorisation well conditioned). */
+static __global__ void k_hot_start(GqpDev D, double t_min, double lam_min)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D.B) return;
+    D.iter[i] = 0;
+    D.status[i] = GQP_RUNNING;
+    D.alpha[i] = 1.0;
+    D.mu[i] = 0.0;
+    D.smu[i] = 0.0;
+    for (int k = 0; k <= D.N; k++)
+    {
+        const GqpStage &S = D.st[k];
+        const int nct = 2 * (S.nb + S.ng) + 2 * S.ns;
+        for (int e = 0; e < nct; e++)
+        {
+            if (!((GATL(D.amask, k * D.AW + (e >> 6)) >> (e & 63)) & 1)) continue;
+            const double tv = GATL(D.t, S.o_ct + e), lv = GATL(D.lam, S.o_ct + e);
+            if (!(tv >= t_min)) GATL(D.t, S.o_ct + e) = t_min;
+            if (!(lv >= lam_min)) GATL(D.lam, S.o_ct + e) = lam_min;
+        }
+    }
+}
+
 static __global__ void k_status_restore(GqpDev D, const int *saved_status)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -1,7 +1,16 @@
 /*
  * ocp_qp_host.cpp -- acados-shaped host API (include/acados_amd/ocp_qp_interface.h) on top
- * of the device batch C-ABI.  Host code only: no kernels here.  Each function cites the
+ * of the device batch C-ABI: the plain containers (dims / in / out / seed / res) and the INNER plugin, i.e. the 17
+ * slots of qp_solver_config.  The condensing module, the outer xcond-solver vtable and the acados_c-shaped
+ * convenience layer live in ocp_qp_xcond.cpp.  Host code only: no kernels here.  Each function cites the
  * reference function whose contract it follows (paths relative to /root/reference).
+ *
+ * Memory rule of the reference (ocp_qp_interface.c:513-563: the caller computes sizes and allocates ONE block, the
+ * callee carves it; no malloc inside `evaluate`): every host array `evaluate` touches on the single-QP path --
+ * structure signature, statistics table, status / iteration slots -- is carved from the block handed to
+ * memory_assign.  What is NOT in that block are device-side resources (the HBM batch, its stream, the pinned staging
+ * buffers), created on the first evaluate and released by `terminate`; and the per-batch tables of the batch
+ * EXTENSION (n > 1, not part of the reference ABI), which are sized once per batch size.
  */
 #include "acados_amd/ocp_qp_interface.h"
 
@@ -16,17 +25,20 @@
 #include <vector>
 
 #include "acados_amd/ocp_qp_gpu_batch.h"
+#include "ocp_qp_host_internal.h"
+
+using gqp_host::align8;
+using gqp_host::cond_request;
 
 namespace
 {
-
-inline char *align8(char *p) { return (char *) (((uintptr_t) p + 7) & ~(uintptr_t) 7); }
 
 struct gpu_ipm_opts
 {
     /* names as d_ocp_qp_ipm_arg_set / ocp_qp_hpipm_opts_set (ocp_qp_hpipm.c:142-183) */
     double mu0, tol_stat, tol_eq, tol_ineq, tol_comp, alpha_min, tau_min, reg_prim, t0_min, lam0_min;
     int iter_max, warm_start, cond_pred_corr, print_level, ric_alg, t0_init, update_fact_exit;
+    int noticed; /* bit set: options that are accepted without effect and have been announced once */
 };
 
 /* one member array of ocp_qp_in / ocp_qp_out and its place in the per-instance bulk blob */
@@ -34,19 +46,18 @@ enum { F_A, F_B, F_b, F_Q, F_S, F_R, F_q, F_r, F_lb, F_ub, F_lbm, F_ubm, F_C, F_
        F_Zl, F_Zu, F_zl, F_zu, F_lls, F_lus, F_llsm, F_lusm, O_ux, O_pi, O_lam, O_t };
 struct blob_seg { int off, len, fid, k, shift; };
 
+/* device-side resources of one solver memory + the tables of the batch extension */
 struct batch_cache
 {
     ocp_qp_gpu_batch *batch = nullptr;
     int n = 0;
-    bool blocks_sent = false; /* user block sizes handed to this device batch */
-    std::vector<int> sig; /* dims + idxb + idxs_rev + idxe of the batch */
-    std::vector<double> stat;
-    std::vector<double> stage; /* host staging [n][len] */
-    /* bulk pack / unpack: segment tables (built once per batch) and PINNED staging [n][bulk_len] */
-    std::vector<blob_seg> seg_in, seg_out;
+    int cond_N_sent = -1;            /* condensing request the device batch has been configured for */
+    std::vector<int> blocks_sent;
+    std::vector<blob_seg> seg_in, seg_out; /* bulk pack / unpack segment tables (built once per batch) */
     int L_in = 0, L_out = 0;
-    double *blob_in = nullptr, *blob_out = nullptr;
+    double *blob_in = nullptr, *blob_out = nullptr; /* PINNED staging [n][bulk_len] */
     size_t cap_in = 0, cap_out = 0;
+    std::vector<int> st, it;         /* batch extension: per-instance status / iterations (n > 1) */
     ~batch_cache()
     {
         if (blob_in) (void) hipHostFree(blob_in);
@@ -80,7 +91,7 @@ inline double *out_field(ocp_qp_out *q, int fid, int k)
 }
 
 /* instances [lo, hi) in parallel on host threads (member arrays of n QPs are copied one by one: the copies of
- * different instances are independent) */
+ * different instances are independent); batch extension only -- one QP is copied by the calling thread */
 template <class F>
 void par_instances(int n, F f)
 {
@@ -110,13 +121,21 @@ void pinned_reserve(double *&p, size_t &cap, size_t cnt)
     cap = cnt;
 }
 
+#define GPU_IPM_STAT_M 20
+
 struct gpu_ipm_memory
 {
-    batch_cache *cache;
+    batch_cache *cache;         /* device-side resources, see the header comment */
     double time_qp_solver_call;
     int iter;
     int status;
     int stat_m;
+    /* carved from the caller's block (memory_assign) */
+    int *sig, *sig_scratch;     /* structure signature of the QP the device batch was built for / of the incoming one */
+    int sig_cap, sig_len;
+    double *stat;               /* stat_m x stat_rows, HPIPM-shaped (ocp_qp_hpipm.c:255-297 "stat") */
+    int stat_rows;
+    int st_it[2];               /* status / iterations of the single-QP path */
 };
 
 double now_s()
@@ -140,23 +159,35 @@ int vlen(const ocp_qp_dims *d, const char *f, int k)
     return -1;
 }
 
-std::vector<int> structure_sig(const ocp_qp_in *in)
+} // namespace
+
+namespace gqp_host
 {
-    const ocp_qp_dims *d = in->dim;
-    std::vector<int> s;
-    s.push_back(d->N);
-    for (int k = 0; k <= d->N; k++)
-    {
-        int v[] = {d->nx[k], d->nu[k], d->nbx[k], d->nbu[k], d->ng[k], d->ns[k], d->nbxe[k]};
-        s.insert(s.end(), v, v + 7);
-        s.insert(s.end(), in->idxb[k], in->idxb[k] + d->nb[k]);
-        s.insert(s.end(), in->idxs_rev[k], in->idxs_rev[k] + d->nb[k] + d->ng[k]);
-        s.insert(s.end(), in->idxe[k], in->idxe[k] + d->nbxe[k]);
-    }
-    return s;
+
+int structure_sig_len(const ocp_qp_dims *d)
+{
+    int len = 1;
+    for (int k = 0; k <= d->N; k++) len += 7 + 2 * d->nb[k] + d->ng[k] + d->nbxe[k];
+    return len;
 }
 
-} // namespace
+int structure_sig_fill(const ocp_qp_in *in, int *s)
+{
+    const ocp_qp_dims *d = in->dim;
+    int p = 0;
+    s[p++] = d->N;
+    for (int k = 0; k <= d->N; k++)
+    {
+        const int v[] = {d->nx[k], d->nu[k], d->nbx[k], d->nbu[k], d->ng[k], d->ns[k], d->nbxe[k]};
+        memcpy(s + p, v, sizeof(v)); p += 7;
+        memcpy(s + p, in->idxb[k], sizeof(int) * d->nb[k]); p += d->nb[k];
+        memcpy(s + p, in->idxs_rev[k], sizeof(int) * (d->nb[k] + d->ng[k])); p += d->nb[k] + d->ng[k];
+        memcpy(s + p, in->idxe[k], sizeof(int) * d->nbxe[k]); p += d->nbxe[k];
+    }
+    return p;
+}
+
+} // namespace gqp_host
 
 extern "C" {
 
@@ -405,16 +436,26 @@ void ocp_qp_out_get(ocp_qp_out *out, int k, const char *field, void *value)
     }
 }
 
-/* ocp_qp_common.c:874-921, line by line on the plain containers */
-/* d_ocp_qp_seed (acados/ocp_qp/ocp_qp_common.h: ocp_qp_seed): seed_g [r; q; zl; zu], seed_b, seed_d
- * [lb lg ub ug ls us] (natural sign), seed_m; one calloc'ed block */
-ocp_qp_seed *ocp_qp_seed_create(ocp_qp_dims *dims)
+/* d_ocp_qp_seed (acados/ocp_qp/ocp_qp_common.h: ocp_qp_seed; ocp_qp_common.c:263-300): seed_g [r; q; zl; zu],
+ * seed_b, seed_d [lb lg ub ug ls us] (natural sign), seed_m; one block, zero-initialised */
+static size_t seed_doubles(const ocp_qp_dims *dims)
 {
     const int N = dims->N;
     size_t cnt = 0;
     for (int k = 0; k <= N; k++)
         cnt += dims->nu[k] + dims->nx[k] + 2 * dims->ns[k] + (k < N ? dims->nx[k + 1] : 0) + 4 * (size_t) (dims->nb[k] + dims->ng[k] + dims->ns[k]);
-    char *raw = (char *) calloc(1, sizeof(ocp_qp_seed) + 4 * (N + 1) * sizeof(double *) + cnt * sizeof(double) + 64);
+    return cnt;
+}
+
+acados_size_t ocp_qp_seed_calculate_size(ocp_qp_dims *dims)
+{
+    return sizeof(ocp_qp_seed) + 4 * (dims->N + 1) * sizeof(double *) + seed_doubles(dims) * sizeof(double) + 64;
+}
+
+ocp_qp_seed *ocp_qp_seed_assign(ocp_qp_dims *dims, void *raw_memory)
+{
+    const int N = dims->N;
+    char *raw = (char *) raw_memory;
     ocp_qp_seed *sd = (ocp_qp_seed *) raw;
     raw = align8(raw + sizeof(ocp_qp_seed));
     sd->dim = dims;
@@ -423,6 +464,7 @@ ocp_qp_seed *ocp_qp_seed_create(ocp_qp_dims *dims)
     sd->seed_d = (double **) raw; raw += (N + 1) * sizeof(double *);
     sd->seed_m = (double **) raw; raw += (N + 1) * sizeof(double *);
     double *p = (double *) align8(raw);
+    memset(p, 0, seed_doubles(dims) * sizeof(double));
     for (int k = 0; k <= N; k++)
     {
         const int nct = 2 * (dims->nb[k] + dims->ng[k] + dims->ns[k]);
@@ -434,8 +476,11 @@ ocp_qp_seed *ocp_qp_seed_create(ocp_qp_dims *dims)
     return sd;
 }
 
+ocp_qp_seed *ocp_qp_seed_create(ocp_qp_dims *dims) { return ocp_qp_seed_assign(dims, calloc(1, ocp_qp_seed_calculate_size(dims))); }
+
 void ocp_qp_seed_free(void *seed) { free(seed); }
 
+/* ocp_qp_common.c:874-921, line by line on the plain containers */
 void ocp_qp_compute_t(ocp_qp_in *in, ocp_qp_out *out)
 {
     const ocp_qp_dims *d = in->dim;
@@ -475,6 +520,265 @@ void ocp_qp_compute_t(ocp_qp_in *in, ocp_qp_out *out)
     }
 }
 
+
+/* ------------------------------------------------------ KKT residuals */
+/* ocp_qp_res / ocp_qp_res_ws and ocp_qp_res_compute / _nrm_inf (ocp_qp_common.c:497-667): the residual vectors of an
+ * arbitrary (qp_in, qp_out) pair, evaluated ON THE DEVICE by a kernel that shares nothing with the IPM sweeps
+ * (res_kernels.hpp).  The workspace owns a one-instance device batch (device-side resource: release it with
+ * ocp_qp_res_workspace_free, or use ocp_qp_inf_norm_residuals, which creates and releases one per call like
+ * ocp_qp_interface.c:642-650 does with its malloc'ed pair). */
+struct ocp_qp_res_ws_
+{
+    gqp_host::single_batch sb;
+};
+
+static size_t res_doubles(const ocp_qp_dims *d)
+{
+    size_t cnt = 0;
+    for (int k = 0; k <= d->N; k++)
+        cnt += d->nu[k] + d->nx[k] + 2 * d->ns[k] + (k < d->N ? d->nx[k + 1] : 0) + 4 * (size_t) (d->nb[k] + d->ng[k] + d->ns[k]);
+    return cnt;
+}
+
+acados_size_t ocp_qp_res_calculate_size(ocp_qp_dims *dims)
+{
+    return sizeof(ocp_qp_res) + 4 * (dims->N + 1) * sizeof(double *) + res_doubles(dims) * sizeof(double) + 64;
+}
+
+ocp_qp_res *ocp_qp_res_assign(ocp_qp_dims *dims, void *raw_memory)
+{
+    const int N = dims->N;
+    char *raw = (char *) raw_memory;
+    ocp_qp_res *r = (ocp_qp_res *) raw;
+    raw = align8(raw + sizeof(ocp_qp_res));
+    r->dim = dims;
+    r->res_g = (double **) raw; raw += (N + 1) * sizeof(double *);
+    r->res_b = (double **) raw; raw += (N + 1) * sizeof(double *);
+    r->res_d = (double **) raw; raw += (N + 1) * sizeof(double *);
+    r->res_m = (double **) raw; raw += (N + 1) * sizeof(double *);
+    double *p = (double *) align8(raw);
+    for (int k = 0; k <= N; k++)
+    {
+        const int nct = 2 * (dims->nb[k] + dims->ng[k] + dims->ns[k]);
+        r->res_g[k] = p; p += dims->nu[k] + dims->nx[k] + 2 * dims->ns[k];
+        r->res_b[k] = p; p += k < N ? dims->nx[k + 1] : 0;
+        r->res_d[k] = p; p += nct;
+        r->res_m[k] = p; p += nct;
+    }
+    return r;
+}
+
+ocp_qp_res *ocp_qp_res_create(ocp_qp_dims *dims) { return ocp_qp_res_assign(dims, calloc(1, ocp_qp_res_calculate_size(dims))); }
+void ocp_qp_res_free(void *res) { free(res); }
+
+acados_size_t ocp_qp_res_workspace_calculate_size(ocp_qp_dims *dims) { return sizeof(ocp_qp_res_ws) + 8; }
+
+ocp_qp_res_ws *ocp_qp_res_workspace_assign(ocp_qp_dims *dims, void *raw_memory)
+{
+    ocp_qp_res_ws *ws = (ocp_qp_res_ws *) align8((char *) raw_memory);
+    memset(ws, 0, sizeof(*ws));
+    return ws;
+}
+
+ocp_qp_res_ws *ocp_qp_res_workspace_create(ocp_qp_dims *dims)
+{
+    return ocp_qp_res_workspace_assign(dims, calloc(1, ocp_qp_res_workspace_calculate_size(dims)));
+}
+
+/* releases the device batch and the block obtained from ocp_qp_res_workspace_create */
+void ocp_qp_res_workspace_free(ocp_qp_res_ws *ws)
+{
+    if (!ws) return;
+    gqp_host::single_batch_free(&ws->sb);
+    free(ws);
+}
+
+/* ocp_qp_common.c:559-594 */
+void ocp_qp_res_compute(ocp_qp_in *qp_in, ocp_qp_out *qp_out, ocp_qp_res *qp_res, ocp_qp_res_ws *res_ws)
+{
+    qp_info *info = (qp_info *) qp_out->misc;
+    if (info && info->t_computed == 0)
+    {
+        ocp_qp_compute_t(qp_in, qp_out);
+        info->t_computed = 1;
+    }
+    if (gqp_host::single_batch_load_in(&res_ws->sb, qp_in) != 0)
+    {
+        printf("\nerror: ocp_qp_res_compute: no GPU batch could be created (no device or unsupported shape)\n");
+        exit(1);
+    }
+    ocp_qp_gpu_batch *b = res_ws->sb.batch;
+    const ocp_qp_dims *d = qp_in->dim;
+    gqp_host::single_batch_push_out(b, d, qp_out);
+    if (ocp_qp_gpu_batch_res_compute(b) != 0) exit(1);
+    for (int k = 0; k <= d->N; k++)
+    {
+        const int nv = d->nu[k] + d->nx[k];
+        if (nv) ocp_qp_gpu_batch_get(b, "res_g", k, qp_res->res_g[k], 0);
+        if (d->ns[k]) ocp_qp_gpu_batch_get(b, "res_gs", k, qp_res->res_g[k] + nv, 0);
+        if (k < d->N && d->nx[k + 1]) ocp_qp_gpu_batch_get(b, "res_b", k, qp_res->res_b[k], 0);
+        if (d->nb[k] + d->ng[k] + d->ns[k])
+        {
+            ocp_qp_gpu_batch_get(b, "res_d", k, qp_res->res_d[k], 0);
+            ocp_qp_gpu_batch_get(b, "res_m", k, qp_res->res_m[k], 0);
+        }
+    }
+}
+
+/* ocp_qp_common.c:598-667 */
+void ocp_qp_res_compute_nrm_inf(ocp_qp_res *qp_res, double res[4])
+{
+    const ocp_qp_dims *d = qp_res->dim;
+    auto nrm = [](const double *v, int n, double &acc) {
+        for (int e = 0; e < n; e++)
+        {
+            const double a = v[e] < 0.0 ? -v[e] : v[e];
+            if (a > acc || v[e] != v[e]) acc = a;
+        }
+    };
+    res[0] = res[1] = res[2] = res[3] = 0.0;
+    for (int k = 0; k <= d->N; k++)
+    {
+        const int nct = 2 * (d->nb[k] + d->ng[k] + d->ns[k]);
+        nrm(qp_res->res_g[k], d->nu[k] + d->nx[k] + 2 * d->ns[k], res[0]);
+        if (k < d->N) nrm(qp_res->res_b[k], d->nx[k + 1], res[1]);
+        nrm(qp_res->res_d[k], nct, res[2]);
+        nrm(qp_res->res_m[k], nct, res[3]);
+    }
+}
+
+/* ocp_qp_interface.c:642-650 */
+void ocp_qp_inf_norm_residuals(ocp_qp_dims *dims, ocp_qp_in *qp_in, ocp_qp_out *qp_out, double *res)
+{
+    ocp_qp_res *qp_res = ocp_qp_res_create(dims);
+    ocp_qp_res_ws *res_ws = ocp_qp_res_workspace_create(dims);
+    ocp_qp_res_compute(qp_in, qp_out, qp_res, res_ws);
+    ocp_qp_res_compute_nrm_inf(qp_res, res);
+    ocp_qp_res_free(qp_res);
+    ocp_qp_res_workspace_free(res_ws);
+}
+
+} /* extern "C" */
+
+/* ------------------------------------ one QP <-> a one-instance device batch */
+namespace gqp_host
+{
+
+struct cfield { const char *name; int fid; int dyn; int matrix; };
+static const cfield k_cfields[] = {
+    {"A", F_A, 1, 1}, {"B", F_B, 1, 1}, {"b", F_b, 1, 0}, {"Q", F_Q, 0, 1}, {"S", F_S, 0, 1}, {"R", F_R, 0, 1}, {"q", F_q, 0, 0},
+    {"r", F_r, 0, 0}, {"C", F_C, 0, 1}, {"D", F_D, 0, 1}, {"lg", F_lg, 0, 0}, {"ug", F_ug, 0, 0}, {"lg_mask", F_lgm, 0, 0},
+    {"ug_mask", F_ugm, 0, 0}, {"Zl", F_Zl, 0, 1}, {"Zu", F_Zu, 0, 1}, {"zl", F_zl, 0, 0}, {"zu", F_zu, 0, 0}, {"lls", F_lls, 0, 0},
+    {"lus", F_lus, 0, 0}, {"lls_mask", F_llsm, 0, 0}, {"lus_mask", F_lusm, 0, 0}};
+
+static int clen(const ocp_qp_dims *d, const char *f, int k)
+{
+    const int n = vlen(d, f, k);
+    if (n >= 0) return n;
+    return (f[0] == 'l' || f[0] == 'u') && f[1] == 'g' ? d->ng[k] : d->ns[k]; /* lg ug (+ masks) | Zl Zu zl zu lls lus (+ masks) */
+}
+
+/* bounds and their masks: the containers keep [bu; bx] in one array, the device batch takes them per kind */
+static void bounds_xfer(ocp_qp_gpu_batch *b, const ocp_qp_in *q, int k, bool to_device)
+{
+    const ocp_qp_dims *d = q->dim;
+    const int nbu = d->nbu[k];
+    struct { const char *name; double *p; int n; } f[] = {
+        {"lbu", q->lb[k], nbu}, {"ubu", q->ub[k], nbu}, {"lbu_mask", q->lb_mask[k], nbu}, {"ubu_mask", q->ub_mask[k], nbu},
+        {"lbx", q->lb[k] + nbu, d->nbx[k]}, {"ubx", q->ub[k] + nbu, d->nbx[k]},
+        {"lbx_mask", q->lb_mask[k] + nbu, d->nbx[k]}, {"ubx_mask", q->ub_mask[k] + nbu, d->nbx[k]}};
+    for (auto &e : f)
+    {
+        if (e.n <= 0) continue;
+        if (to_device) ocp_qp_gpu_batch_set(b, e.name, k, e.p, 0);
+        else ocp_qp_gpu_batch_get(b, e.name, k, e.p, 0);
+    }
+}
+
+int single_batch_load_in(single_batch *sb, const ocp_qp_in *in)
+{
+    const ocp_qp_dims *d = in->dim;
+    const int len = structure_sig_len(d);
+    std::vector<int> sig(len);
+    structure_sig_fill(in, sig.data());
+    if (!sb->batch || sb->sig_len != len || memcmp(sb->sig, sig.data(), sizeof(int) * len) != 0)
+    {
+        single_batch_free(sb);
+        sb->batch = ocp_qp_gpu_batch_create(d->N, d->nx, d->nu, d->nbx, d->nbu, d->ng, d->ns, 1, -1);
+        if (!sb->batch) return -1;
+        sb->sig = (int *) malloc(sizeof(int) * len);
+        memcpy(sb->sig, sig.data(), sizeof(int) * len);
+        sb->sig_len = len;
+        for (int k = 0; k <= d->N; k++)
+        {
+            ocp_qp_gpu_batch_set_int(sb->batch, "idxb", k, in->idxb[k], d->nb[k]);
+            ocp_qp_gpu_batch_set_int(sb->batch, "idxs_rev", k, in->idxs_rev[k], d->nb[k] + d->ng[k]);
+            ocp_qp_gpu_batch_set_int(sb->batch, "idxe", k, in->idxe[k], d->nbxe[k]);
+        }
+    }
+    ocp_qp_gpu_batch *b = sb->batch;
+    for (int k = 0; k <= d->N; k++)
+    {
+        for (const cfield &f : k_cfields)
+            if (!(f.dyn && k == d->N) && clen(d, f.name, k) > 0) ocp_qp_gpu_batch_set(b, f.name, k, in_field(in, f.fid, k), 0);
+        bounds_xfer(b, in, k, true);
+    }
+    return 0;
+}
+
+void single_batch_read_in(ocp_qp_gpu_batch *b, ocp_qp_in *in, int what)
+{
+    const ocp_qp_dims *d = in->dim;
+    for (int k = 0; k <= d->N; k++)
+    {
+        for (const cfield &f : k_cfields)
+            if (!(f.dyn && k == d->N) && clen(d, f.name, k) > 0 && (what & (f.matrix ? 1 : 2)))
+                ocp_qp_gpu_batch_get(b, f.name, k, const_cast<double *>(in_field(in, f.fid, k)), 0);
+        if (what & 2) bounds_xfer(b, in, k, false);
+        if (what & 1)
+        {
+            ocp_qp_gpu_batch_get_int(b, "idxb", k, in->idxb[k]);
+            ocp_qp_gpu_batch_get_int(b, "idxs_rev", k, in->idxs_rev[k]);
+            ocp_qp_gpu_batch_get_int(b, "idxe", k, in->idxe[k]);
+        }
+    }
+}
+
+static void solution_xfer(ocp_qp_gpu_batch *b, const ocp_qp_dims *d, ocp_qp_out *o, bool to_device)
+{
+    for (int k = 0; k <= d->N; k++)
+    {
+        const int nu = d->nu[k], nx = d->nx[k], ns = d->ns[k], nct = 2 * (d->nb[k] + d->ng[k] + ns);
+        struct { const char *name; double *p; int n; } f[] = {
+            {"u", o->ux[k], nu}, {"x", o->ux[k] + nu, nx}, {"sl", o->ux[k] + nu + nx, ns}, {"su", o->ux[k] + nu + nx + ns, ns},
+            {"pi", k < d->N ? o->pi[k] : nullptr, k < d->N ? d->nx[k + 1] : 0}, {"lam", o->lam[k], nct}, {"t", o->t[k], nct}};
+        for (auto &e : f)
+        {
+            if (e.n <= 0) continue;
+            if (to_device) ocp_qp_gpu_batch_set(b, e.name, k, e.p, 0);
+            else ocp_qp_gpu_batch_get(b, e.name, k, e.p, 0);
+        }
+    }
+}
+
+void single_batch_push_out(ocp_qp_gpu_batch *b, const ocp_qp_dims *d, const ocp_qp_out *out)
+{
+    solution_xfer(b, d, const_cast<ocp_qp_out *>(out), true);
+}
+
+void single_batch_pull_out(ocp_qp_gpu_batch *b, const ocp_qp_dims *d, ocp_qp_out *out) { solution_xfer(b, d, out, false); }
+
+void single_batch_free(single_batch *sb)
+{
+    if (sb->batch) ocp_qp_gpu_batch_destroy(sb->batch);
+    free(sb->sig);
+    sb->batch = nullptr; sb->sig = nullptr; sb->sig_len = 0;
+}
+
+} // namespace gqp_host
+
+extern "C" {
+
 /* ------------------------------------------------- inner plugin (vtable) */
 /* ocp_qp_hpipm.c:60-540 */
 
@@ -482,17 +786,34 @@ acados_size_t ocp_qp_gpu_ipm_opts_calculate_size(void *config, void *dims) { ret
 
 void *ocp_qp_gpu_ipm_opts_assign(void *config, void *dims, void *raw_memory) { return align8((char *) raw_memory); }
 
-void ocp_qp_gpu_ipm_opts_initialize_default(void *config, void *dims, void *opts_)
+static void gpu_ipm_mode_defaults(gpu_ipm_opts *o)
 {
-    gpu_ipm_opts *o = (gpu_ipm_opts *) opts_;
-    /* mode BALANCE + the acados overrides of ocp_qp_hpipm.c:101-113 */
+    /* mode BALANCE + the acados overrides of ocp_qp_hpipm.c:101-113 (ocp_qp_hpipm_opts_overwrite_mode_opts: the four
+     * tolerances, iter_max, alpha_min, mu0 are re-applied after EVERY mode change, so the modes do not differ in them) */
     o->mu0 = 1e0; o->tol_stat = 1e-6; o->tol_eq = 1e-8; o->tol_ineq = 1e-8; o->tol_comp = 1e-8;
-    o->alpha_min = 1e-8; o->tau_min = 0.0; o->reg_prim = 1e-15; o->t0_min = 1e-16; o->lam0_min = 1e-16;
-    o->iter_max = 50; o->warm_start = 0; o->cond_pred_corr = 1; o->print_level = 0; o->ric_alg = 1;
+    o->alpha_min = 1e-8; o->reg_prim = 1e-15; o->t0_min = 1e-16; o->lam0_min = 1e-16;
+    o->iter_max = 50; o->warm_start = 0; o->cond_pred_corr = 1; o->ric_alg = 1;
     o->t0_init = 2; o->update_fact_exit = 0;
 }
 
+void ocp_qp_gpu_ipm_opts_initialize_default(void *config, void *dims, void *opts_)
+{
+    gpu_ipm_opts *o = (gpu_ipm_opts *) opts_;
+    gpu_ipm_mode_defaults(o);
+    o->print_level = 0;
+    o->tau_min = 0.0; /* m_relax, ocp_qp_hpipm.c:126 */
+    o->noticed = 0;
+}
+
 void ocp_qp_gpu_ipm_opts_update(void *config, void *dims, void *opts) {}
+
+/* options that are part of the HPIPM-named surface but select nothing in this backend: said once per opts object */
+static void notice_once(gpu_ipm_opts *o, int bit, const char *field, const char *what)
+{
+    if (o->noticed & (1 << bit)) return;
+    o->noticed |= 1 << bit;
+    printf("acados_amd: ocp_qp_gpu_ipm: option %s accepted, %s\n", field, what);
+}
 
 void ocp_qp_gpu_ipm_opts_set(void *config, void *opts_, const char *field, void *value)
 {
@@ -507,10 +828,12 @@ void ocp_qp_gpu_ipm_opts_set(void *config, void *opts_, const char *field, void 
             printf("ocp_qp_gpu_ipm_opts_set: got non-supported mode %s\n", mode);
             exit(1);
         }
-        /* a mode change re-applies the acados overrides (ocp_qp_hpipm.c:146-165) */
-        const int pl = o->print_level;
-        ocp_qp_gpu_ipm_opts_initialize_default(config, nullptr, o);
-        o->print_level = pl;
+        /* a mode change re-applies the acados overrides (ocp_qp_hpipm.c:146-165); print_level and tau_min (m_relax)
+         * live outside the HPIPM argument struct there and survive it */
+        gpu_ipm_mode_defaults(o);
+        if (strcmp(mode, "BALANCE"))
+            notice_once(o, 0, "hpipm_mode", "one IPM variant exists (the BALANCE-class Mehrotra predictor-corrector); the mode "
+                                            "only re-applies the acados default tolerances");
     }
     else if (!strcmp(field, "print_level")) o->print_level = *i;
     else if (!strcmp(field, "tau_min")) o->tau_min = *d;
@@ -521,13 +844,22 @@ void ocp_qp_gpu_ipm_opts_set(void *config, void *opts_, const char *field, void 
     else if (!strcmp(field, "tol_comp")) o->tol_comp = *d;
     else if (!strcmp(field, "warm_start")) o->warm_start = *i;
     else if (!strcmp(field, "mu0")) { if (*d > 0.0) o->mu0 = *d; }
-    else if (!strcmp(field, "t0_init")) o->t0_init = *i;
-    else if (!strcmp(field, "ric_alg")) o->ric_alg = *i;
+    else if (!strcmp(field, "t0_init"))
+    {
+        o->t0_init = *i;
+        if (*i != 2) notice_once(o, 1, "t0_init", "the cold start uses ONE initialisation of t / lam (the oracle-pinned one)");
+    }
+    else if (!strcmp(field, "ric_alg"))
+    {
+        o->ric_alg = *i;
+        if (*i != 1) notice_once(o, 2, "ric_alg", "only the square-root Riccati recursion (ric_alg = 1) is implemented");
+    }
     else if (!strcmp(field, "alpha_min")) o->alpha_min = *d;
     else if (!strcmp(field, "reg_prim")) o->reg_prim = *d;
-    else if (!strcmp(field, "t0_min")) o->t0_min = *d;
-    else if (!strcmp(field, "lam0_min")) o->lam0_min = *d;
-    else if (!strcmp(field, "update_fact_exit")) o->update_fact_exit = *i;
+    else if (!strcmp(field, "t0_min")) o->t0_min = *d;       /* lower clip of t at a hot start */
+    else if (!strcmp(field, "lam0_min")) o->lam0_min = *d;   /* lower clip of lam at a hot start */
+    else if (!strcmp(field, "update_fact_exit")) o->update_fact_exit = *i; /* always honoured: the factor sweep factorises
+                                                                              at the iterate it then judges */
     else if (!strcmp(field, "cond_pred_corr")) o->cond_pred_corr = *i;
     else
     {
@@ -542,7 +874,11 @@ void ocp_qp_gpu_ipm_opts_get(void *config, void *opts_, const char *field, void 
     if (!strcmp(field, "t0_min")) *(double *) value = o->t0_min;
     else if (!strcmp(field, "lam0_min")) *(double *) value = o->lam0_min;
     else if (!strcmp(field, "iter_max")) *(int *) value = o->iter_max;
+    else if (!strcmp(field, "warm_start")) *(int *) value = o->warm_start;
     else if (!strcmp(field, "tol_stat")) *(double *) value = o->tol_stat;
+    else if (!strcmp(field, "tol_eq")) *(double *) value = o->tol_eq;
+    else if (!strcmp(field, "tol_ineq")) *(double *) value = o->tol_ineq;
+    else if (!strcmp(field, "tol_comp")) *(double *) value = o->tol_comp;
     else
     {
         printf("\nerror: ocp_qp_gpu_ipm_opts_get: field %s not available\n", field);
@@ -550,13 +886,32 @@ void ocp_qp_gpu_ipm_opts_get(void *config, void *opts_, const char *field, void 
     }
 }
 
-acados_size_t ocp_qp_gpu_ipm_memory_calculate_size(void *config, void *dims, void *opts) { return sizeof(gpu_ipm_memory) + 8; }
+/* statistics rows kept: HPIPM's stat_max is fixed at 50 by acados (ocp_qp_hpipm.c:108); iter_max raised later is
+ * served up to this many rows */
+static int stat_rows_for(const gpu_ipm_opts *o) { return std::max(o ? o->iter_max : 50, 50) + 2; }
 
-void *ocp_qp_gpu_ipm_memory_assign(void *config, void *dims, void *opts, void *raw_memory)
+acados_size_t ocp_qp_gpu_ipm_memory_calculate_size(void *config, void *dims_, void *opts_)
 {
-    gpu_ipm_memory *m = (gpu_ipm_memory *) align8((char *) raw_memory);
+    const ocp_qp_dims *d = (const ocp_qp_dims *) dims_;
+    const int cap = gqp_host::structure_sig_len(d);
+    return sizeof(gpu_ipm_memory) + 2 * sizeof(int) * (size_t) cap
+           + sizeof(double) * GPU_IPM_STAT_M * (size_t) stat_rows_for((const gpu_ipm_opts *) opts_) + 4 * 8;
+}
+
+void *ocp_qp_gpu_ipm_memory_assign(void *config, void *dims_, void *opts_, void *raw_memory)
+{
+    const ocp_qp_dims *d = (const ocp_qp_dims *) dims_;
+    char *c = align8((char *) raw_memory);
+    gpu_ipm_memory *m = (gpu_ipm_memory *) c;
     memset(m, 0, sizeof(*m));
-    m->stat_m = 20;
+    c = align8(c + sizeof(gpu_ipm_memory));
+    m->stat_m = GPU_IPM_STAT_M;
+    m->stat_rows = stat_rows_for((const gpu_ipm_opts *) opts_);
+    m->stat = (double *) c; c += sizeof(double) * GPU_IPM_STAT_M * (size_t) m->stat_rows;
+    m->sig_cap = gqp_host::structure_sig_len(d);
+    m->sig = (int *) c; c += sizeof(int) * (size_t) m->sig_cap;
+    m->sig_scratch = (int *) c; c += sizeof(int) * (size_t) m->sig_cap;
+    memset(m->stat, 0, sizeof(double) * GPU_IPM_STAT_M * (size_t) m->stat_rows);
     return m;
 }
 
@@ -567,8 +922,9 @@ void ocp_qp_gpu_ipm_memory_get(void *config, void *mem_, const char *field, void
     if (!strcmp(field, "time_qp_solver_call")) *(double *) value = m->time_qp_solver_call;
     else if (!strcmp(field, "iter")) *(int *) value = m->iter;
     else if (!strcmp(field, "status")) *(int *) value = m->status;
-    else if (!strcmp(field, "stat")) *(double **) value = m->cache ? m->cache->stat.data() : nullptr;
+    else if (!strcmp(field, "stat")) *(double **) value = m->stat;
     else if (!strcmp(field, "stat_m")) *(int *) value = m->stat_m;
+    else if (!strcmp(field, "stat_rows")) *(int *) value = m->stat_rows; /* rows the table holds (extension) */
     else if (!strcmp(field, "tau_iter")) *(double *) value = 0.0;
     else
     {
@@ -579,11 +935,78 @@ void ocp_qp_gpu_ipm_memory_get(void *config, void *mem_, const char *field, void
 
 acados_size_t ocp_qp_gpu_ipm_workspace_calculate_size(void *config, void *dims, void *opts) { return 0; }
 
-static thread_local int g_cond_N_request = 0; /* set by the xcond level right before evaluate (same thread) */
-static thread_local const int *g_cond_blocks_request = nullptr;
+} /* extern "C" */
 
-int ocp_qp_gpu_ipm_evaluate_batch(void *config, int n, void **qp_in_, void **qp_out_, void *opts_, void **mem_,
-                                  void *work, int *status)
+static void build_segments(batch_cache *bc, ocp_qp_gpu_batch *b, const ocp_qp_dims *d)
+{
+    /* segment tables of the bulk blobs, once per device batch */
+    const int N = d->N;
+    bc->seg_in.clear(); bc->seg_out.clear();
+    bc->L_in = ocp_qp_gpu_batch_bulk_len(b, 0);
+    bc->L_out = ocp_qp_gpu_batch_bulk_len(b, 1);
+    auto add = [&](std::vector<blob_seg> &tab, int output, const char *name, int k, int len, int fid, int shift) {
+        if (len <= 0) return;
+        int seg_len = 0;
+        const int off = ocp_qp_gpu_batch_bulk_offset(b, output, name, k, &seg_len);
+        if (off < 0 || seg_len != len)
+        {
+            if (output) return;
+            printf("\nerror: ocp_qp_gpu_ipm: field %s at stage %d has no place in the device layout\n", name, k);
+            exit(1);
+        }
+        tab.push_back(blob_seg{off, len, fid, k, shift});
+    };
+    for (int k = 0; k <= N; k++)
+    {
+        const int nu = d->nu[k], nx = d->nx[k], nbu = d->nbu[k], nbx = d->nbx[k], ng = d->ng[k], ns = d->ns[k];
+        std::vector<blob_seg> &ti = bc->seg_in, &to = bc->seg_out;
+        if (k < N)
+        {
+            add(ti, 0, "A", k, vlen(d, "A", k), F_A, 0);
+            add(ti, 0, "B", k, vlen(d, "B", k), F_B, 0);
+            add(ti, 0, "b", k, vlen(d, "b", k), F_b, 0);
+        }
+        add(ti, 0, "Q", k, vlen(d, "Q", k), F_Q, 0);
+        add(ti, 0, "S", k, vlen(d, "S", k), F_S, 0);
+        add(ti, 0, "R", k, vlen(d, "R", k), F_R, 0);
+        add(ti, 0, "q", k, vlen(d, "q", k), F_q, 0);
+        add(ti, 0, "r", k, vlen(d, "r", k), F_r, 0);
+        add(ti, 0, "lbu", k, nbu, F_lb, 0);
+        add(ti, 0, "ubu", k, nbu, F_ub, 0);
+        add(ti, 0, "lbx", k, nbx, F_lb, nbu);
+        if (d->nbxe[k] > 0) add(ti, 0, "lbx#value", k, nbx, F_lb, nbu);
+        add(ti, 0, "ubx", k, nbx, F_ub, nbu);
+        add(ti, 0, "lbu_mask", k, nbu, F_lbm, 0);
+        add(ti, 0, "ubu_mask", k, nbu, F_ubm, 0);
+        add(ti, 0, "lbx_mask", k, nbx, F_lbm, nbu);
+        add(ti, 0, "ubx_mask", k, nbx, F_ubm, nbu);
+        add(ti, 0, "C", k, vlen(d, "C", k), F_C, 0);
+        add(ti, 0, "D", k, vlen(d, "D", k), F_D, 0);
+        add(ti, 0, "lg", k, ng, F_lg, 0);
+        add(ti, 0, "ug", k, ng, F_ug, 0);
+        add(ti, 0, "lg_mask", k, ng, F_lgm, 0);
+        add(ti, 0, "ug_mask", k, ng, F_ugm, 0);
+        add(ti, 0, "Zl", k, ns, F_Zl, 0);
+        add(ti, 0, "Zu", k, ns, F_Zu, 0);
+        add(ti, 0, "zl", k, ns, F_zl, 0);
+        add(ti, 0, "zu", k, ns, F_zu, 0);
+        add(ti, 0, "lls", k, ns, F_lls, 0);
+        add(ti, 0, "lus", k, ns, F_lus, 0);
+        add(ti, 0, "lls_mask", k, ns, F_llsm, 0);
+        add(ti, 0, "lus_mask", k, ns, F_lusm, 0);
+        const int nct = 2 * (d->nb[k] + ng + ns);
+        add(to, 1, "u", k, nu, O_ux, 0);
+        add(to, 1, "x", k, nx, O_ux, nu);
+        add(to, 1, "sl", k, ns, O_ux, nu + nx);
+        add(to, 1, "su", k, ns, O_ux, nu + nx + ns);
+        if (k < N) add(to, 1, "pi", k, d->nx[k + 1], O_pi, 0);
+        add(to, 1, "lam", k, nct, O_lam, 0);
+        add(to, 1, "t", k, nct, O_t, 0);
+    }
+}
+
+int gqp_host::gpu_ipm_evaluate_impl(void *config, int n, void **qp_in_, void **qp_out_, void *opts_, void **mem_, void *work,
+                                    int *status, const cond_request *cr)
 {
     const double t_start = now_s();
     ocp_qp_in **ins = (ocp_qp_in **) qp_in_;
@@ -592,18 +1015,36 @@ int ocp_qp_gpu_ipm_evaluate_batch(void *config, int n, void **qp_in_, void **qp_
     gpu_ipm_memory *m = (gpu_ipm_memory *) mem_[0];
     const ocp_qp_dims *d = ins[0]->dim;
     const int N = d->N;
+    const int phase = cr ? cr->phase : 0;
 
-    /* (re)create the device batch when the count or the structure changed */
-    std::vector<int> sig = structure_sig(ins[0]);
-    for (int i = 1; i < n; i++)
-        if (structure_sig(ins[i]) != sig)
-        {
-            printf("\nerror: ocp_qp_gpu_ipm_evaluate_batch: QP %d differs in structure from QP 0\n", i);
-            exit(1);
-        }
-    if (!m->cache) m->cache = new batch_cache();
+    /* (re)create the device batch when the count or the structure changed; signatures are compared in the carved
+     * scratch -- no allocation on this path */
+    const int siglen = gqp_host::structure_sig_len(d);
+    if (siglen > m->sig_cap)
+    {
+        printf("\nerror: ocp_qp_gpu_ipm: the dims of qp_in grew after memory_assign (signature %d > %d ints)\n", siglen, m->sig_cap);
+        exit(1);
+    }
+    gqp_host::structure_sig_fill(ins[0], m->sig_scratch);
+    if (!m->cache) m->cache = new batch_cache(); /* device-side resources: once per memory, released by terminate */
     batch_cache *bc = m->cache;
-    if (!bc->batch || bc->n != n || bc->sig != sig)
+    const bool rebuild = !bc->batch || bc->n != n || m->sig_len != siglen || memcmp(m->sig, m->sig_scratch, sizeof(int) * siglen) != 0;
+    if (rebuild)
+    {
+        memcpy(m->sig, m->sig_scratch, sizeof(int) * siglen);
+        m->sig_len = siglen;
+    }
+    for (int i = 1; i < n; i++)
+    {
+        if (gqp_host::structure_sig_len(ins[i]->dim) == siglen)
+        {
+            gqp_host::structure_sig_fill(ins[i], m->sig_scratch);
+            if (memcmp(m->sig, m->sig_scratch, sizeof(int) * siglen) == 0) continue;
+        }
+        printf("\nerror: ocp_qp_gpu_ipm_evaluate_batch: QP %d differs in structure from QP 0\n", i);
+        exit(1);
+    }
+    if (rebuild)
     {
         if (bc->batch) ocp_qp_gpu_batch_destroy(bc->batch);
         bc->batch = ocp_qp_gpu_batch_create(N, d->nx, d->nu, d->nbx, d->nbu, d->ng, d->ns, n, -1);
@@ -613,16 +1054,16 @@ int ocp_qp_gpu_ipm_evaluate_batch(void *config, int n, void **qp_in_, void **qp_
             exit(1);
         }
         bc->n = n;
-        bc->blocks_sent = false;
-        bc->sig = sig;
-        bc->seg_in.clear();
-        bc->seg_out.clear();
+        bc->cond_N_sent = -1;
+        bc->blocks_sent.clear();
         for (int k = 0; k <= N; k++)
         {
             ocp_qp_gpu_batch_set_int(bc->batch, "idxb", k, ins[0]->idxb[k], d->nb[k]);
             ocp_qp_gpu_batch_set_int(bc->batch, "idxs_rev", k, ins[0]->idxs_rev[k], d->nb[k] + d->ng[k]);
             ocp_qp_gpu_batch_set_int(bc->batch, "idxe", k, ins[0]->idxe[k], d->nbxe[k]);
         }
+        build_segments(bc, bc->batch, d);
+        if (n > 1) { bc->st.assign(n, 0); bc->it.assign(n, 0); }
     }
     ocp_qp_gpu_batch *b = bc->batch;
 
@@ -632,96 +1073,69 @@ int ocp_qp_gpu_ipm_evaluate_batch(void *config, int n, void **qp_in_, void **qp_
     ocp_qp_gpu_batch_opts_set(b, "tol_eq", &o->tol_eq);
     ocp_qp_gpu_batch_opts_set(b, "tol_ineq", &o->tol_ineq);
     ocp_qp_gpu_batch_opts_set(b, "tol_comp", &o->tol_comp);
-    ocp_qp_gpu_batch_opts_set(b, "warm_start", &o->warm_start);
+    /* warm_start 1 = 0: "primal guess is kept ... NOTE: this is the same as 0, as acados resets the initial guess of
+     * primal variables to zero" (acados_ocp_options.py:1029-1031; the reset is ocp_qp_hpipm.c:325-336) */
+    const int ws = o->warm_start >= 2 ? o->warm_start : 0;
+    ocp_qp_gpu_batch_opts_set(b, "warm_start", &ws);
     ocp_qp_gpu_batch_opts_set(b, "mu0", &o->mu0);
     ocp_qp_gpu_batch_opts_set(b, "alpha_min", &o->alpha_min);
     ocp_qp_gpu_batch_opts_set(b, "tau_min", &o->tau_min);
     ocp_qp_gpu_batch_opts_set(b, "reg_prim", &o->reg_prim);
+    ocp_qp_gpu_batch_opts_set(b, "t0_min", &o->t0_min);
+    ocp_qp_gpu_batch_opts_set(b, "lam0_min", &o->lam0_min);
     ocp_qp_gpu_batch_opts_set(b, "cond_pred_corr", &o->cond_pred_corr);
     ocp_qp_gpu_batch_opts_set(b, "print_level", &o->print_level);
     {
-        int cn = g_cond_N_request > 0 ? g_cond_N_request : N;
-        ocp_qp_gpu_batch_opts_set(b, "cond_N", &cn);
-        if (g_cond_blocks_request && cn > 0 && cn < N && !bc->blocks_sent)
+        /* the condensing request arrives as an argument (from the xcond level's opts); the device batch is told only
+         * when it changes -- a change drops the resident condensed batch */
+        const int cn = cr && cr->N2 > 0 && cr->N2 < N ? cr->N2 : N;
+        bool same = cn == bc->cond_N_sent;
+        if (same && cn < N)
         {
-            if (ocp_qp_gpu_batch_opts_set(b, "cond_block_size", g_cond_blocks_request) != 0) exit(1); /* :352-356 */
-            bc->blocks_sent = true;
+            const bool has = cr->block_size != nullptr;
+            same = has ? ((int) bc->blocks_sent.size() == cn + 1 && memcmp(bc->blocks_sent.data(), cr->block_size, sizeof(int) * (cn + 1)) == 0)
+                       : bc->blocks_sent.empty();
+        }
+        if (!same)
+        {
+            int reset = N; /* forces the device batch to drop a child built for other block sizes */
+            ocp_qp_gpu_batch_opts_set(b, "cond_N", &reset);
+            ocp_qp_gpu_batch_opts_set(b, "cond_N", &cn);
+            bc->blocks_sent.clear();
+            if (cn < N && cr->block_size)
+            {
+                if (ocp_qp_gpu_batch_opts_set(b, "cond_block_size", cr->block_size) != 0) exit(1); /* :352-356 */
+                bc->blocks_sent.assign(cr->block_size, cr->block_size + cn + 1);
+            }
+            bc->cond_N_sent = cn;
         }
     }
 
-    /* re-read every member array of qp_in on every call (they alias ocp_nlp memory:
-     * ocp_nlp_common.c:2797-2894) and pack them: one host blob per instance, ONE host->device copy and ONE
-     * launch for the whole batch (ocp_qp_gpu_batch_set_bulk) */
-    std::vector<double> &stg = bc->stage;
-    if (bc->seg_in.empty())
+    if (ws >= 2 && phase != 1)
     {
-        /* segment tables of the bulk blobs, once per device batch */
-        bc->L_in = ocp_qp_gpu_batch_bulk_len(b, 0);
-        bc->L_out = ocp_qp_gpu_batch_bulk_len(b, 1);
-        auto add = [&](std::vector<blob_seg> &tab, int output, const char *name, int k, int len, int fid, int shift) {
-            if (len <= 0) return;
-            int seg_len = 0;
-            const int off = ocp_qp_gpu_batch_bulk_offset(b, output, name, k, &seg_len);
-            if (off < 0 || seg_len != len)
-            {
-                if (output) return;
-                printf("\nerror: ocp_qp_gpu_ipm: field %s at stage %d has no place in the device layout\n", name, k);
-                exit(1);
-            }
-            tab.push_back(blob_seg{off, len, fid, k, shift});
-        };
-        for (int k = 0; k <= N; k++)
-        {
-            const int nu = d->nu[k], nx = d->nx[k], nbu = d->nbu[k], nbx = d->nbx[k], ng = d->ng[k], ns = d->ns[k];
-            std::vector<blob_seg> &ti = bc->seg_in, &to = bc->seg_out;
-            if (k < N)
-            {
-                add(ti, 0, "A", k, vlen(d, "A", k), F_A, 0);
-                add(ti, 0, "B", k, vlen(d, "B", k), F_B, 0);
-                add(ti, 0, "b", k, vlen(d, "b", k), F_b, 0);
-            }
-            add(ti, 0, "Q", k, vlen(d, "Q", k), F_Q, 0);
-            add(ti, 0, "S", k, vlen(d, "S", k), F_S, 0);
-            add(ti, 0, "R", k, vlen(d, "R", k), F_R, 0);
-            add(ti, 0, "q", k, vlen(d, "q", k), F_q, 0);
-            add(ti, 0, "r", k, vlen(d, "r", k), F_r, 0);
-            add(ti, 0, "lbu", k, nbu, F_lb, 0);
-            add(ti, 0, "ubu", k, nbu, F_ub, 0);
-            add(ti, 0, "lbx", k, nbx, F_lb, nbu);
-            if (d->nbxe[k] > 0) add(ti, 0, "lbx#value", k, nbx, F_lb, nbu);
-            add(ti, 0, "ubx", k, nbx, F_ub, nbu);
-            add(ti, 0, "lbu_mask", k, nbu, F_lbm, 0);
-            add(ti, 0, "ubu_mask", k, nbu, F_ubm, 0);
-            add(ti, 0, "lbx_mask", k, nbx, F_lbm, nbu);
-            add(ti, 0, "ubx_mask", k, nbx, F_ubm, nbu);
-            add(ti, 0, "C", k, vlen(d, "C", k), F_C, 0);
-            add(ti, 0, "D", k, vlen(d, "D", k), F_D, 0);
-            add(ti, 0, "lg", k, ng, F_lg, 0);
-            add(ti, 0, "ug", k, ng, F_ug, 0);
-            add(ti, 0, "lg_mask", k, ng, F_lgm, 0);
-            add(ti, 0, "ug_mask", k, ng, F_ugm, 0);
-            add(ti, 0, "Zl", k, ns, F_Zl, 0);
-            add(ti, 0, "Zu", k, ns, F_Zu, 0);
-            add(ti, 0, "zl", k, ns, F_zl, 0);
-            add(ti, 0, "zu", k, ns, F_zu, 0);
-            add(ti, 0, "lls", k, ns, F_lls, 0);
-            add(ti, 0, "lus", k, ns, F_lus, 0);
-            add(ti, 0, "lls_mask", k, ns, F_llsm, 0);
-            add(ti, 0, "lus_mask", k, ns, F_lusm, 0);
-            const int nct = 2 * (d->nb[k] + ng + ns);
-            add(to, 1, "u", k, nu, O_ux, 0);
-            add(to, 1, "x", k, nx, O_ux, nu);
-            add(to, 1, "sl", k, ns, O_ux, nu + nx);
-            add(to, 1, "su", k, ns, O_ux, nu + nx + ns);
-            if (k < N) add(to, 1, "pi", k, d->nx[k + 1], O_pi, 0);
-            add(to, 1, "lam", k, nct, O_lam, 0);
-            add(to, 1, "t", k, nct, O_t, 0);
-        }
+        /* hot start: pi, lam, t of qp_out are the starting point (acados_ocp_options.py:1029-1032).  The reference
+         * zeroes the PRIMAL part of qp_out before every solve, whatever the warm start level (ocp_qp_hpipm.c:325-336: the
+         * QPs of an SQP method live in delta space), so u, x, sl, su go in as zeros.  Staged through the pinned output
+         * blob (same layout as the unpack); written BEFORE the pack, which then puts the equality-flagged values (x0)
+         * back into the iterate. */
+        const size_t L = (size_t) bc->L_out;
+        pinned_reserve(bc->blob_out, bc->cap_out, (size_t) n * L);
+        double *blob = bc->blob_out;
+        const std::vector<blob_seg> &tab = bc->seg_out;
+        par_instances(n, [&](int lo, int hi) {
+            for (int i = lo; i < hi; i++)
+                for (const blob_seg &g : tab)
+                {
+                    if (g.fid == O_ux) memset(blob + (size_t) i * L + g.off, 0, sizeof(double) * g.len);
+                    else memcpy(blob + (size_t) i * L + g.off, out_field(outs[i], g.fid, g.k) + g.shift, sizeof(double) * g.len);
+                }
+        });
+        ocp_qp_gpu_batch_set_bulk_out(b, blob, 0);
     }
+    /* every member array of every qp_in is re-read on every call (they alias ocp_nlp memory:
+     * ocp_nlp_common.c:2797-2894): host threads gather them into ONE pinned blob, then one host->device copy
+     * and one scatter launch move the whole batch (ocp_qp_gpu_batch_set_bulk) */
     {
-        /* every member array of every qp_in is re-read on every call (they alias ocp_nlp memory:
-         * ocp_nlp_common.c:2797-2894): host threads gather them into ONE pinned blob, then one host->device copy
-         * and one scatter launch move the whole batch (ocp_qp_gpu_batch_set_bulk) */
         const size_t L = (size_t) bc->L_in;
         pinned_reserve(bc->blob_in, bc->cap_in, (size_t) n * L);
         double *blob = bc->blob_in;
@@ -733,30 +1147,16 @@ int ocp_qp_gpu_ipm_evaluate_batch(void *config, int n, void **qp_in_, void **qp_
         });
         ocp_qp_gpu_batch_set_bulk(b, blob, 0);
     }
-    if (o->warm_start >= 2)
+    if (phase == 1)
     {
-        /* hot start: the iterate in qp_out is the starting point (acados_ocp_options.py:1029-1032) */
-        for (int k = 0; k <= N; k++)
-        {
-            const int nu = d->nu[k], nx = d->nx[k], ns = d->ns[k];
-            auto pusho = [&](const char *name, int len, auto getter) {
-                if (len <= 0) return;
-                stg.resize((size_t) n * len);
-                for (int i = 0; i < n; i++) memcpy(stg.data() + (size_t) i * len, getter(outs[i]), sizeof(double) * len);
-                ocp_qp_gpu_batch_set(b, name, k, stg.data(), 0);
-            };
-            pusho("u", nu, [&](ocp_qp_out *q) { return q->ux[k]; });
-            pusho("x", nx, [&](ocp_qp_out *q) { return q->ux[k] + nu; });
-            pusho("sl", ns, [&](ocp_qp_out *q) { return q->ux[k] + nu + nx; });
-            pusho("su", ns, [&](ocp_qp_out *q) { return q->ux[k] + nu + nx + ns; });
-            if (k < N) pusho("pi", d->nx[k + 1], [&](ocp_qp_out *q) { return q->pi[k]; });
-            pusho("lam", 2 * (d->nb[k] + d->ng[k] + ns), [&](ocp_qp_out *q) { return q->lam[k]; });
-            pusho("t", 2 * (d->nb[k] + d->ng[k] + ns), [&](ocp_qp_out *q) { return q->t[k]; });
-        }
+        /* RTI preparation (ocp_qp_xcond_solver.c:591-620): matrix part of the condensing, resident on the device */
+        ocp_qp_gpu_batch_condense_lhs(b);
+        return ACADOS_SUCCESS;
     }
     const double t_packed = now_s();
 
-    ocp_qp_gpu_batch_solve(b);
+    if (phase == 2) ocp_qp_gpu_batch_condense_rhs_and_solve(b);
+    else ocp_qp_gpu_batch_solve(b);
     const double t_solved = now_s();
 
     /* unpack: one gather launch + one device->host copy for the whole batch, then host threads scatter */
@@ -772,19 +1172,20 @@ int ocp_qp_gpu_ipm_evaluate_batch(void *config, int n, void **qp_in_, void **qp_
                     memcpy(out_field(outs[i], g.fid, g.k) + g.shift, blob + (size_t) i * L + g.off, sizeof(double) * g.len);
         });
     }
-    std::vector<int> st(n), it(n);
-    ocp_qp_gpu_batch_get_info(b, "status", st.data());
-    ocp_qp_gpu_batch_get_info(b, "iter", it.data());
-    bc->stat.assign((size_t) 20 * (o->iter_max + 2), 0.0);
-    ocp_qp_gpu_batch_get_stat(b, 0, bc->stat.data(), o->iter_max + 2);
+    int *st = n > 1 ? bc->st.data() : &m->st_it[0], *it = n > 1 ? bc->it.data() : &m->st_it[1];
+    ocp_qp_gpu_batch_get_info(b, "status", st);
+    ocp_qp_gpu_batch_get_info(b, "iter", it);
+    memset(m->stat, 0, sizeof(double) * GPU_IPM_STAT_M * (size_t) m->stat_rows);
+    ocp_qp_gpu_batch_get_stat(b, 0, m->stat, m->stat_rows);
     const double t_end = now_s();
 
     int worst = 0;
+    const double t_cond = ocp_qp_gpu_batch_get_scalar(b, "time_xcond"), t_tot = ocp_qp_gpu_batch_get_scalar(b, "time_tot");
     for (int i = 0; i < n; i++)
     {
         qp_info *info = (qp_info *) outs[i]->misc;
-        info->condensing_time = ocp_qp_gpu_batch_get_scalar(b, "time_xcond");
-        info->solve_QP_time = ocp_qp_gpu_batch_get_scalar(b, "time_tot") - info->condensing_time;
+        info->condensing_time = t_cond;
+        info->solve_QP_time = t_tot - t_cond;
         info->interface_time = (t_packed - t_start) + (t_end - t_solved);
         info->total_time = t_end - t_start;
         info->num_iter = it[i];
@@ -803,12 +1204,21 @@ int ocp_qp_gpu_ipm_evaluate_batch(void *config, int n, void **qp_in_, void **qp_
     return worst;
 }
 
+extern "C" {
+
+int ocp_qp_gpu_ipm_evaluate_batch(void *config, int n, void **qp_in, void **qp_out, void *opts, void **mem, void *work,
+                                  int *status)
+{
+    if (n <= 0) return ACADOS_SUCCESS;
+    return gqp_host::gpu_ipm_evaluate_impl(config, n, qp_in, qp_out, opts, mem, work, status, nullptr);
+}
+
 /* ocp_qp_hpipm.c:314-405 */
 int ocp_qp_gpu_ipm(void *config, void *qp_in, void *qp_out, void *opts, void *mem, void *work)
 {
     int status = 0;
     void *ins[1] = {qp_in}, *outs[1] = {qp_out}, *mems[1] = {mem};
-    ocp_qp_gpu_ipm_evaluate_batch(config, 1, ins, outs, opts, mems, work, &status);
+    gqp_host::gpu_ipm_evaluate_impl(config, 1, ins, outs, opts, mems, work, &status, nullptr);
     /* status codes are already acados' (the map of ocp_qp_hpipm.c:398-404 is applied on device) */
     return status;
 }
@@ -890,6 +1300,7 @@ void ocp_qp_gpu_ipm_memory_reset(void *config, void *qp_in, void *qp_out, void *
         delete m->cache;
         m->cache = nullptr;
     }
+    m->sig_len = 0;
 }
 
 /* ocp_qp_hpipm.c:481-506.  The seed is the derivative of the problem data of ONE qp (the one `mem` belongs to,
@@ -987,380 +1398,6 @@ void ocp_qp_gpu_ipm_config_initialize_default(void *config_)
     config->eval_forw_sens = &ocp_qp_gpu_ipm_eval_forw_sens;
     config->eval_adj_sens = &ocp_qp_gpu_ipm_eval_adj_sens;
     config->terminate = &ocp_qp_gpu_ipm_terminate;
-}
-
-/* ------------------------------------------------------ outer level */
-
-struct ocp_qp_xcond_solver_config_
-{
-    qp_solver_config qp_solver;
-    char name[64];
-};
-
-struct ocp_qp_xcond_solver_dims_
-{
-    ocp_qp_dims *orig_dims;
-};
-
-struct xcond_solver_opts
-{
-    void *qp_solver_opts;
-    int cond_N;
-    int cond_ric_alg;
-    bool initialize_next_xcond_qp_from_qp_out;
-    bool warned;
-    int *cond_block_size; /* cond_N + 1 entries or NULL (ocp_qp_partial_condensing.c:305-313) */
-};
-
-struct ocp_qp_solver_
-{
-    ocp_qp_xcond_solver_config *config;
-    ocp_qp_xcond_solver_dims *dims;
-    xcond_solver_opts *opts;
-    void *mem;
-    void *mem_raw;
-};
-
-/* ocp_qp_interface.c:185-259 */
-ocp_qp_xcond_solver_config *ocp_qp_xcond_solver_config_create_from_name(const char *name)
-{
-    if (strcmp(name, "PARTIAL_CONDENSING_GPU_IPM") && strcmp(name, "PARTIAL_CONDENSING_HPIPM"))
-    {
-        printf("\nerror: ocp_qp_xcond_solver_config_create_from_name: QP solver %s not supported by acados_amd\n", name);
-        return nullptr;
-    }
-    ocp_qp_xcond_solver_config *c = (ocp_qp_xcond_solver_config *) calloc(1, sizeof(*c));
-    ocp_qp_gpu_ipm_config_initialize_default(&c->qp_solver);
-    snprintf(c->name, sizeof(c->name), "%s", name);
-    return c;
-}
-
-void ocp_qp_xcond_solver_config_free(ocp_qp_xcond_solver_config *c) { free(c); }
-
-ocp_qp_xcond_solver_dims *ocp_qp_xcond_solver_dims_create(ocp_qp_xcond_solver_config *config, int N)
-{
-    ocp_qp_xcond_solver_dims *d = (ocp_qp_xcond_solver_dims *) calloc(1, sizeof(*d));
-    d->orig_dims = ocp_qp_dims_create(N);
-    return d;
-}
-
-void ocp_qp_xcond_solver_dims_set(void *config, ocp_qp_xcond_solver_dims *dims, int stage, const char *field, int *value)
-{
-    ocp_qp_dims_set(config, dims->orig_dims, stage, field, value);
-}
-
-void ocp_qp_xcond_solver_dims_free(ocp_qp_xcond_solver_dims *d)
-{
-    if (!d) return;
-    ocp_qp_dims_free(d->orig_dims);
-    free(d);
-}
-
-void *ocp_qp_xcond_solver_opts_create(ocp_qp_xcond_solver_config *config, ocp_qp_xcond_solver_dims *dims)
-{
-    xcond_solver_opts *o = (xcond_solver_opts *) calloc(1, sizeof(*o));
-    qp_solver_config *qs = &config->qp_solver;
-    void *raw = calloc(1, qs->opts_calculate_size(qs, dims->orig_dims));
-    o->qp_solver_opts = qs->opts_assign(qs, dims->orig_dims, raw);
-    qs->opts_initialize_default(qs, dims->orig_dims, o->qp_solver_opts);
-    o->cond_N = dims->orig_dims->N;
-    o->cond_ric_alg = 1;
-    return o;
-}
-
-/* ocp_qp_xcond_solver.c:280-312: "cond_" prefix goes to the condensing module */
-void ocp_qp_xcond_solver_opts_set(ocp_qp_xcond_solver_config *config, void *opts_, const char *field, void *value)
-{
-    xcond_solver_opts *o = (xcond_solver_opts *) opts_;
-    if (!strncmp(field, "cond_", 5))
-    {
-        const char *f = field + 5;
-        if (!strcmp(f, "N")) o->cond_N = *(int *) value;
-        else if (!strcmp(f, "ric_alg")) o->cond_ric_alg = *(int *) value;
-        else if (!strcmp(f, "block_size"))
-        {
-            /* N2 + 1 entries; N2 ("cond_N") has to be set before, as in the reference (:305-313) */
-            free(o->cond_block_size);
-            o->cond_block_size = (int *) malloc(sizeof(int) * (o->cond_N + 1));
-            for (int i = 0; i <= o->cond_N; i++) o->cond_block_size[i] = ((int *) value)[i];
-        }
-        else
-        {
-            printf("\nerror: field %s not available in ocp_qp_partial_condensing_opts_set\n", f);
-            exit(1);
-        }
-    }
-    else if (!strcmp(field, "initialize_next_xcond_qp_from_qp_out"))
-        o->initialize_next_xcond_qp_from_qp_out = *(bool *) value;
-    else
-        config->qp_solver.opts_set(&config->qp_solver, o->qp_solver_opts, field, value);
-}
-
-void ocp_qp_xcond_solver_opts_free(void *opts_)
-{
-    xcond_solver_opts *o = (xcond_solver_opts *) opts_;
-    if (!o) return;
-    free(o->qp_solver_opts);
-    free(o->cond_block_size);
-    free(o);
-}
-
-ocp_qp_in *ocp_qp_in_create_from_xcond_dims(ocp_qp_xcond_solver_dims *dims) { return ocp_qp_in_create(dims->orig_dims); }
-ocp_qp_out *ocp_qp_out_create_from_xcond_dims(ocp_qp_xcond_solver_dims *dims) { return ocp_qp_out_create(dims->orig_dims); }
-
-/* ocp_qp_interface.c:513-563 */
-ocp_qp_solver *ocp_qp_create(ocp_qp_xcond_solver_config *config, ocp_qp_xcond_solver_dims *dims, void *opts_)
-{
-    ocp_qp_solver *s = (ocp_qp_solver *) calloc(1, sizeof(*s));
-    qp_solver_config *qs = &config->qp_solver;
-    xcond_solver_opts *o = (xcond_solver_opts *) opts_;
-    s->config = config; s->dims = dims; s->opts = o;
-    s->mem_raw = calloc(1, qs->memory_calculate_size(qs, dims->orig_dims, o->qp_solver_opts));
-    s->mem = qs->memory_assign(qs, dims->orig_dims, o->qp_solver_opts, s->mem_raw);
-    return s;
-}
-
-void ocp_qp_solver_destroy(ocp_qp_solver *s)
-{
-    if (!s) return;
-    s->config->qp_solver.terminate(&s->config->qp_solver, s->mem, nullptr);
-    free(s->mem_raw);
-    free(s);
-}
-
-static void xcond_note(ocp_qp_solver *s)
-{
-    /* the condensing request travels with the call (ocp_qp_xcond_solve: condense -> solve -> expand,
-     * ocp_qp_xcond_solver.c:529-587); the device batch decides whether the QP class is condensable */
-    g_cond_N_request = s->opts->cond_N;
-    g_cond_blocks_request = s->opts->cond_block_size;
-}
-
-/* ocp_qp_interface.c:567-571 -> ocp_qp_xcond_solve (ocp_qp_xcond_solver.c:529-587) */
-int ocp_qp_solve(ocp_qp_solver *s, ocp_qp_in *qp_in, ocp_qp_out *qp_out)
-{
-    xcond_note(s);
-    qp_solver_config *qs = &s->config->qp_solver;
-    return qs->evaluate(qs, qp_in, qp_out, s->opts->qp_solver_opts, s->mem, nullptr);
-}
-
-int ocp_qp_solve_batch(ocp_qp_solver *s, int n, ocp_qp_in **qp_in, ocp_qp_out **qp_out, int *status)
-{
-    xcond_note(s);
-    std::vector<void *> mems(n, nullptr);
-    mems[0] = s->mem;
-    return ocp_qp_gpu_ipm_evaluate_batch(&s->config->qp_solver, n, (void **) qp_in, (void **) qp_out,
-                                         s->opts->qp_solver_opts, mems.data(), nullptr, status);
-}
-
-/* ocp_qp_interface.c:573-595 */
-void ocp_qp_xcond_solver_get_scalar(ocp_qp_solver *s, ocp_qp_out *qp_out, const char *field, void *value)
-{
-    qp_info *info = (qp_info *) qp_out->misc;
-    if (!strcmp(field, "time_tot")) *(double *) value = info->total_time;
-    else if (!strcmp(field, "time_cond") || !strcmp(field, "time_qp_xcond")) *(double *) value = info->condensing_time;
-    else s->config->qp_solver.memory_get(&s->config->qp_solver, s->mem, field, value);
-}
-
-/* outer-level access to the solver_get slot (what ocp_nlp_ddp.c:373-377 does through the xcond vtable) */
-void ocp_qp_solver_eval_forw_sens(ocp_qp_solver *s, ocp_qp_in *qp_in, ocp_qp_seed *seed, ocp_qp_out *sens_out)
-{
-    qp_solver_config *qs = &s->config->qp_solver;
-    qs->eval_forw_sens(qs, qp_in, seed, sens_out, s->opts->qp_solver_opts, s->mem, nullptr);
-}
-
-void ocp_qp_solver_eval_adj_sens(ocp_qp_solver *s, ocp_qp_in *qp_in, ocp_qp_seed *seed, ocp_qp_out *sens_out)
-{
-    qp_solver_config *qs = &s->config->qp_solver;
-    qs->eval_adj_sens(qs, qp_in, seed, sens_out, s->opts->qp_solver_opts, s->mem, nullptr);
-}
-
-void ocp_qp_solver_get_ric(ocp_qp_solver *s, ocp_qp_in *qp_in, ocp_qp_out *qp_out, const char *field, int stage,
-                           void *value, int size1, int size2)
-{
-    qp_solver_config *qs = &s->config->qp_solver;
-    qs->solver_get(qs, qp_in, qp_out, s->opts->qp_solver_opts, s->mem, field, stage, value, size1, size2);
-}
-
-/* ocp_qp_interface.c:597-610 */
-void ocp_qp_solver_get_stats(ocp_qp_solver *s, double *stat_out, const char *qp_solver_name)
-{
-    int iter, stat_m;
-    double *stat;
-    qp_solver_config *qs = &s->config->qp_solver;
-    qs->memory_get(qs, s->mem, "iter", &iter);
-    qs->memory_get(qs, s->mem, "stat", &stat);
-    qs->memory_get(qs, s->mem, "stat_m", &stat_m);
-    if (!stat) return;
-    for (int i = 0; i < stat_m * (iter + 1); i++) stat_out[i] = stat[i];
-}
-
-/* ---- condensing-only boundary (interfaces/acados_c/condensing_interface.c; the `condensing` / `expansion` slots of
- *      ocp_qp_xcond_config, ocp_qp_common.h:84-107, filled by ocp_qp_partial_condensing.c:523-556, :664-689) ----
- * A module owns a one-instance device batch; the condensed QP is handed out in a plain ocp_qp_in of the condensed
- * dims ("xcond_dims"), the solution of it comes back in a plain ocp_qp_out. */
-struct ocp_qp_condensing_module_
-{
-    ocp_qp_dims *dims = nullptr, *xdims = nullptr;
-    int cond_N = 0;
-    std::vector<int> blocks;
-    ocp_qp_gpu_batch *batch = nullptr, *child = nullptr;
-    std::vector<int> sig;
-};
-
-struct cfield { const char *name; int fid; int dyn; };
-static const cfield k_cfields[] = {
-    {"A", F_A, 1}, {"B", F_B, 1}, {"b", F_b, 1}, {"Q", F_Q, 0}, {"S", F_S, 0}, {"R", F_R, 0}, {"q", F_q, 0}, {"r", F_r, 0},
-    {"C", F_C, 0}, {"D", F_D, 0}, {"lg", F_lg, 0}, {"ug", F_ug, 0}, {"lg_mask", F_lgm, 0}, {"ug_mask", F_ugm, 0},
-    {"Zl", F_Zl, 0}, {"Zu", F_Zu, 0}, {"zl", F_zl, 0}, {"zu", F_zu, 0}, {"lls", F_lls, 0}, {"lus", F_lus, 0},
-    {"lls_mask", F_llsm, 0}, {"lus_mask", F_lusm, 0}};
-
-static int clen(const ocp_qp_dims *d, const char *f, int k)
-{
-    const int n = vlen(d, f, k);
-    if (n >= 0) return n;
-    return (f[0] == 'l' || f[0] == 'u') && f[1] == 'g' ? d->ng[k] : d->ns[k]; /* lg ug (+ masks) | Zl Zu zl zu lls lus (+ masks) */
-}
-
-static ocp_qp_gpu_batch *condensing_batch(ocp_qp_condensing_module *m, const ocp_qp_dims *d, int *const *idxb,
-                                          int *const *idxs_rev, int *const *idxe)
-{
-    ocp_qp_gpu_batch *b = ocp_qp_gpu_batch_create(d->N, d->nx, d->nu, d->nbx, d->nbu, d->ng, d->ns, 1, -1);
-    if (!b) return nullptr;
-    for (int k = 0; k <= d->N; k++)
-    {
-        std::vector<int> ib(d->nb[k]), rev(d->nb[k] + d->ng[k], -1), ie(d->nbxe[k]);
-        for (int r = 0; r < d->nb[k]; r++) ib[r] = idxb ? idxb[k][r] : (r < d->nbu[k] ? r : d->nu[k] + r - d->nbu[k]);
-        if (idxs_rev) for (size_t r = 0; r < rev.size(); r++) rev[r] = idxs_rev[k][r];
-        for (int r = 0; r < d->nbxe[k]; r++) ie[r] = idxe ? idxe[k][r] : d->nbu[k] + r;
-        ocp_qp_gpu_batch_set_int(b, "idxb", k, ib.data(), (int) ib.size());
-        ocp_qp_gpu_batch_set_int(b, "idxs_rev", k, rev.data(), (int) rev.size());
-        ocp_qp_gpu_batch_set_int(b, "idxe", k, ie.data(), (int) ie.size());
-    }
-    ocp_qp_gpu_batch_opts_set(b, "cond_N", &m->cond_N);
-    if (!m->blocks.empty() && ocp_qp_gpu_batch_opts_set(b, "cond_block_size", m->blocks.data()) != 0)
-    {
-        printf("\nerror: partial condensing: sum of block_size should match N = %d\n", d->N);
-        exit(1); /* ocp_qp_partial_condensing.c:352-356 */
-    }
-    return b;
-}
-
-ocp_qp_condensing_module *ocp_qp_condensing_create(ocp_qp_dims *dims, int cond_N, const int *block_size)
-{
-    ocp_qp_condensing_module *m = new ocp_qp_condensing_module_();
-    m->dims = dims;
-    m->cond_N = cond_N;
-    if (block_size) m->blocks.assign(block_size, block_size + cond_N + 1);
-    /* the condensed dims depend on the per-stage counts only: a batch with the default index sets tells them */
-    ocp_qp_gpu_batch *probe = condensing_batch(m, dims, nullptr, nullptr, nullptr);
-    ocp_qp_gpu_batch *c = probe ? ocp_qp_gpu_batch_condense(probe) : nullptr;
-    if (!c)
-    {
-        printf("\nerror: ocp_qp_condensing_create: this QP class is not condensed to N2 = %d (no device, cond_N outside 1..N-1, "
-               "or beyond the limits of the condensing kernels)\n", cond_N);
-        if (probe) ocp_qp_gpu_batch_destroy(probe);
-        delete m;
-        return nullptr;
-    }
-    m->xdims = ocp_qp_dims_create(cond_N);
-    const char *names[] = {"nx", "nu", "nb", "nbx", "nbu", "ng", "ns", "nbxe"};
-    int *dst[] = {m->xdims->nx, m->xdims->nu, m->xdims->nb, m->xdims->nbx, m->xdims->nbu, m->xdims->ng, m->xdims->ns, m->xdims->nbxe};
-    for (int q = 0; q < 8; q++) ocp_qp_gpu_batch_get_dims(c, names[q], dst[q]);
-    ocp_qp_gpu_batch_destroy(probe);
-    return m;
-}
-
-void ocp_qp_condensing_free(ocp_qp_condensing_module *m)
-{
-    if (!m) return;
-    if (m->batch) ocp_qp_gpu_batch_destroy(m->batch);
-    ocp_qp_dims_free(m->xdims);
-    delete m;
-}
-
-ocp_qp_dims *ocp_qp_condensing_get_xcond_dims(ocp_qp_condensing_module *m) { return m->xdims; }
-
-/* bounds and their masks: the containers keep [bu; bx] in one array, the device batch takes them per kind */
-static void condensing_bounds(ocp_qp_gpu_batch *b, ocp_qp_in *q, int k, bool to_device)
-{
-    const ocp_qp_dims *d = q->dim;
-    const int nbu = d->nbu[k];
-    struct { const char *name; double *p; int n; } f[] = {
-        {"lbu", q->lb[k], nbu}, {"ubu", q->ub[k], nbu}, {"lbu_mask", q->lb_mask[k], nbu}, {"ubu_mask", q->ub_mask[k], nbu},
-        {"lbx", q->lb[k] + nbu, d->nbx[k]}, {"ubx", q->ub[k] + nbu, d->nbx[k]},
-        {"lbx_mask", q->lb_mask[k] + nbu, d->nbx[k]}, {"ubx_mask", q->ub_mask[k] + nbu, d->nbx[k]}};
-    for (auto &e : f)
-    {
-        if (e.n <= 0) continue;
-        if (to_device) ocp_qp_gpu_batch_set(b, e.name, k, e.p, 0);
-        else ocp_qp_gpu_batch_get(b, e.name, k, e.p, 0);
-    }
-}
-
-int ocp_qp_condense(ocp_qp_condensing_module *m, void *qp_in_, void *xcond_qp_in_)
-{
-    ocp_qp_in *in = (ocp_qp_in *) qp_in_, *xc = (ocp_qp_in *) xcond_qp_in_;
-    const ocp_qp_dims *d = in->dim;
-    std::vector<int> sig = structure_sig(in);
-    if (!m->batch || sig != m->sig)
-    {
-        if (m->batch) ocp_qp_gpu_batch_destroy(m->batch);
-        m->batch = condensing_batch(m, d, in->idxb, in->idxs_rev, in->idxe);
-        m->sig = sig;
-        if (!m->batch) return ACADOS_QP_FAILURE;
-    }
-    ocp_qp_gpu_batch *b = m->batch;
-    for (int k = 0; k <= d->N; k++)
-    {
-        for (const cfield &f : k_cfields)
-            if (!(f.dyn && k == d->N) && clen(d, f.name, k) > 0) ocp_qp_gpu_batch_set(b, f.name, k, in_field(in, f.fid, k), 0);
-        condensing_bounds(b, in, k, true);
-    }
-    ocp_qp_gpu_batch *c = ocp_qp_gpu_batch_condense(b);
-    m->child = c;
-    if (!c) return ACADOS_QP_FAILURE;
-    const ocp_qp_dims *xd = xc->dim;
-    for (int k = 0; k <= xd->N; k++)
-    {
-        for (const cfield &f : k_cfields)
-            if (!(f.dyn && k == xd->N) && clen(xd, f.name, k) > 0)
-                ocp_qp_gpu_batch_get(c, f.name, k, const_cast<double *>(in_field(xc, f.fid, k)), 0);
-        condensing_bounds(c, xc, k, false);
-        ocp_qp_gpu_batch_get_int(c, "idxb", k, xc->idxb[k]);
-        ocp_qp_gpu_batch_get_int(c, "idxs_rev", k, xc->idxs_rev[k]);
-        ocp_qp_gpu_batch_get_int(c, "idxe", k, xc->idxe[k]);
-    }
-    return ACADOS_SUCCESS;
-}
-
-/* ux = [u; x; sl; su], pi, lam, t of one container <-> the fields of a one-instance batch */
-static void condensing_solution(ocp_qp_gpu_batch *b, const ocp_qp_dims *d, ocp_qp_out *o, bool to_device)
-{
-    for (int k = 0; k <= d->N; k++)
-    {
-        const int nu = d->nu[k], nx = d->nx[k], ns = d->ns[k], nct = d->nb[k] + d->ng[k] + ns;
-        struct { const char *name; double *p; int n; } f[] = {
-            {"u", o->ux[k], nu}, {"x", o->ux[k] + nu, nx}, {"sl", o->ux[k] + nu + nx, ns}, {"su", o->ux[k] + nu + nx + ns, ns},
-            {"pi", k < d->N ? o->pi[k] : nullptr, k < d->N ? d->nx[k + 1] : 0}, {"lam", o->lam[k], nct}, {"t", o->t[k], nct}};
-        for (auto &e : f)
-        {
-            if (e.n <= 0) continue;
-            if (to_device) ocp_qp_gpu_batch_set(b, e.name, k, e.p, 0);
-            else ocp_qp_gpu_batch_get(b, e.name, k, e.p, 0);
-        }
-    }
-}
-
-int ocp_qp_expand(ocp_qp_condensing_module *m, void *xcond_qp_out_, void *qp_out_)
-{
-    ocp_qp_out *xo = (ocp_qp_out *) xcond_qp_out_, *out = (ocp_qp_out *) qp_out_;
-    if (!m->batch || !m->child) return ACADOS_QP_FAILURE;
-    condensing_solution(m->child, m->xdims, xo, true);
-    if (ocp_qp_gpu_batch_expand(m->batch) != 0) return ACADOS_QP_FAILURE;
-    condensing_solution(m->batch, m->dims, out, false);
-    if (out->misc) ((qp_info *) out->misc)->t_computed = 1;
-    return ACADOS_SUCCESS;
 }
 
 } /* extern "C" */

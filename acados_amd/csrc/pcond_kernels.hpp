@@ -616,6 +616,56 @@ static __global__ void __launch_bounds__(64) kw_pexpand(GqpDev P, GqpDev Cd, Pco
     }
 }
 
+/* ---------------------------------------------------------------------------------------------------
+ * A solution (or initial guess) of the ORIGINAL QP restated in the variables of the condensed one: what
+ * `condense_qp_out` does (ocp_qp_partial_condensing_condense_qp_out, ocp_qp_partial_condensing.c:559-571 ->
+ * d_part_cond_qp_cond_sol; called by ocp_qp_xcond_solve when initialize_next_xcond_qp_from_qp_out is set,
+ * ocp_qp_xcond_solver.c:554-565).  Pure index work, the inverse of the copies in kw_pexpand: block inputs stacked,
+ * the block's first state, pi at the block boundaries, every inequality row / slack with its multipliers.
+ * One instance per lane, layout-agnostic.
+ * --------------------------------------------------------------------------------------------------- */
+static __global__ void __launch_bounds__(64) k_pcond_sol(GqpDev P, GqpDev Cd, PcondMap Mp)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.B) return;
+    const int NX = P.NX, NU = P.NU, n = NX + NU, NUC = Cd.NU, nc = NUC + NX;
+    for (int jb = 0; jb <= Mp.N2; jb++)
+    {
+        const int k0 = Mp.blk_start[jb < Mp.N2 ? jb : Mp.N2];
+        const int bs = jb < Mp.N2 ? Mp.blk_start[jb + 1] - k0 : 0;
+        for (int e = 0; e < NUC; e++)
+            GATL(Cd.ux, jb * nc + e) = e < bs * NU ? GATL(P.ux, (k0 + e / NU) * n + e % NU) : 0.0;
+        for (int r = 0; r < NX; r++) GATL(Cd.ux, jb * nc + NUC + r) = GATL(P.ux, k0 * n + NU + r);
+        /* pi slot s = multiplier of the dynamics producing x_s: child slot jb+1 <-> parent slot blk_start[jb+1] */
+        if (jb < Mp.N2)
+            for (int r = 0; r < NX; r++) GATL(Cd.pi, (jb + 1) * NX + r) = GATL(P.pi, (k0 + bs) * NX + r);
+        const GqpStage &Sc = Cd.st[jb];
+        const int r0 = Mp.row_off[jb], nbgc = Sc.nb + Sc.ng, q0 = Mp.slk_off[jb];
+        for (int rc = 0; rc < nbgc; rc++)
+        {
+            const int kp = Mp.row_kp[r0 + rc], rp = Mp.row_rp[r0 + rc];
+            const GqpStage &Sp = P.st[kp];
+            const int up = Sp.o_ct + Sp.nb + Sp.ng + rp, uc = Sc.o_ct + nbgc + rc;
+            GATL(Cd.lam, Sc.o_ct + rc) = GATL(P.lam, Sp.o_ct + rp);
+            GATL(Cd.lam, uc) = GATL(P.lam, up);
+            GATL(Cd.t, Sc.o_ct + rc) = GATL(P.t, Sp.o_ct + rp);
+            GATL(Cd.t, uc) = GATL(P.t, up);
+        }
+        for (int sc = 0; sc < Sc.ns; sc++)
+        {
+            const int kp = Mp.slk_kp[q0 + sc], sp = Mp.slk_sp[q0 + sc];
+            const GqpStage &Sp = P.st[kp];
+            const int cp = Sp.o_ct + 2 * (Sp.nb + Sp.ng), cc = Sc.o_ct + 2 * nbgc;
+            GATL(Cd.sv, Sc.o_s + sc) = GATL(P.sv, Sp.o_s + sp);
+            GATL(Cd.sv, Sc.o_s + Sc.ns + sc) = GATL(P.sv, Sp.o_s + Sp.ns + sp);
+            GATL(Cd.lam, cc + sc) = GATL(P.lam, cp + sp);
+            GATL(Cd.lam, cc + Sc.ns + sc) = GATL(P.lam, cp + Sp.ns + sp);
+            GATL(Cd.t, cc + sc) = GATL(P.t, cp + sp);
+            GATL(Cd.t, cc + Sc.ns + sc) = GATL(P.t, cp + Sp.ns + sp);
+        }
+    }
+}
+
 } // namespace gqp
 
 

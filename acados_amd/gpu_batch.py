@@ -175,8 +175,14 @@ class OcpQpGpuBatch:
             return 2 * int(d.nbx[k] + d.nbu[k] + d.ng[k] + d.ns[k])
         if field == "ric_L":
             return int(d.nx[k] + d.nu[k]) ** 2
-        if field == "ric_l":
+        if field in ("ric_l", "res_g"):
             return int(d.nx[k] + d.nu[k])
+        if field == "res_gs":
+            return 2 * int(d.ns[k])
+        if field == "res_b":
+            return int(d.nx[k + 1]) if k < self.N else 0
+        if field in ("res_d", "res_m"):
+            return 2 * int(d.nbx[k] + d.nbu[k] + d.ng[k] + d.ns[k])
         raise ValueError(field)
 
     def get(self, field, stage):
@@ -220,6 +226,17 @@ class OcpQpGpuBatch:
         "sens_pi" / "sens_lam" / "sens_t" / "sens_sl" / "sens_su", stage)"""
         if self._L.ocp_qp_gpu_batch_sens_solve(self._h) != 0:
             raise RuntimeError("ocp_qp_gpu_batch_sens_solve failed")
+
+    # -- KKT residuals of whatever (data, iterate) is in HBM (ocp_qp_res_compute / _nrm_inf) ----------------
+    def res_compute(self):
+        """residual vectors of the current iterate, one launch of a kernel independent of the IPM sweeps; read them with
+        get("res_g" / "res_gs" / "res_b" / "res_d" / "res_m", stage).  Returns the inf-norms [n_batch, 4]
+        (stationarity, dynamics, inequalities, complementarity) as ocp_qp_inf_norm_residuals does."""
+        if self._L.ocp_qp_gpu_batch_res_compute(self._h) != 0:
+            raise RuntimeError("ocp_qp_gpu_batch_res_compute failed")
+        out = np.zeros((self.n_batch, 4))
+        self._L.ocp_qp_gpu_batch_res_nrm_inf(self._h, out.ctypes.data_as(C.POINTER(C.c_double)))
+        return out
 
     def info(self, field):
         out = np.zeros(self.n_batch, dtype=np.int32 if field in ("status", "iter") else np.float64)

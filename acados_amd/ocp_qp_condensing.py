@@ -1,6 +1,7 @@
 """Condensing-only boundary: Python mirror of the reference's `condensing_module`
-(interfaces/acados_c/condensing_interface.h:61-75 -- ocp_qp_condensing_create, ocp_qp_condense, ocp_qp_expand) over the
-C-ABI of include/acados_amd/ocp_qp_interface.h.  Partial condensing N -> N2 runs on the device
+(interfaces/acados_c/condensing_interface.h:42-75 -- ocp_qp_condensing_config_create, ocp_qp_condensing_opts_create,
+ocp_qp_condensing_create, ocp_qp_condense, ocp_qp_expand, same call sequence) over the 20-slot `ocp_qp_xcond_config`
+of include/acados_amd/ocp_qp_interface.h.  Partial condensing N -> N2 runs on the device
 (acados_amd/csrc/pcond_kernels.hpp); this class moves one QP in and the condensed QP / the expanded solution out.
 """
 import ctypes as C
@@ -37,8 +38,11 @@ def _bind(L):
         "ocp_qp_dims_set": (None, [vp, vp, ci, cp, _IP]),
         "ocp_qp_in_create": (vp, [vp]), "ocp_qp_in_free": (None, [vp]), "ocp_qp_in_set": (None, [vp, vp, ci, cp, vp]),
         "ocp_qp_out_create": (vp, [vp]), "ocp_qp_out_free": (None, [vp]), "ocp_qp_out_get": (None, [vp, ci, cp, vp]),
-        "ocp_qp_condensing_create": (vp, [vp, ci, _IP]), "ocp_qp_condensing_free": (None, [vp]),
-        "ocp_qp_condensing_get_xcond_dims": (vp, [vp]),
+        "ocp_qp_condensing_config_create": (vp, [vp]), "ocp_qp_condensing_dims_create": (vp, [vp, ci]),
+        "ocp_qp_condensing_opts_create": (vp, [vp, vp]),
+        "ocp_qp_condensing_create": (vp, [vp, vp, vp]), "ocp_qp_condensing_free": (None, [vp]),
+        "ocp_qp_gpu_pcond_dims_set": (None, [vp, vp, ci, cp, _IP]), "ocp_qp_gpu_pcond_dims_get": (None, [vp, vp, cp, vp]),
+        "ocp_qp_gpu_pcond_opts_set": (None, [vp, cp, vp]),
         "ocp_qp_condense": (ci, [vp, vp, vp]), "ocp_qp_expand": (ci, [vp, vp, vp]),
     }
     for name, (res, args) in sigs.items():
@@ -52,7 +56,7 @@ _DATA = ("A", "B", "b", "Q", "S", "R", "q", "r", "lbx", "ubx", "lbu", "ubu", "C"
 
 
 class AcadosOcpQpCondensing:
-    def __init__(self, qp: AcadosOcpQp, cond_N: int, block_size=None, _clib=None):
+    def __init__(self, qp: AcadosOcpQp, cond_N: int, block_size=None, full=False, _clib=None):
         self._L = _bind(_clib if _clib is not None else _lib.lib())
         self.qp, self.N, self.cond_N = qp, qp.N, int(cond_N)
         L, d = self._L, qp.dims
@@ -61,15 +65,29 @@ class AcadosOcpQpCondensing:
             for name in ("nx", "nu", "nbx", "nbu", "ng", "ns", "nbxe"):
                 v = C.c_int(int(getattr(d, name)[k]))
                 L.ocp_qp_dims_set(None, self.c_dims, k, name.encode(), C.byref(v))
-        bs = None
+        # call sequence of condensing_interface.c: config (plan) -> module dims -> opts -> module
+        plan = C.c_int(1 if full else 0)                      # condensing_plan {PARTIAL_CONDENSING, FULL_CONDENSING}
+        self.c_config = L.ocp_qp_condensing_config_create(C.byref(plan))
+        self.c_mdims = L.ocp_qp_condensing_dims_create(self.c_config, qp.N)
+        for k in range(qp.N + 1):
+            for name in ("nx", "nu", "nbx", "nbu", "ng", "ns", "nbxe"):
+                v = C.c_int(int(getattr(d, name)[k]))
+                L.ocp_qp_gpu_pcond_dims_set(self.c_config, self.c_mdims, k, name.encode(), C.byref(v))
+        self.c_opts = L.ocp_qp_condensing_opts_create(self.c_config, self.c_mdims)
+        if not full:
+            v = C.c_int(self.cond_N)
+            L.ocp_qp_gpu_pcond_opts_set(self.c_opts, b"N", C.byref(v))
         if block_size is not None:
             self._bs = np.ascontiguousarray(block_size, dtype=np.intc)
             assert self._bs.size == self.cond_N + 1
-            bs = self._bs.ctypes.data_as(_IP)
-        self.c_module = L.ocp_qp_condensing_create(self.c_dims, self.cond_N, bs)
+            L.ocp_qp_gpu_pcond_opts_set(self.c_opts, b"block_size", self._bs.ctypes.data_as(C.c_void_p))
+        self.c_module = L.ocp_qp_condensing_create(self.c_config, self.c_mdims, self.c_opts)
         if not self.c_module:
             raise RuntimeError("ocp_qp_condensing_create failed")
-        self.c_xdims = L.ocp_qp_condensing_get_xcond_dims(self.c_module)
+        xd = C.c_void_p()
+        L.ocp_qp_gpu_pcond_dims_get(self.c_config, self.c_mdims, b"xcond_dims", C.byref(xd))
+        self.c_xdims = xd.value
+        self.cond_N = C.cast(self.c_xdims, C.POINTER(_Dims)).contents.N   # N when the class is not condensed
         self.c_in, self.c_out = L.ocp_qp_in_create(self.c_dims), L.ocp_qp_out_create(self.c_dims)
         self.c_xin, self.c_xout = L.ocp_qp_in_create(self.c_xdims), L.ocp_qp_out_create(self.c_xdims)
         self.set_qp(qp)
@@ -160,5 +178,10 @@ class AcadosOcpQpCondensing:
             for p in (self.c_out, self.c_xout):
                 L.ocp_qp_out_free(p)
             L.ocp_qp_dims_free(self.c_dims)
+            import ctypes
+            libc = ctypes.CDLL(None)
+            libc.free.argtypes = [ctypes.c_void_p]
+            for p in (self.c_opts, self.c_mdims, self.c_config):
+                libc.free(p)
         except Exception:
             pass

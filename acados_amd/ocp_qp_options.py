@@ -3,7 +3,7 @@
 
 
 class AcadosOcpQpOptions:
-    SOLVERS = ("PARTIAL_CONDENSING_GPU_IPM", "PARTIAL_CONDENSING_HPIPM")
+    SOLVERS = ("PARTIAL_CONDENSING_GPU_IPM", "PARTIAL_CONDENSING_HPIPM", "FULL_CONDENSING_GPU_IPM")
 
     def __init__(self):
         self.qp_solver = "PARTIAL_CONDENSING_GPU_IPM"
@@ -25,6 +25,10 @@ class AcadosOcpQpOptions:
     def make_consistent(self, N: int):
         if self.qp_solver not in self.SOLVERS:
             raise ValueError(f"qp_solver {self.qp_solver} is not provided by acados_amd; possible values: {self.SOLVERS}")
+        if self.qp_solver.startswith("FULL_CONDENSING"):
+            if self.cond_N not in (None, 1):
+                raise ValueError("full condensing condenses to one block: cond_N must be 1 (or unset)")
+            self.cond_N = 1
         if self.cond_N is None:
             self.cond_N = N
         if self.cond_block_size is not None and sum(self.cond_block_size) != N:

@@ -19,7 +19,9 @@ _FIELDS = ("A", "B", "b", "Q", "S", "R", "q", "r", "idxb", "lbx", "ubx", "lbu", 
            "C", "D", "lg", "ug", "Zl", "Zu", "zl", "zu", "idxe", "idxs_rev")
 _INT = ("idxb", "idxe", "idxs_rev")
 _OPT_FIELDS = ("tol_stat", "tol_eq", "tol_ineq", "tol_comp", "iter_max", "cond_N", "cond_block_size", "warm_start",
-               "cond_ric_alg", "ric_alg", "mu0", "t0_init", "print_level", "hpipm_mode")
+               "cond_ric_alg", "ric_alg", "mu0", "t0_init", "print_level", "hpipm_mode", "tau_min", "t0_min", "lam0_min",
+               "update_fact_exit", "alpha_min")
+_DOUBLE_OPTS = ("tol_stat", "tol_eq", "tol_ineq", "tol_comp", "mu0", "tau_min", "t0_min", "lam0_min", "alpha_min")
 
 
 def _bind(L):
@@ -42,6 +44,9 @@ def _bind(L):
         "ocp_qp_out_free": (None, [vp]),
         "ocp_qp_out_get": (None, [vp, ci, cp, vp]),
         "ocp_qp_solve": (ci, [vp, vp, vp]),
+        "ocp_qp_condense_lhs": (ci, [vp, vp, vp]),
+        "ocp_qp_condense_rhs_and_solve": (ci, [vp, vp, vp]),
+        "ocp_qp_inf_norm_residuals": (None, [vp, vp, vp, C.POINTER(C.c_double)]),
         "ocp_qp_solve_batch": (ci, [vp, ci, C.POINTER(vp), C.POINTER(vp), C.POINTER(ci)]),
         "ocp_qp_xcond_solver_get_scalar": (None, [vp, vp, cp, vp]),
         "ocp_qp_solver_get_stats": (None, [vp, C.POINTER(C.c_double), cp]),
@@ -107,10 +112,12 @@ class AcadosOcpQpSolver:
             ptr = arr.ctypes.data_as(C.c_void_p)
         elif isinstance(value, str):
             ptr = C.cast(C.c_char_p(value.encode()), C.c_void_p)
+        elif field in _DOUBLE_OPTS:     # the C side reads a double whatever Python type the caller used (tol_stat=1)
+            self._keep = C.c_double(float(value)); ptr = C.cast(C.byref(self._keep), C.c_void_p)
         elif isinstance(value, (bool, int, np.integer)):
             self._keep = C.c_int(int(value)); ptr = C.cast(C.byref(self._keep), C.c_void_p)
         elif isinstance(value, float):
-            self._keep = C.c_double(value); ptr = C.cast(C.byref(self._keep), C.c_void_p)
+            raise TypeError(f"option {field} is an integer option, got {value!r}")
         else:
             raise TypeError(f"unsupported type {type(value)} for option {field}")
         self._L.ocp_qp_xcond_solver_opts_set(self.c_config, self.c_opts, field.encode(), ptr)
@@ -147,6 +154,29 @@ class AcadosOcpQpSolver:
     def solve(self) -> int:
         self._status = self._L.ocp_qp_solve(self.c_solver, self.c_in, self.c_out)
         return self._status
+
+    def condense_lhs(self) -> int:
+        """RTI preparation phase: the condense_lhs slot (ocp_qp_xcond_solver.c:591-620)"""
+        return self._L.ocp_qp_condense_lhs(self.c_solver, self.c_in, self.c_out)
+
+    def condense_rhs_and_solve(self) -> int:
+        """RTI feedback phase: the condense_rhs_and_solve slot (ocp_qp_xcond_solver.c:623-669)"""
+        self._status = self._L.ocp_qp_condense_rhs_and_solve(self.c_solver, self.c_in, self.c_out)
+        return self._status
+
+    def set(self, stage: int, field: str, value):
+        """update one field of the QP held by the solver (ocp_qp_in_set)"""
+        a = np.ascontiguousarray(np.ravel(np.asarray(value).astype(np.int32) if field in _INT else np.asarray(value, dtype=float), order="F"))
+        self._L.ocp_qp_in_set(self.c_config, self.c_in, int(stage), field.encode(), a.ctypes.data_as(C.c_void_p))
+
+    def inf_norm_residuals(self) -> np.ndarray:
+        """[stationarity, dynamics, inequalities, complementarity] inf-norms of the KKT residuals of (qp_in, qp_out),
+        recomputed independently of the solver: ocp_qp_inf_norm_residuals (ocp_qp_interface.c:642-650)"""
+        class _In(C.Structure):
+            _fields_ = [("dim", C.c_void_p)]
+        res = (C.c_double * 4)()
+        self._L.ocp_qp_inf_norm_residuals(C.cast(self.c_in, C.POINTER(_In)).contents.dim, self.c_in, self.c_out, res)
+        return np.array(res[:])
 
     def _dim(self, stage, field):
         d = self.qp.dims

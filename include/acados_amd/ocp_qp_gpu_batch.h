@@ -69,10 +69,12 @@ int ocp_qp_gpu_batch_bulk_len(ocp_qp_gpu_batch *b, int output);
 int ocp_qp_gpu_batch_bulk_offset(ocp_qp_gpu_batch *b, int output, const char *field, int stage, int *len);
 int ocp_qp_gpu_batch_set_bulk(ocp_qp_gpu_batch *b, const double *blob, int is_device);
 int ocp_qp_gpu_batch_get_bulk(ocp_qp_gpu_batch *b, double *blob, int is_device);
+/* an iterate in the OUTPUT blob layout written into the batch (inverse of _get_bulk): the starting point of a hot start */
+int ocp_qp_gpu_batch_set_bulk_out(ocp_qp_gpu_batch *b, const double *blob, int is_device);
 
 /* Options by name, as ocp_qp_xcond_solver_opts_set forwards them: iter_max
  * tol_stat tol_eq tol_ineq tol_comp warm_start mu0 alpha_min tau_min reg_prim
- * cond_pred_corr print_level t0_init hpipm_mode ric_alg cond_N (partial condensing to N2 blocks) cond_block_size (int[N2+1], after cond_N; ocp_qp_partial_condensing.c:305-313) profile.  int* or double* or char* as in
+ * cond_pred_corr print_level t0_init t0_min lam0_min (lower clips of t / lam at a hot start) update_fact_exit hpipm_mode ric_alg cond_N (partial condensing to N2 blocks) cond_block_size (int[N2+1], after cond_N; ocp_qp_partial_condensing.c:305-313) profile.  int* or double* or char* as in
  * acados.  Unknown field: message + return -1. */
 int ocp_qp_gpu_batch_opts_set(ocp_qp_gpu_batch *b, const char *field, const void *value);
 
@@ -97,6 +99,14 @@ int ocp_qp_gpu_batch_condense_rhs_and_solve(ocp_qp_gpu_batch *b);
  * solution back to the stages of `b` (x, u, sl, su, pi, lam, t). */
 ocp_qp_gpu_batch *ocp_qp_gpu_batch_condense(ocp_qp_gpu_batch *b);
 int ocp_qp_gpu_batch_expand(ocp_qp_gpu_batch *b);
+/* the other slots of ocp_qp_xcond_config (acados/ocp_qp/ocp_qp_common.h:84-107): _condense_rhs = vector part only on top of
+ * a resident matrix part (`condense_rhs`, ocp_qp_partial_condensing.c:602-630; after ocp_qp_gpu_batch_condense_lhs), returns
+ * the condensed batch; _condense_sol = the current iterate of `b` restated in the condensed variables and written into the
+ * condensed batch (`condense_qp_out`, :559-571): block inputs stacked, first state of each block, pi at the block
+ * boundaries, rows and slacks with their multipliers */
+ocp_qp_gpu_batch *ocp_qp_gpu_batch_condense_rhs(ocp_qp_gpu_batch *b);
+ocp_qp_gpu_batch *ocp_qp_gpu_batch_condensed(ocp_qp_gpu_batch *b); /* the condensed batch owned by `b`, or NULL */
+int ocp_qp_gpu_batch_condense_sol(ocp_qp_gpu_batch *b);
 /* "N" "n_batch" (one int) or "nx" "nu" "nbx" "nbu" "nb" "ng" "ns" "nbxe" (N+1 ints) */
 int ocp_qp_gpu_batch_get_dims(ocp_qp_gpu_batch *b, const char *field, int *out);
 /* "idxb" (nb) "idxs_rev" (nb+ng) "idxe": returns the number of entries written */
@@ -121,6 +131,18 @@ int ocp_qp_gpu_batch_get(ocp_qp_gpu_batch *b, const char *field, int stage, doub
  * After a partially condensed solve the sensitivities are computed in the full space at the expanded solution. */
 int ocp_qp_gpu_batch_sens_set(ocp_qp_gpu_batch *b, const char *field, int stage, const double *data);
 int ocp_qp_gpu_batch_sens_solve(ocp_qp_gpu_batch *b);
+
+/* KKT residuals of an arbitrary (qp_in, qp_out): what ocp_qp_res_compute -> d_ocp_qp_res_compute and
+ * ocp_qp_res_compute_nrm_inf do (acados/ocp_qp/ocp_qp_common.c:559-667; wrapper ocp_qp_inf_norm_residuals,
+ * interfaces/acados_c/ocp_qp_interface.c:642-650; asserted by test/ocp_qp/test_qpsolvers.cpp:240-251).  _res_compute
+ * evaluates the QP data and the iterate (x u sl su pi lam t) that are in HBM right now -- written by a solve, by
+ * ocp_qp_gpu_batch_set, or by an expansion -- in ONE launch of a kernel that shares nothing with the IPM sweeps, and
+ * leaves the residual vectors readable through ocp_qp_gpu_batch_get: "res_g" (nu+nx, stationarity w.r.t. [u; x]),
+ * "res_gs" (2ns, w.r.t. [sl; su]), "res_b" (nx_{k+1}), "res_d" and "res_m" (2(nb+ng+ns), order [lb lg ub ug ls us]).
+ * _res_nrm_inf copies res[i*4 + q] = inf-norm of (res_g, res_b, res_d, res_m) of instance i to the host (and runs
+ * _res_compute first if it has not run). */
+int ocp_qp_gpu_batch_res_compute(ocp_qp_gpu_batch *b);
+int ocp_qp_gpu_batch_res_nrm_inf(ocp_qp_gpu_batch *b, double *res);
 
 /* per-instance: "status" "iter" (int), "res_stat" "res_eq" "res_ineq" "res_comp" "mu" "obj" (double) */
 int ocp_qp_gpu_batch_get_info(ocp_qp_gpu_batch *b, const char *field, void *data);

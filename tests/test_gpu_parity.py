@@ -488,7 +488,7 @@ def test_partial_condensing_general_rows_gpu(gpu_lib):
             # the expanded point in the ORIGINAL QP: a hot-started full-space call finds its KKT residuals at
             # tolerance straight away (one more iteration allowed: the condensed residual norms are not the same norms)
             gb.opts_set("cond_N", N)
-            gb.opts_set("warm_start", 2)
+            gb.opts_set("warm_start", 3)
             assert gb.solve() == 0
             assert int(gb.info("iter").max()) <= 1
     # two iterate paths to the same solution; nearly degenerate instances (lam and t both small) move by more
@@ -537,7 +537,7 @@ def test_random_structures_gpu(gpu_lib, monkeypatch, wpi):
             assert b.solve() == 0, seed
             compare_with_oracle(lambda k, f: b.get(f, k)[69], o, qp, 1e-4, fields=("x", "u", "sl", "su", "pi", "lam", "t"))
             b.opts_set("cond_N", qp.N)
-            b.opts_set("warm_start", 2)
+            b.opts_set("warm_start", 3)
             assert b.solve() == 0 and int(b.info("iter").max()) == 0, seed
 
 
@@ -576,7 +576,7 @@ def test_condensing_only_boundary_gpu(gpu_lib):
         for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
             b.opts_set(f, 1e-8)
         b.opts_set("cond_N", qp.N)
-        b.opts_set("warm_start", 2)
+        b.opts_set("warm_start", 3)
         assert b.solve() == 0 and int(b.info("iter").max()) == 0   # KKT of the ORIGINAL QP at the expanded point
         mod = AcadosOcpQpCondensing(qp, cn, block_size=blocks)
         qc2 = mod.condense()
