@@ -91,3 +91,238 @@ def split(qp, w, off):
         out["u"].append(w[o:o + nu]); out["x"].append(w[o + nu:o + nu + nx])
         out["sl"].append(w[o + nu + nx:o + nu + nx + ns]); out["su"].append(w[o + nu + nx + ns:o + nu + nx + 2 * ns])
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Independent KKT residuals (a10) and solution sensitivities (a12): plain NumPy on the stage data, acados conventions
+# (acados_ocp_qp.py:24-45; multiplier order [lbu lbx lg ubu ubx ug lls lus]; pi[k] multiplies A x + B u + b - x+).
+# Shares no code with oracle/ or the HIP path.
+# ---------------------------------------------------------------------------------------------------------------
+
+def _stage(qp, k):
+    d = qp.dims
+    nu, nx, ns, nb, ng = int(d.nu[k]), int(d.nx[k]), int(d.ns[k]), int(d.nb[k]), int(d.ng[k])
+    H = np.zeros((nu + nx, nu + nx))
+    H[:nu, :nu], H[:nu, nu:], H[nu:, :nu], H[nu:, nu:] = qp.R[k], qp.S[k], qp.S[k].T, qp.Q[k]
+    g = np.concatenate([qp.r[k], qp.q[k]])
+    J = np.zeros((nb + ng, nu + nx))
+    for i in range(nb):
+        J[i, qp.idxb[k][i]] = 1.0
+    if ng:
+        J[nb:, :nu], J[nb:, nu:] = qp.D[k], qp.C[k]
+    lo = np.concatenate([qp.lbu[k], qp.lbx[k], qp.lg[k]])
+    up = np.concatenate([qp.ubu[k], qp.ubx[k], qp.ug[k]])
+    mlo = np.concatenate([qp.lbu_mask[k], qp.lbx_mask[k], qp.lg_mask[k]]) != 0
+    mup = np.concatenate([qp.ubu_mask[k], qp.ubx_mask[k], qp.ug_mask[k]]) != 0
+    eq = np.zeros(nb + ng, dtype=bool)
+    for e in qp.idxe[k]:
+        eq[int(e)] = True
+    return dict(nu=nu, nx=nx, ns=ns, nb=nb, ng=ng, nbg=nb + ng, H=H, g=g, J=J, lo=lo, up=up, mlo=mlo, mup=mup, eq=eq,
+                rev=np.asarray(qp.idxs_rev[k]).astype(int), mls=np.asarray(qp.lls_mask[k]) != 0, mus=np.asarray(qp.lus_mask[k]) != 0)
+
+
+def kkt_residuals(qp, get):
+    """res_g, res_b, res_d, res_m per stage of the iterate get(k, field) (x u sl su pi lam t), the way
+    d_ocp_qp_res_compute defines them (ocp_qp_common.c:559-594 calls it; formulas from the KKT system in
+    ocp_qp_clarabel.c:493-683): masked sides contribute nothing, equality-flagged rows are ordinary box rows"""
+    N = qp.N
+    out = {"res_g": [], "res_b": [], "res_d": [], "res_m": []}
+    for k in range(N + 1):
+        s = _stage(qp, k)
+        nu, ns, nbg = s["nu"], s["ns"], s["nbg"]
+        v = np.concatenate([get(k, "u"), get(k, "x")])
+        sl, su, lam, t = get(k, "sl"), get(k, "su"), get(k, "lam"), get(k, "t")
+        al, au = s["mlo"] | s["eq"], s["mup"] | s["eq"]
+        ll, lu = np.where(al, lam[:nbg], 0.0), np.where(au, lam[nbg:2 * nbg], 0.0)
+        rg = s["H"] @ v + s["g"] - s["J"].T @ (ll - lu)
+        if k < N:
+            pk = get(k, "pi")
+            rg[:nu] += qp.B[k].T @ pk
+            rg[nu:] += qp.A[k].T @ pk
+        if k > 0:
+            rg[nu:] -= get(k - 1, "pi")
+        lls_, lus_ = np.where(s["mls"], lam[2 * nbg:2 * nbg + ns], 0.0), np.where(s["mus"], lam[2 * nbg + ns:], 0.0)
+        rsl = qp.Zl[k] * sl + qp.zl[k] - lls_
+        rsu = qp.Zu[k] * su + qp.zu[k] - lus_
+        c = s["J"] @ v
+        rd, rm = np.zeros(2 * nbg + 2 * ns), np.zeros(2 * nbg + 2 * ns)
+        for i in range(nbg):
+            j = s["rev"][i]
+            if j >= 0:
+                rsl[j] -= ll[i]
+                rsu[j] -= lu[i]
+            if al[i]:
+                rd[i] = c[i] + (sl[j] if j >= 0 else 0.0) - s["lo"][i] - t[i]
+                rm[i] = lam[i] * t[i]
+            if au[i]:
+                rd[nbg + i] = s["up"][i] - c[i] + (su[j] if j >= 0 else 0.0) - t[nbg + i]
+                rm[nbg + i] = lam[nbg + i] * t[nbg + i]
+        for j in range(ns):
+            if s["mls"][j]:
+                rd[2 * nbg + j] = sl[j] - qp.lls[k][j] - t[2 * nbg + j]
+                rm[2 * nbg + j] = lam[2 * nbg + j] * t[2 * nbg + j]
+            if s["mus"][j]:
+                rd[2 * nbg + ns + j] = su[j] - qp.lus[k][j] - t[2 * nbg + ns + j]
+                rm[2 * nbg + ns + j] = lam[2 * nbg + ns + j] * t[2 * nbg + ns + j]
+        out["res_g"].append(np.concatenate([rg, rsl, rsu]))
+        out["res_b"].append(qp.A[k] @ v[nu:] + qp.B[k] @ v[:nu] + qp.b[k] - get(k + 1, "x") if k < N else np.zeros(0))
+        out["res_d"].append(rd)
+        out["res_m"].append(rm)
+    return out
+
+
+def kkt_residual_norms(qp, get):
+    r = kkt_residuals(qp, get)
+    return np.array([max([np.max(np.abs(a)) if a.size else 0.0 for a in r[n]] + [0.0]) for n in ("res_g", "res_b", "res_d", "res_m")])
+
+
+def sens_dense(qp, get, seeds):
+    """d(solution)/d(parameter) from ONE dense solve of the linearised KKT system at the iterate get(k, field) -- what
+    d_ocp_qp_ipm_sens_frw computes with the factorisation at the last IPM iterate (ocp_qp_hpipm.c:481-491):
+
+        [ H   Aeq'  -Ain'  0 ] [dw  ]   [-dg  ]
+        [ Aeq  0     0     0 ] [dnu ] = [ dbeq]
+        [ Ain  0     0    -I ] [dlam]   [ dbin]
+        [ 0    0     T     L ] [dt  ]   [ 0   ]          T = diag(t), L = diag(lam)
+
+    over the inequality sides that take part (mask != 0, not equality-flagged).  seeds: {(field, k): vector}, field in
+    q r b lbu ubu lbx ubx lg ug (natural-sign bounds; an equality-flagged row takes its lbx seed).  Returns a function
+    (k, field) -> array for x u sl su pi lam t, lam/t zero on sides that do not take part."""
+    N, d = qp.N, qp.dims
+    off, nw = [], 0
+    for k in range(N + 1):
+        off.append(nw)
+        nw += int(d.nu[k] + d.nx[k] + 2 * d.ns[k])
+    H, dg = np.zeros((nw, nw)), np.zeros(nw)
+    eq_rows, eq_rhs, eq_tag = [], [], []
+    in_rows, in_rhs, in_tag = [], [], []
+    sd = lambda f, k, n: np.asarray(seeds.get((f, k), np.zeros(n)), dtype=float).reshape(-1)
+    for k in range(N + 1):
+        s = _stage(qp, k)
+        nu, nx, ns, nbg, nb = s["nu"], s["nx"], s["ns"], s["nbg"], s["nb"]
+        o = off[k]
+        H[o:o + nu + nx, o:o + nu + nx] = s["H"]
+        for j in range(ns):
+            H[o + nu + nx + j, o + nu + nx + j] = qp.Zl[k][j]
+            H[o + nu + nx + ns + j, o + nu + nx + ns + j] = qp.Zu[k][j]
+        dg[o:o + nu] = sd("r", k, nu)
+        dg[o + nu:o + nu + nx] = sd("q", k, nx)
+        if k < N:
+            nx1 = int(d.nx[k + 1])
+            row = np.zeros((nx1, nw))
+            row[:, o:o + nu], row[:, o + nu:o + nu + nx] = qp.B[k], qp.A[k]
+            row[:, off[k + 1] + int(d.nu[k + 1]) + np.arange(nx1)] -= np.eye(nx1)
+            db = sd("b", k, nx1)
+            for r in range(nx1):
+                eq_rows.append(row[r]); eq_rhs.append(-db[r]); eq_tag.append(("pi", k, r))
+        dlo = np.concatenate([sd("lbu", k, int(d.nbu[k])), sd("lbx", k, int(d.nbx[k])), sd("lg", k, s["ng"])])
+        dup = np.concatenate([sd("ubu", k, int(d.nbu[k])), sd("ubx", k, int(d.nbx[k])), sd("ug", k, s["ng"])])
+        lam, t = get(k, "lam"), get(k, "t")
+        for i in range(nbg):
+            Ji = np.zeros(nw)
+            Ji[o:o + nu + nx] = s["J"][i]
+            j = s["rev"][i]
+            if s["eq"][i]:
+                eq_rows.append(Ji); eq_rhs.append(dlo[i]); eq_tag.append(("eq", k, i))
+                continue
+            if s["mlo"][i]:
+                r = Ji.copy()
+                if j >= 0:
+                    r[o + nu + nx + j] += 1.0
+                in_rows.append(r); in_rhs.append(dlo[i]); in_tag.append((k, i, lam[i], t[i]))
+            if s["mup"][i]:
+                r = -Ji
+                if j >= 0:
+                    r[o + nu + nx + ns + j] += 1.0
+                in_rows.append(r); in_rhs.append(-dup[i]); in_tag.append((k, nbg + i, lam[nbg + i], t[nbg + i]))
+        for j in range(ns):
+            for side, m in ((0, s["mls"]), (1, s["mus"])):
+                if m[j]:
+                    r = np.zeros(nw)
+                    r[o + nu + nx + side * ns + j] = 1.0
+                    e = 2 * nbg + side * ns + j
+                    in_rows.append(r); in_rhs.append(0.0); in_tag.append((k, e, lam[e], t[e]))
+    Aeq = np.array(eq_rows).reshape(len(eq_rows), nw)
+    Ain = np.array(in_rows).reshape(len(in_rows), nw)
+    ne, ni = Aeq.shape[0], Ain.shape[0]
+    lam_v = np.array([tg[2] for tg in in_tag])
+    t_v = np.array([tg[3] for tg in in_tag])
+    n = nw + ne + 2 * ni
+    K, rhs = np.zeros((n, n)), np.zeros(n)
+    K[:nw, :nw] = H
+    K[:nw, nw:nw + ne] = Aeq.T
+    K[:nw, nw + ne:nw + ne + ni] = -Ain.T
+    K[nw:nw + ne, :nw] = Aeq
+    K[nw + ne:nw + ne + ni, :nw] = Ain
+    K[nw + ne:nw + ne + ni, nw + ne + ni:] = -np.eye(ni)
+    K[nw + ne + ni:, nw + ne:nw + ne + ni] = np.diag(t_v)
+    K[nw + ne + ni:, nw + ne + ni:] = np.diag(lam_v)
+    rhs[:nw] = -dg
+    rhs[nw:nw + ne] = eq_rhs
+    rhs[nw + ne:nw + ne + ni] = in_rhs
+    z = _solve_extended(K, rhs)
+    dw, dnu, dlam, dt = z[:nw], z[nw:nw + ne], z[nw + ne:nw + ne + ni], z[nw + ne + ni:]
+    res = {}
+    for k in range(N + 1):
+        o, nu, nx, ns = off[k], int(d.nu[k]), int(d.nx[k]), int(d.ns[k])
+        res[(k, "u")], res[(k, "x")] = dw[o:o + nu], dw[o + nu:o + nu + nx]
+        res[(k, "sl")], res[(k, "su")] = dw[o + nu + nx:o + nu + nx + ns], dw[o + nu + nx + ns:o + nu + nx + 2 * ns]
+        nct = 2 * int(d.nb[k] + d.ng[k] + d.ns[k])
+        res[(k, "lam")], res[(k, "t")] = np.zeros(nct), np.zeros(nct)
+        if k < N:
+            res[(k, "pi")] = np.zeros(int(d.nx[k + 1]))
+    for q, tg in enumerate(eq_tag):
+        if tg[0] == "pi":
+            res[(tg[1], "pi")][tg[2]] = dnu[q]
+    for q, tg in enumerate(in_tag):
+        res[(tg[0], "lam")][tg[1]] = dlam[q]
+        res[(tg[0], "t")][tg[1]] = dt[q]
+    return _Sens(res, {(tg[0], tg[1]) for tg in in_tag})
+
+
+def _solve_extended(K, rhs):
+    """Gaussian elimination with partial pivoting in 80-bit extended precision + two refinement steps: the KKT matrix of
+    an IPM iterate holds t ~ 1e-10 next to lam ~ 1, its condition number eats most of a double"""
+    n = K.shape[0]
+    A = K.astype(np.longdouble)
+    A0 = A.copy()
+    b0 = rhs.astype(np.longdouble)
+    # row equilibration (the complementarity rows are tiny)
+    sc = np.max(np.abs(A), axis=1)
+    sc[sc == 0] = 1
+    perm = np.arange(n)
+    Lm = np.zeros((n, n), dtype=np.longdouble)
+    for c in range(n):
+        p = c + int(np.argmax(np.abs(A[c:, c]) / sc[perm[c:]]))
+        if p != c:
+            A[[c, p]] = A[[p, c]]
+            Lm[[c, p]] = Lm[[p, c]]
+            perm[[c, p]] = perm[[p, c]]
+        piv = A[c, c]
+        f = A[c + 1:, c] / piv
+        Lm[c + 1:, c] = f
+        A[c + 1:, c:] -= np.outer(f, A[c, c:])
+
+    def lu_solve(b):
+        y = b[perm].copy()
+        for c in range(n):
+            y[c + 1:] -= Lm[c + 1:, c] * y[c]
+        x = np.zeros(n, dtype=np.longdouble)
+        for c in range(n - 1, -1, -1):
+            x[c] = (y[c] - A[c, c + 1:] @ x[c + 1:]) / A[c, c]
+        return x
+
+    x = lu_solve(b0)
+    for _ in range(2):
+        x = x + lu_solve(b0 - A0 @ x)
+    return x.astype(np.float64)
+
+
+class _Sens:
+    """(k, field) -> array; .active = {(k, side index)} of the inequality sides that take part"""
+
+    def __init__(self, res, active):
+        self._res, self.active = res, active
+
+    def __call__(self, k, f):
+        return self._res[(k, f)]

@@ -122,6 +122,9 @@ def test_full_size_properties_gpu(gpu_lib):
     assert np.all(gb.info("status") == 0)
     for n in ("res_stat", "res_eq", "res_ineq", "res_comp"):
         assert gb.info(n).max() <= 1e-8
+    # ... and the same statement from the kernel that shares nothing with the solver: ocp_qp_res_compute + _nrm_inf on the
+    # (data, solution) in HBM, stationarity and complementarity included (mirror of test_qpsolvers.cpp:240-251)
+    assert gb.res_compute().max() <= 1e-8
     it = gb.info("iter")
     assert it.min() >= 1 and it.max() <= 50
     x0 = gb.get("x", 0)
@@ -182,6 +185,8 @@ def test_c3_full_size_properties_gpu(gpu_lib):
         assert int(gb.scalar("cond_N_active")) == (cond_N if cond_N else N)
         for n in ("res_stat", "res_eq", "res_ineq", "res_comp"):
             assert gb.info(n).max() <= 1e-8
+        # KKT residuals of the ORIGINAL QP at the (expanded) solution, recomputed independently of the solver
+        assert gb.res_compute().max() <= (2e-8 if cond_N else 1e-8)
         xk = gb.get("x", 0)
         assert np.array_equal(xk, data["x0"])
         us = []
@@ -255,6 +260,7 @@ def test_c4_full_size_properties_gpu(gpu_lib):
     assert np.all(gb.info("status") == 0)
     for n in ("res_stat", "res_eq", "res_ineq", "res_comp"):
         assert gb.info(n).max() <= 1e-8
+    assert gb.res_compute().max() <= 1e-8     # independent kernel: ocp_qp_res_compute on the (data, solution) in HBM
     assert gb.info("iter").max() <= 50
     xk = gb.get("x", 0)
     assert np.array_equal(xk, data["x0"])
@@ -299,6 +305,8 @@ def test_c5_per_gpu_share_properties_gpu(gpu_lib):
         assert gb.solve() == 0, (nx, nu, N, gb.kernel_name)
         for n in ("res_stat", "res_eq", "res_ineq", "res_comp"):
             assert gb.info(n).max() <= 1e-8
+        # KKT residuals of the ORIGINAL QP at the (expanded) solution, recomputed independently of the solver
+        assert gb.res_compute().max() <= (2e-8 if cond_N else 1e-8)
         xk = gb.get("x", 0)
         assert np.array_equal(xk, data["x0"])
         for k in range(N):
@@ -484,6 +492,9 @@ def test_partial_condensing_general_rows_gpu(gpu_lib):
         assert int(gb.scalar("cond_N_active")) == cond_N
         sol[cond_N] = {f: np.concatenate([gb.get(f, k) for k in range(N + (f != "pi" and f != "u"))], axis=1)
                        for f in ("x", "u", "pi", "lam", "sl", "su")}
+        # KKT residuals of the ORIGINAL QP at the (expanded) solution from the independent residual kernel
+        # (ocp_qp_res_compute): every instance, all four norms
+        assert gb.res_compute().max() <= (2e-8 if cond_N < N else 1e-8)
         if cond_N < N:
             # the expanded point in the ORIGINAL QP: a hot-started full-space call finds its KKT residuals at
             # tolerance straight away (one more iteration allowed: the condensed residual norms are not the same norms)
@@ -491,13 +502,16 @@ def test_partial_condensing_general_rows_gpu(gpu_lib):
             gb.opts_set("warm_start", 3)
             assert gb.solve() == 0
             assert int(gb.info("iter").max()) <= 1
-    # two iterate paths to the same solution; nearly degenerate instances (lam and t both small) move by more
+    # two iterate paths to the same solution, both inside the 1e-8 KKT ball (asserted above by the independent residual
+    # kernel -- that is the sharp statement).  What the ball allows: on a weakly active row complementarity 1e-8 leaves
+    # lam ~ t ~ sqrt(1e-8) = 1e-4, so the primal points of such instances differ by up to ~1e-4 and their multipliers
+    # (not unique in the degenerate limit) by more; everything else agrees to ~1e-6
     for f in ("x", "u", "sl", "su", "pi", "lam"):
         a, c = sol[N][f], sol[20][f]
         err = np.max(np.abs(a - c) / np.maximum(1.0, np.abs(a)), axis=1)
-        # (complementarity 1e-8 leaves lam ~ t ~ 1e-4 on a weakly active row: such instances differ by ~1e-4)
+        primal = f in ("x", "u", "sl", "su")
         w = 1.0 if f in ("x", "u") else 10.0
-        assert np.median(err) <= 2e-6 * w and np.mean(err <= 2e-5 * w) >= 0.9 and err.max() <= 2e-2, \
+        assert np.median(err) <= 2e-6 * w and np.mean(err <= 2e-5 * w) >= 0.9 and err.max() <= (5e-4 if primal else 5e-3), \
             (f, np.median(err), np.sort(err)[-5:])
     for cn in (5, 3):
         qp = mass_spring_qp(N=15)
@@ -535,6 +549,9 @@ def test_random_structures_gpu(gpu_lib, monkeypatch, wpi):
         if qp.N >= 2:
             b.opts_set("cond_N", (qp.N + 1) // 2)
             assert b.solve() == 0, seed
+            # condensed run: another iterate path inside the same 1e-8 KKT ball of the ORIGINAL QP -- asserted by the
+            # independent residual kernel; the direct comparison is at sqrt(tol) = 1e-4 (weakly active rows)
+            assert b.res_compute().max() <= 2e-8, seed
             compare_with_oracle(lambda k, f: b.get(f, k)[69], o, qp, 1e-4, fields=("x", "u", "sl", "su", "pi", "lam", "t"))
             b.opts_set("cond_N", qp.N)
             b.opts_set("warm_start", 3)
