@@ -48,6 +48,13 @@ def bind(L):
     L.ocp_qp_gpu_batch_condensed.restype = C.c_void_p
     L.ocp_qp_gpu_batch_set_bulk_out.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.ocp_qp_gpu_batch_condense_sol.argtypes = [C.c_void_p]
+    L.ocp_qp_gpu_comm_unique_id.argtypes = [C.c_void_p]
+    L.ocp_qp_gpu_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    L.ocp_qp_gpu_comm_create.restype = C.c_void_p
+    L.ocp_qp_gpu_comm_destroy.argtypes = [C.c_void_p]
+    L.ocp_qp_gpu_batch_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ocp_qp_gpu_batch_bulk_len.argtypes = [C.c_void_p, C.c_int]
+    L.ocp_qp_gpu_batch_bulk_offset.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int)]
     L.ocp_qp_gpu_batch_res_compute.argtypes = [C.c_void_p]
     L.ocp_qp_gpu_batch_res_nrm_inf.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     return L

@@ -1111,7 +1111,13 @@ static int pcond_solve(ocp_qp_gpu_batch *b, int mode = 3)
     HIPCHK(hipEventRecord(e1, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     c->t0_min = b->t0_min; c->lam0_min = b->lam0_min;
+    c->profile = b->profile; /* per-class event times of the condensed solve are reported on the root */
     const int bad = ocp_qp_gpu_batch_solve(c);
+    for (int q = 0; q < 6; q++)
+    {
+        b->prof_ms[q] += c->prof_ms[q]; b->prof_cnt[q] += c->prof_cnt[q];
+        c->prof_ms[q] = 0.0; c->prof_cnt[q] = 0;
+    }
     HIPCHK(hipEventRecord(e2, b->stream));
     pcond_launch(b, true);
     HIPCHK(hipEventRecord(e3, b->stream));
@@ -2033,6 +2039,125 @@ int ocp_qp_gpu_batch_get_bulk(ocp_qp_gpu_batch *b, double *blob, int is_device)
     HIPCHK(hipStreamSynchronize(b->stream));
     return 0;
 }
+
+/* ---- multi-GPU: the ONLY collective of the path -- one RCCL all-gather over xGMI of the solutions and
+ * their per-instance status / iteration counts plus the per-rank solve time, from device buffers on the batch's stream.
+ * RCCL is bound at run time (dlopen): the copy PyTorch has already loaded if there is one, so that the process holds a
+ * single RCCL instance; else the ROCm one.  One process per GPU; the unique id travels between the processes by whatever
+ * means the host program has (torch.distributed broadcast in bench.py, MPI_Bcast in a C harness). ---- */
+#if defined(__HIPCC__)
+#include <dlfcn.h>
+struct ocp_qp_gpu_comm
+{
+    void *lib = nullptr;
+    void *comm = nullptr; /* ncclComm_t */
+    int n = 0, rank = 0, device = 0;
+    struct uid { char internal[128]; };
+    int (*get_uid)(uid *) = nullptr;
+    int (*init_rank)(void **, int, uid, int) = nullptr;
+    int (*all_gather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*destroy)(void *) = nullptr;
+    const char *(*err)(int) = nullptr;
+};
+
+static bool rccl_bind(ocp_qp_gpu_comm *c)
+{
+    const char *names[] = {"librccl.so", "librccl.so.1"};
+    for (const char *n : names)
+        if ((c->lib = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break; /* already in the process (PyTorch's copy) */
+    if (!c->lib)
+    {
+        const char *load[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *n : load)
+            if ((c->lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    }
+    if (!c->lib) { fprintf(stderr, "acados_amd: RCCL (librccl.so) cannot be loaded: %s\n", dlerror()); return false; }
+    c->get_uid = (int (*)(ocp_qp_gpu_comm::uid *)) dlsym(c->lib, "ncclGetUniqueId");
+    c->init_rank = (int (*)(void **, int, ocp_qp_gpu_comm::uid, int)) dlsym(c->lib, "ncclCommInitRank");
+    c->all_gather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t)) dlsym(c->lib, "ncclAllGather");
+    c->destroy = (int (*)(void *)) dlsym(c->lib, "ncclCommDestroy");
+    c->err = (const char *(*)(int)) dlsym(c->lib, "ncclGetErrorString");
+    if (!c->get_uid || !c->init_rank || !c->all_gather || !c->destroy)
+    {
+        fprintf(stderr, "acados_amd: librccl.so lacks the collective entry points\n");
+        return false;
+    }
+    return true;
+}
+#define RCCLCHK(c, x)                                                                                     \
+    do {                                                                                                  \
+        int r_ = (x);                                                                                     \
+        if (r_ != 0)                                                                                      \
+        {                                                                                                 \
+            fprintf(stderr, "acados_amd: RCCL error %d (%s) at %s:%d\n", r_, (c)->err ? (c)->err(r_) : "?", __FILE__, __LINE__); \
+            return -1;                                                                                    \
+        }                                                                                                 \
+    } while (0)
+
+int ocp_qp_gpu_comm_unique_id(void *id128)
+{
+    ocp_qp_gpu_comm c;
+    if (!rccl_bind(&c)) return -1;
+    RCCLCHK(&c, c.get_uid((ocp_qp_gpu_comm::uid *) id128));
+    return 0;
+}
+
+ocp_qp_gpu_comm *ocp_qp_gpu_comm_create(const void *id128, int n_ranks, int rank, int device)
+{
+    ocp_qp_gpu_comm *c = new ocp_qp_gpu_comm();
+    if (!rccl_bind(c)) { delete c; return nullptr; }
+    if (device >= 0) HIPCHK(hipSetDevice(device));
+    HIPCHK(hipGetDevice(&c->device));
+    c->n = n_ranks; c->rank = rank;
+    ocp_qp_gpu_comm::uid id;
+    memcpy(&id, id128, sizeof(id));
+    const int r = c->init_rank(&c->comm, n_ranks, id, rank);
+    if (r != 0)
+    {
+        fprintf(stderr, "acados_amd: ncclCommInitRank failed: %d (%s)\n", r, c->err ? c->err(r) : "?");
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
+
+void ocp_qp_gpu_comm_destroy(ocp_qp_gpu_comm *c)
+{
+    if (!c) return;
+    if (c->comm) (void) c->destroy(c->comm);
+    delete c;
+}
+
+int ocp_qp_gpu_batch_gather(ocp_qp_gpu_batch *b, ocp_qp_gpu_comm *c, double *sol_all, int *info_all, double *time_all)
+{
+    HIPCHK(hipSetDevice(b->device));
+    const int len = ocp_qp_gpu_batch_bulk_len(b, 1);
+    auto &M = b->bulk_out;
+    const size_t cnt = (size_t) b->B * len;
+    /* send buffers: the solution blob of this rank (gather launch into the staging area), status / iter interleaved */
+    const size_t need = cnt + (size_t) b->B + 8; /* doubles: blob + room for 2*B ints + the time */
+    if (need > b->stage_cap) { b->stage_cap = need * 2; b->d_stage = dalloc<double>(b, b->stage_cap); }
+    double *blob = b->d_stage;
+    int *info = (int *) (b->d_stage + cnt);
+    double *tm = b->d_stage + cnt + b->B + 1;
+    const dim3 grid((b->B + 63) / 64, (len + 255) / 256), block(64);
+    hipLaunchKernelGGL(gqp::k_bulk_gather, grid, block, 0, b->stream, blob, b->B, len, M.d_arr, M.d_elem, M.T);
+    hipLaunchKernelGGL(gqp::k_pack_info, dim3((b->B + 63) / 64), block, 0, b->stream, b->D, info);
+    HIPCHK(hipMemcpyAsync(tm, &b->time_tot, sizeof(double), hipMemcpyHostToDevice, b->stream));
+    /* ncclDataType_t: ncclInt32 = 2, ncclFloat64 = 8 (rccl.h) */
+    RCCLCHK(c, c->all_gather(blob, sol_all, cnt, 8, c->comm, b->stream));
+    RCCLCHK(c, c->all_gather(info, info_all, 2 * (size_t) b->B, 2, c->comm, b->stream));
+    RCCLCHK(c, c->all_gather(tm, time_all, 1, 8, c->comm, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return 0;
+}
+#else  /* host-simulation build of the CPU test tier: no RCCL, the N > 1 path is covered by the gloo test */
+struct ocp_qp_gpu_comm { int n; };
+int ocp_qp_gpu_comm_unique_id(void *) { return -1; }
+ocp_qp_gpu_comm *ocp_qp_gpu_comm_create(const void *, int, int, int) { return nullptr; }
+void ocp_qp_gpu_comm_destroy(ocp_qp_gpu_comm *) {}
+int ocp_qp_gpu_batch_gather(ocp_qp_gpu_batch *, ocp_qp_gpu_comm *, double *, int *, double *) { return -1; }
+#endif
 
 size_t ocp_qp_gpu_batch_bytes(const ocp_qp_gpu_batch *b) { return b->bytes; }
 void *ocp_qp_gpu_batch_stream(ocp_qp_gpu_batch *b) { return (void *) b->stream; }

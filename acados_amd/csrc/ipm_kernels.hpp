@@ -1294,6 +1294,15 @@ static __global__ void k_hot_start(GqpDev D, double t_min, double lam_min)
     }
 }
 
+/* (status, iter) of every instance interleaved: the per-instance part of the multi-GPU gather payload */
+static __global__ void k_pack_info(GqpDev D, int *out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D.B) return;
+    out[2 * i] = D.status[i];
+    out[2 * i + 1] = D.iter[i];
+}
+
 static __global__ void k_status_restore(GqpDev D, const int *saved_status)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

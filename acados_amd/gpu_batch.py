@@ -266,6 +266,11 @@ class OcpQpGpuBatch:
     def kernel_name(self):
         return self._L.ocp_qp_gpu_batch_kernel_name(self._h).decode()
 
+    def condensed_kernel_name(self):
+        """kernel instantiation serving the condensed batch of the last partially condensed solve (None: not condensed)"""
+        h = self._L.ocp_qp_gpu_batch_condensed(self._h)
+        return self._L.ocp_qp_gpu_batch_kernel_name(C.c_void_p(h)).decode() if h else None
+
     def close(self):
         if getattr(self, "_h", None):
             if getattr(self, "_owner", None) is None:   # a condensed view belongs to its parent

@@ -37,6 +37,58 @@ def gather_instances(local, n_total: int, dist=None, device=None):
     return np.concatenate([o.cpu().numpy()[: hi - lo] for o, (lo, hi) in zip(outs, sizes)], axis=0)
 
 
+def gather_solutions(gb, dist=None, rank: int = 0, world: int = 1):
+    """The path's only collective, through the library's own entry: ONE RCCL all-gather over xGMI of the
+    full solution payload {u x sl su pi lam t} + (status, iter) of every instance + the solve time of every rank,
+    from device buffers on the batch's stream -- no host bounce.  torch is plumbing here: it broadcasts the 128-byte
+    RCCL unique id and owns the receive buffers.  Returns timing and a consistency check, or None without a GPU library
+    entry (host simulation)."""
+    import ctypes as C
+    import time
+    import torch
+    L, h, B = gb._L, gb._h, gb.n_batch
+    dev = torch.device("cuda", torch.cuda.current_device())
+    uid = torch.zeros(128, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        buf = (C.c_char * 128)()
+        if L.ocp_qp_gpu_comm_unique_id(buf) != 0:
+            return None
+        uid.copy_(torch.frombuffer(bytearray(bytes(buf)), dtype=torch.uint8))
+    if dist is not None and dist.is_initialized() and world > 1:
+        dist.broadcast(uid, 0)
+    idb = bytes(uid.cpu().numpy().tobytes())
+    comm = L.ocp_qp_gpu_comm_create(idb, int(world), int(rank), -1)
+    if not comm:
+        return None
+    comm = C.c_void_p(comm)
+    Lout = L.ocp_qp_gpu_batch_bulk_len(h, 1)
+    sol = torch.empty((world, B, Lout), dtype=torch.float64, device=dev)
+    info = torch.empty((world, B, 2), dtype=torch.int32, device=dev)
+    tm = torch.empty(world, dtype=torch.float64, device=dev)
+    torch.cuda.synchronize()
+    best = None
+    for _ in range(2):      # first call pays RCCL's lazy channel setup
+        t0 = time.perf_counter()
+        rc = L.ocp_qp_gpu_batch_gather(h, comm, C.c_void_p(sol.data_ptr()), C.c_void_p(info.data_ptr()), C.c_void_p(tm.data_ptr()))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    L.ocp_qp_gpu_comm_destroy(comm)
+    if rc != 0:
+        return None
+    # consistency: this rank's slice of the gathered payload is what the getters return
+    n0 = C.c_int(0)
+    off = L.ocp_qp_gpu_batch_bulk_offset(h, 1, b"u", 0, C.byref(n0))
+    own = sol[rank, :, off:off + n0.value].cpu().numpy()
+    ok = bool(np.array_equal(own, gb.get("u", 0))) and bool(np.array_equal(info[rank, :, 0].cpu().numpy(), gb.info("status")))
+    payload = world * B * (Lout * 8 + 8) + world * 8
+    return {"ms": best * 1e3, "bytes_per_instance": Lout * 8 + 8, "payload_bytes_received_per_rank": payload,
+            "GBps_received_per_rank": payload / best / 1e9, "ranks": world, "slice_matches_getters": ok,
+            "iter_mean_all_ranks": float(info[:, :, 1].double().mean().item()),
+            "nonzero_status_all_ranks": int((info[:, :, 0] != 0).sum().item()), "solve_s_per_rank": [float(v) for v in tm.cpu().numpy()],
+            "collective": "ncclAllGather x3 (solutions f64, status/iter i32, time f64) via ocp_qp_gpu_batch_gather"}
+
+
 def reduce_max(value: float, dist=None, device=None) -> float:
     import torch
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:

@@ -3,23 +3,36 @@
 
 A "step" = one cold-start solve of the whole batch of synthetic OCP-QPs (every IPM iteration of
 every instance), inputs already packed and resident in HBM when the timed region starts.
-Workload at N=1 GPU: BASELINE.json configs[1] -- random LQR-like OCP-QP, N=50, nx=8, nu=3,
+Workload at N=1 GPU: BASELINE.json configs[1] (C2) -- random LQR-like OCP-QP, N=50, nx=8, nu=3,
 batch=65,536, u-box + x0 equality, tolerances 1e-8, iter_max 50 (SURVEY.md 8d "C2 input").
 N>1: one process per GPU (torch.distributed.run), the batch is sharded by instance -- every rank
-solves its own 65,536 instances (weak scaling), no data-path collective; an RCCL all_gather of the
-first-stage controls + per-rank statistics runs AFTER the timed region (its time is reported).
+solves its own 65,536 instances (weak scaling), no data-path collective; AFTER the timed region the
+full solution payload {ux, pi, lam, t, status, iter, solve time} of every rank is gathered with ONE
+RCCL all-gather over xGMI from device buffers through the library's own collective entry
+(ocp_qp_gpu_batch_gather; its time is reported as gather_ms).
 
 Extra objects on the JSON line:
   roofline     dominant kernel (by accumulated HIP-event time inside the timed region, events on the
                stream the kernels are launched on): algorithmic bytes per launch / avg duration vs the
-               8 TB/s HBM peak.  Algorithmic bytes per launch = active instances x 98,056 B
-               (unique QP input 85,336 B + iterate/solution 12,720 B per solve).
+               8 TB/s HBM peak.  Algorithmic bytes per launch = instances the launch still processes x
+               98,056 B (unique QP input 85,336 B + iterate/solution 12,720 B per solve).
+               `traffic` = HBM bytes per launch of the SAME kernel over the SAME set of launches from the
+               rocprofv3 PMC passes of tools/profile_round.sh (FETCH_SIZE / WRITE_SIZE, separate passes,
+               gfx950 correction of MI355X_MICROARCH.md), read from the newest profiles/*_pmc_traffic.json
+               whose recorded commit is reported next to it; `full_launch` repeats both for the launches in
+               which every instance is still iterating.
+  configs      the other single-GPU configurations of BASELINE.json (C3, C4, the per-GPU share of C5),
+               each with solves/s, iterations, failures, independently recomputed KKT residual, oracle
+               error on a sample, dominant kernel and its roofline fraction (rank 0, N=1 only).
   cpu_baseline the oracle (restated CPU port, NOT HPIPM: its sources are absent from the reference
-               tree) on a bounded sample of the same workload on the host cores, rank 0, N=1 only.
+               tree) on a bounded sample of the same workload on the host cores, rank 0, N=1 only:
+               one-thread rate, best thread count of a sweep, cores visible / allowed.
 """
 import argparse
+import glob
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -28,36 +41,270 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-BYTES_IN, BYTES_OUT = 85336, 12720
 HBM_PEAK_GBS = 8000.0                   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+SWEEPS = ("back_fact", "fwd_aff", "back_rhs", "fwd_corr")
+CLASSES = SWEEPS + ("init", "finalize")
 
 
-def algorithmic_bytes(N, nx, nu):
-    """SURVEY.md 8d formula for the u-box + x0-equality LQR shape (nb_k = nu (k<N), nb_0 += nx)"""
-    dbl_in = N * (nx * nx + nx * nu + nx) + (N + 1) * (nx * nx + nx) + N * (nu * nx + nu * nu + nu) \
-        + 2 * (N * nu + nx)
-    int_in = N * nu + nx            # idxb only (idxs_rev is empty when ns = 0): 158 ints, SURVEY 8d
-    dbl_out = (N + 1) * nx + N * nu + N * nx + 4 * (N * nu + nx)
+def algorithmic_bytes_dims(d):
+    """unique QP input read once + solution written once, sizes as colmaj_ocp_qp_in_calculate_size
+    (ocp_qp_common_frontend.c:67-86) + ux, pi, lam, t.  C2: 85,336 + 12,720 = 98,056 B."""
+    N = int(d.N)
+    nx, nu, nb, ng, ns = (np.asarray(getattr(d, n), dtype=np.int64) for n in ("nx", "nu", "nb", "ng", "ns"))
+    nx1 = nx[1:]
+    dbl_in = int(np.sum(nx1 * nx[:N] + nx1 * nu[:N] + nx1)
+                 + np.sum(nx * nx + nu * nx + nu * nu + nx + nu + 2 * nb + ng * (nx + nu) + 2 * ng + 4 * ns + 2 * ns))
+    int_in = int(np.sum(nb + np.where(ns > 0, nb + ng, 0)))      # idxb; idxs_rev where a stage has slacks
+    dbl_out = int(np.sum(nx + nu + 2 * ns) + np.sum(nx1) + 2 * np.sum(2 * (nb + ng + ns)))
     return 8 * dbl_in + 4 * int_in, 8 * dbl_out
 
 
-def cpu_baseline(data, N, sample, threads):
+def git_head():
+    """commit of the benched tree: git where there is a checkout, else the stamp __graft_entry__.build() leaves next to
+    the library (the GPU box receives a snapshot without .git)"""
+    try:
+        return subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], stderr=subprocess.DEVNULL).decode().strip()
+    except Exception:
+        try:
+            return open(os.path.join(ROOT, "acados_amd", "csrc", "BUILD_COMMIT")).read().strip()
+        except Exception:
+            return None
+
+
+def kernel_symbol(gb, cls):
+    """profile class -> kernel function of the family serving this batch (what rocprofv3 lists)"""
+    name = gb.kernel_name
+    fam = "kb" if name.startswith("1tpi-box") else "kx" if name.startswith("w16") else "kw" if name.startswith("wpi") else "k"
+    table = {"kb": {"back_fact": "kb_factor", "fwd_aff": "kb_forward", "back_rhs": "kb_backrhs", "fwd_corr": "kb_forward"},
+             "kx": {"back_fact": "kx_factor", "fwd_aff": "kx_fwd", "back_rhs": "kx_backrhs", "fwd_corr": "kx_fwd"},
+             "kw": {"back_fact": "kw_factor", "fwd_aff": "kw_fwd", "back_rhs": "kw_backrhs", "fwd_corr": "kw_fwd"},
+             "k": {"back_fact": "k_backward", "fwd_aff": "k_forward", "back_rhs": "k_backward", "fwd_corr": "k_forward"}}
+    return table[fam].get(cls, cls)
+
+
+def sweep_roofline(gb, steps, bytes_per_instance):
+    """roofline object of the dominant sweep of the solves profiled since the last prof_reset"""
+    B = gb.n_batch
+    prof = {c: (gb.scalar(f"prof_ms_{c}"), int(gb.scalar(f"prof_cnt_{c}"))) for c in CLASSES}
+    dom = max(SWEEPS, key=lambda c: prof[c][0])
+    dom_ms, dom_cnt = prof[dom]
+    iters = gb.info("iter")
+    # units one launch processes: launch j of the factor kernel sees the instances that have not converged before
+    # iteration j (iter >= j), the other sweeps those with iter > j; only root-level launches are timed (the last
+    # survivors of a one-instance-per-lane batch continue on a small sub-batch, DESIGN.md 4.1)
+    per_solve = max(dom_cnt // max(steps, 1), 1)
+    hist = np.bincount(iters, minlength=per_solve + 1)
+    still = B - np.cumsum(hist)                      # still[j] = instances with iter > j
+    units = [(B if j == 0 else int(still[j - 1])) if dom == "back_fact" else int(still[j]) for j in range(per_solve)]
+    avg_s = dom_ms * 1e-3 / max(dom_cnt, 1)
+    per_launch = float(np.mean(units)) * bytes_per_instance
+    achieved = per_launch / avg_s / 1e9 if avg_s > 0 else 0.0
+    return dom, prof, {"bound": "hbm", "kernel": f"{kernel_symbol(gb, dom)} ({dom}) of {gb.kernel_name}",
+                       "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                       "bytes_per_launch": per_launch, "units_per_launch": units, "avg_launch_ms": avg_s * 1e3,
+                       "launches_timed": dom_cnt, "kernel_ms_share": {c: prof[c][0] for c in CLASSES}}
+
+
+def pmc_traffic(dom, nx, nu, B, N):
+    """HBM bytes per launch of the dominant C2 kernel from the newest PMC summary under profiles/ (rocprofv3 cannot
+    run inside this process; tools/profile_round.sh regenerates the file for the commit it is run on)"""
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), key=lambda f: (os.path.getmtime(f), f))
+    if not files or (B, N, nx, nu) != (65536, 50, 8, 3):
+        return None
+    want = {"back_fact": f"kb_factor<{nx}, {nu}, false>", "back_rhs": f"kb_backrhs<{nx}, {nu}, false>",
+            "fwd_aff": f"kb_forward<{nx}, {nu}, false, false>", "fwd_corr": f"kb_forward<{nx}, {nu}, false, true>"}.get(dom)
+    try:
+        pmc = json.load(open(files[-1]))
+        e = pmc[want]
+        return {"file": os.path.relpath(files[-1], ROOT), "commit": pmc.get("_commit"),
+                "avg_main": e.get("hbm_bytes_per_launch_avg_main", e["hbm_bytes_per_launch_avg"]),
+                "full": e["hbm_bytes_per_launch_full"], "kernel": want}
+    except Exception:
+        return None
+
+
+def oracle_error(gb, qp_of, idx, N):
+    """max relative primal error of instances `idx` against the oracle (checker only, outside timing)"""
+    from oracle.oracle import OracleQp, default_opts
+    xs = [gb.get("x", k) for k in range(N + 1)]
+    us = [gb.get("u", k) for k in range(N)]
+    err, solved = 0.0, []
+    for i in idx:
+        qp = qp_of(int(i))
+        o = OracleQp(qp)
+        o.solve(default_opts(tol_stat=1e-8, tol_eq=1e-8, tol_ineq=1e-8, tol_comp=1e-8))
+        for k in range(N + 1):
+            r = o.get(k, "x")
+            if r.size:
+                err = max(err, float(np.max(np.abs(xs[k][i][:r.size] - r) / np.maximum(1.0, np.abs(r)))))
+            if k < N:
+                r = o.get(k, "u")
+                if r.size:
+                    err = max(err, float(np.max(np.abs(us[k][i][:r.size] - r) / np.maximum(1.0, np.abs(r)))))
+    return err
+
+
+def cpu_caps():
+    caps = {"logical": os.cpu_count() or 1, "affinity": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None}
+    try:
+        import psutil
+        caps["physical"] = psutil.cpu_count(logical=False)
+    except Exception:
+        caps["physical"] = None
+    try:
+        q = open("/sys/fs/cgroup/cpu.max").read().split()
+        caps["cgroup_quota_cpus"] = None if q[0] == "max" else float(q[0]) / float(q[1])
+    except Exception:
+        caps["cgroup_quota_cpus"] = None
+    return caps
+
+
+def cpu_baseline(data, N, unique, budget_s=25.0):
+    """the oracle on the host cores: `unique` instances of the same workload built once, cloned so that every thread of
+    every probe has >= 64 independent solves; thread counts swept in powers of two up to the cores the process may use"""
     from acados_amd.generators import lqr_instance_qp
-    from oracle.oracle import OracleQp, default_opts, solve_batch
-    qps = [OracleQp(lqr_instance_qp(data, i, N)) for i in range(sample)]
+    from oracle.oracle import OracleQp, clone_handle, default_opts, free_handle, solve_batch_handles
+    t_begin = time.perf_counter()
+    qps = [OracleQp(lqr_instance_qp(data, i, N)) for i in range(unique)]
     opts = default_opts(tol_stat=1e-8, tol_eq=1e-8, tol_ineq=1e-8, tol_comp=1e-8, iter_max=50)
-    best = 1e300
-    for _ in range(3):      # min over repeats, as mass_spring_example.c:336-363 does
-        t0 = time.perf_counter()
-        st = solve_batch(qps, opts, nthreads=threads)
-        best = min(best, time.perf_counter() - t0)
+    caps = cpu_caps()
+    allowed = caps["affinity"] or caps["logical"]
+    if caps["cgroup_quota_cpus"]:
+        allowed = max(1, min(allowed, int(round(caps["cgroup_quota_cpus"]))))
+    handles = [q.h.value for q in qps]
+    clones = []
+
+    def pool(n):
+        while len(handles) + len(clones) < n:
+            clones.append(clone_handle(qps[len(clones) % unique].h))
+        return (handles + [c.value for c in clones])[:n]
+
+    # one thread: 512 solves (~0.5 s)
+    def run(threads, n, reps):
+        hs = pool(n)
+        best = 1e300
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            st = solve_batch_handles(hs, opts, nthreads=threads)
+            best = min(best, time.perf_counter() - t0)
+        assert np.all(st == 0)
+        return n / best
+
+    one = run(1, min(512, max(unique, 64)), 2)
+    sweep = {1: one}
+    th = 2
+    while th <= allowed and time.perf_counter() - t_begin < budget_s:
+        n = max(64 * th, 1024)                       # >= 64 QPs per thread
+        sweep[th] = run(th, n, 2)
+        th *= 2
+    if allowed not in sweep and time.perf_counter() - t_begin < budget_s:
+        sweep[allowed] = run(allowed, max(64 * allowed, 1024), 2)
+    best_t = max(sweep, key=lambda k: sweep[k])
+    # every unique instance solved at least once (the probes above may have touched only the first ones): one pass over
+    # the whole sample with the best thread count -- its solutions are the parity sample
+    t0 = time.perf_counter()
+    st = solve_batch_handles(handles, opts, nthreads=best_t)
+    full_pass = unique / (time.perf_counter() - t0)
     assert np.all(st == 0)
     iters = float(np.mean([q.iter for q in qps]))
-    cpu_baseline.solved = qps     # the same solutions double as the >= 1,024-instance parity sample (SURVEY 8d)
-    return {"value": sample / best, "unit": "OCP-QP solves/s", "cores": threads, "kind": "port",
-            "sample": f"{sample} instances of the same workload (seed 0, first instances), min of 3 repeats, "
-                      f"OpenMP over instances as acados_solver.in.c:3232 does; restated CPU oracle, not HPIPM",
-            "mean_iter": iters}
+    for c in clones:
+        free_handle(c)
+    cpu_baseline.solved = qps     # the same solutions double as the parity sample (SURVEY 8d)
+    return {"value": sweep[best_t], "unit": "OCP-QP solves/s", "cores": best_t, "kind": "port",
+            "sample": f"{unique} instances of the same workload (seed 0, first instances) built once and cloned to >= 64 "
+                      f"independent solves per thread, min of 2 repeats per thread count, OpenMP over instances as "
+                      f"acados_solver.in.c:3232 does; restated CPU oracle, not HPIPM",
+            "one_thread": one, "full_sample_pass": full_pass, "thread_sweep": {str(k): v for k, v in sorted(sweep.items())},
+            "host": caps, "threads_allowed": allowed, "mean_iter": iters, "seconds": time.perf_counter() - t_begin}
+
+
+def tol_setup(gb):
+    for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+        gb.opts_set(f, 1e-8)
+    gb.opts_set("iter_max", 50)
+    gb.opts_set("warm_start", 0)
+
+
+def run_config(name, gb, qp_of, N, dims, steps=2, check=4, extra=None):
+    """one non-headline configuration: warm-up + `steps` timed solves, statistics, independent residual, oracle sample,
+    dominant sweep + roofline fraction"""
+    tol_setup(gb)
+    gb.solve()
+    gb.opts_set("profile", 1)
+    gb.scalar("prof_reset")
+    t0 = time.perf_counter()
+    bad = 0
+    for _ in range(steps):
+        bad += gb.solve()
+    dt = (time.perf_counter() - t0) / steps
+    gb.opts_set("profile", 0)
+    b_in, b_out = algorithmic_bytes_dims(dims)
+    dom, prof, roof = sweep_roofline(gb, steps, b_in + b_out)
+    it = gb.info("iter")
+    res = gb.res_compute()
+    out = {"workload": name, "batch": gb.n_batch, "solves_per_s": gb.n_batch / dt, "ms_per_step": dt * 1e3,
+           "kernel": gb.kernel_name, "mean_iter": float(it.mean()), "max_iter": int(it.max()),
+           "failures": int((gb.info("status") != 0).sum()), "max_kkt_residual_independent": float(res.max()),
+           "bytes_per_instance": b_in + b_out, "roofline": roof,
+           "condense_expand_ms": gb.scalar("time_xcond") * 1e3}
+    if check:
+        idx = np.linspace(0, gb.n_batch - 1, check).astype(int)
+        out["max_rel_primal_err_vs_oracle"] = oracle_error(gb, qp_of, idx, N)
+        out["oracle_checked_instances"] = int(check)
+    if extra:
+        out.update(extra)
+    return out
+
+
+def other_configs(c2_batch, c2_data, args):
+    """C3, C4 and the per-GPU share of C5 on this GPU (BASELINE.json configs[2..4])"""
+    from acados_amd import OcpQpGpuBatch
+    from acados_amd.generators import (C5_CLASSES, chain_soft_batch, chain_soft_dims, chain_soft_instance_qp,
+                                       fill_chain_soft_batch, fill_lqr_batch, lqr_dims, lqr_instance_qp, random_lqr_batch)
+    out = {}
+    N = 50
+    # C3: the C2 batch itself with partial condensing N2 = 10 (same data, resident)
+    c2_batch.opts_set("cond_N", 10)
+    out["C3"] = run_config("C2 data with partial condensing to N2=10 (BASELINE configs[2]), batch 65,536", c2_batch,
+                           lambda i: lqr_instance_qp(c2_data, i, N), N, lqr_dims(N, 8, 3), steps=2, check=args.check_configs)
+    out["C3"]["cond_N_active"] = int(c2_batch.scalar("cond_N_active"))
+    ck = c2_batch.condensed_kernel_name()
+    if ck:   # the IPM sweeps of a condensed solve run on the condensed batch's kernels
+        out["C3"]["kernel"] = f"kw_pcond + {ck} + kw_pexpand"
+        out["C3"]["roofline"]["kernel"] = out["C3"]["roofline"]["kernel"].replace(c2_batch.kernel_name, ck).replace("kb_", "kw_")
+    c2_batch.opts_set("cond_N", N)
+    # C4
+    N4, B4 = 40, args.c4_batch
+    d4 = chain_soft_batch(N=N4, batch=B4, seed=1)
+    g4 = OcpQpGpuBatch(chain_soft_dims(N4), B4)
+    fill_chain_soft_batch(g4, d4, N4)
+    out["C4"] = run_config(f"chain nx=24 nu=3, 4 soft state bounds + 4 soft general rows, ns=8, N=40 (BASELINE configs[3]), batch {B4}",
+                           g4, lambda i: chain_soft_instance_qp(d4, i, N4), N4, chain_soft_dims(N4), steps=2, check=args.check_configs)
+    del g4, d4
+    # C5: the per-GPU share of 524,288 instances on 8 GPUs, split equally over the 9 shape classes
+    per_class = (524288 // 8) // len(C5_CLASSES)
+    classes, tot_t, tot_n, bad, res_max, it_all = [], 0.0, 0, 0, 0.0, []
+    worst_frac = None
+    for ci, (nx, nu, Nc) in enumerate(C5_CLASSES):
+        dc = random_lqr_batch(N=Nc, nx=nx, nu=nu, batch=per_class, seed=200 + ci)
+        gc = OcpQpGpuBatch(lqr_dims(Nc, nx, nu), per_class)
+        fill_lqr_batch(gc, dc, Nc)
+        r = run_config(f"nx={nx} nu={nu} N={Nc}", gc, lambda i: lqr_instance_qp(dc, i, Nc), Nc, lqr_dims(Nc, nx, nu), steps=1,
+                       check=1 if args.check_configs else 0)
+        classes.append({k: r[k] for k in ("workload", "batch", "solves_per_s", "ms_per_step", "kernel", "mean_iter", "failures",
+                                          "max_kkt_residual_independent")} | {"frac": r["roofline"]["frac"], "dominant": r["roofline"]["kernel"]})
+        tot_t += r["ms_per_step"] * 1e-3
+        tot_n += per_class
+        bad += r["failures"]
+        res_max = max(res_max, r["max_kkt_residual_independent"])
+        if worst_frac is None or r["ms_per_step"] > worst_frac[0]:
+            worst_frac = (r["ms_per_step"], r["roofline"])
+        del gc, dc
+    out["C5_share"] = {"workload": f"mixed shape classes nx in {{4,12,24}} x N in {{20,50,100}}, {per_class} instances each = per-GPU share of "
+                                   f"524,288 on 8 GPUs (BASELINE configs[4]); classes solved one after the other",
+                       "batch": tot_n, "solves_per_s": tot_n / tot_t, "seconds": tot_t, "failures": bad,
+                       "max_kkt_residual_independent": res_max, "roofline_of_slowest_class": worst_frac[1], "classes": classes}
+    return out
 
 
 def main():
@@ -69,8 +316,11 @@ def main():
     ap.add_argument("--horizon", type=int, default=50)
     ap.add_argument("--nx", type=int, default=8)
     ap.add_argument("--nu", type=int, default=3)
-    ap.add_argument("--cpu-sample", type=int, default=4096)
+    ap.add_argument("--cpu-sample", type=int, default=2048, help="unique instances built for the CPU baseline / parity sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip C3 / C4 / C5 (the headline line only)")
+    ap.add_argument("--c4-batch", type=int, default=16384)
+    ap.add_argument("--check-configs", type=int, default=4, help="instances per configuration checked against the oracle")
     ap.add_argument("--compact-min", type=int, default=None, help="override the library default of the compaction threshold")
     ap.add_argument("--check", type=int, default=8, help="instances per rank checked against the oracle (outside timing)")
     args = ap.parse_args()
@@ -88,13 +338,13 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     from acados_amd import OcpQpGpuBatch
-    from acados_amd.generators import fill_lqr_batch, lqr_dims, random_lqr_batch
+    from acados_amd.generators import fill_lqr_batch, lqr_dims, lqr_instance_qp, random_lqr_batch
 
     N, nx, nu, B = args.horizon, args.nx, args.nu, args.batch
     # instance ids are global: rank r owns [r*B, (r+1)*B) of one counter-based stream
     data = random_lqr_batch(N=N, nx=nx, nu=nu, batch=B, seed=0, first=rank * B)
-
-    gb = OcpQpGpuBatch(lqr_dims(N, nx, nu), B, device=local_rank)
+    dims = lqr_dims(N, nx, nu)
+    gb = OcpQpGpuBatch(dims, B, device=local_rank)
 
     def to_dev(a):
         t = torch.from_numpy(a).to(dev)
@@ -104,10 +354,7 @@ def main():
     t0 = time.perf_counter()
     fill_lqr_batch(gb, data, N, xp=to_dev)
     t_pack = time.perf_counter() - t0
-    for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
-        gb.opts_set(f, 1e-8)
-    gb.opts_set("iter_max", 50)
-    gb.opts_set("warm_start", 0)
+    tol_setup(gb)
     if args.compact_min is not None:
         gb.opts_set("compact_min", args.compact_min)
 
@@ -129,47 +376,31 @@ def main():
     elapsed = time.perf_counter() - t0
     gb.opts_set("profile", 0)
 
-    from acados_amd.sharding import gather_instances, reduce_max
+    from acados_amd.sharding import gather_solutions, reduce_max
     elapsed = reduce_max(elapsed, dist, dev)      # MAX over ranks
 
     iters = gb.info("iter")
     status = gb.info("status")
     res_max = max(float(gb.info(n).max()) for n in ("res_stat", "res_eq", "res_ineq", "res_comp"))
+    res_indep = float(gb.res_compute().max())
 
-    # ---- gather of solutions + statistics over RCCL/xGMI, outside the timed region ----
-    gather_ms = None
+    # ---- gather of the full solution payload + statistics over RCCL/xGMI, outside the timed region ----
+    gather = gather_solutions(gb, dist, rank, world)       # device buffers, library collective (no host bounce)
     if dist is not None:
-        u0 = gb.get("u", 0)
-        stats = np.array([[float(iters.mean()), float(iters.max()), float((status != 0).sum()), res_max]])
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        u_all = gather_instances(u0, world * B, dist, dev)          # RCCL all_gather over xGMI
-        s_all = gather_instances(stats, world, dist, dev)
-        torch.cuda.synchronize()
-        gather_ms = (time.perf_counter() - t0) * 1e3
-        assert u_all.shape == (world * B, nu)
+        stats = torch.tensor([[float(iters.mean()), float(iters.max()), float((status != 0).sum()), res_max, res_indep]],
+                             dtype=torch.float64, device=dev)
+        s_all = [torch.empty_like(stats) for _ in range(world)]
+        dist.all_gather(s_all, stats)
+        s_all = torch.cat(s_all).cpu().numpy()
         mean_iter, max_iter = float(s_all[:, 0].mean()), int(s_all[:, 1].max())
-        failures, res_max = int(s_all[:, 2].sum()), float(s_all[:, 3].max())
+        failures, res_max, res_indep = int(s_all[:, 2].sum()), float(s_all[:, 3].max()), float(s_all[:, 4].max())
     else:
         mean_iter, max_iter, failures = float(iters.mean()), int(iters.max()), int((status != 0).sum())
 
     # ---- parity spot check against the oracle (checker only, outside timing) ----
     err = None
     if args.check > 0:
-        from acados_amd.generators import lqr_instance_qp
-        from oracle.oracle import OracleQp, default_opts
-        xs = [gb.get("x", k) for k in range(N + 1)]
-        us = [gb.get("u", k) for k in range(N)]
-        err = 0.0
-        for i in np.linspace(0, B - 1, args.check).astype(int):
-            o = OracleQp(lqr_instance_qp(data, int(i), N))
-            o.solve(default_opts(tol_stat=1e-8, tol_eq=1e-8, tol_ineq=1e-8, tol_comp=1e-8))
-            for k in range(N + 1):
-                r = o.get(k, "x")
-                err = max(err, float(np.max(np.abs(xs[k][i] - r) / np.maximum(1.0, np.abs(r)))))
-                if k < N:
-                    r = o.get(k, "u")
-                    err = max(err, float(np.max(np.abs(us[k][i] - r) / np.maximum(1.0, np.abs(r)))))
+        err = oracle_error(gb, lambda i: lqr_instance_qp(data, i, N), np.linspace(0, B - 1, args.check).astype(int), N)
 
     if rank != 0:
         if dist is not None:
@@ -177,35 +408,19 @@ def main():
         return
 
     # ---- roofline of the dominant kernel (HIP events recorded on the launch stream) ----
-    classes = ("back_fact", "fwd_aff", "back_rhs", "fwd_corr", "init", "finalize")
-    prof = {c: (gb.scalar(f"prof_ms_{c}"), int(gb.scalar(f"prof_cnt_{c}"))) for c in classes}
-    dom = max(prof, key=lambda c: prof[c][0])
-    dom_ms, dom_cnt = prof[dom]
-    b_in, b_out = algorithmic_bytes(N, nx, nu)
-    # units one launch processes: launch j of the factor kernel sees the instances that have not converged before
-    # iteration j (iter >= j), the other sweeps those with iter > j; only the launches of the full batch are timed
-    # (the last survivors continue on a small wave-per-instance sub-batch)
-    launches_per_solve = max(dom_cnt // max(args.steps, 1), 1)
-    hist = np.bincount(iters, minlength=launches_per_solve + 1)
-    still = B - np.cumsum(hist)                      # still[j] = instances with iter > j
-    units = [(B if j == 0 else int(still[j - 1])) if dom == "back_fact" else int(still[j]) for j in range(launches_per_solve)]
-    per_launch_bytes = float(np.mean(units)) * (b_in + b_out)
-    avg_s = dom_ms * 1e-3 / max(dom_cnt, 1)
-    achieved = per_launch_bytes / avg_s / 1e9
+    b_in, b_out = algorithmic_bytes_dims(dims)
+    dom, prof, roof = sweep_roofline(gb, args.steps, b_in + b_out)
     solves_per_s = world * B * args.steps / elapsed
-    # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 cannot run inside
-    # this process); corrected as MI355X_MICROARCH.md prescribes, see profiles/r01_v6_pmc_traffic.json
-    kern_sym = {"back_fact": "kb_factor", "fwd_aff": "kb_forward", "back_rhs": "kb_backrhs", "fwd_corr": "kb_forward"}[dom] \
-        if dom in ("back_fact", "fwd_aff", "back_rhs", "fwd_corr") else dom
-    traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_v6_pmc_traffic.json")))
-        want = {"back_fact": f"kb_factor<{nx}, {nu}, false>", "back_rhs": f"kb_backrhs<{nx}, {nu}, false>",
-                "fwd_aff": f"kb_forward<{nx}, {nu}, false, false>", "fwd_corr": f"kb_forward<{nx}, {nu}, false, true>"}.get(dom)
-        if want in pmc and B == 65536 and N == 50:
-            traffic = pmc[want]["hbm_bytes_per_launch_avg"]
-    except Exception:
-        traffic = None
+    tr = pmc_traffic(dom, nx, nu, B, N)
+    roof["traffic"] = tr["avg_main"] if tr else None
+    roof["traffic_source"] = tr
+    roof["traffic_over_algorithmic"] = (tr["avg_main"] / roof["bytes_per_launch"]) if tr else None
+    full_units = [u for u in roof["units_per_launch"] if u == B]
+    roof["full_launch"] = {"bytes": float(B * (b_in + b_out)), "traffic": tr["full"] if tr else None,
+                           "traffic_over_algorithmic": (tr["full"] / (B * (b_in + b_out))) if tr else None,
+                           "launches_per_solve_with_every_instance_active": len(full_units)}
+    roof["whole_solve_GBps"] = solves_per_s / world * (b_in + b_out) / 1e9
+    roof["whole_solve_frac"] = roof["whole_solve_GBps"] / HBM_PEAK_GBS
     out = {
         "metric": "OCP-QP solves/sec (batch) at N=50 nx=8 nu=3",
         "value": solves_per_s,
@@ -222,27 +437,23 @@ def main():
         "config": {"workload": f"random LQR OCP-QP (BASELINE configs[1]): N={N} nx={nx} nu={nu}, u-box + x0 equality, "
                                f"full-space Riccati IPM, cold start, tol 1e-8, iter_max 50",
                    "batch_per_gpu": B, "global_batch": world * B, "parallelism": f"instance-sharded x{world}",
-                   "kernel": gb.kernel_name},
+                   "kernel": gb.kernel_name, "commit": git_head()},
         "ipm": {"mean_iter": mean_iter, "max_iter": max_iter, "failures": failures, "max_kkt_residual": res_max,
+                "max_kkt_residual_independent": res_indep,
                 "max_rel_primal_err_vs_oracle": err, "oracle_checked_instances": args.check,
                 "launches_per_step": int(gb.scalar("launches"))},
-        "roofline": {"bound": "hbm", "kernel": f"{kern_sym} ({dom}) of {gb.kernel_name}",
-                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                     "traffic": traffic,
-                     "bytes_per_launch": per_launch_bytes, "units_per_launch": units, "avg_launch_ms": avg_s * 1e3,
-                     "launches_timed": dom_cnt,
-                     "kernel_ms_share": {c: prof[c][0] for c in classes},
-                     "whole_solve_GBps": solves_per_s / world * (b_in + b_out) / 1e9,
-                     "whole_solve_frac": solves_per_s / world * (b_in + b_out) / 1e9 / HBM_PEAK_GBS},
+        "roofline": roof,
         "pack_s": t_pack,
         "hbm_bytes_per_gpu": gb.bytes,
-        "gather_ms": gather_ms,
+        "gather_ms": gather["ms"] if gather else None,
+        "gather": gather,
     }
     if world == 1 and not args.no_cpu_baseline:
-        threads = os.cpu_count() or 1
-        out["cpu_baseline"] = cpu_baseline(data, N, min(args.cpu_sample, B), threads)
+        out["cpu_baseline"] = cpu_baseline(data, N, min(args.cpu_sample, B))
         if args.check > 0:
             # max relative primal error of the GPU solution against the oracle over the whole CPU sample
+            xs = [gb.get("x", k) for k in range(N + 1)]
+            us = [gb.get("u", k) for k in range(N)]
             err_s = 0.0
             for i, o in enumerate(cpu_baseline.solved):
                 for k in range(N + 1):
@@ -253,7 +464,18 @@ def main():
                         err_s = max(err_s, float(np.max(np.abs(us[k][i] - r) / np.maximum(1.0, np.abs(r)))))
             out["ipm"]["max_rel_primal_err_vs_oracle"] = max(err, err_s)
             out["ipm"]["oracle_checked_instances"] = args.check + len(cpu_baseline.solved)
-    print(json.dumps(out))
+        cpu_baseline.solved = None
+    if world == 1 and not args.no_configs:
+        out["configs"] = other_configs(gb, data, args)
+    # the JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio when its first communicator
+    # comes up -- push that out first
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -151,6 +151,22 @@ int ocp_qp_gpu_batch_get_stat(ocp_qp_gpu_batch *b, int inst, double *stat, int m
 /* scalars of the last solve: "time_tot" (s, HIP events around the whole solve),
  * "time_pack" (s, accumulated since the last solve), "iter_max_batch", "launches" */
 double ocp_qp_gpu_batch_get_scalar(ocp_qp_gpu_batch *b, const char *field);
+/* ---- multi-GPU: instances are independent, one process per GPU, no collective on the data path.  The only
+ * exchange is ONE all-gather of the results after the solve: RCCL over xGMI, device buffers, on the batch's stream.
+ *   _comm_unique_id   rank 0: fills 128 bytes (ncclUniqueId) that the host program hands to every rank
+ *   _comm_create      every rank (collective): communicator of n_ranks processes; `device` < 0 keeps the current device
+ *   _batch_gather     every rank (collective), same n_batch on every rank: gathers into DEVICE buffers
+ *                       sol_all  [n_ranks][n_batch][bulk_len(output)]  u x sl su pi lam t of every instance (the blob layout
+ *                                of ocp_qp_gpu_batch_get_bulk; 12,720 B per instance for the C2 shape)
+ *                       info_all [n_ranks][n_batch][2]  int32 (status, iter)
+ *                       time_all [n_ranks]              solve time of the last solve of each rank (s)
+ * RCCL is bound at run time (the copy already loaded by the process if any).  Returns 0, or -1 with a message. ---- */
+typedef struct ocp_qp_gpu_comm ocp_qp_gpu_comm;
+int ocp_qp_gpu_comm_unique_id(void *id128);
+ocp_qp_gpu_comm *ocp_qp_gpu_comm_create(const void *id128, int n_ranks, int rank, int device);
+void ocp_qp_gpu_comm_destroy(ocp_qp_gpu_comm *c);
+int ocp_qp_gpu_batch_gather(ocp_qp_gpu_batch *b, ocp_qp_gpu_comm *c, double *sol_all, int *info_all, double *time_all);
+
 /* bytes of HBM held by the batch */
 size_t ocp_qp_gpu_batch_bytes(const ocp_qp_gpu_batch *b);
 /* raw HIP stream handle (hipStream_t) the batch launches on, for event timing by the caller */

@@ -1000,6 +1000,35 @@ void oqp_refactor(oqp *qp, const oqp_opts *o)
     riccati_backward(qp, 1);
 }
 
+/* a second handle with the same data (bench.py cpu_baseline: enough independent solves per thread without building
+ * every instance through the Python setters) */
+oqp *oqp_clone(const oqp *src)
+{
+    int N = src->N;
+    int *nx = iz(N + 1), *nu = iz(N + 1), *nbx = iz(N + 1), *nbu = iz(N + 1), *ng = iz(N + 1), *ns = iz(N + 1);
+    for (int k = 0; k <= N; k++)
+    {
+        const stg *s = src->s + k;
+        nx[k] = s->nx; nu[k] = s->nu; nbx[k] = s->nbx; nbu[k] = s->nbu; ng[k] = s->ng; ns[k] = s->ns;
+    }
+    oqp *qp = oqp_create(N, nx, nu, nbx, nbu, ng, ns);
+    free(nx); free(nu); free(nbx); free(nbu); free(ng); free(ns);
+    for (int k = 0; k <= N; k++)
+    {
+        const stg *s = src->s + k;
+        stg *d = qp->s + k;
+        d->nbxe = s->nbxe;
+#define CP(f, cnt) memcpy(d->f, s->f, sizeof(*d->f) * (size_t) (cnt))
+        CP(A, s->nx1 * s->nx); CP(B, s->nx1 * s->nu); CP(b, s->nx1); CP(Q, s->nx * s->nx); CP(S, s->nu * s->nx);
+        CP(R, s->nu * s->nu); CP(q, s->nx); CP(r, s->nu); CP(idxb, s->nb); CP(lb, s->nb); CP(ub, s->nb);
+        CP(lb_mask, s->nb); CP(ub_mask, s->nb); CP(C, s->ng * s->nx); CP(D, s->ng * s->nu); CP(lg, s->ng); CP(ug, s->ng);
+        CP(lg_mask, s->ng); CP(ug_mask, s->ng); CP(Zl, s->ns); CP(Zu, s->ns); CP(zl, s->ns); CP(zu, s->ns);
+        CP(lls, s->ns); CP(lus, s->ns); CP(lls_mask, s->ns); CP(lus_mask, s->ns); CP(idxs_rev, s->nbg); CP(idxe, s->nb);
+#undef CP
+    }
+    return qp;
+}
+
 int oqp_solve_batch(oqp **qps, int n, const oqp_opts *opts, int *status, int nthreads)
 {
     int bad = 0;

@@ -65,6 +65,8 @@ enum { OQP_SUCCESS = 0, OQP_NAN_DETECTED = 1, OQP_MAXITER = 2, OQP_MINSTEP = 3, 
 oqp *oqp_create(int N, const int *nx, const int *nu, const int *nbx, const int *nbu,
                 const int *ng, const int *ns);
 void oqp_free(oqp *qp);
+/* a second, independent handle holding the same problem data */
+oqp *oqp_clone(const oqp *src);
 
 /* field keys are those of ocp_qp_in_set / d_ocp_qp_set as used by
  * acados_ocp_qp_solver.py:277-292: A B b Q S R q r idxb idxbx idxbu lbx ubx lbu ubu

@@ -34,6 +34,8 @@ def lib():
         L.oqp_create.restype = C.c_void_p
         L.oqp_create.argtypes = [C.c_int] + [C.POINTER(C.c_int)] * 6
         L.oqp_free.argtypes = [C.c_void_p]
+        L.oqp_clone.restype = C.c_void_p
+        L.oqp_clone.argtypes = [C.c_void_p]
         L.oqp_set.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_void_p]
         L.oqp_set_nbxe.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.oqp_solve.argtypes = [C.c_void_p, C.POINTER(OqpOpts)]
@@ -146,6 +148,24 @@ class OracleQp:
             lib().oqp_free(self.h)
         except Exception:
             pass
+
+
+def solve_batch_handles(handles, opts=None, nthreads=1):
+    """OpenMP batch solve over raw handles (OracleQp.h or clones of it)"""
+    n = len(handles)
+    hs = (C.c_void_p * n)(*handles)
+    st = (C.c_int * n)()
+    o = opts if opts is not None else default_opts()
+    lib().oqp_solve_batch(hs, n, C.byref(o), st, nthreads)
+    return np.array(st[:])
+
+
+def clone_handle(h):
+    return C.c_void_p(lib().oqp_clone(h))
+
+
+def free_handle(h):
+    lib().oqp_free(h)
 
 
 def solve_batch(oqps, opts=None, nthreads=1):

@@ -1,21 +1,31 @@
 #!/bin/bash
-# rocprofv3 kernel-trace summary of the headline bench (C2) and the rates of the other configurations; run on the
-# GPU box:   gpurun -- 'bash tools/profile_round.sh r01_v5 [full]'
-# writes gpurun_out/<tag>_*.txt (copy what should be kept into profiles/).  `full` also traces the configuration run.
+# Everything the bench line's roofline object refers to, for the commit it is run on; run on the GPU box:
+#     gpurun -- 'bash tools/profile_round.sh r02_v1 <commit> [full]'
+# writes gpurun_out/<tag>_*  (copy into profiles/; bench.py reads the newest profiles/*_pmc_traffic.json):
+#   <tag>_kernel_stats.txt     rocprofv3 --kernel-trace --stats summary of the headline bench (C2)
+#   <tag>_pmc_traffic.json     HBM bytes per launch of every sweep kernel: --pmc FETCH_SIZE / --pmc WRITE_SIZE, SEPARATE
+#                              counter-only passes (no trace domains), gfx950 correction of MI355X_MICROARCH.md
+#   <tag>_bench.json           the bench line of the same build (reads the traffic file just written if copied first)
+# `full` also traces the configuration legs (C3 / C4 / C5) of the bench.
 tag=${1:-rXX}
+commit=${2:-unknown}
 root=$(pwd)
 out=$root/gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/prof_c2 /tmp/prof_cfg
-rocprofv3 --kernel-trace --stats -d /tmp/prof_c2 -- python $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $out/${tag}_bench_under_rocprof.json 2> $out/${tag}_rocprof_c2.log
+rm -rf /tmp/prof_c2 /tmp/prof_cfg /tmp/pmc_f /tmp/pmc_w
+quick="--steps 1 --warmup 0 --no-cpu-baseline --no-configs --check 0"
+rocprofv3 --kernel-trace --stats -d /tmp/prof_c2 -- python $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-configs > $out/${tag}_bench_under_rocprof.json 2> $out/${tag}_rocprof_c2.log
 db=$(find /tmp/prof_c2 -name "*.db" | head -1)
 python $root/profiles/summarize.py kernel $db > $out/${tag}_kernel_stats.txt
-if [ "$2" = "full" ]; then
-    rocprofv3 --kernel-trace --stats -d /tmp/prof_cfg -- python $root/tools/config_rates.py 4096 > $out/${tag}_config_rates.txt 2> $out/${tag}_rocprof_cfg.log
+rocprofv3 --pmc FETCH_SIZE -d /tmp/pmc_f -- python $root/bench.py $quick > /dev/null 2> $out/${tag}_pmc_f.log
+rocprofv3 --pmc WRITE_SIZE -d /tmp/pmc_w -- python $root/bench.py $quick > /dev/null 2> $out/${tag}_pmc_w.log
+f=$(find /tmp/pmc_f -name "*.db" | head -1); w=$(find /tmp/pmc_w -name "*.db" | head -1)
+python $root/profiles/summarize.py traffic $f $w $commit > $out/${tag}_pmc_traffic.json
+cp $out/${tag}_pmc_traffic.json $root/profiles/${tag}_pmc_traffic.json   # the bench below reads the file of THIS build
+if [ "$3" = "full" ]; then
+    rocprofv3 --kernel-trace --stats -d /tmp/prof_cfg -- python $root/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $out/${tag}_bench_configs_under_rocprof.json 2> $out/${tag}_rocprof_cfg.log
     db=$(find /tmp/prof_cfg -name "*.db" | head -1)
     python $root/profiles/summarize.py kernel $db > $out/${tag}_config_kernel_stats.txt
-else
-    cd $root && python tools/config_rates.py 4096 > $out/${tag}_config_rates.txt 2>&1
 fi
-cd $root && python bench.py 2>/dev/null | tail -1 > $out/${tag}_bench.json
+cd $root && python bench.py 2> $out/${tag}_bench_err.log | tail -1 > $out/${tag}_bench.json
