@@ -108,7 +108,12 @@ def sweep_roofline(gb, steps, bytes_per_instance):
 def pmc_traffic(dom, nx, nu, B, N):
     """HBM bytes per launch of the dominant C2 kernel from the newest PMC summary under profiles/ (rocprofv3 cannot
     run inside this process; tools/profile_round.sh regenerates the file for the commit it is run on)"""
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")), key=lambda f: (os.path.getmtime(f), f))
+    import re
+
+    def tag(f):     # rNN_vM_pmc_traffic.json -> (NN, M): the newest generation by NAME (mtimes do not survive the snapshot)
+        m = re.match(r"r(\d+)_v(\d+)_pmc_traffic\.json$", os.path.basename(f))
+        return (int(m.group(1)), int(m.group(2))) if m else None
+    files = sorted((f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")) if tag(f)), key=tag)
     if not files or (B, N, nx, nu) != (65536, 50, 8, 3):
         return None
     want = {"back_fact": f"kb_factor<{nx}, {nu}, false>", "back_rhs": f"kb_backrhs<{nx}, {nu}, false>",
