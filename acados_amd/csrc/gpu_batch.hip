@@ -20,6 +20,7 @@
 #include "ipm_kernels_box.hpp"
 #include "ipm_kernels_wpi.hpp"
 #include "ipm_kernels_w16.hpp"
+#include "ipm_kernels_wpi_mfma.hpp"
 #include "res_kernels.hpp"
 #include "kernel_sets.h"
 
@@ -76,6 +77,7 @@ struct ocp_qp_gpu_batch
     int aos = 0;          /* instance-major arrays: wave-per-instance kernel family */
     int AW = 1;           /* activity words per stage (64 inequality sides each); 2 only for wave-per-instance batches */
     int wpi = 0;          /* wave-per-instance kernels (ipm_kernels_wpi.hpp): one workgroup per instance */
+    bool wpi_mfma = false; /* ... whose factor sweep is the blocked-Cholesky / MFMA kernel (17 <= n <= 32) */
     int w16 = 0;          /* ... whose four sweeps are the 16-lanes-per-instance kernels (ipm_kernels_w16.hpp): 4 instances per workgroup */
     size_t shmem = 0;     /* their dynamic LDS bytes (rhs sweep, init, finalize) */
     size_t shmem_fwd = 0; /* ... of the forward sweeps (one factor buffer instead of two) */
@@ -703,7 +705,19 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
                                                     gqp::kw_factor<4, true>, gqp::kw_factor<5, true>, gqp::kw_factor<6, true>,
                                                     gqp::kw_factor<7, true>, gqp::kw_factor<8, true>};
             const int t8 = (wx + wu + 7) / 8 - 1;
-            const kern_redo_t fact = ref ? gqp::kw_backward<true> : gen ? fact_gen[t8] : fact_box[t8];
+            /* 17 <= n <= 32: blocked Cholesky + the O(n^3) parts on the FP64 matrix pipe (ipm_kernels_wpi_mfma.hpp).
+             * Measured (tools/factor_variants.py, 4,096 instances): C4 class 3.97 vs 4.10 ms per factor launch, box class
+             * nx=24 nu=6 2.40 vs 2.07 ms, condensed C3 shape 0.35 vs 0.33 ms -- the FP64 matrix pipe is slower than the
+             * vector pipe on this chip (tools/mfma_f64_probe), so it serves the class it helps (general rows + slacks) by
+             * default; ACADOS_AMD_WPI_MFMA=1 / 0 forces it on / off for every shape in range */
+            const char *emf = getenv("ACADOS_AMD_WPI_MFMA");
+            const bool mfma = !ref && !w16 && wx + wu > 16 && wx + wu <= 32 && (emf ? atoi(emf) != 0 : gen);
+            static const kern_redo_t fact_mf[2][3] = {{gqp::kw_factor_m<false, 0>, gqp::kw_factor_m<false, 1>, gqp::kw_factor_m<false, 2>},
+                                                      {gqp::kw_factor_m<true, 0>, gqp::kw_factor_m<true, 1>, gqp::kw_factor_m<true, 2>}};
+            const char *epf = getenv("ACADOS_AMD_WPI_MFMA_PF");
+            const int pf = epf ? std::max(0, std::min(2, atoi(epf))) : 0; /* register prefetch did not pay (VGPR pressure) */
+            const kern_redo_t fact = ref ? gqp::kw_backward<true> : mfma ? fact_mf[gen ? 1 : 0][pf] : gen ? fact_gen[t8] : fact_box[t8];
+            b->wpi_mfma = mfma;
             const kern_redo_t rhs = ref ? gqp::kw_backward<false> : gen ? gqp::kw_backrhs<true> : gqp::kw_backrhs<false>;
             const kern_redo_t faff = ref ? gqp::kw_forward<false> : gen ? gqp::kw_fwd<false, true> : gqp::kw_fwd<false, false>;
             const kern_redo_t fcor = ref ? gqp::kw_forward<true> : gen ? gqp::kw_fwd<true, true> : gqp::kw_fwd<true, false>;
@@ -735,7 +749,7 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
             const size_t con = gqp::wpi_con_doubles(wx + wu, mg, ms);
             b->shmem = (ref ? gqp::wpi_lds_doubles(wx, wu) : gqp::wpi3_lds_doubles(wx, wu) + con) * sizeof(double);
             b->shmem_fwd = (ref ? gqp::wpi_lds_doubles(wx, wu) : gqp::wpi3_lds_doubles(wx, wu, 1) + con) * sizeof(double);
-            b->shmem_fact = (ref ? gqp::wpi_lds_doubles(wx, wu) : gqp::wpi2_lds_doubles(wx, wu) + con) * sizeof(double);
+            b->shmem_fact = (ref ? gqp::wpi_lds_doubles(wx, wu) : (mfma ? gqp::wpim_lds_doubles(wx, wu) : gqp::wpi2_lds_doubles(wx, wu)) + con) * sizeof(double);
         }
     }
     if (!b->ks)
@@ -747,8 +761,8 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
     char nm[128];
     if (b->w16) snprintf(nm, sizeof(nm), b->w16_soft ? "w16-soft<NX=%d,NU=%d>" : "w16-box<NX=%d,NU=%d>", b->ks->NX, b->ks->NU);
     else if (b->wpi && (b->ks->NG || b->ks->NS))
-        snprintf(nm, sizeof(nm), "wpi-gen(nx=%d,nu=%d,ng=%d,ns=%d,lds=%zuB)", b->ks->NX, b->ks->NU, b->ks->NG, b->ks->NS, b->shmem_fact);
-    else if (b->wpi) snprintf(nm, sizeof(nm), "wpi-box(nx=%d,nu=%d,lds=%zuB)", b->ks->NX, b->ks->NU, b->shmem);
+        snprintf(nm, sizeof(nm), "wpi-gen(nx=%d,nu=%d,ng=%d,ns=%d,lds=%zuB%s)", b->ks->NX, b->ks->NU, b->ks->NG, b->ks->NS, b->shmem_fact, b->wpi_mfma ? ",mfma" : "");
+    else if (b->wpi) snprintf(nm, sizeof(nm), "wpi-box(nx=%d,nu=%d,lds=%zuB%s)", b->ks->NX, b->ks->NU, b->wpi_mfma ? b->shmem_fact : b->shmem, b->wpi_mfma ? ",mfma" : "");
     else snprintf(nm, sizeof(nm), "1tpi<NX=%d,NU=%d,NG=%d,NS=%d>", b->ks->NX, b->ks->NU, b->ks->NG, b->ks->NS);
     b->kname = nm;
     opts_default(b->O);
@@ -2169,10 +2183,10 @@ const char *ocp_qp_gpu_batch_kernel_name(const ocp_qp_gpu_batch *b) { return b->
 /* development aid (make timing): per-phase cycle counters of the wave-per-instance factor kernel */
 extern "C" void gqp_wpi_cycles_read(unsigned long long *out, int reset)
 {
-    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(gqp::gqp_wpi_cycles), sizeof(unsigned long long) * 8));
+    HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(gqp::gqp_wpi_cycles), sizeof(unsigned long long) * 16));
     if (reset)
     {
-        unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        unsigned long long z[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(gqp::gqp_wpi_cycles), z, sizeof(z)));
     }
 }

@@ -758,7 +758,7 @@ __device__ static inline WpiRow wpi_row(const GqpDev &D, const GqpStage &S, cons
 
 #if defined(GQP_WPI_TIMING)
 /* development aid (not in the default build): cycles per phase of instance 0, lane 0 */
-static __device__ unsigned long long gqp_wpi_cycles[8];
+static __device__ unsigned long long gqp_wpi_cycles[16];
 #endif
 #if defined(GQP_WPI_TIMING) && defined(__HIP_DEVICE_COMPILE__)
 #define GQP_TICK(slot)                                                             \

@@ -273,3 +273,42 @@ def test_sensitivities_soft_and_general_rows_vs_dense(clib, request, monkeypatch
         worst = _check_sens(gb, qps, sdev, sdense, 2e-4, tol_own=2e-4, tol_mult_own=1e-3 if name in ("ug", "lg") else 1e-4,
                             tol_mult=1e-3 if name in ("ug", "lg") else 1e-4, tol_solve=1e-8)
         assert worst <= 2e-4, (name, worst)
+
+
+@pytest.mark.parametrize("clib", TIERS, indirect=True)
+@pytest.mark.parametrize("pf", ["0", "2"])
+def test_mfma_blocked_cholesky_factor_kernel(clib, monkeypatch, pf):
+    """kw_factor_m (ipm_kernels_wpi_mfma.hpp): W = [B A]' Lx+, M += W W' and the rank-4 trailing updates of a blocked
+    Cholesky on v_mfma_f64_16x16x4_f64, forced on for every shape in its range (17 <= nu + nx <= 32): box class
+    nx = 24 nu = 6 (two column tiles of the x-block), nx = 14 nu = 4 (one), the condensed C3 shape nx = 8 nu = 15, and the
+    C4 class with general rows + slacks -- against the oracle, and bit-for-bit status / iteration agreement with the
+    register-tile kernel it stands in for"""
+    from acados_amd import OcpQpGpuBatch
+    from acados_amd.generators import chain_soft_qp, lqr_instance_qp, random_lqr_batch
+    monkeypatch.setenv("ACADOS_AMD_WPI", "1")
+    monkeypatch.setenv("ACADOS_AMD_WPI_MFMA_PF", pf)
+    cases = []
+    for nx, nu, N in ((24, 6, 5), (14, 4, 6), (8, 15, 4), (17, 15, 3)):
+        data = random_lqr_batch(N=N, nx=nx, nu=nu, batch=3, seed=40 + nx)
+        cases.append([lqr_instance_qp(data, i, N) for i in range(3)])
+    cases.append([chain_soft_qp(i, N=5) for i in range(3)])
+    for qps in cases:
+        res = {}
+        for mf in ("1", "0"):
+            monkeypatch.setenv("ACADOS_AMD_WPI_MFMA", mf)
+            b = OcpQpGpuBatch.from_qps(qps, _clib=clib)
+            for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+                b.opts_set(f, 1e-8)
+            assert b.solve() == 0, b.kernel_name
+            assert ("mfma" in b.kernel_name) == (mf == "1"), b.kernel_name
+            assert b.res_compute().max() <= KKT_TOL
+            res[mf] = (b.info("iter").copy(), [b.get("x", k) for k in range(qps[0].N + 1)], b.get("ric_L", 1), b)
+        assert np.array_equal(res["1"][0], res["0"][0])
+        for xa, xb in zip(res["1"][1], res["0"][1]):
+            assert np.allclose(xa, xb, rtol=1e-9, atol=1e-10)
+        assert np.allclose(res["1"][2], res["0"][2], rtol=1e-5, atol=1e-8)      # the factor itself (Gamma ~ 1e10 on active rows: ~1e-6)
+        for i, qp in enumerate(qps):
+            o = OracleQp(qp)
+            assert o.solve(default_opts(tol_stat=1e-8)) == 0
+            for k in range(qp.N + 1):
+                assert np.allclose(res["1"][1][k][i], o.get(k, "x"), rtol=1e-7, atol=1e-8)
