@@ -586,11 +586,12 @@ static void copy_level(const GArrT<T> &big, const GArrT<T> &small, const int *d_
 
 extern "C" {
 
+/* force_ks: a compaction sub-batch runs the very kernel set of its parent; force_wpi: a tail / sensitivity sub-batch is
+ * pinned to the wave-per-instance family at the parent's padded dims.  Plain arguments: the library keeps no state
+ * outside the objects its caller owns (SURVEY 8b "Threading"). */
 static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu, const int *nbx, const int *nbu,
-                                            const int *ng, const int *ns, int n_batch, int device, int force_NX, int force_NU);
-/* per thread: the reference's batch idiom solves distinct capsules from OpenMP threads (acados_solver.in.c:3232-3236) */
-static thread_local const KernelSet *g_force_ks = nullptr; /* set only while a compaction sub-batch is being created */
-static thread_local bool g_force_wpi = false;              /* set only while a tail sub-batch is being created */
+                                            const int *ng, const int *ns, int n_batch, int device, int force_NX, int force_NU,
+                                            const KernelSet *g_force_ks = nullptr, bool g_force_wpi = false);
 
 ocp_qp_gpu_batch *ocp_qp_gpu_batch_create(int N, const int *nx, const int *nu, const int *nbx, const int *nbu,
                                           const int *ng, const int *ns, int n_batch, int device)
@@ -599,7 +600,8 @@ ocp_qp_gpu_batch *ocp_qp_gpu_batch_create(int N, const int *nx, const int *nu, c
 }
 
 static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu, const int *nbx, const int *nbu,
-                                            const int *ng, const int *ns, int n_batch, int device, int force_NX, int force_NU)
+                                            const int *ng, const int *ns, int n_batch, int device, int force_NX, int force_NU,
+                                            const KernelSet *g_force_ks, bool g_force_wpi)
 {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -1308,12 +1310,9 @@ static void compact_into(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch *root, int nact, 
         /* same kernel set (compaction) or the wave-per-instance family at the very same padded dims (tail) */
         const int cap = tail ? std::max(cnt, std::min(b->tail_max, b->list_cap)) : std::max(cnt, (b->Bp + 1) / 2);
         if (tail) b->tail_cap = cap;
-        g_force_ks = b->ks;
-        g_force_wpi = tail;
         ocp_qp_gpu_batch *c = batch_create_shape(b->N, b->nx.data(), b->nu.data(), b->nbx.data(), b->nbu.data(),
-                                                 b->ng.data(), b->ns.data(), cap, b->device, tail ? b->ks->NX : 0, tail ? b->ks->NU : 0);
-        g_force_ks = nullptr;
-        g_force_wpi = false;
+                                                 b->ng.data(), b->ns.data(), cap, b->device, tail ? b->ks->NX : 0, tail ? b->ks->NU : 0,
+                                                 b->ks, tail);
         if (!c) { fprintf(stderr, "acados_amd: cannot create the compaction sub-batch\n"); abort(); }
         c->idxb = b->idxb; c->idxs_rev = b->idxs_rev; c->idxe = b->idxe; c->nbxe = b->nbxe;
         c->compact_min = b->compact_min;
@@ -1542,12 +1541,8 @@ static void sens_solve_sliced(ocp_qp_gpu_batch *b)
     const int cap = b->sens_child ? b->sens_cap : std::min(b->B, env && atoi(env) > 0 ? atoi(env) : GQP_SENS_SLICE);
     if (!b->sens_child)
     {
-        g_force_ks = b->ks;
-        g_force_wpi = true;
         ocp_qp_gpu_batch *c = batch_create_shape(b->N, b->nx.data(), b->nu.data(), b->nbx.data(), b->nbu.data(), b->ng.data(),
-                                                 b->ns.data(), cap, b->device, b->ks->NX, b->ks->NU);
-        g_force_ks = nullptr;
-        g_force_wpi = false;
+                                                 b->ns.data(), cap, b->device, b->ks->NX, b->ks->NU, b->ks, true);
         if (!c) { fprintf(stderr, "acados_amd: cannot create the sensitivity sub-batch\n"); abort(); }
         c->idxb = b->idxb; c->idxs_rev = b->idxs_rev; c->idxe = b->idxe; c->nbxe = b->nbxe;
         c->tail_max = 0;
