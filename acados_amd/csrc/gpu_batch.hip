@@ -101,6 +101,7 @@ struct ocp_qp_gpu_batch
     int *d_map = nullptr;
     int map_cap = 0;
     int *h_nact = nullptr; /* pinned */
+    int *h_ints = nullptr; /* pinned, 2 * Bp ints: per-instance status / iteration read-backs of a solve (no heap traffic per call) */
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double time_tot = 0.0, time_pack = 0.0;
@@ -714,15 +715,36 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
              * default; ACADOS_AMD_WPI_MFMA=1 / 0 forces it on / off for every shape in range */
             const char *emf = getenv("ACADOS_AMD_WPI_MFMA");
             const bool mfma = !ref && !w16 && wx + wu > 16 && wx + wu <= 32 && (emf ? atoi(emf) != 0 : gen);
+            kern_redo_t fact_ct = nullptr, rhs_ct = nullptr, faff_ct = nullptr, fcor_ct = nullptr;
+            {
+                /* compile-time dims where they pay: the condensed C3 shape (nx=8 nu=15, box): factor sweep 0.328 -> 0.287 ms
+                 * per 4,096 launch.  Measured and NOT kept: nx=24 nu=3 general (4.09 -> 5.13 ms) and nx=24 nu=6 box (2.07 ->
+                 * 2.15 ms) -- full unrolling costs those shapes more in registers than the folded arithmetic saves
+                 * (tools/factor_variants.py).  ACADOS_AMD_WPI_CT=0 keeps the run-time-shaped instantiations */
+                const char *ect = getenv("ACADOS_AMD_WPI_CT");
+                if (!ref && !w16 && !(ect && atoi(ect) == 0))
+                {
+#define GQP_CT(GENV, X, U, T)                                                                                     \
+    if (gen == GENV && wx == X && wu == U)                                                                        \
+    {                                                                                                             \
+        fact_ct = gqp::kw_factor<T, GENV, X, U>; rhs_ct = gqp::kw_backrhs<GENV, X, U>;                               \
+        faff_ct = gqp::kw_fwd<false, GENV, X, U>; fcor_ct = gqp::kw_fwd<true, GENV, X, U>;                             \
+    }
+                    GQP_CT(false, 8, 15, 3)
+#undef GQP_CT
+                }
+            }
             static const kern_redo_t fact_mf[2][3] = {{gqp::kw_factor_m<false, 0>, gqp::kw_factor_m<false, 1>, gqp::kw_factor_m<false, 2>},
                                                       {gqp::kw_factor_m<true, 0>, gqp::kw_factor_m<true, 1>, gqp::kw_factor_m<true, 2>}};
             const char *epf = getenv("ACADOS_AMD_WPI_MFMA_PF");
             const int pf = epf ? std::max(0, std::min(2, atoi(epf))) : 0; /* register prefetch did not pay (VGPR pressure) */
-            const kern_redo_t fact = ref ? gqp::kw_backward<true> : mfma ? fact_mf[gen ? 1 : 0][pf] : gen ? fact_gen[t8] : fact_box[t8];
+            const kern_redo_t fact = ref ? gqp::kw_backward<true> : mfma ? fact_mf[gen ? 1 : 0][pf] : fact_ct ? fact_ct : gen ? fact_gen[t8] : fact_box[t8];
             b->wpi_mfma = mfma;
-            const kern_redo_t rhs = ref ? gqp::kw_backward<false> : gen ? gqp::kw_backrhs<true> : gqp::kw_backrhs<false>;
-            const kern_redo_t faff = ref ? gqp::kw_forward<false> : gen ? gqp::kw_fwd<false, true> : gqp::kw_fwd<false, false>;
-            const kern_redo_t fcor = ref ? gqp::kw_forward<true> : gen ? gqp::kw_fwd<true, true> : gqp::kw_fwd<true, false>;
+            kern_redo_t rhs = ref ? gqp::kw_backward<false> : gen ? gqp::kw_backrhs<true> : gqp::kw_backrhs<false>;
+            kern_redo_t faff = ref ? gqp::kw_forward<false> : gen ? gqp::kw_fwd<false, true> : gqp::kw_fwd<false, false>;
+            kern_redo_t fcor = ref ? gqp::kw_forward<true> : gen ? gqp::kw_fwd<true, true> : gqp::kw_fwd<true, false>;
+            if (rhs_ct) { rhs = rhs_ct; faff = faff_ct; fcor = fcor_ct; }
+
             const kern_opts_t init = gen ? gqp::kw_init<true> : gqp::kw_init<false>;
             const kern_plain_t fin = gen ? gqp::kw_finalize<true> : gqp::kw_finalize<false>;
             b->own_ks = KernelSet{wx, wu, mg, ms, init, fact, rhs, faff, fcor, fin,
@@ -772,6 +794,7 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
     HIPCHK(hipEventCreate(&b->ev0));
     HIPCHK(hipEventCreate(&b->ev1));
     HIPCHK(hipHostMalloc((void **) &b->h_nact, sizeof(int)));
+    HIPCHK(hipHostMalloc((void **) &b->h_ints, sizeof(int) * 2 * (size_t) b->Bp));
     return b;
 }
 
@@ -782,6 +805,7 @@ void ocp_qp_gpu_batch_destroy(ocp_qp_gpu_batch *b)
     (void) hipStreamSynchronize(b->stream);
     for (void *p : b->allocs) (void) hipFree(p);
     (void) hipHostFree(b->h_nact);
+    (void) hipHostFree(b->h_ints);
     (void) hipEventDestroy(b->ev0);
     (void) hipEventDestroy(b->ev1);
     for (hipEvent_t e : b->prof_ev) (void) hipEventDestroy(e);
@@ -1286,11 +1310,10 @@ static void run_ipm(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch *root, Prof &prof, hip
 static void compact_into(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch *root, int nact, hipStream_t s, bool tail)
 {
     /* sorted list of the still-iterating instances (sorted => the gather reads stay coalesced) */
-    std::vector<int> st(b->B), list;
-    HIPCHK(hipMemcpy(st.data(), b->D.status, sizeof(int) * b->B, hipMemcpyDeviceToHost));
-    list.reserve(nact);
-    for (int i = 0; i < b->B; i++) if (st[i] == GQP_RUNNING) list.push_back(i);
-    const int cnt = (int) list.size();
+    int *st = b->h_ints, *list = b->h_ints + b->Bp; /* pinned, owned by the level */
+    HIPCHK(hipMemcpy(st, b->D.status, sizeof(int) * b->B, hipMemcpyDeviceToHost));
+    int cnt = 0;
+    for (int i = 0; i < b->B; i++) if (st[i] == GQP_RUNNING) list[cnt++] = i;
     /* capacities follow the level's CAPACITY (Bp), not its current count: a level is re-used by later solves with
      * more survivors (its B changes between solves) */
     if (!b->d_list || cnt > b->list_cap)
@@ -1322,7 +1345,7 @@ static void compact_into(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch *root, int nact, 
         slot = c;
     }
     ocp_qp_gpu_batch *c = slot;
-    HIPCHK(hipMemcpyAsync(b->d_list, list.data(), sizeof(int) * cnt, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(b->d_list, list, sizeof(int) * cnt, hipMemcpyHostToDevice, s));
     c->B = cnt; /* the level works on `cnt` slots of its capacity */
     c->D.B = cnt;
     const dim3 block(64);
@@ -1407,10 +1430,10 @@ int ocp_qp_gpu_batch_solve(ocp_qp_gpu_batch *b)
     HIPCHK(hipEventElapsedTime(&ms, b->ev0, b->ev1));
     b->time_tot = ms * 1e-3;
     {
-        std::vector<int> itv(b->B);
-        HIPCHK(hipMemcpy(itv.data(), D.iter, sizeof(int) * b->B, hipMemcpyDeviceToHost));
+        int *itv = b->h_ints;
+        HIPCHK(hipMemcpy(itv, D.iter, sizeof(int) * b->B, hipMemcpyDeviceToHost));
         int mx = 0;
-        for (int v : itv) mx = std::max(mx, v);
+        for (int q = 0; q < b->B; q++) mx = std::max(mx, itv[q]);
         b->last_iters = mx;
     }
     for (size_t q = 0; q < b->prof_cls.size(); q++)
@@ -1421,8 +1444,8 @@ int ocp_qp_gpu_batch_solve(ocp_qp_gpu_batch *b)
         b->prof_cnt[b->prof_cls[q]]++;
     }
 
-    std::vector<int> st(b->B);
-    HIPCHK(hipMemcpy(st.data(), D.status, sizeof(int) * b->B, hipMemcpyDeviceToHost));
+    int *st = b->h_ints + b->Bp;
+    HIPCHK(hipMemcpy(st, D.status, sizeof(int) * b->B, hipMemcpyDeviceToHost));
     int bad = 0;
     for (int i = 0; i < b->B; i++) bad += st[i] != 0;
     return bad;

@@ -806,12 +806,14 @@ __device__ static inline WpiLds2 wpi2_carve(double *sm, int NX, int NU)
     return L;
 }
 
-template <int T8, bool GEN>
+/* CNX, CNU != 0: the state / input dimensions as COMPILE-TIME constants (the BASELINE shapes): trip counts, row strides
+ * and the packed-triangle arithmetic fold; 0 = run-time dims, any shape */
+template <int T8, bool GEN, int CNX = 0, int CNU = 0>
 /* T8 <= 4: keep two waves per SIMD (<= 256 VGPRs; the GEN variant sits right at the line) */
 __global__ void __launch_bounds__(64) GQP_WAVES_PER_EU(T8 <= 4 ? 2 : 1) kw_factor(GqpDev D, GqpOpts O, int redo)
 {
     GQP_DYN_SHARED(smem);
-    const int NX = D.NX, NU = D.NU, n = NX + NU, NP = n * (n + 1) / 2;
+    const int NX = CNX ? CNX : D.NX, NU = CNX ? CNU : D.NU, n = NX + NU, NP = n * (n + 1) / 2;
     const int inst = blockIdx.x, lane = threadIdx.x;
     if (inst >= D.B) return;
     if (D.status[inst] != GQP_RUNNING) return;
@@ -1371,11 +1373,11 @@ __device__ static inline void wpi_load_B(double *__restrict__ dst, int SXb, cons
     }
 }
 
-template <bool GEN>
+template <bool GEN, int CNX = 0, int CNU = 0>
 __global__ void __launch_bounds__(64) kw_backrhs(GqpDev D, GqpOpts O, int redo)
 {
     GQP_DYN_SHARED(smem);
-    const int NX = D.NX, NU = D.NU, n = NX + NU, NP = n * (n + 1) / 2;
+    const int NX = CNX ? CNX : D.NX, NU = CNX ? CNU : D.NU, n = NX + NU, NP = n * (n + 1) / 2;
     const int inst = blockIdx.x, lane = threadIdx.x;
     if (inst >= D.B) return;
     if (D.status[inst] != GQP_RUNNING) return;
@@ -1548,12 +1550,12 @@ __global__ void __launch_bounds__(64) kw_backrhs(GqpDev D, GqpOpts O, int redo)
 }
 
 /* forward sweep; PFORM (= CORR): lf holds [l_u; p], otherwise the plain l of the factor sweep */
-template <bool CORR, bool GEN>
+template <bool CORR, bool GEN, int CNX = 0, int CNU = 0>
 __global__ void __launch_bounds__(64) kw_fwd(GqpDev D, GqpOpts O, int redo)
 {
     GQP_DYN_SHARED(smem);
     constexpr bool PFORM = CORR;
-    const int NX = D.NX, NU = D.NU, n = NX + NU, NP = n * (n + 1) / 2;
+    const int NX = CNX ? CNX : D.NX, NU = CNX ? CNU : D.NU, n = NX + NU, NP = n * (n + 1) / 2;
     const int inst = blockIdx.x, lane = threadIdx.x;
     if (inst >= D.B) return;
     if (D.status[inst] != GQP_RUNNING) return;

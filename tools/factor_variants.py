@@ -40,9 +40,9 @@ def lqr(nx, nu, N, cond=0):
     return make
 
 
-for mf, pf in (("0", "0"), ("1", "0"), ("1", "1"), ("1", "2")):
-    os.environ["ACADOS_AMD_WPI_MFMA"], os.environ["ACADOS_AMD_WPI_MFMA_PF"] = mf, pf
-    tag = f"MFMA={mf} PF={pf}"
+for mf, pf, ct in (("0", "0", "0"), ("0", "0", "1"), ("1", "0", "1"), ("1", "1", "1"), ("1", "2", "1")):
+    os.environ["ACADOS_AMD_WPI_MFMA"], os.environ["ACADOS_AMD_WPI_MFMA_PF"], os.environ["ACADOS_AMD_WPI_CT"] = mf, pf, ct
+    tag = f"MFMA={mf} PF={pf} CT={ct}"
     run(tag + " C4", c4)
     run(tag + " nx=24 nu=6 N=50", lqr(24, 6, 50))
     run(tag + " C3 (C2, cond_N=10)", lqr(8, 3, 50, 10))
