@@ -20,6 +20,7 @@
 #include "ipm_kernels_box.hpp"
 #include "ipm_kernels_wpi.hpp"
 #include "ipm_kernels_w16.hpp"
+#include "ipm_kernels_w16r.hpp"
 #include "ipm_kernels_wpi_mfma.hpp"
 #include "res_kernels.hpp"
 #include "kernel_sets.h"
@@ -62,7 +63,12 @@ struct W16Set
     {NX, NU, gqp::kx_factor<NX, NU>, gqp::kx_backrhs<NX, NU>, gqp::kx_fwd<NX, NU, false>, gqp::kx_fwd<NX, NU, true>, \
      gqp::kx_factor<NX, NU, true>, gqp::kx_backrhs<NX, NU, true>, gqp::kx_fwd<NX, NU, false, true>,            \
      gqp::kx_fwd<NX, NU, true, true>, 4 * gqp::W16Lds<NX, NU>::SZ * sizeof(double)}
-const W16Set g_w16_sets[] = {GQP_W16(4, 1), GQP_W16(8, 3), GQP_W16(12, 3), GQP_W16(4, 4), GQP_W16(12, 4)};
+/* ... and with 17 <= nu + nx <= 32 (ipm_kernels_w16r.hpp: two rows per lane; box rows without slacks) */
+#define GQP_W16R(NX, NU)                                                                                      \
+    {NX, NU, gqp::ky_factor<NX, NU>, gqp::ky_backrhs<NX, NU>, gqp::ky_fwd<NX, NU, false>, gqp::ky_fwd<NX, NU, true>, \
+     nullptr, nullptr, nullptr, nullptr, 4 * gqp::W16RLds<NX, NU>::SZ * sizeof(double)}
+const W16Set g_w16_sets[] = {GQP_W16(4, 1), GQP_W16(8, 3), GQP_W16(12, 3), GQP_W16(4, 4), GQP_W16(12, 4),
+                             GQP_W16R(8, 15), GQP_W16R(24, 6)};
 
 } // namespace
 
@@ -678,11 +684,13 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
         const bool soft_dims = mg == 0 && ms > 0; /* slacks on box rows only: the SOFT variants, if the structure allows */
         const W16Set *w16 = nullptr;
         {
-            const char *e16 = getenv("ACADOS_AMD_W16");
+            const char *e16 = getenv("ACADOS_AMD_W16"), *e16r = getenv("ACADOS_AMD_W16R");
             if ((!gen || soft_dims) && !need_wpi && !ref && !(e16 && atoi(e16) == 0))
                 for (const W16Set &ws : g_w16_sets)
                 {
-                    const bool fits = force_NX ? (ws.NX == wx && ws.NU == wu) : (ws.NX >= wx && ws.NU >= wu);
+                    bool fits = force_NX ? (ws.NX == wx && ws.NU == wu) : (ws.NX >= wx && ws.NU >= wu);
+                    if (soft_dims && !ws.sfact) fits = false; /* the two-rows-per-lane sets carry no slacks */
+                    if (ws.NX + ws.NU > 16 && (e16r && atoi(e16r) == 0)) fits = false;
                     if (fits && (!w16 || ws.NX + ws.NU < w16->NX + w16->NU)) w16 = &ws;
                 }
         }
@@ -783,7 +791,7 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
         return nullptr;
     }
     char nm[128];
-    if (b->w16) snprintf(nm, sizeof(nm), b->w16_soft ? "w16-soft<NX=%d,NU=%d>" : "w16-box<NX=%d,NU=%d>", b->ks->NX, b->ks->NU);
+    if (b->w16) snprintf(nm, sizeof(nm), b->w16_soft ? "w16-soft<NX=%d,NU=%d>" : b->ks->NX + b->ks->NU > 16 ? "w16r-box<NX=%d,NU=%d>" : "w16-box<NX=%d,NU=%d>", b->ks->NX, b->ks->NU);
     else if (b->wpi && (b->ks->NG || b->ks->NS))
         snprintf(nm, sizeof(nm), "wpi-gen(nx=%d,nu=%d,ng=%d,ns=%d,lds=%zuB%s)", b->ks->NX, b->ks->NU, b->ks->NG, b->ks->NS, b->shmem_fact, b->wpi_mfma ? ",mfma" : "");
     else if (b->wpi) snprintf(nm, sizeof(nm), "wpi-box(nx=%d,nu=%d,lds=%zuB%s)", b->ks->NX, b->ks->NU, b->wpi_mfma ? b->shmem_fact : b->shmem, b->wpi_mfma ? ",mfma" : "");

@@ -268,8 +268,8 @@ def test_c5_shape_classes_and_multiphase_hostsim(hostsim_lib, monkeypatch, fam):
     """C5: shape classes nx in {4,12,24} (nu = ceil(nx/4)) and the multi-phase class whose state
     dimension switches 12 -> 4 mid-horizon (per-stage dims inside one padded kernel shape).
     All three kernel families: one instance per lane (ACADOS_AMD_WPI=0), one wave per instance
-    (ACADOS_AMD_WPI=1 ACADOS_AMD_W16=0) and sixteen lanes per instance (ACADOS_AMD_WPI=1; exists for
-    nu+nx <= 16, nx=24 nu=6 stays one wave per instance)."""
+    (ACADOS_AMD_WPI=1 ACADOS_AMD_W16=0) and sixteen lanes per instance (ACADOS_AMD_WPI=1; one row per lane for
+    nu+nx <= 16, two rows per lane for nx=24 nu=6)."""
     from acados_amd.generators import lqr_instance_qp, multiphase_qp, random_lqr_batch
     monkeypatch.setenv("ACADOS_AMD_WPI", "0" if fam == "1tpi" else "1")
     monkeypatch.setenv("ACADOS_AMD_W16", "1" if fam == "w16" else "0")
@@ -277,7 +277,7 @@ def test_c5_shape_classes_and_multiphase_hostsim(hostsim_lib, monkeypatch, fam):
         data = random_lqr_batch(N=5, nx=nx, nu=nu, batch=2 if fam != "w16" else 5, seed=7)
         nb = 2 if fam != "w16" else 5   # 5 instances: a full 4-instance workgroup and a ragged one
         b = _check_batch_vs_oracle([lqr_instance_qp(data, i, 5) for i in range(nb)], hostsim_lib)
-        want = {"1tpi": "1tpi-box<", "wpi": "wpi-box(", "w16": "w16-box<" if nx + nu <= 16 else "wpi-box("}[fam]
+        want = {"1tpi": "1tpi-box<", "wpi": "wpi-box(", "w16": "w16-box<" if nx + nu <= 16 else "w16r-box<"}[fam]
         assert b.kernel_name.startswith(want)
     b = _check_batch_vs_oracle([multiphase_qp(i, N=8) for i in range(3)], hostsim_lib)
     assert b.kernel_name.startswith({"1tpi": "1tpi-box<NX=12,NU=3", "wpi": "wpi-box(nx=12,nu=3", "w16": "w16-box<NX=12,NU=3>"}[fam])
@@ -873,6 +873,36 @@ def test_sixteen_lanes_covering_shapes_hostsim(hostsim_lib, monkeypatch):
         data = random_lqr_batch(N=5, nx=nx, nu=nu, batch=6, seed=20 + nx)
         b = _check_batch_vs_oracle([lqr_instance_qp(data, i, 5) for i in range(6)], hostsim_lib)
         assert b.kernel_name == want, b.kernel_name
+
+
+def test_sixteen_lanes_two_rows_per_lane_hostsim(hostsim_lib, monkeypatch):
+    """17 <= nu+nx <= 32, box rows only: sixteen lanes per instance with TWO rows per lane (ipm_kernels_w16r.hpp).
+    The compiled shapes <24,6> and <8,15>, shapes padded inside them, state bounds on every stage, fixed initial
+    state, a ragged batch (one full workgroup of four instances + one), and agreement with the wave-per-instance
+    kernels on the same batch (ACADOS_AMD_W16R=0) to rounding"""
+    from acados_amd import OcpQpGpuBatch
+    from acados_amd.generators import lqr_instance_qp, random_lqr_batch
+    for (nx, nu), want in (((24, 6), "w16r-box<NX=24,NU=6>"), ((8, 15), "w16r-box<NX=8,NU=15>"), ((20, 5), "w16r-box<NX=24,NU=6>"),
+                           ((6, 12), "w16r-box<NX=8,NU=15>"), ((13, 4), "w16r-box<NX=24,NU=6>")):
+        data = random_lqr_batch(N=4, nx=nx, nu=nu, batch=5, seed=40 + nx)
+        b = _check_batch_vs_oracle([lqr_instance_qp(data, i, 4) for i in range(5)], hostsim_lib)
+        assert b.kernel_name == want, b.kernel_name
+    # the same batch on both families: iterates agree to rounding, iteration counts are equal
+    data = random_lqr_batch(N=6, nx=24, nu=6, batch=3, seed=3)
+    qps = [lqr_instance_qp(data, i, 6) for i in range(3)]
+    sols = {}
+    for fam in ("1", "0"):
+        monkeypatch.setenv("ACADOS_AMD_W16R", fam)
+        g = OcpQpGpuBatch.from_qps(qps, _clib=hostsim_lib)
+        for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+            g.opts_set(f, 1e-8)
+        assert g.solve() == 0
+        assert g.kernel_name.startswith("w16r-box<" if fam == "1" else "wpi-box(")
+        sols[fam] = ([g.get(f, k) for f in ("x", "u", "lam") for k in range(7)] + [g.get("pi", k) for k in range(6)],
+                     np.array(g.info("iter")))
+    for x, y in zip(sols["1"][0], sols["0"][0]):
+        np.testing.assert_allclose(x, y, rtol=1e-9, atol=1e-9)
+    assert np.array_equal(sols["1"][1], sols["0"][1])
 
 
 def test_solution_sensitivities_after_partial_condensing_hostsim(hostsim_lib, monkeypatch):

@@ -287,6 +287,7 @@ def test_mfma_blocked_cholesky_factor_kernel(clib, monkeypatch, pf):
     from acados_amd import OcpQpGpuBatch
     from acados_amd.generators import chain_soft_qp, lqr_instance_qp, random_lqr_batch
     monkeypatch.setenv("ACADOS_AMD_WPI", "1")
+    monkeypatch.setenv("ACADOS_AMD_W16R", "0")   # the box shapes of this range default to the two-rows-per-lane family
     monkeypatch.setenv("ACADOS_AMD_WPI_MFMA_PF", pf)
     cases = []
     for nx, nu, N in ((24, 6, 5), (14, 4, 6), (8, 15, 4), (17, 15, 3)):
