@@ -29,33 +29,94 @@ namespace gqp
 {
 
 /* per-instance LDS tile (doubles).
- * Factor sweep: exchange buffer (host simulation), pi+ vector, the x-block of the previous factor in CHUNKED rows (row q
- * holds columns 0 .. w(q/8) - 1, w(j) = min(8 (j + 1), NX): the rolled W loop reads a row up to its chunk bound, zero
- * above the diagonal), and a staging region that first carries the packed H block of the stage and then its [B A]'
- * block (leading dimension NX + 1).
+ * Factor sweep: exchange buffer (host simulation) + two regions filled by LDS-DMA one stage ahead: HR, the packed H block
+ * of the stage as it lies in memory, and BR, its [B A]' block as it lies in memory (BR also carries the transposition tile
+ * of the previous factor's x-block once the stage is done with [B A]').
  * rhs-only sweep: exchange buffer + the square x-block tile; forward sweep: exchange buffer + the full factor tile. */
 template <int NX, int NU>
 struct W16RLds
 {
-    static constexpr int n = NX + NU, R = (n + 15) / 16, LDX = NX + 1, LDF = n + 1, LDB = NX + 1, NP = n * (n + 1) / 2;
+    static constexpr int n = NX + NU, R = (n + 15) / 16, LDX = NX + 1, LDF = n + 1, NP = n * (n + 1) / 2, NB = n * NX;
     static constexpr int XB = 0, TA = 16, TF = 16;
     static constexpr int SZ_A = 16 + NX * LDX, SZ_F = 16 + n * LDF;
-    /* chunked x-block tile */
-    static constexpr int NCH = (NX + 7) / 8;
-    static constexpr int cw(int j) { return 8 * (j + 1) < NX ? 8 * (j + 1) : NX; }
-    static constexpr int crow(int q) { return 32 * (q >> 3) * ((q >> 3) + 1) + (q & 7) * cw(q >> 3); }
-    static constexpr int TAC_SZ = 32 * (NCH - 1) * NCH + (NX - 8 * (NCH - 1)) * NX; /* rows of the last chunk are NX wide */
-    static constexpr int PV = 16, TAC = PV + 32, STG = TAC + TAC_SZ;
-    static constexpr int STG_SZ = NP > n * LDB ? NP : n * LDB;
-    static constexpr int SZ_K = STG + STG_SZ;
+    static constexpr int HR = 16, HSZ = (NP + 1) & ~1, BR = HR + HSZ, BSZ = (NB + 1) & ~1;
+    static constexpr int SZ_K = BR + BSZ;
     static constexpr int SZ0 = SZ_A > SZ_F ? SZ_A : SZ_F;
-    static constexpr int SZ = SZ0 > SZ_K ? SZ0 : SZ_K;
+    static constexpr int SZ = ((SZ0 > SZ_K ? SZ0 : SZ_K) + 1) & ~1; /* even: every instance's tile starts on 16 bytes */
 };
+
+/* LDS-DMA (global_load_lds_dwordx4): the 64 lanes copy 16 bytes each from sbase + lane * 16 + IMM (global, wave-uniform
+ * base) to ldsp + lane * 16 + IMM (LDS, wave-uniform base) without touching a VGPR.  Inline asm: the destination base
+ * travels in M0, which the compiler reserves -- saved and restored inside the statement; the compiler neither counts
+ * these requests nor orders LDS reads behind them, the kernel waits by hand (W16R_DMA_WAIT) and drains its own LDS reads
+ * of a region before overwriting it (W16R_LDS_DRAIN).  tools/lds_dma_probe checks the addressing on the GPU. */
+#if defined(__HIP_DEVICE_COMPILE__)
+template <int IMM>
+__device__ static inline void w16r_dma16(const double *sbase, const double *ldsp)
+{
+    const unsigned voff = threadIdx.x * 16u;
+    const unsigned lds = (unsigned) (uintptr_t) (__attribute__((address_space(3))) const double *) ldsp;
+    unsigned keep;
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%4\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds), "n"(IMM) : "memory");
+}
+#define W16R_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define W16R_LDS_DRAIN() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#else
+template <int IMM>
+__device__ static inline void w16r_dma16(const double *sbase, const double *ldsp)
+{
+    const size_t o = (size_t) threadIdx.x * 16 + IMM;
+    memcpy((char *) ldsp + o, (const char *) sbase + o, 16);
+}
+#define W16R_DMA_WAIT() GQP_ROWSYNC()
+#define W16R_LDS_DRAIN() GQP_ROWSYNC()
+#endif
+/* G granules of 16 bytes, contiguous on both sides: full passes of 64 lanes, then the lanes the last pass needs */
+template <int G>
+__device__ static inline void w16r_dma_region(const double *sbase, const double *ldsp)
+{
+    constexpr int NPASS = (G + 63) / 64;
+    W16_UNROLL for (int p = 0; p < NPASS; p++)
+    {
+        const bool full = (p + 1) * 64 <= G;
+        if (full || (int) threadIdx.x < G - 64 * p)
+        {
+            const double *sb = sbase + (p >> 2) * 512, *lp = ldsp + (p >> 2) * 512;
+            switch (p & 3)
+            {
+                case 0: w16r_dma16<0>(sb, lp); break;
+                case 1: w16r_dma16<1024>(sb, lp); break;
+                case 2: w16r_dma16<2048>(sb, lp); break;
+                default: w16r_dma16<3072>(sb, lp); break;
+            }
+        }
+    }
+}
 
 /* value of variable j: lane j & 15 of the row, slot j >> 4 (j is a compile-time constant after unrolling) */
 #define W16R_BC(arr, j) w16_bcast((arr)[(j) >> 4], (j) & 15, xb)
 /* does slot s hold a row >= c ?  (compile-time after unrolling: the lower triangle only) */
 #define W16R_LOW(s, c) (16 * (s) + 15 >= (c))
+/* The lane-dependent predicates of the unrolled stage body (row == j, row > j, c <= cx, ... for every j) are loop
+ * invariant: the compiler hoists hundreds of them out of the stage loop, runs out of scalar registers and spills them
+ * lane by lane.  Laundering the lane's row index once per stage keeps each predicate next to its use. */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define W16R_OPAQUE(x) asm volatile("" : "+v"(x))
+#else
+#define W16R_OPAQUE(x) do { } while (0)
+#endif
+/* development aid (`make timing`): cycles per phase of instance 0, slots of gqp_wpi_cycles */
+#if defined(GQP_WPI_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+#define W16R_TICK(slot)                                                            \
+    do {                                                                           \
+        const unsigned long long now_ = clock64();                                 \
+        if (inst == 0 && l == 0) gqp_wpi_cycles[slot] += now_ - tick_;             \
+        tick_ = now_;                                                              \
+    } while (0)
+#else
+#define W16R_TICK(slot) do { } while (0)
+#endif
 /* the fully unrolled stage body is one basic block of several thousand instructions; left alone, the scheduler hoists
  * hundreds of loads and LDS reads to its top and spills.  A fence between the phases keeps each phase's loads inside it */
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -71,90 +132,160 @@ __global__ void __launch_bounds__(64) ky_factor(GqpDev D, GqpOpts O, int redo)
 {
     GQP_DYN_SHARED(smem);
     typedef W16RLds<NX, NU> LY;
-    constexpr int n = NX + NU, R = LY::R, NP = n * (n + 1) / 2, LDB = LY::LDB;
-    constexpr int NH = (NP + 15) / 16, NBF = (n * NX + 15) / 16; /* flat 16-lane passes over the two stage blocks */
-    const int l = threadIdx.x & 15, inst = blockIdx.x * 4 + (threadIdx.x >> 4);
-    if (inst >= D.B) return;
-    if (D.status[inst] != GQP_RUNNING) return;
-    double *T = smem + (threadIdx.x >> 4) * LY::SZ, *xb = T + LY::XB;
-    double *PV = T + LY::PV;   /* pi+ */
-    double *TA = T + LY::TAC;  /* x-block of the factor of stage k+1, chunked rows, zero above the diagonal */
-    double *SG = T + LY::STG;  /* staging: packed H block, then [B A]' with leading dimension LDB */
-    int row[R], cx[R], tar[R];
+    constexpr int n = NX + NU, R = LY::R, NP = LY::NP, NB = LY::NB;
+    const int l = threadIdx.x & 15, rq = threadIdx.x >> 4;
+    /* Liveness per 16-lane row.  No row leaves the kernel while another one of the wave is alive: all 64 lanes take part
+     * in the LDS-DMA of every live row.  A dead row (converged instance, or beyond the batch) computes on the data of a
+     * valid instance and writes nothing. */
+    const int inst0 = blockIdx.x * 4, Bm1 = D.B - 1;
+    bool aq[4], any = false, alive = false;
+    int iq[4];
+    W16_UNROLL for (int q = 0; q < 4; q++)
+    {
+        iq[q] = inst0 + q <= Bm1 ? inst0 + q : Bm1;
+        aq[q] = inst0 + q <= Bm1 && D.status[iq[q]] == GQP_RUNNING;
+        any = any || aq[q];
+        if (q == rq) alive = aq[q];
+    }
+    if (!any) return;
+    const int inst = inst0 + rq <= Bm1 ? inst0 + rq : Bm1;
+    double *T = smem + rq * LY::SZ, *xb = T + LY::XB;
+    double *HRq = T + LY::HR; /* packed H block of the stage */
+    double *BRq = T + LY::BR; /* [B A]' block of the stage, [row][NX]; later the x-block of the previous factor, [q][NX] */
+    int row[R], cx[R];
     bool mine[R], isx[R];
+    W16_UNROLL for (int s = 0; s < R; s++) row[s] = l + 16 * s;
+
+    /* What a stage reads from HBM arrives ONE STAGE AHEAD while the O(n^3) phases of the stage before run (one wave per
+     * SIMD: nobody else hides the latency).  The two big blocks go straight into LDS by DMA: H as soon as the rows of the
+     * current one are in registers, [B A]' as soon as the stage is done with the current one.  The vectors, the box rows
+     * of the slots (a slot without a row reads row 0 of the stage: always readable) and the descriptor of the stage after
+     * the next land in registers; all of it is waited for once, at the top of the stage. */
+    auto dma_h = [&](int kk)
+    {
+        W16R_LDS_DRAIN();
+        W16_UNROLL for (int q = 0; q < 4; q++)
+            if (aq[q])
+                w16r_dma_region<NP / 2>(D.RSQ.p + (size_t) iq[q] * (size_t) D.RSQ.E + (size_t) kk * NP, smem + q * LY::SZ + LY::HR);
+    };
+    auto dma_b = [&](int kk)
+    {
+        W16R_LDS_DRAIN();
+        W16_UNROLL for (int q = 0; q < 4; q++)
+            if (aq[q])
+                w16r_dma_region<NB / 2>(D.BAt.p + (size_t) iq[q] * (size_t) D.BAt.E + (size_t) kk * NB, smem + q * LY::SZ + LY::BR);
+    };
+    double p_v[R], p_g[R], p_b[R], p_xn[R], p_pin[R], p_pik[R], p_ll[R], p_lu[R], p_tl[R], p_tu[R], p_dl[R], p_du[R];
+    double p_ht = 0.0, p_bt = 0.0; /* last element of an odd-sized block (the DMA moves pairs) */
+    uint64_t p_am, c_bm, c_em, n_bm, n_em; /* activity bits of the next stage; box / equality masks of the current and next one */
+    int c_nb, c_oct, n_nb, n_oct;
+    auto load_desc = [&](int kk)
+    {
+        const GqpStage &Sn = D.st[kk];
+        n_bm = Sn.bmask; n_em = Sn.emask; n_nb = Sn.nb; n_oct = Sn.o_ct;
+    };
+    /* vectors and box rows of stage kk, whose descriptor is in c_* */
+    auto prefetch_v = [&](int kk)
+    {
+        p_am = WAT(D.amask, kk * D.AW);
+        if (NP & 1) p_ht = WAT(D.RSQ, kk * NP + NP - 1);
+        if (NB & 1) p_bt = WAT(D.BAt, kk * NB + NB - 1);
+        W16_UNROLL for (int s = 0; s < R; s++)
+        {
+            const bool mn = row[s] < n, ix = row[s] >= NU && row[s] < n;
+            const int lc = mn ? row[s] : 0, xc = ix ? row[s] - NU : 0;
+            p_v[s] = WAT(D.ux, kk * n + lc);
+            p_g[s] = WAT(D.rq, kk * n + lc);
+            p_b[s] = WAT(D.bvec, kk * NX + xc);
+            p_xn[s] = WAT(D.ux, (kk + 1) * n + NU + xc);
+            p_pin[s] = WAT(D.pi, (kk + 1) * NX + xc);
+            p_pik[s] = WAT(D.pi, kk * NX + xc);
+            const bool hs = mn && (((c_bm & ~c_em) >> row[s]) & 1);
+            const int ib = hs ? popc64(c_bm & (((uint64_t) 1 << row[s]) - 1)) : 0;
+            const int el = c_oct + ib, eu = el + c_nb;
+            p_ll[s] = WAT(D.lam, el); p_lu[s] = WAT(D.lam, eu);
+            p_tl[s] = WAT(D.t, el); p_tu[s] = WAT(D.t, eu);
+            p_dl[s] = WAT(D.dvec, el); p_du[s] = WAT(D.dvec, eu);
+        }
+    };
+    load_desc(D.N);
+    c_bm = n_bm; c_em = n_em; c_nb = n_nb; c_oct = n_oct;
+    dma_h(D.N);
+    dma_b(D.N);
+    prefetch_v(D.N);
+    load_desc(D.N > 0 ? D.N - 1 : 0);
+
+    double Lp[R][NX]; /* rows of the x-block of the factor of stage k+1 held by the state slots, zero above the diagonal */
+    double lxn[R];    /* lx+ of this lane's states */
     W16_UNROLL for (int s = 0; s < R; s++)
     {
-        row[s] = l + 16 * s;
-        mine[s] = row[s] < n;
-        isx[s] = row[s] >= NU && row[s] < n;
-        cx[s] = isx[s] ? row[s] - NU : 0;
-        const int j = cx[s] >> 3, w = 8 * (j + 1) < NX ? 8 * (j + 1) : NX;
-        tar[s] = 32 * j * (j + 1) + (cx[s] & 7) * w; /* LY::crow(cx) */
+        lxn[s] = 0.0;
+        W16_UNROLL for (int c = 0; c < NX; c++) Lp[s][c] = 0.0;
     }
-    /* stage N has no successor: an all-zero tile */
-    for (int e = l; e < LY::TAC_SZ; e += 16) TA[e] = 0.0;
-
-    double lxn[R]; /* lx+ of this lane's states */
-    W16_UNROLL for (int s = 0; s < R; s++) lxn[s] = 0.0;
     double nrm_g = 0.0, nrm_b = 0.0, nrm_d = 0.0, nrm_m = 0.0, musum = 0.0, obj = 0.0, nact = 0.0;
-
+    GQP_TICK_INIT();
     for (int k = D.N; k >= 0; k--)
     {
-        const GqpStage &S = D.st[k];
-        const uint64_t imask = S.bmask & ~S.emask;
-        const uint64_t am = WAT(D.amask, k * D.AW);
-        const int nbg = S.nb;
-
-        /* ---- loads: the packed H block and the [B A]' block of the stage, flat and coalesced over the 16 lanes;
-         * rows / columns are then read from the LDS staging region ---- */
-        double hb[NH], bb[NBF];
-        W16_UNROLL for (int i = 0; i < NH; i++)
+        W16_UNROLL for (int s = 0; s < R; s++)
         {
-            const int e = l + 16 * i;
-            hb[i] = WAT(D.RSQ, k * NP + (e < NP ? e : 0));
+            W16R_OPAQUE(row[s]);
+            mine[s] = row[s] < n;
+            isx[s] = row[s] >= NU && row[s] < n;
+            cx[s] = isx[s] ? row[s] - NU : 0;
         }
-        W16_UNROLL for (int i = 0; i < NBF; i++)
-        {
-            const int e = l + 16 * i;
-            bb[i] = WAT(D.BAt, k * n * NX + (e < n * NX ? e : 0));
-        }
-        double M[R][n], v[R], g[R], rb[R], pin[R], pik[R];
+        W16R_DMA_WAIT(); /* everything issued for this stage has landed */
+        const uint64_t bmask = c_bm, emask = c_em, imask = bmask & ~emask, am = p_am;
+        const int nbg = c_nb, o_ct = c_oct;
+        double M[R][n], v[R], g[R], rb[R], pin[R], pik[R], q_ll[R], q_lu[R], q_tl[R], q_tu[R], q_dl[R], q_du[R];
         bool fixed[R];
         int lc_[R], xc_[R];
         W16_UNROLL for (int s = 0; s < R; s++)
         {
             lc_[s] = mine[s] ? row[s] : 0;
             xc_[s] = isx[s] ? cx[s] : 0;
-            fixed[s] = mine[s] && ((S.emask >> row[s]) & 1);
+            fixed[s] = mine[s] && ((emask >> row[s]) & 1);
             const double zm = mine[s] ? 1.0 : 0.0, zx = isx[s] ? 1.0 : 0.0;
-            v[s] = zm * WAT(D.ux, k * n + lc_[s]);
-            g[s] = zm * WAT(D.rq, k * n + lc_[s]);
-            rb[s] = zx * (WAT(D.bvec, k * NX + xc_[s]) - WAT(D.ux, (k + 1) * n + NU + xc_[s]));
-            pin[s] = zx * WAT(D.pi, (k + 1) * NX + xc_[s]);
-            pik[s] = zx * WAT(D.pi, k * NX + xc_[s]);
+            v[s] = zm * p_v[s];
+            g[s] = zm * p_g[s];
+            rb[s] = zx * (p_b[s] - p_xn[s]);
+            pin[s] = zx * p_pin[s];
+            pik[s] = zx * p_pik[s];
+            q_ll[s] = p_ll[s]; q_lu[s] = p_lu[s]; q_tl[s] = p_tl[s]; q_tu[s] = p_tu[s]; q_dl[s] = p_dl[s]; q_du[s] = p_du[s];
         }
-        GQP_ROWSYNC(); /* the previous stage is done with the staging region */
-        W16_UNROLL for (int i = 0; i < NH; i++)
+        if ((NP & 1) || (NB & 1))
         {
-            const int e = l + 16 * i;
-            if (e < NP) SG[e] = hb[i];
+            if (l == 0)
+            {
+                if (NP & 1) HRq[NP - 1] = p_ht;
+                if (NB & 1) BRq[NB - 1] = p_bt;
+            }
+            GQP_ROWSYNC();
         }
-        W16_UNROLL for (int s = 0; s < R; s++)
-            if (isx[s]) PV[cx[s]] = pin[s];
-        GQP_ROWSYNC();
-        /* symmetric row of H */
+        /* the descriptor loaded a stage ago becomes the next stage's */
+        const uint64_t x_bm = n_bm, x_em = n_em;
+        const int x_nb = n_nb, x_oct = n_oct;
+        /* ---- symmetric row of H from the packed block: H[row][c] = packed[PK(row, c)] for c <= row, packed[PK(c, row)]
+         * above.  A slot knows at compile time which one it is except inside its own 16 x 16 diagonal block, where both
+         * are read and the lane picks (every access: lane base + immediate offset) ---- */
         W16_UNROLL for (int s = 0; s < R; s++)
         {
             const double zm = mine[s] ? 1.0 : 0.0;
-            W16_UNROLL for (int c = 0; c < n; c++) M[s][c] = zm * SG[c <= lc_[s] ? PK(lc_[s], c) : PK(c, lc_[s])];
+            const double *lowp = HRq + PK(lc_[s], 0), *upp = HRq + lc_[s];
+            W16_UNROLL for (int c = 0; c < n; c++)
+            {
+                double h;
+                if (c < 16 * s) h = lowp[c];
+                else if (c > 16 * s + 15) h = upp[PK(c, 0)];
+                else
+                {
+                    const double lo = lowp[c < n - 1 ? c : n - 1], up = upp[PK(c, 0)];
+                    h = c <= lc_[s] ? lo : up;
+                }
+                M[s][c] = zm * h;
+            }
         }
-        GQP_ROWSYNC();
-        W16_UNROLL for (int i = 0; i < NBF; i++)
-        {
-            const int e = l + 16 * i;
-            if (e < n * NX) SG[(e / NX) * LDB + e % NX] = bb[i];
-        }
-        GQP_ROWSYNC();
+        if (k > 0) dma_h(k - 1);
+        W16R_TICK(0);
 
         /* ---- rb += [B A] v (column cx of [B A]'), H v: one broadcast of v per variable serves both ---- */
         double hv[R];
@@ -164,44 +295,50 @@ __global__ void __launch_bounds__(64) ky_factor(GqpDev D, GqpOpts O, int redo)
             const double vr = W16R_BC(v, r);
             W16_UNROLL for (int s = 0; s < R; s++)
             {
-                rb[s] += SG[r * LDB + xc_[s]] * vr; /* idle slots: clamped column, value unused */
+                rb[s] += BRq[r * NX + xc_[s]] * vr; /* idle slots: clamped column, value unused */
                 hv[s] += M[s][r] * vr;
             }
         }
-        /* ---- W rows: W[c] = sum_{q >= c} Br[q] Lx+[q][c], and [B A]' pi+ with the same pass over the row of [B A]'.
-         * A ROLLED loop over q (everything indexed by q lives in LDS; no broadcast inside), in chunks of eight rows
-         * whose width is the chunk bound: straight-line code here let the scheduler hoist every LDS read of the
-         * phase to the top of the stage and spill hundreds of registers ---- */
+        W16_UNROLL for (int s = 0; s < R; s++) { W16R_OPAQUE(rb[s]); W16R_OPAQUE(hv[s]); }
+        W16R_TICK(1);
+        /* ---- W rows: W[c] = sum_{q >= c} Br[q] Lx+[q][c]: Lx+[q][c] is entry c of the register row of the slot that
+         * holds state q, one broadcast feeds both slots; [B A]' pi+ rides along ---- */
         double W[R][NX], gt[R], gadd[R], gam[R];
         W16_UNROLL for (int s = 0; s < R; s++)
         {
             gt[s] = 0.0; gadd[s] = 0.0; gam[s] = 0.0;
             W16_UNROLL for (int c = 0; c < NX; c++) W[s][c] = 0.0;
         }
-        W16_UNROLL for (int j = 0; j < LY::NCH; j++)
+        double brn[R]; /* row entries of [B A]' one column ahead of their use */
+        W16_UNROLL for (int s = 0; s < R; s++) brn[s] = BRq[lc_[s] * NX];
+        W16_UNROLL for (int q = 0; q < NX; q++)
         {
-            constexpr int dummy = 0; (void) dummy;
-            const int q0 = 8 * j, q1 = 8 * (j + 1) < NX ? 8 * (j + 1) : NX, w = q1;
-            const double *TAj = TA + 32 * j * (j + 1);
-            _Pragma("unroll 2")
-            for (int q = q0; q < q1; q++)
+            /* the scheduler must not pull the broadcasts of later columns up here: they are all ready at the top of the
+             * phase, and hoisted they spill */
+            W16R_FENCE();
+            double brq[R];
+            W16_UNROLL for (int s = 0; s < R; s++)
             {
-                const double pc = PV[q];
-                double Brq[R];
-                W16_UNROLL for (int s = 0; s < R; s++)
-                {
-                    Brq[s] = (mine[s] ? 1.0 : 0.0) * SG[lc_[s] * LDB + q];
-                    gt[s] += Brq[s] * pc;
-                }
-                const double *Tq = TAj + (q - q0) * w;
-                W16_UNROLL for (int c = 0; c < NX; c++)
-                    if (c < w)
-                    {
-                        const double Lqc = Tq[c];
-                        W16_UNROLL for (int s = 0; s < R; s++) W[s][c] += Brq[s] * Lqc;
-                    }
+                brq[s] = mine[s] ? brn[s] : 0.0;
+                brn[s] = BRq[lc_[s] * NX + (q + 1 < NX ? q + 1 : q)];
+            }
+            const double pc = W16R_BC(pin, NU + q);
+            W16_UNROLL for (int s = 0; s < R; s++) gt[s] += brq[s] * pc;
+            W16_UNROLL for (int c = 0; c <= q; c++)
+            {
+                const double Lqc = w16_bcast(Lp[(NU + q) >> 4][c], (NU + q) & 15, xb);
+                W16_UNROLL for (int s = 0; s < R; s++) W[s][c] += brq[s] * Lqc;
             }
         }
+        /* The accumulators of the phase are pinned at its end.  Their readers sit in later basic blocks (behind the box-row
+         * branches): machine sinking would move every multiply-add chain down there, while the broadcasts feeding them
+         * (convergent) stay up here -- three hundred values alive across the gap, spilled to scratch. */
+        W16_UNROLL for (int s = 0; s < R; s++)
+        {
+            W16R_OPAQUE(gt[s]);
+            W16_UNROLL for (int c = 0; c < NX; c++) W16R_OPAQUE(W[s][c]);
+        }
+        W16R_TICK(2);
         W16_UNROLL for (int s = 0; s < R; s++)
         {
             if (mine[s])
@@ -210,16 +347,16 @@ __global__ void __launch_bounds__(64) ky_factor(GqpDev D, GqpOpts O, int redo)
                 gt[s] += hv[s] + g[s] - pik[s];
             }
             else gt[s] = 0.0;
-            if (isx[s]) { nacc(nrm_b, rb[s]); WAT(D.rb, k * NX + cx[s]) = rb[s]; }
+            if (isx[s]) { nacc(nrm_b, rb[s]); if (alive) WAT(D.rb, k * NX + cx[s]) = rb[s]; }
             const bool has = mine[s] && ((imask >> row[s]) & 1);
             if (has)
             {
-                const int ib = popc64(S.bmask & (((uint64_t) 1 << row[s]) - 1));
+                const int ib = popc64(bmask & (((uint64_t) 1 << row[s]) - 1));
                 const bool al = (am >> ib) & 1, au = (am >> (nbg + ib)) & 1;
-                const int el = S.o_ct + ib, eu = el + nbg;
-                const double ll = al ? WAT(D.lam, el) : 0.0, lu = au ? WAT(D.lam, eu) : 0.0;
-                const double ttl = al ? WAT(D.t, el) : 1.0, ttu = au ? WAT(D.t, eu) : 1.0;
-                const double lbv = al ? WAT(D.dvec, el) : 0.0, ubv = au ? WAT(D.dvec, eu) : 0.0;
+                const int el = o_ct + ib, eu = el + nbg;
+                const double ll = al ? q_ll[s] : 0.0, lu = au ? q_lu[s] : 0.0;
+                const double ttl = al ? q_tl[s] : 1.0, ttu = au ? q_tu[s] : 1.0;
+                const double lbv = al ? q_dl[s] : 0.0, ubv = au ? q_du[s] : 0.0;
                 const double rdl = al ? v[s] - lbv - ttl : 0.0, rdu = au ? ubv - v[s] - ttu : 0.0;
                 const double rml = al ? ll * ttl - O.tau_min : 0.0, rmu = au ? lu * ttu - O.tau_min : 0.0;
                 nacc(nrm_d, rdl); nacc(nrm_d, rdu); nacc(nrm_m, rml); nacc(nrm_m, rmu);
@@ -229,22 +366,41 @@ __global__ void __launch_bounds__(64) ky_factor(GqpDev D, GqpOpts O, int redo)
                 const double itl = frcp(ttl), itu = frcp(ttu);
                 gam[s] = ll * itl + lu * itu;
                 gadd[s] = (rml + ll * rdl) * itl - (rmu + lu * rdu) * itu;
-                WAT(D.rd, el) = rdl;
-                WAT(D.rd, eu) = rdu;
+                if (alive)
+                {
+                    WAT(D.rd, el) = rdl;
+                    WAT(D.rd, eu) = rdu;
+                }
             }
             if (fixed[s]) gt[s] = 0.0;
-            if (mine[s]) { nacc(nrm_g, gt[s]); WAT(D.rg, k * n + row[s]) = gt[s]; }
+            if (mine[s]) { nacc(nrm_g, gt[s]); if (alive) WAT(D.rg, k * n + row[s]) = gt[s]; }
         }
-        /* w0[c] (state slots) = lx+[c] + sum_{q >= c} Lx+[q][c] rb[q]: column c of the chunked tile */
+        /* w0[c] (state slots) = lx+[c] + sum_{q >= c} Lx+[q][c] rb[q] needs COLUMN c of Lx+: the rows go through the
+         * [B A]' region (the stage is done with it), the slots read their column back */
+        GQP_ROWSYNC();
+        W16_UNROLL for (int s = 0; s < R; s++)
+            if (isx[s])
+            {
+                W16_UNROLL for (int c = 0; c < NX; c++) BRq[cx[s] * NX + c] = Lp[s][c];
+            }
+        GQP_ROWSYNC();
         double w0[R];
         W16_UNROLL for (int s = 0; s < R; s++) w0[s] = lxn[s];
         W16_UNROLL for (int q = 0; q < NX; q++)
         {
             const double rbq = W16R_BC(rb, NU + q);
-            W16_UNROLL for (int s = 0; s < R; s++) w0[s] += (q >= cx[s] ? TA[LY::crow(q) + cx[s]] : 0.0) * rbq;
+            W16_UNROLL for (int s = 0; s < R; s++) w0[s] += BRq[q * NX + xc_[s]] * rbq; /* zero above the diagonal */
         }
         W16_UNROLL for (int s = 0; s < R; s++)
             if (!isx[s]) w0[s] = 0.0;
+        if (k > 0)
+        {
+            /* next stage: its [B A]' block by DMA; vectors, box rows and the descriptor after it into registers */
+            dma_b(k - 1);
+            c_bm = x_bm; c_em = x_em; c_nb = x_nb; c_oct = x_oct;
+            prefetch_v(k - 1);
+            load_desc(k > 1 ? k - 2 : 0);
+        }
         /* m = gt + gadd + W w0 */
         double m[R];
         W16_UNROLL for (int s = 0; s < R; s++) m[s] = gt[s] + gadd[s];
@@ -255,6 +411,8 @@ __global__ void __launch_bounds__(64) ky_factor(GqpDev D, GqpOpts O, int redo)
         }
         W16_UNROLL for (int s = 0; s < R; s++)
             if (fixed[s] || !mine[s]) m[s] = 0.0;
+        W16_UNROLL for (int s = 0; s < R; s++) W16R_OPAQUE(m[s]);
+        W16R_TICK(3);
         /* ---- M += W W' + reg + Gamma (lower triangle: slot s needs column c only if it holds a row >= c) ---- */
         W16_UNROLL for (int q = 0; q < NX; q++)
             W16_UNROLL for (int c = 0; c < n; c++)
@@ -266,15 +424,19 @@ __global__ void __launch_bounds__(64) ky_factor(GqpDev D, GqpOpts O, int redo)
         W16_UNROLL for (int s = 0; s < R; s++)
             W16_UNROLL for (int c = 0; c < n; c++)
                 if (W16R_LOW(s, c)) M[s][c] += (c == row[s]) ? O.reg_prim + gam[s] : 0.0;
-        if (S.emask) /* uniform: only a stage with fixed variables pays for the masking */
+        W16_UNROLL for (int s = 0; s < R; s++)
+            W16_UNROLL for (int c = 0; c < n; c++)
+                if (W16R_LOW(s, c)) W16R_OPAQUE(M[s][c]);
+        if (emask) /* uniform: only a stage with fixed variables pays for the masking */
         {
             W16_UNROLL for (int s = 0; s < R; s++)
                 W16_UNROLL for (int c = 0; c < n; c++)
                 {
-                    const bool fc = (S.emask >> c) & 1;
+                    const bool fc = (emask >> c) & 1;
                     if (fixed[s] || fc) M[s][c] = (c == row[s]) ? 1.0 : 0.0;
                 }
         }
+        W16R_TICK(4);
 
         /* ---- Cholesky on register rows; the rhs entry m rides along (l = L^{-1} m) ---- */
         W16_UNROLL for (int j = 0; j < n; j++)
@@ -305,32 +467,36 @@ __global__ void __launch_bounds__(64) ky_factor(GqpDev D, GqpOpts O, int redo)
                     if (W16R_LOW(s, c)) M[s][c] -= lo[s] * lc;
             }
         }
-
-        /* ---- outputs ---- */
         W16_UNROLL for (int s = 0; s < R; s++)
-            if (mine[s])
+        {
+            W16R_OPAQUE(m[s]);
+            W16_UNROLL for (int c = 0; c < n; c++)
+                if (W16R_LOW(s, c)) W16R_OPAQUE(M[s][c]);
+        }
+        W16R_TICK(5);
+
+        /* ---- outputs: the rows of the factor from registers (both LDS regions are being filled for the next stage) ---- */
+        W16_UNROLL for (int s = 0; s < R; s++)
+            if (mine[s] && alive)
             {
                 W16_UNROLL for (int c = 0; c < n; c++)
                     if (W16R_LOW(s, c) && c <= row[s]) WAT(D.Lf, k * NP + PK(row[s], c)) = M[s][c];
                 WAT(D.lf, k * n + row[s]) = m[s];
             }
-        /* x-block for the next (earlier) stage: chunked rows, zero above the diagonal up to the chunk bound */
-        GQP_ROWSYNC();
+        /* x-block for the next (earlier) stage: register rows of the state slots */
         W16_UNROLL for (int s = 0; s < R; s++)
-            if (isx[s])
-            {
-                const int w = 8 * ((cx[s] >> 3) + 1) < NX ? 8 * ((cx[s] >> 3) + 1) : NX;
-                W16_UNROLL for (int c = 0; c < NX; c++)
-                    if (c < w) TA[tar[s] + c] = (W16R_LOW(s, NU + c) && c <= cx[s]) ? M[s][NU + c] : 0.0;
-            }
-        GQP_ROWSYNC();
-        W16_UNROLL for (int s = 0; s < R; s++) lxn[s] = isx[s] ? m[s] : 0.0;
+        {
+            W16_UNROLL for (int c = 0; c < NX; c++)
+                Lp[s][c] = (W16R_LOW(s, NU + c) && isx[s] && c <= cx[s]) ? M[s][NU + c] : 0.0;
+            lxn[s] = isx[s] ? m[s] : 0.0;
+        }
+        W16R_TICK(6);
     }
 
     nrm_g = w16_rmax(nrm_g, xb); nrm_b = w16_rmax(nrm_b, xb); nrm_d = w16_rmax(nrm_d, xb); nrm_m = w16_rmax(nrm_m, xb);
     musum = w16_rsum(musum, xb); obj = w16_rsum(obj, xb);
     const double nact_d = w16_rsum(nact, xb);
-    if (l == 0)
+    if (l == 0 && alive)
     {
         const int Bp = D.Bp;
         const double mu = nact_d > 0.0 ? musum / nact_d : 0.0;
