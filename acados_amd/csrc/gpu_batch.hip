@@ -23,6 +23,7 @@
 #include "ipm_kernels_w16r.hpp"
 #include "ipm_kernels_wpi_mfma.hpp"
 #include "res_kernels.hpp"
+#include "pcond_kernels_w16.hpp"
 #include "kernel_sets.h"
 
 #define HIPCHK(x)                                                                              \
@@ -69,6 +70,17 @@ struct W16Set
      nullptr, nullptr, nullptr, nullptr, 4 * gqp::W16RLds<NX, NU>::SZ * sizeof(double)}
 const W16Set g_w16_sets[] = {GQP_W16(4, 1), GQP_W16(8, 3), GQP_W16(12, 3), GQP_W16(4, 4), GQP_W16(12, 4),
                              GQP_W16R(8, 15), GQP_W16R(24, 6)};
+
+/* condensing of the box-only class on register rows, sixteen lanes per block (pcond_kernels_w16.hpp): compiled
+ * (NX, NU, block size) with nx + bs * nu <= 32 */
+struct PcondzSet
+{
+    int NX, NU, BS;
+    kern_pcond_t cond;
+    size_t shmem;
+};
+#define GQP_PCONDZ(NX, NU, BS) {NX, NU, BS, gqp::kz_pcond<NX, NU, BS>, 4 * gqp::PcondzLds<NX, NU, BS>::SZ * sizeof(double)}
+const PcondzSet g_pcondz_sets[] = {GQP_PCONDZ(8, 3, 5), GQP_PCONDZ(4, 1, 4)};
 
 } // namespace
 
@@ -128,6 +140,8 @@ struct ocp_qp_gpu_batch
     ocp_qp_gpu_batch *child = nullptr;
     const PcondSet *pc = nullptr;   /* compiled one-instance-per-lane condensing kernels, or ... */
     int pc_rt = 0;                  /* ... the run-time-shaped wave-per-instance ones (kw_pcond / kw_pexpand) */
+    int pc_lane_expand = 0;         /* the expansion runs on the compiled one-instance-per-lane kernel although condensing does not */
+    const PcondzSet *pcz = nullptr; /* condensing on register rows, sixteen lanes per block (box-only class, compiled shapes) */
     size_t pc_shmem = 0;
     std::vector<int> blk_start;
     gqp::PcondMap pmap;
@@ -1017,6 +1031,21 @@ static void pcond_setup(ocp_qp_gpu_batch *b)
         const bool want_1tpi = e1 && atoi(e1) != 0 && box_class;
         if (!(want_1tpi && b->pc) && b->ks->NX + bsmax * b->ks->NU <= 64) b->pc_rt = 1;
     }
+    /* Expansion of a WAVE-TILED parent: element e of eight neighbouring instances shares a 64-byte line, so a kernel that
+     * walks one instance per wave moves eight lines for every one it uses -- kw_pexpand is bound by that traffic (13.3 ms
+     * per 65,536 instances of the C2 shape).  The compiled one-instance-per-lane kernel reads the same data coalesced:
+     * 1.6 ms.  (Condensing stays with kw_pcond: the per-lane block matrices of k_pcond do not fit the register file.) */
+    {
+        const char *e2 = getenv("ACADOS_AMD_PCOND_LANE_EXPAND");
+        b->pc_lane_expand = b->pc && b->pc->BSMAX == bsmax && box_class && !b->aos && !(e2 && atoi(e2) == 0);
+    }
+    b->pcz = nullptr;
+    {
+        const char *e3 = getenv("ACADOS_AMD_PCOND_W16");
+        if (box_class && !(e3 && atoi(e3) == 0))
+            for (const PcondzSet &z : g_pcondz_sets)
+                if (z.NX == b->ks->NX && z.NU == b->ks->NU && z.BS == bsmax) b->pcz = &z;
+    }
     if (!box_class && !b->pc_rt) { decline("the condensed stage (nx + block size * nu > 64) is beyond the condensing kernels"); return; }
     if (!b->pc && !b->pc_rt) { decline("no condensing kernel covers this shape / block size"); return; }
     const int NU = b->ks->NU, BS = b->pc_rt ? bsmax : b->pc->BSMAX;
@@ -1129,7 +1158,12 @@ static void pcond_setup(ocp_qp_gpu_batch *b)
 static void pcond_launch(ocp_qp_gpu_batch *b, bool expand)
 {
     ocp_qp_gpu_batch *c = b->child;
-    if (b->pc_rt || b->AW > 1 || c->AW > 1)
+    if (!expand && b->pcz && b->pc_rt && b->AW <= 1 && c->AW <= 1)
+    {
+        GQP_LAUNCH_COOP(b->pcz->cond, dim3((b->B + 3) / 4, b->pmap.N2 + 1), dim3(64), b->pcz->shmem, b->stream, b->D, c->D, b->pmap);
+        return;
+    }
+    if ((b->pc_rt || b->AW > 1 || c->AW > 1) && !(expand && b->pc_lane_expand && b->AW <= 1 && c->AW <= 1))
     {
         if (expand) GQP_LAUNCH_COOP(gqp::kw_pexpand, dim3(b->Bp), dim3(64), b->pc_shmem, b->stream, b->D, c->D, b->pmap);
         else GQP_LAUNCH_COOP(gqp::kw_pcond, dim3(b->Bp), dim3(64), b->pc_shmem, b->stream, b->D, c->D, b->pmap);
@@ -1808,6 +1842,10 @@ double ocp_qp_gpu_batch_get_scalar(ocp_qp_gpu_batch *b, const char *f)
     if (!strcmp(f, "compactions")) return (double) b->n_compactions;
     if (!strcmp(f, "tail_switches")) return (double) b->n_tail_switches;
     if (!strcmp(f, "cond_N_active")) return b->pcond_state == 1 ? (double) b->cond_N : (double) b->N;
+    /* which condensing / expansion kernels serve the batch: 2 sixteen lanes per block, 1 one instance per lane, 0 one wave
+     * per instance (meaningful once partial condensing is active) */
+    if (!strcmp(f, "pcond_kernel")) return b->pcond_state != 1 ? -1.0 : (b->pcz && b->pc_rt && b->AW <= 1 && b->child->AW <= 1) ? 2.0 : b->pc_rt ? 0.0 : 1.0;
+    if (!strcmp(f, "pexpand_kernel")) return b->pcond_state != 1 ? -1.0 : (!b->pc_rt || b->pc_lane_expand) ? 1.0 : 0.0;
     {
         /* accumulated per-kernel-class event times (ms) and launch counts since the last reset */
         const char *cls[6] = {"init", "back_fact", "fwd_aff", "back_rhs", "fwd_corr", "finalize"};

@@ -31,7 +31,12 @@ def run(tag, nx, nu, N, cond=0, batch=B):
     return [gb.get("x", k) for k in (0, N // 2, N)]
 
 
-for tag, args in (("nx=24 nu=6 N=20", (24, 6, 20)), ("nx=24 nu=6 N=100", (24, 6, 100)), ("C3 (C2, cond_N=10) 65536", (8, 3, 50, 10, 65536))):
+CASES = (("nx=24 nu=6 N=20", (24, 6, 20)), ("nx=24 nu=6 N=100", (24, 6, 100)), ("C3 (C2, cond_N=10) 65536", (8, 3, 50, 10, 65536)))
+if len(sys.argv) > 2:      # one case, the new family only (for a profiler run): c3 | n20 | n100
+    os.environ["ACADOS_AMD_W16R"] = "1"
+    run(*{"c3": ("C3", 8, 3, 50, 10, 65536), "n20": ("n20", 24, 6, 20), "n100": ("n100", 24, 6, 100)}[sys.argv[2]])
+    sys.exit(0)
+for tag, args in CASES:
     sols = {}
     for fam in ("0", "1"):
         os.environ["ACADOS_AMD_W16R"] = fam
