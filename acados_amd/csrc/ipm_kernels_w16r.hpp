@@ -41,7 +41,12 @@ struct W16RLds
     static constexpr int SZ_A = 16 + NX * LDX, SZ_F = 16 + n * LDF;
     static constexpr int HR = 16, HSZ = (NP + 1) & ~1, BR = HR + HSZ, BSZ = (NB + 1) & ~1;
     static constexpr int SZ_K = BR + BSZ;
-    static constexpr int SZ0 = SZ_A > SZ_F ? SZ_A : SZ_F;
+    /* forward sweep: the packed factor and the [B A]' block of the stage by LDS-DMA, in two buffers (the next stage
+     * lands while this one computes) where four workgroups per CU still fit, in one otherwise */
+    static constexpr int FBUF = HSZ + BSZ;
+    static constexpr int NBUF = (16 + 2 * FBUF) * 4 * 8 <= 40960 ? 2 : 1;
+    static constexpr int SZ_F2 = 16 + NBUF * FBUF;
+    static constexpr int SZ0 = SZ_A > SZ_F2 ? SZ_A : SZ_F2;
     static constexpr int SZ = ((SZ0 > SZ_K ? SZ0 : SZ_K) + 1) & ~1; /* even: every instance's tile starts on 16 bytes */
 };
 
@@ -633,71 +638,144 @@ __global__ void __launch_bounds__(64) ky_backrhs(GqpDev D, GqpOpts O, int redo)
 
 /* --------------------------------------------------------------------------------------------------- forward */
 
-/* PFORM (= CORR): lf holds [l_u; p] (written by ky_backrhs), otherwise the plain l of the factor sweep */
+/* PFORM (= CORR): lf holds [l_u; p] (written by ky_backrhs), otherwise the plain l of the factor sweep.
+ * The packed factor and the [B A]' block of a stage arrive in LDS by DMA (two buffers where they fit: the next stage lands
+ * while this one computes); rows AND columns of the factor are read from the packed block where they are used -- no
+ * register copy, no transposition tile.  Vectors and box rows are loaded one stage ahead into registers.  As in the factor
+ * sweep no row leaves while another row of the wave is alive (the DMA needs all 64 lanes); a dead row writes nothing. */
 template <int NX, int NU, bool CORR>
 __global__ void __launch_bounds__(64) ky_fwd(GqpDev D, GqpOpts O, int redo)
 {
     GQP_DYN_SHARED(smem);
     typedef W16RLds<NX, NU> LY;
     constexpr bool PFORM = CORR;
-    constexpr int n = NX + NU, R = LY::R, NP = n * (n + 1) / 2, LDF = LY::LDF;
-    const int l = threadIdx.x & 15, inst = blockIdx.x * 4 + (threadIdx.x >> 4);
-    if (inst >= D.B) return;
-    if (D.status[inst] != GQP_RUNNING) return;
-    if (redo == 1 && !(D.alpha[inst] < 0.0)) return; /* redo = 2: sensitivity pass (direction only, every instance) */
-    double *T = smem + (threadIdx.x >> 4) * LY::SZ, *xb = T + LY::XB, *TF = T + LY::TF;
+    constexpr int n = NX + NU, R = LY::R, NP = LY::NP, NB = LY::NB, NBUF = LY::NBUF;
+    const int l = threadIdx.x & 15, rq = threadIdx.x >> 4;
+    const int inst0 = blockIdx.x * 4, Bm1 = D.B - 1;
+    bool aq[4], any = false, alive = false;
+    int iq[4];
+    W16_UNROLL for (int q = 0; q < 4; q++)
+    {
+        iq[q] = inst0 + q <= Bm1 ? inst0 + q : Bm1;
+        aq[q] = inst0 + q <= Bm1 && D.status[iq[q]] == GQP_RUNNING && !(redo == 1 && !(D.alpha[iq[q]] < 0.0));
+        any = any || aq[q];
+        if (q == rq) alive = aq[q];
+    }
+    if (!any) return; /* redo = 1: only the instances whose corrector step was rejected; redo = 2: sensitivity pass */
+    const int inst = inst0 + rq <= Bm1 ? inst0 + rq : Bm1;
+    double *T = smem + rq * LY::SZ, *xb = T + LY::XB;
     int row[R], cx[R];
     bool mine[R], isx[R];
-    W16_UNROLL for (int s = 0; s < R; s++)
-    {
-        row[s] = l + 16 * s;
-        mine[s] = row[s] < n;
-        isx[s] = row[s] >= NU && row[s] < n;
-        cx[s] = isx[s] ? row[s] - NU : 0;
-    }
+    W16_UNROLL for (int s = 0; s < R; s++) row[s] = l + 16 * s;
     const double smu = CORR ? D.smu[inst] : 0.0;
     const double pscale = (CORR && redo != 1) ? 1.0 : 0.0;
     double alpha = 1.0, S0 = 0.0, S1 = 0.0, S2 = 0.0, nact = 0.0;
     double dx[R]; /* dx of this lane's states for the stage being entered */
     W16_UNROLL for (int s = 0; s < R; s++) dx[s] = 0.0;
 
+    auto dma = [&](int kk)
+    {
+        W16R_LDS_DRAIN();
+        const int off = 16 + (NBUF == 2 ? (kk & 1) * LY::FBUF : 0);
+        W16_UNROLL for (int q = 0; q < 4; q++)
+            if (aq[q])
+            {
+                w16r_dma_region<NP / 2>(D.Lf.p + (size_t) iq[q] * (size_t) D.Lf.E + (size_t) kk * NP, smem + q * LY::SZ + off);
+                w16r_dma_region<NB / 2>(D.BAt.p + (size_t) iq[q] * (size_t) D.BAt.E + (size_t) kk * NB, smem + q * LY::SZ + off + LY::HSZ);
+            }
+    };
+    double p_lv[R], p_rb[R], p_ll[R], p_lu[R], p_tl[R], p_tu[R], p_dl[R], p_du[R], p_pl[R], p_pu[R];
+    double p_ft = 0.0, p_bt = 0.0;
+    uint64_t p_am, c_bm, c_em, n_bm, n_em;
+    int c_nb, c_oct, n_nb, n_oct;
+    auto load_desc = [&](int kk)
+    {
+        const GqpStage &Sn = D.st[kk];
+        n_bm = Sn.bmask; n_em = Sn.emask; n_nb = Sn.nb; n_oct = Sn.o_ct;
+    };
+    auto prefetch_v = [&](int kk) /* descriptor of stage kk in c_* */
+    {
+        p_am = WAT(D.amask, kk * D.AW);
+        if (NP & 1) p_ft = WAT(D.Lf, kk * NP + NP - 1);
+        if (NB & 1) p_bt = WAT(D.BAt, kk * NB + NB - 1);
+        W16_UNROLL for (int s = 0; s < R; s++)
+        {
+            const bool mn = row[s] < n, ix = row[s] >= NU && row[s] < n;
+            const int lc = mn ? row[s] : 0, xc = ix ? row[s] - NU : 0;
+            p_lv[s] = WAT(D.lf, kk * n + lc);
+            p_rb[s] = WAT(D.rb, kk * NX + xc);
+            const bool hs = mn && (((c_bm & ~c_em) >> row[s]) & 1);
+            const int ib = hs ? popc64(c_bm & (((uint64_t) 1 << row[s]) - 1)) : 0;
+            const int el = c_oct + ib, eu = el + c_nb;
+            p_ll[s] = WAT(D.lam, el); p_lu[s] = WAT(D.lam, eu);
+            p_tl[s] = WAT(D.t, el); p_tu[s] = WAT(D.t, eu);
+            p_dl[s] = WAT(D.rd, el); p_du[s] = WAT(D.rd, eu);
+            p_pl[s] = CORR ? WAT(D.pcorr, el) : 0.0; p_pu[s] = CORR ? WAT(D.pcorr, eu) : 0.0;
+        }
+    };
+    load_desc(0);
+    c_bm = n_bm; c_em = n_em; c_nb = n_nb; c_oct = n_oct;
+    dma(0);
+    prefetch_v(0);
+    load_desc(D.N > 0 ? 1 : 0);
+
     for (int k = 0; k <= D.N; k++)
     {
-        const GqpStage &S = D.st[k];
-        const uint64_t imask = S.bmask & ~S.emask;
-        const uint64_t am = WAT(D.amask, k * D.AW);
-        const int nbg = S.nb;
-        /* row of the factor (registers); columns are read from the LDS tile where they are used */
-        double Lr[R][n], lv[R], rbv[R];
+        W16_UNROLL for (int s = 0; s < R; s++)
+        {
+            W16R_OPAQUE(row[s]);
+            mine[s] = row[s] < n;
+            isx[s] = row[s] >= NU && row[s] < n;
+            cx[s] = isx[s] ? row[s] - NU : 0;
+        }
+        W16R_DMA_WAIT();
+        double *LF = T + 16 + (NBUF == 2 ? (k & 1) * LY::FBUF : 0); /* packed factor of the stage */
+        double *BRq = LF + LY::HSZ;                                 /* [B A]' of the stage, [row][NX] */
+        const uint64_t bmask = c_bm, emask = c_em, imask = bmask & ~emask, am = p_am;
+        const int nbg = c_nb, o_ct = c_oct;
+        double lv[R], rbv[R], q_ll[R], q_lu[R], q_tl[R], q_tu[R], q_dl[R], q_du[R], q_pl[R], q_pu[R];
         int lc_[R], xc_[R];
         W16_UNROLL for (int s = 0; s < R; s++)
         {
             lc_[s] = mine[s] ? row[s] : 0;
             xc_[s] = isx[s] ? cx[s] : 0;
-            const double zm = mine[s] ? 1.0 : 0.0, zx = isx[s] ? 1.0 : 0.0;
-            W16_UNROLL for (int c = 0; c < n; c++)
-                Lr[s][c] = W16R_LOW(s, c) ? (c <= lc_[s] ? zm : 0.0) * WAT(D.Lf, k * NP + PK(lc_[s], (c <= lc_[s] ? c : 0))) : 0.0;
-            lv[s] = zm * WAT(D.lf, k * n + lc_[s]);
-            rbv[s] = zx * WAT(D.rb, k * NX + xc_[s]);
+            lv[s] = mine[s] ? p_lv[s] : 0.0;
+            rbv[s] = isx[s] ? p_rb[s] : 0.0;
+            q_ll[s] = p_ll[s]; q_lu[s] = p_lu[s]; q_tl[s] = p_tl[s]; q_tu[s] = p_tu[s];
+            q_dl[s] = p_dl[s]; q_du[s] = p_du[s]; q_pl[s] = p_pl[s]; q_pu[s] = p_pu[s];
         }
-        GQP_ROWSYNC();
-        W16_UNROLL for (int s = 0; s < R; s++)
-            if (mine[s])
+        if ((NP & 1) || (NB & 1))
+        {
+            if (l == 0)
             {
-                W16_UNROLL for (int c = 0; c < n; c++) TF[row[s] * LDF + c] = Lr[s][c];
+                if (NP & 1) LF[NP - 1] = p_ft;
+                if (NB & 1) BRq[NB - 1] = p_bt;
             }
-        GQP_ROWSYNC();
-        /* L[r][row] for this slot's row: column of the factor, zero above the diagonal and for idle slots */
-#define W16R_LC(s, r) ((mine[s] && (r) >= row[s]) ? TF[(r) * LDF + lc_[s]] : 0.0)
+            GQP_ROWSYNC();
+        }
+        if (k < D.N)
+        {
+            if (NBUF == 2) dma(k + 1);
+            c_bm = n_bm; c_em = n_em; c_nb = n_nb; c_oct = n_oct;
+            prefetch_v(k + 1);
+            load_desc(k + 2 <= D.N ? k + 2 : D.N);
+        }
+        /* entries of the packed factor: row of this slot (zero above the diagonal and for idle slots) and column of
+         * this slot's variable (zero above the diagonal) */
+#define W16R_LR(s, c) ((mine[s] && (c) <= row[s]) ? LF[PK(lc_[s], 0) + (c)] : 0.0)
+#define W16R_LC(s, r) ((mine[s] && (r) >= row[s]) ? LF[PK((r), 0) + lc_[s]] : 0.0)
+        double dg[R]; /* diagonal entry of this slot's row */
+        W16_UNROLL for (int s = 0; s < R; s++) dg[s] = mine[s] ? W16R_LR(s, lc_[s]) : 0.0;
 
         if (PFORM && k == 0)
         {
             /* the states of stage 0 are free: recover l_x = Lx^{-1} p */
             W16_UNROLL for (int j = NU; j < n; j++)
             {
-                const double d = w16_bcast(Lr[j >> 4][j], j & 15, xb);
-                const double lj = d != 0.0 ? W16R_BC(lv, j) * frcp(d) : 0.0;
-                W16_UNROLL for (int s = 0; s < R; s++) lv[s] = row[s] == j ? lj : (row[s] > j ? lv[s] - Lr[s][j] * lj : lv[s]);
+                const double d = W16R_BC(dg, j), lvj = W16R_BC(lv, j); /* both broadcasts unconditionally: the rows of a wave stay in step */
+                const double lj = d != 0.0 ? lvj * frcp(d) : 0.0;
+                W16_UNROLL for (int s = 0; s < R; s++)
+                    if (W16R_LOW(s, j)) lv[s] = row[s] == j ? lj : (row[s] > j ? lv[s] - W16R_LR(s, j) * lj : lv[s]);
             }
         }
         /* dpi_k = Lx (Lx' dx) + p  (CORR only; k > 0) */
@@ -715,10 +793,11 @@ __global__ void __launch_bounds__(64) ky_fwd(GqpDev D, GqpOpts O, int redo)
             W16_UNROLL for (int c = 0; c < NX; c++)
             {
                 const double wc = W16R_BC(w0, NU + c);
-                W16_UNROLL for (int s = 0; s < R; s++) a[s] += Lr[s][NU + c] * wc;
+                W16_UNROLL for (int s = 0; s < R; s++)
+                    if (W16R_LOW(s, NU + c)) a[s] += W16R_LR(s, NU + c) * wc;
             }
             W16_UNROLL for (int s = 0; s < R; s++)
-                if (isx[s]) WAT(D.dpi, k * NX + cx[s]) = a[s];
+                if (isx[s] && alive) WAT(D.dpi, k * NX + cx[s]) = a[s];
         }
         /* L' dv = -l for the free block: everything at k = 0, the inputs otherwise; dv of the states = dx for k > 0 */
         double dv[R], acc[R];
@@ -734,8 +813,8 @@ __global__ void __launch_bounds__(64) ky_fwd(GqpDev D, GqpOpts O, int redo)
         W16_UNROLL for (int r = n - 1; r >= 0; r--)
         {
             if (k > 0 && r >= NU) continue; /* uniform: states are given */
-            const double d = w16_bcast(Lr[r >> 4][r], r & 15, xb);
-            const double dvr = d != 0.0 ? W16R_BC(acc, r) * frcp(d) : 0.0;
+            const double d = W16R_BC(dg, r), ar = W16R_BC(acc, r);
+            const double dvr = d != 0.0 ? ar * frcp(d) : 0.0;
             W16_UNROLL for (int s = 0; s < R; s++)
             {
                 if (row[s] == r) dv[s] = dvr;
@@ -745,28 +824,28 @@ __global__ void __launch_bounds__(64) ky_fwd(GqpDev D, GqpOpts O, int redo)
         W16_UNROLL for (int s = 0; s < R; s++)
         {
             if (!mine[s]) dv[s] = 0.0;
-            if (CORR && mine[s]) WAT(D.dux, k * n + row[s]) = dv[s];
+            if (CORR && mine[s] && alive) WAT(D.dux, k * n + row[s]) = dv[s];
         }
-        /* dx of the next stage (column cx of [B A]' straight from memory) */
+        /* dx of the next stage */
         double dxn[R];
         W16_UNROLL for (int s = 0; s < R; s++) dxn[s] = rbv[s];
         W16_UNROLL for (int r = 0; r < n; r++)
         {
             const double dr = W16R_BC(dv, r);
-            W16_UNROLL for (int s = 0; s < R; s++) dxn[s] += WAT(D.BAt, (k * n + r) * NX + xc_[s]) * dr; /* idle slots: clamped column, value unused */
+            W16_UNROLL for (int s = 0; s < R; s++) dxn[s] += BRq[r * NX + xc_[s]] * dr; /* idle slots: clamped column, value unused */
         }
         W16_UNROLL for (int s = 0; s < R; s++)
         {
             const bool has = mine[s] && ((imask >> row[s]) & 1);
             if (has)
             {
-                const int ib = popc64(S.bmask & (((uint64_t) 1 << row[s]) - 1));
+                const int ib = popc64(bmask & (((uint64_t) 1 << row[s]) - 1));
                 const bool al = (am >> ib) & 1, au = (am >> (nbg + ib)) & 1;
-                const int el = S.o_ct + ib, eu = el + nbg;
-                const double ll = al ? WAT(D.lam, el) : 0.0, lu = au ? WAT(D.lam, eu) : 0.0;
-                const double ttl = al ? WAT(D.t, el) : 1.0, ttu = au ? WAT(D.t, eu) : 1.0;
-                const double rdl = al ? WAT(D.rd, el) : 0.0, rdu = au ? WAT(D.rd, eu) : 0.0;
-                const double pl = (CORR && al) ? WAT(D.pcorr, el) : 0.0, pu = (CORR && au) ? WAT(D.pcorr, eu) : 0.0;
+                const int el = o_ct + ib, eu = el + nbg;
+                const double ll = al ? q_ll[s] : 0.0, lu = au ? q_lu[s] : 0.0;
+                const double ttl = al ? q_tl[s] : 1.0, ttu = au ? q_tu[s] : 1.0;
+                const double rdl = al ? q_dl[s] : 0.0, rdu = au ? q_du[s] : 0.0;
+                const double pl = (CORR && al) ? q_pl[s] : 0.0, pu = (CORR && au) ? q_pu[s] : 0.0;
                 const double rml = al ? ll * ttl - O.tau_min + pscale * pl - smu : 0.0;
                 const double rmu = au ? lu * ttu - O.tau_min + pscale * pu - smu : 0.0;
                 const double dtl = al ? dv[s] + rdl : 0.0, dtu = au ? -dv[s] + rdu : 0.0;
@@ -783,18 +862,35 @@ __global__ void __launch_bounds__(64) ky_fwd(GqpDev D, GqpOpts O, int redo)
                     S1 += ll * dtl + ttl * dll + lu * dtu + ttu * dlu;
                     S2 += dll * dtl + dlu * dtu;
                     nact += (double) ((int) al + (int) au);
-                    WAT(D.pcorr, el) = dll * dtl;
-                    WAT(D.pcorr, eu) = dlu * dtu;
+                    if (alive)
+                    {
+                        WAT(D.pcorr, el) = dll * dtl;
+                        WAT(D.pcorr, eu) = dlu * dtu;
+                    }
                 }
-                else
+                else if (alive)
                 {
                     WAT(D.dlam, el) = dll; WAT(D.dlam, eu) = dlu;
                     WAT(D.dt, el) = dtl; WAT(D.dt, eu) = dtu;
                 }
             }
         }
-        W16_UNROLL for (int s = 0; s < R; s++) dx[s] = isx[s] ? dxn[s] : 0.0;
+        W16_UNROLL for (int s = 0; s < R; s++)
+        {
+            dx[s] = isx[s] ? dxn[s] : 0.0;
+            W16R_OPAQUE(dx[s]);
+        }
+        W16R_OPAQUE(alpha);
+        if (NBUF == 1 && k < D.N) dma(k + 1);
+#undef W16R_LR
 #undef W16R_LC
+    }
+    if (!alive) return; /* rows are independent from here on */
+    W16_UNROLL for (int s = 0; s < R; s++)
+    {
+        mine[s] = row[s] < n;
+        isx[s] = row[s] >= NU && row[s] < n;
+        cx[s] = isx[s] ? row[s] - NU : 0;
     }
 
     if (redo == 2) return; /* sensitivity pass: dux, dpi, dlam, dt are the result */
