@@ -65,7 +65,9 @@ __device__ static inline void w16r_dma16(const double *sbase, const double *ldsp
     asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%4\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds), "n"(IMM) : "memory");
 }
-#define W16R_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+/* (s_barrier: a no-op for a one-wave workgroup as far as synchronisation goes; the programming guide orders the reads of
+ * DMA'd data behind "vmcnt, then a barrier") */
+#define W16R_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory")
 #define W16R_LDS_DRAIN() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #else
 template <int IMM>
@@ -532,12 +534,15 @@ __global__ void __launch_bounds__(64) ky_factor(GqpDev D, GqpOpts O, int redo)
 
 /* ------------------------------------------------------------------------------- rhs-only backward (p-form) */
 
+/* PF (shapes whose rows fit the register file twice, e.g. the condensed C3 shape): everything a stage reads is loaded one
+ * stage ahead -- one wave per SIMD, nobody else hides the latency */
 template <int NX, int NU>
 __global__ void __launch_bounds__(64) ky_backrhs(GqpDev D, GqpOpts O, int redo)
 {
     GQP_DYN_SHARED(smem);
     typedef W16RLds<NX, NU> LY;
     constexpr int n = NX + NU, R = LY::R, NP = n * (n + 1) / 2, LDX = LY::LDX;
+    constexpr bool PF = R * (NU + 2 * NX + 12) <= 96;
     const int l = threadIdx.x & 15, inst = blockIdx.x * 4 + (threadIdx.x >> 4);
     if (inst >= D.B) return;
     if (D.status[inst] != GQP_RUNNING) return;
@@ -559,36 +564,72 @@ __global__ void __launch_bounds__(64) ky_backrhs(GqpDev D, GqpOpts O, int redo)
     double pn[R]; /* p of the stage handled before (state slots) */
     W16_UNROLL for (int s = 0; s < R; s++) pn[s] = 0.0;
 
-    for (int k = D.N; k >= 0; k--)
+    /* loads of one stage: row of the factor (first NU columns; x-block for state slots), row of [B A]', vectors, the
+     * slot's box row (a slot without a row reads row 0 of the stage: always readable) */
+    struct StageRegs
+    {
+        double Lu[R][NU > 0 ? NU : 1], Lx[R][NX], Br[R][NX], rb[R], rg[R], ll[R], lu[R], tl[R], tu[R], dl[R], du[R], pl[R], pu[R];
+        uint64_t am, bm, em;
+        int nb, oct;
+    };
+    auto load = [&](int k, StageRegs &G)
     {
         const GqpStage &S = D.st[k];
-        const uint64_t imask = S.bmask & ~S.emask;
-        const uint64_t am = WAT(D.amask, k * D.AW);
-        const int nbg = S.nb;
-        /* row of the factor: the first NU columns and, for state slots, the x-block; row of [B A]' */
+        G.bm = S.bmask; G.em = S.emask; G.nb = S.nb; G.oct = S.o_ct;
+        G.am = WAT(D.amask, k * D.AW);
+        W16_UNROLL for (int s = 0; s < R; s++)
+        {
+            const int lc_ = mine[s] ? row[s] : 0, xl_ = isx[s] ? row[s] : NU, xc_ = isx[s] ? cx[s] : 0;
+            W16_UNROLL for (int c = 0; c < NU; c++) G.Lu[s][c] = WAT(D.Lf, k * NP + PK(lc_, (c <= lc_ ? c : 0)));
+            W16_UNROLL for (int c = 0; c < NX; c++) G.Lx[s][c] = WAT(D.Lf, k * NP + PK(xl_, NU + (c <= xc_ ? c : 0)));
+            W16_UNROLL for (int c = 0; c < NX; c++) G.Br[s][c] = WAT(D.BAt, (k * n + lc_) * NX + c);
+            G.rb[s] = WAT(D.rb, k * NX + xc_);
+            G.rg[s] = WAT(D.rg, k * n + lc_);
+            const bool hs = mine[s] && (((S.bmask & ~S.emask) >> row[s]) & 1);
+            const int ib = hs ? popc64(S.bmask & (((uint64_t) 1 << row[s]) - 1)) : 0;
+            const int el = S.o_ct + ib, eu = el + S.nb;
+            G.ll[s] = WAT(D.lam, el); G.lu[s] = WAT(D.lam, eu);
+            G.tl[s] = WAT(D.t, el); G.tu[s] = WAT(D.t, eu);
+            G.dl[s] = WAT(D.rd, el); G.du[s] = WAT(D.rd, eu);
+            G.pl[s] = WAT(D.pcorr, el); G.pu[s] = WAT(D.pcorr, eu);
+        }
+    };
+    StageRegs Gn;
+    if (PF) load(D.N, Gn);
+
+    for (int k = D.N; k >= 0; k--)
+    {
+        StageRegs G;
+        if (PF)
+        {
+            G = Gn;
+            if (k > 0) load(k - 1, Gn);
+        }
+        else load(k, G);
+        const uint64_t imask = G.bm & ~G.em, am = G.am;
+        const int nbg = G.nb;
         double Lu[R][NU > 0 ? NU : 1], Lx[R][NX], Br[R][NX], rb[R], m[R];
         bool fixed[R];
         W16_UNROLL for (int s = 0; s < R; s++)
         {
-            const int lc_ = mine[s] ? row[s] : 0, xl_ = isx[s] ? row[s] : NU, xc_ = isx[s] ? cx[s] : 0;
+            const int lc_ = mine[s] ? row[s] : 0, xc_ = isx[s] ? cx[s] : 0;
             const double zm = mine[s] ? 1.0 : 0.0, zx = isx[s] ? 1.0 : 0.0;
-            fixed[s] = mine[s] && ((S.emask >> row[s]) & 1);
-            W16_UNROLL for (int c = 0; c < NU; c++) Lu[s][c] = (c <= lc_ ? zm : 0.0) * WAT(D.Lf, k * NP + PK(lc_, (c <= lc_ ? c : 0)));
-            W16_UNROLL for (int c = 0; c < NX; c++) Lx[s][c] = (c <= xc_ ? zx : 0.0) * WAT(D.Lf, k * NP + PK(xl_, NU + (c <= xc_ ? c : 0)));
-            W16_UNROLL for (int c = 0; c < NX; c++) Br[s][c] = zm * WAT(D.BAt, (k * n + lc_) * NX + c);
-            rb[s] = zx * WAT(D.rb, k * NX + xc_);
-            m[s] = zm * WAT(D.rg, k * n + lc_);
+            fixed[s] = mine[s] && ((G.em >> row[s]) & 1);
+            W16_UNROLL for (int c = 0; c < NU; c++) Lu[s][c] = (c <= lc_ ? zm : 0.0) * G.Lu[s][c];
+            W16_UNROLL for (int c = 0; c < NX; c++) Lx[s][c] = (c <= xc_ ? zx : 0.0) * G.Lx[s][c];
+            W16_UNROLL for (int c = 0; c < NX; c++) Br[s][c] = zm * G.Br[s][c];
+            rb[s] = zx * G.rb[s];
+            m[s] = zm * G.rg[s];
             const bool has = mine[s] && ((imask >> row[s]) & 1);
             if (has)
             {
-                const int ib = popc64(S.bmask & (((uint64_t) 1 << row[s]) - 1));
+                const int ib = popc64(G.bm & (((uint64_t) 1 << row[s]) - 1));
                 const bool al = (am >> ib) & 1, au = (am >> (nbg + ib)) & 1;
-                const int el = S.o_ct + ib, eu = el + nbg;
-                const double ll = al ? WAT(D.lam, el) : 0.0, lu = au ? WAT(D.lam, eu) : 0.0;
-                const double ttl = al ? WAT(D.t, el) : 1.0, ttu = au ? WAT(D.t, eu) : 1.0;
-                const double rdl = al ? WAT(D.rd, el) : 0.0, rdu = au ? WAT(D.rd, eu) : 0.0;
-                const double rml = al ? ll * ttl - O.tau_min + pscale * WAT(D.pcorr, el) - smu : 0.0;
-                const double rmu = au ? lu * ttu - O.tau_min + pscale * WAT(D.pcorr, eu) - smu : 0.0;
+                const double ll = al ? G.ll[s] : 0.0, lu = au ? G.lu[s] : 0.0;
+                const double ttl = al ? G.tl[s] : 1.0, ttu = au ? G.tu[s] : 1.0;
+                const double rdl = al ? G.dl[s] : 0.0, rdu = au ? G.du[s] : 0.0;
+                const double rml = al ? ll * ttl - O.tau_min + pscale * G.pl[s] - smu : 0.0;
+                const double rmu = au ? lu * ttu - O.tau_min + pscale * G.pu[s] - smu : 0.0;
                 m[s] += (rml + ll * rdl) * frcp(ttl) - (rmu + lu * rdu) * frcp(ttu);
             }
         }
@@ -618,12 +659,15 @@ __global__ void __launch_bounds__(64) ky_backrhs(GqpDev D, GqpOpts O, int redo)
         /* l_u = Lr^{-1} m_u; the rows below keep m_r -= L[r][j] l_j, which leaves p in the state slots */
         W16_UNROLL for (int j = 0; j < NU; j++)
         {
-            const double d = w16_bcast(Lu[j >> 4][j], j & 15, xb);
-            const double lj = d != 0.0 ? W16R_BC(m, j) * frcp(d) : 0.0;
+            const double d = w16_bcast(Lu[j >> 4][j], j & 15, xb), mj = W16R_BC(m, j);
+            const double lj = d != 0.0 ? mj * frcp(d) : 0.0;
             W16_UNROLL for (int s = 0; s < R; s++) m[s] = row[s] == j ? lj : (row[s] > j ? m[s] - Lu[s][j] * lj : m[s]);
         }
         W16_UNROLL for (int s = 0; s < R; s++)
+        {
+            W16R_OPAQUE(m[s]);
             if (mine[s]) WAT(D.lf, k * n + row[s]) = m[s];
+        }
         /* this stage's x-block becomes "the stage handled before" */
         GQP_ROWSYNC();
         W16_UNROLL for (int s = 0; s < R; s++)
@@ -764,16 +808,21 @@ __global__ void __launch_bounds__(64) ky_fwd(GqpDev D, GqpOpts O, int redo)
          * this slot's variable (zero above the diagonal) */
 #define W16R_LR(s, c) ((mine[s] && (c) <= row[s]) ? LF[PK(lc_[s], 0) + (c)] : 0.0)
 #define W16R_LC(s, r) ((mine[s] && (r) >= row[s]) ? LF[PK((r), 0) + lc_[s]] : 0.0)
-        double dg[R]; /* diagonal entry of this slot's row */
-        W16_UNROLL for (int s = 0; s < R; s++) dg[s] = mine[s] ? W16R_LR(s, lc_[s]) : 0.0;
+        /* reciprocal of the diagonal entry of this slot's row (0 for a zero pivot): every slot computes its own once, the
+         * substitutions below broadcast it -- no reciprocal in their dependent chains */
+        double dg[R];
+        W16_UNROLL for (int s = 0; s < R; s++)
+        {
+            const double d = mine[s] ? W16R_LR(s, lc_[s]) : 0.0;
+            dg[s] = d != 0.0 ? frcp(d) : 0.0;
+        }
 
         if (PFORM && k == 0)
         {
             /* the states of stage 0 are free: recover l_x = Lx^{-1} p */
             W16_UNROLL for (int j = NU; j < n; j++)
             {
-                const double d = W16R_BC(dg, j), lvj = W16R_BC(lv, j); /* both broadcasts unconditionally: the rows of a wave stay in step */
-                const double lj = d != 0.0 ? lvj * frcp(d) : 0.0;
+                const double lj = W16R_BC(lv, j) * W16R_BC(dg, j);
                 W16_UNROLL for (int s = 0; s < R; s++)
                     if (W16R_LOW(s, j)) lv[s] = row[s] == j ? lj : (row[s] > j ? lv[s] - W16R_LR(s, j) * lj : lv[s]);
             }
@@ -813,8 +862,7 @@ __global__ void __launch_bounds__(64) ky_fwd(GqpDev D, GqpOpts O, int redo)
         W16_UNROLL for (int r = n - 1; r >= 0; r--)
         {
             if (k > 0 && r >= NU) continue; /* uniform: states are given */
-            const double d = W16R_BC(dg, r), ar = W16R_BC(acc, r);
-            const double dvr = d != 0.0 ? ar * frcp(d) : 0.0;
+            const double dvr = W16R_BC(acc, r) * W16R_BC(dg, r);
             W16_UNROLL for (int s = 0; s < R; s++)
             {
                 if (row[s] == r) dv[s] = dvr;
