@@ -102,6 +102,7 @@ struct ocp_qp_gpu_batch
     size_t shmem_fact = 0; /* dynamic LDS bytes of the factor sweep */
     bool w16_soft = false; /* ... with soft box rows (one slack per row) */
     KernelSet wpi_ks;      /* the wave-per-instance set of the same padded dims (fallback of w16_soft) */
+    int w16_slots = 0;     /* row slots a sweep launch covers: B, or the live instances once GqpDev::perm lists them */
     size_t w16_shmem = 0;  /* dynamic LDS bytes of a 16-lanes-per-instance workgroup (4 instances) */
     KernelSet own_ks;     /* runtime-shaped kernel set of a wpi batch (ks points here) */
     int xbox = 0;
@@ -109,7 +110,7 @@ struct ocp_qp_gpu_batch
     std::string kname;
     std::vector<GqpStage> st;
     GqpStage *d_st = nullptr;
-    GqpDev D;
+    GqpDev D = {};
     GqpOpts O;
     int nct_tot = 0, ns2_tot = 0, ng_tot = 0;
     std::vector<void *> allocs;
@@ -119,6 +120,7 @@ struct ocp_qp_gpu_batch
     int *d_map = nullptr;
     int map_cap = 0;
     int *h_nact = nullptr; /* pinned */
+    int *d_perm = nullptr, *d_perm_cnt = nullptr; /* sixteen-lanes sweeps: dense list of the still-iterating instances */
     int *h_ints = nullptr; /* pinned, 2 * Bp ints: per-instance status / iteration read-backs of a solve (no heap traffic per call) */
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -376,6 +378,7 @@ void finalize_structure(ocp_qp_gpu_batch *b)
     b->stat_inst = b->B < 64 ? b->B : 64;
     b->stat_rows = 0;
     D.stat = nullptr; D.stat_inst = 0; D.stat_rows = 0;
+    D.perm = nullptr; D.n_perm = 0;
 
     /* neutral padding: unit Hessian diagonal on padded variables */
     const int grid = (b->B + 63) / 64;
@@ -789,6 +792,7 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
                     b->own_ks.box_fwd_aff[q] = ka; b->own_ks.box_fwd_corr[q] = kc;
                 }
                 b->w16 = 1;
+                b->w16_slots = n_batch;
                 b->w16_soft = soft_dims;
                 b->w16_shmem = ws.shmem;
             }
@@ -1234,7 +1238,7 @@ struct IpmKernels
 /* the four sweeps: 16-lanes-per-instance batches pack 4 instances into one 64-lane workgroup */
 #define GQP_SWEEP_LAUNCH(b, kern, shm, s, ...)                                                                \
     do {                                                                                                      \
-        if ((b)->w16) GQP_LAUNCH_COOP(kern, dim3(((b)->B + 3) / 4), dim3(64), (b)->w16_shmem, s, __VA_ARGS__);  \
+        if ((b)->w16) GQP_LAUNCH_COOP(kern, dim3(((b)->w16_slots + 3) / 4), dim3(64), (b)->w16_shmem, s, __VA_ARGS__);  \
         else GQP_IPM_LAUNCH_SHM(b, kern, shm, s, __VA_ARGS__);                                                \
     } while (0)
 
@@ -1292,6 +1296,11 @@ static void run_ipm(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch *root, Prof &prof, hip
     const IpmKernels K = pick_kernels(b);
     GqpDev D = b->D;
     GqpOpts O = effective_opts(root->O);
+    b->w16_slots = b->B;
+    /* sixteen lanes per instance: once a sixth of the slots has converged the sweeps run over a dense list of the live
+     * instances (row slot -> instance, GqpDev::perm) -- no data moves, the grid shrinks, every wave carries four live rows */
+    const char *eperm = getenv("ACADOS_AMD_W16_PERM");
+    const bool use_perm = b->w16 && !(eperm && atoi(eperm) == 0);
     for (;; it++)
     {
         if (b == root) prof.begin(1, s); /* per-class timing covers the root level only (full-batch launches) */
@@ -1303,6 +1312,15 @@ static void run_ipm(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch *root, Prof &prof, hip
         const int nact = *b->h_nact;
         if (root->print_level > 1) printf("acados_amd: ipm iter %d level size %d active %d\n", it, b->B, nact);
         if (nact <= 0 || it > O.iter_max) break;
+        if (use_perm && nact >= 1 && 6 * nact <= 5 * b->w16_slots)
+        {
+            if (!b->d_perm) { b->d_perm = dalloc<int>(b, b->Bp); b->d_perm_cnt = dalloc<int>(b, 1); }
+            HIPCHK(hipMemsetAsync(b->d_perm_cnt, 0, sizeof(int), s));
+            hipLaunchKernelGGL(gqp::k_active_perm, dim3((b->B + 255) / 256), dim3(256), 0, s, D, b->d_perm, b->d_perm_cnt);
+            D.perm = b->d_perm;
+            D.n_perm = nact;
+            b->w16_slots = nact;
+        }
         if (!b->wpi && root->tail_max > 0 && nact <= root->tail_max && 4 * nact <= b->B)
         {
             /* the last survivors of a one-instance-per-lane level: a wave that still has ONE active lane pays
@@ -1343,6 +1361,7 @@ static void run_ipm(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch *root, Prof &prof, hip
             root->launches += 2;
         }
     }
+    b->w16_slots = b->B; /* launches outside this loop (sensitivity passes) cover every instance again */
 }
 
 /* arrays that define a QP instance and its iterate (everything else is recomputed) */

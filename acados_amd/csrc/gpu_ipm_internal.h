@@ -98,6 +98,11 @@ struct GqpDev
     int *n_active; /* single counter: instances still iterating */
     double *stat;  /* [stat_rows][STAT_COLS][Bp_stat] for the first stat_inst instances */
     int stat_inst, stat_rows;
+    /* sixteen-lanes-per-instance sweeps: row slot -> instance.  Null: slot = instance.  Otherwise the n_perm instances that
+     * are still iterating, listed densely (rebuilt by k_active_perm as they converge): the grid shrinks with them and every
+     * wave carries four live rows instead of paying a whole sweep for one */
+    const int *perm;
+    int n_perm;
 };
 
 #define GQP_STAT_COLS 20

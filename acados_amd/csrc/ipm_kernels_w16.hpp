@@ -79,6 +79,20 @@ struct W16Lds
 
 #define W16_UNROLL _Pragma("unroll")
 
+/* instance of row slot `slot` (GqpDev::perm), -1 beyond the live ones */
+__device__ static inline int w16_slot_inst(const GqpDev &D, int slot)
+{
+    if (!D.perm) return slot < D.B ? slot : -1;
+    return slot < D.n_perm ? D.perm[slot] : -1;
+}
+/* the still-iterating instances, densely: one thread per instance, order of arrival (the placement of an instance does not
+ * enter its arithmetic) */
+static __global__ void k_active_perm(GqpDev D, int *perm, int *count)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < D.B && D.status[i] == GQP_RUNNING) perm[atomicAdd(count, 1)] = i;
+}
+
 /* reductions over the 16 lanes of a row (result in every lane) */
 __device__ static inline double w16_rmax(double v, double *xb)
 {
@@ -128,8 +142,8 @@ __global__ void __launch_bounds__(64) kx_factor(GqpDev D, GqpOpts O, int redo)
     GQP_DYN_SHARED(smem);
     typedef W16Lds<NX, NU> LY;
     constexpr int n = NX + NU, NP = n * (n + 1) / 2, LDX = LY::LDX;
-    const int l = threadIdx.x & 15, inst = blockIdx.x * 4 + (threadIdx.x >> 4);
-    if (inst >= D.B) return;
+    const int l = threadIdx.x & 15, inst = w16_slot_inst(D, blockIdx.x * 4 + (threadIdx.x >> 4));
+    if (inst < 0) return;
     if (D.status[inst] != GQP_RUNNING) return;
     double *T = smem + (threadIdx.x >> 4) * LY::SZ, *xb = T + LY::XB;
     double *TA = T + LY::TA; /* x-block of the factor of stage k+1, [q][c] */
@@ -354,8 +368,8 @@ __global__ void __launch_bounds__(64) kx_backrhs(GqpDev D, GqpOpts O, int redo)
     GQP_DYN_SHARED(smem);
     typedef W16Lds<NX, NU> LY;
     constexpr int n = NX + NU, NP = n * (n + 1) / 2, LDX = LY::LDX;
-    const int l = threadIdx.x & 15, inst = blockIdx.x * 4 + (threadIdx.x >> 4);
-    if (inst >= D.B) return;
+    const int l = threadIdx.x & 15, inst = w16_slot_inst(D, blockIdx.x * 4 + (threadIdx.x >> 4));
+    if (inst < 0) return;
     if (D.status[inst] != GQP_RUNNING) return;
     if (redo == 1 && !(D.alpha[inst] < 0.0)) return; /* redo = 2: sensitivity pass (direction only, every instance) */
     double *T = smem + (threadIdx.x >> 4) * LY::SZ, *xb = T + LY::XB, *TA = T + LY::TA;
@@ -471,8 +485,8 @@ __global__ void __launch_bounds__(64) kx_fwd(GqpDev D, GqpOpts O, int redo)
     typedef W16Lds<NX, NU> LY;
     constexpr bool PFORM = CORR;
     constexpr int n = NX + NU, NP = n * (n + 1) / 2, LDF = LY::LDF;
-    const int l = threadIdx.x & 15, inst = blockIdx.x * 4 + (threadIdx.x >> 4);
-    if (inst >= D.B) return;
+    const int l = threadIdx.x & 15, inst = w16_slot_inst(D, blockIdx.x * 4 + (threadIdx.x >> 4));
+    if (inst < 0) return;
     if (D.status[inst] != GQP_RUNNING) return;
     if (redo == 1 && !(D.alpha[inst] < 0.0)) return; /* redo = 2: sensitivity pass (direction only, every instance) */
     double *T = smem + (threadIdx.x >> 4) * LY::SZ, *xb = T + LY::XB, *TF = T + LY::TF;

@@ -144,18 +144,18 @@ __global__ void __launch_bounds__(64) ky_factor(GqpDev D, GqpOpts O, int redo)
     /* Liveness per 16-lane row.  No row leaves the kernel while another one of the wave is alive: all 64 lanes take part
      * in the LDS-DMA of every live row.  A dead row (converged instance, or beyond the batch) computes on the data of a
      * valid instance and writes nothing. */
-    const int inst0 = blockIdx.x * 4, Bm1 = D.B - 1;
+    const int inst0 = blockIdx.x * 4;
     bool aq[4], any = false, alive = false;
-    int iq[4];
+    int iq[4], inst = 0;
     W16_UNROLL for (int q = 0; q < 4; q++)
     {
-        iq[q] = inst0 + q <= Bm1 ? inst0 + q : Bm1;
-        aq[q] = inst0 + q <= Bm1 && D.status[iq[q]] == GQP_RUNNING;
+        const int ir = w16_slot_inst(D, inst0 + q);
+        iq[q] = ir >= 0 ? ir : D.B - 1;
+        aq[q] = ir >= 0 && D.status[iq[q]] == GQP_RUNNING;
         any = any || aq[q];
-        if (q == rq) alive = aq[q];
+        if (q == rq) { alive = aq[q]; inst = iq[q]; }
     }
     if (!any) return;
-    const int inst = inst0 + rq <= Bm1 ? inst0 + rq : Bm1;
     double *T = smem + rq * LY::SZ, *xb = T + LY::XB;
     double *HRq = T + LY::HR; /* packed H block of the stage */
     double *BRq = T + LY::BR; /* [B A]' block of the stage, [row][NX]; later the x-block of the previous factor, [q][NX] */
@@ -543,8 +543,8 @@ __global__ void __launch_bounds__(64) ky_backrhs(GqpDev D, GqpOpts O, int redo)
     typedef W16RLds<NX, NU> LY;
     constexpr int n = NX + NU, R = LY::R, NP = n * (n + 1) / 2, LDX = LY::LDX;
     constexpr bool PF = R * (NU + 2 * NX + 12) <= 96;
-    const int l = threadIdx.x & 15, inst = blockIdx.x * 4 + (threadIdx.x >> 4);
-    if (inst >= D.B) return;
+    const int l = threadIdx.x & 15, inst = w16_slot_inst(D, blockIdx.x * 4 + (threadIdx.x >> 4));
+    if (inst < 0) return;
     if (D.status[inst] != GQP_RUNNING) return;
     if (redo == 1 && !(D.alpha[inst] < 0.0)) return; /* redo = 2: sensitivity pass (direction only, every instance) */
     double *T = smem + (threadIdx.x >> 4) * LY::SZ, *xb = T + LY::XB, *TA = T + LY::TA;
@@ -695,18 +695,18 @@ __global__ void __launch_bounds__(64) ky_fwd(GqpDev D, GqpOpts O, int redo)
     constexpr bool PFORM = CORR;
     constexpr int n = NX + NU, R = LY::R, NP = LY::NP, NB = LY::NB, NBUF = LY::NBUF;
     const int l = threadIdx.x & 15, rq = threadIdx.x >> 4;
-    const int inst0 = blockIdx.x * 4, Bm1 = D.B - 1;
+    const int inst0 = blockIdx.x * 4;
     bool aq[4], any = false, alive = false;
-    int iq[4];
+    int iq[4], inst = 0;
     W16_UNROLL for (int q = 0; q < 4; q++)
     {
-        iq[q] = inst0 + q <= Bm1 ? inst0 + q : Bm1;
-        aq[q] = inst0 + q <= Bm1 && D.status[iq[q]] == GQP_RUNNING && !(redo == 1 && !(D.alpha[iq[q]] < 0.0));
+        const int ir = w16_slot_inst(D, inst0 + q);
+        iq[q] = ir >= 0 ? ir : D.B - 1;
+        aq[q] = ir >= 0 && D.status[iq[q]] == GQP_RUNNING && !(redo == 1 && !(D.alpha[iq[q]] < 0.0));
         any = any || aq[q];
-        if (q == rq) alive = aq[q];
+        if (q == rq) { alive = aq[q]; inst = iq[q]; }
     }
     if (!any) return; /* redo = 1: only the instances whose corrector step was rejected; redo = 2: sensitivity pass */
-    const int inst = inst0 + rq <= Bm1 ? inst0 + rq : Bm1;
     double *T = smem + rq * LY::SZ, *xb = T + LY::XB;
     int row[R], cx[R];
     bool mine[R], isx[R];
