@@ -275,7 +275,9 @@ def other_configs(c2_batch, c2_data, args):
     out["C3"]["cond_N_active"] = int(c2_batch.scalar("cond_N_active"))
     ck = c2_batch.condensed_kernel_name()
     if ck:   # the IPM sweeps of a condensed solve run on the condensed batch's kernels
-        out["C3"]["kernel"] = f"kw_pcond + {ck} + kw_pexpand"
+        pk = {2: "kz_pcond", 1: "k_pcond", 0: "kw_pcond"}.get(int(c2_batch.scalar("pcond_kernel")), "pcond")
+        ek = {1: "k_pexpand", 0: "kw_pexpand"}.get(int(c2_batch.scalar("pexpand_kernel")), "pexpand")
+        out["C3"]["kernel"] = f"{pk} + {ck} + {ek}"
         out["C3"]["roofline"]["kernel"] = out["C3"]["roofline"]["kernel"].replace(c2_batch.kernel_name, ck).replace("kb_", "kw_")
     c2_batch.opts_set("cond_N", N)
     # C4

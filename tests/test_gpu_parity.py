@@ -735,3 +735,73 @@ def test_concurrent_solvers_from_host_threads_gpu(gpu_lib):
         assert len(par.get(i, [])) == 8
         for a, c in zip(seq[i], par[i]):
             assert np.array_equal(a, c), i
+
+
+@pytest.mark.gpu
+def test_two_rows_per_lane_family_gpu(gpu_lib, monkeypatch):
+    """ipm_kernels_w16r.hpp on the device (LDS-DMA staging, register rows, dense list of the live instances): the
+    nx=24 nu=6 class and the condensed C3 shape against the oracle, and against the wave-per-instance kernels on the
+    same batch -- equal iteration counts, iterates equal to rounding; the dense-list launches (ACADOS_AMD_W16_PERM)
+    change nothing in the results.  Ragged batch: 4 k + 3 instances."""
+    from acados_amd import OcpQpGpuBatch
+    from acados_amd.generators import fill_lqr_batch, lqr_dims, lqr_instance_qp, random_lqr_batch
+    for nx, nu, N, B in ((24, 6, 12, 1027), (8, 15, 6, 515), (20, 5, 8, 259)):
+        data = random_lqr_batch(N=N, nx=nx, nu=nu, batch=B, seed=11 + nx)
+        sols = {}
+        for tag, env in (("w16r", {"ACADOS_AMD_W16R": "1", "ACADOS_AMD_W16_PERM": "1"}),
+                         ("noperm", {"ACADOS_AMD_W16R": "1", "ACADOS_AMD_W16_PERM": "0"}),
+                         ("wpi", {"ACADOS_AMD_W16R": "0", "ACADOS_AMD_W16_PERM": "1"})):
+            for k_, v_ in env.items():
+                monkeypatch.setenv(k_, v_)
+            gb = OcpQpGpuBatch(lqr_dims(N, nx, nu), B)
+            fill_lqr_batch(gb, data, N)
+            for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+                gb.opts_set(f, 1e-8)
+            assert gb.solve() == 0
+            assert gb.kernel_name.startswith("wpi-box(" if tag == "wpi" else "w16r-box<"), gb.kernel_name
+            assert gb.res_compute().max() <= KKT_TOL
+            sols[tag] = ([gb.get(f, k) for f in ("x", "u", "lam") for k in range(N + 1)] + [gb.get("pi", k) for k in range(N)],
+                         gb.info("iter").copy())
+            if tag == "w16r":
+                for i in (0, B // 2, B - 1):
+                    qp = lqr_instance_qp(data, i, N)
+                    o = OracleQp(qp)
+                    assert o.solve(default_opts(tol_stat=1e-8)) == 0
+                    compare_with_oracle(lambda k, f: gb.get(f, k)[i], o, qp, 1e-8)
+            del gb
+        assert np.array_equal(sols["w16r"][1], sols["wpi"][1]) and np.array_equal(sols["w16r"][1], sols["noperm"][1])
+        for a, b_ in zip(sols["w16r"][0], sols["noperm"][0]):
+            assert np.array_equal(a, b_)
+        for a, b_ in zip(sols["w16r"][0], sols["wpi"][0]):
+            if a.size:
+                np.testing.assert_allclose(a, b_, rtol=1e-9, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_condensing_kernel_pairs_agree_gpu(gpu_lib, monkeypatch):
+    """C3 shape: condensing sixteen lanes per block + expansion one instance per lane (the default for a wave-tiled parent)
+    against the run-time-shaped wave-per-instance pair: same condensed solve, expanded solutions equal to rounding;
+    batch 4 k + 1 (a row group with three rows beyond the batch)"""
+    from acados_amd import OcpQpGpuBatch
+    from acados_amd.generators import fill_lqr_batch, lqr_dims, random_lqr_batch
+    N, B = 50, 20481
+    data = random_lqr_batch(N=N, batch=B, seed=2)
+    sols = []
+    for z, le, want in (("1", "1", (2, 1)), ("0", "0", (0, 0))):
+        monkeypatch.setenv("ACADOS_AMD_PCOND_W16", z)
+        monkeypatch.setenv("ACADOS_AMD_PCOND_LANE_EXPAND", le)
+        gb = OcpQpGpuBatch(lqr_dims(N, 8, 3), B)
+        fill_lqr_batch(gb, data, N)
+        for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+            gb.opts_set(f, 1e-8)
+        gb.opts_set("cond_N", 10)
+        assert gb.solve() == 0
+        assert (int(gb.scalar("pcond_kernel")), int(gb.scalar("pexpand_kernel"))) == want
+        assert gb.res_compute().max() <= 2e-8
+        sols.append(([gb.get(f, k) for f in ("x", "u", "lam") for k in range(N + 1)] + [gb.get("pi", k) for k in range(N)],
+                     gb.info("iter").copy()))
+        del gb
+    assert np.array_equal(sols[0][1], sols[1][1])
+    for a, b_ in zip(sols[0][0], sols[1][0]):
+        if a.size:
+            np.testing.assert_allclose(a, b_, rtol=1e-7, atol=1e-9)
