@@ -55,21 +55,25 @@ const KernelSet g_ksets[] = {
 /* sixteen-lanes-per-instance sweeps (ipm_kernels_w16.hpp): compiled (NX, NU) with nu + nx <= 16 */
 struct W16Set
 {
-    int NX, NU;
+    int NX, NU, NG; /* NG > 0: two-rows-per-lane GEN kernels (general rows + one slack per row) in the SOFT slots */
     kern_redo_t fact, rhs, faff, fcor;
     kern_redo_t sfact, srhs, sfaff, sfcor; /* SOFT variants: soft box rows, one slack per row */
     size_t shmem;
 };
 #define GQP_W16(NX, NU)                                                                                       \
-    {NX, NU, gqp::kx_factor<NX, NU>, gqp::kx_backrhs<NX, NU>, gqp::kx_fwd<NX, NU, false>, gqp::kx_fwd<NX, NU, true>, \
+    {NX, NU, 0, gqp::kx_factor<NX, NU>, gqp::kx_backrhs<NX, NU>, gqp::kx_fwd<NX, NU, false>, gqp::kx_fwd<NX, NU, true>, \
      gqp::kx_factor<NX, NU, true>, gqp::kx_backrhs<NX, NU, true>, gqp::kx_fwd<NX, NU, false, true>,            \
      gqp::kx_fwd<NX, NU, true, true>, 4 * gqp::W16Lds<NX, NU>::SZ * sizeof(double)}
 /* ... and with 17 <= nu + nx <= 32 (ipm_kernels_w16r.hpp: two rows per lane; box rows without slacks) */
 #define GQP_W16R(NX, NU)                                                                                      \
-    {NX, NU, gqp::ky_factor<NX, NU>, gqp::ky_backrhs<NX, NU>, gqp::ky_fwd<NX, NU, false>, gqp::ky_fwd<NX, NU, true>, \
+    {NX, NU, 0, gqp::ky_factor<NX, NU>, gqp::ky_backrhs<NX, NU>, gqp::ky_fwd<NX, NU, false>, gqp::ky_fwd<NX, NU, true>, \
      nullptr, nullptr, nullptr, nullptr, 4 * gqp::W16RLds<NX, NU>::SZ * sizeof(double)}
+/* ... with general rows and slacks (one slack per row): the C4 class */
+#define GQP_W16G(NX, NU, NG)                                                                                  \
+    {NX, NU, NG, nullptr, nullptr, nullptr, nullptr, gqp::ky_factor<NX, NU, NG>, gqp::ky_backrhs<NX, NU, NG>,     \
+     gqp::ky_fwd<NX, NU, false, NG>, gqp::ky_fwd<NX, NU, true, NG>, 4 * gqp::W16RLds<NX, NU, NG>::SZ * sizeof(double)}
 const W16Set g_w16_sets[] = {GQP_W16(4, 1), GQP_W16(8, 3), GQP_W16(12, 3), GQP_W16(4, 4), GQP_W16(12, 4),
-                             GQP_W16R(8, 15), GQP_W16R(24, 6)};
+                             GQP_W16R(8, 15), GQP_W16R(24, 6), GQP_W16G(24, 3, 4)};
 
 /* condensing of the box-only class on register rows, sixteen lanes per block (pcond_kernels_w16.hpp): compiled
  * (NX, NU, block size) with nx + bs * nu <= 32 */
@@ -101,6 +105,7 @@ struct ocp_qp_gpu_batch
     size_t shmem_fwd = 0; /* ... of the forward sweeps (one factor buffer instead of two) */
     size_t shmem_fact = 0; /* dynamic LDS bytes of the factor sweep */
     bool w16_soft = false; /* ... with soft box rows (one slack per row) */
+    int w16_ng = 0;        /* ... of the GEN two-rows-per-lane set: general rows per stage it carries (slacks on them too) */
     KernelSet wpi_ks;      /* the wave-per-instance set of the same padded dims (fallback of w16_soft) */
     int w16_slots = 0;     /* row slots a sweep launch covers: B, or the live instances once GqpDev::perm lists them */
     size_t w16_shmem = 0;  /* dynamic LDS bytes of a 16-lanes-per-instance workgroup (4 instances) */
@@ -296,9 +301,11 @@ void finalize_structure(ocp_qp_gpu_batch *b)
         {
             const GqpStage &S = b->st[k];
             std::vector<int> refs(S.ns, 0);
-            for (int r = 0; r < S.nb; r++)
+            for (int r = 0; r < S.nb + (b->w16_ng ? S.ng : 0); r++)
                 if (S.srev[r] >= 0) refs[S.srev[r]]++;
             for (int q = 0; q < S.ns; q++) ok = ok && refs[q] == 1;
+            if (!b->w16_ng) ok = ok && S.ng == 0;
+            else ok = ok && __builtin_popcountll(S.bmask & ~S.emask) + S.ng <= 16; /* GEN: one inequality row per lane */
             for (size_t e = 0; e < b->idxe[k].size(); e++) ok = ok && b->idxs_rev[k][b->idxe[k][e]] < 0;
         }
         if (!ok)
@@ -702,11 +709,14 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
         const W16Set *w16 = nullptr;
         {
             const char *e16 = getenv("ACADOS_AMD_W16"), *e16r = getenv("ACADOS_AMD_W16R");
-            if ((!gen || soft_dims) && !need_wpi && !ref && !(e16 && atoi(e16) == 0))
+            const char *e16g = getenv("ACADOS_AMD_W16G");
+            if (!need_wpi && !ref && !(e16 && atoi(e16) == 0))
                 for (const W16Set &ws : g_w16_sets)
                 {
                     bool fits = force_NX ? (ws.NX == wx && ws.NU == wu) : (ws.NX >= wx && ws.NU >= wu);
-                    if (soft_dims && !ws.sfact) fits = false; /* the two-rows-per-lane sets carry no slacks */
+                    if (!gen) fits = fits && ws.fact && ws.NG == 0;
+                    else if (soft_dims) fits = fits && ws.sfact && ws.NG == 0;                       /* slacks on box rows only */
+                    else fits = fits && ws.sfact && ws.NG >= mg && !(e16g && atoi(e16g) == 0);      /* general rows */
                     if (ws.NX + ws.NU > 16 && (e16r && atoi(e16r) == 0)) fits = false;
                     if (fits && (!w16 || ws.NX + ws.NU < w16->NX + w16->NU)) w16 = &ws;
                 }
@@ -783,8 +793,8 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
             {
                 const W16Set &ws = *w16;
                 b->wpi_ks = b->own_ks; /* what the batch falls back to if the slack structure is not one-slack-per-box-row */
-                const kern_redo_t kf = soft_dims ? ws.sfact : ws.fact, kr = soft_dims ? ws.srhs : ws.rhs;
-                const kern_redo_t ka = soft_dims ? ws.sfaff : ws.faff, kc = soft_dims ? ws.sfcor : ws.fcor;
+                const kern_redo_t kf = gen ? ws.sfact : ws.fact, kr = gen ? ws.srhs : ws.rhs;
+                const kern_redo_t ka = gen ? ws.sfaff : ws.faff, kc = gen ? ws.sfcor : ws.fcor;
                 b->own_ks.back_fact = kf; b->own_ks.back_rhs = kr; b->own_ks.fwd_aff = ka; b->own_ks.fwd_corr = kc;
                 for (int q = 0; q < 2; q++)
                 {
@@ -793,7 +803,8 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
                 }
                 b->w16 = 1;
                 b->w16_slots = n_batch;
-                b->w16_soft = soft_dims;
+                b->w16_soft = gen;
+                b->w16_ng = ws.NG;
                 b->w16_shmem = ws.shmem;
             }
             const size_t con = gqp::wpi_con_doubles(wx + wu, mg, ms);
@@ -809,7 +820,8 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
         return nullptr;
     }
     char nm[128];
-    if (b->w16) snprintf(nm, sizeof(nm), b->w16_soft ? "w16-soft<NX=%d,NU=%d>" : b->ks->NX + b->ks->NU > 16 ? "w16r-box<NX=%d,NU=%d>" : "w16-box<NX=%d,NU=%d>", b->ks->NX, b->ks->NU);
+    if (b->w16 && b->w16_ng) snprintf(nm, sizeof(nm), "w16r-gen<NX=%d,NU=%d,NG=%d>", b->ks->NX, b->ks->NU, b->w16_ng);
+    else if (b->w16) snprintf(nm, sizeof(nm), b->w16_soft ? "w16-soft<NX=%d,NU=%d>" : b->ks->NX + b->ks->NU > 16 ? "w16r-box<NX=%d,NU=%d>" : "w16-box<NX=%d,NU=%d>", b->ks->NX, b->ks->NU);
     else if (b->wpi && (b->ks->NG || b->ks->NS))
         snprintf(nm, sizeof(nm), "wpi-gen(nx=%d,nu=%d,ng=%d,ns=%d,lds=%zuB%s)", b->ks->NX, b->ks->NU, b->ks->NG, b->ks->NS, b->shmem_fact, b->wpi_mfma ? ",mfma" : "");
     else if (b->wpi) snprintf(nm, sizeof(nm), "wpi-box(nx=%d,nu=%d,lds=%zuB%s)", b->ks->NX, b->ks->NU, b->wpi_mfma ? b->shmem_fact : b->shmem, b->wpi_mfma ? ",mfma" : "");
@@ -1401,7 +1413,7 @@ static void compact_into(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch *root, int nact, 
         c->idxb = b->idxb; c->idxs_rev = b->idxs_rev; c->idxe = b->idxe; c->nbxe = b->nbxe;
         c->compact_min = b->compact_min;
         c->tail_max = b->tail_max;
-        if (!tail) { c->aos = b->aos; c->wpi = b->wpi; c->shmem = b->shmem; c->shmem_fwd = b->shmem_fwd; c->shmem_fact = b->shmem_fact; c->w16 = b->w16; c->w16_soft = b->w16_soft; c->w16_shmem = b->w16_shmem; }
+        if (!tail) { c->aos = b->aos; c->wpi = b->wpi; c->shmem = b->shmem; c->shmem_fwd = b->shmem_fwd; c->shmem_fact = b->shmem_fact; c->w16 = b->w16; c->w16_soft = b->w16_soft; c->w16_ng = b->w16_ng; c->w16_shmem = b->w16_shmem; }
         finalize_structure(c);
         slot = c;
     }

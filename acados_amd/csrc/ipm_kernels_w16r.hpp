@@ -33,19 +33,21 @@ namespace gqp
  * of the stage as it lies in memory, and BR, its [B A]' block as it lies in memory (BR also carries the transposition tile
  * of the previous factor's x-block once the stage is done with [B A]').
  * rhs-only sweep: exchange buffer + the square x-block tile; forward sweep: exchange buffer + the full factor tile. */
-template <int NX, int NU>
+template <int NX, int NU, int NG = 0>
 struct W16RLds
 {
     static constexpr int n = NX + NU, R = (n + 15) / 16, LDX = NX + 1, LDF = n + 1, NP = n * (n + 1) / 2, NB = n * NX;
+    /* GEN variants: general rows [D C] of the stage, [g][n], + four 16-entry row vectors (value in, gamma / gadd / dlam out) */
+    static constexpr int GSZ = NG > 0 ? ((NG * n + 1) & ~1) + 80 : 0, RWO = (NG * n + 1) & ~1; /* (+ 16: row index of every lane) */
     static constexpr int XB = 0, TA = 16, TF = 16;
-    static constexpr int SZ_A = 16 + NX * LDX, SZ_F = 16 + n * LDF;
+    static constexpr int GTA = 16 + NX * LDX, SZ_A = GTA + GSZ, SZ_F = 16 + n * LDF;
     static constexpr int HR = 16, HSZ = (NP + 1) & ~1, BR = HR + HSZ, BSZ = (NB + 1) & ~1;
-    static constexpr int SZ_K = BR + BSZ;
+    static constexpr int GT = BR + BSZ, SZ_K = GT + GSZ;
     /* forward sweep: the packed factor and the [B A]' block of the stage by LDS-DMA, in two buffers (the next stage
      * lands while this one computes) where four workgroups per CU still fit, in one otherwise */
     static constexpr int FBUF = HSZ + BSZ;
     static constexpr int NBUF = (16 + 2 * FBUF) * 4 * 8 <= 40960 ? 2 : 1;
-    static constexpr int SZ_F2 = 16 + NBUF * FBUF;
+    static constexpr int GTF = 16 + NBUF * FBUF, SZ_F2 = GTF + GSZ;
     static constexpr int SZ0 = SZ_A > SZ_F2 ? SZ_A : SZ_F2;
     static constexpr int SZ = ((SZ0 > SZ_K ? SZ0 : SZ_K) + 1) & ~1; /* even: every instance's tile starts on 16 bytes */
 };
@@ -132,14 +134,289 @@ __device__ static inline void w16r_dma_region(const double *sbase, const double 
 #define W16R_FENCE() do { } while (0)
 #endif
 
+/* ------------------------------------------------------------------- inequality rows with slacks (GEN variants)
+ * The GEN instantiations (template parameter NG > 0: up to NG general rows per stage) also carry slacks, with the structure
+ * of the sixteen-lanes SOFT kernels extended to general rows: every slack belongs to exactly ONE row, box or general (the
+ * host checks it; anything else stays with the wave-per-instance kernels).  A row -- box row of the variable a slot owns,
+ * or general row g handled by lane g of slot 0 -- is processed by ONE lane with the scalar formulas below; what differs is
+ * only the row's value: v_j for a box row, a'v for a general row (a 16-lane sum) and how the result reaches the register
+ * rows (directly / as the rank-one terms gamma a a', a gadd broadcast from lane g).  Algebra: ipm_kernels_wpi.hpp (GEN
+ * kernels) specialised to one row per slack: E = Z + Gamma_s, X = slack stationarity + rho_s, cancellation-free. */
+struct W16RowF
+{
+    double gam, gadd, dlam; /* Hessian weight, gradient term, lam_lower - lam_upper */
+};
+
+/* sum over the 16 lanes of a row, result in every lane */
+__device__ static inline double w16_rowsum(double v, double *xb)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    v += __builtin_amdgcn_update_dpp(0.0, v, 0x128, 0xF, 0xF, true); /* row_ror:8 */
+    v += __builtin_amdgcn_update_dpp(0.0, v, 0x124, 0xF, 0xF, true); /* row_ror:4 */
+    v += __builtin_amdgcn_update_dpp(0.0, v, 0x122, 0xF, 0xF, true); /* row_ror:2 */
+    v += __builtin_amdgcn_update_dpp(0.0, v, 0x121, 0xF, 0xF, true); /* row_ror:1 */
+    return v;
+#else
+    return w16_rsum(v, xb);
+#endif
+}
+
+/* what the row functions need of the stage descriptor (held in registers, loaded one stage ahead where it matters) */
+struct W16Dsc
+{
+    int nb, ng, ns, o_ct, o_s;
+};
+/* The row functions are BRANCH-FREE on their loads: every address is clamped into its array (a row that does not exist reads
+ * element 0 of the stage / of the array), all loads are issued back to back, the values are selected afterwards.  (A
+ * `cond ? load : 0` per element makes the compiler branch around each load and wait for it alone: some thirty exposed
+ * memory latencies per row.)  Stores stay behind their predicate. */
+#define W16R_CLAMP(arr, e) ((e) < (arr).E ? (e) : 0)
+
+/* factor sweep: residuals, norms, duality measure and the row's contribution to the condensed stage system */
+__device__ static inline W16RowF w16r_row_factor(const GqpDev &D, const GqpOpts &O, int inst, bool alive, const W16Dsc S, uint64_t am,
+                                                 bool has, int row_, int sj_, double val, double &nrm_g, double &nrm_d, double &nrm_m,
+                                                 double &musum, double &nact, double &obj)
+{
+    const int nbg = S.nb + S.ng, row = has ? row_ : 0, sj = has ? sj_ : -1;
+    const bool al = has && ((am >> row) & 1), au = has && ((am >> (nbg + row)) & 1), soft = sj >= 0;
+    const int el = W16R_CLAMP(D.lam, S.o_ct + row), eu = W16R_CLAMP(D.lam, S.o_ct + nbg + row);
+    const int sq = soft ? sj : 0, se0 = W16R_CLAMP(D.lam, S.o_ct + 2 * nbg + sq), se1 = W16R_CLAMP(D.lam, S.o_ct + 2 * nbg + S.ns + sq);
+    const int q0 = W16R_CLAMP(D.sv, S.o_s + sq), q1 = W16R_CLAMP(D.sv, S.o_s + S.ns + sq);
+    const bool sal = soft && ((am >> (2 * nbg + sq)) & 1), sau = soft && ((am >> (2 * nbg + S.ns + sq)) & 1);
+    const bool hs = D.sv.E > 0; /* uniform: the batch has slack arrays at all */
+    /* loads */
+    const double v_ll = WAT(D.lam, el), v_lu = WAT(D.lam, eu), v_tl = WAT(D.t, el), v_tu = WAT(D.t, eu);
+    const double v_dl = WAT(D.dvec, el), v_du = WAT(D.dvec, eu);
+    double v_sl = 0.0, v_su = 0.0, v_sll = 0.0, v_slu = 0.0, v_stl = 1.0, v_stu = 1.0, v_sdl = 0.0, v_sdu = 0.0, sZl = 0.0, szl = 0.0, sZu = 0.0, szu = 0.0;
+    if (hs)
+    {
+        v_sl = WAT(D.sv, q0); v_su = WAT(D.sv, q1);
+        v_sll = WAT(D.lam, se0); v_slu = WAT(D.lam, se1); v_stl = WAT(D.t, se0); v_stu = WAT(D.t, se1);
+        v_sdl = WAT(D.dvec, se0); v_sdu = WAT(D.dvec, se1);
+        sZl = WAT(D.Zz, q0 * 2); szl = WAT(D.Zz, q0 * 2 + 1); sZu = WAT(D.Zz, q1 * 2); szu = WAT(D.Zz, q1 * 2 + 1);
+    }
+    W16RowF r = {0.0, 0.0, 0.0};
+    const double ll = al ? v_ll : 0.0, lu = au ? v_lu : 0.0, ttl = al ? v_tl : 1.0, ttu = au ? v_tu : 1.0;
+    const double lbv = al ? v_dl : 0.0, ubv = au ? v_du : 0.0;
+    const double ssl = soft ? v_sl : 0.0, ssu = soft ? v_su : 0.0;
+    const double rdl = al ? val + ssl - lbv - ttl : 0.0, rdu = au ? ubv - val + ssu - ttu : 0.0;
+    const double rml = al ? ll * ttl - O.tau_min : 0.0, rmu = au ? lu * ttu - O.tau_min : 0.0;
+    nacc(nrm_d, rdl); nacc(nrm_d, rdu); nacc(nrm_m, rml); nacc(nrm_m, rmu);
+    musum += ll * ttl + lu * ttu;
+    nact += (double) ((int) al + (int) au);
+    r.dlam = ll - lu;
+    const double itl = frcp(ttl), itu = frcp(ttu);
+    const double bGl = ll * itl, bGu = lu * itu, bRl = (rml + ll * rdl) * itl, bRu = (rmu + lu * rdu) * itu;
+    r.gam = bGl + bGu;
+    r.gadd = bRl - bRu;
+    if (has && alive)
+    {
+        WAT(D.rd, el) = rdl;
+        WAT(D.rd, eu) = rdu;
+    }
+    /* the slack of the row (everything below is neutral for a hard row: soft = false) */
+    const double sll = sal ? v_sll : 0.0, slu = sau ? v_slu : 0.0, stl = sal ? v_stl : 1.0, stu = sau ? v_stu : 1.0;
+    const double sdl = sal ? v_sdl : 0.0, sdu = sau ? v_sdu : 0.0;
+    if (soft) obj += (0.5 * sZl * ssl + szl) * ssl + (0.5 * sZu * ssu + szu) * ssu;
+    const double srdl = sal ? ssl - sdl - stl : 0.0, srdu = sau ? ssu - sdu - stu : 0.0;
+    const double srml = sal ? sll * stl - O.tau_min : 0.0, srmu = sau ? slu * stu - O.tau_min : 0.0;
+    nacc(nrm_d, srdl); nacc(nrm_d, srdu); nacc(nrm_m, srml); nacc(nrm_m, srmu);
+    musum += sll * stl + slu * stu;
+    nact += (double) ((int) sal + (int) sau);
+    const double sitl = frcp(stl), situ = frcp(stu);
+    const double sGl = sll * sitl, sGu = slu * situ;
+    const double sPl = (srml + sll * srdl) * sitl, sPu = (srmu + slu * srdu) * situ;
+    const double Rl = soft ? sZl * ssl + szl - sll - ll : 0.0, Ru = soft ? sZu * ssu + szu - slu - lu : 0.0; /* slack stationarity */
+    nacc(nrm_g, Rl); nacc(nrm_g, Ru);
+    const double El = sZl + sGl, Eu = sZu + sGu, Xl = Rl + sPl, Xu = Ru + sPu; /* D, r~ without the row */
+    const double Dl = El + bGl, Du = Eu + bGu;
+    if (soft && alive)
+    {
+        WAT(D.rd, se0) = srdl;
+        WAT(D.rd, se1) = srdu;
+        WAT(D.rgs, q0) = Rl; WAT(D.rgs, q1) = Ru;
+        WAT(D.sD, q0) = Dl; WAT(D.sD, q1) = Du;
+        WAT(D.sR, q0) = Xl + bRl; WAT(D.sR, q1) = Xu + bRu;
+    }
+    const double Il = Dl != 0.0 ? frcp(Dl) : 0.0, Iu = Du != 0.0 ? frcp(Du) : 0.0;
+    if (soft)
+    {
+        r.gam = bGl * El * Il + bGu * Eu * Iu;
+        r.gadd = (bRl * El - bGl * Xl) * Il - (bRu * Eu - bGu * Xu) * Iu;
+    }
+    return r;
+}
+
+/* rhs-only sweep: the row's gradient term with the corrector's complementarity rhs (rd as stored by the factor sweep) */
+__device__ static inline double w16r_row_rhs(const GqpDev &D, const GqpOpts &O, int inst, bool alive, const W16Dsc S, uint64_t am,
+                                             bool has, int row_, int sj_, double smu, double pscale)
+{
+    const int nbg = S.nb + S.ng, row = has ? row_ : 0, sj = has ? sj_ : -1;
+    const bool al = has && ((am >> row) & 1), au = has && ((am >> (nbg + row)) & 1), soft = sj >= 0;
+    const int el = W16R_CLAMP(D.lam, S.o_ct + row), eu = W16R_CLAMP(D.lam, S.o_ct + nbg + row);
+    const int sq = soft ? sj : 0, e0 = W16R_CLAMP(D.lam, S.o_ct + 2 * nbg + sq), e1 = W16R_CLAMP(D.lam, S.o_ct + 2 * nbg + S.ns + sq);
+    const int q0 = W16R_CLAMP(D.sv, S.o_s + sq), q1 = W16R_CLAMP(D.sv, S.o_s + S.ns + sq);
+    const bool sal = soft && ((am >> (2 * nbg + sq)) & 1), sau = soft && ((am >> (2 * nbg + S.ns + sq)) & 1);
+    const bool hs = D.sv.E > 0;
+    const double v_ll = WAT(D.lam, el), v_lu = WAT(D.lam, eu), v_tl = WAT(D.t, el), v_tu = WAT(D.t, eu);
+    const double v_dl = WAT(D.rd, el), v_du = WAT(D.rd, eu), v_pl = WAT(D.pcorr, el), v_pu = WAT(D.pcorr, eu);
+    double v_sll = 0.0, v_slu = 0.0, v_stl = 1.0, v_stu = 1.0, v_srl = 0.0, v_sru = 0.0, v_spl = 0.0, v_spu = 0.0, sgl = 0.0, sgu = 0.0,
+           sZl = 0.0, sZu = 0.0, sDl = 0.0, sDu = 0.0;
+    if (hs)
+    {
+        v_sll = WAT(D.lam, e0); v_slu = WAT(D.lam, e1); v_stl = WAT(D.t, e0); v_stu = WAT(D.t, e1);
+        v_srl = WAT(D.rd, e0); v_sru = WAT(D.rd, e1); v_spl = WAT(D.pcorr, e0); v_spu = WAT(D.pcorr, e1);
+        sgl = WAT(D.rgs, q0); sgu = WAT(D.rgs, q1);
+        sZl = WAT(D.Zz, q0 * 2); sZu = WAT(D.Zz, q1 * 2);
+        sDl = WAT(D.sD, q0); sDu = WAT(D.sD, q1);
+    }
+    const double ll = al ? v_ll : 0.0, lu = au ? v_lu : 0.0, ttl = al ? v_tl : 1.0, ttu = au ? v_tu : 1.0;
+    const double rdl = al ? v_dl : 0.0, rdu = au ? v_du : 0.0;
+    const double rml = al ? ll * ttl - O.tau_min + pscale * v_pl - smu : 0.0;
+    const double rmu = au ? lu * ttu - O.tau_min + pscale * v_pu - smu : 0.0;
+    const double itl = frcp(ttl), itu = frcp(ttu);
+    const double bRl = (rml + ll * rdl) * itl, bRu = (rmu + lu * rdu) * itu;
+    const double sll = sal ? v_sll : 0.0, slu = sau ? v_slu : 0.0, stl = sal ? v_stl : 1.0, stu = sau ? v_stu : 1.0;
+    const double srdl = sal ? v_srl : 0.0, srdu = sau ? v_sru : 0.0, spl = sal ? v_spl : 0.0, spu = sau ? v_spu : 0.0;
+    const double bGl = ll * itl, bGu = lu * itu;
+    const double srml = sal ? sll * stl - O.tau_min + pscale * spl - smu : 0.0;
+    const double srmu = sau ? slu * stu - O.tau_min + pscale * spu - smu : 0.0;
+    const double sitl = frcp(stl), situ = frcp(stu);
+    const double Xl = sgl + (srml + sll * srdl) * sitl, Xu = sgu + (srmu + slu * srdu) * situ; /* r~ without the row */
+    const double El = sZl + sll * sitl, Eu = sZu + slu * situ;
+    if (soft && alive) { WAT(D.sR, q0) = Xl + bRl; WAT(D.sR, q1) = Xu + bRu; }
+    const double Il = sDl != 0.0 ? frcp(sDl) : 0.0, Iu = sDu != 0.0 ? frcp(sDu) : 0.0;
+    return soft ? (bRl * El - bGl * Xl) * Il - (bRu * Eu - bGu * Xu) * Iu : bRl - bRu;
+}
+
+/* forward sweep: steps of the row's multipliers / slacks for the step dc of the row's value, step length, sums of the
+ * Mehrotra centring (affine sweep) or the steps written out (corrector sweep) */
+template <bool CORR>
+__device__ static inline void w16r_row_fwd(const GqpDev &D, const GqpOpts &O, int inst, bool alive, const W16Dsc S, uint64_t am,
+                                           bool has, int row_, int sj_, double dc, double smu, double pscale, double &alpha, double &S0,
+                                           double &S1, double &S2, double &nact)
+{
+    const int nbg = S.nb + S.ng, row = has ? row_ : 0, sj = has ? sj_ : -1;
+    const bool al = has && ((am >> row) & 1), au = has && ((am >> (nbg + row)) & 1), soft = sj >= 0;
+    const int el = W16R_CLAMP(D.lam, S.o_ct + row), eu = W16R_CLAMP(D.lam, S.o_ct + nbg + row);
+    const int sq = soft ? sj : 0, e0 = W16R_CLAMP(D.lam, S.o_ct + 2 * nbg + sq), e1 = W16R_CLAMP(D.lam, S.o_ct + 2 * nbg + S.ns + sq);
+    const int q0 = W16R_CLAMP(D.sv, S.o_s + sq), q1 = W16R_CLAMP(D.sv, S.o_s + S.ns + sq);
+    const bool sal = soft && ((am >> (2 * nbg + sq)) & 1), sau = soft && ((am >> (2 * nbg + S.ns + sq)) & 1);
+    const bool hs = D.sv.E > 0;
+    const double v_ll = WAT(D.lam, el), v_lu = WAT(D.lam, eu), v_tl = WAT(D.t, el), v_tu = WAT(D.t, eu);
+    const double v_dl = WAT(D.rd, el), v_du = WAT(D.rd, eu);
+    const double v_pl = CORR ? WAT(D.pcorr, el) : 0.0, v_pu = CORR ? WAT(D.pcorr, eu) : 0.0;
+    double v_sll = 0.0, v_slu = 0.0, v_stl = 1.0, v_stu = 1.0, v_srl = 0.0, v_sru = 0.0, v_spl = 0.0, v_spu = 0.0, rsl = 0.0, rsu = 0.0,
+           sZl = 0.0, sZu = 0.0, sDl = 0.0, sDu = 0.0;
+    if (hs)
+    {
+        v_sll = WAT(D.lam, e0); v_slu = WAT(D.lam, e1); v_stl = WAT(D.t, e0); v_stu = WAT(D.t, e1);
+        v_srl = WAT(D.rd, e0); v_sru = WAT(D.rd, e1);
+        if (CORR) { v_spl = WAT(D.pcorr, e0); v_spu = WAT(D.pcorr, e1); }
+        rsl = WAT(D.sR, q0); rsu = WAT(D.sR, q1);
+        sZl = WAT(D.Zz, q0 * 2); sZu = WAT(D.Zz, q1 * 2);
+        sDl = WAT(D.sD, q0); sDu = WAT(D.sD, q1);
+    }
+    const double ll = al ? v_ll : 0.0, lu = au ? v_lu : 0.0, ttl = al ? v_tl : 1.0, ttu = au ? v_tu : 1.0;
+    const double rdl = al ? v_dl : 0.0, rdu = au ? v_du : 0.0;
+    const double pl = al ? v_pl : 0.0, pu = au ? v_pu : 0.0;
+    const double rml = al ? ll * ttl - O.tau_min + pscale * pl - smu : 0.0;
+    const double rmu = au ? lu * ttu - O.tau_min + pscale * pu - smu : 0.0;
+    /* the row's own slack: steps of the slack and of its two bound rows */
+    const double sll = sal ? v_sll : 0.0, slu = sau ? v_slu : 0.0, stl = sal ? v_stl : 1.0, stu = sau ? v_stu : 1.0;
+    const double srdl = sal ? v_srl : 0.0, srdu = sau ? v_sru : 0.0, spl = sal ? v_spl : 0.0, spu = sau ? v_spu : 0.0;
+    const double il = sDl != 0.0 ? frcp(sDl) : 0.0, iu = sDu != 0.0 ? frcp(sDu) : 0.0;
+    const double gl_ = ll * frcp(ttl), gu_ = lu * frcp(ttu);
+    const double dsl = (-rsl - gl_ * dc) * il, dsu = (-rsu + gu_ * dc) * iu;
+    if (CORR && soft && alive) { WAT(D.dsv, q0) = dsl; WAT(D.dsv, q1) = dsu; }
+    const double sitl = frcp(stl), situ = frcp(stu);
+    const double El = sZl + sll * sitl, Eu = sZu + slu * situ;
+    const double dcl = soft ? (El * dc - rsl) * il : dc;   /* dc + ds resp. -dc + ds: the row's own slack step included */
+    const double dcu = soft ? (-Eu * dc - rsu) * iu : -dc;
+    const double srml = sal ? sll * stl - O.tau_min + pscale * spl - smu : 0.0;
+    const double srmu = sau ? slu * stu - O.tau_min + pscale * spu - smu : 0.0;
+    const double sdtl = sal ? dsl + srdl : 0.0, sdtu = sau ? dsu + srdu : 0.0;
+    const double sdll = sal ? -(srml + sll * sdtl) * sitl : 0.0, sdlu = sau ? -(srmu + slu * sdtu) * situ : 0.0;
+    const double q1_ = -sll * frcp(sdll), q2_ = -slu * frcp(sdlu), q3_ = -stl * frcp(sdtl), q4_ = -stu * frcp(sdtu);
+    alpha = (sdll < 0.0 && q1_ < alpha) ? q1_ : alpha;
+    alpha = (sdlu < 0.0 && q2_ < alpha) ? q2_ : alpha;
+    alpha = (sdtl < 0.0 && q3_ < alpha) ? q3_ : alpha;
+    alpha = (sdtu < 0.0 && q4_ < alpha) ? q4_ : alpha;
+    const double dtl = al ? dcl + rdl : 0.0, dtu = au ? dcu + rdu : 0.0;
+    const double dll = al ? -(rml + ll * dtl) * frcp(ttl) : 0.0;
+    const double dlu = au ? -(rmu + lu * dtu) * frcp(ttu) : 0.0;
+    const double c1 = -ll * frcp(dll), c2 = -lu * frcp(dlu), c3 = -ttl * frcp(dtl), c4 = -ttu * frcp(dtu);
+    alpha = (dll < 0.0 && c1 < alpha) ? c1 : alpha;
+    alpha = (dlu < 0.0 && c2 < alpha) ? c2 : alpha;
+    alpha = (dtl < 0.0 && c3 < alpha) ? c3 : alpha;
+    alpha = (dtu < 0.0 && c4 < alpha) ? c4 : alpha;
+    if (!CORR)
+    {
+        S0 += ll * ttl + lu * ttu + sll * stl + slu * stu;
+        S1 += ll * dtl + ttl * dll + lu * dtu + ttu * dlu + sll * sdtl + stl * sdll + slu * sdtu + stu * sdlu;
+        S2 += dll * dtl + dlu * dtu + sdll * sdtl + sdlu * sdtu;
+        nact += (double) ((int) al + (int) au + (int) sal + (int) sau);
+        if (has && alive) { WAT(D.pcorr, el) = dll * dtl; WAT(D.pcorr, eu) = dlu * dtu; }
+        if (soft && alive) { WAT(D.pcorr, e0) = sdll * sdtl; WAT(D.pcorr, e1) = sdlu * sdtu; }
+    }
+    else
+    {
+        if (has && alive)
+        {
+            WAT(D.dlam, el) = dll; WAT(D.dlam, eu) = dlu;
+            WAT(D.dt, el) = dtl; WAT(D.dt, eu) = dtu;
+        }
+        if (soft && alive)
+        {
+            WAT(D.dlam, e0) = sdll; WAT(D.dlam, e1) = sdlu;
+            WAT(D.dt, e0) = sdtl; WAT(D.dt, e1) = sdtu;
+        }
+    }
+}
+
+/* update pass of the corrector sweep for one row (and its slack) */
+__device__ static inline void w16r_row_update(const GqpDev &D, const GqpOpts &O, int inst, const W16Dsc S, uint64_t am, bool has, int row, int sj, double a)
+{
+    if (!has) return;
+    const int nbg = S.nb + S.ng;
+    const int el = S.o_ct + row, eu = el + nbg;
+    if ((am >> row) & 1)
+    {
+        const double lm = WAT(D.lam, el) + a * WAT(D.dlam, el), tt = WAT(D.t, el) + a * WAT(D.dt, el);
+        WAT(D.lam, el) = lm < O.lam_min ? O.lam_min : lm; WAT(D.t, el) = tt < O.t_min ? O.t_min : tt;
+    }
+    if ((am >> (nbg + row)) & 1)
+    {
+        const double lm = WAT(D.lam, eu) + a * WAT(D.dlam, eu), tt = WAT(D.t, eu) + a * WAT(D.dt, eu);
+        WAT(D.lam, eu) = lm < O.lam_min ? O.lam_min : lm; WAT(D.t, eu) = tt < O.t_min ? O.t_min : tt;
+    }
+    if (sj >= 0)
+    {
+        const int ns = S.ns, o_s = S.o_s;
+        WAT(D.sv, o_s + sj) += a * WAT(D.dsv, o_s + sj);
+        WAT(D.sv, o_s + ns + sj) += a * WAT(D.dsv, o_s + ns + sj);
+        for (int w = 0; w < 2; w++)
+        {
+            const int side = 2 * nbg + w * ns + sj, e = S.o_ct + side;
+            if ((am >> side) & 1)
+            {
+                const double lm = WAT(D.lam, e) + a * WAT(D.dlam, e), tt = WAT(D.t, e) + a * WAT(D.dt, e);
+                WAT(D.lam, e) = lm < O.lam_min ? O.lam_min : lm;
+                WAT(D.t, e) = tt < O.t_min ? O.t_min : tt;
+            }
+        }
+    }
+}
+
 /* ------------------------------------------------------------------------------------------------ factor */
 
-template <int NX, int NU>
+template <int NX, int NU, int NG = 0>
 __global__ void __launch_bounds__(64) ky_factor(GqpDev D, GqpOpts O, int redo)
 {
     GQP_DYN_SHARED(smem);
-    typedef W16RLds<NX, NU> LY;
-    constexpr int n = NX + NU, R = LY::R, NP = LY::NP, NB = LY::NB;
+    typedef W16RLds<NX, NU, NG> LY;
+    constexpr bool GEN = NG > 0; /* general rows and slacks (one slack per row): rows through w16r_row_factor */
+    constexpr int n = NX + NU, R = LY::R, NP = LY::NP, NB = LY::NB, NGP = (NG * n + 15) / 16;
     const int l = threadIdx.x & 15, rq = threadIdx.x >> 4;
     /* Liveness per 16-lane row.  No row leaves the kernel while another one of the wave is alive: all 64 lanes take part
      * in the LDS-DMA of every live row.  A dead row (converged instance, or beyond the batch) computes on the data of a
@@ -159,6 +436,9 @@ __global__ void __launch_bounds__(64) ky_factor(GqpDev D, GqpOpts O, int redo)
     double *T = smem + rq * LY::SZ, *xb = T + LY::XB;
     double *HRq = T + LY::HR; /* packed H block of the stage */
     double *BRq = T + LY::BR; /* [B A]' block of the stage, [row][NX]; later the x-block of the previous factor, [q][NX] */
+    double *GTq = T + LY::GT; /* GEN: general rows of the stage, [g][n] */
+    double *RW = GTq + LY::RWO; /* GEN: row vectors, 4 x 16 */
+    int *RI = (int *) (RW + 64); /* GEN: inequality row handled by every lane */
     int row[R], cx[R];
     bool mine[R], isx[R];
     W16_UNROLL for (int s = 0; s < R; s++) row[s] = l + 16 * s;
@@ -185,11 +465,13 @@ __global__ void __launch_bounds__(64) ky_factor(GqpDev D, GqpOpts O, int redo)
     double p_v[R], p_g[R], p_b[R], p_xn[R], p_pin[R], p_pik[R], p_ll[R], p_lu[R], p_tl[R], p_tu[R], p_dl[R], p_du[R];
     double p_ht = 0.0, p_bt = 0.0; /* last element of an odd-sized block (the DMA moves pairs) */
     uint64_t p_am, c_bm, c_em, n_bm, n_em; /* activity bits of the next stage; box / equality masks of the current and next one */
-    int c_nb, c_oct, n_nb, n_oct;
+    int c_nb, c_oct, n_nb, n_oct, c_ng = 0, c_og = 0, n_ng = 0, n_og = 0, c_ns = 0, c_os = 0, n_ns = 0, n_os = 0;
+    double p_G[NGP > 0 ? NGP : 1];
     auto load_desc = [&](int kk)
     {
         const GqpStage &Sn = D.st[kk];
         n_bm = Sn.bmask; n_em = Sn.emask; n_nb = Sn.nb; n_oct = Sn.o_ct;
+        if (GEN) { n_ng = Sn.ng; n_og = Sn.o_g; n_ns = Sn.ns; n_os = Sn.o_s; }
     };
     /* vectors and box rows of stage kk, whose descriptor is in c_* */
     auto prefetch_v = [&](int kk)
@@ -207,16 +489,27 @@ __global__ void __launch_bounds__(64) ky_factor(GqpDev D, GqpOpts O, int redo)
             p_xn[s] = WAT(D.ux, (kk + 1) * n + NU + xc);
             p_pin[s] = WAT(D.pi, (kk + 1) * NX + xc);
             p_pik[s] = WAT(D.pi, kk * NX + xc);
-            const bool hs = mn && (((c_bm & ~c_em) >> row[s]) & 1);
-            const int ib = hs ? popc64(c_bm & (((uint64_t) 1 << row[s]) - 1)) : 0;
-            const int el = c_oct + ib, eu = el + c_nb;
-            p_ll[s] = WAT(D.lam, el); p_lu[s] = WAT(D.lam, eu);
-            p_tl[s] = WAT(D.t, el); p_tu[s] = WAT(D.t, eu);
-            p_dl[s] = WAT(D.dvec, el); p_du[s] = WAT(D.dvec, eu);
+            if (!GEN)
+            {
+                const bool hs = mn && (((c_bm & ~c_em) >> row[s]) & 1);
+                const int ib = hs ? popc64(c_bm & (((uint64_t) 1 << row[s]) - 1)) : 0;
+                const int el = c_oct + ib, eu = el + c_nb;
+                p_ll[s] = WAT(D.lam, el); p_lu[s] = WAT(D.lam, eu);
+                p_tl[s] = WAT(D.t, el); p_tu[s] = WAT(D.t, eu);
+                p_dl[s] = WAT(D.dvec, el); p_du[s] = WAT(D.dvec, eu);
+            }
+        }
+        if (GEN)
+        {
+            W16_UNROLL for (int i = 0; i < NGP; i++)
+            {
+                const int e = l + 16 * i;
+                p_G[i] = WAT(D.DCt, c_og * n + (e < c_ng * n ? e : 0));
+            }
         }
     };
     load_desc(D.N);
-    c_bm = n_bm; c_em = n_em; c_nb = n_nb; c_oct = n_oct;
+    c_bm = n_bm; c_em = n_em; c_nb = n_nb; c_oct = n_oct; c_ng = n_ng; c_og = n_og; c_ns = n_ns; c_os = n_os;
     dma_h(D.N);
     dma_b(D.N);
     prefetch_v(D.N);
@@ -257,7 +550,19 @@ __global__ void __launch_bounds__(64) ky_factor(GqpDev D, GqpOpts O, int redo)
             rb[s] = zx * (p_b[s] - p_xn[s]);
             pin[s] = zx * p_pin[s];
             pik[s] = zx * p_pik[s];
-            q_ll[s] = p_ll[s]; q_lu[s] = p_lu[s]; q_tl[s] = p_tl[s]; q_tu[s] = p_tu[s]; q_dl[s] = p_dl[s]; q_du[s] = p_du[s];
+            if (!GEN) { q_ll[s] = p_ll[s]; q_lu[s] = p_lu[s]; q_tl[s] = p_tl[s]; q_tu[s] = p_tu[s]; q_dl[s] = p_dl[s]; q_du[s] = p_du[s]; }
+        }
+        const int ng = GEN ? c_ng : 0;
+        const W16Dsc dsc = {c_nb, ng, c_ns, c_oct, c_os};
+        const int nbf = popc64(imask); /* box rows that take part (equality-flagged ones do not) */
+        if (GEN)
+        {
+            W16_UNROLL for (int i = 0; i < NGP; i++)
+            {
+                const int e = l + 16 * i;
+                if (e < NG * n) GTq[e] = e < ng * n ? p_G[i] : 0.0;
+            }
+            GQP_ROWSYNC();
         }
         if ((NP & 1) || (NB & 1))
         {
@@ -270,7 +575,7 @@ __global__ void __launch_bounds__(64) ky_factor(GqpDev D, GqpOpts O, int redo)
         }
         /* the descriptor loaded a stage ago becomes the next stage's */
         const uint64_t x_bm = n_bm, x_em = n_em;
-        const int x_nb = n_nb, x_oct = n_oct;
+        const int x_nb = n_nb, x_oct = n_oct, x_ng = n_ng, x_og = n_og, x_ns = n_ns, x_os = n_os;
         /* ---- symmetric row of H from the packed block: H[row][c] = packed[PK(row, c)] for c <= row, packed[PK(c, row)]
          * above.  A slot knows at compile time which one it is except inside its own 16 x 16 diagonal block, where both
          * are read and the lane picks (every access: lane base + immediate offset) ---- */
@@ -308,6 +613,66 @@ __global__ void __launch_bounds__(64) ky_factor(GqpDev D, GqpOpts O, int redo)
         }
         W16_UNROLL for (int s = 0; s < R; s++) { W16R_OPAQUE(rb[s]); W16R_OPAQUE(hv[s]); }
         W16R_TICK(1);
+        double gtr[R], gar[R], gmr[R]; /* GEN: what the inequality rows add to the stationarity residual / gradient / Hessian diagonal */
+        W16_UNROLL for (int s = 0; s < R; s++) { gtr[s] = 0.0; gar[s] = 0.0; gmr[s] = 0.0; }
+        if (GEN)
+        {
+            /* ONE row per lane: lane i < nb + ng processes inequality row i (sorted box rows, then general rows).  The row
+             * values travel through LDS by row index (box rows: written above by the slot that owns the variable; general
+             * rows: a'v, a 16-lane sum), the results come back the same way: the slot of a box row picks its row's
+             * (gamma, gadd, dlam), a general row enters as rank-one terms M += gamma a a', gradient += a gadd,
+             * stationarity residual -= a (lam_l - lam_u) */
+            W16_UNROLL for (int s = 0; s < R; s++)
+                if (mine[s] && ((imask >> row[s]) & 1)) /* value and row index of the slot's box row, to the lane that processes it */
+                {
+                    const int jb = popc64(imask & (((uint64_t) 1 << row[s]) - 1));
+                    RW[jb] = v[s];
+                    RI[jb] = popc64(bmask & (((uint64_t) 1 << row[s]) - 1));
+                }
+            W16_UNROLL for (int g = 0; g < NG; g++)
+            {
+                double t = 0.0;
+                W16_UNROLL for (int s = 0; s < R; s++) t += (mine[s] ? GTq[g * n + lc_[s]] : 0.0) * v[s];
+                t = w16_rowsum(t, xb);
+                if (l == g && g < ng) { RW[nbf + g] = t; RI[nbf + g] = nbg + g; }
+            }
+            GQP_ROWSYNC();
+            const bool hr = l < nbf + ng;
+            const int rr = hr ? RI[l] : 0;
+            const int sjr = hr ? (int) D.st[k].srev[rr] : -1;
+            const W16RowF rf = w16r_row_factor(D, O, inst, alive, dsc, am, hr, rr, sjr, RW[hr ? l : 0], nrm_g, nrm_d, nrm_m, musum, nact, obj);
+            GQP_ROWSYNC();
+            RW[16 + l] = rf.gam; RW[32 + l] = rf.gadd; RW[48 + l] = rf.dlam;
+            GQP_ROWSYNC();
+            W16_UNROLL for (int s = 0; s < R; s++)
+            {
+                const bool has = mine[s] && ((imask >> row[s]) & 1);
+                const int jb = has ? popc64(imask & (((uint64_t) 1 << row[s]) - 1)) : 0;
+                gmr[s] = has ? RW[16 + jb] : 0.0;
+                gar[s] = has ? RW[32 + jb] : 0.0;
+                gtr[s] = has ? RW[48 + jb] : 0.0;
+            }
+            W16_UNROLL for (int g = 0; g < NG; g++)
+            {
+                const int rg_ = nbf + g < 16 ? nbf + g : 15;
+                const double Gg = g < ng ? RW[16 + rg_] : 0.0, Ag = g < ng ? RW[32 + rg_] : 0.0, Lg = g < ng ? RW[48 + rg_] : 0.0;
+                W16_UNROLL for (int s = 0; s < R; s++)
+                {
+                    const double ap = mine[s] ? GTq[g * n + lc_[s]] : 0.0;
+                    gtr[s] += ap * Lg;
+                    gar[s] += ap * Ag;
+                    const double ga = Gg * ap;
+                    W16_UNROLL for (int c = 0; c < n; c++)
+                        if (W16R_LOW(s, c)) M[s][c] += ga * GTq[g * n + c];
+                }
+            }
+            W16_UNROLL for (int s = 0; s < R; s++)
+            {
+                W16R_OPAQUE(gtr[s]); W16R_OPAQUE(gar[s]); W16R_OPAQUE(gmr[s]);
+                W16_UNROLL for (int c = 0; c < n; c++)
+                    if (W16R_LOW(s, c)) W16R_OPAQUE(M[s][c]);
+            }
+        }
         /* ---- W rows: W[c] = sum_{q >= c} Br[q] Lx+[q][c]: Lx+[q][c] is entry c of the register row of the slot that
          * holds state q, one broadcast feeds both slots; [B A]' pi+ rides along ---- */
         double W[R][NX], gt[R], gadd[R], gam[R];
@@ -356,7 +721,8 @@ __global__ void __launch_bounds__(64) ky_factor(GqpDev D, GqpOpts O, int redo)
             else gt[s] = 0.0;
             if (isx[s]) { nacc(nrm_b, rb[s]); if (alive) WAT(D.rb, k * NX + cx[s]) = rb[s]; }
             const bool has = mine[s] && ((imask >> row[s]) & 1);
-            if (has)
+            if (GEN) { }
+            else if (has)
             {
                 const int ib = popc64(bmask & (((uint64_t) 1 << row[s]) - 1));
                 const bool al = (am >> ib) & 1, au = (am >> (nbg + ib)) & 1;
@@ -379,8 +745,21 @@ __global__ void __launch_bounds__(64) ky_factor(GqpDev D, GqpOpts O, int redo)
                     WAT(D.rd, eu) = rdu;
                 }
             }
-            if (fixed[s]) gt[s] = 0.0;
-            if (mine[s]) { nacc(nrm_g, gt[s]); if (alive) WAT(D.rg, k * n + row[s]) = gt[s]; }
+            if (!GEN)
+            {
+                if (fixed[s]) gt[s] = 0.0;
+                if (mine[s]) { nacc(nrm_g, gt[s]); if (alive) WAT(D.rg, k * n + row[s]) = gt[s]; }
+            }
+        }
+        if (GEN)
+        {
+            W16_UNROLL for (int s = 0; s < R; s++)
+            {
+                gt[s] -= gtr[s];
+                gadd[s] = gar[s]; gam[s] = gmr[s];
+                if (fixed[s]) gt[s] = 0.0;
+                if (mine[s]) { nacc(nrm_g, gt[s]); if (alive) WAT(D.rg, k * n + row[s]) = gt[s]; }
+            }
         }
         /* w0[c] (state slots) = lx+[c] + sum_{q >= c} Lx+[q][c] rb[q] needs COLUMN c of Lx+: the rows go through the
          * [B A]' region (the stage is done with it), the slots read their column back */
@@ -404,7 +783,7 @@ __global__ void __launch_bounds__(64) ky_factor(GqpDev D, GqpOpts O, int redo)
         {
             /* next stage: its [B A]' block by DMA; vectors, box rows and the descriptor after it into registers */
             dma_b(k - 1);
-            c_bm = x_bm; c_em = x_em; c_nb = x_nb; c_oct = x_oct;
+            c_bm = x_bm; c_em = x_em; c_nb = x_nb; c_oct = x_oct; c_ng = x_ng; c_og = x_og; c_ns = x_ns; c_os = x_os;
             prefetch_v(k - 1);
             load_desc(k > 1 ? k - 2 : 0);
         }
@@ -536,18 +915,20 @@ __global__ void __launch_bounds__(64) ky_factor(GqpDev D, GqpOpts O, int redo)
 
 /* PF (shapes whose rows fit the register file twice, e.g. the condensed C3 shape): everything a stage reads is loaded one
  * stage ahead -- one wave per SIMD, nobody else hides the latency */
-template <int NX, int NU>
+template <int NX, int NU, int NG = 0>
 __global__ void __launch_bounds__(64) ky_backrhs(GqpDev D, GqpOpts O, int redo)
 {
     GQP_DYN_SHARED(smem);
-    typedef W16RLds<NX, NU> LY;
-    constexpr int n = NX + NU, R = LY::R, NP = n * (n + 1) / 2, LDX = LY::LDX;
-    constexpr bool PF = R * (NU + 2 * NX + 12) <= 96;
+    typedef W16RLds<NX, NU, NG> LY;
+    constexpr bool GEN = NG > 0;
+    constexpr int n = NX + NU, R = LY::R, NP = n * (n + 1) / 2, LDX = LY::LDX, NGP = (NG * n + 15) / 16;
+    constexpr bool PF = !GEN && R * (NU + 2 * NX + 12) <= 96;
     const int l = threadIdx.x & 15, inst = w16_slot_inst(D, blockIdx.x * 4 + (threadIdx.x >> 4));
     if (inst < 0) return;
     if (D.status[inst] != GQP_RUNNING) return;
     if (redo == 1 && !(D.alpha[inst] < 0.0)) return; /* redo = 2: sensitivity pass (direction only, every instance) */
-    double *T = smem + (threadIdx.x >> 4) * LY::SZ, *xb = T + LY::XB, *TA = T + LY::TA;
+    double *T = smem + (threadIdx.x >> 4) * LY::SZ, *xb = T + LY::XB, *TA = T + LY::TA, *GTq = T + LY::GTA, *RW = GTq + LY::RWO;
+    int *RI = (int *) (RW + 64);
     int row[R], cx[R];
     bool mine[R], isx[R];
     W16_UNROLL for (int s = 0; s < R; s++)
@@ -585,13 +966,16 @@ __global__ void __launch_bounds__(64) ky_backrhs(GqpDev D, GqpOpts O, int redo)
             W16_UNROLL for (int c = 0; c < NX; c++) G.Br[s][c] = WAT(D.BAt, (k * n + lc_) * NX + c);
             G.rb[s] = WAT(D.rb, k * NX + xc_);
             G.rg[s] = WAT(D.rg, k * n + lc_);
-            const bool hs = mine[s] && (((S.bmask & ~S.emask) >> row[s]) & 1);
-            const int ib = hs ? popc64(S.bmask & (((uint64_t) 1 << row[s]) - 1)) : 0;
-            const int el = S.o_ct + ib, eu = el + S.nb;
-            G.ll[s] = WAT(D.lam, el); G.lu[s] = WAT(D.lam, eu);
-            G.tl[s] = WAT(D.t, el); G.tu[s] = WAT(D.t, eu);
-            G.dl[s] = WAT(D.rd, el); G.du[s] = WAT(D.rd, eu);
-            G.pl[s] = WAT(D.pcorr, el); G.pu[s] = WAT(D.pcorr, eu);
+            if (!GEN)
+            {
+                const bool hs = mine[s] && (((S.bmask & ~S.emask) >> row[s]) & 1);
+                const int ib = hs ? popc64(S.bmask & (((uint64_t) 1 << row[s]) - 1)) : 0;
+                const int el = S.o_ct + ib, eu = el + S.nb;
+                G.ll[s] = WAT(D.lam, el); G.lu[s] = WAT(D.lam, eu);
+                G.tl[s] = WAT(D.t, el); G.tu[s] = WAT(D.t, eu);
+                G.dl[s] = WAT(D.rd, el); G.du[s] = WAT(D.rd, eu);
+                G.pl[s] = WAT(D.pcorr, el); G.pu[s] = WAT(D.pcorr, eu);
+            }
         }
     };
     StageRegs Gn;
@@ -621,7 +1005,8 @@ __global__ void __launch_bounds__(64) ky_backrhs(GqpDev D, GqpOpts O, int redo)
             rb[s] = zx * G.rb[s];
             m[s] = zm * G.rg[s];
             const bool has = mine[s] && ((imask >> row[s]) & 1);
-            if (has)
+            if (GEN) { }
+            else if (has)
             {
                 const int ib = popc64(G.bm & (((uint64_t) 1 << row[s]) - 1));
                 const bool al = (am >> ib) & 1, au = (am >> (nbg + ib)) & 1;
@@ -631,6 +1016,42 @@ __global__ void __launch_bounds__(64) ky_backrhs(GqpDev D, GqpOpts O, int redo)
                 const double rml = al ? ll * ttl - O.tau_min + pscale * G.pl[s] - smu : 0.0;
                 const double rmu = au ? lu * ttu - O.tau_min + pscale * G.pu[s] - smu : 0.0;
                 m[s] += (rml + ll * rdl) * frcp(ttl) - (rmu + lu * rdu) * frcp(ttu);
+            }
+        }
+        if (GEN)
+        {
+            /* general rows: gradient term of row g from lane g, applied as a gadd through the rows of [D C] */
+            const GqpStage &S = D.st[k];
+            const int ng = S.ng;
+            GQP_ROWSYNC();
+            W16_UNROLL for (int i = 0; i < NGP; i++)
+            {
+                const int e = l + 16 * i;
+                if (e < NG * n) GTq[e] = e < ng * n ? WAT(D.DCt, S.o_g * n + e) : 0.0;
+            }
+            GQP_ROWSYNC();
+            /* one inequality row per lane (sorted box rows, then general rows); results back through LDS by row index */
+            const W16Dsc dsc = {S.nb, S.ng, S.ns, S.o_ct, S.o_s};
+            const int nbf = popc64(imask);
+            W16_UNROLL for (int s = 0; s < R; s++)
+                if (mine[s] && ((imask >> row[s]) & 1))
+                    RI[popc64(imask & (((uint64_t) 1 << row[s]) - 1))] = popc64(G.bm & (((uint64_t) 1 << row[s]) - 1));
+            if (l < ng) RI[nbf + l] = S.nb + l;
+            GQP_ROWSYNC();
+            const bool hr = l < nbf + ng;
+            const int rr = hr ? RI[l] : 0;
+            RW[32 + l] = w16r_row_rhs(D, O, inst, true, dsc, am, hr, rr, hr ? (int) S.srev[rr] : -1, smu, pscale);
+            GQP_ROWSYNC();
+            W16_UNROLL for (int s = 0; s < R; s++)
+            {
+                const bool has = mine[s] && ((imask >> row[s]) & 1);
+                m[s] += has ? RW[32 + popc64(imask & (((uint64_t) 1 << row[s]) - 1))] : 0.0;
+            }
+            W16_UNROLL for (int g = 0; g < NG; g++)
+            {
+                const int rg_ = nbf + g < 16 ? nbf + g : 15;
+                const double Ag = g < ng ? RW[32 + rg_] : 0.0;
+                W16_UNROLL for (int s = 0; s < R; s++) m[s] += (mine[s] ? GTq[g * n + (mine[s] ? row[s] : 0)] : 0.0) * Ag;
             }
         }
         /* y = Lx+ (Lx+' rb) + p+ */
@@ -687,13 +1108,13 @@ __global__ void __launch_bounds__(64) ky_backrhs(GqpDev D, GqpOpts O, int redo)
  * while this one computes); rows AND columns of the factor are read from the packed block where they are used -- no
  * register copy, no transposition tile.  Vectors and box rows are loaded one stage ahead into registers.  As in the factor
  * sweep no row leaves while another row of the wave is alive (the DMA needs all 64 lanes); a dead row writes nothing. */
-template <int NX, int NU, bool CORR>
+template <int NX, int NU, bool CORR, int NG = 0>
 __global__ void __launch_bounds__(64) ky_fwd(GqpDev D, GqpOpts O, int redo)
 {
     GQP_DYN_SHARED(smem);
-    typedef W16RLds<NX, NU> LY;
-    constexpr bool PFORM = CORR;
-    constexpr int n = NX + NU, R = LY::R, NP = LY::NP, NB = LY::NB, NBUF = LY::NBUF;
+    typedef W16RLds<NX, NU, NG> LY;
+    constexpr bool PFORM = CORR, GEN = NG > 0;
+    constexpr int n = NX + NU, R = LY::R, NP = LY::NP, NB = LY::NB, NBUF = LY::NBUF, NGP = (NG * n + 15) / 16;
     const int l = threadIdx.x & 15, rq = threadIdx.x >> 4;
     const int inst0 = blockIdx.x * 4;
     bool aq[4], any = false, alive = false;
@@ -707,7 +1128,8 @@ __global__ void __launch_bounds__(64) ky_fwd(GqpDev D, GqpOpts O, int redo)
         if (q == rq) { alive = aq[q]; inst = iq[q]; }
     }
     if (!any) return; /* redo = 1: only the instances whose corrector step was rejected; redo = 2: sensitivity pass */
-    double *T = smem + rq * LY::SZ, *xb = T + LY::XB;
+    double *T = smem + rq * LY::SZ, *xb = T + LY::XB, *GTq = T + LY::GTF, *RW = GTq + LY::RWO;
+    int *RI = (int *) (RW + 64);
     int row[R], cx[R];
     bool mine[R], isx[R];
     W16_UNROLL for (int s = 0; s < R; s++) row[s] = l + 16 * s;
@@ -748,13 +1170,16 @@ __global__ void __launch_bounds__(64) ky_fwd(GqpDev D, GqpOpts O, int redo)
             const int lc = mn ? row[s] : 0, xc = ix ? row[s] - NU : 0;
             p_lv[s] = WAT(D.lf, kk * n + lc);
             p_rb[s] = WAT(D.rb, kk * NX + xc);
-            const bool hs = mn && (((c_bm & ~c_em) >> row[s]) & 1);
-            const int ib = hs ? popc64(c_bm & (((uint64_t) 1 << row[s]) - 1)) : 0;
-            const int el = c_oct + ib, eu = el + c_nb;
-            p_ll[s] = WAT(D.lam, el); p_lu[s] = WAT(D.lam, eu);
-            p_tl[s] = WAT(D.t, el); p_tu[s] = WAT(D.t, eu);
-            p_dl[s] = WAT(D.rd, el); p_du[s] = WAT(D.rd, eu);
-            p_pl[s] = CORR ? WAT(D.pcorr, el) : 0.0; p_pu[s] = CORR ? WAT(D.pcorr, eu) : 0.0;
+            if (!GEN)
+            {
+                const bool hs = mn && (((c_bm & ~c_em) >> row[s]) & 1);
+                const int ib = hs ? popc64(c_bm & (((uint64_t) 1 << row[s]) - 1)) : 0;
+                const int el = c_oct + ib, eu = el + c_nb;
+                p_ll[s] = WAT(D.lam, el); p_lu[s] = WAT(D.lam, eu);
+                p_tl[s] = WAT(D.t, el); p_tu[s] = WAT(D.t, eu);
+                p_dl[s] = WAT(D.rd, el); p_du[s] = WAT(D.rd, eu);
+                p_pl[s] = CORR ? WAT(D.pcorr, el) : 0.0; p_pu[s] = CORR ? WAT(D.pcorr, eu) : 0.0;
+            }
         }
     };
     load_desc(0);
@@ -785,8 +1210,25 @@ __global__ void __launch_bounds__(64) ky_fwd(GqpDev D, GqpOpts O, int redo)
             xc_[s] = isx[s] ? cx[s] : 0;
             lv[s] = mine[s] ? p_lv[s] : 0.0;
             rbv[s] = isx[s] ? p_rb[s] : 0.0;
-            q_ll[s] = p_ll[s]; q_lu[s] = p_lu[s]; q_tl[s] = p_tl[s]; q_tu[s] = p_tu[s];
-            q_dl[s] = p_dl[s]; q_du[s] = p_du[s]; q_pl[s] = p_pl[s]; q_pu[s] = p_pu[s];
+            if (!GEN)
+            {
+                q_ll[s] = p_ll[s]; q_lu[s] = p_lu[s]; q_tl[s] = p_tl[s]; q_tu[s] = p_tu[s];
+                q_dl[s] = p_dl[s]; q_du[s] = p_du[s]; q_pl[s] = p_pl[s]; q_pu[s] = p_pu[s];
+            }
+        }
+        W16Dsc gdsc = {c_nb, 0, 0, c_oct, 0};
+        const int nbf = popc64(imask);
+        if (GEN)
+        {
+            /* general rows of the stage (read again below: a'dv), descriptor fields and slack indices of the rows */
+            const GqpStage &S = D.st[k];
+            gdsc.ng = S.ng; gdsc.ns = S.ns; gdsc.o_s = S.o_s;
+            W16_UNROLL for (int i = 0; i < NGP; i++)
+            {
+                const int e = l + 16 * i;
+                if (e < NG * n) GTq[e] = e < S.ng * n ? WAT(D.DCt, S.o_g * n + e) : 0.0;
+            }
+            GQP_ROWSYNC();
         }
         if ((NP & 1) || (NB & 1))
         {
@@ -885,7 +1327,16 @@ __global__ void __launch_bounds__(64) ky_fwd(GqpDev D, GqpOpts O, int redo)
         W16_UNROLL for (int s = 0; s < R; s++)
         {
             const bool has = mine[s] && ((imask >> row[s]) & 1);
-            if (has)
+            if (GEN)
+            {
+                if (has) /* step and row index of the slot's box row, to the lane that processes it */
+                {
+                    const int jb = popc64(imask & (((uint64_t) 1 << row[s]) - 1));
+                    RW[jb] = dv[s];
+                    RI[jb] = popc64(bmask & (((uint64_t) 1 << row[s]) - 1));
+                }
+            }
+            else if (has)
             {
                 const int ib = popc64(bmask & (((uint64_t) 1 << row[s]) - 1));
                 const bool al = (am >> ib) & 1, au = (am >> (nbg + ib)) & 1;
@@ -922,6 +1373,24 @@ __global__ void __launch_bounds__(64) ky_fwd(GqpDev D, GqpOpts O, int redo)
                     WAT(D.dt, el) = dtl; WAT(D.dt, eu) = dtu;
                 }
             }
+        }
+        if (GEN)
+        {
+            /* one inequality row per lane: lane i processes row i (sorted box rows, then general rows) with the step of the
+             * row's value from LDS (box rows: written above; general rows: a'dv, a 16-lane sum) */
+            W16_UNROLL for (int g = 0; g < NG; g++)
+            {
+                double t = 0.0;
+                W16_UNROLL for (int s = 0; s < R; s++) t += (mine[s] ? GTq[g * n + lc_[s]] : 0.0) * dv[s];
+                t = w16_rowsum(t, xb);
+                if (l == g && g < gdsc.ng) { RW[nbf + g] = t; RI[nbf + g] = gdsc.nb + g; }
+            }
+            GQP_ROWSYNC();
+            const bool hr = l < nbf + gdsc.ng;
+            const int rr = hr ? RI[l] : 0;
+            const int sjr = hr ? (int) D.st[k].srev[rr] : -1;
+            w16r_row_fwd<CORR>(D, O, inst, alive, gdsc, am, hr, rr, sjr, RW[hr ? l : 0], smu, pscale, alpha, S0, S1, S2, nact);
+            GQP_ROWSYNC();
         }
         W16_UNROLL for (int s = 0; s < R; s++)
         {
@@ -985,6 +1454,24 @@ __global__ void __launch_bounds__(64) ky_fwd(GqpDev D, GqpOpts O, int redo)
         {
             const double p0 = WAT(D.pi, k * NX + xc_), dp = WAT(D.dpi, k * NX + xc_);
             if (isx[s]) WAT(D.pi, k * NX + cx[s]) = p0 + a * dp;
+        }
+        if (GEN)
+        {
+            for (int k = 0; k <= D.N; k++)
+            {
+                const GqpStage &S = D.st[k];
+                const W16Dsc dsc = {S.nb, S.ng, S.ns, S.o_ct, S.o_s};
+                const uint64_t am = WAT(D.amask, k * D.AW);
+                {
+                    /* box row of the slot (equality-flagged rows take no part), general row l in slot 0 */
+                    const bool hb = mine[s] && (((S.bmask & ~S.emask) >> row[s]) & 1);
+                    const int ib = hb ? popc64(S.bmask & (((uint64_t) 1 << row[s]) - 1)) : 0;
+                    w16r_row_update(D, O, inst, dsc, am, hb, ib, (int) S.srev[ib], a);
+                    const bool hg = s == 0 && l < S.ng;
+                    w16r_row_update(D, O, inst, dsc, am, hg, S.nb + (hg ? l : 0), (int) S.srev[S.nb + (hg ? l : 0)], a);
+                }
+            }
+            continue;
         }
         /* distinct arrays: tell the compiler, so that the loads of several stages can be in flight */
         const GqpStage *__restrict__ st_ = D.st;

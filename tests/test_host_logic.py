@@ -198,7 +198,11 @@ def test_c4_shape_general_constraints_and_slacks_hostsim(hostsim_lib, monkeypatc
     from acados_amd.generators import chain_soft_qp
     monkeypatch.setenv("ACADOS_AMD_WPI", wpi)
     b = _check_batch_vs_oracle([chain_soft_qp(i, N=6) for i in range(2)], hostsim_lib)
-    assert b.kernel_name.startswith("wpi-gen(nx=24,nu=3,ng=4,ns=8" if wpi == "1" else "1tpi<NX=24,NU=3,NG=4,NS=8>")
+    assert b.kernel_name.startswith("w16r-gen<NX=24,NU=3,NG=4>" if wpi == "1" else "1tpi<NX=24,NU=3,NG=4,NS=8>")
+    if wpi == "1":   # the wave-per-instance GEN kernels the class ran on before (and still does where a slack is shared)
+        monkeypatch.setenv("ACADOS_AMD_W16G", "0")
+        b = _check_batch_vs_oracle([chain_soft_qp(i, N=6) for i in range(2)], hostsim_lib)
+        assert b.kernel_name.startswith("wpi-gen(nx=24,nu=3,ng=4,ns=8")
 
 
 def test_more_than_64_inequality_sides_hostsim(hostsim_lib):
@@ -694,7 +698,7 @@ def test_solution_sensitivities_soft_constraints_hostsim(hostsim_lib, monkeypatc
                               + [g.get(pre + "sl", k) for k in range(1, N + 1)] + [g.get(pre + "su", k) for k in range(1, N + 1)], axis=1)
 
     ref = build(data)
-    assert ref.kernel_name.startswith("wpi-gen(")
+    assert ref.kernel_name.startswith("w16r-gen<")   # (the wave-per-instance GEN kernels: same test on the GPU tier, ACADOS_AMD_W16G=0)
     e = np.zeros((B, 24)); e[:, 7] = 1.0
     h = 1e-3
     for name in ("q", "x0"):

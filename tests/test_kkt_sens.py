@@ -238,8 +238,9 @@ def test_sensitivities_box_vs_dense(clib, request, monkeypatch, fam):
         assert worst <= 1e-6, (name, worst)
 
 
+@pytest.mark.parametrize("fam", ["w16r-gen<", "wpi-gen("])
 @pytest.mark.parametrize("clib", TIERS, indirect=True)
-def test_sensitivities_soft_and_general_rows_vs_dense(clib, request, monkeypatch):
+def test_sensitivities_soft_and_general_rows_vs_dense(clib, request, monkeypatch, fam):
     """a12 on the general-constraint / slack kernels (C4 class: soft state bounds + soft general rows): seeds in q, b,
     x0 and in a general-row bound; x, u, slacks, pi and the multipliers of every instance against the dense solve at the
     oracle's solution (extended-precision LU).  Tolerance 2e-4 relative at the acados tolerances (1e-8): the stage matrix
@@ -251,6 +252,7 @@ def test_sensitivities_soft_and_general_rows_vs_dense(clib, request, monkeypatch
     from acados_amd.generators import chain_soft_batch, chain_soft_dims, chain_soft_instance_qp, fill_chain_soft_batch
     gpu = "gpu" in request.node.callspec.id.split("-")
     monkeypatch.setenv("ACADOS_AMD_WPI", "1")
+    monkeypatch.setenv("ACADOS_AMD_W16G", "1" if fam.startswith("w16r") else "0")   # both families that carry general rows + slacks
     N, B = (4, 5) if gpu else (3, 2)
     data = chain_soft_batch(N=N, batch=B, seed=1)
     gb = OcpQpGpuBatch(chain_soft_dims(N), B, _clib=clib)
@@ -258,7 +260,7 @@ def test_sensitivities_soft_and_general_rows_vs_dense(clib, request, monkeypatch
     for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
         gb.opts_set(f, 1e-8)
     assert gb.solve() == 0
-    assert gb.kernel_name.startswith("wpi-gen(")
+    assert gb.kernel_name.startswith(fam)
     qps = [chain_soft_instance_qp(data, i, N) for i in range(B)]
     rng = np.random.default_rng(9)
     ex, eg = rng.standard_normal((B, 24)), rng.standard_normal((B, 4))

@@ -8,12 +8,20 @@ import torch  # noqa: F401  (HIP runtime first)
 from acados_amd import OcpQpGpuBatch, _lib
 from acados_amd.generators import fill_lqr_batch, lqr_dims, random_lqr_batch
 
-nx, nu, N, B = (int(a) for a in (sys.argv[1:5] if len(sys.argv) >= 5 else (24, 6, 50, 4096)))
+c4 = len(sys.argv) > 1 and sys.argv[1] == "c4"     # the C4 class (general rows + slacks): python tools/w16r_phase_cycles.py c4 [batch]
 L = _lib.bind(ctypes.CDLL(os.path.join(ROOT, "acados_amd", "csrc", "libacados_amd_qp_timing.so")))
 L.gqp_wpi_cycles_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
-data = random_lqr_batch(N=N, nx=nx, nu=nu, batch=B, seed=1)
-gb = OcpQpGpuBatch(lqr_dims(N, nx, nu), B, _clib=L)
-fill_lqr_batch(gb, data, N)
+if c4:
+    from acados_amd.generators import chain_soft_batch, chain_soft_dims, fill_chain_soft_batch
+    N, B = 40, int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+    data = chain_soft_batch(N=N, batch=B, seed=1)
+    gb = OcpQpGpuBatch(chain_soft_dims(N), B, _clib=L)
+    fill_chain_soft_batch(gb, data, N)
+else:
+    nx, nu, N, B = (int(a) for a in (sys.argv[1:5] if len(sys.argv) >= 5 else (24, 6, 50, 4096)))
+    data = random_lqr_batch(N=N, nx=nx, nu=nu, batch=B, seed=1)
+    gb = OcpQpGpuBatch(lqr_dims(N, nx, nu), B, _clib=L)
+    fill_lqr_batch(gb, data, N)
 for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
     gb.opts_set(f, 1e-8)
 gb.solve()
