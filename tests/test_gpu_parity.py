@@ -223,15 +223,18 @@ def _check_batch_vs_oracle_gpu(qps, n_check, tol=1e-8, tol_stat=1e-8):
     return b
 
 
-def test_c4_chain_soft_constraints_gpu(gpu_lib):
-    """C4 shape: N=40 nx=24 nu=3, hard input bounds, soft state bounds, soft general rows, ns=8"""
+@pytest.mark.parametrize("fam", ["w16r-gen<NX=24,NU=3,NG=4>", "wpi-gen(nx=24,nu=3,ng=4,ns=8"])
+def test_c4_chain_soft_constraints_gpu(gpu_lib, monkeypatch, fam):
+    """C4 shape: N=40 nx=24 nu=3, hard input bounds, soft state bounds, soft general rows, ns=8 -- on the two-rows-per-lane
+    GEN kernels (default) and on the wave-per-instance GEN kernels"""
     from acados_amd.generators import chain_soft_qp
+    monkeypatch.setenv("ACADOS_AMD_W16G", "1" if fam.startswith("w16r") else "0")
     # all four tolerances at 1e-8 (what ocp_nlp sets, ocp_nlp_common.c:1281-1293).  Instance 53 is the one
     # that used to stall at res_stat ~1e-5 with mu at 1e-16 until the slack block was eliminated in its
     # cancellation-free form (DESIGN.md): it is part of the batch on purpose.
     qps = [chain_soft_qp(i, N=40) for i in range(96)]
     b = _check_batch_vs_oracle_gpu(qps, 4, tol=1e-7, tol_stat=1e-8)
-    assert b.kernel_name.startswith("wpi-gen(nx=24,nu=3,ng=4,ns=8")
+    assert b.kernel_name.startswith(fam)
     o = OracleQp(qps[53])
     assert o.solve(default_opts(tol_stat=1e-8)) == 0
     compare_with_oracle(lambda k, f: b.get(f, k)[53], o, qps[53], 1e-7)
@@ -260,7 +263,7 @@ def test_c4_full_size_properties_gpu(gpu_lib):
     fill_chain_soft_batch(gb, data, N)
     for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
         gb.opts_set(f, 1e-8)
-    assert gb.solve() == 0 and gb.kernel_name.startswith("wpi-gen(nx=24,nu=3,ng=4,ns=8")
+    assert gb.solve() == 0 and gb.kernel_name.startswith("w16r-gen<NX=24,NU=3,NG=4>")
     assert np.all(gb.info("status") == 0)
     for n in ("res_stat", "res_eq", "res_ineq", "res_comp"):
         assert gb.info(n).max() <= 1e-8
