@@ -18,7 +18,12 @@
  * Same algorithm, HBM arrays and slot conventions as ipm_kernels_w16.hpp / ipm_kernels_wpi.hpp (whose init / finalize
  * kernels serve this family too); box constraints without slacks (soft rows and general rows stay with the
  * wave-per-instance kernels).  Shapes are compile-time.
- * The CPU test tier runs these kernels under tests/hostsim like the one-row family.
+ * The CPU test tier runs these kernels under tests/hostsim like the one-row family.  One rule follows from it for the kernels
+ * that use LDS-DMA: the host simulation copies a lane's 16 bytes when THAT lane reaches the call and keeps the lanes of a
+ * block in step by counting their yields (every GQP_ROWSYNC, every broadcast), so the four rows of a workgroup must execute
+ * the same number of broadcasts -- no broadcast inside a value-dependent conditional (`d != 0 ? bcast(x) / d : 0` let a row
+ * with an empty LDS tile run a stage ahead of the others and overwrite the buffer they were still reading).  On the device
+ * the wavefront executes in lockstep anyway.
  */
 #ifndef IPM_KERNELS_W16R_HPP_
 #define IPM_KERNELS_W16R_HPP_

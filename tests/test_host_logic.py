@@ -923,6 +923,39 @@ def test_sixteen_lanes_two_rows_per_lane_hostsim(hostsim_lib, monkeypatch):
     assert np.array_equal(sols["1"][1], sols["0"][1])
 
 
+def test_two_rows_per_lane_general_rows_and_slacks_hostsim(hostsim_lib, monkeypatch):
+    """w16r-gen (C4 class: soft state bounds + soft general rows, one slack per row) against the wave-per-instance GEN
+    kernels on the same ragged batch: equal iteration counts, solutions (x, u, slacks, multipliers) equal to 1e-9; a
+    structure the family does not cover (a slack shared by two rows) falls back to the wave-per-instance kernels"""
+    from acados_amd import OcpQpGpuBatch
+    from acados_amd.generators import chain_soft_qp
+    N, B = 3, 5
+    qps = [chain_soft_qp(i, N=N) for i in range(B)]
+    sols = {}
+    for fam in ("1", "0"):
+        monkeypatch.setenv("ACADOS_AMD_W16G", fam)
+        g = OcpQpGpuBatch.from_qps(qps, _clib=hostsim_lib)
+        for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+            g.opts_set(f, 1e-8)
+        assert g.solve() == 0
+        assert g.kernel_name.startswith("w16r-gen<NX=24,NU=3,NG=4>" if fam == "1" else "wpi-gen(")
+        sols[fam] = ([g.get(f, k) for f in ("x", "u", "lam", "sl", "su") for k in range(N + 1)] + [g.get("pi", k) for k in range(N)],
+                     np.array(g.info("iter")))
+    assert np.array_equal(sols["1"][1], sols["0"][1])
+    for a, c in zip(sols["1"][0], sols["0"][0]):
+        if a.size:
+            np.testing.assert_allclose(a, c, rtol=1e-9, atol=1e-9)
+    monkeypatch.setenv("ACADOS_AMD_W16G", "1")
+    qp = chain_soft_qp(0, N=N)
+    rev = np.array(qp.idxs_rev[1]).copy()
+    soft = np.flatnonzero(rev >= 0)
+    rev[soft[1]] = rev[soft[0]]          # two rows of stage 1 share one slack
+    qp.idxs_rev[1] = rev
+    g = OcpQpGpuBatch.from_qps([qp], _clib=hostsim_lib)
+    g.solve()
+    assert g.kernel_name.startswith("wpi-gen("), g.kernel_name
+
+
 def test_solution_sensitivities_after_partial_condensing_hostsim(hostsim_lib, monkeypatch):
     """sensitivities of a partially condensed solve: computed in the full space at the expanded solution, equal to
     the finite differences of (partially condensed) solves"""
