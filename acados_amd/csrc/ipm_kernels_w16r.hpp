@@ -75,6 +75,13 @@ __device__ static inline void w16r_dma16(const double *sbase, const double *ldsp
 /* (s_barrier: a no-op for a one-wave workgroup as far as synchronisation goes; the programming guide orders the reads of
  * DMA'd data behind "vmcnt, then a barrier") */
 #define W16R_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory")
+/* The kernels that use LDS-DMA are pinned to ONE wave per SIMD, whatever their register count.  Measured (the C3 shape, forward
+ * sweep built for two waves per SIMD): a few instances in 65,536 come out wrong as soon as two of these waves share a SIMD
+ * -- not an LDS overrun (padding the allocation by a few KB changes nothing), not the spill code of that build (the same
+ * binary is correct when a 60 KB allocation leaves room for two workgroups per CU, one per SIMD), not cured by 512 idle
+ * cycles after the vmcnt wait.  One wave per SIMD is what every test and every measurement runs; the attribute keeps a
+ * future compiler from packing two. */
+#define W16R_ONE_WAVE_PER_SIMD __attribute__((amdgpu_waves_per_eu(1, 1)))
 #define W16R_LDS_DRAIN() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #else
 template <int IMM>
@@ -84,6 +91,7 @@ __device__ static inline void w16r_dma16(const double *sbase, const double *ldsp
     memcpy((char *) ldsp + o, (const char *) sbase + o, 16);
 }
 #define W16R_DMA_WAIT() GQP_ROWSYNC()
+#define W16R_ONE_WAVE_PER_SIMD
 #define W16R_LDS_DRAIN() GQP_ROWSYNC()
 #endif
 /* G granules of 16 bytes, contiguous on both sides: full passes of 64 lanes, then the lanes the last pass needs */
@@ -416,7 +424,7 @@ __device__ static inline void w16r_row_update(const GqpDev &D, const GqpOpts &O,
 /* ------------------------------------------------------------------------------------------------ factor */
 
 template <int NX, int NU, int NG = 0>
-__global__ void __launch_bounds__(64) ky_factor(GqpDev D, GqpOpts O, int redo)
+__global__ void __launch_bounds__(64) W16R_ONE_WAVE_PER_SIMD ky_factor(GqpDev D, GqpOpts O, int redo)
 {
     GQP_DYN_SHARED(smem);
     typedef W16RLds<NX, NU, NG> LY;
@@ -1114,7 +1122,7 @@ __global__ void __launch_bounds__(64) ky_backrhs(GqpDev D, GqpOpts O, int redo)
  * register copy, no transposition tile.  Vectors and box rows are loaded one stage ahead into registers.  As in the factor
  * sweep no row leaves while another row of the wave is alive (the DMA needs all 64 lanes); a dead row writes nothing. */
 template <int NX, int NU, bool CORR, int NG = 0>
-__global__ void __launch_bounds__(64) ky_fwd(GqpDev D, GqpOpts O, int redo)
+__global__ void __launch_bounds__(64) W16R_ONE_WAVE_PER_SIMD ky_fwd(GqpDev D, GqpOpts O, int redo)
 {
     GQP_DYN_SHARED(smem);
     typedef W16RLds<NX, NU, NG> LY;
