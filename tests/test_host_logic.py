@@ -375,6 +375,10 @@ def test_partial_condensing_hostsim(hostsim_lib, monkeypatch):
     data = random_lqr_batch(N=8, nx=4, nu=1, batch=5, seed=5)
     b = run([lqr_instance_qp(data, i, 8) for i in range(5)], 2, 2)
     assert b.scalar("pcond_kernel") == 2
+    data = random_lqr_batch(N=7, nx=4, nu=1, batch=3, seed=6)     # blocks of 4 and 3: a short block inside the compiled shape
+    b = run([lqr_instance_qp(data, i, 7) for i in range(3)], 2, 2)
+    assert b.scalar("pcond_kernel") == 2
+    run([lqr_instance_qp(data, i, 7) for i in range(3)], 2, 2, split=True)
     run([load_qp("qp_test/last_qp_nonuniform_pendulum.json")], 3, 3)   # N=7 -> 3, 2, 2 ; x0 equality rows
 
 
