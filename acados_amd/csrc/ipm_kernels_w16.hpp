@@ -52,33 +52,6 @@ __device__ static inline double w16_bcast(double v, int j, double *)
         case 12: return w16_bc<12>(v); case 13: return w16_bc<13>(v); case 14: return w16_bc<14>(v); default: return w16_bc<15>(v);
     }
 }
-/* acc += (value of lane j of the row) * oth in ONE instruction: v_fmac_f64 takes the row broadcast as a DPP modifier of its
- * first source (DP-ALU DPP, gfx90a+: row_newbcast only).  The compiler never forms it (it emits v_mov_b64_dpp + v_fmac_f64:
- * 8 + 4 cycles per wave against 6, tools/dpp_fma_probe), hence inline asm -- not volatile: a pure function of its inputs,
- * free to be scheduled.  The compiler does not know the statement reads `src` through DPP, so the wait states a DPP read
- * needs after a VALU write of its source (2) or after a write of EXEC (5) are the kernel's business: W16_DPP_SETTLE(...)
- * behind the last write of the broadcast sources / at the top of a phase. */
-template <int J>
-__device__ static inline void w16_fmabc_(double &acc, double src, double oth)
-{
-    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(src), "v"(oth), "n"(J));
-}
-__device__ static inline void w16_fma_bc(double &acc, double src, int j, double oth, double *)
-{
-    switch (j)
-    {
-        case 0: w16_fmabc_<0>(acc, src, oth); break; case 1: w16_fmabc_<1>(acc, src, oth); break;
-        case 2: w16_fmabc_<2>(acc, src, oth); break; case 3: w16_fmabc_<3>(acc, src, oth); break;
-        case 4: w16_fmabc_<4>(acc, src, oth); break; case 5: w16_fmabc_<5>(acc, src, oth); break;
-        case 6: w16_fmabc_<6>(acc, src, oth); break; case 7: w16_fmabc_<7>(acc, src, oth); break;
-        case 8: w16_fmabc_<8>(acc, src, oth); break; case 9: w16_fmabc_<9>(acc, src, oth); break;
-        case 10: w16_fmabc_<10>(acc, src, oth); break; case 11: w16_fmabc_<11>(acc, src, oth); break;
-        case 12: w16_fmabc_<12>(acc, src, oth); break; case 13: w16_fmabc_<13>(acc, src, oth); break;
-        case 14: w16_fmabc_<14>(acc, src, oth); break; default: w16_fmabc_<15>(acc, src, oth); break;
-    }
-}
-/* five idle cycles, ordered behind the computation of x (an operand the following fused broadcasts read) */
-#define W16_DPP_SETTLE(x) asm volatile("s_nop 4" : "+v"(x))
 #else
 /* host simulation (tests/hostsim defines GQP_ROWSYNC as a per-row thread barrier) and the host pass of hipcc
  * (kernels are only parsed there): the broadcast goes through the exchange buffer */
@@ -94,8 +67,6 @@ __device__ static inline double w16_bcast(double v, int j, double *xbuf)
     GQP_ROWSYNC();
     return r;
 }
-__device__ static inline void w16_fma_bc(double &acc, double src, int j, double oth, double *xbuf) { acc += w16_bcast(src, j, xbuf) * oth; }
-#define W16_DPP_SETTLE(x) do { } while (0)
 #endif
 
 /* per-instance LDS tile (doubles): exchange buffer, x-block tiles of two factors, one full factor tile, vectors */
@@ -288,9 +259,8 @@ __global__ void __launch_bounds__(64) kx_factor(GqpDev D, GqpOpts O, int redo)
         /* ---- W row: W[c] = sum_{q >= c} Br[q] Lx+[q][c], Lx+[q][c] = entry c of the row held by lane NU + q ---- */
         double W[NX];
         W16_UNROLL for (int c = 0; c < NX; c++) W[c] = 0.0;
-        W16_DPP_SETTLE(Lp[0]);
         W16_UNROLL for (int q = 0; q < NX; q++)
-            W16_UNROLL for (int c = 0; c <= q; c++) w16_fma_bc(W[c], Lp[c], NU + q, Br[q], xb);
+            W16_UNROLL for (int c = 0; c <= q; c++) W[c] += Br[q] * w16_bcast(Lp[c], NU + q, xb);
         /* w0[c] (state lanes) = lx+[c] + sum_{q >= c} Lx+[q][c] rb[q]: column c of Lx+ is LpT */
         double w0 = lxn;
         W16_UNROLL for (int q = 0; q < NX; q++)
@@ -304,9 +274,8 @@ __global__ void __launch_bounds__(64) kx_factor(GqpDev D, GqpOpts O, int redo)
         W16_UNROLL for (int c = 0; c < NX; c++) m += W[c] * w16_bcast(w0, NU + c, xb);
         if (fixed || !mine) m = 0.0;
         /* ---- M += W W' + reg + Gamma: M[c] += sum_q W_l[q] W_c[q] ---- */
-        W16_UNROLL for (int q = 0; q < NX; q++) W16_DPP_SETTLE(W[q]);
         W16_UNROLL for (int q = 0; q < NX; q++)
-            W16_UNROLL for (int c = 0; c < n; c++) w16_fma_bc(M[c], W[q], c, W[q], xb);
+            W16_UNROLL for (int c = 0; c < n; c++) M[c] += W[q] * w16_bcast(W[q], c, xb);
         W16_UNROLL for (int c = 0; c < n; c++) M[c] += (c == l) ? O.reg_prim + gam : 0.0;
         if (S.emask) /* uniform: only a stage with fixed variables pays for the masking */
         {
@@ -329,10 +298,8 @@ __global__ void __launch_bounds__(64) kx_factor(GqpDev D, GqpOpts O, int redo)
              * rows above keep their entry */
             const double Llj = l >= j ? M[j] * inv : M[j];
             M[j] = Llj;
-            double lo = l > j ? Llj : 0.0; /* finished rows take no part in the trailing update */
-            const double nlo = -lo;
-            W16_DPP_SETTLE(lo);
-            W16_UNROLL for (int c = j + 1; c < n; c++) w16_fma_bc(M[c], lo, c, nlo, xb);
+            const double lo = l > j ? Llj : 0.0; /* finished rows take no part in the trailing update */
+            W16_UNROLL for (int c = j + 1; c < n; c++) M[c] -= lo * w16_bcast(lo, c, xb);
             m = l == j ? lj : m - lo * lj;
         }
 
