@@ -10,11 +10,16 @@
  * (slot 0, slot 1).  Variable j lives in lane j & 15, slot j >> 4, so a broadcast of "the value of variable j" is
  * still ONE DPP move with an immediate lane, and one broadcast feeds R multiply-adds.
  *
- * Differences from the one-row family, all of them about registers (n = 30 leaves no room for everything):
- *   - the x-block of the factor of the stage handled before lives in the per-instance LDS tile TA and is read from
- *     there (uniform address per instance for the W product, column reads for Lx+' rb) instead of two register copies;
- *   - the column of the factor the forward sweep needs is read from the LDS tile TF where it is used;
- *   - only the lower triangle is carried: slot 0 (rows < 16) never touches columns >= 16.
+ * Differences from the one-row family, all of them about registers and latency (n = 30 needs ~420 registers: one wave per
+ * SIMD, four workgroups per CU, 40 KB of LDS each):
+ *   - what a stage reads from HBM arrives one stage ahead: the packed H / factor block and the [B A]' block by LDS-DMA
+ *     (global_load_lds_dwordx4, no VGPR in between), vectors and box rows by plain loads into registers;
+ *   - rows and columns of H, of the factor and of [B A]' are read from their LDS images where they are used (lane base +
+ *     immediate offset); the previous factor's x-block stays in the register rows of the state slots and is broadcast from
+ *     there (factor sweep) or sits in a small LDS tile (rhs-only sweep);
+ *   - only the lower triangle is carried: slot 0 (rows < 16) never touches columns >= 16;
+ *   - accumulators are pinned at the end of their phase and the lanes' row index is laundered once per stage: machine
+ *     sinking and loop-invariant code motion otherwise spill hundreds of registers (W16R_OPAQUE).
  * Same algorithm, HBM arrays and slot conventions as ipm_kernels_w16.hpp / ipm_kernels_wpi.hpp (whose init / finalize
  * kernels serve this family too); box constraints without slacks (soft rows and general rows stay with the
  * wave-per-instance kernels).  Shapes are compile-time.
@@ -37,15 +42,16 @@ namespace gqp
  * Factor sweep: exchange buffer (host simulation) + two regions filled by LDS-DMA one stage ahead: HR, the packed H block
  * of the stage as it lies in memory, and BR, its [B A]' block as it lies in memory (BR also carries the transposition tile
  * of the previous factor's x-block once the stage is done with [B A]').
- * rhs-only sweep: exchange buffer + the square x-block tile; forward sweep: exchange buffer + the full factor tile. */
+ * rhs-only sweep: exchange buffer + the square x-block tile; forward sweep: exchange buffer + packed factor and [B A]' by
+ * LDS-DMA (two buffers where 40 KB per workgroup allow).  GEN variants add the stage's general rows and the row vectors. */
 template <int NX, int NU, int NG = 0>
 struct W16RLds
 {
-    static constexpr int n = NX + NU, R = (n + 15) / 16, LDX = NX + 1, LDF = n + 1, NP = n * (n + 1) / 2, NB = n * NX;
+    static constexpr int n = NX + NU, R = (n + 15) / 16, LDX = NX + 1, NP = n * (n + 1) / 2, NB = n * NX;
     /* GEN variants: general rows [D C] of the stage, [g][n], + four 16-entry row vectors (value in, gamma / gadd / dlam out) */
     static constexpr int GSZ = NG > 0 ? ((NG * n + 1) & ~1) + 80 : 0, RWO = (NG * n + 1) & ~1; /* (+ 16: row index of every lane) */
-    static constexpr int XB = 0, TA = 16, TF = 16;
-    static constexpr int GTA = 16 + NX * LDX, SZ_A = GTA + GSZ, SZ_F = 16 + n * LDF;
+    static constexpr int XB = 0, TA = 16;
+    static constexpr int GTA = 16 + NX * LDX, SZ_A = GTA + GSZ;
     static constexpr int HR = 16, HSZ = (NP + 1) & ~1, BR = HR + HSZ, BSZ = (NB + 1) & ~1;
     static constexpr int GT = BR + BSZ, SZ_K = GT + GSZ;
     /* forward sweep: the packed factor and the [B A]' block of the stage by LDS-DMA, in two buffers (the next stage
