@@ -1,6 +1,7 @@
 /*
- * ipm_kernels_w16r.hpp -- SIXTEEN LANES PER INSTANCE, SEVERAL ROWS PER LANE: box-constrained stage blocks with
- * 17 <= nu + nx <= 32 (the nx = 24 classes of C5, the condensed shape of C3: nx = 8, nu = 15).
+ * ipm_kernels_w16r.hpp -- SIXTEEN LANES PER INSTANCE, SEVERAL ROWS PER LANE: stage blocks with 17 <= nu + nx <= 32 -- box
+ * constrained (the nx = 24 classes of C5, the condensed shape of C3: nx = 8, nu = 15) or, in the GEN instantiations, with
+ * general rows and slacks (C4).
  *
  * The wave-per-instance kernels (ipm_kernels_wpi.hpp) are bound by ONE wave's dependent instruction stream
  * (profiles/r02_wpi_phase_cycles.txt: ~9,400 instructions and ~98,000 cycles per stage at n = 30), most of it LDS
@@ -21,8 +22,8 @@
  *   - accumulators are pinned at the end of their phase and the lanes' row index is laundered once per stage: machine
  *     sinking and loop-invariant code motion otherwise spill hundreds of registers (W16R_OPAQUE).
  * Same algorithm, HBM arrays and slot conventions as ipm_kernels_w16.hpp / ipm_kernels_wpi.hpp (whose init / finalize
- * kernels serve this family too); box constraints without slacks (soft rows and general rows stay with the
- * wave-per-instance kernels).  Shapes are compile-time.
+ * kernels serve this family too).  Shapes are compile-time; general rows and slacks: see "inequality rows with slacks"
+ * below (one slack per row; shared slacks stay with the wave-per-instance kernels).
  * The CPU test tier runs these kernels under tests/hostsim like the one-row family.  One rule follows from it for the kernels
  * that use LDS-DMA: the host simulation copies a lane's 16 bytes when THAT lane reaches the call and keeps the lanes of a
  * block in step by counting their yields (every GQP_ROWSYNC, every broadcast), so the four rows of a workgroup must execute
