@@ -532,7 +532,7 @@ __global__ void __launch_bounds__(64) W16R_ONE_WAVE_PER_SIMD ky_factor(GqpDev D,
     c_bm = n_bm; c_em = n_em; c_nb = n_nb; c_oct = n_oct; c_ng = n_ng; c_og = n_og; c_ns = n_ns; c_os = n_os;
     dma_h(D.N);
     dma_b(D.N);
-    prefetch_v(D.N);
+    if (!GEN) prefetch_v(D.N);
     load_desc(D.N > 0 ? D.N - 1 : 0);
 
     double Lp[R][NX]; /* rows of the x-block of the factor of stage k+1 held by the state slots, zero above the diagonal */
@@ -553,6 +553,11 @@ __global__ void __launch_bounds__(64) W16R_ONE_WAVE_PER_SIMD ky_factor(GqpDev D,
             isx[s] = row[s] >= NU && row[s] < n;
             cx[s] = isx[s] ? row[s] - NU : 0;
         }
+        /* GEN: the vectors and the general rows of the stage are loaded HERE, in front of the wait for the DMA'd blocks (one
+         * exposed latency), not one stage ahead: the register file of this variant has no room for values that live across
+         * the stage, and a prefetched value that is spilled on arrival waits alone behind its own load -- thirty serialised
+         * memory latencies, 27 k cycles per stage */
+        if (GEN) prefetch_v(k);
         W16R_DMA_WAIT(); /* everything issued for this stage has landed */
         const uint64_t bmask = c_bm, emask = c_em, imask = bmask & ~emask, am = p_am;
         const int nbg = c_nb, o_ct = c_oct;
@@ -656,11 +661,13 @@ __global__ void __launch_bounds__(64) W16R_ONE_WAVE_PER_SIMD ky_factor(GqpDev D,
                 t = w16_rowsum(t, xb);
                 if (l == g && g < ng) { RW[nbf + g] = t; RI[nbf + g] = nbg + g; }
             }
+            W16R_TICK(7);
             GQP_ROWSYNC();
             const bool hr = l < nbf + ng;
             const int rr = hr ? RI[l] : 0;
             const int sjr = hr ? (int) D.st[k].srev[rr] : -1;
             const W16RowF rf = w16r_row_factor(D, O, inst, alive, dsc, am, hr, rr, sjr, RW[hr ? l : 0], nrm_g, nrm_d, nrm_m, musum, nact, obj);
+            W16R_TICK(8);
             GQP_ROWSYNC();
             RW[16 + l] = rf.gam; RW[32 + l] = rf.gadd; RW[48 + l] = rf.dlam;
             GQP_ROWSYNC();
@@ -686,6 +693,7 @@ __global__ void __launch_bounds__(64) W16R_ONE_WAVE_PER_SIMD ky_factor(GqpDev D,
                         if (W16R_LOW(s, c)) M[s][c] += ga * GTq[g * n + c];
                 }
             }
+            W16R_TICK(9);
             W16_UNROLL for (int s = 0; s < R; s++)
             {
                 W16R_OPAQUE(gtr[s]); W16R_OPAQUE(gar[s]); W16R_OPAQUE(gmr[s]);
@@ -781,6 +789,7 @@ __global__ void __launch_bounds__(64) W16R_ONE_WAVE_PER_SIMD ky_factor(GqpDev D,
                 if (mine[s]) { nacc(nrm_g, gt[s]); if (alive) WAT(D.rg, k * n + row[s]) = gt[s]; }
             }
         }
+        W16R_TICK(10);
         /* w0[c] (state slots) = lx+[c] + sum_{q >= c} Lx+[q][c] rb[q] needs COLUMN c of Lx+: the rows go through the
          * [B A]' region (the stage is done with it), the slots read their column back */
         GQP_ROWSYNC();
@@ -799,14 +808,16 @@ __global__ void __launch_bounds__(64) W16R_ONE_WAVE_PER_SIMD ky_factor(GqpDev D,
         }
         W16_UNROLL for (int s = 0; s < R; s++)
             if (!isx[s]) w0[s] = 0.0;
+        W16R_TICK(11);
         if (k > 0)
         {
             /* next stage: its [B A]' block by DMA; vectors, box rows and the descriptor after it into registers */
             dma_b(k - 1);
             c_bm = x_bm; c_em = x_em; c_nb = x_nb; c_oct = x_oct; c_ng = x_ng; c_og = x_og; c_ns = x_ns; c_os = x_os;
-            prefetch_v(k - 1);
+            if (!GEN) prefetch_v(k - 1); /* GEN: at the top of the stage, see there */
             load_desc(k > 1 ? k - 2 : 0);
         }
+        W16R_TICK(12);
         /* m = gt + gadd + W w0 */
         double m[R];
         W16_UNROLL for (int s = 0; s < R; s++) m[s] = gt[s] + gadd[s];

@@ -32,8 +32,13 @@ L.gqp_wpi_cycles_read(buf.ctypes.data, 1)
 it = int(gb.info("iter")[0]) + 1
 names = ["loads -> LDS staging, rows of H", "rb += [B A] v, H v", "W = [B A]' Lx+ (rolled), [B A]' pi+", "box rows, w0, m", "M += W W'",
          "Cholesky (+ rhs)", "factor -> HBM, x-block -> LDS"]
-tot = buf[:7].sum()
+extra = {7: "  (rows: values to the lanes, general-row sums)", 8: "  (rows: the row functions)", 9: "  (rows: results back, rank-one terms)",
+         10: "  (after W: stationarity residual, stores)", 11: "  (x-block transposed through LDS, w0)", 12: "  (DMA of the next [B A]', prefetch of the next vectors)"}
+tot = buf[:13].sum()
 print(f"kernel {gb.kernel_name}  batch {B}  instance 0: {it} factor sweeps, {N + 1} stages each")
 for q, nm in enumerate(names):
     print(f"  {nm:44s} {int(buf[q]) / it / (N + 1):10.0f} cycles/stage  {100.0 * int(buf[q]) / int(tot):5.1f} %")
+for q, nm in extra.items():
+    if buf[q]:
+        print(f"  {nm:44s} {int(buf[q]) / it / (N + 1):10.0f} cycles/stage  {100.0 * int(buf[q]) / int(tot):5.1f} %")
 print(f"  total                  {int(tot) / it / (N + 1):10.0f} cycles/stage (clock64 ticks)")
