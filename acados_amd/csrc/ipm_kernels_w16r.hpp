@@ -1184,11 +1184,12 @@ __global__ void __launch_bounds__(64) W16R_ONE_WAVE_PER_SIMD ky_fwd(GqpDev D, Gq
     double p_lv[R], p_rb[R], p_ll[R], p_lu[R], p_tl[R], p_tu[R], p_dl[R], p_du[R], p_pl[R], p_pu[R];
     double p_ft = 0.0, p_bt = 0.0;
     uint64_t p_am, c_bm, c_em, n_bm, n_em;
-    int c_nb, c_oct, n_nb, n_oct;
+    int c_nb, c_oct, n_nb, n_oct, c_ng = 0, c_ns = 0, c_os = 0, c_og = 0, n_ng = 0, n_ns = 0, n_os = 0, n_og = 0;
     auto load_desc = [&](int kk)
     {
         const GqpStage &Sn = D.st[kk];
         n_bm = Sn.bmask; n_em = Sn.emask; n_nb = Sn.nb; n_oct = Sn.o_ct;
+        if (GEN) { n_ng = Sn.ng; n_ns = Sn.ns; n_os = Sn.o_s; n_og = Sn.o_g; }
     };
     auto prefetch_v = [&](int kk) /* descriptor of stage kk in c_* */
     {
@@ -1214,7 +1215,7 @@ __global__ void __launch_bounds__(64) W16R_ONE_WAVE_PER_SIMD ky_fwd(GqpDev D, Gq
         }
     };
     load_desc(0);
-    c_bm = n_bm; c_em = n_em; c_nb = n_nb; c_oct = n_oct;
+    c_bm = n_bm; c_em = n_em; c_nb = n_nb; c_oct = n_oct; c_ng = n_ng; c_ns = n_ns; c_os = n_os; c_og = n_og;
     dma(0);
     prefetch_v(0);
     load_desc(D.N > 0 ? 1 : 0);
@@ -1227,6 +1228,16 @@ __global__ void __launch_bounds__(64) W16R_ONE_WAVE_PER_SIMD ky_fwd(GqpDev D, Gq
             mine[s] = row[s] < n;
             isx[s] = row[s] >= NU && row[s] < n;
             cx[s] = isx[s] ? row[s] - NU : 0;
+        }
+        /* GEN: the general rows of the stage, issued in front of the wait for the DMA'd blocks (descriptor in registers) */
+        double gtl[NGP > 0 ? NGP : 1];
+        if (GEN)
+        {
+            W16_UNROLL for (int i = 0; i < NGP; i++)
+            {
+                const int e = l + 16 * i;
+                gtl[i] = WAT(D.DCt, c_og * n + (e < c_ng * n ? e : 0));
+            }
         }
         W16R_DMA_WAIT();
         double *LF = T + 16 + (NBUF == 2 ? (k & 1) * LY::FBUF : 0); /* packed factor of the stage */
@@ -1252,12 +1263,11 @@ __global__ void __launch_bounds__(64) W16R_ONE_WAVE_PER_SIMD ky_fwd(GqpDev D, Gq
         if (GEN)
         {
             /* general rows of the stage (read again below: a'dv), descriptor fields and slack indices of the rows */
-            const GqpStage &S = D.st[k];
-            gdsc.ng = S.ng; gdsc.ns = S.ns; gdsc.o_s = S.o_s;
+            gdsc.ng = c_ng; gdsc.ns = c_ns; gdsc.o_s = c_os;
             W16_UNROLL for (int i = 0; i < NGP; i++)
             {
                 const int e = l + 16 * i;
-                if (e < NG * n) GTq[e] = e < S.ng * n ? WAT(D.DCt, S.o_g * n + e) : 0.0;
+                if (e < NG * n) GTq[e] = e < c_ng * n ? gtl[i] : 0.0;
             }
             GQP_ROWSYNC();
         }
@@ -1273,7 +1283,7 @@ __global__ void __launch_bounds__(64) W16R_ONE_WAVE_PER_SIMD ky_fwd(GqpDev D, Gq
         if (k < D.N)
         {
             if (NBUF == 2) dma(k + 1);
-            c_bm = n_bm; c_em = n_em; c_nb = n_nb; c_oct = n_oct;
+            c_bm = n_bm; c_em = n_em; c_nb = n_nb; c_oct = n_oct; c_ng = n_ng; c_ns = n_ns; c_os = n_os; c_og = n_og;
             prefetch_v(k + 1);
             load_desc(k + 2 <= D.N ? k + 2 : D.N);
         }
