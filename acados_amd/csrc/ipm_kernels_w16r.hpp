@@ -981,13 +981,36 @@ __global__ void __launch_bounds__(64) ky_backrhs(GqpDev D, GqpOpts O, int redo)
     struct StageRegs
     {
         double Lu[R][NU > 0 ? NU : 1], Lx[R][NX], Br[R][NX], rb[R], rg[R], ll[R], lu[R], tl[R], tu[R], dl[R], du[R], pl[R], pu[R];
+        double gt[NGP > 0 ? NGP : 1]; /* GEN: the general rows of the stage, flat over the 16 lanes */
         uint64_t am, bm, em;
         int nb, oct;
     };
+    /* GEN: the stage descriptor one stage ahead in registers, so that everything a stage reads can be issued at once */
+    struct Desc
+    {
+        uint64_t bm, em;
+        int nb, oct, ng, ns, os, og;
+    };
+    auto load_desc = [&](int k, Desc &d)
+    {
+        const GqpStage &S = D.st[k];
+        d.bm = S.bmask; d.em = S.emask; d.nb = S.nb; d.oct = S.o_ct; d.ng = S.ng; d.ns = S.ns; d.os = S.o_s; d.og = S.o_g;
+    };
+    Desc cd = {}, nd = {};
+    if (GEN) load_desc(D.N, cd);
     auto load = [&](int k, StageRegs &G)
     {
         const GqpStage &S = D.st[k];
-        G.bm = S.bmask; G.em = S.emask; G.nb = S.nb; G.oct = S.o_ct;
+        if (GEN)
+        {
+            G.bm = cd.bm; G.em = cd.em; G.nb = cd.nb; G.oct = cd.oct;
+            W16_UNROLL for (int i = 0; i < NGP; i++)
+            {
+                const int e = l + 16 * i;
+                G.gt[i] = WAT(D.DCt, cd.og * n + (e < cd.ng * n ? e : 0));
+            }
+        }
+        else { G.bm = S.bmask; G.em = S.emask; G.nb = S.nb; G.oct = S.o_ct; }
         G.am = WAT(D.amask, k * D.AW);
         W16_UNROLL for (int s = 0; s < R; s++)
         {
@@ -1021,6 +1044,7 @@ __global__ void __launch_bounds__(64) ky_backrhs(GqpDev D, GqpOpts O, int redo)
             if (k > 0) load(k - 1, Gn);
         }
         else load(k, G);
+        if (GEN && k > 0) load_desc(k - 1, nd);
         const uint64_t imask = G.bm & ~G.em, am = G.am;
         const int nbg = G.nb;
         double Lu[R][NU > 0 ? NU : 1], Lx[R][NX], Br[R][NX], rb[R], m[R];
@@ -1053,21 +1077,21 @@ __global__ void __launch_bounds__(64) ky_backrhs(GqpDev D, GqpOpts O, int redo)
         {
             /* general rows: gradient term of row g from lane g, applied as a gadd through the rows of [D C] */
             const GqpStage &S = D.st[k];
-            const int ng = S.ng;
+            const int ng = cd.ng;
             GQP_ROWSYNC();
             W16_UNROLL for (int i = 0; i < NGP; i++)
             {
                 const int e = l + 16 * i;
-                if (e < NG * n) GTq[e] = e < ng * n ? WAT(D.DCt, S.o_g * n + e) : 0.0;
+                if (e < NG * n) GTq[e] = e < ng * n ? G.gt[i] : 0.0;
             }
             GQP_ROWSYNC();
             /* one inequality row per lane (sorted box rows, then general rows); results back through LDS by row index */
-            const W16Dsc dsc = {S.nb, S.ng, S.ns, S.o_ct, S.o_s};
+            const W16Dsc dsc = {cd.nb, cd.ng, cd.ns, cd.oct, cd.os};
             const int nbf = popc64(imask);
             W16_UNROLL for (int s = 0; s < R; s++)
                 if (mine[s] && ((imask >> row[s]) & 1))
                     RI[popc64(imask & (((uint64_t) 1 << row[s]) - 1))] = popc64(G.bm & (((uint64_t) 1 << row[s]) - 1));
-            if (l < ng) RI[nbf + l] = S.nb + l;
+            if (l < ng) RI[nbf + l] = cd.nb + l;
             GQP_ROWSYNC();
             const bool hr = l < nbf + ng;
             const int rr = hr ? RI[l] : 0;
@@ -1129,6 +1153,7 @@ __global__ void __launch_bounds__(64) ky_backrhs(GqpDev D, GqpOpts O, int redo)
             }
         GQP_ROWSYNC();
         W16_UNROLL for (int s = 0; s < R; s++) pn[s] = isx[s] ? m[s] : 0.0;
+        if (GEN) cd = nd;
     }
 }
 
