@@ -718,6 +718,10 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
                     else if (soft_dims) fits = fits && ws.sfact && ws.NG == 0;                       /* slacks on box rows only */
                     else fits = fits && ws.sfact && ws.NG >= mg && !(e16g && atoi(e16g) == 0);      /* general rows */
                     if (ws.NX + ws.NU > 16 && (e16r && atoi(e16r) == 0)) fits = false;
+                    /* two rows per lane: dims run PADDED inside the compiled shape, so its ~2.3x over the wave-per-instance
+                     * kernels (which take dims at run time) is gone once the padded block has more than twice the work:
+                     * the shape must cover at least 77 % of the compiled nu + nx */
+                    if (ws.NX + ws.NU > 16 && !force_NX && 13 * (wx + wu) < 10 * (ws.NX + ws.NU)) fits = false;
                     if (fits && (!w16 || ws.NX + ws.NU < w16->NX + w16->NU)) w16 = &ws;
                 }
         }

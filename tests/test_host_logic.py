@@ -905,10 +905,10 @@ def test_sixteen_lanes_two_rows_per_lane_hostsim(hostsim_lib, monkeypatch):
     from acados_amd import OcpQpGpuBatch
     from acados_amd.generators import lqr_instance_qp, random_lqr_batch
     for (nx, nu), want in (((24, 6), "w16r-box<NX=24,NU=6>"), ((8, 15), "w16r-box<NX=8,NU=15>"), ((20, 5), "w16r-box<NX=24,NU=6>"),
-                           ((6, 12), "w16r-box<NX=8,NU=15>"), ((13, 4), "w16r-box<NX=24,NU=6>")):
+                           ((6, 12), "w16r-box<NX=8,NU=15>"), ((13, 4), "wpi-box(nx=13,nu=4")):   # (13,4): 17 of 30 -- too much padding
         data = random_lqr_batch(N=4, nx=nx, nu=nu, batch=5, seed=40 + nx)
         b = _check_batch_vs_oracle([lqr_instance_qp(data, i, 4) for i in range(5)], hostsim_lib)
-        assert b.kernel_name == want, b.kernel_name
+        assert b.kernel_name.startswith(want), b.kernel_name
     # the same batch on both families: iterates agree to rounding, iteration counts are equal
     data = random_lqr_batch(N=6, nx=24, nu=6, batch=3, seed=3)
     qps = [lqr_instance_qp(data, i, 6) for i in range(3)]
