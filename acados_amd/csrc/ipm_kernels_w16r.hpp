@@ -147,7 +147,8 @@ __device__ static inline void w16r_dma_region(const double *sbase, const double 
 #define W16R_TICK(slot) do { } while (0)
 #endif
 /* the fully unrolled stage body is one basic block of several thousand instructions; left alone, the scheduler hoists
- * hundreds of loads and LDS reads to its top and spills.  A fence between the phases keeps each phase's loads inside it */
+ * hundreds of loads and LDS reads to its top and spills.  A fence keeps the broadcasts of the W product column by column
+ * (what keeps the multiply-add chains of a phase in place is W16R_OPAQUE: the fence does not bind machine sinking) */
 #if defined(__HIP_DEVICE_COMPILE__)
 #define W16R_FENCE() __builtin_amdgcn_sched_barrier(0)
 #else
@@ -156,12 +157,14 @@ __device__ static inline void w16r_dma_region(const double *sbase, const double 
 
 /* ------------------------------------------------------------------- inequality rows with slacks (GEN variants)
  * The GEN instantiations (template parameter NG > 0: up to NG general rows per stage) also carry slacks, with the structure
- * of the sixteen-lanes SOFT kernels extended to general rows: every slack belongs to exactly ONE row, box or general (the
- * host checks it; anything else stays with the wave-per-instance kernels).  A row -- box row of the variable a slot owns,
- * or general row g handled by lane g of slot 0 -- is processed by ONE lane with the scalar formulas below; what differs is
- * only the row's value: v_j for a box row, a'v for a general row (a 16-lane sum) and how the result reaches the register
- * rows (directly / as the rank-one terms gamma a a', a gadd broadcast from lane g).  Algebra: ipm_kernels_wpi.hpp (GEN
- * kernels) specialised to one row per slack: E = Z + Gamma_s, X = slack stationarity + rho_s, cancellation-free. */
+ * of the sixteen-lanes SOFT kernels extended to general rows: every slack belongs to exactly ONE row, box or general, and a
+ * stage has at most 16 inequality rows that take part (the host checks both; anything else stays with the
+ * wave-per-instance kernels).  EVERY row -- the sorted box rows that are not equality-flagged, then the general rows -- is
+ * processed by ONE lane (lane i <-> i-th such row) with the scalar formulas below; a row's value reaches its lane through a
+ * 16-entry LDS vector (box row: v_j, written by the slot that owns variable j; general row: a'v, a 16-lane sum), its
+ * results return the same way: (gamma, gadd, dlam) of a box row to the slot of its variable, a general row as the
+ * rank-one terms gamma a a' / a gadd on the register rows.  Algebra: ipm_kernels_wpi.hpp (GEN kernels) specialised to one
+ * row per slack: E = Z + Gamma_s, X = slack stationarity + rho_s, cancellation-free. */
 struct W16RowF
 {
     double gam, gadd, dlam; /* Hessian weight, gradient term, lam_lower - lam_upper */
