@@ -689,16 +689,41 @@ __global__ void __launch_bounds__(64) kb_forward(GqpDev D, GqpOpts O, int redo)
     }
     /* no inequality rows (mu == 0 exactly): the Newton step solves the QP, take it fully */
     const double a = D.mu[i] > 0.0 ? alpha * 0.995 : 1.0;
+    /* update pass.  Straight-line per stage like the sweep above: every load of the stage (62 for C2) is issued before
+     * the first store, rows that do not exist are read through the clamped index, a side that does not take part gets
+     * its own value written back; the stage structure is fetched one stage ahead.  (With a branch per row and side the
+     * pass made one memory round trip per row -- 4 loads in flight per wave -- and ran at 3.1 TB/s.) */
+    StageU Sn = stage_u(D.st, 0);
+    uint64_t amn = GAT(D.amask, 0);
     for (int k = 0; k <= D.N; k++)
     {
-        const StageU S = stage_u(D.st, k);
+        const StageU S = Sn;
+        const uint64_t am = amn;
+        {
+            const int kn = k < D.N ? k + 1 : k;
+            Sn = stage_u(D.st, kn);
+            amn = GAT(D.amask, kn);
+        }
         const uint64_t imask = S.bmask & ~S.emask;
-        const uint64_t am = GAT(D.amask, k);
         const int nbg = S.nb;
-        { const Acc aux_ = ACC(D.ux, k * n), adux_ = ACC(D.dux, k * n);
-          UNROLL for (int j = 0; j < n; j++) aux_.st(j, aux_.ld(j) + a * adux_.ld(j)); }
-        { const Acc api_ = ACC(D.pi, (k + 1) * NX), adpi_ = ACC(D.dpi, (k + 1) * NX);
-          UNROLL for (int c = 0; c < NX; c++) api_.st(c, api_.ld(c) + a * adpi_.ld(c)); }
+        const Acc aux_ = ACC(D.ux, k * n), adux_ = ACC(D.dux, k * n);
+        const Acc api_ = ACC(D.pi, (k + 1) * NX), adpi_ = ACC(D.dpi, (k + 1) * NX);
+        double vx[n], vdx[n], vp[NX], vdp[NX];
+        UNROLL for (int j = 0; j < n; j++) { vx[j] = aux_.ld(j); vdx[j] = adux_.ld(j); }
+        UNROLL for (int c = 0; c < NX; c++) { vp[c] = api_.ld(c); vdp[c] = adpi_.ld(c); }
+        double vl[2 * NB], vdl[2 * NB], vt[2 * NB], vdt[2 * NB];
+        UNROLL for (int j = 0; j < NB; j++)
+        {
+            GQP_ROW(j, has, ib);
+            UNROLL for (int side = 0; side < 2; side++)
+            {
+                const int e = S.o_ct + side * nbg + ib;
+                vl[2 * j + side] = ACC(D.lam, 0).ld(e); vdl[2 * j + side] = ACC(D.dlam, 0).ld(e);
+                vt[2 * j + side] = ACC(D.t, 0).ld(e); vdt[2 * j + side] = ACC(D.dt, 0).ld(e);
+            }
+        }
+        UNROLL for (int j = 0; j < n; j++) aux_.st(j, vx[j] + a * vdx[j]);
+        UNROLL for (int c = 0; c < NX; c++) api_.st(c, vp[c] + a * vdp[c]);
         UNROLL for (int j = 0; j < NB; j++)
         {
             GQP_ROW(j, has, ib);
@@ -706,11 +731,11 @@ __global__ void __launch_bounds__(64) kb_forward(GqpDev D, GqpOpts O, int redo)
             UNROLL for (int side = 0; side < 2; side++)
             {
                 const int e = S.o_ct + side * nbg + ib;
-                if (!((am >> (side * nbg + ib)) & 1)) continue;
-                const double lam = ACC(D.lam, 0).ld(e) + a * ACC(D.dlam, 0).ld(e);
-                const double t = ACC(D.t, 0).ld(e) + a * ACC(D.dt, 0).ld(e);
-                ACC(D.lam, 0).st(e, lam < O.lam_min ? O.lam_min : lam);
-                ACC(D.t, 0).st(e, t < O.t_min ? O.t_min : t);
+                const bool act = (am >> (side * nbg + ib)) & 1;
+                const double lam = vl[2 * j + side] + a * vdl[2 * j + side];
+                const double t = vt[2 * j + side] + a * vdt[2 * j + side];
+                ACC(D.lam, 0).st(e, act ? (lam < O.lam_min ? O.lam_min : lam) : vl[2 * j + side]);
+                ACC(D.t, 0).st(e, act ? (t < O.t_min ? O.t_min : t) : vt[2 * j + side]);
             }
         }
     }
