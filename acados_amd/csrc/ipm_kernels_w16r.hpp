@@ -86,8 +86,11 @@ __device__ static inline void w16r_dma16(const double *sbase, const double *ldsp
  * sweep built for two waves per SIMD): a few instances in 65,536 come out wrong as soon as two of these waves share a SIMD
  * -- not an LDS overrun (padding the allocation by a few KB changes nothing), not the spill code of that build (the same
  * binary is correct when a 60 KB allocation leaves room for two workgroups per CU, one per SIMD), not cured by 512 idle
- * cycles after the vmcnt wait.  One wave per SIMD is what every test and every measurement runs; the attribute keeps a
- * future compiler from packing two. */
+ * cycles after the vmcnt wait.  The mechanism itself is sound with two and four waves per SIMD (tools/lds_dma_probe/probe2:
+ * the same double-buffered stage pipeline on 8,192 workgroups; probe3: ordinary loads and DMA requests of a wave return in
+ * issue order, so the compiler's partial vmcnt waits stay valid with uncounted DMA requests in flight) -- what fails is
+ * specific to these kernels and still open.  One wave per SIMD is what every test and every measurement runs; the
+ * attribute keeps a future compiler from packing two. */
 #define W16R_ONE_WAVE_PER_SIMD __attribute__((amdgpu_waves_per_eu(1, 1)))
 #define W16R_LDS_DRAIN() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #else
