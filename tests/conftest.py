@@ -83,3 +83,37 @@ def compare_with_oracle(get_fn, oracle, qp, tol, fields=("x", "u", "sl", "su", "
             assert err <= tol, f"{f} at stage {k}: {err} > {tol}\n got {got}\n ref {ref}"
             worst = max(worst, err)
     return worst
+
+
+def check_finished_lanes_ride_along(clib, N, B, seed, alone):
+    """One-instance-per-lane box sweeps (ipm_kernels_box.hpp, GQP_WAVE_ANY): a lane whose instance has finished keeps
+    running the sweeps on its unchanged iterate while another lane of its wave iterates.  Nothing of the finished instance
+    may move: the instances `alone` of a B-instance batch (iteration counts differ inside every wave) are solved once more
+    as batches of one on the same kernels, where nothing rides along, and solution, multipliers, iteration count and
+    the factor of the last factorisation are compared bit for bit."""
+    import numpy as np
+    from acados_amd import OcpQpGpuBatch
+    from acados_amd.generators import fill_lqr_batch, lqr_dims, random_lqr_batch
+    data = random_lqr_batch(N=N, batch=B, seed=seed)
+
+    def solve(d, n):
+        gb = OcpQpGpuBatch(lqr_dims(N, 8, 3), n, _clib=clib)
+        fill_lqr_batch(gb, d, N)
+        gb.opts_set("tol_stat", 1e-8)
+        gb.opts_set("tail_max", 0)   # no hand-over to another kernel family: this is about bit identity
+        assert gb.solve() == 0
+        assert gb.kernel_name.startswith("1tpi-box"), gb.kernel_name
+        return gb
+
+    full = solve(data, B)
+    it = full.info("iter")
+    assert len(set(it.tolist())) >= 3, it          # instances really finish at different iterations
+    for i in alone:
+        one = solve({k: v[i:i + 1] for k, v in data.items()}, 1)
+        assert int(one.info("iter")[0]) == int(it[i]), i
+        for f in ("res_stat", "res_comp", "mu"):
+            assert one.info(f)[0] == full.info(f)[i], (f, i)
+        for k in range(N + 1):
+            for f in ("x", "u", "lam", "t", "ric_L", "ric_l") + (("pi",) if k < N else ()):
+                assert np.array_equal(one.get(f, k)[0], full.get(f, k)[i]), (f, k, i)
+    return it

@@ -811,3 +811,17 @@ def test_condensing_kernel_pairs_agree_gpu(gpu_lib, monkeypatch):
     for a, b_ in zip(sols[0][0], sols[1][0]):
         if a.size:
             np.testing.assert_allclose(a, b_, rtol=1e-7, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_finished_lanes_ride_along_gpu(gpu_lib, monkeypatch):
+    """one-instance-per-lane box sweeps: lanes whose instance has finished ride along while a lane of their wave iterates
+    (full-line stores); the instances that finish first in each of the three waves -- the longest riders -- and a few
+    others end bit-identical to the same instance solved alone"""
+    from conftest import check_finished_lanes_ride_along
+    monkeypatch.setenv("ACADOS_AMD_WPI", "0")   # one instance per lane whatever the batch size
+    N, B = 20, 192
+    it = check_finished_lanes_ride_along(gpu_lib, N, B, 7, alone=list(range(0, B, 17)))
+    first = [int(np.argmin(it[w * 64:(w + 1) * 64])) + w * 64 for w in range(3)]
+    last = [int(np.argmax(it[w * 64:(w + 1) * 64])) + w * 64 for w in range(3)]
+    check_finished_lanes_ride_along(gpu_lib, N, B, 7, alone=first + last)

@@ -442,6 +442,15 @@ def test_compaction_is_bit_identical_hostsim(hostsim_lib):
             assert np.array_equal(runs[0].get(f, k), runs[1].get(f, k)), (f, k)
 
 
+def test_finished_lanes_ride_along_hostsim(hostsim_lib, monkeypatch):
+    """a finished instance that rides along with its wave (the host build lets EVERY finished lane ride along until the
+    batch is done) ends bit-identical to the same instance solved alone"""
+    from conftest import check_finished_lanes_ride_along
+    monkeypatch.setenv("ACADOS_AMD_WPI", "0")   # one instance per lane whatever the batch size
+    it = check_finished_lanes_ride_along(hostsim_lib, N=10, B=40, seed=5, alone=range(0, 40, 3))
+    assert it.max() - it.min() >= 2
+
+
 def test_json_wire_format_roundtrip(tmp_path):
     """f3: the dump_last_qp_to_json format is read AND written (zero-padded stage keys, natural-sign
     bounds); a round trip preserves every field bit for bit"""
