@@ -59,19 +59,20 @@ struct W16Set
     kern_redo_t fact, rhs, faff, fcor;
     kern_redo_t sfact, srhs, sfaff, sfcor; /* SOFT variants: soft box rows, one slack per row */
     size_t shmem;
+    kern_redo_t solve, ssolve; /* the whole solve in one launch (small batches); null: launch per sweep only */
 };
 #define GQP_W16(NX, NU)                                                                                       \
     {NX, NU, 0, gqp::kx_factor<NX, NU>, gqp::kx_backrhs<NX, NU>, gqp::kx_fwd<NX, NU, false>, gqp::kx_fwd<NX, NU, true>, \
      gqp::kx_factor<NX, NU, true>, gqp::kx_backrhs<NX, NU, true>, gqp::kx_fwd<NX, NU, false, true>,            \
-     gqp::kx_fwd<NX, NU, true, true>, 4 * gqp::W16Lds<NX, NU>::SZ * sizeof(double)}
+     gqp::kx_fwd<NX, NU, true, true>, 4 * gqp::W16Lds<NX, NU>::SZ * sizeof(double), gqp::kx_solve<NX, NU>, gqp::kx_solve<NX, NU, true>}
 /* ... and with 17 <= nu + nx <= 32 (ipm_kernels_w16r.hpp: two rows per lane; box rows without slacks) */
 #define GQP_W16R(NX, NU)                                                                                      \
     {NX, NU, 0, gqp::ky_factor<NX, NU>, gqp::ky_backrhs<NX, NU>, gqp::ky_fwd<NX, NU, false>, gqp::ky_fwd<NX, NU, true>, \
-     nullptr, nullptr, nullptr, nullptr, 4 * gqp::W16RLds<NX, NU>::SZ * sizeof(double)}
+     nullptr, nullptr, nullptr, nullptr, 4 * gqp::W16RLds<NX, NU>::SZ * sizeof(double), nullptr, nullptr}
 /* ... with general rows and slacks (one slack per row): the C4 class */
 #define GQP_W16G(NX, NU, NG)                                                                                  \
     {NX, NU, NG, nullptr, nullptr, nullptr, nullptr, gqp::ky_factor<NX, NU, NG>, gqp::ky_backrhs<NX, NU, NG>,     \
-     gqp::ky_fwd<NX, NU, false, NG>, gqp::ky_fwd<NX, NU, true, NG>, 4 * gqp::W16RLds<NX, NU, NG>::SZ * sizeof(double)}
+     gqp::ky_fwd<NX, NU, false, NG>, gqp::ky_fwd<NX, NU, true, NG>, 4 * gqp::W16RLds<NX, NU, NG>::SZ * sizeof(double), nullptr, nullptr}
 const W16Set g_w16_sets[] = {GQP_W16(4, 1), GQP_W16(8, 3), GQP_W16(12, 3), GQP_W16(4, 4), GQP_W16(12, 4),
                              GQP_W16R(8, 15), GQP_W16R(24, 6), GQP_W16G(24, 3, 4)};
 
@@ -109,6 +110,9 @@ struct ocp_qp_gpu_batch
     KernelSet wpi_ks;      /* the wave-per-instance set of the same padded dims (fallback of w16_soft) */
     int w16_slots = 0;     /* row slots a sweep launch covers: B, or the live instances once GqpDev::perm lists them */
     size_t w16_shmem = 0;  /* dynamic LDS bytes of a 16-lanes-per-instance workgroup (4 instances) */
+    kern_redo_t w16_solve = nullptr; /* whole-solve kernel of the family (batches of at most solve_max instances) */
+    int solve_max = 256;   /* largest batch that is solved in one launch (option "solve_max", 0 = off) */
+    int n_single_launch = 0;
     KernelSet own_ks;     /* runtime-shaped kernel set of a wpi batch (ks points here) */
     int xbox = 0;
     const KernelSet *ks = nullptr;
@@ -312,6 +316,7 @@ void finalize_structure(ocp_qp_gpu_batch *b)
         {
             b->own_ks = b->wpi_ks;
             b->w16 = 0;
+            b->w16_solve = nullptr;
             b->w16_soft = false;
             char nm[160];
             snprintf(nm, sizeof(nm), "wpi-gen(nx=%d,nu=%d,ng=%d,ns=%d,lds=%zuB)", b->ks->NX, b->ks->NU, b->ks->NG, b->ks->NS, b->shmem_fact);
@@ -810,6 +815,7 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
                 b->w16_soft = gen;
                 b->w16_ng = ws.NG;
                 b->w16_shmem = ws.shmem;
+                b->w16_solve = gen ? ws.ssolve : ws.solve;
             }
             const size_t con = gqp::wpi_con_doubles(wx + wu, mg, ms);
             b->shmem = (ref ? gqp::wpi_lds_doubles(wx, wu) : gqp::wpi3_lds_doubles(wx, wu) + con) * sizeof(double);
@@ -950,6 +956,7 @@ int ocp_qp_gpu_batch_opts_set(ocp_qp_gpu_batch *b, const char *f, const void *v)
     else if (!strcmp(f, "profile")) b->profile = *i;
     else if (!strcmp(f, "compact_min")) b->compact_min = *i;
     else if (!strcmp(f, "tail_max")) b->tail_max = *i;
+    else if (!strcmp(f, "solve_max")) b->solve_max = *i;
     else if (!strcmp(f, "cond_N"))
     {
         if (*i != b->cond_N)
@@ -1317,6 +1324,19 @@ static void run_ipm(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch *root, Prof &prof, hip
      * instances (row slot -> instance, GqpDev::perm) -- no data moves, the grid shrinks, every wave carries four live rows */
     const char *eperm = getenv("ACADOS_AMD_W16_PERM");
     const bool use_perm = b->w16 && !(eperm && atoi(eperm) == 0);
+    if (b == root && b->w16 && b->w16_solve && b->B <= root->solve_max && !D.perm)
+    {
+        /* small batch: every 16-lane row runs this loop by itself inside one launch (kx_solve) */
+        prof.begin(1, s);
+        GQP_SWEEP_LAUNCH(b, b->w16_solve, 0, s, D, O, 0);
+        prof.end(s);
+        root->launches++;
+        root->n_single_launch++;
+        HIPCHK(hipMemcpyAsync(b->h_nact, D.n_active, sizeof(int), hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (*b->h_nact <= 0) return;
+        /* (never taken: a row leaves the kernel only with its instance out of the RUNNING state) */
+    }
     for (;; it++)
     {
         if (b == root) prof.begin(1, s); /* per-class timing covers the root level only (full-batch launches) */
@@ -1472,6 +1492,7 @@ int ocp_qp_gpu_batch_solve(ocp_qp_gpu_batch *b)
     b->launches = 0;
     b->n_compactions = 0;
     b->n_tail_switches = 0;
+    b->n_single_launch = 0;
     /* kernel classes: 0 init, 1 back_fact, 2 fwd_aff, 3 back_rhs, 4 fwd_corr, 5 finalize */
     b->prof_cls.clear();
     Prof prof;
@@ -1876,6 +1897,7 @@ double ocp_qp_gpu_batch_get_scalar(ocp_qp_gpu_batch *b, const char *f)
     if (!strcmp(f, "time_xcond")) return b->time_xcond;
     if (!strcmp(f, "compactions")) return (double) b->n_compactions;
     if (!strcmp(f, "tail_switches")) return (double) b->n_tail_switches;
+    if (!strcmp(f, "single_launch_solves")) return (double) b->n_single_launch;
     if (!strcmp(f, "cond_N_active")) return b->pcond_state == 1 ? (double) b->cond_N : (double) b->N;
     /* which condensing / expansion kernels serve the batch: 2 sixteen lanes per block, 1 one instance per lane, 0 one wave
      * per instance (meaningful once partial condensing is active) */

@@ -136,8 +136,8 @@ __device__ static inline int w16_srev(const GqpStage &S, int ib)
  * host checks it, gpu_batch.hip): the slack block of a row is eliminated by the lane that owns the row, with the
  * cancellation-free formulas of ipm_kernels_wpi.hpp specialised to one row per slack (E = Z + Gamma_s, X = slack
  * stationarity + rho_s); nothing crosses lanes. */
-template <int NX, int NU, bool SOFT = false>
-__global__ void __launch_bounds__(64) kx_factor(GqpDev D, GqpOpts O, int redo)
+template <int NX, int NU, bool SOFT>
+__device__ static inline void kx_factor_body(const GqpDev &D, const GqpOpts &O, int redo)
 {
     GQP_DYN_SHARED(smem);
     typedef W16Lds<NX, NU> LY;
@@ -362,8 +362,8 @@ __global__ void __launch_bounds__(64) kx_factor(GqpDev D, GqpOpts O, int redo)
 
 /* ------------------------------------------------------------------------------- rhs-only backward (p-form) */
 
-template <int NX, int NU, bool SOFT = false>
-__global__ void __launch_bounds__(64) kx_backrhs(GqpDev D, GqpOpts O, int redo)
+template <int NX, int NU, bool SOFT>
+__device__ static inline void kx_backrhs_body(const GqpDev &D, const GqpOpts &O, int redo)
 {
     GQP_DYN_SHARED(smem);
     typedef W16Lds<NX, NU> LY;
@@ -478,8 +478,8 @@ __global__ void __launch_bounds__(64) kx_backrhs(GqpDev D, GqpOpts O, int redo)
 /* --------------------------------------------------------------------------------------------------- forward */
 
 /* PFORM (= CORR): lf holds [l_u; p] (written by kx_backrhs), otherwise the plain l of the factor sweep */
-template <int NX, int NU, bool CORR, bool SOFT = false>
-__global__ void __launch_bounds__(64) kx_fwd(GqpDev D, GqpOpts O, int redo)
+template <int NX, int NU, bool CORR, bool SOFT>
+__device__ static inline void kx_fwd_body(const GqpDev &D, const GqpOpts &O, int redo)
 {
     GQP_DYN_SHARED(smem);
     typedef W16Lds<NX, NU> LY;
@@ -742,6 +742,55 @@ __global__ void __launch_bounds__(64) kx_fwd(GqpDev D, GqpOpts O, int redo)
         D.alpha[inst] = alpha;
         D.iter[inst] = it + 1;
         if (st) { st[4 * D.stat_inst] = alpha; st[5 * D.stat_inst] = alpha; }
+    }
+}
+
+/* ------------------------------------------------------------------------------------------------ kernels */
+
+template <int NX, int NU, bool SOFT = false>
+__global__ void __launch_bounds__(64) kx_factor(GqpDev D, GqpOpts O, int redo) { kx_factor_body<NX, NU, SOFT>(D, O, redo); }
+template <int NX, int NU, bool SOFT = false>
+__global__ void __launch_bounds__(64) kx_backrhs(GqpDev D, GqpOpts O, int redo) { kx_backrhs_body<NX, NU, SOFT>(D, O, redo); }
+template <int NX, int NU, bool CORR, bool SOFT = false>
+__global__ void __launch_bounds__(64) kx_fwd(GqpDev D, GqpOpts O, int redo) { kx_fwd_body<NX, NU, CORR, SOFT>(D, O, redo); }
+
+/* Between two sweeps of the whole-solve kernel: what the row's lanes stored (iterate, factor, the per-instance scalars lane 0
+ * writes) is read by the other lanes of the row in the next sweep.  Same wave, same CU: completion of the stores is all it
+ * takes (workgroup scope). */
+#if defined(__HIP_DEVICE_COMPILE__)
+#define W16_SWEEP_FENCE() __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup")
+#else
+#define W16_SWEEP_FENCE() GQP_ROWSYNC()
+#endif
+
+/* The whole solve in ONE launch (small batches: a QP of an acados control loop, a handful of them).  The rows of this
+ * family are independent of each other -- no sweep needs anything from another instance -- so every 16-lane row runs the
+ * host loop of run_ipm by itself: factor sweep (which also decides whether the instance is done), affine sweep,
+ * corrector right-hand side, corrector sweep, and the conditional redo pair, until its instance leaves the RUNNING state
+ * (converged, iteration limit, minimum step, NaN: all decided in the factor sweep, as in the launch-per-sweep loop).
+ * Per-instance arithmetic is that of the separate kernels, bit for bit; what disappears is 4-6 launches, a device-to-host
+ * copy and a stream synchronisation per IPM iteration -- for one QP most of the time of a solve.  Rows of a wave that
+ * finish early idle until the wave's last row is done, which is why large batches stay on the launch-per-sweep loop
+ * (dense list of the live instances, gpu_batch.hip). */
+template <int NX, int NU, bool SOFT = false>
+__global__ void __launch_bounds__(64) kx_solve(GqpDev D, GqpOpts O, int)
+{
+    const int inst = w16_slot_inst(D, blockIdx.x * 4 + (threadIdx.x >> 4));
+    if (inst < 0) return;
+    for (;;)
+    {
+        kx_factor_body<NX, NU, SOFT>(D, O, 0);
+        W16_SWEEP_FENCE();
+        if (D.status[inst] != GQP_RUNNING) break;
+        kx_fwd_body<NX, NU, false, SOFT>(D, O, 0);
+        W16_SWEEP_FENCE();
+        for (int redo = 0; redo <= (O.cond_pred_corr ? 1 : 0); redo++)
+        {
+            kx_backrhs_body<NX, NU, SOFT>(D, O, redo);
+            W16_SWEEP_FENCE();
+            kx_fwd_body<NX, NU, true, SOFT>(D, O, redo);
+            W16_SWEEP_FENCE();
+        }
     }
 }
 

@@ -117,3 +117,39 @@ def check_finished_lanes_ride_along(clib, N, B, seed, alone):
             for f in ("x", "u", "lam", "t", "ric_L", "ric_l") + (("pi",) if k < N else ()):
                 assert np.array_equal(one.get(f, k)[0], full.get(f, k)[i]), (f, k, i)
     return it
+
+
+def check_whole_solve_in_one_launch(clib, qp_sets):
+    """Small batches of the sixteen-lanes family: the whole solve in ONE launch (kx_solve: every 16-lane row runs the IPM
+    loop by itself) against the launch-per-sweep loop of the same kernels (option solve_max = 0) -- statuses, iteration
+    counts, residuals, the per-iteration statistics and every solution array bit for bit."""
+    import numpy as np
+    from acados_amd import OcpQpGpuBatch
+    used = {}
+    for qps in qp_sets:
+        runs = []
+        for smax in (0, 256):
+            b = OcpQpGpuBatch.from_qps(qps, _clib=clib)
+            for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+                b.opts_set(f, 1e-8)
+            b.opts_set("iter_max", 60)
+            b.opts_set("solve_max", smax)
+            b.solve()
+            runs.append(b)
+        a, o = runs
+        if not o.kernel_name.startswith(("w16-box<", "w16-soft<")):
+            assert int(o.scalar("single_launch_solves")) == 0, o.kernel_name
+            continue
+        fam = o.kernel_name.split("<")[0]
+        used[fam] = used.get(fam, 0) + 1
+        assert int(a.scalar("single_launch_solves")) == 0 and int(o.scalar("single_launch_solves")) == 1
+        assert int(o.scalar("launches")) < int(a.scalar("launches")) and int(a.scalar("launches")) >= 12
+        for f in ("status", "iter", "res_stat", "res_eq", "res_ineq", "res_comp", "mu"):
+            assert np.array_equal(a.info(f), o.info(f)), (f, o.kernel_name)
+        qp = qps[0]
+        for k in range(qp.N + 1):
+            fields = ["x", "u", "lam", "t", "ric_L", "ric_l"] + (["pi"] if k < qp.N else [])
+            fields += ["sl", "su"] if int(qp.dims.ns[k]) else []
+            for f in fields:
+                assert np.array_equal(a.get(f, k), o.get(f, k)), (f, k, o.kernel_name)
+    return used

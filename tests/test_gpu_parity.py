@@ -825,3 +825,21 @@ def test_finished_lanes_ride_along_gpu(gpu_lib, monkeypatch):
     first = [int(np.argmin(it[w * 64:(w + 1) * 64])) + w * 64 for w in range(3)]
     last = [int(np.argmax(it[w * 64:(w + 1) * 64])) + w * 64 for w in range(3)]
     check_finished_lanes_ride_along(gpu_lib, N, B, 7, alone=first + last)
+
+
+@pytest.mark.gpu
+def test_whole_solve_in_one_launch_gpu(gpu_lib, monkeypatch):
+    """small batches: the whole solve in one launch (kx_solve) is the launch-per-sweep loop of the same kernels bit for
+    bit -- hard and soft box rows, a single QP, 64 different C2-shaped instances (16 waves, rows of a wave finish at
+    different iterations), 250 instances (the largest batches that take this path)"""
+    from conftest import check_whole_solve_in_one_launch
+    from acados_amd.generators import lqr_instance_qp, mass_spring_qp, random_lqr_batch
+    from random_qp import random_structure_qp
+    monkeypatch.setenv("ACADOS_AMD_WPI", "1")   # (tests/conftest.py switches the small-batch rule off)
+    sets = [[random_structure_qp(seed, allow_general=False)] * (1 + seed % 7) for seed in range(24)]
+    data = random_lqr_batch(N=30, nx=8, nu=3, batch=250, seed=11)
+    sets.append([lqr_instance_qp(data, i, 30) for i in range(64)])
+    sets.append([lqr_instance_qp(data, i, 30) for i in range(250)])
+    sets.append([mass_spring_qp(N=20)])
+    used = check_whole_solve_in_one_launch(gpu_lib, sets)
+    assert used.get("w16-box", 0) >= 4 and used.get("w16-soft", 0) >= 4, used

@@ -451,6 +451,21 @@ def test_finished_lanes_ride_along_hostsim(hostsim_lib, monkeypatch):
     assert it.max() - it.min() >= 2
 
 
+def test_whole_solve_in_one_launch_hostsim(hostsim_lib, monkeypatch):
+    """kx_solve against the launch-per-sweep loop, bit for bit: random structures without general rows (hard and soft box
+    rows, per-stage dims), ragged batches of 1, 5 and 6 instances (a single row, one full workgroup + 1 / + 2)"""
+    from conftest import check_whole_solve_in_one_launch
+    from acados_amd.generators import lqr_instance_qp, mass_spring_qp, random_lqr_batch
+    from random_qp import random_structure_qp
+    monkeypatch.setenv("ACADOS_AMD_WPI", "1")
+    sets = [[random_structure_qp(seed, allow_general=False)] * (1 + seed % 5) for seed in range(16)]
+    data = random_lqr_batch(N=7, nx=8, nu=3, batch=6, seed=2)
+    sets.append([lqr_instance_qp(data, i, 7) for i in range(6)])        # different instances: rows finish at different iterations
+    sets.append([mass_spring_qp(N=8)])                                   # the single QP of an acados control loop
+    used = check_whole_solve_in_one_launch(hostsim_lib, sets)
+    assert used.get("w16-box", 0) >= 3 and used.get("w16-soft", 0) >= 3, used
+
+
 def test_json_wire_format_roundtrip(tmp_path):
     """f3: the dump_last_qp_to_json format is read AND written (zero-padded stage keys, natural-sign
     bounds); a round trip preserves every field bit for bit"""
