@@ -815,6 +815,11 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
                 b->w16_soft = gen;
                 b->w16_ng = ws.NG;
                 b->w16_shmem = ws.shmem;
+                if (const char *ea = getenv("ACADOS_AMD_W16_LDS_ALIGN")) /* development: allocation rounded up / padded */
+                {
+                    const size_t a = (size_t) atoi(ea);
+                    if (a > 1) b->w16_shmem = (b->w16_shmem + a - 1) / a * a;
+                }
                 b->w16_solve = gen ? ws.ssolve : ws.solve;
             }
             const size_t con = gqp::wpi_con_doubles(wx + wu, mg, ms);

@@ -73,6 +73,13 @@ struct W16RLds
 template <int IMM>
 __device__ static inline void w16r_dma16(const double *sbase, const double *ldsp)
 {
+#if defined(W16R_NO_DMA) /* development builds: the same copy through registers, waits inserted by the compiler */
+    const size_t o = (size_t) threadIdx.x * 16 + IMM;
+    const double a = *(const double *) ((const char *) sbase + o), b = *(const double *) ((const char *) sbase + o + 8);
+    *(double *) ((char *) ldsp + o) = a;
+    *(double *) ((char *) ldsp + o + 8) = b;
+    return;
+#endif
     const unsigned voff = threadIdx.x * 16u;
     const unsigned lds = (unsigned) (uintptr_t) (__attribute__((address_space(3))) const double *) ldsp;
     unsigned keep;
@@ -82,16 +89,32 @@ __device__ static inline void w16r_dma16(const double *sbase, const double *ldsp
 /* (s_barrier: a no-op for a one-wave workgroup as far as synchronisation goes; the programming guide orders the reads of
  * DMA'd data behind "vmcnt, then a barrier") */
 #define W16R_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory")
-/* The kernels that use LDS-DMA are pinned to ONE wave per SIMD, whatever their register count.  Measured (the C3 shape, forward
- * sweep built for two waves per SIMD): a few instances in 65,536 come out wrong as soon as two of these waves share a SIMD
- * -- not an LDS overrun (padding the allocation by a few KB changes nothing), not the spill code of that build (the same
- * binary is correct when a 60 KB allocation leaves room for two workgroups per CU, one per SIMD), not cured by 512 idle
- * cycles after the vmcnt wait.  The mechanism itself is sound with two and four waves per SIMD (tools/lds_dma_probe/probe2:
- * the same double-buffered stage pipeline on 8,192 workgroups; probe3: ordinary loads and DMA requests of a wave return in
- * issue order, so the compiler's partial vmcnt waits stay valid with uncounted DMA requests in flight) -- what fails is
- * specific to these kernels and still open.  One wave per SIMD is what every test and every measurement runs; the
- * attribute keeps a future compiler from packing two. */
+/* The factor and the forward sweep are pinned to ONE wave per SIMD, whatever their register count.  Measured on the C3 shape
+ * <8,15> (development builds, `make variant`, tools/stress_w16r.py / variant_rate.py):
+ *   - the forward sweep built for two waves per SIMD gives a few dozen wrong instances in 65,536 (whole workgroups of four)
+ *     as soon as two of its waves share a SIMD; the factor sweep built the same way is correct;
+ *   - NOT the LDS-DMA: the same build with the DMA replaced by a copy through registers (W16R_NO_DMA) fails the same way,
+ *     and the mechanism alone is exact with 2 and 4 waves per SIMD (tools/lds_dma_probe/probe2, probe3);
+ *   - not an LDS overrun or an allocation granule (padding / rounding the allocation up to 512 ... 4,096 bytes changes
+ *     nothing), not the spill code as such (the same binary is correct when a 60 KB allocation leaves room for only two
+ *     workgroups per CU), not cured by idle cycles after the waits;
+ *   - and two waves per SIMD do not pay here anyway: at 256 registers both sweeps spill, C3 65.6 -> 77.4 ms with the factor
+ *     sweep alone built that way (74.6 / 85.9 ms with the forward sweep / both).
+ * One wave per SIMD is what every test and every measurement runs; the attribute keeps a future compiler from packing
+ * two.  The fault in the forward sweep is unexplained. */
 #define W16R_ONE_WAVE_PER_SIMD __attribute__((amdgpu_waves_per_eu(1, 1)))
+/* development builds (make variant): two waves per SIMD for the factor and the forward sweeps (W16R_WPE2) or one of them (the rhs-only sweep has no LDS-DMA and no attribute) -- the open problem above */
+#define W16R_TWO_WAVES_PER_SIMD __attribute__((amdgpu_waves_per_eu(2, 2)))
+#if defined(W16R_WPE2) || defined(W16R_WPE2_FACT)
+#define W16R_WPE_FACT W16R_TWO_WAVES_PER_SIMD
+#else
+#define W16R_WPE_FACT W16R_ONE_WAVE_PER_SIMD
+#endif
+#if defined(W16R_WPE2) || defined(W16R_WPE2_FWD)
+#define W16R_WPE_FWD W16R_TWO_WAVES_PER_SIMD
+#else
+#define W16R_WPE_FWD W16R_ONE_WAVE_PER_SIMD
+#endif
 #define W16R_LDS_DRAIN() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #else
 template <int IMM>
@@ -101,7 +124,8 @@ __device__ static inline void w16r_dma16(const double *sbase, const double *ldsp
     memcpy((char *) ldsp + o, (const char *) sbase + o, 16);
 }
 #define W16R_DMA_WAIT() GQP_ROWSYNC()
-#define W16R_ONE_WAVE_PER_SIMD
+#define W16R_WPE_FACT
+#define W16R_WPE_FWD
 #define W16R_LDS_DRAIN() GQP_ROWSYNC()
 #endif
 /* G granules of 16 bytes, contiguous on both sides: full passes of 64 lanes, then the lanes the last pass needs */
@@ -437,7 +461,7 @@ __device__ static inline void w16r_row_update(const GqpDev &D, const GqpOpts &O,
 /* ------------------------------------------------------------------------------------------------ factor */
 
 template <int NX, int NU, int NG = 0>
-__global__ void __launch_bounds__(64) W16R_ONE_WAVE_PER_SIMD ky_factor(GqpDev D, GqpOpts O, int redo)
+__global__ void __launch_bounds__(64) W16R_WPE_FACT ky_factor(GqpDev D, GqpOpts O, int redo)
 {
     GQP_DYN_SHARED(smem);
     typedef W16RLds<NX, NU, NG> LY;
@@ -1171,7 +1195,7 @@ __global__ void __launch_bounds__(64) ky_backrhs(GqpDev D, GqpOpts O, int redo)
  * register copy, no transposition tile.  Vectors and box rows are loaded one stage ahead into registers.  As in the factor
  * sweep no row leaves while another row of the wave is alive (the DMA needs all 64 lanes); a dead row writes nothing. */
 template <int NX, int NU, bool CORR, int NG = 0>
-__global__ void __launch_bounds__(64) W16R_ONE_WAVE_PER_SIMD ky_fwd(GqpDev D, GqpOpts O, int redo)
+__global__ void __launch_bounds__(64) W16R_WPE_FWD ky_fwd(GqpDev D, GqpOpts O, int redo)
 {
     GQP_DYN_SHARED(smem);
     typedef W16RLds<NX, NU, NG> LY;

@@ -71,12 +71,13 @@ def git_head():
             return None
 
 
-def kernel_symbol(gb, cls):
-    """profile class -> kernel function of the family serving this batch (what rocprofv3 lists)"""
-    name = gb.kernel_name
-    fam = "kb" if name.startswith("1tpi-box") else "kx" if name.startswith("w16") else "kw" if name.startswith("wpi") else "k"
+def kernel_symbol(name, cls):
+    """profile class -> kernel function of the family `name` (a batch's kernel_name) runs on (what rocprofv3 lists)"""
+    fam = ("kb" if name.startswith("1tpi-box") else "ky" if name.startswith("w16r") else "kx" if name.startswith("w16")
+           else "kw" if name.startswith("wpi") else "k")
     table = {"kb": {"back_fact": "kb_factor", "fwd_aff": "kb_forward", "back_rhs": "kb_backrhs", "fwd_corr": "kb_forward"},
              "kx": {"back_fact": "kx_factor", "fwd_aff": "kx_fwd", "back_rhs": "kx_backrhs", "fwd_corr": "kx_fwd"},
+             "ky": {"back_fact": "ky_factor", "fwd_aff": "ky_fwd", "back_rhs": "ky_backrhs", "fwd_corr": "ky_fwd"},
              "kw": {"back_fact": "kw_factor", "fwd_aff": "kw_fwd", "back_rhs": "kw_backrhs", "fwd_corr": "kw_fwd"},
              "k": {"back_fact": "k_backward", "fwd_aff": "k_forward", "back_rhs": "k_backward", "fwd_corr": "k_forward"}}
     return table[fam].get(cls, cls)
@@ -99,7 +100,7 @@ def sweep_roofline(gb, steps, bytes_per_instance):
     avg_s = dom_ms * 1e-3 / max(dom_cnt, 1)
     per_launch = float(np.mean(units)) * bytes_per_instance
     achieved = per_launch / avg_s / 1e9 if avg_s > 0 else 0.0
-    return dom, prof, {"bound": "hbm", "kernel": f"{kernel_symbol(gb, dom)} ({dom}) of {gb.kernel_name}",
+    return dom, prof, {"bound": "hbm", "kernel": f"{kernel_symbol(gb.kernel_name, dom)} ({dom}) of {gb.kernel_name}", "sweep": dom,
                        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                        "bytes_per_launch": per_launch, "units_per_launch": units, "avg_launch_ms": avg_s * 1e3,
                        "launches_timed": dom_cnt, "kernel_ms_share": {c: prof[c][0] for c in CLASSES}}
@@ -278,7 +279,8 @@ def other_configs(c2_batch, c2_data, args):
         pk = {2: "kz_pcond", 1: "k_pcond", 0: "kw_pcond"}.get(int(c2_batch.scalar("pcond_kernel")), "pcond")
         ek = {1: "k_pexpand", 0: "kw_pexpand"}.get(int(c2_batch.scalar("pexpand_kernel")), "pexpand")
         out["C3"]["kernel"] = f"{pk} + {ck} + {ek}"
-        out["C3"]["roofline"]["kernel"] = out["C3"]["roofline"]["kernel"].replace(c2_batch.kernel_name, ck).replace("kb_", "kw_")
+        dom3 = out["C3"]["roofline"]["sweep"]
+        out["C3"]["roofline"]["kernel"] = f"{kernel_symbol(ck, dom3)} ({dom3}) of {ck}"
     c2_batch.opts_set("cond_N", N)
     # C4
     N4, B4 = 40, args.c4_batch

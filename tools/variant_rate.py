@@ -1,0 +1,25 @@
+"""Development aid: C3 (65,536 instances, partial condensing to N2 = 10) solve time on the product library and on
+development builds of it (make variant TAG=...):  python tools/variant_rate.py [libacados_amd_qp_<tag>.so ...]"""
+import ctypes, os, sys, time
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from acados_amd import OcpQpGpuBatch, _lib
+from acados_amd.generators import fill_lqr_batch, lqr_dims, random_lqr_batch
+
+N, B = 50, 65536
+data = random_lqr_batch(N=N, nx=8, nu=3, batch=B, seed=3)
+for name in [None] + sys.argv[1:]:
+    clib = None if name is None else _lib.bind(ctypes.CDLL(os.path.join(ROOT, "acados_amd", "csrc", name)))
+    g = OcpQpGpuBatch(lqr_dims(N, 8, 3), B, _clib=clib)
+    fill_lqr_batch(g, data, N)
+    for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+        g.opts_set(f, 1e-8)
+    g.opts_set("cond_N", 10)
+    g.opts_set("profile", 1)
+    bad = g.solve()
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter(); bad = g.solve(); ts.append(time.perf_counter() - t0)
+    kkt = float(np.max(g.res_compute()))
+    print(f"{name or 'product library':34s} C3 solve {min(ts) * 1e3:7.2f} ms  failures {bad}  kkt {kkt:.3e}  kernel {g.condensed_kernel_name()}", flush=True)
