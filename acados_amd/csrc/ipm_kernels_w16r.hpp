@@ -424,37 +424,51 @@ __device__ static inline void w16r_row_fwd(const GqpDev &D, const GqpOpts &O, in
     }
 }
 
-/* update pass of the corrector sweep for one row (and its slack) */
-__device__ static inline void w16r_row_update(const GqpDev &D, const GqpOpts &O, int inst, const W16Dsc S, uint64_t am, bool has, int row, int sj, double a)
+/* update pass of the corrector sweep for one row (and its slack), in two halves: every load of the row -- its two sides,
+ * the two slack values, the two slack sides: 20 -- through clamped addresses, and, once the loads of every row the lane
+ * handles in this stage are in flight, the stores; a side that does not take part keeps its value (its stores stay behind
+ * the predicate).  (With a branch per side the pass made five memory round trips per row and stage, one row after the
+ * other: more than half of the C4 corrector sweep.) */
+struct W16RowU
 {
-    if (!has) return;
-    const int nbg = S.nb + S.ng;
-    const int el = S.o_ct + row, eu = el + nbg;
-    if ((am >> row) & 1)
+    int e[4], q0, q1;
+    bool act[4], hs;
+    double lm[4], dl[4], tt[4], dt[4], v0, d0, v1, d1;
+};
+__device__ static inline W16RowU w16r_row_update_load(const GqpDev &D, int inst, const W16Dsc S, uint64_t am, bool has, int row, int sj)
+{
+    W16RowU u;
+    const int nbg = S.nb + S.ng, ns = S.ns, o_s = S.o_s;
+    const int r = has ? row : 0, sq = (has && sj >= 0) ? sj : 0;
+    u.hs = has && sj >= 0;
+    u.e[0] = S.o_ct + r; u.e[1] = u.e[0] + nbg; u.e[2] = S.o_ct + 2 * nbg + sq; u.e[3] = u.e[2] + ns;
+    u.act[0] = has && ((am >> r) & 1); u.act[1] = has && ((am >> (nbg + r)) & 1);
+    u.act[2] = u.hs && ((am >> (2 * nbg + sq)) & 1); u.act[3] = u.hs && ((am >> (2 * nbg + ns + sq)) & 1);
+    W16_UNROLL for (int w = 0; w < 4; w++)
     {
-        const double lm = WAT(D.lam, el) + a * WAT(D.dlam, el), tt = WAT(D.t, el) + a * WAT(D.dt, el);
-        WAT(D.lam, el) = lm < O.lam_min ? O.lam_min : lm; WAT(D.t, el) = tt < O.t_min ? O.t_min : tt;
+        const int ec = W16R_CLAMP(D.lam, u.e[w]);
+        u.lm[w] = WAT(D.lam, ec); u.dl[w] = WAT(D.dlam, ec); u.tt[w] = WAT(D.t, ec); u.dt[w] = WAT(D.dt, ec);
     }
-    if ((am >> (nbg + row)) & 1)
+    u.q0 = o_s + sq; u.q1 = o_s + ns + sq;
+    const int s0 = W16R_CLAMP(D.sv, u.q0), s1 = W16R_CLAMP(D.sv, u.q1);
+    u.v0 = WAT(D.sv, s0); u.d0 = WAT(D.dsv, s0); u.v1 = WAT(D.sv, s1); u.d1 = WAT(D.dsv, s1);
+    return u;
+}
+__device__ static inline void w16r_row_update_store(const GqpDev &D, const GqpOpts &O, int inst, const W16RowU &u, double a)
+{
+    W16_UNROLL for (int w = 0; w < 4; w++)
     {
-        const double lm = WAT(D.lam, eu) + a * WAT(D.dlam, eu), tt = WAT(D.t, eu) + a * WAT(D.dt, eu);
-        WAT(D.lam, eu) = lm < O.lam_min ? O.lam_min : lm; WAT(D.t, eu) = tt < O.t_min ? O.t_min : tt;
-    }
-    if (sj >= 0)
-    {
-        const int ns = S.ns, o_s = S.o_s;
-        WAT(D.sv, o_s + sj) += a * WAT(D.dsv, o_s + sj);
-        WAT(D.sv, o_s + ns + sj) += a * WAT(D.dsv, o_s + ns + sj);
-        for (int w = 0; w < 2; w++)
+        const double l2 = u.lm[w] + a * u.dl[w], t2 = u.tt[w] + a * u.dt[w];
+        if (u.act[w])
         {
-            const int side = 2 * nbg + w * ns + sj, e = S.o_ct + side;
-            if ((am >> side) & 1)
-            {
-                const double lm = WAT(D.lam, e) + a * WAT(D.dlam, e), tt = WAT(D.t, e) + a * WAT(D.dt, e);
-                WAT(D.lam, e) = lm < O.lam_min ? O.lam_min : lm;
-                WAT(D.t, e) = tt < O.t_min ? O.t_min : tt;
-            }
+            WAT(D.lam, u.e[w]) = l2 < O.lam_min ? O.lam_min : l2;
+            WAT(D.t, u.e[w]) = t2 < O.t_min ? O.t_min : t2;
         }
+    }
+    if (u.hs)
+    {
+        WAT(D.sv, u.q0) = u.v0 + a * u.d0;
+        WAT(D.sv, u.q1) = u.v1 + a * u.d1;
     }
 }
 
@@ -1551,24 +1565,7 @@ __global__ void __launch_bounds__(64) W16R_WPE_FWD ky_fwd(GqpDev D, GqpOpts O, i
             const double p0 = WAT(D.pi, k * NX + xc_), dp = WAT(D.dpi, k * NX + xc_);
             if (isx[s]) WAT(D.pi, k * NX + cx[s]) = p0 + a * dp;
         }
-        if (GEN)
-        {
-            for (int k = 0; k <= D.N; k++)
-            {
-                const GqpStage &S = D.st[k];
-                const W16Dsc dsc = {S.nb, S.ng, S.ns, S.o_ct, S.o_s};
-                const uint64_t am = WAT(D.amask, k * D.AW);
-                {
-                    /* box row of the slot (equality-flagged rows take no part), general row l in slot 0 */
-                    const bool hb = mine[s] && (((S.bmask & ~S.emask) >> row[s]) & 1);
-                    const int ib = hb ? popc64(S.bmask & (((uint64_t) 1 << row[s]) - 1)) : 0;
-                    w16r_row_update(D, O, inst, dsc, am, hb, ib, (int) S.srev[ib], a);
-                    const bool hg = s == 0 && l < S.ng;
-                    w16r_row_update(D, O, inst, dsc, am, hg, S.nb + (hg ? l : 0), (int) S.srev[S.nb + (hg ? l : 0)], a);
-                }
-            }
-            continue;
-        }
+        if (GEN) continue; /* rows and slacks of the GEN variants: below, all slots of a stage together */
         /* distinct arrays: tell the compiler, so that the loads of several stages can be in flight */
         const GqpStage *__restrict__ st_ = D.st;
         const uint64_t *__restrict__ am_ = D.amask.p + (size_t) inst * D.amask.E;
@@ -1590,6 +1587,29 @@ __global__ void __launch_bounds__(64) W16R_WPE_FWD ky_fwd(GqpDev D, GqpOpts O, i
             const double tl = t_[el] + a * dt_[el], tu = t_[eu] + a * dt_[eu];
             if (al) { lam_[el] = laml < O.lam_min ? O.lam_min : laml; t_[el] = tl < O.t_min ? O.t_min : tl; }
             if (au) { lam_[eu] = lamu < O.lam_min ? O.lam_min : lamu; t_[eu] = tu < O.t_min ? O.t_min : tu; }
+        }
+    }
+    if (GEN)
+    {
+        /* box row of every slot (equality-flagged rows take no part) and general row l (slot 0): the loads of all of them,
+         * then the stores -- the row -> slack map and the values: two memory round trips per stage.  (Issuing the loads of
+         * stage k + 1 in front of the stores of stage k as well: measured, no gain.) */
+        for (int k = 0; k <= D.N; k++)
+        {
+            const GqpStage &S = D.st[k];
+            const W16Dsc dsc = {S.nb, S.ng, S.ns, S.o_ct, S.o_s};
+            const uint64_t am = WAT(D.amask, k * D.AW);
+            W16RowU ub[R];
+            W16_UNROLL for (int s = 0; s < R; s++)
+            {
+                const bool hb = mine[s] && (((S.bmask & ~S.emask) >> row[s]) & 1);
+                const int ib = hb ? popc64(S.bmask & (((uint64_t) 1 << row[s]) - 1)) : 0;
+                ub[s] = w16r_row_update_load(D, inst, dsc, am, hb, ib, (int) S.srev[ib]);
+            }
+            const bool hg = l < S.ng;
+            const W16RowU ug = w16r_row_update_load(D, inst, dsc, am, hg, S.nb + (hg ? l : 0), (int) S.srev[S.nb + (hg ? l : 0)]);
+            W16_UNROLL for (int s = 0; s < R; s++) w16r_row_update_store(D, O, inst, ub[s], a);
+            w16r_row_update_store(D, O, inst, ug, a);
         }
     }
     if (l == 0)
