@@ -679,60 +679,69 @@ __device__ static inline void kx_fwd_body(const GqpDev &D, const GqpOpts &O, int
     }
     const double a = D.mu[inst] > 0.0 ? alpha * 0.995 : 1.0;
     /* update: one lane per variable / state / box row of the stage (dux, dpi, dlam, dt were written by these very
-     * lanes); separate loops with independent iterations, several stages in flight */
-    const int lc_ = mine ? l : 0, xc_ = isx ? cx : 0;
-    _Pragma("unroll 4")
-    for (int k = 0; k <= D.N; k++)
+     * lanes).  Everything the lane updates in CH consecutive stages -- variable, state multiplier, the two sides of its box
+     * row, with SOFT the row's slack values and slack sides -- is loaded through clamped addresses before the first store
+     * of the chunk: one memory round trip per chunk (three loops with four stages in flight each made 3 CH / 4 of them;
+     * ipm_kernels_w16r.hpp has the measurement). */
     {
-        const double u0 = WAT(D.ux, k * n + lc_), du = WAT(D.dux, k * n + lc_);
-        if (mine) WAT(D.ux, k * n + l) = u0 + a * du;
-    }
-    _Pragma("unroll 4")
-    for (int k = 1; k <= D.N; k++)
-    {
-        const double p0 = WAT(D.pi, k * NX + xc_), dp = WAT(D.dpi, k * NX + xc_);
-        if (isx) WAT(D.pi, k * NX + cx) = p0 + a * dp;
-    }
-    {
-        /* distinct arrays: tell the compiler, so that the loads of several stages can be in flight */
+        constexpr int CH = SOFT ? 4 : 6;
+        const int lc_ = mine ? l : 0, xc_ = isx ? cx : 0;
         const GqpStage *__restrict__ st_ = D.st;
         const uint64_t *__restrict__ am_ = D.amask.p + (size_t) inst * D.amask.E;
-        double *__restrict__ lam_ = D.lam.p + (size_t) inst * D.lam.E;
-        double *__restrict__ t_ = D.t.p + (size_t) inst * D.t.E;
-        const double *__restrict__ dlam_ = D.dlam.p + (size_t) inst * D.dlam.E;
-        const double *__restrict__ dt_ = D.dt.p + (size_t) inst * D.dt.E;
-        _Pragma("unroll 4")
-        for (int k = 0; k <= D.N; k++)
+        for (int k0 = 0; k0 <= D.N; k0 += CH)
         {
-            const uint64_t bm = st_[k].bmask, imask = bm & ~st_[k].emask;
-            const uint64_t am = am_[k * D.AW];
-            const int nbg = st_[k].nb;
-            const bool has = mine && ((imask >> l) & 1);
-            const int ib = has ? popc64(bm & (((uint64_t) 1 << l) - 1)) : 0;
-            const int el = st_[k].o_ct + ib, eu = el + nbg;
-            const bool al = has && ((am >> ib) & 1), au = has && ((am >> (nbg + ib)) & 1);
-            const double laml = lam_[el] + a * dlam_[el], lamu = lam_[eu] + a * dlam_[eu];
-            const double tl = t_[el] + a * dt_[el], tu = t_[eu] + a * dt_[eu];
-            if (al) { lam_[el] = laml < O.lam_min ? O.lam_min : laml; t_[el] = tl < O.t_min ? O.t_min : tl; }
-            if (au) { lam_[eu] = lamu < O.lam_min ? O.lam_min : lamu; t_[eu] = tu < O.t_min ? O.t_min : tu; }
-            if (SOFT && has)
+            double u0[CH], du[CH], p0[CH], dp[CH], lm[CH][4], dl[CH][4], tt[CH][4], dt[CH][4], sv0[CH], sd0[CH], sv1[CH], sd1[CH];
+            int e[CH][4], q0[CH], q1[CH];
+            bool act[CH][4], hs[CH];
+            W16_UNROLL for (int c = 0; c < CH; c++)
             {
-                const int sj = w16_srev(st_[k], ib);
-                if (sj >= 0)
+                const int k = k0 + c <= D.N ? k0 + c : D.N; /* beyond the horizon: the last stage once more, nothing stored */
+                const uint64_t bm = st_[k].bmask, imask = bm & ~st_[k].emask;
+                const uint64_t am = am_[k * D.AW];
+                const int nbg = st_[k].nb, o_ct = st_[k].o_ct;
+                u0[c] = WAT(D.ux, k * n + lc_); du[c] = WAT(D.dux, k * n + lc_);
+                p0[c] = WAT(D.pi, k * NX + xc_); dp[c] = WAT(D.dpi, k * NX + xc_);
+                const bool has = mine && ((imask >> l) & 1);
+                const int ib = has ? popc64(bm & (((uint64_t) 1 << l) - 1)) : 0;
+                e[c][0] = o_ct + ib; e[c][1] = e[c][0] + nbg;
+                act[c][0] = has && ((am >> ib) & 1); act[c][1] = has && ((am >> (nbg + ib)) & 1);
+                hs[c] = false;
+                if (SOFT)
                 {
-                    const int ns = st_[k].ns, o_s = st_[k].o_s;
-                    WAT(D.sv, o_s + sj) += a * WAT(D.dsv, o_s + sj);
-                    WAT(D.sv, o_s + ns + sj) += a * WAT(D.dsv, o_s + ns + sj);
-                    for (int w = 0; w < 2; w++)
+                    const int sj = has ? w16_srev(st_[k], ib) : -1;
+                    const int ns = st_[k].ns, o_s = st_[k].o_s, sq = sj >= 0 ? sj : 0;
+                    hs[c] = sj >= 0;
+                    e[c][2] = o_ct + 2 * nbg + sq; e[c][3] = e[c][2] + ns;
+                    act[c][2] = hs[c] && ((am >> (2 * nbg + sq)) & 1); act[c][3] = hs[c] && ((am >> (2 * nbg + ns + sq)) & 1);
+                    q0[c] = o_s + sq; q1[c] = o_s + ns + sq;
+                    const int s0 = q0[c] < D.sv.E ? q0[c] : 0, s1 = q1[c] < D.sv.E ? q1[c] : 0;
+                    sv0[c] = WAT(D.sv, s0); sd0[c] = WAT(D.dsv, s0); sv1[c] = WAT(D.sv, s1); sd1[c] = WAT(D.dsv, s1);
+                }
+                W16_UNROLL for (int w = 0; w < (SOFT ? 4 : 2); w++)
+                {
+                    const int ec = e[c][w] < D.lam.E ? e[c][w] : 0;
+                    lm[c][w] = WAT(D.lam, ec); dl[c][w] = WAT(D.dlam, ec); tt[c][w] = WAT(D.t, ec); dt[c][w] = WAT(D.dt, ec);
+                }
+            }
+            W16_UNROLL for (int c = 0; c < CH; c++)
+            {
+                const int k = k0 + c;
+                if (k > D.N) break;
+                if (mine) WAT(D.ux, k * n + l) = u0[c] + a * du[c];
+                if (isx && k >= 1) WAT(D.pi, k * NX + cx) = p0[c] + a * dp[c];
+                W16_UNROLL for (int w = 0; w < (SOFT ? 4 : 2); w++)
+                {
+                    const double l2 = lm[c][w] + a * dl[c][w], t2 = tt[c][w] + a * dt[c][w];
+                    if (act[c][w])
                     {
-                        const int side = 2 * nbg + w * ns + sj, e = st_[k].o_ct + side;
-                        if ((am >> side) & 1)
-                        {
-                            const double lm = lam_[e] + a * dlam_[e], tt = t_[e] + a * dt_[e];
-                            lam_[e] = lm < O.lam_min ? O.lam_min : lm;
-                            t_[e] = tt < O.t_min ? O.t_min : tt;
-                        }
+                        WAT(D.lam, e[c][w]) = l2 < O.lam_min ? O.lam_min : l2;
+                        WAT(D.t, e[c][w]) = t2 < O.t_min ? O.t_min : t2;
                     }
+                }
+                if (SOFT && hs[c])
+                {
+                    WAT(D.sv, q0[c]) = sv0[c] + a * sd0[c];
+                    WAT(D.sv, q1[c]) = sv1[c] + a * sd1[c];
                 }
             }
         }

@@ -150,7 +150,7 @@ __device__ static inline void w16r_dma_region(const double *sbase, const double 
     }
 }
 
-#define W16R_UPD_CH 4 /* stages per chunk of the update pass of the corrector sweep */
+#define W16R_UPD_CH 6 /* stages per chunk of the update pass of the corrector sweep */
 
 /* value of variable j: lane j & 15 of the row, slot j >> 4 (j is a compile-time constant after unrolling) */
 #define W16R_BC(arr, j) w16_bcast((arr)[(j) >> 4], (j) & 15, xb)
