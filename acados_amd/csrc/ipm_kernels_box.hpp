@@ -187,7 +187,11 @@ __device__ static inline Acc acc_at(GArr arr, size_t e0, int i)
  * results bit for bit, the work arrays of the other sweeps are scratch -- and skip every per-instance scalar.  A wave with
  * holes writes partial 128-byte lines, and those cost far more than the bytes they carry (measured on C2: the factor
  * sweep with 82 % of the lanes live took 2.60 ms against 1.73 ms with every lane live; the sweeps that store little were
- * 2-3 % slower).  The host build runs one lane at a time and treats every wave as live: the ghost path is what it tests. */
+ * 2-3 % slower).  What keeps the factor of a finished instance intact: statuses change in the factor sweep only and every
+ * lane of a wave takes the ride-along decision on the same statuses at the start of a launch, so a wave that ran the
+ * rhs-only sweep (which overwrites lf) also runs the next factor sweep (which restores it), and the loop always ends behind a
+ * factor sweep.  The host build runs one lane at a time -- a per-tile decision there would see statuses change between the
+ * lanes of one launch and break exactly that -- and treats every wave as live: the ghost path is what it tests. */
 #if defined(__HIP_DEVICE_COMPILE__)
 #define GQP_WAVE_ANY(x) (__builtin_amdgcn_ballot_w64(x) != 0)
 #else
