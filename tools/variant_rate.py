@@ -25,4 +25,4 @@ for name in [None] + sys.argv[1:]:
     ms = {c: g.scalar("prof_ms_" + c) / max(g.scalar("prof_cnt_" + c), 1) for c in ("back_fact", "fwd_aff", "back_rhs", "fwd_corr")}
     print(f"{name or 'product library':34s} C3 solve {min(ts) * 1e3:7.2f} ms  failures {bad}  kkt {kkt:.3e}  kernel {g.condensed_kernel_name()}"
           f"  per launch: fact {ms['back_fact']:.3f} faff {ms['fwd_aff']:.3f} rhs {ms['back_rhs']:.3f} fcor {ms['fwd_corr']:.3f} ms"
-          f" ({int(g.scalar('prof_cnt_fwd_corr'))} launches)", flush=True)
+          f" ({int(g.scalar('prof_cnt_fwd_corr'))} launches)  condense + expand {g.scalar('time_xcond') * 1e3:.2f} ms", flush=True)
