@@ -55,6 +55,13 @@ def bind(L):
     L.ocp_qp_gpu_batch_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.ocp_qp_gpu_batch_bulk_len.argtypes = [C.c_void_p, C.c_int]
     L.ocp_qp_gpu_batch_bulk_offset.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int)]
+    L.ocp_qp_gpu_batch_sens_bulk_len.argtypes = [C.c_void_p, C.c_int]
+    L.ocp_qp_gpu_batch_sens_bulk_offset.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int)]
+    L.ocp_qp_gpu_batch_sens_set_bulk.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.ocp_qp_gpu_batch_sens_get_bulk.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.ocp_qp_gpu_host_alloc.argtypes = [C.c_size_t]
+    L.ocp_qp_gpu_host_alloc.restype = C.c_void_p
+    L.ocp_qp_gpu_host_free.argtypes = [C.c_void_p]
     L.ocp_qp_gpu_batch_res_compute.argtypes = [C.c_void_p]
     L.ocp_qp_gpu_batch_res_nrm_inf.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
     return L

@@ -188,8 +188,9 @@ struct ocp_qp_gpu_batch
         std::vector<std::string> fields; /* per segment */
         std::vector<int> seg_stage, seg_off, seg_len;
         int *d_arr = nullptr, *d_elem = nullptr, *d_moff = nullptr, *d_mstage = nullptr, *d_mbit = nullptr;
+        int *d_sgn = nullptr, *d_elem2 = nullptr; /* seed blob only: sign of the entry in the residual arrays, slot in sfix */
         gqp::GArrTable T;
-    } bulk_in, bulk_out;
+    } bulk_in, bulk_out, bulk_seed;
 };
 
 namespace
@@ -1608,11 +1609,18 @@ int ocp_qp_gpu_batch_sens_set(ocp_qp_gpu_batch *b, const char *f, int k, const d
         if (arr.p == b->D.rq.p) dst = b->D.rg;
         else if (arr.p == b->D.bvec.p) dst = b->D.rb;
         else if (arr.p == b->D.dvec.p) { dst = b->D.rd; sign = (base[0] == 'l' && base[1] != 'u') || !strcmp(base, "lls") ? -1.0 : 1.0; }
+        else if (!strcmp(base, "zl") || !strcmp(base, "zu"))
+        {
+            /* gradient of the slack penalty: the slack part of the stationarity residual, indexed like sl / su */
+            dst = b->D.rgs;
+            const GqpStage &S = b->st[k];
+            for (int j = 0; j < len; j++) map[j] = S.o_s + (base[1] == 'u' ? S.ns : 0) + j;
+        }
     }
     if (len < 0 || !dst.p)
     {
-        fprintf(stderr, "acados_amd: ocp_qp_gpu_batch_sens_set: %s is not a seed of this stage (seeds: seed_q seed_r seed_b "
-                        "seed_lbu seed_ubu seed_lbx seed_ubx seed_lg seed_ug)\n", f);
+        fprintf(stderr, "acados_amd: ocp_qp_gpu_batch_sens_set: %s is not a seed of this stage (seeds: seed_q seed_r seed_zl seed_zu seed_b "
+                        "seed_lbu seed_ubu seed_lbx seed_ubx seed_lg seed_ug seed_lls seed_lus)\n", f);
         return -1;
     }
     if (len == 0) return 0;
@@ -2178,6 +2186,135 @@ int ocp_qp_gpu_batch_get_bulk(ocp_qp_gpu_batch *b, double *blob, int is_device)
     if (!is_device) HIPCHK(hipMemcpyAsync(blob, dst, sizeof(double) * cnt, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     return 0;
+}
+
+/* ---- bulk seeds / sensitivities: every seed of every instance in one host->device copy and one launch, every
+ * direction back in one launch and one copy (the batched eval_forw_sens / eval_adj_sens of the acados-side adapter;
+ * callers interfaces/acados_template/acados_template/c_templates_tera/acados_solver.in.c:3292-3337) ---- */
+static const char *const k_seed_fields[] = {"r", "q", "zl", "zu", "b", "lbu", "lbx", "lg", "ubu", "ubx", "ug", "lls", "lus"};
+
+static void seed_build(ocp_qp_gpu_batch *b)
+{
+    auto &M = b->bulk_seed;
+    if (M.built) return;
+    finalize_structure(b);
+    const GqpDev &D = b->D;
+    std::vector<int> h_arr, h_elem, h_sgn, h_elem2;
+    for (int k = 0; k <= b->N; k++)
+        for (const char *f : k_seed_fields)
+        {
+            std::vector<int> map, map2;
+            GArr arr = {nullptr, 0, 0}, arr2 = {nullptr, 0, 0};
+            const int len = field_map(b, f, k, map, &arr, &map2, &arr2);
+            if (len <= 0) continue;
+            const GqpStage &S = b->st[k];
+            const bool slack_grad = f[0] == 'z';
+            int a = -1, sgn = 1;
+            if (slack_grad) a = 1;
+            else if (arr.p == D.rq.p) a = 0;
+            else if (arr.p == D.bvec.p) a = 2;
+            else if (arr.p == D.dvec.p) { a = 3; sgn = (f[0] == 'l') ? -1 : 1; } /* lbu lbx lg lls lus: lower bounds */
+            M.fields.push_back(std::string("seed_") + f); M.seg_stage.push_back(k);
+            M.seg_off.push_back((int) h_arr.size()); M.seg_len.push_back(len);
+            for (int e = 0; e < len; e++)
+            {
+                int el = map[e];
+                if (slack_grad) el = S.o_s + (f[1] == 'u' ? S.ns : 0) + e; /* rgs is indexed like sv */
+                h_arr.push_back(el >= 0 ? a : -1); h_elem.push_back(el >= 0 ? el : 0); h_sgn.push_back(sgn);
+                h_elem2.push_back(arr2.p && map2[e] >= 0 ? map2[e] : -1);
+            }
+        }
+    M.len = (int) h_arr.size();
+    M.d_arr = dalloc<int>(b, M.len); M.d_elem = dalloc<int>(b, M.len); M.d_sgn = dalloc<int>(b, M.len); M.d_elem2 = dalloc<int>(b, M.len);
+    if (M.len)
+    {
+        HIPCHK(hipMemcpy(M.d_arr, h_arr.data(), sizeof(int) * M.len, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(M.d_elem, h_elem.data(), sizeof(int) * M.len, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(M.d_sgn, h_sgn.data(), sizeof(int) * M.len, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(M.d_elem2, h_elem2.data(), sizeof(int) * M.len, hipMemcpyHostToDevice));
+    }
+    M.built = true;
+}
+
+int ocp_qp_gpu_batch_sens_bulk_len(ocp_qp_gpu_batch *b, int output)
+{
+    if (output) return ocp_qp_gpu_batch_bulk_len(b, 1);
+    HIPCHK(hipSetDevice(b->device));
+    seed_build(b);
+    return b->bulk_seed.len;
+}
+
+int ocp_qp_gpu_batch_sens_bulk_offset(ocp_qp_gpu_batch *b, int output, const char *field, int stage, int *len)
+{
+    if (output)
+    {
+        if (strncmp(field, "sens_", 5)) { if (len) *len = 0; return -1; }
+        return ocp_qp_gpu_batch_bulk_offset(b, 1, field + 5, stage, len);
+    }
+    ocp_qp_gpu_batch_sens_bulk_len(b, 0);
+    auto &M = b->bulk_seed;
+    for (size_t q = 0; q < M.fields.size(); q++)
+        if (M.seg_stage[q] == stage && M.fields[q] == field)
+        {
+            if (len) *len = M.seg_len[q];
+            return M.seg_off[q];
+        }
+    if (len) *len = 0;
+    return -1;
+}
+
+int ocp_qp_gpu_batch_sens_set_bulk(ocp_qp_gpu_batch *b, const double *blob, int is_device)
+{
+    const int len = ocp_qp_gpu_batch_sens_bulk_len(b, 0);
+    if (sens_begin(b)) return -1; /* zeroes the seed arrays, factorises at the solution where the sweeps run in place */
+    if (len == 0) return 0;
+    auto &M = b->bulk_seed;
+    const GqpDev &D = b->D;
+    const GArr table[5] = {D.rg, D.rgs, D.rb, D.rd, b->sfix};
+    for (int q = 0; q < 16; q++) M.T.a[q] = q < 5 ? table[q] : GArr{nullptr, 0, 0};
+    const double *src = stage_in(b, blob, (size_t) b->B * len, is_device);
+    const dim3 grid((b->B + 63) / 64, (len + 255) / 256), block(64);
+    hipLaunchKernelGGL(gqp::k_bulk_scatter_seed, grid, block, 0, b->stream, src, b->B, len, M.d_arr, M.d_elem, M.d_sgn, M.d_elem2, M.T);
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return 0;
+}
+
+int ocp_qp_gpu_batch_sens_get_bulk(ocp_qp_gpu_batch *b, double *blob, int is_device)
+{
+    const int len = ocp_qp_gpu_batch_bulk_len(b, 1);
+    auto &M = b->bulk_out;
+    gqp::GArrTable T = M.T; /* same element maps as the solution, read from the direction arrays */
+    const GqpDev &D = b->D;
+    T.a[7] = D.dux; T.a[8] = D.dsv; T.a[9] = D.dpi; T.a[10] = D.dlam; T.a[11] = D.dt;
+    const size_t cnt = (size_t) b->B * len;
+    double *dst = blob;
+    if (!is_device)
+    {
+        if (cnt > b->stage_cap) { b->stage_cap = cnt * 2; b->d_stage = dalloc<double>(b, b->stage_cap); }
+        dst = b->d_stage;
+    }
+    const dim3 grid((b->B + 63) / 64, (len + 255) / 256), block(64);
+    hipLaunchKernelGGL(gqp::k_bulk_gather, grid, block, 0, b->stream, dst, b->B, len, M.d_arr, M.d_elem, T);
+    if (!is_device) HIPCHK(hipMemcpyAsync(blob, dst, sizeof(double) * cnt, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return 0;
+}
+
+/* pinned host memory for callers that stage their own blobs (the acados-side adapter is plain C and has no HIP) */
+void *ocp_qp_gpu_host_alloc(size_t bytes)
+{
+    void *p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 8) != hipSuccess)
+    {
+        fprintf(stderr, "acados_amd: cannot allocate %zu bytes of pinned host memory\n", bytes);
+        return nullptr;
+    }
+    return p;
+}
+
+void ocp_qp_gpu_host_free(void *p)
+{
+    if (p) (void) hipHostFree(p);
 }
 
 /* ---- multi-GPU: the ONLY collective of the path -- one RCCL all-gather over xGMI of the solutions and

@@ -1138,6 +1138,24 @@ static __global__ void k_bulk_scatter(const double *blob, int nb, int len, const
     }
 }
 
+/* seeds of a sensitivity solve, all fields of all stages in one launch: entry e of the blob goes (with its sign: the
+ * residual arrays hold lower-bound seeds negated) to array T.a[map_arr[e]] and, where the row is an equality-flagged
+ * bound, also into the table's array 4 (derivative of the fixed variable itself) */
+static __global__ void k_bulk_scatter_seed(const double *blob, int nb, int len, const int *map_arr, const int *map_elem,
+                                           const int *map_sgn, const int *map_elem2, GArrTable T)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nb) return;
+    const int e0 = blockIdx.y * 256, e1 = e0 + 256 < len ? e0 + 256 : len;
+    for (int e = e0; e < e1; e++)
+    {
+        const double v = blob[(size_t) i * len + e];
+        const int a = map_arr[e];
+        if (a >= 0) GATL(T.a[a], map_elem[e]) = map_sgn[e] < 0 ? -v : v;
+        if (map_elem2[e] >= 0) GATL(T.a[4], map_elem2[e]) = v;
+    }
+}
+
 static __global__ void k_bulk_gather(double *blob, int nb, int len, const int *map_arr, const int *map_elem, GArrTable T)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

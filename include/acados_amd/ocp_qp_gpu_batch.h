@@ -131,6 +131,19 @@ int ocp_qp_gpu_batch_get(ocp_qp_gpu_batch *b, const char *field, int stage, doub
  * After a partially condensed solve the sensitivities are computed in the full space at the expanded solution. */
 int ocp_qp_gpu_batch_sens_set(ocp_qp_gpu_batch *b, const char *field, int stage, const double *data);
 int ocp_qp_gpu_batch_sens_solve(ocp_qp_gpu_batch *b);
+/* The same in bulk -- every seed of every instance in ONE host->device copy and one launch, every direction back in one
+ * launch and one copy: the batched eval_forw_sens / eval_adj_sens (acados_solver.in.c:3292-3337 loops the single-QP
+ * slots of ocp_qp_hpipm.c:481-506 over the capsules).  Seed blob (output = 0), per instance the concatenation, stage by
+ * stage, of  seed_r seed_q seed_zl seed_zu | seed_b | seed_lbu seed_lbx seed_lg seed_ubu seed_ubx seed_ug seed_lls seed_lus
+ * i.e. d_ocp_qp_seed's seed_g[k], seed_b[k], seed_d[k] one after the other, NATURAL sign (acados stores the upper part of
+ * seed_d negated like d, ocp_nlp_common.c:4078-4081: its adapter flips it).  _sens_set_bulk opens a fresh seed set
+ * (whatever single seeds were set before are overwritten) ; _sens_solve as above; _sens_get_bulk returns the directions
+ * in the OUTPUT blob layout of ocp_qp_gpu_batch_get_bulk (sens_u sens_x sens_sl sens_su sens_pi sens_lam sens_t).
+ * _sens_bulk_len / _sens_bulk_offset: doubles per instance and position of one field ("seed_q" ... / "sens_x" ...). */
+int ocp_qp_gpu_batch_sens_bulk_len(ocp_qp_gpu_batch *b, int output);
+int ocp_qp_gpu_batch_sens_bulk_offset(ocp_qp_gpu_batch *b, int output, const char *field, int stage, int *len);
+int ocp_qp_gpu_batch_sens_set_bulk(ocp_qp_gpu_batch *b, const double *blob, int is_device);
+int ocp_qp_gpu_batch_sens_get_bulk(ocp_qp_gpu_batch *b, double *blob, int is_device);
 
 /* KKT residuals of an arbitrary (qp_in, qp_out): what ocp_qp_res_compute -> d_ocp_qp_res_compute and
  * ocp_qp_res_compute_nrm_inf do (acados/ocp_qp/ocp_qp_common.c:559-667; wrapper ocp_qp_inf_norm_residuals,
@@ -166,6 +179,11 @@ int ocp_qp_gpu_comm_unique_id(void *id128);
 ocp_qp_gpu_comm *ocp_qp_gpu_comm_create(const void *id128, int n_ranks, int rank, int device);
 void ocp_qp_gpu_comm_destroy(ocp_qp_gpu_comm *c);
 int ocp_qp_gpu_batch_gather(ocp_qp_gpu_batch *b, ocp_qp_gpu_comm *c, double *sol_all, int *info_all, double *time_all);
+
+/* pinned (page-locked) host memory for callers that stage their own bulk blobs -- the acados-side adapter is plain C
+ * and links no HIP; NULL (with a message) on failure */
+void *ocp_qp_gpu_host_alloc(size_t bytes);
+void ocp_qp_gpu_host_free(void *p);
 
 /* bytes of HBM held by the batch */
 size_t ocp_qp_gpu_batch_bytes(const ocp_qp_gpu_batch *b);

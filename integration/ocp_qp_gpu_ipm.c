@@ -3,13 +3,23 @@
  * acados/ocp_qp/ next to ocp_qp_hpipm.c.  It is written against acados' OWN types -- ocp_qp_in / ocp_qp_out are HPIPM's
  * d_ocp_qp / d_ocp_qp_sol holding BLASFEO matrices (acados/ocp_qp/ocp_qp_common.h:49-54), panel-major in the default
  * build (external/CMakeLists.txt:46) -- and talks to libacados_amd_qp.so through the device-batch C-ABI
- * (include/acados_amd/ocp_qp_gpu_batch.h) only.  It fills the 17 slots of qp_solver_config (ocp_qp_common.h:60-79):
+ * (include/acados_amd/ocp_qp_gpu_batch.h) only.  Two entry levels:
  *
- *     ocp_qp_gpu_ipm_acados_config_initialize_default(config->qp_solver);
- *
- * in the `case PARTIAL_CONDENSING_GPU_IPM:` of ocp_qp_xcond_solver_config_initialize_from_plan
- * (interfaces/acados_c/ocp_qp_interface.c:91-182), with HPIPM's partial condensing in the xcond slot
- * (INTEGRATION.md section 3).
+ *   1. the 17 slots of qp_solver_config (ocp_qp_common.h:60-79), one QP per call:
+ *          ocp_qp_gpu_ipm_acados_config_initialize_default(config->qp_solver);
+ *      in the `case PARTIAL_CONDENSING_GPU_IPM:` of ocp_qp_xcond_solver_config_initialize_from_plan
+ *      (interfaces/acados_c/ocp_qp_interface.c:91-182), with HPIPM's partial condensing in the xcond slot
+ *      (INTEGRATION.md section 3);
+ *   2. the BATCH entries the reference does not have (SURVEY 8b "Threading"): n capsules' QPs -- acados structs, one
+ *      `mem` each -- go to the GPU as ONE device batch per structure class:
+ *          ocp_qp_gpu_ipm_acados_evaluate_batch(config, n, qp_in[], qp_out[], opts, mem[], work)
+ *          ocp_qp_gpu_ipm_acados_eval_sens_batch(config, n, qp_in[], seed[], sens_qp_out[], opts, mem[], work)
+ *      They replace the per-capsule loops `#pragma omp parallel for ... ocp_nlp_solve(capsule[i])` ->
+ *      config->evaluate(...) of acados_solver.in.c:3222-3243 (call site ocp_nlp_common.c:4517) and
+ *      acados_solver.in.c:3292-3337 (call sites ocp_nlp_common.c:4091, 4141): host threads unpack the n panel-major QPs
+ *      into one pinned blob, ONE host->device copy + ONE scatter launch, one device batch solve, one gather launch + one
+ *      copy back, host threads pack the n qp_out.  QPs that differ in structure (dims, idxb, idxs_rev, idxe) are bucketed
+ *      by structure signature, one device batch per bucket, buckets solved concurrently.
  *
  * Data access rule followed (pattern of acados/ocp_qp/ocp_qp_clarabel.c:205-683, 1018-1072): matrices only
  * through blasfeo_unpack_dmat / blasfeo_unpack_tran_dmat, vectors through blasfeo_unpack_dvec / blasfeo_pack_dvec;
@@ -17,8 +27,10 @@
  * ocp_nlp_common.c:3119-3138); d = [lb; lg; -ub; -ug; ls; us] (ocp_qp_common.c:897-906) -> natural-sign bounds; every
  * member array is re-read on every evaluate (they alias ocp_nlp memory, ocp_nlp_common.c:2797-2894).
  *
- * Memory rule: opts and memory are carved from the caller's block (sizes from dims); the only things kept outside are
- * the device batch and its stream (released by `terminate`, ocp_qp_common.h:78).  No malloc in evaluate.
+ * Memory rule: opts and memory are carved from the caller's block (sizes from dims) -- staging, structure signature and
+ * the segment tables of the single-QP path included: no malloc in `evaluate`.  Kept outside the block: the device batch
+ * and its stream (released by `terminate`, ocp_qp_common.h:78) and, for the batch entries, the per-bucket tables and
+ * pinned staging, sized once per (n, structure) and owned by mem[0] of the call (released by its terminate / reset).
  *
  * In this repository the file is compiled and RUN in the test tiers against tests/mock_acados/include (stand-ins for
  * the HPIPM / BLASFEO / acados declarations restated from the fields acados touches): tests/test_mock_acados.py.
@@ -40,13 +52,52 @@ typedef struct
     int iter_max, warm_start, print_level, ric_alg, t0_init, update_fact_exit;
 } ocp_qp_gpu_ipm_opts;
 
+/* one piece of a bulk blob <-> one sub-block of a BLASFEO object of the QP */
+enum { SEG_VEC = 0, SEG_MAT = 1, SEG_MAT_T = 2 };
+enum { SRC_BAbt = 0, SRC_RSQrq, SRC_DCt, SRC_b, SRC_rqz, SRC_d, SRC_dmask, SRC_Z,  /* qp_in */
+       SRC_ux, SRC_pi, SRC_lam, SRC_t,                                             /* qp_out */
+       SRC_seed_g, SRC_seed_b, SRC_seed_d };                                       /* seed */
 typedef struct
 {
-    ocp_qp_gpu_batch *batch;  /* device-side resource, released by terminate */
-    int *sig;                 /* structure the batch was built for (carved) */
-    int sig_len, sig_cap;
-    double *blob_in, *blob_out; /* host staging of the bulk pack / unpack (carved) */
-    int cap_in, cap_out;
+    int off, len;   /* position in the per-instance blob */
+    int kind, src, k;
+    int ai, aj;     /* first row (vector: first entry) / first column of the sub-block */
+    int m, n;       /* rows, columns of the sub-block (SEG_MAT_T: the blob holds its transpose, n x m) */
+    int neg;        /* stored negated in acados (upper bounds in d, ocp_qp_common.c:897-906) */
+} gpu_seg;
+
+/* one structure class = one device batch */
+typedef struct
+{
+    ocp_qp_gpu_batch *batch;
+    int n;                       /* instances */
+    int *sig, sig_len, sig_cap;  /* structure the batch was built for */
+    gpu_seg *seg_in, *seg_out, *seg_seed;
+    int n_in, n_out, n_seed, seg_cap_in, seg_cap_out, seg_cap_seed;
+    int L_in, L_out, L_seed;     /* doubles per instance of the three blobs */
+    double *blob_in, *blob_out;  /* staging: carved (single QP) or pinned (batch entries) */
+    size_t cap_in, cap_out;      /* doubles */
+    int *members;                /* batch entries: index of each instance in the caller's arrays */
+    int *st, *it;                /* per-instance status / iterations of the last solve */
+    int status;                  /* worst status of the last solve */
+} gpu_bucket;
+
+struct ocp_qp_gpu_ipm_memory_;
+typedef struct
+{
+    struct ocp_qp_gpu_ipm_memory_ *owner; /* mem[0] of the call that built the group: its terminate releases it */
+    int n, nbk;
+    gpu_bucket *bk;
+    int *bucket_of, *pos_of;     /* per caller index */
+    int *scratch, scratch_cap;   /* signature scratch */
+} gpu_group;
+
+typedef struct ocp_qp_gpu_ipm_memory_
+{
+    gpu_bucket own;              /* the single-QP path: a bucket of one, everything carved */
+    gpu_group *group;            /* batch entries: the group this memory's QP was solved in last (NULL: own) ... */
+    int g_bucket, g_pos;         /* ... and where */
+    int *sig_scratch;
     double time_qp_solver_call;
     int iter, status;
 } ocp_qp_gpu_ipm_memory;
@@ -71,13 +122,14 @@ static int sig_len(const ocp_qp_dims *d)
 
 static int blob_in_cap(const ocp_qp_dims *d)
 {
-    int len = 0;
+    int len = 0, getter = 0;
     for (int k = 0; k <= d->N; k++)
     {
         const int nx = d->nx[k], nu = d->nu[k], nx1 = k < d->N ? d->nx[k + 1] : 0;
         len += nx1 * (nx + nu + 1) + (nu + nx) * (nu + nx) + nu + nx + 5 * d->nb[k] + d->ng[k] * (nu + nx) + 4 * d->ng[k] + 8 * d->ns[k];
+        if ((nu + nx) * (nu + nx + 1) > getter) getter = (nu + nx) * (nu + nx + 1); /* solver_get stages ric_L, ric_l here */
     }
-    return len;
+    return len > getter ? len : getter;
 }
 
 static int blob_out_cap(const ocp_qp_dims *d)
@@ -88,7 +140,11 @@ static int blob_out_cap(const ocp_qp_dims *d)
     return len;
 }
 
-/* ------------------------------------------------------------------ opts (ocp_qp_hpipm.c:60-183) */
+#define SEGS_IN_PER_STAGE 34   /* A B b R S Q r q zl zu + 9 bound pieces + 8 masks + Zl Zu + C D (+ lbx#value) */
+#define SEGS_OUT_PER_STAGE 7   /* u x sl su pi lam t */
+#define SEGS_SEED_PER_STAGE 13 /* r q zl zu b lbu lbx lg ubu ubx ug lls lus */
+
+/* ------------------------------------------------------------------ dims / opts (ocp_qp_hpipm.c:60-183) */
 
 static void gpu_dims_set(void *config_, void *dims_, int stage, const char *field, int *value)
 {
@@ -153,21 +209,34 @@ static void gpu_opts_get(void *config, void *opts_, const char *field, void *val
 static acados_size_t gpu_memory_calculate_size(void *config, void *dims_, void *opts)
 {
     const ocp_qp_dims *d = (const ocp_qp_dims *) dims_;
-    return sizeof(ocp_qp_gpu_ipm_memory) + sizeof(int) * (size_t) sig_len(d) + sizeof(double) * (size_t) (blob_in_cap(d) + blob_out_cap(d)) + 4 * 8;
+    const size_t nst = (size_t) d->N + 1;
+    return sizeof(ocp_qp_gpu_ipm_memory) + 2 * sizeof(int) * (size_t) sig_len(d)
+           + sizeof(double) * (size_t) (blob_in_cap(d) + blob_out_cap(d))
+           + sizeof(gpu_seg) * nst * (SEGS_IN_PER_STAGE + SEGS_OUT_PER_STAGE + SEGS_SEED_PER_STAGE) + 2 * sizeof(int) + 8 * 8;
 }
 
 static void *gpu_memory_assign(void *config, void *dims_, void *opts, void *raw_memory)
 {
     const ocp_qp_dims *d = (const ocp_qp_dims *) dims_;
+    const int nst = d->N + 1;
     char *c = align8((char *) raw_memory);
     ocp_qp_gpu_ipm_memory *m = (ocp_qp_gpu_ipm_memory *) c;
     memset(m, 0, sizeof(*m));
     c = align8(c + sizeof(*m));
-    m->cap_in = blob_in_cap(d); m->cap_out = blob_out_cap(d);
-    m->blob_in = (double *) c; c += sizeof(double) * (size_t) m->cap_in;
-    m->blob_out = (double *) c; c += sizeof(double) * (size_t) m->cap_out;
-    m->sig_cap = sig_len(d);
-    m->sig = (int *) c;
+    gpu_bucket *bk = &m->own;
+    bk->n = 1;
+    bk->cap_in = (size_t) blob_in_cap(d); bk->cap_out = (size_t) blob_out_cap(d);
+    bk->blob_in = (double *) c; c += sizeof(double) * bk->cap_in;
+    bk->blob_out = (double *) c; c += sizeof(double) * bk->cap_out;
+    bk->seg_cap_in = nst * SEGS_IN_PER_STAGE; bk->seg_cap_out = nst * SEGS_OUT_PER_STAGE; bk->seg_cap_seed = nst * SEGS_SEED_PER_STAGE;
+    bk->seg_in = (gpu_seg *) c; c += sizeof(gpu_seg) * (size_t) bk->seg_cap_in;
+    bk->seg_out = (gpu_seg *) c; c += sizeof(gpu_seg) * (size_t) bk->seg_cap_out;
+    bk->seg_seed = (gpu_seg *) c; c += sizeof(gpu_seg) * (size_t) bk->seg_cap_seed;
+    bk->sig_cap = sig_len(d);
+    bk->sig = (int *) c; c += sizeof(int) * (size_t) bk->sig_cap;
+    m->sig_scratch = (int *) c; c += sizeof(int) * (size_t) bk->sig_cap; /* its own scratch: a signature can be longer than a staging blob */
+    bk->st = (int *) c; c += sizeof(int);
+    bk->it = (int *) c; c += sizeof(int);
     return m;
 }
 
@@ -182,7 +251,7 @@ static void gpu_memory_get(void *config, void *mem_, const char *field, void *va
 
 static acados_size_t gpu_workspace_calculate_size(void *config, void *dims, void *opts) { return 0; }
 
-/* ------------------------------------------------------------------ evaluate (ocp_qp_hpipm.c:314-405) */
+/* ------------------------------------------------------------------ structure signature, segment tables */
 
 static int fill_sig(const ocp_qp_in *in, int *s)
 {
@@ -200,108 +269,187 @@ static int fill_sig(const ocp_qp_in *in, int *s)
     return p;
 }
 
-/* destination of one field in the input blob (NULL when the field has no entry at this stage) */
-static double *slot(ocp_qp_gpu_ipm_memory *m, const char *field, int k, int expect)
+static void seg_add(ocp_qp_gpu_batch *b, gpu_seg *tab, int *cnt, int cap, int which, const char *field, int k, int expect,
+                    int kind, int src, int ai, int aj, int m, int n, int neg)
 {
+    /* which: 0 input blob, 1 output blob, 2 seed blob */
     int len = 0;
-    const int off = ocp_qp_gpu_batch_bulk_offset(m->batch, 0, field, k, &len);
-    if (off < 0 || len == 0) return NULL;
+    const int off = which == 2 ? ocp_qp_gpu_batch_sens_bulk_offset(b, 0, field, k, &len) : ocp_qp_gpu_batch_bulk_offset(b, which, field, k, &len);
+    if (off < 0 || len == 0) return;
     if (len != expect)
     {
-        printf("\nerror: ocp_qp_gpu_ipm: field %s at stage %d has %d entries in the device layout, %d in qp_in\n", field, k, len, expect);
+        printf("\nerror: ocp_qp_gpu_ipm: field %s at stage %d has %d entries in the device layout, %d in the acados struct\n", field, k, len, expect);
         exit(1);
     }
-    return m->blob_in + off;
+    if (*cnt >= cap) { printf("\nerror: ocp_qp_gpu_ipm: segment table too small\n"); exit(1); }
+    gpu_seg *g = tab + (*cnt)++;
+    g->off = off; g->len = len; g->kind = kind; g->src = src; g->k = k; g->ai = ai; g->aj = aj; g->m = m; g->n = n; g->neg = neg;
 }
 
-static int ocp_qp_gpu_ipm_acados(void *config, void *qp_in_, void *qp_out_, void *opts_, void *mem_, void *work)
+/* where every field of the three blobs lives in the acados structs: once per device batch */
+static void build_segments(gpu_bucket *bk, const ocp_qp_dims *d)
 {
-    const double t_start = now_s();
-    ocp_qp_in *in = (ocp_qp_in *) qp_in_;
-    ocp_qp_out *out = (ocp_qp_out *) qp_out_;
-    ocp_qp_gpu_ipm_opts *o = (ocp_qp_gpu_ipm_opts *) opts_;
-    ocp_qp_gpu_ipm_memory *m = (ocp_qp_gpu_ipm_memory *) mem_;
-    const ocp_qp_dims *d = in->dim;
+    ocp_qp_gpu_batch *b = bk->batch;
     const int N = d->N;
-    qp_info *info = (qp_info *) out->misc;
-
-    /* device batch: (re)created when the structure changes; the signature is compared in carved memory */
-    {
-        int *scratch = (int *) m->blob_out; /* blob_out is idle until the unpack and large enough */
-        const int len = fill_sig(in, scratch);
-        if (len > m->sig_cap) { printf("\nerror: ocp_qp_gpu_ipm: dims of qp_in grew after memory_assign\n"); exit(1); }
-        if (!m->batch || m->sig_len != len || memcmp(m->sig, scratch, sizeof(int) * len) != 0)
-        {
-            if (m->batch) ocp_qp_gpu_batch_destroy(m->batch);
-            m->batch = ocp_qp_gpu_batch_create(N, d->nx, d->nu, d->nbx, d->nbu, d->ng, d->ns, 1, -1);
-            if (!m->batch) { printf("\nerror: ocp_qp_gpu_ipm: no GPU batch could be created (no device or unsupported shape)\n"); exit(1); }
-            memcpy(m->sig, scratch, sizeof(int) * len);
-            m->sig_len = len;
-            for (int k = 0; k <= N; k++)
-            {
-                ocp_qp_gpu_batch_set_int(m->batch, "idxb", k, in->idxb[k], d->nb[k]);
-                ocp_qp_gpu_batch_set_int(m->batch, "idxs_rev", k, in->idxs_rev[k], d->nb[k] + d->ng[k]);
-                ocp_qp_gpu_batch_set_int(m->batch, "idxe", k, in->idxe[k], d->nbxe[k]);
-            }
-            if (ocp_qp_gpu_batch_bulk_len(m->batch, 0) > m->cap_in || ocp_qp_gpu_batch_bulk_len(m->batch, 1) > m->cap_out)
-            {
-                printf("\nerror: ocp_qp_gpu_ipm: bulk blob larger than the carved staging\n");
-                exit(1);
-            }
-        }
-    }
-    ocp_qp_gpu_batch *b = m->batch;
-
-    /* every member array of qp_in, re-read on every call, unpacked from BLASFEO storage straight into the blob */
-    memset(m->blob_in, 0, sizeof(double) * (size_t) ocp_qp_gpu_batch_bulk_len(b, 0));
+    bk->n_in = bk->n_out = bk->n_seed = 0;
+    bk->L_in = ocp_qp_gpu_batch_bulk_len(b, 0);
+    bk->L_out = ocp_qp_gpu_batch_bulk_len(b, 1);
+    bk->L_seed = ocp_qp_gpu_batch_sens_bulk_len(b, 0);
+#define IN(field, expect, kind, src, ai, aj, m, n, neg) seg_add(b, bk->seg_in, &bk->n_in, bk->seg_cap_in, 0, field, k, expect, kind, src, ai, aj, m, n, neg)
+#define OUT(field, expect, src, ai) seg_add(b, bk->seg_out, &bk->n_out, bk->seg_cap_out, 1, field, k, expect, SEG_VEC, src, ai, 0, expect, 1, 0)
+#define SEED(field, expect, src, ai, neg) seg_add(b, bk->seg_seed, &bk->n_seed, bk->seg_cap_seed, 2, field, k, expect, SEG_VEC, src, ai, 0, expect, 1, neg)
     for (int k = 0; k <= N; k++)
     {
         const int nu = d->nu[k], nx = d->nx[k], nx1 = k < N ? d->nx[k + 1] : 0;
         const int nbu = d->nbu[k], nbx = d->nbx[k], nb = d->nb[k], ng = d->ng[k], ns = d->ns[k];
-        double *p;
         if (k < N)
         {
             /* BAbt = [B'; A'; b'] (print.c:234-325): A (nx+ x nx) = (rows nu.. of BAbt)', B (nx+ x nu) = (rows 0..nu)' */
-            if ((p = slot(m, "A", k, nx1 * nx))) blasfeo_unpack_tran_dmat(nx, nx1, in->BAbt + k, nu, 0, p, nx1);
-            if ((p = slot(m, "B", k, nx1 * nu))) blasfeo_unpack_tran_dmat(nu, nx1, in->BAbt + k, 0, 0, p, nx1);
-            if ((p = slot(m, "b", k, nx1))) blasfeo_unpack_dvec(nx1, in->b + k, 0, p, 1); /* the VECTOR, not the last row */
+            IN("A", nx1 * nx, SEG_MAT_T, SRC_BAbt, nu, 0, nx, nx1, 0);
+            IN("B", nx1 * nu, SEG_MAT_T, SRC_BAbt, 0, 0, nu, nx1, 0);
+            IN("b", nx1, SEG_VEC, SRC_b, 0, 0, nx1, 1, 0); /* the VECTOR, not the last row */
         }
         /* RSQrq: lower triangle of [[R, S], [S', Q]] -- only the lower triangle is valid */
-        if ((p = slot(m, "R", k, nu * nu))) blasfeo_unpack_dmat(nu, nu, in->RSQrq + k, 0, 0, p, nu);
-        if ((p = slot(m, "S", k, nu * nx))) blasfeo_unpack_tran_dmat(nx, nu, in->RSQrq + k, nu, 0, p, nu); /* S (nu x nx) = (S')' */
-        if ((p = slot(m, "Q", k, nx * nx))) blasfeo_unpack_dmat(nx, nx, in->RSQrq + k, nu, nu, p, nx);
+        IN("R", nu * nu, SEG_MAT, SRC_RSQrq, 0, 0, nu, nu, 0);
+        IN("S", nu * nx, SEG_MAT_T, SRC_RSQrq, nu, 0, nx, nu, 0); /* S (nu x nx) = (S')' */
+        IN("Q", nx * nx, SEG_MAT, SRC_RSQrq, nu, nu, nx, nx, 0);
         /* rqz = [r; q; zl; zu]: the vectors ocp_nlp writes every iteration */
-        if ((p = slot(m, "r", k, nu))) blasfeo_unpack_dvec(nu, in->rqz + k, 0, p, 1);
-        if ((p = slot(m, "q", k, nx))) blasfeo_unpack_dvec(nx, in->rqz + k, nu, p, 1);
-        if ((p = slot(m, "zl", k, ns))) blasfeo_unpack_dvec(ns, in->rqz + k, nu + nx, p, 1);
-        if ((p = slot(m, "zu", k, ns))) blasfeo_unpack_dvec(ns, in->rqz + k, nu + nx + ns, p, 1);
+        IN("r", nu, SEG_VEC, SRC_rqz, 0, 0, nu, 1, 0);
+        IN("q", nx, SEG_VEC, SRC_rqz, nu, 0, nx, 1, 0);
+        IN("zl", ns, SEG_VEC, SRC_rqz, nu + nx, 0, ns, 1, 0);
+        IN("zu", ns, SEG_VEC, SRC_rqz, nu + nx + ns, 0, ns, 1, 0);
         /* d = [lb; lg; -ub; -ug; ls; us] with lb = [lbu; lbx] (ocp_qp_common.c:897-906): natural sign for the device */
-        if ((p = slot(m, "lbu", k, nbu))) blasfeo_unpack_dvec(nbu, in->d + k, 0, p, 1);
-        if ((p = slot(m, "lbx", k, nbx))) blasfeo_unpack_dvec(nbx, in->d + k, nbu, p, 1);
-        if ((p = slot(m, "lbx#value", k, nbx))) blasfeo_unpack_dvec(nbx, in->d + k, nbu, p, 1); /* equality-flagged: the value of x */
-        if ((p = slot(m, "lg", k, ng))) blasfeo_unpack_dvec(ng, in->d + k, nb, p, 1);
-        if ((p = slot(m, "ubu", k, nbu))) { blasfeo_unpack_dvec(nbu, in->d + k, nb + ng, p, 1); for (int e = 0; e < nbu; e++) p[e] = -p[e]; }
-        if ((p = slot(m, "ubx", k, nbx))) { blasfeo_unpack_dvec(nbx, in->d + k, nb + ng + nbu, p, 1); for (int e = 0; e < nbx; e++) p[e] = -p[e]; }
-        if ((p = slot(m, "ug", k, ng))) { blasfeo_unpack_dvec(ng, in->d + k, 2 * nb + ng, p, 1); for (int e = 0; e < ng; e++) p[e] = -p[e]; }
-        if ((p = slot(m, "lls", k, ns))) blasfeo_unpack_dvec(ns, in->d + k, 2 * nb + 2 * ng, p, 1);
-        if ((p = slot(m, "lus", k, ns))) blasfeo_unpack_dvec(ns, in->d + k, 2 * nb + 2 * ng + ns, p, 1);
+        IN("lbu", nbu, SEG_VEC, SRC_d, 0, 0, nbu, 1, 0);
+        IN("lbx", nbx, SEG_VEC, SRC_d, nbu, 0, nbx, 1, 0);
+        IN("lbx#value", nbx, SEG_VEC, SRC_d, nbu, 0, nbx, 1, 0); /* equality-flagged: the value of x */
+        IN("lg", ng, SEG_VEC, SRC_d, nb, 0, ng, 1, 0);
+        IN("ubu", nbu, SEG_VEC, SRC_d, nb + ng, 0, nbu, 1, 1);
+        IN("ubx", nbx, SEG_VEC, SRC_d, nb + ng + nbu, 0, nbx, 1, 1);
+        IN("ug", ng, SEG_VEC, SRC_d, 2 * nb + ng, 0, ng, 1, 1);
+        IN("lls", ns, SEG_VEC, SRC_d, 2 * nb + 2 * ng, 0, ns, 1, 0);
+        IN("lus", ns, SEG_VEC, SRC_d, 2 * nb + 2 * ng + ns, 0, ns, 1, 0);
         /* d_mask: same positions, 1.0 / 0.0 (aliased to nlp_in->dmask, ocp_nlp_common.c:2894) */
-        if ((p = slot(m, "lbu_mask", k, nbu))) blasfeo_unpack_dvec(nbu, in->d_mask + k, 0, p, 1);
-        if ((p = slot(m, "lbx_mask", k, nbx))) blasfeo_unpack_dvec(nbx, in->d_mask + k, nbu, p, 1);
-        if ((p = slot(m, "lg_mask", k, ng))) blasfeo_unpack_dvec(ng, in->d_mask + k, nb, p, 1);
-        if ((p = slot(m, "ubu_mask", k, nbu))) blasfeo_unpack_dvec(nbu, in->d_mask + k, nb + ng, p, 1);
-        if ((p = slot(m, "ubx_mask", k, nbx))) blasfeo_unpack_dvec(nbx, in->d_mask + k, nb + ng + nbu, p, 1);
-        if ((p = slot(m, "ug_mask", k, ng))) blasfeo_unpack_dvec(ng, in->d_mask + k, 2 * nb + ng, p, 1);
-        if ((p = slot(m, "lls_mask", k, ns))) blasfeo_unpack_dvec(ns, in->d_mask + k, 2 * nb + 2 * ng, p, 1);
-        if ((p = slot(m, "lus_mask", k, ns))) blasfeo_unpack_dvec(ns, in->d_mask + k, 2 * nb + 2 * ng + ns, p, 1);
+        IN("lbu_mask", nbu, SEG_VEC, SRC_dmask, 0, 0, nbu, 1, 0);
+        IN("lbx_mask", nbx, SEG_VEC, SRC_dmask, nbu, 0, nbx, 1, 0);
+        IN("lg_mask", ng, SEG_VEC, SRC_dmask, nb, 0, ng, 1, 0);
+        IN("ubu_mask", nbu, SEG_VEC, SRC_dmask, nb + ng, 0, nbu, 1, 0);
+        IN("ubx_mask", nbx, SEG_VEC, SRC_dmask, nb + ng + nbu, 0, nbx, 1, 0);
+        IN("ug_mask", ng, SEG_VEC, SRC_dmask, 2 * nb + ng, 0, ng, 1, 0);
+        IN("lls_mask", ns, SEG_VEC, SRC_dmask, 2 * nb + 2 * ng, 0, ns, 1, 0);
+        IN("lus_mask", ns, SEG_VEC, SRC_dmask, 2 * nb + 2 * ng + ns, 0, ns, 1, 0);
         /* Z = [Zl; Zu] */
-        if ((p = slot(m, "Zl", k, ns))) blasfeo_unpack_dvec(ns, in->Z + k, 0, p, 1);
-        if ((p = slot(m, "Zu", k, ns))) blasfeo_unpack_dvec(ns, in->Z + k, ns, p, 1);
+        IN("Zl", ns, SEG_VEC, SRC_Z, 0, 0, ns, 1, 0);
+        IN("Zu", ns, SEG_VEC, SRC_Z, ns, 0, ns, 1, 0);
         /* DCt = [D'; C'] ((nu+nx) x ng): C (ng x nx) = (rows nu.. )', D (ng x nu) = (rows 0..nu)' */
-        if ((p = slot(m, "C", k, ng * nx))) blasfeo_unpack_tran_dmat(nx, ng, in->DCt + k, nu, 0, p, ng);
-        if ((p = slot(m, "D", k, ng * nu))) blasfeo_unpack_tran_dmat(nu, ng, in->DCt + k, 0, 0, p, ng);
+        IN("C", ng * nx, SEG_MAT_T, SRC_DCt, nu, 0, nx, ng, 0);
+        IN("D", ng * nu, SEG_MAT_T, SRC_DCt, 0, 0, nu, ng, 0);
+
+        /* solution: ux = [u; x; sl; su], lam / t ordered [lb lg ub ug ls us] as HPIPM's */
+        const int nct = 2 * (nb + ng + ns);
+        OUT("u", nu, SRC_ux, 0);
+        OUT("x", nx, SRC_ux, nu);
+        OUT("sl", ns, SRC_ux, nu + nx);
+        OUT("su", ns, SRC_ux, nu + nx + ns);
+        if (k < N) OUT("pi", nx1, SRC_pi, 0);
+        OUT("lam", nct, SRC_lam, 0);
+        OUT("t", nct, SRC_t, 0);
+
+        /* seeds: seed_g = d[r; q; zl; zu], seed_b = d b, seed_d laid out like d -- upper part negated like d
+         * (ocp_nlp_common.c:4078-4081 builds it that way for the nonlinear rows); the device takes natural signs */
+        SEED("seed_r", nu, SRC_seed_g, 0, 0);
+        SEED("seed_q", nx, SRC_seed_g, nu, 0);
+        SEED("seed_zl", ns, SRC_seed_g, nu + nx, 0);
+        SEED("seed_zu", ns, SRC_seed_g, nu + nx + ns, 0);
+        if (k < N) SEED("seed_b", nx1, SRC_seed_b, 0, 0);
+        SEED("seed_lbu", nbu, SRC_seed_d, 0, 0);
+        SEED("seed_lbx", nbx, SRC_seed_d, nbu, 0);
+        SEED("seed_lg", ng, SRC_seed_d, nb, 0);
+        SEED("seed_ubu", nbu, SRC_seed_d, nb + ng, 1);
+        SEED("seed_ubx", nbx, SRC_seed_d, nb + ng + nbu, 1);
+        SEED("seed_ug", ng, SRC_seed_d, 2 * nb + ng, 1);
+        SEED("seed_lls", ns, SRC_seed_d, 2 * nb + 2 * ng, 0);
+        SEED("seed_lus", ns, SRC_seed_d, 2 * nb + 2 * ng + ns, 0);
     }
-    /* options by name */
+#undef IN
+#undef OUT
+#undef SEED
+}
+
+/* (re)create the device batch of a bucket for the structure of `in` (n instances) */
+static void bucket_build(gpu_bucket *bk, const ocp_qp_in *in, const int *sig, int len)
+{
+    const ocp_qp_dims *d = in->dim;
+    const int N = d->N;
+    if (bk->batch) ocp_qp_gpu_batch_destroy(bk->batch);
+    bk->batch = ocp_qp_gpu_batch_create(N, d->nx, d->nu, d->nbx, d->nbu, d->ng, d->ns, bk->n, -1);
+    if (!bk->batch) { printf("\nerror: ocp_qp_gpu_ipm: no GPU batch could be created (no device or unsupported shape)\n"); exit(1); }
+    memcpy(bk->sig, sig, sizeof(int) * len);
+    bk->sig_len = len;
+    for (int k = 0; k <= N; k++)
+    {
+        ocp_qp_gpu_batch_set_int(bk->batch, "idxb", k, in->idxb[k], d->nb[k]);
+        ocp_qp_gpu_batch_set_int(bk->batch, "idxs_rev", k, in->idxs_rev[k], d->nb[k] + d->ng[k]);
+        ocp_qp_gpu_batch_set_int(bk->batch, "idxe", k, in->idxe[k], d->nbxe[k]);
+    }
+    build_segments(bk, d);
+}
+
+/* ------------------------------------------------------------------ blob <-> acados structs, one instance */
+
+static void unpack_segs(const gpu_seg *tab, int cnt, double *blob, struct blasfeo_dmat *const *mats, struct blasfeo_dvec *const *vecs)
+{
+    for (int s = 0; s < cnt; s++)
+    {
+        const gpu_seg *g = tab + s;
+        double *p = blob + g->off;
+        if (g->kind == SEG_VEC)
+        {
+            blasfeo_unpack_dvec(g->m, vecs[g->src] + g->k, g->ai, p, 1);
+            if (g->neg) for (int e = 0; e < g->len; e++) p[e] = -p[e];
+        }
+        else if (g->kind == SEG_MAT) blasfeo_unpack_dmat(g->m, g->n, mats[g->src] + g->k, g->ai, g->aj, p, g->m);
+        else blasfeo_unpack_tran_dmat(g->m, g->n, mats[g->src] + g->k, g->ai, g->aj, p, g->n);
+    }
+}
+
+/* every member array of qp_in, re-read on every call, unpacked from BLASFEO storage straight into the blob */
+static void unpack_qp_in(const gpu_bucket *bk, ocp_qp_in *in, double *blob)
+{
+    struct blasfeo_dmat *mats[3] = {in->BAbt, in->RSQrq, in->DCt};
+    struct blasfeo_dvec *vecs[8] = {NULL, NULL, NULL, in->b, in->rqz, in->d, in->d_mask, in->Z};
+    unpack_segs(bk->seg_in, bk->n_in, blob, mats, vecs);
+}
+
+static void unpack_seed(const gpu_bucket *bk, ocp_qp_seed *seed, double *blob)
+{
+    struct blasfeo_dvec *vecs[15] = {NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, seed->seed_g, seed->seed_b, seed->seed_d};
+    unpack_segs(bk->seg_seed, bk->n_seed, blob, NULL, vecs);
+}
+
+/* hot start: pi, lam, t of qp_out; the primal part stays zero as ocp_qp_hpipm.c:325-336 leaves it before every solve */
+static void unpack_qp_out_duals(const gpu_bucket *bk, ocp_qp_out *out, double *blob)
+{
+    struct blasfeo_dvec *vecs[12] = {NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, out->ux, out->pi, out->lam, out->t};
+    for (int s = 0; s < bk->n_out; s++)
+    {
+        const gpu_seg *g = bk->seg_out + s;
+        if (g->src == SRC_ux) memset(blob + g->off, 0, sizeof(double) * (size_t) g->len);
+        else blasfeo_unpack_dvec(g->m, vecs[g->src] + g->k, g->ai, blob + g->off, 1);
+    }
+}
+
+static void pack_qp_out(const gpu_bucket *bk, const double *blob, ocp_qp_out *out)
+{
+    struct blasfeo_dvec *vecs[12] = {NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, out->ux, out->pi, out->lam, out->t};
+    for (int s = 0; s < bk->n_out; s++)
+    {
+        const gpu_seg *g = bk->seg_out + s;
+        blasfeo_pack_dvec(g->m, (double *) blob + g->off, 1, vecs[g->src] + g->k, g->ai);
+    }
+}
+
+static void apply_opts(ocp_qp_gpu_batch *b, const ocp_qp_gpu_ipm_opts *o, int ws)
+{
     ocp_qp_gpu_batch_opts_set(b, "iter_max", &o->iter_max);
     ocp_qp_gpu_batch_opts_set(b, "tol_stat", &o->tol_stat);
     ocp_qp_gpu_batch_opts_set(b, "tol_eq", &o->tol_eq);
@@ -312,60 +460,258 @@ static int ocp_qp_gpu_ipm_acados(void *config, void *qp_in_, void *qp_out_, void
     ocp_qp_gpu_batch_opts_set(b, "t0_min", &o->t0_min);
     ocp_qp_gpu_batch_opts_set(b, "lam0_min", &o->lam0_min);
     ocp_qp_gpu_batch_opts_set(b, "print_level", &o->print_level);
-    const int ws = o->warm_start >= 2 ? o->warm_start : 0; /* 1 = 0, acados_ocp_options.py:1029-1031 */
     ocp_qp_gpu_batch_opts_set(b, "warm_start", &ws);
-    if (ws >= 2)
+}
+
+/* the device part of a solve: staged blobs -> device batch -> staged solution, statuses */
+static void bucket_solve(gpu_bucket *bk, const ocp_qp_gpu_ipm_opts *o, int ws)
+{
+    ocp_qp_gpu_batch *b = bk->batch;
+    apply_opts(b, o, ws);
+    /* the starting point goes in before the pack, which then restores the equality-flagged values (x0) */
+    if (ws >= 2) ocp_qp_gpu_batch_set_bulk_out(b, bk->blob_out, 0);
+    ocp_qp_gpu_batch_set_bulk(b, bk->blob_in, 0);
+    ocp_qp_gpu_batch_solve(b);
+    ocp_qp_gpu_batch_get_bulk(b, bk->blob_out, 0);
+    ocp_qp_gpu_batch_get_info(b, "status", bk->st);
+    ocp_qp_gpu_batch_get_info(b, "iter", bk->it);
+    int worst = 0;
+    for (int i = 0; i < bk->n; i++)
+        if (bk->st[i] != ACADOS_SUCCESS && (worst == 0 || worst == ACADOS_MAXITER)) worst = bk->st[i];
+    bk->status = worst;
+}
+
+/* ------------------------------------------------------------------ evaluate (ocp_qp_hpipm.c:314-405) */
+
+static int ocp_qp_gpu_ipm_acados(void *config, void *qp_in_, void *qp_out_, void *opts_, void *mem_, void *work)
+{
+    const double t_start = now_s();
+    ocp_qp_in *in = (ocp_qp_in *) qp_in_;
+    ocp_qp_out *out = (ocp_qp_out *) qp_out_;
+    ocp_qp_gpu_ipm_opts *o = (ocp_qp_gpu_ipm_opts *) opts_;
+    ocp_qp_gpu_ipm_memory *m = (ocp_qp_gpu_ipm_memory *) mem_;
+    gpu_bucket *bk = &m->own;
+    qp_info *info = (qp_info *) out->misc;
+
+    /* device batch: (re)created when the structure changes; the signature is compared in carved memory */
     {
-        /* hot start: pi, lam, t of qp_out; primal zeroed as ocp_qp_hpipm.c:325-336 does before every solve.  Written
-         * before the pack, which then restores the equality-flagged values (x0) */
-        const int Lo = ocp_qp_gpu_batch_bulk_len(b, 1);
-        memset(m->blob_out, 0, sizeof(double) * (size_t) Lo);
-        for (int k = 0; k <= N; k++)
+        if (sig_len(in->dim) > bk->sig_cap) { printf("\nerror: ocp_qp_gpu_ipm: dims of qp_in grew after memory_assign\n"); exit(1); }
+        const int len = fill_sig(in, m->sig_scratch);
+        if (!bk->batch || bk->sig_len != len || memcmp(bk->sig, m->sig_scratch, sizeof(int) * len) != 0)
         {
-            const int nct = 2 * (d->nb[k] + d->ng[k] + d->ns[k]);
-            int len = 0, off;
-            if (k < N && (off = ocp_qp_gpu_batch_bulk_offset(b, 1, "pi", k, &len)) >= 0) blasfeo_unpack_dvec(len, out->pi + k, 0, m->blob_out + off, 1);
-            if (nct && (off = ocp_qp_gpu_batch_bulk_offset(b, 1, "lam", k, &len)) >= 0) blasfeo_unpack_dvec(len, out->lam + k, 0, m->blob_out + off, 1);
-            if (nct && (off = ocp_qp_gpu_batch_bulk_offset(b, 1, "t", k, &len)) >= 0) blasfeo_unpack_dvec(len, out->t + k, 0, m->blob_out + off, 1);
+            bucket_build(bk, in, m->sig_scratch, len);
+            if ((size_t) bk->L_in > bk->cap_in || (size_t) bk->L_out > bk->cap_out || (size_t) bk->L_seed > bk->cap_in)
+            {
+                printf("\nerror: ocp_qp_gpu_ipm: bulk blob larger than the carved staging\n");
+                exit(1);
+            }
         }
-        ocp_qp_gpu_batch_set_bulk_out(b, m->blob_out, 0);
     }
-    ocp_qp_gpu_batch_set_bulk(b, m->blob_in, 0);
+    m->group = NULL; /* this memory's QP lives in its own batch from now on */
+
+    const int ws = o->warm_start >= 2 ? o->warm_start : 0; /* 1 = 0, acados_ocp_options.py:1029-1031 */
+    memset(bk->blob_in, 0, sizeof(double) * (size_t) bk->L_in);
+    unpack_qp_in(bk, in, bk->blob_in);
+    if (ws >= 2) unpack_qp_out_duals(bk, out, bk->blob_out);
     const double t_packed = now_s();
 
-    ocp_qp_gpu_batch_solve(b);
+    bucket_solve(bk, o, ws);
     const double t_solved = now_s();
 
-    /* solution -> qp_out (BLASFEO vectors); lam, t ordered [lb lg ub ug ls us] as HPIPM's */
-    ocp_qp_gpu_batch_get_bulk(b, m->blob_out, 0);
-    for (int k = 0; k <= N; k++)
-    {
-        const int nu = d->nu[k], nx = d->nx[k], ns = d->ns[k];
-        int len = 0, off;
-        if ((off = ocp_qp_gpu_batch_bulk_offset(b, 1, "u", k, &len)) >= 0) blasfeo_pack_dvec(len, m->blob_out + off, 1, out->ux + k, 0);
-        if ((off = ocp_qp_gpu_batch_bulk_offset(b, 1, "x", k, &len)) >= 0) blasfeo_pack_dvec(len, m->blob_out + off, 1, out->ux + k, nu);
-        if ((off = ocp_qp_gpu_batch_bulk_offset(b, 1, "sl", k, &len)) >= 0) blasfeo_pack_dvec(len, m->blob_out + off, 1, out->ux + k, nu + nx);
-        if ((off = ocp_qp_gpu_batch_bulk_offset(b, 1, "su", k, &len)) >= 0) blasfeo_pack_dvec(len, m->blob_out + off, 1, out->ux + k, nu + nx + ns);
-        if (k < N && (off = ocp_qp_gpu_batch_bulk_offset(b, 1, "pi", k, &len)) >= 0) blasfeo_pack_dvec(len, m->blob_out + off, 1, out->pi + k, 0);
-        if ((off = ocp_qp_gpu_batch_bulk_offset(b, 1, "lam", k, &len)) >= 0) blasfeo_pack_dvec(len, m->blob_out + off, 1, out->lam + k, 0);
-        if ((off = ocp_qp_gpu_batch_bulk_offset(b, 1, "t", k, &len)) >= 0) blasfeo_pack_dvec(len, m->blob_out + off, 1, out->t + k, 0);
-    }
-    int st = 0, it = 0;
-    ocp_qp_gpu_batch_get_info(b, "status", &st);
-    ocp_qp_gpu_batch_get_info(b, "iter", &it);
+    pack_qp_out(bk, bk->blob_out, out);
     const double t_end = now_s();
     if (info)
     {
-        info->solve_QP_time = ocp_qp_gpu_batch_get_scalar(b, "time_tot");
+        info->solve_QP_time = ocp_qp_gpu_batch_get_scalar(bk->batch, "time_tot");
         info->condensing_time = 0.0;
         info->interface_time = (t_packed - t_start) + (t_end - t_solved);
         info->total_time = t_end - t_start;
-        info->num_iter = it;
+        info->num_iter = bk->it[0];
         info->t_computed = 1; /* t comes from the device (ocp_qp_compute_t restated there for the rows the IPM skipped) */
     }
-    m->iter = it; m->status = st; m->time_qp_solver_call = t_solved - t_packed;
-    return st; /* already return_values_t (acados/utils/types.h:74-87) */
+    m->iter = bk->it[0]; m->status = bk->st[0]; m->time_qp_solver_call = t_solved - t_packed;
+    return bk->st[0]; /* already return_values_t (acados/utils/types.h:74-87) */
 }
+
+/* ------------------------------------------------------------------ the batch entries */
+
+static void bucket_release(gpu_bucket *bk)
+{
+    if (bk->batch) ocp_qp_gpu_batch_destroy(bk->batch);
+    ocp_qp_gpu_host_free(bk->blob_in); ocp_qp_gpu_host_free(bk->blob_out);
+    free(bk->sig); free(bk->seg_in); free(bk->seg_out); free(bk->seg_seed); free(bk->members); free(bk->st); free(bk->it);
+    memset(bk, 0, sizeof(*bk));
+}
+
+static void group_release(gpu_group *g)
+{
+    if (!g) return;
+    for (int q = 0; q < g->nbk; q++) bucket_release(g->bk + q);
+    free(g->bk); free(g->bucket_of); free(g->pos_of); free(g->scratch);
+    free(g);
+}
+
+static void *xcalloc(size_t cnt, size_t sz)
+{
+    void *p = calloc(cnt ? cnt : 1, sz);
+    if (!p) { printf("\nerror: ocp_qp_gpu_ipm: out of host memory\n"); exit(1); }
+    return p;
+}
+
+/* group of the n QPs of this call: reused as long as n and every QP's structure are what they were, else rebuilt --
+ * QPs are bucketed by structure signature, one device batch per bucket */
+static gpu_group *group_for(int n, ocp_qp_in **ins, ocp_qp_gpu_ipm_memory **mems)
+{
+    ocp_qp_gpu_ipm_memory *m0 = mems[0];
+    gpu_group *g = m0->group && m0->group->owner == m0 ? m0->group : NULL;
+    int need = 0;
+    for (int i = 0; i < n; i++) { const int l = sig_len(ins[i]->dim); if (l > need) need = l; }
+    if (g && g->n == n)
+    {
+        int same = g->scratch_cap >= need;
+        for (int i = 0; i < n && same; i++)
+        {
+            const gpu_bucket *bk = g->bk + g->bucket_of[i];
+            same = sig_len(ins[i]->dim) == bk->sig_len && fill_sig(ins[i], g->scratch) == bk->sig_len
+                   && memcmp(bk->sig, g->scratch, sizeof(int) * bk->sig_len) == 0;
+        }
+        if (same) return g;
+    }
+    group_release(g);
+    g = (gpu_group *) xcalloc(1, sizeof(gpu_group));
+    g->owner = m0; g->n = n;
+    g->bucket_of = (int *) xcalloc(n, sizeof(int)); g->pos_of = (int *) xcalloc(n, sizeof(int));
+    g->scratch = (int *) xcalloc(need, sizeof(int)); g->scratch_cap = need;
+    int cap_bk = 4;
+    g->bk = (gpu_bucket *) xcalloc(cap_bk, sizeof(gpu_bucket));
+    for (int i = 0; i < n; i++)
+    {
+        const int len = fill_sig(ins[i], g->scratch);
+        int q = 0;
+        for (; q < g->nbk; q++)
+            if (g->bk[q].sig_len == len && memcmp(g->bk[q].sig, g->scratch, sizeof(int) * len) == 0) break;
+        if (q == g->nbk)
+        {
+            if (g->nbk == cap_bk)
+            {
+                cap_bk *= 2;
+                g->bk = (gpu_bucket *) realloc(g->bk, sizeof(gpu_bucket) * cap_bk);
+                if (!g->bk) { printf("\nerror: ocp_qp_gpu_ipm: out of host memory\n"); exit(1); }
+                memset(g->bk + g->nbk, 0, sizeof(gpu_bucket) * (cap_bk - g->nbk));
+            }
+            gpu_bucket *bk = g->bk + g->nbk++;
+            bk->sig = (int *) xcalloc(len, sizeof(int)); bk->sig_cap = len; bk->sig_len = len;
+            memcpy(bk->sig, g->scratch, sizeof(int) * len);
+            bk->members = (int *) xcalloc(n, sizeof(int));
+        }
+        gpu_bucket *bk = g->bk + q;
+        g->bucket_of[i] = q; g->pos_of[i] = bk->n;
+        bk->members[bk->n++] = i;
+    }
+    for (int q = 0; q < g->nbk; q++)
+    {
+        gpu_bucket *bk = g->bk + q;
+        const ocp_qp_in *in0 = ins[bk->members[0]];
+        const int nst = in0->dim->N + 1;
+        bk->seg_cap_in = nst * SEGS_IN_PER_STAGE; bk->seg_cap_out = nst * SEGS_OUT_PER_STAGE; bk->seg_cap_seed = nst * SEGS_SEED_PER_STAGE;
+        bk->seg_in = (gpu_seg *) xcalloc(bk->seg_cap_in, sizeof(gpu_seg));
+        bk->seg_out = (gpu_seg *) xcalloc(bk->seg_cap_out, sizeof(gpu_seg));
+        bk->seg_seed = (gpu_seg *) xcalloc(bk->seg_cap_seed, sizeof(gpu_seg));
+        bk->st = (int *) xcalloc(bk->n, sizeof(int)); bk->it = (int *) xcalloc(bk->n, sizeof(int));
+        memcpy(g->scratch, bk->sig, sizeof(int) * bk->sig_len);
+        bucket_build(bk, in0, g->scratch, bk->sig_len);
+        /* pinned staging: the input blob also stages the seeds (never longer than the QP data) */
+        int per = bk->L_in > bk->L_seed ? bk->L_in : bk->L_seed;
+        for (int k = 0; k < nst; k++) /* solver_get stages ric_L and ric_l of the whole bucket */
+        {
+            const int nv = in0->dim->nu[k] + in0->dim->nx[k];
+            if (nv * (nv + 1) > per) per = nv * (nv + 1);
+        }
+        bk->cap_in = (size_t) bk->n * (size_t) per;
+        bk->cap_out = (size_t) bk->n * (size_t) bk->L_out;
+        bk->blob_in = (double *) ocp_qp_gpu_host_alloc(sizeof(double) * bk->cap_in);
+        bk->blob_out = (double *) ocp_qp_gpu_host_alloc(sizeof(double) * bk->cap_out);
+        if (!bk->blob_in || !bk->blob_out) exit(1);
+    }
+    m0->group = g;
+    return g;
+}
+
+/*
+ * n QPs in acados structs -> one device batch per structure class.  `mem[i]` is the qp solver memory of capsule i (each
+ * from this plugin's memory_assign); afterwards memory_get(mem[i], "status" / "iter" / "time_qp_solver_call") and
+ * qp_out[i]->misc answer for QP i exactly as after a single evaluate, and the sensitivity / solver_get slots called with
+ * mem[i] address instance i of the shared batch.  Returns the worst status (0, else the first that is not MAXITER).
+ */
+int ocp_qp_gpu_ipm_acados_evaluate_batch(void *config, int n, void **qp_in_, void **qp_out_, void *opts_, void **mem_, void *work)
+{
+    if (n <= 0) return ACADOS_SUCCESS;
+    const double t_start = now_s();
+    ocp_qp_in **ins = (ocp_qp_in **) qp_in_;
+    ocp_qp_out **outs = (ocp_qp_out **) qp_out_;
+    ocp_qp_gpu_ipm_memory **mems = (ocp_qp_gpu_ipm_memory **) mem_;
+    ocp_qp_gpu_ipm_opts *o = (ocp_qp_gpu_ipm_opts *) opts_;
+    gpu_group *g = group_for(n, ins, mems);
+    const int ws = o->warm_start >= 2 ? o->warm_start : 0;
+
+    /* host threads: every member array of every qp_in, panel-major -> the bucket's pinned blob */
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; i++)
+    {
+        const gpu_bucket *bk = g->bk + g->bucket_of[i];
+        double *blob = bk->blob_in + (size_t) g->pos_of[i] * (size_t) bk->L_in;
+        memset(blob, 0, sizeof(double) * (size_t) bk->L_in);
+        unpack_qp_in(bk, ins[i], blob);
+        if (ws >= 2) unpack_qp_out_duals(bk, outs[i], bk->blob_out + (size_t) g->pos_of[i] * (size_t) bk->L_out);
+    }
+    const double t_packed = now_s();
+
+    /* one copy + one scatter launch, the solve, one gather launch + one copy per bucket; buckets run side by side
+     * (each device batch has its own stream) */
+#pragma omp parallel for schedule(dynamic, 1) if (g->nbk > 1)
+    for (int q = 0; q < g->nbk; q++) bucket_solve(g->bk + q, o, ws);
+    const double t_solved = now_s();
+
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; i++)
+    {
+        const gpu_bucket *bk = g->bk + g->bucket_of[i];
+        pack_qp_out(bk, bk->blob_out + (size_t) g->pos_of[i] * (size_t) bk->L_out, outs[i]);
+    }
+    const double t_end = now_s();
+
+    int worst = 0;
+    for (int i = 0; i < n; i++)
+    {
+        const gpu_bucket *bk = g->bk + g->bucket_of[i];
+        const int st = bk->st[g->pos_of[i]], it = bk->it[g->pos_of[i]];
+        qp_info *info = (qp_info *) outs[i]->misc;
+        if (info)
+        {
+            info->solve_QP_time = ocp_qp_gpu_batch_get_scalar(bk->batch, "time_tot"); /* of the whole bucket */
+            info->condensing_time = 0.0;
+            info->interface_time = (t_packed - t_start) + (t_end - t_solved);
+            info->total_time = t_end - t_start;
+            info->num_iter = it;
+            info->t_computed = 1;
+        }
+        ocp_qp_gpu_ipm_memory *mi = mems[i];
+        mi->group = g; mi->g_bucket = g->bucket_of[i]; mi->g_pos = g->pos_of[i];
+        mi->iter = it; mi->status = st; mi->time_qp_solver_call = t_solved - t_packed;
+        if (st != ACADOS_SUCCESS && (worst == 0 || worst == ACADOS_MAXITER)) worst = st;
+    }
+    return worst;
+}
+
+/* where the QP of this memory was solved last */
+static gpu_bucket *bucket_of_mem(ocp_qp_gpu_ipm_memory *m, int *pos)
+{
+    if (m->group) { *pos = m->g_pos; return m->group->bk + m->g_bucket; }
+    *pos = 0;
+    return &m->own;
+}
+
+/* ------------------------------------------------------------------ getters, sensitivities */
 
 static void gpu_solver_get(void *config_, void *qp_in_, void *qp_out_, void *opts_, void *mem_, const char *field, int stage,
                            void *value, int size1, int size2)
@@ -375,10 +721,14 @@ static void gpu_solver_get(void *config_, void *qp_in_, void *qp_out_, void *opt
     ocp_qp_gpu_ipm_memory *m = (ocp_qp_gpu_ipm_memory *) mem_;
     const int nx = in->dim->nx[stage], nu = in->dim->nu[stage], nv = nu + nx;
     double *out = (double *) value;
-    if (!m->batch) { printf("\nocp_qp_gpu_ipm_solver_get: no factorisation available (solve first)\n"); exit(1); }
-    double *L = m->blob_in, *l = m->blob_in + nv * nv; /* staging is idle between evaluates: (nu+nx)^2 + nu+nx fit */
-    ocp_qp_gpu_batch_get(m->batch, "ric_L", stage, L, 0);
-    ocp_qp_gpu_batch_get(m->batch, "ric_l", stage, l, 0);
+    int pos = 0;
+    gpu_bucket *bk = bucket_of_mem(m, &pos);
+    if (!bk->batch) { printf("\nocp_qp_gpu_ipm_solver_get: no factorisation available (solve first)\n"); exit(1); }
+    /* staging is idle between evaluates: n * ((nu+nx)^2 + nu+nx) fit (blob_in_cap) */
+    double *Lb = bk->blob_in, *lb = bk->blob_in + (size_t) bk->n * nv * nv;
+    ocp_qp_gpu_batch_get(bk->batch, "ric_L", stage, Lb, 0);
+    ocp_qp_gpu_batch_get(bk->batch, "ric_l", stage, lb, 0);
+    const double *L = Lb + (size_t) pos * nv * nv, *l = lb + (size_t) pos * nv;
     if (!strcmp(field, "P"))
         for (int c = 0; c < nx; c++) for (int r = 0; r < nx; r++)
         {
@@ -413,17 +763,73 @@ static void gpu_solver_get(void *config_, void *qp_in_, void *qp_out_, void *opt
 static void gpu_memory_reset(void *config, void *qp_in, void *qp_out, void *opts, void *mem_, void *work)
 {
     ocp_qp_gpu_ipm_memory *m = (ocp_qp_gpu_ipm_memory *) mem_;
-    if (m->batch) ocp_qp_gpu_batch_destroy(m->batch);
-    m->batch = NULL;
-    m->sig_len = 0;
+    if (m->own.batch) ocp_qp_gpu_batch_destroy(m->own.batch);
+    m->own.batch = NULL;
+    m->own.sig_len = 0;
+    if (m->group && m->group->owner == m) group_release(m->group); /* the other members' pointers dangle: a batch is torn down as a whole */
+    m->group = NULL;
 }
 
-static void gpu_eval_sens(void *config, void *qp_in, void *seed, void *qp_out, void *opts, void *mem, void *work)
+/*
+ * ocp_qp_hpipm.c:481-506 -> d_ocp_qp_ipm_sens_frw / _sens_adj: d(solution)/d(parameter) for the seed = derivative of the
+ * problem data, with the factorisation at the solution.  `seed` is HPIPM's d_ocp_qp_seed (BLASFEO vectors seed_g /
+ * seed_b / seed_d laid out like rqz / b / d); the result lands in sens_qp_out (ux, pi, lam, t -- what
+ * ocp_nlp_common.c:4095-4104 copies).  The KKT matrix of the Newton system is symmetric, so the adjoint solve of a seed
+ * is the forward solve of the same seed (acados seeds only seed_g there and reads ux, pi: ocp_nlp_common.c:4128-4160).
+ */
+static void bucket_sens(gpu_bucket *bk)
 {
-    /* d_ocp_qp_seed holds BLASFEO vectors seed_g / seed_b / seed_d laid out like rqz / b / d: unpack them as above and
-     * hand them to ocp_qp_gpu_batch_sens_set / _sens_solve (ocp_qp_gpu_batch.h); not part of the mock-build test */
-    printf("\nerror: ocp_qp_gpu_ipm: eval_forw_sens / eval_adj_sens through the acados adapter: bind ocp_qp_gpu_batch_sens_*\n");
-    exit(1);
+    if (ocp_qp_gpu_batch_sens_set_bulk(bk->batch, bk->blob_in, 0) != 0 || ocp_qp_gpu_batch_sens_solve(bk->batch) != 0
+        || ocp_qp_gpu_batch_sens_get_bulk(bk->batch, bk->blob_out, 0) != 0)
+    {
+        printf("\nerror: ocp_qp_gpu_ipm: sensitivity solve failed\n");
+        exit(1);
+    }
+}
+
+static void gpu_eval_sens(void *config, void *qp_in, void *seed_, void *sens_qp_out_, void *opts, void *mem_, void *work)
+{
+    ocp_qp_gpu_ipm_memory *m = (ocp_qp_gpu_ipm_memory *) mem_;
+    int pos = 0;
+    gpu_bucket *bk = bucket_of_mem(m, &pos);
+    if (!bk->batch) { printf("\nerror: ocp_qp_gpu_ipm: eval_forw_sens / eval_adj_sens before the first evaluate\n"); exit(1); }
+    /* the seed belongs to this memory's instance; the other instances of a shared batch get zero seeds */
+    memset(bk->blob_in, 0, sizeof(double) * (size_t) bk->n * (size_t) bk->L_seed);
+    unpack_seed(bk, (ocp_qp_seed *) seed_, bk->blob_in + (size_t) pos * (size_t) bk->L_seed);
+    bucket_sens(bk);
+    pack_qp_out(bk, bk->blob_out + (size_t) pos * (size_t) bk->L_out, (ocp_qp_out *) sens_qp_out_);
+}
+
+/* the same for all n capsules of the last ocp_qp_gpu_ipm_acados_evaluate_batch at once: one seed each, one device pass
+ * per structure class (replaces the loops of acados_solver.in.c:3292-3337) */
+void ocp_qp_gpu_ipm_acados_eval_sens_batch(void *config, int n, void **qp_in, void **seed_, void **sens_qp_out_, void *opts, void **mem_, void *work)
+{
+    if (n <= 0) return;
+    ocp_qp_gpu_ipm_memory **mems = (ocp_qp_gpu_ipm_memory **) mem_;
+    gpu_group *g = mems[0]->group;
+    int ok = g != NULL && g->n == n;
+    for (int i = 0; i < n && ok; i++) ok = mems[i]->group == g;
+    if (!ok)
+    {
+        printf("\nerror: ocp_qp_gpu_ipm_acados_eval_sens_batch: the %d memories are not those of the last evaluate_batch\n", n);
+        exit(1);
+    }
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; i++)
+    {
+        const gpu_bucket *bk = g->bk + mems[i]->g_bucket;
+        double *blob = bk->blob_in + (size_t) mems[i]->g_pos * (size_t) bk->L_seed;
+        memset(blob, 0, sizeof(double) * (size_t) bk->L_seed);
+        unpack_seed(bk, (ocp_qp_seed *) seed_[i], blob);
+    }
+#pragma omp parallel for schedule(dynamic, 1) if (g->nbk > 1)
+    for (int q = 0; q < g->nbk; q++) bucket_sens(g->bk + q);
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; i++)
+    {
+        const gpu_bucket *bk = g->bk + mems[i]->g_bucket;
+        pack_qp_out(bk, bk->blob_out + (size_t) mems[i]->g_pos * (size_t) bk->L_out, (ocp_qp_out *) sens_qp_out_[i]);
+    }
 }
 
 static void gpu_terminate(void *config, void *mem, void *work) { gpu_memory_reset(config, NULL, NULL, NULL, mem, work); }

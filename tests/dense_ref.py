@@ -186,7 +186,7 @@ def sens_dense(qp, get, seeds):
         [ 0    0     T     L ] [dt  ]   [ 0   ]          T = diag(t), L = diag(lam)
 
     over the inequality sides that take part (mask != 0, not equality-flagged).  seeds: {(field, k): vector}, field in
-    q r b lbu ubu lbx ubx lg ug (natural-sign bounds; an equality-flagged row takes its lbx seed).  Returns a function
+    q r zl zu b lbu ubu lbx ubx lg ug lls lus (natural-sign bounds; an equality-flagged row takes its lbx seed).  Returns a function
     (k, field) -> array for x u sl su pi lam t, lam/t zero on sides that do not take part."""
     N, d = qp.N, qp.dims
     off, nw = [], 0
@@ -207,6 +207,8 @@ def sens_dense(qp, get, seeds):
             H[o + nu + nx + ns + j, o + nu + nx + ns + j] = qp.Zu[k][j]
         dg[o:o + nu] = sd("r", k, nu)
         dg[o + nu:o + nu + nx] = sd("q", k, nx)
+        dg[o + nu + nx:o + nu + nx + ns] = sd("zl", k, ns)
+        dg[o + nu + nx + ns:o + nu + nx + 2 * ns] = sd("zu", k, ns)
         if k < N:
             nx1 = int(d.nx[k + 1])
             row = np.zeros((nx1, nw))
@@ -241,7 +243,7 @@ def sens_dense(qp, get, seeds):
                     r = np.zeros(nw)
                     r[o + nu + nx + side * ns + j] = 1.0
                     e = 2 * nbg + side * ns + j
-                    in_rows.append(r); in_rhs.append(0.0); in_tag.append((k, e, lam[e], t[e]))
+                    in_rows.append(r); in_rhs.append(sd("lls" if side == 0 else "lus", k, ns)[j]); in_tag.append((k, e, lam[e], t[e]))
     Aeq = np.array(eq_rows).reshape(len(eq_rows), nw)
     Ain = np.array(in_rows).reshape(len(in_rows), nw)
     ne, ni = Aeq.shape[0], Ain.shape[0]

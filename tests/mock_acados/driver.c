@@ -1,145 +1,134 @@
 /*
  * TEST INFRASTRUCTURE ONLY -- drives integration/ocp_qp_gpu_ipm.c the way acados drives an inner QP plugin, on QP
- * data held in (mock) HPIPM / BLASFEO storage.
+ * data held in (mock) HPIPM / BLASFEO storage (tests/mock_acados/qp_loader.h packs it the way acados' setters do and
+ * poisons everything a plugin must not read).
  *
- *   driver <qp.txt> <out.txt> [repeat]
+ *   driver <qp.txt> <out.txt> [repeat | sens]
+ *       one capsule through the 17 slots in acados' order (sizes -> assign -> defaults -> opts_set -> evaluate;
+ *       ocp_qp_interface.c:513-563).  `repeat`: ONLY the vectors b / rqz change between two evaluates (what ocp_nlp does
+ *       every SQP iteration), the second solution is written.  `sens`: after the solve a seed built acados' way
+ *       (ocp_nlp_common.c:4057-4081) goes through eval_forw_sens; solution, then "sens" lines, are written.
  *
- * qp.txt (written by tests/test_mock_acados.py from an AcadosOcpQp): "N", then per stage "dims k nx nu nbx nbu ng ns nbxe",
- * then lines "<field> <k> <n> v0 v1 ..." with column-major matrices and natural-sign bounds.  The driver packs them the
- * way acados' setters do -- BAbt = [B'; A'; b'], RSQrq lower triangle + [r' q'] row, DCt = [D'; C'],
- * d = [lb; lg; -ub; -ug; ls; us], rqz = [r; q; zl; zu] (print.c:220-429, ocp_qp_common.c:897-906) -- in panel-major
- * storage, POISONS what a plugin must not read (last rows of BAbt / RSQrq, strict upper triangle of RSQrq), calls the 17
- * slots in acados' order (sizes -> assign -> defaults -> opts_set -> evaluate; ocp_qp_interface.c:513-563) and writes the
- * solution.  With `repeat` it changes ONLY the vectors b / rqz / d between two evaluates (what ocp_nlp does every SQP
- * iteration) and writes the second solution.
+ *   driver batch <n> <qpA.txt> <qpB.txt|-> <out.bin> [sens] [reps]
+ *       n capsules (instance i = base QP A, or B for odd i when given, with the vectors perturbed by mock_perturb(i)),
+ *       one memory each, solved by ONE call of ocp_qp_gpu_ipm_acados_evaluate_batch -- the replacement of the per-capsule
+ *       loop of acados_solver.in.c:3222-3243; with `sens` followed by ocp_qp_gpu_ipm_acados_eval_sens_batch on per-instance
+ *       seeds.  out.bin: per instance the solution (and then the sensitivities) as raw doubles
+ *       [ux_0..ux_N, pi_0..pi_{N-1}, lam_0..lam_N, t_0..t_N]; stdout: one line "batch n .. ms_per_call .. status ..",
+ *       then per instance "i status iter".
  */
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
-#include "acados/ocp_qp/ocp_qp_common.h"
+#include "qp_loader.h"
 
 void ocp_qp_gpu_ipm_acados_config_initialize_default(void *config_);
+int ocp_qp_gpu_ipm_acados_evaluate_batch(void *config, int n, void **qp_in, void **qp_out, void *opts, void **mem, void *work);
+void ocp_qp_gpu_ipm_acados_eval_sens_batch(void *config, int n, void **qp_in, void **seed, void **sens_qp_out, void *opts, void **mem, void *work);
 
-#define MAXN 128
-static int N;
-static struct d_ocp_qp_dim dim;
-static struct d_ocp_qp qp;
-static struct d_ocp_qp_sol sol;
-static qp_info info;
-
-static double *readvec(FILE *f, int n)
+static double now_s(void)
 {
-    double *v = (double *) calloc(n > 0 ? n : 1, sizeof(double));
-    for (int i = 0; i < n; i++) if (fscanf(f, "%lf", v + i) != 1) { fprintf(stderr, "driver: short vector\n"); exit(2); }
-    return v;
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double) ts.tv_sec + 1e-9 * (double) ts.tv_nsec;
+}
+
+static void *make_opts(qp_solver_config *config, struct d_ocp_qp_dim *dim)
+{
+    void *opts = config->opts_assign(config, dim, calloc(1, config->opts_calculate_size(config, dim)));
+    config->opts_initialize_default(config, dim, opts);
+    double tol = 1e-8;
+    int itmax = 50, pl = 0, ws = 0;
+    config->opts_set(config, opts, "tol_stat", &tol); config->opts_set(config, opts, "tol_eq", &tol);
+    config->opts_set(config, opts, "tol_ineq", &tol); config->opts_set(config, opts, "tol_comp", &tol);
+    config->opts_set(config, opts, "iter_max", &itmax); config->opts_set(config, opts, "print_level", &pl);
+    config->opts_set(config, opts, "warm_start", &ws);
+    config->opts_update(config, dim, opts);
+    return opts;
+}
+
+static int run_batch(int argc, char **argv)
+{
+    if (argc < 6) return 2;
+    const int n = atoi(argv[2]);
+    const int two = strcmp(argv[4], "-") != 0;
+    int do_sens = 0, reps = 1;
+    for (int a = 6; a < argc; a++) { if (!strcmp(argv[a], "sens")) do_sens = 1; else reps = atoi(argv[a]); }
+    qp_solver_config config;
+    memset(&config, 0, sizeof(config));
+    ocp_qp_gpu_ipm_acados_config_initialize_default(&config);
+
+    mock_capsule **caps = calloc(n, sizeof(*caps));
+    void **ins = calloc(n, sizeof(void *)), **outs = calloc(n, sizeof(void *)), **mems = calloc(n, sizeof(void *));
+    void **seeds = calloc(n, sizeof(void *)), **sens = calloc(n, sizeof(void *));
+    for (int i = 0; i < n; i++)
+    {
+        caps[i] = mock_load_qp(argv[two && (i & 1) ? 4 : 3]);
+        mock_perturb(caps[i], i);
+        ins[i] = &caps[i]->qp; outs[i] = &caps[i]->sol; seeds[i] = &caps[i]->seed; sens[i] = &caps[i]->sens;
+    }
+    void *opts = make_opts(&config, &caps[0]->dim);
+    for (int i = 0; i < n; i++)
+        mems[i] = config.memory_assign(&config, &caps[i]->dim, opts, calloc(1, config.memory_calculate_size(&config, &caps[i]->dim, opts)));
+
+    int status = ocp_qp_gpu_ipm_acados_evaluate_batch(&config, n, ins, outs, opts, mems, NULL); /* builds the device batches */
+    double best = 1e30;
+    for (int r = 0; r < reps; r++)
+    {
+        const double t0 = now_s();
+        status = ocp_qp_gpu_ipm_acados_evaluate_batch(&config, n, ins, outs, opts, mems, NULL);
+        const double dt = now_s() - t0;
+        if (dt < best) best = dt;
+    }
+    double sens_s = 0.0;
+    if (do_sens)
+    {
+        for (int i = 0; i < n; i++) mock_fill_seed(caps[i], i);
+        const double t0 = now_s();
+        ocp_qp_gpu_ipm_acados_eval_sens_batch(&config, n, ins, seeds, sens, opts, mems, NULL);
+        sens_s = now_s() - t0;
+    }
+    printf("batch n %d ms_per_call %.3f status %d interface_ms %.3f solve_ms %.3f sens_ms %.3f\n", n, best * 1e3, status,
+           caps[0]->info.interface_time * 1e3, caps[0]->info.solve_QP_time * 1e3, sens_s * 1e3);
+    FILE *g = fopen(argv[5], "wb");
+    for (int i = 0; i < n; i++)
+    {
+        int iter = -1, st = -1;
+        config.memory_get(&config, mems[i], "iter", &iter);
+        config.memory_get(&config, mems[i], "status", &st);
+        printf("%d %d %d %d %d\n", i, st, iter, caps[i]->info.num_iter, caps[i]->info.t_computed);
+        mock_write_sol_bin(g, &caps[i]->dim, &caps[i]->sol);
+        if (do_sens) mock_write_sol_bin(g, &caps[i]->dim, &caps[i]->sens);
+    }
+    fclose(g);
+    /* a single-capsule slot after a batch call: the sensitivity of capsule n-1 alone through its own memory must equal
+     * its share of the batched call */
+    if (do_sens)
+    {
+        mock_capsule *c = caps[n - 1];
+        struct d_ocp_qp_sol chk;
+        mock_alloc_sol(&c->dim, &chk);
+        config.eval_forw_sens(&config, &c->qp, &c->seed, &chk, opts, mems[n - 1], NULL);
+        double worst = 0.0;
+        for (int s = 0; s <= c->dim.N; s++)
+            for (int e = 0; e < c->dim.nu[s] + c->dim.nx[s]; e++)
+                worst = fmax(worst, fabs(BLASFEO_DVECEL(chk.ux + s, e) - BLASFEO_DVECEL(c->sens.ux + s, e)));
+        printf("single_vs_batch_sens %.3e\n", worst);
+    }
+    config.terminate(&config, mems[0], NULL);
+    return 0;
 }
 
 int main(int argc, char **argv)
 {
+    if (argc >= 2 && !strcmp(argv[1], "batch")) return run_batch(argc, argv);
     if (argc < 3) return 2;
-    FILE *f = fopen(argv[1], "r");
-    if (!f || fscanf(f, "%d", &N) != 1) return 2;
-    int *arr[10];
-    for (int q = 0; q < 10; q++) arr[q] = (int *) calloc(N + 1, sizeof(int));
-    dim.nx = arr[0]; dim.nu = arr[1]; dim.nb = arr[2]; dim.nbx = arr[3]; dim.nbu = arr[4]; dim.ng = arr[5]; dim.ns = arr[6];
-    dim.nbxe = arr[7]; dim.nbue = arr[8]; dim.nge = arr[9]; dim.N = N;
-    qp.dim = &dim; sol.dim = &dim;
-    qp.BAbt = calloc(N + 1, sizeof(struct blasfeo_dmat)); qp.RSQrq = calloc(N + 1, sizeof(struct blasfeo_dmat));
-    qp.DCt = calloc(N + 1, sizeof(struct blasfeo_dmat));
-    qp.b = calloc(N + 1, sizeof(struct blasfeo_dvec)); qp.rqz = calloc(N + 1, sizeof(struct blasfeo_dvec));
-    qp.d = calloc(N + 1, sizeof(struct blasfeo_dvec)); qp.d_mask = calloc(N + 1, sizeof(struct blasfeo_dvec));
-    qp.m = calloc(N + 1, sizeof(struct blasfeo_dvec)); qp.Z = calloc(N + 1, sizeof(struct blasfeo_dvec));
-    qp.idxb = calloc(N + 1, sizeof(int *)); qp.idxs_rev = calloc(N + 1, sizeof(int *)); qp.idxe = calloc(N + 1, sizeof(int *));
-    qp.diag_H_flag = calloc(N + 1, sizeof(int));
-    sol.ux = calloc(N + 1, sizeof(struct blasfeo_dvec)); sol.pi = calloc(N + 1, sizeof(struct blasfeo_dvec));
-    sol.lam = calloc(N + 1, sizeof(struct blasfeo_dvec)); sol.t = calloc(N + 1, sizeof(struct blasfeo_dvec));
-    sol.misc = &info;
-
-    char field[64];
-    int k, n;
-    int allocated = 0;
-    while (fscanf(f, "%63s %d", field, &k) == 2)
-    {
-        if (!strcmp(field, "dims"))
-        {
-            if (fscanf(f, "%d %d %d %d %d %d %d", &dim.nx[k], &dim.nu[k], &dim.nbx[k], &dim.nbu[k], &dim.ng[k], &dim.ns[k], &dim.nbxe[k]) != 7) return 2;
-            dim.nb[k] = dim.nbx[k] + dim.nbu[k];
-            continue;
-        }
-        if (!allocated)
-        {
-            for (int s = 0; s <= N; s++)
-            {
-                const int nu = dim.nu[s], nx = dim.nx[s], nx1 = s < N ? dim.nx[s + 1] : 0, nb = dim.nb[s], ng = dim.ng[s], ns = dim.ns[s];
-                const int nct = 2 * (nb + ng + ns);
-                blasfeo_allocate_dmat(nu + nx + 1, nx1, qp.BAbt + s);
-                blasfeo_allocate_dmat(nu + nx + 1, nu + nx, qp.RSQrq + s);
-                blasfeo_allocate_dmat(nu + nx, ng, qp.DCt + s);
-                blasfeo_allocate_dvec(nx1, qp.b + s); blasfeo_allocate_dvec(nu + nx + 2 * ns, qp.rqz + s);
-                blasfeo_allocate_dvec(nct, qp.d + s); blasfeo_allocate_dvec(nct, qp.d_mask + s); blasfeo_allocate_dvec(nct, qp.m + s);
-                blasfeo_allocate_dvec(2 * ns, qp.Z + s);
-                blasfeo_dvecse(nct, 1.0, qp.d_mask + s, 0);
-                qp.idxb[s] = calloc(nb + 1, sizeof(int)); qp.idxs_rev[s] = calloc(nb + ng + 1, sizeof(int)); qp.idxe[s] = calloc(nb + 1, sizeof(int));
-                for (int e = 0; e < dim.nbu[s]; e++) qp.idxb[s][e] = e;
-                for (int e = 0; e < dim.nbx[s]; e++) qp.idxb[s][dim.nbu[s] + e] = nu + e;
-                for (int e = 0; e < nb + ng; e++) qp.idxs_rev[s][e] = -1;
-                blasfeo_allocate_dvec(nu + nx + 2 * ns, sol.ux + s); blasfeo_allocate_dvec(nx1, sol.pi + s);
-                blasfeo_allocate_dvec(nct, sol.lam + s); blasfeo_allocate_dvec(nct, sol.t + s);
-                /* what a plugin must NOT read: last rows of BAbt / RSQrq and the strict upper triangle of RSQrq */
-                for (int c = 0; c < nx1; c++) BLASFEO_DMATEL(qp.BAbt + s, nu + nx, c) = 1e30;
-                for (int c = 0; c < nu + nx; c++)
-                {
-                    BLASFEO_DMATEL(qp.RSQrq + s, nu + nx, c) = -1e30;
-                    for (int r = 0; r < c; r++) BLASFEO_DMATEL(qp.RSQrq + s, r, c) = 7e77;
-                }
-            }
-            allocated = 1;
-        }
-        if (fscanf(f, "%d", &n) != 1) return 2;
-        const int nu = dim.nu[k], nx = dim.nx[k], nx1 = k < N ? dim.nx[k + 1] : 0, nbu = dim.nbu[k], nb = dim.nb[k], ng = dim.ng[k], ns = dim.ns[k];
-        if (!strcmp(field, "idxb") || !strcmp(field, "idxs_rev") || !strcmp(field, "idxe"))
-        {
-            int *dst = !strcmp(field, "idxb") ? qp.idxb[k] : !strcmp(field, "idxs_rev") ? qp.idxs_rev[k] : qp.idxe[k];
-            for (int e = 0; e < n; e++) if (fscanf(f, "%d", dst + e) != 1) return 2;
-            continue;
-        }
-        double *v = readvec(f, n);
-        /* d_ocp_qp_set_* semantics */
-        if (!strcmp(field, "A")) blasfeo_pack_tran_dmat(nx1, nx, v, nx1, qp.BAbt + k, nu, 0);
-        else if (!strcmp(field, "B")) blasfeo_pack_tran_dmat(nx1, nu, v, nx1, qp.BAbt + k, 0, 0);
-        else if (!strcmp(field, "b")) blasfeo_pack_dvec(nx1, v, 1, qp.b + k, 0);
-        else if (!strcmp(field, "Q")) { for (int c = 0; c < nx; c++) for (int r = c; r < nx; r++) BLASFEO_DMATEL(qp.RSQrq + k, nu + r, nu + c) = v[r + nx * c]; }
-        else if (!strcmp(field, "R")) { for (int c = 0; c < nu; c++) for (int r = c; r < nu; r++) BLASFEO_DMATEL(qp.RSQrq + k, r, c) = v[r + nu * c]; }
-        else if (!strcmp(field, "S")) blasfeo_pack_tran_dmat(nu, nx, v, nu, qp.RSQrq + k, nu, 0); /* S (nu x nx) stored as S' in the lower-left block */
-        else if (!strcmp(field, "r")) blasfeo_pack_dvec(nu, v, 1, qp.rqz + k, 0);
-        else if (!strcmp(field, "q")) blasfeo_pack_dvec(nx, v, 1, qp.rqz + k, nu);
-        else if (!strcmp(field, "zl")) blasfeo_pack_dvec(ns, v, 1, qp.rqz + k, nu + nx);
-        else if (!strcmp(field, "zu")) blasfeo_pack_dvec(ns, v, 1, qp.rqz + k, nu + nx + ns);
-        else if (!strcmp(field, "Zl")) blasfeo_pack_dvec(ns, v, 1, qp.Z + k, 0);
-        else if (!strcmp(field, "Zu")) blasfeo_pack_dvec(ns, v, 1, qp.Z + k, ns);
-        else if (!strcmp(field, "C")) blasfeo_pack_tran_dmat(ng, nx, v, ng, qp.DCt + k, nu, 0);
-        else if (!strcmp(field, "D")) blasfeo_pack_tran_dmat(ng, nu, v, ng, qp.DCt + k, 0, 0);
-        else
-        {
-            /* bounds and masks: position in d / d_mask, sign flipped for the upper bounds (ocp_qp_common.c:897-906) */
-            const char *names[] = {"lbu", "lbx", "lg", "ubu", "ubx", "ug", "lls", "lus"};
-            const int off[] = {0, nbu, nb, nb + ng, nb + ng + nbu, 2 * nb + ng, 2 * nb + 2 * ng, 2 * nb + 2 * ng + ns};
-            const double sgn[] = {1, 1, 1, -1, -1, -1, 1, 1};
-            int hit = 0;
-            for (int q = 0; q < 8; q++)
-            {
-                char mname[32];
-                snprintf(mname, sizeof(mname), "%s_mask", names[q]);
-                if (!strcmp(field, names[q])) { for (int e = 0; e < n; e++) BLASFEO_DVECEL(qp.d + k, off[q] + e) = sgn[q] * v[e]; hit = 1; }
-                else if (!strcmp(field, mname)) { for (int e = 0; e < n; e++) BLASFEO_DVECEL(qp.d_mask + k, off[q] + e) = v[e]; hit = 1; }
-            }
-            if (!hit) { fprintf(stderr, "driver: unknown field %s\n", field); return 2; }
-        }
-        free(v);
-    }
-    fclose(f);
+    mock_capsule *c = mock_load_qp(argv[1]);
+    struct d_ocp_qp_dim *dim = &c->dim;
+    const int N = dim->N;
 
     /* ---- the plugin, driven through its 17 slots in acados' order ---- */
     qp_solver_config config;
@@ -147,49 +136,42 @@ int main(int argc, char **argv)
     ocp_qp_gpu_ipm_acados_config_initialize_default(&config);
     void **slots = (void **) &config;
     for (int q = 0; q < 17; q++) if (!slots[q]) { fprintf(stderr, "driver: slot %d empty\n", q); return 3; }
-    void *opts = config.opts_assign(&config, &dim, calloc(1, config.opts_calculate_size(&config, &dim)));
-    config.opts_initialize_default(&config, &dim, opts);
-    double tol = 1e-8;
-    int itmax = 50, pl = 0, ws = 0;
-    config.opts_set(&config, opts, "tol_stat", &tol); config.opts_set(&config, opts, "tol_eq", &tol);
-    config.opts_set(&config, opts, "tol_ineq", &tol); config.opts_set(&config, opts, "tol_comp", &tol);
-    config.opts_set(&config, opts, "iter_max", &itmax); config.opts_set(&config, opts, "print_level", &pl);
-    config.opts_set(&config, opts, "warm_start", &ws);
-    config.opts_update(&config, &dim, opts);
-    void *mem = config.memory_assign(&config, &dim, opts, calloc(1, config.memory_calculate_size(&config, &dim, opts)));
-    void *work = calloc(1, config.workspace_calculate_size(&config, &dim, opts) + 8);
+    void *opts = make_opts(&config, dim);
+    void *mem = config.memory_assign(&config, dim, opts, calloc(1, config.memory_calculate_size(&config, dim, opts)));
+    void *work = calloc(1, config.workspace_calculate_size(&config, dim, opts) + 8);
 
-    int status = config.evaluate(&config, &qp, &sol, opts, mem, work);
-    if (argc > 3)
+    int status = config.evaluate(&config, &c->qp, &c->sol, opts, mem, work);
+    if (argc > 3 && !strcmp(argv[3], "repeat"))
     {
         /* what ocp_nlp changes between two SQP iterations: ONLY the vectors (ocp_nlp_common.c:3119-3138) */
         for (int s = 0; s <= N; s++)
         {
-            for (int e = 0; e < dim.nu[s] + dim.nx[s]; e++) BLASFEO_DVECEL(qp.rqz + s, e) += 0.05 * ((e + s) % 3 - 1);
-            if (s < N) for (int e = 0; e < dim.nx[s + 1]; e++) BLASFEO_DVECEL(qp.b + s, e) += 0.01 * ((e + 2 * s) % 3 - 1);
+            for (int e = 0; e < dim->nu[s] + dim->nx[s]; e++) BLASFEO_DVECEL(c->qp.rqz + s, e) += 0.05 * ((e + s) % 3 - 1);
+            if (s < N) for (int e = 0; e < dim->nx[s + 1]; e++) BLASFEO_DVECEL(c->qp.b + s, e) += 0.01 * ((e + 2 * s) % 3 - 1);
         }
-        status = config.evaluate(&config, &qp, &sol, opts, mem, work);
+        status = config.evaluate(&config, &c->qp, &c->sol, opts, mem, work);
     }
     int iter = -1, st2 = -1;
     config.memory_get(&config, mem, "iter", &iter);
     config.memory_get(&config, mem, "status", &st2);
 
     FILE *g = fopen(argv[2], "w");
-    fprintf(g, "status %d %d iter %d %d t_computed %d\n", status, st2, iter, info.num_iter, info.t_computed);
-    for (int s = 0; s <= N; s++)
-    {
-        const int nv = dim.nu[s] + dim.nx[s] + 2 * dim.ns[s], nx1 = s < N ? dim.nx[s + 1] : 0, nct = 2 * (dim.nb[s] + dim.ng[s] + dim.ns[s]);
-        fprintf(g, "ux %d", s); for (int e = 0; e < nv; e++) fprintf(g, " %.17g", BLASFEO_DVECEL(sol.ux + s, e)); fprintf(g, "\n");
-        fprintf(g, "pi %d", s); for (int e = 0; e < nx1; e++) fprintf(g, " %.17g", BLASFEO_DVECEL(sol.pi + s, e)); fprintf(g, "\n");
-        fprintf(g, "lam %d", s); for (int e = 0; e < nct; e++) fprintf(g, " %.17g", BLASFEO_DVECEL(sol.lam + s, e)); fprintf(g, "\n");
-        fprintf(g, "t %d", s); for (int e = 0; e < nct; e++) fprintf(g, " %.17g", BLASFEO_DVECEL(sol.t + s, e)); fprintf(g, "\n");
-    }
+    fprintf(g, "status %d %d iter %d %d t_computed %d\n", status, st2, iter, c->info.num_iter, c->info.t_computed);
+    mock_write_sol(g, dim, &c->sol);
     /* Riccati gains through the solver_get slot (ocp_nlp_ddp.c:373-377) */
     {
-        const int nu = dim.nu[1], nx = dim.nx[1];
+        const int nu = dim->nu[1], nx = dim->nx[1];
         double *K = calloc(nu * nx + 1, sizeof(double));
-        config.solver_get(&config, &qp, &sol, opts, mem, "K", 1, K, nu, nx);
+        config.solver_get(&config, &c->qp, &c->sol, opts, mem, "K", 1, K, nu, nx);
         fprintf(g, "K 1"); for (int e = 0; e < nu * nx; e++) fprintf(g, " %.17g", K[e]); fprintf(g, "\n");
+    }
+    if (argc > 3 && !strcmp(argv[3], "sens"))
+    {
+        /* ocp_nlp_common_eval_param_sens (ocp_nlp_common.c:4039-4105): zero seed, fill, eval_forw_sens, read ux pi lam */
+        mock_fill_seed(c, 0);
+        config.eval_forw_sens(&config, &c->qp, &c->seed, &c->sens, opts, mem, work);
+        fprintf(g, "sens 0\n");
+        mock_write_sol(g, dim, &c->sens);
     }
     fclose(g);
     config.terminate(&config, mem, work);

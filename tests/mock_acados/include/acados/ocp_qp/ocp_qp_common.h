@@ -9,6 +9,7 @@
 typedef struct d_ocp_qp_dim ocp_qp_dims;
 typedef struct d_ocp_qp ocp_qp_in;
 typedef struct d_ocp_qp_sol ocp_qp_out;
+typedef struct d_ocp_qp_seed ocp_qp_seed;
 
 #ifndef QP_SOLVER_CONFIG_
 #define QP_SOLVER_CONFIG_

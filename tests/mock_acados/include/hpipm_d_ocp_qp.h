@@ -43,4 +43,14 @@ struct d_ocp_qp_sol
     void *misc;                  /* qp_info */
 };
 
+/* seed of a sensitivity solve (hpipm_d_ocp_qp_seed.h): fields acados writes, ocp_nlp_common.c:4057-4081, 4133 */
+struct d_ocp_qp_seed
+{
+    struct d_ocp_qp_dim *dim;
+    struct blasfeo_dvec *seed_g; /* like rqz */
+    struct blasfeo_dvec *seed_b; /* like b */
+    struct blasfeo_dvec *seed_d; /* like d: [lb; lg; -ub; -ug; ls; us] */
+    struct blasfeo_dvec *seed_m;
+};
+
 #endif
