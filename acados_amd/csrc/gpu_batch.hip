@@ -26,13 +26,16 @@
 #include "pcond_kernels_w16.hpp"
 #include "kernel_sets.h"
 
+/* a failing HIP call is not something a solve can recover from (lost device, out of HBM): message + exit(1), acados'
+ * convention for errors that are not a solver status (`printf(...); exit(1);` throughout acados/ocp_qp/); what a solve
+ * itself can report -- NaN, MAXITER, MINSTEP, infeasible -- comes back per instance as acados return codes */
 #define HIPCHK(x)                                                                              \
     do {                                                                                       \
         hipError_t e_ = (x);                                                                   \
         if (e_ != hipSuccess)                                                                  \
         {                                                                                      \
-            fprintf(stderr, "acados_amd: HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
-            abort();                                                                           \
+            fprintf(stderr, "\nerror: acados_amd: HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+            exit(1);                                                                           \
         }                                                                                      \
     } while (0)
 
@@ -262,7 +265,7 @@ void finalize_structure(ocp_qp_gpu_batch *b)
         if (nct > 64 * b->AW || nbg > GQP_MAX_ROWS)
         {
             fprintf(stderr, "acados_amd: stage %d has %d inequality sides (> %d): unsupported\n", k, nct, 64 * b->AW);
-            abort(); /* not reachable through ocp_qp_gpu_batch_create, which refuses such dims */
+            exit(1); /* not reachable through ocp_qp_gpu_batch_create, which refuses such dims */
         }
         /* sort box rows by variable */
         std::vector<int> order(S.nb);
@@ -274,23 +277,23 @@ void finalize_structure(ocp_qp_gpu_batch *b)
             const int ob = order[sp];
             b->perm[k][ob] = sp;
             const int iv = b->idxb[k][ob];
-            if (iv < 0 || iv >= b->nu[k] + b->nx[k]) { fprintf(stderr, "acados_amd: idxb out of range at stage %d\n", k); abort(); }
+            if (iv < 0 || iv >= b->nu[k] + b->nx[k]) { fprintf(stderr, "acados_amd: idxb out of range at stage %d\n", k); exit(1); }
             const int pv = padded_var(b, k, iv);
-            if ((S.bmask >> pv) & 1) { fprintf(stderr, "acados_amd: duplicate idxb entry at stage %d: unsupported\n", k); abort(); }
+            if ((S.bmask >> pv) & 1) { fprintf(stderr, "acados_amd: duplicate idxb entry at stage %d: unsupported\n", k); exit(1); }
             S.bmask |= (uint64_t) 1 << pv;
         }
         for (int r = 0; r < GQP_MAX_ROWS; r++) S.srev[r] = -1;
         for (int r = 0; r < nbg; r++)
         {
             const int sj = b->idxs_rev[k][r];
-            if (sj >= S.ns) { fprintf(stderr, "acados_amd: idxs_rev out of range at stage %d\n", k); abort(); }
+            if (sj >= S.ns) { fprintf(stderr, "acados_amd: idxs_rev out of range at stage %d\n", k); exit(1); }
             const int row = r < S.nb ? b->perm[k][r] : r;
             S.srev[row] = (int8_t) sj;
         }
         for (size_t e = 0; e < b->idxe[k].size(); e++)
         {
             const int ob = b->idxe[k][e];
-            if (ob < 0 || ob >= S.nb) { fprintf(stderr, "acados_amd: idxe out of range at stage %d\n", k); abort(); }
+            if (ob < 0 || ob >= S.nb) { fprintf(stderr, "acados_amd: idxe out of range at stage %d\n", k); exit(1); }
             S.emask |= (uint64_t) 1 << padded_var(b, k, b->idxb[k][ob]);
         }
         o_ct += nct; o_s += 2 * S.ns; o_g += S.ng;
@@ -960,6 +963,18 @@ int ocp_qp_gpu_batch_opts_set(ocp_qp_gpu_batch *b, const char *f, const void *v)
     else if (!strcmp(f, "cond_pred_corr")) o.cond_pred_corr = *i;
     else if (!strcmp(f, "print_level")) b->print_level = *i;
     else if (!strcmp(f, "profile")) b->profile = *i;
+    else if (!strcmp(f, "marker"))
+    {
+        /* one empty launch named k_marker<id> on the batch's stream (id 0..15): section mark for rocprofv3 summaries */
+        typedef void (*marker_t)(int *);
+        static const marker_t mk[16] = {gqp::k_marker<0>, gqp::k_marker<1>, gqp::k_marker<2>, gqp::k_marker<3>, gqp::k_marker<4>,
+                                        gqp::k_marker<5>, gqp::k_marker<6>, gqp::k_marker<7>, gqp::k_marker<8>, gqp::k_marker<9>,
+                                        gqp::k_marker<10>, gqp::k_marker<11>, gqp::k_marker<12>, gqp::k_marker<13>,
+                                        gqp::k_marker<14>, gqp::k_marker<15>};
+        HIPCHK(hipSetDevice(b->device));
+        hipLaunchKernelGGL(mk[*i & 15], dim3(1), dim3(64), 0, b->stream, (int *) nullptr);
+        HIPCHK(hipStreamSynchronize(b->stream));
+    }
     else if (!strcmp(f, "compact_min")) b->compact_min = *i;
     else if (!strcmp(f, "tail_max")) b->tail_max = *i;
     else if (!strcmp(f, "solve_max")) b->solve_max = *i;
@@ -1439,7 +1454,7 @@ static void compact_into(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch *root, int nact, 
         ocp_qp_gpu_batch *c = batch_create_shape(b->N, b->nx.data(), b->nu.data(), b->nbx.data(), b->nbu.data(),
                                                  b->ng.data(), b->ns.data(), cap, b->device, tail ? b->ks->NX : 0, tail ? b->ks->NU : 0,
                                                  b->ks, tail);
-        if (!c) { fprintf(stderr, "acados_amd: cannot create the compaction sub-batch\n"); abort(); }
+        if (!c) { fprintf(stderr, "acados_amd: cannot create the compaction sub-batch\n"); exit(1); }
         c->idxb = b->idxb; c->idxs_rev = b->idxs_rev; c->idxe = b->idxe; c->nbxe = b->nbxe;
         c->compact_min = b->compact_min;
         c->tail_max = b->tail_max;
@@ -1677,7 +1692,7 @@ static void sens_solve_sliced(ocp_qp_gpu_batch *b)
     {
         ocp_qp_gpu_batch *c = batch_create_shape(b->N, b->nx.data(), b->nu.data(), b->nbx.data(), b->nbu.data(), b->ng.data(),
                                                  b->ns.data(), cap, b->device, b->ks->NX, b->ks->NU, b->ks, true);
-        if (!c) { fprintf(stderr, "acados_amd: cannot create the sensitivity sub-batch\n"); abort(); }
+        if (!c) { fprintf(stderr, "acados_amd: cannot create the sensitivity sub-batch\n"); exit(1); }
         c->idxb = b->idxb; c->idxs_rev = b->idxs_rev; c->idxe = b->idxe; c->nbxe = b->nbxe;
         c->tail_max = 0;
         finalize_structure(c);

@@ -1138,6 +1138,14 @@ static __global__ void k_bulk_scatter(const double *blob, int nb, int len, const
     }
 }
 
+/* a launch that does nothing but carry a number in its NAME: the profile summaries (profiles/summarize.py) cut the
+ * dispatch sequence of a traced run into labelled sections with it (option "marker") */
+template <int ID>
+static __global__ void k_marker(int *sink)
+{
+    if (sink && threadIdx.x == 1023) *sink = ID;
+}
+
 /* seeds of a sensitivity solve, all fields of all stages in one launch: entry e of the blob goes (with its sign: the
  * residual arrays hold lower-bound seeds negated) to array T.a[map_arr[e]] and, where the row is an equality-flagged
  * bound, also into the table's array 4 (derivative of the fixed variable itself) */

@@ -706,6 +706,7 @@ int single_batch_load_in(single_batch *sb, const ocp_qp_in *in)
         single_batch_free(sb);
         sb->batch = ocp_qp_gpu_batch_create(d->N, d->nx, d->nu, d->nbx, d->nbu, d->ng, d->ns, 1, -1);
         if (!sb->batch) return -1;
+        sb->generation++;
         sb->sig = (int *) malloc(sizeof(int) * len);
         memcpy(sb->sig, sig.data(), sizeof(int) * len);
         sb->sig_len = len;

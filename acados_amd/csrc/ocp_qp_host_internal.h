@@ -37,6 +37,7 @@ struct single_batch
     ocp_qp_gpu_batch *batch;
     int *sig;     /* structure signature of the QP the batch was built for (malloc'ed with the batch) */
     int sig_len;
+    int generation; /* bumped whenever `batch` is (re)created: a new batch often lands on the old one's address */
 };
 int structure_sig_len(const ocp_qp_dims *d);
 int structure_sig_fill(const ocp_qp_in *in, int *dst);

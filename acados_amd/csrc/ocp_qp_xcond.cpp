@@ -51,7 +51,7 @@ double now_s()
 struct pcond_device
 {
     gqp_host::single_batch sb;           /* the ORIGINAL QP as a one-instance device batch */
-    ocp_qp_gpu_batch *configured;        /* batch the condensing options have been sent to */
+    int configured_gen;                  /* generation of `sb.batch` the condensing options have been sent to (-1: none) */
     int N2_sent;
 };
 
@@ -339,11 +339,13 @@ static ocp_qp_gpu_batch *pcond_load(ocp_qp_partial_condensing_memory *mem, ocp_q
         exit(1);
     }
     ocp_qp_gpu_batch *b = dev->sb.batch;
-    if (dev->configured != b || dev->N2_sent != opts->N2)
+    /* keyed on the batch's generation, not on its address: a batch re-created for a changed structure (idxb, idxs_rev,
+     * idxe) often gets the address of the one just destroyed and would never be told cond_N */
+    if (dev->configured_gen != dev->sb.generation || dev->N2_sent != opts->N2)
     {
         ocp_qp_gpu_batch_opts_set(b, "cond_N", &opts->N2);
         if (opts->block_size_was_set && ocp_qp_gpu_batch_opts_set(b, "cond_block_size", opts->block_size) != 0) exit(1);
-        dev->configured = b;
+        dev->configured_gen = dev->sb.generation;
         dev->N2_sent = opts->N2;
     }
     return b;
@@ -497,7 +499,7 @@ void ocp_qp_gpu_pcond_memory_release(void *mem_)
     if (!mem || !mem->device) return;
     pcond_device *dev = (pcond_device *) mem->device;
     gqp_host::single_batch_free(&dev->sb);
-    dev->configured = nullptr;
+    dev->configured_gen = -1;
 }
 
 /* ocp_qp_partial_condensing.c:720-750 */

@@ -130,15 +130,18 @@ def pmc_traffic(dom, nx, nu, B, N):
 
 
 def oracle_error(gb, qp_of, idx, N):
-    """max relative primal error of instances `idx` against the oracle (checker only, outside timing)"""
-    from oracle.oracle import OracleQp, default_opts
+    """max relative primal error of instances `idx` against the oracle (checker only, outside timing); the oracle solves
+    the sample as one OpenMP batch over the host cores the process may use"""
+    from oracle.oracle import OracleQp, default_opts, solve_batch_handles
     xs = [gb.get("x", k) for k in range(N + 1)]
     us = [gb.get("u", k) for k in range(N)]
-    err, solved = 0.0, []
-    for i in idx:
-        qp = qp_of(int(i))
-        o = OracleQp(qp)
-        o.solve(default_opts(tol_stat=1e-8, tol_eq=1e-8, tol_ineq=1e-8, tol_comp=1e-8))
+    qps = [OracleQp(qp_of(int(i))) for i in idx]
+    if not qps:
+        return 0.0
+    solve_batch_handles([q.h.value for q in qps], default_opts(tol_stat=1e-8, tol_eq=1e-8, tol_ineq=1e-8, tol_comp=1e-8),
+                        nthreads=threads_allowed())
+    err = 0.0
+    for i, o in zip(idx, qps):
         for k in range(N + 1):
             r = o.get(k, "x")
             if r.size:
@@ -148,6 +151,33 @@ def oracle_error(gb, qp_of, idx, N):
                 if r.size:
                     err = max(err, float(np.max(np.abs(us[k][i][:r.size] - r) / np.maximum(1.0, np.abs(r)))))
     return err
+
+
+def config_traffic(section, symbol, sweep):
+    """HBM bytes per launch of a configuration's dominant kernel from the newest per-section PMC summary under profiles/
+    (tools/profile_round.sh <tag> <commit> full; sections are cut by the marker launches run_config brackets its timed
+    solves with)"""
+    import re
+
+    def tag(f):
+        m = re.match(r"r(\d+)_v(\d+)_config_pmc_traffic\.json$", os.path.basename(f))
+        return (int(m.group(1)), int(m.group(2))) if m else None
+    files = sorted((f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_config_pmc_traffic.json")) if tag(f)), key=tag)
+    if not files:
+        return None
+    try:
+        pmc = json.load(open(files[-1]))
+        sec = pmc["sections"][str(section)]
+        cand = {k: v for k, v in sec.items() if k.startswith(symbol + "<")}
+        if not cand:
+            return None
+        # the two forward sweeps share a symbol: the corrector sweep (update pass included) moves more bytes
+        pick = (min if sweep == "fwd_aff" else max)(cand, key=lambda k: cand[k]["hbm_bytes_per_launch_avg_main"])
+        e = cand[pick]
+        return {"file": os.path.relpath(files[-1], ROOT), "commit": pmc.get("_commit"), "kernel": pick, "section": section,
+                "avg_main": e["hbm_bytes_per_launch_avg_main"], "full": e["hbm_bytes_per_launch_full"], "launches": e["launches"]}
+    except Exception:
+        return None
 
 
 def cpu_caps():
@@ -163,6 +193,14 @@ def cpu_caps():
     except Exception:
         caps["cgroup_quota_cpus"] = None
     return caps
+
+
+def threads_allowed():
+    caps = cpu_caps()
+    allowed = caps["affinity"] or caps["logical"]
+    if caps["cgroup_quota_cpus"]:
+        allowed = max(1, min(allowed, int(round(caps["cgroup_quota_cpus"]))))
+    return allowed
 
 
 def cpu_baseline(data, N, unique, budget_s=25.0):
@@ -231,21 +269,30 @@ def tol_setup(gb):
     gb.opts_set("warm_start", 0)
 
 
-def run_config(name, gb, qp_of, N, dims, steps=2, check=4, extra=None):
+def run_config(name, gb, qp_of, N, dims, steps=2, check=4, extra=None, section=0, sweep_kernel_name=None):
     """one non-headline configuration: warm-up + `steps` timed solves, statistics, independent residual, oracle sample,
-    dominant sweep + roofline fraction"""
+    dominant sweep + roofline fraction (+ the PMC traffic of the same kernel from the per-section summary)"""
     tol_setup(gb)
     gb.solve()
     gb.opts_set("profile", 1)
     gb.scalar("prof_reset")
+    gb.opts_set("marker", section)       # section mark for the rocprofv3 summaries (an empty launch, outside timing)
     t0 = time.perf_counter()
     bad = 0
     for _ in range(steps):
         bad += gb.solve()
     dt = (time.perf_counter() - t0) / steps
+    gb.opts_set("marker", 0)
     gb.opts_set("profile", 0)
     b_in, b_out = algorithmic_bytes_dims(dims)
     dom, prof, roof = sweep_roofline(gb, steps, b_in + b_out)
+    kname = sweep_kernel_name() if sweep_kernel_name else gb.kernel_name
+    roof["kernel"] = f"{kernel_symbol(kname, dom)} ({dom}) of {kname}"
+    tr = config_traffic(section, kernel_symbol(kname, dom), dom) if section else None
+    roof["traffic"] = tr["avg_main"] if tr else None
+    roof["traffic_source"] = tr
+    roof["traffic_over_algorithmic"] = (tr["avg_main"] / roof["bytes_per_launch"]) if tr else None
+    roof["traffic_GBps"] = (tr["avg_main"] / (roof["avg_launch_ms"] * 1e-3) / 1e9) if tr and roof["avg_launch_ms"] > 0 else None
     it = gb.info("iter")
     res = gb.res_compute()
     out = {"workload": name, "batch": gb.n_batch, "solves_per_s": gb.n_batch / dt, "ms_per_step": dt * 1e3,
@@ -254,9 +301,9 @@ def run_config(name, gb, qp_of, N, dims, steps=2, check=4, extra=None):
            "bytes_per_instance": b_in + b_out, "roofline": roof,
            "condense_expand_ms": gb.scalar("time_xcond") * 1e3}
     if check:
-        idx = np.linspace(0, gb.n_batch - 1, check).astype(int)
+        idx = np.unique(np.linspace(0, gb.n_batch - 1, check).astype(int))
         out["max_rel_primal_err_vs_oracle"] = oracle_error(gb, qp_of, idx, N)
-        out["oracle_checked_instances"] = int(check)
+        out["oracle_checked_instances"] = int(idx.size)
     if extra:
         out.update(extra)
     return out
@@ -271,16 +318,16 @@ def other_configs(c2_batch, c2_data, args):
     N = 50
     # C3: the C2 batch itself with partial condensing N2 = 10 (same data, resident)
     c2_batch.opts_set("cond_N", 10)
+    # (the IPM sweeps of a condensed solve run on the condensed batch's kernels)
     out["C3"] = run_config("C2 data with partial condensing to N2=10 (BASELINE configs[2]), batch 65,536", c2_batch,
-                           lambda i: lqr_instance_qp(c2_data, i, N), N, lqr_dims(N, 8, 3), steps=2, check=args.check_configs)
+                           lambda i: lqr_instance_qp(c2_data, i, N), N, lqr_dims(N, 8, 3), steps=2, check=args.check_configs,
+                           section=1, sweep_kernel_name=lambda: c2_batch.condensed_kernel_name() or c2_batch.kernel_name)
     out["C3"]["cond_N_active"] = int(c2_batch.scalar("cond_N_active"))
     ck = c2_batch.condensed_kernel_name()
-    if ck:   # the IPM sweeps of a condensed solve run on the condensed batch's kernels
+    if ck:
         pk = {2: "kz_pcond", 1: "k_pcond", 0: "kw_pcond"}.get(int(c2_batch.scalar("pcond_kernel")), "pcond")
         ek = {1: "k_pexpand", 0: "kw_pexpand"}.get(int(c2_batch.scalar("pexpand_kernel")), "pexpand")
         out["C3"]["kernel"] = f"{pk} + {ck} + {ek}"
-        dom3 = out["C3"]["roofline"]["sweep"]
-        out["C3"]["roofline"]["kernel"] = f"{kernel_symbol(ck, dom3)} ({dom3}) of {ck}"
     c2_batch.opts_set("cond_N", N)
     # C4
     N4, B4 = 40, args.c4_batch
@@ -288,7 +335,7 @@ def other_configs(c2_batch, c2_data, args):
     g4 = OcpQpGpuBatch(chain_soft_dims(N4), B4)
     fill_chain_soft_batch(g4, d4, N4)
     out["C4"] = run_config(f"chain nx=24 nu=3, 4 soft state bounds + 4 soft general rows, ns=8, N=40 (BASELINE configs[3]), batch {B4}",
-                           g4, lambda i: chain_soft_instance_qp(d4, i, N4), N4, chain_soft_dims(N4), steps=2, check=args.check_configs)
+                           g4, lambda i: chain_soft_instance_qp(d4, i, N4), N4, chain_soft_dims(N4), steps=2, check=args.check_configs, section=2)
     del g4, d4
     # C5: the per-GPU share of 524,288 instances on 8 GPUs, split equally over the 9 shape classes.  Every class is one
     # device batch with its own HIP stream; the classes are solved CONCURRENTLY (one host thread per class, the solve
@@ -310,11 +357,17 @@ def other_configs(c2_batch, c2_data, args):
         t_conc = time.perf_counter() - t0
     classes, tot_t, tot_n, bad, res_max = [], 0.0, 0, 0, 0.0
     worst_frac = None
-    for (nx, nu, Nc), gc, dc in batches:
+    per_class_check = -(-args.check_configs // len(batches)) if args.check_configs else 0     # the sample is spread over the classes
+    for ci, ((nx, nu, Nc), gc, dc) in enumerate(batches):
         r = run_config(f"nx={nx} nu={nu} N={Nc}", gc, lambda i: lqr_instance_qp(dc, i, Nc), Nc, lqr_dims(Nc, nx, nu), steps=1,
-                       check=1 if args.check_configs else 0)
+                       check=per_class_check, section=3 + ci)
         classes.append({k: r[k] for k in ("workload", "batch", "solves_per_s", "ms_per_step", "kernel", "mean_iter", "failures",
-                                          "max_kkt_residual_independent")} | {"frac": r["roofline"]["frac"], "dominant": r["roofline"]["kernel"]})
+                                          "max_kkt_residual_independent")}
+                       | {"frac": r["roofline"]["frac"], "dominant": r["roofline"]["kernel"], "avg_launch_ms": r["roofline"]["avg_launch_ms"],
+                          "traffic": r["roofline"]["traffic"], "traffic_over_algorithmic": r["roofline"]["traffic_over_algorithmic"],
+                          "traffic_GBps": r["roofline"]["traffic_GBps"],
+                          "max_rel_primal_err_vs_oracle": r.get("max_rel_primal_err_vs_oracle"),
+                          "oracle_checked_instances": r.get("oracle_checked_instances", 0)})
         tot_t += r["ms_per_step"] * 1e-3
         tot_n += per_class
         bad += r["failures"]
@@ -326,7 +379,9 @@ def other_configs(c2_batch, c2_data, args):
                                    f"524,288 on 8 GPUs (BASELINE configs[4]); nine device batches solved concurrently on their own streams",
                        "batch": tot_n, "solves_per_s": tot_n / t_conc, "seconds": t_conc, "failures": bad + bad_conc,
                        "solves_per_s_one_after_the_other": tot_n / tot_t, "seconds_one_after_the_other": tot_t,
-                       "max_kkt_residual_independent": res_max, "roofline_of_slowest_class": worst_frac[1], "classes": classes}
+                       "max_kkt_residual_independent": res_max, "roofline_of_slowest_class": worst_frac[1], "classes": classes,
+                       "max_rel_primal_err_vs_oracle": max((c["max_rel_primal_err_vs_oracle"] or 0.0) for c in classes),
+                       "oracle_checked_instances": sum(c["oracle_checked_instances"] for c in classes)}
     return out
 
 
@@ -343,7 +398,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-configs", action="store_true", help="skip C3 / C4 / C5 (the headline line only)")
     ap.add_argument("--c4-batch", type=int, default=16384)
-    ap.add_argument("--check-configs", type=int, default=4, help="instances per configuration checked against the oracle")
+    ap.add_argument("--check-configs", type=int, default=1024,
+                    help="instances per configuration checked against the oracle (OpenMP batch on the host, outside timing; SURVEY 8d asks >= 1,024)")
     ap.add_argument("--compact-min", type=int, default=None, help="override the library default of the compaction threshold")
     ap.add_argument("--check", type=int, default=8, help="instances per rank checked against the oracle (outside timing)")
     args = ap.parse_args()
@@ -437,6 +493,8 @@ def main():
     tr = pmc_traffic(dom, nx, nu, B, N)
     roof["traffic"] = tr["avg_main"] if tr else None
     roof["traffic_source"] = tr
+    roof["traffic_note"] = ("HBM bytes per launch from the committed rocprofv3 PMC summary named in traffic_source (counter passes "
+                            "cannot run inside this process); the time it is divided by is measured live in this run")
     roof["traffic_over_algorithmic"] = (tr["avg_main"] / roof["bytes_per_launch"]) if tr else None
     full_units = [u for u in roof["units_per_launch"] if u == B]
     roof["full_launch"] = {"bytes": float(B * (b_in + b_out)), "traffic": tr["full"] if tr else None,

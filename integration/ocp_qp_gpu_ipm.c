@@ -246,6 +246,11 @@ static void gpu_memory_get(void *config, void *mem_, const char *field, void *va
     if (!strcmp(field, "time_qp_solver_call")) *(double *) value = m->time_qp_solver_call;
     else if (!strcmp(field, "iter")) *(int *) value = m->iter;
     else if (!strcmp(field, "status")) *(int *) value = m->status;
+    else if (!strcmp(field, "kernel_name")) /* extension: which kernel family serves this memory's QP (const char *) */
+    {
+        const gpu_bucket *bk = m->group ? m->group->bk + m->g_bucket : &m->own;
+        *(const char **) value = bk->batch ? ocp_qp_gpu_batch_kernel_name(bk->batch) : "";
+    }
     else { printf("\nerror: ocp_qp_gpu_ipm_memory_get: field %s not available\n", field); exit(1); }
 }
 

@@ -2,7 +2,8 @@
 """Turn rocprofv3 (rocpd sqlite) outputs into the small text summaries kept under profiles/.
 usage: summarize.py kernel <results.db>   -> per-kernel calls / total / average (kernel-trace --stats)
        summarize.py pmc <results.db>      -> per-kernel counter sums and per-launch averages
-       summarize.py traffic <fetch.db> <write.db> -> JSON: HBM bytes per launch of every gqp kernel"""
+       summarize.py traffic <fetch.db> <write.db> -> JSON: HBM bytes per launch of every gqp kernel
+       summarize.py sections <fetch.db> <write.db> -> the same per marker-delimited section (the configuration legs)"""
 import sqlite3
 import sys
 
@@ -15,7 +16,7 @@ def kernel(db):
     print("\nper-dispatch durations of the IPM kernels (us), in launch order, first 60:")
     rows = cur.execute("select name,duration,vgpr_count,accum_vgpr_count,sgpr_count,scratch_size from kernels "
                        "where name like '%gqp::k_backward%' or name like '%gqp::k_forward%' or name like '%gqp::kb_%' "
-                       "or name like '%gqp::kw_%' order by start limit 60").fetchall()
+                       "or name like '%gqp::kw_%' or name like '%gqp::kx_%' or name like '%gqp::ky_%' or name like '%gqp::kz_%' order by start limit 60").fetchall()
     for name, dur, v, a, s, sc in rows:
         short = name.split("gqp::")[1].split("(")[0]
         print(f"  {short:40s} {dur / 1e3:10.1f}  vgpr {v} agpr {a} sgpr {s} scratch {sc}")
@@ -55,6 +56,54 @@ def traffic(fetch_db, write_db, commit=None):
     print(json.dumps(out, indent=1))
 
 
+def sections(fetch_db, write_db, commit=None):
+    """HBM bytes per launch of every gqp kernel, per SECTION of the run: bench.py brackets the timed solves of each
+    configuration with marker launches (`k_marker<ID>`, option "marker"), the dispatch sequence is cut at them.
+    Sections: 1 = C3, 2 = C4, 3.. = the C5 classes in generator order; 0 closes a section."""
+    import json
+    import re
+    out = {"_note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate counter-only passes over `bench.py --steps 1 "
+                    "--warmup 0 --no-cpu-baseline --check 0 --check-configs 0` (configuration legs included); bytes = "
+                    "(2*FETCH_SIZE + WRITE_SIZE) * 1024 per MI355X_MICROARCH.md (HBM section).  Per section (marker id) and "
+                    "kernel: launches, average over the launches that carry work (> 1 % of the largest) and the largest.",
+           "_commit": commit, "sections": {}}
+    q = "select kernel_name, value from counters_collection where counter_name=? order by dispatch_id"
+
+    def cut(db, counter):
+        """label -> kernel -> [counter value of every launch, in order]; launches outside a section are dropped (the
+        concurrent C5 leg interleaves its nine streams differently from run to run: it carries no marker)"""
+        label, d = None, {}
+        for k, v in sqlite3.connect(db).cursor().execute(q, (counter,)):
+            if "gqp::" not in k:
+                continue
+            short = k.split("gqp::")[1].split("(")[0]
+            m = re.match(r"k_marker<(\d+)>", short)
+            if m:
+                label = int(m.group(1)) or None
+            elif label is not None:
+                d.setdefault(str(label), {}).setdefault(short, []).append(v)
+        return d
+    f, w = cut(fetch_db, "FETCH_SIZE"), cut(write_db, "WRITE_SIZE")
+    acc = {}
+    for lab in f:
+        for short, fv in f[lab].items():
+            wv = w.get(lab, {}).get(short)
+            if wv is None or len(wv) != len(fv):
+                out.setdefault("_mismatch", []).append(f"section {lab} {short}: {len(fv)} vs {0 if wv is None else len(wv)} launches")
+                continue
+            acc.setdefault(lab, {})[short] = [((2 * a + b) * 1024, a, b) for a, b in zip(fv, wv)]
+    for lab, ks in acc.items():
+        sec = out["sections"].setdefault(lab, {})
+        for short, rows in ks.items():
+            tot = [r[0] for r in rows]
+            mx = max(tot)
+            main = [t for t in tot if t > 0.01 * mx] or [0.0]
+            sec[short] = {"launches": len(tot), "launches_main": len(main), "fetch_kib_avg": sum(r[1] for r in rows) / len(rows),
+                          "write_kib_avg": sum(r[2] for r in rows) / len(rows), "hbm_bytes_per_launch_avg": sum(tot) / len(tot),
+                          "hbm_bytes_per_launch_avg_main": sum(main) / len(main), "hbm_bytes_per_launch_full": mx}
+    print(json.dumps(out, indent=1))
+
+
 def pmc(db):
     cur = sqlite3.connect(db).cursor()
     q = ("select kernel_name, counter_name, count(*), sum(value), avg(value), max(value) from counters_collection "
@@ -65,7 +114,7 @@ def pmc(db):
 
 
 if __name__ == "__main__":
-    if sys.argv[1] == "traffic":
-        traffic(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else None)
+    if sys.argv[1] in ("traffic", "sections"):
+        {"traffic": traffic, "sections": sections}[sys.argv[1]](sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else None)
     else:
         {"kernel": kernel, "pmc": pmc}[sys.argv[1]](sys.argv[2])

@@ -91,8 +91,13 @@ static int run_batch(int argc, char **argv)
         ocp_qp_gpu_ipm_acados_eval_sens_batch(&config, n, ins, seeds, sens, opts, mems, NULL);
         sens_s = now_s() - t0;
     }
-    printf("batch n %d ms_per_call %.3f status %d interface_ms %.3f solve_ms %.3f sens_ms %.3f\n", n, best * 1e3, status,
-           caps[0]->info.interface_time * 1e3, caps[0]->info.solve_QP_time * 1e3, sens_s * 1e3);
+    const char *kname = "";
+    config.memory_get(&config, mems[0], "kernel_name", &kname);
+    int it_max = 0;
+    for (int i = 0; i < n; i++) if (caps[i]->info.num_iter > it_max) it_max = caps[i]->info.num_iter;
+    printf("batch n %d ms_per_call %.3f status %d interface_ms %.3f solve_ms %.3f sens_ms %.3f iter_max %d\n", n, best * 1e3, status,
+           caps[0]->info.interface_time * 1e3, caps[0]->info.solve_QP_time * 1e3, sens_s * 1e3, it_max);
+    fprintf(stderr, "kernel of capsule 0: %s\n", kname);
     FILE *g = fopen(argv[5], "wb");
     for (int i = 0; i < n; i++)
     {

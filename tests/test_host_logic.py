@@ -890,6 +890,39 @@ def test_condensing_module_acados_api_hostsim(hostsim_lib):
         assert np.max(np.abs(x - xr)) <= 1e-4 * max(1.0, np.max(np.abs(xr)))
 
 
+def test_condense_after_structure_change_hostsim(hostsim_lib):
+    """one condensing module, two condense calls with the index sets changed in between (idxb of stage 3 reversed): the
+    device batch is re-created -- often at the address of the one just destroyed -- and must be told cond_N again (the
+    module once compared batch POINTERS and then failed with ACADOS_QP_FAILURE depending on the heap)"""
+    import copy
+    from acados_amd import AcadosOcpQpCondensing
+    from acados_amd.generators import mass_spring_qp
+    qp = mass_spring_qp(N=15)
+    mod = AcadosOcpQpCondensing(qp, 5, _clib=hostsim_lib)
+    qc1 = mod.condense()
+    for rep in range(3):   # several re-creations: whatever the allocator does with the addresses
+        q2 = copy.deepcopy(qp)
+        k = 3 + rep
+        order = np.arange(len(qp.idxb[k]))[::-1]
+        nbu = int(qp.dims.nbu[k])
+        # reversed order inside the u block and inside the x block (acados keeps [u rows; x rows])
+        ou, ox = np.arange(nbu)[::-1], nbu + np.arange(len(order) - nbu)[::-1]
+        perm = np.concatenate([ou, ox])
+        q2.set("idxb", k, np.asarray(qp.idxb[k])[perm])
+        for f, sel in (("lbu", ou), ("ubu", ou), ("lbx", ox - nbu), ("ubx", ox - nbu)):
+            q2.set(f, k, np.asarray(getattr(qp, f)[k])[sel])
+        mod.set_qp(q2)
+        qc2 = mod.condense()          # raised "ocp_qp_condense failed" before
+        assert qc2.N == qc1.N
+        o1, o2 = OracleQp(qc1), OracleQp(qc2)
+        assert o1.solve(default_opts(tol_stat=1e-8)) == 0 and o2.solve(default_opts(tol_stat=1e-8)) == 0
+        for kk in range(qc1.N + 1):   # the same QP with its rows listed in another order: same condensed solution
+            assert np.allclose(o1.get(kk, "x"), o2.get(kk, "x"), rtol=1e-7, atol=1e-9)
+            assert np.allclose(o1.get(kk, "u"), o2.get(kk, "u"), rtol=1e-7, atol=1e-9)
+        mod.set_qp(qp)
+        mod.condense()
+
+
 def test_cond_block_size_option_acados_api_hostsim(hostsim_lib, capfd):
     """`cond_block_size` through the xcond-solver options (ocp_qp_partial_condensing.c:305-313; the Python driver
     sends it like acados_ocp_qp_solver.py does): user blocks reach the device condensing, same solution"""

@@ -257,10 +257,12 @@ def test_acados_adapter_sensitivities(clib, tmp_path, qp_name):
     print("sens vs dense at the oracle's point:", worst)
 
 
-def _run_batch(exe, tmp_path, n, files, sens, reps=1):
+def _run_batch(exe, tmp_path, n, files, sens, reps=1, default_dispatch=False):
     out = str(tmp_path / "batch.bin")
     cmd = [exe, "batch", str(n), files[0], files[1] if len(files) > 1 else "-", out] + (["sens"] if sens else []) + [str(reps)]
     env = dict(os.environ, OMP_NUM_THREADS=str(min(16, os.cpu_count() or 1)))
+    if default_dispatch:      # conftest.py pins the small-batch rule off for the CPU tier; a timing wants the library's own choice
+        env.pop("ACADOS_AMD_WPI_BATCH_MAX", None)
     r = subprocess.run(cmd, capture_output=True, text=True, env=env)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
     lines = r.stdout.strip().splitlines()
@@ -317,7 +319,7 @@ def test_acados_adapter_batch_1024_c2(gpu_lib, tmp_path):
     exe = _build(gpu_lib._name, tmp_path)
     f = str(tmp_path / "qp.txt")
     _write_qp(qp, f)
-    info, per, extra, raw = _run_batch(exe, tmp_path, n, [f], sens=True, reps=5)
+    info, per, extra, raw = _run_batch(exe, tmp_path, n, [f], sens=True, reps=5, default_dispatch=True)
     print("acados-struct batch of 1,024 C2-shaped QPs:", info)
     assert info["status"] == 0 and all(st == 0 for _, st, _, _, _ in per)
     assert extra["single_vs_batch_sens"] <= 1e-12
@@ -335,5 +337,6 @@ def test_acados_adapter_batch_1024_c2(gpu_lib, tmp_path):
             assert np.allclose(sol[("ux", k)], ref, rtol=1e-7, atol=1e-8), (i, k)
         if i % 4 == 0:
             _check_sens_vs_dense(qi, sol, sens, _seeds(qi, i), 1e-6, 1e-2)
-    # 12 ms per call was the bar set by the review (plain containers: 11.9 ms); generous ceiling, the number is printed
-    assert info["ms_per_call"] <= 25.0, info
+    # 12 ms per call was the bar set by the review (plain containers: 11.9 ms); ceiling with headroom for a slow box, the
+    # measured number is printed
+    assert info["ms_per_call"] <= 16.0, info

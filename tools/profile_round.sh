@@ -6,7 +6,8 @@
 #   <tag>_pmc_traffic.json     HBM bytes per launch of every sweep kernel: --pmc FETCH_SIZE / --pmc WRITE_SIZE, SEPARATE
 #                              counter-only passes (no trace domains), gfx950 correction of MI355X_MICROARCH.md
 #   <tag>_bench.json           the bench line of the same build (reads the traffic file just written if copied first)
-# `full` also traces the configuration legs (C3 / C4 / C5) of the bench.
+# `full` also traces the configuration legs (C3 / C4 / C5) of the bench and collects their HBM traffic per configuration
+#   <tag>_config_kernel_stats.txt, <tag>_config_pmc_traffic.json (sections cut by the marker launches of bench.py)
 tag=${1:-rXX}
 commit=${2:-unknown}
 root=$(pwd)
@@ -24,8 +25,17 @@ f=$(find /tmp/pmc_f -name "*.db" | head -1); w=$(find /tmp/pmc_w -name "*.db" | 
 python $root/profiles/summarize.py traffic $f $w $commit > $out/${tag}_pmc_traffic.json
 cp $out/${tag}_pmc_traffic.json $root/profiles/${tag}_pmc_traffic.json   # the bench below reads the file of THIS build
 if [ "$3" = "full" ]; then
-    rocprofv3 --kernel-trace --stats -d /tmp/prof_cfg -- python $root/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $out/${tag}_bench_configs_under_rocprof.json 2> $out/${tag}_rocprof_cfg.log
+    rocprofv3 --kernel-trace --stats -d /tmp/prof_cfg -- python $root/bench.py --steps 1 --warmup 1 --no-cpu-baseline --check 0 --check-configs 0 > $out/${tag}_bench_configs_under_rocprof.json 2> $out/${tag}_rocprof_cfg.log
     db=$(find /tmp/prof_cfg -name "*.db" | head -1)
     python $root/profiles/summarize.py kernel $db > $out/${tag}_config_kernel_stats.txt
+    # HBM traffic of the configuration legs: the same two counter-only passes over the bench WITH its configuration legs;
+    # bench.py brackets every configuration's timed solves with marker launches, summarize.py cuts the sequence there
+    cfgq="--steps 1 --warmup 0 --no-cpu-baseline --check 0 --check-configs 0"
+    rm -rf /tmp/pmc_cf /tmp/pmc_cw
+    rocprofv3 --pmc FETCH_SIZE -d /tmp/pmc_cf -- python $root/bench.py $cfgq > /dev/null 2> $out/${tag}_pmc_cf.log
+    rocprofv3 --pmc WRITE_SIZE -d /tmp/pmc_cw -- python $root/bench.py $cfgq > /dev/null 2> $out/${tag}_pmc_cw.log
+    f=$(find /tmp/pmc_cf -name "*.db" | head -1); w=$(find /tmp/pmc_cw -name "*.db" | head -1)
+    python $root/profiles/summarize.py sections $f $w $commit > $out/${tag}_config_pmc_traffic.json
+    cp $out/${tag}_config_pmc_traffic.json $root/profiles/${tag}_config_pmc_traffic.json
 fi
 cd $root && python bench.py 2> $out/${tag}_bench_err.log | tail -1 > $out/${tag}_bench.json
