@@ -35,6 +35,7 @@
  * In this repository the file is compiled and RUN in the test tiers against tests/mock_acados/include (stand-ins for
  * the HPIPM / BLASFEO / acados declarations restated from the fields acados touches): tests/test_mock_acados.py.
  */
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -50,6 +51,7 @@ typedef struct
 {
     double mu0, tol_stat, tol_eq, tol_ineq, tol_comp, alpha_min, tau_min, reg_prim, t0_min, lam0_min;
     int iter_max, warm_start, print_level, ric_alg, t0_init, update_fact_exit;
+    struct ocp_qp_gpu_ipm_rendezvous_ *rendezvous; /* set: `evaluate` waits for the other capsules and the QPs go as one batch */
 } ocp_qp_gpu_ipm_opts;
 
 /* one piece of a bulk blob <-> one sub-block of a BLASFEO object of the QP */
@@ -97,10 +99,13 @@ typedef struct ocp_qp_gpu_ipm_memory_
     gpu_bucket own;              /* the single-QP path: a bucket of one, everything carved */
     gpu_group *group;            /* batch entries: the group this memory's QP was solved in last (NULL: own) ... */
     int g_bucket, g_pos;         /* ... and where */
+    int rv_index;                /* slot of this memory's capsule in its rendezvous (-1: none yet) */
     int *sig_scratch;
     double time_qp_solver_call;
     int iter, status;
 } ocp_qp_gpu_ipm_memory;
+
+static int rendezvous_evaluate(struct ocp_qp_gpu_ipm_rendezvous_ *r, void *config, void *qp_in, void *qp_out, void *opts, ocp_qp_gpu_ipm_memory *m);
 
 static double now_s(void)
 {
@@ -169,6 +174,7 @@ static void gpu_opts_initialize_default(void *config, void *dims, void *opts_)
     o->mu0 = 1e0; o->tol_stat = 1e-6; o->tol_eq = 1e-8; o->tol_ineq = 1e-8; o->tol_comp = 1e-8; o->alpha_min = 1e-8;
     o->tau_min = 0.0; o->reg_prim = 1e-15; o->t0_min = 1e-16; o->lam0_min = 1e-16;
     o->iter_max = 50; o->warm_start = 0; o->print_level = 0; o->ric_alg = 1; o->t0_init = 2; o->update_fact_exit = 0;
+    o->rendezvous = NULL;
 }
 
 static void gpu_opts_update(void *config, void *dims, void *opts) {}
@@ -193,6 +199,8 @@ static void gpu_opts_set(void *config, void *opts_, const char *field, void *val
     else if (!strcmp(field, "lam0_min")) o->lam0_min = *d;
     else if (!strcmp(field, "update_fact_exit")) o->update_fact_exit = *i;
     else if (!strcmp(field, "hpipm_mode")) { /* one IPM variant; the acados overrides above hold for every mode */ }
+    /* `value` IS the rendezvous (or NULL): reachable from a capsule as ocp_nlp_solver_opts_set(.., "qp_rendezvous", r) */
+    else if (!strcmp(field, "rendezvous")) o->rendezvous = (struct ocp_qp_gpu_ipm_rendezvous_ *) value;
     else { printf("\nerror: ocp_qp_gpu_ipm_opts_set: wrong field: %s\n", field); exit(1); }
 }
 
@@ -237,6 +245,7 @@ static void *gpu_memory_assign(void *config, void *dims_, void *opts, void *raw_
     m->sig_scratch = (int *) c; c += sizeof(int) * (size_t) bk->sig_cap; /* its own scratch: a signature can be longer than a staging blob */
     bk->st = (int *) c; c += sizeof(int);
     bk->it = (int *) c; c += sizeof(int);
+    m->rv_index = -1;
     return m;
 }
 
@@ -495,6 +504,7 @@ static int ocp_qp_gpu_ipm_acados(void *config, void *qp_in_, void *qp_out_, void
     ocp_qp_out *out = (ocp_qp_out *) qp_out_;
     ocp_qp_gpu_ipm_opts *o = (ocp_qp_gpu_ipm_opts *) opts_;
     ocp_qp_gpu_ipm_memory *m = (ocp_qp_gpu_ipm_memory *) mem_;
+    if (o->rendezvous) return rendezvous_evaluate(o->rendezvous, config, qp_in_, qp_out_, opts_, m);
     gpu_bucket *bk = &m->own;
     qp_info *info = (qp_info *) out->misc;
 
@@ -565,17 +575,26 @@ static void *xcalloc(size_t cnt, size_t sz)
 
 /* group of the n QPs of this call: reused as long as n and every QP's structure are what they were, else rebuilt --
  * QPs are bucketed by structure signature, one device batch per bucket */
-static gpu_group *group_for(int n, ocp_qp_in **ins, ocp_qp_gpu_ipm_memory **mems)
+static gpu_group *group_for(int n, ocp_qp_in **ins, ocp_qp_gpu_ipm_memory **mems, const unsigned char *skip, int *fresh)
 {
     ocp_qp_gpu_ipm_memory *m0 = mems[0];
     gpu_group *g = m0->group && m0->group->owner == m0 ? m0->group : NULL;
-    int need = 0;
-    for (int i = 0; i < n; i++) { const int l = sig_len(ins[i]->dim); if (l > need) need = l; }
+    int need = 0, first = -1;
+    for (int i = 0; i < n; i++)
+    {
+        if (skip && skip[i]) continue;
+        if (first < 0) first = i;
+        const int l = sig_len(ins[i]->dim);
+        if (l > need) need = l;
+    }
+    *fresh = 0;
+    if (first < 0) return g; /* nobody takes part */
     if (g && g->n == n)
     {
         int same = g->scratch_cap >= need;
         for (int i = 0; i < n && same; i++)
         {
+            if (skip && skip[i]) continue;
             const gpu_bucket *bk = g->bk + g->bucket_of[i];
             same = sig_len(ins[i]->dim) == bk->sig_len && fill_sig(ins[i], g->scratch) == bk->sig_len
                    && memcmp(bk->sig, g->scratch, sizeof(int) * bk->sig_len) == 0;
@@ -583,6 +602,7 @@ static gpu_group *group_for(int n, ocp_qp_in **ins, ocp_qp_gpu_ipm_memory **mems
         if (same) return g;
     }
     group_release(g);
+    *fresh = 1;
     g = (gpu_group *) xcalloc(1, sizeof(gpu_group));
     g->owner = m0; g->n = n;
     g->bucket_of = (int *) xcalloc(n, sizeof(int)); g->pos_of = (int *) xcalloc(n, sizeof(int));
@@ -591,7 +611,9 @@ static gpu_group *group_for(int n, ocp_qp_in **ins, ocp_qp_gpu_ipm_memory **mems
     g->bk = (gpu_bucket *) xcalloc(cap_bk, sizeof(gpu_bucket));
     for (int i = 0; i < n; i++)
     {
-        const int len = fill_sig(ins[i], g->scratch);
+        /* an instance that does not take part while the group is built rides in the class of the first one that does */
+        const ocp_qp_in *in = skip && skip[i] ? ins[first] : ins[i];
+        const int len = fill_sig(in, g->scratch);
         int q = 0;
         for (; q < g->nbk; q++)
             if (g->bk[q].sig_len == len && memcmp(g->bk[q].sig, g->scratch, sizeof(int) * len) == 0) break;
@@ -616,7 +638,9 @@ static gpu_group *group_for(int n, ocp_qp_in **ins, ocp_qp_gpu_ipm_memory **mems
     for (int q = 0; q < g->nbk; q++)
     {
         gpu_bucket *bk = g->bk + q;
-        const ocp_qp_in *in0 = ins[bk->members[0]];
+        int rep = bk->members[0];
+        for (int e = 0; e < bk->n; e++) if (!(skip && skip[bk->members[e]])) { rep = bk->members[e]; break; }
+        const ocp_qp_in *in0 = skip && skip[rep] ? ins[first] : ins[rep];
         const int nst = in0->dim->N + 1;
         bk->seg_cap_in = nst * SEGS_IN_PER_STAGE; bk->seg_cap_out = nst * SEGS_OUT_PER_STAGE; bk->seg_cap_seed = nst * SEGS_SEED_PER_STAGE;
         bk->seg_in = (gpu_seg *) xcalloc(bk->seg_cap_in, sizeof(gpu_seg));
@@ -648,27 +672,46 @@ static gpu_group *group_for(int n, ocp_qp_in **ins, ocp_qp_gpu_ipm_memory **mems
  * qp_out[i]->misc answer for QP i exactly as after a single evaluate, and the sensitivity / solver_get slots called with
  * mem[i] address instance i of the shared batch.  Returns the worst status (0, else the first that is not MAXITER).
  */
-int ocp_qp_gpu_ipm_acados_evaluate_batch(void *config, int n, void **qp_in_, void **qp_out_, void *opts_, void **mem_, void *work)
+static int evaluate_batch_masked(void *config, int n, void **qp_in_, void **qp_out_, void *opts_, void **mem_, void *work,
+                                 const unsigned char *skip)
 {
+    /* skip[i] != 0: capsule i does not take part in this call (its SQP loop has ended or it waits elsewhere): its
+     * qp_in / qp_out are not touched, its slot of the device batch re-solves the data it holds -- the batch keeps its
+     * size, nothing is re-created while capsules drop out one by one */
     if (n <= 0) return ACADOS_SUCCESS;
     const double t_start = now_s();
     ocp_qp_in **ins = (ocp_qp_in **) qp_in_;
     ocp_qp_out **outs = (ocp_qp_out **) qp_out_;
     ocp_qp_gpu_ipm_memory **mems = (ocp_qp_gpu_ipm_memory **) mem_;
     ocp_qp_gpu_ipm_opts *o = (ocp_qp_gpu_ipm_opts *) opts_;
-    gpu_group *g = group_for(n, ins, mems);
+    int fresh = 0;
+    gpu_group *g = group_for(n, ins, mems, skip, &fresh);
+    if (!g) return ACADOS_SUCCESS;
     const int ws = o->warm_start >= 2 ? o->warm_start : 0;
 
     /* host threads: every member array of every qp_in, panel-major -> the bucket's pinned blob */
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < n; i++)
     {
+        if (skip && skip[i]) continue;
         const gpu_bucket *bk = g->bk + g->bucket_of[i];
         double *blob = bk->blob_in + (size_t) g->pos_of[i] * (size_t) bk->L_in;
         memset(blob, 0, sizeof(double) * (size_t) bk->L_in);
         unpack_qp_in(bk, ins[i], blob);
         if (ws >= 2) unpack_qp_out_duals(bk, outs[i], bk->blob_out + (size_t) g->pos_of[i] * (size_t) bk->L_out);
     }
+    if (skip && (fresh || ws >= 2))
+        for (int q = 0; q < g->nbk; q++)
+        {
+            /* a slot whose capsule is absent: in a new group it has no data yet -- it gets a copy of a present
+             * neighbour's QP; on a hot start its iterate is whatever the last gather left in the staging */
+            const gpu_bucket *bk = g->bk + q;
+            int src = -1;
+            for (int e = 0; e < bk->n && src < 0; e++) if (!skip[bk->members[e]]) src = e;
+            for (int e = 0; e < bk->n && src >= 0 && fresh; e++)
+                if (skip[bk->members[e]])
+                    memcpy(bk->blob_in + (size_t) e * (size_t) bk->L_in, bk->blob_in + (size_t) src * (size_t) bk->L_in, sizeof(double) * (size_t) bk->L_in);
+        }
     const double t_packed = now_s();
 
     /* one copy + one scatter launch, the solve, one gather launch + one copy per bucket; buckets run side by side
@@ -680,6 +723,7 @@ int ocp_qp_gpu_ipm_acados_evaluate_batch(void *config, int n, void **qp_in_, voi
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < n; i++)
     {
+        if (skip && skip[i]) continue;
         const gpu_bucket *bk = g->bk + g->bucket_of[i];
         pack_qp_out(bk, bk->blob_out + (size_t) g->pos_of[i] * (size_t) bk->L_out, outs[i]);
     }
@@ -688,6 +732,7 @@ int ocp_qp_gpu_ipm_acados_evaluate_batch(void *config, int n, void **qp_in_, voi
     int worst = 0;
     for (int i = 0; i < n; i++)
     {
+        if (skip && skip[i]) continue;
         const gpu_bucket *bk = g->bk + g->bucket_of[i];
         const int st = bk->st[g->pos_of[i]], it = bk->it[g->pos_of[i]];
         qp_info *info = (qp_info *) outs[i]->misc;
@@ -706,6 +751,107 @@ int ocp_qp_gpu_ipm_acados_evaluate_batch(void *config, int n, void **qp_in_, voi
         if (st != ACADOS_SUCCESS && (worst == 0 || worst == ACADOS_MAXITER)) worst = st;
     }
     return worst;
+}
+
+int ocp_qp_gpu_ipm_acados_evaluate_batch(void *config, int n, void **qp_in, void **qp_out, void *opts, void **mem, void *work)
+{
+    return evaluate_batch_masked(config, n, qp_in, qp_out, opts, mem, work, NULL);
+}
+
+/*
+ * The same batch WITHOUT touching ocp_nlp: the generated `_acados_batch_solve` keeps its loop
+ *     #pragma omp parallel for  ->  ocp_nlp_solve(capsule[i])                    (acados_solver.in.c:3232-3236)
+ * with one thread per capsule, every capsule's SQP loop reaches qp_solver->evaluate on its own (ocp_nlp_common.c:4517), and
+ * `evaluate` -- with a rendezvous in its opts -- parks the calling thread until every capsule still iterating has arrived;
+ * the last arrival sends all their QPs to the GPU as ONE batch, every thread returns with its own status and continues its
+ * own globalisation / termination test.  A capsule whose ocp_nlp_solve has returned leaves the rendezvous; its slot of the
+ * device batch rides along.  (Capsules share their solver options: the batch runs with the opts of the last arrival.)
+ */
+typedef struct ocp_qp_gpu_ipm_rendezvous_
+{
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    int n, next_index, active, arrived;
+    unsigned long round;
+    void **ins, **outs, **mems;
+    unsigned char *skip;     /* 1: not in this round */
+    void *config, *opts;
+} ocp_qp_gpu_ipm_rendezvous;
+
+ocp_qp_gpu_ipm_rendezvous *ocp_qp_gpu_ipm_acados_rendezvous_create(int n_capsules)
+{
+    ocp_qp_gpu_ipm_rendezvous *r = (ocp_qp_gpu_ipm_rendezvous *) xcalloc(1, sizeof(*r));
+    pthread_mutex_init(&r->mu, NULL);
+    pthread_cond_init(&r->cv, NULL);
+    r->n = r->active = n_capsules;
+    r->ins = (void **) xcalloc(n_capsules, sizeof(void *)); r->outs = (void **) xcalloc(n_capsules, sizeof(void *));
+    r->mems = (void **) xcalloc(n_capsules, sizeof(void *));
+    r->skip = (unsigned char *) xcalloc(n_capsules, 1);
+    memset(r->skip, 1, n_capsules);
+    return r;
+}
+
+void ocp_qp_gpu_ipm_acados_rendezvous_destroy(ocp_qp_gpu_ipm_rendezvous *r)
+{
+    if (!r) return;
+    pthread_mutex_destroy(&r->mu); pthread_cond_destroy(&r->cv);
+    free(r->ins); free(r->outs); free(r->mems); free(r->skip);
+    free(r);
+}
+
+/* every capsule takes part again (before the next `_acados_batch_solve`) */
+void ocp_qp_gpu_ipm_acados_rendezvous_reset(ocp_qp_gpu_ipm_rendezvous *r)
+{
+    pthread_mutex_lock(&r->mu);
+    r->active = r->n; r->arrived = 0;
+    memset(r->skip, 1, r->n);
+    pthread_mutex_unlock(&r->mu);
+}
+
+static void rendezvous_round(ocp_qp_gpu_ipm_rendezvous *r) /* mutex held */
+{
+    if (!r->mems[0])
+    {
+        /* slot 0 owns the device batches (group_for): it must have been filled once */
+        printf("\nerror: ocp_qp_gpu_ipm rendezvous: capsule 0 left before its first QP\n");
+        exit(1);
+    }
+    evaluate_batch_masked(r->config, r->n, r->ins, r->outs, r->opts, r->mems, NULL, r->skip);
+    memset(r->skip, 1, r->n);
+    r->arrived = 0;
+    r->round++;
+    pthread_cond_broadcast(&r->cv);
+}
+
+static int rendezvous_evaluate(ocp_qp_gpu_ipm_rendezvous *r, void *config, void *qp_in, void *qp_out, void *opts, ocp_qp_gpu_ipm_memory *m)
+{
+    pthread_mutex_lock(&r->mu);
+    if (m->rv_index < 0)
+    {
+        if (r->next_index >= r->n) { printf("\nerror: ocp_qp_gpu_ipm rendezvous: more capsules than it was created for (%d)\n", r->n); exit(1); }
+        m->rv_index = r->next_index++;
+    }
+    const int idx = m->rv_index;
+    r->ins[idx] = qp_in; r->outs[idx] = qp_out; r->mems[idx] = m; r->skip[idx] = 0;
+    r->config = config; r->opts = opts;
+    r->arrived++;
+    if (r->arrived >= r->active) rendezvous_round(r);
+    else
+    {
+        const unsigned long my = r->round;
+        while (r->round == my) pthread_cond_wait(&r->cv, &r->mu);
+    }
+    pthread_mutex_unlock(&r->mu);
+    return m->status;
+}
+
+/* capsule done (its ocp_nlp_solve returned): the others no longer wait for it */
+void ocp_qp_gpu_ipm_acados_rendezvous_leave(ocp_qp_gpu_ipm_rendezvous *r)
+{
+    pthread_mutex_lock(&r->mu);
+    r->active--;
+    if (r->arrived > 0 && r->arrived >= r->active) rendezvous_round(r);
+    pthread_mutex_unlock(&r->mu);
 }
 
 /* where the QP of this memory was solved last */

@@ -16,8 +16,15 @@
  *       seeds.  out.bin: per instance the solution (and then the sensitivities) as raw doubles
  *       [ux_0..ux_N, pi_0..pi_{N-1}, lam_0..lam_N, t_0..t_N]; stdout: one line "batch n .. ms_per_call .. status ..",
  *       then per instance "i status iter".
+ *
+ *   driver rendezvous <n> <qp.txt> <out.bin>
+ *       what an UNMODIFIED `_acados_batch_solve` does (acados_solver.in.c:3232-3236): n threads, each running its own
+ *       capsule's loop -- capsule i makes 1 + i % 3 "SQP iterations" (vectors perturbed, then the plugin's `evaluate` SLOT
+ *       through the vtable) and returns.  With a rendezvous in the solver options the n evaluates of an iteration reach the
+ *       GPU as one batch although nobody calls a batch entry.  out.bin: every capsule's last solution.
  */
 #include <math.h>
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -28,6 +35,9 @@
 void ocp_qp_gpu_ipm_acados_config_initialize_default(void *config_);
 int ocp_qp_gpu_ipm_acados_evaluate_batch(void *config, int n, void **qp_in, void **qp_out, void *opts, void **mem, void *work);
 void ocp_qp_gpu_ipm_acados_eval_sens_batch(void *config, int n, void **qp_in, void **seed, void **sens_qp_out, void *opts, void **mem, void *work);
+void *ocp_qp_gpu_ipm_acados_rendezvous_create(int n_capsules);
+void ocp_qp_gpu_ipm_acados_rendezvous_destroy(void *r);
+void ocp_qp_gpu_ipm_acados_rendezvous_leave(void *r);
 
 static double now_s(void)
 {
@@ -127,9 +137,64 @@ static int run_batch(int argc, char **argv)
     return 0;
 }
 
+typedef struct
+{
+    qp_solver_config *config;
+    mock_capsule *cap;
+    void *opts, *mem, *rv;
+    int index, iters, status, qp_iter_last;
+} rv_thread;
+
+static void *rv_capsule_loop(void *arg)
+{
+    rv_thread *t = (rv_thread *) arg;
+    for (int j = 0; j < t->iters; j++)
+    {
+        mock_perturb(t->cap, t->index + 100 * j);   /* "linearisation": new vectors */
+        t->status = t->config->evaluate(t->config, &t->cap->qp, &t->cap->sol, t->opts, t->mem, NULL);
+        t->qp_iter_last = t->cap->info.num_iter;
+    }
+    ocp_qp_gpu_ipm_acados_rendezvous_leave(t->rv);  /* ocp_nlp_solve returned */
+    return NULL;
+}
+
+static int run_rendezvous(int argc, char **argv)
+{
+    if (argc < 5) return 2;
+    const int n = atoi(argv[2]);
+    qp_solver_config config;
+    memset(&config, 0, sizeof(config));
+    ocp_qp_gpu_ipm_acados_config_initialize_default(&config);
+    void *rv = ocp_qp_gpu_ipm_acados_rendezvous_create(n);
+    rv_thread *th = calloc(n, sizeof(*th));
+    pthread_t *tid = calloc(n, sizeof(*tid));
+    for (int i = 0; i < n; i++)
+    {
+        th[i].config = &config; th[i].cap = mock_load_qp(argv[3]); th[i].index = i; th[i].iters = 1 + i % 3; th[i].rv = rv;
+        th[i].opts = make_opts(&config, &th[i].cap->dim);          /* every capsule has its own opts object, as in acados */
+        config.opts_set(&config, th[i].opts, "rendezvous", rv);
+        th[i].mem = config.memory_assign(&config, &th[i].cap->dim, th[i].opts, calloc(1, config.memory_calculate_size(&config, &th[i].cap->dim, th[i].opts)));
+    }
+    for (int i = 0; i < n; i++) pthread_create(tid + i, NULL, rv_capsule_loop, th + i);
+    for (int i = 0; i < n; i++) pthread_join(tid[i], NULL);
+    FILE *g = fopen(argv[4], "wb");
+    for (int i = 0; i < n; i++)
+    {
+        int st = -1;
+        config.memory_get(&config, th[i].mem, "status", &st);
+        printf("%d %d %d %d\n", i, th[i].status, st, th[i].qp_iter_last);
+        mock_write_sol_bin(g, &th[i].cap->dim, &th[i].cap->sol);
+    }
+    fclose(g);
+    config.terminate(&config, th[0].mem, NULL);
+    ocp_qp_gpu_ipm_acados_rendezvous_destroy(rv);
+    return 0;
+}
+
 int main(int argc, char **argv)
 {
     if (argc >= 2 && !strcmp(argv[1], "batch")) return run_batch(argc, argv);
+    if (argc >= 2 && !strcmp(argv[1], "rendezvous")) return run_rendezvous(argc, argv);
     if (argc < 3) return 2;
     mock_capsule *c = mock_load_qp(argv[1]);
     struct d_ocp_qp_dim *dim = &c->dim;

@@ -27,7 +27,7 @@ def _build(libpath, tmp_path):
     libdir, libname = os.path.dirname(libpath), os.path.basename(libpath)
     cmd = ["gcc", "-std=gnu11", "-O2", "-fopenmp", "-Wall", "-Wno-unused-parameter", "-I", os.path.join(MOCK, "include"), "-I", os.path.join(ROOT, "include"),
            os.path.join(MOCK, "driver.c"), os.path.join(ROOT, "integration", "ocp_qp_gpu_ipm.c"), "-o", exe,
-           "-L", libdir, "-l:" + libname, "-Wl,-rpath," + libdir, "-lm"]
+           "-L", libdir, "-l:" + libname, "-Wl,-rpath," + libdir, "-lm", "-lpthread"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     return exe
@@ -340,3 +340,35 @@ def test_acados_adapter_batch_1024_c2(gpu_lib, tmp_path):
     # 12 ms per call was the bar set by the review (plain containers: 11.9 ms); ceiling with headroom for a slow box, the
     # measured number is printed
     assert info["ms_per_call"] <= 16.0, info
+
+
+@pytest.mark.parametrize("clib", TIERS, indirect=True)
+def test_acados_adapter_rendezvous_unmodified_batch_loop(clib, tmp_path):
+    """what an UNMODIFIED `_acados_batch_solve` does (acados_solver.in.c:3232-3236) -- one thread per capsule, each calling
+    the plugin's `evaluate` SLOT from its own loop, capsule i for 1 + i % 3 iterations -- with a rendezvous in the solver
+    options: the evaluates of an iteration are collected into one device batch, capsules that have finished leave and
+    their slot rides along.  Every capsule's last solution against the oracle on its own (cumulatively perturbed) QP."""
+    from acados_amd.generators import mass_spring_qp
+    qp = mass_spring_qp(N=5)
+    exe = _build(clib._name, tmp_path)
+    f, out = str(tmp_path / "qp.txt"), str(tmp_path / "rv.bin")
+    _write_qp(qp, f)
+    n = 7
+    r = subprocess.run([exe, "rendezvous", str(n), f, out], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    per = [tuple(int(x) for x in ln.split()) for ln in r.stdout.strip().splitlines()[:n]]
+    raw = np.fromfile(out)
+    p = 0
+    for i in range(n):
+        qi = qp
+        for j in range(1 + i % 3):
+            qi = _perturbed(qi, i + 100 * j)
+        sol, used = _split_bin(qi, raw[p:]); p += used
+        o = OracleQp(qi)
+        assert o.solve(default_opts(tol_stat=1e-8)) == 0
+        assert per[i][0] == i and per[i][1] == 0 and per[i][2] == 0 and abs(per[i][3] - o.iter) <= 1, (per[i], o.iter)
+        for k in range(qi.N + 1):
+            ref = np.concatenate([o.get(k, "u"), o.get(k, "x")])
+            assert np.allclose(sol[("ux", k)], ref, rtol=1e-7, atol=1e-8), (i, k)
+            assert np.allclose(sol[("lam", k)], o.get(k, "lam"), rtol=1e-5, atol=1e-6)
+    assert p == raw.size
