@@ -483,7 +483,8 @@ __global__ void __launch_bounds__(64) W16R_WPE_FACT ky_factor(GqpDev D, GqpOpts 
     typedef W16RLds<NX, NU, NG> LY;
     constexpr bool GEN = NG > 0; /* general rows and slacks (one slack per row): rows through w16r_row_factor */
     constexpr int n = NX + NU, R = LY::R, NP = LY::NP, NB = LY::NB, NGP = (NG * n + 15) / 16;
-    const int l = threadIdx.x & 15, rq = threadIdx.x >> 4;
+    int l = threadIdx.x & 15;
+    const int rq = threadIdx.x >> 4;
     /* Liveness per 16-lane row.  No row leaves the kernel while another one of the wave is alive: all 64 lanes take part
      * in the LDS-DMA of every live row.  A dead row (converged instance, or beyond the batch) computes on the data of a
      * valid instance and writes nothing. */
@@ -599,6 +600,11 @@ __global__ void __launch_bounds__(64) W16R_WPE_FACT ky_factor(GqpDev D, GqpOpts 
             isx[s] = row[s] >= NU && row[s] < n;
             cx[s] = isx[s] ? row[s] - NU : 0;
         }
+        /* GEN: the same for the instance and the lane index.  Everything derived from them alone -- the lane's base address
+         * in each of the ~20 arrays the stage touches, the element indices of the general rows -- is loop invariant, gets
+         * hoisted out of the stage loop, lives across its register peak and was spilled: 80 registers, reloaded from
+         * scratch one by one in front of the loads they address.  Recomputing them per stage costs a multiply-add each. */
+        if (GEN) { W16R_OPAQUE(inst); W16R_OPAQUE(l); }
         /* GEN: the vectors and the general rows of the stage are loaded HERE, in front of the wait for the DMA'd blocks (one
          * exposed latency), not one stage ahead: the register file of this variant has no room for values that live across
          * the stage, and a prefetched value that is spilled on arrival waits alone behind its own load -- thirty serialised
@@ -650,24 +656,35 @@ __global__ void __launch_bounds__(64) W16R_WPE_FACT ky_factor(GqpDev D, GqpOpts 
         /* ---- symmetric row of H from the packed block: H[row][c] = packed[PK(row, c)] for c <= row, packed[PK(c, row)]
          * above.  A slot knows at compile time which one it is except inside its own 16 x 16 diagonal block, where both
          * are read and the lane picks (every access: lane base + immediate offset) ---- */
-        W16_UNROLL for (int s = 0; s < R; s++)
+        auto load_M = [&]()
         {
-            const double zm = mine[s] ? 1.0 : 0.0;
-            const double *lowp = HRq + PK(lc_[s], 0), *upp = HRq + lc_[s];
-            W16_UNROLL for (int c = 0; c < n; c++)
+            W16_UNROLL for (int s = 0; s < R; s++)
             {
-                double h;
-                if (c < 16 * s) h = lowp[c];
-                else if (c > 16 * s + 15) h = upp[PK(c, 0)];
-                else
+                const double zm = mine[s] ? 1.0 : 0.0;
+                const double *lowp = HRq + PK(lc_[s], 0), *upp = HRq + lc_[s];
+                W16_UNROLL for (int c = 0; c < n; c++)
                 {
-                    const double lo = lowp[c < n - 1 ? c : n - 1], up = upp[PK(c, 0)];
-                    h = c <= lc_[s] ? lo : up;
+                    double h;
+                    if (c < 16 * s) h = lowp[c];
+                    else if (c > 16 * s + 15) h = upp[PK(c, 0)];
+                    else if (GEN) h = *(c <= lc_[s] ? lowp + c : upp + PK(c, 0)); /* the lane picks the ADDRESS: one read */
+                    else
+                    {
+                        const double lo = lowp[c < n - 1 ? c : n - 1], up = upp[PK(c, 0)];
+                        h = c <= lc_[s] ? lo : up;
+                    }
+                    M[s][c] = zm * h;
                 }
-                M[s][c] = zm * h;
+                if (GEN) W16R_FENCE(); /* slot by slot: all reads of both slots in flight at once was the register peak of the stage */
             }
-        }
-        if (k > 0) dma_h(k - 1);
+            if (k > 0) dma_h(k - 1);
+        };
+        /* GEN: the rows of H come AFTER the inequality rows.  The row functions keep ~40 loaded values and as many addresses
+         * alive per lane; with the 54 entries of M beside them (and the previous factor's x-block, which must stay) the
+         * register file overflowed: 126 spilled registers, and their scratch traffic -- 16,384 instances x 256 B per
+         * register -- is HBM traffic (the factor launch moved 2.26x its algorithmic bytes).  H v then takes its own pass of
+         * broadcasts of v (n DPP moves), which is nothing beside a spill. */
+        if (!GEN) load_M();
         W16R_TICK(0);
 
         /* ---- rb += [B A] v (column cx of [B A]'), H v: one broadcast of v per variable serves both ---- */
@@ -679,10 +696,10 @@ __global__ void __launch_bounds__(64) W16R_WPE_FACT ky_factor(GqpDev D, GqpOpts 
             W16_UNROLL for (int s = 0; s < R; s++)
             {
                 rb[s] += BRq[r * NX + xc_[s]] * vr; /* idle slots: clamped column, value unused */
-                hv[s] += M[s][r] * vr;
+                if (!GEN) hv[s] += M[s][r] * vr;
             }
         }
-        W16_UNROLL for (int s = 0; s < R; s++) { W16R_OPAQUE(rb[s]); W16R_OPAQUE(hv[s]); }
+        W16_UNROLL for (int s = 0; s < R; s++) { W16R_OPAQUE(rb[s]); if (!GEN) W16R_OPAQUE(hv[s]); }
         W16R_TICK(1);
         double gtr[R], gar[R], gmr[R]; /* GEN: what the inequality rows add to the stationarity residual / gradient / Hessian diagonal */
         W16_UNROLL for (int s = 0; s < R; s++) { gtr[s] = 0.0; gar[s] = 0.0; gmr[s] = 0.0; }
@@ -728,24 +745,49 @@ __global__ void __launch_bounds__(64) W16R_WPE_FACT ky_factor(GqpDev D, GqpOpts 
             W16_UNROLL for (int g = 0; g < NG; g++)
             {
                 const int rg_ = nbf + g < 16 ? nbf + g : 15;
-                const double Gg = g < ng ? RW[16 + rg_] : 0.0, Ag = g < ng ? RW[32 + rg_] : 0.0, Lg = g < ng ? RW[48 + rg_] : 0.0;
+                const double Ag = g < ng ? RW[32 + rg_] : 0.0, Lg = g < ng ? RW[48 + rg_] : 0.0;
                 W16_UNROLL for (int s = 0; s < R; s++)
                 {
                     const double ap = mine[s] ? GTq[g * n + lc_[s]] : 0.0;
                     gtr[s] += ap * Lg;
                     gar[s] += ap * Ag;
-                    const double ga = Gg * ap;
-                    W16_UNROLL for (int c = 0; c < n; c++)
-                        if (W16R_LOW(s, c)) M[s][c] += ga * GTq[g * n + c];
                 }
             }
+            W16_UNROLL for (int s = 0; s < R; s++) { W16R_OPAQUE(gtr[s]); W16R_OPAQUE(gar[s]); W16R_OPAQUE(gmr[s]); }
             W16R_TICK(9);
-            W16_UNROLL for (int s = 0; s < R; s++)
+            /* now the rows of H, H v, and the general rows' rank-one terms M += gamma a a' (gamma of row g still sits in the
+             * row vector, a in the LDS copy of [D C]) */
+            load_M();
+            W16_UNROLL for (int r = 0; r < n; r++)
             {
-                W16R_OPAQUE(gtr[s]); W16R_OPAQUE(gar[s]); W16R_OPAQUE(gmr[s]);
+                const double vr = W16R_BC(v, r);
+                W16_UNROLL for (int s = 0; s < R; s++) hv[s] += M[s][r] * vr;
+            }
+            W16_UNROLL for (int s = 0; s < R; s++) W16R_OPAQUE(hv[s]);
+            int zg = 0; /* always zero; laundered through the previous row's result: the reads of row g + 1 depend on it */
+            W16_UNROLL for (int g = 0; g < NG; g++)
+            {
+                /* one general row at a time: hoisted together, the NG x n reads of [D C] were the register peak of the stage */
+                const double *Gr = GTq + zg + g * n;
+                const int rg_ = nbf + g < 16 ? nbf + g : 15;
+                const double Gg = g < ng ? RW[16 + rg_] : 0.0;
+                W16_UNROLL for (int s = 0; s < R; s++)
+                {
+                    const double ga = Gg * (mine[s] ? Gr[lc_[s]] : 0.0);
+                    W16_UNROLL for (int c = 0; c < n; c++)
+                        if (W16R_LOW(s, c)) M[s][c] += ga * Gr[c];
+                }
+                /* every multiply-add of this row in place before the next row's reads are issued */
+                W16_UNROLL for (int s = 0; s < R; s++)
+                    W16_UNROLL for (int c = 0; c < n; c++)
+                        if (W16R_LOW(s, c)) W16R_OPAQUE(M[s][c]);
+#if defined(__HIP_DEVICE_COMPILE__)
+                asm volatile("" : "+v"(zg) : "v"(M[R - 1][0]));
+#endif
+            }
+            W16_UNROLL for (int s = 0; s < R; s++)
                 W16_UNROLL for (int c = 0; c < n; c++)
                     if (W16R_LOW(s, c)) W16R_OPAQUE(M[s][c]);
-            }
         }
         /* ---- W rows: W[c] = sum_{q >= c} Br[q] Lx+[q][c]: Lx+[q][c] is entry c of the register row of the slot that
          * holds state q, one broadcast feeds both slots; [B A]' pi+ rides along ---- */
@@ -939,6 +981,7 @@ __global__ void __launch_bounds__(64) W16R_WPE_FACT ky_factor(GqpDev D, GqpOpts 
         W16R_TICK(5);
 
         /* ---- outputs: the rows of the factor from registers (both LDS regions are being filled for the next stage) ---- */
+        if (GEN) W16R_OPAQUE(inst); /* the store addresses are formed here, not at the top of the stage (see there) */
         W16_UNROLL for (int s = 0; s < R; s++)
             if (mine[s] && alive)
             {
