@@ -302,6 +302,7 @@ void *ocp_qp_gpu_pcond_memory_assign(void *dims_, void *opts_, void *raw_memory)
     mem->time_qp_xcond = 0.0;
     mem->ptr_qp_in = nullptr;
     mem->ptr_pcond_qp_in = nullptr;
+    mem->ptr_qp_seed = nullptr;
     mem->dims = dims;
     return mem;
 }
@@ -464,30 +465,97 @@ static void copy_seed(const ocp_qp_seed *a, ocp_qp_seed *b)
     }
 }
 
+/* Seeds through the condensing (N2 < N).  Vector condensing is LINEAR and homogeneous in the vector data (b, r, q, zl, zu,
+ * bounds): the condensed gradient is Gamma'(H c + g) with c the block's accumulated offsets, the condensed bounds are
+ * d - a_x'c, the condensed dynamics offset is the block's c -- no constant term.  So the condensed seed is the vector
+ * condensing (condense_rhs) of a QP with the SAME matrices whose vectors are the seeds, and the expansion of the condensed
+ * sensitivities is the expansion kernel run on that QP: dx+ = A dx + B du + seed_b, d pi from stationarity with seed_q,
+ * dt = d(row value) - seed_d.  The device batch of the module holds the original QP: its vector fields are overwritten
+ * by the seeds for the duration of the call and restored from qp_in afterwards.  (HPIPM: d_part_cond_qp_cond_seed /
+ * d_part_cond_qp_expand_sol_seed, ocp_qp_partial_condensing.c:634-662, 691-717.) */
+static void seed_vectors_to_device(ocp_qp_gpu_batch *b, const ocp_qp_dims *d, const ocp_qp_seed *sd)
+{
+    for (int k = 0; k <= d->N; k++)
+    {
+        const int nu = d->nu[k], nx = d->nx[k], ns = d->ns[k], nbu = d->nbu[k], nbx = d->nbx[k], nb = d->nb[k], ng = d->ng[k];
+        double *g = sd->seed_g[k], *dd = sd->seed_d[k];
+        struct { const char *name; double *p; int n; } f[] = {
+            {"r", g, nu}, {"q", g + nu, nx}, {"zl", g + nu + nx, ns}, {"zu", g + nu + nx + ns, ns},
+            {"b", k < d->N ? sd->seed_b[k] : nullptr, k < d->N ? d->nx[k + 1] : 0},
+            {"lbu", dd, nbu}, {"lbx", dd + nbu, nbx}, {"lg", dd + nb, ng},
+            {"ubu", dd + nb + ng, nbu}, {"ubx", dd + nb + ng + nbu, nbx}, {"ug", dd + 2 * nb + ng, ng},
+            {"lls", dd + 2 * nb + 2 * ng, ns}, {"lus", dd + 2 * nb + 2 * ng + ns, ns}};
+        for (auto &e : f)
+            if (e.n > 0) ocp_qp_gpu_batch_set(b, e.name, k, e.p, 0);
+    }
+}
+
+static void seed_vectors_from_device(ocp_qp_gpu_batch *c, const ocp_qp_dims *d, ocp_qp_seed *sd)
+{
+    for (int k = 0; k <= d->N; k++)
+    {
+        const int nu = d->nu[k], nx = d->nx[k], ns = d->ns[k], nbu = d->nbu[k], nbx = d->nbx[k], nb = d->nb[k], ng = d->ng[k];
+        double *g = sd->seed_g[k], *dd = sd->seed_d[k];
+        struct { const char *name; double *p; int n; } f[] = {
+            {"r", g, nu}, {"q", g + nu, nx}, {"zl", g + nu + nx, ns}, {"zu", g + nu + nx + ns, ns},
+            {"b", k < d->N ? sd->seed_b[k] : nullptr, k < d->N ? d->nx[k + 1] : 0},
+            {"lbu", dd, nbu}, {"lbx", dd + nbu, nbx}, {"lg", dd + nb, ng},
+            {"ubu", dd + nb + ng, nbu}, {"ubx", dd + nb + ng + nbu, nbx}, {"ug", dd + 2 * nb + ng, ng},
+            {"lls", dd + 2 * nb + 2 * ng, ns}, {"lus", dd + 2 * nb + 2 * ng + ns, ns}};
+        for (auto &e : f)
+            if (e.n > 0) ocp_qp_gpu_batch_get(c, e.name, k, e.p, 0);
+        memset(sd->seed_m[k], 0, sizeof(double) * 2 * (nb + ng + ns));
+    }
+}
+
 /* :634-660 */
 int ocp_qp_gpu_pcond_condense_rhs_seed(void *qp_in_, void *seed_, void *pcond_seed_, void *opts_, void *mem_, void *work)
 {
+    ocp_qp_in *qp_in = (ocp_qp_in *) qp_in_;
+    ocp_qp_seed *seed = (ocp_qp_seed *) seed_, *xs = (ocp_qp_seed *) pcond_seed_;
+    ocp_qp_partial_condensing_opts *opts = (ocp_qp_partial_condensing_opts *) opts_;
     ocp_qp_partial_condensing_memory *mem = (ocp_qp_partial_condensing_memory *) mem_;
-    if (mem->dims->condensed)
+    const double t0 = now_s();
+    mem->ptr_qp_in = qp_in;
+    mem->ptr_qp_seed = seed;
+    if (!mem->dims->condensed) copy_seed(seed, xs);
+    else
     {
-        printf("\nerror: partial condensing on the device: seeds are not condensed (N2 < N); the xcond-solver vtable of this "
-               "backend evaluates sensitivities in the full space at the expanded solution (eval_forw_sens / eval_adj_sens)\n");
-        exit(1);
+        ocp_qp_gpu_batch *b = pcond_load(mem, opts, qp_in);   /* matrices (and, for now, the vectors) of qp_in */
+        if (ocp_qp_gpu_batch_condense_lhs(b) != 0) return ACADOS_QP_FAILURE;
+        seed_vectors_to_device(b, qp_in->dim, seed);
+        ocp_qp_gpu_batch *c = ocp_qp_gpu_batch_condense_rhs(b);
+        if (!c) return ACADOS_QP_FAILURE;
+        seed_vectors_from_device(c, xs->dim, xs);
+        if (gqp_host::single_batch_load_in(&((pcond_device *) mem->device)->sb, qp_in) != 0) return ACADOS_QP_FAILURE; /* vectors back */
     }
-    copy_seed((const ocp_qp_seed *) seed_, (ocp_qp_seed *) pcond_seed_);
+    mem->time_qp_xcond += now_s() - t0;
     return ACADOS_SUCCESS;
 }
 
 /* :691-716 */
 int ocp_qp_gpu_pcond_expand_sol_seed(void *pcond_qp_out_, void *qp_out_, void *opts_, void *mem_, void *work)
 {
+    ocp_qp_out *xo = (ocp_qp_out *) pcond_qp_out_, *out = (ocp_qp_out *) qp_out_;
     ocp_qp_partial_condensing_memory *mem = (ocp_qp_partial_condensing_memory *) mem_;
-    if (mem->dims->condensed)
+    const double t0 = now_s();
+    if (!mem->dims->condensed) copy_qp_out(xo, out);
+    else
     {
-        printf("\nerror: partial condensing on the device: seeds are not condensed (N2 < N), see condense_rhs_seed\n");
-        exit(1);
+        pcond_device *dev = (pcond_device *) mem->device;
+        ocp_qp_gpu_batch *b = dev->sb.batch, *c = b ? ocp_qp_gpu_batch_condensed(b) : nullptr;
+        if (!c || !mem->ptr_qp_in || !mem->ptr_qp_seed)
+        {
+            printf("\nerror: partial condensing: expand_sol_seed before condense_rhs_seed\n");
+            return ACADOS_QP_FAILURE;
+        }
+        seed_vectors_to_device(b, mem->ptr_qp_in->dim, mem->ptr_qp_seed);
+        gqp_host::single_batch_push_out(c, xo->dim, xo);
+        if (ocp_qp_gpu_batch_expand(b) != 0) return ACADOS_QP_FAILURE;
+        gqp_host::single_batch_pull_out(b, out->dim, out);
+        if (gqp_host::single_batch_load_in(&dev->sb, mem->ptr_qp_in) != 0) return ACADOS_QP_FAILURE;
     }
-    copy_qp_out((const ocp_qp_out *) pcond_qp_out_, (ocp_qp_out *) qp_out_);
+    mem->time_qp_xcond += now_s() - t0;
     return ACADOS_SUCCESS;
 }
 

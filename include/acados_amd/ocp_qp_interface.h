@@ -255,6 +255,7 @@ typedef struct
     double time_qp_xcond;
     ocp_qp_in *ptr_qp_in;
     ocp_qp_in *ptr_pcond_qp_in;
+    ocp_qp_seed *ptr_qp_seed; /* seed of the last condense_rhs_seed (needed by expand_sol_seed, :648) */
     ocp_qp_partial_condensing_dims *dims;
     void *device;            /* device-side state (the original QP as a one-instance HBM batch) */
 } ocp_qp_partial_condensing_memory;

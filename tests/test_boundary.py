@@ -375,6 +375,84 @@ def test_condensing_slots_composed_like_xcond_solve(clib, monkeypatch):
     assert q_evaluate(qcfg, xcond_in, xcond_out, qopts, qmem, None) == 0
     assert expansion(xcond_out, qp_out, xopts, xmem, None) == 0
     check()
+    # ---- sensitivities through the condensing, line by line (ocp_qp_xcond_solver.c:680-697): condense_rhs_seed ->
+    # qp_solver->eval_forw_sens on the condensed QP -> expand_sol_seed; against ONE dense solve of the linearised KKT system
+    # of the ORIGINAL QP at the oracle's solution (tests/dense_ref.py) ----
+    from dense_ref import sens_dense
+    condense_rhs_seed, expand_sol_seed = F(ci, vp, vp, vp, vp, vp, vp)(xc[15]), F(ci, vp, vp, vp, vp, vp)(xc[19])
+    q_eval_forw_sens = F(None, vp, vp, vp, vp, vp, vp, vp)(inner[14])
+    xcond_seed = vp()
+    x_mem_get(xcfg, xmem, b"xcond_seed", C.byref(xcond_seed))
+
+    class _Dims(C.Structure):
+        _fields_ = [("N", ci)] + [(n_, C.POINTER(ci)) for n_ in ("nx", "nu", "nb", "nbx", "nbu", "ng", "ns", "nbxe", "nbue", "nge")]
+
+    class _Seed(C.Structure):
+        _fields_ = [("dim", C.POINTER(_Dims))] + [(n_, C.POINTER(C.POINTER(C.c_double))) for n_ in ("seed_g", "seed_b", "seed_d", "seed_m")]
+
+    class _In(C.Structure):
+        _fields_ = [("dim", C.POINTER(_Dims))]
+
+    L.ocp_qp_seed_create.restype, L.ocp_qp_seed_create.argtypes = vp, [vp]
+    L.ocp_qp_out_create.restype, L.ocp_qp_out_create.argtypes = vp, [vp]
+    dim_ptr = C.cast(qp_in, C.POINTER(_In)).contents.dim
+    seed = vp(L.ocp_qp_seed_create(dim_ptr))
+    sens_out = vp(L.ocp_qp_out_create(dim_ptr))
+    sd = C.cast(seed, C.POINTER(_Seed)).contents
+    rng = np.random.default_rng(5)
+    d = qp.dims
+    seeds = {}
+    for k in range(N + 1):
+        nu, nx, nbu, nbx = int(d.nu[k]), int(d.nx[k]), int(d.nbu[k]), int(d.nbx[k])
+        seeds[("r", k)], seeds[("q", k)] = rng.standard_normal(nu), rng.standard_normal(nx)
+        if k < N:
+            seeds[("b", k)] = rng.standard_normal(int(d.nx[k + 1]))
+        seeds[("lbu", k)], seeds[("ubu", k)] = 0.1 * rng.standard_normal(nbu), 0.1 * rng.standard_normal(nbu)
+        if k == 0:
+            e = rng.standard_normal(nbx)
+            seeds[("lbx", 0)], seeds[("ubx", 0)] = e, e          # x0: both sides, ocp_nlp_common.c:4057-4066
+        else:
+            seeds[("lbx", k)], seeds[("ubx", k)] = 0.1 * rng.standard_normal(nbx), 0.1 * rng.standard_normal(nbx)
+        nb = nbu + nbx
+        g = np.concatenate([seeds[("r", k)], seeds[("q", k)]])
+        for e_, v_ in enumerate(g):
+            sd.seed_g[k][e_] = v_
+        if k < N:
+            for e_, v_ in enumerate(seeds[("b", k)]):
+                sd.seed_b[k][e_] = v_
+        dd = np.concatenate([seeds[("lbu", k)], seeds[("lbx", k)], seeds[("ubu", k)], seeds[("ubx", k)]])   # natural sign (this library's containers)
+        assert dd.size == 2 * nb
+        for e_, v_ in enumerate(dd):
+            sd.seed_d[k][e_] = v_
+    assert condensing(qp_in, xcond_in, xopts, xmem, None) == 0
+    assert q_evaluate(qcfg, xcond_in, xcond_out, qopts, qmem, None) == 0      # factorisation at the condensed solution
+    assert expansion(xcond_out, qp_out, xopts, xmem, None) == 0
+    assert condense_rhs_seed(qp_in, seed, xcond_seed, xopts, xmem, None) == 0
+    q_eval_forw_sens(qcfg, xcond_in, xcond_seed, xcond_out, qopts, qmem, None)
+    assert expand_sol_seed(xcond_out, sens_out, xopts, xmem, None) == 0
+    ref = sens_dense(qp, o.get, seeds)
+    scale = max(1.0, max(np.max(np.abs(ref(k, f))) for k in range(N + 1) for f in ("x", "u") if ref(k, f).size))
+    worst = 0.0
+    for k in range(N + 1):
+        for f in ("x", "u", "pi"):
+            if f == "pi" and k == N:
+                continue
+            got = drv.get(k, f, unique_duals=False, _c_out=sens_out)
+            err = np.max(np.abs(got - ref(k, f))) / scale if got.size else 0.0
+            assert err <= 1e-5, (k, f, err, got, ref(k, f))
+            worst = max(worst, err)
+        got, want = drv.get(k, "lam", unique_duals=False, _c_out=sens_out), ref(k, "lam")
+        sel = np.array([(k, e_) in ref.active for e_ in range(want.size)], dtype=bool)
+        if sel.any():
+            assert np.max(np.abs(got[sel] - want[sel])) <= 1e-3 * max(scale, np.max(np.abs(want[sel]))), (k, got[sel], want[sel])
+    print("sensitivities through condense_rhs_seed / expand_sol_seed vs dense KKT solve:", worst)
+    # the evaluate after it still solves the ORIGINAL data (the seed pass restored the vectors)
+    assert condensing(qp_in, xcond_in, xopts, xmem, None) == 0
+    assert q_evaluate(qcfg, xcond_in, xcond_out, qopts, qmem, None) == 0
+    assert expansion(xcond_out, qp_out, xopts, xmem, None) == 0
+    check()
+    L.ocp_qp_seed_free(seed)
+    L.ocp_qp_out_free(sens_out)
     q_terminate(qcfg, qmem, None)
     L.ocp_qp_gpu_pcond_memory_release.argtypes = [vp]
     L.ocp_qp_gpu_pcond_memory_release(xmem)
