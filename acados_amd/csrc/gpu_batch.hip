@@ -2348,6 +2348,10 @@ struct ocp_qp_gpu_comm
     int (*get_uid)(uid *) = nullptr;
     int (*init_rank)(void **, int, uid, int) = nullptr;
     int (*all_gather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*group_start)() = nullptr;
+    int (*group_end)() = nullptr;
     int (*destroy)(void *) = nullptr;
     const char *(*err)(int) = nullptr;
 };
@@ -2367,6 +2371,10 @@ static bool rccl_bind(ocp_qp_gpu_comm *c)
     c->get_uid = (int (*)(ocp_qp_gpu_comm::uid *)) dlsym(c->lib, "ncclGetUniqueId");
     c->init_rank = (int (*)(void **, int, ocp_qp_gpu_comm::uid, int)) dlsym(c->lib, "ncclCommInitRank");
     c->all_gather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t)) dlsym(c->lib, "ncclAllGather");
+    c->send = (int (*)(const void *, size_t, int, int, void *, hipStream_t)) dlsym(c->lib, "ncclSend");
+    c->recv = (int (*)(void *, size_t, int, int, void *, hipStream_t)) dlsym(c->lib, "ncclRecv");
+    c->group_start = (int (*)()) dlsym(c->lib, "ncclGroupStart");
+    c->group_end = (int (*)()) dlsym(c->lib, "ncclGroupEnd");
     c->destroy = (int (*)(void *)) dlsym(c->lib, "ncclCommDestroy");
     c->err = (const char *(*)(int)) dlsym(c->lib, "ncclGetErrorString");
     if (!c->get_uid || !c->init_rank || !c->all_gather || !c->destroy)
@@ -2420,7 +2428,10 @@ void ocp_qp_gpu_comm_destroy(ocp_qp_gpu_comm *c)
     delete c;
 }
 
-int ocp_qp_gpu_batch_gather(ocp_qp_gpu_batch *b, ocp_qp_gpu_comm *c, double *sol_all, int *info_all, double *time_all)
+/* root < 0: all-gather (every rank receives everything); root >= 0: gather to that rank (point-to-point sends over xGMI
+ * inside one RCCL group: every other rank moves 1x its payload instead of receiving n_ranks x -- SURVEY 5 costs the
+ * 8-GPU C2 payload at 5.5 ms this way against ~40 ms for the ring all-gather); the buffers of the other ranks may be NULL */
+static int gather_impl(ocp_qp_gpu_batch *b, ocp_qp_gpu_comm *c, int root, double *sol_all, int *info_all, double *time_all)
 {
     HIPCHK(hipSetDevice(b->device));
     const int len = ocp_qp_gpu_batch_bulk_len(b, 1);
@@ -2437,11 +2448,44 @@ int ocp_qp_gpu_batch_gather(ocp_qp_gpu_batch *b, ocp_qp_gpu_comm *c, double *sol
     hipLaunchKernelGGL(gqp::k_pack_info, dim3((b->B + 63) / 64), block, 0, b->stream, b->D, info);
     HIPCHK(hipMemcpyAsync(tm, &b->time_tot, sizeof(double), hipMemcpyHostToDevice, b->stream));
     /* ncclDataType_t: ncclInt32 = 2, ncclFloat64 = 8 (rccl.h) */
-    RCCLCHK(c, c->all_gather(blob, sol_all, cnt, 8, c->comm, b->stream));
-    RCCLCHK(c, c->all_gather(info, info_all, 2 * (size_t) b->B, 2, c->comm, b->stream));
-    RCCLCHK(c, c->all_gather(tm, time_all, 1, 8, c->comm, b->stream));
+    if (root < 0)
+    {
+        RCCLCHK(c, c->all_gather(blob, sol_all, cnt, 8, c->comm, b->stream));
+        RCCLCHK(c, c->all_gather(info, info_all, 2 * (size_t) b->B, 2, c->comm, b->stream));
+        RCCLCHK(c, c->all_gather(tm, time_all, 1, 8, c->comm, b->stream));
+    }
+    else
+    {
+        if (!c->send || !c->recv || !c->group_start || !c->group_end || root >= c->n)
+        {
+            fprintf(stderr, "acados_amd: ocp_qp_gpu_batch_gather_root: librccl.so lacks ncclSend / ncclRecv, or root %d out of range\n", root);
+            return -1;
+        }
+        RCCLCHK(c, c->group_start());
+        RCCLCHK(c, c->send(blob, cnt, 8, root, c->comm, b->stream));
+        RCCLCHK(c, c->send(info, 2 * (size_t) b->B, 2, root, c->comm, b->stream));
+        RCCLCHK(c, c->send(tm, 1, 8, root, c->comm, b->stream));
+        if (c->rank == root)
+            for (int r = 0; r < c->n; r++)
+            {
+                RCCLCHK(c, c->recv(sol_all + (size_t) r * cnt, cnt, 8, r, c->comm, b->stream));
+                RCCLCHK(c, c->recv(info_all + (size_t) r * 2 * (size_t) b->B, 2 * (size_t) b->B, 2, r, c->comm, b->stream));
+                RCCLCHK(c, c->recv(time_all + r, 1, 8, r, c->comm, b->stream));
+            }
+        RCCLCHK(c, c->group_end());
+    }
     HIPCHK(hipStreamSynchronize(b->stream));
     return 0;
+}
+
+int ocp_qp_gpu_batch_gather(ocp_qp_gpu_batch *b, ocp_qp_gpu_comm *c, double *sol_all, int *info_all, double *time_all)
+{
+    return gather_impl(b, c, -1, sol_all, info_all, time_all);
+}
+
+int ocp_qp_gpu_batch_gather_root(ocp_qp_gpu_batch *b, ocp_qp_gpu_comm *c, int root, double *sol_all, int *info_all, double *time_all)
+{
+    return gather_impl(b, c, root < 0 ? 0 : root, sol_all, info_all, time_all);
 }
 #else  /* host-simulation build of the CPU test tier: no RCCL, the N > 1 path is covered by the gloo test */
 struct ocp_qp_gpu_comm { int n; };
@@ -2449,6 +2493,7 @@ int ocp_qp_gpu_comm_unique_id(void *) { return -1; }
 ocp_qp_gpu_comm *ocp_qp_gpu_comm_create(const void *, int, int, int) { return nullptr; }
 void ocp_qp_gpu_comm_destroy(ocp_qp_gpu_comm *) {}
 int ocp_qp_gpu_batch_gather(ocp_qp_gpu_batch *, ocp_qp_gpu_comm *, double *, int *, double *) { return -1; }
+int ocp_qp_gpu_batch_gather_root(ocp_qp_gpu_batch *, ocp_qp_gpu_comm *, int, double *, int *, double *) { return -1; }
 #endif
 
 size_t ocp_qp_gpu_batch_bytes(const ocp_qp_gpu_batch *b) { return b->bytes; }

@@ -112,6 +112,10 @@ __device__ static inline void w16r_dma16(const double *sbase, const double *ldsp
 #endif
 #if defined(W16R_WPE2) || defined(W16R_WPE2_FWD)
 #define W16R_WPE_FWD W16R_TWO_WAVES_PER_SIMD
+#elif defined(W16R_WPE2_FWD_AFF) /* ... only the affine / only the corrector instantiation of the forward sweep */
+#define W16R_WPE_FWD __attribute__((amdgpu_waves_per_eu(CORR ? 1 : 2, CORR ? 1 : 2)))
+#elif defined(W16R_WPE2_FWD_CORR)
+#define W16R_WPE_FWD __attribute__((amdgpu_waves_per_eu(CORR ? 2 : 1, CORR ? 2 : 1)))
 #else
 #define W16R_WPE_FWD W16R_ONE_WAVE_PER_SIMD
 #endif
@@ -150,7 +154,9 @@ __device__ static inline void w16r_dma_region(const double *sbase, const double 
     }
 }
 
+#ifndef W16R_UPD_CH
 #define W16R_UPD_CH 6 /* stages per chunk of the update pass of the corrector sweep */
+#endif
 
 /* value of variable j: lane j & 15 of the row, slot j >> 4 (j is a compile-time constant after unrolling) */
 #define W16R_BC(arr, j) w16_bcast((arr)[(j) >> 4], (j) & 15, xb)

@@ -73,6 +73,23 @@ def gather_solutions(gb, dist=None, rank: int = 0, world: int = 1):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
+    # the same payload to rank 0 only (ncclSend / ncclRecv in one group): 1x per link instead of n_ranks x per rank
+    root_ms, root_ok = None, None
+    if hasattr(L, "ocp_qp_gpu_batch_gather_root") and rc == 0:
+        sol_r = torch.zeros_like(sol) if rank == 0 else None
+        info_r = torch.zeros_like(info) if rank == 0 else None
+        tm_r = torch.zeros_like(tm) if rank == 0 else None
+        ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+        for _ in range(2):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            rr = L.ocp_qp_gpu_batch_gather_root(h, comm, 0, ptr(sol_r), ptr(info_r), ptr(tm_r))
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            if rr == 0:
+                root_ms = dt * 1e3 if root_ms is None else min(root_ms, dt * 1e3)
+        if rank == 0 and root_ms is not None:
+            root_ok = bool(torch.equal(sol_r, sol)) and bool(torch.equal(info_r, info))
     L.ocp_qp_gpu_comm_destroy(comm)
     if rc != 0:
         return None
@@ -86,7 +103,9 @@ def gather_solutions(gb, dist=None, rank: int = 0, world: int = 1):
             "GBps_received_per_rank": payload / best / 1e9, "ranks": world, "slice_matches_getters": ok,
             "iter_mean_all_ranks": float(info[:, :, 1].double().mean().item()),
             "nonzero_status_all_ranks": int((info[:, :, 0] != 0).sum().item()), "solve_s_per_rank": [float(v) for v in tm.cpu().numpy()],
-            "collective": "ncclAllGather x3 (solutions f64, status/iter i32, time f64) via ocp_qp_gpu_batch_gather"}
+            "collective": "ncclAllGather x3 (solutions f64, status/iter i32, time f64) via ocp_qp_gpu_batch_gather",
+            "gather_to_root_ms": root_ms, "gather_to_root_equals_all_gather": root_ok,
+            "gather_to_root": "ncclSend / ncclRecv group to rank 0 via ocp_qp_gpu_batch_gather_root (1x payload per link)"}
 
 
 def reduce_max(value: float, dist=None, device=None) -> float:

@@ -179,6 +179,9 @@ int ocp_qp_gpu_comm_unique_id(void *id128);
 ocp_qp_gpu_comm *ocp_qp_gpu_comm_create(const void *id128, int n_ranks, int rank, int device);
 void ocp_qp_gpu_comm_destroy(ocp_qp_gpu_comm *c);
 int ocp_qp_gpu_batch_gather(ocp_qp_gpu_batch *b, ocp_qp_gpu_comm *c, double *sol_all, int *info_all, double *time_all);
+/* the same payload to ONE rank (ncclSend / ncclRecv in one group): every other rank moves 1x its payload over its xGMI
+ * link to `root` instead of receiving n_ranks x; sol_all / info_all / time_all are read on `root` only (NULL elsewhere) */
+int ocp_qp_gpu_batch_gather_root(ocp_qp_gpu_batch *b, ocp_qp_gpu_comm *c, int root, double *sol_all, int *info_all, double *time_all);
 
 /* pinned (page-locked) host memory for callers that stage their own bulk blobs -- the acados-side adapter is plain C
  * and links no HIP; NULL (with a message) on failure */

@@ -843,3 +843,55 @@ def test_whole_solve_in_one_launch_gpu(gpu_lib, monkeypatch):
     sets.append([mass_spring_qp(N=20)])
     used = check_whole_solve_in_one_launch(gpu_lib, sets)
     assert used.get("w16-box", 0) >= 4 and used.get("w16-soft", 0) >= 4, used
+
+
+@pytest.mark.gpu
+def test_w16r_repeatability_gpu(gpu_lib):
+    """the LDS-DMA / two-rows-per-lane kernels under repetition and co-residency (round-2 review, item 10): C3 at the
+    BASELINE size (65,536 instances, N2 = 10, condensed shape nx = 8 nu = 15 on `w16r-box`) solved 20 times from a cold start
+    while a SECOND batch (the nx = 24 nu = 6 class, same family, its own stream, driven from another host thread) keeps
+    the chip busy with waves of the same kernels: every repeat must give status 0 on every instance, the independently
+    recomputed KKT residual of every instance within tolerance, and BIT-IDENTICAL solutions and iteration counts (the
+    placement of an instance in the dense list of live instances varies from run to run, its arithmetic must not).
+    A development build with two waves of the forward sweep per SIMD fails exactly this test."""
+    import threading
+    from acados_amd import OcpQpGpuBatch
+    from acados_amd.generators import fill_lqr_batch, lqr_dims, random_lqr_batch
+    N, B = 50, 65536
+    data = random_lqr_batch(N=N, batch=B, seed=3)
+    gb = OcpQpGpuBatch(lqr_dims(N, 8, 3), B)
+    fill_lqr_batch(gb, data, N)
+    side_d = random_lqr_batch(N=20, nx=24, nu=6, batch=4096, seed=9)
+    side = OcpQpGpuBatch(lqr_dims(20, 24, 6), 4096)
+    fill_lqr_batch(side, side_d, 20)
+    for g in (gb, side):
+        for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+            g.opts_set(f, 1e-8)
+    gb.opts_set("cond_N", 10)
+    assert side.solve() == 0
+    side_ref = side.get("x", 10).copy()
+    stop, side_bad = threading.Event(), []
+
+    def churn():
+        while not stop.is_set():
+            if side.solve() != 0 or not np.array_equal(side.get("x", 10), side_ref):
+                side_bad.append(1)
+
+    th = threading.Thread(target=churn)
+    th.start()
+    try:
+        ref = None
+        for rep in range(20):
+            assert gb.solve() == 0, rep
+            assert (gb.condensed_kernel_name() or "").startswith("w16r-box<NX=8,NU=15>")
+            res = gb.res_compute()
+            assert res.shape == (B, 4) and float(res.max()) <= 2e-8, (rep, float(res.max()))
+            sol = (np.concatenate([gb.get("x", k).ravel() for k in (0, N // 2, N)] + [gb.get("u", k).ravel() for k in (0, N - 1)]),
+                   gb.info("iter").copy())
+            if ref is None:
+                ref = sol
+            assert np.array_equal(ref[0], sol[0]) and np.array_equal(ref[1], sol[1]), rep
+    finally:
+        stop.set()
+        th.join()
+    assert not side_bad
