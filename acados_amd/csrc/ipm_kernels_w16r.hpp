@@ -58,7 +58,11 @@ struct W16RLds
     /* forward sweep: the packed factor and the [B A]' block of the stage by LDS-DMA, in two buffers (the next stage
      * lands while this one computes) where four workgroups per CU still fit, in one otherwise */
     static constexpr int FBUF = HSZ + BSZ;
+#if defined(W16R_NBUF1) /* development builds: one buffer in the forward sweep whatever fits */
+    static constexpr int NBUF = 1;
+#else
     static constexpr int NBUF = (16 + 2 * FBUF) * 4 * 8 <= 40960 ? 2 : 1;
+#endif
     static constexpr int GTF = 16 + NBUF * FBUF, SZ_F2 = GTF + GSZ;
     static constexpr int SZ0 = SZ_A > SZ_F2 ? SZ_A : SZ_F2;
     static constexpr int SZ = ((SZ0 > SZ_K ? SZ0 : SZ_K) + 1) & ~1; /* even: every instance's tile starts on 16 bytes */
@@ -83,8 +87,13 @@ __device__ static inline void w16r_dma16(const double *sbase, const double *ldsp
     const unsigned voff = threadIdx.x * 16u;
     const unsigned lds = (unsigned) (uintptr_t) (__attribute__((address_space(3))) const double *) ldsp;
     unsigned keep;
+#if defined(W16R_M0_DELAY) /* development builds: M0 restored long after the request was issued (is M0 sampled at issue?) */
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%4\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds), "n"(IMM) : "memory");
+#else
     asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2 offset:%4\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(sbase), "s"(lds), "n"(IMM) : "memory");
+#endif
 }
 /* (s_barrier: a no-op for a one-wave workgroup as far as synchronisation goes; the programming guide orders the reads of
  * DMA'd data behind "vmcnt, then a barrier") */
@@ -132,6 +141,67 @@ __device__ static inline void w16r_dma16(const double *sbase, const double *ldsp
 #define W16R_WPE_FWD
 #define W16R_LDS_DRAIN() GQP_ROWSYNC()
 #endif
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(W16R_NO_DMA) && !defined(W16R_DMA_UNGROUPED)
+/* NF (1..4) full passes of 64 lanes x 16 bytes from sb / to lp with ONE write of M0: the passes differ in the instruction
+ * offset only (it applies to both sides).  M0 is declared clobbered instead of saved and restored around every request:
+ * written twice per request (set, restore) the scalar unit waited for the request in flight before each write -- the
+ * issue of the 24 requests of a [B A]' block took ~5,000 cycles (profiles/r03_w16r_phase_cycles.txt) */
+template <int NF>
+__device__ static inline void w16r_dma_group(const double *sb, const double *lp)
+{
+    const unsigned voff = threadIdx.x * 16u;
+    const unsigned lds = (unsigned) (uintptr_t) (__attribute__((address_space(3))) const double *) lp;
+    if (NF == 1)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:0"
+                     : : "v"(voff), "s"(sb), "s"(lds) : "memory", "m0");
+    else if (NF == 2)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:0\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024"
+                     : : "v"(voff), "s"(sb), "s"(lds) : "memory", "m0");
+    else if (NF == 3)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:0\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %0, %1 offset:2048"
+                     : : "v"(voff), "s"(sb), "s"(lds) : "memory", "m0");
+    else
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:0\n\tglobal_load_lds_dwordx4 %0, %1 offset:1024\n\t"
+                     "global_load_lds_dwordx4 %0, %1 offset:2048\n\tglobal_load_lds_dwordx4 %0, %1 offset:3072"
+                     : : "v"(voff), "s"(sb), "s"(lds) : "memory", "m0");
+}
+template <int IMM>
+__device__ static inline void w16r_dma_tail(const double *sb, const double *lp)
+{
+    const unsigned voff = threadIdx.x * 16u;
+    const unsigned lds = (unsigned) (uintptr_t) (__attribute__((address_space(3))) const double *) lp;
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1 offset:%3"
+                 : : "v"(voff), "s"(sb), "s"(lds), "n"(IMM) : "memory", "m0");
+}
+/* G granules of 16 bytes, contiguous on both sides: groups of up to four full passes, then the lanes the last pass needs */
+template <int G>
+__device__ static inline void w16r_dma_region(const double *sbase, const double *ldsp)
+{
+    constexpr int NFULL = G / 64, REST = G % 64;
+    W16_UNROLL for (int g4 = 0; g4 * 4 < NFULL; g4++)
+    {
+        const double *sb = sbase + g4 * 512, *lp = ldsp + g4 * 512;
+        const int nf = NFULL - 4 * g4 < 4 ? NFULL - 4 * g4 : 4;
+        if (nf == 1) w16r_dma_group<1>(sb, lp);
+        else if (nf == 2) w16r_dma_group<2>(sb, lp);
+        else if (nf == 3) w16r_dma_group<3>(sb, lp);
+        else w16r_dma_group<4>(sb, lp);
+    }
+    if (REST > 0 && (int) threadIdx.x < REST)
+    {
+        constexpr int p = NFULL;
+        const double *sb = sbase + (p >> 2) * 512, *lp = ldsp + (p >> 2) * 512;
+        switch (p & 3)
+        {
+            case 0: w16r_dma_tail<0>(sb, lp); break;
+            case 1: w16r_dma_tail<1024>(sb, lp); break;
+            case 2: w16r_dma_tail<2048>(sb, lp); break;
+            default: w16r_dma_tail<3072>(sb, lp); break;
+        }
+    }
+}
+#else
 /* G granules of 16 bytes, contiguous on both sides: full passes of 64 lanes, then the lanes the last pass needs */
 template <int G>
 __device__ static inline void w16r_dma_region(const double *sbase, const double *ldsp)
@@ -153,6 +223,7 @@ __device__ static inline void w16r_dma_region(const double *sbase, const double 
         }
     }
 }
+#endif
 
 #ifndef W16R_UPD_CH
 #define W16R_UPD_CH 6 /* stages per chunk of the update pass of the corrector sweep */
@@ -907,8 +978,10 @@ __global__ void __launch_bounds__(64) W16R_WPE_FACT ky_factor(GqpDev D, GqpOpts 
         {
             /* next stage: its [B A]' block by DMA; vectors, box rows and the descriptor after it into registers */
             dma_b(k - 1);
+            W16R_TICK(13);
             c_bm = x_bm; c_em = x_em; c_nb = x_nb; c_oct = x_oct; c_ng = x_ng; c_og = x_og; c_ns = x_ns; c_os = x_os;
             if (!GEN) prefetch_v(k - 1); /* GEN: at the top of the stage, see there */
+            W16R_TICK(14);
             load_desc(k > 1 ? k - 2 : 0);
         }
         W16R_TICK(12);

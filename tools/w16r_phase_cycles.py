@@ -9,7 +9,7 @@ from acados_amd import OcpQpGpuBatch, _lib
 from acados_amd.generators import fill_lqr_batch, lqr_dims, random_lqr_batch
 
 c4 = len(sys.argv) > 1 and sys.argv[1] == "c4"     # the C4 class (general rows + slacks): python tools/w16r_phase_cycles.py c4 [batch]
-L = _lib.bind(ctypes.CDLL(os.path.join(ROOT, "acados_amd", "csrc", "libacados_amd_qp_timing.so")))
+L = _lib.bind(ctypes.CDLL(os.path.join(ROOT, "acados_amd", "csrc", os.environ.get("GQP_TIMING_LIB", "libacados_amd_qp_timing.so"))))
 L.gqp_wpi_cycles_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
 if c4:
     from acados_amd.generators import chain_soft_batch, chain_soft_dims, fill_chain_soft_batch
@@ -33,8 +33,9 @@ it = int(gb.info("iter")[0]) + 1
 names = ["loads -> LDS staging, rows of H", "rb += [B A] v, H v", "W = [B A]' Lx+ (rolled), [B A]' pi+", "box rows, w0, m", "M += W W'",
          "Cholesky (+ rhs)", "factor -> HBM, x-block -> LDS"]
 extra = {7: "  (rows: values to the lanes, general-row sums)", 8: "  (rows: the row functions)", 9: "  (rows: results back, rank-one terms)",
-         10: "  (after W: stationarity residual, stores)", 11: "  (x-block transposed through LDS, w0)", 12: "  (DMA of the next [B A]', prefetch of the next vectors)"}
-tot = buf[:13].sum()
+         10: "  (after W: stationarity residual, stores)", 11: "  (x-block transposed through LDS, w0)", 12: "  (descriptor of the stage after the next)",
+         13: "  (DMA of the next [B A]': drain + issue)", 14: "  (prefetch of the next stage's vectors: issue)"}
+tot = buf[:15].sum()
 print(f"kernel {gb.kernel_name}  batch {B}  instance 0: {it} factor sweeps, {N + 1} stages each")
 for q, nm in enumerate(names):
     print(f"  {nm:44s} {int(buf[q]) / it / (N + 1):10.0f} cycles/stage  {100.0 * int(buf[q]) / int(tot):5.1f} %")
