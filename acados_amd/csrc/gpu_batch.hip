@@ -148,6 +148,7 @@ struct ocp_qp_gpu_batch
     int stat_inst = 0, stat_rows = 0;
     /* partial condensing (pcond_kernels.hpp) */
     int cond_N = 0;                 /* requested N2; 0 or N = full space */
+    int cond_keep_iterate = 0;      /* hot start of a condensed solve from the child's own last iterate (not from the root's) */
     int force_NX = 0, force_NU = 0; /* child batches are pinned to the kernel shape the condense kernel writes */
     std::vector<int> user_blocks;   /* cond_block_size (N2 entries) or empty: N/N2 each, remainder to the first blocks */
     int pcond_state = 0;            /* 0 unchecked, 1 active, -1 not applicable (message printed once) */
@@ -963,6 +964,7 @@ int ocp_qp_gpu_batch_opts_set(ocp_qp_gpu_batch *b, const char *f, const void *v)
     else if (!strcmp(f, "cond_pred_corr")) o.cond_pred_corr = *i;
     else if (!strcmp(f, "print_level")) b->print_level = *i;
     else if (!strcmp(f, "profile")) b->profile = *i;
+    else if (!strcmp(f, "cond_keep_iterate")) b->cond_keep_iterate = *i;
     else if (!strcmp(f, "marker"))
     {
         /* one empty launch named k_marker<id> on the batch's stream (id 0..15): section mark for rocprofv3 summaries */
@@ -1234,9 +1236,10 @@ static int pcond_solve(ocp_qp_gpu_batch *b, int mode = 3)
     c->print_level = b->print_level;
     HIPCHK(hipEventRecord(e0, b->stream));
     pcond_launch(b, false);
-    if (b->O.warm_start >= 2)
+    if (b->O.warm_start >= 2 && !b->cond_keep_iterate)
         /* hot start: the root's iterate restated in the condensed variables (condense_qp_out,
-         * ocp_qp_xcond_solver.c:554-565) is the child's starting point */
+         * ocp_qp_xcond_solver.c:554-565) is the child's starting point -- unless the caller keeps the child's own last
+         * iterate (the reference's default: initialize_next_xcond_qp_from_qp_out clear) */
         hipLaunchKernelGGL(gqp::k_pcond_sol, grid, block, 0, b->stream, b->D, c->D, b->pmap);
     HIPCHK(hipEventRecord(e1, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));

@@ -52,6 +52,7 @@ struct batch_cache
     ocp_qp_gpu_batch *batch = nullptr;
     int n = 0;
     int cond_N_sent = -1;            /* condensing request the device batch has been configured for */
+    bool cond_solved = false;        /* the condensed child holds the iterate of a previous solve (hot start without qp_out) */
     std::vector<int> blocks_sent;
     std::vector<blob_seg> seg_in, seg_out; /* bulk pack / unpack segment tables (built once per batch) */
     int L_in = 0, L_out = 0;
@@ -1056,6 +1057,7 @@ int gqp_host::gpu_ipm_evaluate_impl(void *config, int n, void **qp_in_, void **q
         }
         bc->n = n;
         bc->cond_N_sent = -1;
+        bc->cond_solved = false;
         bc->blocks_sent.clear();
         for (int k = 0; k <= N; k++)
         {
@@ -1109,10 +1111,19 @@ int gqp_host::gpu_ipm_evaluate_impl(void *config, int n, void **qp_in_, void **q
                 bc->blocks_sent.assign(cr->block_size, cr->block_size + cn + 1);
             }
             bc->cond_N_sent = cn;
+            bc->cond_solved = false;
         }
     }
+    /* Hot start of a CONDENSED solve: the reference starts from the condensed iterate kept in its memory (xcond_qp_out) and
+     * re-derives it from the caller's qp_out only when initialize_next_xcond_qp_from_qp_out is set
+     * (ocp_qp_xcond_solver.c:554-571).  Same here: without the flag the condensed batch keeps the iterate of its last
+     * solve (nothing is packed, k_pcond_sol does not run); with it -- or when there is no previous condensed solve -- the
+     * caller's (pi, lam, t) are packed and condensed. */
+    const bool condensed_call = cr && cr->N2 > 0 && cr->N2 < N;
+    const int keep_child = (condensed_call && !cr->init_from_qp_out && bc->cond_solved) ? 1 : 0;
+    ocp_qp_gpu_batch_opts_set(b, "cond_keep_iterate", &keep_child);
 
-    if (ws >= 2 && phase != 1)
+    if (ws >= 2 && phase != 1 && !keep_child)
     {
         /* hot start: pi, lam, t of qp_out are the starting point (acados_ocp_options.py:1029-1032).  The reference
          * zeroes the PRIMAL part of qp_out before every solve, whatever the warm start level (ocp_qp_hpipm.c:325-336: the
@@ -1158,6 +1169,7 @@ int gqp_host::gpu_ipm_evaluate_impl(void *config, int n, void **qp_in_, void **q
 
     if (phase == 2) ocp_qp_gpu_batch_condense_rhs_and_solve(b);
     else ocp_qp_gpu_batch_solve(b);
+    if (condensed_call) bc->cond_solved = true;
     const double t_solved = now_s();
 
     /* unpack: one gather launch + one device->host copy for the whole batch, then host threads scatter */

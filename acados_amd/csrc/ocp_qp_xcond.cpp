@@ -119,6 +119,8 @@ void *ocp_qp_gpu_pcond_dims_assign(void *config, int N, void *raw_memory)
     dims->block_size = (int *) c;
     memset(dims->block_size, 0, sizeof(int) * (N + 1));
     dims->condensed = 0;
+    dims->probe_valid = 0;
+    dims->probe_key = 0;
     return dims;
 }
 
@@ -221,7 +223,21 @@ static void pcond_compute_dims(ocp_qp_partial_condensing_dims *dims, ocp_qp_part
 {
     const ocp_qp_dims *d = dims->orig_dims;
     const int N = d->N, N2 = opts->N2;
+    {
+        /* FNV-1a over everything the result depends on */
+        unsigned long long h = 1469598103934665603ull;
+        auto mix = [&](int v) { h = (h ^ (unsigned long long) (unsigned) v) * 1099511628211ull; };
+        mix(N); mix(N2); mix(opts->full_condensing ? 1 : 0); mix(opts->block_size_was_set ? 1 : 0);
+        int *const arrs[] = {d->nx, d->nu, d->nbx, d->nbu, d->ng, d->ns, d->nbxe};
+        for (int *a : arrs) for (int k = 0; k <= N; k++) mix(a[k]);
+        if (opts->block_size_was_set) for (int i = 0; i < N2 + 1 && N2 > 0 && N2 < N; i++) mix(opts->block_size[i]);
+        if (dims->probe_valid && dims->probe_key == h) return;
+        dims->probe_key = h;
+        dims->probe_valid = 1;
+    }
     dims->condensed = 0;
+    dims->probe_valid = 0;
+    dims->probe_key = 0;
     copy_dims(d, dims->pcond_dims);
     for (int i = 0; i <= N; i++) dims->block_size[i] = i < N ? 1 : 0;
     if (N2 <= 0 || N2 >= N) return;

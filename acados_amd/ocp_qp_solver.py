@@ -20,7 +20,7 @@ _FIELDS = ("A", "B", "b", "Q", "S", "R", "q", "r", "idxb", "lbx", "ubx", "lbu", 
 _INT = ("idxb", "idxe", "idxs_rev")
 _OPT_FIELDS = ("tol_stat", "tol_eq", "tol_ineq", "tol_comp", "iter_max", "cond_N", "cond_block_size", "warm_start",
                "cond_ric_alg", "ric_alg", "mu0", "t0_init", "print_level", "hpipm_mode", "tau_min", "t0_min", "lam0_min",
-               "update_fact_exit", "alpha_min")
+               "update_fact_exit", "alpha_min", "initialize_next_xcond_qp_from_qp_out")
 _DOUBLE_OPTS = ("tol_stat", "tol_eq", "tol_ineq", "tol_comp", "mu0", "tau_min", "t0_min", "lam0_min", "alpha_min")
 
 
@@ -114,6 +114,8 @@ class AcadosOcpQpSolver:
             ptr = C.cast(C.c_char_p(value.encode()), C.c_void_p)
         elif field in _DOUBLE_OPTS:     # the C side reads a double whatever Python type the caller used (tol_stat=1)
             self._keep = C.c_double(float(value)); ptr = C.cast(C.byref(self._keep), C.c_void_p)
+        elif field == "initialize_next_xcond_qp_from_qp_out":    # a C bool (ocp_qp_xcond_solver.c:298-302)
+            self._keep = C.c_bool(bool(value)); ptr = C.cast(C.byref(self._keep), C.c_void_p)
         elif isinstance(value, (bool, int, np.integer)):
             self._keep = C.c_int(int(value)); ptr = C.cast(C.byref(self._keep), C.c_void_p)
         elif isinstance(value, float):

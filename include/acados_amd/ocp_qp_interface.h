@@ -233,6 +233,10 @@ typedef struct
     ocp_qp_dims *pcond_dims;
     int *block_size; /* N2 + 1 entries in use */
     int condensed;
+    /* the condensed dims come from the device library (a probe batch); the result is kept for the (orig dims, N2, block
+     * sizes) it was computed for, so that the size queries acados makes (calculate_size, assign, ...) stay cheap */
+    unsigned long long probe_key;
+    int probe_valid;
 } ocp_qp_partial_condensing_dims;
 
 typedef struct

@@ -505,6 +505,52 @@ def test_hot_start_hostsim(hostsim_lib):
     assert cold.solve() == 0 and cold.get_stats("iter") == it_cold
 
 
+def test_hot_start_condensed_keeps_xcond_iterate_hostsim(hostsim_lib):
+    """warm_start >= 2 with partial condensing: the reference starts the condensed solve from the condensed iterate kept in
+    its memory and re-derives it from the caller's qp_out only when `initialize_next_xcond_qp_from_qp_out` is set
+    (ocp_qp_xcond_solver.c:554-571).  Told apart with an EDITED qp_out (multipliers overwritten with ones): without the
+    flag the edit is not looked at -- the restart from the kept iterate converges in a few iterations; with the flag the
+    solve starts from the edited values and needs visibly more."""
+    import ctypes as C
+    from acados_amd import AcadosOcpQpOptions, AcadosOcpQpSolver
+    from acados_amd.generators import mass_spring_qp
+    qp = mass_spring_qp(N=15)
+    opts = AcadosOcpQpOptions()
+    opts.tol_stat = opts.tol_eq = opts.tol_ineq = opts.tol_comp = 1e-8
+    opts.cond_N = 5
+    s = AcadosOcpQpSolver(qp, opts, _clib=hostsim_lib)
+    assert s.solve() == 0
+    it_cold = s.get_stats("iter")
+    x_ref = [s.get(k, "x") for k in range(qp.N + 1)]
+
+    class _Out(C.Structure):
+        _fields_ = [("dim", C.c_void_p)] + [(n, C.POINTER(C.POINTER(C.c_double))) for n in ("ux", "pi", "lam", "t")] + [("misc", C.c_void_p)]
+
+    def spoil():
+        o = C.cast(s.c_out, C.POINTER(_Out)).contents
+        d = qp.dims
+        for k in range(qp.N + 1):
+            for e in range(2 * int(d.nbx[k] + d.nbu[k] + d.ng[k] + d.ns[k])):
+                o.lam[k][e] = 1.0
+                o.t[k][e] = 1.0
+            if k < qp.N:
+                for e in range(int(d.nx[k + 1])):
+                    o.pi[k][e] = 0.0
+
+    s.opts_set("warm_start", 3)
+    spoil()
+    assert s.solve() == 0
+    it_kept = s.get_stats("iter")
+    spoil()
+    s.opts_set("initialize_next_xcond_qp_from_qp_out", True)
+    assert s.solve() == 0
+    it_from_out = s.get_stats("iter")
+    print("iterations: cold", it_cold, "hot from the kept condensed iterate", it_kept, "hot from the edited qp_out", it_from_out)
+    assert it_kept <= 3 and it_kept < it_cold and it_from_out > it_kept + 2
+    for k in range(qp.N + 1):
+        assert np.allclose(s.get(k, "x"), x_ref[k], atol=1e-6)
+
+
 def test_riccati_getters_hostsim(hostsim_lib):
     """a11: P, p, K, k, Lr of the last factorisation (ocp_qp_hpipm.c:417-478) against the oracle's factor
     at the same iterate; and the feedback-law property Delta u = K Delta x + k on the Newton step"""
