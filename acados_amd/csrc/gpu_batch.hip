@@ -1013,7 +1013,12 @@ int ocp_qp_gpu_batch_opts_set(ocp_qp_gpu_batch *b, const char *f, const void *v)
     else if (!strcmp(f, "lam0_min")) b->lam0_min = *d;
     else if (!strcmp(f, "update_fact_exit")) { /* the factor sweep factorises before it decides: the factor at the exit
                                                   point is always there (and re-done lazily after a hand-over) */ }
-    else if (!strcmp(f, "t0_init")) { /* single initialisation scheme (oracle-pinned) */ }
+    else if (!strcmp(f, "t0_init"))
+    {
+        /* acados_ocp_options.py:1128-1143: 0 lam = t = sqrt(mu0); 1 lam = mu0, t = 1; 2 from the constraint residuals */
+        if (*i < 0 || *i > 2) { fprintf(stderr, "acados_amd: t0_init must be 0, 1 or 2, got %d\n", *i); return -1; }
+        o.t0_init = *i;
+    }
     else if (!strcmp(f, "ric_alg"))
     {
         if (*i != 1) fprintf(stderr, "acados_amd: ric_alg=%d requested, only the square-root Riccati (1) is implemented\n", *i);

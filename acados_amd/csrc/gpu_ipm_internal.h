@@ -39,6 +39,8 @@ struct GqpOpts
 {
     double mu0, tol_stat, tol_eq, tol_ineq, tol_comp, alpha_min, tau_min, lam_min, t_min, reg_prim;
     int iter_max, pred_corr, cond_pred_corr, warm_start;
+    int t0_init; /* cold start of (t, lam): 0 = (sqrt(mu0), sqrt(mu0)), 1 = (1, mu0), 2 = from the constraint residuals
+                    (acados_ocp_options.py:1128-1143); 0 / 1 leave the primal iterate at zero */
 };
 
 /* One per-instance HBM array: `E` elements per instance, stored WAVE-TILED,

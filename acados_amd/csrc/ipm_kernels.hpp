@@ -77,6 +77,9 @@ __global__ void __launch_bounds__(64) k_init(GqpDev D, GqpOpts O)
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= D.B) return;
     const double thr0 = 1e-1;
+    /* t0_init 0 / 1: constant (t, lam), primal iterate and slacks stay at zero -- an infeasible start the IPM handles */
+    const bool heur = O.t0_init != 0 && O.t0_init != 1;
+    const double t_c = O.t0_init == 0 ? sqrt(O.mu0) : 1.0, l_c = O.t0_init == 0 ? sqrt(O.mu0) : O.mu0;
     for (int k = 0; k <= D.N; k++)
     {
         const GqpStage &S = D.st[k];
@@ -92,7 +95,7 @@ __global__ void __launch_bounds__(64) k_init(GqpDev D, GqpOpts O)
             if (!((S.bmask >> j) & 1)) continue;
             const bool fixed = (S.emask >> j) & 1;
             const bool soft = S.srev[ib] >= 0;
-            if (!fixed && !soft)
+            if (!fixed && !soft && heur)
             {
                 const double lb = GATL(D.dvec, S.o_ct + ib), ub = GATL(D.dvec, S.o_ct + nbg + ib);
                 const bool al = (am >> ib) & 1, au = (am >> (nbg + ib)) & 1;
@@ -116,7 +119,7 @@ __global__ void __launch_bounds__(64) k_init(GqpDev D, GqpOpts O)
             UNROLL for (int j = 0; j < NS; j++)
             {
                 sl[j] = 0.0; su[j] = 0.0;
-                if (j < S.ns)
+                if (j < S.ns && heur)
                 {
                     if ((am >> (2 * nbg + j)) & 1) sl[j] = GATL(D.dvec, S.o_ct + 2 * nbg + j) + thr0;
                     if ((am >> (2 * nbg + S.ns + j)) & 1) su[j] = GATL(D.dvec, S.o_ct + 2 * nbg + S.ns + j) + thr0;
@@ -147,7 +150,7 @@ __global__ void __launch_bounds__(64) k_init(GqpDev D, GqpOpts O)
                 const int row = j < n ? ib : S.nb + (j - n);
                 if (j < n) ib++;
                 const int sj = S.srev[row];
-                if (sj < 0) continue;
+                if (sj < 0 || !heur) continue;
                 const double lo = GATL(D.dvec, S.o_ct + row), up = GATL(D.dvec, S.o_ct + nbg + row);
                 const double need_l = lo - cval[j] + thr0, need_u = cval[j] - up + thr0;
                 UNROLL for (int q = 0; q < NS; q++)
@@ -182,11 +185,12 @@ __global__ void __launch_bounds__(64) k_init(GqpDev D, GqpOpts O)
             double tl = cval[j] + ssl - lo, tu = up - cval[j] + ssu;
             if (tl < thr0) tl = thr0;
             if (tu < thr0) tu = thr0;
+            if (!heur) { tl = t_c; tu = t_c; }
             const bool al = (am >> row) & 1, au = (am >> (nbg + row)) & 1;
             GATL(D.t, S.o_ct + row) = al ? tl : 0.0;
             GATL(D.t, S.o_ct + nbg + row) = au ? tu : 0.0;
-            GATL(D.lam, S.o_ct + row) = al ? O.mu0 / tl : 0.0;
-            GATL(D.lam, S.o_ct + nbg + row) = au ? O.mu0 / tu : 0.0;
+            GATL(D.lam, S.o_ct + row) = al ? (heur ? O.mu0 / tl : l_c) : 0.0;
+            GATL(D.lam, S.o_ct + nbg + row) = au ? (heur ? O.mu0 / tu : l_c) : 0.0;
         }
         if (NS > 0)
         {
@@ -197,11 +201,12 @@ __global__ void __launch_bounds__(64) k_init(GqpDev D, GqpOpts O)
                     double tl = sl[j] - GATL(D.dvec, e0), tu = su[j] - GATL(D.dvec, e1);
                     if (tl < thr0) tl = thr0;
                     if (tu < thr0) tu = thr0;
+                    if (!heur) { tl = t_c; tu = t_c; }
                     const bool al = (am >> (2 * nbg + j)) & 1, au = (am >> (2 * nbg + S.ns + j)) & 1;
                     GATL(D.t, e0) = al ? tl : 0.0;
                     GATL(D.t, e1) = au ? tu : 0.0;
-                    GATL(D.lam, e0) = al ? O.mu0 / tl : 0.0;
-                    GATL(D.lam, e1) = au ? O.mu0 / tu : 0.0;
+                    GATL(D.lam, e0) = al ? (heur ? O.mu0 / tl : l_c) : 0.0;
+                    GATL(D.lam, e1) = au ? (heur ? O.mu0 / tu : l_c) : 0.0;
                 }
         }
     }

@@ -1917,6 +1917,9 @@ __global__ void __launch_bounds__(64) kw_init(GqpDev D, GqpOpts O)
     const int inst = blockIdx.x, lane = threadIdx.x;
     if (inst >= D.B) return;
     const double thr0 = 1e-1;
+    /* t0_init 0 / 1: constant (t, lam), primal iterate and slacks stay at zero (see k_init) */
+    const bool heur = O.t0_init != 0 && O.t0_init != 1;
+    const double t_c = O.t0_init == 0 ? sqrt(O.mu0) : 1.0, l_c = O.t0_init == 0 ? sqrt(O.mu0) : O.mu0;
     double *vv = smem, *cv = smem + 64, *ssl = smem + 128, *ssu = smem + 160; /* v, row values, slack values */
     for (int k = 0; k <= D.N; k++)
     {
@@ -1936,7 +1939,7 @@ __global__ void __launch_bounds__(64) kw_init(GqpDev D, GqpOpts O)
             {
                 lb = WAT(D.dvec, S.o_ct + ib); ub = WAT(D.dvec, S.o_ct + nbg + ib);
                 al = abit(am, ib); au = abit(am, nbg + ib);
-                if (!fixed && bsj < 0)
+                if (!fixed && bsj < 0 && heur)
                 {
                     const double tl = v - lb, tu = ub - v;
                     if (al && au)
@@ -1969,10 +1972,10 @@ __global__ void __launch_bounds__(64) kw_init(GqpDev D, GqpOpts O)
             if (iss)
             {
                 double a = 0.0, c = 0.0;
-                if (abit(am, 2 * nbg + lane)) a = WAT(D.dvec, S.o_ct + 2 * nbg + lane) + thr0;
-                if (abit(am, 2 * nbg + S.ns + lane)) c = WAT(D.dvec, S.o_ct + 2 * nbg + S.ns + lane) + thr0;
+                if (heur && abit(am, 2 * nbg + lane)) a = WAT(D.dvec, S.o_ct + 2 * nbg + lane) + thr0;
+                if (heur && abit(am, 2 * nbg + S.ns + lane)) c = WAT(D.dvec, S.o_ct + 2 * nbg + S.ns + lane) + thr0;
                 for (int row = 0; row < nbg; row++)
-                    if (S.srev[row] == lane)
+                    if (heur && S.srev[row] == lane)
                     {
                         const double need_l = WAT(D.dvec, S.o_ct + row) - cv[row] + thr0, need_u = cv[row] - WAT(D.dvec, S.o_ct + nbg + row) + thr0;
                         if (abit(am, row) && need_l > a) a = need_l;
@@ -1984,9 +1987,10 @@ __global__ void __launch_bounds__(64) kw_init(GqpDev D, GqpOpts O)
                 double tl = a - WAT(D.dvec, e0), tu = c - WAT(D.dvec, e1);
                 if (tl < thr0) tl = thr0;
                 if (tu < thr0) tu = thr0;
+                if (!heur) { tl = t_c; tu = t_c; }
                 const bool sal = abit(am, 2 * nbg + lane), sau = abit(am, 2 * nbg + S.ns + lane);
                 WAT(D.t, e0) = sal ? tl : 0.0; WAT(D.t, e1) = sau ? tu : 0.0;
-                WAT(D.lam, e0) = sal ? O.mu0 / tl : 0.0; WAT(D.lam, e1) = sau ? O.mu0 / tu : 0.0;
+                WAT(D.lam, e0) = sal ? (heur ? O.mu0 / tl : l_c) : 0.0; WAT(D.lam, e1) = sau ? (heur ? O.mu0 / tu : l_c) : 0.0;
             }
             __syncthreads();
             if (bsj >= 0) { sl = ssl[bsj]; su = ssu[bsj]; }
@@ -1997,9 +2001,10 @@ __global__ void __launch_bounds__(64) kw_init(GqpDev D, GqpOpts O)
                 double tl = gc + gsl - WAT(D.dvec, S.o_ct + row), tu = WAT(D.dvec, S.o_ct + nbg + row) - gc + gsu;
                 if (tl < thr0) tl = thr0;
                 if (tu < thr0) tu = thr0;
+                if (!heur) { tl = t_c; tu = t_c; }
                 const bool gal = abit(am, row), gau = abit(am, nbg + row);
                 WAT(D.t, S.o_ct + row) = gal ? tl : 0.0; WAT(D.t, S.o_ct + nbg + row) = gau ? tu : 0.0;
-                WAT(D.lam, S.o_ct + row) = gal ? O.mu0 / tl : 0.0; WAT(D.lam, S.o_ct + nbg + row) = gau ? O.mu0 / tu : 0.0;
+                WAT(D.lam, S.o_ct + row) = gal ? (heur ? O.mu0 / tl : l_c) : 0.0; WAT(D.lam, S.o_ct + nbg + row) = gau ? (heur ? O.mu0 / tu : l_c) : 0.0;
             }
             __syncthreads(); /* the exchange buffers are reused by the next stage */
         }
@@ -2008,10 +2013,11 @@ __global__ void __launch_bounds__(64) kw_init(GqpDev D, GqpOpts O)
             double tl = v + sl - lb, tu = ub - v + su;
             if (tl < thr0) tl = thr0;
             if (tu < thr0) tu = thr0;
+            if (!heur) { tl = t_c; tu = t_c; }
             WAT(D.t, S.o_ct + ib) = al ? tl : 0.0;
             WAT(D.t, S.o_ct + nbg + ib) = au ? tu : 0.0;
-            WAT(D.lam, S.o_ct + ib) = al ? O.mu0 / tl : 0.0;
-            WAT(D.lam, S.o_ct + nbg + ib) = au ? O.mu0 / tu : 0.0;
+            WAT(D.lam, S.o_ct + ib) = al ? (heur ? O.mu0 / tl : l_c) : 0.0;
+            WAT(D.lam, S.o_ct + nbg + ib) = au ? (heur ? O.mu0 / tu : l_c) : 0.0;
         }
     }
     if (lane == 0)

@@ -848,8 +848,8 @@ void ocp_qp_gpu_ipm_opts_set(void *config, void *opts_, const char *field, void 
     else if (!strcmp(field, "mu0")) { if (*d > 0.0) o->mu0 = *d; }
     else if (!strcmp(field, "t0_init"))
     {
-        o->t0_init = *i;
-        if (*i != 2) notice_once(o, 1, "t0_init", "the cold start uses ONE initialisation of t / lam (the oracle-pinned one)");
+        if (*i < 0 || *i > 2) { printf("\nerror: ocp_qp_gpu_ipm_opts_set: t0_init must be 0, 1 or 2, got %d\n", *i); exit(1); }
+        o->t0_init = *i; /* 0: lam = t = sqrt(mu0); 1: lam = mu0, t = 1; 2: from the residuals (acados_ocp_options.py:1128-1143) */
     }
     else if (!strcmp(field, "ric_alg"))
     {
@@ -1081,6 +1081,7 @@ int gqp_host::gpu_ipm_evaluate_impl(void *config, int n, void **qp_in_, void **q
     const int ws = o->warm_start >= 2 ? o->warm_start : 0;
     ocp_qp_gpu_batch_opts_set(b, "warm_start", &ws);
     ocp_qp_gpu_batch_opts_set(b, "mu0", &o->mu0);
+    ocp_qp_gpu_batch_opts_set(b, "t0_init", &o->t0_init);
     ocp_qp_gpu_batch_opts_set(b, "alpha_min", &o->alpha_min);
     ocp_qp_gpu_batch_opts_set(b, "tau_min", &o->tau_min);
     ocp_qp_gpu_batch_opts_set(b, "reg_prim", &o->reg_prim);

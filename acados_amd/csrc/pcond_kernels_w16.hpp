@@ -61,7 +61,14 @@ __global__ void __launch_bounds__(64) kz_pcond(GqpDev P, GqpDev Cd, PcondMap Mp)
     typedef PcondzLds<NX, NU, BS> LY;
     constexpr int n = NX + NU, NP = LY::NP, NB = LY::NB, NUC = BS * NU, nc = NUC + NX, NPC = nc * (nc + 1) / 2, R = (nc + 15) / 16;
     const int l = threadIdx.x & 15, rq = threadIdx.x >> 4, jb = blockIdx.y;
-    const int inst_raw = blockIdx.x * 4 + rq;
+    /* XCD-aware block -> instance-group map.  A wave-tiled parent keeps element e of 16 neighbouring instances in one
+     * 128-byte line; this workgroup uses the 32 bytes of its four instances, the other three groups of the line are other
+     * workgroups.  Workgroups go round-robin over the 8 XCDs (each with its own L2): with the identity map those four
+     * groups sit on four different XCDs and every one of them pulls the line from HBM (PMC: 22 GB per launch for 65,536
+     * C2 instances, 2.7x what the kernel needs).  Within each chunk of 32 workgroups, XCD c gets the groups 4c .. 4c + 3. */
+    int gx = blockIdx.x;
+    if ((gx | 31) < (int) gridDim.x) gx = (gx & ~31) + ((gx & 7) << 2) + ((gx >> 3) & 3);
+    const int inst_raw = gx * 4 + rq;
     const bool alive = inst_raw < P.B;
     const int inst = alive ? inst_raw : P.B - 1; /* a row beyond the batch condenses the last instance and writes nothing */
     double *T = smem + rq * LY::SZ, *xb = T + LY::XB;

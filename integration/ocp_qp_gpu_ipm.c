@@ -470,6 +470,7 @@ static void apply_opts(ocp_qp_gpu_batch *b, const ocp_qp_gpu_ipm_opts *o, int ws
     ocp_qp_gpu_batch_opts_set(b, "tol_ineq", &o->tol_ineq);
     ocp_qp_gpu_batch_opts_set(b, "tol_comp", &o->tol_comp);
     ocp_qp_gpu_batch_opts_set(b, "mu0", &o->mu0);
+    ocp_qp_gpu_batch_opts_set(b, "t0_init", &o->t0_init);
     ocp_qp_gpu_batch_opts_set(b, "tau_min", &o->tau_min);
     ocp_qp_gpu_batch_opts_set(b, "t0_min", &o->t0_min);
     ocp_qp_gpu_batch_opts_set(b, "lam0_min", &o->lam0_min);

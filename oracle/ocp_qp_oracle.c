@@ -89,6 +89,7 @@ void oqp_opts_default(oqp_opts *o)
     o->cond_pred_corr = 1;
     o->warm_start = 0;
     o->print_level = 0;
+    o->t0_init = 2;
 }
 
 oqp *oqp_create(int N, const int *nx, const int *nu, const int *nbx, const int *nbu,
@@ -748,6 +749,10 @@ static double step_length(const oqp *qp)
 static void init_var(oqp *qp, const oqp_opts *o)
 {
     const double thr0 = 1e-1;
+    /* t0_init (acados_ocp_options.py:1128-1143): 0 lam = t = sqrt(mu0); 1 lam = mu0, t = 1 -- primal iterate and slacks
+     * stay at zero; 2 (default) slacks from the constraint residuals, clipped at 0.1, lam = mu0 / t */
+    const int heur = o->t0_init != 0 && o->t0_init != 1;
+    const double t_c = o->t0_init == 0 ? sqrt(o->mu0) : 1.0, l_c = o->t0_init == 0 ? sqrt(o->mu0) : o->mu0;
     for (int k = 0; k <= qp->N; k++)
     {
         stg *s = qp->s + k;
@@ -760,7 +765,7 @@ static void init_var(oqp *qp, const oqp_opts *o)
         for (int i = 0; i < s->nb; i++)
         {
             int iv = s->idxb[i];
-            if (s->fixed[iv] || s->idxs_rev[i] >= 0) continue;
+            if (s->fixed[iv] || s->idxs_rev[i] >= 0 || !heur) continue;
             int al = s->act[i], au = s->act[nbg + i];
             double tl = s->ux[iv] - s->lb[i], tu = s->ub[i] - s->ux[iv];
             if (al && au)
@@ -779,13 +784,13 @@ static void init_var(oqp *qp, const oqp_opts *o)
         /* slacks: large enough that every soft row and the slack bound start interior */
         for (int j = 0; j < ns; j++)
         {
-            s->ux[n + j] = s->act[2 * nbg + j] ? s->lls[j] + thr0 : 0.0;
-            s->ux[n + ns + j] = s->act[2 * nbg + ns + j] ? s->lus[j] + thr0 : 0.0;
+            s->ux[n + j] = (heur && s->act[2 * nbg + j]) ? s->lls[j] + thr0 : 0.0;
+            s->ux[n + ns + j] = (heur && s->act[2 * nbg + ns + j]) ? s->lus[j] + thr0 : 0.0;
         }
         for (int i = 0; i < nbg; i++)
         {
             int j = s->idxs_rev[i];
-            if (j < 0) continue;
+            if (j < 0 || !heur) continue;
             double lo = i < s->nb ? s->lb[i] : s->lg[i - s->nb];
             double up = i < s->nb ? s->ub[i] : s->ug[i - s->nb];
             if (s->act[i] && lo - s->c[i] + thr0 > s->ux[n + j]) s->ux[n + j] = lo - s->c[i] + thr0;
@@ -797,6 +802,7 @@ static void init_var(oqp *qp, const oqp_opts *o)
             if (!s->act[i]) { s->lam[i] = 0.0; continue; }
             if (s->t[i] < thr0) s->t[i] = thr0;
             s->lam[i] = o->mu0 / s->t[i];
+            if (!heur) { s->t[i] = t_c; s->lam[i] = l_c; }
         }
     }
 }

@@ -55,6 +55,7 @@ typedef struct
     int cond_pred_corr;/* 1: fall back to pure centering when corrector step collapses */
     int warm_start;    /* 0: cold */
     int print_level;
+    int t0_init;       /* 2; cold start of (t, lam): acados_ocp_options.py:1128-1143 */
 } oqp_opts;
 
 void oqp_opts_default(oqp_opts *opts);

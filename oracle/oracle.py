@@ -16,7 +16,7 @@ _LIB = None
 class OqpOpts(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("mu0", "tol_stat", "tol_eq", "tol_ineq", "tol_comp", "alpha_min",
                                            "tau_min", "lam_min", "t_min", "reg_prim")] + \
-               [(n, C.c_int) for n in ("iter_max", "pred_corr", "cond_pred_corr", "warm_start", "print_level")]
+               [(n, C.c_int) for n in ("iter_max", "pred_corr", "cond_pred_corr", "warm_start", "print_level", "t0_init")]
 
 
 def build(force=False):

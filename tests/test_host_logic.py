@@ -551,6 +551,35 @@ def test_hot_start_condensed_keeps_xcond_iterate_hostsim(hostsim_lib):
         assert np.allclose(s.get(k, "x"), x_ref[k], atol=1e-6)
 
 
+@pytest.mark.parametrize("fam", ["1tpi", "wpi"])
+@pytest.mark.parametrize("t0_init", [0, 1])
+def test_t0_init_schemes_hostsim(hostsim_lib, monkeypatch, fam, t0_init):
+    """`t0_init` (acados_ocp_options.py:1128-1143; ocp_qp_hpipm.c routes it to HPIPM's argument of that name): 0 -> lam = t =
+    sqrt(mu0), 1 -> lam = mu0, t = 1, both with the primal iterate left at zero (an infeasible start), 2 -> the default from
+    the constraint residuals.  Device and oracle run the same scheme: same solution, same iteration count (+-1), and the
+    count differs from the default scheme's (the option selects something)."""
+    from acados_amd import OcpQpGpuBatch
+    from acados_amd.generators import mass_spring_qp
+    monkeypatch.setenv("ACADOS_AMD_WPI", "0" if fam == "1tpi" else "1")
+    diff = 0
+    for qp in (mass_spring_qp(N=8), load_qp("casadi_qp_tests/pendulum_slack.json"), load_qp("qp_test/last_qp_one_sided_test.json")):
+        its = {}
+        for scheme in (t0_init, 2):
+            o = OracleQp(qp)
+            assert o.solve(default_opts(tol_stat=1e-8, t0_init=scheme, mu0=4.0)) == 0
+            b = OcpQpGpuBatch.from_qps([qp, qp], _clib=hostsim_lib)
+            for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+                b.opts_set(f, 1e-8)
+            b.opts_set("mu0", 4.0)
+            b.opts_set("t0_init", scheme)
+            assert b.solve() == 0
+            assert abs(int(b.info("iter")[1]) - o.iter) <= 1, (scheme, b.info("iter"), o.iter)
+            compare_with_oracle(lambda k, f: b.get(f, k)[1], o, qp, 1e-7, fields=("x", "u", "sl", "su", "pi", "lam"))
+            its[scheme] = o.iter
+        diff += abs(its[t0_init] - its[2])
+    assert diff > 0
+
+
 def test_riccati_getters_hostsim(hostsim_lib):
     """a11: P, p, K, k, Lr of the last factorisation (ocp_qp_hpipm.c:417-478) against the oracle's factor
     at the same iterate; and the feedback-law property Delta u = K Delta x + k on the Newton step"""
