@@ -18,6 +18,7 @@
 #include "gpu_ipm_internal.h"
 #include "ipm_kernels.hpp"
 #include "ipm_kernels_box.hpp"
+#include "ipm_kernels_box_small.hpp"
 #include "ipm_kernels_wpi.hpp"
 #include "ipm_kernels_w16.hpp"
 #include "ipm_kernels_w16r.hpp"
@@ -45,6 +46,8 @@ namespace
 #define GQP_WPI_MIN_N 13       /* nu+nx from which the wave-per-instance kernels serve every batch */
 #define GQP_WPI_BATCH_MAX 8192 /* batch size up to which they also serve the smaller stage blocks */
 #define GQP_W16_BATCH_MAX 20480 /* ... where a 16-lanes-per-instance instantiation exists (crossover of the C2 shape: ~20k) */
+#define GQP_W16_SMALL_MAX 4096       /* ... against the pipelined small-block kernels (nu + nx <= 6) */
+#define GQP_W16_SMALL_XBOX_MAX 12288 /* ... the same with box rows on the states */
 
 /* compiled shape classes; a batch is served by the cheapest one that covers it */
 const KernelSet g_ksets[] = {
@@ -230,6 +233,7 @@ void opts_default(GqpOpts &o)
     o.tol_stat = 1e-6; o.tol_eq = 1e-8; o.tol_ineq = 1e-8; o.tol_comp = 1e-8;
     o.alpha_min = 1e-8; o.tau_min = 0.0; o.lam_min = 1e-16; o.t_min = 1e-16; o.reg_prim = 1e-15;
     o.iter_max = 50; o.pred_corr = 1; o.cond_pred_corr = 1; o.warm_start = 0;
+    o.t0_init = 2; /* acados_ocp_options.py:1128-1143: the default is the residual-based start */
 }
 
 /* options as the kernels see them: the complementarity target never drops below 1e-3 tol_comp (barrier floor,
@@ -740,7 +744,15 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
          * of registers, the sixteen-lanes kernels win at every batch size measured (tools/xbox_rate.py) */
         bool xbox_dims = false;
         for (int k = 1; k <= N; k++) xbox_dims = xbox_dims || nbx[k] > 0;
-        const int batch_max = bm ? atoi(bm) : (has_w16 ? (xbox_dims ? INT_MAX : GQP_W16_BATCH_MAX) : GQP_WPI_BATCH_MAX);
+        /* nu + nx <= 6: the pipelined one-instance-per-lane kernels (ipm_kernels_box_small.hpp) take over much earlier
+         * -- measured crossover on nx = 4, nu = 1 between 2,048 and 4,096 instances (N = 100; 4,096 ... 7,281 at N = 20),
+         * with bounds on every state between 7,281 and 16,384; at 65,536 they are 2.7-2.9x (1.4x) ahead
+         * (tools/small_shape_crossover.py) */
+        const bool kb_small = !gen && b->ks && b->ks->NX + b->ks->NU <= 6;
+        const int batch_max = bm ? atoi(bm)
+                            : !has_w16 ? GQP_WPI_BATCH_MAX
+                            : kb_small ? (xbox_dims ? GQP_W16_SMALL_XBOX_MAX : GQP_W16_SMALL_MAX)
+                            : (xbox_dims ? INT_MAX : GQP_W16_BATCH_MAX);
         /* (a shape no compiled one-instance-per-lane set covers runs here whatever the override says) */
         const bool want = g_force_wpi || need_wpi || !b->ks || (env ? atoi(env) != 0 : (wx + wu >= GQP_WPI_MIN_N || n_batch <= batch_max));
         if (want && wx + wu <= 64 && wx >= 1 && mg <= 32 && ms <= 32)
@@ -1303,6 +1315,11 @@ static IpmKernels pick_kernels(const ocp_qp_gpu_batch *b)
     k.rhs = b->use_box ? ks->box_rhs[xb] : ks->back_rhs;
     k.faff = b->use_box ? ks->box_fwd_aff[xb] : ks->fwd_aff;
     k.fcorr = b->use_box ? ks->box_fwd_corr[xb] : ks->fwd_corr;
+    const char *small = getenv("ACADOS_AMD_KB_SMALL");
+    if (b->use_box && !b->wpi && small && atoi(small) == 0 && ks->kb_fact[xb])
+    {
+        k.fact = ks->kb_fact[xb]; k.rhs = ks->kb_rhs[xb]; k.faff = ks->kb_fwd_aff[xb]; k.fcorr = ks->kb_fwd_corr[xb];
+    }
     k.final_ = b->use_box ? ks->box_finalize : ks->finalize;
     return k;
 }

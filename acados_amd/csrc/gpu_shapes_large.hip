@@ -10,6 +10,7 @@
 
 #include "ipm_kernels.hpp"
 #include "ipm_kernels_box.hpp"
+#include "ipm_kernels_box_small.hpp"
 #include "kernel_sets.h"
 
 const KernelSet g_ksets_large[] = {

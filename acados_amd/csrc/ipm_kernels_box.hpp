@@ -93,13 +93,27 @@ struct StageU
     int nb, o_ct;
     uint64_t bmask, emask;
 };
+/* The stage table is written by the host before the first launch and never by a kernel: it is read through the constant
+ * address space, i.e. with SCALAR loads (s_load, lgkmcnt) at every point of a kernel.  Through a plain pointer the
+ * compiler may use scalar loads only until the kernel's first store (the table might alias it); from then on it fetched
+ * the table with vector loads, and every use of a stage's fields -- buffer offsets above all -- first waited for vmcnt to
+ * drain past that load: one exposed round trip per stage, and a stop for any load issued ahead of it. */
 __device__ static inline StageU stage_u(const GqpStage *st, int k)
 {
     StageU S;
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef const GqpStage __attribute__((address_space(4))) *cstage_t;
+    const cstage_t p = (cstage_t) (uintptr_t) (st + k);
+    S.nb = uni(p->nb);
+    S.o_ct = uni(p->o_ct);
+    S.bmask = uni64(p->bmask);
+    S.emask = uni64(p->emask);
+#else
     S.nb = uni(st[k].nb);
     S.o_ct = uni(st[k].o_ct);
     S.bmask = uni64(st[k].bmask);
     S.emask = uni64(st[k].emask);
+#endif
     return S;
 }
 
@@ -131,12 +145,27 @@ struct Acc
     {
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(raw_t, v), rs, voff, (unsigned int) e * bp8, 0);
     }
+    /* element e0 + j, j a compile-time constant after unrolling: the low three bits of j travel in the instruction's
+     * 12-bit immediate offset (8 elements x 512 B), so eight accesses share one scalar offset register instead of
+     * computing one each */
+    __device__ inline double ldj(int e0, int j) const
+    {
+        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rs, voff + (unsigned int) (j & 7) * 512u,
+                                                                                  (unsigned int) (e0 + (j & ~7)) * bp8, 0));
+    }
+    __device__ inline void stj(int e0, int j, double v) const
+    {
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(raw_t, v), rs, voff + (unsigned int) (j & 7) * 512u,
+                                              (unsigned int) (e0 + (j & ~7)) * bp8, 0);
+    }
 #else
     double *p;
     size_t bp;
     double ld(int e) const { return p[(size_t) e * bp]; }
     double ldo(int e, int) const { return p[(size_t) e * bp]; }
     void st(int e, double v) const { p[(size_t) e * bp] = v; }
+    double ldj(int e0, int j) const { return p[(size_t) (e0 + j) * bp]; }
+    void stj(int e0, int j, double v) const { p[(size_t) (e0 + j) * bp] = v; }
 #endif
 };
 

@@ -136,6 +136,15 @@ __device__ static inline int w16_srev(const GqpStage &S, int ib)
  * host checks it, gpu_batch.hip): the slack block of a row is eliminated by the lane that owns the row, with the
  * cancellation-free formulas of ipm_kernels_wpi.hpp specialised to one row per slack (E = Z + Gamma_s, X = slack
  * stationarity + rho_s); nothing crosses lanes. */
+/* Stages requested ahead of the one being computed (register ring, see kx_factor_body); a record is 3 n + NX + 12 doubles
+ * per lane.  Measured at 7,281 instances (MI355X, factor launch, depth 0 -> 1): nx=4 N=100 396 -> 376 us, nx=8 nu=3 N=50
+ * 364 -> 331 us, nx=12 nu=3 N=100 897 -> 806 us; depth 2 spills (nx=12: 1,344 us) or costs the second wave per SIMD. */
+template <int NX, int NU, bool SOFT>
+struct W16Prefetch
+{
+    static constexpr int FACTOR = SOFT ? 0 : 1;
+};
+
 template <int NX, int NU, bool SOFT>
 __device__ static inline void kx_factor_body(const GqpDev &D, const GqpOpts &O, int redo)
 {
@@ -156,32 +165,83 @@ __device__ static inline void kx_factor_body(const GqpDev &D, const GqpOpts &O, 
     double lxn = 0.0; /* lx+ of this lane's state */
     double nrm_g = 0.0, nrm_b = 0.0, nrm_d = 0.0, nrm_m = 0.0, musum = 0.0, obj = 0.0, nact = 0.0;
 
-    for (int k = D.N; k >= 0; k--)
+    /* Everything a stage reads from HBM (symmetric row l of H, row l and column cx of [B A]', vectors, the lane's box row:
+     * n + NX + n + 12 doubles), as one record.  Small shapes keep a ring of PD records in registers: the record of stage
+     * k - PD is requested while stage k computes.  A stage is a dependent chain load -> compute -> store, the per-instance
+     * data of a batch do not fit any cache, and a batch of a few thousand small instances puts fewer than two waves on a
+     * SIMD, so nothing else hides the HBM round trips: they, not the arithmetic, were the launch time of these shapes.
+     * Every address is independent of loaded data (the box row of a lane follows from the stage's masks; a lane without a
+     * row reads row 0 of the stage: always readable), the activity bits select afterwards. */
+    struct StageLoads
+    {
+        double M[n], Br[NX], Bc[n], v, g, bv, xn, pin, pik, ll, lu, tl, tu, dl, du;
+        uint64_t am;
+    };
+#if defined(W16_PF_DEPTH)
+    constexpr int PD = W16_PF_DEPTH;
+#else
+    constexpr int PD = W16Prefetch<NX, NU, SOFT>::FACTOR;
+#endif
+    constexpr int PR = PD > 0 ? PD : 1;
+    const int lc_ = mine ? l : 0, xc_ = isx ? cx : 0;
+    auto load_stage = [&](int k, StageLoads &F)
     {
         const GqpStage &S = D.st[k];
+        F.am = WAT(D.amask, k * D.AW);
+        W16_UNROLL for (int c = 0; c < n; c++) F.M[c] = WAT(D.RSQ, k * NP + (c <= lc_ ? PK(lc_, c) : PK(c, lc_)));
+        W16_UNROLL for (int c = 0; c < NX; c++) F.Br[c] = WAT(D.BAt, (k * n + lc_) * NX + c);
+        W16_UNROLL for (int r = 0; r < n; r++) F.Bc[r] = WAT(D.BAt, (k * n + r) * NX + xc_);
+        F.v = WAT(D.ux, k * n + lc_); F.g = WAT(D.rq, k * n + lc_);
+        F.bv = WAT(D.bvec, k * NX + xc_); F.xn = WAT(D.ux, (k + 1) * n + NU + xc_);
+        F.pin = WAT(D.pi, (k + 1) * NX + xc_); F.pik = WAT(D.pi, k * NX + xc_);
+        const bool hs = mine && (((S.bmask & ~S.emask) >> l) & 1);
+        const int ib = hs ? popc64(S.bmask & (((uint64_t) 1 << l) - 1)) : 0;
+        const int el = S.o_ct + ib, eu = el + S.nb;
+        F.ll = WAT(D.lam, el); F.lu = WAT(D.lam, eu);
+        F.tl = WAT(D.t, el); F.tu = WAT(D.t, eu);
+        F.dl = WAT(D.dvec, el); F.du = WAT(D.dvec, eu);
+    };
+    StageLoads R[PR];
+    if (PD > 0)
+    {
+        W16_UNROLL for (int d = 0; d < PR; d++)
+            if (D.N - d >= 0) load_stage(D.N - d, R[d]);
+    }
+
+    for (int k0 = D.N; k0 >= 0; k0 -= PR)
+    W16_UNROLL for (int d = 0; d < PR; d++)
+    {
+        const int k = k0 - d;
+        if (k < 0) break;
+        const GqpStage &S = D.st[k];
         const uint64_t imask = S.bmask & ~S.emask;
-        const uint64_t am = WAT(D.amask, k * D.AW);
         const int nbg = S.nb;
         const bool fixed = mine && ((S.emask >> l) & 1);
+        StageLoads F;
+        if (PD > 0)
+        {
+            F = R[d];
+            if (k - PR >= 0) load_stage(k - PR, R[d]);
+        }
+        else load_stage(k, F);
+        const uint64_t am = F.am;
 
-        /* ---- loads: symmetric row l of H, row l of [B A]', column cx of [B A]' (state lanes).  Idle lanes read
-         * through clamped indices and zero the values afterwards: no exec-masked branch per load ---- */
-        const int lc_ = mine ? l : 0, xc_ = isx ? cx : 0;
+        /* ---- idle lanes have read through clamped indices and zero the values now: no exec-masked branch per load ---- */
         const double zm = mine ? 1.0 : 0.0, zx = isx ? 1.0 : 0.0;
         double M[n], Br[NX], Bc[n];
-        W16_UNROLL for (int c = 0; c < n; c++) M[c] = zm * WAT(D.RSQ, k * NP + (c <= lc_ ? PK(lc_, c) : PK(c, lc_)));
-        W16_UNROLL for (int c = 0; c < NX; c++) Br[c] = zm * WAT(D.BAt, (k * n + lc_) * NX + c);
-        W16_UNROLL for (int r = 0; r < n; r++) Bc[r] = zx * WAT(D.BAt, (k * n + r) * NX + xc_);
-        const double v = zm * WAT(D.ux, k * n + lc_), g = zm * WAT(D.rq, k * n + lc_);
-        double rb = zx * (WAT(D.bvec, k * NX + xc_) - WAT(D.ux, (k + 1) * n + NU + xc_));
-        const double pin = zx * WAT(D.pi, (k + 1) * NX + xc_), pik = zx * WAT(D.pi, k * NX + xc_);
+        W16_UNROLL for (int c = 0; c < n; c++) M[c] = zm * F.M[c];
+        W16_UNROLL for (int c = 0; c < NX; c++) Br[c] = zm * F.Br[c];
+        W16_UNROLL for (int r = 0; r < n; r++) Bc[r] = zx * F.Bc[r];
+        const double v = zm * F.v, g = zm * F.g;
+        double rb = zx * (F.bv - F.xn);
+        const double pin = zx * F.pin, pik = zx * F.pik;
         const bool has = mine && ((imask >> l) & 1);
         const int ib = has ? popc64(S.bmask & (((uint64_t) 1 << l) - 1)) : 0;
         const bool al = has && ((am >> ib) & 1), au = has && ((am >> (nbg + ib)) & 1);
         const int el = S.o_ct + ib, eu = el + nbg; /* row 0 of the stage when the lane has no row: always readable */
-        const double ll = al ? WAT(D.lam, el) : 0.0, lu = au ? WAT(D.lam, eu) : 0.0;
-        const double ttl = al ? WAT(D.t, el) : 1.0, ttu = au ? WAT(D.t, eu) : 1.0;
-        const double lbv = al ? WAT(D.dvec, el) : 0.0, ubv = au ? WAT(D.dvec, eu) : 0.0;
+        const double ll = al ? F.ll : 0.0, lu = au ? F.lu : 0.0;
+        const double ttl = al ? F.tl : 1.0, ttu = au ? F.tu : 1.0;
+        const double lbv = al ? F.dl : 0.0, ubv = au ? F.du : 0.0;
         /* SOFT: the slack of this lane's row (values, cost, its two bound rows) */
         const int sj = (SOFT && has) ? w16_srev(S, ib) : -1;
         const int sq = sj >= 0 ? sj : 0, se0 = S.o_ct + 2 * nbg + sq, se1 = se0 + S.ns;

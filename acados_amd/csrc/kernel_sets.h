@@ -21,20 +21,27 @@ struct KernelSet
     kern_opts_t init;
     kern_redo_t back_fact, back_rhs, fwd_aff, fwd_corr;
     kern_plain_t finalize;
-    /* fast path for box-only QPs (ipm_kernels_box.hpp); index = XBOX (any box row on a state) */
+    /* fast path for box-only QPs (ipm_kernels_box.hpp; ipm_kernels_box_small.hpp for nu + nx <= 6); index = XBOX (any box
+     * row on a state) */
     kern_redo_t box_fact[2], box_rhs[2], box_fwd_aff[2], box_fwd_corr[2];
     kern_plain_t box_finalize;
+    /* the ipm_kernels_box.hpp kernels for every shape (ACADOS_AMD_KB_SMALL=0: cross-check of the small-block kernels) */
+    kern_redo_t kb_fact[2], kb_rhs[2], kb_fwd_aff[2], kb_fwd_corr[2];
 };
 
 #define GQP_KSET(NX, NU, NG, NS)                                                               \
     {NX, NU, NG, NS, gqp::k_init<NX, NU, NG, NS>, gqp::k_backward<NX, NU, NG, NS, true>,       \
      gqp::k_backward<NX, NU, NG, NS, false>, gqp::k_forward<NX, NU, NG, NS, false>,            \
      gqp::k_forward<NX, NU, NG, NS, true>, gqp::k_finalize<NX, NU, NG, NS>,                    \
+     {gqp::kb_factor_for<NX, NU, false>(), gqp::kb_factor_for<NX, NU, true>()},                \
+     {gqp::kb_backrhs_for<NX, NU, false>(), gqp::kb_backrhs_for<NX, NU, true>()},              \
+     {gqp::kb_forward_for<NX, NU, false, false>(), gqp::kb_forward_for<NX, NU, true, false>()}, \
+     {gqp::kb_forward_for<NX, NU, false, true>(), gqp::kb_forward_for<NX, NU, true, true>()},  \
+     gqp::kb_finalize<NX, NU>,                                                                 \
      {gqp::kb_factor<NX, NU, false>, gqp::kb_factor<NX, NU, true>},                            \
      {gqp::kb_backrhs<NX, NU, false>, gqp::kb_backrhs<NX, NU, true>},                          \
      {gqp::kb_forward<NX, NU, false, false>, gqp::kb_forward<NX, NU, true, false>},            \
-     {gqp::kb_forward<NX, NU, false, true>, gqp::kb_forward<NX, NU, true, true>},              \
-     gqp::kb_finalize<NX, NU>}
+     {gqp::kb_forward<NX, NU, false, true>, gqp::kb_forward<NX, NU, true, true>}}
 
 /* partial condensing: parent shape (NX, NU), blocks of at most BSMAX stages -> child shape
  * (NX, BSMAX*NU); kernels in pcond_kernels.hpp */

@@ -895,3 +895,53 @@ def test_w16r_repeatability_gpu(gpu_lib):
         stop.set()
         th.join()
     assert not side_bad
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("xbox", [False, True])
+def test_small_block_pipeline_gpu(gpu_lib, monkeypatch, xbox):
+    """nx = 4, nu = 1 at the per-GPU share of a C5 class (7,281 instances, N = 20) and at 16,384 with bounds on the states:
+    the default dispatch puts them on the pipelined one-instance-per-lane kernels (ipm_kernels_box_small.hpp); outputs and
+    iteration counts bit-identical to the phase-ordered kernels of ipm_kernels_box.hpp (same arithmetic, same order),
+    iteration counts equal to the sixteen-lanes family's, a sample against the oracle at 1e-8"""
+    from acados_amd import OcpQpGpuBatch
+    from acados_amd.generators import fill_lqr_batch, lqr_dims, lqr_instance_qp, random_lqr_batch
+    nx, nu, N = 4, 1, 20
+    B = 16384 if xbox else 7281
+    monkeypatch.delenv("ACADOS_AMD_WPI_BATCH_MAX", raising=False)      # the default dispatch is what is tested
+    data = random_lqr_batch(N=N, nx=nx, nu=nu, batch=B, seed=77)
+    out = {}
+    for fam in ("small", "phases", "w16"):
+        monkeypatch.setenv("ACADOS_AMD_KB_SMALL", "0" if fam == "phases" else "1")
+        if fam == "w16":
+            monkeypatch.setenv("ACADOS_AMD_WPI", "1")
+        d = lqr_dims(N, nx, nu)
+        if xbox:
+            d.nbx[1:] = nx
+            d.nb[:] = d.nbu + d.nbx
+        gb = OcpQpGpuBatch(d, B)
+        fill_lqr_batch(gb, data, N)
+        if xbox:
+            for k in range(1, N + 1):
+                gb.set("lbx", k, np.full((B, nx), -50.0)); gb.set("ubx", k, np.full((B, nx), 50.0))
+        for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+            gb.opts_set(f, 1e-8)
+        assert gb.solve() == 0
+        assert gb.kernel_name.startswith("w16-box" if fam == "w16" else "1tpi-box<NX=4,NU=1,XBOX=%d" % int(xbox)), gb.kernel_name
+        assert gb.res_compute().max() <= KKT_TOL
+        out[fam] = ([gb.get(f, k) for f in ("x", "lam", "t") for k in range(N + 1)] + [gb.get(f, k) for f in ("u", "pi") for k in range(N)]
+                    + [gb.info("iter")])
+        del gb
+    for a, b in zip(out["small"], out["phases"]):
+        assert np.array_equal(a, b)
+    assert np.max(np.abs(out["small"][-1] - out["w16"][-1])) <= (1 if xbox else 0)
+    if not xbox:
+        worst = 0.0
+        for i in range(0, B, 227):
+            o = OracleQp(lqr_instance_qp(data, i, N))
+            assert o.solve(default_opts(tol_stat=1e-8)) == 0
+            assert out["small"][-1][i] == o.iter
+            for k in range(N + 1):
+                rx = o.get(k, "x")
+                worst = max(worst, np.max(np.abs(out["small"][k][i] - rx) / np.maximum(1.0, np.abs(rx))))
+        assert worst <= 1e-8, worst

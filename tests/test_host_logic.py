@@ -1313,3 +1313,43 @@ def test_degenerate_sizes_hostsim(hostsim_lib, monkeypatch, fam):
     compare_with_oracle(lambda k, f: b.get(f, k)[1], o, qp, 1e-8, fields=("x", "lam", "t"))
     e = OcpQpGpuBatch(lqr_dims(5, 8, 3), 0, _clib=hostsim_lib)
     assert e.solve() == 0 and e.get("x", 0).shape == (0, 8)
+
+
+@pytest.mark.parametrize("xbox", [False, True])
+def test_small_block_pipeline_bit_identical_hostsim(hostsim_lib, monkeypatch, xbox):
+    """nu + nx <= 6: the pipelined one-instance-per-lane kernels (ipm_kernels_box_small.hpp: a stage's loads as one record,
+    a ring of records in flight) against the phase-ordered kernels of ipm_kernels_box.hpp they replace -- same arithmetic
+    in the same order, so every output and every iteration count must be bit-identical; horizons shorter than, equal to
+    and longer than the ring; a ragged batch; a sample against the oracle"""
+    from acados_amd import OcpQpGpuBatch
+    from acados_amd.generators import fill_lqr_batch, lqr_dims, lqr_instance_qp, random_lqr_batch
+    nx, nu, B = 4, 1, 70
+    for N in (1, 2, 3, 9):
+        data = random_lqr_batch(N=N, nx=nx, nu=nu, batch=B, seed=40 + N)
+        out = {}
+        for small in ("1", "0"):
+            monkeypatch.setenv("ACADOS_AMD_KB_SMALL", small)
+            d = lqr_dims(N, nx, nu)
+            if xbox:
+                d.nbx[1:] = nx
+                d.nb[:] = d.nbu + d.nbx
+            gb = OcpQpGpuBatch(d, B, _clib=hostsim_lib)
+            fill_lqr_batch(gb, data, N)
+            if xbox:
+                for k in range(1, N + 1):
+                    gb.set("lbx", k, np.full((B, nx), -50.0)); gb.set("ubx", k, np.full((B, nx), 50.0))
+            gb.opts_set("tol_stat", 1e-8)
+            assert gb.solve() == 0
+            assert gb.kernel_name.startswith("1tpi-box<NX=4,NU=1,XBOX=%d" % int(xbox))
+            out[small] = ([gb.get(f, k) for f in ("x", "lam", "t") for k in range(N + 1)] + [gb.get(f, k) for f in ("u", "pi") for k in range(N)]
+                          + [gb.info("iter"), gb.info("res_stat"), gb.info("res_comp")])
+            assert gb.res_compute().max() <= 1e-7
+        for a, b in zip(out["1"], out["0"]):
+            assert np.array_equal(a, b)
+        if not xbox:
+            for i in (0, 63, 64, 69):
+                o = OracleQp(lqr_instance_qp(data, i, N))
+                assert o.solve(default_opts(tol_stat=1e-8)) == 0
+                assert out["1"][-3][i] == o.iter
+                for k in range(N + 1):
+                    assert np.allclose(out["1"][k][i], o.get(k, "x"), atol=1e-9)
