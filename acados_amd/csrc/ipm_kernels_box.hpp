@@ -101,7 +101,7 @@ struct StageU
 __device__ static inline StageU stage_u(const GqpStage *st, int k)
 {
     StageU S;
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GQP_STAGE_VECTOR_LOADS) /* (development builds: the old fetch, for A/B runs) */
     typedef const GqpStage __attribute__((address_space(4))) *cstage_t;
     const cstage_t p = (cstage_t) (uintptr_t) (st + k);
     S.nb = uni(p->nb);

@@ -2,8 +2,9 @@
  * ipm_kernels_box_small.hpp -- the one-instance-per-lane box kernels (ipm_kernels_box.hpp) for SMALL stage blocks
  * (nu + nx <= 6: the nx = 4 classes of C5), as a software pipeline over the stages.
  *
- * Same arrays, same arithmetic in the same order as kb_factor / kb_backrhs / kb_forward (the tests compare the two
- * families bit for bit), different shape of the code.  The kb kernels are built around the register file of the C2
+ * Same arrays, same arithmetic in the same order as kb_factor / kb_backrhs / kb_forward (bit-identical under the host
+ * simulation; on the device hipcc contracts the multiply-adds of the two code shapes differently: outputs agree to
+ * 1e-13, iteration counts exactly -- tests/test_gpu_parity.py::test_small_block_pipeline_gpu), different shape of the code.  The kb kernels are built around the register file of the C2
  * block (11 x 11): loads in ordered phases, W parked in LDS -- four to five dependent HBM round trips per stage.
  * That is the right trade at 65,536 instances, where HBM bandwidth is the bound.  A class of a few thousand small
  * instances is a different machine: 7,281 instances are 114 waves, one on every ninth SIMD, nothing is bandwidth- or
