@@ -360,7 +360,7 @@ void finalize_structure(ocp_qp_gpu_batch *b)
     GqpDev &D = b->D;
     const size_t Bp = b->Bp;
     D.B = b->B; D.Bp = b->Bp; D.N = N; D.NX = NX; D.NU = NU; D.NG = b->ks->NG; D.NS = b->ks->NS;
-    D.st = b->d_st;
+    D.st = (GqpStagePtr) (uintptr_t) b->d_st;
     const size_t RP = 16; /* spare row elements (clamped dummy row index) */
     D.BAt = garr<double>(b, (size_t) ((N + 1) * n * NX));
     D.bvec = garr<double>(b, (size_t) ((N + 1) * NX));

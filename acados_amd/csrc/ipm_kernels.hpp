@@ -82,7 +82,7 @@ __global__ void __launch_bounds__(64) k_init(GqpDev D, GqpOpts O)
     const double t_c = O.t0_init == 0 ? sqrt(O.mu0) : 1.0, l_c = O.t0_init == 0 ? sqrt(O.mu0) : O.mu0;
     for (int k = 0; k <= D.N; k++)
     {
-        const GqpStage &S = D.st[k];
+        GQP_STAGE_REF S = D.st[k];
         const int nbg = S.nb + S.ng;
         const uint64_t am = GATL(D.amask, k);
         double v[n];
@@ -257,7 +257,7 @@ __global__ void __launch_bounds__(64) k_backward(GqpDev D, GqpOpts O, int redo)
 
     for (int k = D.N; k >= 0; k--)
     {
-        const GqpStage &S = D.st[k];
+        GQP_STAGE_REF S = D.st[k];
         const int nbg = S.nb + S.ng;
         const uint64_t am = GAT(D.amask, k);
         double M[NP];  /* FACT: Hessian then factor ; !FACT: factor loaded from HBM */
@@ -759,7 +759,7 @@ __global__ void __launch_bounds__(64) k_forward(GqpDev D, GqpOpts O, int redo)
 
     for (int k = 0; k <= D.N; k++)
     {
-        const GqpStage &S = D.st[k];
+        GQP_STAGE_REF S = D.st[k];
         const int nbg = S.nb + S.ng;
         const uint64_t am = GAT(D.amask, k);
         double L[NP], l[n], dv[n];
@@ -956,7 +956,7 @@ __global__ void __launch_bounds__(64) k_forward(GqpDev D, GqpOpts O, int redo)
         int nact = 0;
         for (int k = 0; k <= D.N; k++)
         {
-            const GqpStage &S = D.st[k];
+            GQP_STAGE_REF S = D.st[k];
             const int nct = 2 * (S.nb + S.ng) + 2 * S.ns;
             const uint64_t am = GAT(D.amask, k);
             for (int e = 0; e < nct; e++)
@@ -988,7 +988,7 @@ __global__ void __launch_bounds__(64) k_forward(GqpDev D, GqpOpts O, int redo)
         const double a = D.mu[i] > 0.0 ? alpha * 0.995 : 1.0;
         for (int k = 0; k <= D.N; k++)
         {
-            const GqpStage &S = D.st[k];
+            GQP_STAGE_REF S = D.st[k];
             const int nct = 2 * (S.nb + S.ng) + 2 * S.ns;
             const uint64_t am = GAT(D.amask, k);
             UNROLL for (int j = 0; j < n; j++) GAT(D.ux, k * n + j) += a * GAT(D.dux, k * n + j);
@@ -1021,7 +1021,7 @@ __global__ void __launch_bounds__(64) k_finalize(GqpDev D)
     if (i >= D.B) return;
     for (int k = 0; k <= D.N; k++)
     {
-        const GqpStage &S = D.st[k];
+        GQP_STAGE_REF S = D.st[k];
         const int nbg = S.nb + S.ng;
         const uint64_t am = GATL(D.amask, k);
         double v[n];
@@ -1313,7 +1313,7 @@ static __global__ void k_hot_start(GqpDev D, double t_min, double lam_min)
     D.smu[i] = 0.0;
     for (int k = 0; k <= D.N; k++)
     {
-        const GqpStage &S = D.st[k];
+        GQP_STAGE_REF S = D.st[k];
         const int nct = 2 * (S.nb + S.ng) + 2 * S.ns;
         for (int e = 0; e < nct; e++)
         {
@@ -1347,7 +1347,7 @@ static __global__ void k_sens_fixed(GqpDev D, GArr sfix, int out)
     const int NX = D.NX, NU = D.NU, n = NX + NU, NP = n * (n + 1) / 2;
     for (int k = 0; k <= D.N; k++)
     {
-        const GqpStage &S = D.st[k];
+        GQP_STAGE_REF S = D.st[k];
         if (!S.emask) continue;
         for (int j = 0; j < n; j++)
         {

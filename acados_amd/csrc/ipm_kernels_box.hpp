@@ -93,27 +93,13 @@ struct StageU
     int nb, o_ct;
     uint64_t bmask, emask;
 };
-/* The stage table is written by the host before the first launch and never by a kernel: it is read through the constant
- * address space, i.e. with SCALAR loads (s_load, lgkmcnt) at every point of a kernel.  Through a plain pointer the
- * compiler may use scalar loads only until the kernel's first store (the table might alias it); from then on it fetched
- * the table with vector loads, and every use of a stage's fields -- buffer offsets above all -- first waited for vmcnt to
- * drain past that load: one exposed round trip per stage, and a stop for any load issued ahead of it. */
-__device__ static inline StageU stage_u(const GqpStage *st, int k)
+__device__ static inline StageU stage_u(GqpStagePtr st, int k)
 {
     StageU S;
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(GQP_STAGE_VECTOR_LOADS) /* (development builds: the old fetch, for A/B runs) */
-    typedef const GqpStage __attribute__((address_space(4))) *cstage_t;
-    const cstage_t p = (cstage_t) (uintptr_t) (st + k);
-    S.nb = uni(p->nb);
-    S.o_ct = uni(p->o_ct);
-    S.bmask = uni64(p->bmask);
-    S.emask = uni64(p->emask);
-#else
     S.nb = uni(st[k].nb);
     S.o_ct = uni(st[k].o_ct);
     S.bmask = uni64(st[k].bmask);
     S.emask = uni64(st[k].emask);
-#endif
     return S;
 }
 

@@ -123,9 +123,9 @@ __device__ static inline double w16_rmin(double v, double *xb)
 
 /* slack index of sorted box row ib (< 16 here) without a lane-indexed memory access: the first 16 entries of the
  * stage's row -> slack map are two uniform 64-bit words, the lane picks its byte */
-__device__ static inline int w16_srev(const GqpStage &S, int ib)
+__device__ static inline int w16_srev(GQP_STAGE_REF S, int ib)
 {
-    const uint64_t *sp = reinterpret_cast<const uint64_t *>(S.srev);
+    const GQP_CONST_AS uint64_t *sp = (const GQP_CONST_AS uint64_t *) S.srev;
     const uint64_t w = ib < 8 ? sp[0] : sp[1];
     return (int) (int8_t) (w >> ((ib & 7) * 8));
 }
@@ -186,7 +186,7 @@ __device__ static inline void kx_factor_body(const GqpDev &D, const GqpOpts &O, 
     const int lc_ = mine ? l : 0, xc_ = isx ? cx : 0;
     auto load_stage = [&](int k, StageLoads &F)
     {
-        const GqpStage &S = D.st[k];
+        GQP_STAGE_REF S = D.st[k];
         F.am = WAT(D.amask, k * D.AW);
         W16_UNROLL for (int c = 0; c < n; c++) F.M[c] = WAT(D.RSQ, k * NP + (c <= lc_ ? PK(lc_, c) : PK(c, lc_)));
         W16_UNROLL for (int c = 0; c < NX; c++) F.Br[c] = WAT(D.BAt, (k * n + lc_) * NX + c);
@@ -213,7 +213,7 @@ __device__ static inline void kx_factor_body(const GqpDev &D, const GqpOpts &O, 
     {
         const int k = k0 - d;
         if (k < 0) break;
-        const GqpStage &S = D.st[k];
+        GQP_STAGE_REF S = D.st[k];
         const uint64_t imask = S.bmask & ~S.emask;
         const int nbg = S.nb;
         const bool fixed = mine && ((S.emask >> l) & 1);
@@ -443,7 +443,7 @@ __device__ static inline void kx_backrhs_body(const GqpDev &D, const GqpOpts &O,
 
     for (int k = D.N; k >= 0; k--)
     {
-        const GqpStage &S = D.st[k];
+        GQP_STAGE_REF S = D.st[k];
         const uint64_t imask = S.bmask & ~S.emask;
         const uint64_t am = WAT(D.amask, k * D.AW);
         const int nbg = S.nb;
@@ -559,7 +559,7 @@ __device__ static inline void kx_fwd_body(const GqpDev &D, const GqpOpts &O, int
 
     for (int k = 0; k <= D.N; k++)
     {
-        const GqpStage &S = D.st[k];
+        GQP_STAGE_REF S = D.st[k];
         const uint64_t imask = S.bmask & ~S.emask;
         const uint64_t am = WAT(D.amask, k * D.AW);
         const int nbg = S.nb;
@@ -746,7 +746,7 @@ __device__ static inline void kx_fwd_body(const GqpDev &D, const GqpOpts &O, int
     {
         constexpr int CH = SOFT ? 4 : 6;
         const int lc_ = mine ? l : 0, xc_ = isx ? cx : 0;
-        const GqpStage *__restrict__ st_ = D.st;
+        const GqpStagePtr st_ = D.st;
         const uint64_t *__restrict__ am_ = D.amask.p + (size_t) inst * D.amask.E;
         for (int k0 = 0; k0 <= D.N; k0 += CH)
         {

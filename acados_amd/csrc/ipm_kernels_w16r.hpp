@@ -613,7 +613,7 @@ __global__ void __launch_bounds__(64) W16R_WPE_FACT ky_factor(GqpDev D, GqpOpts 
     double p_G[NGP > 0 ? NGP : 1];
     auto load_desc = [&](int kk)
     {
-        const GqpStage &Sn = D.st[kk];
+        GQP_STAGE_REF Sn = D.st[kk];
         n_bm = Sn.bmask; n_em = Sn.emask; n_nb = Sn.nb; n_oct = Sn.o_ct;
         if (GEN) { n_ng = Sn.ng; n_og = Sn.o_g; n_ns = Sn.ns; n_os = Sn.o_s; }
     };
@@ -1161,14 +1161,14 @@ __global__ void __launch_bounds__(64) ky_backrhs(GqpDev D, GqpOpts O, int redo)
     };
     auto load_desc = [&](int k, Desc &d)
     {
-        const GqpStage &S = D.st[k];
+        GQP_STAGE_REF S = D.st[k];
         d.bm = S.bmask; d.em = S.emask; d.nb = S.nb; d.oct = S.o_ct; d.ng = S.ng; d.ns = S.ns; d.os = S.o_s; d.og = S.o_g;
     };
     Desc cd = {}, nd = {};
     if (GEN) load_desc(D.N, cd);
     auto load = [&](int k, StageRegs &G)
     {
-        const GqpStage &S = D.st[k];
+        GQP_STAGE_REF S = D.st[k];
         if (GEN)
         {
             G.bm = cd.bm; G.em = cd.em; G.nb = cd.nb; G.oct = cd.oct;
@@ -1244,7 +1244,7 @@ __global__ void __launch_bounds__(64) ky_backrhs(GqpDev D, GqpOpts O, int redo)
         if (GEN)
         {
             /* general rows: gradient term of row g from lane g, applied as a gadd through the rows of [D C] */
-            const GqpStage &S = D.st[k];
+            GQP_STAGE_REF S = D.st[k];
             const int ng = cd.ng;
             GQP_ROWSYNC();
             W16_UNROLL for (int i = 0; i < NGP; i++)
@@ -1380,7 +1380,7 @@ __global__ void __launch_bounds__(64) W16R_WPE_FWD ky_fwd(GqpDev D, GqpOpts O, i
     int c_nb, c_oct, n_nb, n_oct, c_ng = 0, c_ns = 0, c_os = 0, c_og = 0, n_ng = 0, n_ns = 0, n_os = 0, n_og = 0;
     auto load_desc = [&](int kk)
     {
-        const GqpStage &Sn = D.st[kk];
+        GQP_STAGE_REF Sn = D.st[kk];
         n_bm = Sn.bmask; n_em = Sn.emask; n_nb = Sn.nb; n_oct = Sn.o_ct;
         if (GEN) { n_ng = Sn.ng; n_ns = Sn.ns; n_os = Sn.o_s; n_og = Sn.o_g; }
     };
@@ -1683,7 +1683,7 @@ __global__ void __launch_bounds__(64) W16R_WPE_FWD ky_fwd(GqpDev D, GqpOpts O, i
      * cost 0.68 ms of the C3 corrector sweep's 1.68: measured with the pass compiled out.) */
     {
         constexpr int CH = W16R_UPD_CH;
-        const GqpStage *__restrict__ st_ = D.st;
+        const GqpStagePtr st_ = D.st;
         const uint64_t *__restrict__ am_ = D.amask.p + (size_t) inst * D.amask.E;
         for (int k0 = 0; k0 <= D.N; k0 += CH)
         {
@@ -1741,7 +1741,7 @@ __global__ void __launch_bounds__(64) W16R_WPE_FWD ky_fwd(GqpDev D, GqpOpts O, i
          * stage k + 1 in front of the stores of stage k as well: measured, no gain.) */
         for (int k = 0; k <= D.N; k++)
         {
-            const GqpStage &S = D.st[k];
+            GQP_STAGE_REF S = D.st[k];
             const W16Dsc dsc = {S.nb, S.ng, S.ns, S.o_ct, S.o_s};
             const uint64_t am = WAT(D.amask, k * D.AW);
             W16RowU ub[R];

@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(64) kw_backward(GqpDev D, GqpOpts O, int redo)
 
     for (int k = D.N; k >= 0; k--)
     {
-        const GqpStage &S = D.st[k];
+        GQP_STAGE_REF S = D.st[k];
         const uint64_t imask = S.bmask & ~S.emask;
         const Am128 am = wpi_am(D, inst, k);
         const int nbg = S.nb;
@@ -470,7 +470,7 @@ __global__ void __launch_bounds__(64) kw_forward(GqpDev D, GqpOpts O, int redo)
 
     for (int k = 0; k <= D.N; k++)
     {
-        const GqpStage &S = D.st[k];
+        GQP_STAGE_REF S = D.st[k];
         const uint64_t imask = S.bmask & ~S.emask;
         const Am128 am = wpi_am(D, inst, k);
         const int nbg = S.nb;
@@ -607,7 +607,7 @@ __global__ void __launch_bounds__(64) kw_forward(GqpDev D, GqpOpts O, int redo)
     for (int e = NX + lane; e < (D.N + 1) * NX; e += 64) WAT(D.pi, e) += a * WAT(D.dpi, e);
     for (int k = 0; k <= D.N; k++)
     {
-        const GqpStage &S = D.st[k];
+        GQP_STAGE_REF S = D.st[k];
         const uint64_t imask = S.bmask & ~S.emask;
         const Am128 am = wpi_am(D, inst, k);
         const int nbg = S.nb;
@@ -703,7 +703,7 @@ __device__ static inline WpiCon wpi_con_carve(double *p, int n, int NG, int NS)
 }
 
 /* coalesced copy of the ng x n general rows of a stage into LDS rows of odd stride */
-__device__ static inline void wpi_load_G(const WpiCon &C, const GqpStage &S, const GArr &DCt, int inst, int o_g, int ng, int n, int lane)
+__device__ static inline void wpi_load_G(const WpiCon &C, GQP_STAGE_REF S, const GArr &DCt, int inst, int o_g, int ng, int n, int lane)
 {
     if (lane < S.nb + ng) C.rsj[lane] = S.srev[lane];
     int r = lane / n, c = lane - r * n;
@@ -726,7 +726,7 @@ __device__ static inline void wpi_excl(const WpiCon &C, int nbg, int row, int q,
 }
 
 /* entry idx of the constraint row `row` (box row: unit vector of its variable; general row: row of G) */
-__device__ static inline double wpi_arow(const WpiCon &C, const GqpStage &S, int row, int idx)
+__device__ static inline double wpi_arow(const WpiCon &C, GQP_STAGE_REF S, int row, int idx)
 {
     if (row >= S.nb) return C.G[(row - S.nb) * C.SG + idx];
     return popc64(S.bmask & (((uint64_t) 1 << idx) - 1)) == row && ((S.bmask >> idx) & 1) ? 1.0 : 0.0;
@@ -740,7 +740,7 @@ struct WpiRow
     double ll, lu, tl, tu; /* lam (0 if inactive), t (1 if inactive) */
 };
 
-__device__ static inline WpiRow wpi_row(const GqpDev &D, const GqpStage &S, const Am128 &am, int inst, int row, bool exists)
+__device__ static inline WpiRow wpi_row(const GqpDev &D, GQP_STAGE_REF S, const Am128 &am, int inst, int row, bool exists)
 {
     const int nbg = S.nb + S.ng;
     WpiRow R;
@@ -835,7 +835,7 @@ __global__ void __launch_bounds__(64) GQP_WAVES_PER_EU(T8 <= 4 ? 2 : 1) kw_facto
     GQP_TICK_INIT();
     for (int k = D.N; k >= 0; k--)
     {
-        const GqpStage &S = D.st[k];
+        GQP_STAGE_REF S = D.st[k];
         const uint64_t imask = S.bmask & ~S.emask;
         const Am128 am = wpi_am(D, inst, k);
         const int nbg = S.nb + (GEN ? S.ng : 0);
@@ -1395,7 +1395,7 @@ __global__ void __launch_bounds__(64) kw_backrhs(GqpDev D, GqpOpts O, int redo)
 
     for (int k = D.N; k >= 0; k--)
     {
-        const GqpStage &S = D.st[k];
+        GQP_STAGE_REF S = D.st[k];
         const uint64_t imask = S.bmask & ~S.emask;
         const Am128 am = wpi_am(D, inst, k);
         const int nbg = S.nb + (GEN ? S.ng : 0);
@@ -1574,7 +1574,7 @@ __global__ void __launch_bounds__(64) kw_fwd(GqpDev D, GqpOpts O, int redo)
 
     for (int k = 0; k <= D.N; k++)
     {
-        const GqpStage &S = D.st[k];
+        GQP_STAGE_REF S = D.st[k];
         const uint64_t imask = S.bmask & ~S.emask;
         const Am128 am = wpi_am(D, inst, k);
         const int nbg = S.nb + (GEN ? S.ng : 0);
@@ -1878,13 +1878,13 @@ __global__ void __launch_bounds__(64) kw_fwd(GqpDev D, GqpOpts O, int redo)
     for (int e = NX + lane; e < (D.N + 1) * NX; e += 64) WAT(D.pi, e) += a * WAT(D.dpi, e);
     if (GEN)
     {
-        const GqpStage &SN = D.st[D.N];
+        GQP_STAGE_REF SN = D.st[D.N];
         for (int e = lane; e < SN.o_s + 2 * SN.ns; e += 64) WAT(D.sv, e) += a * WAT(D.dsv, e);
     }
     for (int k = 0; k <= D.N; k++)
     {
         /* one lane per inequality side of the stage (at most 128 sides: two passes) */
-        const GqpStage &S = D.st[k];
+        GQP_STAGE_REF S = D.st[k];
         const Am128 am = wpi_am(D, inst, k);
         const int nct = 2 * (S.nb + S.ng) + 2 * S.ns;
         for (int side = lane; side < nct; side += 64)
@@ -1923,7 +1923,7 @@ __global__ void __launch_bounds__(64) kw_init(GqpDev D, GqpOpts O)
     double *vv = smem, *cv = smem + 64, *ssl = smem + 128, *ssu = smem + 160; /* v, row values, slack values */
     for (int k = 0; k <= D.N; k++)
     {
-        const GqpStage &S = D.st[k];
+        GQP_STAGE_REF S = D.st[k];
         const int nbg = S.nb + (GEN ? S.ng : 0);
         const Am128 am = wpi_am(D, inst, k);
         const bool mine = lane < n, hasb = mine && ((S.bmask >> lane) & 1);
@@ -2039,7 +2039,7 @@ __global__ void __launch_bounds__(64) kw_finalize(GqpDev D)
     if (inst >= D.B) return;
     for (int k = 0; k <= D.N; k++)
     {
-        const GqpStage &S = D.st[k];
+        GQP_STAGE_REF S = D.st[k];
         const int nbg = S.nb + (GEN ? S.ng : 0);
         const Am128 am = wpi_am(D, inst, k);
         if (lane < n && ((S.bmask >> lane) & 1))

@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(64) GQP_WAVES_PER_EU(2) kw_factor_m(GqpDev D, 
     GQP_TICK_INIT();
     for (int k = D.N; k >= 0; k--)
     {
-        const GqpStage &S = D.st[k];
+        GQP_STAGE_REF S = D.st[k];
         const uint64_t imask = S.bmask & ~S.emask;
         const Am128 am = wpi_am(D, inst, k);
         const int nbg = S.nb + (GEN ? S.ng : 0);

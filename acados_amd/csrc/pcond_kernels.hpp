@@ -170,13 +170,13 @@ __global__ void __launch_bounds__(64) k_pcond(GqpDev P, GqpDev Cd, PcondMap Mp)
         if (jb < Mp.N2)
             for (int r = 0; r < NX; r++) GATL(Cd.bvec, jb * NX + r) = c[r];
         /* box rows, activity bits, value of fixed variables */
-        const GqpStage &Sc = Cd.st[jb];
+        GQP_STAGE_REF Sc = Cd.st[jb];
         const int r0 = Mp.row_off[jb], nbc = Sc.nb;
         uint64_t amc = 0;
         for (int rc = 0; rc < nbc; rc++)
         {
             const int kp = Mp.row_kp[r0 + rc], rp = Mp.row_rp[r0 + rc];
-            const GqpStage &Sp = P.st[kp];
+            GQP_STAGE_REF Sp = P.st[kp];
             const uint64_t amp = GATL(P.amask, kp);
             GATL(Cd.dvec, Sc.o_ct + rc) = GATL(P.dvec, Sp.o_ct + rp);
             GATL(Cd.dvec, Sc.o_ct + nbc + rc) = GATL(P.dvec, Sp.o_ct + Sp.nb + rp);
@@ -247,12 +247,12 @@ __global__ void __launch_bounds__(64) k_pexpand(GqpDev P, GqpDev Cd, PcondMap Mp
             }
         }
         /* inequality rows */
-        const GqpStage &Sc = Cd.st[jb];
+        GQP_STAGE_REF Sc = Cd.st[jb];
         const int r0 = Mp.row_off[jb], nbc = Sc.nb;
         for (int rc = 0; rc < nbc; rc++)
         {
             const int kp = Mp.row_kp[r0 + rc], rp = Mp.row_rp[r0 + rc];
-            const GqpStage &Sp = P.st[kp];
+            GQP_STAGE_REF Sp = P.st[kp];
             GATL(P.lam, Sp.o_ct + rp) = GATL(Cd.lam, Sc.o_ct + rc);
             GATL(P.lam, Sp.o_ct + Sp.nb + rp) = GATL(Cd.lam, Sc.o_ct + nbc + rc);
             GATL(P.t, Sp.o_ct + rp) = GATL(Cd.t, Sc.o_ct + rc);
@@ -328,8 +328,8 @@ static __global__ void __launch_bounds__(64) kw_pcond(GqpDev P, GqpDev Cd, Pcond
              * i.e. coefficients a_u E_ii + a_x X, bounds shifted by a_x' c */
             {
                 const int g0 = Mp.gk_off[k], ngk = Mp.gk_off[k + 1] - g0, gbase = g0 - Mp.gk_off[k0];
-                const GqpStage &Sp = P.st[k];
-                const GqpStage &Sc = Cd.st[jb];
+                GQP_STAGE_REF Sp = P.st[k];
+                GQP_STAGE_REF Sc = Cd.st[jb];
                 if (Mp.mode & 1)
                     for (int e = lane; e < ngk * nc; e += 64)
                     {
@@ -459,19 +459,19 @@ static __global__ void __launch_bounds__(64) kw_pcond(GqpDev P, GqpDev Cd, Pcond
             for (int e = lane; e < nc; e += 64) PLAT(Cd.rq, jb * nc + e) = gb[e];
             if (jb < Mp.N2 && lane < NX) PLAT(Cd.bvec, jb * NX + lane) = c[lane];
             /* box rows, activity bits, value of fixed variables */
-            const GqpStage &Sc = Cd.st[jb];
+            GQP_STAGE_REF Sc = Cd.st[jb];
             const int r0 = Mp.row_off[jb], nbc = Sc.nb, nbgc = Sc.nb + Sc.ng, q0 = Mp.slk_off[jb];
             for (int rc = lane; rc < nbc; rc += 64) /* box rows keep their bounds (general rows: written above) */
             {
                 const int kp = Mp.row_kp[r0 + rc], rp = Mp.row_rp[r0 + rc];
-                const GqpStage &Sp = P.st[kp];
+                GQP_STAGE_REF Sp = P.st[kp];
                 PLAT(Cd.dvec, Sc.o_ct + rc) = PLAT(P.dvec, Sp.o_ct + rp);
                 PLAT(Cd.dvec, Sc.o_ct + nbgc + rc) = PLAT(P.dvec, Sp.o_ct + Sp.nb + Sp.ng + rp);
             }
             for (int sc = lane; sc < Sc.ns; sc += 64) /* slacks travel unchanged: cost, bounds */
             {
                 const int kp = Mp.slk_kp[q0 + sc], sp = Mp.slk_sp[q0 + sc];
-                const GqpStage &Sp = P.st[kp];
+                GQP_STAGE_REF Sp = P.st[kp];
                 const int cp = Sp.o_ct + 2 * (Sp.nb + Sp.ng), cc = Sc.o_ct + 2 * nbgc;
                 PLAT(Cd.dvec, cc + sc) = PLAT(P.dvec, cp + sp);
                 PLAT(Cd.dvec, cc + Sc.ns + sc) = PLAT(P.dvec, cp + Sp.ns + sp);
@@ -545,12 +545,12 @@ static __global__ void __launch_bounds__(64) kw_pexpand(GqpDev P, GqpDev Cd, Pco
             __syncthreads();
         }
         /* inequality rows and slacks: same constraints, same multipliers */
-        const GqpStage &Sc = Cd.st[jb];
+        GQP_STAGE_REF Sc = Cd.st[jb];
         const int r0 = Mp.row_off[jb], nbgc = Sc.nb + Sc.ng, q0 = Mp.slk_off[jb];
         for (int rc = lane; rc < nbgc; rc += 64)
         {
             const int kp = Mp.row_kp[r0 + rc], rp = Mp.row_rp[r0 + rc];
-            const GqpStage &Sp = P.st[kp];
+            GQP_STAGE_REF Sp = P.st[kp];
             const int up = Sp.o_ct + Sp.nb + Sp.ng + rp, uc = Sc.o_ct + nbgc + rc;
             PLAT(P.lam, Sp.o_ct + rp) = PLAT(Cd.lam, Sc.o_ct + rc);
             PLAT(P.lam, up) = PLAT(Cd.lam, uc);
@@ -560,7 +560,7 @@ static __global__ void __launch_bounds__(64) kw_pexpand(GqpDev P, GqpDev Cd, Pco
         for (int sc = lane; sc < Sc.ns; sc += 64)
         {
             const int kp = Mp.slk_kp[q0 + sc], sp = Mp.slk_sp[q0 + sc];
-            const GqpStage &Sp = P.st[kp];
+            GQP_STAGE_REF Sp = P.st[kp];
             const int cp = Sp.o_ct + 2 * (Sp.nb + Sp.ng), cc = Sc.o_ct + 2 * nbgc;
             PLAT(P.sv, Sp.o_s + sp) = PLAT(Cd.sv, Sc.o_s + sc);
             PLAT(P.sv, Sp.o_s + Sp.ns + sp) = PLAT(Cd.sv, Sc.o_s + Sc.ns + sc);
@@ -588,7 +588,7 @@ static __global__ void __launch_bounds__(64) kw_pexpand(GqpDev P, GqpDev Cd, Pco
                     pk = PLAT(P.rq, k * n + rr);
                     for (int q = 0; q < n; q++) pk += PLAT(P.RSQ, k * NP + (rr >= q ? PK(rr, q) : PK(q, rr))) * ux[q];
                     for (int q = 0; q < NX; q++) pk += PLAT(P.BAt, (k * n + rr) * NX + q) * pn[q];
-                    const GqpStage &Sp = P.st[k];
+                    GQP_STAGE_REF Sp = P.st[k];
                     const int nbgp = Sp.nb + Sp.ng;
                     auto dlam = [&](int rp) { /* lam_lower - lam_upper of sorted row rp, active sides only */
                         const int su_ = nbgp + rp;
@@ -639,12 +639,12 @@ static __global__ void __launch_bounds__(64) k_pcond_sol(GqpDev P, GqpDev Cd, Pc
         /* pi slot s = multiplier of the dynamics producing x_s: child slot jb+1 <-> parent slot blk_start[jb+1] */
         if (jb < Mp.N2)
             for (int r = 0; r < NX; r++) GATL(Cd.pi, (jb + 1) * NX + r) = GATL(P.pi, (k0 + bs) * NX + r);
-        const GqpStage &Sc = Cd.st[jb];
+        GQP_STAGE_REF Sc = Cd.st[jb];
         const int r0 = Mp.row_off[jb], nbgc = Sc.nb + Sc.ng, q0 = Mp.slk_off[jb];
         for (int rc = 0; rc < nbgc; rc++)
         {
             const int kp = Mp.row_kp[r0 + rc], rp = Mp.row_rp[r0 + rc];
-            const GqpStage &Sp = P.st[kp];
+            GQP_STAGE_REF Sp = P.st[kp];
             const int up = Sp.o_ct + Sp.nb + Sp.ng + rp, uc = Sc.o_ct + nbgc + rc;
             GATL(Cd.lam, Sc.o_ct + rc) = GATL(P.lam, Sp.o_ct + rp);
             GATL(Cd.lam, uc) = GATL(P.lam, up);
@@ -654,7 +654,7 @@ static __global__ void __launch_bounds__(64) k_pcond_sol(GqpDev P, GqpDev Cd, Pc
         for (int sc = 0; sc < Sc.ns; sc++)
         {
             const int kp = Mp.slk_kp[q0 + sc], sp = Mp.slk_sp[q0 + sc];
-            const GqpStage &Sp = P.st[kp];
+            GQP_STAGE_REF Sp = P.st[kp];
             const int cp = Sp.o_ct + 2 * (Sp.nb + Sp.ng), cc = Sc.o_ct + 2 * nbgc;
             GATL(Cd.sv, Sc.o_s + sc) = GATL(P.sv, Sp.o_s + sp);
             GATL(Cd.sv, Sc.o_s + Sc.ns + sc) = GATL(P.sv, Sp.o_s + Sp.ns + sp);

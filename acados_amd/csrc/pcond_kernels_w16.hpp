@@ -265,7 +265,7 @@ __global__ void __launch_bounds__(64) kz_pcond(GqpDev P, GqpDev Cd, PcondMap Mp)
             if (l < NX) PLAT(Cd.bvec, jb * NX + l) = cl;
         }
         /* box rows keep their bounds; activity bits; value of fixed variables */
-        const GqpStage &Sc = Cd.st[jb];
+        GQP_STAGE_REF Sc = Cd.st[jb];
         const int r0 = Mp.row_off[jb], nbc = Sc.nb;
         uint64_t amc = 0;
         W16_UNROLL for (int s = 0; s < R; s++)
@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(64) kz_pcond(GqpDev P, GqpDev Cd, PcondMap Mp)
             const int rc = p[s];
             const bool has = rc < nbc;
             const int kp = Mp.row_kp[r0 + (has ? rc : 0)], rp = Mp.row_rp[r0 + (has ? rc : 0)];
-            const GqpStage &Sp = P.st[kp];
+            GQP_STAGE_REF Sp = P.st[kp];
             const int su = Sp.nb + Sp.ng + rp;
             bool al = false, au = false;
             if (has)

@@ -49,7 +49,7 @@ static __global__ void __launch_bounds__(64) k_res_compute(GqpDev D, ResOut R)
     double n_g = 0.0, n_b = 0.0, n_d = 0.0, n_m = 0.0;
     for (int k = 0; k <= D.N; k++)
     {
-        const GqpStage &S = D.st[k];
+        GQP_STAGE_REF S = D.st[k];
         const int nbg = S.nb + S.ng, ns = S.ns;
         uint64_t am[2] = {GATL(D.amask, k * D.AW), D.AW > 1 ? GATL(D.amask, k * D.AW + 1) : 0};
         auto active = [&](int e) { return (am[e >> 6] >> (e & 63)) & 1; };

@@ -1,5 +1,6 @@
-"""Development aid: launch time per sweep of the sixteen-lanes kernels on small C5 classes (7,281 instances: the per-GPU
-share of one class), on the product library and on development builds of it (make variant TAG=... DEFS=-DW16_PF_DEPTH=d):
+"""Development aid: solve time and launch time per sweep of C5 classes (7,281 instances: the per-GPU share of one class)
+on the product library and on development builds of it (make variant TAG=... DEFS=...); KX_CLASSES="nx,nu,N;..."
+selects the classes, ACADOS_AMD_WPI / ACADOS_AMD_WPI_BATCH_MAX the kernel family:
   python tools/kx_prefetch_rate.py [libacados_amd_qp_<tag>.so ...]"""
 import ctypes, os, sys, time
 import numpy as np
@@ -9,7 +10,8 @@ from acados_amd import OcpQpGpuBatch, _lib
 from acados_amd.generators import fill_lqr_batch, lqr_dims, random_lqr_batch
 
 B = 7281
-CLASSES = ((4, 1, 20), (4, 1, 100)) if os.environ.get("KX_SMALL_ONLY") else ((4, 1, 20), (4, 1, 100), (8, 3, 50), (12, 3, 100))
+CLASSES = (tuple(tuple(int(v) for v in c.split(",")) for c in os.environ["KX_CLASSES"].split(";")) if os.environ.get("KX_CLASSES")
+           else ((4, 1, 20), (4, 1, 100), (8, 3, 50), (12, 3, 100)))
 datas = {c: random_lqr_batch(N=c[2], nx=c[0], nu=c[1], batch=B, seed=200) for c in CLASSES}
 for name in [None] + sys.argv[1:]:
     clib = None if name is None else _lib.bind(ctypes.CDLL(os.path.join(ROOT, "acados_amd", "csrc", name)))
