@@ -144,6 +144,7 @@ struct ocp_qp_gpu_batch
     int print_level = 0;
     double t0_min = 1e-16, lam0_min = 1e-16; /* lower clips of t / lam at a hot start (HPIPM args of the same name) */
     int profile = 0;                 /* per-kernel-class HIP event timing on the launch stream */
+    int stream_priority = 0;         /* HIP stream priority of this batch and of the sub-batches it creates (0: default) */
     std::vector<hipEvent_t> prof_ev; /* pool, pairs (start, stop) */
     std::vector<int> prof_cls;       /* kernel class of each recorded pair */
     double prof_ms[6] = {0, 0, 0, 0, 0, 0};
@@ -958,6 +959,19 @@ int ocp_qp_gpu_batch_set(ocp_qp_gpu_batch *b, const char *f, int stage, const do
     return rc;
 }
 
+/* (re)create the batch's stream with a priority; the batch must be idle */
+static void set_stream_priority(ocp_qp_gpu_batch *b, int prio)
+{
+    int lo = 0, hi = 0; /* hip: "least" (numerically largest) and "greatest" (numerically smallest) priority */
+    HIPCHK(hipSetDevice(b->device));
+    HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    const int p = prio < hi ? hi : (prio > lo ? lo : prio);
+    HIPCHK(hipStreamSynchronize(b->stream));
+    HIPCHK(hipStreamDestroy(b->stream));
+    HIPCHK(hipStreamCreateWithPriority(&b->stream, hipStreamDefault, p));
+    b->stream_priority = prio;
+}
+
 int ocp_qp_gpu_batch_opts_set(ocp_qp_gpu_batch *b, const char *f, const void *v)
 {
     GqpOpts &o = b->O;
@@ -988,6 +1002,14 @@ int ocp_qp_gpu_batch_opts_set(ocp_qp_gpu_batch *b, const char *f, const void *v)
         HIPCHK(hipSetDevice(b->device));
         hipLaunchKernelGGL(mk[*i & 15], dim3(1), dim3(64), 0, b->stream, (int *) nullptr);
         HIPCHK(hipStreamSynchronize(b->stream));
+    }
+    else if (!strcmp(f, "stream_priority"))
+    {
+        /* several batches solved concurrently from host threads (the C5 classes): the long ones on a high-priority
+         * stream (negative value, clamped to the device's range) are dispatched first, the short ones fill the gaps */
+        set_stream_priority(b, *i);
+        if (b->child) set_stream_priority(b->child, *i);
+        if (b->tail) set_stream_priority(b->tail, *i);
     }
     else if (!strcmp(f, "compact_min")) b->compact_min = *i;
     else if (!strcmp(f, "tail_max")) b->tail_max = *i;
@@ -1184,6 +1206,7 @@ static void pcond_setup(ocp_qp_gpu_batch *b)
     h_gk[N + 1] = (int) h_grp.size();
     ocp_qp_gpu_batch *c = batch_create_shape(N2, cnx.data(), cnu.data(), cnbx.data(), cnbu.data(), cng.data(), cns.data(),
                                              b->B, b->device, b->ks->NX, BS * NU);
+    if (c && b->stream_priority) set_stream_priority(c, b->stream_priority);
     if (!c) { decline("the condensed shape has no kernel instantiation"); return; }
     for (int j = 0; j <= N2; j++)
     {
@@ -1479,6 +1502,7 @@ static void compact_into(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch *root, int nact, 
         ocp_qp_gpu_batch *c = batch_create_shape(b->N, b->nx.data(), b->nu.data(), b->nbx.data(), b->nbu.data(),
                                                  b->ng.data(), b->ns.data(), cap, b->device, tail ? b->ks->NX : 0, tail ? b->ks->NU : 0,
                                                  b->ks, tail);
+        if (c && b->stream_priority) set_stream_priority(c, b->stream_priority);
         if (!c) { fprintf(stderr, "acados_amd: cannot create the compaction sub-batch\n"); exit(1); }
         c->idxb = b->idxb; c->idxs_rev = b->idxs_rev; c->idxe = b->idxe; c->nbxe = b->nbxe;
         c->compact_min = b->compact_min;
@@ -1717,6 +1741,7 @@ static void sens_solve_sliced(ocp_qp_gpu_batch *b)
     {
         ocp_qp_gpu_batch *c = batch_create_shape(b->N, b->nx.data(), b->nu.data(), b->nbx.data(), b->nbu.data(), b->ng.data(),
                                                  b->ns.data(), cap, b->device, b->ks->NX, b->ks->NU, b->ks, true);
+        if (c && b->stream_priority) set_stream_priority(c, b->stream_priority);
         if (!c) { fprintf(stderr, "acados_amd: cannot create the sensitivity sub-batch\n"); exit(1); }
         c->idxb = b->idxb; c->idxs_rev = b->idxs_rev; c->idxe = b->idxe; c->nbxe = b->nbxe;
         c->tail_max = 0;

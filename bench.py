@@ -340,7 +340,7 @@ def other_configs(c2_batch, c2_data, args):
     # C5: the per-GPU share of 524,288 instances on 8 GPUs, split equally over the 9 shape classes.  Every class is one
     # device batch with its own HIP stream; the classes are solved CONCURRENTLY (one host thread per class, the solve
     # call releases the GIL) -- small, latency-bound batches overlap on the chip -- and, for reference, one after the other
-    from concurrent.futures import ThreadPoolExecutor
+    from acados_amd.shape_classes import ConcurrentClasses
     per_class = (524288 // 8) // len(C5_CLASSES)
     batches = []
     for ci, (nx, nu, Nc) in enumerate(C5_CLASSES):
@@ -350,10 +350,10 @@ def other_configs(c2_batch, c2_data, args):
         tol_setup(gc)
         gc.solve()                                     # warm-up
         batches.append(((nx, nu, Nc), gc, dc))
-    with ThreadPoolExecutor(max_workers=len(batches)) as pool:
-        list(pool.map(lambda b: b[1].solve(), batches))     # warm-up of the concurrent path
+    with ConcurrentClasses([b[1] for b in batches]) as cc:
+        cc.solve()                                     # warm-up of the concurrent path
         t0 = time.perf_counter()
-        bad_conc = sum(pool.map(lambda b: b[1].solve(), batches))
+        bad_conc = cc.solve()
         t_conc = time.perf_counter() - t0
     classes, tot_t, tot_n, bad, res_max = [], 0.0, 0, 0, 0.0
     worst_frac = None
@@ -376,7 +376,7 @@ def other_configs(c2_batch, c2_data, args):
             worst_frac = (r["ms_per_step"], r["roofline"])
     del batches
     out["C5_share"] = {"workload": f"mixed shape classes nx in {{4,12,24}} x N in {{20,50,100}}, {per_class} instances each = per-GPU share of "
-                                   f"524,288 on 8 GPUs (BASELINE configs[4]); nine device batches solved concurrently on their own streams",
+                                   f"524,288 on 8 GPUs (BASELINE configs[4]); nine device batches solved concurrently on their own streams, the longest class on a high-priority one (acados_amd/shape_classes.py)",
                        "batch": tot_n, "solves_per_s": tot_n / t_conc, "seconds": t_conc, "failures": bad + bad_conc,
                        "solves_per_s_one_after_the_other": tot_n / tot_t, "seconds_one_after_the_other": tot_t,
                        "max_kkt_residual_independent": res_max, "roofline_of_slowest_class": worst_frac[1], "classes": classes,

@@ -57,6 +57,9 @@ static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKi
 static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = nullptr; return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+#define hipStreamDefault 0u
+static inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned int, int) { *s = nullptr; return hipSuccess; }
+static inline hipError_t hipDeviceGetStreamPriorityRange(int *least, int *greatest) { *least = 1; *greatest = -1; return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new hostsim_event(); return hipSuccess; }

@@ -948,3 +948,34 @@ def test_small_block_pipeline_gpu(gpu_lib, monkeypatch, xbox):
                 rx = o.get(k, "x")
                 worst = max(worst, np.max(np.abs(out["small"][k][i] - rx) / np.maximum(1.0, np.abs(rx))))
         assert worst <= 1e-8, worst
+
+
+@pytest.mark.gpu
+def test_concurrent_shape_classes_gpu(gpu_lib, monkeypatch):
+    """acados_amd/shape_classes.py on the device: three C5 classes (three kernel families) solved from one host thread
+    each, the class with the most work on a high-priority HIP stream; every output bit-identical to the same batches
+    solved one after the other, over several concurrent repeats"""
+    from acados_amd import OcpQpGpuBatch
+    from acados_amd.generators import fill_lqr_batch, lqr_dims, random_lqr_batch
+    from acados_amd.shape_classes import ConcurrentClasses
+    monkeypatch.delenv("ACADOS_AMD_WPI_BATCH_MAX", raising=False)
+    classes = [(4, 1, 50, 7281), (12, 3, 20, 3000), (24, 6, 20, 3000)]
+    batches, ref = [], []
+    for ci, (nx, nu, N, B) in enumerate(classes):
+        data = random_lqr_batch(N=N, nx=nx, nu=nu, batch=B, seed=300 + ci)
+        gb = OcpQpGpuBatch(lqr_dims(N, nx, nu), B)
+        fill_lqr_batch(gb, data, N)
+        for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+            gb.opts_set(f, 1e-8)
+        assert gb.solve() == 0
+        ref.append([gb.get(f, k).copy() for f in ("x", "lam") for k in range(N + 1)] + [gb.info("iter").copy()])
+        batches.append(gb)
+    assert [b.kernel_name.split("<")[0] for b in batches] == ["1tpi-box", "w16-box", "w16r-box"]
+    with ConcurrentClasses(batches) as cc:
+        for _ in range(3):
+            assert cc.solve() == 0
+            for gb, r, (nx, nu, N, B) in zip(batches, ref, classes):
+                got = [gb.get(f, k) for f in ("x", "lam") for k in range(N + 1)] + [gb.info("iter")]
+                for a, b in zip(got, r):
+                    assert np.array_equal(a, b)
+                assert gb.res_compute().max() <= KKT_TOL

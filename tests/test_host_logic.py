@@ -1353,3 +1353,29 @@ def test_small_block_pipeline_bit_identical_hostsim(hostsim_lib, monkeypatch, xb
                 assert out["1"][-3][i] == o.iter
                 for k in range(N + 1):
                     assert np.allclose(out["1"][k][i], o.get(k, "x"), atol=1e-9)
+
+
+def test_concurrent_shape_classes_hostsim(hostsim_lib):
+    """acados_amd/shape_classes.py: several device batches solved from one host thread each, the class with the most work
+    on a high-priority stream; results are those of the classes solved one after the other"""
+    from acados_amd import OcpQpGpuBatch
+    from acados_amd.generators import fill_lqr_batch, lqr_dims, random_lqr_batch
+    from acados_amd.shape_classes import ConcurrentClasses, estimated_work
+    classes = [(4, 1, 6, 9), (8, 3, 5, 7), (4, 1, 12, 5)]
+    batches, ref = [], []
+    for ci, (nx, nu, N, B) in enumerate(classes):
+        data = random_lqr_batch(N=N, nx=nx, nu=nu, batch=B, seed=60 + ci)
+        gb = OcpQpGpuBatch(lqr_dims(N, nx, nu), B, _clib=hostsim_lib)
+        fill_lqr_batch(gb, data, N)
+        gb.opts_set("tol_stat", 1e-8)
+        assert gb.solve() == 0
+        ref.append([gb.get("x", k).copy() for k in range(N + 1)] + [gb.info("iter").copy()])
+        batches.append(gb)
+    assert int(np.argmax([estimated_work(b) for b in batches])) == 1
+    with ConcurrentClasses(batches) as cc:
+        for _ in range(2):
+            assert cc.solve() == 0
+            for gb, r, (nx, nu, N, B) in zip(batches, ref, classes):
+                for k in range(N + 1):
+                    assert np.array_equal(gb.get("x", k), r[k])
+                assert np.array_equal(gb.info("iter"), r[-1])

@@ -2,7 +2,8 @@
 multi-phase class, 524,288 instances in total, every class split over all ranks (one process per GPU).
     python tools/bench_c5.py [--total 524288]                      # 1 GPU: this rank holds everything it is given
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 tools/bench_c5.py
-Each rank solves its share of every class as one device batch; timed region = all solves of the rank, data resident
+Each rank solves its share of every class as one device batch, the classes concurrently (acados_amd/shape_classes.py);
+timed region = all solves of the rank, data resident
 in HBM; MAX over ranks; one JSON line on rank 0.  No collective on the data path: an all_gather of statistics after
 the timed region."""
 import argparse, json, os, sys, time
@@ -50,8 +51,14 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    from acados_amd.shape_classes import ConcurrentClasses
+    cc = ConcurrentClasses([gb for _, gb in batches])   # one host thread per class, the longest class on a high-priority stream
+    cc.solve()                                          # warm-up of the concurrent path
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
     t0 = time.perf_counter()
-    bad = sum(gb.solve() for _, gb in batches)
+    bad = cc.solve()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
