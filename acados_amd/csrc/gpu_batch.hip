@@ -144,6 +144,7 @@ struct ocp_qp_gpu_batch
     int print_level = 0;
     double t0_min = 1e-16, lam0_min = 1e-16; /* lower clips of t / lam at a hot start (HPIPM args of the same name) */
     int profile = 0;                 /* per-kernel-class HIP event timing on the launch stream */
+    bool kb_plain = true;            /* one-instance-per-lane box batch: the phase-ordered kernels (false: the pipelined small-block ones) */
     int stream_priority = 0;         /* HIP stream priority of this batch and of the sub-batches it creates (0: default) */
     std::vector<hipEvent_t> prof_ev; /* pool, pairs (start, stop) */
     std::vector<int> prof_cls;       /* kernel class of each recorded pair */
@@ -339,8 +340,12 @@ void finalize_structure(ocp_qp_gpu_batch *b)
         if (((b->st[k].bmask & ~b->st[k].emask) >> NU) != 0) b->xbox = 1;
     if (b->use_box && !b->wpi)
     {
+        /* nu + nx <= 6: the pipelined kernels of ipm_kernels_box_small.hpp ("1tpi-pipe"); ACADOS_AMD_KB_SMALL=0 keeps the
+         * phase-ordered ones of ipm_kernels_box.hpp (cross-check) */
+        const char *small = getenv("ACADOS_AMD_KB_SMALL");
+        b->kb_plain = (small && atoi(small) == 0) || NX + NU > 6;
         char nm[160];
-        snprintf(nm, sizeof(nm), "1tpi-box<NX=%d,NU=%d,XBOX=%d>", NX, NU, b->xbox);
+        snprintf(nm, sizeof(nm), "1tpi-%s<NX=%d,NU=%d,XBOX=%d>", b->kb_plain ? "box" : "pipe", NX, NU, b->xbox);
         b->kname = nm;
     }
     if (b->wpi)
@@ -1338,8 +1343,7 @@ static IpmKernels pick_kernels(const ocp_qp_gpu_batch *b)
     k.rhs = b->use_box ? ks->box_rhs[xb] : ks->back_rhs;
     k.faff = b->use_box ? ks->box_fwd_aff[xb] : ks->fwd_aff;
     k.fcorr = b->use_box ? ks->box_fwd_corr[xb] : ks->fwd_corr;
-    const char *small = getenv("ACADOS_AMD_KB_SMALL");
-    if (b->use_box && !b->wpi && small && atoi(small) == 0 && ks->kb_fact[xb])
+    if (b->use_box && !b->wpi && b->kb_plain && ks->kb_fact[xb])
     {
         k.fact = ks->kb_fact[xb]; k.rhs = ks->kb_rhs[xb]; k.faff = ks->kb_fwd_aff[xb]; k.fcorr = ks->kb_fwd_corr[xb];
     }

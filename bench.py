@@ -73,9 +73,10 @@ def git_head():
 
 def kernel_symbol(name, cls):
     """profile class -> kernel function of the family `name` (a batch's kernel_name) runs on (what rocprofv3 lists)"""
-    fam = ("kb" if name.startswith("1tpi-box") else "ky" if name.startswith("w16r") else "kx" if name.startswith("w16")
+    fam = ("kbs" if name.startswith("1tpi-pipe") else "kb" if name.startswith("1tpi-box") else "ky" if name.startswith("w16r") else "kx" if name.startswith("w16")
            else "kw" if name.startswith("wpi") else "k")
-    table = {"kb": {"back_fact": "kb_factor", "fwd_aff": "kb_forward", "back_rhs": "kb_backrhs", "fwd_corr": "kb_forward"},
+    table = {"kbs": {"back_fact": "kbs_factor", "fwd_aff": "kbs_forward", "back_rhs": "kbs_backrhs", "fwd_corr": "kbs_forward"},
+             "kb": {"back_fact": "kb_factor", "fwd_aff": "kb_forward", "back_rhs": "kb_backrhs", "fwd_corr": "kb_forward"},
              "kx": {"back_fact": "kx_factor", "fwd_aff": "kx_fwd", "back_rhs": "kx_backrhs", "fwd_corr": "kx_fwd"},
              "ky": {"back_fact": "ky_factor", "fwd_aff": "ky_fwd", "back_rhs": "ky_backrhs", "fwd_corr": "ky_fwd"},
              "kw": {"back_fact": "kw_factor", "fwd_aff": "kw_fwd", "back_rhs": "kw_backrhs", "fwd_corr": "kw_fwd"},

@@ -929,7 +929,7 @@ def test_small_block_pipeline_gpu(gpu_lib, monkeypatch, xbox):
         for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
             gb.opts_set(f, 1e-8)
         assert gb.solve() == 0
-        assert gb.kernel_name.startswith("w16-box" if fam == "w16" else "1tpi-box<NX=4,NU=1,XBOX=%d" % int(xbox)), gb.kernel_name
+        assert gb.kernel_name.startswith("w16-box" if fam == "w16" else "1tpi-%s<NX=4,NU=1,XBOX=%d" % ("pipe" if fam == "small" else "box", int(xbox))), gb.kernel_name
         assert gb.res_compute().max() <= KKT_TOL
         out[fam] = ([gb.get(f, k) for f in ("x", "lam", "t") for k in range(N + 1)] + [gb.get(f, k) for f in ("u", "pi") for k in range(N)]
                     + [gb.info("iter")])
@@ -970,7 +970,7 @@ def test_concurrent_shape_classes_gpu(gpu_lib, monkeypatch):
         assert gb.solve() == 0
         ref.append([gb.get(f, k).copy() for f in ("x", "lam") for k in range(N + 1)] + [gb.info("iter").copy()])
         batches.append(gb)
-    assert [b.kernel_name.split("<")[0] for b in batches] == ["1tpi-box", "w16-box", "w16r-box"]
+    assert [b.kernel_name.split("<")[0] for b in batches] == ["1tpi-pipe", "w16-box", "w16r-box"]
     with ConcurrentClasses(batches) as cc:
         for _ in range(3):
             assert cc.solve() == 0

@@ -281,7 +281,7 @@ def test_c5_shape_classes_and_multiphase_hostsim(hostsim_lib, monkeypatch, fam):
         data = random_lqr_batch(N=5, nx=nx, nu=nu, batch=2 if fam != "w16" else 5, seed=7)
         nb = 2 if fam != "w16" else 5   # 5 instances: a full 4-instance workgroup and a ragged one
         b = _check_batch_vs_oracle([lqr_instance_qp(data, i, 5) for i in range(nb)], hostsim_lib)
-        want = {"1tpi": "1tpi-box<", "wpi": "wpi-box(", "w16": "w16-box<" if nx + nu <= 16 else "w16r-box<"}[fam]
+        want = {"1tpi": "1tpi-pipe<" if nx + nu <= 6 else "1tpi-box<", "wpi": "wpi-box(", "w16": "w16-box<" if nx + nu <= 16 else "w16r-box<"}[fam]
         assert b.kernel_name.startswith(want)
     b = _check_batch_vs_oracle([multiphase_qp(i, N=8) for i in range(3)], hostsim_lib)
     assert b.kernel_name.startswith({"1tpi": "1tpi-box<NX=12,NU=3", "wpi": "wpi-box(nx=12,nu=3", "w16": "w16-box<NX=12,NU=3>"}[fam])
@@ -1340,7 +1340,7 @@ def test_small_block_pipeline_bit_identical_hostsim(hostsim_lib, monkeypatch, xb
                     gb.set("lbx", k, np.full((B, nx), -50.0)); gb.set("ubx", k, np.full((B, nx), 50.0))
             gb.opts_set("tol_stat", 1e-8)
             assert gb.solve() == 0
-            assert gb.kernel_name.startswith("1tpi-box<NX=4,NU=1,XBOX=%d" % int(xbox))
+            assert gb.kernel_name.startswith("1tpi-%s<NX=4,NU=1,XBOX=%d" % ("pipe" if small == "1" else "box", int(xbox)))
             out[small] = ([gb.get(f, k) for f in ("x", "lam", "t") for k in range(N + 1)] + [gb.get(f, k) for f in ("u", "pi") for k in range(N)]
                           + [gb.info("iter"), gb.info("res_stat"), gb.info("res_comp")])
             assert gb.res_compute().max() <= 1e-7
