@@ -41,7 +41,7 @@ struct GqpStage
  * vector loads, and the first use of a stage's fields -- offsets, masks -- waited for vmcnt to drain past that load: an
  * exposed round trip per stage and a stop for everything requested ahead of it (register prefetch, LDS-DMA).  Measured on
  * C2 (one-instance-per-lane kernels, same box): 58.6 -> 57.1 ms per solve. */
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(GQP_STAGE_VECTOR_LOADS) /* (development builds: the old fetch, for A/B runs) */
 #define GQP_CONST_AS __attribute__((address_space(4)))
 #else
 #define GQP_CONST_AS

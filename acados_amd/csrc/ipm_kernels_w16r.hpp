@@ -98,19 +98,28 @@ __device__ static inline void w16r_dma16(const double *sbase, const double *ldsp
 /* (s_barrier: a no-op for a one-wave workgroup as far as synchronisation goes; the programming guide orders the reads of
  * DMA'd data behind "vmcnt, then a barrier") */
 #define W16R_DMA_WAIT() asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory")
-/* The factor and the forward sweep are pinned to ONE wave per SIMD, whatever their register count.  Measured on the C3 shape
- * <8,15> (development builds, `make variant`, tools/stress_w16r.py / variant_rate.py):
- *   - the forward sweep built for two waves per SIMD gives a few dozen wrong instances in 65,536 (whole workgroups of four)
- *     as soon as two of its waves share a SIMD; the factor sweep built the same way is correct;
- *   - NOT the LDS-DMA: the same build with the DMA replaced by a copy through registers (W16R_NO_DMA) fails the same way,
- *     and the mechanism alone is exact with 2 and 4 waves per SIMD (tools/lds_dma_probe/probe2, probe3);
- *   - not an LDS overrun or an allocation granule (padding / rounding the allocation up to 512 ... 4,096 bytes changes
- *     nothing), not the spill code as such (the same binary is correct when a 60 KB allocation leaves room for only two
- *     workgroups per CU), not cured by idle cycles after the waits;
- *   - and two waves per SIMD do not pay here anyway: at 256 registers both sweeps spill, C3 65.6 -> 77.4 ms with the factor
- *     sweep alone built that way (74.6 / 85.9 ms with the forward sweep / both).
- * One wave per SIMD is what every test and every measurement runs; the attribute keeps a future compiler from packing
- * two.  The fault in the forward sweep is unexplained. */
+/* The factor and the forward sweep are pinned to ONE wave per SIMD, whatever their register count.  History of the fault
+ * that made this a rule (C3 shape <8,15>, development builds `make variant`, tools/stress_w16r.py / variant_rate.py):
+ *   - rounds 2-3: the AFFINE forward sweep built for two waves per SIMD gave 30-160 wrong instances in 65,536 (whole
+ *     workgroups, NaN, a different set every solve) as soon as two of its waves shared a SIMD; the corrector instantiation
+ *     and the factor sweep built the same way were exact.  Not the LDS-DMA (a copy through registers fails the same way; the
+ *     mechanism alone is exact at 2 and 4 waves per SIMD, tools/lds_dma_probe/probe2, probe3), not an LDS overrun, not the
+ *     runtime's scratch handling, not the spill code as read;
+ *   - round 3, narrowed to ONE construct: the stage descriptor fetched with VECTOR loads (what hipcc emitted for the
+ *     plain-pointer stage table behind a kernel's first store: `global_load_dword v, v_zero, s[..]` x3) and consumed
+ *     behind the compiler's PARTIAL waits (`s_waitcnt vmcnt(4)` / `vmcnt(3)` in front of `v_readfirstlane` / `v_mov`).
+ *     Same two-waves build, descriptor loads followed by `s_waitcnt vmcnt(0)` (GQP_STAGE_VECTOR_FULLWAIT): exact.  Same
+ *     build with the table in the constant address space (s_load; what ships now): exact at two waves per SIMD, and at
+ *     three with 344 bytes of forced spills (W16R_WPE3_FWD_AFF).  Only reverting the table to the plain pointer
+ *     (GQP_STAGE_VECTOR_LOADS) brings the failures back (33 / 58 / 83 per solve).  So: not occupancy as such, not spills --
+ *     a partial vmcnt wait in front of the descriptor's consumers was not enough in that kernel under co-residency.  The
+ *     load / wait pattern in isolation (tools/lds_dma_probe/probe4: uniform-address table loads, per-lane cold loads
+ *     behind them, consumers behind vmcnt(4)...(2), 1 / 2 / 4 waves per SIMD) is exact, so what else in that kernel's
+ *     VMEM stream the count missed is not identified; no shipped kernel contains the construct any more (the stage table
+ *     is read with scalar loads in every family), and none of them has scratch;
+ *   - two waves per SIMD do not pay here anyway: with the scalar table the affine sweep fits 254 registers without
+ *     scratch and takes 0.513 ms per launch at two waves per SIMD against 0.506 at one (C3, same box).
+ * One wave per SIMD is what every test and every measurement runs; the attribute keeps a future compiler from packing two. */
 #define W16R_ONE_WAVE_PER_SIMD __attribute__((amdgpu_waves_per_eu(1, 1)))
 /* development builds (make variant): two waves per SIMD for the factor and the forward sweeps (W16R_WPE2) or one of them (the rhs-only sweep has no LDS-DMA and no attribute) -- the open problem above */
 #define W16R_TWO_WAVES_PER_SIMD __attribute__((amdgpu_waves_per_eu(2, 2)))
@@ -123,6 +132,8 @@ __device__ static inline void w16r_dma16(const double *sbase, const double *ldsp
 #define W16R_WPE_FWD W16R_TWO_WAVES_PER_SIMD
 #elif defined(W16R_WPE2_FWD_AFF) /* ... only the affine / only the corrector instantiation of the forward sweep */
 #define W16R_WPE_FWD __attribute__((amdgpu_waves_per_eu(CORR ? 1 : 2, CORR ? 1 : 2)))
+#elif defined(W16R_WPE3_FWD_AFF) /* ... three waves per SIMD (<= 170 registers: forces spills) for the affine instantiation */
+#define W16R_WPE_FWD __attribute__((amdgpu_waves_per_eu(CORR ? 1 : 3, CORR ? 1 : 3)))
 #elif defined(W16R_WPE2_FWD_CORR)
 #define W16R_WPE_FWD __attribute__((amdgpu_waves_per_eu(CORR ? 2 : 1, CORR ? 2 : 1)))
 #else
@@ -1383,6 +1394,10 @@ __global__ void __launch_bounds__(64) W16R_WPE_FWD ky_fwd(GqpDev D, GqpOpts O, i
         GQP_STAGE_REF Sn = D.st[kk];
         n_bm = Sn.bmask; n_em = Sn.emask; n_nb = Sn.nb; n_oct = Sn.o_ct;
         if (GEN) { n_ng = Sn.ng; n_ns = Sn.ns; n_os = Sn.o_s; n_og = Sn.o_g; }
+#if defined(GQP_STAGE_VECTOR_FULLWAIT) && defined(__HIP_DEVICE_COMPILE__)
+        /* development build (with GQP_STAGE_VECTOR_LOADS): the vector-loaded descriptor complete before anything else is issued */
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(n_nb), "+v"(n_oct), "+v"(n_bm), "+v"(n_em) : : "memory");
+#endif
     };
     auto prefetch_v = [&](int kk) /* descriptor of stage kk in c_* */
     {
