@@ -9,7 +9,8 @@ import re
 import numpy as np
 import pytest
 
-from conftest import GOLDEN_PAIRS, INPUT_ONLY, ROOT, compare_with_oracle, fold_stage0, load_qp, load_sol
+from conftest import (GOLDEN_PAIRS, INPUT_ONLY, ROOT, compare_condensed_with_oracle, compare_with_oracle, fold_stage0, load_qp,
+                      load_sol)
 from oracle.oracle import OracleQp, default_opts
 
 ALL_QPS = [p for p, _ in GOLDEN_PAIRS] + INPUT_ONLY
@@ -857,7 +858,7 @@ def test_random_structures_partial_condensing_hostsim(hostsim_lib):
     close to the oracle's solution (the two iterate paths stop at different points of the 1e-8 complementarity ball)"""
     from acados_amd import OcpQpGpuBatch
     from random_qp import random_structure_qp
-    condensed = 0
+    condensed = sharp = 0
     for seed in range(40):
         qp = random_structure_qp(seed)
         if qp.N < 2:
@@ -871,12 +872,13 @@ def test_random_structures_partial_condensing_hostsim(hostsim_lib):
         b.opts_set("cond_N", (qp.N + 1) // 2)
         assert b.solve() == 0, seed
         condensed += int(b.scalar("cond_N_active")) == (qp.N + 1) // 2
-        compare_with_oracle(lambda k, f: b.get(f, k)[1], o, qp, 1e-4, fields=("x", "u", "sl", "su", "pi", "lam", "t"))
+        sharp += compare_condensed_with_oracle(lambda k, f: b.get(f, k)[1], o, qp)
         b.opts_set("cond_N", qp.N)
         b.opts_set("warm_start", 3)
         assert b.solve() == 0 and int(b.info("iter").max()) == 0, seed
         assert max(b.info(n).max() for n in ("res_stat", "res_eq", "res_ineq", "res_comp")) <= 1e-8
-    assert condensed >= 30
+    # all but the weakly active instances are compared at 2e-6 (primal) / 1e-7 (multipliers of inactive rows)
+    assert condensed >= 30 and sharp >= 28, (condensed, sharp)
 
 
 def test_condensing_only_boundary_hostsim(hostsim_lib):
@@ -910,7 +912,7 @@ def test_condensing_only_boundary_hostsim(hostsim_lib):
                 if v.size:
                     c.set(f, k, np.tile(v, (2, 1)))
         b.expand()
-        compare_with_oracle(lambda k, f: b.get(f, k)[1], o, qp, tol, fields=("x", "u", "sl", "su", "pi", "lam", "t"))
+        compare_condensed_with_oracle(lambda k, f: b.get(f, k)[1], o, qp, loose=tol)
         # ... and the expanded point satisfies the original KKT conditions at tolerance
         for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
             b.opts_set(f, 1e-8)
@@ -958,7 +960,7 @@ def test_condensing_module_acados_api_hostsim(hostsim_lib):
         oc = OracleQp(qc)
         assert oc.solve(default_opts(tol_stat=1e-8, iter_max=60)) == 0
         get = mod.expand(lambda k, f: oc.get(k, f))
-        compare_with_oracle(get, o, qp, 1e-4, fields=("x", "u", "sl", "su", "pi", "lam", "t"))
+        compare_condensed_with_oracle(get, o, qp)
         # objective values agree: the condensed QP is the same problem (up to the constant the elimination drops,
         # which both solutions share) -- compare the primal solutions' cost in the ORIGINAL QP instead
         x = np.concatenate([get(k, "x") for k in range(qp.N + 1)]); xr = np.concatenate([o.get(k, "x") for k in range(qp.N + 1)])
