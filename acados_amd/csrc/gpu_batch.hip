@@ -46,6 +46,7 @@ namespace
 #define GQP_WPI_MIN_N 13       /* nu+nx from which the wave-per-instance kernels serve every batch */
 #define GQP_WPI_BATCH_MAX 8192 /* batch size up to which they also serve the smaller stage blocks */
 #define GQP_W16_BATCH_MAX 20480 /* ... where a 16-lanes-per-instance instantiation exists (crossover of the C2 shape: ~20k) */
+#define GQP_WPI_GEN_SMALL_MAX 2048   /* ... for nu + nx <= 6 with general rows / shared slacks (compiled general set) */
 #define GQP_W16_SMALL_MAX 4096       /* ... against the pipelined small-block kernels (nu + nx <= 6) */
 #define GQP_W16_SMALL_XBOX_MAX 12288 /* ... the same with box rows on the states */
 
@@ -755,8 +756,12 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
          * with bounds on every state between 7,281 and 16,384; at 65,536 they are 2.7-2.9x (1.4x) ahead
          * (tools/small_shape_crossover.py) */
         const bool kb_small = !gen && b->ks && b->ks->NX + b->ks->NU <= 6;
+        /* general rows / shared slacks on a small block with a compiled one-instance-per-lane set (the reference's golden
+         * structure pend_idxs_rev_min_qp0: nx = 4, nu = 1, two general rows sharing one slack): 1,024 instances 3.45 ms
+         * there against 2.65 ms on the wave-per-instance kernels, 8,192: 4.4 against 9.2 ms, 65,536: 8.4 against 74 ms */
+        const bool gen_small = gen && b->ks && b->ks->NX + b->ks->NU <= 6;
         const int batch_max = bm ? atoi(bm)
-                            : !has_w16 ? GQP_WPI_BATCH_MAX
+                            : !has_w16 ? (gen_small ? GQP_WPI_GEN_SMALL_MAX : GQP_WPI_BATCH_MAX)
                             : kb_small ? (xbox_dims ? GQP_W16_SMALL_XBOX_MAX : GQP_W16_SMALL_MAX)
                             : (xbox_dims ? INT_MAX : GQP_W16_BATCH_MAX);
         /* (a shape no compiled one-instance-per-lane set covers runs here whatever the override says) */
