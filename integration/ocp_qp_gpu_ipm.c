@@ -85,25 +85,38 @@ typedef struct
 } gpu_bucket;
 
 struct ocp_qp_gpu_ipm_memory_;
-typedef struct
+typedef struct gpu_group_
 {
     struct ocp_qp_gpu_ipm_memory_ *owner; /* mem[0] of the call that built the group: its terminate releases it */
     int n, nbk;
     gpu_bucket *bk;
     int *bucket_of, *pos_of;     /* per caller index */
     int *scratch, scratch_cap;   /* signature scratch */
+    /* The header of a group is never handed back to the allocator: when a group is released its resources go, the header
+     * goes to a pool with its generation advanced.  A memory that still points at it (a capsule of an earlier batch call
+     * whose owner has rebuilt or released the group) sees the generation mismatch and falls back to its own bucket
+     * instead of following a dangling pointer. */
+    unsigned gen;
+    struct gpu_group_ *next_free;
 } gpu_group;
 
 typedef struct ocp_qp_gpu_ipm_memory_
 {
     gpu_bucket own;              /* the single-QP path: a bucket of one, everything carved */
     gpu_group *group;            /* batch entries: the group this memory's QP was solved in last (NULL: own) ... */
+    unsigned group_gen;          /* ... its generation at that time (mem_group() checks it) ... */
     int g_bucket, g_pos;         /* ... and where */
     int rv_index;                /* slot of this memory's capsule in its rendezvous (-1: none yet) */
     int *sig_scratch;
     double time_qp_solver_call;
     int iter, status;
 } ocp_qp_gpu_ipm_memory;
+
+/* the group a memory belongs to, if that group is still the one it was solved in */
+static gpu_group *mem_group(const ocp_qp_gpu_ipm_memory *m)
+{
+    return m->group && m->group->gen == m->group_gen && m->group->owner ? m->group : NULL;
+}
 
 static int rendezvous_evaluate(struct ocp_qp_gpu_ipm_rendezvous_ *r, void *config, void *qp_in, void *qp_out, void *opts, ocp_qp_gpu_ipm_memory *m);
 
@@ -257,7 +270,8 @@ static void gpu_memory_get(void *config, void *mem_, const char *field, void *va
     else if (!strcmp(field, "status")) *(int *) value = m->status;
     else if (!strcmp(field, "kernel_name")) /* extension: which kernel family serves this memory's QP (const char *) */
     {
-        const gpu_bucket *bk = m->group ? m->group->bk + m->g_bucket : &m->own;
+        const gpu_group *gg = mem_group(m);
+        const gpu_bucket *bk = gg ? gg->bk + m->g_bucket : &m->own;
         *(const char **) value = bk->batch ? ocp_qp_gpu_batch_kernel_name(bk->batch) : "";
     }
     else { printf("\nerror: ocp_qp_gpu_ipm_memory_get: field %s not available\n", field); exit(1); }
@@ -559,12 +573,20 @@ static void bucket_release(gpu_bucket *bk)
     memset(bk, 0, sizeof(*bk));
 }
 
+static pthread_mutex_t g_group_pool_mu = PTHREAD_MUTEX_INITIALIZER;
+static gpu_group *g_group_pool = NULL; /* released headers (see gpu_group::gen); the only state of this file outside caller-owned objects */
+
 static void group_release(gpu_group *g)
 {
     if (!g) return;
     for (int q = 0; q < g->nbk; q++) bucket_release(g->bk + q);
     free(g->bk); free(g->bucket_of); free(g->pos_of); free(g->scratch);
-    free(g);
+    const unsigned gen = g->gen + 1;
+    memset(g, 0, sizeof(*g)); /* owner = NULL: not a live group */
+    g->gen = gen;
+    pthread_mutex_lock(&g_group_pool_mu);
+    g->next_free = g_group_pool; g_group_pool = g;
+    pthread_mutex_unlock(&g_group_pool_mu);
 }
 
 static void *xcalloc(size_t cnt, size_t sz)
@@ -579,7 +601,7 @@ static void *xcalloc(size_t cnt, size_t sz)
 static gpu_group *group_for(int n, ocp_qp_in **ins, ocp_qp_gpu_ipm_memory **mems, const unsigned char *skip, int *fresh)
 {
     ocp_qp_gpu_ipm_memory *m0 = mems[0];
-    gpu_group *g = m0->group && m0->group->owner == m0 ? m0->group : NULL;
+    gpu_group *g = mem_group(m0) && m0->group->owner == m0 ? m0->group : NULL;
     int need = 0, first = -1;
     for (int i = 0; i < n; i++)
     {
@@ -604,7 +626,12 @@ static gpu_group *group_for(int n, ocp_qp_in **ins, ocp_qp_gpu_ipm_memory **mems
     }
     group_release(g);
     *fresh = 1;
-    g = (gpu_group *) xcalloc(1, sizeof(gpu_group));
+    pthread_mutex_lock(&g_group_pool_mu);
+    g = g_group_pool;
+    if (g) g_group_pool = g->next_free;
+    pthread_mutex_unlock(&g_group_pool_mu);
+    if (g) { const unsigned gen = g->gen + 1; memset(g, 0, sizeof(*g)); g->gen = gen; }
+    else { g = (gpu_group *) xcalloc(1, sizeof(gpu_group)); g->gen = 1; }
     g->owner = m0; g->n = n;
     g->bucket_of = (int *) xcalloc(n, sizeof(int)); g->pos_of = (int *) xcalloc(n, sizeof(int));
     g->scratch = (int *) xcalloc(need, sizeof(int)); g->scratch_cap = need;
@@ -663,7 +690,7 @@ static gpu_group *group_for(int n, ocp_qp_in **ins, ocp_qp_gpu_ipm_memory **mems
         bk->blob_out = (double *) ocp_qp_gpu_host_alloc(sizeof(double) * bk->cap_out);
         if (!bk->blob_in || !bk->blob_out) exit(1);
     }
-    m0->group = g;
+    m0->group = g; m0->group_gen = g->gen;
     return g;
 }
 
@@ -747,7 +774,8 @@ static int evaluate_batch_masked(void *config, int n, void **qp_in_, void **qp_o
             info->t_computed = 1;
         }
         ocp_qp_gpu_ipm_memory *mi = mems[i];
-        mi->group = g; mi->g_bucket = g->bucket_of[i]; mi->g_pos = g->pos_of[i];
+        if (mem_group(mi) && mi->group != g && mi->group->owner == mi) group_release(mi->group); /* it led another batch before */
+        mi->group = g; mi->group_gen = g->gen; mi->g_bucket = g->bucket_of[i]; mi->g_pos = g->pos_of[i];
         mi->iter = it; mi->status = st; mi->time_qp_solver_call = t_solved - t_packed;
         if (st != ACADOS_SUCCESS && (worst == 0 || worst == ACADOS_MAXITER)) worst = st;
     }
@@ -858,7 +886,8 @@ void ocp_qp_gpu_ipm_acados_rendezvous_leave(ocp_qp_gpu_ipm_rendezvous *r)
 /* where the QP of this memory was solved last */
 static gpu_bucket *bucket_of_mem(ocp_qp_gpu_ipm_memory *m, int *pos)
 {
-    if (m->group) { *pos = m->g_pos; return m->group->bk + m->g_bucket; }
+    gpu_group *g = mem_group(m);
+    if (g) { *pos = m->g_pos; return g->bk + m->g_bucket; }
     *pos = 0;
     return &m->own;
 }
@@ -918,7 +947,7 @@ static void gpu_memory_reset(void *config, void *qp_in, void *qp_out, void *opts
     if (m->own.batch) ocp_qp_gpu_batch_destroy(m->own.batch);
     m->own.batch = NULL;
     m->own.sig_len = 0;
-    if (m->group && m->group->owner == m) group_release(m->group); /* the other members' pointers dangle: a batch is torn down as a whole */
+    if (mem_group(m) && m->group->owner == m) group_release(m->group); /* the other members see the generation change (mem_group) */
     m->group = NULL;
 }
 
@@ -958,9 +987,9 @@ void ocp_qp_gpu_ipm_acados_eval_sens_batch(void *config, int n, void **qp_in, vo
 {
     if (n <= 0) return;
     ocp_qp_gpu_ipm_memory **mems = (ocp_qp_gpu_ipm_memory **) mem_;
-    gpu_group *g = mems[0]->group;
+    gpu_group *g = mem_group(mems[0]);
     int ok = g != NULL && g->n == n;
-    for (int i = 0; i < n && ok; i++) ok = mems[i]->group == g;
+    for (int i = 0; i < n && ok; i++) ok = mem_group(mems[i]) == g;
     if (!ok)
     {
         printf("\nerror: ocp_qp_gpu_ipm_acados_eval_sens_batch: the %d memories are not those of the last evaluate_batch\n", n);
