@@ -133,6 +133,28 @@ static int run_batch(int argc, char **argv)
                 worst = fmax(worst, fabs(BLASFEO_DVECEL(chk.ux + s, e) - BLASFEO_DVECEL(c->sens.ux + s, e)));
         printf("single_vs_batch_sens %.3e\n", worst);
     }
+    /* regrouping: the first half of the capsules is solved again as a smaller batch (the owner rebuilds the group), then the
+     * LAST capsule -- whose memory still remembers the released group -- goes through the single-QP slot and must be
+     * answered from its own batch, with the same solution as in the big batch */
+    if (n >= 4)
+    {
+        mock_capsule *c = caps[n - 1];
+        struct d_ocp_qp_sol before;
+        mock_alloc_sol(&c->dim, &before);
+        for (int s = 0; s <= c->dim.N; s++)
+            for (int e = 0; e < c->dim.nu[s] + c->dim.nx[s]; e++) BLASFEO_DVECEL(before.ux + s, e) = BLASFEO_DVECEL(c->sol.ux + s, e);
+        const int st_half = ocp_qp_gpu_ipm_acados_evaluate_batch(&config, n / 2, ins, outs, opts, mems, NULL);
+        int st_last = -1, it_last = -1;
+        config.memory_get(&config, mems[n - 1], "status", &st_last);   /* answered from the memory itself */
+        config.memory_get(&config, mems[n - 1], "iter", &it_last);
+        const int st_single = config.evaluate(&config, &c->qp, &c->sol, opts, mems[n - 1], NULL);
+        double worst = 0.0;
+        for (int s = 0; s <= c->dim.N; s++)
+            for (int e = 0; e < c->dim.nu[s] + c->dim.nx[s]; e++)
+                worst = fmax(worst, fabs(BLASFEO_DVECEL(before.ux + s, e) - BLASFEO_DVECEL(c->sol.ux + s, e)));
+        printf("regroup half_status %d last_status %d last_iter %d single_status %d single_vs_batch %.3e\n", st_half, st_last, it_last, st_single, worst);
+        config.terminate(&config, mems[n - 1], NULL);
+    }
     config.terminate(&config, mems[0], NULL);
     return 0;
 }

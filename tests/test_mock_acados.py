@@ -270,6 +270,10 @@ def _run_batch(exe, tmp_path, n, files, sens, reps=1, default_dispatch=False):
     info = {head[i]: float(head[i + 1]) for i in range(1, len(head) - 1, 2)}
     per = [tuple(int(x) for x in ln.split()) for ln in lines[1:1 + n]]
     extra = {ln.split()[0]: float(ln.split()[1]) for ln in lines[1 + n:] if len(ln.split()) == 2}
+    for ln in lines[1 + n:]:                       # "regroup key value key value ..."
+        w = ln.split()
+        if w and w[0] == "regroup":
+            extra.update({"regroup_" + w[i]: float(w[i + 1]) for i in range(1, len(w) - 1, 2)})
     return info, per, extra, np.fromfile(out)
 
 
@@ -287,6 +291,10 @@ def test_acados_adapter_batch_two_structures(clib, tmp_path):
     n = 7
     info, per, extra, raw = _run_batch(exe, tmp_path, n, [fa, fb], sens=True)
     assert info["status"] == 0 and extra["single_vs_batch_sens"] <= 1e-12
+    # after the owner rebuilt the group for a smaller batch, the last capsule's memory (which still remembers the released
+    # group) answers status / iter from itself and its single-QP slot solves in its own batch: same solution
+    assert extra["regroup_half_status"] == 0 and extra["regroup_last_status"] == 0 and extra["regroup_last_iter"] == per[n - 1][2]
+    assert extra["regroup_single_status"] == 0 and extra["regroup_single_vs_batch"] <= 1e-9
     p = 0
     for i in range(n):
         base = qb if i & 1 else qa
