@@ -128,6 +128,8 @@ struct ocp_qp_gpu_batch
     GqpStage *d_st = nullptr;
     GqpDev D = {};
     GqpOpts O;
+    bool has_slack = false;            /* some stage has slack variables (set with the dims) */
+    double tol_comp_soft_scale = 1e-3; /* effective_opts: exit tolerance on complementarity of a soft-constrained class */
     int nct_tot = 0, ns2_tot = 0, ng_tot = 0;
     std::vector<void *> allocs;
     size_t bytes = 0;
@@ -239,12 +241,20 @@ void opts_default(GqpOpts &o)
     o.t0_init = 2; /* acados_ocp_options.py:1128-1143: the default is the residual-based start */
 }
 
-/* options as the kernels see them: the complementarity target never drops below 1e-3 tol_comp (barrier floor,
- * see oracle/ocp_qp_oracle.c tau_eff: below that only the rounding error of the Newton step grows) */
-GqpOpts effective_opts(const GqpOpts &o)
+/* options as the kernels see them.
+ * (1) Soft-constrained classes (any stage with slacks): the complementarity tolerance the exit test uses is
+ *     tol_comp * tol_comp_soft_scale (default 1e-3, option "tol_comp_soft_scale", 1 = off).  A soft row with a small
+ *     multiplier lam* sits at t = mu / lam* on the central path, and with slack penalties of 1e2 the primal solution is
+ *     flat: at mu ~ 1e-8 the C4 iterate is a median 3e-7 / worst 1e-4 (relative) away from the exact solution although
+ *     all four KKT residuals are <= 1e-8 (profiles/r04_c4_distance_to_solution.txt) -- two solvers stopping inside that
+ *     ball cannot agree to 1e-6.  Three more orders of mu cost 1.4 iterations of 12.7 and bring it to 3e-10 / 3e-6 * sqrt.
+ * (2) Barrier floor: the complementarity target never drops below 1e-3 of that tolerance (see oracle/ocp_qp_oracle.c
+ *     tau_eff: below it only the rounding error of the Newton step grows). */
+GqpOpts effective_opts(const GqpOpts &o, const ocp_qp_gpu_batch *b)
 {
     GqpOpts e = o;
-    const double f = 1e-3 * o.tol_comp;
+    if (b->has_slack && b->tol_comp_soft_scale > 0.0 && b->tol_comp_soft_scale < 1.0) e.tol_comp = o.tol_comp * b->tol_comp_soft_scale;
+    const double f = 1e-3 * e.tol_comp;
     if (e.tau_min < f) e.tau_min = f;
     return e;
 }
@@ -268,6 +278,7 @@ void finalize_structure(ocp_qp_gpu_batch *b)
         GqpStage &S = b->st[k];
         memset(&S, 0, sizeof(S));
         S.nb = b->nb[k]; S.ng = b->ng[k]; S.ns = b->ns[k];
+        if (S.ns > 0) b->has_slack = true;
         S.o_ct = o_ct; S.o_s = o_s; S.o_g = o_g; S.has_dyn = k < N;
         const int nbg = S.nb + S.ng, nct = 2 * nbg + 2 * S.ns;
         if (nct > 64 * b->AW || nbg > GQP_MAX_ROWS)
@@ -996,6 +1007,7 @@ int ocp_qp_gpu_batch_opts_set(ocp_qp_gpu_batch *b, const char *f, const void *v)
     else if (!strcmp(f, "mu0")) { if (*d > 0.0) o.mu0 = *d; }
     else if (!strcmp(f, "alpha_min")) o.alpha_min = *d;
     else if (!strcmp(f, "tau_min")) o.tau_min = *d;
+    else if (!strcmp(f, "tol_comp_soft_scale")) b->tol_comp_soft_scale = *d;
     else if (!strcmp(f, "reg_prim")) o.reg_prim = *d;
     else if (!strcmp(f, "cond_pred_corr")) o.cond_pred_corr = *i;
     else if (!strcmp(f, "print_level")) b->print_level = *i;
@@ -1283,6 +1295,7 @@ static int pcond_solve(ocp_qp_gpu_batch *b, int mode = 3)
     hipEvent_t e0, e1, e2, e3;
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventCreate(&e2)); HIPCHK(hipEventCreate(&e3));
     c->O = b->O;
+    c->tol_comp_soft_scale = b->tol_comp_soft_scale;
     c->print_level = b->print_level;
     HIPCHK(hipEventRecord(e0, b->stream));
     pcond_launch(b, false);
@@ -1396,7 +1409,7 @@ static void run_ipm(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch *root, Prof &prof, hip
 {
     const IpmKernels K = pick_kernels(b);
     GqpDev D = b->D;
-    GqpOpts O = effective_opts(root->O);
+    GqpOpts O = effective_opts(root->O, root);
     b->w16_slots = b->B;
     /* sixteen lanes per instance: once a sixth of the slots has converged the sweeps run over a dense list of the live
      * instances (row slot -> instance, GqpDev::perm) -- no data moves, the grid shrinks, every wave carries four live rows */
@@ -1534,6 +1547,7 @@ static void compact_into(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch *root, int nact, 
     HIPCHK(hipMemcpyAsync(c->D.n_active, c->h_nact, sizeof(int), hipMemcpyHostToDevice, s));
     /* the level keeps its own statistics rows for its first slots; merged into the parent's table afterwards */
     c->O = root->O;
+    c->tol_comp_soft_scale = root->tol_comp_soft_scale;
     ensure_stat(c);
     HIPCHK(hipMemsetAsync(c->D.stat, 0, sizeof(double) * (size_t) c->stat_rows * GQP_STAT_COLS * c->stat_inst, s));
     HIPCHK(hipStreamSynchronize(s)); /* `list` (host) must outlive the copy */
@@ -1565,7 +1579,7 @@ int ocp_qp_gpu_batch_solve(ocp_qp_gpu_batch *b)
     ensure_stat(b);
     const KernelSet *ks = b->ks;
     GqpDev D = b->D;
-    GqpOpts O = effective_opts(b->O);
+    GqpOpts O = effective_opts(b->O, b);
     const dim3 grid((b->B + 63) / 64), block(64);
     hipStream_t s = b->stream;
     b->launches = 0;
@@ -1636,7 +1650,7 @@ static void refactor_at_solution(ocp_qp_gpu_batch *b)
     hipStream_t s = b->stream;
     const dim3 g64((b->B + 63) / 64), blk(64);
     if (!b->d_saved_status) b->d_saved_status = dalloc<int>(b, b->Bp);
-    GqpOpts O = effective_opts(b->O);
+    GqpOpts O = effective_opts(b->O, b);
     hipLaunchKernelGGL(gqp::k_sens_prep, g64, blk, 0, s, b->D, O.tau_min, b->d_saved_status);
     GQP_SWEEP_LAUNCH(b, pick_kernels(b).fact, b->shmem_fact, s, b->D, O, 0);
     hipLaunchKernelGGL(gqp::k_status_restore, g64, blk, 0, s, b->D, b->d_saved_status);
@@ -1724,7 +1738,7 @@ int ocp_qp_gpu_batch_sens_set(ocp_qp_gpu_batch *b, const char *f, int k, const d
 static void sens_pass(ocp_qp_gpu_batch *b, hipStream_t s)
 {
     const dim3 g64((b->B + 63) / 64), blk(64);
-    GqpOpts O = effective_opts(b->O);
+    GqpOpts O = effective_opts(b->O, b);
     const IpmKernels K = pick_kernels(b);
     hipLaunchKernelGGL(gqp::k_sens_fixed, g64, blk, 0, s, b->D, b->sfix, 0);
     hipLaunchKernelGGL(gqp::k_sens_prep, g64, blk, 0, s, b->D, O.tau_min, b->d_saved_status);
@@ -1763,6 +1777,7 @@ static void sens_solve_sliced(ocp_qp_gpu_batch *b)
     }
     ocp_qp_gpu_batch *c = b->sens_child;
     c->O = b->O;
+    c->tol_comp_soft_scale = b->tol_comp_soft_scale;
     std::vector<int> list(cap);
     const dim3 block(64);
     for (int i0 = 0; i0 < b->B; i0 += cap)
@@ -1986,6 +2001,8 @@ double ocp_qp_gpu_batch_get_scalar(ocp_qp_gpu_batch *b, const char *f)
     if (!strcmp(f, "tail_switches")) return (double) b->n_tail_switches;
     if (!strcmp(f, "single_launch_solves")) return (double) b->n_single_launch;
     if (!strcmp(f, "cond_N_active")) return b->pcond_state == 1 ? (double) b->cond_N : (double) b->N;
+    if (!strcmp(f, "tol_comp_soft_scale")) return b->tol_comp_soft_scale;
+    if (!strcmp(f, "tol_comp_effective")) { finalize_structure(b); return effective_opts(b->O, b).tol_comp; }
     /* which condensing / expansion kernels serve the batch: 2 sixteen lanes per block, 1 one instance per lane, 0 one wave
      * per instance (meaningful once partial condensing is active) */
     if (!strcmp(f, "pcond_kernel")) return b->pcond_state != 1 ? -1.0 : (b->pcz && b->pc_rt && b->AW <= 1 && b->child->AW <= 1) ? 2.0 : b->pc_rt ? 0.0 : 1.0;

@@ -37,6 +37,7 @@ struct gpu_ipm_opts
 {
     /* names as d_ocp_qp_ipm_arg_set / ocp_qp_hpipm_opts_set (ocp_qp_hpipm.c:142-183) */
     double mu0, tol_stat, tol_eq, tol_ineq, tol_comp, alpha_min, tau_min, reg_prim, t0_min, lam0_min;
+    double tol_comp_soft_scale; /* exit tolerance on complementarity of soft-constrained classes = tol_comp * this (gpu_batch.hip effective_opts) */
     int iter_max, warm_start, cond_pred_corr, print_level, ric_alg, t0_init, update_fact_exit;
     int noticed; /* bit set: options that are accepted without effect and have been announced once */
 };
@@ -804,6 +805,7 @@ void ocp_qp_gpu_ipm_opts_initialize_default(void *config, void *dims, void *opts
     gpu_ipm_mode_defaults(o);
     o->print_level = 0;
     o->tau_min = 0.0; /* m_relax, ocp_qp_hpipm.c:126 */
+    o->tol_comp_soft_scale = 1e-3;
     o->noticed = 0;
 }
 
@@ -833,9 +835,16 @@ void ocp_qp_gpu_ipm_opts_set(void *config, void *opts_, const char *field, void 
         /* a mode change re-applies the acados overrides (ocp_qp_hpipm.c:146-165); print_level and tau_min (m_relax)
          * live outside the HPIPM argument struct there and survive it */
         gpu_ipm_mode_defaults(o);
-        if (strcmp(mode, "BALANCE"))
-            notice_once(o, 0, "hpipm_mode", "one IPM variant exists (the BALANCE-class Mehrotra predictor-corrector); the mode "
-                                            "only re-applies the acados default tolerances");
+        /* What d_ocp_qp_ipm_arg_set_default(mode) changes BEHIND the acados overrides is HPIPM-internal (upstream
+         * knowledge; sources absent here): SPEED_ABS = no conditional corrector (cond_pred_corr 0), absolute-form residuals;
+         * SPEED = conditional corrector, no iterative refinement; BALANCE = + 2 refinement steps, LQ fallback; ROBUST = 4
+         * refinement steps, LQ factorisation.  This backend has the corrector switch -- mapped -- and neither iterative
+         * refinement nor an LQ factorisation of the KKT blocks: SPEED == BALANCE == ROBUST here, said once. */
+        if (!strcmp(mode, "SPEED_ABS")) o->cond_pred_corr = 0;
+        if (!strcmp(mode, "SPEED_ABS") || !strcmp(mode, "ROBUST"))
+            notice_once(o, 0, "hpipm_mode", !strcmp(mode, "ROBUST")
+                            ? "iterative refinement / LQ factorisation of ROBUST have no counterpart here: same arithmetic as BALANCE"
+                            : "SPEED_ABS maps to the unconditional corrector (cond_pred_corr 0); residuals stay in relative form");
     }
     else if (!strcmp(field, "print_level")) o->print_level = *i;
     else if (!strcmp(field, "tau_min")) o->tau_min = *d;
@@ -853,8 +862,16 @@ void ocp_qp_gpu_ipm_opts_set(void *config, void *opts_, const char *field, void 
     }
     else if (!strcmp(field, "ric_alg"))
     {
+        /* ric_alg 0 (classical Riccati: P carried unfactored, only R + B'PB must be positive definite --
+         * acados_ocp_options.py:1084-1101) exists for full-space Hessians that are indefinite; every kernel family here
+         * carries the Cholesky factor of P (square-root form, ric_alg 1, the acados default).  Accepting 0 and running the
+         * square-root form would factorise an indefinite block silently: refused like a wrong field. */
+        if (*i != 1)
+        {
+            printf("\nerror: ocp_qp_gpu_ipm_opts_set: ric_alg = %d not available in this backend (only the square-root Riccati recursion, ric_alg = 1)\n", *i);
+            exit(1);
+        }
         o->ric_alg = *i;
-        if (*i != 1) notice_once(o, 2, "ric_alg", "only the square-root Riccati recursion (ric_alg = 1) is implemented");
     }
     else if (!strcmp(field, "alpha_min")) o->alpha_min = *d;
     else if (!strcmp(field, "reg_prim")) o->reg_prim = *d;
@@ -863,6 +880,7 @@ void ocp_qp_gpu_ipm_opts_set(void *config, void *opts_, const char *field, void 
     else if (!strcmp(field, "update_fact_exit")) o->update_fact_exit = *i; /* always honoured: the factor sweep factorises
                                                                               at the iterate it then judges */
     else if (!strcmp(field, "cond_pred_corr")) o->cond_pred_corr = *i;
+    else if (!strcmp(field, "tol_comp_soft_scale")) o->tol_comp_soft_scale = *d; /* backend-specific, not an HPIPM name */
     else
     {
         printf("\nerror: ocp_qp_gpu_ipm_opts_set: wrong field: %s\n", field);
@@ -1084,6 +1102,7 @@ int gqp_host::gpu_ipm_evaluate_impl(void *config, int n, void **qp_in_, void **q
     ocp_qp_gpu_batch_opts_set(b, "t0_init", &o->t0_init);
     ocp_qp_gpu_batch_opts_set(b, "alpha_min", &o->alpha_min);
     ocp_qp_gpu_batch_opts_set(b, "tau_min", &o->tau_min);
+    ocp_qp_gpu_batch_opts_set(b, "tol_comp_soft_scale", &o->tol_comp_soft_scale);
     ocp_qp_gpu_batch_opts_set(b, "reg_prim", &o->reg_prim);
     ocp_qp_gpu_batch_opts_set(b, "t0_min", &o->t0_min);
     ocp_qp_gpu_batch_opts_set(b, "lam0_min", &o->lam0_min);

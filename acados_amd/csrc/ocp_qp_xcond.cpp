@@ -232,15 +232,15 @@ static void pcond_compute_dims(ocp_qp_partial_condensing_dims *dims, ocp_qp_part
         for (int *a : arrs) for (int k = 0; k <= N; k++) mix(a[k]);
         if (opts->block_size_was_set) for (int i = 0; i < N2 + 1 && N2 > 0 && N2 < N; i++) mix(opts->block_size[i]);
         if (dims->probe_valid && dims->probe_key == h) return;
+        /* valid only once the dims below have been computed for THIS key (set at both successful ends of the function;
+         * the refusals exit) */
+        dims->probe_valid = 0;
         dims->probe_key = h;
-        dims->probe_valid = 1;
     }
     dims->condensed = 0;
-    dims->probe_valid = 0;
-    dims->probe_key = 0;
     copy_dims(d, dims->pcond_dims);
     for (int i = 0; i <= N; i++) dims->block_size[i] = i < N ? 1 : 0;
-    if (N2 <= 0 || N2 >= N) return;
+    if (N2 <= 0 || N2 >= N) { dims->probe_valid = 1; return; }
     if (opts->block_size_was_set)
     {
         int sum = 0;
@@ -290,6 +290,7 @@ static void pcond_compute_dims(ocp_qp_partial_condensing_dims *dims, ocp_qp_part
         exit(1);
     }
     ocp_qp_gpu_batch_destroy(probe);
+    dims->probe_valid = 1;
 }
 
 /* :330-465 */

@@ -333,3 +333,90 @@ def multiphase_qp(i=0, N=20, nx_a=12, nx_b=4, nu=3, seed=2):
             qp.set("idxb", k, np.arange(nuk + nx)); qp.set("idxe", k, nuk + np.arange(nx))
     qp.make_consistent()
     return qp
+
+
+# ---- C5 "multi-phase" class as a BATCH (nx switching 12 -> 4 at k = N/2 through a non-square A) ----------
+# multiphase_qp above draws every stage's blocks anew (one QP object at a time: the small parity tests); the batch form is
+# time-invariant inside a phase, like random_lqr_batch, and vectorised over the instances (counter-based streams: instance
+# i sees the same numbers whatever the batch size or the rank that generates it).
+
+def multiphase_dims(N=20, nx_a=12, nx_b=4, nu=3):
+    d = AcadosOcpQpDims(N)
+    ks = N // 2
+    d.nx[:ks + 1] = nx_a
+    d.nx[ks + 1:] = nx_b
+    d.nu[:N] = nu
+    d.nbu[:N] = nu
+    d.nbx[0] = nx_a
+    d.nb[:] = d.nbu + d.nbx
+    d.nbxe[0] = nx_a
+    return d
+
+
+def multiphase_batch(N=20, nx_a=12, nx_b=4, nu=3, batch=1024, seed=2, first=0):
+    out = {"N": N, "nx_a": nx_a, "nx_b": nx_b, "nu": nu}
+    tag = 100
+    for ph, (nx1, nx) in (("a", (nx_a, nx_a)), ("s", (nx_b, nx_a)), ("b", (nx_b, nx_b))):
+        out["A" + ph] = 0.9 * np.eye(nx1, nx)[None] + 0.02 * _stream(seed, tag + 1, (batch, nx1, nx), first=first)
+        out["B" + ph] = 0.3 * _stream(seed, tag + 2, (batch, nx1, nu), first=first)
+        out["b" + ph] = 0.1 * _stream(seed, tag + 3, (batch, nx1), first=first)
+        tag += 10
+    for ph, nx in (("a", nx_a), ("b", nx_b)):
+        G = _stream(seed, tag + 1, (batch, nx, nx), "normal", first=first) / np.sqrt(nx)
+        out["Q" + ph] = np.eye(nx)[None] + 0.1 * G @ np.transpose(G, (0, 2, 1))
+        out["S" + ph] = 0.05 * _stream(seed, tag + 2, (batch, nu, nx), "normal", first=first)
+        out["q" + ph] = 0.1 * _stream(seed, tag + 3, (batch, nx), "normal", first=first)
+        tag += 10
+    out["R"] = np.broadcast_to(2.0 * np.eye(nu), (batch, nu, nu)).copy()
+    out["r"] = 0.1 * _stream(seed, tag + 1, (batch, nu), "normal", first=first)
+    out["x0"] = _stream(seed, tag + 2, (batch, nx_a), first=first)
+    out["lbu"], out["ubu"] = -0.5 * np.ones((batch, nu)), 0.5 * np.ones((batch, nu))
+    return out
+
+
+def _multiphase_stage(data, k):
+    """names of the blocks stage k uses: (dynamics phase or None, cost phase)"""
+    N, ks = data["N"], data["N"] // 2
+    return (None if k == N else "a" if k < ks else "s" if k == ks else "b"), ("a" if k <= ks else "b")
+
+
+def multiphase_instance_qp(data, i, N=None):
+    N = data["N"]
+    nu = data["nu"]
+    qp = AcadosOcpQp(N)
+    for k in range(N + 1):
+        dyn, cost = _multiphase_stage(data, k)
+        nx = data["Q" + cost].shape[1]
+        qp.set("Q", k, data["Q" + cost][i]); qp.set("q", k, data["q" + cost][i])
+        if dyn is not None:
+            qp.set("R", k, data["R"][i]); qp.set("r", k, data["r"][i]); qp.set("S", k, data["S" + cost][i])
+            qp.set("A", k, data["A" + dyn][i]); qp.set("B", k, data["B" + dyn][i]); qp.set("b", k, data["b" + dyn][i])
+            qp.set("lbu", k, data["lbu"][i]); qp.set("ubu", k, data["ubu"][i])
+        else:
+            qp.set("R", k, np.zeros((0, 0))); qp.set("S", k, np.zeros((0, nx))); qp.set("r", k, np.zeros(0))
+        if k == 0:
+            qp.set("lbx", k, data["x0"][i]); qp.set("ubx", k, data["x0"][i])
+            qp.set("idxb", k, np.arange(nu + nx)); qp.set("idxe", k, nu + np.arange(nx))
+    qp.make_consistent()
+    return qp
+
+
+def fill_multiphase_batch(gb, data):
+    N, nu, nx_a = data["N"], data["nu"], data["nx_a"]
+    gb.set_int("idxe", 0, nu + np.arange(nx_a))
+
+    def blk(a):
+        a = np.asarray(a, dtype=np.float64)
+        if a.ndim == 3:
+            a = np.transpose(a, (0, 2, 1))
+        return np.ascontiguousarray(a.reshape(a.shape[0], -1))
+
+    cache = {n: blk(v) for n, v in data.items() if isinstance(v, np.ndarray)}
+    for k in range(N + 1):
+        dyn, cost = _multiphase_stage(data, k)
+        gb.set("Q", k, cache["Q" + cost]); gb.set("q", k, cache["q" + cost])
+        if dyn is not None:
+            gb.set("R", k, cache["R"]); gb.set("r", k, cache["r"]); gb.set("S", k, cache["S" + cost])
+            gb.set("A", k, cache["A" + dyn]); gb.set("B", k, cache["B" + dyn]); gb.set("b", k, cache["b" + dyn])
+            gb.set("lbu", k, cache["lbu"]); gb.set("ubu", k, cache["ubu"])
+    gb.set("lbx", 0, cache["x0"]); gb.set("ubx", 0, cache["x0"])

@@ -35,5 +35,10 @@ class AcadosOcpQpOptions:
             raise ValueError("cond_block_size must sum to N")
         if self.warm_start not in (0, 1, 2, 3):
             raise ValueError("warm_start must be 0, 1, 2 or 3")
+        if self.ric_alg not in (0, 1):
+            raise ValueError(f"Invalid ric_alg value. ric_alg must be in [0, 1], got {self.ric_alg}.")
+        if self.ric_alg == 0:
+            raise ValueError("ric_alg = 0 (classical Riccati for an indefinite full-space Hessian) is not available in acados_amd: "
+                             "every kernel family carries the Cholesky factor of P (ric_alg = 1, the acados default)")
         if self.hpipm_mode not in ("BALANCE", "SPEED_ABS", "SPEED", "ROBUST"):
             raise ValueError("invalid hpipm_mode")

@@ -20,8 +20,8 @@ _FIELDS = ("A", "B", "b", "Q", "S", "R", "q", "r", "idxb", "lbx", "ubx", "lbu", 
 _INT = ("idxb", "idxe", "idxs_rev")
 _OPT_FIELDS = ("tol_stat", "tol_eq", "tol_ineq", "tol_comp", "iter_max", "cond_N", "cond_block_size", "warm_start",
                "cond_ric_alg", "ric_alg", "mu0", "t0_init", "print_level", "hpipm_mode", "tau_min", "t0_min", "lam0_min",
-               "update_fact_exit", "alpha_min", "initialize_next_xcond_qp_from_qp_out")
-_DOUBLE_OPTS = ("tol_stat", "tol_eq", "tol_ineq", "tol_comp", "mu0", "tau_min", "t0_min", "lam0_min", "alpha_min")
+               "update_fact_exit", "alpha_min", "initialize_next_xcond_qp_from_qp_out", "tol_comp_soft_scale")
+_DOUBLE_OPTS = ("tol_stat", "tol_eq", "tol_ineq", "tol_comp", "mu0", "tau_min", "t0_min", "lam0_min", "alpha_min", "tol_comp_soft_scale")
 
 
 def _bind(L):

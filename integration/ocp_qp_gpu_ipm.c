@@ -50,7 +50,8 @@
 typedef struct
 {
     double mu0, tol_stat, tol_eq, tol_ineq, tol_comp, alpha_min, tau_min, reg_prim, t0_min, lam0_min;
-    int iter_max, warm_start, print_level, ric_alg, t0_init, update_fact_exit;
+    double tol_comp_soft_scale; /* backend-specific: exit tolerance on complementarity of soft-constrained classes = tol_comp * this */
+    int iter_max, warm_start, print_level, ric_alg, t0_init, update_fact_exit, cond_pred_corr;
     struct ocp_qp_gpu_ipm_rendezvous_ *rendezvous; /* set: `evaluate` waits for the other capsules and the QPs go as one batch */
 } ocp_qp_gpu_ipm_opts;
 
@@ -187,6 +188,7 @@ static void gpu_opts_initialize_default(void *config, void *dims, void *opts_)
     o->mu0 = 1e0; o->tol_stat = 1e-6; o->tol_eq = 1e-8; o->tol_ineq = 1e-8; o->tol_comp = 1e-8; o->alpha_min = 1e-8;
     o->tau_min = 0.0; o->reg_prim = 1e-15; o->t0_min = 1e-16; o->lam0_min = 1e-16;
     o->iter_max = 50; o->warm_start = 0; o->print_level = 0; o->ric_alg = 1; o->t0_init = 2; o->update_fact_exit = 0;
+    o->cond_pred_corr = 1; o->tol_comp_soft_scale = 1e-3;
     o->rendezvous = NULL;
 }
 
@@ -207,11 +209,23 @@ static void gpu_opts_set(void *config, void *opts_, const char *field, void *val
     else if (!strcmp(field, "tau_min")) o->tau_min = *d;
     else if (!strcmp(field, "mu0")) { if (*d > 0.0) o->mu0 = *d; }
     else if (!strcmp(field, "t0_init")) o->t0_init = *i;
-    else if (!strcmp(field, "ric_alg")) o->ric_alg = *i;
+    else if (!strcmp(field, "ric_alg"))
+    {
+        /* the device kernels carry the Cholesky factor of P (square-root Riccati); the classical recursion for an indefinite
+         * full-space Hessian is not available: refused, not silently replaced */
+        if (*i != 1) { printf("\nerror: ocp_qp_gpu_ipm_opts_set: ric_alg = %d not available (only ric_alg = 1)\n", *i); exit(1); }
+        o->ric_alg = *i;
+    }
+    else if (!strcmp(field, "tol_comp_soft_scale")) o->tol_comp_soft_scale = *d;
     else if (!strcmp(field, "t0_min")) o->t0_min = *d;
     else if (!strcmp(field, "lam0_min")) o->lam0_min = *d;
     else if (!strcmp(field, "update_fact_exit")) o->update_fact_exit = *i;
-    else if (!strcmp(field, "hpipm_mode")) { /* one IPM variant; the acados overrides above hold for every mode */ }
+    else if (!strcmp(field, "hpipm_mode"))
+    {
+        /* the acados overrides hold for every mode (ocp_qp_hpipm.c:146-165); of what the modes change inside HPIPM this
+         * backend has the conditional corrector: SPEED_ABS switches it off, the other modes are one arithmetic */
+        o->cond_pred_corr = strcmp((const char *) value, "SPEED_ABS") ? 1 : 0;
+    }
     /* `value` IS the rendezvous (or NULL): reachable from a capsule as ocp_nlp_solver_opts_set(.., "qp_rendezvous", r) */
     else if (!strcmp(field, "rendezvous")) o->rendezvous = (struct ocp_qp_gpu_ipm_rendezvous_ *) value;
     else { printf("\nerror: ocp_qp_gpu_ipm_opts_set: wrong field: %s\n", field); exit(1); }
@@ -486,6 +500,8 @@ static void apply_opts(ocp_qp_gpu_batch *b, const ocp_qp_gpu_ipm_opts *o, int ws
     ocp_qp_gpu_batch_opts_set(b, "mu0", &o->mu0);
     ocp_qp_gpu_batch_opts_set(b, "t0_init", &o->t0_init);
     ocp_qp_gpu_batch_opts_set(b, "tau_min", &o->tau_min);
+    ocp_qp_gpu_batch_opts_set(b, "tol_comp_soft_scale", &o->tol_comp_soft_scale);
+    ocp_qp_gpu_batch_opts_set(b, "cond_pred_corr", &o->cond_pred_corr);
     ocp_qp_gpu_batch_opts_set(b, "t0_min", &o->t0_min);
     ocp_qp_gpu_batch_opts_set(b, "lam0_min", &o->lam0_min);
     ocp_qp_gpu_batch_opts_set(b, "print_level", &o->print_level);

@@ -12,6 +12,22 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
+# Exit rule of the product for soft-constrained classes (gpu_batch.hip effective_opts): a QP with slack variables is
+# iterated until complementarity <= tol_comp * 1e-3 (option tol_comp_soft_scale).  The C oracle has no such rule -- it
+# stops where the tolerances it is given say.  OracleQp.solve applies the product's rule to the options it hands down so
+# that the two are compared at the same effective tolerance (iteration counts included); soft_scale=1.0 switches it off.
+SOFT_COMP_SCALE = 1e-3
+
+
+def soft_opts(opts, has_slack, soft_scale=None):
+    """copy of `opts` with the product's exit rule for soft-constrained classes applied"""
+    o = OqpOpts()
+    C.memmove(C.byref(o), C.byref(opts), C.sizeof(OqpOpts))
+    sc = SOFT_COMP_SCALE if soft_scale is None else soft_scale
+    if has_slack and 0.0 < sc < 1.0:
+        o.tol_comp = opts.tol_comp * sc
+    return o
+
 
 class OqpOpts(C.Structure):
     _fields_ = [(n, C.c_double) for n in ("mu0", "tol_stat", "tol_eq", "tol_ineq", "tol_comp", "alpha_min",
@@ -97,8 +113,12 @@ class OracleQp:
         if v.size:
             assert lib().oqp_set(self.h, name.encode(), stage, v.ctypes.data_as(C.c_void_p)) == 0
 
-    def solve(self, opts=None, **kw):
-        self.opts = opts if opts is not None else default_opts(**kw)
+    @property
+    def has_slack(self):
+        return bool(np.any(np.asarray(self.qp.dims.ns) > 0))
+
+    def solve(self, opts=None, soft_scale=None, **kw):
+        self.opts = soft_opts(opts if opts is not None else default_opts(**kw), self.has_slack, soft_scale)
         self.status = lib().oqp_solve(self.h, C.byref(self.opts))
         return self.status
 

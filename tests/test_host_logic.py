@@ -794,6 +794,8 @@ def test_solution_sensitivities_soft_constraints_hostsim(hostsim_lib, monkeypatc
         fill_chain_soft_batch(gb, d, N)
         for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
             gb.opts_set(f, 1e-8)
+        gb.opts_set("tol_comp_soft_scale", 1.0)   # sensitivities of a soft class are taken at the 1e-8 iterate: three more orders of mu
+                                                  # cost three digits of the direction (Gamma = lam / t), the docstring above
         assert gb.solve() == 0
         return gb
 
@@ -1204,6 +1206,7 @@ def test_solution_sensitivities_soft_box_rows_hostsim(hostsim_lib, monkeypatch):
                 gb.set(f, k, np.full((B, nx), v))
         for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
             gb.opts_set(f, 1e-8)
+        gb.opts_set("tol_comp_soft_scale", 1.0)   # sensitivities of a soft class: at the 1e-8 iterate (Gamma = lam / t stays ~1e10)
         assert gb.solve() == 0
         return gb
 

@@ -156,7 +156,7 @@ def test_riccati_getters_gpu(gpu_lib, monkeypatch):
 
 
 def _check_sens(gb, qps, seeds_dev, seeds_dense, tol, fields=("x", "u", "pi", "sl", "su", "lam", "t"), tol_own=1e-8, tol_mult=1e-4,
-                tol_mult_own=2e-6, tol_solve=1e-9):
+                tol_mult_own=2e-6, tol_solve=1e-9, soft_scale=None):
     """device sensitivities of EVERY instance against the dense linearised-KKT solve (tests/dense_ref.py), twice:
     at the ORACLE's solution of the same QP -- a reference the solver under test had no part in: primal and pi at `tol`,
     lam / t at `tol_mult` (d lam of a nearly active side depends on how far the complementarity products of the two
@@ -168,7 +168,7 @@ def _check_sens(gb, qps, seeds_dev, seeds_dense, tol, fields=("x", "u", "pi", "s
     worst = 0.0
     for i, qp in enumerate(qps):
         o = OracleQp(qp)
-        assert o.solve(default_opts(tol_stat=tol_solve, tol_eq=tol_solve, tol_ineq=tol_solve, tol_comp=tol_solve)) == 0
+        assert o.solve(default_opts(tol_stat=tol_solve, tol_eq=tol_solve, tol_ineq=tol_solve, tol_comp=tol_solve), soft_scale=soft_scale) == 0
         sd = {key: val[i] for key, val in seeds_dense.items()}
         for which, ref in (("oracle", sens_dense(qp, o.get, sd)), ("own", sens_dense(qp, _getter(gb, i), sd))):
             scale = max(1.0, max(np.max(np.abs(ref(k, f))) for k in range(qp.N + 1) for f in ("x", "u") if ref(k, f).size))
@@ -259,6 +259,7 @@ def test_sensitivities_soft_and_general_rows_vs_dense(clib, request, monkeypatch
     fill_chain_soft_batch(gb, data, N)
     for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
         gb.opts_set(f, 1e-8)
+    gb.opts_set("tol_comp_soft_scale", 1.0)   # the docstring's Gamma * eps: a one-shot sensitivity solve is taken at the 1e-8 iterate
     assert gb.solve() == 0
     assert gb.kernel_name.startswith(fam)
     qps = [chain_soft_instance_qp(data, i, N) for i in range(B)]
@@ -274,7 +275,7 @@ def test_sensitivities_soft_and_general_rows_vs_dense(clib, request, monkeypatch
     for name, (sdev, sdense) in cases.items():
         print("seed case", name)
         worst = _check_sens(gb, qps, sdev, sdense, 2e-4, tol_own=2e-4, tol_mult_own=1e-3 if name in ("ug", "lg") else 1e-4,
-                            tol_mult=1e-3 if name in ("ug", "lg") else 5e-4, tol_solve=1e-8)
+                            tol_mult=1e-3 if name in ("ug", "lg") else 5e-4, tol_solve=1e-8, soft_scale=1.0)
         assert worst <= 2e-4, (name, worst)
 
 
