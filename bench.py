@@ -133,7 +133,7 @@ def pmc_traffic(dom, nx, nu, B, N):
 TIGHT = dict(tol_stat=1e-9, tol_eq=1e-11, tol_ineq=1e-11, tol_comp=1e-12, iter_max=100)   # the "solution" the distances below refer to
 
 
-def oracle_error(gb, qp_of, idx, N, tight=True):
+def oracle_error(gb, qp_of, idx, N, tight=True, same_tol=True):
     """instances `idx` against the oracle (checker only, outside timing; the oracle solves the sample as one OpenMP batch
     over the host cores the process may use), twice:
       same_tol  the oracle at the device's effective tolerances (1e-8 x 4; soft-constrained classes: complementarity at
@@ -165,12 +165,13 @@ def oracle_error(gb, qp_of, idx, N, tight=True):
         return e
 
     hs = [q.h.value for q in qps]
-    st = solve_batch_handles(hs, soft_opts(default_opts(tol_stat=1e-8, tol_eq=1e-8, tol_ineq=1e-8, tol_comp=1e-8), qps[0].has_slack, scale),
-                             nthreads=threads_allowed())
-    e = errs()
-    out = {"same_tol_max": float(e.max()), "same_tol_median": float(np.median(e)), "same_tol_above_1e-6": int((e > 1e-6).sum()),
-           "oracle_failures": int((st != 0).sum()), "instances": len(qps),
-           "oracle_mean_iter": float(np.mean([q.iter for q in qps]))}
+    out = {"instances": len(qps)}
+    if same_tol:
+        st = solve_batch_handles(hs, soft_opts(default_opts(tol_stat=1e-8, tol_eq=1e-8, tol_ineq=1e-8, tol_comp=1e-8), qps[0].has_slack, scale),
+                                 nthreads=threads_allowed())
+        e = errs()
+        out.update({"same_tol_max": float(e.max()), "same_tol_median": float(np.median(e)), "same_tol_above_1e-6": int((e > 1e-6).sum()),
+                    "oracle_failures": int((st != 0).sum()), "oracle_mean_iter": float(np.mean([q.iter for q in qps]))})
     if tight:
         st = solve_batch_handles(hs, default_opts(**TIGHT), nthreads=threads_allowed())
         ok = st == 0
@@ -367,7 +368,38 @@ def other_configs(c2_batch, c2_data, args):
     fill_chain_soft_batch(g4, d4, N4)
     out["C4"] = run_config(f"chain nx=24 nu=3, 4 soft state bounds + 4 soft general rows, ns=8, N=40 (BASELINE configs[3]), batch {B4}",
                            g4, lambda i: chain_soft_instance_qp(d4, i, N4), N4, chain_soft_dims(N4), steps=2, check=args.check_configs, section=2)
+    # the same batch at the plain 1e-8 exit (tol_comp_soft_scale 1): what the default exit rule of a soft-constrained class
+    # costs, and the ball it removes
+    g4.opts_set("tol_comp_soft_scale", 1.0)
+    g4.solve()
+    t0 = time.perf_counter()
+    bad = g4.solve()
+    dt = time.perf_counter() - t0
+    it = g4.info("iter")
+    out["C4"]["exit_rule"] = {"tol_comp_soft_scale": 1e-3, "effective_tol_comp": 1e-11,
+                              "note": "soft-constrained classes iterate until complementarity <= tol_comp x 1e-3 (DESIGN.md 3); "
+                                      "plain_exit = the same batch stopped at 1e-8 x 4"}
+    out["C4"]["plain_exit"] = {"solves_per_s": B4 / dt, "ms_per_step": dt * 1e3, "mean_iter": float(it.mean()), "max_iter": int(it.max()),
+                               "failures": int(bad), "max_kkt_residual_independent": float(g4.res_compute().max())}
+    if args.check_configs:
+        idx = np.unique(np.linspace(0, B4 - 1, args.check_configs).astype(int))
+        out["C4"]["plain_exit"]["oracle_check"] = oracle_error(g4, lambda i: chain_soft_instance_qp(d4, i, N4), idx, N4)
     del g4, d4
+    # C2 once more with complementarity at 1e-11 (a user's choice for a hard-constrained class): the distance to the solution is
+    # the tolerance's -- at 1e-8 x 4 an IPM stops on the central path, t = mu / lam* on a weakly active row
+    c2_batch.opts_set("tol_comp", 1e-11)
+    c2_batch.solve()
+    t0 = time.perf_counter()
+    bad = c2_batch.solve()
+    dt = time.perf_counter() - t0
+    it = c2_batch.info("iter")
+    out["C2_tol_comp_1e-11"] = {"workload": "the headline batch with tol_comp 1e-11 (tol_stat / eq / ineq 1e-8)", "batch": c2_batch.n_batch,
+                                "solves_per_s": c2_batch.n_batch / dt, "ms_per_step": dt * 1e3, "mean_iter": float(it.mean()),
+                                "max_iter": int(it.max()), "failures": int(bad)}
+    if args.check_configs:
+        idx = np.unique(np.linspace(0, c2_batch.n_batch - 1, args.check_configs).astype(int))
+        out["C2_tol_comp_1e-11"]["oracle_check"] = oracle_error(c2_batch, lambda i: lqr_instance_qp(c2_data, i, N), idx, N, same_tol=False)
+    c2_batch.opts_set("tol_comp", 1e-8)
     # C5: the per-GPU share of 524,288 instances on 8 GPUs, split equally over the 9 shape classes.  Every class is one
     # device batch with its own HIP stream; the classes are solved CONCURRENTLY (one host thread per class, the solve
     # call releases the GIL) -- small, latency-bound batches overlap on the chip -- and, for reference, one after the other
@@ -380,7 +412,17 @@ def other_configs(c2_batch, c2_data, args):
         fill_lqr_batch(gc, dc, Nc)
         tol_setup(gc)
         gc.solve()                                     # warm-up
-        batches.append(((nx, nu, Nc), gc, dc))
+        batches.append((f"nx={nx} nu={nu} N={Nc}", gc, (lambda dc=dc, Nc=Nc: (lambda i: lqr_instance_qp(dc, i, Nc)))(), Nc, lqr_dims(Nc, nx, nu)))
+    # ... "additionally one class with nx switching 12 -> 4 at k = N/2 via a non-square A" (SURVEY.md 8d): per-stage dims
+    # inside one padded kernel shape; same share as the other classes
+    from acados_amd.generators import fill_multiphase_batch, multiphase_batch, multiphase_dims, multiphase_instance_qp
+    Nm = 50
+    dm = multiphase_batch(N=Nm, batch=per_class)
+    gm = OcpQpGpuBatch(multiphase_dims(Nm), per_class)
+    fill_multiphase_batch(gm, dm)
+    tol_setup(gm)
+    gm.solve()
+    batches.append((f"multi-phase nx=12->4 at k={Nm // 2} nu=3 N={Nm}", gm, lambda i: multiphase_instance_qp(dm, i), Nm, multiphase_dims(Nm)))
     with ConcurrentClasses([b[1] for b in batches]) as cc:
         cc.solve()                                     # warm-up of the concurrent path
         t0 = time.perf_counter()
@@ -389,9 +431,8 @@ def other_configs(c2_batch, c2_data, args):
     classes, tot_t, tot_n, bad, res_max = [], 0.0, 0, 0, 0.0
     worst_frac = None
     per_class_check = -(-args.check_configs // len(batches)) if args.check_configs else 0     # the sample is spread over the classes
-    for ci, ((nx, nu, Nc), gc, dc) in enumerate(batches):
-        r = run_config(f"nx={nx} nu={nu} N={Nc}", gc, lambda i: lqr_instance_qp(dc, i, Nc), Nc, lqr_dims(Nc, nx, nu), steps=1,
-                       check=per_class_check, section=3 + ci)
+    for ci, (label, gc, qp_of_c, Nc, dims_c) in enumerate(batches):
+        r = run_config(label, gc, qp_of_c, Nc, dims_c, steps=1, check=per_class_check, section=3 + ci)
         classes.append({k: r[k] for k in ("workload", "batch", "solves_per_s", "ms_per_step", "kernel", "mean_iter", "failures",
                                           "max_kkt_residual_independent")}
                        | {"frac": r["roofline"]["frac"], "dominant": r["roofline"]["kernel"], "avg_launch_ms": r["roofline"]["avg_launch_ms"],
@@ -400,14 +441,14 @@ def other_configs(c2_batch, c2_data, args):
                           "max_rel_primal_err_vs_oracle": r.get("max_rel_primal_err_vs_oracle"),
                           "oracle_checked_instances": r.get("oracle_checked_instances", 0)})
         tot_t += r["ms_per_step"] * 1e-3
-        tot_n += per_class
+        tot_n += gc.n_batch
         bad += r["failures"]
         res_max = max(res_max, r["max_kkt_residual_independent"])
         if worst_frac is None or r["ms_per_step"] > worst_frac[0]:
             worst_frac = (r["ms_per_step"], r["roofline"])
     del batches
     out["C5_share"] = {"workload": f"mixed shape classes nx in {{4,12,24}} x N in {{20,50,100}}, {per_class} instances each = per-GPU share of "
-                                   f"524,288 on 8 GPUs (BASELINE configs[4]); nine device batches solved concurrently on their own streams, the longest class on a high-priority one (acados_amd/shape_classes.py)",
+                                   f"524,288 on 8 GPUs (BASELINE configs[4]), plus the multi-phase class (nx 12 -> 4 at N/2, same share); ten device batches solved concurrently on their own streams, the longest class on a high-priority one (acados_amd/shape_classes.py)",
                        "batch": tot_n, "solves_per_s": tot_n / t_conc, "seconds": t_conc, "failures": bad + bad_conc,
                        "solves_per_s_one_after_the_other": tot_n / tot_t, "seconds_one_after_the_other": tot_t,
                        "max_kkt_residual_independent": res_max, "roofline_of_slowest_class": worst_frac[1], "classes": classes,
@@ -577,6 +618,12 @@ def main():
             out["ipm"]["max_rel_primal_err_vs_oracle"] = max(err, err_s)
             out["ipm"]["oracle_checked_instances"] = args.check + len(cpu_baseline.solved)
         cpu_baseline.solved = None
+    if world == 1 and args.check_configs and not args.no_configs:
+        idx = np.unique(np.linspace(0, B - 1, args.check_configs).astype(int))
+        oe = oracle_error(gb, lambda i: lqr_instance_qp(data, i, N), idx, N)
+        out["ipm"]["oracle_check"] = oe
+        out["ipm"]["max_rel_primal_err_vs_oracle"] = max(out["ipm"]["max_rel_primal_err_vs_oracle"] or 0.0, oe["same_tol_max"])
+        out["ipm"]["oracle_checked_instances"] = int(out["ipm"]["oracle_checked_instances"]) + int(idx.size)
     if world == 1 and not args.no_configs:
         out["configs"] = other_configs(gb, data, args)
     # the JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio when its first communicator

@@ -6,7 +6,7 @@ tests/one_sided_constraints_test.py:140-169 (lam >= 0, masked multiplier exactly
 import numpy as np
 import pytest
 
-from conftest import GOLDEN_PAIRS, INPUT_ONLY, fold_stage0, load_qp, load_sol
+from conftest import GOLDEN_PAIRS, INPUT_ONLY, compare_with_oracle, fold_stage0, load_qp, load_sol
 from oracle.oracle import OracleQp, default_opts
 
 
@@ -103,3 +103,91 @@ def test_oracle_batch_openmp_equals_sequential():
     for a, b in zip(seq, par):
         for k in range(11):
             assert np.array_equal(a.get(k, "x"), b.get(k, "x"))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Round 4: the tight oracle is pinned on a reference it has no part in -- a dense active-set solve with an optimality
+# certificate (tests/dense_ref.py::solve_exact) -- on the shapes the reference's fixtures do not cover: a C4-shaped
+# instance (general rows + slacks, 1,763 variables) and a condensed-C3-shaped one (nx = 8, nu = 15, N2 = 10).
+# ---------------------------------------------------------------------------------------------------------------
+
+TIGHT = dict(tol_stat=1e-9, tol_eq=1e-11, tol_ineq=1e-11, tol_comp=1e-12, iter_max=100)
+
+
+def _dist(o, qp, sol):
+    return max(float(np.max(np.abs(o.get(k, f) - sol[f][k]) / np.maximum(1.0, np.abs(sol[f][k]))))
+               for k in range(qp.N + 1) for f in ("x", "u", "sl", "su") if sol[f][k].size)
+
+
+def test_exact_dense_reference_c4_shaped():
+    """one full-size C4 instance (N=40 nx=24 nu=3, 4 soft state bounds + 4 soft general rows per stage, ns=8): the dense
+    active-set solution carries its own certificate (every inactive row feasible, every active multiplier >= 0,
+    stationarity 1e-12: it IS the solution of this strictly convex QP); the tight oracle is within 1e-9 of it, the oracle at
+    the acados tolerances is ~1e-7 away (the central-path offset t = mu / lam*), and the exit rule of soft-constrained
+    classes (complementarity at tol_comp x 1e-3) removes three orders of that"""
+    from dense_ref import solve_exact, split
+    from acados_amd.generators import chain_soft_batch, chain_soft_instance_qp
+    N = 40
+    data = chain_soft_batch(N=N, batch=2, seed=1)
+    qp = chain_soft_instance_qp(data, 1, N)
+    w, off, info = solve_exact(qp)
+    assert info["cert"] <= 1e-11 and info["stationarity"] <= 1e-10, info
+    sol = split(qp, w, off)
+    o = OracleQp(qp)
+    assert o.solve(default_opts(**TIGHT), soft_scale=1.0) == 0
+    d_tight = _dist(o, qp, sol)
+    assert o.solve(default_opts(tol_stat=1e-8), soft_scale=1.0) == 0
+    d_plain, it_plain = _dist(o, qp, sol), o.iter
+    assert o.solve(default_opts(tol_stat=1e-8)) == 0           # the product's exit rule (oracle.SOFT_COMP_SCALE)
+    d_rule, it_rule = _dist(o, qp, sol), o.iter
+    print(f"C4-shaped: distance to the certified solution: tight {d_tight:.2e}, 1e-8 x 4 {d_plain:.2e} ({it_plain} it), "
+          f"soft exit rule {d_rule:.2e} ({it_rule} it)")
+    assert d_tight <= 1e-9 and d_rule <= 1e-8 and d_plain > 10 * d_rule and it_rule <= it_plain + 3
+
+
+def test_exact_dense_reference_condensed_c3_shaped(hostsim_lib):
+    """a C2 instance (N=50 nx=8 nu=3) condensed to N2=10 on the device kernels (host simulation), the condensed QP (nx=8,
+    nu=15) read back and solved by the dense active-set method: the tight oracle on the CONDENSED QP is within 1e-9 of it,
+    and the certified condensed solution, expanded by the device kernels, is the tight oracle's solution of the ORIGINAL QP"""
+    from dense_ref import solve_exact, split
+    from acados_amd import AcadosOcpQpCondensing
+    from acados_amd.generators import lqr_instance_qp, random_lqr_batch
+    N = 50
+    data = random_lqr_batch(N=N, batch=4, seed=0)
+    qp = lqr_instance_qp(data, 3, N)
+    mod = AcadosOcpQpCondensing(qp, 10, _clib=hostsim_lib)
+    qc = mod.condense()
+    assert qc.N == 10 and int(qc.dims.nu[0]) == 15 and int(qc.dims.nx[1]) == 8
+    w, off, info = solve_exact(qc)
+    assert info["cert"] <= 1e-11 and info["stationarity"] <= 1e-10, info
+    sol = split(qc, w, off)
+    oc = OracleQp(qc)
+    assert oc.solve(default_opts(**TIGHT)) == 0
+    assert _dist(oc, qc, sol) <= 1e-9
+    o = OracleQp(qp)
+    assert o.solve(default_opts(**TIGHT)) == 0
+    # expansion needs multipliers too: take them from the tight oracle of the condensed QP, the primal part from the dense solve
+    def cond_sol(k, f):
+        return sol[f][k] if f in ("x", "u", "sl", "su") else oc.get(k, f)
+    get = mod.expand(cond_sol)
+    err = max(float(np.max(np.abs(get(k, f) - o.get(k, f)) / np.maximum(1.0, np.abs(o.get(k, f))))) for k in range(N + 1) for f in ("x", "u") if o.get(k, f).size)
+    assert err <= 1e-8, err
+
+
+def test_multiphase_batch_generator_hostsim(hostsim_lib):
+    """the batched multi-phase generator (C5: nx 12 -> 4 at N/2 through a non-square A): what fill_multiphase_batch packs is
+    what multiphase_instance_qp hands to the oracle"""
+    from acados_amd import OcpQpGpuBatch
+    from acados_amd.generators import fill_multiphase_batch, multiphase_batch, multiphase_dims, multiphase_instance_qp
+    N, B = 6, 5
+    data = multiphase_batch(N=N, batch=B)
+    gb = OcpQpGpuBatch(multiphase_dims(N), B, _clib=hostsim_lib)
+    fill_multiphase_batch(gb, data)
+    gb.opts_set("tol_stat", 1e-8)
+    assert gb.solve() == 0
+    for i in range(B):
+        qp = multiphase_instance_qp(data, i)
+        assert qp.dims.signature() == multiphase_dims(N).signature()
+        o = OracleQp(qp)
+        assert o.solve(default_opts(tol_stat=1e-8)) == 0
+        compare_with_oracle(lambda k, f: gb.get(f, k)[i][:o.get(k, f).size], o, qp, 1e-8, fields=("x", "u", "pi", "lam"))
