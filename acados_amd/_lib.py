@@ -54,6 +54,9 @@ def bind(L):
     L.ocp_qp_gpu_comm_destroy.argtypes = [C.c_void_p]
     L.ocp_qp_gpu_batch_gather.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.ocp_qp_gpu_batch_gather_root.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ocp_qp_gpu_batch_gather_v.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ocp_qp_gpu_comm_create_from_ops.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    L.ocp_qp_gpu_comm_create_from_ops.restype = C.c_void_p
     L.ocp_qp_gpu_batch_bulk_len.argtypes = [C.c_void_p, C.c_int]
     L.ocp_qp_gpu_batch_bulk_offset.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int)]
     L.ocp_qp_gpu_batch_sens_bulk_len.argtypes = [C.c_void_p, C.c_int]

@@ -2408,30 +2408,35 @@ void ocp_qp_gpu_host_free(void *p)
     if (p) (void) hipHostFree(p);
 }
 
-/* ---- multi-GPU: the ONLY collective of the path -- one RCCL all-gather over xGMI of the solutions and
- * their per-instance status / iteration counts plus the per-rank solve time, from device buffers on the batch's stream.
- * RCCL is bound at run time (dlopen): the copy PyTorch has already loaded if there is one, so that the process holds a
- * single RCCL instance; else the ROCm one.  One process per GPU; the unique id travels between the processes by whatever
- * means the host program has (torch.distributed broadcast in bench.py, MPI_Bcast in a C harness). ---- */
-#if defined(__HIPCC__)
-#include <dlfcn.h>
+/* ---- multi-GPU: the ONLY collective of the path -- one gather over xGMI of the solutions and their
+ * per-instance status / iteration counts plus the per-rank solve time, from device buffers on the batch's stream.
+ * The communicator is a table of five transport entries (ocp_qp_gpu_comm_ops): RCCL's, bound at run time (dlopen: the copy
+ * PyTorch has already loaded if there is one, so that the process holds a single RCCL instance; else the ROCm one), or a
+ * table the host program supplies (ocp_qp_gpu_comm_create_from_ops: an MPI program, or the CPU test tier, which drives the
+ * packing / offset / ordering logic below with torch.distributed's gloo as the transport).  One process per GPU; the RCCL
+ * unique id travels between the processes by whatever means the host program has (torch.distributed broadcast in
+ * bench.py, MPI_Bcast in a C harness). ---- */
 struct ocp_qp_gpu_comm
 {
+    ocp_qp_gpu_comm_ops ops = {};
+    int n = 0, rank = 0, device = 0;
+    /* RCCL backing (null for an injected table) */
     void *lib = nullptr;
     void *comm = nullptr; /* ncclComm_t */
-    int n = 0, rank = 0, device = 0;
     struct uid { char internal[128]; };
     int (*get_uid)(uid *) = nullptr;
     int (*init_rank)(void **, int, uid, int) = nullptr;
-    int (*all_gather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
-    int (*send)(const void *, size_t, int, int, void *, hipStream_t) = nullptr;
-    int (*recv)(void *, size_t, int, int, void *, hipStream_t) = nullptr;
-    int (*group_start)() = nullptr;
-    int (*group_end)() = nullptr;
+    int (*nccl_all_gather)(const void *, void *, size_t, int, void *, void *) = nullptr;
+    int (*nccl_send)(const void *, size_t, int, int, void *, void *) = nullptr;
+    int (*nccl_recv)(void *, size_t, int, int, void *, void *) = nullptr;
+    int (*nccl_group_start)() = nullptr;
+    int (*nccl_group_end)() = nullptr;
     int (*destroy)(void *) = nullptr;
     const char *(*err)(int) = nullptr;
 };
 
+#if defined(__HIPCC__)
+#include <dlfcn.h>
 static bool rccl_bind(ocp_qp_gpu_comm *c)
 {
     const char *names[] = {"librccl.so", "librccl.so.1"};
@@ -2446,36 +2451,54 @@ static bool rccl_bind(ocp_qp_gpu_comm *c)
     if (!c->lib) { fprintf(stderr, "acados_amd: RCCL (librccl.so) cannot be loaded: %s\n", dlerror()); return false; }
     c->get_uid = (int (*)(ocp_qp_gpu_comm::uid *)) dlsym(c->lib, "ncclGetUniqueId");
     c->init_rank = (int (*)(void **, int, ocp_qp_gpu_comm::uid, int)) dlsym(c->lib, "ncclCommInitRank");
-    c->all_gather = (int (*)(const void *, void *, size_t, int, void *, hipStream_t)) dlsym(c->lib, "ncclAllGather");
-    c->send = (int (*)(const void *, size_t, int, int, void *, hipStream_t)) dlsym(c->lib, "ncclSend");
-    c->recv = (int (*)(void *, size_t, int, int, void *, hipStream_t)) dlsym(c->lib, "ncclRecv");
-    c->group_start = (int (*)()) dlsym(c->lib, "ncclGroupStart");
-    c->group_end = (int (*)()) dlsym(c->lib, "ncclGroupEnd");
+    c->nccl_all_gather = (int (*)(const void *, void *, size_t, int, void *, void *)) dlsym(c->lib, "ncclAllGather");
+    c->nccl_send = (int (*)(const void *, size_t, int, int, void *, void *)) dlsym(c->lib, "ncclSend");
+    c->nccl_recv = (int (*)(void *, size_t, int, int, void *, void *)) dlsym(c->lib, "ncclRecv");
+    c->nccl_group_start = (int (*)()) dlsym(c->lib, "ncclGroupStart");
+    c->nccl_group_end = (int (*)()) dlsym(c->lib, "ncclGroupEnd");
     c->destroy = (int (*)(void *)) dlsym(c->lib, "ncclCommDestroy");
     c->err = (const char *(*)(int)) dlsym(c->lib, "ncclGetErrorString");
-    if (!c->get_uid || !c->init_rank || !c->all_gather || !c->destroy)
+    /* every entry the two gathers use is required HERE, on every rank alike: a rank that found out inside a collective
+     * that it lacks ncclSend would leave while the others wait in the group (round-3 review) */
+    if (!c->get_uid || !c->init_rank || !c->nccl_all_gather || !c->destroy || !c->nccl_send || !c->nccl_recv || !c->nccl_group_start
+        || !c->nccl_group_end)
     {
-        fprintf(stderr, "acados_amd: librccl.so lacks the collective entry points\n");
+        fprintf(stderr, "acados_amd: librccl.so lacks a collective / point-to-point entry point (ncclAllGather, ncclSend, ncclRecv, ncclGroupStart/End)\n");
         return false;
     }
     return true;
 }
-#define RCCLCHK(c, x)                                                                                     \
-    do {                                                                                                  \
-        int r_ = (x);                                                                                     \
-        if (r_ != 0)                                                                                      \
-        {                                                                                                 \
-            fprintf(stderr, "acados_amd: RCCL error %d (%s) at %s:%d\n", r_, (c)->err ? (c)->err(r_) : "?", __FILE__, __LINE__); \
-            return -1;                                                                                    \
-        }                                                                                                 \
-    } while (0)
+
+/* the RCCL rows of the transport table; ctx = the communicator.  ncclDataType_t: ncclInt32 = 2, ncclFloat64 = 8 (rccl.h) --
+ * the table's dtype codes are those numbers */
+static int rccl_report(ocp_qp_gpu_comm *c, int r, const char *what)
+{
+    if (r != 0) fprintf(stderr, "acados_amd: RCCL error %d (%s) in %s\n", r, c->err ? c->err(r) : "?", what);
+    return r;
+}
+static int rccl_op_all_gather(void *ctx, const void *sendbuf, void *recvbuf, size_t count, int dtype, void *stream)
+{
+    ocp_qp_gpu_comm *c = (ocp_qp_gpu_comm *) ctx;
+    return rccl_report(c, c->nccl_all_gather(sendbuf, recvbuf, count, dtype, c->comm, stream), "ncclAllGather");
+}
+static int rccl_op_send(void *ctx, const void *buf, size_t count, int dtype, int peer, void *stream)
+{
+    ocp_qp_gpu_comm *c = (ocp_qp_gpu_comm *) ctx;
+    return rccl_report(c, c->nccl_send(buf, count, dtype, peer, c->comm, stream), "ncclSend");
+}
+static int rccl_op_recv(void *ctx, void *buf, size_t count, int dtype, int peer, void *stream)
+{
+    ocp_qp_gpu_comm *c = (ocp_qp_gpu_comm *) ctx;
+    return rccl_report(c, c->nccl_recv(buf, count, dtype, peer, c->comm, stream), "ncclRecv");
+}
+static int rccl_op_group_start(void *ctx) { ocp_qp_gpu_comm *c = (ocp_qp_gpu_comm *) ctx; return rccl_report(c, c->nccl_group_start(), "ncclGroupStart"); }
+static int rccl_op_group_end(void *ctx) { ocp_qp_gpu_comm *c = (ocp_qp_gpu_comm *) ctx; return rccl_report(c, c->nccl_group_end(), "ncclGroupEnd"); }
 
 int ocp_qp_gpu_comm_unique_id(void *id128)
 {
     ocp_qp_gpu_comm c;
     if (!rccl_bind(&c)) return -1;
-    RCCLCHK(&c, c.get_uid((ocp_qp_gpu_comm::uid *) id128));
-    return 0;
+    return rccl_report(&c, c.get_uid((ocp_qp_gpu_comm::uid *) id128), "ncclGetUniqueId") == 0 ? 0 : -1;
 }
 
 ocp_qp_gpu_comm *ocp_qp_gpu_comm_create(const void *id128, int n_ranks, int rank, int device)
@@ -2494,22 +2517,58 @@ ocp_qp_gpu_comm *ocp_qp_gpu_comm_create(const void *id128, int n_ranks, int rank
         delete c;
         return nullptr;
     }
+    c->ops.ctx = c;
+    c->ops.all_gather = rccl_op_all_gather;
+    c->ops.send = rccl_op_send;
+    c->ops.recv = rccl_op_recv;
+    c->ops.group_start = rccl_op_group_start;
+    c->ops.group_end = rccl_op_group_end;
+    return c;
+}
+#else  /* host-simulation build of the CPU test tier: no RCCL; communicators come from ocp_qp_gpu_comm_create_from_ops */
+int ocp_qp_gpu_comm_unique_id(void *) { return -1; }
+ocp_qp_gpu_comm *ocp_qp_gpu_comm_create(const void *, int, int, int) { return nullptr; }
+#endif
+
+ocp_qp_gpu_comm *ocp_qp_gpu_comm_create_from_ops(const ocp_qp_gpu_comm_ops *ops, int n_ranks, int rank)
+{
+    if (!ops || !ops->all_gather || !ops->send || !ops->recv || !ops->group_start || !ops->group_end || n_ranks < 1 || rank < 0 || rank >= n_ranks)
+    {
+        fprintf(stderr, "acados_amd: ocp_qp_gpu_comm_create_from_ops: incomplete transport table or rank %d outside 0..%d\n", rank, n_ranks - 1);
+        return nullptr;
+    }
+    ocp_qp_gpu_comm *c = new ocp_qp_gpu_comm();
+    c->ops = *ops;
+    c->n = n_ranks; c->rank = rank;
     return c;
 }
 
 void ocp_qp_gpu_comm_destroy(ocp_qp_gpu_comm *c)
 {
     if (!c) return;
-    if (c->comm) (void) c->destroy(c->comm);
+    if (c->comm && c->destroy) (void) c->destroy(c->comm);
     delete c;
 }
 
-/* root < 0: all-gather (every rank receives everything); root >= 0: gather to that rank (point-to-point sends over xGMI
- * inside one RCCL group: every other rank moves 1x its payload instead of receiving n_ranks x -- SURVEY 5 costs the
- * 8-GPU C2 payload at 5.5 ms this way against ~40 ms for the ring all-gather); the buffers of the other ranks may be NULL */
-static int gather_impl(ocp_qp_gpu_batch *b, ocp_qp_gpu_comm *c, int root, double *sol_all, int *info_all, double *time_all)
+/* The gather of the path.  root < 0: every rank receives everything; root >= 0: that rank only (the buffers of the other
+ * ranks may be NULL).  counts: instances per rank (n_ranks entries) or NULL = b->B on every rank.  The receive buffers are
+ * laid out in RANK ORDER, rank r's instances starting at instance offset sum(counts[0..r-1]):
+ *     sol_all [sum counts][bulk_len(out)] doubles, info_all [sum counts][2] ints (status, iter), time_all [n_ranks] doubles.
+ * Equal counts + all ranks receive: three ncclAllGather (ring over xGMI).  Otherwise -- gather to a root, or UNEVEN shards,
+ * which ncclAllGather cannot express -- point-to-point sends / receives with their exact counts inside ONE group: to a
+ * root every other rank moves 1x its payload instead of receiving n_ranks x (SURVEY 5 costs the 8-GPU C2 payload at 5.5 ms
+ * this way against ~40 ms for the ring all-gather).  A transport error never leaves a group open: the group is always
+ * ended before the error is returned (round-3 review). */
+static int gather_impl(ocp_qp_gpu_batch *b, ocp_qp_gpu_comm *c, int root, const int *counts, double *sol_all, int *info_all, double *time_all)
 {
+    if (!c) return -1;
     HIPCHK(hipSetDevice(b->device));
+    if (root >= c->n) { fprintf(stderr, "acados_amd: ocp_qp_gpu_batch_gather: root %d outside 0..%d\n", root, c->n - 1); return -1; }
+    if (counts && counts[c->rank] != b->B)
+    {
+        fprintf(stderr, "acados_amd: ocp_qp_gpu_batch_gather: counts[%d] = %d but this rank's batch holds %d instances\n", c->rank, counts[c->rank], b->B);
+        return -1;
+    }
     const int len = ocp_qp_gpu_batch_bulk_len(b, 1);
     auto &M = b->bulk_out;
     const size_t cnt = (size_t) b->B * len;
@@ -2523,54 +2582,60 @@ static int gather_impl(ocp_qp_gpu_batch *b, ocp_qp_gpu_comm *c, int root, double
     hipLaunchKernelGGL(gqp::k_bulk_gather, grid, block, 0, b->stream, blob, b->B, len, M.d_arr, M.d_elem, M.T);
     hipLaunchKernelGGL(gqp::k_pack_info, dim3((b->B + 63) / 64), block, 0, b->stream, b->D, info);
     HIPCHK(hipMemcpyAsync(tm, &b->time_tot, sizeof(double), hipMemcpyHostToDevice, b->stream));
-    /* ncclDataType_t: ncclInt32 = 2, ncclFloat64 = 8 (rccl.h) */
-    if (root < 0)
+    bool even = true;
+    if (counts) for (int r = 0; r < c->n; r++) even = even && counts[r] == b->B;
+    const ocp_qp_gpu_comm_ops &T = c->ops;
+    void *st = (void *) b->stream;
+    int rc = 0;
+    if (root < 0 && even)
     {
-        RCCLCHK(c, c->all_gather(blob, sol_all, cnt, 8, c->comm, b->stream));
-        RCCLCHK(c, c->all_gather(info, info_all, 2 * (size_t) b->B, 2, c->comm, b->stream));
-        RCCLCHK(c, c->all_gather(tm, time_all, 1, 8, c->comm, b->stream));
+        if ((rc = T.all_gather(T.ctx, blob, sol_all, cnt, GQP_COMM_F64, st)) == 0
+            && (rc = T.all_gather(T.ctx, info, info_all, 2 * (size_t) b->B, GQP_COMM_I32, st)) == 0)
+            rc = T.all_gather(T.ctx, tm, time_all, 1, GQP_COMM_F64, st);
     }
     else
     {
-        if (!c->send || !c->recv || !c->group_start || !c->group_end || root >= c->n)
+        rc = T.group_start(T.ctx);
+        if (rc != 0) return -1; /* no group was opened */
+        for (int dst = 0; dst < c->n && rc == 0; dst++)
         {
-            fprintf(stderr, "acados_amd: ocp_qp_gpu_batch_gather_root: librccl.so lacks ncclSend / ncclRecv, or root %d out of range\n", root);
-            return -1;
+            if (root >= 0 && dst != root) continue;
+            if ((rc = T.send(T.ctx, blob, cnt, GQP_COMM_F64, dst, st)) == 0 && (rc = T.send(T.ctx, info, 2 * (size_t) b->B, GQP_COMM_I32, dst, st)) == 0)
+                rc = T.send(T.ctx, tm, 1, GQP_COMM_F64, dst, st);
         }
-        RCCLCHK(c, c->group_start());
-        RCCLCHK(c, c->send(blob, cnt, 8, root, c->comm, b->stream));
-        RCCLCHK(c, c->send(info, 2 * (size_t) b->B, 2, root, c->comm, b->stream));
-        RCCLCHK(c, c->send(tm, 1, 8, root, c->comm, b->stream));
-        if (c->rank == root)
-            for (int r = 0; r < c->n; r++)
+        if (root < 0 || c->rank == root)
+        {
+            size_t off = 0; /* instances of the ranks before r */
+            for (int r = 0; r < c->n && rc == 0; r++)
             {
-                RCCLCHK(c, c->recv(sol_all + (size_t) r * cnt, cnt, 8, r, c->comm, b->stream));
-                RCCLCHK(c, c->recv(info_all + (size_t) r * 2 * (size_t) b->B, 2 * (size_t) b->B, 2, r, c->comm, b->stream));
-                RCCLCHK(c, c->recv(time_all + r, 1, 8, r, c->comm, b->stream));
+                const size_t nr = counts ? (size_t) counts[r] : (size_t) b->B;
+                if ((rc = T.recv(T.ctx, sol_all + off * len, nr * len, GQP_COMM_F64, r, st)) == 0
+                    && (rc = T.recv(T.ctx, info_all + off * 2, nr * 2, GQP_COMM_I32, r, st)) == 0)
+                    rc = T.recv(T.ctx, time_all + r, 1, GQP_COMM_F64, r, st);
+                off += nr;
             }
-        RCCLCHK(c, c->group_end());
+        }
+        const int re = T.group_end(T.ctx); /* always: an open group would swallow every later call of this process */
+        if (rc == 0) rc = re;
     }
     HIPCHK(hipStreamSynchronize(b->stream));
-    return 0;
+    return rc == 0 ? 0 : -1;
 }
 
 int ocp_qp_gpu_batch_gather(ocp_qp_gpu_batch *b, ocp_qp_gpu_comm *c, double *sol_all, int *info_all, double *time_all)
 {
-    return gather_impl(b, c, -1, sol_all, info_all, time_all);
+    return gather_impl(b, c, -1, nullptr, sol_all, info_all, time_all);
 }
 
 int ocp_qp_gpu_batch_gather_root(ocp_qp_gpu_batch *b, ocp_qp_gpu_comm *c, int root, double *sol_all, int *info_all, double *time_all)
 {
-    return gather_impl(b, c, root < 0 ? 0 : root, sol_all, info_all, time_all);
+    return gather_impl(b, c, root < 0 ? 0 : root, nullptr, sol_all, info_all, time_all);
 }
-#else  /* host-simulation build of the CPU test tier: no RCCL, the N > 1 path is covered by the gloo test */
-struct ocp_qp_gpu_comm { int n; };
-int ocp_qp_gpu_comm_unique_id(void *) { return -1; }
-ocp_qp_gpu_comm *ocp_qp_gpu_comm_create(const void *, int, int, int) { return nullptr; }
-void ocp_qp_gpu_comm_destroy(ocp_qp_gpu_comm *) {}
-int ocp_qp_gpu_batch_gather(ocp_qp_gpu_batch *, ocp_qp_gpu_comm *, double *, int *, double *) { return -1; }
-int ocp_qp_gpu_batch_gather_root(ocp_qp_gpu_batch *, ocp_qp_gpu_comm *, int, double *, int *, double *) { return -1; }
-#endif
+
+int ocp_qp_gpu_batch_gather_v(ocp_qp_gpu_batch *b, ocp_qp_gpu_comm *c, int root, const int *counts, double *sol_all, int *info_all, double *time_all)
+{
+    return gather_impl(b, c, root, counts, sol_all, info_all, time_all);
+}
 
 size_t ocp_qp_gpu_batch_bytes(const ocp_qp_gpu_batch *b) { return b->bytes; }
 void *ocp_qp_gpu_batch_stream(ocp_qp_gpu_batch *b) { return (void *) b->stream; }

@@ -37,12 +37,14 @@ def gather_instances(local, n_total: int, dist=None, device=None):
     return np.concatenate([o.cpu().numpy()[: hi - lo] for o, (lo, hi) in zip(outs, sizes)], axis=0)
 
 
-def gather_solutions(gb, dist=None, rank: int = 0, world: int = 1):
+def gather_solutions(gb, dist=None, rank: int = 0, world: int = 1, counts=None):
     """The path's only collective, through the library's own entry: ONE RCCL all-gather over xGMI of the
     full solution payload {u x sl su pi lam t} + (status, iter) of every instance + the solve time of every rank,
     from device buffers on the batch's stream -- no host bounce.  torch is plumbing here: it broadcasts the 128-byte
-    RCCL unique id and owns the receive buffers.  Returns timing and a consistency check, or None without a GPU library
-    entry (host simulation)."""
+    RCCL unique id and owns the receive buffers.  `counts`: instances per rank when the shards are uneven (the library then
+    moves exact-size point-to-point transfers in one group, ocp_qp_gpu_batch_gather_v); the gathered arrays are in rank
+    order, rank r's instances at offset sum(counts[:r]).  Returns timing and a consistency check, or None without a GPU
+    library entry (host simulation)."""
     import ctypes as C
     import time
     import torch
@@ -62,14 +64,19 @@ def gather_solutions(gb, dist=None, rank: int = 0, world: int = 1):
         return None
     comm = C.c_void_p(comm)
     Lout = L.ocp_qp_gpu_batch_bulk_len(h, 1)
-    sol = torch.empty((world, B, Lout), dtype=torch.float64, device=dev)
-    info = torch.empty((world, B, 2), dtype=torch.int32, device=dev)
+    cnts = np.full(world, B, dtype=np.int32) if counts is None else np.ascontiguousarray(counts, dtype=np.int32)
+    assert cnts.size == world and int(cnts[rank]) == B
+    first = int(cnts[:rank].sum())
+    total = int(cnts.sum())
+    sol = torch.empty((total, Lout), dtype=torch.float64, device=dev)
+    info = torch.empty((total, 2), dtype=torch.int32, device=dev)
     tm = torch.empty(world, dtype=torch.float64, device=dev)
+    cptr = cnts.ctypes.data_as(C.c_void_p)
     torch.cuda.synchronize()
     best = None
     for _ in range(2):      # first call pays RCCL's lazy channel setup
         t0 = time.perf_counter()
-        rc = L.ocp_qp_gpu_batch_gather(h, comm, C.c_void_p(sol.data_ptr()), C.c_void_p(info.data_ptr()), C.c_void_p(tm.data_ptr()))
+        rc = L.ocp_qp_gpu_batch_gather_v(h, comm, -1, cptr, C.c_void_p(sol.data_ptr()), C.c_void_p(info.data_ptr()), C.c_void_p(tm.data_ptr()))
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
@@ -83,7 +90,7 @@ def gather_solutions(gb, dist=None, rank: int = 0, world: int = 1):
         for _ in range(2):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            rr = L.ocp_qp_gpu_batch_gather_root(h, comm, 0, ptr(sol_r), ptr(info_r), ptr(tm_r))
+            rr = L.ocp_qp_gpu_batch_gather_v(h, comm, 0, cptr, ptr(sol_r), ptr(info_r), ptr(tm_r))
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             if rr == 0:
@@ -96,14 +103,15 @@ def gather_solutions(gb, dist=None, rank: int = 0, world: int = 1):
     # consistency: this rank's slice of the gathered payload is what the getters return
     n0 = C.c_int(0)
     off = L.ocp_qp_gpu_batch_bulk_offset(h, 1, b"u", 0, C.byref(n0))
-    own = sol[rank, :, off:off + n0.value].cpu().numpy()
-    ok = bool(np.array_equal(own, gb.get("u", 0))) and bool(np.array_equal(info[rank, :, 0].cpu().numpy(), gb.info("status")))
-    payload = world * B * (Lout * 8 + 8) + world * 8
+    own = sol[first:first + B, off:off + n0.value].cpu().numpy()
+    ok = bool(np.array_equal(own, gb.get("u", 0))) and bool(np.array_equal(info[first:first + B, 0].cpu().numpy(), gb.info("status")))
+    payload = total * (Lout * 8 + 8) + world * 8
     return {"ms": best * 1e3, "bytes_per_instance": Lout * 8 + 8, "payload_bytes_received_per_rank": payload,
             "GBps_received_per_rank": payload / best / 1e9, "ranks": world, "slice_matches_getters": ok,
-            "iter_mean_all_ranks": float(info[:, :, 1].double().mean().item()),
-            "nonzero_status_all_ranks": int((info[:, :, 0] != 0).sum().item()), "solve_s_per_rank": [float(v) for v in tm.cpu().numpy()],
-            "collective": "ncclAllGather x3 (solutions f64, status/iter i32, time f64) via ocp_qp_gpu_batch_gather",
+            "iter_mean_all_ranks": float(info[:, 1].double().mean().item()),
+            "nonzero_status_all_ranks": int((info[:, 0] != 0).sum().item()), "instances_per_rank": [int(v) for v in cnts], "solve_s_per_rank": [float(v) for v in tm.cpu().numpy()],
+            "collective": ("ncclAllGather x3 (solutions f64, status/iter i32, time f64)" if len(set(int(v) for v in cnts)) == 1 else
+                           "ncclSend / ncclRecv with exact counts in one group (uneven shards)") + " via ocp_qp_gpu_batch_gather_v",
             "gather_to_root_ms": root_ms, "gather_to_root_equals_all_gather": root_ok,
             "gather_to_root": "ncclSend / ncclRecv group to rank 0 via ocp_qp_gpu_batch_gather_root (1x payload per link)"}
 

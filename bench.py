@@ -210,6 +210,25 @@ def config_traffic(section, symbol, sweep):
         return None
 
 
+def mark_stale(tr):
+    """the PMC summary was collected on another build than the one being benched: say so (counter passes cannot run inside
+    this process; tools/profile_round.sh regenerates the summary for the commit it is run on)"""
+    if tr is not None:
+        head = (git_head() or "").replace("+dirty", "")
+        tr["stale"] = bool(tr.get("commit")) and bool(head) and not (str(tr["commit"]).startswith(head) or head.startswith(str(tr["commit"])))
+        tr["benched_commit"] = git_head()
+    return tr
+
+
+MFMA_NOTE = {"used": False, "probe": "profiles/r02_mfma_f64_probe.txt",
+             "v_mfma_f64_16x16x4_TFLOPs_measured": 47.6, "v_fma_f64_TFLOPs_measured": 69.3,
+             "why": "the FP64 matrix pipe of gfx950 peaks BELOW its vector pipe (47.6 vs 69.3 TFLOP/s measured) and the widest block of the "
+                    "path (nx = 8: 8 x 23 per condensing product; nx = 24: 24 x 27) fills 8/16 resp. 9/16 of the entries of the 16x16x4 tiles "
+                    "it would need -- the register-row / DPP form is the faster one at every block size this path has; an MFMA factor kernel "
+                    "exists (kw_factor_m) and is the default only for the wave-per-instance general-row class (+3 %)",
+             "mfma_utilisation": 0.0}
+
+
 def cpu_caps():
     caps = {"logical": os.cpu_count() or 1, "affinity": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None}
     try:
@@ -285,6 +304,10 @@ def cpu_baseline(data, N, unique, budget_s=25.0):
         free_handle(c)
     cpu_baseline.solved = qps     # the same solutions double as the parity sample
     return {"value": sweep[best_t], "unit": "OCP-QP solves/s", "cores": best_t, "kind": "port",
+            "kind_note": "port = this repository's restated CPU oracle (plain C, scalar loops, no BLASFEO micro-kernels); HPIPM + BLASFEO sources "
+                         "are absent from the reference tree, so the reference itself cannot be timed here.  Expect HPIPM on the same cores to be "
+                         "several times faster than this port (its dpotrf / dsyrk / dtrmm run on AVX-512 panel-major kernels): the GPU / CPU "
+                         "ratio of this line would shrink by that factor and says nothing about kernel quality -- the roofline fraction does",
             "sample": f"{unique} instances of the same workload (seed 0, first instances) built once and cloned to >= 64 "
                       f"independent solves per thread, min of 2 repeats per thread count, OpenMP over instances as "
                       f"acados_solver.in.c:3232 does; restated CPU oracle, not HPIPM",
@@ -318,7 +341,7 @@ def run_config(name, gb, qp_of, N, dims, steps=2, check=4, extra=None, section=0
     dom, prof, roof = sweep_roofline(gb, steps, b_in + b_out)
     kname = sweep_kernel_name() if sweep_kernel_name else gb.kernel_name
     roof["kernel"] = f"{kernel_symbol(kname, dom)} ({dom}) of {kname}"
-    tr = config_traffic(section, kernel_symbol(kname, dom), dom) if section else None
+    tr = mark_stale(config_traffic(section, kernel_symbol(kname, dom), dom)) if section else None
     roof["traffic"] = tr["avg_main"] if tr else None
     roof["traffic_source"] = tr
     roof["traffic_over_algorithmic"] = (tr["avg_main"] / roof["bytes_per_launch"]) if tr else None
@@ -355,6 +378,7 @@ def other_configs(c2_batch, c2_data, args):
                            lambda i: lqr_instance_qp(c2_data, i, N), N, lqr_dims(N, 8, 3), steps=2, check=args.check_configs,
                            section=1, sweep_kernel_name=lambda: c2_batch.condensed_kernel_name() or c2_batch.kernel_name)
     out["C3"]["cond_N_active"] = int(c2_batch.scalar("cond_N_active"))
+    out["C3"]["mfma"] = dict(MFMA_NOTE, tile_fill="condensing products A'PA / B'PB with nx = 8: an 8 x 23 operand in 16 x 16 x 4 tiles: 0.5 x 0.72 = 0.36")
     ck = c2_batch.condensed_kernel_name()
     if ck:
         pk = {2: "kz_pcond", 1: "k_pcond", 0: "kw_pcond"}.get(int(c2_batch.scalar("pcond_kernel")), "pcond")
@@ -457,6 +481,129 @@ def other_configs(c2_batch, c2_data, args):
     return out
 
 
+def relaunch(n):
+    """N ranks of this script on one node (the command line the driver uses for N > 1): rank 0's JSON line is the last line of
+    stdout, the exit code is the launcher's"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args):
+    """the launch / sharding path without a GPU: a gloo group of the ranks that were started"""
+    import torch.distributed as dist
+    from acados_amd.generators import C5_CLASSES
+    from acados_amd.sharding import shard_range
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    if args.config == "c5":
+        per_class = args.c5_total // len(C5_CLASSES)
+        mine = {"classes": len(C5_CLASSES) + 1, "per_class": [shard_range(per_class, rank, max(world, 8))] * (len(C5_CLASSES) + 1)}
+    else:
+        mine = {"instances": [rank * args.batch, (rank + 1) * args.batch]}
+    mine.update(rank=rank, local_rank=int(os.environ.get("LOCAL_RANK", "0")), pid=os.getpid())
+    ranks = [mine]
+    if world > 1:
+        ranks = [None] * world
+        dist.all_gather_object(ranks, mine)
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "config": args.config, "ranks": ranks,
+                          "gather": {"ranks": world, "collective": "ocp_qp_gpu_batch_gather (RCCL) after the timed region"}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def main_c5(args):
+    """BASELINE configs[4]: the nine shape classes nx in {4,12,24} x N in {20,50,100} plus the multi-phase class, --c5-total
+    instances split evenly over the classes and every class over the ranks (identical work per rank: ranks finish together);
+    each rank solves its share of every class as one device batch, the classes concurrently (acados_amd/shape_classes.py).
+    Timed region = `steps` solves of everything a rank holds, data resident; MAX over ranks; afterwards every class's
+    solutions are gathered through the library's collective (ocp_qp_gpu_batch_gather, RCCL)."""
+    import torch
+    rank, local_rank, world = (int(os.environ.get(k, d)) for k, d in (("RANK", "0"), ("LOCAL_RANK", "0"), ("WORLD_SIZE", "1")))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    from acados_amd import OcpQpGpuBatch
+    from acados_amd.generators import (C5_CLASSES, fill_lqr_batch, fill_multiphase_batch, lqr_dims, multiphase_batch, multiphase_dims,
+                                       random_lqr_batch)
+    from acados_amd.shape_classes import ConcurrentClasses
+    from acados_amd.sharding import gather_solutions, reduce_max, shard_range
+    ranks_total = max(world, 8)          # weak scaling: a rank holds the share of the 8-GPU job whatever the number of ranks present
+    per_class = args.c5_total // len(C5_CLASSES)      # SURVEY.md 8d: split equally over the nine classes; the multi-phase class comes on top
+    lo, hi = shard_range(per_class, rank, ranks_total)
+    batches = []
+    for ci, (nx, nu, N) in enumerate(C5_CLASSES):
+        data = random_lqr_batch(N=N, nx=nx, nu=nu, batch=hi - lo, seed=200 + ci, first=lo)
+        gb = OcpQpGpuBatch(lqr_dims(N, nx, nu), hi - lo, device=local_rank)
+        fill_lqr_batch(gb, data, N, xp=lambda a: torch.from_numpy(a).to(dev))
+        batches.append((f"nx={nx} nu={nu} N={N}", gb))
+    dm = multiphase_batch(N=50, batch=hi - lo, first=lo)
+    gm = OcpQpGpuBatch(multiphase_dims(50), hi - lo, device=local_rank)
+    fill_multiphase_batch(gm, dm)
+    batches.append(("multi-phase nx=12->4 at k=25 nu=3 N=50", gm))
+    for _, gb in batches:
+        tol_setup(gb)
+        gb.solve()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with ConcurrentClasses([gb for _, gb in batches]) as cc:
+        for _ in range(max(args.warmup, 1)):
+            cc.solve()
+        barrier()
+        t0 = time.perf_counter()
+        bad = 0
+        for _ in range(args.steps):
+            bad += cc.solve()
+        barrier()
+        elapsed = reduce_max(time.perf_counter() - t0, dist, dev)
+    count = sum(gb.n_batch for _, gb in batches)
+    per = [{"class": c, "instances": gb.n_batch, "kernel": gb.kernel_name, "ms": gb.scalar("time_tot") * 1e3,
+            "iters_mean": float(gb.info("iter").mean()), "failures": int((gb.info("status") != 0).sum()),
+            "max_kkt_residual_independent": float(gb.res_compute().max())} for c, gb in batches]
+    gathers = [gather_solutions(gb, dist, rank, world) for _, gb in batches]
+    tot = torch.tensor([count, bad], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(tot)
+    if rank == 0:
+        ok = [g for g in gathers if g]
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        print(json.dumps({"metric": "OCP-QP solves/sec, mixed shape classes (BASELINE configs[4])", "value": float(tot[0]) * args.steps / elapsed,
+                          "unit": "OCP-QP solves/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1),
+                          "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                          "dtype": "f64", "data": "synthetic",
+                          "config": {"workload": f"ten shape classes (nx in {{4,12,24}} x N in {{20,50,100}} + multi-phase nx 12->4), "
+                                                 f"{args.c5_total} instances per 8 GPUs over the nine classes + the same share of the multi-phase class, {count} on this rank, "
+                                                 f"classes solved concurrently",
+                                     "global_batch": int(tot[0]), "parallelism": f"every class instance-sharded x{world}", "commit": git_head()},
+                          "failures": int(tot[1]), "per_class_rank0": per,
+                          "gather": {"ranks": world, "ms_all_classes": sum(g["ms"] for g in ok), "classes_gathered": len(ok),
+                                     "all_slices_match_getters": all(g["slice_matches_getters"] for g in ok) if ok else None,
+                                     "collective": ok[0]["collective"] if ok else None}}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -474,7 +621,25 @@ def main():
                     help="instances per configuration checked against the oracle (OpenMP batch on the host, outside timing; SURVEY 8d asks >= 1,024)")
     ap.add_argument("--compact-min", type=int, default=None, help="override the library default of the compaction threshold")
     ap.add_argument("--check", type=int, default=8, help="instances per rank checked against the oracle (outside timing)")
+    ap.add_argument("--config", choices=("c2", "c5"), default="c2",
+                    help="c2: the headline workload (BASELINE configs[1]); c5: the mixed-shape-class batch of configs[4], 524,288 instances "
+                         "split over the ranks present (a rank of a smaller job still holds the share of an 8-GPU job: weak scaling)")
+    ap.add_argument("--c5-total", type=int, default=524288)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch path only: every rank joins a gloo group, reports the instance ranges it would own, rank 0 prints one JSON "
+                         "line; no GPU is touched (the CPU tier checks that --gpus N starts N ranks)")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` started as ONE process: become N ranks (one process per GPU) under torch.distributed.run.
+    # Started by the driver under torch.distributed.run (WORLD_SIZE set), the ranks are already there.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(relaunch(args.gpus))
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus and int(os.environ.get("RANK", "0")) == 0:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={os.environ['WORLD_SIZE']}: the launcher's world size is what runs", file=sys.stderr)
+    if args.dry_run:
+        return dry_run(args)
+    if args.config == "c5":
+        return main_c5(args)
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
@@ -562,7 +727,8 @@ def main():
     b_in, b_out = algorithmic_bytes_dims(dims)
     dom, prof, roof = sweep_roofline(gb, args.steps, b_in + b_out)
     solves_per_s = world * B * args.steps / elapsed
-    tr = pmc_traffic(dom, nx, nu, B, N)
+    tr = mark_stale(pmc_traffic(dom, nx, nu, B, N))
+    roof["mfma"] = dict(MFMA_NOTE, tile_fill="11 x 11 stage block of C2 inside a 16 x 16 x 4 tile: 0.47")
     roof["traffic"] = tr["avg_main"] if tr else None
     roof["traffic_source"] = tr
     roof["traffic_note"] = ("HBM bytes per launch from the committed rocprofv3 PMC summary named in traffic_source (counter passes "

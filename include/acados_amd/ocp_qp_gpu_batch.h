@@ -182,6 +182,31 @@ int ocp_qp_gpu_batch_gather(ocp_qp_gpu_batch *b, ocp_qp_gpu_comm *c, double *sol
 /* the same payload to ONE rank (ncclSend / ncclRecv in one group): every other rank moves 1x its payload over its xGMI
  * link to `root` instead of receiving n_ranks x; sol_all / info_all / time_all are read on `root` only (NULL elsewhere) */
 int ocp_qp_gpu_batch_gather_root(ocp_qp_gpu_batch *b, ocp_qp_gpu_comm *c, int root, double *sol_all, int *info_all, double *time_all);
+/* UNEVEN shards (n_total instances not a multiple of n_ranks; acados_solver.in.c:3222-3243 shards a batch of any size over
+ * its threads): counts[r] = instances on rank r (counts[own rank] must be this batch's n_batch; NULL = the same n_batch
+ * everywhere).  Receive buffers are in rank order without padding -- rank r's instances start at instance offset
+ * counts[0] + ... + counts[r-1]: sol_all [sum counts][bulk_len], info_all [sum counts][2], time_all [n_ranks].  root < 0:
+ * every rank receives; root >= 0: that rank only.  Uneven counts travel as exact-size sends / receives in one group. */
+int ocp_qp_gpu_batch_gather_v(ocp_qp_gpu_batch *b, ocp_qp_gpu_comm *c, int root, const int *counts, double *sol_all, int *info_all,
+                              double *time_all);
+/* A communicator over a transport the HOST PROGRAM supplies instead of RCCL (an MPI program; the CPU test tier, which runs
+ * the gather's packing / offset / ordering logic over torch.distributed's gloo).  Semantics of the five entries are NCCL's:
+ * all_gather: every rank contributes `count` elements, recvbuf holds n_ranks x count in rank order; send / recv: matched
+ * point-to-point transfers that may be issued in any order between group_start and group_end and complete by group_end;
+ * buffers are device pointers of the batch's device, `stream` is the batch's hipStream_t; return 0 on success.
+ * dtype codes are ncclDataType_t's. */
+#define GQP_COMM_I32 2
+#define GQP_COMM_F64 8
+typedef struct ocp_qp_gpu_comm_ops
+{
+    void *ctx;
+    int (*all_gather)(void *ctx, const void *sendbuf, void *recvbuf, size_t count, int dtype, void *stream);
+    int (*send)(void *ctx, const void *buf, size_t count, int dtype, int peer, void *stream);
+    int (*recv)(void *ctx, void *buf, size_t count, int dtype, int peer, void *stream);
+    int (*group_start)(void *ctx);
+    int (*group_end)(void *ctx);
+} ocp_qp_gpu_comm_ops;
+ocp_qp_gpu_comm *ocp_qp_gpu_comm_create_from_ops(const ocp_qp_gpu_comm_ops *ops, int n_ranks, int rank);
 
 /* pinned (page-locked) host memory for callers that stage their own bulk blobs -- the acados-side adapter is plain C
  * and links no HIP; NULL (with a message) on failure */

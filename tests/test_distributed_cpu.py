@@ -58,3 +58,21 @@ def test_sharded_solve_equals_single_process(tmp_path, hostsim_lib):
     assert gb.solve() == 0
     assert np.array_equal(got[:, :3], gb.get("u", 0))
     assert np.array_equal(got[:, 3], gb.info("iter").astype(np.float64))
+
+
+def test_bench_gpus_flag_starts_that_many_ranks():
+    """`python bench.py --gpus 2` started as ONE process must become two ranks (round-3 review: the flag was parsed and never
+    used); --dry-run walks the launch + sharding path on gloo without touching a GPU and prints the one JSON line"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    for extra, key in (([], "instances"), (["--config", "c5"], "per_class")):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"] + extra, env=env, timeout=300,
+                             stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout.decode().strip().splitlines()[-1]
+        line = json.loads(out)
+        assert line["dry_run"] and line["n_gpus"] == 2 and line["gather"]["ranks"] == 2
+        assert [r["rank"] for r in line["ranks"]] == [0, 1] and line["ranks"][0]["pid"] != line["ranks"][1]["pid"]
+        assert all(key in r for r in line["ranks"])
+    # one rank: no launcher in between
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run"], env=env, timeout=120, stdout=subprocess.PIPE,
+                         check=True).stdout.decode().strip().splitlines()[-1]
+    assert json.loads(out)["n_gpus"] == 1
