@@ -30,13 +30,18 @@
 /* a failing HIP call is not something a solve can recover from (lost device, out of HBM): message + exit(1), acados'
  * convention for errors that are not a solver status (`printf(...); exit(1);` throughout acados/ocp_qp/); what a solve
  * itself can report -- NaN, MAXITER, MINSTEP, infeasible -- comes back per instance as acados return codes */
+/* ... with one exception (round-3 review): a HIP error is not the caller's mistake, and n host threads of an MPC fleet may
+ * share this process (rendezvous mode).  HIPCHK reports and THROWS; every extern "C" entry that does device work catches at
+ * the boundary (function-try-block) and returns -1 (NULL for the creators): the adapters turn that into ACADOS_QP_FAILURE
+ * for the instances of the call, the process lives on.  No exception ever crosses the C-ABI. */
+struct gqp_hip_failure { int code; };
 #define HIPCHK(x)                                                                              \
     do {                                                                                       \
         hipError_t e_ = (x);                                                                   \
         if (e_ != hipSuccess)                                                                  \
         {                                                                                      \
             fprintf(stderr, "\nerror: acados_amd: HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
-            exit(1);                                                                           \
+            throw gqp_hip_failure{(int) e_};                                                   \
         }                                                                                      \
     } while (0)
 
@@ -658,9 +663,11 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
 
 ocp_qp_gpu_batch *ocp_qp_gpu_batch_create(int N, const int *nx, const int *nu, const int *nbx, const int *nbu,
                                           const int *ng, const int *ns, int n_batch, int device)
+try
 {
     return batch_create_shape(N, nx, nu, nbx, nbu, ng, ns, n_batch, device, 0, 0);
 }
+catch (const gqp_hip_failure &) { return nullptr; }
 
 static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu, const int *nbx, const int *nbu,
                                             const int *ng, const int *ns, int n_batch, int device, int force_NX, int force_NU,
@@ -891,6 +898,7 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
 }
 
 void ocp_qp_gpu_batch_destroy(ocp_qp_gpu_batch *b)
+try
 {
     if (!b) return;
     (void) hipSetDevice(b->device);
@@ -908,8 +916,10 @@ void ocp_qp_gpu_batch_destroy(ocp_qp_gpu_batch *b)
     if (b->sens_child) ocp_qp_gpu_batch_destroy(b->sens_child);
     delete b;
 }
+catch (const gqp_hip_failure &) {}
 
 int ocp_qp_gpu_batch_set_int(ocp_qp_gpu_batch *b, const char *f, int k, const int *v, int cnt)
+try
 {
     if (b->finalized)
     {
@@ -925,8 +935,10 @@ int ocp_qp_gpu_batch_set_int(ocp_qp_gpu_batch *b, const char *f, int k, const in
     fprintf(stderr, "acados_amd: ocp_qp_gpu_batch_set_int: unknown field %s\n", f);
     return -1;
 }
+catch (const gqp_hip_failure &) { return -1; }
 
 int ocp_qp_gpu_batch_set(ocp_qp_gpu_batch *b, const char *f, int stage, const double *data, int is_device)
+try
 {
     HIPCHK(hipSetDevice(b->device));
     finalize_structure(b);
@@ -979,6 +991,7 @@ int ocp_qp_gpu_batch_set(ocp_qp_gpu_batch *b, const char *f, int stage, const do
     if (rc) fprintf(stderr, "acados_amd: ocp_qp_gpu_batch_set: unknown field %s (stage %d)\n", f, stage);
     return rc;
 }
+catch (const gqp_hip_failure &) { return -1; }
 
 /* (re)create the batch's stream with a priority; the batch must be idle */
 static void set_stream_priority(ocp_qp_gpu_batch *b, int prio)
@@ -994,6 +1007,7 @@ static void set_stream_priority(ocp_qp_gpu_batch *b, int prio)
 }
 
 int ocp_qp_gpu_batch_opts_set(ocp_qp_gpu_batch *b, const char *f, const void *v)
+try
 {
     GqpOpts &o = b->O;
     const double *d = (const double *) v;
@@ -1100,6 +1114,7 @@ int ocp_qp_gpu_batch_opts_set(ocp_qp_gpu_batch *b, const char *f, const void *v)
     }
     return 0;
 }
+catch (const gqp_hip_failure &) { return -1; }
 
 
 /* ---- partial condensing (ocp_qp_partial_condensing.c:523-556, :664-689) ---- */
@@ -1567,6 +1582,7 @@ static void compact_back(ocp_qp_gpu_batch *b, hipStream_t s, ocp_qp_gpu_batch *c
 }
 
 int ocp_qp_gpu_batch_solve(ocp_qp_gpu_batch *b)
+try
 {
     HIPCHK(hipSetDevice(b->device));
     finalize_structure(b);
@@ -1641,6 +1657,7 @@ int ocp_qp_gpu_batch_solve(ocp_qp_gpu_batch *b)
     for (int i = 0; i < b->B; i++) bad += st[i] != 0;
     return bad;
 }
+catch (const gqp_hip_failure &) { return -1; }
 
 /* One factor sweep at the final iterate with every instance awake: Lf / lf of the whole batch belong to the
  * solution afterwards (after a tail switch the root's factors of the handed-over instances are older).  Statuses
@@ -1676,6 +1693,7 @@ static int sens_begin(ocp_qp_gpu_batch *b)
 }
 
 int ocp_qp_gpu_batch_sens_set(ocp_qp_gpu_batch *b, const char *f, int k, const double *data)
+try
 {
     HIPCHK(hipSetDevice(b->device));
     finalize_structure(b);
@@ -1733,6 +1751,7 @@ int ocp_qp_gpu_batch_sens_set(ocp_qp_gpu_batch *b, const char *f, int k, const d
     }
     return 0;
 }
+catch (const gqp_hip_failure &) { return -1; }
 
 /* the seed pass on a wave-per-instance / sixteen-lanes batch whose factor belongs to the solution */
 static void sens_pass(ocp_qp_gpu_batch *b, hipStream_t s)
@@ -1809,6 +1828,7 @@ static void sens_solve_sliced(ocp_qp_gpu_batch *b)
 }
 
 int ocp_qp_gpu_batch_sens_solve(ocp_qp_gpu_batch *b)
+try
 {
     HIPCHK(hipSetDevice(b->device));
     finalize_structure(b);
@@ -1826,8 +1846,10 @@ int ocp_qp_gpu_batch_sens_solve(ocp_qp_gpu_batch *b)
     b->sens_open = false;
     return 0;
 }
+catch (const gqp_hip_failure &) { return -1; }
 
 int ocp_qp_gpu_batch_get(ocp_qp_gpu_batch *b, const char *f, int k, double *data, int is_device)
+try
 {
     HIPCHK(hipSetDevice(b->device));
     finalize_structure(b);
@@ -1918,11 +1940,13 @@ int ocp_qp_gpu_batch_get(ocp_qp_gpu_batch *b, const char *f, int k, double *data
     HIPCHK(hipStreamSynchronize(b->stream));
     return 0;
 }
+catch (const gqp_hip_failure &) { return -1; }
 
 /* KKT residuals of the QP data and the iterate (ux, pi, lam, t) that are in HBM right now -- whoever put them there
  * (the solver, a warm-start set, an expansion): ocp_qp_res_compute + ocp_qp_res_compute_nrm_inf of
  * acados/ocp_qp/ocp_qp_common.c:559-667 for the whole batch in one launch.  Independent of the IPM sweeps. */
 int ocp_qp_gpu_batch_res_compute(ocp_qp_gpu_batch *b)
+try
 {
     HIPCHK(hipSetDevice(b->device));
     finalize_structure(b);
@@ -1943,9 +1967,11 @@ int ocp_qp_gpu_batch_res_compute(ocp_qp_gpu_batch *b)
     HIPCHK(hipGetLastError());
     return 0;
 }
+catch (const gqp_hip_failure &) { return -1; }
 
 /* res[i * 4 + q]: inf-norms of res_g, res_b, res_d, res_m of instance i (ocp_qp_res_compute_nrm_inf) */
 int ocp_qp_gpu_batch_res_nrm_inf(ocp_qp_gpu_batch *b, double *res)
+try
 {
     if (!b->R.nrm && ocp_qp_gpu_batch_res_compute(b) != 0) return -1;
     std::vector<double> h(4 * (size_t) b->Bp);
@@ -1954,8 +1980,10 @@ int ocp_qp_gpu_batch_res_nrm_inf(ocp_qp_gpu_batch *b, double *res)
         for (int q = 0; q < 4; q++) res[(size_t) i * 4 + q] = h[(size_t) q * b->Bp + i];
     return 0;
 }
+catch (const gqp_hip_failure &) { return -1; }
 
 int ocp_qp_gpu_batch_get_info(ocp_qp_gpu_batch *b, const char *f, void *data)
+try
 {
     HIPCHK(hipSetDevice(b->device));
     finalize_structure(b);
@@ -1975,8 +2003,10 @@ int ocp_qp_gpu_batch_get_info(ocp_qp_gpu_batch *b, const char *f, void *data)
     fprintf(stderr, "acados_amd: ocp_qp_gpu_batch_get_info: unknown field %s\n", f);
     return -1;
 }
+catch (const gqp_hip_failure &) { return -1; }
 
 int ocp_qp_gpu_batch_get_stat(ocp_qp_gpu_batch *b, int inst, double *stat, int max_rows)
+try
 {
     HIPCHK(hipSetDevice(b->device));
     if (b->pcond_state == 1 && b->child) return ocp_qp_gpu_batch_get_stat(b->child, inst, stat, max_rows);
@@ -1989,6 +2019,7 @@ int ocp_qp_gpu_batch_get_stat(ocp_qp_gpu_batch *b, int inst, double *stat, int m
             stat[r * GQP_STAT_COLS + c] = h[((size_t) r * GQP_STAT_COLS + c) * b->stat_inst + inst];
     return rows;
 }
+catch (const gqp_hip_failure &) { return -1; }
 
 double ocp_qp_gpu_batch_get_scalar(ocp_qp_gpu_batch *b, const char *f)
 {
@@ -2029,6 +2060,7 @@ double ocp_qp_gpu_batch_get_scalar(ocp_qp_gpu_batch *b, const char *f)
 }
 
 int ocp_qp_gpu_batch_condense_lhs(ocp_qp_gpu_batch *b)
+try
 {
     HIPCHK(hipSetDevice(b->device));
     finalize_structure(b);
@@ -2042,10 +2074,12 @@ int ocp_qp_gpu_batch_condense_lhs(ocp_qp_gpu_batch *b)
     b->lhs_ready = true;
     return 0;
 }
+catch (const gqp_hip_failure &) { return -1; }
 
 /* condensing-only boundary (interfaces/acados_c/condensing_interface.h:73-75): the condensed QP as an object of its
  * own, and the expansion of a solution of it */
 ocp_qp_gpu_batch *ocp_qp_gpu_batch_condense(ocp_qp_gpu_batch *b)
+try
 {
     HIPCHK(hipSetDevice(b->device));
     finalize_structure(b);
@@ -2059,10 +2093,12 @@ ocp_qp_gpu_batch *ocp_qp_gpu_batch_condense(ocp_qp_gpu_batch *b)
     b->lhs_ready = false;
     return b->child;
 }
+catch (const gqp_hip_failure &) { return nullptr; }
 
 /* vector part alone (gbar, bbar, bounds) on top of a resident matrix part: the `condense_rhs` slot of
  * ocp_qp_xcond_config (ocp_qp_partial_condensing.c:602-630); returns the condensed batch like _condense */
 ocp_qp_gpu_batch *ocp_qp_gpu_batch_condense_rhs(ocp_qp_gpu_batch *b)
+try
 {
     HIPCHK(hipSetDevice(b->device));
     finalize_structure(b);
@@ -2073,10 +2109,12 @@ ocp_qp_gpu_batch *ocp_qp_gpu_batch_condense_rhs(ocp_qp_gpu_batch *b)
     HIPCHK(hipGetLastError());
     return b->child;
 }
+catch (const gqp_hip_failure &) { return nullptr; }
 
 /* the current iterate of `b` restated in the condensed variables, written into the condensed batch: the
  * `condense_qp_out` slot (ocp_qp_partial_condensing.c:559-571) */
 int ocp_qp_gpu_batch_condense_sol(ocp_qp_gpu_batch *b)
+try
 {
     HIPCHK(hipSetDevice(b->device));
     if (b->pcond_state != 1 || !b->child) return -1;
@@ -2085,11 +2123,13 @@ int ocp_qp_gpu_batch_condense_sol(ocp_qp_gpu_batch *b)
     HIPCHK(hipGetLastError());
     return 0;
 }
+catch (const gqp_hip_failure &) { return -1; }
 
 /* the condensed batch currently owned by `b` (after _condense / _condense_lhs), or NULL */
 ocp_qp_gpu_batch *ocp_qp_gpu_batch_condensed(ocp_qp_gpu_batch *b) { return b->pcond_state == 1 ? b->child : nullptr; }
 
 int ocp_qp_gpu_batch_expand(ocp_qp_gpu_batch *b)
+try
 {
     HIPCHK(hipSetDevice(b->device));
     if (b->pcond_state != 1 || !b->child) return -1;
@@ -2099,6 +2139,7 @@ int ocp_qp_gpu_batch_expand(ocp_qp_gpu_batch *b)
     HIPCHK(hipGetLastError());
     return 0;
 }
+catch (const gqp_hip_failure &) { return -1; }
 
 int ocp_qp_gpu_batch_get_dims(ocp_qp_gpu_batch *b, const char *f, int *out)
 {
@@ -2124,11 +2165,13 @@ int ocp_qp_gpu_batch_get_int(ocp_qp_gpu_batch *b, const char *f, int k, int *out
 }
 
 int ocp_qp_gpu_batch_condense_rhs_and_solve(ocp_qp_gpu_batch *b)
+try
 {
     const int bad = ocp_qp_gpu_batch_solve(b); /* uses mode 2 when the lhs is in place */
     b->lhs_ready = false;
     return bad;
 }
+catch (const gqp_hip_failure &) { return -1; }
 
 
 /* ---- bulk pack / unpack ---- */
@@ -2227,6 +2270,7 @@ int ocp_qp_gpu_batch_bulk_offset(ocp_qp_gpu_batch *b, int output, const char *fi
 }
 
 int ocp_qp_gpu_batch_set_bulk(ocp_qp_gpu_batch *b, const double *blob, int is_device)
+try
 {
     const int len = ocp_qp_gpu_batch_bulk_len(b, 0);
     auto &M = b->bulk_in;
@@ -2247,10 +2291,12 @@ int ocp_qp_gpu_batch_set_bulk(ocp_qp_gpu_batch *b, const double *blob, int is_de
     HIPCHK(hipEventDestroy(e0)); HIPCHK(hipEventDestroy(e1));
     return 0;
 }
+catch (const gqp_hip_failure &) { return -1; }
 
 /* an iterate in the OUTPUT blob layout (u x sl su pi lam t) written into the batch: the starting point of a hot
  * start, one host->device copy and one launch (inverse of _get_bulk) */
 int ocp_qp_gpu_batch_set_bulk_out(ocp_qp_gpu_batch *b, const double *blob, int is_device)
+try
 {
     const int len = ocp_qp_gpu_batch_bulk_len(b, 1);
     auto &M = b->bulk_out;
@@ -2260,8 +2306,10 @@ int ocp_qp_gpu_batch_set_bulk_out(ocp_qp_gpu_batch *b, const double *blob, int i
     HIPCHK(hipStreamSynchronize(b->stream));
     return 0;
 }
+catch (const gqp_hip_failure &) { return -1; }
 
 int ocp_qp_gpu_batch_get_bulk(ocp_qp_gpu_batch *b, double *blob, int is_device)
+try
 {
     const int len = ocp_qp_gpu_batch_bulk_len(b, 1);
     auto &M = b->bulk_out;
@@ -2278,6 +2326,7 @@ int ocp_qp_gpu_batch_get_bulk(ocp_qp_gpu_batch *b, double *blob, int is_device)
     HIPCHK(hipStreamSynchronize(b->stream));
     return 0;
 }
+catch (const gqp_hip_failure &) { return -1; }
 
 /* ---- bulk seeds / sensitivities: every seed of every instance in one host->device copy and one launch, every
  * direction back in one launch and one copy (the batched eval_forw_sens / eval_adj_sens of the acados-side adapter;
@@ -2355,6 +2404,7 @@ int ocp_qp_gpu_batch_sens_bulk_offset(ocp_qp_gpu_batch *b, int output, const cha
 }
 
 int ocp_qp_gpu_batch_sens_set_bulk(ocp_qp_gpu_batch *b, const double *blob, int is_device)
+try
 {
     const int len = ocp_qp_gpu_batch_sens_bulk_len(b, 0);
     if (sens_begin(b)) return -1; /* zeroes the seed arrays, factorises at the solution where the sweeps run in place */
@@ -2369,8 +2419,10 @@ int ocp_qp_gpu_batch_sens_set_bulk(ocp_qp_gpu_batch *b, const double *blob, int 
     HIPCHK(hipStreamSynchronize(b->stream));
     return 0;
 }
+catch (const gqp_hip_failure &) { return -1; }
 
 int ocp_qp_gpu_batch_sens_get_bulk(ocp_qp_gpu_batch *b, double *blob, int is_device)
+try
 {
     const int len = ocp_qp_gpu_batch_bulk_len(b, 1);
     auto &M = b->bulk_out;
@@ -2390,6 +2442,7 @@ int ocp_qp_gpu_batch_sens_get_bulk(ocp_qp_gpu_batch *b, double *blob, int is_dev
     HIPCHK(hipStreamSynchronize(b->stream));
     return 0;
 }
+catch (const gqp_hip_failure &) { return -1; }
 
 /* pinned host memory for callers that stage their own blobs (the acados-side adapter is plain C and has no HIP) */
 void *ocp_qp_gpu_host_alloc(size_t bytes)
@@ -2502,6 +2555,7 @@ int ocp_qp_gpu_comm_unique_id(void *id128)
 }
 
 ocp_qp_gpu_comm *ocp_qp_gpu_comm_create(const void *id128, int n_ranks, int rank, int device)
+try
 {
     ocp_qp_gpu_comm *c = new ocp_qp_gpu_comm();
     if (!rccl_bind(c)) { delete c; return nullptr; }
@@ -2525,6 +2579,7 @@ ocp_qp_gpu_comm *ocp_qp_gpu_comm_create(const void *id128, int n_ranks, int rank
     c->ops.group_end = rccl_op_group_end;
     return c;
 }
+catch (const gqp_hip_failure &) { return nullptr; }
 #else  /* host-simulation build of the CPU test tier: no RCCL; communicators come from ocp_qp_gpu_comm_create_from_ops */
 int ocp_qp_gpu_comm_unique_id(void *) { return -1; }
 ocp_qp_gpu_comm *ocp_qp_gpu_comm_create(const void *, int, int, int) { return nullptr; }
@@ -2623,19 +2678,25 @@ static int gather_impl(ocp_qp_gpu_batch *b, ocp_qp_gpu_comm *c, int root, const 
 }
 
 int ocp_qp_gpu_batch_gather(ocp_qp_gpu_batch *b, ocp_qp_gpu_comm *c, double *sol_all, int *info_all, double *time_all)
+try
 {
     return gather_impl(b, c, -1, nullptr, sol_all, info_all, time_all);
 }
+catch (const gqp_hip_failure &) { return -1; }
 
 int ocp_qp_gpu_batch_gather_root(ocp_qp_gpu_batch *b, ocp_qp_gpu_comm *c, int root, double *sol_all, int *info_all, double *time_all)
+try
 {
     return gather_impl(b, c, root < 0 ? 0 : root, nullptr, sol_all, info_all, time_all);
 }
+catch (const gqp_hip_failure &) { return -1; }
 
 int ocp_qp_gpu_batch_gather_v(ocp_qp_gpu_batch *b, ocp_qp_gpu_comm *c, int root, const int *counts, double *sol_all, int *info_all, double *time_all)
+try
 {
     return gather_impl(b, c, root, counts, sol_all, info_all, time_all);
 }
+catch (const gqp_hip_failure &) { return -1; }
 
 size_t ocp_qp_gpu_batch_bytes(const ocp_qp_gpu_batch *b) { return b->bytes; }
 void *ocp_qp_gpu_batch_stream(ocp_qp_gpu_batch *b) { return (void *) b->stream; }

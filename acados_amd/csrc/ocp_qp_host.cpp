@@ -1025,6 +1025,19 @@ static void build_segments(batch_cache *bc, ocp_qp_gpu_batch *b, const ocp_qp_di
     }
 }
 
+/* the device failed under this call (the library has reported the HIP error): every QP of the call is a QP failure --
+ * what ocp_nlp turns into ACADOS_QP_FAILURE and a clean return (ocp_nlp_sqp.c:720-751) -- and the process lives on */
+static int device_failure(int n, ocp_qp_out **outs, int *status, void **mem_)
+{
+    for (int i = 0; i < n; i++)
+    {
+        if (status) status[i] = ACADOS_QP_FAILURE;
+        if (outs && outs[i] && outs[i]->misc) { qp_info *info = (qp_info *) outs[i]->misc; info->num_iter = 0; info->t_computed = 0; }
+        if (mem_ && mem_[i]) { gpu_ipm_memory *mi = (gpu_ipm_memory *) mem_[i]; mi->iter = 0; mi->status = ACADOS_QP_FAILURE; }
+    }
+    return ACADOS_QP_FAILURE;
+}
+
 int gqp_host::gpu_ipm_evaluate_impl(void *config, int n, void **qp_in_, void **qp_out_, void *opts_, void **mem_, void *work,
                                     int *status, const cond_request *cr)
 {
@@ -1177,18 +1190,19 @@ int gqp_host::gpu_ipm_evaluate_impl(void *config, int n, void **qp_in_, void **q
                 for (const blob_seg &g : tab)
                     memcpy(blob + (size_t) i * L + g.off, in_field(ins[i], g.fid, g.k) + g.shift, sizeof(double) * g.len);
         });
-        ocp_qp_gpu_batch_set_bulk(b, blob, 0);
+        if (ocp_qp_gpu_batch_set_bulk(b, blob, 0) != 0) return device_failure(n, outs, status, mem_);
     }
     if (phase == 1)
     {
         /* RTI preparation (ocp_qp_xcond_solver.c:591-620): matrix part of the condensing, resident on the device */
-        ocp_qp_gpu_batch_condense_lhs(b);
-        return ACADOS_SUCCESS;
+        return ocp_qp_gpu_batch_condense_lhs(b) == 0 ? ACADOS_SUCCESS : device_failure(n, outs, status, mem_);
     }
     const double t_packed = now_s();
 
-    if (phase == 2) ocp_qp_gpu_batch_condense_rhs_and_solve(b);
-    else ocp_qp_gpu_batch_solve(b);
+    /* >= 0: instances with non-zero status; < 0: the device failed (HIP error reported by the library) -- every QP of the
+     * call comes back as ACADOS_QP_FAILURE, nothing is read from the device, the process goes on */
+    const int dev_rc = phase == 2 ? ocp_qp_gpu_batch_condense_rhs_and_solve(b) : ocp_qp_gpu_batch_solve(b);
+    if (dev_rc < 0) return device_failure(n, outs, status, mem_);
     if (condensed_call) bc->cond_solved = true;
     const double t_solved = now_s();
 
@@ -1196,7 +1210,7 @@ int gqp_host::gpu_ipm_evaluate_impl(void *config, int n, void **qp_in_, void **q
     {
         const size_t L = (size_t) bc->L_out;
         pinned_reserve(bc->blob_out, bc->cap_out, (size_t) n * L);
-        ocp_qp_gpu_batch_get_bulk(b, bc->blob_out, 0);
+        if (ocp_qp_gpu_batch_get_bulk(b, bc->blob_out, 0) != 0) return device_failure(n, outs, status, mem_);
         const double *blob = bc->blob_out;
         const std::vector<blob_seg> &tab = bc->seg_out;
         par_instances(n, [&](int lo, int hi) {

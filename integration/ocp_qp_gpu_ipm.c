@@ -43,7 +43,7 @@
 
 #include "acados/ocp_qp/ocp_qp_common.h"
 #include "acados/utils/types.h"
-#include "blasfeo_d_aux.h"
+#include "blasfeo/include/blasfeo_d_aux.h"
 
 #include "acados_amd/ocp_qp_gpu_batch.h"
 
@@ -83,7 +83,20 @@ typedef struct
     int *members;                /* batch entries: index of each instance in the caller's arrays */
     int *st, *it;                /* per-instance status / iterations of the last solve */
     int status;                  /* worst status of the last solve */
+    /* After a batched solve (evaluate_batch / a rendezvous round) every capsule of a structure class shares this bucket:
+     * its device batch, its pinned staging, its seed state.  The generated batch loops call the per-capsule slots
+     * solver_get / eval_forw_sens / eval_adj_sens inside `#pragma omp parallel for` (acados_solver.in.c:3292-3337): staging,
+     * device pass and read-back of one capsule are one critical section (round-3 review: they raced). */
+    pthread_mutex_t mu;
+    int mu_live;
 } gpu_bucket;
+
+static void bucket_lock(gpu_bucket *bk)
+{
+    if (!bk->mu_live) { pthread_mutex_init(&bk->mu, NULL); bk->mu_live = 1; } /* own bucket: first use is single-threaded (evaluate) */
+    pthread_mutex_lock(&bk->mu);
+}
+static void bucket_unlock(gpu_bucket *bk) { pthread_mutex_unlock(&bk->mu); }
 
 struct ocp_qp_gpu_ipm_memory_;
 typedef struct gpu_group_
@@ -120,6 +133,7 @@ static gpu_group *mem_group(const ocp_qp_gpu_ipm_memory *m)
 }
 
 static int rendezvous_evaluate(struct ocp_qp_gpu_ipm_rendezvous_ *r, void *config, void *qp_in, void *qp_out, void *opts, ocp_qp_gpu_ipm_memory *m);
+static void group_release(gpu_group *g);
 
 static double now_s(void)
 {
@@ -514,12 +528,17 @@ static void bucket_solve(gpu_bucket *bk, const ocp_qp_gpu_ipm_opts *o, int ws)
     ocp_qp_gpu_batch *b = bk->batch;
     apply_opts(b, o, ws);
     /* the starting point goes in before the pack, which then restores the equality-flagged values (x0) */
-    if (ws >= 2) ocp_qp_gpu_batch_set_bulk_out(b, bk->blob_out, 0);
-    ocp_qp_gpu_batch_set_bulk(b, bk->blob_in, 0);
-    ocp_qp_gpu_batch_solve(b);
-    ocp_qp_gpu_batch_get_bulk(b, bk->blob_out, 0);
-    ocp_qp_gpu_batch_get_info(b, "status", bk->st);
-    ocp_qp_gpu_batch_get_info(b, "iter", bk->it);
+    /* a negative return = the device failed (HIP error, reported by the library): every QP of the bucket comes back as
+     * ACADOS_QP_FAILURE -- ocp_nlp ends that capsule's solve cleanly (ocp_nlp_sqp.c:720-751) -- and the process, with the
+     * other host threads of an MPC fleet in it, lives on */
+    if ((ws >= 2 && ocp_qp_gpu_batch_set_bulk_out(b, bk->blob_out, 0) != 0) || ocp_qp_gpu_batch_set_bulk(b, bk->blob_in, 0) != 0
+        || ocp_qp_gpu_batch_solve(b) < 0 || ocp_qp_gpu_batch_get_bulk(b, bk->blob_out, 0) != 0
+        || ocp_qp_gpu_batch_get_info(b, "status", bk->st) != 0 || ocp_qp_gpu_batch_get_info(b, "iter", bk->it) != 0)
+    {
+        for (int i = 0; i < bk->n; i++) { bk->st[i] = ACADOS_QP_FAILURE; bk->it[i] = 0; }
+        bk->status = ACADOS_QP_FAILURE;
+        return;
+    }
     int worst = 0;
     for (int i = 0; i < bk->n; i++)
         if (bk->st[i] != ACADOS_SUCCESS && (worst == 0 || worst == ACADOS_MAXITER)) worst = bk->st[i];
@@ -553,7 +572,10 @@ static int ocp_qp_gpu_ipm_acados(void *config, void *qp_in_, void *qp_out_, void
             }
         }
     }
-    m->group = NULL; /* this memory's QP lives in its own batch from now on */
+    /* this memory's QP lives in its own batch from now on; a group this memory OWNS (it was mem[0] of a batch call) goes with
+     * it -- nobody else could release it later (round-3 review); the other members see the generation change (mem_group) */
+    if (mem_group(m) && m->group->owner == m) group_release(m->group);
+    m->group = NULL;
 
     const int ws = o->warm_start >= 2 ? o->warm_start : 0; /* 1 = 0, acados_ocp_options.py:1029-1031 */
     memset(bk->blob_in, 0, sizeof(double) * (size_t) bk->L_in);
@@ -586,6 +608,7 @@ static void bucket_release(gpu_bucket *bk)
     if (bk->batch) ocp_qp_gpu_batch_destroy(bk->batch);
     ocp_qp_gpu_host_free(bk->blob_in); ocp_qp_gpu_host_free(bk->blob_out);
     free(bk->sig); free(bk->seg_in); free(bk->seg_out); free(bk->seg_seed); free(bk->members); free(bk->st); free(bk->it);
+    if (bk->mu_live) pthread_mutex_destroy(&bk->mu);
     memset(bk, 0, sizeof(*bk));
 }
 
@@ -674,6 +697,7 @@ static gpu_group *group_for(int n, ocp_qp_in **ins, ocp_qp_gpu_ipm_memory **mems
             bk->sig = (int *) xcalloc(len, sizeof(int)); bk->sig_cap = len; bk->sig_len = len;
             memcpy(bk->sig, g->scratch, sizeof(int) * len);
             bk->members = (int *) xcalloc(n, sizeof(int));
+            pthread_mutex_init(&bk->mu, NULL); bk->mu_live = 1;
         }
         gpu_bucket *bk = g->bk + q;
         g->bucket_of[i] = q; g->pos_of[i] = bk->n;
@@ -921,11 +945,18 @@ static void gpu_solver_get(void *config_, void *qp_in_, void *qp_out_, void *opt
     int pos = 0;
     gpu_bucket *bk = bucket_of_mem(m, &pos);
     if (!bk->batch) { printf("\nocp_qp_gpu_ipm_solver_get: no factorisation available (solve first)\n"); exit(1); }
-    /* staging is idle between evaluates: n * ((nu+nx)^2 + nu+nx) fit (blob_in_cap) */
+    /* staging is idle between evaluates: n * ((nu+nx)^2 + nu+nx) fit (blob_in_cap); shared by the capsules of a class ->
+     * locked, and this capsule's block is copied out before the lock is dropped */
+    bucket_lock(bk);
     double *Lb = bk->blob_in, *lb = bk->blob_in + (size_t) bk->n * nv * nv;
     ocp_qp_gpu_batch_get(bk->batch, "ric_L", stage, Lb, 0);
     ocp_qp_gpu_batch_get(bk->batch, "ric_l", stage, lb, 0);
-    const double *L = Lb + (size_t) pos * nv * nv, *l = lb + (size_t) pos * nv;
+    double *mine = (double *) malloc(sizeof(double) * (size_t) (nv * nv + nv + 1));
+    if (!mine) { printf("\nerror: ocp_qp_gpu_ipm_solver_get: out of host memory\n"); exit(1); }
+    memcpy(mine, Lb + (size_t) pos * nv * nv, sizeof(double) * (size_t) (nv * nv));
+    memcpy(mine + nv * nv, lb + (size_t) pos * nv, sizeof(double) * (size_t) nv);
+    bucket_unlock(bk);
+    const double *L = mine, *l = mine + nv * nv;
     if (!strcmp(field, "P"))
         for (int c = 0; c < nx; c++) for (int r = 0; r < nx; r++)
         {
@@ -955,6 +986,7 @@ static void gpu_solver_get(void *config_, void *qp_in_, void *qp_out_, void *opt
         for (int c = 0; c < nu; c++) for (int r = 0; r < nu; r++) out[r + nu * c] = r >= c ? L[r + nv * c] : 0.0;
     else
         printf("\nocp_qp_gpu_ipm_solver_get: field %s not supported", field);
+    free(mine);
 }
 
 static void gpu_memory_reset(void *config, void *qp_in, void *qp_out, void *opts, void *mem_, void *work)
@@ -990,11 +1022,16 @@ static void gpu_eval_sens(void *config, void *qp_in, void *seed_, void *sens_qp_
     int pos = 0;
     gpu_bucket *bk = bucket_of_mem(m, &pos);
     if (!bk->batch) { printf("\nerror: ocp_qp_gpu_ipm: eval_forw_sens / eval_adj_sens before the first evaluate\n"); exit(1); }
-    /* the seed belongs to this memory's instance; the other instances of a shared batch get zero seeds */
+    /* the seed belongs to this memory's instance; the other instances of a shared batch get zero seeds.  One capsule at a
+     * time per class (the per-capsule slot of a SHARED batch costs a pass over the whole batch: n capsules calling it are
+     * n passes -- ocp_qp_gpu_ipm_acados_eval_sens_batch below does the n seeds in ONE pass and is what a batched caller
+     * should use; this slot stays correct, not fast, under the generated OpenMP loops) */
+    bucket_lock(bk);
     memset(bk->blob_in, 0, sizeof(double) * (size_t) bk->n * (size_t) bk->L_seed);
     unpack_seed(bk, (ocp_qp_seed *) seed_, bk->blob_in + (size_t) pos * (size_t) bk->L_seed);
     bucket_sens(bk);
     pack_qp_out(bk, bk->blob_out + (size_t) pos * (size_t) bk->L_out, (ocp_qp_out *) sens_qp_out_);
+    bucket_unlock(bk);
 }
 
 /* the same for all n capsules of the last ocp_qp_gpu_ipm_acados_evaluate_batch at once: one seed each, one device pass

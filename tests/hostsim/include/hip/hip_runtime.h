@@ -60,7 +60,21 @@ static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 #define hipStreamDefault 0u
 static inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned int, int) { *s = nullptr; return hipSuccess; }
 static inline hipError_t hipDeviceGetStreamPriorityRange(int *least, int *greatest) { *least = 1; *greatest = -1; return hipSuccess; }
-static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+/* fault injection for the CPU tier (tests/test_boundary.py::test_device_failure_is_a_status_not_an_exit): with
+ * GQP_HOSTSIM_FAIL_SYNC=n in the environment the n-th stream synchronisation from now on reports an error (once) */
+static inline hipError_t hipStreamSynchronize(hipStream_t)
+{
+    const char *e = getenv("GQP_HOSTSIM_FAIL_SYNC");
+    if (e && *e)
+    {
+        static int seen = 0;
+        static int armed_for = -1;
+        const int n = atoi(e);
+        if (n != armed_for) { armed_for = n; seen = 0; }
+        if (n > 0 && ++seen == n) { seen = -1000000000; return 719; }
+    }
+    return hipSuccess;
+}
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new hostsim_event(); return hipSuccess; }
 static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }

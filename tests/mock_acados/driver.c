@@ -119,6 +119,41 @@ static int run_batch(int argc, char **argv)
         if (do_sens) mock_write_sol_bin(g, &caps[i]->dim, &caps[i]->sens);
     }
     fclose(g);
+    /* the generated batch loops call the PER-CAPSULE slots inside `#pragma omp parallel for` (acados_solver.in.c:3292-3337:
+     * eval_param_sens / eval_solution_sens_adj_p per capsule; ocp_nlp_ddp.c:373-377 reads K, k per capsule): after a batched
+     * solve the capsules of a class share one device batch and its staging -- every capsule's slot result, computed with
+     * all capsules in flight at once, must be its share of the batched call (sensitivities) resp. what the serial call
+     * returns (gains) */
+    if (do_sens)
+    {
+        double worst = 0.0, worst_k = 0.0;
+        struct d_ocp_qp_sol *chk = calloc(n, sizeof(*chk));
+        double **Kser = calloc(n, sizeof(double *)), **Kpar = calloc(n, sizeof(double *));
+        for (int i = 0; i < n; i++)
+        {
+            mock_alloc_sol(&caps[i]->dim, chk + i);
+            const int nu = caps[i]->dim.nu[1], nx = caps[i]->dim.nx[1];
+            Kser[i] = calloc((size_t) (nu * nx + 1), sizeof(double)); Kpar[i] = calloc((size_t) (nu * nx + 1), sizeof(double));
+            if (nu > 0) config.solver_get(&config, &caps[i]->qp, &caps[i]->sol, opts, mems[i], "K", 1, Kser[i], nu, nx);
+        }
+#pragma omp parallel for schedule(dynamic, 1) num_threads(8)
+        for (int i = 0; i < n; i++)
+        {
+            config.eval_forw_sens(&config, &caps[i]->qp, &caps[i]->seed, chk + i, opts, mems[i], NULL);
+            const int nu = caps[i]->dim.nu[1], nx = caps[i]->dim.nx[1];
+            if (nu > 0) config.solver_get(&config, &caps[i]->qp, &caps[i]->sol, opts, mems[i], "K", 1, Kpar[i], nu, nx);
+        }
+        for (int i = 0; i < n; i++)
+        {
+            mock_capsule *c = caps[i];
+            for (int s = 0; s <= c->dim.N; s++)
+                for (int e = 0; e < c->dim.nu[s] + c->dim.nx[s]; e++)
+                    worst = fmax(worst, fabs(BLASFEO_DVECEL(chk[i].ux + s, e) - BLASFEO_DVECEL(c->sens.ux + s, e)));
+            for (int e = 0; e < c->dim.nu[1] * c->dim.nx[1]; e++) worst_k = fmax(worst_k, fabs(Kser[i][e] - Kpar[i][e]));
+        }
+        printf("threaded_slots_vs_batch_sens %.3e\n", worst);
+        printf("threaded_slots_gain_K %.3e\n", worst_k);
+    }
     /* a single-capsule slot after a batch call: the sensitivity of capsule n-1 alone through its own memory must equal
      * its share of the batched call */
     if (do_sens)

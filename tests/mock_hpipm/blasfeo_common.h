@@ -1,0 +1,5 @@
+/* TEST INFRASTRUCTURE ONLY -- stand-in for BLASFEO's blasfeo_common.h as acados' utility headers include it (flat name) */
+#ifndef STANDIN_FLAT_BLASFEO_COMMON_H_
+#define STANDIN_FLAT_BLASFEO_COMMON_H_
+#include "blasfeo/include/blasfeo_d_aux.h"
+#endif

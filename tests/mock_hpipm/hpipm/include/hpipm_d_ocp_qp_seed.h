@@ -1,0 +1,6 @@
+/* TEST INFRASTRUCTURE ONLY -- stand-in for HPIPM's hpipm/include/hpipm_d_ocp_qp_seed.h (empty submodule in /root/reference): nothing on the
+ * OCP-QP plugin path reads these structs; the reference headers that include this file only name them through pointers */
+#ifndef STANDIN_HPIPM_D_OCP_QP_SEED_H_
+#define STANDIN_HPIPM_D_OCP_QP_SEED_H_
+#include "hpipm_d_ocp_qp.h"
+#endif

@@ -1384,3 +1384,32 @@ def test_concurrent_shape_classes_hostsim(hostsim_lib):
                 for k in range(N + 1):
                     assert np.array_equal(gb.get("x", k), r[k])
                 assert np.array_equal(gb.info("iter"), r[-1])
+
+
+def test_device_failure_is_a_status_not_an_exit_hostsim(hostsim_lib, monkeypatch):
+    """a HIP error under a solve (injected: the n-th stream synchronisation reports hipErrorLaunchFailure) comes back as -1 from
+    the device-batch entry and as ACADOS_QP_FAILURE from the plugin's evaluate -- what ocp_nlp handles (ocp_nlp_sqp.c:720-751) --
+    instead of exit(1) taking the process, and the other capsules of an MPC fleet, down (round-3 review); the next call on
+    the same objects solves normally"""
+    from acados_amd import AcadosOcpQpOptions, AcadosOcpQpSolver, OcpQpGpuBatch
+    from acados_amd.generators import fill_lqr_batch, lqr_dims, mass_spring_qp, random_lqr_batch
+    N, B = 5, 3
+    data = random_lqr_batch(N=N, batch=B, seed=3)
+    gb = OcpQpGpuBatch(lqr_dims(N, 8, 3), B, _clib=hostsim_lib)
+    fill_lqr_batch(gb, data, N)
+    assert gb.solve() == 0
+    x_ok = gb.get("x", N).copy()
+    monkeypatch.setenv("GQP_HOSTSIM_FAIL_SYNC", "2")
+    assert gb.solve() == -1
+    monkeypatch.setenv("GQP_HOSTSIM_FAIL_SYNC", "")
+    assert gb.solve() == 0 and np.array_equal(gb.get("x", N), x_ok)
+    # through the 22-slot vtable (acados_c layer)
+    qp = mass_spring_qp(N=6)
+    opts = AcadosOcpQpOptions()
+    s = AcadosOcpQpSolver(qp, opts=opts, _clib=hostsim_lib)
+    assert s.solve() == 0
+    u_ok = s.get(0, "u").copy()
+    monkeypatch.setenv("GQP_HOSTSIM_FAIL_SYNC", "3")
+    assert s.solve() == 4            # ACADOS_QP_FAILURE (types.h:74-87)
+    monkeypatch.setenv("GQP_HOSTSIM_FAIL_SYNC", "")
+    assert s.solve() == 0 and np.allclose(s.get(0, "u"), u_ok, atol=1e-12)

@@ -22,10 +22,27 @@ def clib(request):
     return request.getfixturevalue("hostsim_lib" if request.param == "hostsim" else "gpu_lib")
 
 
-def _build(libpath, tmp_path):
+REFERENCE = "/root/reference"
+PREBUILT = os.path.join(ROOT, "integration", "_ref_build", "mock_acados_driver")    # integration/Makefile, built by __graft_entry__.build()
+
+
+def _build(libpath, tmp_path, headers="restated"):
+    """headers = "restated": the acados declarations restated under tests/mock_acados/include (runs everywhere);
+    headers = "reference": acados/ocp_qp/ocp_qp_common.h and acados/utils/types.h are the REFERENCE'S OWN files (-I /root/reference),
+    only hpipm/include/*.h and blasfeo/include/*.h (empty submodules there) are stand-ins (tests/mock_hpipm).  /root/reference
+    does not exist on the GPU box: there the binary built from the same sources in the build container (integration/Makefile,
+    linked against the product library) is run."""
     exe = str(tmp_path / "mock_acados_driver")
     libdir, libname = os.path.dirname(libpath), os.path.basename(libpath)
-    cmd = ["gcc", "-std=gnu11", "-O2", "-fopenmp", "-Wall", "-Wno-unused-parameter", "-I", os.path.join(MOCK, "include"), "-I", os.path.join(ROOT, "include"),
+    if headers == "reference":
+        if not os.path.isdir(os.path.join(REFERENCE, "acados", "ocp_qp")):
+            if libname == "libacados_amd_qp.so" and os.path.exists(PREBUILT):
+                return PREBUILT
+            pytest.skip("no reference tree and no prebuilt reference-header driver for this library")
+        inc = ["-I", REFERENCE, "-I", os.path.join(ROOT, "tests", "mock_hpipm"), "-I", MOCK]
+    else:
+        inc = ["-I", os.path.join(MOCK, "include")]
+    cmd = ["gcc", "-std=gnu11", "-O2", "-fopenmp", "-Wall", "-Wno-unused-parameter"] + inc + ["-I", os.path.join(ROOT, "include"),
            os.path.join(MOCK, "driver.c"), os.path.join(ROOT, "integration", "ocp_qp_gpu_ipm.c"), "-o", exe,
            "-L", libdir, "-l:" + libname, "-Wl,-rpath," + libdir, "-lm", "-lpthread"]
     r = subprocess.run(cmd, capture_output=True, text=True)
@@ -159,12 +176,13 @@ def _check_sens_vs_dense(qp, sol, sens, seeds, tol, tol_mult):
 
 
 @pytest.mark.parametrize("clib", TIERS, indirect=True)
+@pytest.mark.parametrize("headers", ["restated", "reference"])
 @pytest.mark.parametrize("qp_name", ["mass_spring", "casadi_qp_tests/pendulum_slack.json", "casadi_qp_tests/pend_idxs_rev_min_qp0.json",
                                      "qp_test/last_qp_one_sided_test.json"])
-def test_acados_adapter_compiled_and_run(clib, tmp_path, qp_name):
+def test_acados_adapter_compiled_and_run(clib, tmp_path, qp_name, headers):
     from acados_amd.generators import mass_spring_qp
     qp = mass_spring_qp(N=15) if qp_name == "mass_spring" else load_qp(qp_name)
-    exe = _build(clib._name, tmp_path)
+    exe = _build(clib._name, tmp_path, headers)
     qp_file, sol_file = str(tmp_path / "qp.txt"), str(tmp_path / "sol.txt")
     _write_qp(qp, qp_file)
     env = dict(os.environ)
@@ -291,6 +309,9 @@ def test_acados_adapter_batch_two_structures(clib, tmp_path):
     n = 7
     info, per, extra, raw = _run_batch(exe, tmp_path, n, [fa, fb], sens=True)
     assert info["status"] == 0 and extra["single_vs_batch_sens"] <= 1e-12
+    # the per-capsule slots called from 8 OpenMP threads at once (the generated batch loops, acados_solver.in.c:3292-3337) on the
+    # shared device batches: each capsule gets ITS sensitivity / ITS gain (they raced on the staging blob before round 4)
+    assert extra["threaded_slots_vs_batch_sens"] <= 1e-12 and extra["threaded_slots_gain_K"] == 0.0
     # after the owner rebuilt the group for a smaller batch, the last capsule's memory (which still remembers the released
     # group) answers status / iter from itself and its single-QP slot solves in its own batch: same solution
     assert extra["regroup_half_status"] == 0 and extra["regroup_last_status"] == 0 and extra["regroup_last_iter"] == per[n - 1][2]
