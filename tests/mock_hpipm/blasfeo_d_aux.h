@@ -2,4 +2,5 @@
 #ifndef STANDIN_FLAT_BLASFEO_D_AUX_H_
 #define STANDIN_FLAT_BLASFEO_D_AUX_H_
 #include "blasfeo/include/blasfeo_d_aux.h"
+#include "mock_hpipm.h"
 #endif

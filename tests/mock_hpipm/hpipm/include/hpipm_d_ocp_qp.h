@@ -3,7 +3,7 @@
  * /root/reference on the include path, acados/ocp_qp/ocp_qp_common.h, acados/utils/types.h ... are the reference's OWN files. */
 #ifndef STANDIN_HPIPM_D_OCP_QP_H_
 #define STANDIN_HPIPM_D_OCP_QP_H_
-#include "../../../mock_acados/include/hpipm_d_ocp_qp.h"
-struct d_ocp_qp_res;
-struct d_ocp_qp_res_ws;
+#include "../../mock_hpipm.h"
+
+
 #endif

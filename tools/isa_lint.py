@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""ISA lint of the built library (run by `make` in acados_amd/csrc and by tests/test_isa_lint.py):
+
+  rule 1  no kernel that issues LDS-DMA (`global_load_lds_*`, inline asm in ipm_kernels_w16r.hpp / pcond_kernels_w16.hpp: the
+          compiler neither counts those requests nor orders anything behind them) may contain a PARTIAL vector-memory wait
+          -- `s_waitcnt vmcnt(n)` with n > 0 -- anywhere: with DMA requests in flight the count the compiler reasons with is
+          not the count of the hardware, so "my load has landed because at most n are outstanding" does not hold.  This is
+          the construct the two-waves-per-SIMD fault of rounds 2-3 was narrowed to (profiles/r04_vmcnt_probe.txt);
+  rule 2  no kernel of the two-rows / condensing families (ky_*, kz_*) uses scratch (private segment) or has spilled registers:
+          spill traffic is HBM traffic there;
+  rule 3  every ky_* / kz_* kernel that issues LDS-DMA is built for ONE wave per SIMD (>= 257 registers, or the occupancy the
+          attribute amdgpu_waves_per_eu(1,1) leaves in the metadata): the only configuration every test and measurement runs.
+
+    python tools/isa_lint.py [acados_amd/csrc/libacados_amd_qp.so]      exit code 1 + a list on violation
+"""
+import os
+import re
+import struct
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
+
+
+def code_objects(path):
+    """gfx950 code objects embedded in a hipcc-built shared library (uncompressed clang offload bundles in .hip_fatbin)"""
+    data = open(path, "rb").read()
+    out = []
+    for m in re.finditer(re.escape(MAGIC), data):
+        base = m.start()
+        (n,) = struct.unpack_from("<Q", data, base + 24)
+        p = base + 32
+        for _ in range(n):
+            off, size, tl = struct.unpack_from("<QQQ", data, p)
+            triple = data[p + 24:p + 24 + tl].decode()
+            p += 24 + tl
+            if "gfx950" in triple and size:
+                out.append(data[base + off:base + off + size])
+    return out
+
+
+def kernels(disasm):
+    """{symbol: [instruction lines]} of a llvm-objdump -d listing"""
+    out, cur = {}, None
+    for ln in disasm.splitlines():
+        m = re.match(r"^[0-9a-f]+ <(.+)>:$", ln)
+        if m:
+            cur = m.group(1)
+            out[cur] = []
+        elif cur is not None and ln.startswith("\t"):
+            out[cur].append(ln.strip().split("//")[0].strip())
+    return out
+
+
+def metadata(path):
+    """{kernel symbol: (vgprs, agprs, scratch bytes, sgpr spills, vgpr spills)} from the AMDGPU metadata note"""
+    txt = subprocess.run([READELF, "--notes", path], capture_output=True, text=True).stdout
+    out, name = {}, None
+    vals = {}
+    for ln in txt.splitlines():
+        m = re.match(r"\s*-?\s*\.?(agpr_count|name|private_segment_fixed_size|sgpr_spill_count|symbol|vgpr_count|vgpr_spill_count):\s*(.*)$", ln.strip().lstrip("- "))
+        if not m:
+            continue
+        k, v = m.group(1), m.group(2).strip().strip("'\"")
+        if k == "name":
+            if vals.get("symbol"):
+                out[vals["symbol"].replace(".kd", "")] = vals
+            vals = {}
+        vals[k] = v
+    if vals.get("symbol"):
+        out[vals["symbol"].replace(".kd", "")] = vals
+    return out
+
+
+def demangle(names):
+    r = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True)
+    return dict(zip(names, r.stdout.splitlines()))
+
+
+def lint(lib):
+    bad, report = [], []
+    for ci, co in enumerate(code_objects(lib)):
+        with tempfile.NamedTemporaryFile(suffix=".co", delete=False) as f:
+            f.write(co)
+            tmp = f.name
+        try:
+            dis = subprocess.run([OBJDUMP, "-d", tmp], capture_output=True, text=True).stdout
+            meta = metadata(tmp)
+        finally:
+            os.unlink(tmp)
+        ks = kernels(dis)
+        names = demangle(list(ks))
+        for sym, ins in ks.items():
+            dn = names.get(sym, sym)
+            fam = re.search(r"\bgqp::(k[yz]_\w+)", dn)
+            dma = [i for i, t in enumerate(ins) if t.startswith("global_load_lds")]
+            partial = [(i, t) for i, t in enumerate(ins) if t.startswith("s_waitcnt") and re.search(r"vmcnt\((\d+)\)", t)
+                       and int(re.search(r"vmcnt\((\d+)\)", t).group(1)) > 0]
+            md = meta.get(sym, {})
+            if dma:
+                report.append(f"{dn.split('(')[0]}: {len(dma)} LDS-DMA requests, {len(partial)} partial vmcnt waits, "
+                              f"vgpr {md.get('vgpr_count', '?')} agpr {md.get('agpr_count', '?')} scratch {md.get('private_segment_fixed_size', '?')}")
+                if partial:
+                    bad.append(f"rule 1: {dn.split('(')[0]}: {len(partial)} x s_waitcnt vmcnt(n > 0) in a kernel with LDS-DMA, first: '{partial[0][1]}' at instruction {partial[0][0]}")
+                if fam and md:
+                    regs = int(md.get("vgpr_count", 0)) + int(md.get("agpr_count", 0))
+                    if regs <= 256:
+                        bad.append(f"rule 3: {dn.split('(')[0]}: {regs} registers: two waves of an LDS-DMA kernel would fit one SIMD")
+            if fam and md:
+                if int(md.get("private_segment_fixed_size", 0)) or int(md.get("vgpr_spill_count", 0)):
+                    bad.append(f"rule 2: {dn.split('(')[0]}: scratch {md.get('private_segment_fixed_size')} B, {md.get('vgpr_spill_count')} spilled VGPRs")
+    return bad, report
+
+
+if __name__ == "__main__":
+    lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "acados_amd", "csrc", "libacados_amd_qp.so")
+    bad, report = lint(lib)
+    for r in report:
+        print(r)
+    if bad:
+        print("\nISA LINT FAILED:")
+        for b in bad:
+            print("  " + b)
+        sys.exit(1)
+    print(f"ISA lint: {len(report)} LDS-DMA kernels checked, no violation")
