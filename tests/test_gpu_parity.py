@@ -881,8 +881,25 @@ def test_w16r_repeatability_gpu(gpu_lib):
             if side.solve() != 0 or not np.array_equal(side.get("x", 10), side_ref):
                 side_bad.append(1)
 
+    # ... and a FOREIGN kernel -- a plain streaming copy of 2 GB on a third stream, small register footprint: its waves take
+    # the free slots of the SIMDs the two-rows waves run on (round-3 review: the co-resident waves of the C5 leg are not only
+    # this family's).  What LDS-DMA and partial vmcnt waits do under such co-residency: profiles/r04_vmcnt_probe.txt
+    import torch
+    fstream = torch.cuda.Stream()
+    fa = torch.zeros(1 << 28, dtype=torch.float64, device="cuda")
+    fb = torch.empty_like(fa)
+
+    def foreign():
+        with torch.cuda.stream(fstream):
+            while not stop.is_set():
+                for _ in range(8):
+                    fb.copy_(fa, non_blocking=True)
+                fstream.synchronize()
+
     th = threading.Thread(target=churn)
     th.start()
+    tf = threading.Thread(target=foreign)
+    tf.start()
     try:
         ref = None
         for rep in range(20):
@@ -896,6 +913,8 @@ def test_w16r_repeatability_gpu(gpu_lib):
                 ref = sol
             assert np.array_equal(ref[0], sol[0]) and np.array_equal(ref[1], sol[1]), rep
     finally:
+        stop.set()
+        tf.join()
         stop.set()
         th.join()
     assert not side_bad
