@@ -25,6 +25,7 @@
 #include "ipm_kernels_wpi_mfma.hpp"
 #include "res_kernels.hpp"
 #include "pcond_kernels_w16.hpp"
+#include "pcond_kernels_mfma.hpp"
 #include "kernel_sets.h"
 
 /* a failing HIP call is not something a solve can recover from (lost device, out of HBM): message + exit(1), acados'
@@ -95,8 +96,9 @@ struct PcondzSet
     int NX, NU, BS;
     kern_pcond_t cond;
     size_t shmem;
+    kern_pcond_t cond_m; /* the same contraction on the FP64 matrix pipe, v_mfma_f64_4x4x4_4b_f64 (pcond_kernels_mfma.hpp): the default */
 };
-#define GQP_PCONDZ(NX, NU, BS) {NX, NU, BS, gqp::kz_pcond<NX, NU, BS>, 4 * gqp::PcondzLds<NX, NU, BS>::SZ * sizeof(double)}
+#define GQP_PCONDZ(NX, NU, BS) {NX, NU, BS, gqp::kz_pcond<NX, NU, BS>, 4 * gqp::PcondzLds<NX, NU, BS>::SZ * sizeof(double), gqp::km_pcond<NX, NU, BS>}
 const PcondzSet g_pcondz_sets[] = {GQP_PCONDZ(8, 3, 5), GQP_PCONDZ(4, 1, 4)};
 
 } // namespace
@@ -170,6 +172,7 @@ struct ocp_qp_gpu_batch
     int pc_rt = 0;                  /* ... the run-time-shaped wave-per-instance ones (kw_pcond / kw_pexpand) */
     int pc_lane_expand = 0;         /* the expansion runs on the compiled one-instance-per-lane kernel although condensing does not */
     const PcondzSet *pcz = nullptr; /* condensing on register rows, sixteen lanes per block (box-only class, compiled shapes) */
+    int pcz_mfma = 1;               /* ... on the FP64 matrix pipe (km_pcond); ACADOS_AMD_PCOND_MFMA=0: on register rows with DPP broadcasts (kz_pcond) */
     size_t pc_shmem = 0;
     std::vector<int> blk_start;
     gqp::PcondMap pmap;
@@ -1171,6 +1174,8 @@ static void pcond_setup(ocp_qp_gpu_batch *b)
         if (box_class && !(e3 && atoi(e3) == 0))
             for (const PcondzSet &z : g_pcondz_sets)
                 if (z.NX == b->ks->NX && z.NU == b->ks->NU && z.BS == bsmax) b->pcz = &z;
+        const char *e4 = getenv("ACADOS_AMD_PCOND_MFMA");
+        b->pcz_mfma = !(e4 && atoi(e4) == 0);
     }
     if (!box_class && !b->pc_rt) { decline("the condensed stage (nx + block size * nu > 64) is beyond the condensing kernels"); return; }
     if (!b->pc && !b->pc_rt) { decline("no condensing kernel covers this shape / block size"); return; }
@@ -1287,7 +1292,11 @@ static void pcond_launch(ocp_qp_gpu_batch *b, bool expand)
     ocp_qp_gpu_batch *c = b->child;
     if (!expand && b->pcz && b->pc_rt && b->AW <= 1 && c->AW <= 1)
     {
-        GQP_LAUNCH_COOP(b->pcz->cond, dim3((b->B + 3) / 4, b->pmap.N2 + 1), dim3(64), b->pcz->shmem, b->stream, b->D, c->D, b->pmap);
+        const dim3 grid((b->B + 3) / 4, b->pmap.N2 + 1);
+        if (b->pcz_mfma)
+            GQP_LAUNCH_COOP(b->pcz->cond_m, dim3((b->B + KM_PCOND_THREADS / 16 - 1) / (KM_PCOND_THREADS / 16), b->pmap.N2 + 1), dim3(KM_PCOND_THREADS), 0,
+                            b->stream, b->D, c->D, b->pmap);
+        else GQP_LAUNCH_COOP(b->pcz->cond, grid, dim3(64), b->pcz->shmem, b->stream, b->D, c->D, b->pmap);
         return;
     }
     if ((b->pc_rt || b->AW > 1 || c->AW > 1) && !(expand && b->pc_lane_expand && b->AW <= 1 && c->AW <= 1))
@@ -2036,7 +2045,7 @@ double ocp_qp_gpu_batch_get_scalar(ocp_qp_gpu_batch *b, const char *f)
     if (!strcmp(f, "tol_comp_effective")) { finalize_structure(b); return effective_opts(b->O, b).tol_comp; }
     /* which condensing / expansion kernels serve the batch: 2 sixteen lanes per block, 1 one instance per lane, 0 one wave
      * per instance (meaningful once partial condensing is active) */
-    if (!strcmp(f, "pcond_kernel")) return b->pcond_state != 1 ? -1.0 : (b->pcz && b->pc_rt && b->AW <= 1 && b->child->AW <= 1) ? 2.0 : b->pc_rt ? 0.0 : 1.0;
+    if (!strcmp(f, "pcond_kernel")) return b->pcond_state != 1 ? -1.0 : (b->pcz && b->pc_rt && b->AW <= 1 && b->child->AW <= 1) ? (b->pcz_mfma ? 3.0 : 2.0) : b->pc_rt ? 0.0 : 1.0;
     if (!strcmp(f, "pexpand_kernel")) return b->pcond_state != 1 ? -1.0 : (!b->pc_rt || b->pc_lane_expand) ? 1.0 : 0.0;
     {
         /* accumulated per-kernel-class event times (ms) and launch counts since the last reset */

@@ -100,7 +100,7 @@ static inline int atomicAdd(int *p, int v) { int o = *p; *p = o + v; return o; }
  * context switch well under 1 us -- the CPU test tier runs the wave-per-instance kernels thousands of times.) */
 struct hostsim_coop
 {
-    enum { MAXL = 64, STACK = 1 << 20 };
+    enum { MAXL = 256, STACK = 1 << 20 }; /* (256: the four independent waves of a km_pcond workgroup) */
     struct state
     {
         ucontext_t sched, ctx[MAXL];

@@ -789,16 +789,17 @@ def test_two_rows_per_lane_family_gpu(gpu_lib, monkeypatch):
 
 @pytest.mark.gpu
 def test_condensing_kernel_pairs_agree_gpu(gpu_lib, monkeypatch):
-    """C3 shape: condensing sixteen lanes per block + expansion one instance per lane (the default for a wave-tiled parent)
-    against the run-time-shaped wave-per-instance pair: same condensed solve, expanded solutions equal to rounding;
-    batch 4 k + 1 (a row group with three rows beyond the batch)"""
+    """C3 shape: condensing on the FP64 matrix pipe (v_mfma_f64_4x4x4_4b_f64, the default) + expansion one instance per lane
+    against the same contraction on register rows (DPP broadcasts) and against the run-time-shaped wave-per-instance pair:
+    same condensed solve, expanded solutions equal to rounding; batch 4 k + 1 (a group with three instances beyond the batch)"""
     from acados_amd import OcpQpGpuBatch
     from acados_amd.generators import fill_lqr_batch, lqr_dims, random_lqr_batch
     N, B = 50, 20481
     data = random_lqr_batch(N=N, batch=B, seed=2)
     sols = []
-    for z, le, want in (("1", "1", (2, 1)), ("0", "0", (0, 0))):
+    for z, mf, le, want in (("1", "1", "1", (3, 1)), ("1", "0", "1", (2, 1)), ("0", "1", "0", (0, 0))):
         monkeypatch.setenv("ACADOS_AMD_PCOND_W16", z)
+        monkeypatch.setenv("ACADOS_AMD_PCOND_MFMA", mf)
         monkeypatch.setenv("ACADOS_AMD_PCOND_LANE_EXPAND", le)
         gb = OcpQpGpuBatch(lqr_dims(N, 8, 3), B)
         fill_lqr_batch(gb, data, N)
@@ -811,10 +812,11 @@ def test_condensing_kernel_pairs_agree_gpu(gpu_lib, monkeypatch):
         sols.append(([gb.get(f, k) for f in ("x", "u", "lam") for k in range(N + 1)] + [gb.get("pi", k) for k in range(N)],
                      gb.info("iter").copy()))
         del gb
-    assert np.array_equal(sols[0][1], sols[1][1])
-    for a, b_ in zip(sols[0][0], sols[1][0]):
-        if a.size:
-            np.testing.assert_allclose(a, b_, rtol=1e-7, atol=1e-9)
+    for other in sols[1:]:
+        assert np.array_equal(sols[0][1], other[1])
+        for a, b_ in zip(sols[0][0], other[0]):
+            if a.size:
+                np.testing.assert_allclose(a, b_, rtol=1e-7, atol=1e-9)
 
 
 @pytest.mark.gpu

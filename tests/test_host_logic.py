@@ -356,9 +356,14 @@ def test_partial_condensing_hostsim(hostsim_lib, monkeypatch):
     qps = [lqr_instance_qp(data, i, 50) for i in range(2)]
     b = run(qps, 10, 10)
     assert b.kernel_name.startswith("1tpi-box<NX=8,NU=3")
-    # C3 shape, wave-tiled parent: condensing sixteen lanes per block, expansion one instance per lane
+    # C3 shape, wave-tiled parent: condensing on 4 x 4 MFMA tiles (km_pcond), expansion one instance per lane
+    assert b.scalar("pcond_kernel") == 3 and b.scalar("pexpand_kernel") == 1
+    run(qps, 10, 10, split=True)
+    monkeypatch.setenv("ACADOS_AMD_PCOND_MFMA", "0")   # the same contraction on register rows with DPP broadcasts (kz_pcond)
+    b = run(qps, 10, 10)
     assert b.scalar("pcond_kernel") == 2 and b.scalar("pexpand_kernel") == 1
     run(qps, 10, 10, split=True)
+    monkeypatch.delenv("ACADOS_AMD_PCOND_MFMA")
     monkeypatch.setenv("ACADOS_AMD_PCOND_W16", "0")    # the run-time-shaped wave-per-instance pair
     monkeypatch.setenv("ACADOS_AMD_PCOND_LANE_EXPAND", "0")
     b = run(qps, 10, 10)
@@ -375,11 +380,20 @@ def test_partial_condensing_hostsim(hostsim_lib, monkeypatch):
     # workgroup of four rows + one row with three rows beyond the batch
     data = random_lqr_batch(N=8, nx=4, nu=1, batch=5, seed=5)
     b = run([lqr_instance_qp(data, i, 8) for i in range(5)], 2, 2)
+    assert b.scalar("pcond_kernel") == 3
+    monkeypatch.setenv("ACADOS_AMD_PCOND_MFMA", "0")
+    b = run([lqr_instance_qp(data, i, 8) for i in range(5)], 2, 2)
     assert b.scalar("pcond_kernel") == 2
+    monkeypatch.delenv("ACADOS_AMD_PCOND_MFMA")
     data = random_lqr_batch(N=7, nx=4, nu=1, batch=3, seed=6)     # blocks of 4 and 3: a short block inside the compiled shape
+    b = run([lqr_instance_qp(data, i, 7) for i in range(3)], 2, 2)
+    assert b.scalar("pcond_kernel") == 3
+    run([lqr_instance_qp(data, i, 7) for i in range(3)], 2, 2, split=True)
+    monkeypatch.setenv("ACADOS_AMD_PCOND_MFMA", "0")
     b = run([lqr_instance_qp(data, i, 7) for i in range(3)], 2, 2)
     assert b.scalar("pcond_kernel") == 2
     run([lqr_instance_qp(data, i, 7) for i in range(3)], 2, 2, split=True)
+    monkeypatch.delenv("ACADOS_AMD_PCOND_MFMA")
     run([load_qp("qp_test/last_qp_nonuniform_pendulum.json")], 3, 3)   # N=7 -> 3, 2, 2 ; x0 equality rows
 
 
