@@ -22,6 +22,7 @@
 #include "ipm_kernels_wpi.hpp"
 #include "ipm_kernels_w16.hpp"
 #include "ipm_kernels_w16r.hpp"
+#include "ipm_kernels_w16t.hpp"
 #include "ipm_kernels_wpi_mfma.hpp"
 #include "res_kernels.hpp"
 #include "pcond_kernels_w16.hpp"
@@ -73,19 +74,24 @@ struct W16Set
     kern_redo_t sfact, srhs, sfaff, sfcor; /* SOFT variants: soft box rows, one slack per row */
     size_t shmem;
     kern_redo_t solve, ssolve; /* the whole solve in one launch (small batches); null: launch per sweep only */
+    kern_redo_t tfact;         /* two-rows shapes, box rows: the factor sweep on 4 x 4 MFMA tiles (ipm_kernels_w16t.hpp), the default */
+    size_t tshmem;
 };
 #define GQP_W16(NX, NU)                                                                                       \
     {NX, NU, 0, gqp::kx_factor<NX, NU>, gqp::kx_backrhs<NX, NU>, gqp::kx_fwd<NX, NU, false>, gqp::kx_fwd<NX, NU, true>, \
      gqp::kx_factor<NX, NU, true>, gqp::kx_backrhs<NX, NU, true>, gqp::kx_fwd<NX, NU, false, true>,            \
-     gqp::kx_fwd<NX, NU, true, true>, 4 * gqp::W16Lds<NX, NU>::SZ * sizeof(double), gqp::kx_solve<NX, NU>, gqp::kx_solve<NX, NU, true>}
+     gqp::kx_fwd<NX, NU, true, true>, 4 * gqp::W16Lds<NX, NU>::SZ * sizeof(double), gqp::kx_solve<NX, NU>, gqp::kx_solve<NX, NU, true>, \
+     nullptr, 0}
 /* ... and with 17 <= nu + nx <= 32 (ipm_kernels_w16r.hpp: two rows per lane; box rows without slacks) */
 #define GQP_W16R(NX, NU)                                                                                      \
     {NX, NU, 0, gqp::ky_factor<NX, NU>, gqp::ky_backrhs<NX, NU>, gqp::ky_fwd<NX, NU, false>, gqp::ky_fwd<NX, NU, true>, \
-     nullptr, nullptr, nullptr, nullptr, 4 * gqp::W16RLds<NX, NU>::SZ * sizeof(double), nullptr, nullptr}
+     nullptr, nullptr, nullptr, nullptr, 4 * gqp::W16RLds<NX, NU>::SZ * sizeof(double), nullptr, nullptr,                \
+     gqp::kt_factor<NX, NU>, 4 * gqp::W16TLds<NX, NU>::SZ * sizeof(double)}
 /* ... with general rows and slacks (one slack per row): the C4 class */
 #define GQP_W16G(NX, NU, NG)                                                                                  \
     {NX, NU, NG, nullptr, nullptr, nullptr, nullptr, gqp::ky_factor<NX, NU, NG>, gqp::ky_backrhs<NX, NU, NG>,     \
-     gqp::ky_fwd<NX, NU, false, NG>, gqp::ky_fwd<NX, NU, true, NG>, 4 * gqp::W16RLds<NX, NU, NG>::SZ * sizeof(double), nullptr, nullptr}
+     gqp::ky_fwd<NX, NU, false, NG>, gqp::ky_fwd<NX, NU, true, NG>, 4 * gqp::W16RLds<NX, NU, NG>::SZ * sizeof(double), nullptr, nullptr, \
+     nullptr, 0}
 const W16Set g_w16_sets[] = {GQP_W16(4, 1), GQP_W16(8, 3), GQP_W16(12, 3), GQP_W16(4, 4), GQP_W16(12, 4),
                              GQP_W16R(8, 15), GQP_W16R(24, 6), GQP_W16G(24, 3, 4)};
 
@@ -124,6 +130,7 @@ struct ocp_qp_gpu_batch
     KernelSet wpi_ks;      /* the wave-per-instance set of the same padded dims (fallback of w16_soft) */
     int w16_slots = 0;     /* row slots a sweep launch covers: B, or the live instances once GqpDev::perm lists them */
     size_t w16_shmem = 0;  /* dynamic LDS bytes of a 16-lanes-per-instance workgroup (4 instances) */
+    int w16_tiles = 0;     /* two-rows family: factor sweep on 4 x 4 MFMA tiles (kt_factor) */
     kern_redo_t w16_solve = nullptr; /* whole-solve kernel of the family (batches of at most solve_max instances) */
     int solve_max = 256;   /* largest batch that is solved in one launch (option "solve_max", 0 = off) */
     int n_single_launch = 0;
@@ -851,7 +858,9 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
             {
                 const W16Set &ws = *w16;
                 b->wpi_ks = b->own_ks; /* what the batch falls back to if the slack structure is not one-slack-per-box-row */
-                const kern_redo_t kf = gen ? ws.sfact : ws.fact, kr = gen ? ws.srhs : ws.rhs;
+                const char *et = getenv("ACADOS_AMD_W16T"); /* 0: the factor sweep of the two-rows family on register rows (ky_factor) */
+                const bool tiles = !gen && ws.tfact && !(et && atoi(et) == 0);
+                const kern_redo_t kf = gen ? ws.sfact : (tiles ? ws.tfact : ws.fact), kr = gen ? ws.srhs : ws.rhs;
                 const kern_redo_t ka = gen ? ws.sfaff : ws.faff, kc = gen ? ws.sfcor : ws.fcor;
                 b->own_ks.back_fact = kf; b->own_ks.back_rhs = kr; b->own_ks.fwd_aff = ka; b->own_ks.fwd_corr = kc;
                 for (int q = 0; q < 2; q++)
@@ -863,7 +872,8 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
                 b->w16_slots = n_batch;
                 b->w16_soft = gen;
                 b->w16_ng = ws.NG;
-                b->w16_shmem = ws.shmem;
+                b->w16_shmem = tiles && ws.tshmem > ws.shmem ? ws.tshmem : ws.shmem;
+                b->w16_tiles = tiles;
                 if (const char *ea = getenv("ACADOS_AMD_W16_LDS_ALIGN")) /* development: allocation rounded up / padded */
                 {
                     const size_t a = (size_t) atoi(ea);
@@ -1553,7 +1563,7 @@ static void compact_into(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch *root, int nact, 
         c->idxb = b->idxb; c->idxs_rev = b->idxs_rev; c->idxe = b->idxe; c->nbxe = b->nbxe;
         c->compact_min = b->compact_min;
         c->tail_max = b->tail_max;
-        if (!tail) { c->aos = b->aos; c->wpi = b->wpi; c->shmem = b->shmem; c->shmem_fwd = b->shmem_fwd; c->shmem_fact = b->shmem_fact; c->w16 = b->w16; c->w16_soft = b->w16_soft; c->w16_ng = b->w16_ng; c->w16_shmem = b->w16_shmem; }
+        if (!tail) { c->aos = b->aos; c->wpi = b->wpi; c->shmem = b->shmem; c->shmem_fwd = b->shmem_fwd; c->shmem_fact = b->shmem_fact; c->w16 = b->w16; c->w16_soft = b->w16_soft; c->w16_ng = b->w16_ng; c->w16_shmem = b->w16_shmem; c->w16_tiles = b->w16_tiles; }
         finalize_structure(c);
         slot = c;
     }
@@ -2038,6 +2048,7 @@ double ocp_qp_gpu_batch_get_scalar(ocp_qp_gpu_batch *b, const char *f)
     if (!strcmp(f, "launches")) return (double) b->launches;
     if (!strcmp(f, "time_xcond")) return b->time_xcond;
     if (!strcmp(f, "compactions")) return (double) b->n_compactions;
+    if (!strcmp(f, "w16_tiles")) return (double) b->w16_tiles;
     if (!strcmp(f, "tail_switches")) return (double) b->n_tail_switches;
     if (!strcmp(f, "single_launch_solves")) return (double) b->n_single_launch;
     if (!strcmp(f, "cond_N_active")) return b->pcond_state == 1 ? (double) b->cond_N : (double) b->N;

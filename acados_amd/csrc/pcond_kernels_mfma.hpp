@@ -41,45 +41,10 @@
 #define PCOND_KERNELS_MFMA_HPP_
 
 #include "pcond_kernels_w16.hpp"
+#include "mfma4.hpp"
 
 namespace gqp
 {
-
-#if defined(__HIP_DEVICE_COMPILE__)
-__device__ static inline double gqp_mfma4(double p, double q, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(p, q, c, 0, 0, 0); }
-/* bit (x + 4 y) of the result = predicate of lane (x, y) of this lane's MFMA block */
-__device__ static inline unsigned mfma4_blockbits(bool pr)
-{
-    const unsigned long long bal = __ballot(pr) >> (threadIdx.x & 12); /* (bits 2-3 of the lane index: the block) */
-    return (unsigned) ((bal & 0xF) | ((bal >> 12) & 0xF0) | ((bal >> 24) & 0xF00) | ((bal >> 36) & 0xF000));
-}
-#else
-/* host pass of hipcc (never executed) and the host simulation of the CPU test tier: the 64 lanes of a workgroup are
- * coroutines of one host thread, operands are exchanged through storage they share */
-__device__ static inline double gqp_mfma4(double p, double q, double c)
-{
-    __shared__ double m4_a[256], m4_b[256];
-    const int w0 = threadIdx.x & ~63, l = threadIdx.x & 63, blk = (l >> 2) & 3, j = l & 3, i = l >> 4;
-    m4_a[w0 + l] = p; m4_b[w0 + l] = q;
-    __syncthreads();
-    double s = c;
-    for (int k = 0; k < 4; k++) s += m4_a[w0 + i + 4 * blk + 16 * k] * m4_b[w0 + j + 4 * blk + 16 * k];
-    __syncthreads();
-    return s;
-}
-__device__ static inline unsigned mfma4_blockbits(bool pr)
-{
-    __shared__ int m4_f[256];
-    const int w0 = threadIdx.x & ~63, l = threadIdx.x & 63, blk = (l >> 2) & 3;
-    m4_f[w0 + l] = pr ? 1 : 0;
-    __syncthreads();
-    unsigned m = 0;
-    for (int y = 0; y < 4; y++)
-        for (int x = 0; x < 4; x++) m |= m4_f[w0 + x + 4 * blk + 16 * y] ? 1u << (x + 4 * y) : 0u;
-    __syncthreads();
-    return m;
-}
-#endif
 
 #ifndef KM_PCOND_THREADS
 #define KM_PCOND_THREADS 256 /* four waves = the sixteen instances of one 128-byte line of a wave-tiled parent */

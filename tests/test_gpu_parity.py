@@ -746,18 +746,20 @@ def test_concurrent_solvers_from_host_threads_gpu(gpu_lib):
 
 @pytest.mark.gpu
 def test_two_rows_per_lane_family_gpu(gpu_lib, monkeypatch):
-    """ipm_kernels_w16r.hpp on the device (LDS-DMA staging, register rows, dense list of the live instances): the
-    nx=24 nu=6 class and the condensed C3 shape against the oracle, and against the wave-per-instance kernels on the
-    same batch -- equal iteration counts, iterates equal to rounding; the dense-list launches (ACADOS_AMD_W16_PERM)
-    change nothing in the results.  Ragged batch: 4 k + 3 instances."""
+    """ipm_kernels_w16r.hpp / ipm_kernels_w16t.hpp on the device (LDS-DMA staging, factor sweep on 4 x 4 MFMA tiles, dense
+    list of the live instances): the nx=24 nu=6 class and the condensed C3 shape against the oracle, against the factor
+    sweep on register rows (ACADOS_AMD_W16T=0) and against the wave-per-instance kernels on the same batch -- equal
+    iteration counts, iterates equal to rounding; the dense-list launches (ACADOS_AMD_W16_PERM) change nothing in the
+    results.  Ragged batch: 4 k + 3 instances."""
     from acados_amd import OcpQpGpuBatch
     from acados_amd.generators import fill_lqr_batch, lqr_dims, lqr_instance_qp, random_lqr_batch
     for nx, nu, N, B in ((24, 6, 12, 1027), (8, 15, 6, 515), (20, 5, 8, 259), (12, 3, 10, 2051)):   # (12,3): the one-row family
         data = random_lqr_batch(N=N, nx=nx, nu=nu, batch=B, seed=11 + nx)
         sols = {}
-        for tag, env in (("w16r", {"ACADOS_AMD_W16R": "1", "ACADOS_AMD_W16_PERM": "1"}),
-                         ("noperm", {"ACADOS_AMD_W16R": "1", "ACADOS_AMD_W16_PERM": "0"}),
-                         ("wpi", {"ACADOS_AMD_W16R": "0", "ACADOS_AMD_W16_PERM": "1"})):
+        for tag, env in (("w16r", {"ACADOS_AMD_W16R": "1", "ACADOS_AMD_W16_PERM": "1", "ACADOS_AMD_W16T": "1"}),
+                         ("noperm", {"ACADOS_AMD_W16R": "1", "ACADOS_AMD_W16_PERM": "0", "ACADOS_AMD_W16T": "1"}),
+                         ("rows", {"ACADOS_AMD_W16R": "1", "ACADOS_AMD_W16_PERM": "1", "ACADOS_AMD_W16T": "0"}),
+                         ("wpi", {"ACADOS_AMD_W16R": "0", "ACADOS_AMD_W16_PERM": "1", "ACADOS_AMD_W16T": "1"})):
             for k_, v_ in env.items():
                 monkeypatch.setenv(k_, v_)
             gb = OcpQpGpuBatch(lqr_dims(N, nx, nu), B)
@@ -770,6 +772,8 @@ def test_two_rows_per_lane_family_gpu(gpu_lib, monkeypatch):
             else:   # ACADOS_AMD_W16R does not concern this shape: "wpi" is a second dense-list run
                 assert gb.kernel_name.startswith("w16-box<"), gb.kernel_name
             assert gb.res_compute().max() <= KKT_TOL
+            if nx + nu > 16 and tag != "wpi":
+                assert int(gb.scalar("w16_tiles")) == (0 if tag == "rows" else 1)
             sols[tag] = ([gb.get(f, k) for f in ("x", "u", "lam") for k in range(N + 1)] + [gb.get("pi", k) for k in range(N)],
                          gb.info("iter").copy())
             if tag == "w16r":
@@ -780,11 +784,13 @@ def test_two_rows_per_lane_family_gpu(gpu_lib, monkeypatch):
                     compare_with_oracle(lambda k, f: gb.get(f, k)[i], o, qp, 1e-8)
             del gb
         assert np.array_equal(sols["w16r"][1], sols["wpi"][1]) and np.array_equal(sols["w16r"][1], sols["noperm"][1])
+        assert np.array_equal(sols["w16r"][1], sols["rows"][1])
         for a, b_ in zip(sols["w16r"][0], sols["noperm"][0]):
             assert np.array_equal(a, b_)
-        for a, b_ in zip(sols["w16r"][0], sols["wpi"][0]):
-            if a.size:
-                np.testing.assert_allclose(a, b_, rtol=1e-9, atol=1e-9)
+        for other in ("wpi", "rows"):
+            for a, b_ in zip(sols["w16r"][0], sols[other][0]):
+                if a.size:
+                    np.testing.assert_allclose(a, b_, rtol=1e-9, atol=1e-9)
 
 
 @pytest.mark.gpu

@@ -1048,7 +1048,8 @@ def test_sixteen_lanes_covering_shapes_hostsim(hostsim_lib, monkeypatch):
 
 
 def test_sixteen_lanes_two_rows_per_lane_hostsim(hostsim_lib, monkeypatch):
-    """17 <= nu+nx <= 32, box rows only: sixteen lanes per instance with TWO rows per lane (ipm_kernels_w16r.hpp).
+    """17 <= nu+nx <= 32, box rows only: sixteen lanes per instance with TWO rows per lane (ipm_kernels_w16r.hpp), the
+    factor sweep on 4 x 4 MFMA tiles (ipm_kernels_w16t.hpp, the default) or on register rows (ACADOS_AMD_W16T=0).
     The compiled shapes <24,6> and <8,15>, shapes padded inside them, state bounds on every stage, fixed initial
     state, a ragged batch (one full workgroup of four instances + one), and agreement with the wave-per-instance
     kernels on the same batch (ACADOS_AMD_W16R=0) to rounding"""
@@ -1059,6 +1060,12 @@ def test_sixteen_lanes_two_rows_per_lane_hostsim(hostsim_lib, monkeypatch):
         data = random_lqr_batch(N=4, nx=nx, nu=nu, batch=5, seed=40 + nx)
         b = _check_batch_vs_oracle([lqr_instance_qp(data, i, 4) for i in range(5)], hostsim_lib)
         assert b.kernel_name.startswith(want), b.kernel_name
+        if want.startswith("w16r"):
+            assert b.scalar("w16_tiles") == 1
+            monkeypatch.setenv("ACADOS_AMD_W16T", "0")
+            b = _check_batch_vs_oracle([lqr_instance_qp(data, i, 4) for i in range(5)], hostsim_lib)
+            assert b.kernel_name.startswith(want) and b.scalar("w16_tiles") == 0
+            monkeypatch.delenv("ACADOS_AMD_W16T")
     # the same batch on both families: iterates agree to rounding, iteration counts are equal
     data = random_lqr_batch(N=6, nx=24, nu=6, batch=3, seed=3)
     qps = [lqr_instance_qp(data, i, 6) for i in range(3)]

@@ -25,7 +25,7 @@ def test_product_library_passes_the_lint():
     bad, report = isa_lint.lint(os.path.join(ROOT, "acados_amd", "csrc", "libacados_amd_qp.so"))
     assert not bad, bad
     # the two-rows family is what uses LDS-DMA: factor + the two forward sweeps of every compiled shape
-    assert len(report) >= 9 and all("ky_" in r for r in report), report
+    assert len(report) >= 11 and all("ky_" in r or "kt_" in r for r in report), report   # (kt_: the factor sweep on MFMA tiles)
     assert all("scratch 0 B" in r for r in report), report
     strict_bad, _ = isa_lint.lint(os.path.join(ROOT, "acados_amd", "csrc", "libacados_amd_qp.so"), strict=True)
     assert strict_bad and all(b.startswith("rule 1") for b in strict_bad)      # the listing exists: see profiles/r04_vmcnt_probe.txt for why it is not a fault

@@ -9,7 +9,7 @@
           compiler does not know about only makes its partial wait MORE conservative (the load it waits for has its n known
           successors AND the DMA requests behind it; vmcnt(n) releases everything but the last n issued).  With --strict the
           listing becomes rule 1 (what the round-3 review asked for literally) and fails;
-  rule 2  no kernel of the two-rows / condensing families (ky_*, kz_*) uses scratch (private segment) or has spilled registers:
+  rule 2  no kernel of the two-rows / condensing families (ky_*, kt_*, kz_*, km_*) uses scratch (private segment) or has spilled registers:
           spill traffic is HBM traffic there (DESIGN.md 4.4);
   (no occupancy rule: the attribute amdgpu_waves_per_eu(1,1) on these kernels is a register budget for the compiler, not a
    hardware limit -- what keeps them at four waves per CU is their 40 KB of LDS per workgroup, and waves of OTHER kernels
@@ -100,7 +100,7 @@ def lint(lib, strict=False):
         names = demangle(list(ks))
         for sym, ins in ks.items():
             dn = names.get(sym, sym)
-            fam = re.search(r"\bgqp::(k[yz]_\w+)", dn)
+            fam = re.search(r"\bgqp::(k[yztm]_\w+)", dn)
             dma = [i for i, t in enumerate(ins) if t.startswith("global_load_lds")]
             partial = [(i, t) for i, t in enumerate(ins) if t.startswith("s_waitcnt") and re.search(r"vmcnt\((\d+)\)", t)
                        and int(re.search(r"vmcnt\((\d+)\)", t).group(1)) > 0]
