@@ -219,12 +219,16 @@ __global__ void __launch_bounds__(64) W16R_WPE_FACT kt_factor(GqpDev D, GqpOpts 
         GQP_ROWSYNC(); /* exchange 2 (H v, [B A]' pi+ back to the compact form) fills the same slots tile row by tile row */
 
         W16R_TICK(1);
-        /* ---- tiles of H from the packed block: MT(J,I), J <= I, and H v by tile row (operand by x, partial sums per lane) ---- */
-        double MT[NT][NT], MTr[NT];
+        /* ---- tiles of H from the packed block: MT(J,I), J <= I, and H v by tile row (operand by x, partial sums per lane) ----
+         * ROOMY (the C3 shape: 60 tiles, 380 registers): all LDS reads of the three products below may be in flight at once and
+         * the quad sums are taken together at the end; at nx = 24 the register file is full -- one tile row in flight at a
+         * time (fences), its quad sum and its store right behind it.  Two accumulator chains per tile row either way. */
+        constexpr bool BA_REG = NXT * (NT + 1) <= 24, ROOMY = BA_REG;
+        double MT[NT][NT], MTr[NT], hacc[ROOMY ? NT : 1], bacc[ROOMY ? NT : 1], racc[ROOMY ? NXT : 1];
         W16_UNROLL for (int J = 0; J < NT; J++)
         {
-            W16R_FENCE(); /* one tile row of LDS reads in flight at a time: hoisted together they are the register peak of the stage */
-            double acc = 0.0;
+            if (!ROOMY) W16R_FENCE();
+            double acc0 = 0.0, acc1 = 0.0;
             W16_UNROLL for (int I = 0; I < NT; I++)
             {
                 const int r = 4 * J + y - PAD, c = 4 * I + x - PAD; /* natural indices; negative: padding (unit diagonal) */
@@ -233,10 +237,14 @@ __global__ void __launch_bounds__(64) W16R_WPE_FACT kt_factor(GqpDev D, GqpOpts 
                 double h = HRq[e];
                 if (PAD > 0 && (J == 0 || I == 0)) h = (r < 0 || c < 0) ? (r == c ? 1.0 : 0.0) : h;
                 if (J <= I) MT[J][I] = h;
-                acc += h * vx[I];
+                if (I & 1) acc1 += h * vx[I]; else acc0 += h * vx[I];
             }
-            acc = mfma4_qsum(acc);
-            if (x == 0) VXA[4 * J + y] = acc;
+            if (ROOMY) hacc[J] = acc0 + acc1;
+            else
+            {
+                const double t = mfma4_qsum(acc0 + acc1);
+                if (x == 0) VXA[4 * J + y] = t;
+            }
         }
         if (k > 0) dma_h(k - 1);
         W16R_TICK(2);
@@ -244,7 +252,6 @@ __global__ void __launch_bounds__(64) W16R_WPE_FACT kt_factor(GqpDev D, GqpOpts 
         /* (kept in registers for the W product where they are few -- the condensed C3 shape: 14 tiles; at nx = 24 they are 54
          * and the register file is full: there the W product reads them again from LDS, row of tiles by row of tiles, and
          * the DMA of the next stage's block waits until it is done) */
-        constexpr bool BA_REG = NXT * (NT + 1) <= 24;
         auto ba_tile = [&](int Q, int I) -> double
         {
             const int c = 4 * I + x - PAD;
@@ -255,31 +262,43 @@ __global__ void __launch_bounds__(64) W16R_WPE_FACT kt_factor(GqpDev D, GqpOpts 
         double BA[BA_REG ? NXT : 1][NT + 1];
         W16_UNROLL for (int Q = 0; Q < NXT; Q++)
         {
-            W16R_FENCE();
-            double acc = 0.0;
+            if (!ROOMY) W16R_FENCE();
+            double acc0 = 0.0, acc1 = 0.0;
             W16_UNROLL for (int I = 0; I < NT; I++)
             {
                 const double bv = ba_tile(Q, I);
                 if (BA_REG) BA[Q][I] = bv;
-                acc += bv * vx[I];
+                if (I & 1) acc1 += bv * vx[I]; else acc0 += bv * vx[I];
             }
-            rby[Q] += mfma4_qsum(acc); /* b - x+ + [B A] v, the same in the four lanes of a quad */
+            if (ROOMY) racc[Q] = acc0 + acc1;
+            else rby[Q] += mfma4_qsum(acc0 + acc1); /* b - x+ + [B A] v, the same in the four lanes of a quad */
         }
         W16R_TICK(3);
         /* [B A]' pi+ by variable tile row: tiles of [B A]' as they lie, operand by x */
         W16_UNROLL for (int I = 0; I < NT; I++)
         {
-            W16R_FENCE();
+            if (!ROOMY) W16R_FENCE();
             const int r = 4 * I + y - PAD;
-            double acc = 0.0;
+            double acc0 = 0.0, acc1 = 0.0;
             W16_UNROLL for (int Q = 0; Q < NXT; Q++)
             {
                 double bv = BRq[(r > 0 ? r : 0) * NX + 4 * Q + x];
                 if (PAD > 0 && I == 0) bv = r < 0 ? 0.0 : bv;
-                acc += bv * pix[Q];
+                if (Q & 1) acc1 += bv * pix[Q]; else acc0 += bv * pix[Q];
             }
-            acc = mfma4_qsum(acc);
-            if (x == 0) VXB[4 * I + y] = acc;
+            if (ROOMY) bacc[I] = acc0 + acc1;
+            else
+            {
+                const double t = mfma4_qsum(acc0 + acc1);
+                if (x == 0) VXB[4 * I + y] = t;
+            }
+        }
+        if (ROOMY)
+        {
+            W16_UNROLL for (int J = 0; J < NT; J++) { hacc[J] = mfma4_qsum(hacc[J]); bacc[J] = mfma4_qsum(bacc[J]); }
+            W16_UNROLL for (int Q = 0; Q < NXT; Q++) rby[Q] += mfma4_qsum(racc[Q]);
+            if (x == 0)
+                W16_UNROLL for (int J = 0; J < NT; J++) { VXA[4 * J + y] = hacc[J]; VXB[4 * J + y] = bacc[J]; }
         }
         W16R_TICK(4);
         /* next stage: its [B A]' block by DMA; vectors, box rows and the descriptor after it into registers.  Where the register
@@ -398,34 +417,50 @@ __global__ void __launch_bounds__(64) W16R_WPE_FACT kt_factor(GqpDev D, GqpOpts 
         }
 
         W16R_TICK(9);
-        /* ---- blocked Cholesky M = U'U on the upper tiles, the rhs column riding along ---- */
-        W16_UNROLL for (int J = 0; J < NT; J++)
+        /* ---- blocked Cholesky M = U'U on the upper tiles, the rhs column riding along.  One wave per SIMD: nothing hides the
+         * dependent chain of a diagonal block (four rsqrt refinements, ten quad broadcasts: ~1,000 cycles) but this wave's own
+         * independent work -- so the loop is skewed by hand: step J issues the ONE panel product and the ONE trailing product
+         * the next diagonal block needs, broadcasts its rows, and only then the rest of its panel / trailing products, the
+         * stores of its finished row of U and the transposes for the next stage, all of which the chain of block J + 1 does
+         * not depend on and the scheduler may run beside it. ---- */
+        auto rows4 = [&](double dg, double &r0, double &r1, double &r2, double &r3)
         {
             /* rows of the diagonal block to every 16-lane row: r_j = row j of the block, indexed by x */
-            const double dg = MT[J][J];
-            const double r0 = gqp_mfma4(e4[0], dg, 0.0), r1 = gqp_mfma4(e4[1], dg, 0.0), r2 = gqp_mfma4(e4[2], dg, 0.0), r3 = gqp_mfma4(e4[3], dg, 0.0);
-            /* 4 x 4 Cholesky, every lane for its x: lxj = L[x][j]; a non-positive pivot zeroes its column (as ky_factor) */
+            r0 = gqp_mfma4(e4[0], dg, 0.0); r1 = gqp_mfma4(e4[1], dg, 0.0); r2 = gqp_mfma4(e4[2], dg, 0.0); r3 = gqp_mfma4(e4[3], dg, 0.0);
+        };
+        auto diag4 = [&](double r0, double r1, double r2, double r3, double &ut, double &G)
+        {
+            /* 4 x 4 Cholesky, every lane for its x: lxj = L[x][j]; a non-positive pivot zeroes its column (as ky_factor; the
+             * NaN rsqrt returns for it is dropped by the select) */
             const double d0 = mfma4_qbc<0>(r0);
-            const double i0 = d0 > 0.0 ? frsqrt(d0 > 0.0 ? d0 : 1.0) : 0.0;
+            double t0 = frsqrt(d0);
+            W16R_OPAQUE(t0); /* (pinned: the select below must stay a select -- as a branch around the refinement it cuts the chain into basic blocks the products cannot be scheduled into) */
+            const double i0 = d0 > 0.0 ? t0 : 0.0;
             const double lx0 = r0 * i0;
             const double l10 = mfma4_qbc<1>(lx0), l20 = mfma4_qbc<2>(lx0), l30 = mfma4_qbc<3>(lx0);
             const double s1 = r1 - l10 * lx0;
             const double d1 = mfma4_qbc<1>(s1);
-            const double i1 = d1 > 0.0 ? frsqrt(d1 > 0.0 ? d1 : 1.0) : 0.0;
+            double t1 = frsqrt(d1);
+            W16R_OPAQUE(t1);
+            const double i1 = d1 > 0.0 ? t1 : 0.0;
             const double lx1 = s1 * i1;
             const double l21 = mfma4_qbc<2>(lx1), l31 = mfma4_qbc<3>(lx1);
-            const double s2 = r2 - l20 * lx0 - l21 * lx1;
+            const double s2 = (r2 - l20 * lx0) - l21 * lx1;
             const double d2 = mfma4_qbc<2>(s2);
-            const double i2 = d2 > 0.0 ? frsqrt(d2 > 0.0 ? d2 : 1.0) : 0.0;
+            double t2 = frsqrt(d2);
+            W16R_OPAQUE(t2);
+            const double i2 = d2 > 0.0 ? t2 : 0.0;
             const double lx2 = s2 * i2;
             const double l32 = mfma4_qbc<3>(lx2);
-            const double s3 = r3 - l30 * lx0 - l31 * lx1 - l32 * lx2;
+            const double s3 = ((r3 - l30 * lx0) - l31 * lx1) - l32 * lx2;
             const double d3 = mfma4_qbc<3>(s3);
-            const double i3 = d3 > 0.0 ? frsqrt(d3 > 0.0 ? d3 : 1.0) : 0.0;
+            double t3 = frsqrt(d3);
+            W16R_OPAQUE(t3);
+            const double i3 = d3 > 0.0 ? t3 : 0.0;
             const double lx3 = s3 * i3;
             /* U_JJ = L_JJ': [y][x] = L[x][y], x >= y */
             const double uj = y == 0 ? lx0 : (y == 1 ? lx1 : (y == 2 ? lx2 : lx3));
-            MT[J][J] = x >= y ? uj : 0.0;
+            ut = x >= y ? uj : 0.0;
             /* G = L_JJ^-T: [y][x] = Linv[x][y], x >= y (every lane holds all of L_JJ; a zeroed column has a zero row / column here) */
             const double n10 = -l10 * i0 * i1, n21 = -l21 * i1 * i2, n32 = -l32 * i2 * i3;
             const double n20 = -(l20 * i0 + l21 * n10) * i2, n31 = -(l31 * i1 + l32 * n21) * i3;
@@ -434,38 +469,56 @@ __global__ void __launch_bounds__(64) W16R_WPE_FACT kt_factor(GqpDev D, GqpOpts 
             const double gc1 = x == 1 ? i1 : (x == 2 ? n21 : n31);
             const double gc2 = x == 2 ? i2 : n32;
             const double gsel = y == 0 ? gc0 : (y == 1 ? gc1 : (y == 2 ? gc2 : i3));
-            const double G = x >= y ? gsel : 0.0;
-            /* panel: U(J,I) = L_JJ^-1 MT(J,I) */
-            W16_UNROLL for (int I = J + 1; I < NT; I++) MT[J][I] = gqp_mfma4(G, MT[J][I], 0.0);
-            MTr[J] = gqp_mfma4(G, MTr[J], 0.0);
-            /* trailing blocks: MT(K,I) -= U(J,K)' U(J,I), the next diagonal block first */
-            W16_UNROLL for (int K = J + 1; K < NT; K++)
-            {
-                const double nu_ = -MT[J][K];
-                W16_UNROLL for (int I = K; I < NT; I++) MT[K][I] = gqp_mfma4(nu_, MT[J][I], MT[K][I]);
-                MTr[K] = gqp_mfma4(nu_, MTr[J], MTr[K]);
-            }
+            G = x >= y ? gsel : 0.0;
+        };
+        double G, ut;
+        {
+            double r0, r1, r2, r3;
+            rows4(MT[0][0], r0, r1, r2, r3);
+            diag4(r0, r1, r2, r3, ut, G);
         }
-
-        W16R_TICK(10);
-        /* ---- outputs: U(J,I)[y][x] = L[4I + x - PAD][4J + y - PAD] into the packed factor; l by y ---- */
         W16_UNROLL for (int J = 0; J < NT; J++)
         {
-            const int c = 4 * J + y - PAD;
-            W16_UNROLL for (int I = J; I < NT; I++)
+            MT[J][J] = ut;
+            double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0, nu1 = 0.0;
+            if (J + 1 < NT)
             {
-                const int r = 4 * I + x - PAD;
-                if (alive && c >= 0 && r >= c) WAT(D.Lf, k * NP + PK(r, c)) = MT[J][I];
+                /* what the next diagonal block waits for: U(J,J+1) = L_JJ^-1 MT(J,J+1), MT(J+1,J+1) -= U(J,J+1)' U(J,J+1) */
+                MT[J][J + 1] = gqp_mfma4(G, MT[J][J + 1], 0.0);
+                nu1 = -MT[J][J + 1];
+                MT[J + 1][J + 1] = gqp_mfma4(nu1, MT[J][J + 1], MT[J + 1][J + 1]);
+                rows4(MT[J + 1][J + 1], r0, r1, r2, r3);
             }
-            if (alive && x == 0 && c >= 0) WAT(D.lf, k * n + c) = MTr[J];
+            /* the rest of the panel: U(J,I) = L_JJ^-1 MT(J,I) */
+            W16_UNROLL for (int I = J + 2; I < NT; I++) MT[J][I] = gqp_mfma4(G, MT[J][I], 0.0);
+            MTr[J] = gqp_mfma4(G, MTr[J], 0.0);
+            /* the rest of the trailing blocks: MT(K,I) -= U(J,K)' U(J,I) */
+            W16_UNROLL for (int K = J + 1; K < NT; K++)
+            {
+                const double nu_ = K == J + 1 ? nu1 : -MT[J][K];
+                W16_UNROLL for (int I = (K == J + 1 ? K + 1 : K); I < NT; I++) MT[K][I] = gqp_mfma4(nu_, MT[J][I], MT[K][I]);
+                MTr[K] = gqp_mfma4(nu_, MTr[J], MTr[K]);
+            }
+            /* state block for the next (earlier) stage: natural tiles Lx(Q,C) = U(C,Q)' (one product with the identity), lx by y */
+            if (J >= XT0)
+            {
+                W16_UNROLL for (int Q = J - XT0; Q < NXT; Q++) Lx[Q][J - XT0] = gqp_mfma4(MT[J][XT0 + Q], i4, 0.0);
+                lxy[J - XT0] = MTr[J];
+            }
+            if (J + 1 < NT) diag4(r0, r1, r2, r3, ut, G);
+            /* (behind the chain: the predicated stores are basic blocks of their own, the products above and the chain are one)
+             * outputs of the finished row: U(J,I)[y][x] = L[4I + x - PAD][4J + y - PAD] into the packed factor; l by y */
+            {
+                const int c = 4 * J + y - PAD;
+                W16_UNROLL for (int I = J; I < NT; I++)
+                {
+                    const int r = 4 * I + x - PAD;
+                    if (alive && c >= 0 && r >= c) WAT(D.Lf, k * NP + PK(r, c)) = MT[J][I];
+                }
+                if (alive && x == 0 && c >= 0) WAT(D.lf, k * n + c) = MTr[J];
+            }
         }
-        W16R_TICK(11);
-        /* state block for the next (earlier) stage: natural tiles Lx(Q,C) = U(C,Q)' (one product with the identity), lx by y */
-        W16_UNROLL for (int Q = 0; Q < NXT; Q++)
-        {
-            W16_UNROLL for (int C = 0; C <= Q; C++) Lx[Q][C] = gqp_mfma4(MT[XT0 + C][XT0 + Q], i4, 0.0);
-            lxy[Q] = MTr[XT0 + Q];
-        }
+        W16R_TICK(10);
         W16R_TICK(12);
     }
 

@@ -271,6 +271,11 @@ class OcpQpGpuBatch:
         h = self._L.ocp_qp_gpu_batch_condensed(self._h)
         return self._L.ocp_qp_gpu_batch_kernel_name(C.c_void_p(h)).decode() if h else None
 
+    def condensed_scalar(self, field):
+        """`scalar(field)` of the condensed batch of the last partially condensed solve (None: not condensed)"""
+        h = self._L.ocp_qp_gpu_batch_condensed(self._h)
+        return self._L.ocp_qp_gpu_batch_get_scalar(C.c_void_p(h), field.encode()) if h else None
+
     def close(self):
         if getattr(self, "_h", None):
             if getattr(self, "_owner", None) is None:   # a condensed view belongs to its parent

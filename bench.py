@@ -220,13 +220,50 @@ def mark_stale(tr):
     return tr
 
 
-MFMA_NOTE = {"used": False, "probe": "profiles/r02_mfma_f64_probe.txt",
-             "v_mfma_f64_16x16x4_TFLOPs_measured": 47.6, "v_fma_f64_TFLOPs_measured": 69.3,
-             "why": "the FP64 matrix pipe of gfx950 peaks BELOW its vector pipe (47.6 vs 69.3 TFLOP/s measured) and the widest block of the "
-                    "path (nx = 8: 8 x 23 per condensing product; nx = 24: 24 x 27) fills 8/16 resp. 9/16 of the entries of the 16x16x4 tiles "
-                    "it would need -- the register-row / DPP form is the faster one at every block size this path has; an MFMA factor kernel "
-                    "exists (kw_factor_m) and is the default only for the wave-per-instance general-row class (+3 %)",
-             "mfma_utilisation": 0.0}
+def mfma_util():
+    """newest profiles/rNN_vM_mfma_util.json (tools/profile_mfma.sh: rocprofv3 PMC SQ_INSTS_MFMA / SQ_VALU_MFMA_BUSY_CYCLES /
+    GRBM_GUI_ACTIVE over one C3 solve): matrix-pipe utilisation of the kernels that issue MFMAs"""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mfma_util.json")))
+    if not files:
+        return None
+    try:
+        j = json.load(open(files[-1]))
+    except Exception:
+        return None
+    return {"file": os.path.relpath(files[-1], ROOT), "commit": j.get("_commit"),
+            "kernels": {k: {f: v.get(f) for f in ("mfma_utilisation", "mfma_TFLOPs", "frac_of_measured_mfma_peak_73.2", "avg_us", "mfma_instructions_per_launch")}
+                        for k, v in j.get("kernels", {}).items()}}
+
+
+MFMA_PROBES = {"v_mfma_f64_4x4x4_4b_TFLOPs_measured": 73.2, "v_mfma_f64_16x16x4_TFLOPs_measured": 47.6, "v_fma_f64_TFLOPs_measured": 69.3,
+               "dpp_broadcast_plus_2_fma_cycles": 14.3, "mfma_4x4x4_4b_cycles": 17.2,
+               "probes": ["profiles/r04_mfma4x4x4_probe.txt", "profiles/r04_mfma4x4x4_layout.txt", "profiles/r02_mfma_f64_probe.txt"]}
+# C2 (the headline): one instance per lane, every sweep HBM-bound at 5-6 TB/s of real traffic -- no matrix product to offload
+MFMA_NOTE_C2 = dict(MFMA_PROBES, used=False, mfma_utilisation=0.0,
+                    why="the C2 sweeps run one instance per lane and are bound by HBM traffic (roofline.bound = hbm); the 11 x 11 stage "
+                        "blocks live in the lanes' registers.  Where the path has matrix products between lanes -- the partial condensing "
+                        "contraction and the Riccati factor sweep of the condensed / nx = 24 QPs (configs.C3, configs.C5_share) -- they run on "
+                        "v_mfma_f64_4x4x4_4b_f64, the one FP64 MFMA shape whose tiles nx = 8 fills and the one that beats the vector pipe "
+                        "on gfx950 (73.2 vs 69.3 TFLOP/s measured; the 16x16x4 shape: 47.6)")
+
+
+def mfma_note_c3(batch):
+    u = mfma_util()
+    pk, tiles = int(batch.scalar("pcond_kernel")), None
+    try:
+        tiles = int(batch.condensed_scalar("w16_tiles"))
+    except Exception:
+        pass
+    return dict(MFMA_PROBES, used=(pk == 3 or bool(tiles)),
+                kernels={"km_pcond (partial condensing, Z'HZ / [B A]Z on 4 x 4 tiles, pcond_kernels_mfma.hpp)": pk == 3,
+                         "kt_factor (Riccati factor sweep of the condensed QP: W = [B A]'Lx+, M += WW', blocked Cholesky, ipm_kernels_w16t.hpp)": tiles},
+                tile_fill="nx = 8: 2 x 2 tiles, nc = 23 + 1 vector column = 6 tiles: 1.0 (zero tiles of the block's later inputs skipped at compile time)",
+                utilisation=u,
+                mfma_utilisation=(max((k.get("mfma_utilisation") or 0.0) for k in u["kernels"].values()) if u and u["kernels"] else None),
+                note="utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x active cycles) from the committed PMC summary named in utilisation.file "
+                     "(counter passes cannot run inside this process); both kernels are bound by memory latency / dependent chains at one or two "
+                     "waves per SIMD, not by the matrix pipe (DESIGN.md 4.5, 4.6)")
 
 
 def cpu_caps():
@@ -378,10 +415,10 @@ def other_configs(c2_batch, c2_data, args):
                            lambda i: lqr_instance_qp(c2_data, i, N), N, lqr_dims(N, 8, 3), steps=2, check=args.check_configs,
                            section=1, sweep_kernel_name=lambda: c2_batch.condensed_kernel_name() or c2_batch.kernel_name)
     out["C3"]["cond_N_active"] = int(c2_batch.scalar("cond_N_active"))
-    out["C3"]["mfma"] = dict(MFMA_NOTE, tile_fill="condensing products A'PA / B'PB with nx = 8: an 8 x 23 operand in 16 x 16 x 4 tiles: 0.5 x 0.72 = 0.36")
+    out["C3"]["mfma"] = mfma_note_c3(c2_batch)
     ck = c2_batch.condensed_kernel_name()
     if ck:
-        pk = {2: "kz_pcond", 1: "k_pcond", 0: "kw_pcond"}.get(int(c2_batch.scalar("pcond_kernel")), "pcond")
+        pk = {3: "km_pcond", 2: "kz_pcond", 1: "k_pcond", 0: "kw_pcond"}.get(int(c2_batch.scalar("pcond_kernel")), "pcond")
         ek = {1: "k_pexpand", 0: "kw_pexpand"}.get(int(c2_batch.scalar("pexpand_kernel")), "pexpand")
         out["C3"]["kernel"] = f"{pk} + {ck} + {ek}"
     c2_batch.opts_set("cond_N", N)
@@ -728,7 +765,7 @@ def main():
     dom, prof, roof = sweep_roofline(gb, args.steps, b_in + b_out)
     solves_per_s = world * B * args.steps / elapsed
     tr = mark_stale(pmc_traffic(dom, nx, nu, B, N))
-    roof["mfma"] = dict(MFMA_NOTE, tile_fill="11 x 11 stage block of C2 inside a 16 x 16 x 4 tile: 0.47")
+    roof["mfma"] = MFMA_NOTE_C2
     roof["traffic"] = tr["avg_main"] if tr else None
     roof["traffic_source"] = tr
     roof["traffic_note"] = ("HBM bytes per launch from the committed rocprofv3 PMC summary named in traffic_source (counter passes "

@@ -3,7 +3,10 @@
 usage: summarize.py kernel <results.db>   -> per-kernel calls / total / average (kernel-trace --stats)
        summarize.py pmc <results.db>      -> per-kernel counter sums and per-launch averages
        summarize.py traffic <fetch.db> <write.db> -> JSON: HBM bytes per launch of every gqp kernel
-       summarize.py sections <fetch.db> <write.db> -> the same per marker-delimited section (the configuration legs)"""
+       summarize.py sections <fetch.db> <write.db> -> the same per marker-delimited section (the configuration legs)
+       summarize.py mfma <pmc.db> <trace.db> [commit] -> JSON: matrix-pipe utilisation of every kernel that issues MFMAs
+                                                  (--pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES;
+                                                   durations from a --kernel-trace run of the same command)"""
 import sqlite3
 import sys
 
@@ -104,6 +107,42 @@ def sections(fetch_db, write_db, commit=None):
     print(json.dumps(out, indent=1))
 
 
+def mfma(pmc_db, trace_db, commit=None):
+    """per kernel: MFMA instructions, busy cycles of the matrix pipe, utilisation = busy cycles / (SIMDs x cycles the GPU
+    was active for the launch).  GRBM_GUI_ACTIVE comes back summed over the 8 XCDs (a 2.9 ms launch reports 50.6 M = 8 x
+    2.2 GHz x 2.9 ms), SQ_VALU_MFMA_BUSY_CYCLES summed over the 1,024 SIMDs in cycles (16 per v_mfma_f64_4x4x4_4b_f64)."""
+    import json
+    cur = sqlite3.connect(pmc_db).cursor()
+    vals = {}
+    for k, c, n, s_ in cur.execute("select kernel_name, counter_name, count(*), sum(value) from counters_collection group by kernel_name, counter_name"):
+        vals.setdefault(k, {})[c] = (n, s_)
+    dur = {}
+    for name, calls, tot in sqlite3.connect(trace_db).cursor().execute("select name,total_calls,total_duration from top_kernels"):
+        dur[name] = (calls, tot)
+    out = {"_note": "rocprofv3 --pmc SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVES over one C3 solve "
+                    "(tools/c3_once.py 65536 1), durations from a --kernel-trace --stats pass of the same command; "
+                    "utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); TFLOPs = MFMA instructions x 512 "
+                    "flops / kernel time (v_mfma_f64_4x4x4_4b_f64: four 4x4x4 products; measured peak of that instruction 73.2 TFLOP/s, "
+                    "profiles/r04_mfma4x4x4_probe.txt)", "_commit": commit, "kernels": {}}
+    for k, v in vals.items():
+        if "SQ_INSTS_MFMA" not in v or v["SQ_INSTS_MFMA"][1] <= 0 or "gqp::" not in k:
+            continue
+        short = k.split("gqp::")[1].split("(")[0]
+        n = v["SQ_INSTS_MFMA"][0]
+        insts, busy, gui = v["SQ_INSTS_MFMA"][1], v.get("SQ_VALU_MFMA_BUSY_CYCLES", (0, 0))[1], v.get("GRBM_GUI_ACTIVE", (0, 0))[1]
+        d = dur.get(k)
+        e = {"launches": n, "mfma_instructions_per_launch": insts / n, "mfma_busy_cycles_per_launch": busy / n,
+             "gpu_active_cycles_per_launch_per_xcd": gui / 8 / n,
+             "mfma_utilisation": busy / (1024.0 * gui / 8) if gui else None}
+        if d:
+            e["avg_us"] = d[1] / d[0]           # (top_kernels.total_duration is in microseconds)
+            secs = d[1] * 1e-6
+            e["mfma_TFLOPs"] = insts * (d[0] / n) * 512.0 / secs / 1e12 if secs > 0 else None
+            e["frac_of_measured_mfma_peak_73.2"] = e["mfma_TFLOPs"] / 73.2 if e["mfma_TFLOPs"] else None
+        out["kernels"][short] = e
+    print(json.dumps(out, indent=1))
+
+
 def pmc(db):
     cur = sqlite3.connect(db).cursor()
     q = ("select kernel_name, counter_name, count(*), sum(value), avg(value), max(value) from counters_collection "
@@ -114,7 +153,9 @@ def pmc(db):
 
 
 if __name__ == "__main__":
-    if sys.argv[1] in ("traffic", "sections"):
+    if sys.argv[1] == "mfma":
+        mfma(sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else None)
+    elif sys.argv[1] in ("traffic", "sections"):
         {"traffic": traffic, "sections": sections}[sys.argv[1]](sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else None)
     else:
         {"kernel": kernel, "pmc": pmc}[sys.argv[1]](sys.argv[2])
