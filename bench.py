@@ -123,7 +123,7 @@ def pmc_traffic(dom, nx, nu, B, N):
     try:
         pmc = json.load(open(files[-1]))
         e = pmc[want]
-        return {"file": os.path.relpath(files[-1], ROOT), "commit": pmc.get("_commit"),
+        return {"file": os.path.relpath(files[-1], ROOT), "commit": pmc.get("_commit"), "src_hash": pmc.get("_src_hash"),
                 "avg_main": e.get("hbm_bytes_per_launch_avg_main", e["hbm_bytes_per_launch_avg"]),
                 "full": e["hbm_bytes_per_launch_full"], "kernel": want}
     except Exception:
@@ -204,7 +204,7 @@ def config_traffic(section, symbol, sweep):
         # the two forward sweeps share a symbol: the corrector sweep (update pass included) moves more bytes
         pick = (min if sweep == "fwd_aff" else max)(cand, key=lambda k: cand[k]["hbm_bytes_per_launch_avg_main"])
         e = cand[pick]
-        return {"file": os.path.relpath(files[-1], ROOT), "commit": pmc.get("_commit"), "kernel": pick, "section": section,
+        return {"file": os.path.relpath(files[-1], ROOT), "commit": pmc.get("_commit"), "src_hash": pmc.get("_src_hash"), "kernel": pick, "section": section,
                 "avg_main": e["hbm_bytes_per_launch_avg_main"], "full": e["hbm_bytes_per_launch_full"], "launches": e["launches"]}
     except Exception:
         return None
@@ -215,8 +215,16 @@ def mark_stale(tr):
     this process; tools/profile_round.sh regenerates the summary for the commit it is run on)"""
     if tr is not None:
         head = (git_head() or "").replace("+dirty", "")
-        tr["stale"] = bool(tr.get("commit")) and bool(head) and not (str(tr["commit"]).startswith(head) or head.startswith(str(tr["commit"])))
         tr["benched_commit"] = git_head()
+        if tr.get("src_hash"):
+            # the summary records a hash of the library's sources: a later commit that touches only documents, tests or tools
+            # leaves it valid
+            sys.path.insert(0, os.path.join(ROOT, "profiles"))
+            from summarize import kernel_src_hash
+            tr["benched_src_hash"] = kernel_src_hash()
+            tr["stale"] = tr["src_hash"] != tr["benched_src_hash"]
+        else:
+            tr["stale"] = bool(tr.get("commit")) and bool(head) and not (str(tr["commit"]).startswith(head) or head.startswith(str(tr["commit"])))
     return tr
 
 
@@ -231,9 +239,9 @@ def mfma_util():
         j = json.load(open(files[-1]))
     except Exception:
         return None
-    return {"file": os.path.relpath(files[-1], ROOT), "commit": j.get("_commit"),
+    return mark_stale({"file": os.path.relpath(files[-1], ROOT), "commit": j.get("_commit"), "src_hash": j.get("_src_hash"),
             "kernels": {k: {f: v.get(f) for f in ("mfma_utilisation", "mfma_TFLOPs", "frac_of_measured_mfma_peak_73.2", "avg_us", "mfma_instructions_per_launch")}
-                        for k, v in j.get("kernels", {}).items()}}
+                        for k, v in j.get("kernels", {}).items()}})
 
 
 MFMA_PROBES = {"v_mfma_f64_4x4x4_4b_TFLOPs_measured": 73.2, "v_mfma_f64_16x16x4_TFLOPs_measured": 47.6, "v_fma_f64_TFLOPs_measured": 69.3,

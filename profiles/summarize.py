@@ -11,6 +11,18 @@ import sqlite3
 import sys
 
 
+def kernel_src_hash():
+    """sha256 over the kernel / host sources of the library (acados_amd/csrc): what a PMC summary was measured on.  bench.py
+    compares it with the tree it runs in -- a later commit that touches only documents or tests does not make a summary stale"""
+    import glob, hashlib, os
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "acados_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(root, "*.hpp")) + glob.glob(os.path.join(root, "*.hip")) + glob.glob(os.path.join(root, "*.h")) + glob.glob(os.path.join(root, "*.cpp"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def kernel(db):
     cur = sqlite3.connect(db).cursor()
     print(f"{'kernel':80s} {'calls':>6s} {'total_us':>12s} {'avg_us':>10s} {'pct':>6s}")
@@ -33,7 +45,7 @@ def traffic(fetch_db, write_db, commit=None):
                     "_avg: all launches of that kernel in the solve; _avg_main: the launches that carry work (> 1 % of the "
                     "largest one -- leaves out the conditional redo launches, which touch flagged instances only, i.e. the "
                     "same set of launches bench.py times with HIP events); _full: the largest launch (every instance active).",
-           "_commit": commit}
+           "_commit": commit, "_src_hash": kernel_src_hash()}
     q = "select kernel_name, value from counters_collection where counter_name=? order by dispatch_id"
     def per_kernel(db, counter):
         d = {}
@@ -69,7 +81,7 @@ def sections(fetch_db, write_db, commit=None):
                     "--warmup 0 --no-cpu-baseline --check 0 --check-configs 0` (configuration legs included); bytes = "
                     "(2*FETCH_SIZE + WRITE_SIZE) * 1024 per MI355X_MICROARCH.md (HBM section).  Per section (marker id) and "
                     "kernel: launches, average over the launches that carry work (> 1 % of the largest) and the largest.",
-           "_commit": commit, "sections": {}}
+           "_commit": commit, "_src_hash": kernel_src_hash(), "sections": {}}
     q = "select kernel_name, value from counters_collection where counter_name=? order by dispatch_id"
 
     def cut(db, counter):
@@ -123,7 +135,7 @@ def mfma(pmc_db, trace_db, commit=None):
                     "(tools/c3_once.py 65536 1), durations from a --kernel-trace --stats pass of the same command; "
                     "utilisation = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8 XCDs); TFLOPs = MFMA instructions x 512 "
                     "flops / kernel time (v_mfma_f64_4x4x4_4b_f64: four 4x4x4 products; measured peak of that instruction 73.2 TFLOP/s, "
-                    "profiles/r04_mfma4x4x4_probe.txt)", "_commit": commit, "kernels": {}}
+                    "profiles/r04_mfma4x4x4_probe.txt)", "_commit": commit, "_src_hash": kernel_src_hash(), "kernels": {}}
     for k, v in vals.items():
         if "SQ_INSTS_MFMA" not in v or v["SQ_INSTS_MFMA"][1] <= 0 or "gqp::" not in k:
             continue

@@ -7,7 +7,8 @@
 #                              counter-only passes (no trace domains), gfx950 correction of MI355X_MICROARCH.md
 #   <tag>_bench.json           the bench line of the same build (reads the traffic file just written if copied first)
 # `full` also traces the configuration legs (C3 / C4 / C5) of the bench and collects their HBM traffic per configuration
-#   <tag>_config_kernel_stats.txt, <tag>_config_pmc_traffic.json (sections cut by the marker launches of bench.py)
+#   <tag>_config_kernel_stats.txt, <tag>_config_pmc_traffic.json (sections cut by the marker launches of bench.py),
+#   <tag>_mfma_util.json (tools/profile_mfma.sh: MFMA instructions / busy cycles of km_pcond and kt_factor over one C3 solve)
 tag=${1:-rXX}
 commit=${2:-unknown}
 root=$(pwd)
@@ -37,5 +38,8 @@ if [ "$3" = "full" ]; then
     f=$(find /tmp/pmc_cf -name "*.db" | head -1); w=$(find /tmp/pmc_cw -name "*.db" | head -1)
     python $root/profiles/summarize.py sections $f $w $commit > $out/${tag}_config_pmc_traffic.json
     cp $out/${tag}_config_pmc_traffic.json $root/profiles/${tag}_config_pmc_traffic.json
+    # matrix-pipe utilisation of the kernels that issue MFMAs (km_pcond, kt_factor) over one C3 solve
+    (cd $root && bash tools/profile_mfma.sh $tag $commit > /dev/null 2>&1)
+    cp $out/${tag}_mfma_util.json $root/profiles/${tag}_mfma_util.json
 fi
 cd $root && python bench.py 2> $out/${tag}_bench_err.log | tail -1 > $out/${tag}_bench.json
