@@ -71,8 +71,11 @@ def git_head():
             return None
 
 
-def kernel_symbol(name, cls):
-    """profile class -> kernel function of the family `name` (a batch's kernel_name) runs on (what rocprofv3 lists)"""
+def kernel_symbol(name, cls, tiles=False):
+    """profile class -> kernel function of the family `name` (a batch's kernel_name) runs on (what rocprofv3 lists);
+    tiles: the factor sweep of the two-rows family runs on 4 x 4 MFMA tiles (kt_factor, scalar "w16_tiles")"""
+    if tiles and name.startswith("w16r") and cls == "back_fact":
+        return "kt_factor"
     fam = ("kbs" if name.startswith("1tpi-pipe") else "kb" if name.startswith("1tpi-box") else "ky" if name.startswith("w16r") else "kx" if name.startswith("w16")
            else "kw" if name.startswith("wpi") else "k")
     table = {"kbs": {"back_fact": "kbs_factor", "fwd_aff": "kbs_forward", "back_rhs": "kbs_backrhs", "fwd_corr": "kbs_forward"},
@@ -101,7 +104,7 @@ def sweep_roofline(gb, steps, bytes_per_instance):
     avg_s = dom_ms * 1e-3 / max(dom_cnt, 1)
     per_launch = float(np.mean(units)) * bytes_per_instance
     achieved = per_launch / avg_s / 1e9 if avg_s > 0 else 0.0
-    return dom, prof, {"bound": "hbm", "kernel": f"{kernel_symbol(gb.kernel_name, dom)} ({dom}) of {gb.kernel_name}", "sweep": dom,
+    return dom, prof, {"bound": "hbm", "kernel": f"{kernel_symbol(gb.kernel_name, dom, bool(gb.scalar('w16_tiles')))} ({dom}) of {gb.kernel_name}", "sweep": dom,
                        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                        "bytes_per_launch": per_launch, "units_per_launch": units, "avg_launch_ms": avg_s * 1e3,
                        "launches_timed": dom_cnt, "kernel_ms_share": {c: prof[c][0] for c in CLASSES}}
@@ -385,8 +388,9 @@ def run_config(name, gb, qp_of, N, dims, steps=2, check=4, extra=None, section=0
     b_in, b_out = algorithmic_bytes_dims(dims)
     dom, prof, roof = sweep_roofline(gb, steps, b_in + b_out)
     kname = sweep_kernel_name() if sweep_kernel_name else gb.kernel_name
-    roof["kernel"] = f"{kernel_symbol(kname, dom)} ({dom}) of {kname}"
-    tr = mark_stale(config_traffic(section, kernel_symbol(kname, dom), dom)) if section else None
+    tiles = bool(gb.condensed_scalar("w16_tiles") if sweep_kernel_name and gb.condensed_kernel_name() else gb.scalar("w16_tiles"))
+    roof["kernel"] = f"{kernel_symbol(kname, dom, tiles)} ({dom}) of {kname}"
+    tr = mark_stale(config_traffic(section, kernel_symbol(kname, dom, tiles), dom)) if section else None
     roof["traffic"] = tr["avg_main"] if tr else None
     roof["traffic_source"] = tr
     roof["traffic_over_algorithmic"] = (tr["avg_main"] / roof["bytes_per_launch"]) if tr else None
