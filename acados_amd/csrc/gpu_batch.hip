@@ -130,6 +130,7 @@ struct ocp_qp_gpu_batch
     KernelSet wpi_ks;      /* the wave-per-instance set of the same padded dims (fallback of w16_soft) */
     int w16_slots = 0;     /* row slots a sweep launch covers: B, or the live instances once GqpDev::perm lists them */
     size_t w16_shmem = 0;  /* dynamic LDS bytes of a 16-lanes-per-instance workgroup (4 instances) */
+    size_t w16_shmem_fact = 0; /* ... of the factor sweep (the tile sweep of the small two-rows shapes runs two waves per SIMD: its own, smaller tile) */
     int w16_tiles = 0;     /* two-rows family: factor sweep on 4 x 4 MFMA tiles (kt_factor) */
     kern_redo_t w16_solve = nullptr; /* whole-solve kernel of the family (batches of at most solve_max instances) */
     int solve_max = 256;   /* largest batch that is solved in one launch (option "solve_max", 0 = off) */
@@ -872,12 +873,13 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
                 b->w16_slots = n_batch;
                 b->w16_soft = gen;
                 b->w16_ng = ws.NG;
-                b->w16_shmem = tiles && ws.tshmem > ws.shmem ? ws.tshmem : ws.shmem;
+                b->w16_shmem = ws.shmem;
+                b->w16_shmem_fact = tiles ? ws.tshmem : ws.shmem;
                 b->w16_tiles = tiles;
                 if (const char *ea = getenv("ACADOS_AMD_W16_LDS_ALIGN")) /* development: allocation rounded up / padded */
                 {
                     const size_t a = (size_t) atoi(ea);
-                    if (a > 1) b->w16_shmem = (b->w16_shmem + a - 1) / a * a;
+                    if (a > 1) { b->w16_shmem = (b->w16_shmem + a - 1) / a * a; b->w16_shmem_fact = (b->w16_shmem_fact + a - 1) / a * a; }
                 }
                 b->w16_solve = gen ? ws.ssolve : ws.solve;
             }
@@ -1386,6 +1388,13 @@ struct IpmKernels
         else GQP_IPM_LAUNCH_SHM(b, kern, shm, s, __VA_ARGS__);                                                \
     } while (0)
 
+/* the factor sweep: its own LDS tile in the sixteen-lanes families */
+#define GQP_FACT_LAUNCH(b, kern, s, ...)                                                                      \
+    do {                                                                                                      \
+        if ((b)->w16) GQP_LAUNCH_COOP(kern, dim3(((b)->w16_slots + 3) / 4), dim3(64), (b)->w16_shmem_fact, s, __VA_ARGS__); \
+        else GQP_IPM_LAUNCH_SHM(b, kern, (b)->shmem_fact, s, __VA_ARGS__);                                    \
+    } while (0)
+
 static IpmKernels pick_kernels(const ocp_qp_gpu_batch *b)
 {
     const KernelSet *ks = b->ks;
@@ -1465,7 +1474,7 @@ static void run_ipm(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch *root, Prof &prof, hip
     for (;; it++)
     {
         if (b == root) prof.begin(1, s); /* per-class timing covers the root level only (full-batch launches) */
-        GQP_SWEEP_LAUNCH(b, K.fact, b->shmem_fact, s, D, O, 0);
+        GQP_FACT_LAUNCH(b, K.fact, s, D, O, 0);
         if (b == root) prof.end(s);
         root->launches++;
         HIPCHK(hipMemcpyAsync(b->h_nact, D.n_active, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -1563,7 +1572,7 @@ static void compact_into(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch *root, int nact, 
         c->idxb = b->idxb; c->idxs_rev = b->idxs_rev; c->idxe = b->idxe; c->nbxe = b->nbxe;
         c->compact_min = b->compact_min;
         c->tail_max = b->tail_max;
-        if (!tail) { c->aos = b->aos; c->wpi = b->wpi; c->shmem = b->shmem; c->shmem_fwd = b->shmem_fwd; c->shmem_fact = b->shmem_fact; c->w16 = b->w16; c->w16_soft = b->w16_soft; c->w16_ng = b->w16_ng; c->w16_shmem = b->w16_shmem; c->w16_tiles = b->w16_tiles; }
+        if (!tail) { c->aos = b->aos; c->wpi = b->wpi; c->shmem = b->shmem; c->shmem_fwd = b->shmem_fwd; c->shmem_fact = b->shmem_fact; c->w16 = b->w16; c->w16_soft = b->w16_soft; c->w16_ng = b->w16_ng; c->w16_shmem = b->w16_shmem; c->w16_shmem_fact = b->w16_shmem_fact; c->w16_tiles = b->w16_tiles; }
         finalize_structure(c);
         slot = c;
     }
@@ -1688,7 +1697,7 @@ static void refactor_at_solution(ocp_qp_gpu_batch *b)
     if (!b->d_saved_status) b->d_saved_status = dalloc<int>(b, b->Bp);
     GqpOpts O = effective_opts(b->O, b);
     hipLaunchKernelGGL(gqp::k_sens_prep, g64, blk, 0, s, b->D, O.tau_min, b->d_saved_status);
-    GQP_SWEEP_LAUNCH(b, pick_kernels(b).fact, b->shmem_fact, s, b->D, O, 0);
+    GQP_FACT_LAUNCH(b, pick_kernels(b).fact, s, b->D, O, 0);
     hipLaunchKernelGGL(gqp::k_status_restore, g64, blk, 0, s, b->D, b->d_saved_status);
     HIPCHK(hipStreamSynchronize(s));
     b->factor_stale = false;

@@ -75,8 +75,31 @@ __device__ static inline double w16t_bsum(double v, double *vx, int l)
     return r;
 }
 
+/* Waves per SIMD.  The shapes whose tiles are few (the condensed C3 shape: 27 tiles of M, 14 of [B A]) fit 256 registers
+ * without scratch when nothing is held that can be read again -- tiles of [B A] from LDS in the W product, one tile row of LDS
+ * reads in flight, the next stage's vectors requested behind the per-variable work -- and then TWO waves share a SIMD: the
+ * dependent chains of the diagonal blocks and the LDS / memory round trips of one wave are the other one's issue slots (what
+ * ky_factor never reached: at the 256-register line it spilled and lost).  W16T_ONE_WAVE keeps one wave per SIMD with
+ * everything in registers (development builds: the A/B).  nx = 24 needs ~480 registers either way. */
 template <int NX, int NU>
-__global__ void __launch_bounds__(64) W16R_WPE_FACT kt_factor(GqpDev D, GqpOpts O, int redo)
+struct W16TShape
+{
+    static constexpr bool SMALL = (NX / 4) * (((NX + NU + 3) & ~3) / 4 + 1) <= 24;
+#if defined(W16T_ONE_WAVE)
+    static constexpr bool TWO_WAVES = false;
+#else
+    static constexpr bool TWO_WAVES = SMALL;
+#endif
+    static constexpr int WPE = TWO_WAVES ? 2 : 1;
+};
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define W16T_WPE(NX, NU) __attribute__((amdgpu_waves_per_eu(W16TShape<NX, NU>::WPE, W16TShape<NX, NU>::WPE)))
+#else
+#define W16T_WPE(NX, NU)
+#endif
+template <int NX, int NU>
+__global__ void __launch_bounds__(64) W16T_WPE(NX, NU) kt_factor(GqpDev D, GqpOpts O, int redo)
 {
     GQP_DYN_SHARED(smem);
     typedef W16TLds<NX, NU> LY;
@@ -190,7 +213,12 @@ __global__ void __launch_bounds__(64) W16R_WPE_FACT kt_factor(GqpDev D, GqpOpts 
         bool fixed[R];
         /* ---- exchange 1: v by x, pi+ by x, b - x+ by y ---- */
         GQP_ROWSYNC();
-        if (PAD > 0 && l < PAD) VXA[l] = 0.0;
+        if (PAD > 0)
+        {
+            double zero = 0.0;
+            W16R_OPAQUE(zero); /* (materialised here: as a loop-invariant constant it was the one value spilled at 256 registers) */
+            if (l < PAD) VXA[l] = zero;
+        }
         W16_UNROLL for (int s = 0; s < R; s++)
         {
             fixed[s] = mine[s] && ((emask >> row[s]) & 1);
@@ -223,7 +251,7 @@ __global__ void __launch_bounds__(64) W16R_WPE_FACT kt_factor(GqpDev D, GqpOpts 
          * ROOMY (the C3 shape: 60 tiles, 380 registers): all LDS reads of the three products below may be in flight at once and
          * the quad sums are taken together at the end; at nx = 24 the register file is full -- one tile row in flight at a
          * time (fences), its quad sum and its store right behind it.  Two accumulator chains per tile row either way. */
-        constexpr bool BA_REG = NXT * (NT + 1) <= 24, ROOMY = BA_REG;
+        constexpr bool BA_REG = W16TShape<NX, NU>::SMALL && !W16TShape<NX, NU>::TWO_WAVES, ROOMY = BA_REG;
         double MT[NT][NT], MTr[NT], hacc[ROOMY ? NT : 1], bacc[ROOMY ? NT : 1], racc[ROOMY ? NXT : 1];
         W16_UNROLL for (int J = 0; J < NT; J++)
         {
