@@ -91,7 +91,7 @@ struct W16Set
 #define GQP_W16G(NX, NU, NG)                                                                                  \
     {NX, NU, NG, nullptr, nullptr, nullptr, nullptr, gqp::ky_factor<NX, NU, NG>, gqp::ky_backrhs<NX, NU, NG>,     \
      gqp::ky_fwd<NX, NU, false, NG>, gqp::ky_fwd<NX, NU, true, NG>, 4 * gqp::W16RLds<NX, NU, NG>::SZ * sizeof(double), nullptr, nullptr, \
-     nullptr, 0}
+     gqp::kt_factor<NX, NU, NG>, 4 * gqp::W16TLds<NX, NU, NG>::SZ * sizeof(double)}
 const W16Set g_w16_sets[] = {GQP_W16(4, 1), GQP_W16(8, 3), GQP_W16(12, 3), GQP_W16(4, 4), GQP_W16(12, 4),
                              GQP_W16R(8, 15), GQP_W16R(24, 6), GQP_W16G(24, 3, 4)};
 
@@ -860,8 +860,9 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
                 const W16Set &ws = *w16;
                 b->wpi_ks = b->own_ks; /* what the batch falls back to if the slack structure is not one-slack-per-box-row */
                 const char *et = getenv("ACADOS_AMD_W16T"); /* 0: the factor sweep of the two-rows family on register rows (ky_factor) */
-                const bool tiles = !gen && ws.tfact && !(et && atoi(et) == 0);
-                const kern_redo_t kf = gen ? ws.sfact : (tiles ? ws.tfact : ws.fact), kr = gen ? ws.srhs : ws.rhs;
+                const char *etg = getenv("ACADOS_AMD_W16T_GEN"); /* ... of the GEN instantiations alone */
+                const bool tiles = ws.tfact && !(et && atoi(et) == 0) && !(gen && etg && atoi(etg) == 0);
+                const kern_redo_t kf = tiles ? ws.tfact : (gen ? ws.sfact : ws.fact), kr = gen ? ws.srhs : ws.rhs;
                 const kern_redo_t ka = gen ? ws.sfaff : ws.faff, kc = gen ? ws.sfcor : ws.fcor;
                 b->own_ks.back_fact = kf; b->own_ks.back_rhs = kr; b->own_ks.fwd_aff = ka; b->own_ks.fwd_corr = kc;
                 for (int q = 0; q < 2; q++)

@@ -43,16 +43,20 @@
 namespace gqp
 {
 
-template <int NX, int NU>
+template <int NX, int NU, int NG = 0>
 struct W16TLds
 {
     static constexpr int n = NX + NU, NP = n * (n + 1) / 2, NB = n * NX;
     static constexpr int NPD = (n + 3) & ~3, PAD = NPD - n, NT = NPD / 4, NXT = NX / 4, XT0 = NT - NXT;
-    /* vector exchange (three vectors at a time), packed H block, [B A]' block (both by LDS-DMA as they lie in memory) */
-    static constexpr int VA = 0, VB = NPD, VC = NPD + (NPD > NX ? NPD : NX);
-    static constexpr int VSZ = (VC + NX + 1) & ~1; /* (the block reductions at the end of the kernel reuse the first 16) */
+    /* vector exchange (three vectors at a time), packed H block, [B A]' block (both by LDS-DMA as they lie in memory); GEN: the
+     * general rows [D C] of the stage [g][n], four 16-entry row vectors (value in; gamma / gadd / dlam out) and the row index
+     * of every lane -- the third exchange vector (b - x+, read back before the row vectors are written) shares the first */
+    static constexpr int VA = 0, VB = NPD, VC_OWN = NPD + (NPD > NX ? NPD : NX);
+    static constexpr int VSZ = NG > 0 ? ((VC_OWN + 1) & ~1) : ((VC_OWN + NX + 1) & ~1); /* (the block reductions at the end of the kernel reuse the first 16) */
     static constexpr int HR = VSZ, HSZ = (NP + 1) & ~1, BR = HR + HSZ, BSZ = (NB + 1) & ~1;
-    static constexpr int SZ = (BR + BSZ + 1) & ~1;
+    static constexpr int GT = BR + BSZ, GN = NG > 0 ? ((NG * n + 1) & ~1) : 0, RW = GT + GN, RI = RW + 64;
+    static constexpr int VC = NG > 0 ? RW : VC_OWN;
+    static constexpr int SZ = ((NG > 0 ? RI + 8 : GT) + 1) & ~1;
 };
 
 /* max / sum over the sixteen lanes of a block (once per launch): through LDS */
@@ -81,10 +85,10 @@ __device__ static inline double w16t_bsum(double v, double *vx, int l)
  * dependent chains of the diagonal blocks and the LDS / memory round trips of one wave are the other one's issue slots (what
  * ky_factor never reached: at the 256-register line it spilled and lost).  W16T_ONE_WAVE keeps one wave per SIMD with
  * everything in registers (development builds: the A/B).  nx = 24 needs ~480 registers either way. */
-template <int NX, int NU>
+template <int NX, int NU, int NG = 0>
 struct W16TShape
 {
-    static constexpr bool SMALL = (NX / 4) * (((NX + NU + 3) & ~3) / 4 + 1) <= 24;
+    static constexpr bool SMALL = NG == 0 && (NX / 4) * (((NX + NU + 3) & ~3) / 4 + 1) <= 24;
 #if defined(W16T_ONE_WAVE)
     static constexpr bool TWO_WAVES = false;
 #else
@@ -94,15 +98,17 @@ struct W16TShape
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
-#define W16T_WPE(NX, NU) __attribute__((amdgpu_waves_per_eu(W16TShape<NX, NU>::WPE, W16TShape<NX, NU>::WPE)))
+#define W16T_WPE(NX, NU, NG) __attribute__((amdgpu_waves_per_eu(W16TShape<NX, NU, NG>::WPE, W16TShape<NX, NU, NG>::WPE)))
 #else
-#define W16T_WPE(NX, NU)
+#define W16T_WPE(NX, NU, NG)
 #endif
-template <int NX, int NU>
-__global__ void __launch_bounds__(64) W16T_WPE(NX, NU) kt_factor(GqpDev D, GqpOpts O, int redo)
+template <int NX, int NU, int NG = 0>
+__global__ void __launch_bounds__(64) W16T_WPE(NX, NU, NG) kt_factor(GqpDev D, GqpOpts O, int redo)
 {
     GQP_DYN_SHARED(smem);
-    typedef W16TLds<NX, NU> LY;
+    typedef W16TLds<NX, NU, NG> LY;
+    constexpr bool GEN = NG > 0; /* general rows and slacks (one slack per row): every inequality row through w16r_row_factor, as ky_factor */
+    constexpr int NGP = (NG * (NX + NU) + 15) / 16;
     static_assert(NX % 4 == 0, "kt_factor: the state block must be whole 4 x 4 tile rows");
     constexpr int n = NX + NU, R = (n + 15) / 16, NP = LY::NP, NB = LY::NB, PAD = LY::PAD, NT = LY::NT, NXT = LY::NXT, XT0 = LY::XT0;
     const int lane = threadIdx.x & 63, x = lane & 3, y = lane >> 4, bq = (lane >> 2) & 3;
@@ -123,6 +129,9 @@ __global__ void __launch_bounds__(64) W16T_WPE(NX, NU) kt_factor(GqpDev D, GqpOp
     if (!any) return;
     double *T = smem + bq * LY::SZ, *VXA = T + LY::VA, *VXB = T + LY::VB, *VXC = T + LY::VC;
     double *HRq = T + LY::HR, *BRq = T + LY::BR;
+    double *GTq = T + LY::GT;     /* GEN: general rows of the stage, [g][n] */
+    double *RW = T + LY::RW;      /* GEN: row vectors, 4 x 16 */
+    int *RI = (int *) (T + LY::RI); /* GEN: inequality row handled by every lane */
     int row[R], cx[R];
     bool mine[R], isx[R];
     W16_UNROLL for (int s = 0; s < R; s++) row[s] = l + 16 * s;
@@ -145,11 +154,13 @@ __global__ void __launch_bounds__(64) W16T_WPE(NX, NU) kt_factor(GqpDev D, GqpOp
     double p_v[R], p_g[R], p_b[R], p_xn[R], p_pin[R], p_pik[R], p_ll[R], p_lu[R], p_tl[R], p_tu[R], p_dl[R], p_du[R];
     double p_ht = 0.0, p_bt = 0.0;
     uint64_t p_am, c_bm, c_em, n_bm, n_em;
-    int c_nb, c_oct, n_nb, n_oct;
+    int c_nb, c_oct, n_nb, n_oct, c_ng = 0, c_og = 0, n_ng = 0, n_og = 0, c_ns = 0, c_os = 0, n_ns = 0, n_os = 0;
+    double p_G[NGP > 0 ? NGP : 1];
     auto load_desc = [&](int kk)
     {
         GQP_STAGE_REF Sn = D.st[kk];
         n_bm = Sn.bmask; n_em = Sn.emask; n_nb = Sn.nb; n_oct = Sn.o_ct;
+        if (GEN) { n_ng = Sn.ng; n_og = Sn.o_g; n_ns = Sn.ns; n_os = Sn.o_s; }
     };
     auto prefetch_v = [&](int kk)
     {
@@ -166,19 +177,30 @@ __global__ void __launch_bounds__(64) W16T_WPE(NX, NU) kt_factor(GqpDev D, GqpOp
             p_xn[s] = WAT(D.ux, (kk + 1) * n + NU + xc);
             p_pin[s] = WAT(D.pi, (kk + 1) * NX + xc);
             p_pik[s] = WAT(D.pi, kk * NX + xc);
-            const bool hs = mn && (((c_bm & ~c_em) >> row[s]) & 1);
-            const int ib = hs ? popc64(c_bm & (((uint64_t) 1 << row[s]) - 1)) : 0;
-            const int el = c_oct + ib, eu = el + c_nb;
-            p_ll[s] = WAT(D.lam, el); p_lu[s] = WAT(D.lam, eu);
-            p_tl[s] = WAT(D.t, el); p_tu[s] = WAT(D.t, eu);
-            p_dl[s] = WAT(D.dvec, el); p_du[s] = WAT(D.dvec, eu);
+            if (!GEN)
+            {
+                const bool hs = mn && (((c_bm & ~c_em) >> row[s]) & 1);
+                const int ib = hs ? popc64(c_bm & (((uint64_t) 1 << row[s]) - 1)) : 0;
+                const int el = c_oct + ib, eu = el + c_nb;
+                p_ll[s] = WAT(D.lam, el); p_lu[s] = WAT(D.lam, eu);
+                p_tl[s] = WAT(D.t, el); p_tu[s] = WAT(D.t, eu);
+                p_dl[s] = WAT(D.dvec, el); p_du[s] = WAT(D.dvec, eu);
+            }
+        }
+        if (GEN)
+        {
+            W16_UNROLL for (int i = 0; i < NGP; i++)
+            {
+                const int e = l + 16 * i;
+                p_G[i] = WAT(D.DCt, c_og * n + (e < c_ng * n ? e : 0));
+            }
         }
     };
     load_desc(D.N);
-    c_bm = n_bm; c_em = n_em; c_nb = n_nb; c_oct = n_oct;
+    c_bm = n_bm; c_em = n_em; c_nb = n_nb; c_oct = n_oct; c_ng = n_ng; c_og = n_og; c_ns = n_ns; c_os = n_os;
     dma_h(D.N);
     dma_b(D.N);
-    prefetch_v(D.N);
+    if (!GEN) prefetch_v(D.N);
     load_desc(D.N > 0 ? D.N - 1 : 0);
 
     /* natural tiles of the state block of the factor of stage k + 1 (Q >= C) and its rhs part by y (lanes x == 0) */
@@ -205,10 +227,17 @@ __global__ void __launch_bounds__(64) W16T_WPE(NX, NU) kt_factor(GqpDev D, GqpOp
         /* (the lane's base addresses in the ~15 arrays of the stage are loop invariant: hoisted, they live across the register
          * peak and are spilled -- recomputed per stage instead, as in the GEN instantiations of ky_factor) */
         W16R_OPAQUE(inst); W16R_OPAQUE(l);
+        /* GEN: the vectors and the general rows of the stage are loaded HERE, in front of the wait for the DMA'd blocks (one
+         * exposed latency), not a stage ahead: the register file of this variant has no room for values that live across a
+         * stage (ky_factor, same place) */
+        if (GEN) prefetch_v(k);
         W16R_DMA_WAIT(); /* everything issued for this stage has landed */
         W16R_TICK(0);
         const uint64_t bmask = c_bm, emask = c_em, imask = bmask & ~emask, am = p_am;
         const int nbg = c_nb, o_ct = c_oct;
+        const int ng = GEN ? c_ng : 0;
+        const W16Dsc dsc = {c_nb, ng, c_ns, c_oct, c_os};
+        const int nbf = popc64(imask); /* box rows that take part (equality-flagged ones do not) */
         double v[R], g[R], pik[R], q_ll[R], q_lu[R], q_tl[R], q_tu[R], q_dl[R], q_du[R];
         bool fixed[R];
         /* ---- exchange 1: v by x, pi+ by x, b - x+ by y ---- */
@@ -225,7 +254,7 @@ __global__ void __launch_bounds__(64) W16T_WPE(NX, NU) kt_factor(GqpDev D, GqpOp
             v[s] = mine[s] ? p_v[s] : 0.0;
             g[s] = mine[s] ? p_g[s] : 0.0;
             pik[s] = isx[s] ? p_pik[s] : 0.0;
-            q_ll[s] = p_ll[s]; q_lu[s] = p_lu[s]; q_tl[s] = p_tl[s]; q_tu[s] = p_tu[s]; q_dl[s] = p_dl[s]; q_du[s] = p_du[s];
+            if (!GEN) { q_ll[s] = p_ll[s]; q_lu[s] = p_lu[s]; q_tl[s] = p_tl[s]; q_tu[s] = p_tu[s]; q_dl[s] = p_dl[s]; q_du[s] = p_du[s]; }
             if (mine[s]) VXA[PAD + row[s]] = v[s];
             if (isx[s]) { VXB[cx[s]] = p_pin[s]; VXC[cx[s]] = p_b[s] - p_xn[s]; }
         }
@@ -237,7 +266,15 @@ __global__ void __launch_bounds__(64) W16T_WPE(NX, NU) kt_factor(GqpDev D, GqpOp
                 if (NB & 1) BRq[NB - 1] = p_bt;
             }
         }
+        if (GEN)
+            W16_UNROLL for (int i = 0; i < NGP; i++)
+            {
+                const int e = l + 16 * i;
+                if (e < NG * n) GTq[e] = e < ng * n ? p_G[i] : 0.0;
+            }
         GQP_ROWSYNC();
+        /* the descriptor loaded a stage ago becomes the next stage's (GEN fields) */
+        const int x_ng = n_ng, x_og = n_og, x_ns = n_ns, x_os = n_os;
         /* the descriptor loaded a stage ago becomes the next stage's */
         const uint64_t x_bm = n_bm, x_em = n_em;
         const int x_nb = n_nb, x_oct = n_oct;
@@ -245,13 +282,70 @@ __global__ void __launch_bounds__(64) W16T_WPE(NX, NU) kt_factor(GqpDev D, GqpOp
         W16_UNROLL for (int I = 0; I < NT; I++) vx[I] = VXA[4 * I + x];
         W16_UNROLL for (int Q = 0; Q < NXT; Q++) { pix[Q] = VXB[4 * Q + x]; rby[Q] = VXC[4 * Q + y]; }
         GQP_ROWSYNC(); /* exchange 2 (H v, [B A]' pi+ back to the compact form) fills the same slots tile row by tile row */
+        /* ---- GEN: every inequality row -- the sorted box rows that take part, then the general rows -- by ONE lane of the block
+         * with the branch-free row functions of ky_factor (residuals, norms, slack elimination), BEFORE the tiles of H are
+         * loaded (the row functions keep ~40 values and as many addresses alive).  Row values travel through the row vectors
+         * by row index: a box row's v_j from the slot that owns the variable, a general row's a'v as one tile row of the
+         * vector-pipe product below (operand by x, quad sum, the result by y = g); the results come back the same way ---- */
+        double gtr[R], gar[R], gmr[R]; /* what the inequality rows add to the stationarity residual / gradient / Hessian diagonal */
+        W16_UNROLL for (int s = 0; s < R; s++) { gtr[s] = 0.0; gar[s] = 0.0; gmr[s] = 0.0; }
+        if (GEN)
+        {
+            W16_UNROLL for (int s = 0; s < R; s++)
+                if (mine[s] && ((imask >> row[s]) & 1))
+                {
+                    const int jb = popc64(imask & (((uint64_t) 1 << row[s]) - 1));
+                    RW[jb] = v[s];
+                    RI[jb] = popc64(bmask & (((uint64_t) 1 << row[s]) - 1));
+                }
+            {
+                double acc = 0.0;
+                W16_UNROLL for (int I = 0; I < NT; I++)
+                {
+                    const int c = 4 * I + x - PAD;
+                    double a = GTq[(y < NG ? y : 0) * n + (c > 0 ? c : 0)];
+                    if (y >= ng || c < 0) a = 0.0;
+                    acc += a * vx[I];
+                }
+                acc = mfma4_qsum(acc);
+                if (y < ng) { RW[nbf + y] = acc; RI[nbf + y] = nbg + y; } /* (the four lanes of the quad write the same value) */
+            }
+            GQP_ROWSYNC();
+            const bool hr = l < nbf + ng;
+            const int rr = hr ? RI[l] : 0;
+            const int sjr = hr ? (int) D.st[k].srev[rr] : -1;
+            const W16RowF rf = w16r_row_factor(D, O, inst, alive, dsc, am, hr, rr, sjr, RW[hr ? l : 0], nrm_g, nrm_d, nrm_m, musum, nact, obj);
+            GQP_ROWSYNC();
+            RW[16 + l] = rf.gam; RW[32 + l] = rf.gadd; RW[48 + l] = rf.dlam;
+            GQP_ROWSYNC();
+            W16_UNROLL for (int s = 0; s < R; s++)
+            {
+                const bool has = mine[s] && ((imask >> row[s]) & 1);
+                const int jb = has ? popc64(imask & (((uint64_t) 1 << row[s]) - 1)) : 0;
+                gmr[s] = has ? RW[16 + jb] : 0.0;
+                gar[s] = has ? RW[32 + jb] : 0.0;
+                gtr[s] = has ? RW[48 + jb] : 0.0;
+            }
+            W16_UNROLL for (int g_ = 0; g_ < NG; g_++)
+            {
+                const int rg_ = nbf + g_ < 16 ? nbf + g_ : 15;
+                const double Ag = g_ < ng ? RW[32 + rg_] : 0.0, Lg = g_ < ng ? RW[48 + rg_] : 0.0;
+                W16_UNROLL for (int s = 0; s < R; s++)
+                {
+                    const double ap = mine[s] ? GTq[g_ * n + (mine[s] ? row[s] : 0)] : 0.0;
+                    gtr[s] += ap * Lg;
+                    gar[s] += ap * Ag;
+                }
+            }
+            W16_UNROLL for (int s = 0; s < R; s++) { W16R_OPAQUE(gtr[s]); W16R_OPAQUE(gar[s]); W16R_OPAQUE(gmr[s]); }
+        }
 
         W16R_TICK(1);
         /* ---- tiles of H from the packed block: MT(J,I), J <= I, and H v by tile row (operand by x, partial sums per lane) ----
          * ROOMY (the C3 shape: 60 tiles, 380 registers): all LDS reads of the three products below may be in flight at once and
          * the quad sums are taken together at the end; at nx = 24 the register file is full -- one tile row in flight at a
          * time (fences), its quad sum and its store right behind it.  Two accumulator chains per tile row either way. */
-        constexpr bool BA_REG = W16TShape<NX, NU>::SMALL && !W16TShape<NX, NU>::TWO_WAVES, ROOMY = BA_REG;
+        constexpr bool BA_REG = W16TShape<NX, NU, NG>::SMALL && !W16TShape<NX, NU, NG>::TWO_WAVES, ROOMY = BA_REG;
         double MT[NT][NT], MTr[NT], hacc[ROOMY ? NT : 1], bacc[ROOMY ? NT : 1], racc[ROOMY ? NXT : 1];
         W16_UNROLL for (int J = 0; J < NT; J++)
         {
@@ -337,8 +431,8 @@ __global__ void __launch_bounds__(64) W16T_WPE(NX, NU) kt_factor(GqpDev D, GqpOp
         constexpr bool PF_EARLY = BA_REG;
         auto next_stage_vectors = [&]()
         {
-            c_bm = x_bm; c_em = x_em; c_nb = x_nb; c_oct = x_oct;
-            prefetch_v(k - 1);
+            c_bm = x_bm; c_em = x_em; c_nb = x_nb; c_oct = x_oct; c_ng = x_ng; c_og = x_og; c_ns = x_ns; c_os = x_os;
+            if (!GEN) prefetch_v(k - 1); /* GEN: at the top of the stage, see there */
             load_desc(k > 1 ? k - 2 : 0);
         };
         if (BA_REG && k > 0) dma_b(k - 1);
@@ -364,7 +458,12 @@ __global__ void __launch_bounds__(64) W16T_WPE(NX, NU) kt_factor(GqpDev D, GqpOp
                 obj += (0.5 * hv + g[s]) * v[s];
                 gt[s] = bp + hv + g[s] - pik[s];
             }
-            const bool has = mine[s] && ((imask >> row[s]) & 1);
+            const bool has = !GEN && mine[s] && ((imask >> row[s]) & 1);
+            if (GEN)
+            {
+                gt[s] -= gtr[s];
+                gadd[s] = gar[s]; gam[s] = gmr[s];
+            }
             if (has)
             {
                 const int ib = popc64(bmask & (((uint64_t) 1 << row[s]) - 1));
@@ -425,6 +524,23 @@ __global__ void __launch_bounds__(64) W16T_WPE(NX, NU) kt_factor(GqpDev D, GqpOp
                 W16_UNROLL for (int I = J; I < NT; I++) MT[J][I] = gqp_mfma4(WT[J], WT[I], MT[J][I]);
                 MTr[J] = gqp_mfma4(WT[J], WT[NT], MTr[J]);
             }
+        }
+        if (GEN)
+        {
+            /* general rows: M += A' diag(gamma) A as one more chain of tile products -- A(0,I)[y][x] = a_y[4I + x - PAD] from the
+             * LDS copy of [D C], gamma_g still in the row vector */
+            double At[NT], Ag[NT];
+            const int rg_ = nbf + y < 16 ? nbf + y : 15;
+            const double gmy = y < ng ? RW[16 + rg_] : 0.0;
+            W16_UNROLL for (int I = 0; I < NT; I++)
+            {
+                const int c = 4 * I + x - PAD;
+                double a = GTq[(y < NG ? y : 0) * n + (c > 0 ? c : 0)];
+                if (y >= ng || c < 0) a = 0.0;
+                At[I] = a; Ag[I] = gmy * a;
+            }
+            W16_UNROLL for (int J = 0; J < NT; J++)
+                W16_UNROLL for (int I = J; I < NT; I++) MT[J][I] = gqp_mfma4(At[J], Ag[I], MT[J][I]);
         }
         W16R_TICK(8);
         if (!BA_REG && k > 0) dma_b(k - 1);
