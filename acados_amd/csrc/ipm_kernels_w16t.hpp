@@ -346,26 +346,44 @@ __global__ void __launch_bounds__(64) W16T_WPE(NX, NU, NG) kt_factor(GqpDev D, G
          * the quad sums are taken together at the end; at nx = 24 the register file is full -- one tile row in flight at a
          * time (fences), its quad sum and its store right behind it.  Two accumulator chains per tile row either way. */
         constexpr bool BA_REG = W16TShape<NX, NU, NG>::SMALL && !W16TShape<NX, NU, NG>::TWO_WAVES, ROOMY = BA_REG;
+        /* PIPE1 (one wave per SIMD, full register file: nx = 24): the LDS reads of tile row r + 1 are issued in front of the
+         * multiply-adds of tile row r -- with a fence per row and nothing in flight across it every one of the 22 rows of the three
+         * products exposed an LDS round trip */
+        constexpr bool PIPE1 = !ROOMY && !W16TShape<NX, NU, NG>::TWO_WAVES;
         double MT[NT][NT], MTr[NT], hacc[ROOMY ? NT : 1], bacc[ROOMY ? NT : 1], racc[ROOMY ? NXT : 1];
-        W16_UNROLL for (int J = 0; J < NT; J++)
+        auto h_tile = [&](int J, int I) -> double
         {
-            if (!ROOMY) W16R_FENCE();
-            double acc0 = 0.0, acc1 = 0.0;
-            W16_UNROLL for (int I = 0; I < NT; I++)
+            const int r = 4 * J + y - PAD, c = 4 * I + x - PAD; /* natural indices; negative: padding (unit diagonal) */
+            const int rr = r > 0 ? r : 0, cc = c > 0 ? c : 0;
+            const int e = J < I ? PK(cc, rr) : (J > I ? PK(rr, cc) : (rr >= cc ? PK(rr, cc) : PK(cc, rr)));
+            double h = HRq[e];
+            if (PAD > 0 && (J == 0 || I == 0)) h = (r < 0 || c < 0) ? (r == c ? 1.0 : 0.0) : h;
+            return h;
+        };
+        {
+            double cur[PIPE1 ? NT : 1], nxt[PIPE1 ? NT : 1];
+            if (PIPE1)
+                W16_UNROLL for (int I = 0; I < NT; I++) cur[I] = h_tile(0, I);
+            W16_UNROLL for (int J = 0; J < NT; J++)
             {
-                const int r = 4 * J + y - PAD, c = 4 * I + x - PAD; /* natural indices; negative: padding (unit diagonal) */
-                const int rr = r > 0 ? r : 0, cc = c > 0 ? c : 0;
-                const int e = J < I ? PK(cc, rr) : (J > I ? PK(rr, cc) : (rr >= cc ? PK(rr, cc) : PK(cc, rr)));
-                double h = HRq[e];
-                if (PAD > 0 && (J == 0 || I == 0)) h = (r < 0 || c < 0) ? (r == c ? 1.0 : 0.0) : h;
-                if (J <= I) MT[J][I] = h;
-                if (I & 1) acc1 += h * vx[I]; else acc0 += h * vx[I];
-            }
-            if (ROOMY) hacc[J] = acc0 + acc1;
-            else
-            {
-                const double t = mfma4_qsum(acc0 + acc1);
-                if (x == 0) VXA[4 * J + y] = t;
+                if (PIPE1 && J + 1 < NT)
+                    W16_UNROLL for (int I = 0; I < NT; I++) nxt[I] = h_tile(J + 1, I);
+                if (!ROOMY) W16R_FENCE();
+                double acc0 = 0.0, acc1 = 0.0;
+                W16_UNROLL for (int I = 0; I < NT; I++)
+                {
+                    const double h = PIPE1 ? cur[I] : h_tile(J, I);
+                    if (J <= I) MT[J][I] = h;
+                    if (I & 1) acc1 += h * vx[I]; else acc0 += h * vx[I];
+                }
+                if (ROOMY) hacc[J] = acc0 + acc1;
+                else
+                {
+                    const double t = mfma4_qsum(acc0 + acc1);
+                    if (x == 0) VXA[4 * J + y] = t;
+                }
+                if (PIPE1)
+                    W16_UNROLL for (int I = 0; I < NT; I++) cur[I] = nxt[I];
             }
         }
         if (k > 0) dma_h(k - 1);
@@ -381,38 +399,61 @@ __global__ void __launch_bounds__(64) W16T_WPE(NX, NU, NG) kt_factor(GqpDev D, G
             if (PAD > 0 && I == 0) bv = c < 0 ? 0.0 : bv;
             return bv;
         };
-        double BA[BA_REG ? NXT : 1][NT + 1];
-        W16_UNROLL for (int Q = 0; Q < NXT; Q++)
+        auto bt_tile = [&](int I, int Q) -> double /* tiles of [B A]' as they lie: rows = variables */
         {
-            if (!ROOMY) W16R_FENCE();
-            double acc0 = 0.0, acc1 = 0.0;
-            W16_UNROLL for (int I = 0; I < NT; I++)
+            const int r = 4 * I + y - PAD;
+            double bv = BRq[(r > 0 ? r : 0) * NX + 4 * Q + x];
+            if (PAD > 0 && I == 0) bv = r < 0 ? 0.0 : bv;
+            return bv;
+        };
+        double BA[BA_REG ? NXT : 1][NT + 1];
+        {
+            double cur[PIPE1 ? NT : 1], nxt[PIPE1 ? NT : 1];
+            if (PIPE1)
+                W16_UNROLL for (int I = 0; I < NT; I++) cur[I] = ba_tile(0, I);
+            W16_UNROLL for (int Q = 0; Q < NXT; Q++)
             {
-                const double bv = ba_tile(Q, I);
-                if (BA_REG) BA[Q][I] = bv;
-                if (I & 1) acc1 += bv * vx[I]; else acc0 += bv * vx[I];
+                if (PIPE1 && Q + 1 < NXT)
+                    W16_UNROLL for (int I = 0; I < NT; I++) nxt[I] = ba_tile(Q + 1, I);
+                if (!ROOMY) W16R_FENCE();
+                double acc0 = 0.0, acc1 = 0.0;
+                W16_UNROLL for (int I = 0; I < NT; I++)
+                {
+                    const double bv = PIPE1 ? cur[I] : ba_tile(Q, I);
+                    if (BA_REG) BA[Q][I] = bv;
+                    if (I & 1) acc1 += bv * vx[I]; else acc0 += bv * vx[I];
+                }
+                if (ROOMY) racc[Q] = acc0 + acc1;
+                else rby[Q] += mfma4_qsum(acc0 + acc1); /* b - x+ + [B A] v, the same in the four lanes of a quad */
+                if (PIPE1)
+                    W16_UNROLL for (int I = 0; I < NT; I++) cur[I] = nxt[I];
             }
-            if (ROOMY) racc[Q] = acc0 + acc1;
-            else rby[Q] += mfma4_qsum(acc0 + acc1); /* b - x+ + [B A] v, the same in the four lanes of a quad */
         }
         W16R_TICK(3);
         /* [B A]' pi+ by variable tile row: tiles of [B A]' as they lie, operand by x */
-        W16_UNROLL for (int I = 0; I < NT; I++)
         {
-            if (!ROOMY) W16R_FENCE();
-            const int r = 4 * I + y - PAD;
-            double acc0 = 0.0, acc1 = 0.0;
-            W16_UNROLL for (int Q = 0; Q < NXT; Q++)
+            double cur[PIPE1 ? NXT : 1], nxt[PIPE1 ? NXT : 1];
+            if (PIPE1)
+                W16_UNROLL for (int Q = 0; Q < NXT; Q++) cur[Q] = bt_tile(0, Q);
+            W16_UNROLL for (int I = 0; I < NT; I++)
             {
-                double bv = BRq[(r > 0 ? r : 0) * NX + 4 * Q + x];
-                if (PAD > 0 && I == 0) bv = r < 0 ? 0.0 : bv;
-                if (Q & 1) acc1 += bv * pix[Q]; else acc0 += bv * pix[Q];
-            }
-            if (ROOMY) bacc[I] = acc0 + acc1;
-            else
-            {
-                const double t = mfma4_qsum(acc0 + acc1);
-                if (x == 0) VXB[4 * I + y] = t;
+                if (PIPE1 && I + 1 < NT)
+                    W16_UNROLL for (int Q = 0; Q < NXT; Q++) nxt[Q] = bt_tile(I + 1, Q);
+                if (!ROOMY) W16R_FENCE();
+                double acc0 = 0.0, acc1 = 0.0;
+                W16_UNROLL for (int Q = 0; Q < NXT; Q++)
+                {
+                    const double bv = PIPE1 ? cur[Q] : bt_tile(I, Q);
+                    if (Q & 1) acc1 += bv * pix[Q]; else acc0 += bv * pix[Q];
+                }
+                if (ROOMY) bacc[I] = acc0 + acc1;
+                else
+                {
+                    const double t = mfma4_qsum(acc0 + acc1);
+                    if (x == 0) VXB[4 * I + y] = t;
+                }
+                if (PIPE1)
+                    W16_UNROLL for (int Q = 0; Q < NXT; Q++) cur[Q] = nxt[Q];
             }
         }
         if (ROOMY)
@@ -509,15 +550,31 @@ __global__ void __launch_bounds__(64) W16T_WPE(NX, NU, NG) kt_factor(GqpDev D, G
          * that of W' gets lx+ added: w0 = lx+ + Lx+' rb ---- */
         double rbt[NXT]; /* the rhs column of [B A | rb] */
         W16_UNROLL for (int Q = 0; Q < NXT; Q++) rbt[Q] = x == 0 ? rby[Q] : 0.0;
+        /* (!BA_REG: the tiles of [B A] come from LDS one tile row ahead of the products that use them -- the row of the next
+         * (C, Q) pair is requested before the products of this one are issued, across the update of M as well; with all reads of a
+         * pair in front of its own products every pair exposed an LDS round trip: 21 of them per stage at nx = 24) */
+        constexpr bool BA_PIPE = !BA_REG && !W16TShape<NX, NU, NG>::TWO_WAVES; /* (at two waves per SIMD the second row in flight is the spill; the other wave covers the round trip there) */
+        double bcur[BA_PIPE ? NT : 1], bnxt[BA_PIPE ? NT : 1];
+        if (BA_PIPE)
+            W16_UNROLL for (int I = 0; I < NT; I++) bcur[I] = ba_tile(0, I);
         W16_UNROLL for (int C = 0; C < NXT; C++)
         {
             double WT[NT + 1];
             W16_UNROLL for (int I = 0; I <= NT; I++) WT[I] = (I == NT && x == 0) ? lxy[C] : 0.0;
             W16_UNROLL for (int Q = C; Q < NXT; Q++)
             {
-                if (!BA_REG) W16R_FENCE(); /* (the tiles of one row of [B A] in flight, not all of them) */
-                W16_UNROLL for (int I = 0; I < NT; I++) WT[I] = gqp_mfma4(Lx[Q][C], BA_REG ? BA[Q][I] : ba_tile(Q, I), WT[I]);
+                if (BA_PIPE)
+                {
+                    const int Qn = Q + 1 < NXT ? Q + 1 : C + 1; /* the next pair: (C, Q + 1), or (C + 1, C + 1) behind the last row */
+                    if (Qn < NXT)
+                        W16_UNROLL for (int I = 0; I < NT; I++) bnxt[I] = ba_tile(Qn, I);
+                    W16R_FENCE();
+                }
+                else if (!BA_REG) W16R_FENCE(); /* (the tiles of one row of [B A] in flight, not all of them) */
+                W16_UNROLL for (int I = 0; I < NT; I++) WT[I] = gqp_mfma4(Lx[Q][C], BA_REG ? BA[Q][I] : (BA_PIPE ? bcur[I] : ba_tile(Q, I)), WT[I]);
                 WT[NT] = gqp_mfma4(Lx[Q][C], rbt[Q], WT[NT]);
+                if (BA_PIPE)
+                    W16_UNROLL for (int I = 0; I < NT; I++) bcur[I] = bnxt[I];
             }
             W16_UNROLL for (int J = 0; J < NT; J++)
             {

@@ -445,6 +445,10 @@ def other_configs(c2_batch, c2_data, args):
     fill_chain_soft_batch(g4, d4, N4)
     out["C4"] = run_config(f"chain nx=24 nu=3, 4 soft state bounds + 4 soft general rows, ns=8, N=40 (BASELINE configs[3]), batch {B4}",
                            g4, lambda i: chain_soft_instance_qp(d4, i, N4), N4, chain_soft_dims(N4), steps=2, check=args.check_configs, section=2)
+    out["C4"]["mfma"] = dict(MFMA_PROBES, used=bool(g4.scalar("w16_tiles")),
+                             kernels={"kt_factor<24,3,4> (Riccati factor sweep with general rows + slacks on 4 x 4 tiles; M += A' diag(gamma) A "
+                                      "of the general rows as one more chain of tile products)": bool(g4.scalar("w16_tiles"))},
+                             tile_fill="n = 27 -> 28 = 7 tiles (one padding row), nx = 24 = 6 tiles: 0.96")
     # the same batch at the plain 1e-8 exit (tol_comp_soft_scale 1): what the default exit rule of a soft-constrained class
     # costs, and the ball it removes
     g4.opts_set("tol_comp_soft_scale", 1.0)
