@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(64) W16T_WPE(NX, NU, NG) kt_factor(GqpDev D, G
     c_bm = n_bm; c_em = n_em; c_nb = n_nb; c_oct = n_oct; c_ng = n_ng; c_og = n_og; c_ns = n_ns; c_os = n_os;
     dma_h(D.N);
     dma_b(D.N);
-    if (!GEN) prefetch_v(D.N);
+    prefetch_v(D.N);
     load_desc(D.N > 0 ? D.N - 1 : 0);
 
     /* natural tiles of the state block of the factor of stage k + 1 (Q >= C) and its rhs part by y (lanes x == 0) */
@@ -227,10 +227,9 @@ __global__ void __launch_bounds__(64) W16T_WPE(NX, NU, NG) kt_factor(GqpDev D, G
         /* (the lane's base addresses in the ~15 arrays of the stage are loop invariant: hoisted, they live across the register
          * peak and are spilled -- recomputed per stage instead, as in the GEN instantiations of ky_factor) */
         W16R_OPAQUE(inst); W16R_OPAQUE(l);
-        /* GEN: the vectors and the general rows of the stage are loaded HERE, in front of the wait for the DMA'd blocks (one
-         * exposed latency), not a stage ahead: the register file of this variant has no room for values that live across a
-         * stage (ky_factor, same place) */
-        if (GEN) prefetch_v(k);
+        /* (GEN: ky_factor loads the vectors and the general rows of the stage at this point, one exposed latency per stage -- its
+         * register file has no room for values that live across a stage.  Here they are requested a stage ahead like the box
+         * shapes', behind the per-variable work, where the row functions' registers are free again) */
         W16R_DMA_WAIT(); /* everything issued for this stage has landed */
         W16R_TICK(0);
         const uint64_t bmask = c_bm, emask = c_em, imask = bmask & ~emask, am = p_am;
@@ -473,7 +472,7 @@ __global__ void __launch_bounds__(64) W16T_WPE(NX, NU, NG) kt_factor(GqpDev D, G
         auto next_stage_vectors = [&]()
         {
             c_bm = x_bm; c_em = x_em; c_nb = x_nb; c_oct = x_oct; c_ng = x_ng; c_og = x_og; c_ns = x_ns; c_os = x_os;
-            if (!GEN) prefetch_v(k - 1); /* GEN: at the top of the stage, see there */
+            prefetch_v(k - 1);
             load_desc(k > 1 ? k - 2 : 0);
         };
         if (BA_REG && k > 0) dma_b(k - 1);
