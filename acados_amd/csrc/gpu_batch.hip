@@ -1020,6 +1020,10 @@ static void set_stream_priority(ocp_qp_gpu_batch *b, int prio)
     HIPCHK(hipStreamDestroy(b->stream));
     HIPCHK(hipStreamCreateWithPriority(&b->stream, hipStreamDefault, p));
     b->stream_priority = prio;
+    /* sub-batches that exist already and launch on streams of their own (the sensitivity slices, the condensed batch) follow;
+     * the ones created later take the priority at creation (round-3 advice) */
+    if (b->sens_child) set_stream_priority(b->sens_child, prio);
+    if (b->child) set_stream_priority(b->child, prio);
 }
 
 int ocp_qp_gpu_batch_opts_set(ocp_qp_gpu_batch *b, const char *f, const void *v)
@@ -1059,8 +1063,7 @@ try
     {
         /* several batches solved concurrently from host threads (the C5 classes): the long ones on a high-priority
          * stream (negative value, clamped to the device's range) are dispatched first, the short ones fill the gaps */
-        set_stream_priority(b, *i);
-        if (b->child) set_stream_priority(b->child, *i);
+        set_stream_priority(b, *i); /* (the condensed batch and the sensitivity slices follow inside) */
         if (b->tail) set_stream_priority(b->tail, *i);
     }
     else if (!strcmp(f, "compact_min")) b->compact_min = *i;
