@@ -1,6 +1,7 @@
 /*
- * ipm_kernels_w16t.hpp -- the FACTOR SWEEP of the two-rows family (17 <= nu + nx <= 32, box rows: the condensed C3 shape,
- * the nx = 24 classes of C5) with its three O(n^3) parts on the FP64 matrix pipe, v_mfma_f64_4x4x4_4b_f64.
+ * ipm_kernels_w16t.hpp -- the FACTOR SWEEP of the two-rows family (17 <= nu + nx <= 32: the condensed C3 shape, the nx = 24
+ * classes of C5, and with general rows + slacks C4) with its three O(n^3) parts on the FP64 matrix pipe,
+ * v_mfma_f64_4x4x4_4b_f64.
  *
  * ky_factor (ipm_kernels_w16r.hpp) feeds every two multiply-adds with one DPP row broadcast: W = [B A]' Lx+, M += W W' and the
  * Cholesky are 28 k of its 58 k cycles per stage at n = 30 (profiles/r03_w16r_phase_cycles.txt), bound by the issue of
@@ -8,7 +9,7 @@
  * instruction at 17-19 cycles for 512 flops (profiles/r04_mfma4x4x4_probe.txt), needs no broadcast at all, and its four
  * blocks are exactly the four instances a wavefront of this family carries.  So this kernel keeps ky_factor's contract --
  * same HBM arrays in and out (the packed factor Lf / lf the other three sweeps read), same LDS-DMA staging one stage ahead,
- * same per-variable arithmetic, one wave per SIMD -- and changes the mapping inside the stage:
+ * same per-variable arithmetic -- and changes the mapping inside the stage:
  *
  *   lanes     block b = (lane >> 2) & 3 = instance; inside it x = lane & 3, y = lane >> 4 (mfma4.hpp).  Matrices are 4 x 4
  *             tiles in the D layout (lane (x, y) holds [y][x]); gqp_mfma4(P, Q, C) = C + P' Q.
@@ -31,8 +32,15 @@
  *             lane l = x + 4 y of the block owns variables l and l + 16); H v, [B A] v, [B A]' pi+ are tile products on the
  *             vector pipe (operand by x, result by y after a quad sum); three small exchanges through LDS per stage move
  *             vectors between the compact form and the by-x / by-y forms.
- * Same results as ky_factor up to the order of the floating-point sums (ACADOS_AMD_W16T=0 keeps ky_factor; both test tiers
- * compare the two).  General rows and slacks (the GEN instantiations) stay with ky_factor.
+ *   waves     nx = 24 (box and GEN): one wave per SIMD at ~480-510 registers, tiles of [B A] re-read from LDS by the W product,
+ *             the LDS reads of tile row r + 1 issued in front of the work of row r, the next stage's vectors requested behind the
+ *             per-variable work.  The C3 shape: TWO waves per SIMD at 256 registers (W16TShape), and with them HBM-bound like
+ *             the three other sweeps of that shape.
+ *   GEN       general rows + slacks (NG > 0, C4): the branch-free row functions of ky_factor unchanged (one inequality row per
+ *             lane of the block, before the tiles of H are loaded); a general row's a'v is one more tile row of the
+ *             vector-pipe product, M += A' diag(gamma) A one more chain of tile products.
+ * Same results as ky_factor up to the order of the floating-point sums (ACADOS_AMD_W16T=0 / ACADOS_AMD_W16T_GEN=0 keep ky_factor;
+ * both test tiers compare the two).  Measurements: DESIGN.md 4.6, profiles/NOTES.md (round 4).
  */
 #ifndef IPM_KERNELS_W16T_HPP_
 #define IPM_KERNELS_W16T_HPP_
