@@ -223,18 +223,23 @@ def _check_batch_vs_oracle_gpu(qps, n_check, tol=1e-8, tol_stat=1e-8):
     return b
 
 
-@pytest.mark.parametrize("fam", ["w16r-gen<NX=24,NU=3,NG=4>", "wpi-gen(nx=24,nu=3,ng=4,ns=8"])
+@pytest.mark.parametrize("fam", ["w16r-gen<NX=24,NU=3,NG=4>", "w16r-gen<NX=24,NU=3,NG=4>/rows", "wpi-gen(nx=24,nu=3,ng=4,ns=8"])
 def test_c4_chain_soft_constraints_gpu(gpu_lib, monkeypatch, fam):
     """C4 shape: N=40 nx=24 nu=3, hard input bounds, soft state bounds, soft general rows, ns=8 -- on the two-rows-per-lane
-    GEN kernels (default) and on the wave-per-instance GEN kernels"""
+    GEN kernels with the factor sweep on 4 x 4 MFMA tiles (kt_factor<24,3,4>, the default) or on register rows ("/rows":
+    ky_factor<24,3,4>, ACADOS_AMD_W16T_GEN=0), and on the wave-per-instance GEN kernels"""
     from acados_amd.generators import chain_soft_qp
     monkeypatch.setenv("ACADOS_AMD_W16G", "1" if fam.startswith("w16r") else "0")
+    monkeypatch.setenv("ACADOS_AMD_W16T_GEN", "0" if fam.endswith("/rows") else "1")
+    rows, fam = fam.endswith("/rows"), fam.split("/")[0]
     # all four tolerances at 1e-8 (what ocp_nlp sets, ocp_nlp_common.c:1281-1293).  Instance 53 is the one
     # that used to stall at res_stat ~1e-5 with mu at 1e-16 until the slack block was eliminated in its
     # cancellation-free form (DESIGN.md): it is part of the batch on purpose.
     qps = [chain_soft_qp(i, N=40) for i in range(96)]
     b = _check_batch_vs_oracle_gpu(qps, 4, tol=1e-7, tol_stat=1e-8)
     assert b.kernel_name.startswith(fam)
+    if fam.startswith("w16r"):
+        assert int(b.scalar("w16_tiles")) == (0 if rows else 1)
     o = OracleQp(qps[53])
     assert o.solve(default_opts(tol_stat=1e-8)) == 0
     compare_with_oracle(lambda k, f: b.get(f, k)[53], o, qps[53], 1e-7)

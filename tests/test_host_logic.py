@@ -1093,19 +1093,26 @@ def test_two_rows_per_lane_general_rows_and_slacks_hostsim(hostsim_lib, monkeypa
     N, B = 3, 5
     qps = [chain_soft_qp(i, N=N) for i in range(B)]
     sols = {}
-    for fam in ("1", "0"):
-        monkeypatch.setenv("ACADOS_AMD_W16G", fam)
+    # "1": the default (factor sweep on 4 x 4 MFMA tiles, kt_factor<24,3,4>); "rows": the same family with the factor sweep on
+    # register rows (ky_factor<24,3,4>, ACADOS_AMD_W16T_GEN=0); "0": the wave-per-instance GEN kernels
+    for fam in ("1", "rows", "0"):
+        monkeypatch.setenv("ACADOS_AMD_W16G", "0" if fam == "0" else "1")
+        monkeypatch.setenv("ACADOS_AMD_W16T_GEN", "0" if fam == "rows" else "1")
         g = OcpQpGpuBatch.from_qps(qps, _clib=hostsim_lib)
         for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
             g.opts_set(f, 1e-8)
         assert g.solve() == 0
-        assert g.kernel_name.startswith("w16r-gen<NX=24,NU=3,NG=4>" if fam == "1" else "wpi-gen(")
+        assert g.kernel_name.startswith("wpi-gen(" if fam == "0" else "w16r-gen<NX=24,NU=3,NG=4>")
+        if fam != "0":
+            assert g.scalar("w16_tiles") == (1 if fam == "1" else 0)
         sols[fam] = ([g.get(f, k) for f in ("x", "u", "lam", "sl", "su") for k in range(N + 1)] + [g.get("pi", k) for k in range(N)],
                      np.array(g.info("iter")))
-    assert np.array_equal(sols["1"][1], sols["0"][1])
-    for a, c in zip(sols["1"][0], sols["0"][0]):
-        if a.size:
-            np.testing.assert_allclose(a, c, rtol=1e-9, atol=1e-9)
+    monkeypatch.delenv("ACADOS_AMD_W16T_GEN")
+    for other in ("rows", "0"):
+        assert np.array_equal(sols["1"][1], sols[other][1])
+        for a, c in zip(sols["1"][0], sols[other][0]):
+            if a.size:
+                np.testing.assert_allclose(a, c, rtol=1e-9, atol=1e-9)
     monkeypatch.setenv("ACADOS_AMD_W16G", "1")
     qp = chain_soft_qp(0, N=N)
     rev = np.array(qp.idxs_rev[1]).copy()
