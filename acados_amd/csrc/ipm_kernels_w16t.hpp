@@ -45,7 +45,6 @@
 #ifndef IPM_KERNELS_W16T_HPP_
 #define IPM_KERNELS_W16T_HPP_
 
-#include <type_traits>
 #include "ipm_kernels_w16r.hpp"
 #include "mfma4.hpp"
 
@@ -67,17 +66,6 @@ struct W16TLds
     static constexpr int VC = NG > 0 ? RW : VC_OWN;
     static constexpr int SZ = ((NG > 0 ? RI + 8 : GT) + 1) & ~1;
 };
-
-/* f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a constant expression in the body */
-template <int N, int I = 0, class F>
-__device__ static inline void w16t_static_for(F &&f)
-{
-    if constexpr (I < N)
-    {
-        f(std::integral_constant<int, I>{});
-        w16t_static_for<N, I + 1>(f);
-    }
-}
 
 /* max / sum over the sixteen lanes of a block (once per launch): through LDS */
 __device__ static inline double w16t_bmax(double v, double *vx, int l)
@@ -118,10 +106,8 @@ struct W16TShape
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
-#define W16T_INLINE __attribute__((always_inline))
 #define W16T_WPE(NX, NU, NG) __attribute__((amdgpu_waves_per_eu(W16TShape<NX, NU, NG>::WPE, W16TShape<NX, NU, NG>::WPE)))
 #else
-#define W16T_INLINE
 #define W16T_WPE(NX, NU, NG)
 #endif
 template <int NX, int NU, int NG = 0>
@@ -650,151 +636,6 @@ __global__ void __launch_bounds__(64) W16T_WPE(NX, NU, NG) kt_factor(GqpDev D, G
             /* rows of the diagonal block to every 16-lane row: r_j = row j of the block, indexed by x */
             r0 = gqp_mfma4(e4[0], dg, 0.0); r1 = gqp_mfma4(e4[1], dg, 0.0); r2 = gqp_mfma4(e4[2], dg, 0.0); r3 = gqp_mfma4(e4[3], dg, 0.0);
         };
-#if defined(W16T_INTERLEAVE)
-        /* development variant: the products that do not feed the next diagonal block issued from INSIDE its chain, one behind
-         * every few dependent vector instructions, each slot closed by a scheduling fence so that the order stands */
-        auto rsq_e = [&](double d, auto &&emit) W16T_INLINE -> double
-        {
-#if defined(__HIP_DEVICE_COMPILE__)
-            double yv = __builtin_amdgcn_rsq(d);
-            const double h = 0.5 * d;
-            emit();
-            double e = __builtin_fma(-h * yv, yv, 0.5);
-            emit();
-            yv = __builtin_fma(yv, e, yv);
-            emit();
-            e = __builtin_fma(-h * yv, yv, 0.5);
-            emit();
-            yv = __builtin_fma(yv, e, yv);
-            W16R_OPAQUE(yv);
-            return yv;
-#else
-            emit(); emit(); emit(); emit();
-            return frsqrt(d);
-#endif
-        };
-        auto diag4 = [&](double r0, double r1, double r2, double r3, double &ut, double &G, auto &&emit) W16T_INLINE
-        {
-            const double d0 = mfma4_qbc<0>(r0);
-            emit();
-            const double t0 = rsq_e(d0, emit);
-            const double i0 = d0 > 0.0 ? t0 : 0.0;
-            const double lx0 = r0 * i0;
-            emit();
-            const double l10 = mfma4_qbc<1>(lx0), l20 = mfma4_qbc<2>(lx0), l30 = mfma4_qbc<3>(lx0);
-            emit();
-            const double s1 = r1 - l10 * lx0;
-            const double d1 = mfma4_qbc<1>(s1);
-            emit();
-            const double t1 = rsq_e(d1, emit);
-            const double i1 = d1 > 0.0 ? t1 : 0.0;
-            const double lx1 = s1 * i1;
-            emit();
-            const double l21 = mfma4_qbc<2>(lx1), l31 = mfma4_qbc<3>(lx1);
-            emit();
-            const double s2 = (r2 - l20 * lx0) - l21 * lx1;
-            const double d2 = mfma4_qbc<2>(s2);
-            emit();
-            const double t2 = rsq_e(d2, emit);
-            const double i2 = d2 > 0.0 ? t2 : 0.0;
-            const double lx2 = s2 * i2;
-            emit();
-            const double l32 = mfma4_qbc<3>(lx2);
-            emit();
-            const double s3 = ((r3 - l30 * lx0) - l31 * lx1) - l32 * lx2;
-            const double d3 = mfma4_qbc<3>(s3);
-            emit();
-            const double t3 = rsq_e(d3, emit);
-            const double i3 = d3 > 0.0 ? t3 : 0.0;
-            const double lx3 = s3 * i3;
-            emit();
-            const double uj = y == 0 ? lx0 : (y == 1 ? lx1 : (y == 2 ? lx2 : lx3));
-            ut = x >= y ? uj : 0.0;
-            emit();
-            const double n10 = -l10 * i0 * i1, n21 = -l21 * i1 * i2, n32 = -l32 * i2 * i3;
-            emit();
-            const double n20 = -(l20 * i0 + l21 * n10) * i2, n31 = -(l31 * i1 + l32 * n21) * i3;
-            emit();
-            const double n30 = -(l30 * i0 + l31 * n10 + l32 * n20) * i3;
-            emit();
-            const double gc0 = x == 0 ? i0 : (x == 1 ? n10 : (x == 2 ? n20 : n30));
-            const double gc1 = x == 1 ? i1 : (x == 2 ? n21 : n31);
-            const double gc2 = x == 2 ? i2 : n32;
-            emit();
-            const double gsel = y == 0 ? gc0 : (y == 1 ? gc1 : (y == 2 ? gc2 : i3));
-            G = x >= y ? gsel : 0.0;
-        };
-        constexpr int SITES = 36; /* issue slots of one chain (rsq_e: 4 each) */
-        double G, ut;
-        {
-            double r0, r1, r2, r3;
-            rows4(MT[0][0], r0, r1, r2, r3);
-            diag4(r0, r1, r2, r3, ut, G, [] {});
-        }
-        w16t_static_for<NT>([&](auto Jc) W16T_INLINE
-        {
-            constexpr int J = decltype(Jc)::value; /* (a constant expression: the loops below must unroll before anything else, or the tiles end up indexed in memory) */
-            MT[J][J] = ut;
-            const double Gj = G;
-            double r0 = 0.0, r1 = 0.0, r2 = 0.0, r3 = 0.0, nu[NT];
-            W16_UNROLL for (int K = 0; K < NT; K++) nu[K] = 0.0;
-            if (J + 1 < NT)
-            {
-                MT[J][J + 1] = gqp_mfma4(Gj, MT[J][J + 1], 0.0);
-                nu[J + 1] = -MT[J][J + 1];
-                MT[J + 1][J + 1] = gqp_mfma4(nu[J + 1], MT[J][J + 1], MT[J + 1][J + 1]);
-                rows4(MT[J + 1][J + 1], r0, r1, r2, r3);
-            }
-            constexpr int nrest = (NT - J - 2 > 0 ? NT - J - 2 : 0) + 1 + (J + 1 < NT ? NT - J - 1 : 0)
-                                  + (NT - J - 2 > 0 ? (NT - J - 2) * (NT - J - 1) / 2 + (NT - J - 2) : 0) + (J >= XT0 ? NT - J : 0);
-            auto rest_one = [&](int q) W16T_INLINE
-            {
-                int c = 0;
-                W16_UNROLL for (int I = J + 2; I < NT; I++)
-                    if (c++ == q) MT[J][I] = gqp_mfma4(Gj, MT[J][I], 0.0);
-                if (c++ == q) MTr[J] = gqp_mfma4(Gj, MTr[J], 0.0);
-                if (J + 1 < NT)
-                {
-                    W16_UNROLL for (int I = J + 2; I < NT; I++)
-                        if (c++ == q) MT[J + 1][I] = gqp_mfma4(nu[J + 1], MT[J][I], MT[J + 1][I]);
-                    if (c++ == q) MTr[J + 1] = gqp_mfma4(nu[J + 1], MTr[J], MTr[J + 1]);
-                }
-                W16_UNROLL for (int K = J + 2; K < NT; K++)
-                {
-                    W16_UNROLL for (int I = K; I < NT; I++)
-                        if (c++ == q)
-                        {
-                            if (I == K) nu[K] = -MT[J][K];
-                            MT[K][I] = gqp_mfma4(nu[K], MT[J][I], MT[K][I]);
-                        }
-                    if (c++ == q) MTr[K] = gqp_mfma4(nu[K], MTr[J], MTr[K]);
-                }
-                if (J >= XT0)
-                    W16_UNROLL for (int Q = J - XT0; Q < NXT; Q++)
-                        if (c++ == q) Lx[Q][J - XT0] = gqp_mfma4(MT[J][XT0 + Q], i4, 0.0);
-            };
-            int qn = 0;
-            constexpr int per = (nrest + SITES - 1) / SITES;
-            auto emit = [&]() W16T_INLINE
-            {
-                W16_UNROLL for (int r = 0; r < per; r++) { rest_one(qn); qn++; }
-                W16R_FENCE();
-            };
-            if (J + 1 < NT) diag4(r0, r1, r2, r3, ut, G, emit);
-            W16_UNROLL for (int r = 0; r < nrest; r++)
-                if (r >= qn) rest_one(r);
-            if (J >= XT0) lxy[J - XT0] = MTr[J];
-            {
-                const int c = 4 * J + y - PAD;
-                W16_UNROLL for (int I = J; I < NT; I++)
-                {
-                    const int r = 4 * I + x - PAD;
-                    if (alive && c >= 0 && r >= c) WAT(D.Lf, k * NP + PK(r, c)) = MT[J][I];
-                }
-                if (alive && x == 0 && c >= 0) WAT(D.lf, k * n + c) = MTr[J];
-            }
-        });
-#else
         auto diag4 = [&](double r0, double r1, double r2, double r3, double &ut, double &G)
         {
             /* 4 x 4 Cholesky, every lane for its x: lxj = L[x][j]; a non-positive pivot zeroes its column (as ky_factor; the
@@ -885,7 +726,6 @@ __global__ void __launch_bounds__(64) W16T_WPE(NX, NU, NG) kt_factor(GqpDev D, G
                 if (alive && x == 0 && c >= 0) WAT(D.lf, k * n + c) = MTr[J];
             }
         }
-#endif
         W16R_TICK(10);
         W16R_TICK(12);
     }
