@@ -231,11 +231,12 @@ def mark_stale(tr):
     return tr
 
 
-def mfma_util():
-    """newest profiles/rNN_vM_mfma_util.json (tools/profile_mfma.sh: rocprofv3 PMC SQ_INSTS_MFMA / SQ_VALU_MFMA_BUSY_CYCLES /
-    GRBM_GUI_ACTIVE over one C3 solve): matrix-pipe utilisation of the kernels that issue MFMAs"""
+def mfma_util(suffix=""):
+    """newest profiles/rNN_vM_mfma_util<suffix>.json (tools/profile_mfma.sh: rocprofv3 PMC SQ_INSTS_MFMA / SQ_VALU_MFMA_BUSY_CYCLES /
+    GRBM_GUI_ACTIVE over one C3 solve; suffix "_c4_c5": tools/profile_mfma_c4_c5.sh, the C4 batch and the nx=24 nu=6 N=50 class):
+    matrix-pipe utilisation of the kernels that issue MFMAs"""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_mfma_util.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_mfma_util{suffix}.json")))
     if not files:
         return None
     try:
@@ -448,7 +449,8 @@ def other_configs(c2_batch, c2_data, args):
     out["C4"]["mfma"] = dict(MFMA_PROBES, used=bool(g4.scalar("w16_tiles")),
                              kernels={"kt_factor<24,3,4> (Riccati factor sweep with general rows + slacks on 4 x 4 tiles; M += A' diag(gamma) A "
                                       "of the general rows as one more chain of tile products)": bool(g4.scalar("w16_tiles"))},
-                             tile_fill="n = 27 -> 28 = 7 tiles (one padding row), nx = 24 = 6 tiles: 0.96")
+                             tile_fill="n = 27 -> 28 = 7 tiles (one padding row), nx = 24 = 6 tiles: 0.96",
+                             utilisation=mfma_util("_c4_c5"))
     # the same batch at the plain 1e-8 exit (tol_comp_soft_scale 1): what the default exit rule of a soft-constrained class
     # costs, and the ball it removes
     g4.opts_set("tol_comp_soft_scale", 1.0)
