@@ -144,7 +144,7 @@ struct ocp_qp_gpu_batch
     GqpDev D = {};
     GqpOpts O;
     bool has_slack = false;            /* some stage has slack variables (set with the dims) */
-    double tol_comp_soft_scale = 1e-3; /* effective_opts: exit tolerance on complementarity of a soft-constrained class */
+    double tol_comp_soft_scale = 1.0; /* effective_opts: opt-in tighter exit on complementarity of a soft-constrained class (1 = the tolerance as given, the reference's semantics) */
     int nct_tot = 0, ns2_tot = 0, ng_tot = 0;
     std::vector<void *> allocs;
     size_t bytes = 0;
@@ -258,8 +258,9 @@ void opts_default(GqpOpts &o)
 }
 
 /* options as the kernels see them.
- * (1) Soft-constrained classes (any stage with slacks): the complementarity tolerance the exit test uses is
- *     tol_comp * tol_comp_soft_scale (default 1e-3, option "tol_comp_soft_scale", 1 = off).  A soft row with a small
+ * (1) OPT-IN (option "tol_comp_soft_scale", default 1 = off: the solver stops at the tol_comp it is given, as HPIPM does,
+ *     ocp_qp_hpipm.c:104-107).  With a value < 1, soft-constrained classes (any stage with slacks) use
+ *     tol_comp * tol_comp_soft_scale in the exit test.  Why one may want it: a soft row with a small
  *     multiplier lam* sits at t = mu / lam* on the central path, and with slack penalties of 1e2 the primal solution is
  *     flat: at mu ~ 1e-8 the C4 iterate is a median 3e-7 / worst 1e-4 (relative) away from the exact solution although
  *     all four KKT residuals are <= 1e-8 (profiles/r04_c4_distance_to_solution.txt) -- two solvers stopping inside that
@@ -357,6 +358,7 @@ void finalize_structure(ocp_qp_gpu_batch *b)
             b->w16 = 0;
             b->w16_solve = nullptr;
             b->w16_soft = false;
+            b->w16_tiles = 0;
             char nm[160];
             snprintf(nm, sizeof(nm), "wpi-gen(nx=%d,nu=%d,ng=%d,ns=%d,lds=%zuB)", b->ks->NX, b->ks->NU, b->ks->NG, b->ks->NS, b->shmem_fact);
             b->kname = nm;

@@ -805,7 +805,7 @@ void ocp_qp_gpu_ipm_opts_initialize_default(void *config, void *dims, void *opts
     gpu_ipm_mode_defaults(o);
     o->print_level = 0;
     o->tau_min = 0.0; /* m_relax, ocp_qp_hpipm.c:126 */
-    o->tol_comp_soft_scale = 1e-3;
+    o->tol_comp_soft_scale = 1.0; /* opt-in (< 1): tighter complementarity exit for soft-constrained QPs; 1 = the reference's semantics */
     o->noticed = 0;
 }
 

@@ -71,6 +71,113 @@ def git_head():
             return None
 
 
+LINE_LIMIT = 4096      # bytes; the driver keeps an 8 KB tail of stdout and parses its LAST line (round 4's 22 KB line was lost)
+
+
+def _r(v, sig=5):
+    """floats at `sig` significant digits (the detail file keeps full precision)"""
+    if isinstance(v, float):
+        return float(f"{v:.{sig}g}") if np.isfinite(v) else None
+    return v
+
+
+def _pick(d, keys, sig=5):
+    return {k: _r(d[k], sig) for k in keys if isinstance(d, dict) and k in d and not isinstance(d[k], (dict, list))}
+
+
+def compact_line(out, detail_path=None):
+    """The ONE line the driver parses: headline fields, `config`, `ipm`, `roofline` (scalars + the source of the PMC traffic),
+    `cpu_baseline` (value, cores, kind, sample, one_thread) and one short record per other configuration.  Everything else
+    (per-class tables, launch histograms, MFMA probe notes, oracle distance statistics, gather detail) goes to the detail file
+    named in `detail`.  Asserted < LINE_LIMIT by tests/test_bench_line.py on the committed round-4 line."""
+    head = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line = {k: _r(out[k], 7) for k in head if k in out}
+    cfg = out.get("config", {})
+    line["config"] = {k: cfg[k] for k in ("workload", "batch_per_gpu", "global_batch", "parallelism", "kernel", "commit") if k in cfg}
+    if "ipm" in out:
+        line["ipm"] = _pick(out["ipm"], ("mean_iter", "max_iter", "failures", "max_kkt_residual_independent", "max_rel_primal_err_vs_oracle",
+                                         "oracle_checked_instances", "launches_per_step", "wave_max_iter_mean"), 4)
+        if out["ipm"].get("iter_hist"):
+            line["ipm"]["iter_hist"] = out["ipm"]["iter_hist"]
+    ro = out.get("roofline")
+    if ro:
+        r = _pick(ro, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "bytes_per_launch",
+                       "avg_launch_ms", "launches_timed", "whole_solve_frac"))
+        ts = ro.get("traffic_source")
+        r["traffic_source"] = _pick(ts, ("file", "commit", "stale")) if ts else None
+        fl = ro.get("full_launch")
+        if fl:
+            r["full_launch_traffic_over_algorithmic"] = _r(fl.get("traffic_over_algorithmic"))
+        mf = ro.get("mfma")
+        if mf:
+            r["mfma_utilisation"] = mf.get("mfma_utilisation")
+        line["roofline"] = r
+    cb = out.get("cpu_baseline")
+    if cb:
+        c = _pick(cb, ("value", "unit", "cores", "kind", "one_thread", "mean_iter"))
+        c["sample"] = f"{cb.get('unique', '')} C2 instances (seed 0), OpenMP over instances, restated CPU oracle (not HPIPM: sources absent)".strip()
+        line["cpu_baseline"] = c
+    if out.get("gather"):
+        line["gather"] = _pick(out["gather"], ("ms", "ranks", "GBps_received_per_rank", "slice_matches_getters", "gather_to_root_ms"), 4)
+    if "configs" in out:
+        cs = {}
+        for name, c in out["configs"].items():
+            ro_c = c.get("roofline") or c.get("roofline_of_slowest_class") or {}
+            rec = _pick(c, ("batch", "solves_per_s", "ms_per_step", "mean_iter", "failures", "max_rel_primal_err_vs_oracle",
+                            "condense_expand_ms", "solves_per_s_one_after_the_other"), 4)
+            rec.update({"frac": _r(ro_c.get("frac"), 3), "traffic_over_algorithmic": _r(ro_c.get("traffic_over_algorithmic"), 3)})
+            mf = c.get("mfma") or {}
+            u = (mf.get("utilisation") or {}).get("kernels") if isinstance(mf.get("utilisation"), dict) else None
+            if u:
+                rec["mfma_utilisation"] = _r(max((k.get("mfma_utilisation") or 0.0) for k in u.values()), 3)
+            for leg in ("plain_exit", "tight_exit"):        # C4: the other exit rule (round 4 lines: plain_exit; now: tight_exit, opt-in)
+                if leg in c:
+                    rec[leg + "_solves_per_s"] = _r(c[leg].get("solves_per_s"), 4)
+            if "classes" in c:          # C5: one number per class, in the order of the detail file
+                rec["class_solves_per_s"] = [_r(k["solves_per_s"], 3) for k in c["classes"]]
+                rec["class_frac"] = [_r(k["frac"], 2) for k in c["classes"]]
+            cs[name] = {k: v for k, v in rec.items() if v is not None}
+        line["configs"] = cs
+    for k in ("failures", "pack_s", "hbm_bytes_per_gpu"):
+        if k in out and k not in line:
+            line[k] = _r(out[k], 4)
+    if detail_path:
+        line["detail"] = detail_path
+    s = json.dumps(line, separators=(",", ":"))
+    if len(s) >= LINE_LIMIT:           # never lose the line: drop the optional parts in order of weight
+        for k in ("configs", "gather", "ipm"):
+            if k == "configs" and "configs" in line:
+                line["configs"] = {n: _pick(c, ("solves_per_s", "frac", "failures"), 4) for n, c in line["configs"].items()}
+            else:
+                line.pop(k, None)
+            s = json.dumps(line, separators=(",", ":"))
+            if len(s) < LINE_LIMIT:
+                break
+    return s
+
+
+def emit(out, args):
+    """full object -> detail file, compact object -> the last line of stdout"""
+    path = getattr(args, "detail_file", None) or os.path.join(ROOT, "gpurun_out", "bench_detail.json")
+    rel = None
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(out, f, indent=1)
+        rel = os.path.relpath(path, ROOT)
+    except OSError:
+        pass
+    # the JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio when its first communicator
+    # comes up -- push that out first
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    print(compact_line(out, rel), flush=True)
+
+
 def kernel_symbol(name, cls, tiles=False):
     """profile class -> kernel function of the family `name` (a batch's kernel_name) runs on (what rocprofv3 lists);
     tiles: the factor sweep of the two-rows family runs on 4 x 4 MFMA tiles (kt_factor, scalar "w16_tiles")"""
@@ -352,7 +459,7 @@ def cpu_baseline(data, N, unique, budget_s=25.0):
     for c in clones:
         free_handle(c)
     cpu_baseline.solved = qps     # the same solutions double as the parity sample
-    return {"value": sweep[best_t], "unit": "OCP-QP solves/s", "cores": best_t, "kind": "port",
+    return {"value": sweep[best_t], "unit": "OCP-QP solves/s", "cores": best_t, "kind": "port", "unique": unique,
             "kind_note": "port = this repository's restated CPU oracle (plain C, scalar loops, no BLASFEO micro-kernels); HPIPM + BLASFEO sources "
                          "are absent from the reference tree, so the reference itself cannot be timed here.  Expect HPIPM on the same cores to be "
                          "several times faster than this port (its dpotrf / dsyrk / dtrmm run on AVX-512 panel-major kernels): the GPU / CPU "
@@ -451,22 +558,22 @@ def other_configs(c2_batch, c2_data, args):
                                       "of the general rows as one more chain of tile products)": bool(g4.scalar("w16_tiles"))},
                              tile_fill="n = 27 -> 28 = 7 tiles (one padding row), nx = 24 = 6 tiles: 0.96",
                              utilisation=mfma_util("_c4_c5"))
-    # the same batch at the plain 1e-8 exit (tol_comp_soft_scale 1): what the default exit rule of a soft-constrained class
-    # costs, and the ball it removes
-    g4.opts_set("tol_comp_soft_scale", 1.0)
+    # the same batch with the OPT-IN tighter exit of a soft-constrained class (tol_comp_soft_scale 1e-3: complementarity at
+    # 1e-11): what it costs, and the ball it removes
+    g4.opts_set("tol_comp_soft_scale", 1e-3)
     g4.solve()
     t0 = time.perf_counter()
     bad = g4.solve()
     dt = time.perf_counter() - t0
     it = g4.info("iter")
-    out["C4"]["exit_rule"] = {"tol_comp_soft_scale": 1e-3, "effective_tol_comp": 1e-11,
-                              "note": "soft-constrained classes iterate until complementarity <= tol_comp x 1e-3 (DESIGN.md 3); "
-                                      "plain_exit = the same batch stopped at 1e-8 x 4"}
-    out["C4"]["plain_exit"] = {"solves_per_s": B4 / dt, "ms_per_step": dt * 1e3, "mean_iter": float(it.mean()), "max_iter": int(it.max()),
+    out["C4"]["exit_rule"] = {"tol_comp_soft_scale": 1.0, "effective_tol_comp": 1e-8,
+                              "note": "default: the solver stops at the tol_comp it is given (ocp_qp_hpipm.c:104-107); tight_exit = the same "
+                                      "batch with the opt-in tol_comp_soft_scale 1e-3 (complementarity at 1e-11, DESIGN.md 3)"}
+    out["C4"]["tight_exit"] = {"solves_per_s": B4 / dt, "ms_per_step": dt * 1e3, "mean_iter": float(it.mean()), "max_iter": int(it.max()),
                                "failures": int(bad), "max_kkt_residual_independent": float(g4.res_compute().max())}
     if args.check_configs:
         idx = np.unique(np.linspace(0, B4 - 1, args.check_configs).astype(int))
-        out["C4"]["plain_exit"]["oracle_check"] = oracle_error(g4, lambda i: chain_soft_instance_qp(d4, i, N4), idx, N4)
+        out["C4"]["tight_exit"]["oracle_check"] = oracle_error(g4, lambda i: chain_soft_instance_qp(d4, i, N4), idx, N4)
     del g4, d4
     # C2 once more with complementarity at 1e-11 (a user's choice for a hard-constrained class): the distance to the solution is
     # the tolerance's -- at 1e-8 x 4 an IPM stops on the central path, t = mu / lam* on a weakly active row
@@ -637,29 +744,29 @@ def main_c5(args):
     per = [{"class": c, "instances": gb.n_batch, "kernel": gb.kernel_name, "ms": gb.scalar("time_tot") * 1e3,
             "iters_mean": float(gb.info("iter").mean()), "failures": int((gb.info("status") != 0).sum()),
             "max_kkt_residual_independent": float(gb.res_compute().max())} for c, gb in batches]
-    gathers = [gather_solutions(gb, dist, rank, world) for _, gb in batches]
+    # shards of a class are uneven when per_class is not a multiple of the rank count (58,254 = 6 x 7,282 + 2 x 7,281): the
+    # library's exact-count gather (ocp_qp_gpu_batch_gather_v) needs every rank's count
+    counts = [hi_r - lo_r for lo_r, hi_r in (shard_range(per_class, r, ranks_total) for r in range(world))]
+    gathers = [gather_solutions(gb, dist, rank, world, counts=counts) for _, gb in batches]
     tot = torch.tensor([count, bad], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(tot)
     if rank == 0:
         ok = [g for g in gathers if g]
-        try:
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        except Exception:
-            pass
-        print(json.dumps({"metric": "OCP-QP solves/sec, mixed shape classes (BASELINE configs[4])", "value": float(tot[0]) * args.steps / elapsed,
-                          "unit": "OCP-QP solves/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1),
-                          "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                          "dtype": "f64", "data": "synthetic",
-                          "config": {"workload": f"ten shape classes (nx in {{4,12,24}} x N in {{20,50,100}} + multi-phase nx 12->4), "
-                                                 f"{args.c5_total} instances per 8 GPUs over the nine classes + the same share of the multi-phase class, {count} on this rank, "
-                                                 f"classes solved concurrently",
-                                     "global_batch": int(tot[0]), "parallelism": f"every class instance-sharded x{world}", "commit": git_head()},
-                          "failures": int(tot[1]), "per_class_rank0": per,
-                          "gather": {"ranks": world, "ms_all_classes": sum(g["ms"] for g in ok), "classes_gathered": len(ok),
-                                     "all_slices_match_getters": all(g["slice_matches_getters"] for g in ok) if ok else None,
-                                     "collective": ok[0]["collective"] if ok else None}}), flush=True)
+        out = {"metric": "OCP-QP solves/sec, mixed shape classes (BASELINE configs[4])", "value": float(tot[0]) * args.steps / elapsed,
+               "unit": "OCP-QP solves/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1),
+               "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f64", "data": "synthetic",
+               "config": {"workload": f"ten shape classes (nx in {{4,12,24}} x N in {{20,50,100}} + multi-phase nx 12->4), "
+                                      f"{args.c5_total} instances per 8 GPUs over the nine classes + the same share of the multi-phase class, {count} on this rank, "
+                                      f"classes solved concurrently",
+                          "global_batch": int(tot[0]), "parallelism": f"every class instance-sharded x{world}", "commit": git_head()},
+               "failures": int(tot[1]), "per_class_rank0": per,
+               "gather": {"ranks": world, "ms": sum(g["ms"] for g in ok), "ms_all_classes": sum(g["ms"] for g in ok), "classes_gathered": len(ok),
+                          "slice_matches_getters": all(g["slice_matches_getters"] for g in ok) if ok else None,
+                          "instances_per_rank": counts,
+                          "collective": ok[0]["collective"] if ok else None}}
+        emit(out, args)
     if dist is not None:
         dist.destroy_process_group()
 
@@ -685,6 +792,8 @@ def main():
                     help="c2: the headline workload (BASELINE configs[1]); c5: the mixed-shape-class batch of configs[4], 524,288 instances "
                          "split over the ranks present (a rank of a smaller job still holds the share of an 8-GPU job: weak scaling)")
     ap.add_argument("--c5-total", type=int, default=524288)
+    ap.add_argument("--detail-file", default=None,
+                    help="where the full result object goes (default gpurun_out/bench_detail.json); stdout's last line is the compact one")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch path only: every rank joins a gloo group, reports the instance ranges it would own, rank 0 prints one JSON "
                          "line; no GPU is touched (the CPU tier checks that --gpus N starts N ranks)")
@@ -852,15 +961,7 @@ def main():
         out["ipm"]["oracle_checked_instances"] = int(out["ipm"]["oracle_checked_instances"]) + int(idx.size)
     if world == 1 and not args.no_configs:
         out["configs"] = other_configs(gb, data, args)
-    # the JSON line is the LAST thing on stdout: RCCL prints a version banner through C stdio when its first communicator
-    # comes up -- push that out first
-    try:
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
-    except Exception:
-        pass
-    sys.stdout.flush()
-    print(json.dumps(out), flush=True)
+    emit(out, args)
     if dist is not None:
         dist.destroy_process_group()
 

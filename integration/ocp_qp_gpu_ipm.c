@@ -202,7 +202,7 @@ static void gpu_opts_initialize_default(void *config, void *dims, void *opts_)
     o->mu0 = 1e0; o->tol_stat = 1e-6; o->tol_eq = 1e-8; o->tol_ineq = 1e-8; o->tol_comp = 1e-8; o->alpha_min = 1e-8;
     o->tau_min = 0.0; o->reg_prim = 1e-15; o->t0_min = 1e-16; o->lam0_min = 1e-16;
     o->iter_max = 50; o->warm_start = 0; o->print_level = 0; o->ric_alg = 1; o->t0_init = 2; o->update_fact_exit = 0;
-    o->cond_pred_corr = 1; o->tol_comp_soft_scale = 1e-3;
+    o->cond_pred_corr = 1; o->tol_comp_soft_scale = 1.0;
     o->rendezvous = NULL;
 }
 

@@ -138,7 +138,7 @@ def test_exact_dense_reference_c4_shaped():
     d_tight = _dist(o, qp, sol)
     assert o.solve(default_opts(tol_stat=1e-8), soft_scale=1.0) == 0
     d_plain, it_plain = _dist(o, qp, sol), o.iter
-    assert o.solve(default_opts(tol_stat=1e-8)) == 0           # the product's exit rule (oracle.SOFT_COMP_SCALE)
+    assert o.solve(default_opts(tol_stat=1e-8), soft_scale=1e-3) == 0           # the product's OPT-IN exit rule (tol_comp_soft_scale 1e-3)
     d_rule, it_rule = _dist(o, qp, sol), o.iter
     print(f"C4-shaped: distance to the certified solution: tight {d_tight:.2e}, 1e-8 x 4 {d_plain:.2e} ({it_plain} it), "
           f"soft exit rule {d_rule:.2e} ({it_rule} it)")

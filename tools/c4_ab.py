@@ -10,7 +10,7 @@ from acados_amd.generators import chain_soft_batch, chain_soft_dims, fill_chain_
 extra = [a for a in sys.argv[1:] if a.endswith(".so")]   # development builds of the library to run beside the product
 args = [a for a in sys.argv[1:] if not a.endswith(".so")]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-libs = {n_: _lib.bind(ctypes.CDLL(os.path.join(ROOT, "acados_amd", "csrc", n_))) for n_ in extra}
+libs = {n_: _lib.bind(ctypes.CDLL(os.path.join(ROOT, "tools", "ab", n_))) for n_ in extra}
 N, B = 40, int(args[0]) if args else 16384
 data = chain_soft_batch(N=N, batch=B, seed=1)
 ref = None

@@ -14,7 +14,7 @@ CLASSES = (tuple(tuple(int(v) for v in c.split(",")) for c in os.environ["KX_CLA
            else ((4, 1, 20), (4, 1, 100), (8, 3, 50), (12, 3, 100)))
 datas = {c: random_lqr_batch(N=c[2], nx=c[0], nu=c[1], batch=B, seed=200) for c in CLASSES}
 for name in [None] + sys.argv[1:]:
-    clib = None if name is None else _lib.bind(ctypes.CDLL(os.path.join(ROOT, "acados_amd", "csrc", name)))
+    clib = None if name is None else _lib.bind(ctypes.CDLL(os.path.join(ROOT, "tools", "ab", name)))
     for (nx, nu, N) in CLASSES:
         g = OcpQpGpuBatch(lqr_dims(N, nx, nu), B, _clib=clib)
         fill_lqr_batch(g, datas[(nx, nu, N)], N)

@@ -25,8 +25,23 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"
-READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+import shutil
+
+
+def _llvm_tool(name):
+    """the LLVM binutils of the ROCm install the library was built with: $ROCM_PATH, beside $HIPCC, /opt/rocm, then PATH"""
+    roots = [os.environ.get("ROCM_PATH"), os.path.dirname(os.path.dirname(os.path.realpath(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")))), "/opt/rocm"]
+    for r in roots:
+        if r:
+            for sub in ("lib/llvm/bin", "llvm/bin"):
+                c = os.path.join(r, sub, name)
+                if os.path.exists(c):
+                    return c
+    return shutil.which(name)
+
+
+OBJDUMP = _llvm_tool("llvm-objdump")
+READELF = _llvm_tool("llvm-readelf")
 MAGIC = b"__CLANG_OFFLOAD_BUNDLE__"
 
 
@@ -119,6 +134,9 @@ def lint(lib, strict=False):
 if __name__ == "__main__":
     args = [a for a in sys.argv[1:] if a != "--strict"]
     lib = args[0] if args else os.path.join(ROOT, "acados_amd", "csrc", "libacados_amd_qp.so")
+    if not OBJDUMP or not READELF:
+        print("ISA lint skipped: llvm-objdump / llvm-readelf not found (ROCM_PATH, beside HIPCC, /opt/rocm, PATH)")
+        sys.exit(3)      # the Makefile treats 3 as a warning; 1 is a lint violation
     bad, report = lint(lib, strict="--strict" in sys.argv)
     for r in report:
         print(r)

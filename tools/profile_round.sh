@@ -5,7 +5,8 @@
 #   <tag>_kernel_stats.txt     rocprofv3 --kernel-trace --stats summary of the headline bench (C2)
 #   <tag>_pmc_traffic.json     HBM bytes per launch of every sweep kernel: --pmc FETCH_SIZE / --pmc WRITE_SIZE, SEPARATE
 #                              counter-only passes (no trace domains), gfx950 correction of MI355X_MICROARCH.md
-#   <tag>_bench.json           the bench line of the same build (reads the traffic file just written if copied first)
+#   <tag>_bench.json           the full result object of the same build (reads the traffic file just written if copied first)
+#   <tag>_bench_line.json      the compact line the driver parses (stdout's last line)
 # `full` also traces the configuration legs (C3 / C4 / C5) of the bench and collects their HBM traffic per configuration
 #   <tag>_config_kernel_stats.txt, <tag>_config_pmc_traffic.json (sections cut by the marker launches of bench.py),
 #   <tag>_mfma_util.json (tools/profile_mfma.sh: MFMA instructions / busy cycles of km_pcond and kt_factor over one C3 solve)
@@ -42,4 +43,5 @@ if [ "$3" = "full" ]; then
     (cd $root && bash tools/profile_mfma.sh $tag $commit > /dev/null 2>&1)
     cp $out/${tag}_mfma_util.json $root/profiles/${tag}_mfma_util.json
 fi
-cd $root && python bench.py 2> $out/${tag}_bench_err.log | tail -1 > $out/${tag}_bench.json
+# the full object goes to <tag>_bench.json (what the tests and bench.py's readers load), the line the driver parses to <tag>_bench_line.json
+cd $root && python bench.py --detail-file $out/${tag}_bench.json 2> $out/${tag}_bench_err.log | tail -1 > $out/${tag}_bench_line.json

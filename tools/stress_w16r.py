@@ -15,7 +15,7 @@ CLIB = None
 if len(sys.argv) > 2:
     import ctypes
     from acados_amd import _lib
-    CLIB = _lib.bind(ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "acados_amd", "csrc", sys.argv[2])))
+    CLIB = _lib.bind(ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "ab", sys.argv[2])))
 
 
 def lqr(nx, nu, N, B, cond=0):

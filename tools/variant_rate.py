@@ -12,7 +12,7 @@ N, B = 50, 65536
 C2 = len(sys.argv) > 1 and sys.argv[1] == "c2"
 data = random_lqr_batch(N=N, nx=8, nu=3, batch=B, seed=3)
 for name in [None] + sys.argv[(2 if C2 else 1):]:
-    clib = None if name is None else _lib.bind(ctypes.CDLL(os.path.join(ROOT, "acados_amd", "csrc", name)))
+    clib = None if name is None else _lib.bind(ctypes.CDLL(os.path.join(ROOT, "tools", "ab", name)))
     g = OcpQpGpuBatch(lqr_dims(N, 8, 3), B, _clib=clib)
     fill_lqr_batch(g, data, N)
     for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):

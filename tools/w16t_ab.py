@@ -12,7 +12,7 @@ from acados_amd.generators import fill_lqr_batch, lqr_dims, random_lqr_batch
 extra = [a for a in sys.argv[1:] if a.endswith(".so")]
 cases = [a for a in sys.argv[1:] if not a.endswith(".so")] or ["c3", "24,6,20", "24,6,100"]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-libs = {name: _lib.bind(ctypes.CDLL(os.path.join(ROOT, "acados_amd", "csrc", name))) for name in extra}
+libs = {name: _lib.bind(ctypes.CDLL(os.path.join(ROOT, "tools", "ab", name))) for name in extra}
 for case in cases:
     if case == "c3":
         nx, nu, N, B, cond = 8, 3, 50, 65536, 10

@@ -8,7 +8,7 @@ import torch  # noqa: F401  (HIP runtime first)
 from acados_amd import OcpQpGpuBatch, _lib
 from acados_amd.generators import fill_lqr_batch, lqr_dims, random_lqr_batch
 
-L = _lib.bind(ctypes.CDLL(os.path.join(ROOT, "acados_amd", "csrc", os.environ.get("GQP_TIMING_LIB", "libacados_amd_qp_timing.so"))))
+L = _lib.bind(ctypes.CDLL(os.path.join(ROOT, "tools", "ab", os.environ.get("GQP_TIMING_LIB", "libacados_amd_qp_timing.so"))))
 L.gqp_wpi_cycles_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
 if len(sys.argv) > 1 and sys.argv[1] == "c4":     # the C4 class (general rows + slacks): python tools/w16t_phase_cycles.py c4 [batch]
     from acados_amd.generators import chain_soft_batch, chain_soft_dims, fill_chain_soft_batch

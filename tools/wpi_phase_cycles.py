@@ -11,7 +11,7 @@ from acados_amd.generators import fill_lqr_batch, lqr_dims, random_lqr_batch
 c4 = len(sys.argv) > 1 and sys.argv[1] == "c4"      # the C4 class (general rows + slacks) instead of a box-constrained LQR shape
 nx, nu, N, B = (24, 3, 40, int(sys.argv[2]) if len(sys.argv) > 2 else 1536) if c4 else \
     (int(a) for a in (sys.argv[1:5] if len(sys.argv) >= 5 else (24, 6, 50, 1280)))
-L = _lib.bind(ctypes.CDLL(os.path.join(ROOT, "acados_amd", "csrc", "libacados_amd_qp_timing.so")))
+L = _lib.bind(ctypes.CDLL(os.path.join(ROOT, "tools", "ab", "libacados_amd_qp_timing.so")))
 L.gqp_wpi_cycles_read.argtypes = [ctypes.c_void_p, ctypes.c_int]
 if c4:
     from acados_amd.generators import chain_soft_batch, chain_soft_dims, fill_chain_soft_batch
