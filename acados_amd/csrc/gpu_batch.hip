@@ -2056,6 +2056,7 @@ try
 catch (const gqp_hip_failure &) { return -1; }
 
 double ocp_qp_gpu_batch_get_scalar(ocp_qp_gpu_batch *b, const char *f)
+try
 {
     if (!strcmp(f, "time_tot")) return b->time_tot;
     if (!strcmp(f, "time_pack")) { double t = b->time_pack; b->time_pack = 0.0; return t; }
@@ -2093,6 +2094,7 @@ double ocp_qp_gpu_batch_get_scalar(ocp_qp_gpu_batch *b, const char *f)
     fprintf(stderr, "acados_amd: ocp_qp_gpu_batch_get_scalar: unknown field %s\n", f);
     return -1.0;
 }
+catch (const gqp_hip_failure &) { return NAN; } /* "tol_comp_effective" finalises the structure on the device */
 
 int ocp_qp_gpu_batch_condense_lhs(ocp_qp_gpu_batch *b)
 try
@@ -2282,7 +2284,7 @@ static void bulk_build(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch::BulkMap &M, const 
     M.built = true;
 }
 
-int ocp_qp_gpu_batch_bulk_len(ocp_qp_gpu_batch *b, int output)
+static int gqp_bulk_len_impl(ocp_qp_gpu_batch *b, int output) /* throws gqp_hip_failure: callers are inside a guarded entry */
 {
     HIPCHK(hipSetDevice(b->device));
     auto &M = output ? b->bulk_out : b->bulk_in;
@@ -2290,9 +2292,9 @@ int ocp_qp_gpu_batch_bulk_len(ocp_qp_gpu_batch *b, int output)
     return M.len;
 }
 
-int ocp_qp_gpu_batch_bulk_offset(ocp_qp_gpu_batch *b, int output, const char *field, int stage, int *len)
+static int gqp_bulk_offset_impl(ocp_qp_gpu_batch *b, int output, const char *field, int stage, int *len)
 {
-    ocp_qp_gpu_batch_bulk_len(b, output);
+    gqp_bulk_len_impl(b, output);
     auto &M = output ? b->bulk_out : b->bulk_in;
     for (size_t q = 0; q < M.fields.size(); q++)
         if (M.seg_stage[q] == stage && M.fields[q] == field)
@@ -2304,10 +2306,21 @@ int ocp_qp_gpu_batch_bulk_offset(ocp_qp_gpu_batch *b, int output, const char *fi
     return -1;
 }
 
+/* the C-ABI entries of the layout queries: the first of them after create builds the per-stage structure and the segment
+ * tables on the device (dalloc / hipMemcpy / hipFuncSetAttribute) -- where an out-of-memory error of a large batch shows up
+ * first.  No exception crosses the C ABI: -1 (no valid length / offset is negative) */
+int ocp_qp_gpu_batch_bulk_len(ocp_qp_gpu_batch *b, int output)
+try { return gqp_bulk_len_impl(b, output); }
+catch (const gqp_hip_failure &) { return -1; }
+
+int ocp_qp_gpu_batch_bulk_offset(ocp_qp_gpu_batch *b, int output, const char *field, int stage, int *len)
+try { return gqp_bulk_offset_impl(b, output, field, stage, len); }
+catch (const gqp_hip_failure &) { if (len) *len = 0; return -1; }
+
 int ocp_qp_gpu_batch_set_bulk(ocp_qp_gpu_batch *b, const double *blob, int is_device)
 try
 {
-    const int len = ocp_qp_gpu_batch_bulk_len(b, 0);
+    const int len = gqp_bulk_len_impl(b, 0);
     auto &M = b->bulk_in;
     hipEvent_t e0, e1;
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
@@ -2333,7 +2346,7 @@ catch (const gqp_hip_failure &) { return -1; }
 int ocp_qp_gpu_batch_set_bulk_out(ocp_qp_gpu_batch *b, const double *blob, int is_device)
 try
 {
-    const int len = ocp_qp_gpu_batch_bulk_len(b, 1);
+    const int len = gqp_bulk_len_impl(b, 1);
     auto &M = b->bulk_out;
     const double *src = stage_in(b, blob, (size_t) b->B * len, is_device);
     const dim3 grid((b->B + 63) / 64, (len + 255) / 256), block(64);
@@ -2346,7 +2359,7 @@ catch (const gqp_hip_failure &) { return -1; }
 int ocp_qp_gpu_batch_get_bulk(ocp_qp_gpu_batch *b, double *blob, int is_device)
 try
 {
-    const int len = ocp_qp_gpu_batch_bulk_len(b, 1);
+    const int len = gqp_bulk_len_impl(b, 1);
     auto &M = b->bulk_out;
     const size_t cnt = (size_t) b->B * len;
     double *dst = blob;
@@ -2411,22 +2424,22 @@ static void seed_build(ocp_qp_gpu_batch *b)
     M.built = true;
 }
 
-int ocp_qp_gpu_batch_sens_bulk_len(ocp_qp_gpu_batch *b, int output)
+static int gqp_sens_bulk_len_impl(ocp_qp_gpu_batch *b, int output)
 {
-    if (output) return ocp_qp_gpu_batch_bulk_len(b, 1);
+    if (output) return gqp_bulk_len_impl(b, 1);
     HIPCHK(hipSetDevice(b->device));
     seed_build(b);
     return b->bulk_seed.len;
 }
 
-int ocp_qp_gpu_batch_sens_bulk_offset(ocp_qp_gpu_batch *b, int output, const char *field, int stage, int *len)
+static int gqp_sens_bulk_offset_impl(ocp_qp_gpu_batch *b, int output, const char *field, int stage, int *len)
 {
     if (output)
     {
         if (strncmp(field, "sens_", 5)) { if (len) *len = 0; return -1; }
-        return ocp_qp_gpu_batch_bulk_offset(b, 1, field + 5, stage, len);
+        return gqp_bulk_offset_impl(b, 1, field + 5, stage, len);
     }
-    ocp_qp_gpu_batch_sens_bulk_len(b, 0);
+    gqp_sens_bulk_len_impl(b, 0);
     auto &M = b->bulk_seed;
     for (size_t q = 0; q < M.fields.size(); q++)
         if (M.seg_stage[q] == stage && M.fields[q] == field)
@@ -2438,10 +2451,18 @@ int ocp_qp_gpu_batch_sens_bulk_offset(ocp_qp_gpu_batch *b, int output, const cha
     return -1;
 }
 
+int ocp_qp_gpu_batch_sens_bulk_len(ocp_qp_gpu_batch *b, int output)
+try { return gqp_sens_bulk_len_impl(b, output); }
+catch (const gqp_hip_failure &) { return -1; }
+
+int ocp_qp_gpu_batch_sens_bulk_offset(ocp_qp_gpu_batch *b, int output, const char *field, int stage, int *len)
+try { return gqp_sens_bulk_offset_impl(b, output, field, stage, len); }
+catch (const gqp_hip_failure &) { if (len) *len = 0; return -1; }
+
 int ocp_qp_gpu_batch_sens_set_bulk(ocp_qp_gpu_batch *b, const double *blob, int is_device)
 try
 {
-    const int len = ocp_qp_gpu_batch_sens_bulk_len(b, 0);
+    const int len = gqp_sens_bulk_len_impl(b, 0);
     if (sens_begin(b)) return -1; /* zeroes the seed arrays, factorises at the solution where the sweeps run in place */
     if (len == 0) return 0;
     auto &M = b->bulk_seed;
@@ -2459,7 +2480,7 @@ catch (const gqp_hip_failure &) { return -1; }
 int ocp_qp_gpu_batch_sens_get_bulk(ocp_qp_gpu_batch *b, double *blob, int is_device)
 try
 {
-    const int len = ocp_qp_gpu_batch_bulk_len(b, 1);
+    const int len = gqp_bulk_len_impl(b, 1);
     auto &M = b->bulk_out;
     gqp::GArrTable T = M.T; /* same element maps as the solution, read from the direction arrays */
     const GqpDev &D = b->D;
@@ -2659,7 +2680,7 @@ static int gather_impl(ocp_qp_gpu_batch *b, ocp_qp_gpu_comm *c, int root, const 
         fprintf(stderr, "acados_amd: ocp_qp_gpu_batch_gather: counts[%d] = %d but this rank's batch holds %d instances\n", c->rank, counts[c->rank], b->B);
         return -1;
     }
-    const int len = ocp_qp_gpu_batch_bulk_len(b, 1);
+    const int len = gqp_bulk_len_impl(b, 1);
     auto &M = b->bulk_out;
     const size_t cnt = (size_t) b->B * len;
     /* send buffers: the solution blob of this rank (gather launch into the staging area), status / iter interleaved */

@@ -957,13 +957,14 @@ acados_size_t ocp_qp_gpu_ipm_workspace_calculate_size(void *config, void *dims, 
 
 } /* extern "C" */
 
-static void build_segments(batch_cache *bc, ocp_qp_gpu_batch *b, const ocp_qp_dims *d)
+static int build_segments(batch_cache *bc, ocp_qp_gpu_batch *b, const ocp_qp_dims *d)
 {
-    /* segment tables of the bulk blobs, once per device batch */
+    /* segment tables of the bulk blobs, once per device batch; -1: the device failed (the first device work after create) */
     const int N = d->N;
     bc->seg_in.clear(); bc->seg_out.clear();
     bc->L_in = ocp_qp_gpu_batch_bulk_len(b, 0);
     bc->L_out = ocp_qp_gpu_batch_bulk_len(b, 1);
+    if (bc->L_in < 0 || bc->L_out < 0) { bc->L_in = bc->L_out = 0; return -1; }
     auto add = [&](std::vector<blob_seg> &tab, int output, const char *name, int k, int len, int fid, int shift) {
         if (len <= 0) return;
         int seg_len = 0;
@@ -1023,6 +1024,7 @@ static void build_segments(batch_cache *bc, ocp_qp_gpu_batch *b, const ocp_qp_di
         add(to, 1, "lam", k, nct, O_lam, 0);
         add(to, 1, "t", k, nct, O_t, 0);
     }
+    return 0;
 }
 
 /* the device failed under this call (the library has reported the HIP error): every QP of the call is a QP failure --
@@ -1096,7 +1098,12 @@ int gqp_host::gpu_ipm_evaluate_impl(void *config, int n, void **qp_in_, void **q
             ocp_qp_gpu_batch_set_int(bc->batch, "idxs_rev", k, ins[0]->idxs_rev[k], d->nb[k] + d->ng[k]);
             ocp_qp_gpu_batch_set_int(bc->batch, "idxe", k, ins[0]->idxe[k], d->nbxe[k]);
         }
-        build_segments(bc, bc->batch, d);
+        if (build_segments(bc, bc->batch, d) != 0)
+        {
+            ocp_qp_gpu_batch_destroy(bc->batch);
+            bc->batch = nullptr;      /* the next call builds it again */
+            return device_failure(n, outs, status, mem_);
+        }
         if (n > 1) { bc->st.assign(n, 0); bc->it.assign(n, 0); }
     }
     ocp_qp_gpu_batch *b = bc->batch;

@@ -343,14 +343,16 @@ static void seg_add(ocp_qp_gpu_batch *b, gpu_seg *tab, int *cnt, int cap, int wh
 }
 
 /* where every field of the three blobs lives in the acados structs: once per device batch */
-static void build_segments(gpu_bucket *bk, const ocp_qp_dims *d)
+static int build_segments(gpu_bucket *bk, const ocp_qp_dims *d)
 {
     ocp_qp_gpu_batch *b = bk->batch;
     const int N = d->N;
     bk->n_in = bk->n_out = bk->n_seed = 0;
+    /* the first device work after create (structure tables, out of HBM shows up here): negative = the device failed */
     bk->L_in = ocp_qp_gpu_batch_bulk_len(b, 0);
     bk->L_out = ocp_qp_gpu_batch_bulk_len(b, 1);
     bk->L_seed = ocp_qp_gpu_batch_sens_bulk_len(b, 0);
+    if (bk->L_in < 0 || bk->L_out < 0 || bk->L_seed < 0) { bk->L_in = bk->L_out = bk->L_seed = 0; return -1; }
 #define IN(field, expect, kind, src, ai, aj, m, n, neg) seg_add(b, bk->seg_in, &bk->n_in, bk->seg_cap_in, 0, field, k, expect, kind, src, ai, aj, m, n, neg)
 #define OUT(field, expect, src, ai) seg_add(b, bk->seg_out, &bk->n_out, bk->seg_cap_out, 1, field, k, expect, SEG_VEC, src, ai, 0, expect, 1, 0)
 #define SEED(field, expect, src, ai, neg) seg_add(b, bk->seg_seed, &bk->n_seed, bk->seg_cap_seed, 2, field, k, expect, SEG_VEC, src, ai, 0, expect, 1, neg)
@@ -429,10 +431,12 @@ static void build_segments(gpu_bucket *bk, const ocp_qp_dims *d)
 #undef IN
 #undef OUT
 #undef SEED
+    return 0;
 }
 
-/* (re)create the device batch of a bucket for the structure of `in` (n instances) */
-static void bucket_build(gpu_bucket *bk, const ocp_qp_in *in, const int *sig, int len)
+/* (re)create the device batch of a bucket for the structure of `in` (n instances); -1: the device failed while the batch's
+ * structure was built (the batch is gone, the next call tries again) */
+static int bucket_build(gpu_bucket *bk, const ocp_qp_in *in, const int *sig, int len)
 {
     const ocp_qp_dims *d = in->dim;
     const int N = d->N;
@@ -447,7 +451,14 @@ static void bucket_build(gpu_bucket *bk, const ocp_qp_in *in, const int *sig, in
         ocp_qp_gpu_batch_set_int(bk->batch, "idxs_rev", k, in->idxs_rev[k], d->nb[k] + d->ng[k]);
         ocp_qp_gpu_batch_set_int(bk->batch, "idxe", k, in->idxe[k], d->nbxe[k]);
     }
-    build_segments(bk, d);
+    if (build_segments(bk, d) != 0)
+    {
+        ocp_qp_gpu_batch_destroy(bk->batch);
+        bk->batch = NULL;
+        bk->sig_len = 0;
+        return -1;
+    }
+    return 0;
 }
 
 /* ------------------------------------------------------------------ blob <-> acados structs, one instance */
@@ -526,6 +537,12 @@ static void apply_opts(ocp_qp_gpu_batch *b, const ocp_qp_gpu_ipm_opts *o, int ws
 static void bucket_solve(gpu_bucket *bk, const ocp_qp_gpu_ipm_opts *o, int ws)
 {
     ocp_qp_gpu_batch *b = bk->batch;
+    if (!b) /* the device failed while this bucket's batch was built (bucket_build) */
+    {
+        for (int i = 0; i < bk->n; i++) { bk->st[i] = ACADOS_QP_FAILURE; bk->it[i] = 0; }
+        bk->status = ACADOS_QP_FAILURE;
+        return;
+    }
     apply_opts(b, o, ws);
     /* the starting point goes in before the pack, which then restores the equality-flagged values (x0) */
     /* a negative return = the device failed (HIP error, reported by the library): every QP of the bucket comes back as
@@ -564,7 +581,12 @@ static int ocp_qp_gpu_ipm_acados(void *config, void *qp_in_, void *qp_out_, void
         const int len = fill_sig(in, m->sig_scratch);
         if (!bk->batch || bk->sig_len != len || memcmp(bk->sig, m->sig_scratch, sizeof(int) * len) != 0)
         {
-            bucket_build(bk, in, m->sig_scratch, len);
+            if (bucket_build(bk, in, m->sig_scratch, len) != 0)
+            {
+                info->num_iter = 0; info->t_computed = 0;
+                m->status = ACADOS_QP_FAILURE; m->iter = 0;
+                return ACADOS_QP_FAILURE;
+            }
             if ((size_t) bk->L_in > bk->cap_in || (size_t) bk->L_out > bk->cap_out || (size_t) bk->L_seed > bk->cap_in)
             {
                 printf("\nerror: ocp_qp_gpu_ipm: bulk blob larger than the carved staging\n");
@@ -716,7 +738,7 @@ static gpu_group *group_for(int n, ocp_qp_in **ins, ocp_qp_gpu_ipm_memory **mems
         bk->seg_seed = (gpu_seg *) xcalloc(bk->seg_cap_seed, sizeof(gpu_seg));
         bk->st = (int *) xcalloc(bk->n, sizeof(int)); bk->it = (int *) xcalloc(bk->n, sizeof(int));
         memcpy(g->scratch, bk->sig, sizeof(int) * bk->sig_len);
-        bucket_build(bk, in0, g->scratch, bk->sig_len);
+        (void) bucket_build(bk, in0, g->scratch, bk->sig_len); /* on a device failure the bucket has no batch: bucket_solve fails its QPs */
         /* pinned staging: the input blob also stages the seeds (never longer than the QP data) */
         int per = bk->L_in > bk->L_seed ? bk->L_in : bk->L_seed;
         for (int k = 0; k < nst; k++) /* solver_get stages ric_L and ric_l of the whole bucket */
@@ -725,7 +747,7 @@ static gpu_group *group_for(int n, ocp_qp_in **ins, ocp_qp_gpu_ipm_memory **mems
             if (nv * (nv + 1) > per) per = nv * (nv + 1);
         }
         bk->cap_in = (size_t) bk->n * (size_t) per;
-        bk->cap_out = (size_t) bk->n * (size_t) bk->L_out;
+        bk->cap_out = (size_t) bk->n * (size_t) (bk->L_out > 0 ? bk->L_out : 1);
         bk->blob_in = (double *) ocp_qp_gpu_host_alloc(sizeof(double) * bk->cap_in);
         bk->blob_out = (double *) ocp_qp_gpu_host_alloc(sizeof(double) * bk->cap_out);
         if (!bk->blob_in || !bk->blob_out) exit(1);
