@@ -1084,19 +1084,23 @@ try
     else if (!strcmp(f, "cond_block_size"))
     {
         /* user block sizes, N2 + 1 entries as ocp_qp_partial_condensing.c:305-313; set cond_N first.  They must sum to
-         * N (:346-356); the last entry -- inputs condensed into the terminal stage -- must be 0 in this build. */
+         * N (:346-356).  A non-zero LAST entry (the reference's own test: qp_solver_cond_block_size = [6, 5, 4, 2, 2, 1],
+         * examples/acados_python/tests/pcond_getters_test.py:200) asks HPIPM to fold the last stages' inputs into the terminal
+         * stage; here those stages form one more block in front of an input-free terminal stage (the condensed QP has
+         * N2 + 1 stages with inputs instead of N2 -- the solution of the original QP is the same, the layout of the condensed
+         * one differs: INTEGRATION.md 3). */
         const int N2 = b->cond_N;
         if (N2 <= 0 || N2 >= b->N) { fprintf(stderr, "acados_amd: cond_block_size needs cond_N in 1..N-1 first\n"); return -1; }
         int sum = 0;
         for (int j = 0; j <= N2; j++) sum += i[j];
-        bool ok = sum == b->N && i[N2] == 0;
+        bool ok = sum == b->N && i[N2] >= 0;
         for (int j = 0; j < N2; j++) ok = ok && i[j] >= 1;
         if (!ok)
         {
-            fprintf(stderr, "acados_amd: partial condensing: block sizes must be >= 1, sum to N = %d (got %d) and end with 0\n", b->N, sum);
+            fprintf(stderr, "acados_amd: partial condensing: block sizes must be >= 1 (the last one >= 0) and sum to N = %d (got %d)\n", b->N, sum);
             return -1;
         }
-        b->user_blocks.assign(i, i + N2);
+        b->user_blocks.assign(i, i + N2 + (i[N2] > 0 ? 1 : 0));
         b->pcond_state = 0;
         if (b->child) { ocp_qp_gpu_batch_destroy(b->child); b->child = nullptr; }
     }
@@ -1141,13 +1145,14 @@ catch (const gqp_hip_failure &) { return -1; }
 /* ---- partial condensing (ocp_qp_partial_condensing.c:523-556, :664-689) ---- */
 static void pcond_setup(ocp_qp_gpu_batch *b)
 {
-    const int N = b->N, N2 = b->cond_N;
+    /* blocks with inputs: cond_N of them, one more when the user's last block size is not 0 (see "cond_block_size") */
+    const int N = b->N, N2 = (int) b->user_blocks.size() == b->cond_N + 1 ? b->cond_N + 1 : b->cond_N;
     b->pcond_state = -1;
     auto decline = [&](const char *why) {
         fprintf(stderr, "acados_amd: cond_N=%d requested but %s; solving the full-space QP (N2 = N, the default of "
                         "ocp_qp_partial_condensing.c:243-265) -- the solution is identical\n", N2, why);
     };
-    if (N2 <= 0 || N2 >= N) return;
+    if (b->cond_N <= 0 || b->cond_N >= N) return;
     /* block sizes as d_part_cond_qp_compute_block_size: N/N2 each, remainder to the first blocks */
     b->blk_start.assign(N2 + 1, 0);
     int bsmax = 0;
@@ -2067,7 +2072,7 @@ try
     if (!strcmp(f, "w16_tiles")) return (double) b->w16_tiles;
     if (!strcmp(f, "tail_switches")) return (double) b->n_tail_switches;
     if (!strcmp(f, "single_launch_solves")) return (double) b->n_single_launch;
-    if (!strcmp(f, "cond_N_active")) return b->pcond_state == 1 ? (double) b->cond_N : (double) b->N;
+    if (!strcmp(f, "cond_N_active")) return b->pcond_state == 1 ? (double) b->child->N : (double) b->N;
     if (!strcmp(f, "tol_comp_soft_scale")) return b->tol_comp_soft_scale;
     if (!strcmp(f, "tol_comp_effective")) { finalize_structure(b); return effective_opts(b->O, b).tol_comp; }
     /* which condensing / expansion kernels serve the batch: 2 sixteen lanes per block, 1 one instance per lane, 0 one wave
@@ -2337,6 +2342,32 @@ try
     HIPCHK(hipEventElapsedTime(&ms, e0, e1));
     b->time_pack += ms * 1e-3;
     HIPCHK(hipEventDestroy(e0)); HIPCHK(hipEventDestroy(e1));
+    return 0;
+}
+catch (const gqp_hip_failure &) { return -1; }
+
+/* the QP data of the batch in the INPUT blob layout (inverse of _set_bulk): how the acados-side condensing module reads the
+ * condensed QP of a child batch back into acados' containers (integration/ocp_qp_gpu_pcond.c) -- one launch (+ one for the
+ * masks) and one device->host copy instead of one copy per field and stage */
+int ocp_qp_gpu_batch_get_bulk_in(ocp_qp_gpu_batch *b, double *blob, int is_device)
+try
+{
+    const int len = gqp_bulk_len_impl(b, 0);
+    auto &M = b->bulk_in;
+    const size_t cnt = (size_t) b->B * len;
+    double *dst = blob;
+    if (!is_device)
+    {
+        if (cnt > b->stage_cap) { b->stage_cap = cnt * 2; b->d_stage = dalloc<double>(b, b->stage_cap); }
+        dst = b->d_stage;
+    }
+    const dim3 grid((b->B + 63) / 64, (len + 255) / 256), block(64);
+    hipLaunchKernelGGL(gqp::k_bulk_gather, grid, block, 0, b->stream, dst, b->B, len, M.d_arr, M.d_elem, M.T);
+    if (M.nm)
+        hipLaunchKernelGGL(gqp::k_bulk_masks_get, dim3((b->B + 63) / 64), block, 0, b->stream, dst, b->B, len, M.d_moff,
+                           M.d_mstage, M.d_mbit, M.nm, b->D.amask, b->AW);
+    if (!is_device) HIPCHK(hipMemcpyAsync(blob, dst, sizeof(double) * cnt, hipMemcpyDeviceToHost, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
     return 0;
 }
 catch (const gqp_hip_failure &) { return -1; }

@@ -1198,6 +1198,20 @@ static __global__ void k_bulk_masks(const double *blob, int nb, int len, const i
     }
 }
 
+/* the reverse: mask entries of the blob <- the bits (1.0 / 0.0) */
+static __global__ void k_bulk_masks_get(double *blob, int nb, int len, const int *m_off, const int *m_stage,
+                                        const int *m_bit, int nm, GArrU64 amask, int AW)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nb) return;
+    for (int q = 0; q < nm; q++)
+    {
+        if (m_bit[q] < 0) { blob[(size_t) i * len + m_off[q]] = 0.0; continue; }
+        const int w = m_stage[q] * AW + (m_bit[q] >> 6), bit = m_bit[q] & 63;
+        blob[(size_t) i * len + m_off[q]] = ((GATL(amask, w) >> bit) & 1) ? 1.0 : 0.0;
+    }
+}
+
 /* gather (dir 0): slot s of the dense level `c` <- instance list[s] of level `b`; scatter (dir 1):
  * the reverse.  blockIdx.y selects a chunk of 64 elements, so the copy is parallel over elements;
  * `list` is sorted, so the strided side still touches few 512-byte lines per wave. */

@@ -271,11 +271,13 @@ static void pcond_compute_dims(ocp_qp_partial_condensing_dims *dims, ocp_qp_part
     if (c)
     {
         ocp_qp_dims *x = dims->pcond_dims;
-        x->N = N2;
+        /* N2, or N2 + 1 when the user's last block size is not 0 (the device condenses that block in front of an input-free
+         * terminal stage: gpu_batch.hip "cond_block_size") */
+        ocp_qp_gpu_batch_get_dims(c, "N", &x->N);
         const char *names[] = {"nx", "nu", "nb", "nbx", "nbu", "ng", "ns", "nbxe"};
         int *dst[] = {x->nx, x->nu, x->nb, x->nbx, x->nbu, x->ng, x->ns, x->nbxe};
         for (int q = 0; q < 8; q++) ocp_qp_gpu_batch_get_dims(c, names[q], dst[q]);
-        for (int k = 0; k <= N2; k++) { x->nbue[k] = 0; x->nge[k] = 0; }
+        for (int k = 0; k <= x->N; k++) { x->nbue[k] = 0; x->nge[k] = 0; }
         dims->condensed = 1;
         for (int i = 0; i <= N2; i++)
             dims->block_size[i] = opts->block_size_was_set ? opts->block_size[i] : (i < N2 ? N / N2 + (i < N % N2 ? 1 : 0) : 0);

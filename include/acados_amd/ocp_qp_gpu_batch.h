@@ -69,12 +69,16 @@ int ocp_qp_gpu_batch_bulk_len(ocp_qp_gpu_batch *b, int output);
 int ocp_qp_gpu_batch_bulk_offset(ocp_qp_gpu_batch *b, int output, const char *field, int stage, int *len);
 int ocp_qp_gpu_batch_set_bulk(ocp_qp_gpu_batch *b, const double *blob, int is_device);
 int ocp_qp_gpu_batch_get_bulk(ocp_qp_gpu_batch *b, double *blob, int is_device);
+/* the QP DATA of the batch in the INPUT blob layout (inverse of _set_bulk): how a condensing module on acados' types reads the
+ * condensed QP of a child batch (ocp_qp_gpu_batch_condense) into the container the reference's orchestration hands to the QP
+ * solver next (xcond_qp_in, ocp_qp_partial_condensing.c:523-556; integration/ocp_qp_gpu_pcond.c) */
+int ocp_qp_gpu_batch_get_bulk_in(ocp_qp_gpu_batch *b, double *blob, int is_device);
 /* an iterate in the OUTPUT blob layout written into the batch (inverse of _get_bulk): the starting point of a hot start */
 int ocp_qp_gpu_batch_set_bulk_out(ocp_qp_gpu_batch *b, const double *blob, int is_device);
 
 /* Options by name, as ocp_qp_xcond_solver_opts_set forwards them: iter_max
  * tol_stat tol_eq tol_ineq tol_comp warm_start mu0 alpha_min tau_min reg_prim
- * cond_pred_corr print_level t0_init t0_min lam0_min (lower clips of t / lam at a hot start) update_fact_exit hpipm_mode ric_alg cond_N (partial condensing to N2 blocks) cond_block_size (int[N2+1], after cond_N; ocp_qp_partial_condensing.c:305-313) profile.  int* or double* or char* as in
+ * cond_pred_corr print_level t0_init t0_min lam0_min (lower clips of t / lam at a hot start) update_fact_exit hpipm_mode ric_alg cond_N (partial condensing to N2 blocks) cond_block_size (int[N2+1], after cond_N; ocp_qp_partial_condensing.c:305-313; a non-zero last entry becomes one more block in front of an input-free terminal stage) profile.  int* or double* or char* as in
  * acados.  Unknown field: message + return -1. */
 int ocp_qp_gpu_batch_opts_set(ocp_qp_gpu_batch *b, const char *field, const void *value);
 

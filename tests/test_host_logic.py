@@ -916,10 +916,13 @@ def test_condensing_only_boundary_hostsim(hostsim_lib):
             arr = (ctypes.c_int * len(blocks))(*blocks)
             assert b._L.ocp_qp_gpu_batch_opts_set(b._h, b"cond_block_size", arr) == 0
         c = b.condense()
-        assert c is not None and c.N == cond_N
+        # a non-zero last block size (the reference's own test, pcond_getters_test.py:200) is one more block with inputs in
+        # front of an input-free terminal stage
+        n_blk = cond_N + (1 if blocks is not None and blocks[-1] else 0)
+        assert c is not None and c.N == n_blk
         qc = c.to_qp(1)
         if blocks is not None:
-            assert list(qc.dims.nu[:cond_N]) == [bs * int(qp.dims.nu[0]) for bs in blocks[:cond_N]]
+            assert list(qc.dims.nu[:n_blk]) == [bs * int(qp.dims.nu[0]) for bs in blocks[:n_blk]] and qc.dims.nu[n_blk] == 0
         oc = OracleQp(qc)
         assert oc.solve(default_opts(tol_stat=1e-8, iter_max=60)) == 0
         for k in range(c.N + 1):
@@ -939,6 +942,10 @@ def test_condensing_only_boundary_hostsim(hostsim_lib):
     import ctypes
     data = random_lqr_batch(N=10, batch=1, seed=5)
     roundtrip(lqr_instance_qp(data, 0, 10), 3, blocks=[2, 5, 3, 0])
+    roundtrip(lqr_instance_qp(data, 0, 10), 3, blocks=[2, 5, 2, 1])
+    data20 = random_lqr_batch(N=20, nx=4, nu=1, batch=1, seed=6)
+    roundtrip(lqr_instance_qp(data20, 0, 20), 5, blocks=[6, 5, 4, 2, 2, 1])      # pcond_getters_test.py:200
+    roundtrip(mass_spring_qp(N=15), 3, blocks=[5, 5, 3, 2])
     roundtrip(mass_spring_qp(N=15), 5)
     n = 0
     for seed in range(24):
@@ -960,7 +967,7 @@ def test_condensing_module_acados_api_hostsim(hostsim_lib):
     from acados_amd import AcadosOcpQpCondensing
     from acados_amd.generators import mass_spring_qp
     from random_qp import random_structure_qp
-    cases = [(mass_spring_qp(N=15), 5, None), (mass_spring_qp(N=15), 4, [3, 4, 4, 4, 0]),
+    cases = [(mass_spring_qp(N=15), 5, None), (mass_spring_qp(N=15), 4, [3, 4, 4, 4, 0]), (mass_spring_qp(N=15), 4, [3, 4, 4, 3, 1]),
              (load_qp("casadi_qp_tests/pend_idxs_rev_min_qp0.json"), 3, None), (load_qp("qp_test/last_qp_one_sided_test.json"), 4, None)]
     cases += [(random_structure_qp(s), None, None) for s in (0, 4, 7, 13, 22)]
     for qp, cn, blocks in cases:
@@ -969,10 +976,11 @@ def test_condensing_module_acados_api_hostsim(hostsim_lib):
         assert o.solve(default_opts(tol_stat=1e-8, iter_max=60)) == 0
         mod = AcadosOcpQpCondensing(qp, cn, block_size=blocks, _clib=hostsim_lib)
         xd = mod.xcond_dims()
+        n_blk = cn + (1 if blocks is not None and blocks[-1] else 0)
         if blocks is not None:
-            assert list(xd["nu"][:cn]) == [bs * int(qp.dims.nu[0]) for bs in blocks[:cn]]
+            assert list(xd["nu"][:n_blk]) == [bs * int(qp.dims.nu[0]) for bs in blocks[:n_blk]]
         qc = mod.condense()
-        assert qc.N == cn and list(qc.dims.nx) == list(xd["nx"])
+        assert qc.N == n_blk and list(qc.dims.nx) == list(xd["nx"])
         oc = OracleQp(qc)
         assert oc.solve(default_opts(tol_stat=1e-8, iter_max=60)) == 0
         get = mod.expand(lambda k, f: oc.get(k, f))
@@ -1027,11 +1035,12 @@ def test_cond_block_size_option_acados_api_hostsim(hostsim_lib, capfd):
     opts = AcadosOcpQpOptions()
     opts.tol_stat = opts.tol_eq = opts.tol_ineq = opts.tol_comp = 1e-8
     opts.cond_N = 4
-    opts.cond_block_size = [3, 4, 4, 4, 0]
-    s = AcadosOcpQpSolver(qp, opts, _clib=hostsim_lib)
-    assert s.solve() == 0
-    compare_with_oracle(lambda k, f: s.get(k, f, unique_duals=False), o, qp, 2e-7, fields=("x", "u", "pi", "lam", "t"))
-    assert "solving the full-space QP" not in capfd.readouterr().err
+    for blocks in ([3, 4, 4, 4, 0], [3, 4, 4, 2, 2]):
+        opts.cond_block_size = blocks
+        s = AcadosOcpQpSolver(qp, opts, _clib=hostsim_lib)
+        assert s.solve() == 0
+        compare_with_oracle(lambda k, f: s.get(k, f, unique_duals=False), o, qp, 2e-7, fields=("x", "u", "pi", "lam", "t"))
+        assert "solving the full-space QP" not in capfd.readouterr().err
 
 
 def test_sixteen_lanes_covering_shapes_hostsim(hostsim_lib, monkeypatch):
