@@ -217,6 +217,9 @@ struct ocp_qp_gpu_batch
         std::vector<int> seg_stage, seg_off, seg_len;
         int *d_arr = nullptr, *d_elem = nullptr, *d_moff = nullptr, *d_mstage = nullptr, *d_mbit = nullptr;
         int *d_sgn = nullptr, *d_elem2 = nullptr; /* seed blob only: sign of the entry in the residual arrays, slot in sfix */
+        int *d_arr_g = nullptr, *d_elem_g = nullptr; /* input blob, READ direction (_get_bulk_in): the strict upper triangles of
+                                                        Q and R (not written: only the lower triangle of the caller's block is
+                                                        valid) are read from the mirrored element */
         gqp::GArrTable T;
     } bulk_in, bulk_out, bulk_seed;
 };
@@ -1100,9 +1103,13 @@ try
             fprintf(stderr, "acados_amd: partial condensing: block sizes must be >= 1 (the last one >= 0) and sum to N = %d (got %d)\n", b->N, sum);
             return -1;
         }
-        b->user_blocks.assign(i, i + N2 + (i[N2] > 0 ? 1 : 0));
-        b->pcond_state = 0;
-        if (b->child) { ocp_qp_gpu_batch_destroy(b->child); b->child = nullptr; }
+        const std::vector<int> blocks(i, i + N2 + (i[N2] > 0 ? 1 : 0));
+        if (blocks != b->user_blocks) /* the same sizes again (an adapter sends its options before every solve): nothing to redo */
+        {
+            b->user_blocks = blocks;
+            b->pcond_state = 0;
+            if (b->child) { ocp_qp_gpu_batch_destroy(b->child); b->child = nullptr; }
+        }
     }
     else if (!strcmp(f, "t0_min")) b->t0_min = *d;
     else if (!strcmp(f, "lam0_min")) b->lam0_min = *d;
@@ -2234,7 +2241,7 @@ static void bulk_build(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch::BulkMap &M, const 
         for (int q = 0; q < 12; q++) if (table[q].p == a.p) return q;
         return -1;
     };
-    std::vector<int> h_arr, h_elem, h_moff, h_mstage, h_mbit;
+    std::vector<int> h_arr, h_elem, h_moff, h_mstage, h_mbit, h_arr_g, h_elem_g;
     for (int k = 0; k <= b->N; k++)
         for (int fi = 0; fi < nf; fi++)
         {
@@ -2260,6 +2267,22 @@ static void bulk_build(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch::BulkMap &M, const 
                     h_arr.push_back(map[e] >= 0 ? table_index(arr) : -1); h_elem.push_back(map[e] >= 0 ? map[e] : 0);
                 }
             }
+            if (nf == 30) /* the input blob: read-direction map */
+            {
+                const bool sym = !strcmp(f, "Q") || !strcmp(f, "R");
+                const int dim = sym ? (f[0] == 'Q' ? b->nx[k] : b->nu[k]) : 0;
+                for (int e = 0; e < len; e++)
+                {
+                    int a = h_arr[h_arr.size() - len + e], el = h_elem[h_elem.size() - len + e];
+                    if (sym && a < 0)
+                    {
+                        const int r = e % dim, c = e / dim;       /* column-major, r < c here */
+                        const int m = map[r * dim + c];           /* element (c, r) */
+                        if (m >= 0) { a = table_index(arr); el = m; }
+                    }
+                    h_arr_g.push_back(a); h_elem_g.push_back(el);
+                }
+            }
             if (arr2.p)
             {
                 /* equality-flagged x bounds also define the value of the variable: a second, hidden
@@ -2271,6 +2294,7 @@ static void bulk_build(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch::BulkMap &M, const 
                 for (int e = 0; e < len; e++)
                 {
                     h_arr.push_back(map2[e] >= 0 ? table_index(arr2) : -1); h_elem.push_back(map2[e] >= 0 ? map2[e] : 0);
+                    if (nf == 30) { h_arr_g.push_back(h_arr.back()); h_elem_g.push_back(h_elem.back()); }
                 }
             }
         }
@@ -2279,6 +2303,12 @@ static void bulk_build(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch::BulkMap &M, const 
     M.d_arr = dalloc<int>(b, M.len); M.d_elem = dalloc<int>(b, M.len);
     HIPCHK(hipMemcpy(M.d_arr, h_arr.data(), sizeof(int) * M.len, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(M.d_elem, h_elem.data(), sizeof(int) * M.len, hipMemcpyHostToDevice));
+    if (nf == 30 && M.len)
+    {
+        M.d_arr_g = dalloc<int>(b, M.len); M.d_elem_g = dalloc<int>(b, M.len);
+        HIPCHK(hipMemcpy(M.d_arr_g, h_arr_g.data(), sizeof(int) * M.len, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(M.d_elem_g, h_elem_g.data(), sizeof(int) * M.len, hipMemcpyHostToDevice));
+    }
     M.d_moff = dalloc<int>(b, M.nm); M.d_mstage = dalloc<int>(b, M.nm); M.d_mbit = dalloc<int>(b, M.nm);
     if (M.nm)
     {
@@ -2362,7 +2392,7 @@ try
         dst = b->d_stage;
     }
     const dim3 grid((b->B + 63) / 64, (len + 255) / 256), block(64);
-    hipLaunchKernelGGL(gqp::k_bulk_gather, grid, block, 0, b->stream, dst, b->B, len, M.d_arr, M.d_elem, M.T);
+    hipLaunchKernelGGL(gqp::k_bulk_gather, grid, block, 0, b->stream, dst, b->B, len, M.d_arr_g, M.d_elem_g, M.T);
     if (M.nm)
         hipLaunchKernelGGL(gqp::k_bulk_masks_get, dim3((b->B + 63) / 64), block, 0, b->stream, dst, b->B, len, M.d_moff,
                            M.d_mstage, M.d_mbit, M.nm, b->D.amask, b->AW);

@@ -1206,7 +1206,7 @@ static __global__ void k_bulk_masks_get(double *blob, int nb, int len, const int
     if (i >= nb) return;
     for (int q = 0; q < nm; q++)
     {
-        if (m_bit[q] < 0) { blob[(size_t) i * len + m_off[q]] = 0.0; continue; }
+        if (m_bit[q] < 0) { blob[(size_t) i * len + m_off[q]] = 1.0; continue; } /* an equality-flagged bound: always in force */
         const int w = m_stage[q] * AW + (m_bit[q] >> 6), bit = m_bit[q] & 63;
         blob[(size_t) i * len + m_off[q]] = ((GATL(amask, w) >> bit) & 1) ? 1.0 : 0.0;
     }

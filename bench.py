@@ -929,7 +929,12 @@ def main():
         "ipm": {"mean_iter": mean_iter, "max_iter": max_iter, "failures": failures, "max_kkt_residual": res_max,
                 "max_kkt_residual_independent": res_indep,
                 "max_rel_primal_err_vs_oracle": err, "oracle_checked_instances": args.check,
-                "launches_per_step": int(gb.scalar("launches"))},
+                "launches_per_step": int(gb.scalar("launches")),
+                # the structural waste of one instance per lane: a wave streams its tiles until its LAST lane has converged.
+                # iter_hist[j] = instances (this rank) that took j iterations; wave_max_iter_mean = mean over the 64-instance tiles
+                # of the tile's largest count (what every sweep's traffic is proportional to) against mean_iter
+                "iter_hist": np.bincount(iters).tolist(),
+                "wave_max_iter_mean": float(iters[:(iters.size // 64) * 64].reshape(-1, 64).max(axis=1).mean()) if iters.size >= 64 else float(iters.max())},
         "roofline": roof,
         "pack_s": t_pack,
         "hbm_bytes_per_gpu": gb.bytes,

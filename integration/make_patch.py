@@ -15,6 +15,74 @@ import tempfile
 REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
 HERE = os.path.dirname(os.path.abspath(__file__))
 
+# the lock-step batch call of the generated solver (next to _acados_batch_solve, acados_solver.in.c:3222-3243)
+BATCH_GPU_QP = '''{%- if solver_options.qp_solver == "PARTIAL_CONDENSING_GPU_IPM" and solver_options.nlp_solver_type == "SQP_RTI" %}
+#include "acados/ocp_nlp/ocp_nlp_sqp_rti.h"
+#include "acados/ocp_qp/ocp_qp_gpu_ipm.h"
+/*
+ * One RTI step of EVERY capsule with ONE device batch for the QPs (ACADOS_WITH_GPU_IPM): host threads linearise and set up each
+ * capsule's QP (phase 1: ocp_nlp_solve returns in front of the QP solve), the N_batch QPs -- acados structs, as each capsule's NLP
+ * solver scaled them -- go to the GPU in one call (partial condensing, IPM and expansion fused on the device), host threads
+ * finish the step (phase 2: dual correction, globalisation, update of the iterate).  Unlike the one-thread-per-capsule loop
+ * above, num_threads_in_batch_solve is only the width of the two host phases; the batch may hold thousands of capsules.
+ * The capsules share their solver options (the batch runs with capsule 0's).
+ */
+void {{ name }}_acados_batch_solve_gpu_qp({{ name }}_solver_capsule ** capsules, int * status_out, int N_batch, int num_threads_in_batch_solve)
+{
+    int num_threads_bkp;
+    if (num_threads_in_batch_solve > 1)
+    {
+        num_threads_bkp = omp_get_num_threads();
+        omp_set_num_threads(num_threads_in_batch_solve);
+    }
+
+    int phase = 1;
+    #pragma omp parallel for
+    for (int i = 0; i < N_batch; i++)
+    {
+        ocp_nlp_solver_opts_set(capsules[i]->nlp_config, capsules[i]->nlp_opts, "qp_batch_phase", &phase);
+        status_out[i] = ocp_nlp_solve(capsules[i]->nlp_solver, capsules[i]->nlp_in, capsules[i]->nlp_out);
+    }
+
+    ocp_qp_in **qp_in = malloc(N_batch * sizeof(ocp_qp_in *));
+    ocp_qp_out **qp_out = malloc(N_batch * sizeof(ocp_qp_out *));
+    void **qp_mem = malloc(N_batch * sizeof(void *));
+    for (int i = 0; i < N_batch; i++)
+    {
+        ocp_nlp_memory *nlp_mem;
+        ocp_nlp_get(capsules[i]->nlp_solver, "nlp_mem", &nlp_mem);
+        qp_in[i] = nlp_mem->scaled_qp_in;
+        qp_out[i] = nlp_mem->scaled_qp_out;
+        qp_mem[i] = nlp_mem->qp_solver_mem;
+    }
+    ocp_nlp_sqp_rti_opts *opts0 = capsules[0]->nlp_opts;
+    ocp_qp_gpu_xcond_solver_acados_evaluate_batch(capsules[0]->nlp_config->qp_solver, capsules[0]->nlp_dims->qp_solver, N_batch,
+                                                  qp_in, qp_out, opts0->nlp_opts->qp_solver_opts, qp_mem, NULL);
+    free(qp_in);
+    free(qp_out);
+    free(qp_mem);
+
+    phase = 2;
+    #pragma omp parallel for
+    for (int i = 0; i < N_batch; i++)
+    {
+        ocp_nlp_solver_opts_set(capsules[i]->nlp_config, capsules[i]->nlp_opts, "qp_batch_phase", &phase);
+        status_out[i] = ocp_nlp_solve(capsules[i]->nlp_solver, capsules[i]->nlp_in, capsules[i]->nlp_out);
+        int phase_off = 0;
+        ocp_nlp_solver_opts_set(capsules[i]->nlp_config, capsules[i]->nlp_opts, "qp_batch_phase", &phase_off);
+    }
+
+    if (num_threads_in_batch_solve > 1)
+    {
+        omp_set_num_threads( num_threads_bkp );
+    }
+    return;
+}
+{%- endif %}
+
+
+'''
+
 EDITS = {
     # 1. the enum value, among the partial-condensing solvers (they have to come before the full-condensing ones: :58-59)
     "interfaces/acados_c/ocp_qp_interface.h": [
@@ -32,13 +100,75 @@ EDITS = {
          "#ifdef ACADOS_WITH_GPU_IPM\n        case PARTIAL_CONDENSING_GPU_IPM:\n"
          "            ocp_qp_xcond_solver_config_initialize_default(solver_config);\n"
          "            ocp_qp_gpu_ipm_acados_config_initialize_default(solver_config->qp_solver);\n"
-         "            ocp_qp_partial_condensing_config_initialize_default(solver_config->xcond);\n"
+         "            // partial condensing ON THE DEVICE (km_pcond / k_pexpand of libacados_amd_qp.so) behind ocp_qp_xcond_config\n"
+         "            ocp_qp_gpu_pcond_acados_config_initialize_default(solver_config->xcond);\n"
          "            break;\n#endif\n"
          "#ifdef ACADOS_WITH_QPDUNES\n        case PARTIAL_CONDENSING_QPDUNES:\n"),
         ('#ifdef ACADOS_WITH_QPDUNES\n    else if (!strcmp(solver_name, "PARTIAL_CONDENSING_QPDUNES"))\n',
          '#ifdef ACADOS_WITH_GPU_IPM\n    else if (!strcmp(solver_name, "PARTIAL_CONDENSING_GPU_IPM"))\n    {\n'
          '        plan.qp_solver = PARTIAL_CONDENSING_GPU_IPM;\n    }\n#endif\n'
          '#ifdef ACADOS_WITH_QPDUNES\n    else if (!strcmp(solver_name, "PARTIAL_CONDENSING_QPDUNES"))\n'),
+    ],
+    # 2b. the condensing module's device batch goes with the solver (the xcond vtable has no terminate slot, ocp_qp_common.h:84-107)
+    "acados/ocp_qp/ocp_qp_xcond_solver.c": [
+        ('#include "acados/utils/types.h"\n',
+         '#include "acados/utils/types.h"\n\n#ifdef ACADOS_WITH_GPU_IPM\n#include "acados/ocp_qp/ocp_qp_gpu_ipm.h"\n#endif\n'),
+        ("    qp_solver->terminate(config->qp_solver, memory->solver_memory, work->qp_solver_work);\n",
+         "    qp_solver->terminate(config->qp_solver, memory->solver_memory, work->qp_solver_work);\n"
+         "#ifdef ACADOS_WITH_GPU_IPM\n"
+         "    if (ocp_qp_gpu_pcond_acados_is_module(config->xcond)) ocp_qp_gpu_pcond_acados_memory_release(memory->xcond_memory);\n"
+         "#endif\n"),
+    ],
+    # 2c. lock-step batch (acados_solver.in.c:3222-3243): an SQP-RTI feedback step that stops in front of the QP solve
+    # (phase 1) and resumes behind it (phase 2), so that the QPs of ALL capsules are solved by ONE device batch in between
+    "acados/ocp_nlp/ocp_nlp_common.h": [
+        ("    int ext_qp_res;\n",
+         "    int ext_qp_res;\n"
+         "    int qp_batch_phase;  // 0: as ever; 1: return in front of the QP solve; 2: resume behind it (QP solved in a device batch)\n"),
+    ],
+    "acados/ocp_nlp/ocp_nlp_common.c": [
+        ("    opts->ext_qp_res = 0;\n", "    opts->ext_qp_res = 0;\n    opts->qp_batch_phase = 0;\n"),
+        ('        else if (!strcmp(field, "ext_qp_res"))\n',
+         '        else if (!strcmp(field, "qp_batch_phase"))\n        {\n            int* qp_batch_phase = (int *) value;\n'
+         '            opts->qp_batch_phase = *qp_batch_phase;\n        }\n'
+         '        else if (!strcmp(field, "ext_qp_res"))\n'),
+        ("    // solve qp\n    acados_tic(&timer);\n    if (precondensed_lhs)\n    {\n",
+         "    // lock-step batch on a GPU QP solver: phase 1 stops here -- the caller sends every capsule's (scaled) QP to the device in\n"
+         "    // ONE batch (ocp_qp_gpu_xcond_solver_acados_evaluate_batch) -- phase 2 picks the result up from the QP solver's memory\n"
+         "    if (nlp_opts->qp_batch_phase == 1)\n    {\n        return ACADOS_SUCCESS;\n    }\n\n"
+         "    // solve qp\n    acados_tic(&timer);\n"
+         "    if (nlp_opts->qp_batch_phase == 2)\n    {\n"
+         '        qp_solver->memory_get(qp_solver, qp_mem, "status", &qp_status);\n    }\n'
+         "    else if (precondensed_lhs)\n    {\n"),
+    ],
+    "acados/ocp_nlp/ocp_nlp_sqp_rti.c": [
+        ("    int qp_iter = 0;\n    int qp_status, globalization_status;\n\n    // update QP rhs for SQP (step prim var, abs dual var)\n",
+         "    int qp_iter = 0;\n    int qp_status, globalization_status;\n\n"
+         "    // lock-step batch (nlp_opts->qp_batch_phase): phase 2 resumes behind the QP solve, everything in front of it ran in phase 1\n"
+         "    if (nlp_opts->qp_batch_phase == 2)\n    {\n        goto qp_batch_resume;\n    }\n\n"
+         "    // update QP rhs for SQP (step prim var, abs dual var)\n"),
+        ("    // solve QP\n    bool precondensed_lhs = true;\n",
+         "qp_batch_resume: ;\n    // solve QP\n    bool precondensed_lhs = true;\n"),
+        ("    qp_status = ocp_nlp_solve_qp_and_correct_dual(config, dims, nlp_opts, nlp_mem, nlp_work, precondensed_lhs, NULL, NULL, NULL, NULL, NULL);\n\n"
+         "    qp_info *qp_info_;\n",
+         "    qp_status = ocp_nlp_solve_qp_and_correct_dual(config, dims, nlp_opts, nlp_mem, nlp_work, precondensed_lhs, NULL, NULL, NULL, NULL, NULL);\n"
+         "    if (nlp_opts->qp_batch_phase == 1)\n    {\n"
+         "        // the QP is set up (vectors, regularisation, warm-start option): it is solved with the other capsules' QPs\n"
+         "        return;\n    }\n\n"
+         "    qp_info *qp_info_;\n"),
+        ("    int rti_phase = opts->rti_phase;\n\n    if (rti_phase == FEEDBACK)\n",
+         "    int rti_phase = opts->rti_phase;\n\n    if (rti_phase == FEEDBACK || opts->nlp_opts->qp_batch_phase == 2)\n"),
+    ],
+    "interfaces/acados_template/acados_template/c_templates_tera/acados_solver.in.h": [
+        ("ACADOS_SYMBOL_EXPORT void {{ name }}_acados_batch_solve({{ name }}_solver_capsule ** capsules, int * status_out, int N_batch, int num_threads_in_batch_solve);\n",
+         "ACADOS_SYMBOL_EXPORT void {{ name }}_acados_batch_solve({{ name }}_solver_capsule ** capsules, int * status_out, int N_batch, int num_threads_in_batch_solve);\n"
+         '{%- if solver_options.qp_solver == "PARTIAL_CONDENSING_GPU_IPM" and solver_options.nlp_solver_type == "SQP_RTI" %}\n'
+         "// lock-step RTI over the batch, the QPs of all capsules in ONE device batch per call\n"
+         "ACADOS_SYMBOL_EXPORT void {{ name }}_acados_batch_solve_gpu_qp({{ name }}_solver_capsule ** capsules, int * status_out, int N_batch, int num_threads_in_batch_solve);\n"
+         "{%- endif %}\n"),
+    ],
+    "interfaces/acados_template/acados_template/c_templates_tera/acados_solver.in.c": [
+        ("void {{ name }}_acados_batch_setup_qp_matrices_and_factorize(", BATCH_GPU_QP + "void {{ name }}_acados_batch_setup_qp_matrices_and_factorize("),
     ],
     # 3. build options
     "CMakeLists.txt": [
@@ -52,7 +182,8 @@ EDITS = {
     "acados/CMakeLists.txt": [
         ('if(NOT ACADOS_WITH_CLARABEL)\n    list(REMOVE_ITEM ACADOS_SRC "${PROJECT_SOURCE_DIR}/acados/ocp_qp/ocp_qp_clarabel.c")\nendif()\n',
          'if(NOT ACADOS_WITH_CLARABEL)\n    list(REMOVE_ITEM ACADOS_SRC "${PROJECT_SOURCE_DIR}/acados/ocp_qp/ocp_qp_clarabel.c")\nendif()\n\n'
-         'if(NOT ACADOS_WITH_GPU_IPM)\n    list(REMOVE_ITEM ACADOS_SRC "${PROJECT_SOURCE_DIR}/acados/ocp_qp/ocp_qp_gpu_ipm.c")\nendif()\n'),
+         'if(NOT ACADOS_WITH_GPU_IPM)\n    list(REMOVE_ITEM ACADOS_SRC "${PROJECT_SOURCE_DIR}/acados/ocp_qp/ocp_qp_gpu_ipm.c")\n'
+         '    list(REMOVE_ITEM ACADOS_SRC "${PROJECT_SOURCE_DIR}/acados/ocp_qp/ocp_qp_gpu_pcond.c")\nendif()\n'),
         ("    target_compile_definitions(acados PUBLIC ACADOS_WITH_CLARABEL)\nendif()\n",
          "    target_compile_definitions(acados PUBLIC ACADOS_WITH_CLARABEL)\nendif()\n\n"
          "if(ACADOS_WITH_GPU_IPM)\n"
@@ -96,6 +227,7 @@ extern "C" {
 #endif
 
 #include "acados/ocp_qp/ocp_qp_common.h"
+#include "acados/ocp_qp/ocp_qp_xcond_solver.h"
 #include "acados/utils/types.h"
 
 /* fills the 17 slots of qp_solver_config (the counterpart of ocp_qp_hpipm_config_initialize_default, ocp_qp_hpipm.c:517-540) */
@@ -106,6 +238,18 @@ void ocp_qp_gpu_ipm_acados_config_initialize_default(void *config);
 int ocp_qp_gpu_ipm_acados_evaluate_batch(void *config, int n, void **qp_in, void **qp_out, void *opts, void **mem, void *work);
 void ocp_qp_gpu_ipm_acados_eval_sens_batch(void *config, int n, void **qp_in, void **seed, void **sens_qp_out, void *opts, void **mem,
                                            void *work);
+
+/* partial condensing on the device behind ocp_qp_xcond_config (acados/ocp_qp/ocp_qp_gpu_pcond.c = integration/ocp_qp_gpu_pcond.c):
+ * fills the 20 slots (the counterpart of ocp_qp_partial_condensing_config_initialize_default, ocp_qp_partial_condensing.c:720-750) */
+void ocp_qp_gpu_pcond_acados_config_initialize_default(void *config);
+/* the module's device batch (the vtable has no terminate slot; ocp_qp_xcond_solver_terminate calls this) */
+void ocp_qp_gpu_pcond_acados_memory_release(void *mem);
+int ocp_qp_gpu_pcond_acados_is_module(const void *xcond_config);
+
+/* batch route at the level of the 22-slot solver `ocp_nlp` holds: n capsules' ORIGINAL QPs, condensing options taken from the
+ * condensing module's opts, condensing + IPM + expansion fused on the device; mem[i] = capsule i's ocp_qp_xcond_solver_memory */
+int ocp_qp_gpu_xcond_solver_acados_evaluate_batch(void *config, ocp_qp_xcond_solver_dims *dims, int n, ocp_qp_in **qp_in, ocp_qp_out **qp_out,
+                                                  void *opts, void **mem, void *work);
 
 /* rendezvous: the n `evaluate` calls of an UNMODIFIED _acados_batch_solve loop become one device batch (option "rendezvous") */
 typedef struct ocp_qp_gpu_ipm_rendezvous_ ocp_qp_gpu_ipm_rendezvous;
@@ -142,7 +286,7 @@ def main():
         import re
         patch = re.sub(r"^(---|\+\+\+) (\S+)\t.*$", r"\1 \2", r.stdout, flags=re.M)      # no timestamps: the file is reproducible
         head = ("# Registration of PARTIAL_CONDENSING_GPU_IPM in an acados checkout (INTEGRATION.md 3).  Apply from the acados root:\n"
-                "#     patch -p1 < acados.patch && cp <acados_amd>/integration/ocp_qp_gpu_ipm.c acados/ocp_qp/\n"
+                "#     patch -p1 < acados.patch && cp <acados_amd>/integration/ocp_qp_gpu_{ipm.c,pcond.c,segments.h} acados/ocp_qp/\n"
                 "#     cmake -DACADOS_WITH_GPU_IPM=ON -DACADOS_AMD_QP_DIR=<acados_amd> ..\n"
                 "# Generated by integration/make_patch.py against the reference tree; checked by tests/test_integration_patch.py.\n")
         open(os.path.join(HERE, "acados.patch"), "w").write(head + patch)

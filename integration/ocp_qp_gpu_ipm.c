@@ -46,38 +46,28 @@
 #include "blasfeo/include/blasfeo_d_aux.h"
 
 #include "acados_amd/ocp_qp_gpu_batch.h"
+#include "ocp_qp_gpu_segments.h" /* segment tables: device blobs <-> BLASFEO containers (shared with ocp_qp_gpu_pcond.c) */
 
 typedef struct
 {
     double mu0, tol_stat, tol_eq, tol_ineq, tol_comp, alpha_min, tau_min, reg_prim, t0_min, lam0_min;
     double tol_comp_soft_scale; /* backend-specific: exit tolerance on complementarity of soft-constrained classes = tol_comp * this */
     int iter_max, warm_start, print_level, ric_alg, t0_init, update_fact_exit, cond_pred_corr;
+    /* extension (not an HPIPM name; the outer solver never forwards "cond_" strings, ocp_qp_xcond_solver.c:294-297): partial
+     * condensing INSIDE the device solve -- the QPs handed to evaluate / evaluate_batch are the original ones, condensing, IPM and
+     * expansion run back to back on the device.  Set by ocp_qp_gpu_xcond_solver_acados_evaluate_batch (ocp_qp_gpu_pcond.c) from
+     * the condensing module's options, or directly by a harness; 0 / N: off */
+    int cond_N, cond_block_size_set, cond_block_cap;
+    int *cond_block_size;        /* carved behind the struct: N + 2 entries */
     struct ocp_qp_gpu_ipm_rendezvous_ *rendezvous; /* set: `evaluate` waits for the other capsules and the QPs go as one batch */
 } ocp_qp_gpu_ipm_opts;
-
-/* one piece of a bulk blob <-> one sub-block of a BLASFEO object of the QP */
-enum { SEG_VEC = 0, SEG_MAT = 1, SEG_MAT_T = 2 };
-enum { SRC_BAbt = 0, SRC_RSQrq, SRC_DCt, SRC_b, SRC_rqz, SRC_d, SRC_dmask, SRC_Z,  /* qp_in */
-       SRC_ux, SRC_pi, SRC_lam, SRC_t,                                             /* qp_out */
-       SRC_seed_g, SRC_seed_b, SRC_seed_d };                                       /* seed */
-typedef struct
-{
-    int off, len;   /* position in the per-instance blob */
-    int kind, src, k;
-    int ai, aj;     /* first row (vector: first entry) / first column of the sub-block */
-    int m, n;       /* rows, columns of the sub-block (SEG_MAT_T: the blob holds its transpose, n x m) */
-    int neg;        /* stored negated in acados (upper bounds in d, ocp_qp_common.c:897-906) */
-} gpu_seg;
 
 /* one structure class = one device batch */
 typedef struct
 {
-    ocp_qp_gpu_batch *batch;
+    union { gpu_layout lay; struct { GPU_LAYOUT_MEMBERS }; }; /* bk->batch, bk->seg_in, ... ARE bk->lay.batch, ... */
     int n;                       /* instances */
     int *sig, sig_len, sig_cap;  /* structure the batch was built for */
-    gpu_seg *seg_in, *seg_out, *seg_seed;
-    int n_in, n_out, n_seed, seg_cap_in, seg_cap_out, seg_cap_seed;
-    int L_in, L_out, L_seed;     /* doubles per instance of the three blobs */
     double *blob_in, *blob_out;  /* staging: carved (single QP) or pinned (batch entries) */
     size_t cap_in, cap_out;      /* doubles */
     int *members;                /* batch entries: index of each instance in the caller's arrays */
@@ -142,40 +132,6 @@ static double now_s(void)
     return (double) ts.tv_sec + 1e-9 * (double) ts.tv_nsec;
 }
 
-static char *align8(char *p) { return (char *) (((size_t) p + 7) & ~(size_t) 7); }
-
-/* ------------------------------------------------------------------ sizes from dims */
-
-static int sig_len(const ocp_qp_dims *d)
-{
-    int len = 1;
-    for (int k = 0; k <= d->N; k++) len += 7 + 2 * d->nb[k] + d->ng[k] + d->nbxe[k];
-    return len;
-}
-
-static int blob_in_cap(const ocp_qp_dims *d)
-{
-    int len = 0, getter = 0;
-    for (int k = 0; k <= d->N; k++)
-    {
-        const int nx = d->nx[k], nu = d->nu[k], nx1 = k < d->N ? d->nx[k + 1] : 0;
-        len += nx1 * (nx + nu + 1) + (nu + nx) * (nu + nx) + nu + nx + 5 * d->nb[k] + d->ng[k] * (nu + nx) + 4 * d->ng[k] + 8 * d->ns[k];
-        if ((nu + nx) * (nu + nx + 1) > getter) getter = (nu + nx) * (nu + nx + 1); /* solver_get stages ric_L, ric_l here */
-    }
-    return len > getter ? len : getter;
-}
-
-static int blob_out_cap(const ocp_qp_dims *d)
-{
-    int len = 0;
-    for (int k = 0; k <= d->N; k++)
-        len += d->nu[k] + d->nx[k] + 2 * d->ns[k] + (k < d->N ? d->nx[k + 1] : 0) + 4 * (d->nb[k] + d->ng[k] + d->ns[k]);
-    return len;
-}
-
-#define SEGS_IN_PER_STAGE 34   /* A B b R S Q r q zl zu + 9 bound pieces + 8 masks + Zl Zu + C D (+ lbx#value) */
-#define SEGS_OUT_PER_STAGE 7   /* u x sl su pi lam t */
-#define SEGS_SEED_PER_STAGE 13 /* r q zl zu b lbu lbx lg ubu ubx ug lls lus */
 
 /* ------------------------------------------------------------------ dims / opts (ocp_qp_hpipm.c:60-183) */
 
@@ -192,8 +148,18 @@ static void gpu_dims_set(void *config_, void *dims_, int stage, const char *fiel
     d->nb[stage] = d->nbx[stage] + d->nbu[stage];
 }
 
-static acados_size_t gpu_opts_calculate_size(void *config, void *dims) { return sizeof(ocp_qp_gpu_ipm_opts) + 8; }
-static void *gpu_opts_assign(void *config, void *dims, void *raw_memory) { return align8((char *) raw_memory); }
+static acados_size_t gpu_opts_calculate_size(void *config, void *dims_)
+{
+    return size8(sizeof(ocp_qp_gpu_ipm_opts) + sizeof(int) * (size_t) (((const ocp_qp_dims *) dims_)->N + 2) + 2 * 8);
+}
+static void *gpu_opts_assign(void *config, void *dims_, void *raw_memory)
+{
+    char *c = align8((char *) raw_memory);
+    ocp_qp_gpu_ipm_opts *o = (ocp_qp_gpu_ipm_opts *) c;
+    o->cond_block_cap = ((const ocp_qp_dims *) dims_)->N + 2;
+    o->cond_block_size = (int *) align8(c + sizeof(ocp_qp_gpu_ipm_opts));
+    return o;
+}
 
 static void gpu_opts_initialize_default(void *config, void *dims, void *opts_)
 {
@@ -203,6 +169,7 @@ static void gpu_opts_initialize_default(void *config, void *dims, void *opts_)
     o->tau_min = 0.0; o->reg_prim = 1e-15; o->t0_min = 1e-16; o->lam0_min = 1e-16;
     o->iter_max = 50; o->warm_start = 0; o->print_level = 0; o->ric_alg = 1; o->t0_init = 2; o->update_fact_exit = 0;
     o->cond_pred_corr = 1; o->tol_comp_soft_scale = 1.0;
+    o->cond_N = 0; o->cond_block_size_set = 0;
     o->rendezvous = NULL;
 }
 
@@ -231,6 +198,14 @@ static void gpu_opts_set(void *config, void *opts_, const char *field, void *val
         o->ric_alg = *i;
     }
     else if (!strcmp(field, "tol_comp_soft_scale")) o->tol_comp_soft_scale = *d;
+    else if (!strcmp(field, "cond_N")) { if (*i != o->cond_N) { o->cond_N = *i; o->cond_block_size_set = 0; } }
+    else if (!strcmp(field, "cond_block_size"))
+    {
+        /* cond_N + 1 entries, cond_N first (ocp_qp_partial_condensing.c:305-313) */
+        if (o->cond_N <= 0 || o->cond_N + 1 > o->cond_block_cap) { printf("\nerror: ocp_qp_gpu_ipm_opts_set: cond_block_size needs cond_N (1..N-1) first\n"); exit(1); }
+        memcpy(o->cond_block_size, i, sizeof(int) * (size_t) (o->cond_N + 1));
+        o->cond_block_size_set = 1;
+    }
     else if (!strcmp(field, "t0_min")) o->t0_min = *d;
     else if (!strcmp(field, "lam0_min")) o->lam0_min = *d;
     else if (!strcmp(field, "update_fact_exit")) o->update_fact_exit = *i;
@@ -259,9 +234,9 @@ static acados_size_t gpu_memory_calculate_size(void *config, void *dims_, void *
 {
     const ocp_qp_dims *d = (const ocp_qp_dims *) dims_;
     const size_t nst = (size_t) d->N + 1;
-    return sizeof(ocp_qp_gpu_ipm_memory) + 2 * sizeof(int) * (size_t) sig_len(d)
-           + sizeof(double) * (size_t) (blob_in_cap(d) + blob_out_cap(d))
-           + sizeof(gpu_seg) * nst * (SEGS_IN_PER_STAGE + SEGS_OUT_PER_STAGE + SEGS_SEED_PER_STAGE) + 2 * sizeof(int) + 8 * 8;
+    return size8(sizeof(ocp_qp_gpu_ipm_memory) + 2 * sizeof(int) * (size_t) sig_len(d)
+                 + sizeof(double) * (size_t) (blob_in_cap(d) + blob_out_cap(d))
+                 + sizeof(gpu_seg) * nst * (SEGS_IN_PER_STAGE + SEGS_OUT_PER_STAGE + SEGS_SEED_PER_STAGE) + 2 * sizeof(int) + 8 * 8);
 }
 
 static void *gpu_memory_assign(void *config, void *dims_, void *opts, void *raw_memory)
@@ -302,137 +277,16 @@ static void gpu_memory_get(void *config, void *mem_, const char *field, void *va
         const gpu_bucket *bk = gg ? gg->bk + m->g_bucket : &m->own;
         *(const char **) value = bk->batch ? ocp_qp_gpu_batch_kernel_name(bk->batch) : "";
     }
+    else if (!strcmp(field, "cond_N_active")) /* extension: stages of the QP the device IPM ran on in the last solve (int; N: not condensed) */
+    {
+        const gpu_group *gg = mem_group(m);
+        const gpu_bucket *bk = gg ? gg->bk + m->g_bucket : &m->own;
+        *(int *) value = bk->batch ? (int) ocp_qp_gpu_batch_get_scalar(bk->batch, "cond_N_active") : -1;
+    }
     else { printf("\nerror: ocp_qp_gpu_ipm_memory_get: field %s not available\n", field); exit(1); }
 }
 
 static acados_size_t gpu_workspace_calculate_size(void *config, void *dims, void *opts) { return 0; }
-
-/* ------------------------------------------------------------------ structure signature, segment tables */
-
-static int fill_sig(const ocp_qp_in *in, int *s)
-{
-    const ocp_qp_dims *d = in->dim;
-    int p = 0;
-    s[p++] = d->N;
-    for (int k = 0; k <= d->N; k++)
-    {
-        const int v[7] = {d->nx[k], d->nu[k], d->nbx[k], d->nbu[k], d->ng[k], d->ns[k], d->nbxe[k]};
-        memcpy(s + p, v, sizeof(v)); p += 7;
-        memcpy(s + p, in->idxb[k], sizeof(int) * d->nb[k]); p += d->nb[k];
-        memcpy(s + p, in->idxs_rev[k], sizeof(int) * (d->nb[k] + d->ng[k])); p += d->nb[k] + d->ng[k];
-        memcpy(s + p, in->idxe[k], sizeof(int) * d->nbxe[k]); p += d->nbxe[k];
-    }
-    return p;
-}
-
-static void seg_add(ocp_qp_gpu_batch *b, gpu_seg *tab, int *cnt, int cap, int which, const char *field, int k, int expect,
-                    int kind, int src, int ai, int aj, int m, int n, int neg)
-{
-    /* which: 0 input blob, 1 output blob, 2 seed blob */
-    int len = 0;
-    const int off = which == 2 ? ocp_qp_gpu_batch_sens_bulk_offset(b, 0, field, k, &len) : ocp_qp_gpu_batch_bulk_offset(b, which, field, k, &len);
-    if (off < 0 || len == 0) return;
-    if (len != expect)
-    {
-        printf("\nerror: ocp_qp_gpu_ipm: field %s at stage %d has %d entries in the device layout, %d in the acados struct\n", field, k, len, expect);
-        exit(1);
-    }
-    if (*cnt >= cap) { printf("\nerror: ocp_qp_gpu_ipm: segment table too small\n"); exit(1); }
-    gpu_seg *g = tab + (*cnt)++;
-    g->off = off; g->len = len; g->kind = kind; g->src = src; g->k = k; g->ai = ai; g->aj = aj; g->m = m; g->n = n; g->neg = neg;
-}
-
-/* where every field of the three blobs lives in the acados structs: once per device batch */
-static int build_segments(gpu_bucket *bk, const ocp_qp_dims *d)
-{
-    ocp_qp_gpu_batch *b = bk->batch;
-    const int N = d->N;
-    bk->n_in = bk->n_out = bk->n_seed = 0;
-    /* the first device work after create (structure tables, out of HBM shows up here): negative = the device failed */
-    bk->L_in = ocp_qp_gpu_batch_bulk_len(b, 0);
-    bk->L_out = ocp_qp_gpu_batch_bulk_len(b, 1);
-    bk->L_seed = ocp_qp_gpu_batch_sens_bulk_len(b, 0);
-    if (bk->L_in < 0 || bk->L_out < 0 || bk->L_seed < 0) { bk->L_in = bk->L_out = bk->L_seed = 0; return -1; }
-#define IN(field, expect, kind, src, ai, aj, m, n, neg) seg_add(b, bk->seg_in, &bk->n_in, bk->seg_cap_in, 0, field, k, expect, kind, src, ai, aj, m, n, neg)
-#define OUT(field, expect, src, ai) seg_add(b, bk->seg_out, &bk->n_out, bk->seg_cap_out, 1, field, k, expect, SEG_VEC, src, ai, 0, expect, 1, 0)
-#define SEED(field, expect, src, ai, neg) seg_add(b, bk->seg_seed, &bk->n_seed, bk->seg_cap_seed, 2, field, k, expect, SEG_VEC, src, ai, 0, expect, 1, neg)
-    for (int k = 0; k <= N; k++)
-    {
-        const int nu = d->nu[k], nx = d->nx[k], nx1 = k < N ? d->nx[k + 1] : 0;
-        const int nbu = d->nbu[k], nbx = d->nbx[k], nb = d->nb[k], ng = d->ng[k], ns = d->ns[k];
-        if (k < N)
-        {
-            /* BAbt = [B'; A'; b'] (print.c:234-325): A (nx+ x nx) = (rows nu.. of BAbt)', B (nx+ x nu) = (rows 0..nu)' */
-            IN("A", nx1 * nx, SEG_MAT_T, SRC_BAbt, nu, 0, nx, nx1, 0);
-            IN("B", nx1 * nu, SEG_MAT_T, SRC_BAbt, 0, 0, nu, nx1, 0);
-            IN("b", nx1, SEG_VEC, SRC_b, 0, 0, nx1, 1, 0); /* the VECTOR, not the last row */
-        }
-        /* RSQrq: lower triangle of [[R, S], [S', Q]] -- only the lower triangle is valid */
-        IN("R", nu * nu, SEG_MAT, SRC_RSQrq, 0, 0, nu, nu, 0);
-        IN("S", nu * nx, SEG_MAT_T, SRC_RSQrq, nu, 0, nx, nu, 0); /* S (nu x nx) = (S')' */
-        IN("Q", nx * nx, SEG_MAT, SRC_RSQrq, nu, nu, nx, nx, 0);
-        /* rqz = [r; q; zl; zu]: the vectors ocp_nlp writes every iteration */
-        IN("r", nu, SEG_VEC, SRC_rqz, 0, 0, nu, 1, 0);
-        IN("q", nx, SEG_VEC, SRC_rqz, nu, 0, nx, 1, 0);
-        IN("zl", ns, SEG_VEC, SRC_rqz, nu + nx, 0, ns, 1, 0);
-        IN("zu", ns, SEG_VEC, SRC_rqz, nu + nx + ns, 0, ns, 1, 0);
-        /* d = [lb; lg; -ub; -ug; ls; us] with lb = [lbu; lbx] (ocp_qp_common.c:897-906): natural sign for the device */
-        IN("lbu", nbu, SEG_VEC, SRC_d, 0, 0, nbu, 1, 0);
-        IN("lbx", nbx, SEG_VEC, SRC_d, nbu, 0, nbx, 1, 0);
-        IN("lbx#value", nbx, SEG_VEC, SRC_d, nbu, 0, nbx, 1, 0); /* equality-flagged: the value of x */
-        IN("lg", ng, SEG_VEC, SRC_d, nb, 0, ng, 1, 0);
-        IN("ubu", nbu, SEG_VEC, SRC_d, nb + ng, 0, nbu, 1, 1);
-        IN("ubx", nbx, SEG_VEC, SRC_d, nb + ng + nbu, 0, nbx, 1, 1);
-        IN("ug", ng, SEG_VEC, SRC_d, 2 * nb + ng, 0, ng, 1, 1);
-        IN("lls", ns, SEG_VEC, SRC_d, 2 * nb + 2 * ng, 0, ns, 1, 0);
-        IN("lus", ns, SEG_VEC, SRC_d, 2 * nb + 2 * ng + ns, 0, ns, 1, 0);
-        /* d_mask: same positions, 1.0 / 0.0 (aliased to nlp_in->dmask, ocp_nlp_common.c:2894) */
-        IN("lbu_mask", nbu, SEG_VEC, SRC_dmask, 0, 0, nbu, 1, 0);
-        IN("lbx_mask", nbx, SEG_VEC, SRC_dmask, nbu, 0, nbx, 1, 0);
-        IN("lg_mask", ng, SEG_VEC, SRC_dmask, nb, 0, ng, 1, 0);
-        IN("ubu_mask", nbu, SEG_VEC, SRC_dmask, nb + ng, 0, nbu, 1, 0);
-        IN("ubx_mask", nbx, SEG_VEC, SRC_dmask, nb + ng + nbu, 0, nbx, 1, 0);
-        IN("ug_mask", ng, SEG_VEC, SRC_dmask, 2 * nb + ng, 0, ng, 1, 0);
-        IN("lls_mask", ns, SEG_VEC, SRC_dmask, 2 * nb + 2 * ng, 0, ns, 1, 0);
-        IN("lus_mask", ns, SEG_VEC, SRC_dmask, 2 * nb + 2 * ng + ns, 0, ns, 1, 0);
-        /* Z = [Zl; Zu] */
-        IN("Zl", ns, SEG_VEC, SRC_Z, 0, 0, ns, 1, 0);
-        IN("Zu", ns, SEG_VEC, SRC_Z, ns, 0, ns, 1, 0);
-        /* DCt = [D'; C'] ((nu+nx) x ng): C (ng x nx) = (rows nu.. )', D (ng x nu) = (rows 0..nu)' */
-        IN("C", ng * nx, SEG_MAT_T, SRC_DCt, nu, 0, nx, ng, 0);
-        IN("D", ng * nu, SEG_MAT_T, SRC_DCt, 0, 0, nu, ng, 0);
-
-        /* solution: ux = [u; x; sl; su], lam / t ordered [lb lg ub ug ls us] as HPIPM's */
-        const int nct = 2 * (nb + ng + ns);
-        OUT("u", nu, SRC_ux, 0);
-        OUT("x", nx, SRC_ux, nu);
-        OUT("sl", ns, SRC_ux, nu + nx);
-        OUT("su", ns, SRC_ux, nu + nx + ns);
-        if (k < N) OUT("pi", nx1, SRC_pi, 0);
-        OUT("lam", nct, SRC_lam, 0);
-        OUT("t", nct, SRC_t, 0);
-
-        /* seeds: seed_g = d[r; q; zl; zu], seed_b = d b, seed_d laid out like d -- upper part negated like d
-         * (ocp_nlp_common.c:4078-4081 builds it that way for the nonlinear rows); the device takes natural signs */
-        SEED("seed_r", nu, SRC_seed_g, 0, 0);
-        SEED("seed_q", nx, SRC_seed_g, nu, 0);
-        SEED("seed_zl", ns, SRC_seed_g, nu + nx, 0);
-        SEED("seed_zu", ns, SRC_seed_g, nu + nx + ns, 0);
-        if (k < N) SEED("seed_b", nx1, SRC_seed_b, 0, 0);
-        SEED("seed_lbu", nbu, SRC_seed_d, 0, 0);
-        SEED("seed_lbx", nbx, SRC_seed_d, nbu, 0);
-        SEED("seed_lg", ng, SRC_seed_d, nb, 0);
-        SEED("seed_ubu", nbu, SRC_seed_d, nb + ng, 1);
-        SEED("seed_ubx", nbx, SRC_seed_d, nb + ng + nbu, 1);
-        SEED("seed_ug", ng, SRC_seed_d, 2 * nb + ng, 1);
-        SEED("seed_lls", ns, SRC_seed_d, 2 * nb + 2 * ng, 0);
-        SEED("seed_lus", ns, SRC_seed_d, 2 * nb + 2 * ng + ns, 0);
-    }
-#undef IN
-#undef OUT
-#undef SEED
-    return 0;
-}
 
 /* (re)create the device batch of a bucket for the structure of `in` (n instances); -1: the device failed while the batch's
  * structure was built (the batch is gone, the next call tries again) */
@@ -451,7 +305,7 @@ static int bucket_build(gpu_bucket *bk, const ocp_qp_in *in, const int *sig, int
         ocp_qp_gpu_batch_set_int(bk->batch, "idxs_rev", k, in->idxs_rev[k], d->nb[k] + d->ng[k]);
         ocp_qp_gpu_batch_set_int(bk->batch, "idxe", k, in->idxe[k], d->nbxe[k]);
     }
-    if (build_segments(bk, d) != 0)
+    if (gpu_layout_build(&bk->lay, d) != 0)
     {
         ocp_qp_gpu_batch_destroy(bk->batch);
         bk->batch = NULL;
@@ -459,60 +313,6 @@ static int bucket_build(gpu_bucket *bk, const ocp_qp_in *in, const int *sig, int
         return -1;
     }
     return 0;
-}
-
-/* ------------------------------------------------------------------ blob <-> acados structs, one instance */
-
-static void unpack_segs(const gpu_seg *tab, int cnt, double *blob, struct blasfeo_dmat *const *mats, struct blasfeo_dvec *const *vecs)
-{
-    for (int s = 0; s < cnt; s++)
-    {
-        const gpu_seg *g = tab + s;
-        double *p = blob + g->off;
-        if (g->kind == SEG_VEC)
-        {
-            blasfeo_unpack_dvec(g->m, vecs[g->src] + g->k, g->ai, p, 1);
-            if (g->neg) for (int e = 0; e < g->len; e++) p[e] = -p[e];
-        }
-        else if (g->kind == SEG_MAT) blasfeo_unpack_dmat(g->m, g->n, mats[g->src] + g->k, g->ai, g->aj, p, g->m);
-        else blasfeo_unpack_tran_dmat(g->m, g->n, mats[g->src] + g->k, g->ai, g->aj, p, g->n);
-    }
-}
-
-/* every member array of qp_in, re-read on every call, unpacked from BLASFEO storage straight into the blob */
-static void unpack_qp_in(const gpu_bucket *bk, ocp_qp_in *in, double *blob)
-{
-    struct blasfeo_dmat *mats[3] = {in->BAbt, in->RSQrq, in->DCt};
-    struct blasfeo_dvec *vecs[8] = {NULL, NULL, NULL, in->b, in->rqz, in->d, in->d_mask, in->Z};
-    unpack_segs(bk->seg_in, bk->n_in, blob, mats, vecs);
-}
-
-static void unpack_seed(const gpu_bucket *bk, ocp_qp_seed *seed, double *blob)
-{
-    struct blasfeo_dvec *vecs[15] = {NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, seed->seed_g, seed->seed_b, seed->seed_d};
-    unpack_segs(bk->seg_seed, bk->n_seed, blob, NULL, vecs);
-}
-
-/* hot start: pi, lam, t of qp_out; the primal part stays zero as ocp_qp_hpipm.c:325-336 leaves it before every solve */
-static void unpack_qp_out_duals(const gpu_bucket *bk, ocp_qp_out *out, double *blob)
-{
-    struct blasfeo_dvec *vecs[12] = {NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, out->ux, out->pi, out->lam, out->t};
-    for (int s = 0; s < bk->n_out; s++)
-    {
-        const gpu_seg *g = bk->seg_out + s;
-        if (g->src == SRC_ux) memset(blob + g->off, 0, sizeof(double) * (size_t) g->len);
-        else blasfeo_unpack_dvec(g->m, vecs[g->src] + g->k, g->ai, blob + g->off, 1);
-    }
-}
-
-static void pack_qp_out(const gpu_bucket *bk, const double *blob, ocp_qp_out *out)
-{
-    struct blasfeo_dvec *vecs[12] = {NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, out->ux, out->pi, out->lam, out->t};
-    for (int s = 0; s < bk->n_out; s++)
-    {
-        const gpu_seg *g = bk->seg_out + s;
-        blasfeo_pack_dvec(g->m, (double *) blob + g->off, 1, vecs[g->src] + g->k, g->ai);
-    }
 }
 
 static void apply_opts(ocp_qp_gpu_batch *b, const ocp_qp_gpu_ipm_opts *o, int ws)
@@ -527,6 +327,9 @@ static void apply_opts(ocp_qp_gpu_batch *b, const ocp_qp_gpu_ipm_opts *o, int ws
     ocp_qp_gpu_batch_opts_set(b, "tau_min", &o->tau_min);
     ocp_qp_gpu_batch_opts_set(b, "tol_comp_soft_scale", &o->tol_comp_soft_scale);
     ocp_qp_gpu_batch_opts_set(b, "cond_pred_corr", &o->cond_pred_corr);
+    /* partial condensing inside the device solve (0 = off; the library keeps its condensed batch while cond_N is unchanged) */
+    ocp_qp_gpu_batch_opts_set(b, "cond_N", &o->cond_N);
+    if (o->cond_N > 0 && o->cond_block_size_set) ocp_qp_gpu_batch_opts_set(b, "cond_block_size", o->cond_block_size);
     ocp_qp_gpu_batch_opts_set(b, "t0_min", &o->t0_min);
     ocp_qp_gpu_batch_opts_set(b, "lam0_min", &o->lam0_min);
     ocp_qp_gpu_batch_opts_set(b, "print_level", &o->print_level);
@@ -601,14 +404,14 @@ static int ocp_qp_gpu_ipm_acados(void *config, void *qp_in_, void *qp_out_, void
 
     const int ws = o->warm_start >= 2 ? o->warm_start : 0; /* 1 = 0, acados_ocp_options.py:1029-1031 */
     memset(bk->blob_in, 0, sizeof(double) * (size_t) bk->L_in);
-    unpack_qp_in(bk, in, bk->blob_in);
-    if (ws >= 2) unpack_qp_out_duals(bk, out, bk->blob_out);
+    unpack_qp_in(&bk->lay, in, bk->blob_in);
+    if (ws >= 2) unpack_qp_out_duals(&bk->lay, out, bk->blob_out);
     const double t_packed = now_s();
 
     bucket_solve(bk, o, ws);
     const double t_solved = now_s();
 
-    pack_qp_out(bk, bk->blob_out, out);
+    pack_qp_out(&bk->lay, bk->blob_out, out);
     const double t_end = now_s();
     if (info)
     {
@@ -787,8 +590,8 @@ static int evaluate_batch_masked(void *config, int n, void **qp_in_, void **qp_o
         const gpu_bucket *bk = g->bk + g->bucket_of[i];
         double *blob = bk->blob_in + (size_t) g->pos_of[i] * (size_t) bk->L_in;
         memset(blob, 0, sizeof(double) * (size_t) bk->L_in);
-        unpack_qp_in(bk, ins[i], blob);
-        if (ws >= 2) unpack_qp_out_duals(bk, outs[i], bk->blob_out + (size_t) g->pos_of[i] * (size_t) bk->L_out);
+        unpack_qp_in(&bk->lay, ins[i], blob);
+        if (ws >= 2) unpack_qp_out_duals(&bk->lay, outs[i], bk->blob_out + (size_t) g->pos_of[i] * (size_t) bk->L_out);
     }
     if (skip && (fresh || ws >= 2))
         for (int q = 0; q < g->nbk; q++)
@@ -815,7 +618,7 @@ static int evaluate_batch_masked(void *config, int n, void **qp_in_, void **qp_o
     {
         if (skip && skip[i]) continue;
         const gpu_bucket *bk = g->bk + g->bucket_of[i];
-        pack_qp_out(bk, bk->blob_out + (size_t) g->pos_of[i] * (size_t) bk->L_out, outs[i]);
+        pack_qp_out(&bk->lay, bk->blob_out + (size_t) g->pos_of[i] * (size_t) bk->L_out, outs[i]);
     }
     const double t_end = now_s();
 
@@ -1050,9 +853,9 @@ static void gpu_eval_sens(void *config, void *qp_in, void *seed_, void *sens_qp_
      * should use; this slot stays correct, not fast, under the generated OpenMP loops) */
     bucket_lock(bk);
     memset(bk->blob_in, 0, sizeof(double) * (size_t) bk->n * (size_t) bk->L_seed);
-    unpack_seed(bk, (ocp_qp_seed *) seed_, bk->blob_in + (size_t) pos * (size_t) bk->L_seed);
+    unpack_seed(&bk->lay, (ocp_qp_seed *) seed_, bk->blob_in + (size_t) pos * (size_t) bk->L_seed);
     bucket_sens(bk);
-    pack_qp_out(bk, bk->blob_out + (size_t) pos * (size_t) bk->L_out, (ocp_qp_out *) sens_qp_out_);
+    pack_qp_out(&bk->lay, bk->blob_out + (size_t) pos * (size_t) bk->L_out, (ocp_qp_out *) sens_qp_out_);
     bucket_unlock(bk);
 }
 
@@ -1076,7 +879,7 @@ void ocp_qp_gpu_ipm_acados_eval_sens_batch(void *config, int n, void **qp_in, vo
         const gpu_bucket *bk = g->bk + mems[i]->g_bucket;
         double *blob = bk->blob_in + (size_t) mems[i]->g_pos * (size_t) bk->L_seed;
         memset(blob, 0, sizeof(double) * (size_t) bk->L_seed);
-        unpack_seed(bk, (ocp_qp_seed *) seed_[i], blob);
+        unpack_seed(&bk->lay, (ocp_qp_seed *) seed_[i], blob);
     }
 #pragma omp parallel for schedule(dynamic, 1) if (g->nbk > 1)
     for (int q = 0; q < g->nbk; q++) bucket_sens(g->bk + q);
@@ -1084,7 +887,7 @@ void ocp_qp_gpu_ipm_acados_eval_sens_batch(void *config, int n, void **qp_in, vo
     for (int i = 0; i < n; i++)
     {
         const gpu_bucket *bk = g->bk + mems[i]->g_bucket;
-        pack_qp_out(bk, bk->blob_out + (size_t) mems[i]->g_pos * (size_t) bk->L_out, (ocp_qp_out *) sens_qp_out_[i]);
+        pack_qp_out(&bk->lay, bk->blob_out + (size_t) mems[i]->g_pos * (size_t) bk->L_out, (ocp_qp_out *) sens_qp_out_[i]);
     }
 }
 
