@@ -672,7 +672,10 @@ def dry_run(args):
         dist.init_process_group("gloo")
     if args.config == "c5":
         per_class = args.c5_total // len(C5_CLASSES)
-        mine = {"classes": len(C5_CLASSES) + 1, "per_class": [shard_range(per_class, rank, max(world, 8))] * (len(C5_CLASSES) + 1)}
+        # every class (the nine shapes + the multi-phase one) is split the same way: one range per rank says it all; gather_counts is
+        # what main_c5 hands to the library's exact-count gather (uneven shards: 58,254 = 6 x 7,282 + 2 x 7,281)
+        mine = {"classes": len(C5_CLASSES) + 1, "per_class": list(shard_range(per_class, rank, max(world, 8))),
+                "gather_counts": [hi - lo for lo, hi in (shard_range(per_class, r, max(world, 8)) for r in range(world))]}
     else:
         mine = {"instances": [rank * args.batch, (rank + 1) * args.batch]}
     mine.update(rank=rank, local_rank=int(os.environ.get("LOCAL_RANK", "0")), pid=os.getpid())
@@ -683,7 +686,8 @@ def dry_run(args):
         dist.barrier()
     if rank == 0:
         print(json.dumps({"dry_run": True, "n_gpus": world, "config": args.config, "ranks": ranks,
-                          "gather": {"ranks": world, "collective": "ocp_qp_gpu_batch_gather (RCCL) after the timed region"}}), flush=True)
+                          "gather": {"ranks": world, "collective": "ocp_qp_gpu_batch_gather (RCCL) after the timed region"}},
+                         separators=(",", ":")), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

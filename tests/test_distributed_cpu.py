@@ -72,6 +72,19 @@ def test_bench_gpus_flag_starts_that_many_ranks():
         assert line["dry_run"] and line["n_gpus"] == 2 and line["gather"]["ranks"] == 2
         assert [r["rank"] for r in line["ranks"]] == [0, 1] and line["ranks"][0]["pid"] != line["ranks"][1]["pid"]
         assert all(key in r for r in line["ranks"])
+    # the driver's largest job: 8 ranks on the mixed-class configuration.  Shards of a class are UNEVEN (58,254 = 6 x 7,282 + 2 x 7,281):
+    # every rank reports the same per-rank counts -- what main_c5 passes to the exact-count gather (round-4 advice: it assumed even
+    # shards) -- they tile the class without gap or overlap, and the line stays below the 4 KB the driver can read
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run", "--config", "c5"], env=env, timeout=600,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout.decode().strip().splitlines()[-1]
+    line = json.loads(out)
+    assert len(out) < 4096 and line["n_gpus"] == 8 and [r["rank"] for r in line["ranks"]] == list(range(8))
+    per_class = 524288 // 9
+    counts = line["ranks"][0]["gather_counts"]
+    assert all(r["gather_counts"] == counts for r in line["ranks"]) and sum(counts) == per_class and sorted(set(counts)) == [7281, 7282]
+    edges = [r["per_class"] for r in line["ranks"]]
+    assert edges[0][0] == 0 and edges[-1][1] == per_class and all(edges[i][1] == edges[i + 1][0] for i in range(7))
+    assert [hi - lo for lo, hi in edges] == counts
     # one rank: no launcher in between
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run"], env=env, timeout=120, stdout=subprocess.PIPE,
                          check=True).stdout.decode().strip().splitlines()[-1]
