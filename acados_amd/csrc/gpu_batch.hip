@@ -92,8 +92,14 @@ struct W16Set
     {NX, NU, NG, nullptr, nullptr, nullptr, nullptr, gqp::ky_factor<NX, NU, NG>, gqp::ky_backrhs<NX, NU, NG>,     \
      gqp::ky_fwd<NX, NU, false, NG>, gqp::ky_fwd<NX, NU, true, NG>, 4 * gqp::W16RLds<NX, NU, NG>::SZ * sizeof(double), nullptr, nullptr, \
      gqp::kt_factor<NX, NU, NG>, 4 * gqp::W16TLds<NX, NU, NG>::SZ * sizeof(double)}
+/* ... the same on register rows only (ky_factor): the tile sweep of this instantiation does not fit the register file
+ * (kt_factor<24,3,8>: 6 spilled VGPRs; spill traffic is HBM traffic there -- the ISA lint of `make` refuses it) */
+#define GQP_W16G_ROWS(NX, NU, NG)                                                                             \
+    {NX, NU, NG, nullptr, nullptr, nullptr, nullptr, gqp::ky_factor<NX, NU, NG>, gqp::ky_backrhs<NX, NU, NG>,     \
+     gqp::ky_fwd<NX, NU, false, NG>, gqp::ky_fwd<NX, NU, true, NG>, 4 * gqp::W16RLds<NX, NU, NG>::SZ * sizeof(double), nullptr, nullptr, \
+     nullptr, 0}
 const W16Set g_w16_sets[] = {GQP_W16(4, 1), GQP_W16(8, 3), GQP_W16(12, 3), GQP_W16(4, 4), GQP_W16(12, 4),
-                             GQP_W16R(8, 15), GQP_W16R(24, 6), GQP_W16G(24, 3, 4)};
+                             GQP_W16R(8, 15), GQP_W16R(24, 6), GQP_W16G(24, 3, 4), GQP_W16G_ROWS(24, 3, 8)};
 
 /* condensing of the box-only class on register rows, sixteen lanes per block (pcond_kernels_w16.hpp): compiled
  * (NX, NU, block size) with nx + bs * nu <= 32 */

@@ -246,6 +246,33 @@ def test_c4_chain_soft_constraints_gpu(gpu_lib, monkeypatch, fam):
     assert abs(int(b.info("iter")[53]) - o.iter) <= 1 and o.iter < 20
 
 
+def test_chain_class_with_eight_general_rows_gpu(gpu_lib, monkeypatch):
+    """the "ng = 8 chain class" (nx = 24, nu = 3, N = 40: 15 inequality rows per stage, ns = 12) on the two-rows-per-lane GEN kernels
+    (w16r-gen<24,3,8>) against the oracle, the same iteration counts as the wave-per-instance GEN kernels it used to fall back to,
+    and at least 1.8 x their rate on 2,048 instances (round-4 review, item 7)"""
+    import time
+    from acados_amd import OcpQpGpuBatch
+    from acados_amd.generators import chain_soft_qp
+    qps = [chain_soft_qp(i, N=40, ng=8) for i in range(64)]
+    monkeypatch.setenv("ACADOS_AMD_W16G", "1")
+    b = _check_batch_vs_oracle_gpu(qps, 4, tol=1e-7, tol_stat=1e-8)
+    assert b.kernel_name.startswith("w16r-gen<NX=24,NU=3,NG=8>")
+    big = qps * 32
+    rate, iters = {}, {}
+    for fam, env in (("w16r-gen", "1"), ("wpi-gen", "0")):
+        monkeypatch.setenv("ACADOS_AMD_W16G", env)
+        g = OcpQpGpuBatch.from_qps(big)
+        for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+            g.opts_set(f, 1e-8)
+        assert g.kernel_name.startswith(fam) and g.solve() == 0
+        t0 = time.perf_counter()
+        assert g.solve() == 0
+        rate[fam], iters[fam] = len(big) / (time.perf_counter() - t0), g.info("iter").copy()
+    print("ng = 8 chain class, 2,048 instances:", {k: f"{v:.3e} solves/s" for k, v in rate.items()})
+    assert np.array_equal(iters["w16r-gen"], iters["wpi-gen"])
+    assert rate["w16r-gen"] >= 1.8 * rate["wpi-gen"], rate
+
+
 def test_c4_one_instance_per_lane_kernels_gpu(gpu_lib, monkeypatch):
     """the general one-instance-per-lane kernels (what shapes below nu+nx = 13 with general rows / slacks
     run on) on the C4 shape, forced with ACADOS_AMD_WPI=0"""

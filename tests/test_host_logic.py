@@ -206,6 +206,21 @@ def test_c4_shape_general_constraints_and_slacks_hostsim(hostsim_lib, monkeypatc
         assert b.kernel_name.startswith("wpi-gen(nx=24,nu=3,ng=4,ns=8")
 
 
+def test_chain_class_with_eight_general_rows_hostsim(hostsim_lib, monkeypatch):
+    """the "ng = 8 chain class" of the round-4 review (nx = 24, nu = 3, 3 hard input rows + 4 soft state rows + 8 soft general rows =
+    15 inequality rows per stage, ns = 12): served by the two-rows-per-lane GEN kernels (w16r-gen<24,3,8>, factor sweep on register
+    rows: the tile sweep of this instantiation spills) instead of the wave-per-instance ones; both against the oracle"""
+    from acados_amd.generators import chain_soft_qp
+    monkeypatch.setenv("ACADOS_AMD_WPI", "1")
+    qps = [chain_soft_qp(i, N=6, ng=8) for i in range(5)]       # ragged: one full workgroup of four instances + one
+    b = _check_batch_vs_oracle(qps, hostsim_lib)
+    assert b.kernel_name.startswith("w16r-gen<NX=24,NU=3,NG=8>") and int(b.scalar("w16_tiles")) == 0
+    it = b.info("iter").copy()
+    monkeypatch.setenv("ACADOS_AMD_W16G", "0")
+    b2 = _check_batch_vs_oracle(qps, hostsim_lib)
+    assert b2.kernel_name.startswith("wpi-gen(nx=24,nu=3,ng=8,ns=12") and np.array_equal(it, b2.info("iter"))
+
+
 def test_more_than_64_inequality_sides_hostsim(hostsim_lib):
     """stages with 65..128 inequality sides (two activity words per stage, wave-per-instance kernels only):
     nx + nu = 40 with x0 as equality bounds (80 sides at stage 0), and partial condensing with blocks of 10
