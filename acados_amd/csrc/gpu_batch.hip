@@ -87,7 +87,8 @@ struct W16Set
     {NX, NU, 0, gqp::ky_factor<NX, NU>, gqp::ky_backrhs<NX, NU>, gqp::ky_fwd<NX, NU, false>, gqp::ky_fwd<NX, NU, true>, \
      nullptr, nullptr, nullptr, nullptr, 4 * gqp::W16RLds<NX, NU>::SZ * sizeof(double), nullptr, nullptr,                \
      gqp::kt_factor<NX, NU>, 4 * gqp::W16TLds<NX, NU>::SZ * sizeof(double)}
-/* ... with general rows and slacks (one slack per row): the C4 class */
+/* ... with general rows and slacks (one slack per row): the C4 class; the same kernels at nu + nx <= 16 (R = 1 row per lane:
+ * <12,4,4>, <8,3,4>) put general rows + slacks of the small shapes on the sixteen-lanes family too */
 #define GQP_W16G(NX, NU, NG)                                                                                  \
     {NX, NU, NG, nullptr, nullptr, nullptr, nullptr, gqp::ky_factor<NX, NU, NG>, gqp::ky_backrhs<NX, NU, NG>,     \
      gqp::ky_fwd<NX, NU, false, NG>, gqp::ky_fwd<NX, NU, true, NG>, 4 * gqp::W16RLds<NX, NU, NG>::SZ * sizeof(double), nullptr, nullptr, \
@@ -99,7 +100,7 @@ struct W16Set
      gqp::ky_fwd<NX, NU, false, NG>, gqp::ky_fwd<NX, NU, true, NG>, 4 * gqp::W16RLds<NX, NU, NG>::SZ * sizeof(double), nullptr, nullptr, \
      nullptr, 0}
 const W16Set g_w16_sets[] = {GQP_W16(4, 1), GQP_W16(8, 3), GQP_W16(12, 3), GQP_W16(4, 4), GQP_W16(12, 4),
-                             GQP_W16R(8, 15), GQP_W16R(24, 6), GQP_W16G(24, 3, 4), GQP_W16G_ROWS(24, 3, 8)};
+                             GQP_W16R(8, 15), GQP_W16R(24, 6), GQP_W16G(24, 3, 4), GQP_W16G_ROWS(24, 3, 8), GQP_W16G(12, 4, 4), GQP_W16G(8, 3, 4)};
 
 /* condensing of the box-only class on register rows, sixteen lanes per block (pcond_kernels_w16.hpp): compiled
  * (NX, NU, block size) with nx + bs * nu <= 32 */
@@ -777,7 +778,9 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
                     bool fits = force_NX ? (ws.NX == wx && ws.NU == wu) : (ws.NX >= wx && ws.NU >= wu);
                     if (!gen) fits = fits && ws.fact && ws.NG == 0;
                     else if (soft_dims) fits = fits && ws.sfact && ws.NG == 0;                       /* slacks on box rows only */
-                    else fits = fits && ws.sfact && ws.NG >= mg && !(e16g && atoi(e16g) == 0);      /* general rows */
+                    /* general rows (a small block with a compiled one-instance-per-lane general set -- the golden shared-slack
+                     * structure, nx = 4, nu = 1 -- keeps the dispatch it was measured with: gen_small below) */
+                    else fits = fits && ws.sfact && ws.NG >= mg && !(e16g && atoi(e16g) == 0) && !(b->ks && b->ks->NX + b->ks->NU <= 6);
                     if (ws.NX + ws.NU > 16 && (e16r && atoi(e16r) == 0)) fits = false;
                     /* two rows per lane: dims run PADDED inside the compiled shape, so its ~2.3x over the wave-per-instance
                      * kernels (which take dims at run time) is gone once the padded block has more than twice the work:
@@ -803,7 +806,9 @@ static ocp_qp_gpu_batch *batch_create_shape(int N, const int *nx, const int *nu,
         const int batch_max = bm ? atoi(bm)
                             : !has_w16 ? (gen_small ? GQP_WPI_GEN_SMALL_MAX : GQP_WPI_BATCH_MAX)
                             : kb_small ? (xbox_dims ? GQP_W16_SMALL_XBOX_MAX : GQP_W16_SMALL_MAX)
-                            : (xbox_dims ? INT_MAX : GQP_W16_BATCH_MAX);
+                            /* general rows / slacks on the sixteen-lanes GEN kernels: the one-instance-per-lane alternative is the
+                             * general set of a (much) larger padded shape with its blocks in scratch -- never */
+                            : (xbox_dims || (gen && !soft_dims && !gen_small) ? INT_MAX : GQP_W16_BATCH_MAX);
         /* (a shape no compiled one-instance-per-lane set covers runs here whatever the override says) */
         const bool want = g_force_wpi || need_wpi || !b->ks || (env ? atoi(env) != 0 : (wx + wu >= GQP_WPI_MIN_N || n_batch <= batch_max));
         if (want && wx + wu <= 64 && wx >= 1 && mg <= 32 && ms <= 32)

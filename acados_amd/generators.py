@@ -154,7 +154,7 @@ def fill_lqr_batch(gb, data, N, xp=None):
     gb.set("ubx", 0, x0)
 
 
-def chain_soft_qp(i=0, N=40, nx=24, nu=3, seed=1, ng=4):
+def chain_soft_qp(i=0, N=40, nx=24, nu=3, seed=1, ng=4, nsx=4):
     """Configuration C4, instance i: chain-like linearisation data with
     hard input bounds, 4 soft state bounds, 4 soft general rows, ns = 8 slacks
     (idxs_rev: soft x-bounds -> slacks 0..3, general rows -> slacks 4..7), Z = 1e2, z = 1e1,
@@ -169,8 +169,8 @@ def chain_soft_qp(i=0, N=40, nx=24, nu=3, seed=1, ng=4):
     Q = np.diag(g.uniform(0.1, 10.0, nx))
     R = np.diag(g.uniform(0.01, 1.0, nu))
     x0 = g.uniform(-1.0, 1.0, nx)
-    nsx = 4                                      # (ng = 4: C4; ng = 8: the "ng = 8 chain class" of the round-4 review, 15 rows per stage)
-    ixs = nu + 6 * np.arange(nsx) + 1            # wall constraint on the "y positions"
+    # (ng = 4, nsx = 4: C4; ng = 8: the "ng = 8 chain class" of the round-4 review, 15 rows per stage)
+    ixs = nu + (nx // nsx) * np.arange(nsx) + 1  # wall constraint on the "y positions" (every sixth state of the nx = 24 chain)
     qp = AcadosOcpQp(N)
     for k in range(N + 1):
         last = k == N

@@ -273,6 +273,33 @@ def test_chain_class_with_eight_general_rows_gpu(gpu_lib, monkeypatch):
     assert rate["w16r-gen"] >= 1.8 * rate["wpi-gen"], rate
 
 
+def test_general_rows_and_slacks_at_small_shapes_gpu(gpu_lib, monkeypatch):
+    """general rows + slacks at nu + nx <= 16 on the sixteen-lanes GEN kernels (w16r-gen<12,4,4>, <8,3,4> at one row per lane): oracle
+    parity, identical iteration counts and the rate against the wave-per-instance GEN kernels they replace (4,096 instances)"""
+    import time
+    from acados_amd import OcpQpGpuBatch
+    from acados_amd.generators import chain_soft_qp
+    for (nx, nu, ng, nsx), want in (((12, 4, 4, 4), "w16r-gen<NX=12,NU=4,NG=4>"), ((8, 3, 4, 2), "w16r-gen<NX=8,NU=3,NG=4>")):
+        qps = [chain_soft_qp(i, N=30, nx=nx, nu=nu, ng=ng, nsx=nsx) for i in range(64)]
+        monkeypatch.setenv("ACADOS_AMD_W16G", "1")
+        b = _check_batch_vs_oracle_gpu(qps, 4, tol=1e-7, tol_stat=1e-8)
+        assert b.kernel_name == want
+        big = qps * 64
+        rate, iters = {}, {}
+        for fam, env in (("w16r-gen", "1"), ("wpi-gen", "0")):
+            monkeypatch.setenv("ACADOS_AMD_W16G", env)
+            g = OcpQpGpuBatch.from_qps(big)
+            for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+                g.opts_set(f, 1e-8)
+            assert g.kernel_name.startswith(fam) and g.solve() == 0
+            t0 = time.perf_counter()
+            assert g.solve() == 0
+            rate[fam], iters[fam] = len(big) / (time.perf_counter() - t0), g.info("iter").copy()
+        print((nx, nu, ng), "4,096 instances:", {k: f"{v:.3e} solves/s" for k, v in rate.items()})
+        assert np.array_equal(iters["w16r-gen"], iters["wpi-gen"])
+        assert rate["w16r-gen"] >= 1.5 * rate["wpi-gen"], rate
+
+
 def test_c4_one_instance_per_lane_kernels_gpu(gpu_lib, monkeypatch):
     """the general one-instance-per-lane kernels (what shapes below nu+nx = 13 with general rows / slacks
     run on) on the C4 shape, forced with ACADOS_AMD_WPI=0"""

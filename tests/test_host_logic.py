@@ -221,6 +221,29 @@ def test_chain_class_with_eight_general_rows_hostsim(hostsim_lib, monkeypatch):
     assert b2.kernel_name.startswith("wpi-gen(nx=24,nu=3,ng=8,ns=12") and np.array_equal(it, b2.info("iter"))
 
 
+def test_general_rows_and_slacks_at_small_shapes_on_sixteen_lanes_hostsim(hostsim_lib, monkeypatch):
+    """general rows + slacks (one slack per row) at nu + nx <= 16 used to run on the wave-per-instance GEN kernels at every batch
+    size; the two-rows GEN kernels instantiated at R = 1 row per lane (<12,4,4>, <8,3,4>; factor sweep on 4 x 4 MFMA tiles) take
+    them, shapes padded inside the compiled ones included -- same solution as the oracle, same iteration counts as wpi-gen"""
+    from acados_amd.generators import chain_soft_qp
+    monkeypatch.setenv("ACADOS_AMD_WPI", "1")
+    for (nx, nu, ng, nsx), want in (((12, 4, 4, 4), "w16r-gen<NX=12,NU=4,NG=4>"), ((10, 3, 4, 3), "w16r-gen<NX=12,NU=4,NG=4>"),
+                                    ((8, 3, 4, 2), "w16r-gen<NX=8,NU=3,NG=4>"), ((8, 3, 2, 4), "w16r-gen<NX=8,NU=3,NG=4>")):
+        qps = [chain_soft_qp(i, N=6, nx=nx, nu=nu, ng=ng, nsx=nsx) for i in range(5)]
+        monkeypatch.setenv("ACADOS_AMD_W16G", "1")
+        b = _check_batch_vs_oracle(qps, hostsim_lib)
+        assert b.kernel_name == want and int(b.scalar("w16_tiles")) == 1, b.kernel_name
+        it = b.info("iter").copy()
+        monkeypatch.setenv("ACADOS_AMD_W16G", "0")
+        b2 = _check_batch_vs_oracle(qps, hostsim_lib)
+        assert b2.kernel_name.startswith("wpi-gen(") and np.array_equal(it, b2.info("iter"))
+    # the golden shared-slack structure (nx = 4, nu = 1, two general rows on one slack) keeps its own dispatch: a slack shared by
+    # several rows is not what these kernels carry
+    monkeypatch.setenv("ACADOS_AMD_W16G", "1")
+    b = _check_batch_vs_oracle([load_qp("casadi_qp_tests/pend_idxs_rev_min_qp0.json")] * 3, hostsim_lib)
+    assert b.kernel_name.startswith("wpi-gen("), b.kernel_name
+
+
 def test_more_than_64_inequality_sides_hostsim(hostsim_lib):
     """stages with 65..128 inequality sides (two activity words per stage, wave-per-instance kernels only):
     nx + nu = 40 with x0 as equality bounds (80 sides at stage 0), and partial condensing with blocks of 10
