@@ -114,6 +114,11 @@ typedef struct ocp_qp_gpu_ipm_memory_
     int *sig_scratch;
     double time_qp_solver_call;
     int iter, status;
+    /* per-iteration statistics of this memory's QP, HPIPM-shaped (ocp_qp_hpipm.c:255-297 "stat" / "stat_m": what
+     * ocp_qp_solver_get_stats and the Python getter read): stat_m columns x (iter + 1) rows, carved, filled on demand from the device
+     * table (the library keeps it for the first 64 instances of a batch) */
+    double *stat;
+    int stat_m, stat_rows;
 } ocp_qp_gpu_ipm_memory;
 
 /* the group a memory belongs to, if that group is still the one it was solved in */
@@ -230,13 +235,21 @@ static void gpu_opts_get(void *config, void *opts_, const char *field, void *val
 
 /* ------------------------------------------------------------------ memory */
 
+#define GPU_IPM_STAT_M 20 /* columns of the statistics table, as HPIPM's */
+static int stat_rows_for(const void *opts_)
+{
+    const ocp_qp_gpu_ipm_opts *o = (const ocp_qp_gpu_ipm_opts *) opts_;
+    return (o && o->iter_max > 50 ? o->iter_max : 50) + 2;
+}
+
 static acados_size_t gpu_memory_calculate_size(void *config, void *dims_, void *opts)
 {
     const ocp_qp_dims *d = (const ocp_qp_dims *) dims_;
     const size_t nst = (size_t) d->N + 1;
     return size8(sizeof(ocp_qp_gpu_ipm_memory) + 2 * sizeof(int) * (size_t) sig_len(d)
                  + sizeof(double) * (size_t) (blob_in_cap(d) + blob_out_cap(d))
-                 + sizeof(gpu_seg) * nst * (SEGS_IN_PER_STAGE + SEGS_OUT_PER_STAGE + SEGS_SEED_PER_STAGE) + 2 * sizeof(int) + 8 * 8);
+                 + sizeof(gpu_seg) * nst * (SEGS_IN_PER_STAGE + SEGS_OUT_PER_STAGE + SEGS_SEED_PER_STAGE) + 2 * sizeof(int)
+                 + sizeof(double) * GPU_IPM_STAT_M * (size_t) stat_rows_for(opts) + 9 * 8);
 }
 
 static void *gpu_memory_assign(void *config, void *dims_, void *opts, void *raw_memory)
@@ -261,6 +274,11 @@ static void *gpu_memory_assign(void *config, void *dims_, void *opts, void *raw_
     m->sig_scratch = (int *) c; c += sizeof(int) * (size_t) bk->sig_cap; /* its own scratch: a signature can be longer than a staging blob */
     bk->st = (int *) c; c += sizeof(int);
     bk->it = (int *) c; c += sizeof(int);
+    c = align8(c);
+    m->stat_m = GPU_IPM_STAT_M;
+    m->stat_rows = stat_rows_for(opts);
+    m->stat = (double *) c; c += sizeof(double) * GPU_IPM_STAT_M * (size_t) m->stat_rows;
+    memset(m->stat, 0, sizeof(double) * GPU_IPM_STAT_M * (size_t) m->stat_rows);
     m->rv_index = -1;
     return m;
 }
@@ -277,6 +295,17 @@ static void gpu_memory_get(void *config, void *mem_, const char *field, void *va
         const gpu_bucket *bk = gg ? gg->bk + m->g_bucket : &m->own;
         *(const char **) value = bk->batch ? ocp_qp_gpu_batch_kernel_name(bk->batch) : "";
     }
+    else if (!strcmp(field, "stat"))
+    {
+        /* ocp_qp_hpipm.c:262-266: pointer to the table of the last solve (rows 0..iter) */
+        const gpu_group *gg = mem_group(m);
+        const gpu_bucket *bk = gg ? gg->bk + m->g_bucket : &m->own;
+        memset(m->stat, 0, sizeof(double) * (size_t) m->stat_m * (size_t) m->stat_rows);
+        if (bk->batch) ocp_qp_gpu_batch_get_stat(bk->batch, gg ? m->g_pos : 0, m->stat, m->stat_rows);
+        *(double **) value = m->stat;
+    }
+    else if (!strcmp(field, "stat_m")) *(int *) value = m->stat_m;
+    else if (!strcmp(field, "tau_iter")) *(double *) value = 0.0; /* (the barrier parameter the solver ended on is not tracked per capsule) */
     else if (!strcmp(field, "cond_N_active")) /* extension: stages of the QP the device IPM ran on in the last solve (int; N: not condensed) */
     {
         const gpu_group *gg = mem_group(m);

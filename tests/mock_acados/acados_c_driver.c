@@ -99,7 +99,16 @@ int main(int argc, char **argv)
         ocp_qp_xcond_solver_get_scalar(solver, qp_out, "time_tot", &t_tot);
         ocp_qp_dims *xd = NULL;
         config->xcond->dims_get(config->xcond, dims->xcond_dims, "xcond_dims", &xd);
-        fprintf(g, "N2 %d status %d iter %d xcond_N %d res %.17g %.17g %.17g %.17g time_tot %.6g\n", N2, status, iter, xd->N, res[0], res[1], res[2], res[3], t_tot);
+        /* the per-iteration statistics through the reference's ocp_qp_solver_get_stats (ocp_qp_interface.c:612-625: memory_get "iter",
+         * "stat", "stat_m"); the last row holds the residuals the solver stopped on */
+        double *stats = calloc((size_t) 20 * (size_t) (itmax + 2), sizeof(double));
+        int stat_m = 0;
+        ocp_qp_solver_get_stats(solver, stats, "PARTIAL_CONDENSING_GPU_IPM");
+        solver->config->memory_get(solver->config, solver->mem, "stat_m", &stat_m);
+        const double *last = stats + (size_t) stat_m * (size_t) iter;
+        fprintf(g, "N2 %d status %d iter %d xcond_N %d res %.17g %.17g %.17g %.17g time_tot %.6g stat_m %d stat_last %.17g %.17g %.17g %.17g %.17g\n", N2, status,
+                iter, xd->N, res[0], res[1], res[2], res[3], t_tot, stat_m, last[6], last[7], last[8], last[9], last[10]);
+        free(stats);
         mock_write_sol(g, &cap->dim, qp_out);
         /* the PATCHED terminate of the reference's outer solver releases the condensing module's device batch */
         config->terminate(config, solver->mem, solver->work);

@@ -69,7 +69,8 @@ def _run(exe, qp, tmp_path, n2s, by_name=False):
     for ln in open(out_file).read().splitlines():
         p = ln.split()
         if p[0] == "N2":
-            cur = {"N2": int(p[1]), "status": int(p[3]), "iter": int(p[5]), "xcond_N": int(p[7]), "res": [float(v) for v in p[9:13]], "sol": {}}
+            cur = {"N2": int(p[1]), "status": int(p[3]), "iter": int(p[5]), "xcond_N": int(p[7]), "res": [float(v) for v in p[9:13]],
+                   "stat_m": int(p[16]), "stat_last": [float(v) for v in p[18:23]], "sol": {}}
             runs.append(cur)
         else:
             cur["sol"][(p[0], int(p[1]))] = np.array([float(x) for x in p[2:]])
@@ -91,6 +92,9 @@ def test_reference_unit_test_through_the_patched_acados_c_layer(clib, tmp_path, 
         assert r["status"] == 0                                            # REQUIRE(acados_return == 0)
         assert max(r["res"]) <= 1e-8 * (1 + 1e-3) + 1e-13, r["res"]        # REQUIRE(max_res <= tol), tol of the IPM solvers
         assert r["xcond_N"] == r["N2"] and abs(r["iter"] - o.iter) <= 1
+        # ocp_qp_solver_get_stats (memory_get "stat" / "stat_m" of the plugin, HPIPM-shaped): the row of the last iteration carries
+        # mu and the four residuals the solver stopped on
+        assert r["stat_m"] == 20 and 0.0 < r["stat_last"][0] < 1e-6 and max(r["stat_last"][1:]) <= 1e-8, r["stat_last"]
         for k in range(qp.N + 1):
             ref = np.concatenate([o.get(k, "u"), o.get(k, "x")])
             assert np.allclose(r["sol"][("ux", k)], ref, rtol=1e-7, atol=1e-8), (r["N2"], k)
