@@ -440,6 +440,7 @@ void finalize_structure(ocp_qp_gpu_batch *b)
     D.res = dalloc<double>(b, 4 * Bp);
     D.mu = dalloc<double>(b, Bp); D.smu = dalloc<double>(b, Bp);
     D.alpha = dalloc<double>(b, Bp); D.obj = dalloc<double>(b, Bp);
+    D.apend = dalloc<double>(b, Bp);
     D.iter = dalloc<int>(b, Bp); D.status = dalloc<int>(b, Bp);
     D.n_active = dalloc<int>(b, 1);
     b->stat_inst = b->B < 64 ? b->B : 64;
@@ -1682,6 +1683,7 @@ try
         hipLaunchKernelGGL(gqp::k_hot_start, grid, block, 0, s, D, std::max(clip, b->t0_min), std::max(clip, b->lam0_min));
         b->launches++;
     }
+    HIPCHK(hipMemsetAsync(D.apend, 0, sizeof(double) * (size_t) b->Bp, s)); /* no step pending (a solve always ends behind a factor sweep; belt and braces) */
     run_ipm(b, b, prof, s, 0);
     b->factor_stale = b->n_tail_switches + b->n_compactions > 0;
     b->sens_open = false;

@@ -110,6 +110,9 @@ struct GqpDev
     /* per instance scalars */
     double *res;   /* [4] */
     double *mu, *smu, *alpha, *obj;
+    double *apend; /* step length of a step (dux, dpi, dlam, dt) that is computed but not applied yet: the corrector sweep of the
+                      phase-ordered one-instance-per-lane kernels leaves it to the next factor sweep (ipm_kernels_box.hpp, "folded
+                      update"); 0 = nothing pending.  Other families apply their steps themselves and leave it 0 */
     int *iter, *status;
     int *n_active; /* single counter: instances still iterating */
     double *stat;  /* [stat_rows][STAT_COLS][Bp_stat] for the first stat_inst instances */

@@ -213,6 +213,12 @@ __device__ static inline Acc acc_at(GArr arr, size_t e0, int i)
 #define GQP_WAVE_ANY(x) true
 #endif
 
+/* 1: the corrector sweep leaves its step to the next factor sweep (see kb_factor); 0: it applies it in a pass of its own (the
+ * cross-check: make variant TAG=nofold DEFS=-DGQP_KB_FOLD=0) */
+#ifndef GQP_KB_FOLD
+#define GQP_KB_FOLD 1
+#endif
+
 #define GQP_ROW_CHUNK 4  /* rows of [B A]' fetched per load phase in kb_factor */
 #define GQP_HROW_CHUNK 3 /* Hessian rows fetched per load phase in kb_factor */
 
@@ -253,6 +259,15 @@ __global__ void __launch_bounds__(64) kb_factor(GqpDev D, GqpOpts O, int redo)
      * registers instead of being fetched again (16 of the 227 loads of a C2 stage); slot N + 1 is zero by convention */
     double xn[NX], pin[NX];
     UNROLL for (int c = 0; c < NX; c++) { xn[c] = 0.0; pin[c] = 0.0; }
+#if GQP_KB_FOLD
+    /* FOLDED UPDATE.  The corrector sweep (kb_forward<CORR>) leaves its step (dux, dpi, dlam, dt) and the step length
+     * (D.apend) behind instead of applying them in a pass of its own: this sweep reads the iterate anyway -- it adds the step
+     * as it loads a stage and stores the new iterate.  Saves one read of (ux, pi, lam, t) per iteration, 31 of the ~ 950 doubles
+     * an iteration moves per stage.  apd = 0: nothing pending (first iteration, a finished lane riding along: the iterate is
+     * stored back as it is -- selects, not arithmetic, so that it stays bit for bit). */
+    const double apd = run ? D.apend[i] : 0.0;
+    const bool pend = apd != 0.0;
+#endif
 
     for (int k = D.N; k >= 0; k--)
     {
@@ -274,6 +289,14 @@ __global__ void __launch_bounds__(64) kb_factor(GqpDev D, GqpOpts O, int redo)
         double rb[NX], v[n], gt[n];
         UNROLL for (int c = 0; c < NX; c++) rb[c] = ACC(D.bvec, 0).ld(k * NX + c) - xn[c];
         UNROLL for (int j = 0; j < n; j++) v[j] = ACC(D.ux, 0).ld(k * n + j);
+#if GQP_KB_FOLD
+        {
+            double dv[n];
+            UNROLL for (int j = 0; j < n; j++) dv[j] = ACC(D.dux, 0).ld(k * n + j);
+            UNROLL for (int j = 0; j < n; j++) v[j] = pend ? v[j] + apd * dv[j] : v[j];
+            UNROLL for (int j = 0; j < n; j++) ACC(D.ux, 0).st(k * n + j, v[j]);
+        }
+#endif
 
         /* ---------------- dynamics, GQP_ROW_CHUNK rows of [B A]' per load phase ----------------
          * rb += row*v_r, gt_r = row.pi+, W_r = row * Lx+ (state rows of W go to LDS) */
@@ -314,15 +337,46 @@ __global__ void __launch_bounds__(64) kb_factor(GqpDev D, GqpOpts O, int redo)
         double g[n], pik[NX];
         UNROLL for (int j = 0; j < n; j++) g[j] = ACC(D.rq, 0).ldo(k * n + j, ord);
         UNROLL for (int c = 0; c < NX; c++) pik[c] = ACC(D.pi, 0).ldo(k * NX + c, ord);
+#if GQP_KB_FOLD
+        if (k > 0) /* (slot 0 of pi is zero by convention and takes no step; slot k is the multiplier of the dynamics producing x_k) */
+        {
+            double dp[NX];
+            UNROLL for (int c = 0; c < NX; c++) dp[c] = ACC(D.dpi, 0).ldo(k * NX + c, ord);
+            UNROLL for (int c = 0; c < NX; c++) pik[c] = pend ? pik[c] + apd * dp[c] : pik[c];
+            UNROLL for (int c = 0; c < NX; c++) ACC(D.pi, 0).st(k * NX + c, pik[c]);
+        }
+#endif
         double rdl[NB], rdu[NB], gadd[NB], gam[NB];
         UNROLL for (int j = 0; j < NB; j++)
         {
             GQP_ROW(j, has, ib);
             const int el = S.o_ct + ib, eu = el + nbg;
             const double lbv = ACC(D.dvec, 0).ldo(el, ord), ubv = ACC(D.dvec, 0).ldo(eu, ord);
+#if GQP_KB_FOLD
+            double laml = ACC(D.lam, 0).ldo(el, ord), lamu = ACC(D.lam, 0).ldo(eu, ord);
+            double tl = ACC(D.t, 0).ldo(el, ord), tu = ACC(D.t, 0).ldo(eu, ord);
+            const bool al = has && ((am >> ib) & 1), au = has && ((am >> (nbg + ib)) & 1);
+            {
+                /* the step of the row's multipliers and slacks, floored as the update pass floors them; a side that does not take
+                 * part keeps its value; every existing row is written back (whole lines) */
+                const double dll = ACC(D.dlam, 0).ldo(el, ord), dlu = ACC(D.dlam, 0).ldo(eu, ord);
+                const double dtl = ACC(D.dt, 0).ldo(el, ord), dtu = ACC(D.dt, 0).ldo(eu, ord);
+                const double nll = laml + apd * dll, nlu = lamu + apd * dlu, ntl = tl + apd * dtl, ntu = tu + apd * dtu;
+                laml = (pend && al) ? (nll < O.lam_min ? O.lam_min : nll) : laml;
+                lamu = (pend && au) ? (nlu < O.lam_min ? O.lam_min : nlu) : lamu;
+                tl = (pend && al) ? (ntl < O.t_min ? O.t_min : ntl) : tl;
+                tu = (pend && au) ? (ntu < O.t_min ? O.t_min : ntu) : tu;
+                if (has)
+                {
+                    ACC(D.lam, 0).st(el, laml); ACC(D.lam, 0).st(eu, lamu);
+                    ACC(D.t, 0).st(el, tl); ACC(D.t, 0).st(eu, tu);
+                }
+            }
+#else
             const double laml = ACC(D.lam, 0).ldo(el, ord), lamu = ACC(D.lam, 0).ldo(eu, ord);
             const double tl = ACC(D.t, 0).ldo(el, ord), tu = ACC(D.t, 0).ldo(eu, ord);
             const bool al = has && ((am >> ib) & 1), au = has && ((am >> (nbg + ib)) & 1);
+#endif
             const double ll = al ? laml : 0.0, lu = au ? lamu : 0.0;
             const double ttl = al ? tl : 1.0, ttu = au ? tu : 1.0;
             rdl[j] = al ? v[j] - lbv - ttl : 0.0;
@@ -451,6 +505,9 @@ __global__ void __launch_bounds__(64) kb_factor(GqpDev D, GqpOpts O, int redo)
     }
 
     if (!run) return;
+#if GQP_KB_FOLD
+    D.apend[i] = 0.0; /* applied */
+#endif
     const double mu = nact > 0 ? musum / nact : 0.0;
     D.mu[i] = mu;
     D.obj[i] = obj;
@@ -724,6 +781,15 @@ __global__ void __launch_bounds__(64) kb_forward(GqpDev D, GqpOpts O, int redo)
     }
     /* no inequality rows (mu == 0 exactly): the Newton step solves the QP, take it fully */
     const double a = !run ? 0.0 : D.mu[i] > 0.0 ? alpha * 0.995 : 1.0;
+#if GQP_KB_FOLD
+    /* folded update: the step stays in (dux, dpi, dlam, dt), the next factor sweep applies it (kb_factor) */
+    if (!run) return;
+    D.apend[i] = a;
+    D.alpha[i] = alpha;
+    D.iter[i] = it + 1;
+    if (st) { st[4 * D.stat_inst] = alpha; st[5 * D.stat_inst] = alpha; }
+    return;
+#endif
     /* update pass.  Straight-line per stage like the sweep above: every load of the stage (62 for C2) is issued before
      * the first store, rows that do not exist are read through the clamped index, a side that does not take part gets
      * its own value written back; the stage structure is fetched one stage ahead.  (With a branch per row and side the
