@@ -139,6 +139,7 @@ struct ocp_qp_gpu_batch
     size_t w16_shmem = 0;  /* dynamic LDS bytes of a 16-lanes-per-instance workgroup (4 instances) */
     size_t w16_shmem_fact = 0; /* ... of the factor sweep (the tile sweep of the small two-rows shapes runs two waves per SIMD: its own, smaller tile) */
     int w16_tiles = 0;     /* two-rows family: factor sweep on 4 x 4 MFMA tiles (kt_factor) */
+    int *d_side_map = nullptr; /* k_step_update: side -> stage * 128 + activity bit (-1: equality-flagged row), built on first use */
     kern_redo_t w16_solve = nullptr; /* whole-solve kernel of the family (batches of at most solve_max instances) */
     int solve_max = 256;   /* largest batch that is solved in one launch (option "solve_max", 0 = off) */
     int n_single_launch = 0;
@@ -263,7 +264,7 @@ void opts_default(GqpOpts &o)
     o.mu0 = 1e0;
     o.tol_stat = 1e-6; o.tol_eq = 1e-8; o.tol_ineq = 1e-8; o.tol_comp = 1e-8;
     o.alpha_min = 1e-8; o.tau_min = 0.0; o.lam_min = 1e-16; o.t_min = 1e-16; o.reg_prim = 1e-15;
-    o.iter_max = 50; o.pred_corr = 1; o.cond_pred_corr = 1; o.warm_start = 0;
+    o.iter_max = 50; o.pred_corr = 1; o.cond_pred_corr = 1; o.warm_start = 0; o.ext_update = 0;
     o.t0_init = 2; /* acados_ocp_options.py:1128-1143: the default is the residual-based start */
 }
 
@@ -1478,11 +1479,46 @@ static void compact_back(ocp_qp_gpu_batch *b, hipStream_t s, ocp_qp_gpu_batch *c
  * copied into a dense sub-batch, the loop continues there (recursively), and the results are
  * scattered back.  Per-instance arithmetic is unchanged, so results are bit-identical.
  */
+/* side -> (stage, activity bit) of k_step_update, once per batch */
+static const int *side_map(ocp_qp_gpu_batch *b)
+{
+    if (b->d_side_map) return b->d_side_map;
+    std::vector<int> h((size_t) std::max(b->nct_tot, 1), -1);
+    for (int k = 0; k <= b->N; k++)
+    {
+        const GqpStage &S = b->st[k];
+        const int nbg = S.nb + S.ng;
+        int sp = 0;
+        for (int pv = 0; pv < 64; pv++)
+            if ((S.bmask >> pv) & 1)
+            {
+                if (!((S.emask >> pv) & 1)) { h[S.o_ct + sp] = k * 128 + sp; h[S.o_ct + nbg + sp] = k * 128 + nbg + sp; }
+                sp++;
+            }
+        for (int g = 0; g < S.ng; g++) { h[S.o_ct + S.nb + g] = k * 128 + S.nb + g; h[S.o_ct + nbg + S.nb + g] = k * 128 + nbg + S.nb + g; }
+        for (int q = 0; q < 2 * S.ns; q++) h[S.o_ct + 2 * nbg + q] = k * 128 + 2 * nbg + q;
+    }
+    b->d_side_map = dalloc<int>(b, h.size());
+    HIPCHK(hipMemcpy(b->d_side_map, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice));
+    return b->d_side_map;
+}
+
 static void run_ipm(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch *root, Prof &prof, hipStream_t s, int it)
 {
     const IpmKernels K = pick_kernels(b);
     GqpDev D = b->D;
     GqpOpts O = effective_opts(root->O, root);
+    /* sixteen-lanes families, launch per sweep: the step is applied by a launch of its own (k_step_update) instead of a pass at
+     * the end of the corrector sweep, which walks the stages one after the other inside a latency-bound kernel.  Measured
+     * (tools/ext_update_ab.py, profiles/r05_ext_update_ab.txt; identical iterates): general rows + slacks (two memory round trips
+     * per stage in the pass) C4 124.0 -> 120.4 ms; box classes of 7,281 instances +0.2 ... +1.1 %; the condensed C3 batch
+     * (65,536 instances, bandwidth-bound: the pass overlaps with other workgroups' sweeps, a launch of its own does not) 48.4 ->
+     * 49.4 ms -- so: GEN always, box classes up to 16,384 instances.  ACADOS_AMD_EXT_UPDATE=0 / 1 forces the pass / the launch */
+    const char *eext = getenv("ACADOS_AMD_EXT_UPDATE");
+    const bool ext_update = b->w16 && (eext ? atoi(eext) != 0 : (b->w16_ng > 0 || b->B <= 16384));
+    GqpOpts Oc = O; /* options of the corrector-sweep launches */
+    Oc.ext_update = ext_update ? 1 : 0;
+    const int *smap = ext_update ? side_map(b) : nullptr;
     b->w16_slots = b->B;
     /* sixteen lanes per instance: once a sixth of the slots has converged the sweeps run over a dense list of the live
      * instances (row slot -> instance, GqpDev::perm) -- no data moves, the grid shrinks, every wave carries four live rows */
@@ -1551,14 +1587,21 @@ static void run_ipm(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch *root, Prof &prof, hip
         GQP_SWEEP_LAUNCH(b, K.rhs, b->shmem, s, D, O, 0);
         if (b == root) prof.end(s);
         if (b == root) prof.begin(4, s);
-        GQP_SWEEP_LAUNCH(b, K.fcorr, b->shmem_fwd, s, D, O, 0);
+        GQP_SWEEP_LAUNCH(b, K.fcorr, b->shmem_fwd, s, D, Oc, 0);
         if (b == root) prof.end(s);
         root->launches += 3;
         if (O.cond_pred_corr)
         {
             GQP_SWEEP_LAUNCH(b, K.rhs, b->shmem, s, D, O, 1);
-            GQP_SWEEP_LAUNCH(b, K.fcorr, b->shmem_fwd, s, D, O, 1);
+            GQP_SWEEP_LAUNCH(b, K.fcorr, b->shmem_fwd, s, D, Oc, 1);
             root->launches += 2;
+        }
+        if (ext_update)
+        {
+            /* (behind the redo pair: an instance whose corrector collapsed gets its step length there) */
+            const int blocks = D.ux.aos ? b->B : (b->B + 63) / 64;
+            hipLaunchKernelGGL(gqp::k_step_update, dim3(blocks), dim3(64), 0, s, D, O, smap, b->nct_tot, b->ns2_tot);
+            root->launches++;
         }
     }
     b->w16_slots = b->B; /* launches outside this loop (sensitivity passes) cover every instance again */

@@ -55,6 +55,8 @@ struct GqpOpts
     int iter_max, pred_corr, cond_pred_corr, warm_start;
     int t0_init; /* cold start of (t, lam): 0 = (sqrt(mu0), sqrt(mu0)), 1 = (1, mu0), 2 = from the constraint residuals
                     (acados_ocp_options.py:1128-1143); 0 / 1 leave the primal iterate at zero */
+    int ext_update; /* set by the host loop for the launch-per-sweep corrector sweeps of the sixteen-lanes families: the sweep leaves
+                       its step length in GqpDev::apend and the step is applied by k_step_update, a launch of its own (ipm_kernels.hpp) */
 };
 
 /* One per-instance HBM array: `E` elements per instance, stored WAVE-TILED,

@@ -1143,6 +1143,42 @@ static __global__ void k_bulk_scatter(const double *blob, int nb, int len, const
     }
 }
 
+/*
+ * The step of an iteration applied by a launch of its own: (ux, pi, sv) += a d(.), (lam, t) of every side that takes part
+ * += a d(.) floored at (lam_min, t_min) -- exactly what the update passes at the end of the corrector sweeps do, but with the
+ * whole chip: those passes walk the stages of an instance one after the other inside a kernel whose waves are there for the
+ * sweep's dependent chain (sixteen lanes per instance: N / 4..6 memory round trips per launch, twice that with general rows
+ * -- 0.9 of the 2.5 ms of C4's corrector sweep), here every element is its own work item.
+ *   instance-major arrays (the sixteen-lanes / wave-per-instance families): one wavefront per instance, lanes over elements;
+ *   wave-tiled arrays: one lane per instance, 64 instances per wavefront, elements one after the other (coalesced across lanes).
+ * side_map[e] = stage * 128 + bit of side e in the stage's activity word(s), or -1 for a side that takes no step (the two sides
+ * of an equality-flagged box row).  a = GqpDev::apend[i], written by the corrector sweep (O.ext_update) for every instance it
+ * ran; instances that are not iterating are skipped.
+ */
+static __global__ void __launch_bounds__(64) k_step_update(GqpDev D, GqpOpts O, const int *side_map, int n_sides, int n_sv)
+{
+    const bool aos = D.ux.aos != 0;
+    const int lane = threadIdx.x & 63;
+    const int i = aos ? (int) blockIdx.x : (int) blockIdx.x * 64 + lane;
+    if (i >= D.B || D.status[i] != GQP_RUNNING) return;
+    const double a = D.apend[i];
+    if (a == 0.0) return;
+    const int n = D.NX + D.NU, e0 = aos ? lane : 0, de = aos ? 64 : 1;
+    for (int e = e0; e < (D.N + 1) * n; e += de) GATL(D.ux, e) += a * GATL(D.dux, e);
+    for (int e = D.NX + e0; e < (D.N + 1) * D.NX; e += de) GATL(D.pi, e) += a * GATL(D.dpi, e);
+    for (int e = e0; e < n_sv; e += de) GATL(D.sv, e) += a * GATL(D.dsv, e);
+    for (int e = e0; e < n_sides; e += de)
+    {
+        const int sb = side_map[e];
+        if (sb < 0) continue;
+        const int k = sb >> 7, bit = sb & 127;
+        if (!((GATL(D.amask, k * D.AW + (bit >> 6)) >> (bit & 63)) & 1)) continue;
+        const double lam = GATL(D.lam, e) + a * GATL(D.dlam, e), t = GATL(D.t, e) + a * GATL(D.dt, e);
+        GATL(D.lam, e) = lam < O.lam_min ? O.lam_min : lam;
+        GATL(D.t, e) = t < O.t_min ? O.t_min : t;
+    }
+}
+
 /* a launch that does nothing but carry a number in its NAME: the profile summaries (profiles/summarize.py) cut the
  * dispatch sequence of a traced run into labelled sections with it (option "marker") */
 template <int ID>

@@ -738,6 +738,19 @@ __device__ static inline void kx_fwd_body(const GqpDev &D, const GqpOpts &O, int
         return;
     }
     const double a = D.mu[inst] > 0.0 ? alpha * 0.995 : 1.0;
+    if (O.ext_update)
+    {
+        /* launch-per-sweep loop: the step is applied by k_step_update (ipm_kernels.hpp), every element its own work item
+         * (kx_solve, the whole solve in one launch, keeps the pass below) */
+        if (l == 0)
+        {
+            D.apend[inst] = a;
+            D.alpha[inst] = alpha;
+            D.iter[inst] = it + 1;
+            if (st) { st[4 * D.stat_inst] = alpha; st[5 * D.stat_inst] = alpha; }
+        }
+        return;
+    }
     /* update: one lane per variable / state / box row of the stage (dux, dpi, dlam, dt were written by these very
      * lanes).  Everything the lane updates in CH consecutive stages -- variable, state multiplier, the two sides of its box
      * row, with SOFT the row's slack values and slack sides -- is loaded through clamped addresses before the first store

@@ -1691,6 +1691,18 @@ __global__ void __launch_bounds__(64) W16R_WPE_FWD ky_fwd(GqpDev D, GqpOpts O, i
     if (l == 0) { D.alpha[inst] = alpha; D.iter[inst] = it + 1; }
     return;
 #endif
+    if (O.ext_update)
+    {
+        /* launch-per-sweep loop: the step is applied by k_step_update (ipm_kernels.hpp), every element its own work item */
+        if (l == 0)
+        {
+            D.apend[inst] = a;
+            D.alpha[inst] = alpha;
+            D.iter[inst] = it + 1;
+            if (st) { st[4 * D.stat_inst] = alpha; st[5 * D.stat_inst] = alpha; }
+        }
+        return;
+    }
     /* update: one slot per variable / state / box row of the stage (dux, dpi, dlam, dt were written by these very
      * slots).  Everything the lane updates in W16R_UPD_CH consecutive stages -- both slots: variable, state multiplier, the
      * two sides of the box row -- is loaded through clamped addresses before the first store of the chunk: one memory
