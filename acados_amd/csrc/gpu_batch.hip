@@ -1513,9 +1513,10 @@ static void run_ipm(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch *root, Prof &prof, hip
      * (tools/ext_update_ab.py, profiles/r05_ext_update_ab.txt; identical iterates): general rows + slacks (two memory round trips
      * per stage in the pass) C4 124.0 -> 120.4 ms; box classes of 7,281 instances +0.2 ... +1.1 %; the condensed C3 batch
      * (65,536 instances, bandwidth-bound: the pass overlaps with other workgroups' sweeps, a launch of its own does not) 48.4 ->
-     * 49.4 ms -- so: GEN always, box classes up to 16,384 instances.  ACADOS_AMD_EXT_UPDATE=0 / 1 forces the pass / the launch */
+     * 49.4 ms; short horizons (N = 20) lose what one more launch per iteration costs (r05_ext_update_ab2.txt: -2.6 % at nx = 12) -- so:
+     * GEN always, box classes up to 16,384 instances from N = 50 on.  ACADOS_AMD_EXT_UPDATE=0 / 1 forces the pass / the launch */
     const char *eext = getenv("ACADOS_AMD_EXT_UPDATE");
-    const bool ext_update = b->w16 && (eext ? atoi(eext) != 0 : (b->w16_ng > 0 || b->B <= 16384));
+    const bool ext_update = b->w16 && (eext ? atoi(eext) != 0 : (b->w16_ng > 0 || (b->B <= 16384 && b->N >= 50)));
     GqpOpts Oc = O; /* options of the corrector-sweep launches */
     Oc.ext_update = ext_update ? 1 : 0;
     const int *smap = ext_update ? side_map(b) : nullptr;
@@ -1599,8 +1600,8 @@ static void run_ipm(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch *root, Prof &prof, hip
         if (ext_update)
         {
             /* (behind the redo pair: an instance whose corrector collapsed gets its step length there) */
-            const int blocks = D.ux.aos ? b->B : (b->B + 63) / 64;
-            hipLaunchKernelGGL(gqp::k_step_update, dim3(blocks), dim3(64), 0, s, D, O, smap, b->nct_tot, b->ns2_tot);
+            const int blocks = D.ux.aos ? b->B : (b->B + GQP_UPD_THREADS - 1) / GQP_UPD_THREADS;
+            hipLaunchKernelGGL(gqp::k_step_update, dim3(blocks), dim3(GQP_UPD_THREADS), 0, s, D, O, smap, b->nct_tot, b->ns2_tot);
             root->launches++;
         }
     }

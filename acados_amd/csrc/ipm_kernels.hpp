@@ -1149,33 +1149,59 @@ static __global__ void k_bulk_scatter(const double *blob, int nb, int len, const
  * whole chip: those passes walk the stages of an instance one after the other inside a kernel whose waves are there for the
  * sweep's dependent chain (sixteen lanes per instance: N / 4..6 memory round trips per launch, twice that with general rows
  * -- 0.9 of the 2.5 ms of C4's corrector sweep), here every element is its own work item.
- *   instance-major arrays (the sixteen-lanes / wave-per-instance families): one wavefront per instance, lanes over elements;
- *   wave-tiled arrays: one lane per instance, 64 instances per wavefront, elements one after the other (coalesced across lanes).
+ *   instance-major arrays (the sixteen-lanes / wave-per-instance families): one workgroup of 256 per instance, threads over elements;
+ *   wave-tiled arrays: one thread per instance, elements one after the other (coalesced across lanes).
  * side_map[e] = stage * 128 + bit of side e in the stage's activity word(s), or -1 for a side that takes no step (the two sides
  * of an equality-flagged box row).  a = GqpDev::apend[i], written by the corrector sweep (O.ext_update) for every instance it
  * ran; instances that are not iterating are skipped.
  */
-static __global__ void __launch_bounds__(64) k_step_update(GqpDev D, GqpOpts O, const int *side_map, int n_sides, int n_sv)
+#define GQP_UPD_THREADS 256 /* work items per instance (instance-major arrays) */
+static __global__ void __launch_bounds__(GQP_UPD_THREADS) k_step_update(GqpDev D, GqpOpts O, const int *side_map, int n_sides, int n_sv)
 {
     const bool aos = D.ux.aos != 0;
-    const int lane = threadIdx.x & 63;
-    const int i = aos ? (int) blockIdx.x : (int) blockIdx.x * 64 + lane;
+    const int tid = threadIdx.x;
+    const int i = aos ? (int) blockIdx.x : (int) blockIdx.x * GQP_UPD_THREADS + tid;
     if (i >= D.B || D.status[i] != GQP_RUNNING) return;
     const double a = D.apend[i];
     if (a == 0.0) return;
-    const int n = D.NX + D.NU, e0 = aos ? lane : 0, de = aos ? 64 : 1;
-    for (int e = e0; e < (D.N + 1) * n; e += de) GATL(D.ux, e) += a * GATL(D.dux, e);
-    for (int e = D.NX + e0; e < (D.N + 1) * D.NX; e += de) GATL(D.pi, e) += a * GATL(D.dpi, e);
-    for (int e = e0; e < n_sv; e += de) GATL(D.sv, e) += a * GATL(D.dsv, e);
-    for (int e = e0; e < n_sides; e += de)
+    const int n = D.NX + D.NU, e0 = aos ? tid : 0, de = aos ? GQP_UPD_THREADS : 1;
+    /* four elements per thread and round trip: all loads of a chunk are issued before its first store (a plain `x += a dx` loop makes
+     * one memory round trip per element: the stores may alias the next loads as far as the compiler knows) */
+#define GQP_UPD_AXPY(X, DX, FIRST, COUNT)                                                          \
+    for (int e = (FIRST) + e0; e < (COUNT); e += 4 * de)                                           \
+    {                                                                                              \
+        double x_[4], d_[4];                                                                       \
+        UNROLL for (int q = 0; q < 4; q++)                                                         \
+        {                                                                                          \
+            const int ee = e + q * de < (COUNT) ? e + q * de : e;                                  \
+            x_[q] = GATL(X, ee); d_[q] = GATL(DX, ee);                                             \
+        }                                                                                          \
+        UNROLL for (int q = 0; q < 4; q++)                                                         \
+            if (e + q * de < (COUNT)) GATL(X, e + q * de) = x_[q] + a * d_[q];                     \
+    }
+    GQP_UPD_AXPY(D.ux, D.dux, 0, (D.N + 1) * n)
+    GQP_UPD_AXPY(D.pi, D.dpi, D.NX, (D.N + 1) * D.NX)
+    GQP_UPD_AXPY(D.sv, D.dsv, 0, n_sv)
+#undef GQP_UPD_AXPY
+    for (int e = e0; e < n_sides; e += 4 * de)
     {
-        const int sb = side_map[e];
-        if (sb < 0) continue;
-        const int k = sb >> 7, bit = sb & 127;
-        if (!((GATL(D.amask, k * D.AW + (bit >> 6)) >> (bit & 63)) & 1)) continue;
-        const double lam = GATL(D.lam, e) + a * GATL(D.dlam, e), t = GATL(D.t, e) + a * GATL(D.dt, e);
-        GATL(D.lam, e) = lam < O.lam_min ? O.lam_min : lam;
-        GATL(D.t, e) = t < O.t_min ? O.t_min : t;
+        double l_[4], dl_[4], t_[4], dt_[4];
+        bool on[4];
+        UNROLL for (int q = 0; q < 4; q++)
+        {
+            const int ee = e + q * de < n_sides ? e + q * de : e;
+            const int sb = side_map[ee];
+            const int k = sb >= 0 ? sb >> 7 : 0, bit = sb >= 0 ? sb & 127 : 0;
+            on[q] = e + q * de < n_sides && sb >= 0 && ((GATL(D.amask, k * D.AW + (bit >> 6)) >> (bit & 63)) & 1);
+            l_[q] = GATL(D.lam, ee); dl_[q] = GATL(D.dlam, ee); t_[q] = GATL(D.t, ee); dt_[q] = GATL(D.dt, ee);
+        }
+        UNROLL for (int q = 0; q < 4; q++)
+            if (on[q])
+            {
+                const double lam = l_[q] + a * dl_[q], t = t_[q] + a * dt_[q];
+                GATL(D.lam, e + q * de) = lam < O.lam_min ? O.lam_min : lam;
+                GATL(D.t, e + q * de) = t < O.t_min ? O.t_min : t;
+            }
     }
 }
 
