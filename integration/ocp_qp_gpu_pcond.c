@@ -481,7 +481,7 @@ static int pc_read_child(ocp_qp_gpu_pcond_memory *mem, ocp_qp_gpu_batch *c, ocp_
 
 /* handed through (N2 = N or a class the device does not condense): xcond_qp_in := qp_in, as the reference's module amounts to
  * with blocks of one stage */
-static void pc_copy_qp_in(ocp_qp_in *a, ocp_qp_in *b, int what)
+static void pc_copy_qp_in(ocp_qp_in *a, ocp_qp_in *b, int what, double *tmp)
 {
     const ocp_qp_dims *d = a->dim;
     for (int k = 0; k <= d->N; k++)
@@ -490,11 +490,10 @@ static void pc_copy_qp_in(ocp_qp_in *a, ocp_qp_in *b, int what)
         const int nct = 2 * (nb + ng + ns);
         if (what & 1)
         {
-            double *tmp = (double *) malloc(sizeof(double) * (size_t) ((nv + 1) * (nv + 1) + 1));
+            /* (through the carved staging blob: no allocation inside a condensing call; it holds a whole QP, a block fits) */
             blasfeo_unpack_dmat(nv, nx1, a->BAbt + k, 0, 0, tmp, nv); blasfeo_pack_dmat(nv, nx1, tmp, nv, b->BAbt + k, 0, 0);
             blasfeo_unpack_dmat(nv, nv, a->RSQrq + k, 0, 0, tmp, nv); blasfeo_pack_dmat(nv, nv, tmp, nv, b->RSQrq + k, 0, 0);
             blasfeo_unpack_dmat(nv, ng, a->DCt + k, 0, 0, tmp, nv); blasfeo_pack_dmat(nv, ng, tmp, nv, b->DCt + k, 0, 0);
-            free(tmp);
             for (int i = 0; i < 2 * ns; i++) BLASFEO_DVECEL(b->Z + k, i) = BLASFEO_DVECEL(a->Z + k, i);
             memcpy(b->idxb[k], a->idxb[k], sizeof(int) * (size_t) nb);
             memcpy(b->idxs_rev[k], a->idxs_rev[k], sizeof(int) * (size_t) (nb + ng));
@@ -540,7 +539,7 @@ static int pc_condense_any(void *qp_in_, void *xin_, void *opts_, void *mem_, in
     const double t0 = pc_now_s();
     mem->ptr_qp_in = qp_in;
     int rc = ACADOS_SUCCESS;
-    if (!mem->dims->condensed) pc_copy_qp_in(qp_in, x, what);
+    if (!mem->dims->condensed) pc_copy_qp_in(qp_in, x, what, mem->blob);
     else
     {
         ocp_qp_gpu_batch *b = pc_load(mem, opts, qp_in), *c = NULL;
