@@ -202,10 +202,23 @@ static int run_batch(int argc, char **argv)
     }
     ocp_qp_dims *xd = NULL;
     config->xcond->dims_get(config->xcond, dims->xcond_dims, "xcond_dims", &xd);
+    /* the reference's residual entry (ocp_qp_common.c:559-667) on EVERY capsule's (qp_in, qp_out) of the batch call */
+    double res_max = 0.0;
+    {
+        ocp_qp_res *res = ocp_qp_res_assign(dims->orig_dims, calloc(1, ocp_qp_res_calculate_size(dims->orig_dims)));
+        ocp_qp_res_ws *res_ws = ocp_qp_res_workspace_assign(dims->orig_dims, calloc(1, ocp_qp_res_workspace_calculate_size(dims->orig_dims)));
+        for (int i = 0; i < n; i++)
+        {
+            double nrm[4];
+            ocp_qp_res_compute(ins[i], outs[i], res, res_ws);
+            ocp_qp_res_compute_nrm_inf(res, nrm);
+            for (int q = 0; q < 4; q++) res_max = fmax(res_max, nrm[q]);
+        }
+    }
     int cond_active = -1; /* stages of the QP the device IPM ran on in the batch call: the condensed one */
     config->qp_solver->memory_get(config->qp_solver, ((ocp_qp_xcond_solver_memory *) mems[0])->solver_memory, "cond_N_active", &cond_active);
-    printf("batch n %d ms_per_call %.6f status %d fused_vs_orchestrated %.17g orchestrated_status %d xcond_N %d xcond_nu0 %d cond_N_active %d end\n", n, best * 1e3,
-           status, fvo, st_one, xd->N, xd->nu[0], cond_active);
+    printf("batch n %d ms_per_call %.6f status %d fused_vs_orchestrated %.17g orchestrated_status %d xcond_N %d xcond_nu0 %d cond_N_active %d res_max %.17g end\n", n,
+           best * 1e3, status, fvo, st_one, xd->N, xd->nu[0], cond_active, res_max);
     FILE *g = fopen(argv[4], "wb");
     for (int i = 0; i < n; i++)
     {

@@ -180,6 +180,7 @@ def test_batch_through_the_reference_solver_objects_fused_on_device(clib, tmp_pa
         assert "solving the full-space QP" not in err, err
         assert info["status"] == 0 and info["orchestrated_status"] == 0 and info["xcond_N"] == n_stages and info["cond_N_active"] == n_stages
         assert info["fused_vs_orchestrated"] <= 1e-9
+        assert info["res_max"] <= 1e-8 * (1 + 1e-3) + 1e-13          # the reference's residual entry, every capsule
         per_inst = raw.size // n
         assert per_inst * n == raw.size
         for i in range(n):
@@ -213,6 +214,7 @@ def test_batch_1024_c3_shaped_through_the_reference_solver_objects(gpu_lib, tmp_
     assert info["status"] == 0 and all(st == 0 for _, st, _, _, _ in per) and info["orchestrated_status"] == 0
     assert info["xcond_N"] == 10 and info["xcond_nu0"] == 15 and info["cond_N_active"] == 10
     assert info["fused_vs_orchestrated"] <= 1e-8
+    assert info["res_max"] <= 1e-8 * (1 + 1e-3) + 1e-13              # the reference's residual entry on all 1,024 capsules
     per_inst = raw.size // n
     assert per_inst * n == raw.size
     for i in list(range(0, n, 37)) + [n - 1]:
