@@ -22,10 +22,17 @@
 
 #include "acados_amd/ocp_qp_gpu_batch.h"
 
-static char *align8(char *p) { return (char *) (((size_t) p + 7) & ~(size_t) 7); }
+/* (not every function is used by both translation units) */
+#if defined(__GNUC__)
+#define GPU_SEG_FN static __attribute__((unused))
+#else
+#define GPU_SEG_FN static
+#endif
+
+GPU_SEG_FN char *align8(char *p) { return (char *) (((size_t) p + 7) & ~(size_t) 7); }
 /* every *_calculate_size is a multiple of 8: the reference carves the next object right behind and asserts its alignment
  * (ocp_qp_xcond_solver.c:230, 379; make_int_multiple_of(8, &size) in its own modules) */
-static acados_size_t size8(size_t s) { return (acados_size_t) ((s + 7) & ~(size_t) 7); }
+GPU_SEG_FN acados_size_t size8(size_t s) { return (acados_size_t) ((s + 7) & ~(size_t) 7); }
 
 /* one piece of a bulk blob <-> one sub-block of a BLASFEO object of the QP */
 enum { SEG_VEC = 0, SEG_MAT = 1, SEG_MAT_T = 2 };
@@ -52,14 +59,14 @@ typedef struct { GPU_LAYOUT_MEMBERS } gpu_layout;
 
 /* ------------------------------------------------------------------ sizes from dims */
 
-static int sig_len(const ocp_qp_dims *d)
+GPU_SEG_FN int sig_len(const ocp_qp_dims *d)
 {
     int len = 1;
     for (int k = 0; k <= d->N; k++) len += 7 + 2 * d->nb[k] + d->ng[k] + d->nbxe[k];
     return len;
 }
 
-static int blob_in_cap(const ocp_qp_dims *d)
+GPU_SEG_FN int blob_in_cap(const ocp_qp_dims *d)
 {
     int len = 0, getter = 0;
     for (int k = 0; k <= d->N; k++)
@@ -71,7 +78,7 @@ static int blob_in_cap(const ocp_qp_dims *d)
     return len > getter ? len : getter;
 }
 
-static int blob_out_cap(const ocp_qp_dims *d)
+GPU_SEG_FN int blob_out_cap(const ocp_qp_dims *d)
 {
     int len = 0;
     for (int k = 0; k <= d->N; k++)
@@ -85,7 +92,7 @@ static int blob_out_cap(const ocp_qp_dims *d)
 
 /* ------------------------------------------------------------------ structure signature, segment tables */
 
-static int fill_sig(const ocp_qp_in *in, int *s)
+GPU_SEG_FN int fill_sig(const ocp_qp_in *in, int *s)
 {
     const ocp_qp_dims *d = in->dim;
     int p = 0;
@@ -101,7 +108,7 @@ static int fill_sig(const ocp_qp_in *in, int *s)
     return p;
 }
 
-static void seg_add(ocp_qp_gpu_batch *b, gpu_seg *tab, int *cnt, int cap, int which, const char *field, int k, int expect,
+GPU_SEG_FN void seg_add(ocp_qp_gpu_batch *b, gpu_seg *tab, int *cnt, int cap, int which, const char *field, int k, int expect,
                     int kind, int src, int ai, int aj, int m, int n, int neg)
 {
     /* which: 0 input blob, 1 output blob, 2 seed blob */
@@ -119,7 +126,7 @@ static void seg_add(ocp_qp_gpu_batch *b, gpu_seg *tab, int *cnt, int cap, int wh
 }
 
 /* where every field of the three blobs lives in the acados structs: once per device batch */
-static int gpu_layout_build(gpu_layout *bk, const ocp_qp_dims *d)
+GPU_SEG_FN int gpu_layout_build(gpu_layout *bk, const ocp_qp_dims *d)
 {
     ocp_qp_gpu_batch *b = bk->batch;
     const int N = d->N;
@@ -212,7 +219,7 @@ static int gpu_layout_build(gpu_layout *bk, const ocp_qp_dims *d)
 
 /* ------------------------------------------------------------------ blob <-> acados structs, one instance */
 
-static void unpack_segs(const gpu_seg *tab, int cnt, double *blob, struct blasfeo_dmat *const *mats, struct blasfeo_dvec *const *vecs)
+GPU_SEG_FN void unpack_segs(const gpu_seg *tab, int cnt, double *blob, struct blasfeo_dmat *const *mats, struct blasfeo_dvec *const *vecs)
 {
     for (int s = 0; s < cnt; s++)
     {
@@ -229,21 +236,21 @@ static void unpack_segs(const gpu_seg *tab, int cnt, double *blob, struct blasfe
 }
 
 /* every member array of qp_in, re-read on every call, unpacked from BLASFEO storage straight into the blob */
-static void unpack_qp_in(const gpu_layout *bk, ocp_qp_in *in, double *blob)
+GPU_SEG_FN void unpack_qp_in(const gpu_layout *bk, ocp_qp_in *in, double *blob)
 {
     struct blasfeo_dmat *mats[3] = {in->BAbt, in->RSQrq, in->DCt};
     struct blasfeo_dvec *vecs[8] = {NULL, NULL, NULL, in->b, in->rqz, in->d, in->d_mask, in->Z};
     unpack_segs(bk->seg_in, bk->n_in, blob, mats, vecs);
 }
 
-static void unpack_seed(const gpu_layout *bk, ocp_qp_seed *seed, double *blob)
+GPU_SEG_FN void unpack_seed(const gpu_layout *bk, ocp_qp_seed *seed, double *blob)
 {
     struct blasfeo_dvec *vecs[15] = {NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, seed->seed_g, seed->seed_b, seed->seed_d};
     unpack_segs(bk->seg_seed, bk->n_seed, blob, NULL, vecs);
 }
 
 /* hot start: pi, lam, t of qp_out; the primal part stays zero as ocp_qp_hpipm.c:325-336 leaves it before every solve */
-static void unpack_qp_out_duals(const gpu_layout *bk, ocp_qp_out *out, double *blob)
+GPU_SEG_FN void unpack_qp_out_duals(const gpu_layout *bk, ocp_qp_out *out, double *blob)
 {
     struct blasfeo_dvec *vecs[12] = {NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, out->ux, out->pi, out->lam, out->t};
     for (int s = 0; s < bk->n_out; s++)
@@ -254,7 +261,7 @@ static void unpack_qp_out_duals(const gpu_layout *bk, ocp_qp_out *out, double *b
     }
 }
 
-static void pack_qp_out(const gpu_layout *bk, const double *blob, ocp_qp_out *out)
+GPU_SEG_FN void pack_qp_out(const gpu_layout *bk, const double *blob, ocp_qp_out *out)
 {
     struct blasfeo_dvec *vecs[12] = {NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, out->ux, out->pi, out->lam, out->t};
     for (int s = 0; s < bk->n_out; s++)

@@ -212,7 +212,7 @@ def test_chain_class_with_eight_general_rows_hostsim(hostsim_lib, monkeypatch):
     rows: the tile sweep of this instantiation spills) instead of the wave-per-instance ones; both against the oracle"""
     from acados_amd.generators import chain_soft_qp
     monkeypatch.setenv("ACADOS_AMD_WPI", "1")
-    qps = [chain_soft_qp(i, N=6, ng=8) for i in range(5)]       # ragged: one full workgroup of four instances + one
+    qps = [chain_soft_qp(i, N=4, ng=8) for i in range(5)]       # ragged: one full workgroup of four instances + one
     b = _check_batch_vs_oracle(qps, hostsim_lib)
     assert b.kernel_name.startswith("w16r-gen<NX=24,NU=3,NG=8>") and int(b.scalar("w16_tiles")) == 0
     it = b.info("iter").copy()
@@ -228,8 +228,8 @@ def test_general_rows_and_slacks_at_small_shapes_on_sixteen_lanes_hostsim(hostsi
     from acados_amd.generators import chain_soft_qp
     monkeypatch.setenv("ACADOS_AMD_WPI", "1")
     for (nx, nu, ng, nsx), want in (((12, 4, 4, 4), "w16r-gen<NX=12,NU=4,NG=4>"), ((10, 3, 4, 3), "w16r-gen<NX=12,NU=4,NG=4>"),
-                                    ((8, 3, 4, 2), "w16r-gen<NX=8,NU=3,NG=4>"), ((8, 3, 2, 4), "w16r-gen<NX=8,NU=3,NG=4>")):
-        qps = [chain_soft_qp(i, N=6, nx=nx, nu=nu, ng=ng, nsx=nsx) for i in range(5)]
+                                    ((8, 3, 2, 4), "w16r-gen<NX=8,NU=3,NG=4>")):
+        qps = [chain_soft_qp(i, N=4, nx=nx, nu=nu, ng=ng, nsx=nsx) for i in range(5)]
         monkeypatch.setenv("ACADOS_AMD_W16G", "1")
         b = _check_batch_vs_oracle(qps, hostsim_lib)
         assert b.kernel_name == want and int(b.scalar("w16_tiles")) == 1, b.kernel_name
