@@ -1069,3 +1069,57 @@ def test_concurrent_shape_classes_gpu(gpu_lib, monkeypatch):
                 for a, b in zip(got, r):
                     assert np.array_equal(a, b)
                 assert gb.res_compute().max() <= KKT_TOL
+
+
+def test_device_against_certified_dense_solutions_gpu(gpu_lib, monkeypatch):
+    """The device against a reference NEITHER the oracle NOR the kernels have a part in: tests/dense_ref.py::solve_exact -- a dense
+    path-following + active-set solve of the stacked QP whose result carries its own optimality certificate (every inactive row
+    feasible, every active multiplier >= 0, stationarity ~1e-12) -- on one or two instances of every kernel family the BASELINE
+    configurations run on: C2 (one instance per lane, and the same instances on the sixteen-lanes kernels), the condensed C3 path,
+    an nx = 12 and an nx = 24 class of C5 (one / two rows per lane, MFMA tile factor), the multi-phase class, the C4 class and the
+    ng = 8 chain class (GEN).  The device runs at tight tolerances (complementarity 1e-12): what remains is the distance of an
+    interior point to the vertex: measured 2e-12 ... 3e-11 relative on the primal solution, asserted at 1e-9."""
+    from dense_ref import solve_exact, split
+    from acados_amd import OcpQpGpuBatch
+    from acados_amd.generators import chain_soft_qp, lqr_instance_qp, multiphase_batch, multiphase_instance_qp, random_lqr_batch
+    c2 = random_lqr_batch(N=50, nx=8, nu=3, batch=2, seed=0)
+    d12 = random_lqr_batch(N=20, nx=12, nu=3, batch=1, seed=203)
+    d24 = random_lqr_batch(N=20, nx=24, nu=6, batch=1, seed=206)
+    dm = multiphase_batch(N=20, batch=1)
+    cases = [("C2 1tpi", [lqr_instance_qp(c2, i, 50) for i in range(2)], {"ACADOS_AMD_WPI": "0"}, 0, "1tpi-box"),
+             ("C2 w16", [lqr_instance_qp(c2, i, 50) for i in range(2)], {"ACADOS_AMD_WPI": "1"}, 0, "w16-box"),
+             ("C3 condensed", [lqr_instance_qp(c2, i, 50) for i in range(2)], {"ACADOS_AMD_WPI": "0"}, 10, "1tpi-box"),
+             ("nx=12", [lqr_instance_qp(d12, 0, 20)], {}, 0, "w16-box<NX=12"),
+             ("nx=24", [lqr_instance_qp(d24, 0, 20)], {}, 0, "w16r-box<NX=24"),
+             ("multi-phase", [multiphase_instance_qp(dm, 0)], {}, 0, "w16-box<NX=12"),
+             ("C4 class", [chain_soft_qp(1, N=10)], {}, 0, "w16r-gen<NX=24,NU=3,NG=4>"),
+             ("ng=8 chain class", [chain_soft_qp(2, N=10, ng=8)], {}, 0, "w16r-gen<NX=24,NU=3,NG=8>")]
+    worst = {}
+    for name, qps, env, cond, fam in cases:
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        b = OcpQpGpuBatch.from_qps(qps)
+        for f, v in (("tol_stat", 1e-9), ("tol_eq", 1e-11), ("tol_ineq", 1e-11), ("tol_comp", 1e-12)):
+            b.opts_set(f, v)
+        b.opts_set("iter_max", 100)
+        if cond:
+            b.opts_set("cond_N", cond)
+        assert b.solve() == 0, name
+        assert b.kernel_name.startswith(fam), (name, b.kernel_name)
+        if cond:
+            assert int(b.scalar("cond_N_active")) == cond
+        for i, qp in enumerate(qps):
+            w, off, info = solve_exact(qp)
+            assert info["cert"] <= 1e-10 and info["stationarity"] <= 1e-9, (name, info)
+            sol = split(qp, w, off)
+            e = 0.0
+            for k in range(qp.N + 1):
+                for f in ("x", "u", "sl", "su"):
+                    ref = sol[f][k]
+                    if ref.size:
+                        e = max(e, float(np.max(np.abs(b.get(f, k)[i][:ref.size] - ref) / np.maximum(1.0, np.abs(ref)))))
+            worst[name] = max(worst.get(name, 0.0), e)
+        for k_ in env:
+            monkeypatch.delenv(k_)
+    print("device vs certified dense solutions (rel. primal):", {k: f"{v:.1e}" for k, v in worst.items()})
+    assert max(worst.values()) <= 1e-9, worst
