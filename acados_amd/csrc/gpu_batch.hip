@@ -157,6 +157,8 @@ struct ocp_qp_gpu_batch
     std::vector<void *> allocs;
     size_t bytes = 0;
     double *d_stage = nullptr; /* staging for host->device field blocks */
+    double *d_chunks = nullptr; /* the input blob handed over in pieces (_set_bulk_chunk): its own buffer -- d_stage is reused by */
+    size_t chunks_cap = 0;      /* every other transfer (a hot start's _set_bulk_out comes between the chunks and the scatter) */
     size_t stage_cap = 0;
     int *d_map = nullptr;
     int map_cap = 0;
@@ -2429,6 +2431,44 @@ try
     HIPCHK(hipEventElapsedTime(&ms, e0, e1));
     b->time_pack += ms * 1e-3;
     HIPCHK(hipEventDestroy(e0)); HIPCHK(hipEventDestroy(e1));
+    return 0;
+}
+catch (const gqp_hip_failure &) { return -1; }
+
+/* _set_bulk in pieces: a caller that fills its blob instance range by instance range (host threads unpacking n acados structs)
+ * hands every finished range over at once -- the host->device copy of range j runs while range j + 1 is still being filled --
+ * and scatters when the last one is in.  `blob_chunk` points at instance `first` of the caller's (pinned) blob; nothing is waited
+ * for here.  _set_bulk_staged: the scatter launch (+ masks) over what the chunks brought, then the usual wait. */
+int ocp_qp_gpu_batch_set_bulk_chunk(ocp_qp_gpu_batch *b, const double *blob_chunk, int first, int count)
+try
+{
+    const int len = gqp_bulk_len_impl(b, 0);
+    if (first < 0 || count < 0 || first + count > b->B) return -1;
+    const size_t cnt = (size_t) b->B * len;
+    if (cnt > b->chunks_cap)
+    {
+        HIPCHK(hipStreamSynchronize(b->stream)); /* (only ever on the first chunk of a batch: nothing of it is in flight yet) */
+        b->chunks_cap = cnt * 2;
+        b->d_chunks = dalloc<double>(b, b->chunks_cap);
+    }
+    if (count)
+        HIPCHK(hipMemcpyAsync(b->d_chunks + (size_t) first * len, blob_chunk, sizeof(double) * (size_t) count * len, hipMemcpyHostToDevice, b->stream));
+    return 0;
+}
+catch (const gqp_hip_failure &) { return -1; }
+
+int ocp_qp_gpu_batch_set_bulk_staged(ocp_qp_gpu_batch *b)
+try
+{
+    const int len = gqp_bulk_len_impl(b, 0);
+    auto &M = b->bulk_in;
+    if ((size_t) b->B * len > b->chunks_cap) return -1; /* no chunk was ever handed over */
+    const dim3 grid((b->B + 63) / 64, (len + 255) / 256), block(64);
+    hipLaunchKernelGGL(gqp::k_bulk_scatter, grid, block, 0, b->stream, (const double *) b->d_chunks, b->B, len, M.d_arr, M.d_elem, M.T);
+    if (M.nm)
+        hipLaunchKernelGGL(gqp::k_bulk_masks, dim3((b->B + 63) / 64), block, 0, b->stream, (const double *) b->d_chunks, b->B, len, M.d_moff,
+                           M.d_mstage, M.d_mbit, M.nm, b->D.amask, b->AW);
+    HIPCHK(hipStreamSynchronize(b->stream));
     return 0;
 }
 catch (const gqp_hip_failure &) { return -1; }

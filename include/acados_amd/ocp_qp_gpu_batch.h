@@ -69,6 +69,11 @@ int ocp_qp_gpu_batch_bulk_len(ocp_qp_gpu_batch *b, int output);
 int ocp_qp_gpu_batch_bulk_offset(ocp_qp_gpu_batch *b, int output, const char *field, int stage, int *len);
 int ocp_qp_gpu_batch_set_bulk(ocp_qp_gpu_batch *b, const double *blob, int is_device);
 int ocp_qp_gpu_batch_get_bulk(ocp_qp_gpu_batch *b, double *blob, int is_device);
+/* _set_bulk in pieces (the batch entries of the acados-side adapter: the host->device copy of instance range j overlaps with the host
+ * threads still unpacking range j + 1): `blob_chunk` = instance `first` of the caller's pinned blob, `count` instances, asynchronous;
+ * _set_bulk_staged scatters what the chunks brought (all n_batch instances must have been handed over) and waits */
+int ocp_qp_gpu_batch_set_bulk_chunk(ocp_qp_gpu_batch *b, const double *blob_chunk, int first, int count);
+int ocp_qp_gpu_batch_set_bulk_staged(ocp_qp_gpu_batch *b);
 /* the QP DATA of the batch in the INPUT blob layout (inverse of _set_bulk): how a condensing module on acados' types reads the
  * condensed QP of a child batch (ocp_qp_gpu_batch_condense) into the container the reference's orchestration hands to the QP
  * solver next (xcond_qp_in, ocp_qp_partial_condensing.c:523-556; integration/ocp_qp_gpu_pcond.c) */

@@ -365,8 +365,9 @@ static void apply_opts(ocp_qp_gpu_batch *b, const ocp_qp_gpu_ipm_opts *o, int ws
     ocp_qp_gpu_batch_opts_set(b, "warm_start", &ws);
 }
 
-/* the device part of a solve: staged blobs -> device batch -> staged solution, statuses */
-static void bucket_solve(gpu_bucket *bk, const ocp_qp_gpu_ipm_opts *o, int ws)
+/* the device part of a solve: staged blobs -> device batch -> staged solution, statuses.  `staged`: the input blob is on the device
+ * already (handed over in chunks while it was being filled, evaluate_batch_masked): only its scatter launch is left */
+static void bucket_solve(gpu_bucket *bk, const ocp_qp_gpu_ipm_opts *o, int ws, int staged)
 {
     ocp_qp_gpu_batch *b = bk->batch;
     if (!b) /* the device failed while this bucket's batch was built (bucket_build) */
@@ -380,7 +381,8 @@ static void bucket_solve(gpu_bucket *bk, const ocp_qp_gpu_ipm_opts *o, int ws)
     /* a negative return = the device failed (HIP error, reported by the library): every QP of the bucket comes back as
      * ACADOS_QP_FAILURE -- ocp_nlp ends that capsule's solve cleanly (ocp_nlp_sqp.c:720-751) -- and the process, with the
      * other host threads of an MPC fleet in it, lives on */
-    if ((ws >= 2 && ocp_qp_gpu_batch_set_bulk_out(b, bk->blob_out, 0) != 0) || ocp_qp_gpu_batch_set_bulk(b, bk->blob_in, 0) != 0
+    if ((ws >= 2 && ocp_qp_gpu_batch_set_bulk_out(b, bk->blob_out, 0) != 0)
+        || (staged ? ocp_qp_gpu_batch_set_bulk_staged(b) : ocp_qp_gpu_batch_set_bulk(b, bk->blob_in, 0)) != 0
         || ocp_qp_gpu_batch_solve(b) < 0 || ocp_qp_gpu_batch_get_bulk(b, bk->blob_out, 0) != 0
         || ocp_qp_gpu_batch_get_info(b, "status", bk->st) != 0 || ocp_qp_gpu_batch_get_info(b, "iter", bk->it) != 0)
     {
@@ -437,7 +439,7 @@ static int ocp_qp_gpu_ipm_acados(void *config, void *qp_in_, void *qp_out_, void
     if (ws >= 2) unpack_qp_out_duals(&bk->lay, out, bk->blob_out);
     const double t_packed = now_s();
 
-    bucket_solve(bk, o, ws);
+    bucket_solve(bk, o, ws, 0);
     const double t_solved = now_s();
 
     pack_qp_out(&bk->lay, bk->blob_out, out);
@@ -611,16 +613,49 @@ static int evaluate_batch_masked(void *config, int n, void **qp_in_, void **qp_o
     if (!g) return ACADOS_SUCCESS;
     const int ws = o->warm_start >= 2 ? o->warm_start : 0;
 
-    /* host threads: every member array of every qp_in, panel-major -> the bucket's pinned blob */
-#pragma omp parallel for schedule(static)
-    for (int i = 0; i < n; i++)
+    /* host threads: every member array of every qp_in, panel-major -> the bucket's pinned blob.  Every capsule present (the batch
+     * entry; a rendezvous round may have absent ones): bucket by bucket and, inside a large bucket, in CHUNKS of instances -- a
+     * finished chunk goes to the device at once (asynchronous copy on the batch's stream), so the host->device copy of the QP data
+     * (85 KB per C2-shaped QP: as long as the unpacking itself) runs while the host threads unpack the next chunk */
+    int staged = 0;
+    if (!skip && !getenv("ACADOS_AMD_NO_CHUNKS"))
     {
-        if (skip && skip[i]) continue;
-        const gpu_bucket *bk = g->bk + g->bucket_of[i];
-        double *blob = bk->blob_in + (size_t) g->pos_of[i] * (size_t) bk->L_in;
-        memset(blob, 0, sizeof(double) * (size_t) bk->L_in);
-        unpack_qp_in(&bk->lay, ins[i], blob);
-        if (ws >= 2) unpack_qp_out_duals(&bk->lay, outs[i], bk->blob_out + (size_t) g->pos_of[i] * (size_t) bk->L_out);
+        staged = 1;
+        for (int q = 0; q < g->nbk; q++)
+        {
+            gpu_bucket *bk = g->bk + q;
+            const int nch = bk->n >= 512 ? 8 : (bk->n >= 128 ? 4 : 1), per = (bk->n + nch - 1) / nch;
+            for (int c0 = 0; c0 < bk->n; c0 += per)
+            {
+                const int c1 = c0 + per < bk->n ? c0 + per : bk->n;
+#pragma omp parallel for schedule(static)
+                for (int e = c0; e < c1; e++)
+                {
+                    const int i = bk->members[e];
+                    double *blob = bk->blob_in + (size_t) e * (size_t) bk->L_in;
+                    memset(blob, 0, sizeof(double) * (size_t) bk->L_in);
+                    unpack_qp_in(&bk->lay, ins[i], blob);
+                    if (ws >= 2) unpack_qp_out_duals(&bk->lay, outs[i], bk->blob_out + (size_t) e * (size_t) bk->L_out);
+                }
+                /* (no device batch: the device failed while it was built, bucket_solve fails the bucket's QPs; a failed copy:
+                 * the whole blob once more through _set_bulk, which reports it) */
+                if (!bk->batch || ocp_qp_gpu_batch_set_bulk_chunk(bk->batch, bk->blob_in + (size_t) c0 * (size_t) bk->L_in, c0, c1 - c0) != 0)
+                    staged = 0;
+            }
+        }
+    }
+    else
+    {
+#pragma omp parallel for schedule(static)
+        for (int i = 0; i < n; i++)
+        {
+            if (skip && skip[i]) continue;
+            const gpu_bucket *bk = g->bk + g->bucket_of[i];
+            double *blob = bk->blob_in + (size_t) g->pos_of[i] * (size_t) bk->L_in;
+            memset(blob, 0, sizeof(double) * (size_t) bk->L_in);
+            unpack_qp_in(&bk->lay, ins[i], blob);
+            if (ws >= 2) unpack_qp_out_duals(&bk->lay, outs[i], bk->blob_out + (size_t) g->pos_of[i] * (size_t) bk->L_out);
+        }
     }
     if (skip && (fresh || ws >= 2))
         for (int q = 0; q < g->nbk; q++)
@@ -639,7 +674,7 @@ static int evaluate_batch_masked(void *config, int n, void **qp_in_, void **qp_o
     /* one copy + one scatter launch, the solve, one gather launch + one copy per bucket; buckets run side by side
      * (each device batch has its own stream) */
 #pragma omp parallel for schedule(dynamic, 1) if (g->nbk > 1)
-    for (int q = 0; q < g->nbk; q++) bucket_solve(g->bk + q, o, ws);
+    for (int q = 0; q < g->nbk; q++) bucket_solve(g->bk + q, o, ws, staged);
     const double t_solved = now_s();
 
 #pragma omp parallel for schedule(static)

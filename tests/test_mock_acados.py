@@ -275,12 +275,13 @@ def test_acados_adapter_sensitivities(clib, tmp_path, qp_name):
     print("sens vs dense at the oracle's point:", worst)
 
 
-def _run_batch(exe, tmp_path, n, files, sens, reps=1, default_dispatch=False):
-    out = str(tmp_path / "batch.bin")
+def _run_batch(exe, tmp_path, n, files, sens, reps=1, default_dispatch=False, extra_env=None, tag="batch"):
+    out = str(tmp_path / (tag + ".bin"))
     cmd = [exe, "batch", str(n), files[0], files[1] if len(files) > 1 else "-", out] + (["sens"] if sens else []) + [str(reps)]
     env = dict(os.environ, OMP_NUM_THREADS=str(min(16, os.cpu_count() or 1)))
     if default_dispatch:      # conftest.py pins the small-batch rule off for the CPU tier; a timing wants the library's own choice
         env.pop("ACADOS_AMD_WPI_BATCH_MAX", None)
+    env.update(extra_env or {})
     r = subprocess.run(cmd, capture_output=True, text=True, env=env)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
     lines = r.stdout.strip().splitlines()
@@ -333,6 +334,35 @@ def test_acados_adapter_batch_two_structures(clib, tmp_path):
                 assert np.allclose(sol[("pi", k)], o.get(k, "pi"), rtol=1e-6, atol=1e-7)
         soft = int(np.sum(qp.dims.ns)) > 0
         _check_sens_vs_dense(qp, sol, sens, _seeds(qp, i), 2e-4 if soft else 1e-6, 1e-2)
+    assert p == raw.size
+
+
+@pytest.mark.parametrize("clib", TIERS, indirect=True)
+def test_acados_adapter_batch_chunked_staging(clib, tmp_path):
+    """the batch entry hands its input blob over in chunks (ocp_qp_gpu_batch_set_bulk_chunk: the copy of chunk j runs while the
+    host threads unpack chunk j + 1; 4 chunks from 128 QPs of a class on): 150 + 149 capsules of two classes, byte for byte the
+    output of the same call with the blob handed over whole, and a few capsules against the oracle"""
+    from acados_amd.generators import mass_spring_qp
+    qa, qb = mass_spring_qp(N=6), load_qp("casadi_qp_tests/pendulum_slack.json")
+    exe = _build(clib._name, tmp_path)
+    fa, fb = str(tmp_path / "qa.txt"), str(tmp_path / "qb.txt")
+    _write_qp(qa, fa); _write_qp(qb, fb)
+    n = 299
+    info, per, extra, raw = _run_batch(exe, tmp_path, n, [fa, fb], sens=False)
+    info0, per0, _, raw0 = _run_batch(exe, tmp_path, n, [fa, fb], sens=False, extra_env={"ACADOS_AMD_NO_CHUNKS": "1"}, tag="whole")
+    assert info["status"] == 0 and info0["status"] == 0 and per == per0
+    assert raw.size == raw0.size and np.array_equal(raw, raw0)
+    p = 0
+    for i in range(n):
+        qp = _perturbed(qb if i & 1 else qa, i)
+        sol, used = _split_bin(qp, raw[p:]); p += used
+        if i % 41 and i != n - 1:
+            continue
+        o = OracleQp(qp)
+        assert o.solve(default_opts(tol_stat=1e-8)) == 0
+        for k in range(qp.N + 1):
+            ref = np.concatenate([o.get(k, "u"), o.get(k, "x"), o.get(k, "sl"), o.get(k, "su")])
+            assert np.allclose(sol[("ux", k)], ref, rtol=1e-7, atol=1e-8), (i, k)
     assert p == raw.size
 
 
