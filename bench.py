@@ -118,7 +118,7 @@ def compact_line(out, detail_path=None):
         c["sample"] = f"{cb.get('unique', '')} C2 instances (seed 0), OpenMP over instances, restated CPU oracle (not HPIPM: sources absent)".strip()
         line["cpu_baseline"] = c
     if out.get("gather"):
-        line["gather"] = _pick(out["gather"], ("ms", "ranks", "GBps_received_per_rank", "slice_matches_getters", "gather_to_root_ms"), 4)
+        line["gather"] = _pick(out["gather"], ("ms", "ranks", "GBps_received_per_rank", "slice_matches_getters", "gather_to_root_ms", "error"), 4)
     if "configs" in out:
         cs = {}
         for name, c in out["configs"].items():
@@ -648,6 +648,45 @@ def other_configs(c2_batch, c2_data, args):
     return out
 
 
+GATHER_LIMIT_S = 240.0
+
+
+def guarded_gather(fn, world, limit_s=None):
+    """The solutions gather is the one step of an N > 1 run that has never met more than one device (RCCL has only
+    ever run as one rank here).  It runs after everything the line needs has been measured; with more than one rank it runs on a
+    helper thread under a time limit, so that a collective that never completes costs the gather record, not the run: returns
+    (result or None, error string or None).  The caller emits its line and, if the error says the collective is still in flight, leaves
+    the process with os._exit (the helper thread cannot be joined)."""
+    if world <= 1:
+        return fn(), None
+    import threading
+    import torch
+    limit_s = float(os.environ.get("ACADOS_AMD_GATHER_LIMIT_S", GATHER_LIMIT_S)) if limit_s is None else limit_s
+    box, dev_idx = {}, torch.cuda.current_device() if torch.cuda.is_available() else None
+
+    def run():
+        try:
+            if dev_idx is not None:
+                torch.cuda.set_device(dev_idx)      # the current device is per thread
+            box["v"] = fn()
+        except Exception as e:      # noqa: BLE001 -- reported on the line
+            box["e"] = f"{type(e).__name__}: {e}"
+    th = threading.Thread(target=run, daemon=True)
+    th.start()
+    th.join(limit_s)
+    if th.is_alive():
+        return None, f"in flight after {limit_s:.0f} s"
+    return box.get("v"), box.get("e")
+
+
+def leave_after_stuck_gather(err):
+    """a collective still in flight holds the stream and a thread: no destroy_process_group, no interpreter shutdown"""
+    if err and err.startswith("in flight"):
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
+
+
 def relaunch(n):
     """N ranks of this script on one node (the command line the driver uses for N > 1): rank 0's JSON line is the last line of
     stdout, the exit code is the launcher's"""
@@ -751,12 +790,12 @@ def main_c5(args):
     # shards of a class are uneven when per_class is not a multiple of the rank count (58,254 = 6 x 7,282 + 2 x 7,281): the
     # library's exact-count gather (ocp_qp_gpu_batch_gather_v) needs every rank's count
     counts = [hi_r - lo_r for lo_r, hi_r in (shard_range(per_class, r, ranks_total) for r in range(world))]
-    gathers = [gather_solutions(gb, dist, rank, world, counts=counts) for _, gb in batches]
     tot = torch.tensor([count, bad], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(tot)
+    gathers, gerr = guarded_gather(lambda: [gather_solutions(gb, dist, rank, world, counts=counts) for _, gb in batches], world)
     if rank == 0:
-        ok = [g for g in gathers if g]
+        ok = [g for g in (gathers or []) if g]
         out = {"metric": "OCP-QP solves/sec, mixed shape classes (BASELINE configs[4])", "value": float(tot[0]) * args.steps / elapsed,
                "unit": "OCP-QP solves/s", "n_gpus": world, "steps": args.steps, "warmup": max(args.warmup, 1),
                "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -770,7 +809,10 @@ def main_c5(args):
                           "slice_matches_getters": all(g["slice_matches_getters"] for g in ok) if ok else None,
                           "instances_per_rank": counts,
                           "collective": ok[0]["collective"] if ok else None}}
+        if gerr:
+            out["gather"]["error"] = gerr
         emit(out, args)
+    leave_after_stuck_gather(gerr)
     if dist is not None:
         dist.destroy_process_group()
 
@@ -873,8 +915,6 @@ def main():
     res_max = max(float(gb.info(n).max()) for n in ("res_stat", "res_eq", "res_ineq", "res_comp"))
     res_indep = float(gb.res_compute().max())
 
-    # ---- gather of the full solution payload + statistics over RCCL/xGMI, outside the timed region ----
-    gather = gather_solutions(gb, dist, rank, world)       # device buffers, library collective (no host bounce)
     if dist is not None:
         stats = torch.tensor([[float(iters.mean()), float(iters.max()), float((status != 0).sum()), res_max, res_indep]],
                              dtype=torch.float64, device=dev)
@@ -891,7 +931,14 @@ def main():
     if args.check > 0:
         err = oracle_error(gb, lambda i: lqr_instance_qp(data, i, N), np.linspace(0, B - 1, args.check).astype(int), N, tight=False)["same_tol_max"]
 
+    # ---- gather of the full solution payload + statistics over RCCL/xGMI, outside the timed region, LAST: everything the line
+    # reports is in hand by then (guarded_gather) ----
+    def the_gather():
+        return gather_solutions(gb, dist, rank, world)       # device buffers, library collective (no host bounce)
+
     if rank != 0:
+        _, gerr = guarded_gather(the_gather, world)
+        leave_after_stuck_gather(gerr)
         if dist is not None:
             dist.destroy_process_group()
         return
@@ -942,8 +989,8 @@ def main():
         "roofline": roof,
         "pack_s": t_pack,
         "hbm_bytes_per_gpu": gb.bytes,
-        "gather_ms": gather["ms"] if gather else None,
-        "gather": gather,
+        "gather_ms": None,
+        "gather": None,
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(data, N, min(args.cpu_sample, B))
@@ -970,7 +1017,11 @@ def main():
         out["ipm"]["oracle_checked_instances"] = int(out["ipm"]["oracle_checked_instances"]) + int(idx.size)
     if world == 1 and not args.no_configs:
         out["configs"] = other_configs(gb, data, args)
+    gather, gerr = guarded_gather(the_gather, world)
+    out["gather_ms"] = gather["ms"] if gather else None
+    out["gather"] = gather if gather or not gerr else {"ranks": world, "error": gerr}
     emit(out, args)
+    leave_after_stuck_gather(gerr)
     if dist is not None:
         dist.destroy_process_group()
 

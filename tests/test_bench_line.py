@@ -60,3 +60,24 @@ def test_nan_and_inf_do_not_reach_the_line():
     full["roofline"]["traffic_over_algorithmic"] = float("nan")
     full["ipm"]["max_rel_primal_err_vs_oracle"] = float("inf")
     strict_loads(bench.compact_line(full))
+
+
+def test_gather_guard_reports_instead_of_hanging():
+    """N > 1: the solutions gather (the one step that has never met a second device) runs last and under a time limit --
+    a collective that never completes costs the gather record, not the line"""
+    import time
+    import bench
+    v, e = bench.guarded_gather(lambda: {"ms": 1.0}, world=1)
+    assert v == {"ms": 1.0} and e is None
+    v, e = bench.guarded_gather(lambda: {"ms": 2.0}, world=2, limit_s=5.0)
+    assert v == {"ms": 2.0} and e is None
+    t0 = time.time()
+    v, e = bench.guarded_gather(lambda: time.sleep(30), world=2, limit_s=0.5)
+    assert v is None and e.startswith("in flight") and time.time() - t0 < 5.0
+
+    def boom():
+        raise RuntimeError("ncclCommInitRank failed")
+    v, e = bench.guarded_gather(boom, world=2, limit_s=5.0)
+    assert v is None and "ncclCommInitRank" in e
+    line = bench.compact_line({"metric": "m", "value": 1.0, "gather": {"ranks": 2, "error": e}})
+    assert json.loads(line)["gather"]["error"] == e
