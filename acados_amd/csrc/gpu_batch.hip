@@ -419,7 +419,10 @@ void finalize_structure(ocp_qp_gpu_batch *b)
     D.AW = b->AW;
     D.amask = garr<uint64_t>(b, (size_t) ((N + 1) * b->AW));
     D.DCt = garr<double>(b, (size_t) (o_g * n));
-    D.Zz = garr<double>(b, (size_t) (o_s * 2));
+    /* (at least one (Z, z) pair: the branch-free row functions of the sixteen-lanes GEN kernels read the pair of slack 0 through
+     * clamped addresses also in a batch without slacks -- with one element per instance the z of the LAST instance lay behind the
+     * allocation: found by the structure fuzz of round 5, a fault only where the array ended on a page boundary) */
+    D.Zz = garr<double>(b, (size_t) (o_s > 0 ? o_s * 2 : 2));
     D.ux = garr<double>(b, (size_t) ((N + 2) * n));
     D.sv = garr<double>(b, (size_t) (o_s));
     D.pi = garr<double>(b, (size_t) ((N + 2) * NX));

@@ -949,9 +949,9 @@ __global__ void __launch_bounds__(64) k_forward(GqpDev D, GqpOpts O, int redo)
 
     const int it = D.iter[i];
     double *st = (i < D.stat_inst && it + 1 < D.stat_rows) ? D.stat + (size_t) (it + 1) * GQP_STAT_COLS * D.stat_inst + i : nullptr;
-    if (!CORR)
+    /* duality measure at the end of the step of length a: sum (lam + a dlam)(t + a dt) / rows taking part */
+    auto mu_after = [&](double a_) -> double
     {
-        /* mu_aff and sigma = (mu_aff/mu)^3 */
         double s = 0.0;
         int nact = 0;
         for (int k = 0; k <= D.N; k++)
@@ -962,12 +962,17 @@ __global__ void __launch_bounds__(64) k_forward(GqpDev D, GqpOpts O, int redo)
             for (int e = 0; e < nct; e++)
                 if ((am >> e) & 1)
                 {
-                    s += (GAT(D.lam, S.o_ct + e) + alpha * GAT(D.dlam, S.o_ct + e)) * (GAT(D.t, S.o_ct + e) + alpha * GAT(D.dt, S.o_ct + e));
+                    s += (GAT(D.lam, S.o_ct + e) + a_ * GAT(D.dlam, S.o_ct + e)) * (GAT(D.t, S.o_ct + e) + a_ * GAT(D.dt, S.o_ct + e));
                     nact++;
                 }
         }
+        return nact > 0 ? s / nact : 0.0;
+    };
+    if (!CORR)
+    {
+        /* mu_aff and sigma = (mu_aff/mu)^3 */
         const double mu = D.mu[i];
-        const double mu_aff = nact > 0 ? s / nact : 0.0;
+        const double mu_aff = mu_after(alpha);
         double sigma = mu > 0.0 ? mu_aff / mu : 0.0;
         sigma = sigma * sigma * sigma;
         D.smu[i] = sigma * mu;
@@ -977,10 +982,10 @@ __global__ void __launch_bounds__(64) k_forward(GqpDev D, GqpOpts O, int redo)
     else
     {
         const double alpha_aff = dabs(D.alpha[i]);
-        if (O.cond_pred_corr && !redo && alpha < 0.1 * alpha_aff)
+        if (O.cond_pred_corr && !redo && mu_after(alpha) > 2.0 * D.mu[i])
         {
-            /* corrector collapsed: ask the host loop for a centering-only re-solve
-             * (flag = negative alpha); no update this pass */
+            /* conditional corrector (GQP_COND_RULE, gpu_ipm_internal.h): the step would more than double the duality
+             * measure -- ask the host loop for a centering-only re-solve (flag = negative alpha); no update this pass */
             D.alpha[i] = -alpha_aff;
             return;
         }

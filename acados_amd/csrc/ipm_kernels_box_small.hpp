@@ -510,13 +510,11 @@ __global__ void __launch_bounds__(64) kbs_forward(GqpDev D, GqpOpts O, int redo)
                 alpha = (dtl < 0.0 && c3 < alpha) ? c3 : alpha;
                 alpha = (dtu < 0.0 && c4 < alpha) ? c4 : alpha;
             }
-            if (!CORR)
-            {
-                S0 += ll * ttl + lu * ttu;
-                S1 += ll * dtl + ttl * dll + lu * dtu + ttu * dlu;
-                S2 += dll * dtl + dlu * dtu;
-                nact += (int) al + (int) au;
-            }
+            /* (corrector sweep too: the conditional corrector asks for the duality measure its step ends at) */
+            S0 += ll * ttl + lu * ttu;
+            S1 += ll * dtl + ttl * dll + lu * dtu + ttu * dlu;
+            S2 += dll * dtl + dlu * dtu;
+            nact += (int) al + (int) au;
             o_dll[j] = dll; o_dlu[j] = dlu; o_dtl[j] = dtl; o_dtu[j] = dtu;
         }
         UNROLL for (int j = 0; j < NB; j++)
@@ -555,7 +553,7 @@ __global__ void __launch_bounds__(64) kbs_forward(GqpDev D, GqpOpts O, int redo)
         return;
     }
     const double alpha_aff = dabs(D.alpha[i]);
-    if (run && O.cond_pred_corr && !redo && alpha < 0.1 * alpha_aff)
+    if (run && O.cond_pred_corr && !redo && nact > 0 && (S0 + alpha * S1 + alpha * alpha * S2) / nact > 2.0 * D.mu[i])
     {
         D.alpha[i] = -alpha_aff; /* flag for the redo pair */
         return;

@@ -669,12 +669,13 @@ __device__ static inline void kx_fwd_body(const GqpDev &D, const GqpOpts &O, int
                 alpha = (sdlu < 0.0 && q2 < alpha) ? q2 : alpha;
                 alpha = (sdtl < 0.0 && q3 < alpha) ? q3 : alpha;
                 alpha = (sdtu < 0.0 && q4 < alpha) ? q4 : alpha;
+                /* (the sums in the corrector sweep too: the conditional corrector asks for the duality measure its step ends at) */
+                S0 += sll * stl + slu * stu;
+                S1 += sll * sdtl + stl * sdll + slu * sdtu + stu * sdlu;
+                S2 += sdll * sdtl + sdlu * sdtu;
+                nact += (double) ((int) sal + (int) sau);
                 if (!CORR)
                 {
-                    S0 += sll * stl + slu * stu;
-                    S1 += sll * sdtl + stl * sdll + slu * sdtu + stu * sdlu;
-                    S2 += sdll * sdtl + sdlu * sdtu;
-                    nact += (double) ((int) sal + (int) sau);
                     WAT(D.pcorr, e0) = sdll * sdtl;
                     WAT(D.pcorr, e1) = sdlu * sdtu;
                 }
@@ -692,12 +693,12 @@ __device__ static inline void kx_fwd_body(const GqpDev &D, const GqpOpts &O, int
             alpha = (dlu < 0.0 && c2 < alpha) ? c2 : alpha;
             alpha = (dtl < 0.0 && c3 < alpha) ? c3 : alpha;
             alpha = (dtu < 0.0 && c4 < alpha) ? c4 : alpha;
+            S0 += ll * ttl + lu * ttu;
+            S1 += ll * dtl + ttl * dll + lu * dtu + ttu * dlu;
+            S2 += dll * dtl + dlu * dtu;
+            nact += (double) ((int) al + (int) au);
             if (!CORR)
             {
-                S0 += ll * ttl + lu * ttu;
-                S1 += ll * dtl + ttl * dll + lu * dtu + ttu * dlu;
-                S2 += dll * dtl + dlu * dtu;
-                nact += (double) ((int) al + (int) au);
                 WAT(D.pcorr, el) = dll * dtl;
                 WAT(D.pcorr, eu) = dlu * dtu;
             }
@@ -732,10 +733,17 @@ __device__ static inline void kx_fwd_body(const GqpDev &D, const GqpOpts &O, int
     }
     const double alpha_aff = dabs(D.alpha[inst]);
     GQP_ROWSYNC(); /* everybody has read alpha[inst] */
-    if (O.cond_pred_corr && !redo && alpha < 0.1 * alpha_aff)
+    if (O.cond_pred_corr && !redo)
     {
-        if (l == 0) D.alpha[inst] = -alpha_aff;
-        return;
+        /* conditional corrector: a step that would more than double the duality measure is taken again with the centering term
+         * alone (redo pair of the host loop) */
+        S0 = w16_rsum(S0, xb); S1 = w16_rsum(S1, xb); S2 = w16_rsum(S2, xb);
+        const double nact_d = w16_rsum(nact, xb);
+        if (nact_d > 0.0 && (S0 + alpha * S1 + alpha * alpha * S2) / nact_d > 2.0 * D.mu[inst])
+        {
+            if (l == 0) D.alpha[inst] = -alpha_aff;
+            return;
+        }
     }
     const double a = D.mu[inst] > 0.0 ? alpha * 0.995 : 1.0;
     if (O.ext_update)

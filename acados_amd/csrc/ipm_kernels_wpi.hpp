@@ -555,12 +555,13 @@ __global__ void __launch_bounds__(64) kw_forward(GqpDev D, GqpOpts O, int redo)
             alpha = (dlu < 0.0 && c2 < alpha) ? c2 : alpha;
             alpha = (dtl < 0.0 && c3 < alpha) ? c3 : alpha;
             alpha = (dtu < 0.0 && c4 < alpha) ? c4 : alpha;
+            /* (the sums in the corrector sweep too: the conditional corrector asks for the duality measure its step ends at) */
+            S0 += ll * ttl + lu * ttu;
+            S1 += ll * dtl + ttl * dll + lu * dtu + ttu * dlu;
+            S2 += dll * dtl + dlu * dtu;
+            nact += (int) al + (int) au;
             if (!CORR)
             {
-                S0 += ll * ttl + lu * ttu;
-                S1 += ll * dtl + ttl * dll + lu * dtu + ttu * dlu;
-                S2 += dll * dtl + dlu * dtu;
-                nact += (int) al + (int) au;
                 WAT(D.pcorr, el) = dll * dtl;
                 WAT(D.pcorr, eu) = dlu * dtu;
             }
@@ -595,11 +596,18 @@ __global__ void __launch_bounds__(64) kw_forward(GqpDev D, GqpOpts O, int redo)
         return;
     }
     const double alpha_aff = dabs(D.alpha[inst]);
-    if (O.cond_pred_corr && !redo && alpha < 0.1 * alpha_aff)
+    if (O.cond_pred_corr && !redo)
     {
-        __syncthreads(); /* everybody has read alpha[inst] */
-        if (lane == 0) D.alpha[inst] = -alpha_aff;
-        return;
+        /* conditional corrector: a step that would more than double the duality measure is taken again with the centering term
+         * alone (redo pair of the host loop) */
+        S0 = wpi_sum(S0, L.red, lane); S1 = wpi_sum(S1, L.red, lane); S2 = wpi_sum(S2, L.red, lane);
+        const double nact_d = wpi_sum((double) nact, L.red, lane);
+        if (nact_d > 0.0 && (S0 + alpha * S1 + alpha * alpha * S2) / nact_d > 2.0 * D.mu[inst])
+        {
+            __syncthreads(); /* everybody has read alpha[inst] */
+            if (lane == 0) D.alpha[inst] = -alpha_aff;
+            return;
+        }
     }
     const double a = D.mu[inst] > 0.0 ? alpha * 0.995 : 1.0;
     /* update: the arrays of one instance are contiguous */
@@ -1746,12 +1754,12 @@ __global__ void __launch_bounds__(64) kw_fwd(GqpDev D, GqpOpts O, int redo)
                 alpha = (dlu < 0.0 && c2 < alpha) ? c2 : alpha;
                 alpha = (dtl < 0.0 && c3 < alpha) ? c3 : alpha;
                 alpha = (dtu < 0.0 && c4 < alpha) ? c4 : alpha;
+                S0 += sll * stl + slu * stu;
+                S1 += sll * dtl + stl * dll + slu * dtu + stu * dlu;
+                S2 += dll * dtl + dlu * dtu;
+                nact += (int) sal + (int) sau;
                 if (!CORR)
                 {
-                    S0 += sll * stl + slu * stu;
-                    S1 += sll * dtl + stl * dll + slu * dtu + stu * dlu;
-                    S2 += dll * dtl + dlu * dtu;
-                    nact += (int) sal + (int) sau;
                     WAT(D.pcorr, e0) = dll * dtl;
                     WAT(D.pcorr, e1) = dlu * dtu;
                 }
@@ -1797,12 +1805,12 @@ __global__ void __launch_bounds__(64) kw_fwd(GqpDev D, GqpOpts O, int redo)
                 alpha = (dlu < 0.0 && c2 < alpha) ? c2 : alpha;
                 alpha = (dtl < 0.0 && c3 < alpha) ? c3 : alpha;
                 alpha = (dtu < 0.0 && c4 < alpha) ? c4 : alpha;
+                S0 += Rg.ll * Rg.tl + Rg.lu * Rg.tu;
+                S1 += Rg.ll * dtl + Rg.tl * dll + Rg.lu * dtu + Rg.tu * dlu;
+                S2 += dll * dtl + dlu * dtu;
+                nact += (int) Rg.al + (int) Rg.au;
                 if (!CORR)
                 {
-                    S0 += Rg.ll * Rg.tl + Rg.lu * Rg.tu;
-                    S1 += Rg.ll * dtl + Rg.tl * dll + Rg.lu * dtu + Rg.tu * dlu;
-                    S2 += dll * dtl + dlu * dtu;
-                    nact += (int) Rg.al + (int) Rg.au;
                     WAT(D.pcorr, Rg.el) = dll * dtl;
                     WAT(D.pcorr, Rg.eu) = dlu * dtu;
                 }
@@ -1825,12 +1833,12 @@ __global__ void __launch_bounds__(64) kw_fwd(GqpDev D, GqpOpts O, int redo)
             alpha = (dlu < 0.0 && c2 < alpha) ? c2 : alpha;
             alpha = (dtl < 0.0 && c3 < alpha) ? c3 : alpha;
             alpha = (dtu < 0.0 && c4 < alpha) ? c4 : alpha;
+            S0 += ll * ttl + lu * ttu;
+            S1 += ll * dtl + ttl * dll + lu * dtu + ttu * dlu;
+            S2 += dll * dtl + dlu * dtu;
+            nact += (int) al + (int) au;
             if (!CORR)
             {
-                S0 += ll * ttl + lu * ttu;
-                S1 += ll * dtl + ttl * dll + lu * dtu + ttu * dlu;
-                S2 += dll * dtl + dlu * dtu;
-                nact += (int) al + (int) au;
                 WAT(D.pcorr, el) = dll * dtl;
                 WAT(D.pcorr, eu) = dlu * dtu;
             }
@@ -1867,11 +1875,18 @@ __global__ void __launch_bounds__(64) kw_fwd(GqpDev D, GqpOpts O, int redo)
         return;
     }
     const double alpha_aff = dabs(D.alpha[inst]);
-    if (O.cond_pred_corr && !redo && alpha < 0.1 * alpha_aff)
+    if (O.cond_pred_corr && !redo)
     {
-        __syncthreads(); /* everybody has read alpha[inst] */
-        if (lane == 0) D.alpha[inst] = -alpha_aff;
-        return;
+        /* conditional corrector: a step that would more than double the duality measure is taken again with the centering term
+         * alone (redo pair of the host loop) */
+        S0 = wpi_sum(S0, L.red, lane); S1 = wpi_sum(S1, L.red, lane); S2 = wpi_sum(S2, L.red, lane);
+        const double nact_d = wpi_sum((double) nact, L.red, lane);
+        if (nact_d > 0.0 && (S0 + alpha * S1 + alpha * alpha * S2) / nact_d > 2.0 * D.mu[inst])
+        {
+            __syncthreads(); /* everybody has read alpha[inst] */
+            if (lane == 0) D.alpha[inst] = -alpha_aff;
+            return;
+        }
     }
     const double a = D.mu[inst] > 0.0 ? alpha * 0.995 : 1.0;
     for (int e = lane; e < (D.N + 1) * n; e += 64) WAT(D.ux, e) += a * WAT(D.dux, e);

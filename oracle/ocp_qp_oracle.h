@@ -52,7 +52,7 @@ typedef struct
     double reg_prim;   /* 1e-15 */
     int iter_max;      /* 50 */
     int pred_corr;     /* 1: Mehrotra predictor-corrector */
-    int cond_pred_corr;/* 1: fall back to pure centering when corrector step collapses */
+    int cond_pred_corr;/* 1: the step is taken again with the centering term alone when it would more than double the duality measure */
     int warm_start;    /* 0: cold */
     int print_level;
     int t0_init;       /* 2; cold start of (t, lam): acados_ocp_options.py:1128-1143 */

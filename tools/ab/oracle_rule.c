@@ -17,6 +17,7 @@
 #include "ocp_qp_oracle.h"
 
 #include <math.h>
+int g_redo[64];
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -944,16 +945,11 @@ int oqp_solve(oqp *qp, const oqp_opts *o)
             riccati_forward(qp);
             expand_step(qp, rm_ptr);
             alpha = step_length(qp);
-            /* conditional corrector (HPIPM's cond_pred_corr, on in the SPEED / BALANCE / ROBUST modes acados uses; HPIPM's sources
-             * are absent from the reference tree -- upstream knowledge of d_ocp_qp_ipm_solve): the duality measure at the end of
-             * the predictor-corrector step is evaluated, and a step that would more than double it is computed again from the
-             * centering term alone.  (Rounds 1-5 of this restatement asked `alpha < 0.1 alpha_aff` instead: identical on every
-             * golden vector and on the BASELINE configurations -- neither test ever fires there -- but on random structures with
-             * perturbed costs it left limit cycles of the Mehrotra iteration standing: 10 of 15,360 instances at MAXITER against
-             * 0 with this test, which also never needs more iterations; tools/fuzz_parity.py, profiles/NOTES.md round 5) */
-            double mu_pc = 0.0;
-            if (o->cond_pred_corr)
+            int redo_ = 0;
+            if (o->cond_pred_corr == 1) redo_ = alpha < 0.1 * alpha_aff;
+            else if (o->cond_pred_corr >= 2)
             {
+                double mu_pc = 0.0;
                 for (int k = 0; k <= N; k++)
                 {
                     stg *s = qp->s + k;
@@ -961,10 +957,13 @@ int oqp_solve(oqp *qp, const oqp_opts *o)
                         if (s->act[i]) mu_pc += (s->lam[i] + alpha * s->dlam[i]) * (s->t[i] + alpha * s->dt[i]);
                 }
                 mu_pc /= qp->n_act;
+                redo_ = mu_pc > 2.0 * mu;
+                if (o->cond_pred_corr == 3) redo_ = redo_ || alpha < 0.1 * alpha_aff;
             }
-            if (o->cond_pred_corr && mu_pc > 2.0 * mu)
+            if (redo_) __sync_fetch_and_add(&g_redo[it < 63 ? it : 63], 1);
+            if (redo_)
             {
-                /* drop the second-order term, keep centering */
+                /* corrector collapsed: drop the second-order term, keep centering */
                 for (int k = 0; k <= N; k++)
                 {
                     stg *s = qp->s + k;
