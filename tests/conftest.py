@@ -33,7 +33,9 @@ def hostsim_lib():
     """g++ build of the kernel sources against the host-simulation shim (test infra only)."""
     from hostsim.build import build
     from acados_amd import _lib
-    return _lib.bind(ctypes.CDLL(build()))
+    # ACADOS_AMD_HOSTSIM_LIB: another build of the same sources, e.g. tools/asan_hostsim.sh's (-fsanitize=address: the device
+    # arrays of the host simulation are heap blocks, an out-of-bounds element is reported with its source line)
+    return _lib.bind(ctypes.CDLL(os.environ.get("ACADOS_AMD_HOSTSIM_LIB") or build()))
 
 
 @pytest.fixture(scope="session")
