@@ -71,6 +71,26 @@ def main():
                     if abs(int(b.info("iter")[i]) - o.iter) > 1:
                         fails.append((seed, mode, name, f"iterations {int(b.info('iter')[i])} vs oracle {o.iter}"))
                     compare_with_oracle(lambda k, f: b.get(f, k)[i], o, qp, 3e-7, fields=("x", "u", "sl", "su", "pi", "lam", "t"))
+                    if mode == "default":
+                        # hot start from the solution: converged at the first residual evaluation (or one iteration), same point;
+                        # then a new right-hand side through the RTI split (condense_lhs once, condense_rhs_and_solve) = a plain solve
+                        x0 = b.get("x", qp.N).copy()
+                        b.opts_set("warm_start", 3)
+                        bad2 = b.solve()
+                        if bad2 or int(b.info("iter").max()) > 1 or np.max(np.abs(b.get("x", qp.N) - x0)) > 1e-7 * (1 + np.max(np.abs(x0))):
+                            fails.append((seed, "hot", name, f"hot start: {bad2} failed, iters {int(b.info('iter').max())}, dx {np.max(np.abs(b.get('x', qp.N) - x0)):.2e}"))
+                        b.opts_set("warm_start", 0)
+                        if qp.N >= 2:
+                            b.opts_set("cond_N", (qp.N + 1) // 2)
+                            b.condense_lhs()
+                            qk = b.get("q", 1)
+                            b.set("q", 1, qk * 1.25 + 0.1)
+                            r1 = b.condense_rhs_and_solve()
+                            xa = b.get("x", qp.N).copy()
+                            r2 = b.solve()
+                            if r1 or r2 or np.max(np.abs(b.get("x", qp.N) - xa)) > 1e-9 * (1 + np.max(np.abs(xa))):
+                                fails.append((seed, "rti", name, f"RTI split vs plain solve: {r1} {r2} dx {np.max(np.abs(b.get('x', qp.N) - xa)):.2e}"))
+                        continue
                     # every copy is the same QP: the batch must agree with itself
                     for f in ("x", "u"):
                         for k in (0, qp.N):
