@@ -188,3 +188,40 @@ def check_whole_solve_in_one_launch(clib, qp_sets):
             for f in fields:
                 assert np.array_equal(a.get(f, k), o.get(f, k)), (f, k, o.kernel_name)
     return used
+
+
+def limit_cycle_case(clib):
+    """tests/test_host_logic.py::test_conditional_corrector_ends_a_limit_cycle_hostsim and its GPU-tier twin: the five instances of
+    the perturbed batch of random structure 7105 that ran into a four-cycle of the Mehrotra iteration before the conditional
+    corrector applied HPIPM's test; clib = None: the product library"""
+    from oracle.oracle import OracleQp, default_opts
+    from acados_amd import OcpQpGpuBatch
+    from random_qp import random_structure_qp
+    seed, B = 7105, 1536
+    qp = random_structure_qp(seed, nx_max=12, nu_max=4, allow_general=(seed % 5 != 0), allow_slack=(seed % 7 != 0))
+    g = np.random.default_rng(seed + 9000)
+    src = OcpQpGpuBatch.from_qps([qp] * B, _clib=clib)
+    for k in range(qp.N + 1):
+        for f in ("q", "r"):
+            a0 = src.get(f, k)
+            if a0.shape[1]:
+                src.set(f, k, a0 * g.uniform(-2.0, 3.0, (B, 1)) + 0.3 * g.standard_normal(a0.shape))
+    hard = [src.to_qp(i) for i in (155, 896, 1176, 1188, 1267)]     # the five instances of the batch that cycled
+    for fam in ("0", "1"):
+        os.environ["ACADOS_AMD_WPI"] = fam
+        try:
+            b = OcpQpGpuBatch.from_qps(hard, _clib=clib)
+        finally:
+            del os.environ["ACADOS_AMD_WPI"]
+        for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+            b.opts_set(f, 1e-8)
+        b.opts_set("iter_max", 80)
+        assert b.solve() == 0, (b.kernel_name, b.info("status"), b.info("iter"))
+        for i, q in enumerate(hard):
+            o = OracleQp(q)
+            assert o.solve(default_opts(tol_stat=1e-8, iter_max=80)) == 0 and o.iter <= 20
+            assert abs(int(b.info("iter")[i]) - o.iter) <= 1, (b.kernel_name, i, b.info("iter"), o.iter)
+            compare_with_oracle(lambda k, f: b.get(f, k)[i], o, q, 1e-7, fields=("x", "u", "pi", "lam", "t"))
+        # without the conditional corrector the cycle is still there (what the test is about)
+        b.opts_set("cond_pred_corr", 0)
+        assert b.solve() > 0

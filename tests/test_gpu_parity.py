@@ -7,7 +7,7 @@ library on a real MI355X; the oracle (CPU) is the checker only.  Tolerances are 
 import numpy as np
 import pytest
 
-from conftest import GOLDEN_PAIRS, INPUT_ONLY, compare_condensed_with_oracle, compare_with_oracle, load_qp, load_sol
+from conftest import GOLDEN_PAIRS, INPUT_ONLY, compare_condensed_with_oracle, compare_with_oracle, limit_cycle_case, load_qp, load_sol
 from oracle.oracle import OracleQp, default_opts
 
 # tolerance of an INDEPENDENTLY recomputed residual for a solve at tol 1e-8: the IPM judges complementarity by
@@ -1069,6 +1069,14 @@ def test_concurrent_shape_classes_gpu(gpu_lib, monkeypatch):
                 for a, b in zip(got, r):
                     assert np.array_equal(a, b)
                 assert gb.res_compute().max() <= KKT_TOL
+
+
+def test_conditional_corrector_ends_a_limit_cycle_gpu(gpu_lib):
+    """the GPU-tier twin of tests/test_host_logic.py::test_conditional_corrector_ends_a_limit_cycle_hostsim: the five instances that
+    cycled before the conditional corrector applied HPIPM's test, on the one-instance-per-lane and the sixteen-lanes kernels of
+    the device, against the oracle (iteration counts within one, solution at 1e-7); without the conditional corrector they still
+    end at MAXITER"""
+    limit_cycle_case(None)
 
 
 def test_device_against_certified_dense_solutions_gpu(gpu_lib, monkeypatch):

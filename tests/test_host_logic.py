@@ -9,7 +9,7 @@ import re
 import numpy as np
 import pytest
 
-from conftest import (GOLDEN_PAIRS, INPUT_ONLY, ROOT, compare_condensed_with_oracle, compare_with_oracle, fold_stage0, load_qp,
+from conftest import (GOLDEN_PAIRS, limit_cycle_case, INPUT_ONLY, ROOT, compare_condensed_with_oracle, compare_with_oracle, fold_stage0, load_qp,
                       load_sol)
 from oracle.oracle import OracleQp, default_opts
 
@@ -911,36 +911,7 @@ def test_conditional_corrector_ends_a_limit_cycle_hostsim(hostsim_lib):
     one input bounded, random structure 7105 with its linear cost terms scaled -- runs into a four-cycle at mu ~ 3e-4 and ends at
     MAXITER, on the device and in the oracle alike.  The test HPIPM applies (the step is taken again with the centering term
     alone when it would more than double the duality measure) ends the cycle: both converge, in the same number of iterations."""
-    from acados_amd import OcpQpGpuBatch
-    from random_qp import random_structure_qp
-    seed, B = 7105, 1536
-    qp = random_structure_qp(seed, nx_max=12, nu_max=4, allow_general=(seed % 5 != 0), allow_slack=(seed % 7 != 0))
-    g = np.random.default_rng(seed + 9000)
-    src = OcpQpGpuBatch.from_qps([qp] * B, _clib=hostsim_lib)
-    for k in range(qp.N + 1):
-        for f in ("q", "r"):
-            a0 = src.get(f, k)
-            if a0.shape[1]:
-                src.set(f, k, a0 * g.uniform(-2.0, 3.0, (B, 1)) + 0.3 * g.standard_normal(a0.shape))
-    hard = [src.to_qp(i) for i in (155, 896, 1176, 1188, 1267)]     # the five instances of the batch that cycled
-    for fam in ("0", "1"):
-        os.environ["ACADOS_AMD_WPI"] = fam
-        try:
-            b = OcpQpGpuBatch.from_qps(hard, _clib=hostsim_lib)
-        finally:
-            del os.environ["ACADOS_AMD_WPI"]
-        for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
-            b.opts_set(f, 1e-8)
-        b.opts_set("iter_max", 80)
-        assert b.solve() == 0, (b.kernel_name, b.info("status"), b.info("iter"))
-        for i, q in enumerate(hard):
-            o = OracleQp(q)
-            assert o.solve(default_opts(tol_stat=1e-8, iter_max=80)) == 0 and o.iter <= 20
-            assert abs(int(b.info("iter")[i]) - o.iter) <= 1, (b.kernel_name, i, b.info("iter"), o.iter)
-            compare_with_oracle(lambda k, f: b.get(f, k)[i], o, q, 1e-7, fields=("x", "u", "pi", "lam", "t"))
-        # without the conditional corrector the cycle is still there (what the test is about)
-        b.opts_set("cond_pred_corr", 0)
-        assert b.solve() > 0
+    limit_cycle_case(hostsim_lib)
 
 
 def test_random_structures_partial_condensing_hostsim(hostsim_lib):
