@@ -1071,6 +1071,29 @@ def test_concurrent_shape_classes_gpu(gpu_lib, monkeypatch):
                 assert gb.res_compute().max() <= KKT_TOL
 
 
+def test_structure_fuzz_gpu(gpu_lib):
+    """a slice of tools/fuzz_parity.py in the GPU tier: 48 random structures (four size classes up to nx = 40) through the default
+    dispatch, both forced families and the condensed path with 70 copies each, a hot start and the RTI split per structure, and a
+    batch of 1,536 perturbed instances per structure (tail switch, live-instance permutation, redo pair) with six instances
+    against the oracle on the data read back from the device.  Asserted: none of the disagreements that mean a defect (an
+    exception, copies of one QP that differ, a hot start that iterates, an RTI pair that is not the plain solve, an independent
+    residual above the tolerance); listed but tolerated: fields a few 1e-7 beyond the comparison's tolerance, a slowest instance two
+    iterations from the oracle, instances at MAXITER (limit cycles the oracle has too: DESIGN 3)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_parity.py"))
+    fz = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fz)
+    fails, fams = fz.run("gpu", 7000, 7048)
+    kinds = {}
+    for f in fails:
+        kinds.setdefault(fz.kind(f), []).append(f)
+    print("structure fuzz, seeds 7000-7047:", {k: len(v) for k, v in kinds.items()}, "families", len(fams))
+    bad = {k: v for k, v in kinds.items() if k in ("hot", "rti", "residual", "copies", "error")}
+    assert not bad, bad
+    assert len(fams) >= 8, fams
+    assert len(kinds.get("maxiter", [])) <= 6 and len(kinds.get("tolerance", [])) <= 12, kinds
+
+
 def test_conditional_corrector_ends_a_limit_cycle_gpu(gpu_lib):
     """the GPU-tier twin of tests/test_host_logic.py::test_conditional_corrector_ends_a_limit_cycle_hostsim: the five instances that
     cycled before the conditional corrector applied HPIPM's test, on the one-instance-per-lane and the sixteen-lanes kernels of

@@ -17,9 +17,28 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
 
-def main():
-    tier, lo, hi = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
-    copies = int(sys.argv[4]) if len(sys.argv) > 4 else (3 if tier == "hostsim" else 70)
+def kind(f):
+    """what a disagreement is: 'tolerance' (a field a few 1e-7 beyond the comparison's tolerance: another point of the same 1e-8
+    ball), 'iterations' (a slowest instance two iterations from the oracle), 'maxiter' (a limit cycle of the iteration, the oracle
+    has it too), or one of the kinds that mean a defect: 'hot', 'rti', 'residual', 'copies', 'error'"""
+    m = f[-1]
+    if f[1] in ("hot", "rti"):
+        return f[1]
+    if m.startswith("mismatch"):
+        return "tolerance"
+    if "not converged" in m or "did not converge" in m:
+        return "maxiter"
+    if "iterations" in m:
+        return "iterations"
+    if "residual" in m:
+        return "residual"
+    if "copies differ" in m:
+        return "copies"
+    return "error"
+
+
+def run(tier, lo, hi, copies=None, batch=None):
+    copies = copies or (3 if tier == "hostsim" else 70)
     from conftest import compare_condensed_with_oracle, compare_with_oracle
     from random_qp import random_structure_qp
     from acados_amd import OcpQpGpuBatch
@@ -106,7 +125,7 @@ def main():
         # on the data read back from the device, every instance through the independent residual kernel
         if tier != "hostsim" or seed % 10 == 0 or os.environ.get("FUZZ_BATCH_ALL"):
             os.environ.pop("ACADOS_AMD_WPI", None)
-            B = 1536 if tier != "hostsim" or os.environ.get("FUZZ_BATCH_ALL") else 96
+            B = batch or (1536 if tier != "hostsim" or os.environ.get("FUZZ_BATCH_ALL") else 96)
             name = "?"
             try:
                 if os.environ.get("FUZZ_VERBOSE"):
@@ -148,10 +167,19 @@ def main():
         if (seed - lo) % 25 == 24:
             print(f"seed {seed}: {len(fails)} disagreements so far, {time.time() - t0:.0f} s", flush=True)
     os.environ.pop("ACADOS_AMD_WPI", None)
+    return fails, fams
+
+
+def main():
+    tier, lo, hi = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    fails, fams = run(tier, lo, hi, int(sys.argv[4]) if len(sys.argv) > 4 else None)
     print("kernel families met:", dict(sorted(fams.items(), key=lambda kv: -kv[1])))
-    print(f"{hi - lo} seeds, {len(fails)} disagreements")
+    kinds = {}
     for f in fails:
-        print("  ", f)
+        kinds[kind(f)] = kinds.get(kind(f), 0) + 1
+    print(f"{hi - lo} seeds, {len(fails)} disagreements {kinds}")
+    for f in fails:
+        print("  ", kind(f), f)
 
 
 if __name__ == "__main__":
