@@ -4,6 +4,8 @@ library on a real MI355X; the oracle (CPU) is the checker only.  Tolerances are 
   * vs the reference's golden vectors: atol 1e-5 on lam, pi (test_ocpqp_solver.py:43)
   * KKT residuals <= 1e-8 (test_qpsolvers.cpp:83-86, 240-251)
 """
+import os
+
 import numpy as np
 import pytest
 
