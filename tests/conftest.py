@@ -225,3 +225,51 @@ def limit_cycle_case(clib):
         # without the conditional corrector the cycle is still there (what the test is about)
         b.opts_set("cond_pred_corr", 0)
         assert b.solve() > 0
+
+
+def bulk_chunk_case(clib):
+    """C-ABI parity of the input blob entries (include/acados_amd/ocp_qp_gpu_batch.h): the QP data of a batch read as ONE blob
+    (_get_bulk_in), written into fresh batches whole (_set_bulk) and in uneven chunks (_set_bulk_chunk x 3 + _set_bulk_staged):
+    the same blob back, the same solve bit for bit; the refusals of the chunk entries.  clib = None: the product library"""
+    import ctypes as C
+    from acados_amd import OcpQpGpuBatch
+    from random_qp import random_structure_qp
+    for seed in (3, 22, 41):       # general rows + shared slacks + one-sided rows / box only / per-stage dims
+        qp = random_structure_qp(seed)
+        B = 37
+        g = np.random.default_rng(seed)
+        a = OcpQpGpuBatch.from_qps([qp] * B, _clib=clib)
+        for k in range(qp.N + 1):
+            for f in ("q", "r"):
+                v = a.get(f, k)
+                if v.shape[1]:
+                    a.set(f, k, v * g.uniform(0.5, 1.5, (B, 1)))
+        L = a._L
+        n = L.ocp_qp_gpu_batch_bulk_len(a._h, 0)
+        assert n > 0
+        blob = np.zeros((B, n))
+        assert L.ocp_qp_gpu_batch_get_bulk_in(a._h, blob.ctypes.data_as(C.c_void_p), 0) == 0
+        assert np.isfinite(blob).all() and np.abs(blob).max() > 0
+        assert a.solve() == 0
+        outs = []
+        for how in ("whole", "chunks"):
+            b = OcpQpGpuBatch.from_qps([qp] * B, _clib=clib)     # (structure and index sets; the data is overwritten below)
+            if how == "whole":
+                assert L.ocp_qp_gpu_batch_set_bulk(b._h, blob.ctypes.data_as(C.c_void_p), 0) == 0
+            else:
+                assert L.ocp_qp_gpu_batch_set_bulk_staged(b._h) == -1          # nothing handed over yet
+                for lo, hi in ((0, 5), (5, 30), (30, 37)):
+                    part = np.ascontiguousarray(blob[lo:hi])
+                    assert L.ocp_qp_gpu_batch_set_bulk_chunk(b._h, part.ctypes.data_as(C.c_void_p), lo, hi - lo) == 0
+                    del part                                                    # (hostsim copies at once; the GPU tier syncs below)
+                assert L.ocp_qp_gpu_batch_set_bulk_chunk(b._h, blob.ctypes.data_as(C.c_void_p), 30, 8) == -1   # beyond the batch
+                assert L.ocp_qp_gpu_batch_set_bulk_staged(b._h) == 0
+            back = np.zeros((B, n))
+            assert L.ocp_qp_gpu_batch_get_bulk_in(b._h, back.ctypes.data_as(C.c_void_p), 0) == 0
+            assert np.array_equal(back, blob), (seed, how)
+            assert b.solve() == 0
+            assert np.array_equal(b.info("iter"), a.info("iter"))
+            for k in range(qp.N + 1):
+                for f in ("x", "u", "lam"):
+                    assert np.array_equal(b.get(f, k), a.get(f, k)), (seed, how, f, k)
+            outs.append(b)

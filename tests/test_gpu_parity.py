@@ -9,7 +9,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import GOLDEN_PAIRS, INPUT_ONLY, compare_condensed_with_oracle, compare_with_oracle, limit_cycle_case, load_qp, load_sol
+from conftest import GOLDEN_PAIRS, INPUT_ONLY, bulk_chunk_case, compare_condensed_with_oracle, compare_with_oracle, limit_cycle_case, load_qp, load_sol
 from oracle.oracle import OracleQp, default_opts
 
 # tolerance of an INDEPENDENTLY recomputed residual for a solve at tol 1e-8: the IPM judges complementarity by
@@ -1071,6 +1071,11 @@ def test_concurrent_shape_classes_gpu(gpu_lib, monkeypatch):
                 for a, b in zip(got, r):
                     assert np.array_equal(a, b)
                 assert gb.res_compute().max() <= KKT_TOL
+
+
+def test_bulk_blob_whole_and_in_chunks_gpu(gpu_lib):
+    """_get_bulk_in / _set_bulk / _set_bulk_chunk + _set_bulk_staged through the C-ABI on the device (tests/conftest.py::bulk_chunk_case)"""
+    bulk_chunk_case(None)
 
 
 def test_structure_fuzz_gpu(gpu_lib):

@@ -9,7 +9,7 @@ import re
 import numpy as np
 import pytest
 
-from conftest import (GOLDEN_PAIRS, limit_cycle_case, INPUT_ONLY, ROOT, compare_condensed_with_oracle, compare_with_oracle, fold_stage0, load_qp,
+from conftest import (GOLDEN_PAIRS, bulk_chunk_case, limit_cycle_case, INPUT_ONLY, ROOT, compare_condensed_with_oracle, compare_with_oracle, fold_stage0, load_qp,
                       load_sol)
 from oracle.oracle import OracleQp, default_opts
 
@@ -912,6 +912,11 @@ def test_conditional_corrector_ends_a_limit_cycle_hostsim(hostsim_lib):
     MAXITER, on the device and in the oracle alike.  The test HPIPM applies (the step is taken again with the centering term
     alone when it would more than double the duality measure) ends the cycle: both converge, in the same number of iterations."""
     limit_cycle_case(hostsim_lib)
+
+
+def test_bulk_blob_whole_and_in_chunks_hostsim(hostsim_lib):
+    """_get_bulk_in / _set_bulk / _set_bulk_chunk + _set_bulk_staged through the C-ABI (tests/conftest.py::bulk_chunk_case)"""
+    bulk_chunk_case(hostsim_lib)
 
 
 def test_random_structures_partial_condensing_hostsim(hostsim_lib):
