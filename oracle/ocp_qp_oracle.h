@@ -26,7 +26,12 @@
  * fixtures (tests/golden/: last_qp_*.json -> sqp_sol_*.json, lam/pi @1e-5,
  * examples/acados_python/tests/qp_test/test_ocpqp_solver.py:43-53) and against an
  * independent dense KKT solve (SciPy) on the input-only casadi_tests fixtures.
- * Iteration counts and per-iteration statistics are UNPINNED (no HPIPM here).
+ * Iteration counts and per-iteration statistics are UNPINNED (no HPIPM here): the
+ * safeguards of the iteration -- the conditional corrector (a step that would more
+ * than double the duality measure is taken again from the centering term alone),
+ * the 0.995 step scaling, sigma = (mu_aff/mu)^3 -- are restated from upstream
+ * knowledge of HPIPM's solve loop; the golden vectors pin where the iteration ends,
+ * not its path (ocp_qp_oracle.c, "conditional corrector").
  */
 #ifndef OCP_QP_ORACLE_H_
 #define OCP_QP_ORACLE_H_
