@@ -8,7 +8,9 @@
 #     bash tools/asan_hostsim.sh fuzz 8000 8030                                  (tools/fuzz_parity.py hostsim <lo> <hi>)
 root=$(cd "$(dirname "$0")/.." && pwd)
 lib=$root/tools/ab/libgqp_hostsim_asan.so
-asan=$(gcc -print-file-name=libasan.so)
+# (libstdc++ beside it: ASan resolves __cxa_throw when it starts -- inside python, which has no C++ runtime yet, the first exception
+# of the library would end in "CHECK failed: real___cxa_throw != 0")
+asan="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libstdc++.so.6)"
 mkdir -p $root/tools/ab
 build() {
     (cd $root/tests/hostsim && g++ -O1 -g -fsanitize=address -fno-omit-frame-pointer -std=c++17 -fPIC -shared -x c++ -Wno-unknown-pragmas \
@@ -18,8 +20,8 @@ build() {
 case "$1" in
     build) build ;;
     pytest) shift; [ -f $lib ] || build
-        LD_PRELOAD=$asan ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 ACADOS_AMD_HOSTSIM_LIB=$lib python -m pytest "$@" ;;
+        LD_PRELOAD="$asan" ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 ACADOS_AMD_HOSTSIM_LIB=$lib python -m pytest "$@" ;;
     fuzz) [ -f $lib ] || build
-        LD_PRELOAD=$asan ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 FUZZ_HOSTSIM_LIB=$lib python $root/tools/fuzz_parity.py hostsim $2 $3 ;;
+        LD_PRELOAD="$asan" ASAN_OPTIONS=detect_leaks=0:halt_on_error=1 FUZZ_HOSTSIM_LIB=$lib python $root/tools/fuzz_parity.py hostsim $2 $3 ;;
     *) echo "usage: $0 build | pytest <args> | fuzz <lo> <hi>" ;;
 esac
