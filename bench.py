@@ -42,6 +42,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0                   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_COPY_GBS = 6290.0                   # same guide: what a float4 copy sustains on this part (the practical ceiling of a streaming kernel)
 SWEEPS = ("back_fact", "fwd_aff", "back_rhs", "fwd_corr")
 CLASSES = SWEEPS + ("init", "finalize")
 
@@ -102,7 +103,7 @@ def compact_line(out, detail_path=None):
     ro = out.get("roofline")
     if ro:
         r = _pick(ro, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "bytes_per_launch",
-                       "avg_launch_ms", "launches_timed", "whole_solve_frac"))
+                       "avg_launch_ms", "launches_timed", "whole_solve_frac", "traffic_GBps", "traffic_frac_of_sustained_copy"))
         ts = ro.get("traffic_source")
         r["traffic_source"] = _pick(ts, ("file", "commit", "stale")) if ts else None
         fl = ro.get("full_launch")
@@ -954,6 +955,10 @@ def main():
     roof["traffic_note"] = ("HBM bytes per launch from the committed rocprofv3 PMC summary named in traffic_source (counter passes "
                             "cannot run inside this process); the time it is divided by is measured live in this run")
     roof["traffic_over_algorithmic"] = (tr["avg_main"] / roof["bytes_per_launch"]) if tr else None
+    # the REAL rate of the dominant sweep (PMC bytes of the committed summary over the launch time measured here) against the copy
+    # rate the part sustains: how much of the gap between `frac` and 1 is bytes the sweep also carries, how much is rate
+    roof["traffic_GBps"] = (tr["avg_main"] / (roof["avg_launch_ms"] * 1e-3) / 1e9) if tr and roof.get("avg_launch_ms") else None
+    roof["traffic_frac_of_sustained_copy"] = (roof["traffic_GBps"] / HBM_COPY_GBS) if roof["traffic_GBps"] else None
     full_units = [u for u in roof["units_per_launch"] if u == B]
     roof["full_launch"] = {"bytes": float(B * (b_in + b_out)), "traffic": tr["full"] if tr else None,
                            "traffic_over_algorithmic": (tr["full"] / (B * (b_in + b_out))) if tr else None,
