@@ -332,7 +332,7 @@ static int bucket_build(gpu_bucket *bk, const ocp_qp_in *in, const int *sig, int
     {
         ocp_qp_gpu_batch_set_int(bk->batch, "idxb", k, in->idxb[k], d->nb[k]);
         ocp_qp_gpu_batch_set_int(bk->batch, "idxs_rev", k, in->idxs_rev[k], d->nb[k] + d->ng[k]);
-        ocp_qp_gpu_batch_set_int(bk->batch, "idxe", k, in->idxe[k], d->nbxe[k]);
+        ocp_qp_gpu_batch_set_int(bk->batch, "idxe", k, in->idxe[k] + d->nbue[k], d->nbxe[k]); /* [bue | bxe | ge]: the bxe part */
     }
     if (gpu_layout_build(&bk->lay, d) != 0)
     {

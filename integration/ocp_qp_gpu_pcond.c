@@ -439,7 +439,7 @@ static ocp_qp_gpu_batch *pc_load(ocp_qp_gpu_pcond_memory *mem, const ocp_qp_gpu_
         {
             ocp_qp_gpu_batch_set_int(p->batch, "idxb", k, in->idxb[k], d->nb[k]);
             ocp_qp_gpu_batch_set_int(p->batch, "idxs_rev", k, in->idxs_rev[k], d->nb[k] + d->ng[k]);
-            ocp_qp_gpu_batch_set_int(p->batch, "idxe", k, in->idxe[k], d->nbxe[k]);
+            ocp_qp_gpu_batch_set_int(p->batch, "idxe", k, in->idxe[k] + d->nbue[k], d->nbxe[k]); /* [bue | bxe | ge]: the bxe part */
         }
         if (gpu_layout_build(p, d) != 0 || (size_t) p->L_in > mem->blob_cap || (size_t) p->L_out > mem->blob_cap)
         {

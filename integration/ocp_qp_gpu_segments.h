@@ -103,7 +103,10 @@ GPU_SEG_FN int fill_sig(const ocp_qp_in *in, int *s)
         memcpy(s + p, v, sizeof(v)); p += 7;
         memcpy(s + p, in->idxb[k], sizeof(int) * d->nb[k]); p += d->nb[k];
         memcpy(s + p, in->idxs_rev[k], sizeof(int) * (d->nb[k] + d->ng[k])); p += d->nb[k] + d->ng[k];
-        memcpy(s + p, in->idxe[k], sizeof(int) * d->nbxe[k]); p += d->nbxe[k];
+        /* acados orders idxe [bue | bxe | ge] (ocp_nlp_constraints_bgh.c:637-655): the equality-flagged STATE bounds are what the device
+         * eliminates (the ocp_qp interface of the path knows no others: acados_ocp_qp.py:374-379); an equality-flagged input bound
+         * or general row stays the lb = ub pair it also is */
+        memcpy(s + p, in->idxe[k] + d->nbue[k], sizeof(int) * d->nbxe[k]); p += d->nbxe[k];
     }
     return p;
 }
