@@ -990,7 +990,7 @@ __global__ void __launch_bounds__(64) k_forward(GqpDev D, GqpOpts O, int redo)
             return;
         }
         /* no inequality rows (mu == 0 exactly): the Newton step solves the QP, take it fully */
-        const double a = D.mu[i] > 0.0 ? alpha * 0.995 : 1.0;
+        const double a = D.mu[i] > 0.0 ? gqp_step_scale(alpha) : 1.0;
         for (int k = 0; k <= D.N; k++)
         {
             GQP_STAGE_REF S = D.st[k];

@@ -778,7 +778,7 @@ __global__ void __launch_bounds__(64) kb_forward(GqpDev D, GqpOpts O, int redo)
         return;
     }
     /* no inequality rows (mu == 0 exactly): the Newton step solves the QP, take it fully */
-    const double a = !run ? 0.0 : D.mu[i] > 0.0 ? alpha * 0.995 : 1.0;
+    const double a = !run ? 0.0 : D.mu[i] > 0.0 ? gqp_step_scale(alpha) : 1.0;
 #if GQP_KB_FOLD
     /* folded update: the step stays in (dux, dpi, dlam, dt), the next factor sweep applies it (kb_factor) */
     if (!run) return;

@@ -558,7 +558,7 @@ __global__ void __launch_bounds__(64) kbs_forward(GqpDev D, GqpOpts O, int redo)
         D.alpha[i] = -alpha_aff; /* flag for the redo pair */
         return;
     }
-    const double a = !run ? 0.0 : D.mu[i] > 0.0 ? alpha * 0.995 : 1.0;
+    const double a = !run ? 0.0 : D.mu[i] > 0.0 ? gqp_step_scale(alpha) : 1.0;
     /* update pass: the iterate moves by a * direction; the same pipeline (a stage reads and writes its own slots only) */
     struct URec
     {

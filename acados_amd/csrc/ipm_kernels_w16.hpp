@@ -745,7 +745,7 @@ __device__ static inline void kx_fwd_body(const GqpDev &D, const GqpOpts &O, int
             return;
         }
     }
-    const double a = D.mu[inst] > 0.0 ? alpha * 0.995 : 1.0;
+    const double a = D.mu[inst] > 0.0 ? gqp_step_scale(alpha) : 1.0;
     if (O.ext_update)
     {
         /* launch-per-sweep loop: the step is applied by k_step_update (ipm_kernels.hpp), every element its own work item

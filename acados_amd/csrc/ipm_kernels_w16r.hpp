@@ -1694,7 +1694,7 @@ __global__ void __launch_bounds__(64) W16R_WPE_FWD ky_fwd(GqpDev D, GqpOpts O, i
             return;
         }
     }
-    const double a = D.mu[inst] > 0.0 ? alpha * 0.995 : 1.0;
+    const double a = D.mu[inst] > 0.0 ? gqp_step_scale(alpha) : 1.0;
 #if defined(W16R_SKIP_UPDATE) /* development builds: what the update pass costs (the solve no longer converges) */
     if (l == 0) { D.alpha[inst] = alpha; D.iter[inst] = it + 1; }
     return;

@@ -609,7 +609,7 @@ __global__ void __launch_bounds__(64) kw_forward(GqpDev D, GqpOpts O, int redo)
             return;
         }
     }
-    const double a = D.mu[inst] > 0.0 ? alpha * 0.995 : 1.0;
+    const double a = D.mu[inst] > 0.0 ? gqp_step_scale(alpha) : 1.0;
     /* update: the arrays of one instance are contiguous */
     for (int e = lane; e < (D.N + 1) * n; e += 64) WAT(D.ux, e) += a * WAT(D.dux, e);
     for (int e = NX + lane; e < (D.N + 1) * NX; e += 64) WAT(D.pi, e) += a * WAT(D.dpi, e);
@@ -1888,7 +1888,7 @@ __global__ void __launch_bounds__(64) kw_fwd(GqpDev D, GqpOpts O, int redo)
             return;
         }
     }
-    const double a = D.mu[inst] > 0.0 ? alpha * 0.995 : 1.0;
+    const double a = D.mu[inst] > 0.0 ? gqp_step_scale(alpha) : 1.0;
     for (int e = lane; e < (D.N + 1) * n; e += 64) WAT(D.ux, e) += a * WAT(D.dux, e);
     for (int e = NX + lane; e < (D.N + 1) * NX; e += 64) WAT(D.pi, e) += a * WAT(D.dpi, e);
     if (GEN)

@@ -142,7 +142,10 @@ def test_exact_dense_reference_c4_shaped():
     d_rule, it_rule = _dist(o, qp, sol), o.iter
     print(f"C4-shaped: distance to the certified solution: tight {d_tight:.2e}, 1e-8 x 4 {d_plain:.2e} ({it_plain} it), "
           f"soft exit rule {d_rule:.2e} ({it_rule} it)")
-    assert d_tight <= 1e-9 and d_rule <= 1e-8 and d_plain > 10 * d_rule and it_rule <= it_plain + 3
+    # (while the step was scaled by the constant 0.995 the plain exit of this instance ended ~1e-7 away and the rule bought two orders;
+    # with the scaling of HPIPM's update the last steps are nearly full steps and the plain exit itself ends at 2e-9, in the same 14
+    # iterations: the rule must never be worse, its distance bar stands)
+    assert d_tight <= 1e-9 and d_rule <= 1e-8 and d_rule <= 1.001 * d_plain and it_rule <= it_plain + 3
 
 
 def test_exact_dense_reference_condensed_c3_shaped(hostsim_lib):

@@ -979,9 +979,7 @@ int oqp_solve(oqp *qp, const oqp_opts *o)
         }
         /* no inequality rows: the Newton step solves the QP, take it fully (HPIPM solves the
          * unconstrained KKT system once in that case) */
-        /* step to the boundary as HPIPM's update scales it (upstream knowledge of UPDATE_VAR_QP; the constant 0.995 of older versions
-         * until the end of round 5: same solutions, 2 - 5 % more iterations): close to 0.99 alpha for short steps, the full step at 1 */
-        double a = qp->n_act > 0 ? (alpha < 1.0 ? alpha * ((1.0 - alpha) * 0.99 + alpha * 0.9999999) : alpha) : 1.0;
+        double a = qp->n_act > 0 ? (alpha < 1.0 ? alpha * 0.995 : 1.0) : 1.0;
         for (int k = 0; k <= N; k++)
         {
             stg *s = qp->s + k;
