@@ -29,7 +29,7 @@
  * Iteration counts and per-iteration statistics are UNPINNED (no HPIPM here): the
  * safeguards of the iteration -- the conditional corrector (a step that would more
  * than double the duality measure is taken again from the centering term alone),
- * the 0.995 step scaling, sigma = (mu_aff/mu)^3 -- are restated from upstream
+ * the scaling of the step to the boundary ((1 - a) 0.99 + a 0.9999999), sigma = (mu_aff/mu)^3 -- are restated from upstream
  * knowledge of HPIPM's solve loop; the golden vectors pin where the iteration ends,
  * not its path (ocp_qp_oracle.c, "conditional corrector").
  */
