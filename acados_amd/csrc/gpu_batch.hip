@@ -152,6 +152,13 @@ struct ocp_qp_gpu_batch
     GqpDev D = {};
     GqpOpts O;
     bool has_slack = false;            /* some stage has slack variables (set with the dims) */
+    /* terminal polishing step (option "polish", opt-in: polish_pass below) */
+    int polish = 0;
+    double polish_ratio = 1e-3;
+    int n_polished = 0, n_polish_reverted = 0;
+    int *d_pol_status = nullptr, *d_pol_iter = nullptr, *d_pol_flag = nullptr, *d_pol_cnt = nullptr;
+    double *d_pol_sc = nullptr;
+    GArr pol_ux = {nullptr, 0, 0}, pol_sv = {nullptr, 0, 0}, pol_pi = {nullptr, 0, 0}, pol_lam = {nullptr, 0, 0}, pol_t = {nullptr, 0, 0};
     double tol_comp_soft_scale = 1.0; /* effective_opts: opt-in tighter exit on complementarity of a soft-constrained class (1 = the tolerance as given, the reference's semantics) */
     int nct_tot = 0, ns2_tot = 0, ng_tot = 0;
     std::vector<void *> allocs;
@@ -1065,6 +1072,8 @@ try
     else if (!strcmp(f, "alpha_min")) o.alpha_min = *d;
     else if (!strcmp(f, "tau_min")) o.tau_min = *d;
     else if (!strcmp(f, "tol_comp_soft_scale")) b->tol_comp_soft_scale = *d;
+    else if (!strcmp(f, "polish")) b->polish = *i != 0;
+    else if (!strcmp(f, "polish_ratio")) b->polish_ratio = *d;
     else if (!strcmp(f, "reg_prim")) o.reg_prim = *d;
     else if (!strcmp(f, "cond_pred_corr")) o.cond_pred_corr = *i;
     else if (!strcmp(f, "print_level")) b->print_level = *i;
@@ -1368,6 +1377,7 @@ static int pcond_solve(ocp_qp_gpu_batch *b, int mode = 3)
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventCreate(&e2)); HIPCHK(hipEventCreate(&e3));
     c->O = b->O;
     c->tol_comp_soft_scale = b->tol_comp_soft_scale;
+    c->polish = b->polish; c->polish_ratio = b->polish_ratio;
     c->print_level = b->print_level;
     HIPCHK(hipEventRecord(e0, b->stream));
     pcond_launch(b, false);
@@ -1613,6 +1623,71 @@ static void run_ipm(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch *root, Prof &prof, hip
     b->w16_slots = b->B; /* launches outside this loop (sensitivity passes) cover every instance again */
 }
 
+/*
+ * Terminal polishing step (option "polish" = 1, opt-in; status and iteration counts of the solve are unchanged).  Behind the loop,
+ * converged instances that still hold a BALANCED complementarity pair -- min(lam, t) > polish_ratio * max(lam, t) on a row that takes
+ * part: the weakly active rows an IPM leaves at t = mu / lam*, the whole of the distance between its exit point and the solution
+ *  -- run ONE more iteration of the same four sweeps (k_polish_select: iteration counter 0 against iter_max 1, exit
+ * tolerances that cannot be met, statistics table off).  Near the solution a Mehrotra iteration is the affine step but for
+ * sigma = (mu_aff / mu)^3 ~ 1e-9: mu falls by three orders and more.  The polished point must pass the exit test the solve was
+ * run with; an instance whose does not gets its iterate back (k_polish_restore / k_polish_revert: counted in "polish_reverted").
+ * Cost: one iteration + one factor sweep over the instances selected -- in the one-instance-per-lane family over every 64-instance
+ * tile that holds one.  Measured: profiles/NOTES.md round 6.
+ */
+static void run_ipm(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch *root, Prof &prof, hipStream_t s, int it);
+static void polish_pass(ocp_qp_gpu_batch *b, Prof &prof, hipStream_t s)
+{
+    b->n_polished = b->n_polish_reverted = 0;
+    GqpDev &D = b->D;
+    if (!b->d_pol_status)
+    {
+        b->d_pol_status = dalloc<int>(b, b->Bp); b->d_pol_iter = dalloc<int>(b, b->Bp); b->d_pol_flag = dalloc<int>(b, b->Bp);
+        b->d_pol_cnt = dalloc<int>(b, 2);
+        b->d_pol_sc = dalloc<double>(b, (size_t) 6 * b->Bp);
+        b->pol_ux = garr<double>(b, D.ux.E); b->pol_sv = garr<double>(b, D.sv.E); b->pol_pi = garr<double>(b, D.pi.E);
+        b->pol_lam = garr<double>(b, D.lam.E); b->pol_t = garr<double>(b, D.t.E);
+    }
+    const dim3 g64((b->B + 63) / 64), blk(64);
+    HIPCHK(hipMemsetAsync(b->d_pol_cnt, 0, 2 * sizeof(int), s));
+    hipLaunchKernelGGL(gqp::k_polish_select, g64, blk, 0, s, D, side_map(b), b->nct_tot, b->polish_ratio, b->d_pol_status, b->d_pol_iter, b->d_pol_sc,
+                       b->d_pol_cnt);
+    HIPCHK(hipMemcpyAsync(b->h_nact, b->d_pol_cnt, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const int nsel = *b->h_nact;
+    b->launches++;
+    if (nsel <= 0)
+    {
+        hipLaunchKernelGGL(gqp::k_status_restore, g64, blk, 0, s, D, b->d_pol_status); /* (nothing changed; keeps the two paths alike) */
+        return;
+    }
+    const struct { GArr src, dst; } cp[] = {{D.ux, b->pol_ux}, {D.sv, b->pol_sv}, {D.pi, b->pol_pi}, {D.lam, b->pol_lam}, {D.t, b->pol_t}};
+    for (const auto &c : cp) HIPCHK(hipMemcpyAsync(c.dst.p, c.src.p, sizeof(double) * (size_t) c.src.E * b->Bp, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(D.n_active, b->h_nact, sizeof(int), hipMemcpyHostToDevice, s));
+    const GqpOpts keep = b->O;
+    const int keep_stat = D.stat_inst;
+    b->O.tol_stat = b->O.tol_eq = b->O.tol_ineq = b->O.tol_comp = -1.0; /* the loop's exit test cannot pass: it ends at iter_max */
+    b->O.iter_max = 1;
+    const GqpOpts Oeff = effective_opts(keep, b);
+    b->O.tau_min = Oeff.tau_min; /* the barrier floor of the solve (derived from ITS tol_comp) */
+    D.stat_inst = 0;             /* the statistics table keeps the solve's rows */
+    run_ipm(b, b, prof, s, 0);
+    b->O = keep;
+    D.stat_inst = keep_stat;
+    hipLaunchKernelGGL(gqp::k_polish_restore, g64, blk, 0, s, D, Oeff, b->d_pol_status, b->d_pol_iter, b->d_pol_sc, b->d_pol_flag, b->d_pol_cnt + 1);
+    HIPCHK(hipMemcpyAsync(b->h_nact, b->d_pol_cnt + 1, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    b->launches++;
+    b->n_polished = nsel;
+    b->n_polish_reverted = *b->h_nact;
+    if (b->n_polish_reverted > 0)
+    {
+        const int blocks = D.ux.aos ? b->B : (b->B + GQP_UPD_THREADS - 1) / GQP_UPD_THREADS;
+        hipLaunchKernelGGL(gqp::k_polish_revert, dim3(blocks), dim3(GQP_UPD_THREADS), 0, s, D, b->d_pol_flag, b->pol_ux, b->pol_sv, b->pol_pi, b->pol_lam,
+                           b->pol_t);
+        b->launches++;
+    }
+}
+
 /* arrays that define a QP instance and its iterate (everything else is recomputed) */
 #define GQP_FOR_STATE_ARRAYS(X) X(BAt) X(bvec) X(RSQ) X(rq) X(dvec) X(DCt) X(Zz) X(ux) X(sv) X(pi) X(lam) X(t)
 #define GQP_FOR_RESULT_ARRAYS(X) X(ux) X(sv) X(pi) X(lam) X(t)
@@ -1734,6 +1809,7 @@ try
     }
     HIPCHK(hipMemsetAsync(D.apend, 0, sizeof(double) * (size_t) b->Bp, s)); /* no step pending (a solve always ends behind a factor sweep; belt and braces) */
     run_ipm(b, b, prof, s, 0);
+    if (b->polish) polish_pass(b, prof, s);
     b->factor_stale = b->n_tail_switches + b->n_compactions > 0;
     b->sens_open = false;
     GQP_IPM_LAUNCH(b, pick_kernels(b).final_, s, D);
@@ -2143,6 +2219,9 @@ try
     if (!strcmp(f, "single_launch_solves")) return (double) b->n_single_launch;
     if (!strcmp(f, "cond_N_active")) return b->pcond_state == 1 ? (double) b->child->N : (double) b->N;
     if (!strcmp(f, "tol_comp_soft_scale")) return b->tol_comp_soft_scale;
+    if (!strcmp(f, "polish")) return b->polish;
+    if (!strcmp(f, "polished")) return b->child && b->pcond_state == 1 && b->cond_N > 0 && b->cond_N < b->N ? b->child->n_polished : b->n_polished;
+    if (!strcmp(f, "polish_reverted")) return b->child && b->pcond_state == 1 && b->cond_N > 0 && b->cond_N < b->N ? b->child->n_polish_reverted : b->n_polish_reverted;
     if (!strcmp(f, "tol_comp_effective")) { finalize_structure(b); return effective_opts(b->O, b).tol_comp; }
     /* which condensing / expansion kernels serve the batch: 2 sixteen lanes per block, 1 one instance per lane, 0 one wave
      * per instance (meaningful once partial condensing is active) */

@@ -1421,6 +1421,81 @@ static __global__ void k_status_restore(GqpDev D, const int *saved_status)
     if (i < D.B) D.status[i] = saved_status[i];
 }
 
+/* ---- terminal polishing step (option "polish", opt-in; gpu_batch.hip polish_pass) ----
+ * An IPM stops ON the central path: a weakly active row with multiplier lam* sits at t = mu / lam*, so at tol_comp 1e-8 the returned
+ * point can be 1e-6 ... 1e-4 away from the solution although every KKT residual is below tolerance.  Such rows are
+ * the ones whose pair (lam, t) is BALANCED at the exit -- min(lam, t) > ratio * max(lam, t) -- where a strictly active / inactive
+ * row has one of the two at the size of mu.  k_polish_select wakes the converged instances that hold such a pair for ONE more
+ * iteration of the sweeps (iteration counter 0 against iter_max 1, exit tolerances that cannot be met); k_polish_restore puts
+ * (status, iter) back where the solve left them and flags the instances whose polished point no longer passes the exit test the
+ * solve was run with -- k_polish_revert copies their iterate back from the copy taken before the step. */
+static __global__ void k_polish_select(GqpDev D, const int *side_map, int n_sides, double ratio, int *saved_status, int *saved_iter, double *saved_sc,
+                                       int *count)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D.B) return;
+    const int st = D.status[i];
+    saved_status[i] = st;
+    saved_iter[i] = D.iter[i];
+    for (int q = 0; q < 4; q++) saved_sc[q * D.Bp + i] = D.res[q * D.Bp + i]; /* what the getters report for an instance that is reverted */
+    saved_sc[4 * D.Bp + i] = D.mu[i];
+    saved_sc[5 * D.Bp + i] = D.obj[i];
+    if (st != 0) return;
+    bool weak = false;
+    for (int e = 0; e < n_sides && !weak; e++)
+    {
+        const int sb = side_map[e];
+        if (sb < 0) continue;
+        const int k = sb >> 7, bit = sb & 127;
+        if (!((GATL(D.amask, k * D.AW + (bit >> 6)) >> (bit & 63)) & 1)) continue;
+        const double l = GATL(D.lam, e), t = GATL(D.t, e);
+        const double lo = l < t ? l : t, hi = l < t ? t : l;
+        weak = lo > ratio * hi;
+    }
+    if (!weak) return;
+    D.status[i] = GQP_RUNNING;
+    D.iter[i] = 0;
+    D.alpha[i] = 1.0;
+    atomicAdd(count, 1);
+}
+
+static __global__ void k_polish_restore(GqpDev D, GqpOpts O, const int *saved_status, const int *saved_iter, const double *saved_sc, int *flag, int *count)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= D.B) return;
+    const bool polished = saved_status[i] == 0 && D.status[i] != 0; /* woken by k_polish_select (left at MAXITER of the one-iteration loop) */
+    flag[i] = 0;
+    if (polished || D.status[i] == GQP_RUNNING)
+    {
+        const double g = D.res[0 * D.Bp + i], b = D.res[1 * D.Bp + i], d = D.res[2 * D.Bp + i], m = D.res[3 * D.Bp + i];
+        const bool ok = g <= O.tol_stat && b <= O.tol_eq && d <= O.tol_ineq && m <= O.tol_comp; /* false for NaN */
+        if (!ok)
+        {
+            flag[i] = 1;
+            atomicAdd(count, 1);
+            for (int q = 0; q < 4; q++) D.res[q * D.Bp + i] = saved_sc[q * D.Bp + i];
+            D.mu[i] = saved_sc[4 * D.Bp + i];
+            D.obj[i] = saved_sc[5 * D.Bp + i];
+        }
+    }
+    D.status[i] = saved_status[i];
+    D.iter[i] = saved_iter[i];
+}
+
+static __global__ void __launch_bounds__(GQP_UPD_THREADS) k_polish_revert(GqpDev D, const int *flag, GArr ux, GArr sv, GArr pi, GArr lam, GArr t)
+{
+    const bool aos = D.ux.aos != 0;
+    const int tid = threadIdx.x;
+    const int i = aos ? (int) blockIdx.x : (int) blockIdx.x * GQP_UPD_THREADS + tid;
+    if (i >= D.B || !flag[i]) return;
+    const int e0 = aos ? tid : 0, de = aos ? GQP_UPD_THREADS : 1;
+    for (int e = e0; e < D.ux.E; e += de) GATL(D.ux, e) = GATL(ux, e);
+    for (int e = e0; e < D.sv.E; e += de) GATL(D.sv, e) = GATL(sv, e);
+    for (int e = e0; e < D.pi.E; e += de) GATL(D.pi, e) = GATL(pi, e);
+    for (int e = e0; e < D.lam.E; e += de) GATL(D.lam, e) = GATL(lam, e);
+    for (int e = e0; e < D.t.E; e += de) GATL(D.t, e) = GATL(t, e);
+}
+
 static __global__ void k_sens_fixed(GqpDev D, GArr sfix, int out)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

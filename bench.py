@@ -86,6 +86,16 @@ def _pick(d, keys, sig=5):
     return {k: _r(d[k], sig) for k in keys if isinstance(d, dict) and k in d and not isinstance(d[k], (dict, list))}
 
 
+DIST_KEYS = ("median", "q99", "max", "above_1e-6", "instances")
+
+
+def _dist(rec):
+    """{median, q99, max, above_1e-6, instances} of the relative primal distance between what the device returns and THE solution
+    (oracle at complementarity 1e-12; oracle_error's `dist_to_solution`) of one configuration record, or None"""
+    d = rec.get("dist_to_solution") or (rec.get("oracle_check") or {}).get("dist_to_solution")
+    return _pick(d, DIST_KEYS, 3) if d else None
+
+
 def compact_line(out, detail_path=None):
     """The ONE line the driver parses: headline fields, `config`, `ipm`, `roofline` (scalars + the source of the PMC traffic),
     `cpu_baseline` (value, cores, kind, sample, one_thread) and one short record per other configuration.  Everything else
@@ -100,6 +110,9 @@ def compact_line(out, detail_path=None):
                                          "oracle_checked_instances", "launches_per_step", "wave_max_iter_mean"), 4)
         if out["ipm"].get("iter_hist"):
             line["ipm"]["iter_hist"] = out["ipm"]["iter_hist"]
+        d = _dist(out["ipm"])
+        if d:
+            line["ipm"]["dist_to_solution"] = d
     ro = out.get("roofline")
     if ro:
         r = _pick(ro, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "bytes_per_launch",
@@ -125,15 +138,22 @@ def compact_line(out, detail_path=None):
         for name, c in out["configs"].items():
             ro_c = c.get("roofline") or c.get("roofline_of_slowest_class") or {}
             rec = _pick(c, ("batch", "solves_per_s", "ms_per_step", "mean_iter", "failures", "max_rel_primal_err_vs_oracle",
-                            "condense_expand_ms", "solves_per_s_one_after_the_other"), 4)
+                            "condense_expand_ms", "solves_per_s_one_after_the_other", "polished"), 4)
             rec.update({"frac": _r(ro_c.get("frac"), 3), "traffic_over_algorithmic": _r(ro_c.get("traffic_over_algorithmic"), 3)})
             mf = c.get("mfma") or {}
             u = (mf.get("utilisation") or {}).get("kernels") if isinstance(mf.get("utilisation"), dict) else None
             if u:
                 rec["mfma_utilisation"] = _r(max((k.get("mfma_utilisation") or 0.0) for k in u.values()), 3)
-            for leg in ("plain_exit", "tight_exit"):        # C4: the other exit rule (round 4 lines: plain_exit; now: tight_exit, opt-in)
+            d = _dist(c)
+            if d:
+                rec["dist_to_solution"] = d
+            if "quoted_exit" in c:
+                rec["quoted_exit"] = c["quoted_exit"]
+            for leg in ("plain_exit", "tight_exit", "polish"):   # C4: the other exit rules beside the one the record's rate is quoted at
                 if leg in c:
                     rec[leg + "_solves_per_s"] = _r(c[leg].get("solves_per_s"), 4)
+                    if c[leg].get("max_rel_primal_err_vs_oracle") is not None:
+                        rec[leg + "_err_vs_oracle"] = _r(c[leg]["max_rel_primal_err_vs_oracle"], 3)
             if "classes" in c:          # C5: one number per class, in the order of the detail file
                 rec["class_solves_per_s"] = [_r(k["solves_per_s"], 3) for k in c["classes"]]
                 rec["class_frac"] = [_r(k["frac"], 2) for k in c["classes"]]
@@ -526,6 +546,31 @@ def run_config(name, gb, qp_of, N, dims, steps=2, check=4, extra=None, section=0
     return out
 
 
+def polish_leg(gb, qp_of, N, check):
+    """the batch as it is configured + the opt-in terminal polishing step (option "polish": converged instances that hold a balanced
+    pair min(lam, t) > 1e-3 max(lam, t) run one more iteration; status / iter unchanged): rate, how many instances it touched, and the
+    distance to THE solution (oracle at complementarity 1e-12) it leaves -- `max_rel_primal_err_vs_oracle` of this record is that
+    distance's maximum (the oracle has no polishing step: a same-tolerance comparison would measure the ORACLE's distance)"""
+    gb.opts_set("polish", 1)
+    gb.solve()
+    t0 = time.perf_counter()
+    bad = 0
+    for _ in range(2):
+        bad += gb.solve()
+    dt = (time.perf_counter() - t0) / 2
+    it = gb.info("iter")
+    rec = {"batch": gb.n_batch, "solves_per_s": gb.n_batch / dt, "ms_per_step": dt * 1e3, "mean_iter": float(it.mean()), "max_iter": int(it.max()),
+           "failures": int((gb.info("status") != 0).sum()), "max_kkt_residual_independent": float(gb.res_compute().max()),
+           "polished": int(gb.scalar("polished")), "polish_reverted": int(gb.scalar("polish_reverted"))}
+    if check:
+        idx = np.unique(np.linspace(0, gb.n_batch - 1, check).astype(int))
+        oe = oracle_error(gb, qp_of, idx, N, same_tol=False)
+        rec.update({"oracle_check": oe, "max_rel_primal_err_vs_oracle": oe["dist_to_solution"]["max"], "oracle_checked_instances": int(idx.size),
+                    "err_reference": "oracle at complementarity 1e-12 (distance to the solution)"})
+    gb.opts_set("polish", 0)
+    return rec
+
+
 def other_configs(c2_batch, c2_data, args):
     """C3, C4 and the per-GPU share of C5 on this GPU (BASELINE.json configs[2..4])"""
     from acados_amd import OcpQpGpuBatch
@@ -559,22 +604,43 @@ def other_configs(c2_batch, c2_data, args):
                                       "of the general rows as one more chain of tile products)": bool(g4.scalar("w16_tiles"))},
                              tile_fill="n = 27 -> 28 = 7 tiles (one padding row), nx = 24 = 6 tiles: 0.96",
                              utilisation=mfma_util("_c4_c5"))
-    # the same batch with the OPT-IN tighter exit of a soft-constrained class (tol_comp_soft_scale 1e-3: complementarity at
-    # 1e-11): what it costs, and the ball it removes
+    # The rate QUOTED for C4 (configs.C4.solves_per_s) is the one at which the north-star parity bar holds on the >= 1,024-instance
+    # sample (max relative primal error vs the oracle <= 1e-6): the soft-constrained class leaves so flat a 1e-8 ball that two runs
+    # of ONE algorithm differ by 3e-6 inside it, so the bar can only be promised at the opt-in tighter exit
+    # tol_comp_soft_scale 1e-3 (complementarity at 1e-11, both sides).  The library's DEFAULT stays the reference's stopping
+    # semantics (ocp_qp_hpipm.c:104-107): that run is `plain_exit`, the secondary number.
+    plain = {k: out["C4"][k] for k in ("solves_per_s", "ms_per_step", "mean_iter", "max_iter", "failures", "max_kkt_residual_independent")}
+    for k in ("max_rel_primal_err_vs_oracle", "oracle_checked_instances", "oracle_check"):
+        if k in out["C4"]:
+            plain[k] = out["C4"].pop(k)
+    plain["exit_rule"] = "tol_comp as given (1e-8): the library default = the reference's semantics"
     g4.opts_set("tol_comp_soft_scale", 1e-3)
     g4.solve()
     t0 = time.perf_counter()
-    bad = g4.solve()
-    dt = time.perf_counter() - t0
+    bad = 0
+    for _ in range(2):
+        bad += g4.solve()
+    dt = (time.perf_counter() - t0) / 2
     it = g4.info("iter")
-    out["C4"]["exit_rule"] = {"tol_comp_soft_scale": 1.0, "effective_tol_comp": 1e-8,
-                              "note": "default: the solver stops at the tol_comp it is given (ocp_qp_hpipm.c:104-107); tight_exit = the same "
-                                      "batch with the opt-in tol_comp_soft_scale 1e-3 (complementarity at 1e-11, DESIGN.md 3)"}
-    out["C4"]["tight_exit"] = {"solves_per_s": B4 / dt, "ms_per_step": dt * 1e3, "mean_iter": float(it.mean()), "max_iter": int(it.max()),
-                               "failures": int(bad), "max_kkt_residual_independent": float(g4.res_compute().max())}
+    tight = {"solves_per_s": B4 / dt, "ms_per_step": dt * 1e3, "mean_iter": float(it.mean()), "max_iter": int(it.max()),
+             "failures": int((g4.info("status") != 0).sum()), "max_kkt_residual_independent": float(g4.res_compute().max())}
     if args.check_configs:
         idx = np.unique(np.linspace(0, B4 - 1, args.check_configs).astype(int))
-        out["C4"]["tight_exit"]["oracle_check"] = oracle_error(g4, lambda i: chain_soft_instance_qp(d4, i, N4), idx, N4)
+        oe = oracle_error(g4, lambda i: chain_soft_instance_qp(d4, i, N4), idx, N4)
+        tight.update({"oracle_check": oe, "max_rel_primal_err_vs_oracle": oe["same_tol_max"], "oracle_checked_instances": int(idx.size)})
+    out["C4"]["plain_exit"] = plain
+    out["C4"]["tight_exit"] = dict(tight)
+    g4.opts_set("tol_comp_soft_scale", 1.0)
+    out["C4"]["polish"] = polish_leg(g4, lambda i: chain_soft_instance_qp(d4, i, N4), N4, args.check_configs)
+    quoted = "tight_exit" if (not args.check_configs or plain.get("max_rel_primal_err_vs_oracle", 0.0) > 1e-6) else "plain_exit"
+    out["C4"].update(tight if quoted == "tight_exit" else plain)
+    out["C4"]["quoted_exit"] = quoted
+    out["C4"]["exit_rule"] = {"quoted": quoted, "tol_comp_soft_scale": 1e-3 if quoted == "tight_exit" else 1.0,
+                              "effective_tol_comp": 1e-11 if quoted == "tight_exit" else 1e-8,
+                              "note": "solves_per_s of this record = the exit rule at which max_rel_primal_err_vs_oracle <= 1e-6 holds on the sample "
+                                      "(north_star bar); plain_exit = the library default (tol_comp as given, ocp_qp_hpipm.c:104-107); tight_exit = "
+                                      "opt-in tol_comp_soft_scale 1e-3 (complementarity at 1e-11, DESIGN.md 3); roofline / traffic of the record "
+                                      "are the plain run's launches (same kernels, same bytes per launch)"}
     del g4, d4
     # C2 once more with complementarity at 1e-11 (a user's choice for a hard-constrained class): the distance to the solution is
     # the tolerance's -- at 1e-8 x 4 an IPM stops on the central path, t = mu / lam* on a weakly active row
@@ -591,6 +657,8 @@ def other_configs(c2_batch, c2_data, args):
         idx = np.unique(np.linspace(0, c2_batch.n_batch - 1, args.check_configs).astype(int))
         out["C2_tol_comp_1e-11"]["oracle_check"] = oracle_error(c2_batch, lambda i: lqr_instance_qp(c2_data, i, N), idx, N, same_tol=False)
     c2_batch.opts_set("tol_comp", 1e-8)
+    out["C2_polish"] = dict(polish_leg(c2_batch, lambda i: lqr_instance_qp(c2_data, i, N), N, args.check_configs),
+                            workload="the headline batch at the plain 1e-8 exit + the opt-in terminal polishing step (option polish)")
     # C5: the per-GPU share of 524,288 instances on 8 GPUs, split equally over the 9 shape classes.  Every class is one
     # device batch with its own HIP stream; the classes are solved CONCURRENTLY (one host thread per class, the solve
     # call releases the GIL) -- small, latency-bound batches overlap on the chip -- and, for reference, one after the other
@@ -631,7 +699,8 @@ def other_configs(c2_batch, c2_data, args):
                           "traffic_over_algorithmic_full_launch": r["roofline"].get("traffic_over_algorithmic_full_launch"),
                           "traffic_GBps": r["roofline"]["traffic_GBps"],
                           "max_rel_primal_err_vs_oracle": r.get("max_rel_primal_err_vs_oracle"),
-                          "oracle_checked_instances": r.get("oracle_checked_instances", 0)})
+                          "oracle_checked_instances": r.get("oracle_checked_instances", 0),
+                          "dist_to_solution": (r.get("oracle_check") or {}).get("dist_to_solution")})
         tot_t += r["ms_per_step"] * 1e-3
         tot_n += gc.n_batch
         bad += r["failures"]
@@ -646,6 +715,11 @@ def other_configs(c2_batch, c2_data, args):
                        "max_kkt_residual_independent": res_max, "roofline_of_slowest_class": worst_frac[1], "classes": classes,
                        "max_rel_primal_err_vs_oracle": max((c["max_rel_primal_err_vs_oracle"] or 0.0) for c in classes),
                        "oracle_checked_instances": sum(c["oracle_checked_instances"] for c in classes)}
+    ds = [c["dist_to_solution"] for c in classes if c.get("dist_to_solution")]
+    if ds:      # per-class statistics pooled: max / counts exact, median and q99 = the largest class value (an upper bound of the pooled one)
+        out["C5_share"]["dist_to_solution"] = {"median": max(d["median"] for d in ds), "q99": max(d["q99"] for d in ds), "max": max(d["max"] for d in ds),
+                                               "above_1e-6": sum(d["above_1e-6"] for d in ds), "instances": sum(d["instances"] for d in ds),
+                                               "pooled": "over the classes: max and counts exact; median / q99 = the largest class value"}
     return out
 
 

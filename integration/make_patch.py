@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Generates integration/acados.patch: the registration of PARTIAL_CONDENSING_GPU_IPM in an acados checkout.
-The edits are made on a scratch copy of the eight reference files they touch and `diff -u` writes the patch, so the patch
+The edits are made on a scratch copy of the reference files they touch and `diff -u` writes the patch, so the patch
 applies by construction (`patch -p1 --dry-run` is re-checked in tests/test_integration_patch.py).  Nothing of the reference
 is stored in this repository besides the context lines a unified diff carries.
 
@@ -40,7 +40,7 @@ void {{ name }}_acados_batch_solve_gpu_qp({{ name }}_solver_capsule ** capsules,
     #pragma omp parallel for
     for (int i = 0; i < N_batch; i++)
     {
-        ocp_nlp_solver_opts_set(capsules[i]->nlp_config, capsules[i]->nlp_opts, "qp_batch_phase", &phase);
+        ocp_nlp_solver_opts_set(capsules[i]->nlp_config, capsules[i]->nlp_opts, "batch_qp_phase", &phase);
         status_out[i] = ocp_nlp_solve(capsules[i]->nlp_solver, capsules[i]->nlp_in, capsules[i]->nlp_out);
     }
 
@@ -66,10 +66,10 @@ void {{ name }}_acados_batch_solve_gpu_qp({{ name }}_solver_capsule ** capsules,
     #pragma omp parallel for
     for (int i = 0; i < N_batch; i++)
     {
-        ocp_nlp_solver_opts_set(capsules[i]->nlp_config, capsules[i]->nlp_opts, "qp_batch_phase", &phase);
+        ocp_nlp_solver_opts_set(capsules[i]->nlp_config, capsules[i]->nlp_opts, "batch_qp_phase", &phase);
         status_out[i] = ocp_nlp_solve(capsules[i]->nlp_solver, capsules[i]->nlp_in, capsules[i]->nlp_out);
         int phase_off = 0;
-        ocp_nlp_solver_opts_set(capsules[i]->nlp_config, capsules[i]->nlp_opts, "qp_batch_phase", &phase_off);
+        ocp_nlp_solver_opts_set(capsules[i]->nlp_config, capsules[i]->nlp_opts, "batch_qp_phase", &phase_off);
     }
 
     if (num_threads_in_batch_solve > 1)
@@ -124,40 +124,65 @@ EDITS = {
     "acados/ocp_nlp/ocp_nlp_common.h": [
         ("    int ext_qp_res;\n",
          "    int ext_qp_res;\n"
-         "    int qp_batch_phase;  // 0: as ever; 1: return in front of the QP solve; 2: resume behind it (QP solved in a device batch)\n"),
+         "    // TRANSIENT, not an option string: SQP_RTI's feedback step sets it around ITS call of ocp_nlp_solve_qp_and_correct_dual only\n"
+         "    // (1: return in front of the QP solve; 2: resume behind it, the QP was solved in a device batch); 0 for every other caller\n"
+         "    int batch_qp_phase;\n"),
     ],
     "acados/ocp_nlp/ocp_nlp_common.c": [
-        ("    opts->ext_qp_res = 0;\n", "    opts->ext_qp_res = 0;\n    opts->qp_batch_phase = 0;\n"),
-        ('        else if (!strcmp(field, "ext_qp_res"))\n',
-         '        else if (!strcmp(field, "qp_batch_phase"))\n        {\n            int* qp_batch_phase = (int *) value;\n'
-         '            opts->qp_batch_phase = *qp_batch_phase;\n        }\n'
-         '        else if (!strcmp(field, "ext_qp_res"))\n'),
+        ("    opts->ext_qp_res = 0;\n", "    opts->ext_qp_res = 0;\n    opts->batch_qp_phase = 0;\n"),
         ("    // solve qp\n    acados_tic(&timer);\n    if (precondensed_lhs)\n    {\n",
          "    // lock-step batch on a GPU QP solver: phase 1 stops here -- the caller sends every capsule's (scaled) QP to the device in\n"
          "    // ONE batch (ocp_qp_gpu_xcond_solver_acados_evaluate_batch) -- phase 2 picks the result up from the QP solver's memory\n"
-         "    if (nlp_opts->qp_batch_phase == 1)\n    {\n        return ACADOS_SUCCESS;\n    }\n\n"
+         "    if (nlp_opts->batch_qp_phase == 1)\n    {\n        return ACADOS_SUCCESS;\n    }\n\n"
          "    // solve qp\n    acados_tic(&timer);\n"
-         "    if (nlp_opts->qp_batch_phase == 2)\n    {\n"
+         "    if (nlp_opts->batch_qp_phase == 2)\n    {\n"
          '        qp_solver->memory_get(qp_solver, qp_mem, "status", &qp_status);\n    }\n'
          "    else if (precondensed_lhs)\n    {\n"),
+        # phase 2: the condensing ran inside the device batch -- the module's own timer still holds an earlier per-capsule call
+        ('    qp_solver->memory_get(qp_solver, qp_mem, "time_qp_xcond", &tmp_time);\n    nlp_timings->time_qp_xcond += tmp_time;\n\n'
+         "    // evaluate QP residual externally\n",
+         "    if (nlp_opts->batch_qp_phase != 2)\n    {\n"
+         '        qp_solver->memory_get(qp_solver, qp_mem, "time_qp_xcond", &tmp_time);\n        nlp_timings->time_qp_xcond += tmp_time;\n    }\n\n'
+         "    // evaluate QP residual externally\n"),
+    ],
+    # the option lives in SQP_RTI's OWN opts ("batch_qp_phase": no `qp_` prefix -- ocp_nlp_opts_set routes every `qp_*` string to the
+    # QP solver, ocp_nlp_common.c:1337-1349, as acados' own `ext_qp_res` shows) and only the feedback step's QP solve is split
+    "acados/ocp_nlp/ocp_nlp_sqp_rti.h": [
+        ("    int rti_log_only_available_residuals;\n",
+         "    int rti_log_only_available_residuals;\n"
+         "    int batch_qp_phase;  // 0: as ever; 1: the feedback step returns in front of its QP solve; 2: it resumes behind it (lock-step batch)\n"),
     ],
     "acados/ocp_nlp/ocp_nlp_sqp_rti.c": [
+        ("    opts->rti_log_only_available_residuals = 0;\n", "    opts->rti_log_only_available_residuals = 0;\n    opts->batch_qp_phase = 0;\n"),
+        ('        else if (!strcmp(field, "as_rti_level"))\n',
+         '        else if (!strcmp(field, "batch_qp_phase"))\n        {\n            int* batch_qp_phase = (int *) value;\n'
+         '            if (*batch_qp_phase < 0 || *batch_qp_phase > 2)\n            {\n'
+         '                printf("\\nerror: ocp_nlp_sqp_rti_opts_set: invalid value for batch_qp_phase field.\\n");\n'
+         '                printf("possible values are: 0, 1, 2, got %d.\\n", *batch_qp_phase);\n                exit(1);\n            }\n'
+         '            opts->batch_qp_phase = *batch_qp_phase;\n        }\n'
+         '        else if (!strcmp(field, "as_rti_level"))\n'),
         ("    int qp_iter = 0;\n    int qp_status, globalization_status;\n\n    // update QP rhs for SQP (step prim var, abs dual var)\n",
          "    int qp_iter = 0;\n    int qp_status, globalization_status;\n\n"
-         "    // lock-step batch (nlp_opts->qp_batch_phase): phase 2 resumes behind the QP solve, everything in front of it ran in phase 1\n"
-         "    if (nlp_opts->qp_batch_phase == 2)\n    {\n        goto qp_batch_resume;\n    }\n\n"
+         "    // lock-step batch (opts->batch_qp_phase): phase 2 resumes behind the QP solve, everything in front of it ran in phase 1\n"
+         "    if (opts->batch_qp_phase == 2)\n    {\n        goto batch_qp_resume;\n    }\n\n"
          "    // update QP rhs for SQP (step prim var, abs dual var)\n"),
         ("    // solve QP\n    bool precondensed_lhs = true;\n",
-         "qp_batch_resume: ;\n    // solve QP\n    bool precondensed_lhs = true;\n"),
+         "batch_qp_resume: ;\n    // solve QP\n    bool precondensed_lhs = true;\n"),
         ("    qp_status = ocp_nlp_solve_qp_and_correct_dual(config, dims, nlp_opts, nlp_mem, nlp_work, precondensed_lhs, NULL, NULL, NULL, NULL, NULL);\n\n"
          "    qp_info *qp_info_;\n",
+         "    nlp_opts->batch_qp_phase = opts->batch_qp_phase;   // this call only: no other caller of the function ever sees it set\n"
          "    qp_status = ocp_nlp_solve_qp_and_correct_dual(config, dims, nlp_opts, nlp_mem, nlp_work, precondensed_lhs, NULL, NULL, NULL, NULL, NULL);\n"
-         "    if (nlp_opts->qp_batch_phase == 1)\n    {\n"
+         "    nlp_opts->batch_qp_phase = 0;\n"
+         "    if (opts->batch_qp_phase == 1)\n    {\n"
          "        // the QP is set up (vectors, regularisation, warm-start option): it is solved with the other capsules' QPs\n"
          "        return;\n    }\n\n"
          "    qp_info *qp_info_;\n"),
         ("    int rti_phase = opts->rti_phase;\n\n    if (rti_phase == FEEDBACK)\n",
-         "    int rti_phase = opts->rti_phase;\n\n    if (rti_phase == FEEDBACK || opts->nlp_opts->qp_batch_phase == 2)\n"),
+         "    int rti_phase = opts->rti_phase;\n\n"
+         "    if (opts->batch_qp_phase != 0 && (opts->as_rti_level != STANDARD_RTI || rti_phase == PREPARATION))\n    {\n"
+         '        printf("ocp_nlp_sqp_rti: batch_qp_phase != 0 splits the FEEDBACK step of standard RTI; it is not supported with AS-RTI or rti_phase == PREPARATION.\\n\\n");\n'
+         "        exit(1);\n    }\n\n"
+         "    if (rti_phase == FEEDBACK || opts->batch_qp_phase == 2)\n"),
     ],
     "interfaces/acados_template/acados_template/c_templates_tera/acados_solver.in.h": [
         ("ACADOS_SYMBOL_EXPORT void {{ name }}_acados_batch_solve({{ name }}_solver_capsule ** capsules, int * status_out, int N_batch, int num_threads_in_batch_solve);\n",

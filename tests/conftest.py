@@ -154,6 +154,56 @@ def check_finished_lanes_ride_along(clib, N, B, seed, alone):
     return it
 
 
+def check_polish(clib, N, B, seed, nx=8, nu=3, ratio=None):
+    """The terminal polishing step (option "polish", gpu_batch.hip polish_pass): converged instances that hold a balanced pair
+    min(lam, t) > 1e-3 max(lam, t) run one more iteration.  Asserted: status and iteration counts are the plain solve's; instances
+    that were not selected are bit-identical; the polished point passes the exit test the solve ran with (independent KKT kernel);
+    the distance to THE solution (oracle at complementarity 1e-12) of the polished instances falls by an order of magnitude in the
+    maximum and never grows beyond rounding.  Returns (distance plain, distance polished, polished mask)."""
+    import numpy as np
+    from acados_amd import OcpQpGpuBatch
+    from acados_amd.generators import fill_lqr_batch, lqr_dims, lqr_instance_qp, random_lqr_batch
+    from oracle.oracle import OracleQp, default_opts
+    data = random_lqr_batch(N=N, nx=nx, nu=nu, batch=B, seed=seed)
+    runs = []
+    for pol in (0, 1):
+        gb = OcpQpGpuBatch(lqr_dims(N, nx, nu), B, _clib=clib)
+        fill_lqr_batch(gb, data, N)
+        for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+            gb.opts_set(f, 1e-8)
+        gb.opts_set("polish", pol)
+        if ratio is not None:
+            gb.opts_set("polish_ratio", float(ratio))
+        assert gb.solve() == 0
+        assert gb.res_compute().max() <= 1e-8 * (1.0 + 1e-3) + 1e-13
+        runs.append(gb)
+    plain, pol = runs
+    assert int(plain.scalar("polished")) == 0
+    npol, nrev = int(pol.scalar("polished")), int(pol.scalar("polish_reverted"))
+    for f in ("status", "iter"):
+        assert np.array_equal(plain.info(f), pol.info(f)), f
+    xs = [[g.get("x", k) for k in range(N + 1)] for g in runs]
+    us = [[g.get("u", k) for k in range(N)] for g in runs]
+    changed = np.zeros(B, dtype=bool)
+    for k in range(N + 1):
+        changed |= np.any(xs[0][k] != xs[1][k], axis=1)
+        if k < N:
+            changed |= np.any(us[0][k] != us[1][k], axis=1)
+    assert changed.sum() <= npol - nrev and (npol == 0 or changed.sum() >= 1), (changed.sum(), npol, nrev)
+    dist = np.zeros((2, B))
+    for i in range(B):
+        o = OracleQp(lqr_instance_qp(data, i, N))
+        assert o.solve(default_opts(tol_stat=1e-9, tol_eq=1e-11, tol_ineq=1e-11, tol_comp=1e-12, iter_max=100)) == 0
+        for r in range(2):
+            for k in range(N + 1):
+                ref = o.get(k, "x")
+                dist[r, i] = max(dist[r, i], np.max(np.abs(xs[r][k][i] - ref) / np.maximum(1.0, np.abs(ref))))
+                if k < N:
+                    ref = o.get(k, "u")
+                    dist[r, i] = max(dist[r, i], np.max(np.abs(us[r][k][i] - ref) / np.maximum(1.0, np.abs(ref))))
+    return dist[0], dist[1], changed
+
+
 def check_whole_solve_in_one_launch(clib, qp_sets):
     """Small batches of the sixteen-lanes family: the whole solve in ONE launch (kx_solve: every 16-lane row runs the IPM
     loop by itself) against the launch-per-sweep loop of the same kernels (option solve_max = 0) -- statuses, iteration

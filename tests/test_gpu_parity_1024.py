@@ -62,8 +62,19 @@ def test_c2_and_c3_1024_instances_gpu(gpu_lib):
     print("C3", e)
     d = e["dist_to_solution"]
     assert e["same_tol_max"] <= 1e-6 and d["median"] <= 1e-6 and d["q99"] <= 1e-4 and d["max"] <= 1e-3, e
-    # the distance is the tolerance's: three more orders on complementarity (a user's choice for a hard-constrained class)
+    # the opt-in terminal polishing step at the plain exit: status and iteration counts unchanged, exit test still passed, the tail
+    # of the distance gone (measured: 53 of 1,024 above 1e-6 without it)
     gb.opts_set("cond_N", N)
+    it0, st0 = gb.info("iter").copy(), gb.info("status").copy()
+    gb.opts_set("polish", 1)
+    assert gb.solve() == 0 and gb.res_compute().max() <= KKT_TOL
+    assert np.array_equal(gb.info("iter"), it0) and np.array_equal(gb.info("status"), st0)
+    xp = oracle_error(gb, lambda i: lqr_instance_qp(data, i, N), idx, N, same_tol=False)
+    print("C2 with the polishing step", xp, "polished", gb.scalar("polished"), "reverted", gb.scalar("polish_reverted"))
+    assert 0 < gb.scalar("polished") < B and gb.scalar("polish_reverted") <= 0.01 * gb.scalar("polished")
+    assert xp["dist_to_solution"]["max"] <= 1e-6 and xp["dist_to_solution"]["above_1e-6"] == 0, xp
+    gb.opts_set("polish", 0)
+    # the distance is the tolerance's: three more orders on complementarity (a user's choice for a hard-constrained class)
     gb.opts_set("tol_comp", 1e-11)
     assert gb.solve() == 0
     xs = oracle_error(gb, lambda i: lqr_instance_qp(data, i, N), idx, N, same_tol=False)
@@ -82,7 +93,8 @@ def test_c4_1024_instances_gpu(gpu_lib):
     _tols(gb)
     idx = _sample(B)
     qp_of = lambda i: chain_soft_instance_qp(data, i, N)
-    # DEFAULT: the solver stops at the tol_comp it is given (the reference's semantics, ocp_qp_hpipm.c:104-107)
+    # DEFAULT: the solver stops at the tol_comp it is given (the reference's semantics, ocp_qp_hpipm.c:104-107).  NOT the leg the
+    # bench line quotes C4's rate at (bench.py other_configs: the rate is quoted where the flat 1e-6 bar below holds)
     assert gb.scalar("tol_comp_soft_scale") == 1.0 and abs(gb.scalar("tol_comp_effective") - 1e-8) < 1e-20
     assert gb.solve() == 0 and gb.kernel_name.startswith("w16r-gen<NX=24,NU=3,NG=4>")
     assert gb.info("iter").max() <= 25
@@ -95,8 +107,8 @@ def test_c4_1024_instances_gpu(gpu_lib):
     assert e1["oracle_failures"] == 0 and d1["reference_not_converged"] == 0
     assert e1["same_tol_median"] <= 1e-8 and e1["same_tol_max"] <= max(1e-6, 2.0 * d1["max"]), e1
     assert d1["median"] <= 1e-5 and d1["max"] <= 1e-3, e1
-    # OPT-IN tighter exit (tol_comp_soft_scale 1e-3: complementarity at 1e-11, both sides): within 1e-6 of the oracle and of
-    # the solution
+    # OPT-IN tighter exit (tol_comp_soft_scale 1e-3: complementarity at 1e-11, both sides) -- the leg that backs the rate quoted for
+    # C4: FLAT 1e-6 against the oracle at the same tolerance and against the solution
     gb.opts_set("tol_comp_soft_scale", 1e-3)
     assert abs(gb.scalar("tol_comp_effective") - 1e-11) < 1e-24
     assert gb.solve() == 0 and gb.res_compute().max() <= KKT_TOL
@@ -109,6 +121,13 @@ def test_c4_1024_instances_gpu(gpu_lib):
     # (one more order -- scale 1e-4, complementarity 1e-12 -- is past what FP64 carries for this class: Gamma = lam / t of the
     #  active soft rows reaches 1e16, stationarity is lost to rounding and 38 of 16,384 instances end in MAXITER: DESIGN.md 3)
     assert d1["median"] > 10 * d["median"]
+    # the opt-in terminal polishing step at the PLAIN exit (no change of what tol_comp means): what it does to the same sample
+    gb.opts_set("tol_comp_soft_scale", 1.0)
+    gb.opts_set("polish", 1)
+    assert gb.solve() == 0 and gb.res_compute().max() <= KKT_TOL
+    xp = oracle_error(gb, qp_of, idx, N, same_tol=False)
+    print("C4 plain exit + polishing step", xp, "polished", gb.scalar("polished"), "reverted", gb.scalar("polish_reverted"))
+    assert gb.scalar("polished") > 0 and xp["dist_to_solution"]["q99"] <= d1["q99"] and xp["dist_to_solution"]["median"] <= d1["median"]
 
 
 def test_c5_1024_instances_gpu(gpu_lib):

@@ -505,6 +505,20 @@ def test_finished_lanes_ride_along_hostsim(hostsim_lib, monkeypatch):
     assert it.max() - it.min() >= 2
 
 
+@pytest.mark.parametrize("fam", ["1tpi", "wpi", "w16"])
+def test_terminal_polishing_step_hostsim(hostsim_lib, monkeypatch, fam):
+    """option "polish" (opt-in): one more iteration for the converged instances that hold a weakly active row -- same status and
+    iteration counts, exit test still passed, the rest of the batch bit-identical, the tail of the distance to the solution gone"""
+    from conftest import check_polish
+    monkeypatch.setenv("ACADOS_AMD_WPI", "0" if fam == "1tpi" else "1")
+    monkeypatch.setenv("ACADOS_AMD_W16", "1" if fam == "w16" else "0")
+    # (a batch this small holds no pair above the default ratio 1e-3: the selection threshold is lowered so that it picks some)
+    d0, d1, changed = check_polish(hostsim_lib, N=8, B=48, seed=21, ratio=3e-6)
+    assert changed.sum() >= 2
+    # (the reference itself is ~1e-9 from the exact solution: below 2e-8 a distance says nothing)
+    assert d1[changed].max() <= 0.1 * d0[changed].max() and np.all(d1 <= np.maximum(d0 * 1.01, 2e-8)), (d0[changed], d1[changed])
+
+
 def test_whole_solve_in_one_launch_hostsim(hostsim_lib, monkeypatch):
     """kx_solve against the launch-per-sweep loop, bit for bit: random structures without general rows (hard and soft box
     rows, per-stage dims), ragged batches of 1, 5 and 6 instances (a single row, one full workgroup + 1 / + 2)"""

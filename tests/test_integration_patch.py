@@ -16,7 +16,7 @@ FILES = ["interfaces/acados_c/ocp_qp_interface.h", "interfaces/acados_c/ocp_qp_i
          "interfaces/acados_template/acados_template/acados_ocp_options.py",
          "interfaces/acados_template/acados_template/c_templates_tera/CMakeLists.in.txt",
          "interfaces/acados_template/acados_template/c_templates_tera/Makefile.in",
-         "acados/ocp_qp/ocp_qp_xcond_solver.c", "acados/ocp_nlp/ocp_nlp_common.h", "acados/ocp_nlp/ocp_nlp_common.c", "acados/ocp_nlp/ocp_nlp_sqp_rti.c",
+         "acados/ocp_qp/ocp_qp_xcond_solver.c", "acados/ocp_nlp/ocp_nlp_common.h", "acados/ocp_nlp/ocp_nlp_common.c", "acados/ocp_nlp/ocp_nlp_sqp_rti.h", "acados/ocp_nlp/ocp_nlp_sqp_rti.c",
          "interfaces/acados_template/acados_template/c_templates_tera/acados_solver.in.h",
          "interfaces/acados_template/acados_template/c_templates_tera/acados_solver.in.c"]
 PLUGIN_FILES = ["ocp_qp_gpu_ipm.c", "ocp_qp_gpu_pcond.c", "ocp_qp_gpu_segments.h"]
@@ -69,14 +69,21 @@ def test_patched_registration_compiles_against_reference_headers(tmp_path):
                            capture_output=True, text=True)
         assert r.returncode == 0, (f, r.stderr)
     # the reference's files the lock-step batch touches compile with and without the define: the outer solver's terminate (releases
-    # the condensing module's device batch), ocp_nlp_common.c (qp_batch_phase: return in front of / resume behind the QP solve) and
+    # the condensing module's device batch), ocp_nlp_common.c (batch_qp_phase: return in front of / resume behind the QP solve) and
     # ocp_nlp_sqp_rti.c (the feedback step split at the QP solve)
     for f in ("acados/ocp_qp/ocp_qp_xcond_solver.c", "acados/ocp_nlp/ocp_nlp_common.c", "acados/ocp_nlp/ocp_nlp_sqp_rti.c"):
         for cmd in (base, [a for a in base if a != "-DACADOS_WITH_GPU_IPM"]):
             r = subprocess.run(cmd + [str(root / f)], capture_output=True, text=True)
             assert r.returncode == 0, (f, r.stderr)
     rti = open(root / "acados" / "ocp_nlp" / "ocp_nlp_sqp_rti.c").read()
-    assert rti.count("qp_batch_phase") == 4 and "qp_batch_resume: ;" in rti
+    assert "batch_qp_resume: ;" in rti and "qp_batch_phase" not in rti
+    # the option string has no `qp_` prefix (ocp_nlp_opts_set hands every `qp_*` string to the QP solver, which exits on an unknown field:
+    # ocp_nlp_common.c:1337-1349) and lives in SQP_RTI's own opts; the field of ocp_nlp_opts is set around the feedback step's call only
+    assert '!strcmp(field, "batch_qp_phase")' in rti and "nlp_opts->batch_qp_phase = opts->batch_qp_phase;" in rti and "nlp_opts->batch_qp_phase = 0;" in rti
+    common = open(root / "acados" / "ocp_nlp" / "ocp_nlp_common.c").read()
+    assert '"batch_qp_phase"' not in common and common.count("nlp_opts->batch_qp_phase") == 3
+    tpl = open(root / "interfaces/acados_template/acados_template/c_templates_tera/acados_solver.in.c").read()
+    assert tpl.count('"batch_qp_phase"') == 3 and '"qp_batch_phase"' not in tpl
 
 
 def test_generated_lock_step_batch_call_compiles(tmp_path):
