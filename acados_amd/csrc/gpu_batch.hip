@@ -155,6 +155,7 @@ struct ocp_qp_gpu_batch
     /* terminal polishing step (option "polish", opt-in: polish_pass below) */
     int polish = 0;
     double polish_ratio = 1e-3;
+    double polish_min = 0.0; /* ... and min(lam, t) above this (absolute): a pair whose smaller member is already below the accuracy wanted cannot move the point by more */
     int n_polished = 0, n_polish_reverted = 0;
     int *d_pol_status = nullptr, *d_pol_iter = nullptr, *d_pol_flag = nullptr, *d_pol_cnt = nullptr;
     double *d_pol_sc = nullptr;
@@ -166,6 +167,8 @@ struct ocp_qp_gpu_batch
     double *d_stage = nullptr; /* staging for host->device field blocks */
     double *d_chunks = nullptr; /* the input blob handed over in pieces (_set_bulk_chunk): its own buffer -- d_stage is reused by */
     size_t chunks_cap = 0;      /* every other transfer (a hot start's _set_bulk_out comes between the chunks and the scatter) */
+    long chunks_got = 0;        /* instances handed over since the last _set_bulk_staged (it refuses to scatter a partial blob) */
+    hipEvent_t chunks_ev = nullptr; /* recorded in front of the first chunk of a round: time_pack covers copies + scatter as _set_bulk's does */
     size_t stage_cap = 0;
     int *d_map = nullptr;
     int map_cap = 0;
@@ -954,6 +957,7 @@ try
     (void) hipHostFree(b->h_ints);
     (void) hipEventDestroy(b->ev0);
     (void) hipEventDestroy(b->ev1);
+    if (b->chunks_ev) (void) hipEventDestroy(b->chunks_ev);
     for (hipEvent_t e : b->prof_ev) (void) hipEventDestroy(e);
     (void) hipStreamDestroy(b->stream);
     if (b->child) ocp_qp_gpu_batch_destroy(b->child);
@@ -1072,8 +1076,9 @@ try
     else if (!strcmp(f, "alpha_min")) o.alpha_min = *d;
     else if (!strcmp(f, "tau_min")) o.tau_min = *d;
     else if (!strcmp(f, "tol_comp_soft_scale")) b->tol_comp_soft_scale = *d;
-    else if (!strcmp(f, "polish")) b->polish = *i != 0;
+    else if (!strcmp(f, "polish")) b->polish = *i < 0 ? 0 : (*i > 8 ? 8 : *i);
     else if (!strcmp(f, "polish_ratio")) b->polish_ratio = *d;
+    else if (!strcmp(f, "polish_min")) b->polish_min = *d;
     else if (!strcmp(f, "reg_prim")) o.reg_prim = *d;
     else if (!strcmp(f, "cond_pred_corr")) o.cond_pred_corr = *i;
     else if (!strcmp(f, "print_level")) b->print_level = *i;
@@ -1377,7 +1382,7 @@ static int pcond_solve(ocp_qp_gpu_batch *b, int mode = 3)
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1)); HIPCHK(hipEventCreate(&e2)); HIPCHK(hipEventCreate(&e3));
     c->O = b->O;
     c->tol_comp_soft_scale = b->tol_comp_soft_scale;
-    c->polish = b->polish; c->polish_ratio = b->polish_ratio;
+    c->polish = b->polish; c->polish_ratio = b->polish_ratio; c->polish_min = b->polish_min;
     c->print_level = b->print_level;
     HIPCHK(hipEventRecord(e0, b->stream));
     pcond_launch(b, false);
@@ -1649,7 +1654,7 @@ static void polish_pass(ocp_qp_gpu_batch *b, Prof &prof, hipStream_t s)
     }
     const dim3 g64((b->B + 63) / 64), blk(64);
     HIPCHK(hipMemsetAsync(b->d_pol_cnt, 0, 2 * sizeof(int), s));
-    hipLaunchKernelGGL(gqp::k_polish_select, g64, blk, 0, s, D, side_map(b), b->nct_tot, b->polish_ratio, b->d_pol_status, b->d_pol_iter, b->d_pol_sc,
+    hipLaunchKernelGGL(gqp::k_polish_select, g64, blk, 0, s, D, side_map(b), b->nct_tot, b->polish_ratio, b->polish_min, b->d_pol_status, b->d_pol_iter, b->d_pol_sc,
                        b->d_pol_cnt);
     HIPCHK(hipMemcpyAsync(b->h_nact, b->d_pol_cnt, sizeof(int), hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
@@ -1666,7 +1671,7 @@ static void polish_pass(ocp_qp_gpu_batch *b, Prof &prof, hipStream_t s)
     const GqpOpts keep = b->O;
     const int keep_stat = D.stat_inst;
     b->O.tol_stat = b->O.tol_eq = b->O.tol_ineq = b->O.tol_comp = -1.0; /* the loop's exit test cannot pass: it ends at iter_max */
-    b->O.iter_max = 1;
+    b->O.iter_max = b->polish; /* option value = iterations of the pass (1 unless asked otherwise) */
     const GqpOpts Oeff = effective_opts(keep, b);
     b->O.tau_min = Oeff.tau_min; /* the barrier floor of the solve (derived from ITS tol_comp) */
     D.stat_inst = 0;             /* the statistics table keeps the solve's rows */
@@ -1809,6 +1814,7 @@ try
     }
     HIPCHK(hipMemsetAsync(D.apend, 0, sizeof(double) * (size_t) b->Bp, s)); /* no step pending (a solve always ends behind a factor sweep; belt and braces) */
     run_ipm(b, b, prof, s, 0);
+    b->n_polished = b->n_polish_reverted = 0;
     if (b->polish) polish_pass(b, prof, s);
     b->factor_stale = b->n_tail_switches + b->n_compactions > 0;
     b->sens_open = false;
@@ -2530,9 +2536,16 @@ try
     if (cnt > b->chunks_cap)
     {
         HIPCHK(hipStreamSynchronize(b->stream)); /* (only ever on the first chunk of a batch: nothing of it is in flight yet) */
-        b->chunks_cap = cnt * 2;
+        b->chunks_cap = cnt; /* B * len is fixed for a batch: exactly that */
         b->d_chunks = dalloc<double>(b, b->chunks_cap);
+        b->chunks_got = 0;
     }
+    if (b->chunks_got == 0)
+    {
+        if (!b->chunks_ev) HIPCHK(hipEventCreate(&b->chunks_ev));
+        HIPCHK(hipEventRecord(b->chunks_ev, b->stream));
+    }
+    b->chunks_got += count;
     if (count)
         HIPCHK(hipMemcpyAsync(b->d_chunks + (size_t) first * len, blob_chunk, sizeof(double) * (size_t) count * len, hipMemcpyHostToDevice, b->stream));
     return 0;
@@ -2545,12 +2558,25 @@ try
     const int len = gqp_bulk_len_impl(b, 0);
     auto &M = b->bulk_in;
     if ((size_t) b->B * len > b->chunks_cap) return -1; /* no chunk was ever handed over */
+    /* every instance must have arrived in THIS round: a missing range would scatter the previous call's data for those instances
+     * (ranges are the caller's to keep disjoint: the count is what can be checked here) */
+    const long got = b->chunks_got;
+    b->chunks_got = 0;
+    if (got != (long) b->B)
+    {
+        fprintf(stderr, "acados_amd: ocp_qp_gpu_batch_set_bulk_staged: %ld of %d instances were handed over since the last scatter\n", got, b->B);
+        return -1;
+    }
     const dim3 grid((b->B + 63) / 64, (len + 255) / 256), block(64);
     hipLaunchKernelGGL(gqp::k_bulk_scatter, grid, block, 0, b->stream, (const double *) b->d_chunks, b->B, len, M.d_arr, M.d_elem, M.T);
     if (M.nm)
         hipLaunchKernelGGL(gqp::k_bulk_masks, dim3((b->B + 63) / 64), block, 0, b->stream, (const double *) b->d_chunks, b->B, len, M.d_moff,
                            M.d_mstage, M.d_mbit, M.nm, b->D.amask, b->AW);
+    HIPCHK(hipEventRecord(b->ev1, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, b->chunks_ev, b->ev1));
+    b->time_pack += ms * 1e-3;
     return 0;
 }
 catch (const gqp_hip_failure &) { return -1; }

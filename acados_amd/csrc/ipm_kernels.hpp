@@ -1429,7 +1429,7 @@ static __global__ void k_status_restore(GqpDev D, const int *saved_status)
  * iteration of the sweeps (iteration counter 0 against iter_max 1, exit tolerances that cannot be met); k_polish_restore puts
  * (status, iter) back where the solve left them and flags the instances whose polished point no longer passes the exit test the
  * solve was run with -- k_polish_revert copies their iterate back from the copy taken before the step. */
-static __global__ void k_polish_select(GqpDev D, const int *side_map, int n_sides, double ratio, int *saved_status, int *saved_iter, double *saved_sc,
+static __global__ void k_polish_select(GqpDev D, const int *side_map, int n_sides, double ratio, double vmin, int *saved_status, int *saved_iter, double *saved_sc,
                                        int *count)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1450,7 +1450,7 @@ static __global__ void k_polish_select(GqpDev D, const int *side_map, int n_side
         if (!((GATL(D.amask, k * D.AW + (bit >> 6)) >> (bit & 63)) & 1)) continue;
         const double l = GATL(D.lam, e), t = GATL(D.t, e);
         const double lo = l < t ? l : t, hi = l < t ? t : l;
-        weak = lo > ratio * hi;
+        weak = lo > ratio * hi && lo > vmin;
     }
     if (!weak) return;
     D.status[i] = GQP_RUNNING;

@@ -189,11 +189,13 @@ static void pc_compute_dims(ocp_qp_gpu_pcond_dims *dims, const ocp_qp_gpu_pcond_
         exit(1);
     }
     /* x0 equality rows as counted by nbxe (the dims depend on counts only); default index sets otherwise */
-    int *ie = (int *) calloc((size_t) N + 64, sizeof(int));
+    int ie_cap = 1;
+    for (int k = 0; k <= N; k++) if (d->nbxe[k] > ie_cap) ie_cap = d->nbxe[k];
+    int *ie = (int *) calloc((size_t) ie_cap, sizeof(int));
     for (int k = 0; k <= N; k++)
         if (d->nbxe[k] > 0)
         {
-            int cnt = d->nbxe[k] < N + 64 ? d->nbxe[k] : N + 64;
+            const int cnt = d->nbxe[k];
             for (int r = 0; r < cnt; r++) ie[r] = d->nbu[k] + r;
             ocp_qp_gpu_batch_set_int(probe, "idxe", k, ie, cnt);
         }
@@ -575,6 +577,16 @@ static int pc_condense_qp_out(void *qp_in_, void *xin_, void *qp_out_, void *xou
     return ACADOS_SUCCESS;
 }
 
+/* the parent batch's vector fields back to the QP's own (they hold the seeds between the two seed slots) */
+static int pc_restore_qp_vectors(ocp_qp_gpu_pcond_memory *mem)
+{
+    mem->seeds_resident = 0;
+    if (!mem->par.batch || !mem->ptr_qp_in) return -1;
+    memset(mem->blob, 0, sizeof(double) * (size_t) mem->par.L_in);
+    unpack_qp_in(&mem->par, mem->ptr_qp_in, mem->blob);
+    return ocp_qp_gpu_batch_set_bulk(mem->par.batch, mem->blob, 0);
+}
+
 static int pc_expand_any(void *xout_, void *qp_out_, void *mem_, int seeds)
 {
     ocp_qp_out *xo = (ocp_qp_out *) xout_, *out = (ocp_qp_out *) qp_out_;
@@ -585,7 +597,13 @@ static int pc_expand_any(void *xout_, void *qp_out_, void *mem_, int seeds)
     else
     {
         ocp_qp_gpu_batch *b = mem->par.batch, *c = b ? ocp_qp_gpu_batch_condensed(b) : NULL;
-        if (!c || pc_child_layout(mem, c) != 0) return ACADOS_QP_FAILURE;
+        /* a plain expansion while the seeds of an unfinished seed pair are still resident runs on the QP's own vectors */
+        if (!seeds && mem->seeds_resident && pc_restore_qp_vectors(mem) != 0) return ACADOS_QP_FAILURE;
+        if (!c || pc_child_layout(mem, c) != 0)
+        {
+            if (mem->seeds_resident) pc_restore_qp_vectors(mem);
+            return ACADOS_QP_FAILURE;
+        }
         /* seeds: the expansion kernel runs on the QP whose VECTORS are the seeds -- what pc_condense_rhs_seed left on the device */
         if (seeds && (!mem->ptr_qp_in || !mem->ptr_seed || !mem->seeds_resident))
         {
@@ -596,14 +614,7 @@ static int pc_expand_any(void *xout_, void *qp_out_, void *mem_, int seeds)
         if (ocp_qp_gpu_batch_set_bulk_out(c, mem->blob, 0) != 0 || ocp_qp_gpu_batch_expand(b) != 0
             || ocp_qp_gpu_batch_get_bulk(b, mem->blob, 0) != 0) rc = ACADOS_QP_FAILURE;
         else pack_qp_out(&mem->par, mem->blob, out);
-        if (seeds)
-        {
-            /* the QP's own vectors back */
-            memset(mem->blob, 0, sizeof(double) * (size_t) mem->par.L_in);
-            unpack_qp_in(&mem->par, mem->ptr_qp_in, mem->blob);
-            if (ocp_qp_gpu_batch_set_bulk(b, mem->blob, 0) != 0) rc = ACADOS_QP_FAILURE;
-            mem->seeds_resident = 0;
-        }
+        if (seeds && pc_restore_qp_vectors(mem) != 0) rc = ACADOS_QP_FAILURE; /* the QP's own vectors back */
     }
     if (!seeds && out->misc) ((qp_info *) out->misc)->t_computed = 1; /* t comes from the expansion kernel, every row */
     mem->time_qp_xcond += pc_now_s() - t0;
@@ -630,6 +641,15 @@ static int pc_condense_rhs_seed(void *qp_in_, void *seed_, void *xseed_, void *o
     mem->ptr_qp_in = qp_in;
     mem->ptr_seed = seed;
     if (!mem->dims->condensed) { pc_copy_seed(seed, xs); mem->time_qp_xcond += pc_now_s() - t0; return ACADOS_SUCCESS; }
+    /* seed_m (a seed on the complementarity rhs) has no counterpart in the vector condensing: acados leaves it zero
+     * (d_ocp_qp_seed_set_zero, then seed_g / seed_b / seed_d: ocp_nlp_common.c:4057-4081); anything else is refused, not dropped */
+    for (int k = 0; k <= qp_in->dim->N; k++)
+        for (int i = 0; i < 2 * (qp_in->dim->nb[k] + qp_in->dim->ng[k] + qp_in->dim->ns[k]); i++)
+            if (BLASFEO_DVECEL(seed->seed_m + k, i) != 0.0)
+            {
+                printf("\nerror: ocp_qp_gpu_pcond: condense_rhs_seed with a non-zero seed_m (stage %d) is not supported\n", k);
+                return ACADOS_QP_FAILURE;
+            }
     /* a SHELL of qp_in whose vector members are the seed's: seed_g = [r; q; zl; zu] is laid out like rqz, seed_b like b, seed_d
      * like d (upper halves negated, ocp_nlp_common.c:4078-4081) -- the segment tables of the input blob read them as they are;
      * matrices, masks and index sets stay qp_in's */
@@ -637,7 +657,12 @@ static int pc_condense_rhs_seed(void *qp_in_, void *seed_, void *xseed_, void *o
     shell.b = seed->seed_b; shell.rqz = seed->seed_g; shell.d = seed->seed_d;
     ocp_qp_gpu_batch *b = pc_load(mem, opts, &shell);
     ocp_qp_gpu_batch *c = b ? ocp_qp_gpu_batch_condense(b) : NULL;
-    if (!c || pc_child_layout(mem, c) != 0 || ocp_qp_gpu_batch_get_bulk_in(c, mem->blob, 0) != 0) return ACADOS_QP_FAILURE;
+    if (!c || pc_child_layout(mem, c) != 0 || ocp_qp_gpu_batch_get_bulk_in(c, mem->blob, 0) != 0)
+    {
+        /* pc_load has replaced the parent batch's vectors with the seeds: a later expansion must not run on them */
+        if (b) pc_restore_qp_vectors(mem);
+        return ACADOS_QP_FAILURE;
+    }
     mem->seeds_resident = 1; /* until expand_sol_seed has run (it restores the QP's own vectors) */
     /* the condensed QP's vector fields ARE the condensed seeds: [r q zl zu] -> seed_g, b -> seed_b, bounds -> seed_d (upper
      * halves negated like d, ocp_nlp_common.c:4078-4081) */

@@ -960,7 +960,7 @@ int oqp_solve(oqp *qp, const oqp_opts *o)
                     for (int i = 0; i < s->nct; i++)
                         if (s->act[i]) mu_pc += (s->lam[i] + alpha * s->dlam[i]) * (s->t[i] + alpha * s->dt[i]);
                 }
-                mu_pc /= qp->n_act;
+                if (qp->n_act > 0) mu_pc /= qp->n_act; /* (as the device kernels guard it; this block only runs with n_act > 0) */
             }
             if (o->cond_pred_corr && mu_pc > 2.0 * mu)
             {

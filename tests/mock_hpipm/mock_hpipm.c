@@ -17,12 +17,12 @@
 static char *al64(char *p) { return (char *) (((uintptr_t) p + 63) & ~(uintptr_t) 63); }
 
 /* ------------------------------------------------------------------ BLASFEO */
+/* symmetric in (m, n) and zero-friendly like BLASFEO's own (pm * cn + a diagonal's worth): the reference sizes some blocks as (a, b) and
+ * creates them as (b, a) with one of the two zero (ocp_nlp_cost_ls.c:174 / 212, Vz) */
 hpipm_size_t blasfeo_memsize_dmat(int m, int n)
 {
-    const int pm = (m + MOCK_PS - 1) / MOCK_PS * MOCK_PS;
-    int cn = (n + MOCK_PS - 1) / MOCK_PS * MOCK_PS;
-    if (cn == 0) cn = MOCK_PS;
-    return sizeof(double) * (size_t) (pm * cn + cn + MOCK_PS);
+    const int pm = (m + MOCK_PS - 1) / MOCK_PS * MOCK_PS, cn = (n + MOCK_PS - 1) / MOCK_PS * MOCK_PS;
+    return sizeof(double) * (size_t) (pm * cn + pm + cn + MOCK_PS);
 }
 hpipm_size_t blasfeo_memsize_dvec(int m) { return sizeof(double) * (size_t) ((m + MOCK_PS - 1) / MOCK_PS * MOCK_PS + MOCK_PS); }
 void blasfeo_create_dmat(int m, int n, struct blasfeo_dmat *sA, void *mem)
@@ -30,7 +30,6 @@ void blasfeo_create_dmat(int m, int n, struct blasfeo_dmat *sA, void *mem)
     sA->m = m; sA->n = n;
     sA->pm = (m + MOCK_PS - 1) / MOCK_PS * MOCK_PS;
     sA->cn = (n + MOCK_PS - 1) / MOCK_PS * MOCK_PS;
-    if (sA->cn == 0) sA->cn = MOCK_PS;
     sA->memsize = (int) blasfeo_memsize_dmat(m, n);
     sA->mem = (double *) mem; sA->pA = sA->mem; sA->dA = sA->pA + sA->pm * sA->cn; sA->use_dA = 0;
 }
