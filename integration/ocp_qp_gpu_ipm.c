@@ -113,6 +113,7 @@ typedef struct ocp_qp_gpu_ipm_memory_
     int rv_index;                /* slot of this memory's capsule in its rendezvous (-1: none yet) */
     int *sig_scratch;
     double time_qp_solver_call;
+    double time_unpack_in, time_pack_out; /* extension: host time spent reading qp_in into / writing qp_out from the staging blobs */
     int iter, status;
     /* per-iteration statistics of this memory's QP, HPIPM-shaped (ocp_qp_hpipm.c:255-297 "stat" / "stat_m": what
      * ocp_qp_solver_get_stats and the Python getter read): stat_m columns x (iter + 1) rows, carved, filled on demand from the device
@@ -287,6 +288,8 @@ static void gpu_memory_get(void *config, void *mem_, const char *field, void *va
 {
     ocp_qp_gpu_ipm_memory *m = (ocp_qp_gpu_ipm_memory *) mem_;
     if (!strcmp(field, "time_qp_solver_call")) *(double *) value = m->time_qp_solver_call;
+    else if (!strcmp(field, "time_unpack_in")) *(double *) value = m->time_unpack_in;
+    else if (!strcmp(field, "time_pack_out")) *(double *) value = m->time_pack_out;
     else if (!strcmp(field, "iter")) *(int *) value = m->iter;
     else if (!strcmp(field, "status")) *(int *) value = m->status;
     else if (!strcmp(field, "kernel_name")) /* extension: which kernel family serves this memory's QP (const char *) */
@@ -706,6 +709,7 @@ static int evaluate_batch_masked(void *config, int n, void **qp_in_, void **qp_o
         if (mem_group(mi) && mi->group != g && mi->group->owner == mi) group_release(mi->group); /* it led another batch before */
         mi->group = g; mi->group_gen = g->gen; mi->g_bucket = g->bucket_of[i]; mi->g_pos = g->pos_of[i];
         mi->iter = it; mi->status = st; mi->time_qp_solver_call = t_solved - t_packed;
+        mi->time_unpack_in = t_packed - t_start; mi->time_pack_out = t_end - t_solved;
         if (st != ACADOS_SUCCESS && (worst == 0 || worst == ACADOS_MAXITER)) worst = st;
     }
     return worst;

@@ -19,6 +19,7 @@
 #include "acados/ocp_qp/ocp_qp_common.h"
 #include "acados/utils/types.h"
 #include "blasfeo/include/blasfeo_d_aux.h"
+#include "blasfeo/include/blasfeo_d_aux_ext_dep.h"
 
 #include "acados_amd/ocp_qp_gpu_batch.h"
 
@@ -54,8 +55,86 @@ typedef struct
     ocp_qp_gpu_batch *batch; \
     gpu_seg *seg_in, *seg_out, *seg_seed; \
     int n_in, n_out, n_seed, seg_cap_in, seg_cap_out, seg_cap_seed; \
-    int L_in, L_out, L_seed; /* doubles per instance of the three blobs */
+    int L_in, L_out, L_seed; /* doubles per instance of the three blobs */ \
+    int ps;                  /* panel height of BLASFEO's matrix storage as PROBED (gpu_probe_panel_size); 0: every block through blasfeo_unpack_* */
 typedef struct { GPU_LAYOUT_MEMBERS } gpu_layout;
+
+/* ------------------------------------------------------------------ BLASFEO's storage, probed
+ *
+ * blasfeo_unpack_dmat / _tran_dmat are library calls per sub-block: ~20 of them per stage, 1,000 per C2-shaped QP, each a few dozen
+ * doubles -- the call and its per-element index arithmetic, not the bytes, were the cost of reading n capsules' QPs (0.9 GB/s per host
+ * thread, profiles/r05_orchestration_latency.txt).  The batch entries copy panel runs instead: element (i, j) of a panel-major matrix
+ * lives at pA[(i - i % ps) * cn + j * ps + i % ps], so a column of a sub-block is <= ceil(m / ps) + 1 contiguous runs and a row is one
+ * strided walk.  Nothing of BLASFEO's internals is ASSUMED: the panel height is found by packing a test matrix through the library's
+ * own blasfeo_pack_dmat and looking where the values went, and a vector through blasfeo_pack_dvec; any other layout (column-major
+ * builds, a panel height that is not found) returns 0 and every block keeps going through blasfeo_unpack_* (ACADOS_AMD_LA_API=1
+ * forces that path: the byte-for-byte cross-check of tests/test_mock_acados.py).
+ */
+GPU_SEG_FN int gpu_probe_panel_size(void)
+{
+#if defined(MF_COLMAJ)
+    return 0;
+#else
+    enum { PM = 37, PN = 3 };
+    if (getenv("ACADOS_AMD_LA_API")) return 0;
+    struct blasfeo_dmat sA;
+    struct blasfeo_dvec sv;
+    double a[PM * PN];
+    for (int j = 0; j < PN; j++) for (int i = 0; i < PM; i++) a[i + PM * j] = 1.0 + i + 100.0 * j;
+    blasfeo_allocate_dmat(PM, PN, &sA);
+    blasfeo_allocate_dvec(PM, &sv);
+    blasfeo_pack_dmat(PM, PN, a, PM, &sA, 0, 0);
+    blasfeo_pack_dvec(PM, a, 1, &sv, 0);
+    int found = 0;
+    for (int ps = 2; ps <= 16 && !found; ps *= 2)
+    {
+        int ok = sA.pm % ps == 0 && sA.cn >= PN;
+        for (int j = 0; j < PN && ok; j++)
+            for (int i = 0; i < PM && ok; i++)
+            {
+                const long idx = (long) (i - i % ps) * sA.cn + (long) j * ps + i % ps;
+                ok = idx < (long) sA.pm * sA.cn && sA.pA[idx] == a[i + PM * j];
+            }
+        if (ok) found = ps;
+    }
+    for (int i = 0; i < PM && found; i++) if (sv.pa[i] != a[i]) found = 0; /* vectors: one contiguous array */
+    blasfeo_free_dmat(&sA);
+    blasfeo_free_dvec(&sv);
+    return found;
+#endif
+}
+
+#if !defined(MF_COLMAJ)
+/* sub-block (ai, aj), m x n -> column-major dst (ld m) */
+GPU_SEG_FN void pm_unpack(int ps, int m, int n, const struct blasfeo_dmat *sA, int ai, int aj, double *dst)
+{
+    const int cn = sA->cn;
+    for (int j = 0; j < n; j++)
+    {
+        int r = ai, left = m;
+        double *d = dst + (size_t) m * j;
+        while (left > 0)
+        {
+            const int in = r % ps, run = ps - in < left ? ps - in : left;
+            const double *src = sA->pA + (size_t) (r - in) * cn + (size_t) (aj + j) * ps + in;
+            for (int e = 0; e < run; e++) d[e] = src[e];
+            d += run; r += run; left -= run;
+        }
+    }
+}
+/* ... -> its transpose, n x m column-major (ld n): dst[j + n * i] = A(ai + i, aj + j) */
+GPU_SEG_FN void pm_unpack_tran(int ps, int m, int n, const struct blasfeo_dmat *sA, int ai, int aj, double *dst)
+{
+    const int cn = sA->cn;
+    for (int i = 0; i < m; i++)
+    {
+        const int r = ai + i, in = r % ps;
+        const double *src = sA->pA + (size_t) (r - in) * cn + (size_t) aj * ps + in;
+        double *d = dst + (size_t) n * i;
+        for (int j = 0; j < n; j++) d[j] = src[(size_t) j * ps];
+    }
+}
+#endif
 
 /* ------------------------------------------------------------------ sizes from dims */
 
@@ -134,6 +213,7 @@ GPU_SEG_FN int gpu_layout_build(gpu_layout *bk, const ocp_qp_dims *d)
     ocp_qp_gpu_batch *b = bk->batch;
     const int N = d->N;
     bk->n_in = bk->n_out = bk->n_seed = 0;
+    bk->ps = gpu_probe_panel_size();
     /* the first device work after create (structure tables, out of HBM shows up here): negative = the device failed */
     bk->L_in = ocp_qp_gpu_batch_bulk_len(b, 0);
     bk->L_out = ocp_qp_gpu_batch_bulk_len(b, 1);
@@ -222,8 +302,27 @@ GPU_SEG_FN int gpu_layout_build(gpu_layout *bk, const ocp_qp_dims *d)
 
 /* ------------------------------------------------------------------ blob <-> acados structs, one instance */
 
-GPU_SEG_FN void unpack_segs(const gpu_seg *tab, int cnt, double *blob, struct blasfeo_dmat *const *mats, struct blasfeo_dvec *const *vecs)
+GPU_SEG_FN void unpack_segs(const gpu_seg *tab, int cnt, double *blob, struct blasfeo_dmat *const *mats, struct blasfeo_dvec *const *vecs, int ps)
 {
+#if !defined(MF_COLMAJ)
+    if (ps > 0) /* probed panel-major storage: panel runs instead of a library call per sub-block */
+    {
+        for (int s = 0; s < cnt; s++)
+        {
+            const gpu_seg *g = tab + s;
+            double *p = blob + g->off;
+            if (g->kind == SEG_VEC)
+            {
+                const double *v = (vecs[g->src] + g->k)->pa + g->ai;
+                if (g->neg) for (int e = 0; e < g->len; e++) p[e] = -v[e];
+                else for (int e = 0; e < g->len; e++) p[e] = v[e];
+            }
+            else if (g->kind == SEG_MAT) pm_unpack(ps, g->m, g->n, mats[g->src] + g->k, g->ai, g->aj, p);
+            else pm_unpack_tran(ps, g->m, g->n, mats[g->src] + g->k, g->ai, g->aj, p);
+        }
+        return;
+    }
+#endif
     for (int s = 0; s < cnt; s++)
     {
         const gpu_seg *g = tab + s;
@@ -243,13 +342,13 @@ GPU_SEG_FN void unpack_qp_in(const gpu_layout *bk, ocp_qp_in *in, double *blob)
 {
     struct blasfeo_dmat *mats[3] = {in->BAbt, in->RSQrq, in->DCt};
     struct blasfeo_dvec *vecs[8] = {NULL, NULL, NULL, in->b, in->rqz, in->d, in->d_mask, in->Z};
-    unpack_segs(bk->seg_in, bk->n_in, blob, mats, vecs);
+    unpack_segs(bk->seg_in, bk->n_in, blob, mats, vecs, bk->ps);
 }
 
 GPU_SEG_FN void unpack_seed(const gpu_layout *bk, ocp_qp_seed *seed, double *blob)
 {
     struct blasfeo_dvec *vecs[15] = {NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, NULL, seed->seed_g, seed->seed_b, seed->seed_d};
-    unpack_segs(bk->seg_seed, bk->n_seed, blob, NULL, vecs);
+    unpack_segs(bk->seg_seed, bk->n_seed, blob, NULL, vecs, bk->ps);
 }
 
 /* hot start: pi, lam, t of qp_out; the primal part stays zero as ocp_qp_hpipm.c:325-336 leaves it before every solve */
@@ -270,7 +369,8 @@ GPU_SEG_FN void pack_qp_out(const gpu_layout *bk, const double *blob, ocp_qp_out
     for (int s = 0; s < bk->n_out; s++)
     {
         const gpu_seg *g = bk->seg_out + s;
-        blasfeo_pack_dvec(g->m, (double *) blob + g->off, 1, vecs[g->src] + g->k, g->ai);
+        if (bk->ps > 0) memcpy((vecs[g->src] + g->k)->pa + g->ai, blob + g->off, sizeof(double) * (size_t) g->m); /* probed: one contiguous array */
+        else blasfeo_pack_dvec(g->m, (double *) blob + g->off, 1, vecs[g->src] + g->k, g->ai);
     }
 }
 

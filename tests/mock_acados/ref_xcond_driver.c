@@ -25,6 +25,7 @@
  */
 #include <math.h>
 #include <time.h>
+#include <omp.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -215,10 +216,20 @@ static int run_batch(int argc, char **argv)
             for (int q = 0; q < 4; q++) res_max = fmax(res_max, nrm[q]);
         }
     }
+    /* where the last call's time went (extension fields of the adapter's memory_get; qp_info.solve_QP_time = the device's own event time) */
+    double t_unpack = 0.0, t_pack = 0.0, t_call = 0.0;
+    {
+        void *sm = ((ocp_qp_xcond_solver_memory *) mems[0])->solver_memory;
+        config->qp_solver->memory_get(config->qp_solver, sm, "time_unpack_in", &t_unpack);
+        config->qp_solver->memory_get(config->qp_solver, sm, "time_pack_out", &t_pack);
+        config->qp_solver->memory_get(config->qp_solver, sm, "time_qp_solver_call", &t_call);
+    }
+    const double t_dev = ((qp_info *) outs[0]->misc)->solve_QP_time;
     int cond_active = -1; /* stages of the QP the device IPM ran on in the batch call: the condensed one */
     config->qp_solver->memory_get(config->qp_solver, ((ocp_qp_xcond_solver_memory *) mems[0])->solver_memory, "cond_N_active", &cond_active);
-    printf("batch n %d ms_per_call %.6f status %d fused_vs_orchestrated %.17g orchestrated_status %d xcond_N %d xcond_nu0 %d cond_N_active %d res_max %.17g end\n", n,
-           best * 1e3, status, fvo, st_one, xd->N, xd->nu[0], cond_active, res_max);
+    printf("batch n %d ms_per_call %.6f status %d fused_vs_orchestrated %.17g orchestrated_status %d xcond_N %d xcond_nu0 %d cond_N_active %d res_max %.17g "
+           "unpack_in_ms %.4f copy_and_device_ms %.4f device_solve_ms %.4f pack_out_ms %.4f threads %d end\n", n,
+           best * 1e3, status, fvo, st_one, xd->N, xd->nu[0], cond_active, res_max, t_unpack * 1e3, t_call * 1e3, t_dev * 1e3, t_pack * 1e3, omp_get_max_threads());
     FILE *g = fopen(argv[4], "wb");
     for (int i = 0; i < n; i++)
     {

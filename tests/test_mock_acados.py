@@ -352,6 +352,10 @@ def test_acados_adapter_batch_chunked_staging(clib, tmp_path):
     info0, per0, _, raw0 = _run_batch(exe, tmp_path, n, [fa, fb], sens=False, extra_env={"ACADOS_AMD_NO_CHUNKS": "1"}, tag="whole")
     assert info["status"] == 0 and info0["status"] == 0 and per == per0
     assert raw.size == raw0.size and np.array_equal(raw, raw0)
+    # the panel-run copies of the batch entries (ocp_qp_gpu_segments.h: BLASFEO's storage as PROBED through its own pack routine)
+    # against the same call with every block read through blasfeo_unpack_* (ACADOS_AMD_LA_API=1): byte for byte
+    info1, per1, _, raw1 = _run_batch(exe, tmp_path, n, [fa, fb], sens=False, extra_env={"ACADOS_AMD_LA_API": "1"}, tag="la_api")
+    assert info1["status"] == 0 and per == per1 and np.array_equal(raw, raw1)
     p = 0
     for i in range(n):
         qp = _perturbed(qb if i & 1 else qa, i)
