@@ -47,6 +47,7 @@ def bind(L):
     L.ocp_qp_gpu_batch_condensed.argtypes = [C.c_void_p]
     L.ocp_qp_gpu_batch_condensed.restype = C.c_void_p
     L.ocp_qp_gpu_batch_set_bulk_out.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.ocp_qp_gpu_batch_set_bulk_vec.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.ocp_qp_gpu_batch_get_bulk_in.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.ocp_qp_gpu_batch_set_bulk_chunk.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     L.ocp_qp_gpu_batch_set_bulk_staged.argtypes = [C.c_void_p]

@@ -27,6 +27,7 @@
 #include "res_kernels.hpp"
 #include "pcond_kernels_w16.hpp"
 #include "pcond_kernels_mfma.hpp"
+#include "dense_kernels.hpp"
 #include "kernel_sets.h"
 
 /* a failing HIP call is not something a solve can recover from (lost device, out of HBM): message + exit(1), acados'
@@ -152,6 +153,13 @@ struct ocp_qp_gpu_batch
     GqpDev D = {};
     GqpOpts O;
     bool has_slack = false;            /* some stage has slack variables (set with the dims) */
+    /* full condensing of any size (option "full_dense": dense_kernels.hpp, dense_solve below) */
+    int full_dense = 0;
+    gqp::KdRow *d_kd_rows = nullptr;
+    gqp::KdDims kd = {};
+    int kd_unsupported = 0;
+    double *d_kd_ws = nullptr;
+    int kd_slice = 0;
     /* terminal polishing step (option "polish", opt-in: polish_pass below) */
     int polish = 0;
     double polish_ratio = 1e-3;
@@ -241,7 +249,7 @@ struct ocp_qp_gpu_batch
                                                         Q and R (not written: only the lower triangle of the caller's block is
                                                         valid) are read from the mirrored element */
         gqp::GArrTable T;
-    } bulk_in, bulk_out, bulk_seed;
+    } bulk_in, bulk_out, bulk_seed, bulk_vec;
 };
 
 namespace
@@ -1076,6 +1084,7 @@ try
     else if (!strcmp(f, "alpha_min")) o.alpha_min = *d;
     else if (!strcmp(f, "tau_min")) o.tau_min = *d;
     else if (!strcmp(f, "tol_comp_soft_scale")) b->tol_comp_soft_scale = *d;
+    else if (!strcmp(f, "full_dense")) b->full_dense = *i != 0;
     else if (!strcmp(f, "polish")) b->polish = *i < 0 ? 0 : (*i > 8 ? 8 : *i);
     else if (!strcmp(f, "polish_ratio")) b->polish_ratio = *d;
     else if (!strcmp(f, "polish_min")) b->polish_min = *d;
@@ -1188,6 +1197,7 @@ static void pcond_setup(ocp_qp_gpu_batch *b)
     const int N = b->N, N2 = (int) b->user_blocks.size() == b->cond_N + 1 ? b->cond_N + 1 : b->cond_N;
     b->pcond_state = -1;
     auto decline = [&](const char *why) {
+        if (b->full_dense) return; /* the caller knows: this batch only probes whether ONE block fits a condensed stage (FULL_CONDENSING) */
         fprintf(stderr, "acados_amd: cond_N=%d requested but %s; solving the full-space QP (N2 = N, the default of "
                         "ocp_qp_partial_condensing.c:243-265) -- the solution is identical\n", N2, why);
     };
@@ -1768,11 +1778,92 @@ static void compact_back(ocp_qp_gpu_batch *b, hipStream_t s, ocp_qp_gpu_batch *c
     hipLaunchKernelGGL(gqp::k_compact_scalars, dim3((cnt + 63) / 64), block, 0, s, b->D, c->D, b->d_list, cnt, 1);
 }
 
+/*
+ * FULL CONDENSING of any size (option "full_dense" = 1; FULL_CONDENSING_GPU_IPM past what one condensed stage of the stage-wise
+ * families may carry): one workgroup per instance condenses every state but x0, runs the IPM on the dense problem and expands
+ * (dense_kernels.hpp).  The batch is worked off in slices whose workspace stays below 8 GiB; the family's own finalize kernel
+ * then recovers the multipliers of the equality-flagged rows from stationarity, as after a stage-wise solve.
+ */
+static int dense_solve(ocp_qp_gpu_batch *b)
+{
+    hipStream_t s = b->stream;
+    const GqpDev &D = b->D;
+    if (!b->d_kd_rows)
+    {
+        std::vector<gqp::KdRow> rows;
+        b->kd_unsupported = b->has_slack ? 1 : 0;
+        for (int k = 0; k <= b->N; k++)
+        {
+            const GqpStage &S = b->st[k];
+            const int nbg = S.nb + S.ng;
+            if (S.ns > 0) b->kd_unsupported = 1;
+            int sp = 0;
+            for (int pv = 0; pv < 64; pv++)
+                if ((S.bmask >> pv) & 1)
+                {
+                    const int fixed = (int) ((S.emask >> pv) & 1);
+                    if (fixed && pv >= D.NU && k > 0) b->kd_unsupported = 1; /* a fixed state behind stage 0 is not a dense variable */
+                    rows.push_back({k, pv, -1, S.o_ct + sp, S.o_ct + nbg + sp, sp, nbg + sp, fixed});
+                    sp++;
+                }
+            for (int g = 0; g < S.ng; g++) rows.push_back({k, -1, S.o_g + g, S.o_ct + S.nb + g, S.o_ct + nbg + S.nb + g, S.nb + g, nbg + S.nb + g, 0});
+        }
+        if (b->kd_unsupported)
+            fprintf(stderr, "acados_amd: full_dense: slacks and equality-flagged states behind stage 0 are not supported by the dense path (every "
+                            "instance returns status 4); use the stage-wise solver (cond_N >= 1 blocks within the limits, or none)\n");
+        gqp::KdDims &S = b->kd;
+        const int K = b->N + 1, NX = D.NX, NU = D.NU, n = NX + NU;
+        S.K = K; S.n = n; S.nvu = K * NU; S.nv = S.nvu + NX; S.R = (int) rows.size();
+        size_t o = 0;
+        auto take = [&](size_t cnt) { const size_t at = o; o += (cnt + 7) & ~(size_t) 7; return at; };
+        S.oG = take((size_t) K * NX * S.nv); S.oc = take((size_t) K * NX); S.oH = take((size_t) K * n * n); S.og = take((size_t) K * n);
+        S.orw = take((size_t) K * n); S.oM = take((size_t) S.nv * S.nv); S.orhs = take(S.nv); S.odv = take(S.nv); S.ov = take(S.nv);
+        S.ow = take((size_t) K * n); S.odw = take((size_t) K * n); S.oP = take((size_t) NX * S.nv);
+        S.W = o;
+        b->d_kd_rows = dalloc<gqp::KdRow>(b, rows.size());
+        if (!rows.empty()) HIPCHK(hipMemcpy(b->d_kd_rows, rows.data(), sizeof(gqp::KdRow) * rows.size(), hipMemcpyHostToDevice));
+        const size_t budget = (size_t) 8 << 30;
+        b->kd_slice = (int) std::max<size_t>(1, std::min<size_t>((size_t) b->B, budget / (S.W * sizeof(double))));
+        b->d_kd_ws = dalloc<double>(b, (size_t) b->kd_slice * S.W);
+    }
+    const GqpOpts O = effective_opts(b->O, b);
+    HIPCHK(hipEventRecord(b->ev0, s));
+    for (int first = 0; first < b->B; first += b->kd_slice)
+    {
+        const int cnt = std::min(b->kd_slice, b->B - first);
+        GQP_LAUNCH_COOP(gqp::kd_solve, dim3(cnt), dim3(GQP_KD_THREADS), 0, s, D, O, b->kd, (const gqp::KdRow *) b->d_kd_rows, b->d_kd_ws, first,
+                        b->kd_unsupported);
+    }
+    b->launches = (b->B + b->kd_slice - 1) / b->kd_slice;
+    if (!b->kd_unsupported)
+    {
+        GQP_IPM_LAUNCH(b, pick_kernels(b).final_, s, D);
+        b->launches++;
+    }
+    HIPCHK(hipEventRecord(b->ev1, s));
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, b->ev0, b->ev1));
+    b->time_tot = ms * 1e-3;
+    b->time_xcond = 0.0;
+    b->factor_stale = true;   /* Lf of the stage-wise sweeps does not belong to this solution: the sensitivity slots refactor */
+    b->sens_open = false;
+    int *itv = b->h_ints, *st = b->h_ints + b->Bp;
+    HIPCHK(hipMemcpy(itv, D.iter, sizeof(int) * b->B, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(st, D.status, sizeof(int) * b->B, hipMemcpyDeviceToHost));
+    int mx = 0, bad = 0;
+    for (int q = 0; q < b->B; q++) { mx = std::max(mx, itv[q]); bad += st[q] != 0; }
+    b->last_iters = mx;
+    return bad;
+}
+
 int ocp_qp_gpu_batch_solve(ocp_qp_gpu_batch *b)
 try
 {
     HIPCHK(hipSetDevice(b->device));
     finalize_structure(b);
+    if (b->full_dense) return dense_solve(b);
     if (b->cond_N > 0 && b->cond_N < b->N)
     {
         if (b->pcond_state == 0) pcond_setup(b);
@@ -2226,6 +2317,9 @@ try
     if (!strcmp(f, "cond_N_active")) return b->pcond_state == 1 ? (double) b->child->N : (double) b->N;
     if (!strcmp(f, "tol_comp_soft_scale")) return b->tol_comp_soft_scale;
     if (!strcmp(f, "polish")) return b->polish;
+    if (!strcmp(f, "full_dense")) return b->full_dense;
+    if (!strcmp(f, "dense_columns")) return b->kd.nv;
+    if (!strcmp(f, "dense_workspace_bytes")) return (double) b->kd.W * 8.0 * b->kd_slice;
     if (!strcmp(f, "polished")) return b->child && b->pcond_state == 1 && b->cond_N > 0 && b->cond_N < b->N ? b->child->n_polished : b->n_polished;
     if (!strcmp(f, "polish_reverted")) return b->child && b->pcond_state == 1 && b->cond_N > 0 && b->cond_N < b->N ? b->child->n_polish_reverted : b->n_polish_reverted;
     if (!strcmp(f, "tol_comp_effective")) { finalize_structure(b); return effective_opts(b->O, b).tol_comp; }
@@ -2375,6 +2469,11 @@ static const char *const k_bulk_in_fields[] = {"A", "B", "b", "Q", "S", "R", "q"
                                                "C", "D", "Zl", "Zu", "zl", "zu", "lls", "lus", "lbu_mask", "ubu_mask",
                                                "lbx_mask", "ubx_mask", "lg_mask", "ug_mask", "lls_mask", "lus_mask"};
 static const char *const k_bulk_out_fields[] = {"u", "x", "sl", "su", "pi", "lam", "t"};
+/* the VECTOR part of the input blob (which = 2): what changes between the two halves of an RTI step -- gradient, dynamics offset,
+ * bounds, masks (ocp_nlp_common.c:3119-3138 writes exactly these between condense_lhs and condense_rhs_and_solve); 12.6 KB per
+ * C2-shaped QP against 85 KB for the whole blob */
+static const char *const k_bulk_vec_fields[] = {"b", "q", "r", "lbu", "ubu", "lbx", "ubx", "lg", "ug", "zl", "zu", "lls", "lus", "lbu_mask", "ubu_mask",
+                                                "lbx_mask", "ubx_mask", "lg_mask", "ug_mask", "lls_mask", "lus_mask"};
 
 static void bulk_build(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch::BulkMap &M, const char *const *fields, int nf)
 {
@@ -2469,15 +2568,15 @@ static void bulk_build(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch::BulkMap &M, const 
 static int gqp_bulk_len_impl(ocp_qp_gpu_batch *b, int output) /* throws gqp_hip_failure: callers are inside a guarded entry */
 {
     HIPCHK(hipSetDevice(b->device));
-    auto &M = output ? b->bulk_out : b->bulk_in;
-    bulk_build(b, M, output ? k_bulk_out_fields : k_bulk_in_fields, output ? 7 : 30);
+    auto &M = output == 2 ? b->bulk_vec : (output ? b->bulk_out : b->bulk_in);
+    bulk_build(b, M, output == 2 ? k_bulk_vec_fields : (output ? k_bulk_out_fields : k_bulk_in_fields), output == 2 ? 21 : (output ? 7 : 30));
     return M.len;
 }
 
 static int gqp_bulk_offset_impl(ocp_qp_gpu_batch *b, int output, const char *field, int stage, int *len)
 {
     gqp_bulk_len_impl(b, output);
-    auto &M = output ? b->bulk_out : b->bulk_in;
+    auto &M = output == 2 ? b->bulk_vec : (output ? b->bulk_out : b->bulk_in);
     for (size_t q = 0; q < M.fields.size(); q++)
         if (M.seg_stage[q] == stage && M.fields[q] == field)
         {
@@ -2519,6 +2618,29 @@ try
     HIPCHK(hipEventElapsedTime(&ms, e0, e1));
     b->time_pack += ms * 1e-3;
     HIPCHK(hipEventDestroy(e0)); HIPCHK(hipEventDestroy(e1));
+    return 0;
+}
+catch (const gqp_hip_failure &) { return -1; }
+
+/* the vector fields alone (blob layout: ocp_qp_gpu_batch_bulk_len / _bulk_offset with which = 2): the matrices stay what the last
+ * _set_bulk brought -- the host side of an RTI feedback step (condense_lhs done, new gradient / offsets / bounds) */
+int ocp_qp_gpu_batch_set_bulk_vec(ocp_qp_gpu_batch *b, const double *blob, int is_device)
+try
+{
+    const int len = gqp_bulk_len_impl(b, 2);
+    auto &M = b->bulk_vec;
+    HIPCHK(hipEventRecord(b->ev0, b->stream));
+    const double *src = stage_in(b, blob, (size_t) b->B * len, is_device);
+    const dim3 grid((b->B + 63) / 64, (len + 255) / 256), block(64);
+    hipLaunchKernelGGL(gqp::k_bulk_scatter, grid, block, 0, b->stream, src, b->B, len, M.d_arr, M.d_elem, M.T);
+    if (M.nm)
+        hipLaunchKernelGGL(gqp::k_bulk_masks, dim3((b->B + 63) / 64), block, 0, b->stream, src, b->B, len, M.d_moff,
+                           M.d_mstage, M.d_mbit, M.nm, b->D.amask, b->AW);
+    HIPCHK(hipEventRecord(b->ev1, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, b->ev0, b->ev1));
+    b->time_pack += ms * 1e-3;
     return 0;
 }
 catch (const gqp_hip_failure &) { return -1; }

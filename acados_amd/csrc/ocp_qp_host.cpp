@@ -1154,6 +1154,10 @@ int gqp_host::gpu_ipm_evaluate_impl(void *config, int n, void **qp_in_, void **q
             bc->cond_solved = false;
         }
     }
+    {
+        const int dense = cr && cr->dense ? 1 : 0;
+        ocp_qp_gpu_batch_opts_set(b, "full_dense", &dense);
+    }
     /* Hot start of a CONDENSED solve: the reference starts from the condensed iterate kept in its memory (xcond_qp_out) and
      * re-derives it from the caller's qp_out only when initialize_next_xcond_qp_from_qp_out is set
      * (ocp_qp_xcond_solver.c:554-571).  Same here: without the flag the condensed batch keeps the iterate of its last

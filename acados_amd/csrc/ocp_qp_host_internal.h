@@ -24,6 +24,8 @@ struct cond_request
     const int *block_size; /* N2 + 1 entries or NULL (ocp_qp_partial_condensing.c:305-313) */
     int init_from_qp_out;  /* initialize_next_xcond_qp_from_qp_out: qp_out holds the guess (pi, lam, t) */
     int phase;             /* 0: condense + solve + expand; 1: condense_lhs only; 2: condense_rhs + solve + expand */
+    int dense;             /* FULL_CONDENSING past what one condensed stage may carry: condense to ONE dense problem inside the solve
+                              (device option "full_dense", dense_kernels.hpp); N2 is 0 then */
 };
 
 /* the evaluate of the inner plugin with the condensing request made explicit; `cr` may be NULL */

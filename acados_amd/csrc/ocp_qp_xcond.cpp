@@ -265,6 +265,7 @@ static void pcond_compute_dims(ocp_qp_partial_condensing_dims *dims, ocp_qp_part
             for (int r = 0; r < d->nbxe[k]; r++) ie[r] = d->nbu[k] + r;
             ocp_qp_gpu_batch_set_int(probe, "idxe", k, ie.data(), d->nbxe[k]);
         }
+    if (opts->full_condensing) { const int one = 1; ocp_qp_gpu_batch_opts_set(probe, "full_dense", &one); } /* (no fall-back notice: the dense path takes over) */
     ocp_qp_gpu_batch_opts_set(probe, "cond_N", &N2);
     if (opts->block_size_was_set && ocp_qp_gpu_batch_opts_set(probe, "cond_block_size", opts->block_size) != 0) exit(1);
     ocp_qp_gpu_batch *c = ocp_qp_gpu_batch_condense(probe);
@@ -282,15 +283,10 @@ static void pcond_compute_dims(ocp_qp_partial_condensing_dims *dims, ocp_qp_part
         for (int i = 0; i <= N2; i++)
             dims->block_size[i] = opts->block_size_was_set ? opts->block_size[i] : (i < N2 ? N / N2 + (i < N % N2 ? 1 : 0) : 0);
     }
-    else if (opts->full_condensing)
-    {
-        /* explicit refusal (no silent fall-back to the full space for a solver the user asked for by name) */
-        int mx = 0, mu = 0;
-        for (int k = 0; k <= N; k++) { mx = d->nx[k] > mx ? d->nx[k] : mx; mu = d->nu[k] > mu ? d->nu[k] : mu; }
-        printf("\nerror: FULL_CONDENSING_GPU_IPM: nx + N * nu = %d + %d * %d exceeds the 64 variables (or 64 rows / 128 sides) one "
-               "condensed stage may carry on the device; use PARTIAL_CONDENSING_GPU_IPM with cond_N > 1\n", mx, N, mu);
-        exit(1);
-    }
+    /* FULL_CONDENSING_GPU_IPM past what one condensed STAGE may carry (64 variables, 128 inequality sides): the problem is condensed to
+     * ONE dense problem inside the solve (dense_kernels.hpp: every state but x0 eliminated, dense Cholesky; correctness first -- the
+     * stage-wise solver is faster on every shape measured).  The module's own slots hand the QP through (xcond dims = original dims):
+     * the dense problem lives in the solver's workspace on the device and is not read back. */
     ocp_qp_gpu_batch_destroy(probe);
     dims->probe_valid = 1;
 }
@@ -871,7 +867,7 @@ static int xcond_fused(void *config_, ocp_qp_in *qp_in, ocp_qp_out *qp_out, void
     /* the condensing request of THIS call, read from the opts / memory of THIS solver (no state outside them); a class the
      * module sized as "not condensed" goes to the device as a full-space QP */
     cond_request cr = {xm->dims->condensed ? xo->N2 : 0, xm->dims->condensed && xo->block_size_was_set ? xo->block_size : nullptr,
-                       opts->initialize_next_xcond_qp_from_qp_out ? 1 : 0, phase};
+                       opts->initialize_next_xcond_qp_from_qp_out ? 1 : 0, phase, xo->full_condensing && !xm->dims->condensed ? 1 : 0};
     void *ins[1] = {qp_in}, *outs[1] = {qp_out}, *mems[1] = {mem->solver_memory};
     int status = 0;
     gqp_host::gpu_ipm_evaluate_impl(config->qp_solver, 1, ins, outs, opts->qp_solver_opts, mems, nullptr, &status, &cr);
@@ -1096,7 +1092,8 @@ int ocp_qp_solve_batch(ocp_qp_solver *s, int n, ocp_qp_in **qp_in, ocp_qp_out **
     if (n <= 0) return ACADOS_SUCCESS;
     ocp_qp_partial_condensing_opts *xo = (ocp_qp_partial_condensing_opts *) s->opts->xcond_opts;
     ocp_qp_partial_condensing_memory *xm = (ocp_qp_partial_condensing_memory *) s->mem->xcond_memory;
-    cond_request cr = {xm->dims->condensed ? xo->N2 : 0, xm->dims->condensed && xo->block_size_was_set ? xo->block_size : nullptr, 0, 0};
+    cond_request cr = {xm->dims->condensed ? xo->N2 : 0, xm->dims->condensed && xo->block_size_was_set ? xo->block_size : nullptr, 0, 0,
+                       xo->full_condensing && !xm->dims->condensed ? 1 : 0};
     std::vector<void *> mems(n, nullptr);
     mems[0] = s->mem->solver_memory;
     return gqp_host::gpu_ipm_evaluate_impl(s->config->qp_solver, n, (void **) qp_in, (void **) qp_out, s->opts->qp_solver_opts,

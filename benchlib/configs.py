@@ -307,6 +307,13 @@ def boundary_c3(n=4096, reps=4):
             "batch": n, "solves_per_s": n / t, "ms_per_step": t * 1e3, "failures": int(info.get("status", 0) != 0), "host_threads": int(info.get("threads", threads)),
             "max_kkt_residual_reference_entry": info.get("res_max"), "fused_vs_per_capsule_orchestration": info.get("fused_vs_orchestrated"),
             "phases_ms": {k: info[k] for k in ("unpack_in_ms", "copy_and_device_ms", "device_solve_ms", "pack_out_ms") if k in info},
+            # the same capsules as the two halves of an RTI step: preparation (everything to the device, matrices condensed there) is off the
+            # control loop's critical path; the FEEDBACK call reads and sends only the vector members of every qp_in
+            "rti_feedback": ({"solves_per_s": n / (info["rti_feedback_ms"] * 1e-3), "ms_per_step": info["rti_feedback_ms"],
+                              "preparation_ms": info.get("rti_preparation_ms"), "failures": int(info.get("rti_status", 0) != 0),
+                              "vs_one_call": info.get("rti_vs_one_call"), "upload_bytes_per_qp": 8 * int(info.get("rti_feedback_upload_doubles", 0)),
+                              "pcie_bytes": n * (8 * int(info.get("rti_feedback_upload_doubles", 0)) + b_out)}
+                             if info.get("rti_feedback_ms") else None),
             "pcie_bytes": pcie, "pcie_GBps": pcie / t / 1e9, "pcie_peak_GBps": PCIE_PEAK_GBS, "pcie_frac": pcie / t / 1e9 / PCIE_PEAK_GBS,
             "pcie_note": "algorithmic bytes of SURVEY 8d per QP (85,336 in + 12,720 out; the blob also carries 0/1 masks) over the WHOLE call; "
                          "every call re-reads every member array of every qp_in (ocp_nlp_common.c:2797-2894: they alias ocp_nlp memory)"}

@@ -88,6 +88,9 @@ def compact_line(out, detail_path=None):
             ro_c = c.get("roofline") or c.get("roofline_of_slowest_class") or {}
             rec = _pick(c, ("batch", "solves_per_s", "ms_per_step", "mean_iter", "failures", "max_rel_primal_err_vs_oracle",
                             "condense_expand_ms", "solves_per_s_one_after_the_other", "polished", "host_threads", "pcie_GBps", "pcie_frac", "skipped", "error"), 4)
+            if c.get("rti_feedback"):
+                rec["rti_feedback_solves_per_s"] = _r(c["rti_feedback"]["solves_per_s"], 4)
+                rec["rti_feedback_ms"] = _r(c["rti_feedback"]["ms_per_step"], 4)
             if "phases_ms" in c:
                 rec["phases_ms"] = [_r(c["phases_ms"].get(k), 3) for k in ("unpack_in_ms", "copy_and_device_ms", "device_solve_ms", "pack_out_ms")]
             rec.update({"frac": _r(ro_c.get("frac"), 3), "traffic_over_algorithmic": _r(ro_c.get("traffic_over_algorithmic"), 3)})

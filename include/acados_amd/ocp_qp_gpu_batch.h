@@ -68,6 +68,10 @@ int ocp_qp_gpu_batch_set(ocp_qp_gpu_batch *b, const char *field, int stage, cons
 int ocp_qp_gpu_batch_bulk_len(ocp_qp_gpu_batch *b, int output);
 int ocp_qp_gpu_batch_bulk_offset(ocp_qp_gpu_batch *b, int output, const char *field, int stage, int *len);
 int ocp_qp_gpu_batch_set_bulk(ocp_qp_gpu_batch *b, const double *blob, int is_device);
+/* the VECTOR fields alone (b q r, bounds, zl zu, masks): blob layout of _bulk_len / _bulk_offset with `output` = 2.  The matrices stay
+ * what the last _set_bulk brought: the host->device traffic of an RTI feedback step whose preparation step condensed the matrices
+ * (replaces the vector part of d_ocp_qp_set_* between ocp_qp_xcond_solver.c:591-620 and :623-669; 12.6 KB instead of 85 KB per C2-shaped QP) */
+int ocp_qp_gpu_batch_set_bulk_vec(ocp_qp_gpu_batch *b, const double *blob, int is_device);
 int ocp_qp_gpu_batch_get_bulk(ocp_qp_gpu_batch *b, double *blob, int is_device);
 /* _set_bulk in pieces (the batch entries of the acados-side adapter: the host->device copy of instance range j overlaps with the host
  * threads still unpacking range j + 1): `blob_chunk` = instance `first` of the caller's pinned blob, `count` instances, asynchronous;

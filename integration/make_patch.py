@@ -20,12 +20,18 @@ BATCH_GPU_QP = '''{%- if solver_options.qp_solver == "PARTIAL_CONDENSING_GPU_IPM
 #include "acados/ocp_nlp/ocp_nlp_sqp_rti.h"
 #include "acados/ocp_qp/ocp_qp_gpu_ipm.h"
 /*
- * One RTI step of EVERY capsule with ONE device batch for the QPs (ACADOS_WITH_GPU_IPM): host threads linearise and set up each
- * capsule's QP (phase 1: ocp_nlp_solve returns in front of the QP solve), the N_batch QPs -- acados structs, as each capsule's NLP
- * solver scaled them -- go to the GPU in one call (partial condensing, IPM and expansion fused on the device), host threads
- * finish the step (phase 2: dual correction, globalisation, update of the iterate).  Unlike the one-thread-per-capsule loop
- * above, num_threads_in_batch_solve is only the width of the two host phases; the batch may hold thousands of capsules.
- * The capsules share their solver options (the batch runs with capsule 0's).
+ * One RTI step of EVERY capsule with ONE device batch for the QPs (ACADOS_WITH_GPU_IPM).  What runs is decided by the capsules' own
+ * rti_phase option (acados_ocp_options.py: 0 preparation + feedback, 1 preparation, 2 feedback; the capsules share their options, the
+ * batch runs with capsule 0's):
+ *   0 / 2   host threads linearise and set up each capsule's QP (phase 1: ocp_nlp_solve returns in front of the QP solve), the N_batch
+ *           QPs -- acados structs, as each capsule's NLP solver scaled them -- go to the GPU in one call (partial condensing, IPM and
+ *           expansion fused on the device), host threads finish the step (phase 2: dual correction, globalisation, update of the iterate).
+ *           rti_phase 2 (FEEDBACK) sends only the VECTOR members of the QPs (gradient, offsets, bounds): the matrices are resident
+ *           since the preparation call;
+ *   1       every capsule's preparation step on host threads (its condense_lhs slot has nothing to do: option qp_cond_batch_owned),
+ *           then the matrices of all N_batch QPs to the GPU and the matrix part of the condensing there.
+ * Unlike the one-thread-per-capsule loop above, num_threads_in_batch_solve is only the width of the host phases; the batch may hold
+ * thousands of capsules.
  */
 void {{ name }}_acados_batch_solve_gpu_qp({{ name }}_solver_capsule ** capsules, int * status_out, int N_batch, int num_threads_in_batch_solve)
 {
@@ -36,10 +42,14 @@ void {{ name }}_acados_batch_solve_gpu_qp({{ name }}_solver_capsule ** capsules,
         omp_set_num_threads(num_threads_in_batch_solve);
     }
 
-    int phase = 1;
+    ocp_nlp_sqp_rti_opts *opts0 = capsules[0]->nlp_opts;
+    const int rti_phase = opts0->rti_phase;
+    int phase = rti_phase == PREPARATION ? 0 : 1;
+    int batch_owned = 1;
     #pragma omp parallel for
     for (int i = 0; i < N_batch; i++)
     {
+        ocp_nlp_solver_opts_set(capsules[i]->nlp_config, capsules[i]->nlp_opts, "qp_cond_batch_owned", &batch_owned);
         ocp_nlp_solver_opts_set(capsules[i]->nlp_config, capsules[i]->nlp_opts, "batch_qp_phase", &phase);
         status_out[i] = ocp_nlp_solve(capsules[i]->nlp_solver, capsules[i]->nlp_in, capsules[i]->nlp_out);
     }
@@ -55,22 +65,40 @@ void {{ name }}_acados_batch_solve_gpu_qp({{ name }}_solver_capsule ** capsules,
         qp_out[i] = nlp_mem->scaled_qp_out;
         qp_mem[i] = nlp_mem->qp_solver_mem;
     }
-    ocp_nlp_sqp_rti_opts *opts0 = capsules[0]->nlp_opts;
-    ocp_qp_gpu_xcond_solver_acados_evaluate_batch(capsules[0]->nlp_config->qp_solver, capsules[0]->nlp_dims->qp_solver, N_batch,
-                                                  qp_in, qp_out, opts0->nlp_opts->qp_solver_opts, qp_mem, NULL);
+    if (rti_phase == PREPARATION)
+    {
+        ocp_qp_gpu_xcond_solver_acados_condense_lhs_batch(capsules[0]->nlp_config->qp_solver, capsules[0]->nlp_dims->qp_solver, N_batch,
+                                                          qp_in, opts0->nlp_opts->qp_solver_opts, qp_mem, NULL);
+    }
+    else if (rti_phase == FEEDBACK)
+    {
+        ocp_qp_gpu_xcond_solver_acados_condense_rhs_and_solve_batch(capsules[0]->nlp_config->qp_solver, capsules[0]->nlp_dims->qp_solver, N_batch,
+                                                                    qp_in, qp_out, opts0->nlp_opts->qp_solver_opts, qp_mem, NULL);
+    }
+    else
+    {
+        ocp_qp_gpu_xcond_solver_acados_evaluate_batch(capsules[0]->nlp_config->qp_solver, capsules[0]->nlp_dims->qp_solver, N_batch,
+                                                      qp_in, qp_out, opts0->nlp_opts->qp_solver_opts, qp_mem, NULL);
+    }
     free(qp_in);
     free(qp_out);
     free(qp_mem);
 
-    phase = 2;
-    #pragma omp parallel for
-    for (int i = 0; i < N_batch; i++)
+    if (rti_phase != PREPARATION)
     {
-        ocp_nlp_solver_opts_set(capsules[i]->nlp_config, capsules[i]->nlp_opts, "batch_qp_phase", &phase);
-        status_out[i] = ocp_nlp_solve(capsules[i]->nlp_solver, capsules[i]->nlp_in, capsules[i]->nlp_out);
-        int phase_off = 0;
-        ocp_nlp_solver_opts_set(capsules[i]->nlp_config, capsules[i]->nlp_opts, "batch_qp_phase", &phase_off);
+        phase = 2;
+        #pragma omp parallel for
+        for (int i = 0; i < N_batch; i++)
+        {
+            ocp_nlp_solver_opts_set(capsules[i]->nlp_config, capsules[i]->nlp_opts, "batch_qp_phase", &phase);
+            status_out[i] = ocp_nlp_solve(capsules[i]->nlp_solver, capsules[i]->nlp_in, capsules[i]->nlp_out);
+            int phase_off = 0;
+            ocp_nlp_solver_opts_set(capsules[i]->nlp_config, capsules[i]->nlp_opts, "batch_qp_phase", &phase_off);
+        }
     }
+    batch_owned = 0;
+    for (int i = 0; i < N_batch; i++)
+        ocp_nlp_solver_opts_set(capsules[i]->nlp_config, capsules[i]->nlp_opts, "qp_cond_batch_owned", &batch_owned);
 
     if (num_threads_in_batch_solve > 1)
     {
@@ -261,6 +289,8 @@ void ocp_qp_gpu_ipm_acados_config_initialize_default(void *config);
 /* batch extension: n capsules' QPs as ONE device batch per structure class (replaces the per-capsule loop of
  * acados_solver.in.c:3222-3243); mem[i] = the qp solver memory of capsule i */
 int ocp_qp_gpu_ipm_acados_evaluate_batch(void *config, int n, void **qp_in, void **qp_out, void *opts, void **mem, void *work);
+int ocp_qp_gpu_ipm_acados_condense_lhs_batch(void *config, int n, void **qp_in, void *opts, void **mem, void *work);
+int ocp_qp_gpu_ipm_acados_condense_rhs_and_solve_batch(void *config, int n, void **qp_in, void **qp_out, void *opts, void **mem, void *work);
 void ocp_qp_gpu_ipm_acados_eval_sens_batch(void *config, int n, void **qp_in, void **seed, void **sens_qp_out, void *opts, void **mem,
                                            void *work);
 
@@ -275,6 +305,12 @@ int ocp_qp_gpu_pcond_acados_is_module(const void *xcond_config);
  * condensing module's opts, condensing + IPM + expansion fused on the device; mem[i] = capsule i's ocp_qp_xcond_solver_memory */
 int ocp_qp_gpu_xcond_solver_acados_evaluate_batch(void *config, ocp_qp_xcond_solver_dims *dims, int n, ocp_qp_in **qp_in, ocp_qp_out **qp_out,
                                                   void *opts, void **mem, void *work);
+/* ... and the two halves of an RTI step (the batch counterparts of condense_lhs / condense_rhs_and_solve, ocp_qp_xcond_solver.c:591-669):
+ * the feedback half reads and sends only the vector members of every qp_in, the matrices stay on the device in between */
+int ocp_qp_gpu_xcond_solver_acados_condense_lhs_batch(void *config, ocp_qp_xcond_solver_dims *dims, int n, ocp_qp_in **qp_in, void *opts, void **mem,
+                                                      void *work);
+int ocp_qp_gpu_xcond_solver_acados_condense_rhs_and_solve_batch(void *config, ocp_qp_xcond_solver_dims *dims, int n, ocp_qp_in **qp_in,
+                                                                ocp_qp_out **qp_out, void *opts, void **mem, void *work);
 
 /* rendezvous: the n `evaluate` calls of an UNMODIFIED _acados_batch_solve loop become one device batch (option "rendezvous") */
 typedef struct ocp_qp_gpu_ipm_rendezvous_ ocp_qp_gpu_ipm_rendezvous;

@@ -69,7 +69,11 @@ typedef struct
     int n;                       /* instances */
     int *sig, sig_len, sig_cap;  /* structure the batch was built for */
     double *blob_in, *blob_out;  /* staging: carved (single QP) or pinned (batch entries) */
+    int blob_clean;              /* batch entries: every position of blob_in that no segment writes is zero (nothing but QP data has been staged
+                                    there since the last full clear): the per-call memset -- a second pass over 85 KB per QP -- is skipped */
     size_t cap_in, cap_out;      /* doubles */
+    int lhs_resident;            /* batch entries: the matrices of every instance are on the device and (cond_N < N) condensed -- set by the
+                                    condense_lhs batch entry, consumed by the condense_rhs_and_solve one (an RTI step's two halves) */
     int *members;                /* batch entries: index of each instance in the caller's arrays */
     int *st, *it;                /* per-instance status / iterations of the last solve */
     int status;                  /* worst status of the last solve */
@@ -113,6 +117,7 @@ typedef struct ocp_qp_gpu_ipm_memory_
     int rv_index;                /* slot of this memory's capsule in its rendezvous (-1: none yet) */
     int *sig_scratch;
     double time_qp_solver_call;
+    int upload_doubles;          /* extension: doubles per QP the last batch call sent to the device (the whole input blob, or its vector part) */
     double time_unpack_in, time_pack_out; /* extension: host time spent reading qp_in into / writing qp_out from the staging blobs */
     int iter, status;
     /* per-iteration statistics of this memory's QP, HPIPM-shaped (ocp_qp_hpipm.c:255-297 "stat" / "stat_m": what
@@ -288,6 +293,7 @@ static void gpu_memory_get(void *config, void *mem_, const char *field, void *va
 {
     ocp_qp_gpu_ipm_memory *m = (ocp_qp_gpu_ipm_memory *) mem_;
     if (!strcmp(field, "time_qp_solver_call")) *(double *) value = m->time_qp_solver_call;
+    else if (!strcmp(field, "upload_doubles")) *(int *) value = m->upload_doubles;
     else if (!strcmp(field, "time_unpack_in")) *(double *) value = m->time_unpack_in;
     else if (!strcmp(field, "time_pack_out")) *(double *) value = m->time_pack_out;
     else if (!strcmp(field, "iter")) *(int *) value = m->iter;
@@ -347,6 +353,25 @@ static int bucket_build(gpu_bucket *bk, const ocp_qp_in *in, const int *sig, int
     return 0;
 }
 
+/* the next capsule's QP towards the cache while this one is unpacked: a batch call reads n x 85 KB that n linearisations wrote
+ * long ago (cold), block by block -- one touch per 64-byte line of the big members, enough lines in flight to hide DRAM latency */
+static void prefetch_qp_in(const ocp_qp_in *in)
+{
+    const ocp_qp_dims *d = in->dim;
+    for (int k = 0; k <= d->N; k++)
+    {
+        const struct blasfeo_dmat *ms[3] = {in->BAbt + k, in->RSQrq + k, in->DCt + k};
+        for (int q = 0; q < 3; q++)
+        {
+            const char *p = (const char *) ms[q]->pA;
+            const int bytes = ms[q]->memsize;
+            for (int o = 0; o < bytes; o += 64) __builtin_prefetch(p + o, 0, 1);
+        }
+        __builtin_prefetch(in->rqz[k].pa, 0, 1); __builtin_prefetch(in->d[k].pa, 0, 1); __builtin_prefetch(in->b[k].pa, 0, 1);
+        __builtin_prefetch(in->d_mask[k].pa, 0, 1);
+    }
+}
+
 static void apply_opts(ocp_qp_gpu_batch *b, const ocp_qp_gpu_ipm_opts *o, int ws)
 {
     ocp_qp_gpu_batch_opts_set(b, "iter_max", &o->iter_max);
@@ -370,7 +395,9 @@ static void apply_opts(ocp_qp_gpu_batch *b, const ocp_qp_gpu_ipm_opts *o, int ws
 
 /* the device part of a solve: staged blobs -> device batch -> staged solution, statuses.  `staged`: the input blob is on the device
  * already (handed over in chunks while it was being filled, evaluate_batch_masked): only its scatter launch is left */
-static void bucket_solve(gpu_bucket *bk, const ocp_qp_gpu_ipm_opts *o, int ws, int staged)
+enum { BATCH_SOLVE = 0, BATCH_LHS = 1, BATCH_RHS_SOLVE = 2 }; /* evaluate | RTI preparation (condense_lhs) | RTI feedback (condense_rhs_and_solve) */
+
+static void bucket_solve(gpu_bucket *bk, const ocp_qp_gpu_ipm_opts *o, int ws, int staged, int mode)
 {
     ocp_qp_gpu_batch *b = bk->batch;
     if (!b) /* the device failed while this bucket's batch was built (bucket_build) */
@@ -384,9 +411,21 @@ static void bucket_solve(gpu_bucket *bk, const ocp_qp_gpu_ipm_opts *o, int ws, i
     /* a negative return = the device failed (HIP error, reported by the library): every QP of the bucket comes back as
      * ACADOS_QP_FAILURE -- ocp_nlp ends that capsule's solve cleanly (ocp_nlp_sqp.c:720-751) -- and the process, with the
      * other host threads of an MPC fleet in it, lives on */
+    if (mode == BATCH_LHS)
+    {
+        /* RTI preparation of the whole class: matrices (and everything else) to the device, the matrix part of the condensing there */
+        const int bad = (staged ? ocp_qp_gpu_batch_set_bulk_staged(b) : ocp_qp_gpu_batch_set_bulk(b, bk->blob_in, 0)) != 0 || ocp_qp_gpu_batch_condense_lhs(b) != 0;
+        for (int i = 0; i < bk->n; i++) { bk->st[i] = bad ? ACADOS_QP_FAILURE : ACADOS_SUCCESS; bk->it[i] = 0; }
+        bk->status = bad ? ACADOS_QP_FAILURE : ACADOS_SUCCESS;
+        bk->lhs_resident = !bad;
+        return;
+    }
+    const int vec_only = mode == BATCH_RHS_SOLVE && bk->lhs_resident;
+    bk->lhs_resident = 0;
     if ((ws >= 2 && ocp_qp_gpu_batch_set_bulk_out(b, bk->blob_out, 0) != 0)
-        || (staged ? ocp_qp_gpu_batch_set_bulk_staged(b) : ocp_qp_gpu_batch_set_bulk(b, bk->blob_in, 0)) != 0
-        || ocp_qp_gpu_batch_solve(b) < 0 || ocp_qp_gpu_batch_get_bulk(b, bk->blob_out, 0) != 0
+        || (vec_only ? ocp_qp_gpu_batch_set_bulk_vec(b, bk->blob_in, 0)
+                     : (staged ? ocp_qp_gpu_batch_set_bulk_staged(b) : ocp_qp_gpu_batch_set_bulk(b, bk->blob_in, 0))) != 0
+        || (vec_only ? ocp_qp_gpu_batch_condense_rhs_and_solve(b) : ocp_qp_gpu_batch_solve(b)) < 0 || ocp_qp_gpu_batch_get_bulk(b, bk->blob_out, 0) != 0
         || ocp_qp_gpu_batch_get_info(b, "status", bk->st) != 0 || ocp_qp_gpu_batch_get_info(b, "iter", bk->it) != 0)
     {
         for (int i = 0; i < bk->n; i++) { bk->st[i] = ACADOS_QP_FAILURE; bk->it[i] = 0; }
@@ -442,7 +481,7 @@ static int ocp_qp_gpu_ipm_acados(void *config, void *qp_in_, void *qp_out_, void
     if (ws >= 2) unpack_qp_out_duals(&bk->lay, out, bk->blob_out);
     const double t_packed = now_s();
 
-    bucket_solve(bk, o, ws, 0);
+    bucket_solve(bk, o, ws, 0, BATCH_SOLVE);
     const double t_solved = now_s();
 
     pack_qp_out(&bk->lay, bk->blob_out, out);
@@ -466,7 +505,7 @@ static void bucket_release(gpu_bucket *bk)
 {
     if (bk->batch) ocp_qp_gpu_batch_destroy(bk->batch);
     ocp_qp_gpu_host_free(bk->blob_in); ocp_qp_gpu_host_free(bk->blob_out);
-    free(bk->sig); free(bk->seg_in); free(bk->seg_out); free(bk->seg_seed); free(bk->members); free(bk->st); free(bk->it);
+    free(bk->sig); free(bk->seg_in); free(bk->seg_out); free(bk->seg_seed); free(bk->seg_vec); free(bk->members); free(bk->st); free(bk->it);
     if (bk->mu_live) pthread_mutex_destroy(&bk->mu);
     memset(bk, 0, sizeof(*bk));
 }
@@ -573,6 +612,8 @@ static gpu_group *group_for(int n, ocp_qp_in **ins, ocp_qp_gpu_ipm_memory **mems
         bk->seg_in = (gpu_seg *) xcalloc(bk->seg_cap_in, sizeof(gpu_seg));
         bk->seg_out = (gpu_seg *) xcalloc(bk->seg_cap_out, sizeof(gpu_seg));
         bk->seg_seed = (gpu_seg *) xcalloc(bk->seg_cap_seed, sizeof(gpu_seg));
+        bk->seg_cap_vec = bk->seg_cap_in;
+        bk->seg_vec = (gpu_seg *) xcalloc(bk->seg_cap_vec, sizeof(gpu_seg));
         bk->st = (int *) xcalloc(bk->n, sizeof(int)); bk->it = (int *) xcalloc(bk->n, sizeof(int));
         memcpy(g->scratch, bk->sig, sizeof(int) * bk->sig_len);
         (void) bucket_build(bk, in0, g->scratch, bk->sig_len); /* on a device failure the bucket has no batch: bucket_solve fails its QPs */
@@ -600,7 +641,7 @@ static gpu_group *group_for(int n, ocp_qp_in **ins, ocp_qp_gpu_ipm_memory **mems
  * mem[i] address instance i of the shared batch.  Returns the worst status (0, else the first that is not MAXITER).
  */
 static int evaluate_batch_masked(void *config, int n, void **qp_in_, void **qp_out_, void *opts_, void **mem_, void *work,
-                                 const unsigned char *skip)
+                                 const unsigned char *skip, int mode)
 {
     /* skip[i] != 0: capsule i does not take part in this call (its SQP loop has ended or it waits elsewhere): its
      * qp_in / qp_out are not touched, its slot of the device batch re-solves the data it holds -- the batch keeps its
@@ -614,14 +655,30 @@ static int evaluate_batch_masked(void *config, int n, void **qp_in_, void **qp_o
     int fresh = 0;
     gpu_group *g = group_for(n, ins, mems, skip, &fresh);
     if (!g) return ACADOS_SUCCESS;
-    const int ws = o->warm_start >= 2 ? o->warm_start : 0;
+    const int ws = mode != BATCH_LHS && o->warm_start >= 2 ? o->warm_start : 0; /* (the preparation half has no qp_out) */
+    /* RTI feedback: only the VECTOR members are read and sent where the class's matrices are resident (BATCH_LHS ran on this group);
+     * anything else -- a new group, a class without its preparation -- is a full evaluate */
+    int vec_only = mode == BATCH_RHS_SOLVE && !skip && !fresh;
+    for (int q = 0; q < g->nbk && vec_only; q++) if (!g->bk[q].lhs_resident || g->bk[q].L_vec <= 0) vec_only = 0;
+    if (mode == BATCH_RHS_SOLVE && !vec_only) for (int q = 0; q < g->nbk; q++) g->bk[q].lhs_resident = 0;
 
     /* host threads: every member array of every qp_in, panel-major -> the bucket's pinned blob.  Every capsule present (the batch
      * entry; a rendezvous round may have absent ones): bucket by bucket and, inside a large bucket, in CHUNKS of instances -- a
      * finished chunk goes to the device at once (asynchronous copy on the batch's stream), so the host->device copy of the QP data
      * (85 KB per C2-shaped QP: as long as the unpacking itself) runs while the host threads unpack the next chunk */
     int staged = 0;
-    if (!skip && !getenv("ACADOS_AMD_NO_CHUNKS"))
+    if (vec_only)
+    {
+#pragma omp parallel for schedule(static)
+        for (int i = 0; i < n; i++)
+        {
+            gpu_bucket *bk = g->bk + g->bucket_of[i];
+            unpack_qp_vec(&bk->lay, ins[i], bk->blob_in + (size_t) g->pos_of[i] * (size_t) bk->L_vec);
+            if (ws >= 2) unpack_qp_out_duals(&bk->lay, outs[i], bk->blob_out + (size_t) g->pos_of[i] * (size_t) bk->L_out);
+        }
+        for (int q = 0; q < g->nbk; q++) g->bk[q].blob_clean = 0; /* (the vector blob has its own stride: the full blob's zeros are gone) */
+    }
+    else if (!skip && !getenv("ACADOS_AMD_NO_CHUNKS"))
     {
         staged = 1;
         for (int q = 0; q < g->nbk; q++)
@@ -636,7 +693,8 @@ static int evaluate_batch_masked(void *config, int n, void **qp_in_, void **qp_o
                 {
                     const int i = bk->members[e];
                     double *blob = bk->blob_in + (size_t) e * (size_t) bk->L_in;
-                    memset(blob, 0, sizeof(double) * (size_t) bk->L_in);
+                    if (!bk->blob_clean) memset(blob, 0, sizeof(double) * (size_t) bk->L_in);
+                    if (e + 1 < c1) prefetch_qp_in(ins[bk->members[e + 1]]);
                     unpack_qp_in(&bk->lay, ins[i], blob);
                     if (ws >= 2) unpack_qp_out_duals(&bk->lay, outs[i], bk->blob_out + (size_t) e * (size_t) bk->L_out);
                 }
@@ -655,7 +713,7 @@ static int evaluate_batch_masked(void *config, int n, void **qp_in_, void **qp_o
             if (skip && skip[i]) continue;
             const gpu_bucket *bk = g->bk + g->bucket_of[i];
             double *blob = bk->blob_in + (size_t) g->pos_of[i] * (size_t) bk->L_in;
-            memset(blob, 0, sizeof(double) * (size_t) bk->L_in);
+            if (!bk->blob_clean) memset(blob, 0, sizeof(double) * (size_t) bk->L_in);
             unpack_qp_in(&bk->lay, ins[i], blob);
             if (ws >= 2) unpack_qp_out_duals(&bk->lay, outs[i], bk->blob_out + (size_t) g->pos_of[i] * (size_t) bk->L_out);
         }
@@ -672,13 +730,29 @@ static int evaluate_batch_masked(void *config, int n, void **qp_in_, void **qp_o
                 if (skip[bk->members[e]])
                     memcpy(bk->blob_in + (size_t) e * (size_t) bk->L_in, bk->blob_in + (size_t) src * (size_t) bk->L_in, sizeof(double) * (size_t) bk->L_in);
         }
+    if (!skip && !vec_only) for (int q = 0; q < g->nbk; q++) g->bk[q].blob_clean = 1; /* every slot was cleared (or was clean) and holds QP data only */
     const double t_packed = now_s();
 
     /* one copy + one scatter launch, the solve, one gather launch + one copy per bucket; buckets run side by side
      * (each device batch has its own stream) */
 #pragma omp parallel for schedule(dynamic, 1) if (g->nbk > 1)
-    for (int q = 0; q < g->nbk; q++) bucket_solve(g->bk + q, o, ws, staged);
+    for (int q = 0; q < g->nbk; q++) bucket_solve(g->bk + q, o, ws, staged, mode);
     const double t_solved = now_s();
+    if (mode == BATCH_LHS)
+    {
+        /* nothing to hand back but the verdict: qp_out is the feedback half's */
+        int worst_lhs = 0;
+        for (int q = 0; q < g->nbk; q++) if (g->bk[q].status != ACADOS_SUCCESS) worst_lhs = g->bk[q].status;
+        for (int i = 0; i < n; i++)
+        {
+            ocp_qp_gpu_ipm_memory *mi = mems[i];
+            if (mem_group(mi) && mi->group != g && mi->group->owner == mi) group_release(mi->group);
+            mi->group = g; mi->group_gen = g->gen; mi->g_bucket = g->bucket_of[i]; mi->g_pos = g->pos_of[i];
+            mi->time_unpack_in = t_packed - t_start; mi->time_pack_out = 0.0; mi->time_qp_solver_call = t_solved - t_packed;
+            mi->upload_doubles = g->bk[g->bucket_of[i]].L_in;
+        }
+        return worst_lhs;
+    }
 
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < n; i++)
@@ -710,6 +784,7 @@ static int evaluate_batch_masked(void *config, int n, void **qp_in_, void **qp_o
         mi->group = g; mi->group_gen = g->gen; mi->g_bucket = g->bucket_of[i]; mi->g_pos = g->pos_of[i];
         mi->iter = it; mi->status = st; mi->time_qp_solver_call = t_solved - t_packed;
         mi->time_unpack_in = t_packed - t_start; mi->time_pack_out = t_end - t_solved;
+        mi->upload_doubles = vec_only ? bk->L_vec : bk->L_in;
         if (st != ACADOS_SUCCESS && (worst == 0 || worst == ACADOS_MAXITER)) worst = st;
     }
     return worst;
@@ -717,7 +792,22 @@ static int evaluate_batch_masked(void *config, int n, void **qp_in_, void **qp_o
 
 int ocp_qp_gpu_ipm_acados_evaluate_batch(void *config, int n, void **qp_in, void **qp_out, void *opts, void **mem, void *work)
 {
-    return evaluate_batch_masked(config, n, qp_in, qp_out, opts, mem, work, NULL);
+    return evaluate_batch_masked(config, n, qp_in, qp_out, opts, mem, work, NULL, BATCH_SOLVE);
+}
+
+/* the two halves of an RTI step for n capsules (the batch counterparts of the condense_lhs / condense_rhs_and_solve slots,
+ * ocp_qp_xcond_solver.c:591-669): PREPARATION -- every member array of every qp_in to the device, the matrix part of the condensing
+ * there (nothing is solved, qp_out is not touched); FEEDBACK -- only the VECTOR members (b, rqz, d, d_mask: what ocp_nlp rewrites
+ * between the two, ocp_nlp_common.c:3119-3138) are read and sent, 12.6 KB instead of 85 KB per C2-shaped QP, then the vector part of the
+ * condensing, the IPM and the expansion.  A feedback call whose preparation did not run on the same set of capsules is a full evaluate. */
+int ocp_qp_gpu_ipm_acados_condense_lhs_batch(void *config, int n, void **qp_in, void *opts, void **mem, void *work)
+{
+    return evaluate_batch_masked(config, n, qp_in, NULL, opts, mem, work, NULL, BATCH_LHS);
+}
+
+int ocp_qp_gpu_ipm_acados_condense_rhs_and_solve_batch(void *config, int n, void **qp_in, void **qp_out, void *opts, void **mem, void *work)
+{
+    return evaluate_batch_masked(config, n, qp_in, qp_out, opts, mem, work, NULL, BATCH_RHS_SOLVE);
 }
 
 /*
@@ -778,7 +868,7 @@ static void rendezvous_round(ocp_qp_gpu_ipm_rendezvous *r) /* mutex held */
         printf("\nerror: ocp_qp_gpu_ipm rendezvous: capsule 0 left before its first QP\n");
         exit(1);
     }
-    evaluate_batch_masked(r->config, r->n, r->ins, r->outs, r->opts, r->mems, NULL, r->skip);
+    evaluate_batch_masked(r->config, r->n, r->ins, r->outs, r->opts, r->mems, NULL, r->skip, BATCH_SOLVE);
     memset(r->skip, 1, r->n);
     r->arrived = 0;
     r->round++;
@@ -842,6 +932,7 @@ static void gpu_solver_get(void *config_, void *qp_in_, void *qp_out_, void *opt
      * locked, and this capsule's block is copied out before the lock is dropped */
     bucket_lock(bk);
     double *Lb = bk->blob_in, *lb = bk->blob_in + (size_t) bk->n * nv * nv;
+    bk->blob_clean = 0;
     ocp_qp_gpu_batch_get(bk->batch, "ric_L", stage, Lb, 0);
     ocp_qp_gpu_batch_get(bk->batch, "ric_l", stage, lb, 0);
     double *mine = (double *) malloc(sizeof(double) * (size_t) (nv * nv + nv + 1));
@@ -920,6 +1011,7 @@ static void gpu_eval_sens(void *config, void *qp_in, void *seed_, void *sens_qp_
      * n passes -- ocp_qp_gpu_ipm_acados_eval_sens_batch below does the n seeds in ONE pass and is what a batched caller
      * should use; this slot stays correct, not fast, under the generated OpenMP loops) */
     bucket_lock(bk);
+    bk->blob_clean = 0;
     memset(bk->blob_in, 0, sizeof(double) * (size_t) bk->n * (size_t) bk->L_seed);
     unpack_seed(&bk->lay, (ocp_qp_seed *) seed_, bk->blob_in + (size_t) pos * (size_t) bk->L_seed);
     bucket_sens(bk);
@@ -941,6 +1033,7 @@ void ocp_qp_gpu_ipm_acados_eval_sens_batch(void *config, int n, void **qp_in, vo
         printf("\nerror: ocp_qp_gpu_ipm_acados_eval_sens_batch: the %d memories are not those of the last evaluate_batch\n", n);
         exit(1);
     }
+    for (int q = 0; q < g->nbk; q++) g->bk[q].blob_clean = 0;
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < n; i++)
     {

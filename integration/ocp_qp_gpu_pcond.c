@@ -60,6 +60,8 @@
 
 /* the QP solver's batch entry and its extension options "cond_N" / "cond_block_size" (integration/ocp_qp_gpu_ipm.c) */
 int ocp_qp_gpu_ipm_acados_evaluate_batch(void *config, int n, void **qp_in, void **qp_out, void *opts, void **mem, void *work);
+int ocp_qp_gpu_ipm_acados_condense_lhs_batch(void *config, int n, void **qp_in, void *opts, void **mem, void *work);
+int ocp_qp_gpu_ipm_acados_condense_rhs_and_solve_batch(void *config, int n, void **qp_in, void **qp_out, void *opts, void **mem, void *work);
 void ocp_qp_gpu_ipm_acados_config_initialize_default(void *config_);
 
 typedef struct
@@ -80,6 +82,8 @@ typedef struct
     int *block_size;             /* N + 1 entries */
     bool block_size_was_set;
     int mem_qp_in;
+    int batch_owned;             /* the capsule's QPs are condensed by the BATCH entries (ocp_qp_gpu_xcond_solver_acados_condense_lhs_batch ...): the
+                                    per-capsule condense_lhs slot of an RTI preparation step has nothing to do (option "cond_batch_owned") */
 } ocp_qp_gpu_pcond_opts;
 
 typedef struct
@@ -270,6 +274,7 @@ static void pc_opts_set(void *opts_, const char *field, void *value)
     if (!strcmp(field, "N")) opts->N2 = *(int *) value;
     else if (!strcmp(field, "N_bkp")) opts->N2_bkp = *(int *) value;
     else if (!strcmp(field, "ric_alg")) opts->ric_alg = *(int *) value;
+    else if (!strcmp(field, "batch_owned")) opts->batch_owned = *(int *) value;
     else if (!strcmp(field, "block_size"))
     {
         const int *v = (const int *) value;
@@ -559,7 +564,17 @@ static int pc_condense_any(void *qp_in_, void *xin_, void *opts_, void *mem_, in
 }
 
 static int pc_condensing(void *qp_in, void *xin, void *opts, void *mem, void *work) { return pc_condense_any(qp_in, xin, opts, mem, 3); }
-static int pc_condense_lhs(void *qp_in, void *xin, void *opts, void *mem, void *work) { return pc_condense_any(qp_in, xin, opts, mem, 1); }
+static int pc_condense_lhs(void *qp_in, void *xin, void *opts, void *mem, void *work)
+{
+    if (((ocp_qp_gpu_pcond_opts *) opts)->batch_owned)
+    {
+        /* lock-step batch: the preparation half of ALL capsules runs as one device call right behind the per-capsule preparation steps */
+        ((ocp_qp_gpu_pcond_memory *) mem)->time_qp_xcond = 0.0;
+        ((ocp_qp_gpu_pcond_memory *) mem)->ptr_qp_in = (ocp_qp_in *) qp_in;
+        return ACADOS_SUCCESS;
+    }
+    return pc_condense_any(qp_in, xin, opts, mem, 1);
+}
 static int pc_condense_rhs(void *qp_in, void *xin, void *opts, void *mem, void *work) { return pc_condense_any(qp_in, xin, opts, mem, 2); }
 
 /* :559-571 */
@@ -732,8 +747,8 @@ int ocp_qp_gpu_pcond_acados_is_module(const void *xcond_config_)
  * answers memory_get("iter" / "status" / "time_qp_solver_call") and qp_out[i]->misc as after its own evaluate.
  * Replaces the loop of acados_solver.in.c:3222-3243 at the QP level (integration/acados.patch adds the caller).
  */
-int ocp_qp_gpu_xcond_solver_acados_evaluate_batch(void *config_, ocp_qp_xcond_solver_dims *dims, int n, ocp_qp_in **qp_in, ocp_qp_out **qp_out,
-                                                  void *opts_, void **mem_, void *work_)
+/* which: 0 evaluate (condense + solve + expand), 1 RTI preparation (condense_lhs: :591-620), 2 RTI feedback (condense_rhs_and_solve: :623-669) */
+static int xcond_batch_call(void *config_, ocp_qp_xcond_solver_dims *dims, int n, ocp_qp_in **qp_in, ocp_qp_out **qp_out, void *opts_, void **mem_, int which)
 {
     ocp_qp_xcond_solver_config *config = (ocp_qp_xcond_solver_config *) config_;
     ocp_qp_xcond_solver_opts *opts = (ocp_qp_xcond_solver_opts *) opts_;
@@ -752,10 +767,33 @@ int ocp_qp_gpu_xcond_solver_acados_evaluate_batch(void *config_, ocp_qp_xcond_so
     void **inner = (void **) malloc(sizeof(void *) * (size_t) n);
     if (!inner) { printf("\nerror: ocp_qp_gpu_xcond_solver_acados_evaluate_batch: out of host memory\n"); exit(1); }
     for (int i = 0; i < n; i++) inner[i] = ((ocp_qp_xcond_solver_memory *) mem_[i])->solver_memory;
-    const int rc = ocp_qp_gpu_ipm_acados_evaluate_batch(config->qp_solver, n, (void **) qp_in, (void **) qp_out, opts->qp_solver_opts, inner, NULL);
+    int rc;
+    if (which == 1) rc = ocp_qp_gpu_ipm_acados_condense_lhs_batch(config->qp_solver, n, (void **) qp_in, opts->qp_solver_opts, inner, NULL);
+    else if (which == 2) rc = ocp_qp_gpu_ipm_acados_condense_rhs_and_solve_batch(config->qp_solver, n, (void **) qp_in, (void **) qp_out, opts->qp_solver_opts, inner, NULL);
+    else rc = ocp_qp_gpu_ipm_acados_evaluate_batch(config->qp_solver, n, (void **) qp_in, (void **) qp_out, opts->qp_solver_opts, inner, NULL);
     free(inner);
     /* the per-capsule path solves the CONDENSED QP it is handed: the option is this call's only */
     condN = 0;
     config->qp_solver->opts_set(config->qp_solver, opts->qp_solver_opts, "cond_N", &condN);
     return rc;
+}
+
+int ocp_qp_gpu_xcond_solver_acados_evaluate_batch(void *config_, ocp_qp_xcond_solver_dims *dims, int n, ocp_qp_in **qp_in, ocp_qp_out **qp_out,
+                                                  void *opts_, void **mem_, void *work_)
+{
+    return xcond_batch_call(config_, dims, n, qp_in, qp_out, opts_, mem_, 0);
+}
+
+/* the two halves of an RTI step for n capsules, the matrices resident on the device in between (the batch counterparts of
+ * ocp_qp_xcond_solver_condense_lhs / _condense_rhs_and_solve): the feedback half reads and sends only the vector members of every qp_in */
+int ocp_qp_gpu_xcond_solver_acados_condense_lhs_batch(void *config_, ocp_qp_xcond_solver_dims *dims, int n, ocp_qp_in **qp_in, void *opts_, void **mem_,
+                                                      void *work_)
+{
+    return xcond_batch_call(config_, dims, n, qp_in, NULL, opts_, mem_, 1);
+}
+
+int ocp_qp_gpu_xcond_solver_acados_condense_rhs_and_solve_batch(void *config_, ocp_qp_xcond_solver_dims *dims, int n, ocp_qp_in **qp_in,
+                                                                ocp_qp_out **qp_out, void *opts_, void **mem_, void *work_)
+{
+    return xcond_batch_call(config_, dims, n, qp_in, qp_out, opts_, mem_, 2);
 }

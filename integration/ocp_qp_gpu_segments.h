@@ -53,9 +53,9 @@ typedef struct
 /* the three segment tables of one device batch (input blob, output blob, seed blob) and the blob lengths */
 #define GPU_LAYOUT_MEMBERS \
     ocp_qp_gpu_batch *batch; \
-    gpu_seg *seg_in, *seg_out, *seg_seed; \
-    int n_in, n_out, n_seed, seg_cap_in, seg_cap_out, seg_cap_seed; \
-    int L_in, L_out, L_seed; /* doubles per instance of the three blobs */ \
+    gpu_seg *seg_in, *seg_out, *seg_seed, *seg_vec; \
+    int n_in, n_out, n_seed, n_vec, seg_cap_in, seg_cap_out, seg_cap_seed, seg_cap_vec; \
+    int L_in, L_out, L_seed, L_vec; /* doubles per instance of the blobs (L_vec: the vector part of the input blob, RTI feedback) */ \
     int ps;                  /* panel height of BLASFEO's matrix storage as PROBED (gpu_probe_panel_size); 0: every block through blasfeo_unpack_* */
 typedef struct { GPU_LAYOUT_MEMBERS } gpu_layout;
 
@@ -193,9 +193,10 @@ GPU_SEG_FN int fill_sig(const ocp_qp_in *in, int *s)
 GPU_SEG_FN void seg_add(ocp_qp_gpu_batch *b, gpu_seg *tab, int *cnt, int cap, int which, const char *field, int k, int expect,
                     int kind, int src, int ai, int aj, int m, int n, int neg)
 {
-    /* which: 0 input blob, 1 output blob, 2 seed blob */
+    /* which: 0 input blob, 1 output blob, 2 seed blob, 3 vector part of the input blob */
     int len = 0;
-    const int off = which == 2 ? ocp_qp_gpu_batch_sens_bulk_offset(b, 0, field, k, &len) : ocp_qp_gpu_batch_bulk_offset(b, which, field, k, &len);
+    const int off = which == 2 ? ocp_qp_gpu_batch_sens_bulk_offset(b, 0, field, k, &len)
+                               : ocp_qp_gpu_batch_bulk_offset(b, which == 3 ? 2 : which, field, k, &len);
     if (off < 0 || len == 0) return;
     if (len != expect)
     {
@@ -212,14 +213,20 @@ GPU_SEG_FN int gpu_layout_build(gpu_layout *bk, const ocp_qp_dims *d)
 {
     ocp_qp_gpu_batch *b = bk->batch;
     const int N = d->N;
-    bk->n_in = bk->n_out = bk->n_seed = 0;
+    bk->n_in = bk->n_out = bk->n_seed = bk->n_vec = 0;
     bk->ps = gpu_probe_panel_size();
     /* the first device work after create (structure tables, out of HBM shows up here): negative = the device failed */
     bk->L_in = ocp_qp_gpu_batch_bulk_len(b, 0);
     bk->L_out = ocp_qp_gpu_batch_bulk_len(b, 1);
     bk->L_seed = ocp_qp_gpu_batch_sens_bulk_len(b, 0);
-    if (bk->L_in < 0 || bk->L_out < 0 || bk->L_seed < 0) { bk->L_in = bk->L_out = bk->L_seed = 0; return -1; }
-#define IN(field, expect, kind, src, ai, aj, m, n, neg) seg_add(b, bk->seg_in, &bk->n_in, bk->seg_cap_in, 0, field, k, expect, kind, src, ai, aj, m, n, neg)
+    bk->L_vec = bk->seg_vec ? ocp_qp_gpu_batch_bulk_len(b, 2) : 0;
+    if (bk->L_in < 0 || bk->L_out < 0 || bk->L_seed < 0 || bk->L_vec < 0) { bk->L_in = bk->L_out = bk->L_seed = bk->L_vec = 0; return -1; }
+    /* (a vector field of the input blob also goes into the table of the vector blob, where the owner of the layout carries one) */
+#define IN(field, expect, kind, src, ai, aj, m, n, neg)                                                                                   \
+    do {                                                                                                                                  \
+        seg_add(b, bk->seg_in, &bk->n_in, bk->seg_cap_in, 0, field, k, expect, kind, src, ai, aj, m, n, neg);                             \
+        if ((kind) == SEG_VEC && bk->seg_vec) seg_add(b, bk->seg_vec, &bk->n_vec, bk->seg_cap_vec, 3, field, k, expect, kind, src, ai, aj, m, n, neg); \
+    } while (0)
 #define OUT(field, expect, src, ai) seg_add(b, bk->seg_out, &bk->n_out, bk->seg_cap_out, 1, field, k, expect, SEG_VEC, src, ai, 0, expect, 1, 0)
 #define SEED(field, expect, src, ai, neg) seg_add(b, bk->seg_seed, &bk->n_seed, bk->seg_cap_seed, 2, field, k, expect, SEG_VEC, src, ai, 0, expect, 1, neg)
     for (int k = 0; k <= N; k++)
@@ -343,6 +350,13 @@ GPU_SEG_FN void unpack_qp_in(const gpu_layout *bk, ocp_qp_in *in, double *blob)
     struct blasfeo_dmat *mats[3] = {in->BAbt, in->RSQrq, in->DCt};
     struct blasfeo_dvec *vecs[8] = {NULL, NULL, NULL, in->b, in->rqz, in->d, in->d_mask, in->Z};
     unpack_segs(bk->seg_in, bk->n_in, blob, mats, vecs, bk->ps);
+}
+
+/* the vector members alone (b, rqz, d, d_mask) into the vector blob: the host side of an RTI feedback step */
+GPU_SEG_FN void unpack_qp_vec(const gpu_layout *bk, ocp_qp_in *in, double *blob)
+{
+    struct blasfeo_dvec *vecs[8] = {NULL, NULL, NULL, in->b, in->rqz, in->d, in->d_mask, in->Z};
+    unpack_segs(bk->seg_vec, bk->n_vec, blob, NULL, vecs, bk->ps);
 }
 
 GPU_SEG_FN void unpack_seed(const gpu_layout *bk, ocp_qp_seed *seed, double *blob)

@@ -88,6 +88,7 @@ enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize };
 static inline hipError_t hipFuncSetAttribute(const void *, hipFuncAttribute, int) { return hipSuccess; }
 static inline int atomicSub(int *p, int v) { int o = *p; *p = o - v; return o; }
 static inline int atomicAdd(int *p, int v) { int o = *p; *p = o + v; return o; }
+static inline double atomicAdd(double *p, double v) { double o = *p; *p = o + v; return o; }
 
 /* ---- cooperative kernels (lanes of a block that exchange data through shared memory) ----
  * Kernels that use __syncthreads() and block-shared memory are launched through GQP_LAUNCH_COOP: every lane of a

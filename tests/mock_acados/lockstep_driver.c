@@ -15,7 +15,10 @@
  * The "linearisation" of every step goes through the reference's module code: gradient / constraint residuals / dynamics offsets are
  * written into rqz / d / b of the capsule's qp_in through the aliased pointers (ocp_nlp_common.c:2797-2894, 3119-3138).
  *
- *   lockstep_driver model.txt out.txt n_twins iterations cond_N threads
+ *   lockstep_driver model.txt out.txt n_twins iterations cond_N threads [split]
+ *
+ * split = 1: every step as the two halves of real-time iteration -- rti_phase PREPARATION for all capsules (matrices to the device once,
+ * condensed there), the new x0, rti_phase FEEDBACK (only the QPs' vector members travel) -- through the same batch function.
  */
 #include <omp.h>
 #include <stdio.h>
@@ -203,6 +206,7 @@ int main(int argc, char **argv)
     m.x0 = read_doubles(f, m.n * m.nx);
     fclose(f);
     const int n_twins = atoi(argv[3]), iters = atoi(argv[4]), cond_N = atoi(argv[5]), threads = atoi(argv[6]);
+    const int split = argc > 7 ? atoi(argv[7]) : 0;
     const int n = m.n, nx = m.nx, nu = m.nu;
     g_fun.base.evaluate = &lti_eval; g_fun.base.get_external_workspace_requirement = &lti_ws; g_fun.base.set_external_workspace = &lti_set_ws;
     g_fun.nx = nx; g_fun.nu = nu; g_fun.A = m.A; g_fun.B = m.B; g_fun.with_jac = 0;
@@ -222,14 +226,26 @@ int main(int argc, char **argv)
     FILE *o = fopen(argv[2], "w");
     if (!o) { perror(argv[2]); return 2; }
     double t_lock = 0.0, t_twin = 0.0;
+    double *x0_next = (double *) calloc((size_t) (n + n_twins) * nx, sizeof(double));
     for (int it = 0; it < iters; it++)
     {
-        double t0 = omp_get_wtime();
-        mpc_acados_batch_solve_gpu_qp(lock, st_lock, n, threads);
-        t_lock += omp_get_wtime() - t0;
-        t0 = omp_get_wtime();
-        if (n_twins > 0) mpc_acados_batch_solve(twin, st_twin, n_twins, threads);
-        t_twin += omp_get_wtime() - t0;
+        for (int half = split ? 1 : 0; half <= (split ? 2 : 0); half++)
+        {
+            /* half 0: preparation + feedback in one call; 1: preparation; 2: feedback (the measured state arrives in between) */
+            for (int i = 0; i < n + n_twins; i++)
+            {
+                mpc_solver_capsule *c = i < n ? lock[i] : twin[i - n];
+                int ph = half;
+                ocp_nlp_solver_opts_set(c->nlp_config, c->nlp_opts, "rti_phase", &ph);
+                if (half != 1 && it > 0) capsule_set_x0(c, x0_next + (size_t) i * nx); /* closed loop: the plant is the model */
+            }
+            double t0 = omp_get_wtime();
+            mpc_acados_batch_solve_gpu_qp(lock, st_lock, n, threads);
+            t_lock += omp_get_wtime() - t0;
+            t0 = omp_get_wtime();
+            if (n_twins > 0) mpc_acados_batch_solve(twin, st_twin, n_twins, threads);
+            t_twin += omp_get_wtime() - t0;
+        }
         for (int pass = 0; pass < 2; pass++)
         {
             mpc_solver_capsule **cs = pass ? twin : lock;
@@ -248,11 +264,19 @@ int main(int argc, char **argv)
                 fprintf(o, " x1");
                 for (int r = 0; r < nx; r++) fprintf(o, " %.17g", x1[r]);
                 fprintf(o, "\n");
-                capsule_set_x0(c, x1);       /* closed loop: the plant is the model */
+                memcpy(x0_next + (size_t) (pass ? n + i : i) * nx, x1, sizeof(double) * (size_t) nx);
             }
         }
     }
-    fprintf(o, "time lock %.6f twin %.6f\n", t_lock, t_twin);
+    {
+        /* what the LAST batch call sent per QP (extension field of the adapter's memory_get): the whole input blob, or its vector part */
+        ocp_nlp_memory *nm;
+        int up = -1;
+        ocp_nlp_get(lock[0]->nlp_solver, "nlp_mem", &nm);
+        ocp_qp_xcond_solver_config *qc = lock[0]->nlp_config->qp_solver;
+        qc->qp_solver->memory_get(qc->qp_solver, ((ocp_qp_xcond_solver_memory *) nm->qp_solver_mem)->solver_memory, "upload_doubles", &up);
+        fprintf(o, "time lock %.6f twin %.6f upload_doubles %d\n", t_lock, t_twin, up);
+    }
     fclose(o);
     for (int i = 0; i < n + n_twins; i++)
     {

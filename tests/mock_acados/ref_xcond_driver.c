@@ -42,6 +42,10 @@ void ocp_qp_gpu_pcond_acados_config_initialize_default(void *config_);
 void ocp_qp_gpu_pcond_acados_memory_release(void *mem_);
 int ocp_qp_gpu_xcond_solver_acados_evaluate_batch(void *config_, ocp_qp_xcond_solver_dims *dims, int n, ocp_qp_in **qp_in, ocp_qp_out **qp_out,
                                                   void *opts_, void **mem_, void *work_);
+int ocp_qp_gpu_xcond_solver_acados_condense_lhs_batch(void *config, ocp_qp_xcond_solver_dims *dims, int n, ocp_qp_in **qp_in, void *opts, void **mem,
+                                                      void *work);
+int ocp_qp_gpu_xcond_solver_acados_condense_rhs_and_solve_batch(void *config, ocp_qp_xcond_solver_dims *dims, int n, ocp_qp_in **qp_in,
+                                                                ocp_qp_out **qp_out, void *opts, void **mem, void *work);
 /* acados/dense_qp/dense_qp_common.c is not linked (full condensing is not on this path); the symbol is referenced by
  * ocp_qp_xcond_solver_dims_get_ for the "fcond" module only */
 void dense_qp_dims_get(void *config_, void *dims, const char *field, int *value) { printf("dense_qp_dims_get: not on this path\n"); exit(1); }
@@ -187,6 +191,31 @@ static int run_batch(int argc, char **argv)
         const double dt = now_s() - t0;
         if (dt < best) best = dt;
     }
+    /* the same QPs as the two halves of an RTI step (the batch counterparts of condense_lhs / condense_rhs_and_solve): preparation sends
+     * everything and condenses the matrices, feedback reads and sends only the vector members.  The feedback solution must equal the
+     * one-call solution (same data): compared below.  Best of `reps` pairs. */
+    double best_prep = 1e300, best_fb = 1e300, rti_diff = 0.0;
+    int rti_status = 0, rti_upload = -1;
+    {
+        ocp_qp_out **outs2 = calloc(n, sizeof(void *));
+        for (int i = 0; i < n; i++) outs2[i] = ocp_qp_out_assign(dims->orig_dims, calloc(1, ocp_qp_out_calculate_size(dims->orig_dims)));
+        for (int r = 0; r < reps; r++)
+        {
+            double t0 = now_s();
+            int s1 = ocp_qp_gpu_xcond_solver_acados_condense_lhs_batch(config, dims, n, ins, opts, mems, work);
+            double dt = now_s() - t0;
+            if (dt < best_prep) best_prep = dt;
+            t0 = now_s();
+            int s2 = ocp_qp_gpu_xcond_solver_acados_condense_rhs_and_solve_batch(config, dims, n, ins, outs2, opts, mems, work);
+            dt = now_s() - t0;
+            if (dt < best_fb) best_fb = dt;
+            if (s1 != 0) rti_status = s1;
+            if (s2 != 0) rti_status = s2;
+        }
+        for (int i = 0; i < n; i++) rti_diff = fmax(rti_diff, out_diff(&caps[i]->dim, outs[i], outs2[i]));
+        config->qp_solver->memory_get(config->qp_solver, ((ocp_qp_xcond_solver_memory *) mems[0])->solver_memory, "upload_doubles", &rti_upload);
+        /* (the per-capsule lines below report the state after the LAST call: the feedback half) */
+    }
     /* capsules 0 and n-1 once more through the reference's per-capsule ocp_qp_xcond_solve (device condensing module, host round trip) */
     double fvo = 0.0;
     ocp_qp_out *o2 = ocp_qp_out_assign(dims->orig_dims, calloc(1, ocp_qp_out_calculate_size(dims->orig_dims)));
@@ -228,8 +257,10 @@ static int run_batch(int argc, char **argv)
     int cond_active = -1; /* stages of the QP the device IPM ran on in the batch call: the condensed one */
     config->qp_solver->memory_get(config->qp_solver, ((ocp_qp_xcond_solver_memory *) mems[0])->solver_memory, "cond_N_active", &cond_active);
     printf("batch n %d ms_per_call %.6f status %d fused_vs_orchestrated %.17g orchestrated_status %d xcond_N %d xcond_nu0 %d cond_N_active %d res_max %.17g "
-           "unpack_in_ms %.4f copy_and_device_ms %.4f device_solve_ms %.4f pack_out_ms %.4f threads %d end\n", n,
-           best * 1e3, status, fvo, st_one, xd->N, xd->nu[0], cond_active, res_max, t_unpack * 1e3, t_call * 1e3, t_dev * 1e3, t_pack * 1e3, omp_get_max_threads());
+           "unpack_in_ms %.4f copy_and_device_ms %.4f device_solve_ms %.4f pack_out_ms %.4f threads %d rti_preparation_ms %.6f rti_feedback_ms %.6f "
+           "rti_status %d rti_vs_one_call %.17g rti_feedback_upload_doubles %d end\n", n,
+           best * 1e3, status, fvo, st_one, xd->N, xd->nu[0], cond_active, res_max, t_unpack * 1e3, t_call * 1e3, t_dev * 1e3, t_pack * 1e3, omp_get_max_threads(),
+           best_prep * 1e3, best_fb * 1e3, rti_status, rti_diff, rti_upload);
     FILE *g = fopen(argv[4], "wb");
     for (int i = 0; i < n; i++)
     {

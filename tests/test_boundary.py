@@ -7,7 +7,7 @@
     handed to the condensed QP: condense_qp_out, ocp_qp_xcond_solver.c:554-565)
   - the factorize-only contract of ocp_nlp_common.c:3946-3971: warm_start 3, iter_max 0, update_fact_exit 1,
     t0_min / lam0_min, then sensitivities
-  - FULL_CONDENSING_GPU_IPM: one block where nx + N nu <= 64, refused loudly beyond
+  - FULL_CONDENSING_GPU_IPM: one block where nx + N nu <= 64, the dense path (dense_kernels.hpp) beyond
   - the 20-slot condensing module composed the way ocp_qp_xcond_solve composes it (condensing -> inner evaluate on the
     condensed QP -> expansion), i.e. the DEVICE condensing reached through reference-shaped slots
 """
@@ -246,7 +246,7 @@ def test_factorize_only_contract(clib, monkeypatch):
 def test_full_condensing(clib, monkeypatch, capfd):
     """FULL_CONDENSING_GPU_IPM (f4 tail; the reference's module is ocp_qp_full_condensing.c:468-556): every stage in ONE
     block through the device condensing kernels where nx + N nu <= 64, against the full-space oracle -- box class and
-    a class whose state bounds / general rows become rows of the single condensed stage; refused loudly beyond"""
+    a class whose state bounds / general rows become rows of the single condensed stage; beyond one condensed stage: the dense path"""
     from acados_amd import AcadosOcpQpCondensing, AcadosOcpQpOptions, AcadosOcpQpSolver
     from acados_amd.generators import mass_spring_qp
     for qp in (load_qp("qp_test/last_qp_nonuniform_pendulum.json"), mass_spring_qp(N=4), _soft_qp(0, 2)):
@@ -263,14 +263,22 @@ def test_full_condensing(clib, monkeypatch, capfd):
         c = AcadosOcpQpCondensing(qp, 1, full=True, _clib=clib)
         xd = c.xcond_dims()
         assert c.cond_N == 1 and len(xd["nu"]) == 2 and xd["nu"][0] >= int(np.sum(qp.dims.nu)) and xd["nu"][1] == 0
-    # beyond one condensed stage: explicit refusal at creation (the process exits, as the reference's option errors do)
-    code = ("import sys, ctypes; sys.path.insert(0, %r); sys.path.insert(0, %r + '/tests');"
-            "from acados_amd import AcadosOcpQpOptions, AcadosOcpQpSolver, _lib;"
-            "from acados_amd.generators import mass_spring_qp;"
-            "lib = _lib.bind(ctypes.CDLL(%r)); o = AcadosOcpQpOptions(); o.qp_solver = 'FULL_CONDENSING_GPU_IPM';"
-            "AcadosOcpQpSolver(mass_spring_qp(N=30), o, _clib=lib); print('NOT REFUSED')") % (ROOT, ROOT, clib._name)
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
-    assert r.returncode != 0 and "NOT REFUSED" not in r.stdout and "FULL_CONDENSING_GPU_IPM" in r.stdout, (r.stdout, r.stderr)
+    # beyond one condensed STAGE (64 variables / 128 sides): the dense path (dense_kernels.hpp) -- every state but x0 condensed into ONE
+    # dense problem inside the solve, dense Cholesky; mass-spring N = 24: 25 * 3 + 8 = 83 columns, 24 * 8 state bounds as dense rows
+    qp = mass_spring_qp(N=24)
+    o = OracleQp(qp)
+    assert o.solve(default_opts(tol_stat=1e-8)) == 0
+    opts = AcadosOcpQpOptions()
+    opts.qp_solver = "FULL_CONDENSING_GPU_IPM"
+    opts.tol_stat = opts.tol_eq = opts.tol_ineq = opts.tol_comp = 1e-8
+    s = AcadosOcpQpSolver(qp, opts, _clib=clib)
+    assert s.solve() == 0
+    assert s.inf_norm_residuals().max() <= 1e-8 * (1 + 1e-3) + 1e-12
+    compare_with_oracle(lambda k, f: s.get(k, f), o, qp, 1e-5, fields=("x", "u", "pi"))
+    assert "exceeds the 64 variables" not in capfd.readouterr().out
+    # slacks are not carried by the dense path: a loud failure status, not a wrong answer
+    s2 = AcadosOcpQpSolver(_soft_qp(0, 20), opts, _clib=clib)     # chain class: 24 + 20 * 3 = 84 columns, soft rows
+    assert s2.solve() != 0
 
 
 @pytest.mark.parametrize("clib", TIERS, indirect=True)

@@ -1519,3 +1519,37 @@ def test_device_failure_is_a_status_not_an_exit_hostsim(hostsim_lib, monkeypatch
     assert s.solve() == 4            # ACADOS_QP_FAILURE (types.h:74-87)
     monkeypatch.setenv("GQP_HOSTSIM_FAIL_SYNC", "")
     assert s.solve() == 0 and np.allclose(s.get(0, "u"), u_ok, atol=1e-12)
+
+
+def _full_dense_case(clib, qps, tol=1e-8):
+    """FULL CONDENSING of any size (option full_dense; dense_kernels.hpp): every state but x0 condensed, the IPM on the dense problem,
+    expansion -- against the oracle (stage-wise Riccati IPM on the original QP) and the independent KKT residual kernel"""
+    from acados_amd import OcpQpGpuBatch
+    gb = OcpQpGpuBatch.from_qps(qps, _clib=clib)
+    for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+        gb.opts_set(f, tol)
+    gb.opts_set("full_dense", 1)
+    assert gb.solve() == 0, gb.info("status")
+    assert gb.res_compute().max() <= tol * (1.0 + 1e-3) + 1e-12, gb.res_compute()
+    worst = 0.0
+    for i, qp in enumerate(qps):
+        o = OracleQp(qp)
+        assert o.solve(default_opts(tol_stat=tol, tol_eq=tol, tol_ineq=tol, tol_comp=tol)) == 0
+        for k in range(qp.N + 1):
+            for f in ("x", "u", "pi", "lam") if k < qp.N else ("x", "lam"):
+                ref = o.get(k, f)
+                if ref.size:
+                    worst = max(worst, float(np.max(np.abs(gb.get(f, k)[i][:ref.size] - ref) / np.maximum(1.0, np.abs(ref)))))
+        assert abs(int(gb.info("iter")[i]) - o.iter) <= 3
+    return gb, worst
+
+
+def test_full_condensing_dense_path_hostsim(hostsim_lib):
+    from acados_amd.generators import lqr_instance_qp, mass_spring_qp, random_lqr_batch
+    N = 4
+    data = random_lqr_batch(N=N, batch=3, seed=31)
+    gb, worst = _full_dense_case(hostsim_lib, [lqr_instance_qp(data, i, N) for i in range(3)], tol=1e-10)
+    assert int(gb.scalar("dense_columns")) == (N + 1) * 3 + 8 and worst <= 1e-7, worst
+    # state bounds behind stage 0 become rows of the state map (mass-spring: nb = 11 = 3 inputs + 8 states per stage)
+    gb, worst = _full_dense_case(hostsim_lib, [mass_spring_qp(N=3)], tol=1e-10)
+    assert worst <= 1e-7, worst

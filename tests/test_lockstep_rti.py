@@ -89,17 +89,17 @@ def _mpc_qp(m, x0):
     return qp
 
 
-def _run(exe, m, tmp_path, twins, iters, cond_N, threads=4):
+def _run(exe, m, tmp_path, twins, iters, cond_N, threads=4, split=0):
     mf, of = str(tmp_path / "model.txt"), str(tmp_path / "out.txt")
     _write(m, mf)
-    r = subprocess.run([exe, mf, of, str(twins), str(iters), str(cond_N), str(threads)], capture_output=True, text=True, timeout=1500)
+    r = subprocess.run([exe, mf, of, str(twins), str(iters), str(cond_N), str(threads), str(split)], capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
     rows = {"lock": {}, "twin": {}}
     times = None
     for ln in open(of).read().splitlines():
         p = ln.split()
         if p[0] == "time":
-            times = (float(p[2]), float(p[4]))
+            times = (float(p[2]), float(p[4]), int(p[6]))
             continue
         iu, ix = p.index("u0"), p.index("x1")
         rows[p[0]][(int(p[1]), int(p[2]))] = dict(status=int(p[4]), qp_status=int(p[6]), qp_iter=int(p[8]),
@@ -108,14 +108,18 @@ def _run(exe, m, tmp_path, twins, iters, cond_N, threads=4):
 
 
 @pytest.mark.parametrize("clib", TIERS, indirect=True)
+@pytest.mark.parametrize("split", [0, 1], ids=["one-call", "preparation+feedback"])
 @pytest.mark.parametrize("cond_N", [5, 0], ids=["condensed", "full-space"])
-def test_lock_step_rti_loop_end_to_end(clib, tmp_path, cond_N, request):
+def test_lock_step_rti_loop_end_to_end(clib, tmp_path, cond_N, split, request):
+    """split = 1: every step as the two halves of real-time iteration through the same generated function -- rti_phase PREPARATION (per
+    capsule on host threads, then ocp_qp_gpu_xcond_solver_acados_condense_lhs_batch: all matrices to the device, condensed there), the
+    new x0, rti_phase FEEDBACK (ocp_qp_gpu_xcond_solver_acados_condense_rhs_and_solve_batch: only the QPs' vector members travel)"""
     gpu = "gpu" in request.node.callspec.id
     N, iters = 20, 5
     n, twins = (1024, 24) if gpu else (6, 3)
     m = _model(N, n, seed=7)
     exe = _exe(clib._name)
-    rows, times, log = _run(exe, m, tmp_path, twins, iters, cond_N if cond_N else N)
+    rows, times, log = _run(exe, m, tmp_path, twins, iters, cond_N if cond_N else N, split=split)
     assert "wrong field" not in log and "batch_phase" not in log, log
     assert len(rows["lock"]) == n * iters and len(rows["twin"]) == twins * iters
     # every capsule of every step: NLP status SUCCESS, QP converged
@@ -136,9 +140,13 @@ def test_lock_step_rti_loop_end_to_end(clib, tmp_path, cond_N, request):
         lk = rows["lock"][(0, i)]
         assert np.allclose(lk["u0"], o.get(0, "u"), atol=2e-6) and np.allclose(lk["x1"], o.get(1, "x"), atol=2e-6), (i, lk["u0"], o.get(0, "u"))
         assert np.all(np.abs(lk["u0"]) <= m["umax"] + 1e-9)
+    # what the last batch call sent per QP: the whole input blob (N (nx (nx + nu + 1) + ...) doubles), or -- feedback half of a split
+    # step -- the vector members only
+    full_blob = N * (8 * 8 + 8 * 3 + 8) + (N + 1) * (8 * 8 + 8 + 3) + N * (9 + 3 * 8 + 3)
+    assert (times[2] < 0.3 * full_blob) if split else (times[2] > 0.9 * full_blob), (times[2], full_blob)
     # the closed loop moves: later steps solve different QPs
     assert np.abs(rows["lock"][(iters - 1, 0)]["x1"] - rows["lock"][(0, 0)]["x1"]).max() > 1e-3
-    print(f"lock-step: {n} capsules x {iters} RTI steps {times[0] * 1e3:.1f} ms; per-capsule loop on {twins} twins {times[1] * 1e3:.1f} ms; "
+    print(f"lock-step ({'preparation + feedback' if split else 'one call per step'}): {n} capsules x {iters} RTI steps {times[0] * 1e3:.1f} ms; per-capsule loop on {twins} twins {times[1] * 1e3:.1f} ms; "
           f"max |lock - twin| {worst:.2e}")
 
 

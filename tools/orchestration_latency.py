@@ -13,5 +13,6 @@ _write_qp(lqr_instance_qp(random_lqr_batch(N=50, batch=1, seed=5), 0, 50), f)
 env = dict(os.environ, OMP_NUM_THREADS="16")
 env.pop("ACADOS_AMD_WPI_BATCH_MAX", None)
 for n in [int(a) for a in sys.argv[1:]] or [1024, 4096]:
-    r = subprocess.run([exe, "batch", str(n), f, os.path.join(d, "b.bin"), "--cond-N", "10", "5"], capture_output=True, text=True, env=env)
-    print(r.stdout.splitlines()[0], flush=True)
+    for label, extra in (("panel runs (probed layout)", {}), ("blasfeo_unpack_* per block (ACADOS_AMD_LA_API=1)", {"ACADOS_AMD_LA_API": "1"})):
+        r = subprocess.run([exe, "batch", str(n), f, os.path.join(d, "b.bin"), "--cond-N", "10", "5"], capture_output=True, text=True, env=dict(env, **extra))
+        print(label, "|", r.stdout.splitlines()[0] if r.stdout else r.stderr[-300:], flush=True)
