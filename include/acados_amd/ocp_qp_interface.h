@@ -245,7 +245,7 @@ typedef struct
     int N2_bkp;
     int ric_alg;
     int mem_qp_in;
-    int full_condensing;     /* the FULL_CONDENSING flavour: N2 = 1 and a loud refusal instead of the full-space fall-back */
+    int full_condensing;     /* the FULL_CONDENSING flavour: N2 = 1; past what one condensed stage carries: the dense path inside the solve (dense_kernels.hpp) */
     int *block_size;
     bool block_size_was_set;
 } ocp_qp_partial_condensing_opts;
@@ -424,7 +424,7 @@ void ocp_qp_gpu_xcond_solver_terminate(void *config, void *mem, void *work);
 acados_size_t ocp_qp_xcond_solver_config_calculate_size(void);
 ocp_qp_xcond_solver_config *ocp_qp_xcond_solver_config_assign(void *raw_memory);
 /* accepted names: "PARTIAL_CONDENSING_GPU_IPM", as the drop-in alias that keeps existing scripts unchanged
- * "PARTIAL_CONDENSING_HPIPM", and "FULL_CONDENSING_GPU_IPM" (one block: nx + N nu <= 64, refused loudly beyond);
+ * "PARTIAL_CONDENSING_HPIPM", and "FULL_CONDENSING_GPU_IPM" (one block where nx + N nu <= 64; the dense path of dense_kernels.hpp beyond);
  * anything else returns NULL after printing the reference's message */
 ocp_qp_xcond_solver_config *ocp_qp_xcond_solver_config_create_from_name(const char *qp_solver_name);
 void ocp_qp_xcond_solver_config_free(ocp_qp_xcond_solver_config *config);

@@ -372,6 +372,17 @@ static void prefetch_qp_in(const ocp_qp_in *in)
     }
 }
 
+static void prefetch_qp_vec(const ocp_qp_in *in)
+{
+    const ocp_qp_dims *d = in->dim;
+    for (int k = 0; k <= d->N; k++)
+    {
+        const struct blasfeo_dvec *vs[4] = {in->rqz + k, in->d + k, in->d_mask + k, in->b + k};
+        for (int q = 0; q < 4; q++)
+            for (int o = 0; o < vs[q]->m * (int) sizeof(double); o += 64) __builtin_prefetch((const char *) vs[q]->pa + o, 0, 1);
+    }
+}
+
 static void apply_opts(ocp_qp_gpu_batch *b, const ocp_qp_gpu_ipm_opts *o, int ws)
 {
     ocp_qp_gpu_batch_opts_set(b, "iter_max", &o->iter_max);
@@ -673,6 +684,7 @@ static int evaluate_batch_masked(void *config, int n, void **qp_in_, void **qp_o
         for (int i = 0; i < n; i++)
         {
             gpu_bucket *bk = g->bk + g->bucket_of[i];
+            if (i + 1 < n) prefetch_qp_vec(ins[i + 1]);
             unpack_qp_vec(&bk->lay, ins[i], bk->blob_in + (size_t) g->pos_of[i] * (size_t) bk->L_vec);
             if (ws >= 2) unpack_qp_out_duals(&bk->lay, outs[i], bk->blob_out + (size_t) g->pos_of[i] * (size_t) bk->L_out);
         }
