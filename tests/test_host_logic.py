@@ -1553,3 +1553,29 @@ def test_full_condensing_dense_path_hostsim(hostsim_lib):
     # state bounds behind stage 0 become rows of the state map (mass-spring: nb = 11 = 3 inputs + 8 states per stage)
     gb, worst = _full_dense_case(hostsim_lib, [mass_spring_qp(N=3)], tol=1e-10)
     assert worst <= 1e-7, worst
+
+
+def test_full_condensing_dense_path_random_structures_hostsim(hostsim_lib):
+    """the dense path on random STRUCTURES without slacks (per-stage dims, box subsets, one-sided rows through the masks, general rows,
+    x0 fixed or free): converged, KKT residuals of the ORIGINAL QP by the independent kernel, primal solution against the oracle"""
+    from acados_amd import OcpQpGpuBatch
+    from random_qp import random_structure_qp
+    done = 0
+    for seed in range(14):
+        qp = random_structure_qp(seed, allow_slack=False)
+        o = OracleQp(qp)
+        if o.solve(default_opts(tol_stat=1e-10, tol_eq=1e-10, tol_ineq=1e-10, tol_comp=1e-10)) != 0:
+            continue
+        gb = OcpQpGpuBatch.from_qps([qp, qp], _clib=hostsim_lib)
+        for f in ("tol_stat", "tol_eq", "tol_ineq", "tol_comp"):
+            gb.opts_set(f, 1e-10)
+        gb.opts_set("full_dense", 1)
+        assert gb.solve() == 0, (seed, gb.info("status"))
+        assert gb.res_compute().max() <= 1e-10 * (1.0 + 1e-3) + 1e-12, (seed, gb.res_compute())
+        for k in range(qp.N + 1):
+            for f in ("x", "u") if k < qp.N else ("x",):
+                ref = o.get(k, f)
+                if ref.size:
+                    assert np.allclose(gb.get(f, k)[1][:ref.size], ref, rtol=1e-6, atol=1e-7), (seed, k, f)
+        done += 1
+    assert done >= 10
