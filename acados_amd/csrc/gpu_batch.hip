@@ -220,7 +220,8 @@ struct ocp_qp_gpu_batch
     int compact_min = 1 << 30;           /* levels smaller than this are not compacted; off by default: it only
                                             pays once every sweep kernel is bandwidth-bound */
     ocp_qp_gpu_batch *tail = nullptr;    /* wave-per-instance sub-batch for the last survivors of a one-instance-per-lane level */
-    int tail_max = 12288;                /* switch to it when at most this many instances (and a quarter of the level) remain; 0 = off */
+    int tail_max = 12288;                /* switch to it when at most this many instances (and 1 / tail_div of the level) remain; 0 = off */
+    int tail_div = 4;
     int n_tail_switches = 0;
     /* solution sensitivities / factor at the solution */
     bool factor_stale = false;           /* the last solve finished instances on a sub-level: Lf of the root is not theirs */
@@ -1114,6 +1115,7 @@ try
     }
     else if (!strcmp(f, "compact_min")) b->compact_min = *i;
     else if (!strcmp(f, "tail_max")) b->tail_max = *i;
+    else if (!strcmp(f, "tail_div")) b->tail_div = *i < 1 ? 1 : *i;
     else if (!strcmp(f, "solve_max")) b->solve_max = *i;
     else if (!strcmp(f, "cond_N"))
     {
@@ -1588,7 +1590,7 @@ static void run_ipm(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch *root, Prof &prof, hip
             D.n_perm = nact;
             b->w16_slots = nact;
         }
-        if (!b->wpi && root->tail_max > 0 && nact <= root->tail_max && 4 * nact <= b->B)
+        if (!b->wpi && root->tail_max > 0 && nact <= root->tail_max && (long) root->tail_div * nact <= b->B)
         {
             /* the last survivors of a one-instance-per-lane level: a wave that still has ONE active lane pays
              * the full per-wave latency of every sweep, so the tail continues one wave per instance */
@@ -1741,6 +1743,7 @@ static void compact_into(ocp_qp_gpu_batch *b, ocp_qp_gpu_batch *root, int nact, 
         c->idxb = b->idxb; c->idxs_rev = b->idxs_rev; c->idxe = b->idxe; c->nbxe = b->nbxe;
         c->compact_min = b->compact_min;
         c->tail_max = b->tail_max;
+        c->tail_div = b->tail_div;
         if (!tail) { c->aos = b->aos; c->wpi = b->wpi; c->shmem = b->shmem; c->shmem_fwd = b->shmem_fwd; c->shmem_fact = b->shmem_fact; c->w16 = b->w16; c->w16_soft = b->w16_soft; c->w16_ng = b->w16_ng; c->w16_shmem = b->w16_shmem; c->w16_shmem_fact = b->w16_shmem_fact; c->w16_tiles = b->w16_tiles; }
         finalize_structure(c);
         slot = c;

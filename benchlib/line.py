@@ -35,7 +35,7 @@ def _pick(d, keys, sig=5):
     return {k: _r(d[k], sig) for k in keys if isinstance(d, dict) and k in d and not isinstance(d[k], (dict, list))}
 
 
-DIST_KEYS = ("median", "q99", "max", "above_1e-6", "instances")
+DIST_KEYS = ("median", "q99", "max", "above_1e-6")
 
 
 def _dist(rec):

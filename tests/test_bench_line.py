@@ -20,7 +20,7 @@ def strict_loads(s):
     return json.loads(s, parse_constant=bad)
 
 
-@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[345]_v*_bench.json"))))
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[3456]_v*_bench.json"))))
 def test_committed_lines_compact_below_the_limit(path):
     full = json.load(open(path))
     if "roofline" not in full:
@@ -37,7 +37,8 @@ def test_committed_lines_compact_below_the_limit(path):
     if "configs" in full:
         assert set(j["configs"]) == set(full["configs"])
         for name, c in j["configs"].items():
-            assert c["solves_per_s"] == pytest.approx(full["configs"][name]["solves_per_s"], rel=1e-3)
+            if "solves_per_s" in full["configs"][name]:       # (a leg that was skipped on the box carries its reason instead)
+                assert c["solves_per_s"] == pytest.approx(full["configs"][name]["solves_per_s"], rel=1e-3)
 
 
 def test_the_round4_line_that_was_lost():
