@@ -1119,7 +1119,7 @@ def test_device_against_certified_dense_solutions_gpu(gpu_lib, monkeypatch):
     interior point to the vertex: measured 2e-12 ... 3e-11 relative on the primal solution, asserted at 1e-9."""
     from dense_ref import solve_exact, split
     from acados_amd import OcpQpGpuBatch
-    from acados_amd.generators import chain_soft_qp, lqr_instance_qp, multiphase_batch, multiphase_instance_qp, random_lqr_batch
+    from acados_amd.generators import chain_soft_qp, lqr_instance_qp, mass_spring_qp, multiphase_batch, multiphase_instance_qp, random_lqr_batch
     c2 = random_lqr_batch(N=50, nx=8, nu=3, batch=2, seed=0)
     d12 = random_lqr_batch(N=20, nx=12, nu=3, batch=1, seed=203)
     d24 = random_lqr_batch(N=20, nx=24, nu=6, batch=1, seed=206)
@@ -1131,7 +1131,11 @@ def test_device_against_certified_dense_solutions_gpu(gpu_lib, monkeypatch):
              ("nx=24", [lqr_instance_qp(d24, 0, 20)], {}, 0, "w16r-box<NX=24"),
              ("multi-phase", [multiphase_instance_qp(dm, 0)], {}, 0, "w16-box<NX=12"),
              ("C4 class", [chain_soft_qp(1, N=10)], {}, 0, "w16r-gen<NX=24,NU=3,NG=4>"),
-             ("ng=8 chain class", [chain_soft_qp(2, N=10, ng=8)], {}, 0, "w16r-gen<NX=24,NU=3,NG=8>")]
+             ("ng=8 chain class", [chain_soft_qp(2, N=10, ng=8)], {}, 0, "w16r-gen<NX=24,NU=3,NG=8>"),
+             # the dense path of full condensing (dense_kernels.hpp): C2 (161 dense columns) and the mass-spring class, whose state
+             # bounds behind stage 0 become rows of the state map
+             ("C2 full condensing, dense path", [lqr_instance_qp(c2, i, 50) for i in range(2)], {"ACADOS_AMD_WPI": "0"}, -1, "1tpi-box"),
+             ("mass-spring N=20 full condensing, dense path", [mass_spring_qp(N=20)], {}, -1, "")]
     worst = {}
     for name, qps, env, cond, fam in cases:
         for k_, v_ in env.items():
@@ -1140,11 +1144,13 @@ def test_device_against_certified_dense_solutions_gpu(gpu_lib, monkeypatch):
         for f, v in (("tol_stat", 1e-9), ("tol_eq", 1e-11), ("tol_ineq", 1e-11), ("tol_comp", 1e-12)):
             b.opts_set(f, v)
         b.opts_set("iter_max", 100)
-        if cond:
+        if cond > 0:
             b.opts_set("cond_N", cond)
+        if cond < 0:
+            b.opts_set("full_dense", 1)
         assert b.solve() == 0, name
         assert b.kernel_name.startswith(fam), (name, b.kernel_name)
-        if cond:
+        if cond > 0:
             assert int(b.scalar("cond_N_active")) == cond
         for i, qp in enumerate(qps):
             w, off, info = solve_exact(qp)
