@@ -116,9 +116,9 @@ def test_lock_step_rti_loop_end_to_end(clib, tmp_path, cond_N, split, request):
     new x0, rti_phase FEEDBACK (ocp_qp_gpu_xcond_solver_acados_condense_rhs_and_solve_batch: only the QPs' vector members travel)"""
     gpu = "gpu" in request.node.callspec.id
     N, iters = 20, 5
-    # (GPU tier: the 1,024-capsule run the review asked for on the condensed one-call variant; 256 capsules on the other three -- creating a
+    # (GPU tier: the 1,024-capsule run the review asked for on the condensed one-call variant; 128 capsules on the other three -- creating a
     #  capsule is 50 ms of reference code, most of such a test's time)
-    n, twins = ((1024, 24) if cond_N and not split else (256, 12)) if gpu else (6, 3)
+    n, twins = ((1024, 24) if cond_N and not split else (128, 8)) if gpu else (6, 3)
     m = _model(N, n, seed=7)
     exe = _exe(clib._name)
     rows, times, log = _run(exe, m, tmp_path, twins, iters, cond_N if cond_N else N, split=split)
