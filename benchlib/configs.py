@@ -270,6 +270,26 @@ def write_driver_qp(qp, path):
                     f.write(f"{name} {k} {v.size} " + " ".join(repr(float(x)) for x in v) + "\n")
 
 
+def pcie_rates(mb=256, reps=3):
+    """what THIS box moves over PCIe from / to pinned host memory (one stream, large copies): the practical ceiling of the boundary leg,
+    beside the 63 GB/s spec figure of the guide"""
+    try:
+        import torch
+        h = torch.empty(mb << 20, dtype=torch.uint8).pin_memory()
+        d = torch.empty(mb << 20, dtype=torch.uint8, device="cuda")
+        out = {}
+        for name, (dst, src) in (("h2d", (d, h)), ("d2h", (h, d))):
+            dst.copy_(src, non_blocking=True); torch.cuda.synchronize()
+            best = 1e9
+            for _ in range(reps):
+                t0 = time.perf_counter(); dst.copy_(src, non_blocking=True); torch.cuda.synchronize()
+                best = min(best, time.perf_counter() - t0)
+            out[name + "_GBps"] = (mb << 20) / best / 1e9
+        return out
+    except Exception as e:       # (no torch / no device: the leg still reports its times)
+        return {"error": str(e)[:80]}
+
+
 def boundary_c3(n=4096, reps=4):
     """THROUGH THE BOUNDARY: n C3-shaped capsules (N = 50, nx = 8, nu = 3, cond_N = 10), each an acados `ocp_qp_in` / `ocp_qp_out` pair
     (HPIPM structs, panel-major BLASFEO storage: the stand-ins of tests/mock_hpipm -- the real ones are empty submodules of the
@@ -315,5 +335,6 @@ def boundary_c3(n=4096, reps=4):
                               "pcie_bytes": n * (8 * int(info.get("rti_feedback_upload_doubles", 0)) + b_out)}
                              if info.get("rti_feedback_ms") else None),
             "pcie_bytes": pcie, "pcie_GBps": pcie / t / 1e9, "pcie_peak_GBps": PCIE_PEAK_GBS, "pcie_frac": pcie / t / 1e9 / PCIE_PEAK_GBS,
+            "pcie_measured": pcie_rates(),
             "pcie_note": "algorithmic bytes of SURVEY 8d per QP (85,336 in + 12,720 out; the blob also carries 0/1 masks) over the WHOLE call; "
                          "every call re-reads every member array of every qp_in (ocp_nlp_common.c:2797-2894: they alias ocp_nlp memory)"}

@@ -88,6 +88,8 @@ def compact_line(out, detail_path=None):
             ro_c = c.get("roofline") or c.get("roofline_of_slowest_class") or {}
             rec = _pick(c, ("batch", "solves_per_s", "ms_per_step", "mean_iter", "failures", "max_rel_primal_err_vs_oracle",
                             "condense_expand_ms", "solves_per_s_one_after_the_other", "polished", "host_threads", "pcie_GBps", "pcie_frac", "skipped", "error"), 4)
+            if isinstance(c.get("pcie_measured"), dict) and "h2d_GBps" in c["pcie_measured"]:
+                rec["pcie_h2d_d2h_GBps"] = [_r(c["pcie_measured"]["h2d_GBps"], 3), _r(c["pcie_measured"].get("d2h_GBps"), 3)]
             if c.get("rti_feedback"):
                 rec["rti_feedback_solves_per_s"] = _r(c["rti_feedback"]["solves_per_s"], 4)
                 rec["rti_feedback_ms"] = _r(c["rti_feedback"]["ms_per_step"], 4)

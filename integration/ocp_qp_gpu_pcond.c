@@ -27,8 +27,13 @@
  * Dims of the condensed QP: computed by the device library (the ONE place that decides which classes are condensable and how
  * rows are ordered), asked of a one-instance probe batch when the memory is sized.  Two deliberate differences to
  * d_part_cond_qp_compute_dim, neither of which changes the solution of the ORIGINAL QP:
- *   - x0 is not eliminated (HPIPM's d_ocp_qp_reduce_eq_dof, :542): stage 0 of the condensed QP keeps nx[0] states with the
- *     equality-flagged bounds (idxe), which every solver behind the inner vtable has to honour anyway;
+ *   - (round 6: no longer a difference) x0 IS eliminated before condensing as HPIPM's d_ocp_qp_reduce_eq_dof does (:542): the
+ *     states of stage 0 that equality-flagged bounds fix (idxe) leave the QP on the host -- A_0 x0 goes into b_0, H_0[., F] x0 into
+ *     [r_0; q_0], C_0 x0 into the general bounds -- the device condenses the REDUCED QP (nx[0] smaller by nbxe[0], the rows gone), and
+ *     the expansion puts x0 back and recovers the multipliers of its rows from stationarity (d_ocp_qp_restore_eq_dof, :683).  xcond
+ *     dims / pcond_* getters show what HPIPM's show at stage 0.  Option "reduce_eq_dof" = 0 keeps the rows (the device masks the
+ *     fixed variables itself: what the fused batch route does);
+ *   - block inputs are padded to the condensing kernel's NU where blocks differ in size;
  *   - a non-zero LAST block size (block_size[N2] > 0, e.g. [6,5,4,2,2,1] of pcond_getters_test.py:200) gives one more stage
  *     with inputs in front of an input-free terminal stage (N2 + 1 stages with inputs) instead of inputs in the terminal stage.
  * A class the device does not condense (more than 64 rows in a condensed stage, ...) is handed through with N2 = N -- the
@@ -67,6 +72,8 @@ void ocp_qp_gpu_ipm_acados_config_initialize_default(void *config_);
 typedef struct
 {
     ocp_qp_dims *orig_dims;
+    ocp_qp_dims *red_dims;       /* orig_dims with the equality-flagged states of stage 0 eliminated (d_ocp_qp_dim_reduce_eq_dof) */
+    int reduced;                 /* red_dims differs from orig_dims */
     ocp_qp_dims *pcond_dims;
     int *block_size;             /* N + 1 entries */
     int condensed;               /* 0: handed through (N2 = N, or a class the device does not condense) */
@@ -82,6 +89,7 @@ typedef struct
     int *block_size;             /* N + 1 entries */
     bool block_size_was_set;
     int mem_qp_in;
+    int reduce_eq_dof;           /* 1 (default, as the reference: :542): x0 is eliminated on the host before the device condenses */
     int batch_owned;             /* the capsule's QPs are condensed by the BATCH entries (ocp_qp_gpu_xcond_solver_acados_condense_lhs_batch ...): the
                                     per-capsule condense_lhs slot of an RTI preparation step has nothing to do (option "cond_batch_owned") */
 } ocp_qp_gpu_pcond_opts;
@@ -102,6 +110,15 @@ typedef struct
     ocp_qp_in *ptr_qp_in;        /* last condensed (the seed pair needs it) */
     ocp_qp_seed *ptr_seed;
     int seeds_resident;          /* the parent batch holds the seeds as its vector fields (between the two seed slots) */
+    /* x0 elimination (d_ocp_qp_reduce_eq_dof / _restore_eq_dof, :542 / :683), host side: containers of the REDUCED original QP.  Stages
+     * 1..N alias the caller's member structs (same dims); stage 0 is this memory's own */
+    ocp_qp_in *red_in;
+    ocp_qp_out *red_out, *red_sens;
+    ocp_qp_seed *red_seed;
+    ocp_qp_in *src_in;           /* what the device holds: red_in, or ptr_qp_in where nothing is eliminated */
+    int nF, *f_ib, *f_iv, *f_sign; /* fixed states of stage 0: box row, variable (index in [u; x]), sign of its multiplier at the solution */
+    int *map_var, *map_row;      /* stage 0: variable / box row -> index in the reduced QP, -1: eliminated */
+    double *xbar, *dxbar;        /* value of every eliminated variable (indexed like map_var), and its seed in a sensitivity solve */
 } ocp_qp_gpu_pcond_memory;
 
 static double pc_now_s(void)
@@ -125,7 +142,7 @@ static void copy_dims(const ocp_qp_dims *s, ocp_qp_dims *d)
 
 static acados_size_t pc_dims_calculate_size(void *config, int N)
 {
-    return size8(sizeof(ocp_qp_gpu_pcond_dims) + 2 * ocp_qp_dims_calculate_size(N) + sizeof(int) * (size_t) (N + 1) + 4 * 8);
+    return size8(sizeof(ocp_qp_gpu_pcond_dims) + 3 * ocp_qp_dims_calculate_size(N) + sizeof(int) * (size_t) (N + 1) + 5 * 8);
 }
 
 static void *pc_dims_assign(void *config, int N, void *raw_memory)
@@ -135,6 +152,7 @@ static void *pc_dims_assign(void *config, int N, void *raw_memory)
     memset(dims, 0, sizeof(*dims));
     c = align8(c + sizeof(*dims));
     dims->orig_dims = ocp_qp_dims_assign(N, c); c = align8(c + ocp_qp_dims_calculate_size(N));
+    dims->red_dims = ocp_qp_dims_assign(N, c); c = align8(c + ocp_qp_dims_calculate_size(N));
     dims->pcond_dims = ocp_qp_dims_assign(N, c); c = align8(c + ocp_qp_dims_calculate_size(N)); /* worst case: N2 = N */
     dims->block_size = (int *) c;
     for (int i = 0; i <= N; i++) dims->block_size[i] = i < N ? 1 : 0;
@@ -155,15 +173,29 @@ static void pc_dims_get(void *config, void *dims_, const char *field, void *valu
     else { printf("\nerror: ocp_qp_partial_condensing_dims_get: field %s not available\n", field); exit(1); }
 }
 
+/* d_ocp_qp_dim_reduce_eq_dof (:171): the states of stage 0 fixed by equality-flagged bounds leave the QP */
+static void pc_fill_red_dims(ocp_qp_gpu_pcond_dims *dims, int reduce)
+{
+    copy_dims(dims->orig_dims, dims->red_dims);
+    ocp_qp_dims *r = dims->red_dims;
+    dims->reduced = 0;
+    if (!reduce || r->nbxe[0] <= 0) return;
+    const int nf = r->nbxe[0];
+    r->nx[0] -= nf; r->nbx[0] -= nf; r->nb[0] -= nf;
+    r->nbxe[0] = 0; r->nbue[0] = 0; r->nge[0] = 0; /* (flags of input bounds / general rows carry no meaning on the device: lb = ub pairs) */
+    dims->reduced = 1;
+}
+
 /* dims of the condensed QP for (orig_dims, N2, block sizes): asked of the device library (see the header comment) */
 static void pc_compute_dims(ocp_qp_gpu_pcond_dims *dims, const ocp_qp_gpu_pcond_opts *opts)
 {
-    const ocp_qp_dims *d = dims->orig_dims;
+    pc_fill_red_dims(dims, opts->reduce_eq_dof);
+    const ocp_qp_dims *d = dims->red_dims;
     const int N = d->N, N2 = opts->N2;
     {
         unsigned long long h = 1469598103934665603ull; /* FNV-1a over everything the result depends on */
 #define MIX(v) h = (h ^ (unsigned long long) (unsigned) (v)) * 1099511628211ull
-        MIX(N); MIX(N2); MIX(opts->block_size_was_set ? 1 : 0);
+        MIX(N); MIX(N2); MIX(opts->block_size_was_set ? 1 : 0); MIX(opts->reduce_eq_dof); MIX(dims->orig_dims->nbxe[0]);
         for (int k = 0; k <= N; k++) { MIX(d->nx[k]); MIX(d->nu[k]); MIX(d->nbx[k]); MIX(d->nbu[k]); MIX(d->ng[k]); MIX(d->ns[k]); MIX(d->nbxe[k]); }
         if (opts->block_size_was_set && N2 > 0 && N2 < N) for (int i = 0; i <= N2; i++) MIX(opts->block_size[i]);
 #undef MIX
@@ -231,7 +263,8 @@ static acados_size_t pc_opts_calculate_size(void *dims_)
     ocp_qp_gpu_pcond_dims *dims = (ocp_qp_gpu_pcond_dims *) dims_;
     /* "(temporarily) populate dimensions of new ocp_qp based on N2 == N" (:175-181): the outer solver sizes the QP solver's
      * opts from xcond_dims right after this call (ocp_qp_xcond_solver.c:195-203) */
-    copy_dims(dims->orig_dims, dims->pcond_dims);
+    pc_fill_red_dims(dims, 1);
+    copy_dims(dims->red_dims, dims->pcond_dims);
     dims->probe_valid = 0;
     return size8(sizeof(ocp_qp_gpu_pcond_opts) + sizeof(int) * (size_t) (dims->orig_dims->N + 1) + 3 * 8);
 }
@@ -257,6 +290,8 @@ static void pc_opts_initialize_default(void *dims_, void *opts_)
     opts->ric_alg = 0;
     opts->block_size_was_set = false;
     opts->mem_qp_in = 1;
+    opts->reduce_eq_dof = 1;
+    opts->batch_owned = 0;
     dims->pcond_dims->N = opts->N2;
 }
 
@@ -275,6 +310,7 @@ static void pc_opts_set(void *opts_, const char *field, void *value)
     else if (!strcmp(field, "N_bkp")) opts->N2_bkp = *(int *) value;
     else if (!strcmp(field, "ric_alg")) opts->ric_alg = *(int *) value;
     else if (!strcmp(field, "batch_owned")) opts->batch_owned = *(int *) value;
+    else if (!strcmp(field, "reduce_eq_dof")) opts->reduce_eq_dof = *(int *) value; /* (before memory_calculate_size: the dims follow) */
     else if (!strcmp(field, "block_size"))
     {
         const int *v = (const int *) value;
@@ -301,8 +337,11 @@ static acados_size_t pc_memory_calculate_size(void *dims_, void *opts_)
     ocp_qp_gpu_pcond_opts *opts = (ocp_qp_gpu_pcond_opts *) opts_;
     pc_compute_dims(dims, opts);
     const size_t nst = (size_t) dims->orig_dims->N + 1;
+    const int nv0 = dims->orig_dims->nu[0] + dims->orig_dims->nx[0], nr0 = dims->orig_dims->nb[0] + dims->orig_dims->ng[0];
     return size8(sizeof(ocp_qp_gpu_pcond_memory) + ocp_qp_in_calculate_size(dims->pcond_dims) + ocp_qp_out_calculate_size(dims->pcond_dims)
                  + ocp_qp_seed_calculate_size(dims->pcond_dims) + sizeof(double) * pc_blob_cap(dims->orig_dims, dims->pcond_dims)
+                 + ocp_qp_in_calculate_size(dims->red_dims) + 2 * ocp_qp_out_calculate_size(dims->red_dims) + ocp_qp_seed_calculate_size(dims->red_dims)
+                 + sizeof(int) * (size_t) (4 * nv0 + nr0 + 8) + 2 * sizeof(double) * (size_t) (nv0 + 1) + 10 * 8
                  + 2 * sizeof(gpu_seg) * nst * (SEGS_IN_PER_STAGE + SEGS_OUT_PER_STAGE + SEGS_SEED_PER_STAGE)
                  + 2 * sizeof(int) * (size_t) sig_len(dims->orig_dims) + 10 * 8);
 }
@@ -335,6 +374,21 @@ static void *pc_memory_assign(void *dims_, void *opts_, void *raw_memory)
     mem->sig_cap = sig_len(dims->orig_dims);
     mem->sig = (int *) c; c += sizeof(int) * (size_t) mem->sig_cap;
     mem->sig_scratch = (int *) c; c += sizeof(int) * (size_t) mem->sig_cap;
+    c = align8(c);
+    mem->red_in = ocp_qp_in_assign(dims->red_dims, c); c = align8(c + ocp_qp_in_calculate_size(dims->red_dims));
+    mem->red_out = ocp_qp_out_assign(dims->red_dims, c); c = align8(c + ocp_qp_out_calculate_size(dims->red_dims));
+    mem->red_sens = ocp_qp_out_assign(dims->red_dims, c); c = align8(c + ocp_qp_out_calculate_size(dims->red_dims));
+    mem->red_seed = ocp_qp_seed_assign(dims->red_dims, c); c = align8(c + ocp_qp_seed_calculate_size(dims->red_dims));
+    {
+        const int nv0 = dims->orig_dims->nu[0] + dims->orig_dims->nx[0], nr0 = dims->orig_dims->nb[0] + dims->orig_dims->ng[0];
+        mem->xbar = (double *) c; c = align8(c + sizeof(double) * (size_t) (nv0 + 1));
+        mem->dxbar = (double *) c; c = align8(c + sizeof(double) * (size_t) (nv0 + 1));
+        mem->f_ib = (int *) c; c += sizeof(int) * (size_t) nv0;
+        mem->f_iv = (int *) c; c += sizeof(int) * (size_t) nv0;
+        mem->f_sign = (int *) c; c += sizeof(int) * (size_t) nv0;
+        mem->map_var = (int *) c; c += sizeof(int) * (size_t) nv0;
+        mem->map_row = (int *) c; c += sizeof(int) * (size_t) (nr0 + 1);
+    }
     mem->dims = dims;
     return mem;
 }
@@ -536,6 +590,274 @@ static void pc_copy_seed(ocp_qp_seed *a, ocp_qp_seed *b)
     }
 }
 
+
+/* ------------------------------------------------------------------ x0 elimination on the host (:542, :683)
+ *
+ * d_ocp_qp_reduce_eq_dof / d_ocp_qp_restore_eq_dof restated for what acados flags: states of stage 0 fixed by equality-flagged
+ * bounds (idxe, the [bxe] part).  With F the fixed states, xbar their values (the lower bound) and [u; x_keep] the variables left:
+ *     b_0 += A_0[:, F] xbar,   [r_0; q_0]_keep += H_0[keep, F] xbar,   lg_0 -= C_0[:, F] xbar,  ug_0 likewise,   rows of F leave.
+ * Stages 1..N of the reduced containers ALIAS the caller's member structs (same dims, read on every call).  Element access through
+ * BLASFEO_DMATEL / BLASFEO_DVECEL: one stage, a few hundred elements. */
+#define RSQ_SYM(in_, i_, j_) ((i_) >= (j_) ? BLASFEO_DMATEL((in_)->RSQrq, (i_), (j_)) : BLASFEO_DMATEL((in_)->RSQrq, (j_), (i_)))
+
+static void pc_alias_in_tail(const ocp_qp_in *in, ocp_qp_in *r)
+{
+    const int N = in->dim->N;
+    for (int k = 1; k <= N; k++)
+    {
+        if (k < N) { r->BAbt[k] = in->BAbt[k]; r->b[k] = in->b[k]; }
+        r->RSQrq[k] = in->RSQrq[k]; r->DCt[k] = in->DCt[k]; r->rqz[k] = in->rqz[k]; r->d[k] = in->d[k]; r->d_mask[k] = in->d_mask[k];
+        r->m[k] = in->m[k]; r->Z[k] = in->Z[k];
+        r->idxb[k] = in->idxb[k]; r->idxs_rev[k] = in->idxs_rev[k]; r->idxe[k] = in->idxe[k];
+        r->diag_H_flag[k] = in->diag_H_flag[k];
+    }
+}
+
+/* the reduced original QP (or qp_in itself where nothing is eliminated); fills the maps the other helpers use */
+static ocp_qp_in *pc_reduce_in(ocp_qp_gpu_pcond_memory *mem, ocp_qp_in *in)
+{
+    if (!mem->dims->reduced) { mem->nF = 0; mem->src_in = in; return in; }
+    ocp_qp_in *r = mem->red_in;
+    const ocp_qp_dims *d = in->dim, *rd = r->dim;
+    const int nu = d->nu[0], nx = d->nx[0], nv = nu + nx, nb = d->nb[0], ng = d->ng[0], ns = d->ns[0], nx1 = d->N > 0 ? d->nx[1] : 0;
+    const int nvr = rd->nu[0] + rd->nx[0], nbr = rd->nb[0];
+    pc_alias_in_tail(in, r);
+    /* who leaves */
+    for (int i = 0; i < nv; i++) { mem->map_var[i] = 0; mem->xbar[i] = 0.0; }
+    for (int i = 0; i < nb; i++) mem->map_row[i] = 0;
+    mem->nF = d->nbxe[0];
+    for (int e = 0; e < mem->nF; e++)
+    {
+        const int ib = in->idxe[0][d->nbue[0] + e], iv = in->idxb[0][ib];
+        if (iv < nu || in->idxs_rev[0][ib] >= 0)
+        {
+            printf("\nerror: ocp_qp_gpu_pcond: reduce_eq_dof: an equality-flagged STATE bound without slack is expected at stage 0 (row %d)\n", ib);
+            exit(1);
+        }
+        mem->f_ib[e] = ib; mem->f_iv[e] = iv;
+        mem->map_var[iv] = -1; mem->map_row[ib] = -1;
+        mem->xbar[iv] = BLASFEO_DVECEL(in->d, ib); /* the lower bound (natural sign) = the value */
+    }
+    for (int i = 0, p = 0; i < nv; i++) if (mem->map_var[i] == 0) mem->map_var[i] = p++;
+    for (int i = 0, p = 0; i < nb; i++) if (mem->map_row[i] == 0) mem->map_row[i] = p++;
+    /* dynamics: rows of [B'; A'] of the variables left; b' = b + A[:, F] xbar (vector AND last row) */
+    for (int c = 0; c < nx1; c++)
+    {
+        double bb = BLASFEO_DVECEL(in->b, c);
+        for (int i = 0; i < nv; i++)
+        {
+            if (mem->map_var[i] >= 0) BLASFEO_DMATEL(r->BAbt, mem->map_var[i], c) = BLASFEO_DMATEL(in->BAbt, i, c);
+            else bb += BLASFEO_DMATEL(in->BAbt, i, c) * mem->xbar[i];
+        }
+        BLASFEO_DVECEL(r->b, c) = bb;
+        BLASFEO_DMATEL(r->BAbt, nvr, c) = bb;
+    }
+    /* Hessian: principal block (lower triangle); gradient += H[keep, F] xbar (vector AND last row); zl, zu */
+    for (int i = 0; i < nv; i++)
+    {
+        const int mi = mem->map_var[i];
+        if (mi < 0) continue;
+        double gg = BLASFEO_DVECEL(in->rqz, i);
+        for (int j = 0; j < nv; j++)
+        {
+            const int mj = mem->map_var[j];
+            if (mj < 0) gg += RSQ_SYM(in, i, j) * mem->xbar[j];
+            else if (mj <= mi) BLASFEO_DMATEL(r->RSQrq, mi, mj) = RSQ_SYM(in, i, j);
+        }
+        BLASFEO_DVECEL(r->rqz, mi) = gg;
+        BLASFEO_DMATEL(r->RSQrq, nvr, mi) = gg;
+    }
+    for (int q = 0; q < 2 * ns; q++)
+    {
+        BLASFEO_DVECEL(r->rqz, nvr + q) = BLASFEO_DVECEL(in->rqz, nv + q);
+        BLASFEO_DVECEL(r->Z, q) = BLASFEO_DVECEL(in->Z, q);
+    }
+    /* general rows: [D'; C'] of the variables left; bounds shifted by C[:, F] xbar.  d = [lb; lg; -ub; -ug; ls; us] */
+    for (int g = 0; g < ng; g++)
+    {
+        double cc = 0.0;
+        for (int i = 0; i < nv; i++)
+        {
+            if (mem->map_var[i] >= 0) BLASFEO_DMATEL(r->DCt, mem->map_var[i], g) = BLASFEO_DMATEL(in->DCt, i, g);
+            else cc += BLASFEO_DMATEL(in->DCt, i, g) * mem->xbar[i];
+        }
+        BLASFEO_DVECEL(r->d, nbr + g) = BLASFEO_DVECEL(in->d, nb + g) - cc;
+        BLASFEO_DVECEL(r->d, 2 * nbr + ng + g) = BLASFEO_DVECEL(in->d, 2 * nb + ng + g) + cc; /* (-ug)' = -ug + cc */
+        BLASFEO_DVECEL(r->d_mask, nbr + g) = BLASFEO_DVECEL(in->d_mask, nb + g);
+        BLASFEO_DVECEL(r->d_mask, 2 * nbr + ng + g) = BLASFEO_DVECEL(in->d_mask, 2 * nb + ng + g);
+        BLASFEO_DVECEL(r->m, nbr + g) = BLASFEO_DVECEL(in->m, nb + g);
+        BLASFEO_DVECEL(r->m, 2 * nbr + ng + g) = BLASFEO_DVECEL(in->m, 2 * nb + ng + g);
+        r->idxs_rev[0][nbr + g] = in->idxs_rev[0][nb + g];
+    }
+    /* box rows left */
+    for (int ib = 0; ib < nb; ib++)
+    {
+        const int mr = mem->map_row[ib];
+        if (mr < 0) continue;
+        BLASFEO_DVECEL(r->d, mr) = BLASFEO_DVECEL(in->d, ib);
+        BLASFEO_DVECEL(r->d, nbr + ng + mr) = BLASFEO_DVECEL(in->d, nb + ng + ib);
+        BLASFEO_DVECEL(r->d_mask, mr) = BLASFEO_DVECEL(in->d_mask, ib);
+        BLASFEO_DVECEL(r->d_mask, nbr + ng + mr) = BLASFEO_DVECEL(in->d_mask, nb + ng + ib);
+        BLASFEO_DVECEL(r->m, mr) = BLASFEO_DVECEL(in->m, ib);
+        BLASFEO_DVECEL(r->m, nbr + ng + mr) = BLASFEO_DVECEL(in->m, nb + ng + ib);
+        r->idxb[0][mr] = mem->map_var[in->idxb[0][ib]];
+        r->idxs_rev[0][mr] = in->idxs_rev[0][ib];
+    }
+    for (int q = 0; q < 2 * ns; q++)
+    {
+        BLASFEO_DVECEL(r->d, 2 * nbr + 2 * ng + q) = BLASFEO_DVECEL(in->d, 2 * nb + 2 * ng + q);
+        BLASFEO_DVECEL(r->d_mask, 2 * nbr + 2 * ng + q) = BLASFEO_DVECEL(in->d_mask, 2 * nb + 2 * ng + q);
+        BLASFEO_DVECEL(r->m, 2 * nbr + 2 * ng + q) = BLASFEO_DVECEL(in->m, 2 * nb + 2 * ng + q);
+    }
+    r->diag_H_flag[0] = 0;
+    mem->src_in = r;
+    return r;
+}
+
+/* stages 1..N (and pi of stage 0) of a reduced solution container alias the caller's */
+static ocp_qp_out *pc_alias_out(ocp_qp_out *r, ocp_qp_out *out)
+{
+    const int N = out->dim->N;
+    for (int k = 1; k <= N; k++) { r->ux[k] = out->ux[k]; r->lam[k] = out->lam[k]; r->t[k] = out->t[k]; if (k < N) r->pi[k] = out->pi[k]; }
+    if (N > 0) r->pi[0] = out->pi[0];
+    return r;
+}
+
+/* an iterate of the original QP in the variables / rows of the reduced one (warm start: condense_qp_out) */
+static ocp_qp_out *pc_reduce_out(ocp_qp_gpu_pcond_memory *mem, ocp_qp_out *out)
+{
+    if (!mem->dims->reduced) return out;
+    ocp_qp_out *r = pc_alias_out(mem->red_out, out);
+    const ocp_qp_dims *d = out->dim, *rd = r->dim;
+    const int nv = d->nu[0] + d->nx[0], nb = d->nb[0], ng = d->ng[0], ns = d->ns[0], nvr = rd->nu[0] + rd->nx[0], nbr = rd->nb[0];
+    for (int i = 0; i < nv; i++) if (mem->map_var[i] >= 0) BLASFEO_DVECEL(r->ux, mem->map_var[i]) = BLASFEO_DVECEL(out->ux, i);
+    for (int q = 0; q < 2 * ns; q++) BLASFEO_DVECEL(r->ux, nvr + q) = BLASFEO_DVECEL(out->ux, nv + q);
+    for (int side = 0; side < 2; side++)
+    {
+        const int o = side * (nb + ng), ro = side * (nbr + ng);
+        for (int ib = 0; ib < nb; ib++)
+            if (mem->map_row[ib] >= 0)
+            {
+                BLASFEO_DVECEL(r->lam, ro + mem->map_row[ib]) = BLASFEO_DVECEL(out->lam, o + ib);
+                BLASFEO_DVECEL(r->t, ro + mem->map_row[ib]) = BLASFEO_DVECEL(out->t, o + ib);
+            }
+        for (int g = 0; g < ng; g++)
+        {
+            BLASFEO_DVECEL(r->lam, ro + nbr + g) = BLASFEO_DVECEL(out->lam, o + nb + g);
+            BLASFEO_DVECEL(r->t, ro + nbr + g) = BLASFEO_DVECEL(out->t, o + nb + g);
+        }
+    }
+    for (int q = 0; q < 2 * ns; q++)
+    {
+        BLASFEO_DVECEL(r->lam, 2 * nbr + 2 * ng + q) = BLASFEO_DVECEL(out->lam, 2 * nb + 2 * ng + q);
+        BLASFEO_DVECEL(r->t, 2 * nbr + 2 * ng + q) = BLASFEO_DVECEL(out->t, 2 * nb + 2 * ng + q);
+    }
+    return r;
+}
+
+/* d_ocp_qp_restore_eq_dof (:683): stage 0 of the reduced solution `r` back into `out` (stages 1..N are already there: aliased).
+ * x[F] = xbar (a sensitivity: the seed of the value); the multipliers of the rows of F from stationarity of x[F] in the ORIGINAL QP,
+ *     a = g_F + H[F, :] w_0 + A[:, F]' pi_1 - C[:, F]'(lam_lg - lam_ug),   lam_lb = max(a, 0), lam_ub = max(-a, 0), t = 0;
+ * for a sensitivity (vec = the seed's seed_g, fval = the seed of the value) the same expression is the derivative of `a`, assigned
+ * to the side the multiplier of the SOLUTION lives on (f_sign, kept from the last restore of a solution). */
+static void pc_restore_out(ocp_qp_gpu_pcond_memory *mem, const ocp_qp_in *in, const struct blasfeo_dvec *vec, const double *fval, int is_sens,
+                           ocp_qp_out *r, ocp_qp_out *out)
+{
+    const ocp_qp_dims *d = out->dim, *rd = r->dim;
+    const int nv = d->nu[0] + d->nx[0], nb = d->nb[0], ng = d->ng[0], ns = d->ns[0], nx1 = d->N > 0 ? d->nx[1] : 0;
+    const int nvr = rd->nu[0] + rd->nx[0], nbr = rd->nb[0];
+    for (int i = 0; i < nv; i++) BLASFEO_DVECEL(out->ux, i) = mem->map_var[i] >= 0 ? BLASFEO_DVECEL(r->ux, mem->map_var[i]) : fval[i];
+    for (int q = 0; q < 2 * ns; q++) BLASFEO_DVECEL(out->ux, nv + q) = BLASFEO_DVECEL(r->ux, nvr + q);
+    for (int side = 0; side < 2; side++)
+    {
+        const int o = side * (nb + ng), ro = side * (nbr + ng);
+        for (int ib = 0; ib < nb; ib++)
+            if (mem->map_row[ib] >= 0)
+            {
+                BLASFEO_DVECEL(out->lam, o + ib) = BLASFEO_DVECEL(r->lam, ro + mem->map_row[ib]);
+                BLASFEO_DVECEL(out->t, o + ib) = BLASFEO_DVECEL(r->t, ro + mem->map_row[ib]);
+            }
+        for (int g = 0; g < ng; g++)
+        {
+            BLASFEO_DVECEL(out->lam, o + nb + g) = BLASFEO_DVECEL(r->lam, ro + nbr + g);
+            BLASFEO_DVECEL(out->t, o + nb + g) = BLASFEO_DVECEL(r->t, ro + nbr + g);
+        }
+    }
+    for (int q = 0; q < 2 * ns; q++)
+    {
+        BLASFEO_DVECEL(out->lam, 2 * nb + 2 * ng + q) = BLASFEO_DVECEL(r->lam, 2 * nbr + 2 * ng + q);
+        BLASFEO_DVECEL(out->t, 2 * nb + 2 * ng + q) = BLASFEO_DVECEL(r->t, 2 * nbr + 2 * ng + q);
+    }
+    for (int e = 0; e < mem->nF; e++)
+    {
+        const int ib = mem->f_ib[e], iv = mem->f_iv[e];
+        double a = BLASFEO_DVECEL(vec, iv);
+        for (int j = 0; j < nv; j++) a += RSQ_SYM(in, iv, j) * BLASFEO_DVECEL(out->ux, j);
+        for (int c = 0; c < nx1; c++) a += BLASFEO_DMATEL(in->BAbt, iv, c) * BLASFEO_DVECEL(out->pi, c);
+        for (int g = 0; g < ng; g++)
+            a -= BLASFEO_DMATEL(in->DCt, iv, g) * (BLASFEO_DVECEL(out->lam, nb + g) - BLASFEO_DVECEL(out->lam, 2 * nb + ng + g));
+        if (!is_sens) mem->f_sign[e] = a > 0.0;
+        const int pos = is_sens ? mem->f_sign[e] : a > 0.0;
+        BLASFEO_DVECEL(out->lam, ib) = pos ? a : 0.0;
+        BLASFEO_DVECEL(out->lam, nb + ng + ib) = pos ? 0.0 : -a;
+        BLASFEO_DVECEL(out->t, ib) = 0.0;
+        BLASFEO_DVECEL(out->t, nb + ng + ib) = 0.0;
+    }
+}
+
+/* d_ocp_qp_reduce_eq_dof_seed: the seeds of a sensitivity solve in the reduced QP.  The seed of a fixed state's VALUE is the seed of its
+ * lower bound (seed_d is laid out like d; acados seeds both sides of the x0 rows, ocp_nlp_common.c:4057-4064); it enters like xbar. */
+static ocp_qp_seed *pc_reduce_seed(ocp_qp_gpu_pcond_memory *mem, const ocp_qp_in *in, ocp_qp_seed *seed)
+{
+    if (!mem->dims->reduced) return seed;
+    ocp_qp_seed *r = mem->red_seed;
+    const ocp_qp_dims *d = in->dim, *rd = r->dim;
+    const int N = d->N, nv = d->nu[0] + d->nx[0], nb = d->nb[0], ng = d->ng[0], ns = d->ns[0], nx1 = N > 0 ? d->nx[1] : 0;
+    const int nvr = rd->nu[0] + rd->nx[0], nbr = rd->nb[0];
+    for (int k = 1; k <= N; k++) { r->seed_g[k] = seed->seed_g[k]; r->seed_d[k] = seed->seed_d[k]; r->seed_m[k] = seed->seed_m[k]; if (k < N) r->seed_b[k] = seed->seed_b[k]; }
+    double *dx = mem->dxbar;
+    for (int i = 0; i < nv; i++) dx[i] = 0.0;
+    for (int e = 0; e < mem->nF; e++) dx[mem->f_iv[e]] = BLASFEO_DVECEL(seed->seed_d, mem->f_ib[e]);
+    for (int c = 0; c < nx1; c++)
+    {
+        double bb = BLASFEO_DVECEL(seed->seed_b, c);
+        for (int e = 0; e < mem->nF; e++) bb += BLASFEO_DMATEL(in->BAbt, mem->f_iv[e], c) * dx[mem->f_iv[e]];
+        BLASFEO_DVECEL(r->seed_b, c) = bb;
+    }
+    for (int i = 0; i < nv; i++)
+    {
+        if (mem->map_var[i] < 0) continue;
+        double gg = BLASFEO_DVECEL(seed->seed_g, i);
+        for (int e = 0; e < mem->nF; e++) gg += RSQ_SYM(in, i, mem->f_iv[e]) * dx[mem->f_iv[e]];
+        BLASFEO_DVECEL(r->seed_g, mem->map_var[i]) = gg;
+    }
+    for (int q = 0; q < 2 * ns; q++) BLASFEO_DVECEL(r->seed_g, nvr + q) = BLASFEO_DVECEL(seed->seed_g, nv + q);
+    for (int g = 0; g < ng; g++)
+    {
+        double cc = 0.0;
+        for (int e = 0; e < mem->nF; e++) cc += BLASFEO_DMATEL(in->DCt, mem->f_iv[e], g) * dx[mem->f_iv[e]];
+        BLASFEO_DVECEL(r->seed_d, nbr + g) = BLASFEO_DVECEL(seed->seed_d, nb + g) - cc;
+        BLASFEO_DVECEL(r->seed_d, 2 * nbr + ng + g) = BLASFEO_DVECEL(seed->seed_d, 2 * nb + ng + g) + cc;
+        BLASFEO_DVECEL(r->seed_m, nbr + g) = BLASFEO_DVECEL(seed->seed_m, nb + g);
+        BLASFEO_DVECEL(r->seed_m, 2 * nbr + ng + g) = BLASFEO_DVECEL(seed->seed_m, 2 * nb + ng + g);
+    }
+    for (int ib = 0; ib < nb; ib++)
+    {
+        const int mr = mem->map_row[ib];
+        if (mr < 0) continue;
+        BLASFEO_DVECEL(r->seed_d, mr) = BLASFEO_DVECEL(seed->seed_d, ib);
+        BLASFEO_DVECEL(r->seed_d, nbr + ng + mr) = BLASFEO_DVECEL(seed->seed_d, nb + ng + ib);
+        BLASFEO_DVECEL(r->seed_m, mr) = BLASFEO_DVECEL(seed->seed_m, ib);
+        BLASFEO_DVECEL(r->seed_m, nbr + ng + mr) = BLASFEO_DVECEL(seed->seed_m, nb + ng + ib);
+    }
+    for (int q = 0; q < 2 * ns; q++)
+    {
+        BLASFEO_DVECEL(r->seed_d, 2 * nbr + 2 * ng + q) = BLASFEO_DVECEL(seed->seed_d, 2 * nb + 2 * ng + q);
+        BLASFEO_DVECEL(r->seed_m, 2 * nbr + 2 * ng + q) = BLASFEO_DVECEL(seed->seed_m, 2 * nb + 2 * ng + q);
+    }
+    return r;
+}
+
 /* ------------------------------------------------------------------ the condensing slots */
 
 static int pc_condense_any(void *qp_in_, void *xin_, void *opts_, void *mem_, int what)
@@ -546,10 +868,11 @@ static int pc_condense_any(void *qp_in_, void *xin_, void *opts_, void *mem_, in
     const double t0 = pc_now_s();
     mem->ptr_qp_in = qp_in;
     int rc = ACADOS_SUCCESS;
-    if (!mem->dims->condensed) pc_copy_qp_in(qp_in, x, what, mem->blob);
+    ocp_qp_in *src = pc_reduce_in(mem, qp_in); /* x0 eliminated (:542), or qp_in itself */
+    if (!mem->dims->condensed) pc_copy_qp_in(src, x, what, mem->blob);
     else
     {
-        ocp_qp_gpu_batch *b = pc_load(mem, opts, qp_in), *c = NULL;
+        ocp_qp_gpu_batch *b = pc_load(mem, opts, src), *c = NULL;
         if (b)
         {
             if (what == 3) c = ocp_qp_gpu_batch_condense(b);
@@ -582,6 +905,8 @@ static int pc_condense_qp_out(void *qp_in_, void *xin_, void *qp_out_, void *xou
 {
     ocp_qp_out *out = (ocp_qp_out *) qp_out_, *xo = (ocp_qp_out *) xout_;
     ocp_qp_gpu_pcond_memory *mem = (ocp_qp_gpu_pcond_memory *) mem_;
+    if (mem->dims->reduced && mem->ptr_qp_in != (ocp_qp_in *) qp_in_) pc_reduce_in(mem, (ocp_qp_in *) qp_in_); /* (the maps of stage 0) */
+    out = pc_reduce_out(mem, out);
     if (!mem->dims->condensed) { ocp_qp_out_copy(out, xo); return ACADOS_SUCCESS; }
     ocp_qp_gpu_batch *b = mem->par.batch, *c = b ? ocp_qp_gpu_batch_condensed(b) : NULL;
     if (!c || pc_child_layout(mem, c) != 0) return ACADOS_QP_FAILURE; /* condensing has to run first, as in ocp_qp_xcond_solve */
@@ -596,9 +921,9 @@ static int pc_condense_qp_out(void *qp_in_, void *xin_, void *qp_out_, void *xou
 static int pc_restore_qp_vectors(ocp_qp_gpu_pcond_memory *mem)
 {
     mem->seeds_resident = 0;
-    if (!mem->par.batch || !mem->ptr_qp_in) return -1;
+    if (!mem->par.batch || !mem->src_in) return -1;
     memset(mem->blob, 0, sizeof(double) * (size_t) mem->par.L_in);
-    unpack_qp_in(&mem->par, mem->ptr_qp_in, mem->blob);
+    unpack_qp_in(&mem->par, mem->src_in, mem->blob);
     return ocp_qp_gpu_batch_set_bulk(mem->par.batch, mem->blob, 0);
 }
 
@@ -608,6 +933,9 @@ static int pc_expand_any(void *xout_, void *qp_out_, void *mem_, int seeds)
     ocp_qp_gpu_pcond_memory *mem = (ocp_qp_gpu_pcond_memory *) mem_;
     const double t0 = pc_now_s();
     int rc = ACADOS_SUCCESS;
+    /* x0 eliminated: the expansion lands in the reduced container (stages 1..N of it ARE the caller's), stage 0 is restored below */
+    ocp_qp_out *full = out;
+    if (mem->dims->reduced) out = pc_alias_out(seeds ? mem->red_sens : mem->red_out, full);
     if (!mem->dims->condensed) ocp_qp_out_copy(xo, out);
     else
     {
@@ -631,6 +959,12 @@ static int pc_expand_any(void *xout_, void *qp_out_, void *mem_, int seeds)
         else pack_qp_out(&mem->par, mem->blob, out);
         if (seeds && pc_restore_qp_vectors(mem) != 0) rc = ACADOS_QP_FAILURE; /* the QP's own vectors back */
     }
+    if (mem->dims->reduced && rc == ACADOS_SUCCESS)
+    {
+        if (seeds) pc_restore_out(mem, mem->ptr_qp_in, mem->ptr_seed->seed_g, mem->dxbar, 1, out, full);
+        else pc_restore_out(mem, mem->ptr_qp_in, mem->ptr_qp_in->rqz, mem->xbar, 0, out, full);
+    }
+    out = full;
     if (!seeds && out->misc) ((qp_info *) out->misc)->t_computed = 1; /* t comes from the expansion kernel, every row */
     mem->time_qp_xcond += pc_now_s() - t0;
     return rc;
@@ -655,7 +989,9 @@ static int pc_condense_rhs_seed(void *qp_in_, void *seed_, void *xseed_, void *o
     const double t0 = pc_now_s();
     mem->ptr_qp_in = qp_in;
     mem->ptr_seed = seed;
-    if (!mem->dims->condensed) { pc_copy_seed(seed, xs); mem->time_qp_xcond += pc_now_s() - t0; return ACADOS_SUCCESS; }
+    ocp_qp_in *src = pc_reduce_in(mem, qp_in);          /* (the matrices of the reduced QP; its vectors are replaced by the seeds below) */
+    ocp_qp_seed *rs = pc_reduce_seed(mem, qp_in, seed); /* d_ocp_qp_reduce_eq_dof_seed */
+    if (!mem->dims->condensed) { pc_copy_seed(rs, xs); mem->time_qp_xcond += pc_now_s() - t0; return ACADOS_SUCCESS; }
     /* seed_m (a seed on the complementarity rhs) has no counterpart in the vector condensing: acados leaves it zero
      * (d_ocp_qp_seed_set_zero, then seed_g / seed_b / seed_d: ocp_nlp_common.c:4057-4081); anything else is refused, not dropped */
     for (int k = 0; k <= qp_in->dim->N; k++)
@@ -668,8 +1004,8 @@ static int pc_condense_rhs_seed(void *qp_in_, void *seed_, void *xseed_, void *o
     /* a SHELL of qp_in whose vector members are the seed's: seed_g = [r; q; zl; zu] is laid out like rqz, seed_b like b, seed_d
      * like d (upper halves negated, ocp_nlp_common.c:4078-4081) -- the segment tables of the input blob read them as they are;
      * matrices, masks and index sets stay qp_in's */
-    ocp_qp_in shell = *qp_in;
-    shell.b = seed->seed_b; shell.rqz = seed->seed_g; shell.d = seed->seed_d;
+    ocp_qp_in shell = *src;
+    shell.b = rs->seed_b; shell.rqz = rs->seed_g; shell.d = rs->seed_d;
     ocp_qp_gpu_batch *b = pc_load(mem, opts, &shell);
     ocp_qp_gpu_batch *c = b ? ocp_qp_gpu_batch_condense(b) : NULL;
     if (!c || pc_child_layout(mem, c) != 0 || ocp_qp_gpu_batch_get_bulk_in(c, mem->blob, 0) != 0)

@@ -362,8 +362,8 @@ int main(int argc, char **argv)
     }
 
     FILE *g = fopen(argv[2], "w");
-    fprintf(g, "status %d iter %d iter_info %d t_computed %d status_mem %d rti_status %d xcond_N %d xcond_nu0 %d warm_iter %d\n", status, iter, info->num_iter,
-            info->t_computed, st_mem, rti, xd->N, xd->nu[0], warm_iter);
+    fprintf(g, "status %d iter %d iter_info %d t_computed %d status_mem %d rti_status %d xcond_N %d xcond_nu0 %d warm_iter %d xcond_nx0 %d xcond_nbx0 %d\n", status, iter,
+            info->num_iter, info->t_computed, st_mem, rti, xd->N, xd->nu[0], warm_iter, xd->nx[0], xd->nbx[0]);
     fprintf(g, "checks t_max_diff %.17g rti_max_diff %.17g res %.17g %.17g %.17g %.17g time_call %.6g total %.6g\n", t_diff, rti_diff, nrm[0], nrm[1],
             nrm[2], nrm[3], t_call, info->total_time);
     mock_write_sol(g, &cap->dim, qp_out);

@@ -141,6 +141,9 @@ def test_reference_xcond_solver_drives_both_slots_condensed(clib, tmp_path, qp_n
     assert head["xcond_N"] == n_stages and head["xcond_N"] < qp.N
     bs0 = blocks[0] if blocks else qp.N // N2 + (1 if qp.N % N2 else 0)
     assert head["xcond_nu0"] >= bs0 * int(qp.dims.nu[0])
+    # x0 is eliminated before the device condenses, as HPIPM's d_ocp_qp_reduce_eq_dof does (ocp_qp_partial_condensing.c:542): stage 0 of
+    # the condensed QP carries the states the equality-flagged bounds leave free, and no box rows on the ones they fix (round 6)
+    assert head["xcond_nx0"] == int(qp.dims.nx[0]) - int(qp.dims.nbxe[0]), head
     _check_solution(qp, head, checks, sol)
     # warm start from the solution through the module's condense_qp_out: converges (to the same point, checked in the driver) in
     # no more iterations than the cold solve
