@@ -33,7 +33,8 @@
  *     the expansion puts x0 back and recovers the multipliers of its rows from stationarity (d_ocp_qp_restore_eq_dof, :683).  xcond
  *     dims / pcond_* getters show what HPIPM's show at stage 0.  Option "reduce_eq_dof" = 0 keeps the rows (the device masks the
  *     fixed variables itself: what the fused batch route does);
- *   - block inputs are padded to the condensing kernel's NU where blocks differ in size;
+ *   - a block counts the class's kernel NU inputs per stage it holds: HPIPM's sum of nu wherever every stage of the block has that many
+ *     inputs (uneven user blocks included), larger where a stage inside a block has fewer;
  *   - a non-zero LAST block size (block_size[N2] > 0, e.g. [6,5,4,2,2,1] of pcond_getters_test.py:200) gives one more stage
  *     with inputs in front of an input-free terminal stage (N2 + 1 stages with inputs) instead of inputs in the terminal stage.
  * A class the device does not condense (more than 64 rows in a condensed stage, ...) is handed through with N2 = N -- the
