@@ -332,6 +332,7 @@ def boundary_c3(n=4096, reps=4):
             "rti_feedback": ({"solves_per_s": n / (info["rti_feedback_ms"] * 1e-3), "ms_per_step": info["rti_feedback_ms"],
                               "preparation_ms": info.get("rti_preparation_ms"), "failures": int(info.get("rti_status", 0) != 0),
                               "vs_one_call": info.get("rti_vs_one_call"), "upload_bytes_per_qp": 8 * int(info.get("rti_feedback_upload_doubles", 0)),
+                              "phases_ms": {k: info["fb_" + k] for k in ("unpack_in_ms", "copy_and_device_ms", "pack_out_ms") if "fb_" + k in info},
                               "pcie_bytes": n * (8 * int(info.get("rti_feedback_upload_doubles", 0)) + b_out)}
                              if info.get("rti_feedback_ms") else None),
             "pcie_bytes": pcie, "pcie_GBps": pcie / t / 1e9, "pcie_peak_GBps": PCIE_PEAK_GBS, "pcie_frac": pcie / t / 1e9 / PCIE_PEAK_GBS,

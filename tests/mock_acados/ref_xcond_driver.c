@@ -191,11 +191,21 @@ static int run_batch(int argc, char **argv)
         const double dt = now_s() - t0;
         if (dt < best) best = dt;
     }
+    /* where the time of the last ONE-CALL evaluate went (extension fields of the adapter's memory_get; qp_info.solve_QP_time = the device's own event time) */
+    double t_unpack = 0.0, t_pack = 0.0, t_call = 0.0;
+    {
+        void *sm = ((ocp_qp_xcond_solver_memory *) mems[0])->solver_memory;
+        config->qp_solver->memory_get(config->qp_solver, sm, "time_unpack_in", &t_unpack);
+        config->qp_solver->memory_get(config->qp_solver, sm, "time_pack_out", &t_pack);
+        config->qp_solver->memory_get(config->qp_solver, sm, "time_qp_solver_call", &t_call);
+    }
+    const double t_dev = ((qp_info *) outs[0]->misc)->solve_QP_time;
     /* the same QPs as the two halves of an RTI step (the batch counterparts of condense_lhs / condense_rhs_and_solve): preparation sends
      * everything and condenses the matrices, feedback reads and sends only the vector members.  The feedback solution must equal the
      * one-call solution (same data): compared below.  Best of `reps` pairs. */
     double best_prep = 1e300, best_fb = 1e300, rti_diff = 0.0;
     int rti_status = 0, rti_upload = -1;
+    double fb_unpack = 0.0, fb_call = 0.0, fb_pack = 0.0;
     {
         ocp_qp_out **outs2 = calloc(n, sizeof(void *));
         for (int i = 0; i < n; i++) outs2[i] = ocp_qp_out_assign(dims->orig_dims, calloc(1, ocp_qp_out_calculate_size(dims->orig_dims)));
@@ -214,6 +224,9 @@ static int run_batch(int argc, char **argv)
         }
         for (int i = 0; i < n; i++) rti_diff = fmax(rti_diff, out_diff(&caps[i]->dim, outs[i], outs2[i]));
         config->qp_solver->memory_get(config->qp_solver, ((ocp_qp_xcond_solver_memory *) mems[0])->solver_memory, "upload_doubles", &rti_upload);
+        config->qp_solver->memory_get(config->qp_solver, ((ocp_qp_xcond_solver_memory *) mems[0])->solver_memory, "time_unpack_in", &fb_unpack);
+        config->qp_solver->memory_get(config->qp_solver, ((ocp_qp_xcond_solver_memory *) mems[0])->solver_memory, "time_qp_solver_call", &fb_call);
+        config->qp_solver->memory_get(config->qp_solver, ((ocp_qp_xcond_solver_memory *) mems[0])->solver_memory, "time_pack_out", &fb_pack);
         /* (the per-capsule lines below report the state after the LAST call: the feedback half) */
     }
     /* capsules 0 and n-1 once more through the reference's per-capsule ocp_qp_xcond_solve (device condensing module, host round trip) */
@@ -245,22 +258,13 @@ static int run_batch(int argc, char **argv)
             for (int q = 0; q < 4; q++) res_max = fmax(res_max, nrm[q]);
         }
     }
-    /* where the last call's time went (extension fields of the adapter's memory_get; qp_info.solve_QP_time = the device's own event time) */
-    double t_unpack = 0.0, t_pack = 0.0, t_call = 0.0;
-    {
-        void *sm = ((ocp_qp_xcond_solver_memory *) mems[0])->solver_memory;
-        config->qp_solver->memory_get(config->qp_solver, sm, "time_unpack_in", &t_unpack);
-        config->qp_solver->memory_get(config->qp_solver, sm, "time_pack_out", &t_pack);
-        config->qp_solver->memory_get(config->qp_solver, sm, "time_qp_solver_call", &t_call);
-    }
-    const double t_dev = ((qp_info *) outs[0]->misc)->solve_QP_time;
     int cond_active = -1; /* stages of the QP the device IPM ran on in the batch call: the condensed one */
     config->qp_solver->memory_get(config->qp_solver, ((ocp_qp_xcond_solver_memory *) mems[0])->solver_memory, "cond_N_active", &cond_active);
     printf("batch n %d ms_per_call %.6f status %d fused_vs_orchestrated %.17g orchestrated_status %d xcond_N %d xcond_nu0 %d cond_N_active %d res_max %.17g "
            "unpack_in_ms %.4f copy_and_device_ms %.4f device_solve_ms %.4f pack_out_ms %.4f threads %d rti_preparation_ms %.6f rti_feedback_ms %.6f "
-           "rti_status %d rti_vs_one_call %.17g rti_feedback_upload_doubles %d end\n", n,
+           "rti_status %d rti_vs_one_call %.17g rti_feedback_upload_doubles %d fb_unpack_in_ms %.4f fb_copy_and_device_ms %.4f fb_pack_out_ms %.4f end\n", n,
            best * 1e3, status, fvo, st_one, xd->N, xd->nu[0], cond_active, res_max, t_unpack * 1e3, t_call * 1e3, t_dev * 1e3, t_pack * 1e3, omp_get_max_threads(),
-           best_prep * 1e3, best_fb * 1e3, rti_status, rti_diff, rti_upload);
+           best_prep * 1e3, best_fb * 1e3, rti_status, rti_diff, rti_upload, fb_unpack * 1e3, fb_call * 1e3, fb_pack * 1e3);
     FILE *g = fopen(argv[4], "wb");
     for (int i = 0; i < n; i++)
     {

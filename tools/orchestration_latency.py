@@ -10,7 +10,7 @@ exe = os.path.join(ROOT, "integration", "_ref_build", "ref_xcond_driver")
 d = tempfile.mkdtemp()
 f = os.path.join(d, "qp.txt")
 _write_qp(lqr_instance_qp(random_lqr_batch(N=50, batch=1, seed=5), 0, 50), f)
-env = dict(os.environ, OMP_NUM_THREADS="16")
+env = dict(os.environ, OMP_NUM_THREADS=os.environ.get("ORCH_THREADS", "16"))
 env.pop("ACADOS_AMD_WPI_BATCH_MAX", None)
 for n in [int(a) for a in sys.argv[1:]] or [1024, 4096]:
     for label, extra in (("panel runs (probed layout)", {}), ("blasfeo_unpack_* per block (ACADOS_AMD_LA_API=1)", {"ACADOS_AMD_LA_API": "1"})):
