@@ -264,8 +264,8 @@ def test_full_condensing(clib, monkeypatch, capfd):
         xd = c.xcond_dims()
         assert c.cond_N == 1 and len(xd["nu"]) == 2 and xd["nu"][0] >= int(np.sum(qp.dims.nu)) and xd["nu"][1] == 0
     # beyond one condensed STAGE (64 variables / 128 sides): the dense path (dense_kernels.hpp) -- every state but x0 condensed into ONE
-    # dense problem inside the solve, dense Cholesky; mass-spring N = 24: 25 * 3 + 8 = 83 columns, 24 * 8 state bounds as dense rows
-    qp = mass_spring_qp(N=24)
+    # dense problem inside the solve, dense Cholesky; mass-spring N = 19: 8 + 19 * 3 = 65 > 64 condensed columns (68 dense ones with the padded terminal inputs), 19 * 8 state bounds as dense rows
+    qp = mass_spring_qp(N=19)
     o = OracleQp(qp)
     assert o.solve(default_opts(tol_stat=1e-8)) == 0
     opts = AcadosOcpQpOptions()
