@@ -51,6 +51,10 @@ def bind(L):
     L.ocp_qp_gpu_batch_get_bulk_in.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
     L.ocp_qp_gpu_batch_set_bulk_chunk.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     L.ocp_qp_gpu_batch_set_bulk_staged.argtypes = [C.c_void_p]
+    L.ocp_qp_gpu_host_register.argtypes = [C.c_void_p, C.c_size_t]
+    L.ocp_qp_gpu_host_unregister.argtypes = [C.c_void_p]
+    L.ocp_qp_gpu_batch_gather_tables.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.ocp_qp_gpu_batch_gather_run.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     L.ocp_qp_gpu_batch_condense_sol.argtypes = [C.c_void_p]
     L.ocp_qp_gpu_comm_unique_id.argtypes = [C.c_void_p]
     L.ocp_qp_gpu_comm_create.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]

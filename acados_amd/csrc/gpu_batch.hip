@@ -175,6 +175,10 @@ struct ocp_qp_gpu_batch
     double *d_stage = nullptr; /* staging for host->device field blocks */
     double *d_chunks = nullptr; /* the input blob handed over in pieces (_set_bulk_chunk): its own buffer -- d_stage is reused by */
     size_t chunks_cap = 0;      /* every other transfer (a hot start's _set_bulk_out comes between the chunks and the scatter) */
+    /* zero-copy gather (ocp_qp_gpu_batch_gather_tables / _gather_run): word tables of the full input blob [0] and of its vector part [1] */
+    struct GatherTab { int P = 0, n_words = 0; int *d_slot = nullptr, *d_off = nullptr, *d_pos = nullptr; unsigned char *d_neg = nullptr; } gtab[2];
+    const double **d_gptrs = nullptr;
+    size_t gptrs_cap = 0;
     long chunks_got = 0;        /* instances handed over since the last _set_bulk_staged (it refuses to scatter a partial blob) */
     hipEvent_t chunks_ev = nullptr; /* recorded in front of the first chunk of a round: time_pack covers copies + scatter as _set_bulk's does */
     size_t stage_cap = 0;
@@ -2645,6 +2649,89 @@ try
     HIPCHK(hipEventElapsedTime(&ms, b->ev0, b->ev1));
     b->time_pack += ms * 1e-3;
     return 0;
+}
+catch (const gqp_hip_failure &) { return -1; }
+
+/* ---- zero-copy gather: the device reads the instances' QP data from the caller's own (registered) host memory ----
+ * Through the boundary the host pass that copies n capsules' member arrays into a pinned blob is bound by the host memory system
+ * (1.8 GB/s per thread on 16 threads) while a kernel reads registered host memory at the PCIe rate (56 GB/s,
+ * profiles/r06_zero_copy_probe.txt).  _host_register pins a block and maps it for the device (hipHostRegister; device pointer = host
+ * pointer); _gather_tables takes the class-wide word tables once; _gather_run takes the per-instance source pointers of this call,
+ * gathers into the device-side blob and scatters it as _set_bulk / _set_bulk_vec do -- byte-identical to the blob path. */
+int ocp_qp_gpu_host_register(void *p, size_t bytes)
+{
+    if (hipHostRegister(p, bytes, hipHostRegisterDefault) != hipSuccess) { (void) hipGetLastError(); return -1; }
+    void *dp = nullptr; /* the gather takes HOST addresses: only where the device sees the block at the same one */
+    if (hipHostGetDevicePointer(&dp, p, 0) != hipSuccess || dp != p)
+    {
+        (void) hipGetLastError();
+        (void) hipHostUnregister(p);
+        return -1;
+    }
+    return 0;
+}
+
+int ocp_qp_gpu_host_unregister(void *p)
+{
+    const hipError_t e = hipHostUnregister(p);
+    if (e != hipSuccess) { (void) hipGetLastError(); return -1; }
+    return 0;
+}
+
+int ocp_qp_gpu_batch_gather_tables(ocp_qp_gpu_batch *b, int which, int P, int n_words, const int *w_slot, const int *w_off, const int *w_pos,
+                                   const unsigned char *w_neg)
+try
+{
+    HIPCHK(hipSetDevice(b->device));
+    const int len = gqp_bulk_len_impl(b, which == 2 ? 2 : 0);
+    for (int w = 0; w < n_words; w++)
+        if (w_slot[w] < 0 || w_slot[w] >= P || w_pos[w] < 0 || w_pos[w] >= len || w_off[w] < 0) return -1;
+    auto &G = b->gtab[which == 2 ? 1 : 0];
+    G.P = P; G.n_words = n_words;
+    G.d_slot = dalloc<int>(b, n_words); G.d_off = dalloc<int>(b, n_words); G.d_pos = dalloc<int>(b, n_words); G.d_neg = dalloc<unsigned char>(b, n_words);
+    if (n_words)
+    {
+        HIPCHK(hipMemcpy(G.d_slot, w_slot, sizeof(int) * n_words, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(G.d_off, w_off, sizeof(int) * n_words, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(G.d_pos, w_pos, sizeof(int) * n_words, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(G.d_neg, w_neg, n_words, hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+catch (const gqp_hip_failure &) { return -1; }
+
+int ocp_qp_gpu_batch_gather_run(ocp_qp_gpu_batch *b, int which, const void *const *ptrs)
+try
+{
+    HIPCHK(hipSetDevice(b->device));
+    auto &G = b->gtab[which == 2 ? 1 : 0];
+    if (G.n_words <= 0 || G.P <= 0) return -1;
+    const int len = gqp_bulk_len_impl(b, which == 2 ? 2 : 0);
+    const size_t cnt = (size_t) b->B * gqp_bulk_len_impl(b, 0); /* (one buffer for both blobs: the full one is the longer) */
+    if (cnt > b->chunks_cap)
+    {
+        HIPCHK(hipStreamSynchronize(b->stream));
+        b->chunks_cap = cnt;
+        b->d_chunks = dalloc<double>(b, b->chunks_cap); /* zeroed: positions no word writes stay zero */
+    }
+    const size_t np = (size_t) b->B * G.P;
+    if (np > b->gptrs_cap) { b->gptrs_cap = np; b->d_gptrs = dalloc<const double *>(b, np); }
+    hipEvent_t g0, g1;
+    HIPCHK(hipEventCreate(&g0)); HIPCHK(hipEventCreate(&g1));
+    const double tp = b->time_pack;
+    HIPCHK(hipEventRecord(g0, b->stream));
+    HIPCHK(hipMemcpyAsync(b->d_gptrs, ptrs, sizeof(void *) * np, hipMemcpyHostToDevice, b->stream));
+    hipLaunchKernelGGL(gqp::k_gather_host, dim3((G.n_words + 255) / 256, b->B), dim3(256), 0, b->stream, (const double *const *) b->d_gptrs, G.P, b->B,
+                       G.n_words, (const int *) G.d_slot, (const int *) G.d_off, (const int *) G.d_pos, (const unsigned char *) G.d_neg, b->d_chunks, len);
+    b->chunks_got = 0; /* (the chunk protocol shares the buffer: a round in flight is void) */
+    const int rc = which == 2 ? ocp_qp_gpu_batch_set_bulk_vec(b, b->d_chunks, 1) : ocp_qp_gpu_batch_set_bulk(b, b->d_chunks, 1);
+    HIPCHK(hipEventRecord(g1, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    float ms = 0.f;
+    HIPCHK(hipEventElapsedTime(&ms, g0, g1));
+    b->time_pack = tp + ms * 1e-3; /* gather + scatter */
+    HIPCHK(hipEventDestroy(g0)); HIPCHK(hipEventDestroy(g1));
+    return rc;
 }
 catch (const gqp_hip_failure &) { return -1; }
 

@@ -1236,6 +1236,19 @@ static __global__ void k_bulk_scatter_seed(const double *blob, int nb, int len, 
     }
 }
 
+/* ZERO-COPY GATHER: instance i's QP data read by the device straight from the caller's (registered) host memory -- word w of the
+ * class-wide table is element w_off[w] of the instance's source array w_slot[w] (ptrs[i * P + slot]: acados' BLASFEO storage, panel-major
+ * matrices and plain vectors) and lands at position w_pos[w] of the instance's bulk blob in device memory, negated where w_neg[w].  The
+ * words are sorted by (slot, offset): consecutive lanes read consecutive host addresses, the reads cross PCIe as full lines. */
+static __global__ void __launch_bounds__(256) k_gather_host(const double *const *ptrs, int P, int nb, int n_words, const int *w_slot, const int *w_off,
+                                                            const int *w_pos, const unsigned char *w_neg, double *blob, int len)
+{
+    const int i = blockIdx.y, w = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nb || w >= n_words) return;
+    const double v = ptrs[(size_t) i * P + w_slot[w]][w_off[w]];
+    blob[(size_t) i * len + w_pos[w]] = w_neg[w] ? -v : v;
+}
+
 static __global__ void k_bulk_gather(double *blob, int nb, int len, const int *map_arr, const int *map_elem, GArrTable T)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

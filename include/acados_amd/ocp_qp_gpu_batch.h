@@ -73,6 +73,20 @@ int ocp_qp_gpu_batch_set_bulk(ocp_qp_gpu_batch *b, const double *blob, int is_de
  * (replaces the vector part of d_ocp_qp_set_* between ocp_qp_xcond_solver.c:591-620 and :623-669; 12.6 KB instead of 85 KB per C2-shaped QP) */
 int ocp_qp_gpu_batch_set_bulk_vec(ocp_qp_gpu_batch *b, const double *blob, int is_device);
 int ocp_qp_gpu_batch_get_bulk(ocp_qp_gpu_batch *b, double *blob, int is_device);
+/* ZERO-COPY GATHER (the batch entries of the acados-side adapter, replaces the host pass over n ocp_qp_in structs -- the
+ * d_ocp_qp_set_* / blasfeo_unpack_* loops of an adapter, ocp_qp_clarabel.c:205-683 -- by device reads over PCIe): the device reads every
+ * instance's QP data from the CALLER'S OWN host memory.  _host_register pins a block of it and maps it for the device (hipHostRegister:
+ * the device pointer equals the host pointer; the block stays registered until _host_unregister).  _gather_tables: once per class and
+ * blob (`which` 0: the input blob, 2: its vector part) the word tables -- word w is element w_off[w] of source array w_slot[w] (0 <= slot < P,
+ * e.g. the panel-major storage of one BLASFEO matrix) and goes to position w_pos[w] of the blob (layout of _bulk_len / _bulk_offset), negated
+ * where w_neg[w]; sort the words by (slot, offset) so that consecutive device lanes read consecutive host addresses.  _gather_run: per call
+ * the n_batch * P source addresses (ptrs[i * P + slot], each inside a registered block) -- gather into a device-side blob, then exactly what
+ * _set_bulk / _set_bulk_vec do with it.  0 on success, -1 on a device failure or a table that does not fit the blob. */
+int ocp_qp_gpu_host_register(void *p, size_t bytes);
+int ocp_qp_gpu_host_unregister(void *p);
+int ocp_qp_gpu_batch_gather_tables(ocp_qp_gpu_batch *b, int which, int P, int n_words, const int *w_slot, const int *w_off, const int *w_pos,
+                                   const unsigned char *w_neg);
+int ocp_qp_gpu_batch_gather_run(ocp_qp_gpu_batch *b, int which, const void *const *ptrs);
 /* _set_bulk in pieces (the batch entries of the acados-side adapter: the host->device copy of instance range j overlaps with the host
  * threads still unpacking range j + 1): `blob_chunk` = instance `first` of the caller's pinned blob, `count` instances, asynchronous;
  * _set_bulk_staged scatters what the chunks brought (all n_batch instances must have been handed over) and waits */

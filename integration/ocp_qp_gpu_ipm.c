@@ -40,6 +40,9 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#if defined(_OPENMP)
+#include <omp.h>
+#endif
 
 #include "acados/ocp_qp/ocp_qp_common.h"
 #include "acados/utils/types.h"
@@ -75,6 +78,11 @@ typedef struct
     int lhs_resident;            /* batch entries: the matrices of every instance are on the device and (cond_N < N) condensed -- set by the
                                     condense_lhs batch entry, consumed by the condense_rhs_and_solve one (an RTI step's two halves) */
     int *members;                /* batch entries: index of each instance in the caller's arrays */
+    /* batch entries, zero-copy (zc_prepare): sources per instance, the class's word tables on the device (1) / refused (-1), the cn the
+     * tables were built with and the doubles they read of every source, this call's source addresses (pinned, n x zc_P) */
+    int zc_P, zc_tab;
+    int *zc_cn, *zc_ext;
+    const void **zc_ptrs;
     int *st, *it;                /* per-instance status / iterations of the last solve */
     int status;                  /* worst status of the last solve */
     /* After a batched solve (evaluate_batch / a rendezvous round) every capsule of a structure class shares this bucket:
@@ -99,13 +107,17 @@ typedef struct gpu_group_
     int n, nbk;
     gpu_bucket *bk;
     int *bucket_of, *pos_of;     /* per caller index */
-    int *scratch, scratch_cap;   /* signature scratch */
+    int *scratch, scratch_cap, scratch_nt; /* signature scratch: scratch_cap ints for each of scratch_nt host threads */
     /* The header of a group is never handed back to the allocator: when a group is released its resources go, the header
      * goes to a pool with its generation advanced.  A memory that still points at it (a capsule of an earlier batch call
      * whose owner has rebuilt or released the group) sees the generation mismatch and falls back to its own bucket
      * instead of following a dangling pointer. */
     unsigned gen;
     struct gpu_group_ *next_free;
+    /* zero-copy (zc_prepare): 0 not tried yet, 1 the capsules' QP memory is registered with the device, -1 off for this group */
+    int zc_state, zc_nr, zc_rereg;
+    struct zc_range_ *zc_r;      /* the registered blocks, sorted by address */
+    int *zc_hint;                /* per caller index: the block its last source was found in */
 } gpu_group;
 
 typedef struct ocp_qp_gpu_ipm_memory_
@@ -117,6 +129,7 @@ typedef struct ocp_qp_gpu_ipm_memory_
     int rv_index;                /* slot of this memory's capsule in its rendezvous (-1: none yet) */
     int *sig_scratch;
     double time_qp_solver_call;
+    int zero_copy;               /* extension: the last batch call's QP data was gathered by the device from the capsules' memory (zc_prepare) */
     int upload_doubles;          /* extension: doubles per QP the last batch call sent to the device (the whole input blob, or its vector part) */
     double time_unpack_in, time_pack_out; /* extension: host time spent reading qp_in into / writing qp_out from the staging blobs */
     int iter, status;
@@ -132,6 +145,8 @@ static gpu_group *mem_group(const ocp_qp_gpu_ipm_memory *m)
 {
     return m->group && m->group->gen == m->group_gen && m->group->owner ? m->group : NULL;
 }
+
+typedef struct zc_range_ { char *lo, *hi; } zc_range;
 
 static int rendezvous_evaluate(struct ocp_qp_gpu_ipm_rendezvous_ *r, void *config, void *qp_in, void *qp_out, void *opts, ocp_qp_gpu_ipm_memory *m);
 static void group_release(gpu_group *g);
@@ -294,6 +309,7 @@ static void gpu_memory_get(void *config, void *mem_, const char *field, void *va
     ocp_qp_gpu_ipm_memory *m = (ocp_qp_gpu_ipm_memory *) mem_;
     if (!strcmp(field, "time_qp_solver_call")) *(double *) value = m->time_qp_solver_call;
     else if (!strcmp(field, "upload_doubles")) *(int *) value = m->upload_doubles;
+    else if (!strcmp(field, "zero_copy")) *(int *) value = m->zero_copy;
     else if (!strcmp(field, "time_unpack_in")) *(double *) value = m->time_unpack_in;
     else if (!strcmp(field, "time_pack_out")) *(double *) value = m->time_pack_out;
     else if (!strcmp(field, "iter")) *(int *) value = m->iter;
@@ -404,8 +420,9 @@ static void apply_opts(ocp_qp_gpu_batch *b, const ocp_qp_gpu_ipm_opts *o, int ws
     ocp_qp_gpu_batch_opts_set(b, "warm_start", &ws);
 }
 
-/* the device part of a solve: staged blobs -> device batch -> staged solution, statuses.  `staged`: the input blob is on the device
- * already (handed over in chunks while it was being filled, evaluate_batch_masked): only its scatter launch is left */
+/* the device part of a solve: staged blobs -> device batch -> staged solution, statuses.  `staged` 1: the input blob is on the device
+ * already (handed over in chunks while it was being filled, evaluate_batch_masked): only its scatter launch is left; 2: there is no host
+ * blob -- the device gathers the QP data from the capsules' own memory (zc_prepare filled bk->zc_ptrs) */
 enum { BATCH_SOLVE = 0, BATCH_LHS = 1, BATCH_RHS_SOLVE = 2 }; /* evaluate | RTI preparation (condense_lhs) | RTI feedback (condense_rhs_and_solve) */
 
 static void bucket_solve(gpu_bucket *bk, const ocp_qp_gpu_ipm_opts *o, int ws, int staged, int mode)
@@ -425,7 +442,9 @@ static void bucket_solve(gpu_bucket *bk, const ocp_qp_gpu_ipm_opts *o, int ws, i
     if (mode == BATCH_LHS)
     {
         /* RTI preparation of the whole class: matrices (and everything else) to the device, the matrix part of the condensing there */
-        const int bad = (staged ? ocp_qp_gpu_batch_set_bulk_staged(b) : ocp_qp_gpu_batch_set_bulk(b, bk->blob_in, 0)) != 0 || ocp_qp_gpu_batch_condense_lhs(b) != 0;
+        const int bad = (staged == 2 ? ocp_qp_gpu_batch_gather_run(b, 0, bk->zc_ptrs)
+                                     : (staged ? ocp_qp_gpu_batch_set_bulk_staged(b) : ocp_qp_gpu_batch_set_bulk(b, bk->blob_in, 0))) != 0
+                        || ocp_qp_gpu_batch_condense_lhs(b) != 0;
         for (int i = 0; i < bk->n; i++) { bk->st[i] = bad ? ACADOS_QP_FAILURE : ACADOS_SUCCESS; bk->it[i] = 0; }
         bk->status = bad ? ACADOS_QP_FAILURE : ACADOS_SUCCESS;
         bk->lhs_resident = !bad;
@@ -434,8 +453,9 @@ static void bucket_solve(gpu_bucket *bk, const ocp_qp_gpu_ipm_opts *o, int ws, i
     const int vec_only = mode == BATCH_RHS_SOLVE && bk->lhs_resident;
     bk->lhs_resident = 0;
     if ((ws >= 2 && ocp_qp_gpu_batch_set_bulk_out(b, bk->blob_out, 0) != 0)
-        || (vec_only ? ocp_qp_gpu_batch_set_bulk_vec(b, bk->blob_in, 0)
-                     : (staged ? ocp_qp_gpu_batch_set_bulk_staged(b) : ocp_qp_gpu_batch_set_bulk(b, bk->blob_in, 0))) != 0
+        || (staged == 2 ? ocp_qp_gpu_batch_gather_run(b, vec_only ? 2 : 0, bk->zc_ptrs)
+                        : (vec_only ? ocp_qp_gpu_batch_set_bulk_vec(b, bk->blob_in, 0)
+                                    : (staged ? ocp_qp_gpu_batch_set_bulk_staged(b) : ocp_qp_gpu_batch_set_bulk(b, bk->blob_in, 0)))) != 0
         || (vec_only ? ocp_qp_gpu_batch_condense_rhs_and_solve(b) : ocp_qp_gpu_batch_solve(b)) < 0 || ocp_qp_gpu_batch_get_bulk(b, bk->blob_out, 0) != 0
         || ocp_qp_gpu_batch_get_info(b, "status", bk->st) != 0 || ocp_qp_gpu_batch_get_info(b, "iter", bk->it) != 0)
     {
@@ -515,7 +535,8 @@ static int ocp_qp_gpu_ipm_acados(void *config, void *qp_in_, void *qp_out_, void
 static void bucket_release(gpu_bucket *bk)
 {
     if (bk->batch) ocp_qp_gpu_batch_destroy(bk->batch);
-    ocp_qp_gpu_host_free(bk->blob_in); ocp_qp_gpu_host_free(bk->blob_out);
+    ocp_qp_gpu_host_free(bk->blob_in); ocp_qp_gpu_host_free(bk->blob_out); ocp_qp_gpu_host_free((void *) bk->zc_ptrs);
+    free(bk->zc_cn); free(bk->zc_ext);
     free(bk->sig); free(bk->seg_in); free(bk->seg_out); free(bk->seg_seed); free(bk->seg_vec); free(bk->members); free(bk->st); free(bk->it);
     if (bk->mu_live) pthread_mutex_destroy(&bk->mu);
     memset(bk, 0, sizeof(*bk));
@@ -524,9 +545,18 @@ static void bucket_release(gpu_bucket *bk)
 static pthread_mutex_t g_group_pool_mu = PTHREAD_MUTEX_INITIALIZER;
 static gpu_group *g_group_pool = NULL; /* released headers (see gpu_group::gen); the only state of this file outside caller-owned objects */
 
+static void zc_unregister(gpu_group *g)
+{
+    for (int r = 0; r < g->zc_nr; r++) (void) ocp_qp_gpu_host_unregister(g->zc_r[r].lo);
+    free(g->zc_r); g->zc_r = NULL; g->zc_nr = 0;
+    if (g->zc_state > 0) g->zc_state = 0;
+}
+
 static void group_release(gpu_group *g)
 {
     if (!g) return;
+    zc_unregister(g);
+    free(g->zc_hint);
     for (int q = 0; q < g->nbk; q++) bucket_release(g->bk + q);
     free(g->bk); free(g->bucket_of); free(g->pos_of); free(g->scratch);
     const unsigned gen = g->gen + 1;
@@ -544,6 +574,233 @@ static void *xcalloc(size_t cnt, size_t sz)
     return p;
 }
 
+
+/* ------------------------------------------------------------------ zero-copy: the device reads the capsules' own QP memory
+ *
+ * Reading n capsules' qp_in into a pinned blob is a pass over n x 85 KB (C2-shaped QPs) of cold host memory: bound by the host's memory
+ * system at 26-29 GB/s on 16 threads however the loops are written (profiles/r06_orch_threads.txt), and the host->device copy comes on
+ * top.  A kernel reads host memory that is REGISTERED with the device at the PCIe rate (56 GB/s, profiles/r06_zero_copy_probe.txt).  So
+ * the batch entries (all capsules present, probed panel-major storage) register the blocks the member arrays of the n qp_in live in --
+ * once per group: ~20 us per block -- and hand the device, per call, only the arrays' addresses; the device library gathers the words into
+ * its blob (class-wide word tables: gpu_words_build) and goes on exactly as after _set_bulk.  The memory stays the capsule's: nothing is
+ * copied or moved on the host, every call re-reads the addresses from the structs and checks them against the registered blocks (a
+ * capsule whose qp_in moved: registered again; more than three times: the group goes back to the blob path).  Any refusal -- registration
+ * fails (pages already registered by somebody else, address space holes), a matrix with another cn than the class's -- is the blob path,
+ * whose results are the same byte for byte (tests/test_mock_acados.py).  ACADOS_AMD_ZERO_COPY=0 switches it off, =1 uses it at every size
+ * (by default a call whose whole QP data exceeds 160 MB keeps the chunked blob: zc_prepare).
+ * The blocks are unregistered when the group goes (terminate / memory_reset of the capsule that led the call, a new set of capsules):
+ * destroy capsule 0 of a batch first, as the generated `_free` loop does, or the others' memory is freed while still registered.
+ */
+#if defined(GPU_ZERO_COPY)
+#define ZC_PAGE ((size_t) 4096)
+
+/* ACADOS_AMD_ZERO_COPY: 0 never, 1 always, unset: by size (zc_prepare) */
+static int zc_enabled(void)
+{
+    const char *e = getenv("ACADOS_AMD_ZERO_COPY");
+    return e && e[0] == '0' ? 0 : (e && e[0] == '1' ? 2 : 1);
+}
+
+static int zc_range_cmp(const void *a_, const void *b_)
+{
+    const zc_range *a = (const zc_range *) a_, *b = (const zc_range *) b_;
+    return a->lo < b->lo ? -1 : (a->lo > b->lo);
+}
+
+/* sorted ranges -> merged in place (ranges closer than `gap` bytes become one); returns the new count */
+static int zc_merge(zc_range *r, int cnt, size_t gap)
+{
+    if (cnt == 0) return 0;
+    qsort(r, cnt, sizeof(zc_range), zc_range_cmp);
+    int o = 0;
+    for (int i = 1; i < cnt; i++)
+    {
+        if (r[i].lo <= r[o].hi + gap) { if (r[i].hi > r[o].hi) r[o].hi = r[i].hi; }
+        else r[++o] = r[i];
+    }
+    return o + 1;
+}
+
+/* the class's word tables -> device, once per bucket: 1 done, -1 refused */
+static int zc_tables(gpu_bucket *bk, const ocp_qp_in *in0)
+{
+    const int N = in0->dim->N, P = GPU_WORD_MEMBERS * (N + 1);
+    if (!bk->batch || bk->ps <= 0 || bk->L_in <= 0) return -1;
+    bk->zc_P = P;
+    bk->zc_cn = (int *) xcalloc(3 * (N + 1), sizeof(int));
+    bk->zc_ext = (int *) xcalloc(2 * (size_t) P, sizeof(int)); /* [the whole blob's | its vector part's] */
+    gpu_word_cn(in0, N, bk->zc_cn);
+    for (int which = 0; which < 2; which++) /* the whole input blob; its vector part (RTI feedback) */
+    {
+        const gpu_seg *tab = which ? bk->seg_vec : bk->seg_in;
+        const int cnt = which ? bk->n_vec : bk->n_in;
+        if (which && bk->L_vec <= 0) break;
+        gpu_word *w = NULL;
+        const int nw = gpu_words_build(tab, cnt, N, bk->ps, bk->zc_cn, &w);
+        if (!w) return -1;
+        int *col = (int *) xcalloc(3 * (size_t) nw, sizeof(int));
+        unsigned char *neg = (unsigned char *) xcalloc(nw, 1);
+        for (int q = 0; q < nw; q++)
+        {
+            col[q] = w[q].slot; col[nw + q] = w[q].off; col[2 * nw + q] = w[q].pos; neg[q] = w[q].neg;
+            int *ext = bk->zc_ext + (which ? P : 0);
+            if (w[q].off + 1 > ext[w[q].slot]) ext[w[q].slot] = w[q].off + 1;
+        }
+        const int rc = ocp_qp_gpu_batch_gather_tables(bk->batch, which ? 2 : 0, P, nw, col, col + nw, col + 2 * nw, neg);
+        free(w); free(col); free(neg);
+        if (rc != 0) return -1;
+    }
+    bk->zc_ptrs = (const void **) ocp_qp_gpu_host_alloc(sizeof(void *) * (size_t) bk->n * (size_t) P);
+    return bk->zc_ptrs ? 1 : -1;
+}
+
+/* register the pages under every source array of every capsule: 0 / -1 */
+static int zc_register(gpu_group *g, int n, ocp_qp_in **ins, size_t gap)
+{
+    int cap = 0;
+    for (int q = 0; q < g->nbk; q++) cap += g->bk[q].n * 8; /* (a capsule's arrays are carved from one block or two: grows if not) */
+    zc_range *all = (zc_range *) xcalloc(cap, sizeof(zc_range));
+    int cnt = 0, Pmax = 0;
+    for (int q = 0; q < g->nbk; q++) if (g->bk[q].zc_P > Pmax) Pmax = g->bk[q].zc_P;
+    zc_range *one = (zc_range *) xcalloc(Pmax, sizeof(zc_range));
+    const void **src = (const void **) xcalloc(Pmax, sizeof(void *));
+    for (int i = 0; i < n; i++)
+    {
+        const gpu_bucket *bk = g->bk + g->bucket_of[i];
+        int m = 0;
+        gpu_word_sources(ins[i], ins[i]->dim->N, src, 0);
+        for (int s = 0; s < bk->zc_P; s++)
+        {
+            if (bk->zc_ext[s] == 0) continue;
+            if (!src[s]) { free(all); free(one); free(src); return -1; }
+            one[m].lo = (char *) ((size_t) src[s] & ~(ZC_PAGE - 1));
+            one[m].hi = (char *) (((size_t) src[s] + sizeof(double) * (size_t) bk->zc_ext[s] + ZC_PAGE - 1) & ~(ZC_PAGE - 1));
+            m++;
+        }
+        m = zc_merge(one, m, gap);
+        if (cnt + m > cap)
+        {
+            cap = 2 * (cnt + m);
+            all = (zc_range *) realloc(all, sizeof(zc_range) * cap);
+            if (!all) { printf("\nerror: ocp_qp_gpu_ipm: out of host memory\n"); exit(1); }
+        }
+        memcpy(all + cnt, one, sizeof(zc_range) * m);
+        cnt += m;
+    }
+    free(one); free(src);
+    cnt = zc_merge(all, cnt, 0); /* capsules sharing a page share a block */
+    for (int r = 0; r < cnt; r++)
+        if (ocp_qp_gpu_host_register(all[r].lo, (size_t) (all[r].hi - all[r].lo)) != 0)
+        {
+            for (int u = 0; u < r; u++) (void) ocp_qp_gpu_host_unregister(all[u].lo);
+            free(all);
+            return -1;
+        }
+    g->zc_r = all; g->zc_nr = cnt;
+    return 0;
+}
+
+/* block holding [p, p + bytes): index, -1 none */
+static int zc_find(const gpu_group *g, const char *p, size_t bytes, int hint)
+{
+    if (hint >= 0 && hint < g->zc_nr && p >= g->zc_r[hint].lo && p + bytes <= g->zc_r[hint].hi) return hint;
+    int lo = 0, hi = g->zc_nr - 1;
+    while (lo <= hi)
+    {
+        const int mid = (lo + hi) / 2;
+        if (p < g->zc_r[mid].lo) hi = mid - 1;
+        else if (p >= g->zc_r[mid].hi) lo = mid + 1;
+        else return p + bytes <= g->zc_r[mid].hi ? mid : -1;
+    }
+    return -1;
+}
+
+/* the structs the next capsule's addresses are read from, towards the cache: 168 BLASFEO structs per C2-shaped capsule, cold, one
+ * dependent miss each otherwise */
+static void zc_prefetch(const ocp_qp_in *in, int N, int vec)
+{
+    const char *a[8] = {(const char *) in->b, (const char *) in->rqz, (const char *) in->d, (const char *) in->d_mask, (const char *) in->Z,
+                        (const char *) in->BAbt, (const char *) in->RSQrq, (const char *) in->DCt};
+    const int bytes_v = (N + 1) * (int) sizeof(struct blasfeo_dvec), bytes_m = (N + 1) * (int) sizeof(struct blasfeo_dmat);
+    for (int q = 0; q < (vec ? 5 : 8); q++)
+        for (int o = 0; o < (q < 5 ? bytes_v : bytes_m); o += 64) __builtin_prefetch(a[q] + o, 0, 1);
+}
+
+/* this call's source addresses into the buckets' pinned tables (`vec`: of the vector members only); 1: all of them inside registered
+ * blocks (`check`) and every matrix with the cn the word tables were built for, 0: not */
+static int zc_fill(gpu_group *g, int n, ocp_qp_in **ins, int check, int vec)
+{
+    int ok = 1;
+#pragma omp parallel for schedule(static) reduction(&& : ok)
+    for (int i = 0; i < n; i++)
+    {
+        const gpu_bucket *bk = g->bk + g->bucket_of[i];
+        const int N = ins[i]->dim->N, P = bk->zc_P;
+        const int *ext = vec ? bk->zc_ext + P : bk->zc_ext;
+        const void **row = bk->zc_ptrs + (size_t) g->pos_of[i] * (size_t) P;
+        if (i + 2 < n) { __builtin_prefetch(ins[i + 2], 0, 1); __builtin_prefetch((const char *) ins[i + 2] + 64, 0, 1); }
+        if (i + 1 < n) zc_prefetch(ins[i + 1], N, vec);
+        gpu_word_sources(ins[i], N, row, vec);
+        for (int k = 0; k <= N && !vec; k++)
+            ok = ok && (k == N || ins[i]->BAbt[k].cn == bk->zc_cn[SRC_BAbt * (N + 1) + k]) && ins[i]->RSQrq[k].cn == bk->zc_cn[SRC_RSQrq * (N + 1) + k]
+                 && ins[i]->DCt[k].cn == bk->zc_cn[SRC_DCt * (N + 1) + k];
+        int hint = g->zc_hint[i];
+        for (int s = 0; s < P; s++)
+        {
+            if (ext[s] == 0) { row[s] = NULL; continue; }
+            if (!check) continue;
+            hint = row[s] ? zc_find(g, (const char *) row[s], sizeof(double) * (size_t) ext[s], hint) : -1;
+            if (hint < 0) { ok = 0; break; }
+        }
+        g->zc_hint[i] = hint;
+    }
+    return ok;
+}
+
+/* 1: every bucket's zc_ptrs is filled and the device can read what they point at */
+static int zc_prepare(gpu_group *g, int n, ocp_qp_in **ins, int vec)
+{
+    const int mode = zc_enabled();
+    if (g->zc_state < 0 || !mode) return 0;
+    if (!vec && mode == 1)
+    {
+        /* The whole QP data of a LARGE call stays on the blob path: both are bound by PCIe there, and the gather moves whole 64-byte
+         * lines of 168 small arrays per capsule (1.17x the bytes of the packed blob) without the overlap the chunked blob has -- measured
+         * on C3-shaped capsules (profiles/r06_zero_copy_latency.txt): 1,024 of them (87 MB) 6.4 against 7.0 ms, 4,096 (348 MB) 17.3
+         * against 15.9 ms.  The vector part (an RTI feedback step) is always gathered. */
+        size_t bytes = 0;
+        for (int q = 0; q < g->nbk; q++) bytes += sizeof(double) * (size_t) g->bk[q].n * (size_t) g->bk[q].L_in;
+        if (bytes > ((size_t) 160 << 20)) return 0;
+    }
+    for (int q = 0; q < g->nbk; q++)
+    {
+        gpu_bucket *bk = g->bk + q;
+        if (bk->zc_tab == 0) bk->zc_tab = zc_tables(bk, ins[bk->members[0]]);
+        if (bk->zc_tab < 0) { g->zc_state = -1; return 0; }
+    }
+    if (!g->zc_hint) g->zc_hint = (int *) xcalloc(n, sizeof(int));
+    for (int attempt = 0; attempt < 2; attempt++)
+    {
+        if (g->zc_state == 0)
+        {
+            /* one block per capsule where its arrays sit within 64 KB of each other (they are carved from one allocation); a hole in
+             * between that is not mapped: block by array */
+            if (!zc_fill(g, n, ins, 0, 0) || (zc_register(g, n, ins, 16 * ZC_PAGE) != 0 && zc_register(g, n, ins, 0) != 0)) { g->zc_state = -1; return 0; }
+            g->zc_state = 1;
+        }
+        if (zc_fill(g, n, ins, 1, vec)) return 1;
+        /* a qp_in is somewhere else than last time */
+        zc_unregister(g);
+        if (++g->zc_rereg > 3) break;
+    }
+    zc_unregister(g);
+    g->zc_state = -1;
+    return 0;
+}
+#else
+static int zc_prepare(gpu_group *g, int n, ocp_qp_in **ins, int vec) { return 0; }
+#endif
+
 /* group of the n QPs of this call: reused as long as n and every QP's structure are what they were, else rebuilt --
  * QPs are bucketed by structure signature, one device batch per bucket */
 static gpu_group *group_for(int n, ocp_qp_in **ins, ocp_qp_gpu_ipm_memory **mems, const unsigned char *skip, int *fresh)
@@ -551,26 +808,36 @@ static gpu_group *group_for(int n, ocp_qp_in **ins, ocp_qp_gpu_ipm_memory **mems
     ocp_qp_gpu_ipm_memory *m0 = mems[0];
     gpu_group *g = mem_group(m0) && m0->group->owner == m0 ? m0->group : NULL;
     int need = 0, first = -1;
-    for (int i = 0; i < n; i++)
-    {
-        if (skip && skip[i]) continue;
-        if (first < 0) first = i;
-        const int l = sig_len(ins[i]->dim);
-        if (l > need) need = l;
-    }
+    for (int i = 0; i < n && first < 0; i++) if (!(skip && skip[i])) first = i;
     *fresh = 0;
     if (first < 0) return g; /* nobody takes part */
     if (g && g->n == n)
     {
-        int same = g->scratch_cap >= need;
-        for (int i = 0; i < n && same; i++)
+        /* every capsule's structure re-read and compared on every call (dims, idxb, idxs_rev, idxe: ~300 scattered cache lines per
+         * C2-shaped capsule, cold) -- on the host threads: serial it was 3 of the 4.7 ms a 4,096-capsule call spent before the device */
+        int same = 1;
+#if defined(_OPENMP)
+#pragma omp parallel for schedule(static) reduction(&& : same) num_threads(g->scratch_nt)
+#endif
+        for (int i = 0; i < n; i++)
         {
             if (skip && skip[i]) continue;
             const gpu_bucket *bk = g->bk + g->bucket_of[i];
-            same = sig_len(ins[i]->dim) == bk->sig_len && fill_sig(ins[i], g->scratch) == bk->sig_len
-                   && memcmp(bk->sig, g->scratch, sizeof(int) * bk->sig_len) == 0;
+#if defined(_OPENMP)
+            int *sc = g->scratch + (size_t) omp_get_thread_num() * (size_t) g->scratch_cap;
+#else
+            int *sc = g->scratch;
+#endif
+            const int l = sig_len(ins[i]->dim);
+            same = same && l == bk->sig_len && l <= g->scratch_cap && fill_sig(ins[i], sc) == l && memcmp(bk->sig, sc, sizeof(int) * l) == 0;
         }
         if (same) return g;
+    }
+    for (int i = 0; i < n; i++)
+    {
+        if (skip && skip[i]) continue;
+        const int l = sig_len(ins[i]->dim);
+        if (l > need) need = l;
     }
     group_release(g);
     *fresh = 1;
@@ -582,7 +849,12 @@ static gpu_group *group_for(int n, ocp_qp_in **ins, ocp_qp_gpu_ipm_memory **mems
     else { g = (gpu_group *) xcalloc(1, sizeof(gpu_group)); g->gen = 1; }
     g->owner = m0; g->n = n;
     g->bucket_of = (int *) xcalloc(n, sizeof(int)); g->pos_of = (int *) xcalloc(n, sizeof(int));
-    g->scratch = (int *) xcalloc(need, sizeof(int)); g->scratch_cap = need;
+#if defined(_OPENMP)
+    g->scratch_nt = omp_get_max_threads() > 0 ? omp_get_max_threads() : 1;
+#else
+    g->scratch_nt = 1;
+#endif
+    g->scratch = (int *) xcalloc((size_t) need * (size_t) g->scratch_nt, sizeof(int)); g->scratch_cap = need;
     int cap_bk = 4;
     g->bk = (gpu_bucket *) xcalloc(cap_bk, sizeof(gpu_bucket));
     for (int i = 0; i < n; i++)
@@ -678,7 +950,24 @@ static int evaluate_batch_masked(void *config, int n, void **qp_in_, void **qp_o
      * finished chunk goes to the device at once (asynchronous copy on the batch's stream), so the host->device copy of the QP data
      * (85 KB per C2-shaped QP: as long as the unpacking itself) runs while the host threads unpack the next chunk */
     int staged = 0;
-    if (vec_only)
+    const double t_grouped = now_s();
+    const int zc_on = !skip && zc_prepare(g, n, ins, vec_only);
+    if (getenv("ACADOS_AMD_TRACE_HOST")) fprintf(stderr, "host: group_for %.3f ms, zc_prepare %.3f ms\n", (t_grouped - t_start) * 1e3, (now_s() - t_grouped) * 1e3);
+    if (zc_on)
+    {
+        /* zero-copy: nothing of the QP data is read here -- the device gathers it from the capsules' memory (bucket_solve) */
+        staged = 2;
+        if (ws >= 2)
+        {
+#pragma omp parallel for schedule(static)
+            for (int i = 0; i < n; i++)
+            {
+                gpu_bucket *bk = g->bk + g->bucket_of[i];
+                unpack_qp_out_duals(&bk->lay, outs[i], bk->blob_out + (size_t) g->pos_of[i] * (size_t) bk->L_out);
+            }
+        }
+    }
+    else if (vec_only)
     {
 #pragma omp parallel for schedule(static)
         for (int i = 0; i < n; i++)
@@ -742,7 +1031,7 @@ static int evaluate_batch_masked(void *config, int n, void **qp_in_, void **qp_o
                 if (skip[bk->members[e]])
                     memcpy(bk->blob_in + (size_t) e * (size_t) bk->L_in, bk->blob_in + (size_t) src * (size_t) bk->L_in, sizeof(double) * (size_t) bk->L_in);
         }
-    if (!skip && !vec_only) for (int q = 0; q < g->nbk; q++) g->bk[q].blob_clean = 1; /* every slot was cleared (or was clean) and holds QP data only */
+    if (!skip && !vec_only && staged != 2) for (int q = 0; q < g->nbk; q++) g->bk[q].blob_clean = 1; /* every slot was cleared (or was clean) and holds QP data only */
     const double t_packed = now_s();
 
     /* one copy + one scatter launch, the solve, one gather launch + one copy per bucket; buckets run side by side
@@ -761,7 +1050,7 @@ static int evaluate_batch_masked(void *config, int n, void **qp_in_, void **qp_o
             if (mem_group(mi) && mi->group != g && mi->group->owner == mi) group_release(mi->group);
             mi->group = g; mi->group_gen = g->gen; mi->g_bucket = g->bucket_of[i]; mi->g_pos = g->pos_of[i];
             mi->time_unpack_in = t_packed - t_start; mi->time_pack_out = 0.0; mi->time_qp_solver_call = t_solved - t_packed;
-            mi->upload_doubles = g->bk[g->bucket_of[i]].L_in;
+            mi->upload_doubles = g->bk[g->bucket_of[i]].L_in; mi->zero_copy = staged == 2;
         }
         return worst_lhs;
     }
@@ -796,7 +1085,7 @@ static int evaluate_batch_masked(void *config, int n, void **qp_in_, void **qp_o
         mi->group = g; mi->group_gen = g->gen; mi->g_bucket = g->bucket_of[i]; mi->g_pos = g->pos_of[i];
         mi->iter = it; mi->status = st; mi->time_qp_solver_call = t_solved - t_packed;
         mi->time_unpack_in = t_packed - t_start; mi->time_pack_out = t_end - t_solved;
-        mi->upload_doubles = vec_only ? bk->L_vec : bk->L_in;
+        mi->upload_doubles = vec_only ? bk->L_vec : bk->L_in; mi->zero_copy = staged == 2;
         if (st != ACADOS_SUCCESS && (worst == 0 || worst == ACADOS_MAXITER)) worst = st;
     }
     return worst;

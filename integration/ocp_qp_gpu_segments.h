@@ -307,6 +307,86 @@ GPU_SEG_FN int gpu_layout_build(gpu_layout *bk, const ocp_qp_dims *d)
     return 0;
 }
 
+/* ------------------------------------------------------------------ zero-copy: the input blob as WORDS of the member arrays
+ *
+ * The batch entries let the device read the QP data from the capsules' own memory (ocp_qp_gpu_batch_gather_tables / _gather_run): one
+ * table per structure class says, for every double of the blob, which member array it comes from (slot = member * (N + 1) + stage, the
+ * members in the order of SRC_BAbt .. SRC_Z), at which offset of its storage -- the same index arithmetic as pm_unpack / pm_unpack_tran,
+ * with the PROBED panel height and the matrices' own cn -- and whether it is stored negated.  Sorted by (slot, offset): the device walks
+ * every array in storage order. */
+#if !defined(MF_COLMAJ)
+#define GPU_ZERO_COPY 1
+typedef struct { int slot, off, pos; unsigned char neg; } gpu_word;
+enum { GPU_WORD_MEMBERS = 8 };
+
+GPU_SEG_FN int gpu_word_cmp(const void *a_, const void *b_)
+{
+    const gpu_word *a = (const gpu_word *) a_, *b = (const gpu_word *) b_;
+    if (a->slot != b->slot) return a->slot < b->slot ? -1 : 1;
+    if (a->off != b->off) return a->off < b->off ? -1 : 1;
+    return a->pos < b->pos ? -1 : (a->pos > b->pos);
+}
+
+/* cn[member * (N + 1) + stage] of the three matrix members; returns the number of words, *out malloc'ed (NULL: out of memory) */
+GPU_SEG_FN int gpu_words_build(const gpu_seg *tab, int cnt, int N, int ps, const int *cn, gpu_word **out)
+{
+    size_t total = 0;
+    for (int s = 0; s < cnt; s++) total += (size_t) tab[s].len;
+    gpu_word *w = (gpu_word *) malloc(sizeof(gpu_word) * (total ? total : 1));
+    *out = w;
+    if (!w) return 0;
+    size_t q = 0;
+    for (int s = 0; s < cnt; s++)
+    {
+        const gpu_seg *g = tab + s;
+        const int slot = g->src * (N + 1) + g->k;
+        if (g->kind == SEG_VEC)
+        {
+            for (int e = 0; e < g->len; e++, q++) { w[q].slot = slot; w[q].off = g->ai + e; w[q].pos = g->off + e; w[q].neg = (unsigned char) (g->neg != 0); }
+            continue;
+        }
+        const int c = cn[slot];
+        for (int j = 0; j < g->n; j++)
+            for (int i = 0; i < g->m; i++, q++)
+            {
+                const int r = g->ai + i, in = r % ps;
+                w[q].slot = slot;
+                w[q].off = (r - in) * c + (g->aj + j) * ps + in;
+                w[q].pos = g->off + (g->kind == SEG_MAT ? i + g->m * j : j + g->n * i);
+                w[q].neg = 0;
+            }
+    }
+    qsort(w, q, sizeof(gpu_word), gpu_word_cmp);
+    return (int) q;
+}
+
+/* the storage of the eight members of one qp_in, in slot order (absent: NULL; vec_only: the matrix members are not looked at) */
+GPU_SEG_FN void gpu_word_sources(const ocp_qp_in *in, int N, const void **p, int vec_only)
+{
+    for (int k = 0; k <= N; k++)
+    {
+        p[SRC_BAbt * (N + 1) + k] = k < N && !vec_only ? in->BAbt[k].pA : NULL;
+        p[SRC_RSQrq * (N + 1) + k] = vec_only ? NULL : in->RSQrq[k].pA;
+        p[SRC_DCt * (N + 1) + k] = vec_only ? NULL : in->DCt[k].pA;
+        p[SRC_b * (N + 1) + k] = k < N ? in->b[k].pa : NULL;
+        p[SRC_rqz * (N + 1) + k] = in->rqz[k].pa;
+        p[SRC_d * (N + 1) + k] = in->d[k].pa;
+        p[SRC_dmask * (N + 1) + k] = in->d_mask[k].pa;
+        p[SRC_Z * (N + 1) + k] = in->Z[k].pa;
+    }
+}
+
+GPU_SEG_FN void gpu_word_cn(const ocp_qp_in *in, int N, int *cn) /* 3 * (N + 1) */
+{
+    for (int k = 0; k <= N; k++)
+    {
+        cn[SRC_BAbt * (N + 1) + k] = k < N ? in->BAbt[k].cn : 0;
+        cn[SRC_RSQrq * (N + 1) + k] = in->RSQrq[k].cn;
+        cn[SRC_DCt * (N + 1) + k] = in->DCt[k].cn;
+    }
+}
+#endif /* !MF_COLMAJ */
+
 /* ------------------------------------------------------------------ blob <-> acados structs, one instance */
 
 GPU_SEG_FN void unpack_segs(const gpu_seg *tab, int cnt, double *blob, struct blasfeo_dmat *const *mats, struct blasfeo_dvec *const *vecs, int ps)

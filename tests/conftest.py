@@ -279,8 +279,10 @@ def limit_cycle_case(clib):
 
 def bulk_chunk_case(clib):
     """C-ABI parity of the input blob entries (include/acados_amd/ocp_qp_gpu_batch.h): the QP data of a batch read as ONE blob
-    (_get_bulk_in), written into fresh batches whole (_set_bulk) and in uneven chunks (_set_bulk_chunk x 3 + _set_bulk_staged):
-    the same blob back, the same solve bit for bit; the refusals of the chunk entries.  clib = None: the product library"""
+    (_get_bulk_in), written into fresh batches whole (_set_bulk), in uneven chunks (_set_bulk_chunk x 3 + _set_bulk_staged) and by the
+    ZERO-COPY GATHER (_host_register + _gather_tables + _gather_run: the blob's words spread over three source arrays per instance in a
+    host block the caller owns, some stored negated, read by the device from there): the same blob back, the same solve bit for bit; the
+    refusals of the chunk and table entries.  clib = None: the product library"""
     import ctypes as C
     from acados_amd import OcpQpGpuBatch
     from random_qp import random_structure_qp
@@ -302,10 +304,37 @@ def bulk_chunk_case(clib):
         assert np.isfinite(blob).all() and np.abs(blob).max() > 0
         assert a.solve() == 0
         outs = []
-        for how in ("whole", "chunks"):
+        for how in ("whole", "gather", "chunks"):
             b = OcpQpGpuBatch.from_qps([qp] * B, _clib=clib)     # (structure and index sets; the data is overwritten below)
             if how == "whole":
                 assert L.ocp_qp_gpu_batch_set_bulk(b._h, blob.ctypes.data_as(C.c_void_p), 0) == 0
+            elif how == "gather":
+                P = 3
+                slot = g.integers(0, P, n).astype(np.int32)
+                cnt = np.bincount(slot, minlength=P)
+                off = np.zeros(n, np.int32)
+                for s_ in range(P):                                # every source: its words at shuffled offsets, a gap of 5 in front
+                    off[slot == s_] = 5 + g.permutation(cnt[s_])
+                neg = (g.uniform(size=n) < 0.3).astype(np.uint8)
+                order = np.lexsort((off, slot))                    # sorted by (slot, offset) as the header asks
+                pos = np.arange(n, dtype=np.int32)[order]
+                slot, off, neg = slot[order], off[order], neg[order]
+                stride = int(cnt.max()) + 16
+                block = np.full((B, P, stride), np.nan)            # the caller's memory: NaN wherever no word lives
+                for i in range(B):
+                    block[i, slot, off] = np.where(neg, -blob[i, pos], blob[i, pos])
+                ptrs = np.array([[block[i, s_].ctypes.data for s_ in range(P)] for i in range(B)], dtype=np.uint64)
+                ip = lambda a_: a_.ctypes.data_as(C.c_void_p)
+                bad = pos.copy(); bad[0] = n
+                assert L.ocp_qp_gpu_batch_gather_run(b._h, 0, ip(ptrs)) == -1                              # no tables yet
+                assert L.ocp_qp_gpu_batch_gather_tables(b._h, 0, P, n, ip(slot), ip(off), ip(bad), ip(neg)) == -1   # a word outside the blob
+                assert L.ocp_qp_gpu_batch_gather_tables(b._h, 0, 2, n, ip(slot), ip(off), ip(pos), ip(neg)) == -1   # a source that is not there
+                assert L.ocp_qp_gpu_batch_gather_tables(b._h, 0, P, n, ip(slot), ip(off), ip(pos), ip(neg)) == 0
+                assert L.ocp_qp_gpu_host_register(ip(block), block.nbytes) == 0
+                try:
+                    assert L.ocp_qp_gpu_batch_gather_run(b._h, 0, ip(ptrs)) == 0
+                finally:
+                    assert L.ocp_qp_gpu_host_unregister(ip(block)) == 0
             else:
                 assert L.ocp_qp_gpu_batch_set_bulk_staged(b._h) == -1          # nothing handed over yet
                 for lo, hi in ((0, 5), (5, 30), (30, 37)):

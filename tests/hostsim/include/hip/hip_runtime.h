@@ -51,6 +51,10 @@ static inline hipError_t hipMalloc(void **p, size_t n) { *p = malloc(n); return 
 static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
 static inline hipError_t hipHostMalloc(void **p, size_t n) { *p = malloc(n); return hipSuccess; }
 static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
+enum { hipHostRegisterDefault = 0 };
+static inline hipError_t hipHostRegister(void *, size_t, unsigned) { return hipSuccess; } /* (host memory IS the simulation's device memory) */
+static inline hipError_t hipHostUnregister(void *) { return hipSuccess; }
+static inline hipError_t hipHostGetDevicePointer(void **d, void *h, unsigned) { *d = h; return hipSuccess; }
 static inline hipError_t hipMemset(void *p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void *p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }

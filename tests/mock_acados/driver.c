@@ -105,8 +105,10 @@ static int run_batch(int argc, char **argv)
     config.memory_get(&config, mems[0], "kernel_name", &kname);
     int it_max = 0;
     for (int i = 0; i < n; i++) if (caps[i]->info.num_iter > it_max) it_max = caps[i]->info.num_iter;
-    printf("batch n %d ms_per_call %.3f status %d interface_ms %.3f solve_ms %.3f sens_ms %.3f iter_max %d\n", n, best * 1e3, status,
-           caps[0]->info.interface_time * 1e3, caps[0]->info.solve_QP_time * 1e3, sens_s * 1e3, it_max);
+    int zero_copy = 0;
+    config.memory_get(&config, mems[0], "zero_copy", &zero_copy);
+    printf("batch n %d ms_per_call %.3f status %d interface_ms %.3f solve_ms %.3f sens_ms %.3f iter_max %d zero_copy %d\n", n, best * 1e3, status,
+           caps[0]->info.interface_time * 1e3, caps[0]->info.solve_QP_time * 1e3, sens_s * 1e3, it_max, zero_copy);
     fprintf(stderr, "kernel of capsule 0: %s\n", kname);
     FILE *g = fopen(argv[5], "wb");
     for (int i = 0; i < n; i++)

@@ -193,11 +193,13 @@ static int run_batch(int argc, char **argv)
     }
     /* where the time of the last ONE-CALL evaluate went (extension fields of the adapter's memory_get; qp_info.solve_QP_time = the device's own event time) */
     double t_unpack = 0.0, t_pack = 0.0, t_call = 0.0;
+    int zero_copy = 0;
     {
         void *sm = ((ocp_qp_xcond_solver_memory *) mems[0])->solver_memory;
         config->qp_solver->memory_get(config->qp_solver, sm, "time_unpack_in", &t_unpack);
         config->qp_solver->memory_get(config->qp_solver, sm, "time_pack_out", &t_pack);
         config->qp_solver->memory_get(config->qp_solver, sm, "time_qp_solver_call", &t_call);
+        config->qp_solver->memory_get(config->qp_solver, sm, "zero_copy", &zero_copy);
     }
     const double t_dev = ((qp_info *) outs[0]->misc)->solve_QP_time;
     /* the same QPs as the two halves of an RTI step (the batch counterparts of condense_lhs / condense_rhs_and_solve): preparation sends
@@ -262,9 +264,9 @@ static int run_batch(int argc, char **argv)
     config->qp_solver->memory_get(config->qp_solver, ((ocp_qp_xcond_solver_memory *) mems[0])->solver_memory, "cond_N_active", &cond_active);
     printf("batch n %d ms_per_call %.6f status %d fused_vs_orchestrated %.17g orchestrated_status %d xcond_N %d xcond_nu0 %d cond_N_active %d res_max %.17g "
            "unpack_in_ms %.4f copy_and_device_ms %.4f device_solve_ms %.4f pack_out_ms %.4f threads %d rti_preparation_ms %.6f rti_feedback_ms %.6f "
-           "rti_status %d rti_vs_one_call %.17g rti_feedback_upload_doubles %d fb_unpack_in_ms %.4f fb_copy_and_device_ms %.4f fb_pack_out_ms %.4f end\n", n,
+           "rti_status %d rti_vs_one_call %.17g rti_feedback_upload_doubles %d fb_unpack_in_ms %.4f fb_copy_and_device_ms %.4f fb_pack_out_ms %.4f zero_copy %d end\n", n,
            best * 1e3, status, fvo, st_one, xd->N, xd->nu[0], cond_active, res_max, t_unpack * 1e3, t_call * 1e3, t_dev * 1e3, t_pack * 1e3, omp_get_max_threads(),
-           best_prep * 1e3, best_fb * 1e3, rti_status, rti_diff, rti_upload, fb_unpack * 1e3, fb_call * 1e3, fb_pack * 1e3);
+           best_prep * 1e3, best_fb * 1e3, rti_status, rti_diff, rti_upload, fb_unpack * 1e3, fb_call * 1e3, fb_pack * 1e3, zero_copy);
     FILE *g = fopen(argv[4], "wb");
     for (int i = 0; i < n; i++)
     {

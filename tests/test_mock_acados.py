@@ -348,14 +348,19 @@ def test_acados_adapter_batch_chunked_staging(clib, tmp_path):
     fa, fb = str(tmp_path / "qa.txt"), str(tmp_path / "qb.txt")
     _write_qp(qa, fa); _write_qp(qb, fb)
     n = 299
-    info, per, extra, raw = _run_batch(exe, tmp_path, n, [fa, fb], sens=False)
-    info0, per0, _, raw0 = _run_batch(exe, tmp_path, n, [fa, fb], sens=False, extra_env={"ACADOS_AMD_NO_CHUNKS": "1"}, tag="whole")
-    assert info["status"] == 0 and info0["status"] == 0 and per == per0
+    host = {"ACADOS_AMD_ZERO_COPY": "0"}
+    info, per, extra, raw = _run_batch(exe, tmp_path, n, [fa, fb], sens=False, extra_env=host)
+    info0, per0, _, raw0 = _run_batch(exe, tmp_path, n, [fa, fb], sens=False, extra_env=dict(host, ACADOS_AMD_NO_CHUNKS="1"), tag="whole")
+    assert info["status"] == 0 and info0["status"] == 0 and per == per0 and info["zero_copy"] == 0
     assert raw.size == raw0.size and np.array_equal(raw, raw0)
+    # the default: NO host pass over the QP data at all -- the capsules' memory is registered with the device, which gathers the words of
+    # the blob from BLASFEO's storage itself (ocp_qp_gpu_batch_gather_run; word tables from the same probed layout) -- byte for byte
+    infoz, perz, _, rawz = _run_batch(exe, tmp_path, n, [fa, fb], sens=False, tag="zero_copy")
+    assert infoz["status"] == 0 and infoz["zero_copy"] == 1 and perz == per and np.array_equal(raw, rawz)
     # the panel-run copies of the batch entries (ocp_qp_gpu_segments.h: BLASFEO's storage as PROBED through its own pack routine)
     # against the same call with every block read through blasfeo_unpack_* (ACADOS_AMD_LA_API=1): byte for byte
     info1, per1, _, raw1 = _run_batch(exe, tmp_path, n, [fa, fb], sens=False, extra_env={"ACADOS_AMD_LA_API": "1"}, tag="la_api")
-    assert info1["status"] == 0 and per == per1 and np.array_equal(raw, raw1)
+    assert info1["status"] == 0 and per == per1 and np.array_equal(raw, raw1) and info1["zero_copy"] == 0   # (no probed layout: no gather)
     p = 0
     for i in range(n):
         qp = _perturbed(qb if i & 1 else qa, i)
