@@ -1379,7 +1379,7 @@ static void pcond_launch(ocp_qp_gpu_batch *b, bool expand)
     }
     if ((b->pc_rt || b->AW > 1 || c->AW > 1) && !(expand && b->pc_lane_expand && b->AW <= 1 && c->AW <= 1))
     {
-        if (expand) GQP_LAUNCH_COOP(gqp::kw_pexpand, dim3(b->Bp), dim3(64), b->pc_shmem, b->stream, b->D, c->D, b->pmap);
+        if (expand) GQP_LAUNCH_COOP(gqp::kw_pexpand, dim3(b->Bp, b->pmap.N2 + 1), dim3(64), b->pc_shmem, b->stream, b->D, c->D, b->pmap);
         else GQP_LAUNCH_COOP(gqp::kw_pcond, dim3(b->Bp), dim3(64), b->pc_shmem, b->stream, b->D, c->D, b->pmap);
     }
     else
@@ -2605,6 +2605,20 @@ int ocp_qp_gpu_batch_bulk_offset(ocp_qp_gpu_batch *b, int output, const char *fi
 try { return gqp_bulk_offset_impl(b, output, field, stage, len); }
 catch (const gqp_hip_failure &) { if (len) *len = 0; return -1; }
 
+#define GQP_MASK_SPC 4 /* stages per thread of k_bulk_masks */
+
+/* blob (instance-major) -> the arrays of a bulk map: lanes along the elements where the destinations are instance-major too, through
+ * an LDS tile where they are wave-tiled (ACADOS_AMD_SCATTER_PLAIN=1: one lane per instance, the cross-check) */
+static void bulk_scatter_launch(ocp_qp_gpu_batch *b, const double *src, int len, ocp_qp_gpu_batch::BulkMap &M)
+{
+    if (b->aos && !getenv("ACADOS_AMD_SCATTER_PLAIN"))
+        hipLaunchKernelGGL(gqp::k_bulk_scatter_aos, dim3((len + 255) / 256, b->B), dim3(256), 0, b->stream, src, b->B, len, M.d_arr, M.d_elem, M.T);
+    else if (!getenv("ACADOS_AMD_SCATTER_PLAIN"))
+        GQP_LAUNCH_COOP(gqp::k_bulk_scatter_tile, dim3((b->B + 63) / 64, (len + 63) / 64), dim3(64), 0, b->stream, src, b->B, len, M.d_arr, M.d_elem, M.T);
+    else
+        hipLaunchKernelGGL(gqp::k_bulk_scatter, dim3((b->B + 63) / 64, (len + 255) / 256), dim3(64), 0, b->stream, src, b->B, len, M.d_arr, M.d_elem, M.T);
+}
+
 int ocp_qp_gpu_batch_set_bulk(ocp_qp_gpu_batch *b, const double *blob, int is_device)
 try
 {
@@ -2614,11 +2628,11 @@ try
     HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
     HIPCHK(hipEventRecord(e0, b->stream));
     const double *src = stage_in(b, blob, (size_t) b->B * len, is_device);
-    const dim3 grid((b->B + 63) / 64, (len + 255) / 256), block(64);
-    hipLaunchKernelGGL(gqp::k_bulk_scatter, grid, block, 0, b->stream, src, b->B, len, M.d_arr, M.d_elem, M.T);
+    const dim3 block(64);
+    bulk_scatter_launch(b, src, len, M);
     if (M.nm)
-        hipLaunchKernelGGL(gqp::k_bulk_masks, dim3((b->B + 63) / 64), block, 0, b->stream, src, b->B, len, M.d_moff,
-                           M.d_mstage, M.d_mbit, M.nm, b->D.amask, b->AW);
+        hipLaunchKernelGGL(gqp::k_bulk_masks, dim3((b->B + 63) / 64, (b->N + 1 + GQP_MASK_SPC - 1) / GQP_MASK_SPC), block, 0, b->stream, src, b->B, len, M.d_moff,
+                           M.d_mstage, M.d_mbit, M.nm, b->D.amask, b->AW, GQP_MASK_SPC);
     HIPCHK(hipEventRecord(e1, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     float ms = 0.f;
@@ -2638,11 +2652,11 @@ try
     auto &M = b->bulk_vec;
     HIPCHK(hipEventRecord(b->ev0, b->stream));
     const double *src = stage_in(b, blob, (size_t) b->B * len, is_device);
-    const dim3 grid((b->B + 63) / 64, (len + 255) / 256), block(64);
-    hipLaunchKernelGGL(gqp::k_bulk_scatter, grid, block, 0, b->stream, src, b->B, len, M.d_arr, M.d_elem, M.T);
+    const dim3 block(64);
+    bulk_scatter_launch(b, src, len, M);
     if (M.nm)
-        hipLaunchKernelGGL(gqp::k_bulk_masks, dim3((b->B + 63) / 64), block, 0, b->stream, src, b->B, len, M.d_moff,
-                           M.d_mstage, M.d_mbit, M.nm, b->D.amask, b->AW);
+        hipLaunchKernelGGL(gqp::k_bulk_masks, dim3((b->B + 63) / 64, (b->N + 1 + GQP_MASK_SPC - 1) / GQP_MASK_SPC), block, 0, b->stream, src, b->B, len, M.d_moff,
+                           M.d_mstage, M.d_mbit, M.nm, b->D.amask, b->AW, GQP_MASK_SPC);
     HIPCHK(hipEventRecord(b->ev1, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     float ms = 0.f;
@@ -2779,11 +2793,11 @@ try
         fprintf(stderr, "acados_amd: ocp_qp_gpu_batch_set_bulk_staged: %ld of %d instances were handed over since the last scatter\n", got, b->B);
         return -1;
     }
-    const dim3 grid((b->B + 63) / 64, (len + 255) / 256), block(64);
-    hipLaunchKernelGGL(gqp::k_bulk_scatter, grid, block, 0, b->stream, (const double *) b->d_chunks, b->B, len, M.d_arr, M.d_elem, M.T);
+    const dim3 block(64);
+    bulk_scatter_launch(b, (const double *) b->d_chunks, len, M);
     if (M.nm)
-        hipLaunchKernelGGL(gqp::k_bulk_masks, dim3((b->B + 63) / 64), block, 0, b->stream, (const double *) b->d_chunks, b->B, len, M.d_moff,
-                           M.d_mstage, M.d_mbit, M.nm, b->D.amask, b->AW);
+        hipLaunchKernelGGL(gqp::k_bulk_masks, dim3((b->B + 63) / 64, (b->N + 1 + GQP_MASK_SPC - 1) / GQP_MASK_SPC), block, 0, b->stream, (const double *) b->d_chunks, b->B, len, M.d_moff,
+                           M.d_mstage, M.d_mbit, M.nm, b->D.amask, b->AW, GQP_MASK_SPC);
     HIPCHK(hipEventRecord(b->ev1, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     float ms = 0.f;
@@ -2827,8 +2841,7 @@ try
     const int len = gqp_bulk_len_impl(b, 1);
     auto &M = b->bulk_out;
     const double *src = stage_in(b, blob, (size_t) b->B * len, is_device);
-    const dim3 grid((b->B + 63) / 64, (len + 255) / 256), block(64);
-    hipLaunchKernelGGL(gqp::k_bulk_scatter, grid, block, 0, b->stream, src, b->B, len, M.d_arr, M.d_elem, M.T);
+    bulk_scatter_launch(b, src, len, M);
     HIPCHK(hipStreamSynchronize(b->stream));
     return 0;
 }

@@ -1148,6 +1148,39 @@ static __global__ void k_bulk_scatter(const double *blob, int nb, int len, const
     }
 }
 
+/* the same for INSTANCE-MAJOR destinations (the wave-per-instance families): lanes along the elements of one instance -- source and
+ * destination of a wave are both runs of one instance's memory.  Grid (elements / 256, instances). */
+static __global__ void __launch_bounds__(256) k_bulk_scatter_aos(const double *blob, int nb, int len, const int *map_arr, const int *map_elem,
+                                                                 GArrTable T)
+{
+    const int i = blockIdx.y, e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nb || e >= len) return;
+    const int a = map_arr[e];
+    if (a >= 0) GATL(T.a[a], map_elem[e]) = blob[(size_t) i * len + e];
+}
+
+/* the same through an LDS tile, for WAVE-TILED destinations: the blob is instance-major, so a lane that walks its own instance makes
+ * every load of its wave touch 64 different lines (0.44 ms for 4,096 C3-shaped QPs, 1.6 TB/s of reads + writes).  Here the wave reads
+ * 64 consecutive doubles of one instance per load and writes element e of 64 consecutive instances per store.  Grid (instances / 64,
+ * elements / 64), one wave per block. */
+static __global__ void __launch_bounds__(64) k_bulk_scatter_tile(const double *blob, int nb, int len, const int *map_arr, const int *map_elem,
+                                                                 GArrTable T)
+{
+    __shared__ double tile[64 * 65];
+    const int lane = threadIdx.x, i0 = blockIdx.x * 64, e0 = blockIdx.y * 64;
+    const int ni = nb - i0 < 64 ? nb - i0 : 64, ne = len - e0 < 64 ? len - e0 : 64;
+    for (int r = 0; r < ni; r++)
+        if (lane < ne) tile[lane * 65 + r] = blob[(size_t) (i0 + r) * len + e0 + lane];
+    __syncthreads();
+    const int i = i0 + lane;
+    if (lane < ni)
+        for (int c = 0; c < ne; c++)
+        {
+            const int a = map_arr[e0 + c];
+            if (a >= 0) GATL(T.a[a], map_elem[e0 + c]) = tile[c * 65 + lane];
+        }
+}
+
 /*
  * The step of an iteration applied by a launch of its own: (ux, pi, sv) += a d(.), (lam, t) of every side that takes part
  * += a d(.) floored at (lam_min, t_min) -- exactly what the update passes at the end of the corrector sweeps do, but with the
@@ -1262,20 +1295,32 @@ static __global__ void k_bulk_gather(double *blob, int nb, int len, const int *m
 }
 
 /* mask entries of the blob: (offset in blob, stage, bit) triples */
-static __global__ void k_bulk_masks(const double *blob, int nb, int len, const int *m_off, const int *m_stage,
-                                    const int *m_bit, int nm, GArrU64 amask, int AW)
+static __global__ void k_bulk_masks(const double *__restrict__ blob, int nb, int len, const int *__restrict__ m_off, const int *__restrict__ m_stage,
+                                    const int *__restrict__ m_bit, int nm, GArrU64 amask, int AW, int spc)
 {
+    /* grid.y: groups of `spc` stages (mask words belong to ONE stage: no two groups touch the same word); a word is read once, takes
+     * all its bits in a register and is written once -- a read-modify-write of global memory per ENTRY, one thread walking all of an
+     * instance's entries, was a chain of 300 dependent round trips (0.11 ms whatever the batch size) */
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nb) return;
+    const int s0 = blockIdx.y * spc, s1 = s0 + spc;
+    int wc = -1;
+    uint64_t m = 0;
     for (int q = 0; q < nm; q++)
     {
-        if (m_bit[q] < 0) continue;
-        const int w = m_stage[q] * AW + (m_bit[q] >> 6), bit = m_bit[q] & 63;
-        uint64_t m = GATL(amask, w);
+        const int st = m_stage[q], bq = m_bit[q];
+        if (bq < 0 || st < s0 || st >= s1) continue;
+        const int w = st * AW + (bq >> 6), bit = bq & 63;
+        if (w != wc)
+        {
+            if (wc >= 0) GATL(amask, wc) = m;
+            wc = w;
+            m = GATL(amask, w);
+        }
         if (blob[(size_t) i * len + m_off[q]] != 0.0) m |= (uint64_t) 1 << bit;
         else m &= ~((uint64_t) 1 << bit);
-        GATL(amask, w) = m;
     }
+    if (wc >= 0) GATL(amask, wc) = m;
 }
 
 /* the reverse: mask entries of the blob <- the bits (1.0 / 0.0) */

@@ -518,8 +518,11 @@ static __global__ void __launch_bounds__(64) kw_pexpand(GqpDev P, GqpDev Cd, Pco
     if (inst >= P.B) return;
     double *x = smem, *u = x + 64, *pn = u + 64, *ux = pn + 64; /* ux: [u; x] of the stage being visited */
 
-    for (int jb = 0; jb <= Mp.N2; jb++)
+    /* The blocks of an instance are independent of each other here -- every block starts from the condensed solution's own state and
+     * multiplier -- so the grid is (instances, blocks): one wave walking all N2 + 1 blocks of its instance was a chain of N dependent
+     * mat-vecs with one round trip to memory each (0.91 ms for 4,096 C3-shaped instances, a fifth of the device time of such a batch) */
     {
+        const int jb = blockIdx.y;
         const int k0 = Mp.blk_start[jb < Mp.N2 ? jb : Mp.N2];
         const int bs = jb < Mp.N2 ? Mp.blk_start[jb + 1] - k0 : 1;
         /* forward simulation of the eliminated states */
@@ -606,7 +609,7 @@ static __global__ void __launch_bounds__(64) kw_pexpand(GqpDev P, GqpDev Cd, Pco
         }
         __syncthreads();
     }
-    if (lane == 0)
+    if (lane == 0 && blockIdx.y == 0)
     {
         P.iter[inst] = Cd.iter[inst];
         P.status[inst] = Cd.status[inst];

@@ -290,12 +290,14 @@ def pcie_rates(mb=256, reps=3):
         return {"error": str(e)[:80]}
 
 
-def boundary_c3(n=4096, reps=4):
+def boundary_c3(n=4096, reps=4, larger=16384):
     """THROUGH THE BOUNDARY: n C3-shaped capsules (N = 50, nx = 8, nu = 3, cond_N = 10), each an acados `ocp_qp_in` / `ocp_qp_out` pair
     (HPIPM structs, panel-major BLASFEO storage: the stand-ins of tests/mock_hpipm -- the real ones are empty submodules of the
     reference) with the reference's own 22-slot solver object around the two plugin slots, ONE call of
-    ocp_qp_gpu_xcond_solver_acados_evaluate_batch: host threads read every member array of every qp_in into the pinned blob, chunked
-    host->device copies overlap with that, condensing + IPM + expansion on the device, one copy back, host threads write every qp_out.
+    ocp_qp_gpu_xcond_solver_acados_evaluate_batch: the QP data of every qp_in to the device (host threads fill a pinned blob under chunked
+    host->device copies, or -- smaller calls and the vector part of an RTI feedback step -- the device gathers it from the capsules' own
+    registered memory), condensing + IPM + expansion on the device, one copy back, host threads write every qp_out.  `at_<larger>`: the
+    same at the second size the review asked for.
     What a user of `_acados_batch_solve` gets per call, PCIe included.  The binary is built by
     integration/Makefile where the reference tree exists and travels with the snapshot."""
     exe = os.path.join(ROOT, "integration", "_ref_build", "ref_xcond_driver")
@@ -310,15 +312,25 @@ def boundary_c3(n=4096, reps=4):
     threads = threads_allowed()
     env = dict(os.environ, OMP_NUM_THREADS=str(threads))
     env.pop("ACADOS_AMD_WPI_BATCH_MAX", None)
-    r = subprocess.run([exe, "batch", str(n), f, os.path.join(d, "out.bin"), "--cond-N", "10", str(reps)], capture_output=True, text=True, env=env)
-    try:
-        os.remove(os.path.join(d, "out.bin"))
-    except OSError:
-        pass
-    if r.returncode != 0 or not r.stdout:
-        return {"error": (r.stderr or r.stdout)[-300:]}
-    h = r.stdout.splitlines()[0].split()
-    info = {h[i]: float(h[i + 1]) for i in range(1, len(h) - 1, 2)}
+    def run(n_):
+        r = subprocess.run([exe, "batch", str(n_), f, os.path.join(d, "out.bin"), "--cond-N", "10", str(reps)], capture_output=True, text=True, env=env)
+        try:
+            os.remove(os.path.join(d, "out.bin"))
+        except OSError:
+            pass
+        if r.returncode != 0 or not r.stdout:
+            return None, (r.stderr or r.stdout)[-300:]
+        h = r.stdout.splitlines()[0].split()
+        return {h[i]: float(h[i + 1]) for i in range(1, len(h) - 1, 2)}, None
+    info, err = run(n)
+    if info is None:
+        return {"error": err}
+    big = None
+    if larger and larger > n:
+        bi, berr = run(larger)
+        big = ({"batch": larger, "solves_per_s": larger / (bi["ms_per_call"] * 1e-3), "ms_per_step": bi["ms_per_call"], "failures": int(bi.get("status", 0) != 0),
+                "rti_feedback_solves_per_s": larger / (bi["rti_feedback_ms"] * 1e-3) if bi.get("rti_feedback_ms") else None,
+                "rti_feedback_ms": bi.get("rti_feedback_ms"), "max_kkt_residual_reference_entry": bi.get("res_max")} if bi else {"error": berr})
     b_in, b_out = algorithmic_bytes_dims(lqr_dims(N, 8, 3))
     t = info["ms_per_call"] * 1e-3
     pcie = n * (b_in + b_out)
@@ -327,6 +339,7 @@ def boundary_c3(n=4096, reps=4):
             "batch": n, "solves_per_s": n / t, "ms_per_step": t * 1e3, "failures": int(info.get("status", 0) != 0), "host_threads": int(info.get("threads", threads)),
             "max_kkt_residual_reference_entry": info.get("res_max"), "fused_vs_per_capsule_orchestration": info.get("fused_vs_orchestrated"),
             "phases_ms": {k: info[k] for k in ("unpack_in_ms", "copy_and_device_ms", "device_solve_ms", "pack_out_ms") if k in info},
+            "zero_copy_gather": int(info.get("zero_copy", 0)), f"at_{larger}": big,
             # the same capsules as the two halves of an RTI step: preparation (everything to the device, matrices condensed there) is off the
             # control loop's critical path; the FEEDBACK call reads and sends only the vector members of every qp_in
             "rti_feedback": ({"solves_per_s": n / (info["rti_feedback_ms"] * 1e-3), "ms_per_step": info["rti_feedback_ms"],

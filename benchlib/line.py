@@ -93,6 +93,9 @@ def compact_line(out, detail_path=None):
             if c.get("rti_feedback"):
                 rec["rti_feedback_solves_per_s"] = _r(c["rti_feedback"]["solves_per_s"], 4)
                 rec["rti_feedback_ms"] = _r(c["rti_feedback"]["ms_per_step"], 4)
+            for k_, v_ in c.items():
+                if k_.startswith("at_") and isinstance(v_, dict) and "solves_per_s" in v_:
+                    rec[k_] = [_r(v_["solves_per_s"], 4), _r(v_.get("rti_feedback_solves_per_s"), 4)]   # [one call, RTI feedback half] QP/s
             if "phases_ms" in c:
                 rec["phases_ms"] = [_r(c["phases_ms"].get(k), 3) for k in ("unpack_in_ms", "copy_and_device_ms", "device_solve_ms", "pack_out_ms")]
             rec.update({"frac": _r(ro_c.get("frac"), 3), "traffic_over_algorithmic": _r(ro_c.get("traffic_over_algorithmic"), 3)})

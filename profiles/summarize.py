@@ -37,6 +37,29 @@ def kernel(db):
         print(f"  {short:40s} {dur / 1e3:10.1f}  vgpr {v} agpr {a} sgpr {s} scratch {sc}")
 
 
+def timeline(db, which=-1):
+    """every launch of ONE solve in order (`which`-th window between two init launches, default the last complete one): offset from
+    the window's first launch, duration, the gap to the previous launch's end -- where a latency-bound small batch spends its time"""
+    cur = sqlite3.connect(db).cursor()
+    rows = cur.execute("select name,start,end from kernels order by start").fetchall()
+    marks = [i for i, r in enumerate(rows) if "_init<" in r[0] or "k_init" in r[0]]
+    if len(marks) < 2:
+        print("fewer than two solves in the trace"); return
+    which = int(which)
+    lo, hi = (marks[which - 1], marks[which]) if which < 0 else (marks[which], marks[which + 1])
+    # back up to the uploads in front of the init launch
+    while lo > 0 and rows[lo - 1][1] > rows[lo][1] - 3e6 and "finalize" not in rows[lo - 1][0] and "pexpand" not in rows[lo - 1][0]:
+        lo -= 1
+    t0, prev_end, busy = rows[lo][1], rows[lo][1], 0.0
+    print(f"{'offset_us':>10s} {'dur_us':>9s} {'gap_us':>8s}  kernel")
+    for name, st, en in rows[lo:hi]:
+        short = name.split("gqp::")[1].split("(")[0] if "gqp::" in name else name[:40]
+        print(f"{(st - t0) / 1e3:10.1f} {(en - st) / 1e3:9.1f} {(st - prev_end) / 1e3:8.1f}  {short}")
+        busy += (en - st) / 1e3
+        prev_end = max(prev_end, en)
+    print(f"window {(prev_end - t0) / 1e3:.1f} us, kernels busy {busy:.1f} us, launches {hi - lo}")
+
+
 def traffic(fetch_db, write_db, commit=None):
     import json
     out = {"_note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes over `bench.py --steps 1 --warmup 0 "
@@ -170,4 +193,4 @@ if __name__ == "__main__":
     elif sys.argv[1] in ("traffic", "sections"):
         {"traffic": traffic, "sections": sections}[sys.argv[1]](sys.argv[2], sys.argv[3], sys.argv[4] if len(sys.argv) > 4 else None)
     else:
-        {"kernel": kernel, "pmc": pmc}[sys.argv[1]](sys.argv[2])
+        {"kernel": kernel, "pmc": pmc, "timeline": timeline}[sys.argv[1]](*sys.argv[2:])
