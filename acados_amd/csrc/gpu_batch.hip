@@ -1379,7 +1379,9 @@ static void pcond_launch(ocp_qp_gpu_batch *b, bool expand)
     }
     if ((b->pc_rt || b->AW > 1 || c->AW > 1) && !(expand && b->pc_lane_expand && b->AW <= 1 && c->AW <= 1))
     {
-        if (expand) GQP_LAUNCH_COOP(gqp::kw_pexpand, dim3(b->Bp, b->pmap.N2 + 1), dim3(64), b->pc_shmem, b->stream, b->D, c->D, b->pmap);
+        /* (the expansion keeps four 64-entry vectors in LDS, not the condensing's block matrices: with the small allocation a CU holds
+         *  all the waves its SIMDs take) */
+        if (expand) GQP_LAUNCH_COOP(gqp::kw_pexpand, dim3(b->Bp, b->pmap.N2 + 1), dim3(64), 4 * 64 * sizeof(double), b->stream, b->D, c->D, b->pmap);
         else GQP_LAUNCH_COOP(gqp::kw_pcond, dim3(b->Bp), dim3(64), b->pc_shmem, b->stream, b->D, c->D, b->pmap);
     }
     else
@@ -2607,6 +2609,17 @@ catch (const gqp_hip_failure &) { if (len) *len = 0; return -1; }
 
 #define GQP_MASK_SPC 4 /* stages per thread of k_bulk_masks */
 
+/* the arrays of a bulk map -> blob (instance-major): as bulk_scatter_launch below */
+static void bulk_gather_launch(ocp_qp_gpu_batch *b, double *dst, int len, const int *d_arr, const int *d_elem, const gqp::GArrTable &T)
+{
+    if (b->aos && !getenv("ACADOS_AMD_SCATTER_PLAIN"))
+        hipLaunchKernelGGL(gqp::k_bulk_gather_aos, dim3((len + 255) / 256, b->B), dim3(256), 0, b->stream, dst, b->B, len, d_arr, d_elem, T);
+    else if (!getenv("ACADOS_AMD_SCATTER_PLAIN"))
+        GQP_LAUNCH_COOP(gqp::k_bulk_gather_tile, dim3((b->B + 63) / 64, (len + 63) / 64), dim3(64), 0, b->stream, dst, b->B, len, d_arr, d_elem, T);
+    else
+        hipLaunchKernelGGL(gqp::k_bulk_gather, dim3((b->B + 63) / 64, (len + 255) / 256), dim3(64), 0, b->stream, dst, b->B, len, d_arr, d_elem, T);
+}
+
 /* blob (instance-major) -> the arrays of a bulk map: lanes along the elements where the destinations are instance-major too, through
  * an LDS tile where they are wave-tiled (ACADOS_AMD_SCATTER_PLAIN=1: one lane per instance, the cross-check) */
 static void bulk_scatter_launch(ocp_qp_gpu_batch *b, const double *src, int len, ocp_qp_gpu_batch::BulkMap &M)
@@ -2823,7 +2836,7 @@ try
         dst = b->d_stage;
     }
     const dim3 grid((b->B + 63) / 64, (len + 255) / 256), block(64);
-    hipLaunchKernelGGL(gqp::k_bulk_gather, grid, block, 0, b->stream, dst, b->B, len, M.d_arr_g, M.d_elem_g, M.T);
+    bulk_gather_launch(b, dst, len, M.d_arr_g, M.d_elem_g, M.T);
     if (M.nm)
         hipLaunchKernelGGL(gqp::k_bulk_masks_get, dim3((b->B + 63) / 64), block, 0, b->stream, dst, b->B, len, M.d_moff,
                            M.d_mstage, M.d_mbit, M.nm, b->D.amask, b->AW);
@@ -2860,7 +2873,7 @@ try
         dst = b->d_stage;
     }
     const dim3 grid((b->B + 63) / 64, (len + 255) / 256), block(64);
-    hipLaunchKernelGGL(gqp::k_bulk_gather, grid, block, 0, b->stream, dst, b->B, len, M.d_arr, M.d_elem, M.T);
+    bulk_gather_launch(b, dst, len, M.d_arr, M.d_elem, M.T);
     if (!is_device) HIPCHK(hipMemcpyAsync(blob, dst, sizeof(double) * cnt, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     return 0;
@@ -2984,7 +2997,7 @@ try
         dst = b->d_stage;
     }
     const dim3 grid((b->B + 63) / 64, (len + 255) / 256), block(64);
-    hipLaunchKernelGGL(gqp::k_bulk_gather, grid, block, 0, b->stream, dst, b->B, len, M.d_arr, M.d_elem, T);
+    bulk_gather_launch(b, dst, len, M.d_arr, M.d_elem, T);
     if (!is_device) HIPCHK(hipMemcpyAsync(blob, dst, sizeof(double) * cnt, hipMemcpyDeviceToHost, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     return 0;
@@ -3181,7 +3194,7 @@ static int gather_impl(ocp_qp_gpu_batch *b, ocp_qp_gpu_comm *c, int root, const 
     int *info = (int *) (b->d_stage + cnt);
     double *tm = b->d_stage + cnt + b->B + 1;
     const dim3 grid((b->B + 63) / 64, (len + 255) / 256), block(64);
-    hipLaunchKernelGGL(gqp::k_bulk_gather, grid, block, 0, b->stream, blob, b->B, len, M.d_arr, M.d_elem, M.T);
+    bulk_gather_launch(b, blob, len, M.d_arr, M.d_elem, M.T);
     hipLaunchKernelGGL(gqp::k_pack_info, dim3((b->B + 63) / 64), block, 0, b->stream, b->D, info);
     HIPCHK(hipMemcpyAsync(tm, &b->time_tot, sizeof(double), hipMemcpyHostToDevice, b->stream));
     bool even = true;

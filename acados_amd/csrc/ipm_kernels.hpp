@@ -1294,6 +1294,34 @@ static __global__ void k_bulk_gather(double *blob, int nb, int len, const int *m
     }
 }
 
+/* ... from INSTANCE-MAJOR arrays: lanes along the elements of one instance (k_bulk_scatter_aos the other way round).  Grid (elements / 256,
+ * instances). */
+static __global__ void __launch_bounds__(256) k_bulk_gather_aos(double *blob, int nb, int len, const int *map_arr, const int *map_elem, GArrTable T)
+{
+    const int i = blockIdx.y, e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nb || e >= len) return;
+    const int a = map_arr[e];
+    blob[(size_t) i * len + e] = a >= 0 ? GATL(T.a[a], map_elem[e]) : 0.0;
+}
+
+/* ... from WAVE-TILED arrays, through an LDS tile (k_bulk_scatter_tile the other way round).  Grid (instances / 64, elements / 64). */
+static __global__ void __launch_bounds__(64) k_bulk_gather_tile(double *blob, int nb, int len, const int *map_arr, const int *map_elem, GArrTable T)
+{
+    __shared__ double tile[64 * 65];
+    const int lane = threadIdx.x, i0 = blockIdx.x * 64, e0 = blockIdx.y * 64;
+    const int ni = nb - i0 < 64 ? nb - i0 : 64, ne = len - e0 < 64 ? len - e0 : 64;
+    const int i = i0 + lane;
+    if (lane < ni)
+        for (int c = 0; c < ne; c++)
+        {
+            const int a = map_arr[e0 + c];
+            tile[c * 65 + lane] = a >= 0 ? GATL(T.a[a], map_elem[e0 + c]) : 0.0;
+        }
+    __syncthreads();
+    for (int r = 0; r < ni; r++)
+        if (lane < ne) blob[(size_t) (i0 + r) * len + e0 + lane] = tile[lane * 65 + r];
+}
+
 /* mask entries of the blob: (offset in blob, stage, bit) triples */
 static __global__ void k_bulk_masks(const double *__restrict__ blob, int nb, int len, const int *__restrict__ m_off, const int *__restrict__ m_stage,
                                     const int *__restrict__ m_bit, int nm, GArrU64 amask, int AW, int spc)
