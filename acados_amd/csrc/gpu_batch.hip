@@ -441,7 +441,10 @@ void finalize_structure(ocp_qp_gpu_batch *b)
     D.dvec = garr<double>(b, (size_t) ((o_ct + RP)));
     D.AW = b->AW;
     D.amask = garr<uint64_t>(b, (size_t) ((N + 1) * b->AW));
-    D.DCt = garr<double>(b, (size_t) (o_g * n));
+    /* (+ n spare elements: the sixteen-lanes GEN kernels prefetch the stage's rows of [D C] branch-free, a stage WITHOUT general rows
+     * reads element 0 of its (empty) block -- for such stages at the end of the horizon that is the element behind the last row:
+     * found by the structure fuzz of round 6, seed 9193, a fault only where the array ended on a page boundary) */
+    D.DCt = garr<double>(b, (size_t) (o_g * n + n));
     /* (at least one (Z, z) pair: the branch-free row functions of the sixteen-lanes GEN kernels read the pair of slack 0 through
      * clamped addresses also in a batch without slacks -- with one element per instance the z of the LAST instance lay behind the
      * allocation: found by the structure fuzz of round 5, a fault only where the array ended on a page boundary) */

@@ -277,6 +277,39 @@ def limit_cycle_case(clib):
         assert b.solve() > 0
 
 
+def certified_random_structures_case(clib, seeds, bar=1e-9):
+    """The device kernels against tests/dense_ref.py::solve_exact -- a dense active-set solve that carries its own optimality certificate
+    and has no part in the oracle or the kernels -- on RANDOM STRUCTURES (tests/random_qp.py: general rows, slacks shared by several rows,
+    one-sided and masked rows, free and fixed x0, per-stage dims): every structure class the reference's fixtures hold no answers for
+    (casadi_tests store inputs only).  Tight tolerances on the device (complementarity 1e-12): what remains is the distance of an
+    interior point to the vertex.  Returns {kernel family: worst relative primal distance}."""
+    from acados_amd import OcpQpGpuBatch
+    from dense_ref import solve_exact, split
+    from random_qp import random_structure_qp
+    worst = {}
+    for seed in seeds:
+        qp = random_structure_qp(seed)
+        w, off, info = solve_exact(qp)
+        assert info["cert"] <= 1e-10 and info["stationarity"] <= 1e-9, (seed, info)
+        sol = split(qp, w, off)
+        b = OcpQpGpuBatch.from_qps([qp] * 2, _clib=clib)
+        for f, v in (("tol_stat", 1e-9), ("tol_eq", 1e-11), ("tol_ineq", 1e-11), ("tol_comp", 1e-12)):
+            b.opts_set(f, v)
+        b.opts_set("iter_max", 100)
+        assert b.solve() == 0, (seed, b.kernel_name, b.info("status"))
+        e = 0.0
+        for i in range(2):
+            for k in range(qp.N + 1):
+                for f in ("x", "u", "sl", "su"):
+                    ref = sol[f][k]
+                    if ref.size:
+                        e = max(e, float(np.max(np.abs(b.get(f, k)[i][:ref.size] - ref) / np.maximum(1.0, np.abs(ref)))))
+        assert e <= bar, (seed, b.kernel_name, e)
+        fam = b.kernel_name.split("<")[0].split("(")[0]
+        worst[fam] = max(worst.get(fam, 0.0), e)
+    return worst
+
+
 def bulk_chunk_case(clib):
     """C-ABI parity of the input blob entries (include/acados_amd/ocp_qp_gpu_batch.h): the QP data of a batch read as ONE blob
     (_get_bulk_in), written into fresh batches whole (_set_bulk), in uneven chunks (_set_bulk_chunk x 3 + _set_bulk_staged) and by the

@@ -1175,6 +1175,16 @@ def test_device_against_certified_dense_solutions_gpu(gpu_lib, monkeypatch):
 
 
 @pytest.mark.gpu
+def test_device_against_certified_solutions_on_random_structures_gpu(gpu_lib):
+    """conftest.certified_random_structures_case on the device: sixty random structures (general rows, shared slacks, one-sided / masked
+    rows, free x0, per-stage dims), every kernel family they are dispatched to, against the certified dense solutions"""
+    from conftest import certified_random_structures_case
+    worst = certified_random_structures_case(None, range(60))
+    print("device vs certified dense solutions, 60 random structures:", {k: f"{v:.1e}" for k, v in worst.items()})
+    assert len(worst) >= 2
+
+
+@pytest.mark.gpu
 def test_full_condensing_dense_path_c2_gpu(gpu_lib):
     """FULL CONDENSING of the C2 shape (N = 50, nx = 8, nu = 3: 158 condensed columns + the padded terminal inputs, 300 inequality sides)
     on the dense path (option full_dense, dense_kernels.hpp; VERDICT r05 missing 1): 512 instances, every one converged, the independent

@@ -9,7 +9,7 @@ import re
 import numpy as np
 import pytest
 
-from conftest import (GOLDEN_PAIRS, bulk_chunk_case, limit_cycle_case, INPUT_ONLY, ROOT, compare_condensed_with_oracle, compare_with_oracle, fold_stage0, load_qp,
+from conftest import (GOLDEN_PAIRS, bulk_chunk_case, certified_random_structures_case, limit_cycle_case, INPUT_ONLY, ROOT, compare_condensed_with_oracle, compare_with_oracle, fold_stage0, load_qp,
                       load_sol)
 from oracle.oracle import OracleQp, default_opts
 
@@ -1579,3 +1579,9 @@ def test_full_condensing_dense_path_random_structures_hostsim(hostsim_lib):
                     assert np.allclose(gb.get(f, k)[1][:ref.size], ref, rtol=1e-6, atol=1e-7), (seed, k, f)
         done += 1
     assert done >= 10
+
+
+def test_kernels_against_certified_solutions_on_random_structures_hostsim(hostsim_lib):
+    """conftest.certified_random_structures_case on the host simulation: ten random structures (the GPU tier runs sixty)"""
+    worst = certified_random_structures_case(hostsim_lib, (0, 1, 5, 7, 11, 13, 22, 27, 33, 38))
+    print("kernels (host simulation) vs certified dense solutions:", {k: f"{v:.1e}" for k, v in worst.items()})

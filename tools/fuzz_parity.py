@@ -54,7 +54,8 @@ def run(tier, lo, hi, copies=None, batch=None):
     fails, fams, t0 = [], {}, time.time()
     sizes = [(6, 3), (12, 4), (24, 6), (40, 8)]
     for seed in range(lo, hi):
-        nxm, num = sizes[seed % 4] if tier != "hostsim" else sizes[seed % 3]
+        # (FUZZ_GPU_SIZES=1: the host simulation on the GPU tier's four size classes -- to replay a seed the device tripped over)
+        nxm, num = sizes[seed % 4] if tier != "hostsim" or os.environ.get("FUZZ_GPU_SIZES") else sizes[seed % 3]
         qp = random_structure_qp(seed, nx_max=nxm, nu_max=num, allow_general=(seed % 5 != 0), allow_slack=(seed % 7 != 0))
         o = OracleQp(qp)
         if o.solve(default_opts(tol_stat=1e-8, iter_max=80)) != 0:
