@@ -19,7 +19,7 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_c2 /tmp/prof_cfg /tmp/pmc_f /tmp/pmc_w
 quick="--steps 1 --warmup 0 --no-cpu-baseline --no-configs --check 0"
 rocprofv3 --kernel-trace --stats -d /tmp/prof_c2 -- python $root/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-configs > $out/${tag}_bench_under_rocprof.json 2> $out/${tag}_rocprof_c2.log
-db=$(find /tmp/prof_c2 -name "*.db" | head -1)
+db=$(ls -S $(find /tmp/prof_c2 -name "*.db") | head -1)
 python $root/profiles/summarize.py kernel $db > $out/${tag}_kernel_stats.txt
 rocprofv3 --pmc FETCH_SIZE -d /tmp/pmc_f -- python $root/bench.py $quick > /dev/null 2> $out/${tag}_pmc_f.log
 rocprofv3 --pmc WRITE_SIZE -d /tmp/pmc_w -- python $root/bench.py $quick > /dev/null 2> $out/${tag}_pmc_w.log
@@ -28,7 +28,8 @@ python $root/profiles/summarize.py traffic $f $w $commit > $out/${tag}_pmc_traff
 cp $out/${tag}_pmc_traffic.json $root/profiles/${tag}_pmc_traffic.json   # the bench below reads the file of THIS build
 if [ "$3" = "full" ]; then
     rocprofv3 --kernel-trace --stats -d /tmp/prof_cfg -- python $root/bench.py --steps 1 --warmup 1 --no-cpu-baseline --check 0 --check-configs 0 > $out/${tag}_bench_configs_under_rocprof.json 2> $out/${tag}_rocprof_cfg.log
-    db=$(find /tmp/prof_cfg -name "*.db" | head -1)
+    # (the boundary leg of the bench runs a child process with a trace database of its own: the bench's is the largest)
+    db=$(ls -S $(find /tmp/prof_cfg -name "*.db") | head -1)
     python $root/profiles/summarize.py kernel $db > $out/${tag}_config_kernel_stats.txt
     # HBM traffic of the configuration legs: the same two counter-only passes over the bench WITH its configuration legs;
     # bench.py brackets every configuration's timed solves with marker launches, summarize.py cuts the sequence there
