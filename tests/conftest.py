@@ -310,7 +310,7 @@ def certified_random_structures_case(clib, seeds, bar=1e-9):
     return worst
 
 
-def bulk_chunk_case(clib):
+def bulk_chunk_case(clib, seeds=(3, 22, 41)):
     """C-ABI parity of the input blob entries (include/acados_amd/ocp_qp_gpu_batch.h): the QP data of a batch read as ONE blob
     (_get_bulk_in), written into fresh batches whole (_set_bulk), in uneven chunks (_set_bulk_chunk x 3 + _set_bulk_staged) and by the
     ZERO-COPY GATHER (_host_register + _gather_tables + _gather_run: the blob's words spread over three source arrays per instance in a
@@ -319,7 +319,7 @@ def bulk_chunk_case(clib):
     import ctypes as C
     from acados_amd import OcpQpGpuBatch
     from random_qp import random_structure_qp
-    for seed in (3, 22, 41):       # general rows + shared slacks + one-sided rows / box only / per-stage dims
+    for seed in seeds:             # general rows + shared slacks + one-sided rows / box only / per-stage dims
         qp = random_structure_qp(seed)
         B = 37
         g = np.random.default_rng(seed)
