@@ -176,7 +176,7 @@ struct ocp_qp_gpu_batch
     double *d_chunks = nullptr; /* the input blob handed over in pieces (_set_bulk_chunk): its own buffer -- d_stage is reused by */
     size_t chunks_cap = 0;      /* every other transfer (a hot start's _set_bulk_out comes between the chunks and the scatter) */
     /* zero-copy gather (ocp_qp_gpu_batch_gather_tables / _gather_run): word tables of the full input blob [0] and of its vector part [1] */
-    struct GatherTab { int P = 0, n_words = 0; int *d_slot = nullptr, *d_off = nullptr, *d_pos = nullptr; unsigned char *d_neg = nullptr; } gtab[2];
+    struct GatherTab { int P = 0, n_words = 0, full = 0; int *d_slot = nullptr, *d_off = nullptr, *d_pos = nullptr; unsigned char *d_neg = nullptr; } gtab[2];
     const double **d_gptrs = nullptr;
     size_t gptrs_cap = 0;
     long chunks_got = 0;        /* instances handed over since the last _set_bulk_staged (it refuses to scatter a partial blob) */
@@ -2718,6 +2718,14 @@ try
         if (w_slot[w] < 0 || w_slot[w] >= P || w_pos[w] < 0 || w_pos[w] >= len || w_off[w] < 0) return -1;
     auto &G = b->gtab[which == 2 ? 1 : 0];
     G.P = P; G.n_words = n_words;
+    {
+        /* do the words write EVERY position of the blob?  If not, the gather clears its buffer first: the positions no word writes
+         * are zero for the scatter (the buffer is shared with the other blob and the chunk protocol) */
+        std::vector<char> seen((size_t) len, 0);
+        int covered = 0;
+        for (int w = 0; w < n_words; w++) if (!seen[w_pos[w]]) { seen[w_pos[w]] = 1; covered++; }
+        G.full = covered == len;
+    }
     G.d_slot = dalloc<int>(b, n_words); G.d_off = dalloc<int>(b, n_words); G.d_pos = dalloc<int>(b, n_words); G.d_neg = dalloc<unsigned char>(b, n_words);
     if (n_words)
     {
@@ -2742,7 +2750,7 @@ try
     {
         HIPCHK(hipStreamSynchronize(b->stream));
         b->chunks_cap = cnt;
-        b->d_chunks = dalloc<double>(b, b->chunks_cap); /* zeroed: positions no word writes stay zero */
+        b->d_chunks = dalloc<double>(b, b->chunks_cap);
     }
     const size_t np = (size_t) b->B * G.P;
     if (np > b->gptrs_cap) { b->gptrs_cap = np; b->d_gptrs = dalloc<const double *>(b, np); }
@@ -2751,6 +2759,7 @@ try
     const double tp = b->time_pack;
     HIPCHK(hipEventRecord(g0, b->stream));
     HIPCHK(hipMemcpyAsync(b->d_gptrs, ptrs, sizeof(void *) * np, hipMemcpyHostToDevice, b->stream));
+    if (!G.full) HIPCHK(hipMemsetAsync(b->d_chunks, 0, sizeof(double) * (size_t) b->B * (size_t) len, b->stream));
     hipLaunchKernelGGL(gqp::k_gather_host, dim3((G.n_words + 255) / 256, b->B), dim3(256), 0, b->stream, (const double *const *) b->d_gptrs, G.P, b->B,
                        G.n_words, (const int *) G.d_slot, (const int *) G.d_off, (const int *) G.d_pos, (const unsigned char *) G.d_neg, b->d_chunks, len);
     b->chunks_got = 0; /* (the chunk protocol shares the buffer: a round in flight is void) */

@@ -79,7 +79,8 @@ int ocp_qp_gpu_batch_get_bulk(ocp_qp_gpu_batch *b, double *blob, int is_device);
  * the device pointer equals the host pointer; the block stays registered until _host_unregister).  _gather_tables: once per class and
  * blob (`which` 0: the input blob, 2: its vector part) the word tables -- word w is element w_off[w] of source array w_slot[w] (0 <= slot < P,
  * e.g. the panel-major storage of one BLASFEO matrix) and goes to position w_pos[w] of the blob (layout of _bulk_len / _bulk_offset), negated
- * where w_neg[w]; sort the words by (slot, offset) so that consecutive device lanes read consecutive host addresses.  _gather_run: per call
+ * where w_neg[w]; a position no word writes is zero; sort the words by (slot, offset) so that consecutive device lanes read consecutive host
+ * addresses.  _gather_run: per call
  * the n_batch * P source addresses (ptrs[i * P + slot], each inside a registered block) -- gather into a device-side blob, then exactly what
  * _set_bulk / _set_bulk_vec do with it.  0 on success, -1 on a device failure or a table that does not fit the blob. */
 int ocp_qp_gpu_host_register(void *p, size_t bytes);

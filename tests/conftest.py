@@ -365,6 +365,20 @@ def bulk_chunk_case(clib, seeds=(3, 22, 41)):
                 assert L.ocp_qp_gpu_batch_gather_tables(b._h, 0, P, n, ip(slot), ip(off), ip(pos), ip(neg)) == 0
                 assert L.ocp_qp_gpu_host_register(ip(block), block.nbytes) == 0
                 try:
+                    # a table that leaves a field out (q of stage 1) on a buffer that has held a whole blob: those positions are ZERO
+                    ln = C.c_int(0)
+                    o1 = L.ocp_qp_gpu_batch_bulk_offset(b._h, 0, b"q", 1, C.byref(ln))
+                    if o1 >= 0 and ln.value > 0:
+                        assert L.ocp_qp_gpu_batch_set_bulk_chunk(b._h, ip(blob), 0, B) == 0 and L.ocp_qp_gpu_batch_set_bulk_staged(b._h) == 0
+                        keep = (pos < o1) | (pos >= o1 + ln.value)
+                        part = [np.ascontiguousarray(a_[keep]) for a_ in (slot, off, pos, neg)]
+                        assert L.ocp_qp_gpu_batch_gather_tables(b._h, 0, P, int(keep.sum()), *[ip(a_) for a_ in part]) == 0
+                        assert L.ocp_qp_gpu_batch_gather_run(b._h, 0, ip(ptrs)) == 0
+                        hole = np.zeros((B, n))
+                        assert L.ocp_qp_gpu_batch_get_bulk_in(b._h, ip(hole), 0) == 0
+                        expect = blob.copy(); expect[:, o1:o1 + ln.value] = 0.0
+                        assert np.array_equal(hole, expect), seed
+                        assert L.ocp_qp_gpu_batch_gather_tables(b._h, 0, P, n, ip(slot), ip(off), ip(pos), ip(neg)) == 0
                     assert L.ocp_qp_gpu_batch_gather_run(b._h, 0, ip(ptrs)) == 0
                 finally:
                     assert L.ocp_qp_gpu_host_unregister(ip(block)) == 0
