@@ -587,7 +587,7 @@ static void *xcalloc(size_t cnt, size_t sz)
  * capsule whose qp_in moved: registered again; more than three times: the group goes back to the blob path).  Any refusal -- registration
  * fails (pages already registered by somebody else, address space holes), a matrix with another cn than the class's -- is the blob path,
  * whose results are the same byte for byte (tests/test_mock_acados.py).  ACADOS_AMD_ZERO_COPY=0 switches it off, =1 uses it at every size
- * (by default a call whose whole QP data exceeds 160 MB keeps the chunked blob: zc_prepare).
+ * (by default a call whose whole QP data exceeds 160 MB keeps the chunked blob where more than 12 host threads fill it: zc_prepare).
  * The blocks are unregistered when the group goes (terminate / memory_reset of the capsule that led the call, a new set of capsules):
  * destroy capsule 0 of a batch first, as the generated `_free` loop does, or the others' memory is freed while still registered.
  */
@@ -764,13 +764,20 @@ static int zc_prepare(gpu_group *g, int n, ocp_qp_in **ins, int vec)
     if (g->zc_state < 0 || !mode) return 0;
     if (!vec && mode == 1)
     {
-        /* The whole QP data of a LARGE call stays on the blob path: both are bound by PCIe there, and the gather moves whole 64-byte
-         * lines of 168 small arrays per capsule (1.17x the bytes of the packed blob) without the overlap the chunked blob has -- measured
-         * on C3-shaped capsules (profiles/r06_zero_copy_latency.txt): 1,024 of them (87 MB) 6.4 against 7.0 ms, 4,096 (348 MB) 17.3
-         * against 15.9 ms.  The vector part (an RTI feedback step) is always gathered. */
+        /* The whole QP data of a LARGE call on a host with MANY threads stays on the blob path: both paths are bound by PCIe there, and the
+         * gather moves whole 64-byte lines of 168 small arrays per capsule (1.17x the bytes of the packed blob) without the overlap the
+         * chunked blob has.  Measured on C3-shaped capsules: 1,024 of them (87 MB) 6.0 ms either way; 4,096 (348 MB) on 16 host threads
+         * 15.7-17.4 ms gathered against 14.6-16.6 ms through the blob (profiles/r06_zero_copy_latency.txt) -- but the gather does not
+         * care how many host threads there are (16.0-18.7 ms from 4 to 32 threads) while the blob path needs them all (31.9 ms on 4
+         * threads, 20.1 on 8, 15.4 on 32: profiles/r06_orch_threads_final.txt).  The vector part (an RTI feedback step) is always gathered. */
         size_t bytes = 0;
         for (int q = 0; q < g->nbk; q++) bytes += sizeof(double) * (size_t) g->bk[q].n * (size_t) g->bk[q].L_in;
-        if (bytes > ((size_t) 160 << 20)) return 0;
+#if defined(_OPENMP)
+        const int host_threads = omp_get_max_threads();
+#else
+        const int host_threads = 1;
+#endif
+        if (bytes > ((size_t) 160 << 20) && host_threads > 12) return 0;
     }
     for (int q = 0; q < g->nbk; q++)
     {
